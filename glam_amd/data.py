@@ -1,0 +1,194 @@
+"""Graph containers, PyG-style collation and synthetic ESOL / protein-shaped graphs.
+
+The reference builds its inputs with RDKit + ``torch_geometric.data`` (neither is
+available), so the path's *input layout* is restated here:
+
+* ``Data`` / ``Batch.from_data_list`` follow PyG collation semantics as used by the
+  reference ``DataLoader`` (``src_1gp/trainer.py:37-41``): concatenate ``x`` /
+  ``edge_attr`` / ``y``, offset ``edge_index`` by the cumulative node count, and emit a
+  non-decreasing ``batch`` vector.
+* ``synth_molecule`` emits the tensor layout of ``get_mol_nodes_edges``
+  (``src_1gp/dataset.py:60-97``): ``x[n,15]`` = one-hot(9) atom type | one-hot(3)
+  hybridisation | atomic number, aromatic flag, #H ; ``edge_index`` int64 ``[2,E]`` with
+  both directions of every bond, sorted by ``src*n+dst`` (``dataset.py:84-86``);
+  ``edge_attr[E,4]`` one-hot bond type.  Sizes follow SURVEY.md §8d: atoms/mol ~
+  U{12..28}, chain + ring-closure bonds => E/N ~ 2.05, in-degree 1..4.
+* ``synth_protein`` emits the layout of the contact-map graphs of
+  ``src_2gi_dti_scr/dataset.py:67-103``: ``x[n,49]``, chain edges then symmetric random
+  contacts (unsorted, may hold duplicates), ``edge_attr[E,8]`` continuous.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+_ATOMIC_NUMBERS = np.array([1, 6, 7, 8, 9, 16, 17, 35, 53], dtype=np.float32)
+
+
+class Data:
+    """Minimal attribute bag with the fields the reference model reads
+    (``model.py:47-57``: ``x, edge_index, edge_attr, batch``) plus ``y``."""
+
+    def __init__(self, x=None, edge_index=None, edge_attr=None, y=None, batch=None, **kw):
+        self.x, self.edge_index, self.edge_attr, self.y, self.batch = x, edge_index, edge_attr, y, batch
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def num_nodes(self):
+        return 0 if self.x is None else self.x.size(0)
+
+    @property
+    def num_edges(self):
+        return 0 if self.edge_index is None else self.edge_index.size(1)
+
+    def _tensor_items(self):
+        return [(k, v) for k, v in self.__dict__.items() if torch.is_tensor(v)]
+
+    def to(self, device, non_blocking=False):
+        out = self.__class__.__new__(self.__class__)
+        out.__dict__.update(self.__dict__)
+        for k, v in self._tensor_items():
+            setattr(out, k, v.to(device, non_blocking=non_blocking))
+        # device-side staging caches (CSR) are per-object and per-device
+        out.__dict__.pop("_glam_cache", None)
+        return out
+
+    def __repr__(self):
+        body = ", ".join(f"{k}={list(v.shape)}" for k, v in self._tensor_items())
+        return f"{self.__class__.__name__}({body})"
+
+
+class Batch(Data):
+    """Disjoint union of graphs (PyG ``Batch.from_data_list`` semantics)."""
+
+    num_graphs = 0
+
+    @classmethod
+    def from_data_list(cls, data_list):
+        xs, eis, eas, ys, bs = [], [], [], [], []
+        offset = 0
+        for g, d in enumerate(data_list):
+            n = d.x.size(0)
+            xs.append(d.x)
+            eis.append(d.edge_index + offset)
+            if d.edge_attr is not None:
+                eas.append(d.edge_attr)
+            if d.y is not None:
+                ys.append(d.y)
+            bs.append(torch.full((n,), g, dtype=torch.long))
+            offset += n
+        out = cls(x=torch.cat(xs, 0), edge_index=torch.cat(eis, 1),
+                  edge_attr=torch.cat(eas, 0) if eas else None,
+                  y=torch.cat(ys, 0) if ys else None, batch=torch.cat(bs, 0))
+        out.num_graphs = len(data_list)
+        out.ptr = torch.tensor([0] + [d.x.size(0) for d in data_list]).cumsum(0)
+        return out
+
+
+class DataLoader:
+    """Sequential mini-batch iterator over a list of ``Data`` (the reference's train
+    loader does not shuffle: ``src_1gp/trainer.py:37-38``)."""
+
+    def __init__(self, dataset, batch_size=32, shuffle=False, seed=0):
+        self.dataset, self.batch_size, self.shuffle, self.seed = list(dataset), batch_size, shuffle, seed
+        self._epoch = 0
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = np.arange(len(self.dataset))
+        if self.shuffle:
+            np.random.default_rng(self.seed + self._epoch).shuffle(order)
+        self._epoch += 1
+        for s in range(0, len(order), self.batch_size):
+            yield Batch.from_data_list([self.dataset[i] for i in order[s:s + self.batch_size]])
+
+
+# --------------------------------------------------------------------------------------
+# synthetic graphs
+# --------------------------------------------------------------------------------------
+def _mol_arrays(rng, n_min=12, n_max=28):
+    n = int(rng.integers(n_min, n_max + 1))
+    bonds = {(i, i + 1) for i in range(n - 1)}
+    for _ in range(max(1, n // 10)):
+        i = int(rng.integers(0, max(1, n - 3)))
+        j = min(n - 1, i + int(rng.integers(3, 6)))
+        if j > i:
+            bonds.add((i, j))
+    bonds = sorted(bonds)
+    btype = rng.integers(0, 4, size=len(bonds))
+    src = np.array([b[0] for b in bonds] + [b[1] for b in bonds], dtype=np.int64)
+    dst = np.array([b[1] for b in bonds] + [b[0] for b in bonds], dtype=np.int64)
+    bt = np.concatenate([btype, btype])
+    perm = np.argsort(src * n + dst, kind="stable")
+    src, dst, bt = src[perm], dst[perm], bt[perm]
+    edge_attr = np.zeros((src.size, 4), dtype=np.float32)
+    edge_attr[np.arange(src.size), bt] = 1.0
+    at = rng.integers(0, 9, size=n)
+    hyb = rng.integers(0, 3, size=n)
+    x = np.zeros((n, 15), dtype=np.float32)
+    x[np.arange(n), at] = 1.0
+    x[np.arange(n), 9 + hyb] = 1.0
+    x[:, 12] = _ATOMIC_NUMBERS[at]
+    x[:, 13] = rng.integers(0, 2, size=n)
+    x[:, 14] = rng.integers(0, 4, size=n)
+    return x, np.stack([src, dst]), edge_attr
+
+
+def synth_molecule(rng, n_tasks=1, task="regression"):
+    x, ei, ea = _mol_arrays(rng)
+    if task == "regression":
+        y = rng.standard_normal((1, n_tasks)).astype(np.float32)
+    else:  # multi-task labels with -1 = missing (src_1gp/dataset.py:138)
+        y = rng.integers(-1, 2, size=(1, n_tasks)).astype(np.float32)
+    return Data(torch.from_numpy(x), torch.from_numpy(ei), torch.from_numpy(ea), torch.from_numpy(y))
+
+
+def synth_protein(rng, n_min=200, n_max=800, contacts_per_res=4.0):
+    n = int(rng.integers(n_min, n_max + 1))
+    chain = np.arange(n - 1, dtype=np.int64)
+    m = int(contacts_per_res * n / 2)
+    a = rng.integers(0, n, size=m)
+    b = rng.integers(0, n, size=m)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    src = np.concatenate([chain, chain + 1, a, b])
+    dst = np.concatenate([chain + 1, chain, b, a])
+    x = rng.standard_normal((n, 49)).astype(np.float32)
+    ea = rng.random((src.size, 8)).astype(np.float32)
+    y = rng.standard_normal((1, 1)).astype(np.float32)
+    return Data(torch.from_numpy(x), torch.from_numpy(np.stack([src, dst])), torch.from_numpy(ea),
+                torch.from_numpy(y))
+
+
+def synth_batch(num_graphs, seed=0, n_tasks=1, task="regression"):
+    """ESOL-shaped batch: ``num_graphs`` synthetic molecules collated the
+    PyG way.  B=1024, seed 0 gives N~20.7k nodes, E~42.5k directed edges."""
+    rng = np.random.default_rng(seed)
+    xs, eis, eas, bs, ys = [], [], [], [], []
+    off = 0
+    for g in range(num_graphs):
+        x, ei, ea = _mol_arrays(rng)
+        xs.append(x)
+        eis.append(ei + off)
+        eas.append(ea)
+        bs.append(np.full(x.shape[0], g, dtype=np.int64))
+        off += x.shape[0]
+    if task == "regression":
+        y = rng.standard_normal((num_graphs, n_tasks)).astype(np.float32)
+    else:
+        y = rng.integers(-1, 2, size=(num_graphs, n_tasks)).astype(np.float32)
+    out = Batch(torch.from_numpy(np.concatenate(xs)), torch.from_numpy(np.concatenate(eis, 1)),
+                torch.from_numpy(np.concatenate(eas)), torch.from_numpy(y),
+                torch.from_numpy(np.concatenate(bs)))
+    out.num_graphs = num_graphs
+    sizes = np.array([x.shape[0] for x in xs])
+    out.ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]))
+    return out
+
+
+def synth_protein_batch(num_graphs, seed=0, n_min=200, n_max=800):
+    rng = np.random.default_rng(seed)
+    return Batch.from_data_list([synth_protein(rng, n_min, n_max) for _ in range(num_graphs)])
