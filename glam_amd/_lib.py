@@ -1,0 +1,100 @@
+"""ctypes binding of ``libglam_hip.so`` (C ABI declared in ``include/glam_hip.h``).
+
+The library is the product: if it is missing, or a tensor is not resident on a HIP device,
+every op raises — there is no CPU or eager-PyTorch fallback behind these entry points.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglam_hip.so")
+
+GLAM_E_INVALID, GLAM_E_UNSUPPORTED, GLAM_E_HIP = -1, -2, -3
+
+_vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/glam_hip.h one to one
+SIGNATURES = {
+    "glam_abi_version": (_i32, []),
+    "glam_last_error": (ctypes.c_char_p, []),
+    "glam_csr_workspace_bytes": (_sz, [_i64, _i64]),
+    "glam_csr_build": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "glam_batch_ptr": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "glam_triplet_fwd": (_i32, [_vp] * 8 + [_i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "glam_triplet_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
+    "glam_triplet_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6 + [_sz, _vp]),
+    "glam_pool5_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "glam_pool5_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "glam_segment_pool_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "glam_segment_pool_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "glam_segment_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "glam_segment_attn_bwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp, _vp, _vp]),
+    "glam_edge_reduce_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "glam_edge_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class GlamHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libglam_hip.so (after torch, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GlamHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C glam_amd/csrc`). glam_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI and the header disagree
+        fn.restype, fn.argtypes = res, args
+    if lib.glam_abi_version() != 1:
+        raise GlamHipError("libglam_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = load().glam_last_error().decode("utf-8", "replace")
+    raise GlamHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    """Every op argument must already live in HBM; nothing is silently copied or computed on CPU."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GlamHipError("glam_amd ops run on an MI355X HIP device only (got a CPU tensor); "
+                               "there is no CPU fallback — move the batch and the model to 'cuda'.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GlamHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def f32c(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise GlamHipError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,66 @@
+// Shared host/device helpers for libglam_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/glam_hip.h"
+
+namespace glam {
+
+int fail(int code, const char* fmt, ...);
+
+#define GLAM_LAUNCH_CHECK(name)                                                    \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) return ::glam::fail(GLAM_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+#define GLAM_REQUIRE(cond, ...)                                        \
+    do {                                                               \
+        if (!(cond)) return ::glam::fail(GLAM_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+constexpr int kBlock = 256;        // 4 wavefronts of 64 lanes
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 resident blocks; grid-stride beyond
+
+static inline int grid_for(int64_t work_items, int items_per_block, int cap = kMaxBlocks) {
+    int64_t g = (work_items + items_per_block - 1) / items_per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers -------------------------------------------------------------------------
+// Sum over the G consecutive lanes that share a node (G in {4,8,16,64}); every lane gets the total.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over the 64/G groups of a wavefront, lane-slot wise (lanes l, l+G, l+2G, ... are added).
+template <int G>
+__device__ __forceinline__ float cross_group_sum(float v) {
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ void fma4(float4& acc, float s, float4 a) {
+    acc.x = fmaf(s, a.x, acc.x); acc.y = fmaf(s, a.y, acc.y); acc.z = fmaf(s, a.z, acc.z); acc.w = fmaf(s, a.w, acc.w);
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+__device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+}  // namespace glam

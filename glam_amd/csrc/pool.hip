@@ -1,0 +1,342 @@
+// Graph readouts over contiguous node segments (one wavefront per graph, lanes over channels).
+// Reference semantics replaced: PyG global_mean_pool / global_add_pool / global_max_pool /
+// global_sort_pool(k=3) behind GlobalPool5 (src_1gp/layer.py:197-203), GlobalAttention behind
+// GlobalLAPool (src_1gp/layer.py:206-220) and the attention step of Set2Set (src_1gp/model.py:41).
+// Segment sums run in node order inside one lane => deterministic, no atomics.
+#include "common.h"
+
+namespace glam {
+
+constexpr int kMaxK = 8;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+// ---- GlobalPool5: mean | add | top-k rows by last channel ---------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pool5_fwd(const float* x, const int* ptr, int B, int D, int K, float* out,
+                                                     int* topk_idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int OD = (2 + K) * D;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        // top-K on the last channel; every lane keeps the same list (broadcast loads)
+        float tv[kMaxK];
+        int ti[kMaxK];
+#pragma unroll
+        for (int r = 0; r < kMaxK; ++r) { tv[r] = -INFINITY; ti[r] = -1; }
+        for (int n = beg; n < end; ++n) {
+            float v = x[(size_t)n * D + (D - 1)];
+            int vi = n;
+            bool shifting = false;   // once inserted, the displaced entries just move down one slot
+#pragma unroll
+            for (int r = 0; r < kMaxK; ++r) {
+                if (r < K) {
+                    // strict '>' keeps the lower node index first on ties (stable descending sort);
+                    // an empty slot (ti < 0) always accepts
+                    const bool take = shifting || ti[r] < 0 || v > tv[r];
+                    if (take && vi >= 0) {
+                        const float ov = tv[r]; const int oi = ti[r];
+                        tv[r] = v; ti[r] = vi; v = ov; vi = oi;
+                        shifting = true;
+                    }
+                }
+            }
+        }
+        const float inv_cnt = 1.f / (float)max(end - beg, 1);
+        for (int c = lane; c < D; c += 64) {
+            float s = 0.f;
+            for (int n = beg; n < end; ++n) s += x[(size_t)n * D + c];
+            float* o = out + (size_t)g * OD;
+            o[c] = s * inv_cnt;
+            o[D + c] = s;
+#pragma unroll
+            for (int r = 0; r < kMaxK; ++r)
+                if (r < K) o[(2 + r) * D + c] = ti[r] >= 0 ? x[(size_t)ti[r] * D + c] : 0.f;
+        }
+        if (lane < K) {
+            int sel = -1;
+#pragma unroll
+            for (int r = 0; r < kMaxK; ++r) if (r == lane) sel = ti[r];
+            topk_idx[(size_t)g * K + lane] = sel;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_pool5_bwd(const float* d_out, const int* ptr, const int* topk_idx, int B,
+                                                     int D, int K, float* d_x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int OD = (2 + K) * D;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        const float inv_cnt = 1.f / (float)max(end - beg, 1);
+        int ti[kMaxK];
+#pragma unroll
+        for (int r = 0; r < kMaxK; ++r) ti[r] = r < K ? topk_idx[(size_t)g * K + r] : -1;
+        const float* go = d_out + (size_t)g * OD;
+        for (int c = lane; c < D; c += 64) {
+            const float base = go[c] * inv_cnt + go[D + c];
+            for (int n = beg; n < end; ++n) {
+                float v = base;
+#pragma unroll
+                for (int r = 0; r < kMaxK; ++r)
+                    if (r < K && ti[r] == n) v += go[(2 + r) * D + c];
+                d_x[(size_t)n * D + c] = v;
+            }
+        }
+    }
+}
+
+// ---- scatter(x, batch, reduce = sum | mean | max) over sorted batch -----------------------------
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_segment_pool_fwd(const float* x, const int* ptr, int B, int D, float* out,
+                                                            int* argmax) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        for (int c = lane; c < D; c += 64) {
+            if (MODE == 2) {
+                float best = 0.f;
+                int bi = -1;
+                for (int n = beg; n < end; ++n) {
+                    const float v = x[(size_t)n * D + c];
+                    if (bi < 0 || v > best) { best = v; bi = n; }
+                }
+                out[(size_t)g * D + c] = best;   // empty segment -> 0 (torch_scatter convention)
+                argmax[(size_t)g * D + c] = bi;
+            } else {
+                float s = 0.f;
+                for (int n = beg; n < end; ++n) s += x[(size_t)n * D + c];
+                if (MODE == 1) s *= 1.f / (float)max(end - beg, 1);
+                out[(size_t)g * D + c] = s;
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_segment_pool_bwd(const float* d_out, const int* ptr, const int* argmax,
+                                                            int B, int D, float* d_x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        const float scale = MODE == 1 ? 1.f / (float)max(end - beg, 1) : 1.f;
+        for (int c = lane; c < D; c += 64) {
+            const float go = d_out[(size_t)g * D + c] * scale;
+            const int am = MODE == 2 ? argmax[(size_t)g * D + c] : -1;
+            for (int n = beg; n < end; ++n) d_x[(size_t)n * D + c] = (MODE == 2) ? (n == am ? go : 0.f) : go;
+        }
+    }
+}
+
+// ---- segment-softmax attention readout -----------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_segment_attn_fwd(const float* gate, const float* v, const int* ptr, int B,
+                                                            int D, float* out, float* stats) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        float m = -INFINITY;
+        for (int n = beg + lane; n < end; n += 64) m = fmaxf(m, gate[n]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (end <= beg) m = 0.f;
+        float ssum = 0.f;   // identical on every lane (sequential node order)
+        for (int n = beg; n < end; ++n) ssum += expf(gate[n] - m);
+        const float inv = 1.f / (ssum + 1e-16f);
+        for (int c = lane; c < D; c += 64) {
+            float acc = 0.f;
+            for (int n = beg; n < end; ++n) acc = fmaf(expf(gate[n] - m), v[(size_t)n * D + c], acc);
+            out[(size_t)g * D + c] = acc * inv;
+        }
+        if (lane == 0) { stats[2 * g] = m; stats[2 * g + 1] = ssum; }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_segment_attn_bwd(const float* gate, const float* v, const float* out,
+                                                            const float* stats, const float* d_out, const int* ptr,
+                                                            int B, int D, float* d_gate, float* d_v) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        const float m = stats[2 * g], inv = 1.f / (stats[2 * g + 1] + 1e-16f);
+        float part = 0.f;
+        for (int c = lane; c < D; c += 64) part = fmaf(d_out[(size_t)g * D + c], out[(size_t)g * D + c], part);
+        const float dot_out = group_sum<64>(part);
+        for (int n = beg; n < end; ++n) {
+            const float a = expf(gate[n] - m) * inv;
+            float p = 0.f;
+            for (int c = lane; c < D; c += 64) {
+                const float go = d_out[(size_t)g * D + c];
+                p = fmaf(go, v[(size_t)n * D + c], p);
+                d_v[(size_t)n * D + c] = a * go;
+            }
+            const float dv = group_sum<64>(p);
+            if (lane == 0) d_gate[n] = a * (dv - dot_out);
+        }
+    }
+}
+
+// ---- generic edge -> node reduction over CSR segments (one thread per output element) ------------
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_edge_reduce_fwd(const float* msg, const int* rowptr, const int* eid, int N,
+                                                           int D, float* out, int* argmax) {
+    const size_t total = (size_t)N * D;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int n = (int)(i / D), c = (int)(i % D);
+        const int beg = rowptr[n], end = rowptr[n + 1];
+        if (MODE == 2) {
+            float best = 0.f;
+            int bi = -1;
+            for (int e = beg; e < end; ++e) {
+                const int id = eid[e];
+                const float v = msg[(size_t)id * D + c];
+                if (bi < 0 || v > best) { best = v; bi = id; }
+            }
+            out[i] = best;
+            argmax[i] = bi;
+        } else {
+            float s = 0.f;
+            for (int e = beg; e < end; ++e) s += msg[(size_t)eid[e] * D + c];
+            if (MODE == 1) s *= 1.f / (float)max(end - beg, 1);
+            out[i] = s;
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_edge_reduce_bwd(const float* d_out, const int* rowptr, const int* eid,
+                                                           const int* argmax, int N, int D, float* d_msg) {
+    const size_t total = (size_t)N * D;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int n = (int)(i / D), c = (int)(i % D);
+        const int beg = rowptr[n], end = rowptr[n + 1];
+        const float go = d_out[i] * (MODE == 1 ? 1.f / (float)max(end - beg, 1) : 1.f);
+        const int am = MODE == 2 ? argmax[i] : -1;
+        for (int e = beg; e < end; ++e) {
+            const int id = eid[e];
+            d_msg[(size_t)id * D + c] = (MODE == 2) ? (id == am ? go : 0.f) : go;
+        }
+    }
+}
+
+}  // namespace glam
+
+using namespace glam;
+
+static int pool_dims(const char* fn, int64_t N, int64_t B, int D) {
+    if (N < 0 || B < 0 || N >= INT32_MAX || B >= INT32_MAX) return fail(GLAM_E_INVALID, "%s: N/B out of range", fn);
+    if (D <= 0) return fail(GLAM_E_INVALID, "%s: D=%d", fn, D);
+    return GLAM_OK;
+}
+
+extern "C" int glam_pool5_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int k, float* out,
+                              int32_t* topk_idx, void* stream) {
+    if (int rc = pool_dims("glam_pool5_fwd", N, B, D)) return rc;
+    if (k < 1 || k > kMaxK) return fail(GLAM_E_UNSUPPORTED, "glam_pool5_fwd: k=%d not in 1..%d", k, kMaxK);
+    if (B == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && out && topk_idx && (N == 0 || x), "glam_pool5_fwd: null pointer");
+    hipLaunchKernelGGL(k_pool5_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
+    GLAM_LAUNCH_CHECK("glam_pool5_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_pool5_bwd(const float* d_out, const int32_t* ptr, const int32_t* topk_idx, int64_t N, int64_t B,
+                              int D, int k, float* d_x, void* stream) {
+    if (int rc = pool_dims("glam_pool5_bwd", N, B, D)) return rc;
+    if (k < 1 || k > kMaxK) return fail(GLAM_E_UNSUPPORTED, "glam_pool5_bwd: k=%d not in 1..%d", k, kMaxK);
+    if (B == 0 || N == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && d_out && topk_idx && d_x, "glam_pool5_bwd: null pointer");
+    hipLaunchKernelGGL(k_pool5_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
+    GLAM_LAUNCH_CHECK("glam_pool5_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                                     float* out, int32_t* argmax, void* stream) {
+    if (int rc = pool_dims("glam_segment_pool_fwd", N, B, D)) return rc;
+    if (B == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && out && (N == 0 || x) && (mode != 2 || argmax), "glam_segment_pool_fwd: null pointer");
+    const dim3 grid(grid_for(B, kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(k_segment_pool_fwd<0>, grid, block, 0, s, x, ptr, (int)B, D, out, argmax);
+    else if (mode == 1) hipLaunchKernelGGL(k_segment_pool_fwd<1>, grid, block, 0, s, x, ptr, (int)B, D, out, argmax);
+    else if (mode == 2) hipLaunchKernelGGL(k_segment_pool_fwd<2>, grid, block, 0, s, x, ptr, (int)B, D, out, argmax);
+    else return fail(GLAM_E_INVALID, "glam_segment_pool_fwd: mode=%d", mode);
+    GLAM_LAUNCH_CHECK("glam_segment_pool_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_segment_pool_bwd(const float* d_out, const int32_t* ptr, const int32_t* argmax, int64_t N,
+                                     int64_t B, int D, int mode, float* d_x, void* stream) {
+    if (int rc = pool_dims("glam_segment_pool_bwd", N, B, D)) return rc;
+    if (B == 0 || N == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && d_out && d_x && (mode != 2 || argmax), "glam_segment_pool_bwd: null pointer");
+    const dim3 grid(grid_for(B, kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(k_segment_pool_bwd<0>, grid, block, 0, s, d_out, ptr, argmax, (int)B, D, d_x);
+    else if (mode == 1) hipLaunchKernelGGL(k_segment_pool_bwd<1>, grid, block, 0, s, d_out, ptr, argmax, (int)B, D, d_x);
+    else if (mode == 2) hipLaunchKernelGGL(k_segment_pool_bwd<2>, grid, block, 0, s, d_out, ptr, argmax, (int)B, D, d_x);
+    else return fail(GLAM_E_INVALID, "glam_segment_pool_bwd: mode=%d", mode);
+    GLAM_LAUNCH_CHECK("glam_segment_pool_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_segment_attn_fwd(const float* gate, const float* v, const int32_t* ptr, int64_t N, int64_t B, int D,
+                                     float* out, float* stats, void* stream) {
+    if (int rc = pool_dims("glam_segment_attn_fwd", N, B, D)) return rc;
+    if (B == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && out && stats && (N == 0 || (gate && v)), "glam_segment_attn_fwd: null pointer");
+    hipLaunchKernelGGL(k_segment_attn_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, gate, v, ptr, (int)B, D, out, stats);
+    GLAM_LAUNCH_CHECK("glam_segment_attn_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_segment_attn_bwd(const float* gate, const float* v, const float* out, const float* stats,
+                                     const float* d_out, const int32_t* ptr, int64_t N, int64_t B, int D,
+                                     float* d_gate, float* d_v, void* stream) {
+    if (int rc = pool_dims("glam_segment_attn_bwd", N, B, D)) return rc;
+    if (B == 0 || N == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && gate && v && out && stats && d_out && d_gate && d_v, "glam_segment_attn_bwd: null pointer");
+    hipLaunchKernelGGL(k_segment_attn_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, gate, v, out, stats, d_out, ptr, (int)B, D, d_gate, d_v);
+    GLAM_LAUNCH_CHECK("glam_segment_attn_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_edge_reduce_fwd(const float* msg, const int32_t* rowptr, const int32_t* eid, int64_t N, int64_t E,
+                                    int D, int mode, float* out, int32_t* argmax, void* stream) {
+    if (int rc = pool_dims("glam_edge_reduce_fwd", N, E, D)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(rowptr && out && (E == 0 || (msg && eid)) && (mode != 2 || argmax), "glam_edge_reduce_fwd: null pointer");
+    const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(k_edge_reduce_fwd<0>, grid, block, 0, s, msg, rowptr, eid, (int)N, D, out, argmax);
+    else if (mode == 1) hipLaunchKernelGGL(k_edge_reduce_fwd<1>, grid, block, 0, s, msg, rowptr, eid, (int)N, D, out, argmax);
+    else if (mode == 2) hipLaunchKernelGGL(k_edge_reduce_fwd<2>, grid, block, 0, s, msg, rowptr, eid, (int)N, D, out, argmax);
+    else return fail(GLAM_E_INVALID, "glam_edge_reduce_fwd: mode=%d", mode);
+    GLAM_LAUNCH_CHECK("glam_edge_reduce_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_t* eid, const int32_t* argmax,
+                                    int64_t N, int64_t E, int D, int mode, float* d_msg, void* stream) {
+    if (int rc = pool_dims("glam_edge_reduce_bwd", N, E, D)) return rc;
+    if (N == 0 || E == 0) return GLAM_OK;
+    GLAM_REQUIRE(rowptr && eid && d_out && d_msg && (mode != 2 || argmax), "glam_edge_reduce_bwd: null pointer");
+    const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(k_edge_reduce_bwd<0>, grid, block, 0, s, d_out, rowptr, eid, argmax, (int)N, D, d_msg);
+    else if (mode == 1) hipLaunchKernelGGL(k_edge_reduce_bwd<1>, grid, block, 0, s, d_out, rowptr, eid, argmax, (int)N, D, d_msg);
+    else if (mode == 2) hipLaunchKernelGGL(k_edge_reduce_bwd<2>, grid, block, 0, s, d_out, rowptr, eid, argmax, (int)N, D, d_msg);
+    else return fail(GLAM_E_INVALID, "glam_edge_reduce_bwd: mode=%d", mode);
+    GLAM_LAUNCH_CHECK("glam_edge_reduce_bwd");
+    return GLAM_OK;
+}

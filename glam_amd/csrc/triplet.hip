@@ -1,0 +1,556 @@
+// Fused neighbour-gather / attention-logit / segment-softmax / weighted scatter-add kernels for
+// TripletMessage and TripletMessageLight (reference: src_1gp/layer.py:40-55 and :88-97, executed
+// there as PyG propagate -> message -> torch_scatter aggregate).
+//
+// Mapping (gfx950, wave64): a target node is owned by a GROUP of G consecutive lanes (G in
+// {4,8,16}); lane l of the group owns the float4 channel chunks q = l + G*it (it < ITER) of EVERY
+// head, so one 16-byte load per (edge, head, it) streams the neighbour row xw[src,h,:] and a
+// wavefront processes 64/G nodes at once.  Degree-1..4 molecular segments and degree-100 protein
+// segments take the same code path (the group walks its CSR segment serially; groups of one wave
+// diverge only in trip count).  The attention logits are separable:
+//   logit = leaky(a_i[dst] + <edge_attr[e], M> + a_j[src]),
+// so no [E,H,3C] triplet tensor is ever formed; e_ij = edge_attr[e] @ W_edge is recomputed from the
+// LDS-resident W_edge (De*H*Cp floats) instead of materialising ew[E,H*C].
+// No atomics anywhere: forward reduces a CSR-by-target segment in registers, backward B1 walks the
+// same segments, backward B2 walks the CSR transpose (by source).  Results are bit-reproducible.
+#include "common.h"
+
+namespace glam {
+
+struct FwdArgs {
+    const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
+    const int* rowptr; const int* nbr; const int* eid;
+    int N; int Cp; float slope;
+    float* aggr; float* stats;
+};
+
+template <int DE>
+__device__ __forceinline__ void load_edge_attr(const float* edge_attr, int id, float (&ea)[DE]) {
+    const float* p = edge_attr + (size_t)id * DE;
+#pragma unroll
+    for (int i = 0; i < DE / 4; ++i) {
+        float4 v = ld4(p + 4 * i);
+        ea[4 * i + 0] = v.x; ea[4 * i + 1] = v.y; ea[4 * i + 2] = v.z; ea[4 * i + 3] = v.w;
+    }
+}
+
+// pre-activation attention logit of one edge for every head
+template <int H, int DE>
+__device__ __forceinline__ void edge_pre(const float (&ai)[H], const float4 aj, const float (&ea)[DE],
+                                         const float (&Mr)[DE][H], float (&pre)[H]) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float ee = 0.f;
+#pragma unroll
+        for (int k = 0; k < DE; ++k) ee = fmaf(ea[k], Mr[k][h], ee);
+        pre[h] = ai[h] + ee + f4get(aj, h);
+    }
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// e_ij chunk = sum_k edge_attr[e,k] * W_edge[k,h,chunk]  (W_edge in LDS)
+template <int H, int DE>
+__device__ __forceinline__ float4 edge_chunk(const float* s_w, const float (&ea)[DE], int h, int Cp, int q) {
+    float4 e4 = f4zero();
+#pragma unroll
+    for (int k = 0; k < DE; ++k) fma4(e4, ea[k], ld4(s_w + (k * H + h) * Cp + q * 4));
+    return e4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock) k_triplet_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    float Mr[DE][H];
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) Mr[k][h] = a.M[k * 4 + h];
+
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    int q[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        q[it] = lg + G * it;
+        ok[it] = q[it] < Q;
+        if (!ok[it]) q[it] = 0;
+    }
+
+    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
+        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+        const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
+        float ai[H], m[H], ssum[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { ai[h] = f4get(aiv, h); m[h] = -INFINITY; ssum[h] = 0.f; }
+
+        // pass 1: segment max of the logits (cheap, cached loads only)
+        for (int e = beg; e < end; ++e) {
+            const int s = a.nbr[e], id = a.eid[e];
+            float ea[DE], pre[H];
+            load_edge_attr<DE>(a.edge_attr, id, ea);
+            edge_pre<H, DE>(ai, ld4(a.a_ij + (size_t)s * 8 + 4), ea, Mr, pre);
+#pragma unroll
+            for (int h = 0; h < H; ++h) m[h] = fmaxf(m[h], leaky(pre[h], a.slope));
+        }
+        // pass 2: exp-sum and weighted gather of the neighbour rows
+        float4 acc[H][ITER];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) acc[h][it] = f4zero();
+        for (int e = beg; e < end; ++e) {
+            const int s = a.nbr[e], id = a.eid[e];
+            float ea[DE], pre[H], p[H];
+            load_edge_attr<DE>(a.edge_attr, id, ea);
+            edge_pre<H, DE>(ai, ld4(a.a_ij + (size_t)s * 8 + 4), ea, Mr, pre);
+            const float* xrow = a.xw + (size_t)s * HC;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                p[h] = expf(leaky(pre[h], a.slope) - m[h]);
+                ssum[h] += p[h];
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 xj = ld4(xrow + h * Cp + q[it] * 4);
+                    if constexpr (EMUL) xj = edge_chunk<H, DE>(s_w, ea, h, Cp, q[it]) * xj;
+                    fma4(acc[h][it], p[h], xj);
+                }
+            }
+        }
+        float* orow = a.aggr + (size_t)n * HC;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float inv = 1.f / (ssum[h] + 1e-16f);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+                if (ok[it]) st4(orow + h * Cp + q[it] * 4, inv * acc[h][it]);
+        }
+        if (lg == 0) {
+            float4 mv = f4zero(), sv = f4zero();
+            float* mp = &mv.x; float* sp = &sv.x;
+#pragma unroll
+            for (int h = 0; h < H; ++h) { mp[h] = (end > beg) ? m[h] : 0.f; sp[h] = ssum[h]; }
+            st4(a.stats + (size_t)n * 8, mv);
+            st4(a.stats + (size_t)n * 8 + 4, sv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward B1: walk CSR-by-target.  Per edge: recompute alpha, d_alpha = <d_aggr[dst], e_ij*xw[src]>,
+// softmax + leaky backward -> dpre; accumulate d_a_i per node and d_W_edge / d_M per lane.
+// ------------------------------------------------------------------------------------------------
+struct BwdDstArgs {
+    const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
+    const float* aggr; const float* stats; const float* d_aggr;
+    const int* rowptr; const int* nbr; const int* eid;
+    int N; int Cp; float slope;
+    float* alpha_e; float* dpre_e; float* d_a_ij; float* d_edge_attr; float* partial;
+};
+
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock) k_triplet_bwd_dst(BwdDstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    const int WSZ = EMUL ? DE * HC : 0;          // floats of staged W_edge
+    const int P = WSZ + DE * 4;                  // floats of one block partial: d_W_edge | d_M
+    float* s_w = s_mem;
+    float* s_red = s_mem + WSZ;                  // [4 waves][P]
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    float Mr[DE][H];
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) Mr[k][h] = a.M[k * 4 + h];
+
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    int q[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        q[it] = lg + G * it;
+        ok[it] = q[it] < Q;
+        if (!ok[it]) q[it] = 0;
+    }
+
+    float4 dw[EMUL ? DE : 1][H][ITER];
+    float dM[DE][H];
+#pragma unroll
+    for (int k = 0; k < (EMUL ? DE : 1); ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) dw[k][h][it] = f4zero();
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) dM[k][h] = 0.f;
+
+    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
+        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+        const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
+        const float4 mv = ld4(a.stats + (size_t)n * 8), sv = ld4(a.stats + (size_t)n * 8 + 4);
+        float ai[H], m[H], inv[H], dot[H], dai[H];
+        float4 dag[H][ITER];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            ai[h] = f4get(aiv, h); m[h] = f4get(mv, h); inv[h] = 1.f / (f4get(sv, h) + 1e-16f); dai[h] = 0.f;
+            float part = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const size_t off = (size_t)n * HC + h * Cp + q[it] * 4;
+                dag[h][it] = ok[it] ? ld4(a.d_aggr + off) : f4zero();
+                part += dot4(dag[h][it], ld4(a.aggr + off));
+            }
+            // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
+            dot[h] = group_sum<G>(part);
+        }
+        for (int e = beg; e < end; ++e) {
+            const int s = a.nbr[e], id = a.eid[e];
+            float ea[DE], pre[H], alpha[H], dp[H];
+            load_edge_attr<DE>(a.edge_attr, id, ea);
+            edge_pre<H, DE>(ai, ld4(a.a_ij + (size_t)s * 8 + 4), ea, Mr, pre);
+            const float* xrow = a.xw + (size_t)s * HC;
+            float dea[DE];
+#pragma unroll
+            for (int k = 0; k < DE; ++k) dea[k] = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                alpha[h] = expf(leaky(pre[h], a.slope) - m[h]) * inv[h];
+                float part = 0.f;
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const float4 t = dag[h][it] * ld4(xrow + h * Cp + q[it] * 4);   // d_aggr * x_j
+                    if constexpr (EMUL) {
+                        float4 e4 = f4zero();
+#pragma unroll
+                        for (int k = 0; k < DE; ++k) {
+                            const float4 w = ld4(s_w + (k * H + h) * Cp + q[it] * 4);
+                            fma4(e4, ea[k], w);
+                            fma4(dw[k][h][it], ea[k] * alpha[h], t);
+                            if (a.d_edge_attr) dea[k] = fmaf(alpha[h], dot4(t, w), dea[k]);
+                        }
+                        part += dot4(t, e4);
+                    } else {
+                        part += t.x + t.y + t.z + t.w;
+                    }
+                }
+                const float dalpha = group_sum<G>(part);
+                const float dl = alpha[h] * (dalpha - dot[h]);
+                dp[h] = pre[h] > 0.f ? dl : dl * a.slope;
+                dai[h] += dp[h];
+#pragma unroll
+                for (int k = 0; k < DE; ++k) dM[k][h] = fmaf(ea[k], dp[h], dM[k][h]);
+            }
+            if (a.d_edge_attr) {
+#pragma unroll
+                for (int k = 0; k < DE; ++k) {
+                    float v = EMUL ? group_sum<G>(dea[k]) : 0.f;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) v = fmaf(dp[h], Mr[k][h], v);
+                    dea[k] = v;
+                }
+                if (lg == 0) {
+#pragma unroll
+                    for (int i = 0; i < DE / 4; ++i)
+                        st4(a.d_edge_attr + (size_t)id * DE + 4 * i,
+                            make_float4(dea[4 * i], dea[4 * i + 1], dea[4 * i + 2], dea[4 * i + 3]));
+                }
+            }
+            if (lg == 0) {
+                float4 av = f4zero(), dv = f4zero();
+                float* ap = &av.x; float* dpp = &dv.x;
+#pragma unroll
+                for (int h = 0; h < H; ++h) { ap[h] = alpha[h]; dpp[h] = dp[h]; }
+                st4(a.alpha_e + (size_t)id * 4, av);
+                st4(a.dpre_e + (size_t)id * 4, dv);
+            }
+        }
+        if (lg == 0) {
+            float4 dv = f4zero();
+            float* dpp = &dv.x;
+#pragma unroll
+            for (int h = 0; h < H; ++h) dpp[h] = dai[h];
+            st4(a.d_a_ij + (size_t)n * 8, dv);
+        }
+    }
+
+    // ---- block partial of d_W_edge | d_M: wave shuffle across groups, then 4 waves via LDS ----
+    const int wave = tid >> 6, lane = tid & 63;
+    float* red = s_red + wave * P;
+    if constexpr (EMUL) {
+#pragma unroll
+        for (int k = 0; k < DE; ++k)
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 v = dw[k][h][it];
+                    v.x = cross_group_sum<G>(v.x); v.y = cross_group_sum<G>(v.y);
+                    v.z = cross_group_sum<G>(v.z); v.w = cross_group_sum<G>(v.w);
+                    if (lane < G && ok[it]) st4(red + (k * H + h) * Cp + q[it] * 4, v);
+                }
+    }
+#pragma unroll
+    for (int k = 0; k < DE; ++k) {
+        float4 v = f4zero();
+        float* vp = &v.x;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            // every lane of a group holds the same dM; pick lane 0 of each group before the sum
+            vp[h] = cross_group_sum<G>(dM[k][h]);
+        }
+        if (lane == 0) st4(red + WSZ + k * 4, v);
+    }
+    __syncthreads();
+    float* out = a.partial + (size_t)blockIdx.x * P;
+    for (int i = tid; i < P; i += kBlock)
+        out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward B2: walk the CSR transpose (by source).  d_xw[j] = sum_{e: src=j} alpha_e * e_ij * d_aggr[dst],
+// d_a_j[j] = sum dpre_e.
+// ------------------------------------------------------------------------------------------------
+struct BwdSrcArgs {
+    const float* edge_attr; const float* w_edge; const float* d_aggr; const float* alpha_e; const float* dpre_e;
+    const int* colptr; const int* nbr; const int* eid;
+    int N; int Cp;
+    float* d_xw; float* d_a_ij;
+};
+
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock) k_triplet_bwd_src(BwdSrcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    int q[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        q[it] = lg + G * it;
+        ok[it] = q[it] < Q;
+        if (!ok[it]) q[it] = 0;
+    }
+    for (int j = blockIdx.x * GPB + tid / G; j < a.N; j += gridDim.x * GPB) {
+        const int beg = a.colptr[j], end = a.colptr[j + 1];
+        float4 acc[H][ITER];
+        float4 daj = f4zero();
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) acc[h][it] = f4zero();
+        for (int e = beg; e < end; ++e) {
+            const int n = a.nbr[e], id = a.eid[e];
+            const float4 al = ld4(a.alpha_e + (size_t)id * 4);
+            const float4 dp = ld4(a.dpre_e + (size_t)id * 4);
+            daj.x += dp.x; daj.y += dp.y; daj.z += dp.z; daj.w += dp.w;
+            float ea[DE];
+            if constexpr (EMUL) load_edge_attr<DE>(a.edge_attr, id, ea);
+            const float* grow = a.d_aggr + (size_t)n * HC;
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 dg = ld4(grow + h * Cp + q[it] * 4);
+                    if constexpr (EMUL) dg = edge_chunk<H, DE>(s_w, ea, h, Cp, q[it]) * dg;
+                    fma4(acc[h][it], f4get(al, h), dg);
+                }
+        }
+        float* orow = a.d_xw + (size_t)j * HC;
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+                if (ok[it]) st4(orow + h * Cp + q[it] * 4, acc[h][it]);
+        if (lg == 0) st4(a.d_a_ij + (size_t)j * 8 + 4, daj);
+    }
+}
+
+// out[i] = sum_b partial[b][i], fixed order (deterministic)
+__global__ void __launch_bounds__(kBlock) k_reduce_partials(const float* partial, int nblk, int P, int WSZ,
+                                                           float* d_w_edge, float* d_M) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        s0 += partial[(size_t)(b + 0) * P + i]; s1 += partial[(size_t)(b + 1) * P + i];
+        s2 += partial[(size_t)(b + 2) * P + i]; s3 += partial[(size_t)(b + 3) * P + i];
+    }
+    for (; b < nblk; ++b) s0 += partial[(size_t)b * P + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < WSZ) { if (d_w_edge) d_w_edge[i] = s; }
+    else d_M[i - WSZ] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct FwdOp {
+    static void run(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct BwdDstOp {
+    static void run(const BwdDstArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct BwdSrcOp {
+    static void run(const BwdSrcArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_bwd_src<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+
+struct Shape { int G, ITER; };
+// smallest G*ITER that covers Q = Cp/4 chunks per head
+static bool pick_shape(int Q, Shape* s) {
+    if (Q <= 4) *s = {4, 1};
+    else if (Q <= 8) *s = {8, 1};
+    else if (Q <= 12) *s = {4, 3};
+    else if (Q <= 16) *s = {16, 1};
+    else if (Q <= 24) *s = {8, 3};
+    else if (Q <= 32) *s = {16, 2};
+    else if (Q <= 64) *s = {16, 4};
+    else return false;
+    return true;
+}
+
+template <template <int, int, int, int, bool> class Op, int H, int DE, bool EMUL, typename Args>
+static bool dispatch_shape(Shape sh, const Args& a, int nodes, size_t lds, hipStream_t s, int cap, int* grid_out) {
+#define GLAM_CASE(G_, IT_)                                                   \
+    if (sh.G == G_ && sh.ITER == IT_) {                                      \
+        const int grid = grid_for(nodes, kBlock / G_, cap);                  \
+        if (grid_out) *grid_out = grid;                                      \
+        Op<H, G_, IT_, DE, EMUL>::run(a, grid, lds, s);                      \
+        return true;                                                         \
+    }
+    GLAM_CASE(4, 1) GLAM_CASE(8, 1) GLAM_CASE(4, 3) GLAM_CASE(16, 1) GLAM_CASE(8, 3) GLAM_CASE(16, 2) GLAM_CASE(16, 4)
+#undef GLAM_CASE
+    return false;
+}
+
+template <template <int, int, int, int, bool> class Op, typename Args>
+static bool dispatch(int H, int De, int emul, Shape sh, const Args& a, int nodes, size_t lds, hipStream_t s,
+                     int cap, int* grid_out) {
+    if (emul) {
+        if (H == 3 && De == 4) return dispatch_shape<Op, 3, 4, true>(sh, a, nodes, lds, s, cap, grid_out);
+        if (H == 3 && De == 8) return dispatch_shape<Op, 3, 8, true>(sh, a, nodes, lds, s, cap, grid_out);
+        if (H == 1 && De == 4) return dispatch_shape<Op, 1, 4, true>(sh, a, nodes, lds, s, cap, grid_out);
+        if (H == 1 && De == 8) return dispatch_shape<Op, 1, 8, true>(sh, a, nodes, lds, s, cap, grid_out);
+    } else {
+        if (H == 1 && De == 4) return dispatch_shape<Op, 1, 4, false>(sh, a, nodes, lds, s, cap, grid_out);
+        if (H == 1 && De == 8) return dispatch_shape<Op, 1, 8, false>(sh, a, nodes, lds, s, cap, grid_out);
+    }
+    return false;
+}
+
+static int check_dims(const char* fn, int64_t N, int64_t E, int H, int Cp, int De, Shape* sh) {
+    if (N < 0 || E < 0 || N > INT32_MAX || E > INT32_MAX) return fail(GLAM_E_INVALID, "%s: N/E out of range", fn);
+    if (Cp <= 0 || (Cp & 3)) return fail(GLAM_E_INVALID, "%s: Cp=%d must be a positive multiple of 4", fn, Cp);
+    if (De != 4 && De != 8) return fail(GLAM_E_UNSUPPORTED, "%s: De=%d (host must zero-pad edge features to 4 or 8)", fn, De);
+    if (H < 1 || H > 4) return fail(GLAM_E_UNSUPPORTED, "%s: heads=%d not in 1..4", fn, H);
+    if (!pick_shape(Cp >> 2, sh)) return fail(GLAM_E_UNSUPPORTED, "%s: Cp=%d exceeds 256 channels per head", fn, Cp);
+    return GLAM_OK;
+}
+
+constexpr int kBwdBlocks = 512;  // cap on B1 blocks = rows of the d_W_edge partial buffer
+
+}  // namespace glam
+
+using namespace glam;
+
+extern "C" int glam_triplet_fwd(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                                const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope, float* aggr,
+                                float* stats, void* stream) {
+    Shape sh;
+    if (int rc = check_dims("glam_triplet_fwd", N, E, H, Cp, De, &sh)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(xw && a_ij && M && rowptr && aggr && stats && (E == 0 || (src && eid && edge_attr)) && (!emul || w_edge),
+                 "glam_triplet_fwd: null pointer");
+    GLAM_REQUIRE(aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(stats) && aligned16(edge_attr) &&
+                     aligned16(w_edge), "glam_triplet_fwd: pointers must be 16-byte aligned");
+    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats};
+    const size_t lds = emul ? (size_t)De * H * Cp * sizeof(float) : 0;
+    if (!dispatch<FwdOp>(H, De, emul, sh, a, (int)N, lds, (hipStream_t)stream, kMaxBlocks, nullptr))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
+    GLAM_LAUNCH_CHECK("glam_triplet_fwd");
+    return GLAM_OK;
+}
+
+extern "C" size_t glam_triplet_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int De) {
+    const size_t P = (size_t)De * H * Cp + (size_t)De * 4;
+    return ((size_t)E * 8 + (size_t)kBwdBlocks * P) * sizeof(float) + 256;
+}
+
+extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                                const float* M, const float* aggr, const float* stats, const float* d_aggr,
+                                const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                                const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De,
+                                int emul, float slope, float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M,
+                                float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+    Shape sh;
+    if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
+    GLAM_REQUIRE(d_M && (!emul || d_w_edge), "glam_triplet_bwd: null gradient output");
+    hipStream_t s = (hipStream_t)stream;
+    const int WSZ = emul ? De * H * Cp : 0;
+    const int P = WSZ + De * 4;
+    if (N == 0) {
+        if (emul) (void)hipMemsetAsync(d_w_edge, 0, (size_t)WSZ * 4, s);
+        (void)hipMemsetAsync(d_M, 0, (size_t)De * 16, s);
+        return GLAM_OK;
+    }
+    GLAM_REQUIRE(xw && a_ij && M && aggr && stats && d_aggr && rowptr && colptr && d_xw && d_a_ij && ws,
+                 "glam_triplet_bwd: null pointer");
+    GLAM_REQUIRE(ws_bytes >= glam_triplet_bwd_workspace_bytes(N, E, H, Cp, De), "glam_triplet_bwd: workspace too small");
+    GLAM_REQUIRE(aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(stats) && aligned16(d_aggr) &&
+                     aligned16(d_xw) && aligned16(d_a_ij) && aligned16(edge_attr) && aligned16(w_edge) &&
+                     aligned16(d_edge_attr), "glam_triplet_bwd: pointers must be 16-byte aligned");
+    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
+    float* alpha_e = reinterpret_cast<float*>(base);
+    float* dpre_e = alpha_e + (size_t)E * 4;
+    float* partial = dpre_e + (size_t)E * 4;
+
+    BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
+                  alpha_e, dpre_e, d_a_ij, d_edge_attr, partial};
+    const size_t lds1 = ((size_t)WSZ + 4 * (size_t)P) * sizeof(float);
+    int nblk = 0;
+    if (!dispatch<BwdDstOp>(H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
+    GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
+    hipLaunchKernelGGL(k_reduce_partials, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, nblk, P, WSZ,
+                       d_w_edge, d_M);
+    GLAM_LAUNCH_CHECK("glam_triplet_bwd(reduce)");
+    BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij};
+    const size_t lds2 = (size_t)WSZ * sizeof(float);
+    if (!dispatch<BwdSrcOp>(H, De, emul, sh, b2, (int)N, lds2, s, kMaxBlocks, nullptr))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
+    GLAM_LAUNCH_CHECK("glam_triplet_bwd(B2)");
+    return GLAM_OK;
+}

@@ -1,0 +1,613 @@
+"""MI355X drop-in for the reference's graph-layer module (``src_1gp/layer.py``).
+
+Same class names, constructor signatures, parameter names / shapes / initialisation order and
+``forward`` surfaces as the reference, so that its string-dispatched configuration
+(``exec('self.conv={}(in_dim, out_dim, in_edge_dim)'.format(conv))`` at ``layer.py:227-230,
+244-249``), its checkpoints (``trainer.py:113-138``) and its ``seed_torch`` reproducible init
+all carry over.  The arithmetic of the message-passing path runs in hand-written gfx950
+kernels (``glam_amd/csrc``) reached through the C ABI in ``include/glam_hip.h``; nothing here
+falls back to CPU or to an eager re-implementation.
+
+Reference line citations are relative to ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.nn import Parameter, Dropout  # noqa: F401  (names resolved from config strings)
+from torch.nn import Sequential, Linear, ReLU, CELU, PReLU, RReLU, LeakyReLU, GRU, Sigmoid  # noqa: F401
+from torch.nn.init import kaiming_uniform_, zeros_, ones_  # noqa: F401
+
+from . import ops
+from ._lib import GlamHipError
+
+
+def _ceil4(c):
+    return (c + 3) // 4 * 4
+
+
+def _pad_de(de):
+    if de <= 4:
+        return 4
+    if de <= 8:
+        return 8
+    raise GlamHipError(f"edge_channels={de} > 8 is outside the compiled kernel table")
+
+
+# --------------------------------------------------------------------------------------
+# MessagePassing surface (PyG base class the reference derives from, layer.py:9)
+# --------------------------------------------------------------------------------------
+class MessagePassing(torch.nn.Module):
+    """Carrier of the PyG constructor surface (``aggr``, ``flow``, ``node_dim``).  The
+    gather -> message -> aggregate -> update pipeline PyG's ``propagate`` runs op by op is one
+    fused kernel here, so subclasses implement ``forward`` directly."""
+
+    def __init__(self, aggr="add", flow="source_to_target", node_dim=0, **kwargs):
+        super().__init__()
+        if flow != "source_to_target":
+            raise ValueError("only flow='source_to_target' is supported (the reference never changes it)")
+        self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
+
+    def message(self, *args, **kwargs):
+        raise NotImplementedError("message() is fused into the HIP aggregate kernel; call forward()")
+
+
+# --------------------------------------------------------------------------------------
+# TripletMessage (layer.py:15-64)
+# --------------------------------------------------------------------------------------
+class TripletMessage(MessagePassing):
+    def __init__(self, node_channels, edge_channels, heads=3, negative_slope=0.2, **kwargs):
+        super().__init__(aggr="add", node_dim=0, **kwargs)
+        self.node_channels, self.edge_channels = node_channels, edge_channels
+        self.heads, self.negative_slope = heads, negative_slope
+        # same creation + init order as layer.py:22-34 (uninitialised tensors consume no RNG)
+        self.weight_node = Parameter(torch.empty(node_channels, heads * node_channels))
+        self.weight_edge = Parameter(torch.empty(edge_channels, heads * node_channels))
+        self.weight_triplet_att = Parameter(torch.empty(1, heads, 3 * node_channels))
+        self.weight_scale = Parameter(torch.empty(heads * node_channels, node_channels))
+        self.bias = Parameter(torch.empty(node_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        kaiming_uniform_(self.weight_node)
+        kaiming_uniform_(self.weight_edge)
+        kaiming_uniform_(self.weight_triplet_att)
+        kaiming_uniform_(self.weight_scale)
+        zeros_(self.bias)
+
+    def _staged_weights(self):
+        """Parameter-only staging (no node/edge data): separable attention weights and the
+        4-channel padded layouts the kernels read.  ``logit = a_i[dst] + <edge_attr, M> + a_j[src]``
+        with ``a_i = x @ Wa[:, :4]``, ``a_j = x @ Wa[:, 4:]``."""
+        H, C, De = self.heads, self.node_channels, self.edge_channels
+        Cp, Dp = _ceil4(C), _pad_de(De)
+        att = self.weight_triplet_att[0]                                 # [H, 3C]
+        att_ij = torch.stack([att[:, :C], att[:, 2 * C:]], dim=-1)      # [H, C, 2]
+        Wn = self.weight_node.view(C, H, C)
+        Wa = torch.bmm(Wn.permute(1, 0, 2), att_ij)                      # [H, Cin, 2]
+        Wa = F.pad(Wa.permute(1, 2, 0), (0, 4 - H)).reshape(C, 8)        # [Cin, (i|j) x 4]
+        We = self.weight_edge.view(De, H, C)
+        M = torch.bmm(We.permute(1, 0, 2), att[:, C:2 * C].unsqueeze(-1)).squeeze(-1).t()   # [De, H]
+        M = F.pad(M, (0, 4 - H, 0, Dp - De))
+        if Cp != C or Dp != De:
+            Wn = F.pad(Wn, (0, Cp - C))
+            We = F.pad(We, (0, Cp - C, 0, 0, 0, Dp - De))
+            Ws = F.pad(self.weight_scale.view(H, C, C), (0, 0, 0, Cp - C)).reshape(H * Cp, C)
+        else:
+            Ws = self.weight_scale
+        return Wn.reshape(C, H * Cp), Wa, We.reshape(Dp, H * Cp).contiguous(), M.contiguous(), Ws, Cp, Dp
+
+    def forward(self, x, edge_index, edge_attr, size=None):
+        if self.heads > 4:
+            raise GlamHipError("heads > 4 is outside the compiled kernel table")
+        edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        gi = ops.graph_index(edge_index, x.size(0))
+        Wn, Wa, We, M, Ws, Cp, Dp = self._staged_weights()
+        xw = torch.matmul(x, Wn)                                          # layer.py:37
+        a_ij = torch.matmul(x, Wa)
+        if Dp != edge_attr.size(1):
+            edge_attr = F.pad(edge_attr, (0, Dp - edge_attr.size(1)))
+        aggr = ops.triplet_aggregate(xw, a_ij, edge_attr, We, M, gi, self.heads, Cp, self.negative_slope)
+        return self.update(aggr, Ws)
+
+    def update(self, aggr_out, weight_scale=None):                         # layer.py:57-61
+        w = self.weight_scale if weight_scale is None else weight_scale
+        aggr_out = aggr_out.view(-1, w.size(0))
+        return torch.matmul(aggr_out, w) + self.bias
+
+    def extra_repr(self):
+        return "{node_channels}, {node_channels}, heads={heads}".format(**self.__dict__)
+
+
+# --------------------------------------------------------------------------------------
+# TripletMessageLight (layer.py:67-104)
+# --------------------------------------------------------------------------------------
+class TripletMessageLight(MessagePassing):
+    def __init__(self, node_channels, edge_channels, negative_slope=0.2, **kwargs):
+        super().__init__(aggr="add", node_dim=0, **kwargs)
+        self.node_channels, self.edge_channels = node_channels, edge_channels
+        self.negative_slope = negative_slope
+        self.weight_node = Parameter(torch.empty(node_channels, node_channels))
+        self.weight_triplet_att = Parameter(torch.empty(1, 2 * node_channels + edge_channels))
+        self.bias = Parameter(torch.empty(node_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        kaiming_uniform_(self.weight_node)
+        kaiming_uniform_(self.weight_triplet_att)
+        zeros_(self.bias)
+
+    def forward(self, x, edge_index, edge_attr, size=None):
+        C, De = self.node_channels, self.edge_channels
+        Cp, Dp = _ceil4(C), _pad_de(De)
+        edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        gi = ops.graph_index(edge_index, x.size(0))
+        att = self.weight_triplet_att[0]
+        att_ij = torch.stack([att[:C], att[C + De:]], dim=-1)                       # [C, 2]
+        Wa = torch.matmul(self.weight_node, att_ij)                                 # [Cin, 2]
+        Wa = F.pad(Wa.unsqueeze(-1), (0, 3)).reshape(C, 8)
+        M = F.pad(att[C:C + De].unsqueeze(-1), (0, 3, 0, Dp - De)).contiguous()     # [Dp, 4]
+        Wn = F.pad(self.weight_node, (0, Cp - C)) if Cp != C else self.weight_node
+        xw = torch.matmul(x, Wn)                                                    # layer.py:84
+        a_ij = torch.matmul(x, Wa)
+        if Dp != De:
+            edge_attr = F.pad(edge_attr, (0, Dp - De))
+        aggr = ops.light_aggregate(xw, a_ij, edge_attr, M, gi, Cp, self.negative_slope)
+        return self.update(aggr[:, :C] if Cp != C else aggr)
+
+    def update(self, aggr_out):                                                     # layer.py:99-101
+        return aggr_out + self.bias
+
+    def extra_repr(self):
+        return "{node_channels}, {node_channels}".format(**self.__dict__)
+
+
+class _None(torch.nn.Module):  # placeholder for no norm / dropout / activation (layer.py:107-112)
+    def __init__(self, **params):
+        super().__init__()
+
+    def forward(self, x, batch=None):
+        return x
+
+
+# --------------------------------------------------------------------------------------
+# PyG convolutions the search space can select (layer.py:115-158)
+# --------------------------------------------------------------------------------------
+class NNConv(MessagePassing):
+    """PyG 1.7.2 ``NNConv``: ``x_i' = x_i @ root + aggr_j(x_j @ nn(e_ij).view(in,out)) + bias``."""
+
+    def __init__(self, in_channels, out_channels, nn, aggr="add", root_weight=True, bias=True, **kwargs):
+        super().__init__(aggr=aggr, node_dim=0, **kwargs)
+        self.in_channels, self.out_channels, self.nn = in_channels, out_channels, nn
+        self.root = Parameter(torch.empty(in_channels, out_channels)) if root_weight else None
+        self.bias = Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in self.nn.modules():
+            if m is not self.nn and hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        if self.root is not None:
+            bound = 1.0 / math.sqrt(self.root.size(0))
+            with torch.no_grad():
+                self.root.uniform_(-bound, bound)
+        if self.bias is not None:
+            zeros_(self.bias)
+
+    def forward(self, x, edge_index, edge_attr, size=None):
+        gi = ops.graph_index(edge_index, x.size(0))
+        weight = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
+        msg = torch.bmm(x.index_select(0, edge_index[0]).unsqueeze(1), weight).squeeze(1)
+        out = ops.edge_reduce(msg, gi, self.aggr)
+        if self.root is not None:
+            out = out + torch.matmul(x, self.root)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+def _glorot(t):
+    stdv = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-stdv, stdv)
+
+
+def _with_self_loops(gi, edge_index, n, keep_existing):
+    """``edge_index`` + one self loop per node (GCN keeps existing loops' weight slot, GAT drops
+    them first); staged once per edge list."""
+    key = ("loops", keep_existing)
+    hit = gi.__dict__.setdefault("_derived", {}).get(key)
+    if hit is None:
+        mask = edge_index[0] != edge_index[1]
+        loop = torch.arange(n, dtype=edge_index.dtype, device=edge_index.device).unsqueeze(0).repeat(2, 1)
+        ei = torch.cat([edge_index[:, mask], loop], dim=1).contiguous()
+        hit = (ei, ops.GraphIndex(ei, n), mask)
+        gi._derived[key] = hit
+    return hit
+
+
+class GCNConv(MessagePassing):
+    def __init__(self, in_channels, out_channels, bias=True, **kwargs):
+        super().__init__(aggr="add", node_dim=0, **kwargs)
+        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        self.bias = Parameter(torch.empty(out_channels)) if bias else None
+        _glorot(self.weight)
+        if self.bias is not None:
+            zeros_(self.bias)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        n = x.size(0)
+        gi0 = ops.graph_index(edge_index, n)
+        ei, gi, mask = _with_self_loops(gi0, edge_index, n, True)
+        if edge_weight is None:
+            w = x.new_ones(ei.size(1))
+        else:  # add_remaining_self_loops: existing loops keep their weight
+            loop_w = edge_weight.new_ones(n)
+            inv = ~mask
+            loop_w[edge_index[0][inv]] = edge_weight[inv]
+            w = torch.cat([edge_weight[mask], loop_w])
+        deg = ops.edge_reduce(w, gi, "sum")
+        dis = deg.pow(-0.5)
+        dis = dis.masked_fill(dis == float("inf"), 0)
+        norm = dis[ei[0]] * w * dis[ei[1]]
+        xw = torch.matmul(x, self.weight)
+        out = ops.edge_reduce(norm.view(-1, 1) * xw.index_select(0, ei[0]), gi, "sum")
+        return out if self.bias is None else out + self.bias
+
+
+class GATConv(MessagePassing):
+    """PyG 1.7.2 ``GATConv(in, out)`` with its defaults (heads=1, concat, self loops).  The
+    attention softmax-aggregate is the same fused kernel as TripletMessageLight."""
+
+    def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, bias=True, **kwargs):
+        super().__init__(aggr="add", node_dim=0, **kwargs)
+        if heads != 1:
+            raise GlamHipError("GATConv: only heads=1 (the reference's configuration) is supported")
+        self.heads, self.out_channels, self.negative_slope = heads, out_channels, negative_slope
+        self.lin_l = Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_r = self.lin_l
+        self.att_l = Parameter(torch.empty(1, heads, out_channels))
+        self.att_r = Parameter(torch.empty(1, heads, out_channels))
+        self.bias = Parameter(torch.empty(heads * out_channels)) if bias else None
+        _glorot(self.lin_l.weight)
+        _glorot(self.att_l)
+        _glorot(self.att_r)
+        if self.bias is not None:
+            zeros_(self.bias)
+
+    def forward(self, x, edge_index):
+        n, C = x.size(0), self.out_channels
+        Cp = _ceil4(C)
+        gi0 = ops.graph_index(edge_index, n)
+        ei, gi, _ = _with_self_loops(gi0, edge_index, n, False)
+        xl = self.lin_l(x)
+        a_r = (xl * self.att_r.view(1, C)).sum(-1, keepdim=True)   # target side ("alpha_i")
+        a_l = (xl * self.att_l.view(1, C)).sum(-1, keepdim=True)   # source side ("alpha_j")
+        a_ij = torch.cat([F.pad(a_r, (0, 3)), F.pad(a_l, (0, 3))], dim=1)
+        if Cp != C:
+            xl = F.pad(xl, (0, Cp - C))
+        zeros_e = x.new_zeros(ei.size(1), 4)
+        aggr = ops.light_aggregate(xl, a_ij, zeros_e, x.new_zeros(4, 4), gi, Cp, self.negative_slope)
+        out = aggr[:, :C] if Cp != C else aggr
+        return out if self.bias is None else out + self.bias
+
+
+class _NNConv(torch.nn.Module):  # layer.py:115-122
+    def __init__(self, in_dim, out_dim, edge_in_dim):
+        super().__init__()
+        nn = Sequential(Linear(edge_in_dim, 32), ReLU(), Linear(32, in_dim * out_dim))
+        self.conv = NNConv(in_dim, out_dim, nn, aggr="mean")
+
+    def forward(self, x, edge_index, edge_attr):
+        return self.conv(x, edge_index, edge_attr)
+
+
+class _TripletMessage(torch.nn.Module):  # layer.py:125-131
+    def __init__(self, in_dim, out_dim, edge_in_dim):
+        super().__init__()
+        self.conv = TripletMessage(in_dim, edge_in_dim)  # in_dim == out_dim
+
+    def forward(self, x, edge_index, edge_attr):
+        return self.conv(x, edge_index, edge_attr)
+
+
+class _TripletMessageLight(torch.nn.Module):  # layer.py:134-140
+    def __init__(self, in_dim, out_dim, edge_in_dim):
+        super().__init__()
+        self.conv = TripletMessageLight(in_dim, edge_in_dim)
+
+    def forward(self, x, edge_index, edge_attr):
+        return self.conv(x, edge_index, edge_attr)
+
+
+class _GCNConv(torch.nn.Module):  # layer.py:143-149
+    def __init__(self, in_dim, out_dim, edge_in_dim):
+        super().__init__()
+        self.conv = GCNConv(in_dim, out_dim)
+
+    def forward(self, x, edge_index, edge_attr):
+        return self.conv(x, edge_index)
+
+
+class _GATConv(torch.nn.Module):  # layer.py:152-158
+    def __init__(self, in_dim, out_dim, edge_in_dim):
+        super().__init__()
+        self.conv = GATConv(in_dim, out_dim)
+
+    def forward(self, x, edge_index, edge_attr):
+        return self.conv(x, edge_index)
+
+
+# --------------------------------------------------------------------------------------
+# graph norms (PyG classes wrapped at layer.py:161-194); segment statistics on the HIP pools
+# --------------------------------------------------------------------------------------
+class BatchNorm(torch.nn.Module):
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.module = torch.nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
+
+    def forward(self, x):
+        return self.module(x)
+
+
+class LayerNorm(torch.nn.Module):
+    """PyG graph LayerNorm: statistics over all nodes x channels of each graph."""
+
+    def __init__(self, in_channels, eps=1e-5, affine=True):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = Parameter(torch.ones(in_channels)) if affine else None
+        self.bias = Parameter(torch.zeros(in_channels)) if affine else None
+
+    def forward(self, x, batch=None):
+        if batch is None:
+            x = x - x.mean()
+            out = x / (x.std(unbiased=False) + self.eps)
+        else:
+            sp = ops.segment_ptr(batch)
+            denom = (sp.ptr[1:] - sp.ptr[:-1]).clamp(min=1).to(x.dtype).mul(x.size(-1)).view(-1, 1)
+            mean = ops.segment_pool(x, sp, "sum").sum(dim=-1, keepdim=True) / denom
+            x = x - mean.index_select(0, batch)
+            var = ops.segment_pool(x * x, sp, "sum").sum(dim=-1, keepdim=True) / denom
+            out = x / (var + self.eps).sqrt().index_select(0, batch)
+        if self.weight is not None:
+            out = out * self.weight + self.bias
+        return out
+
+
+class PairNorm(torch.nn.Module):
+    def __init__(self, scale=1.0, scale_individually=False, eps=1e-5):
+        super().__init__()
+        if scale_individually:
+            raise GlamHipError("PairNorm(scale_individually=True) is not used by the reference")
+        self.scale, self.eps = scale, eps
+
+    def forward(self, x, batch=None):
+        if batch is None:
+            x = x - x.mean(dim=0, keepdim=True)
+            return self.scale * x / (self.eps + x.pow(2).sum(-1).mean()).sqrt()
+        sp = ops.segment_ptr(batch)
+        x = x - ops.segment_pool(x, sp, "mean").index_select(0, batch)
+        sq = ops.segment_pool(x.pow(2).sum(-1, keepdim=True), sp, "mean")
+        return self.scale * x / (self.eps + sq.index_select(0, batch)).sqrt()
+
+
+class GraphSizeNorm(torch.nn.Module):
+    def forward(self, x, batch=None):
+        if batch is None:
+            return x * (x.size(0) ** -0.5)
+        sp = ops.segment_ptr(batch)
+        inv = (sp.ptr[1:] - sp.ptr[:-1]).to(x.dtype).pow(-0.5)
+        return x * inv.index_select(0, batch).view(-1, 1)
+
+
+class _BatchNorm(torch.nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.norm = BatchNorm(in_channels)
+
+    def forward(self, x, batch=None):
+        return self.norm(x)
+
+
+class _LayerNorm(torch.nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.norm = LayerNorm(in_channels)
+
+    def forward(self, x, batch=None):
+        return self.norm(x, batch)
+
+
+class _PairNorm(torch.nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.norm = PairNorm()
+
+    def forward(self, x, batch=None):
+        return self.norm(x, batch)
+
+
+class _GraphSizeNorm(torch.nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.norm = GraphSizeNorm()
+
+    def forward(self, x, batch=None):
+        return self.norm(x)   # the reference drops ``batch`` here (layer.py:193-194)
+
+
+# --------------------------------------------------------------------------------------
+# readouts (layer.py:197-220, model.py:41)
+# --------------------------------------------------------------------------------------
+def global_add_pool(x, batch, size=None):
+    return ops.segment_pool(x, ops.segment_ptr(batch, size), "sum")
+
+
+def global_mean_pool(x, batch, size=None):
+    return ops.segment_pool(x, ops.segment_ptr(batch, size), "mean")
+
+
+def global_max_pool(x, batch, size=None):
+    return ops.segment_pool(x, ops.segment_ptr(batch, size), "max")
+
+
+def global_sort_pool(x, batch, k):
+    if k > 8:
+        raise GlamHipError("global_sort_pool: k > 8 is outside the compiled kernel table")
+    return ops.pool5(x, ops.segment_ptr(batch), k)[:, 2 * x.size(1):]
+
+
+class GlobalPool5(torch.nn.Module):
+    def __init__(self, **params):
+        super().__init__()
+
+    def forward(self, x, batch, num_graphs=None):
+        return ops.pool5(x, ops.segment_ptr(batch, num_graphs), 3)   # mean | add | sort-pool(k=3)
+
+
+class GlobalAttention(torch.nn.Module):
+    def __init__(self, gate_nn, nn=None):
+        super().__init__()
+        self.gate_nn, self.nn = gate_nn, nn
+
+    def forward(self, x, batch, size=None):
+        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        sp = ops.segment_ptr(batch, size)
+        gate = self.gate_nn(x).view(-1)
+        v = self.nn(x) if self.nn is not None else x
+        return ops.segment_attention(gate, v, sp)
+
+
+class GlobalLAPool(torch.nn.Module):
+    def __init__(self, in_channels, **params):
+        super().__init__()
+        gated_nn = Linear(in_channels, 1)
+        nn = Linear(in_channels, 2 * in_channels)
+        self.pool = GlobalAttention(gate_nn=gated_nn, nn=nn)
+
+    def forward(self, x, batch, num_graphs=None):
+        return self.pool(x, batch, num_graphs)
+
+
+class Set2Set(torch.nn.Module):
+    """PyG ``Set2Set(in_channels, processing_steps)`` (model.py:41).  The LSTM parameters live in a
+    ``torch.nn.LSTM`` (checkpoint keys ``lstm.*``); the single-step cell is evaluated explicitly."""
+
+    def __init__(self, in_channels, processing_steps, num_layers=1, **params):
+        super().__init__()
+        if num_layers != 1:
+            raise GlamHipError("Set2Set: num_layers != 1 is not used by the reference")
+        self.in_channels, self.out_channels = in_channels, 2 * in_channels
+        self.processing_steps, self.num_layers = processing_steps, num_layers
+        self.lstm = torch.nn.LSTM(self.out_channels, self.in_channels, num_layers)
+
+    def forward(self, x, batch, num_graphs=None):
+        sp = ops.segment_ptr(batch, num_graphs)
+        B, C = sp.B, self.in_channels
+        h, c = x.new_zeros(B, C), x.new_zeros(B, C)
+        q_star = x.new_zeros(B, 2 * C)
+        L = self.lstm
+        for _ in range(self.processing_steps):
+            gates = F.linear(q_star, L.weight_ih_l0, L.bias_ih_l0) + F.linear(h, L.weight_hh_l0, L.bias_hh_l0)
+            i, f, g, o = gates.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            e = (x * h.index_select(0, batch)).sum(dim=-1)
+            r = ops.segment_attention(e, x, sp)
+            q_star = torch.cat([h, r], dim=-1)
+        return q_star
+
+
+# --------------------------------------------------------------------------------------
+# blocks (layer.py:223-267)
+# --------------------------------------------------------------------------------------
+def _build(expr, **local):
+    """The reference resolves module choices by ``exec`` of config strings inside this namespace
+    (layer.py:227-230, 244-249); same mechanism, same names."""
+    return eval(expr, globals(), local)  # noqa: S307 - config strings, exactly as the reference
+
+
+def _act(name):
+    name = name[:-2] if name.endswith("()") else name
+    return _build(name + "()")
+
+
+class LinearBlock(torch.nn.Module):
+    def __init__(self, in_dim=32, out_dim=64, norm="_None", dropout="_None()", act="ReLU()"):
+        super().__init__()
+        self.norm = _build("{}(in_channels=in_dim)".format(norm), in_dim=in_dim)
+        self.dropout = _build(dropout)
+        self.linear = Linear(in_dim, out_dim)
+        self.act = _act(act)
+
+    def forward(self, x, batch=None):
+        x = self.norm(x, batch)
+        x = self.dropout(x)
+        x = self.linear(x)
+        return self.act(x)
+
+
+class MessageBlock(torch.nn.Module):
+    def __init__(self, in_dim=32, out_dim=64, in_edge_dim=13, norm="_None", dropout="Dropout(0.2)",
+                 conv="_NNConv", act="ReLU()", res=True):
+        super().__init__()
+        self.norm = _build("{}(in_channels=in_dim)".format(norm), in_dim=in_dim)
+        self.dropout = _build(dropout)
+        self.conv = _build("{}(in_dim, out_dim, in_edge_dim)".format(conv), in_dim=in_dim, out_dim=out_dim,
+                           in_edge_dim=in_edge_dim)
+        self.gru = GRU(in_dim, out_dim)
+        if conv in ["_GCNConv", "_GATConv"]:
+            self.gru = None
+        self.act = _act(act)
+        self.res = res
+
+    def _gru_step(self, x, h):
+        """One step of ``self.gru`` (seq_len 1, layer.py:262) on its own parameters."""
+        g = self.gru
+        gi = F.linear(x, g.weight_ih_l0, g.bias_ih_l0)
+        gh = F.linear(h, g.weight_hh_l0, g.bias_hh_l0)
+        i_r, i_z, i_n = gi.chunk(3, dim=1)
+        h_r, h_z, h_n = gh.chunk(3, dim=1)
+        r = torch.sigmoid(i_r + h_r)
+        z = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        return (1 - z) * n + z * h
+
+    def forward(self, x, edge_index, edge_attr, h=None, batch=None):
+        identity = x
+        if h is None:
+            h = x.unsqueeze(0)                       # layer.py:254 (pre-norm x seeds the GRU state)
+        x = self.norm(x, batch)
+        x = self.dropout(x)
+        x = self.conv(x, edge_index, edge_attr)      # layer.py:259
+        if self.gru is not None:
+            x = torch.celu(x)                        # layer.py:261
+            x = self._gru_step(x, h.squeeze(0))
+            h = x.unsqueeze(0)
+        x = x if self.res is False else x + identity
+        x = self.act(x)
+        return x, h
+
+
+def _pair_stats(mol_out, pro_out, mol_batch, pro_batch, stats):
+    mol_ptr = ops.segment_ptr(mol_batch).ptr.tolist()
+    pro_ptr = ops.segment_ptr(pro_batch).ptr.tolist()
+    rows = []
+    for i in range(len(mol_ptr) - 1):
+        item = torch.matmul(mol_out[mol_ptr[i]:mol_ptr[i + 1]], pro_out[pro_ptr[i]:pro_ptr[i + 1]].T)
+        if stats == 2:
+            rows.append(torch.stack([item.max(), item.mean()]))
+        else:
+            rows.append(torch.stack([item.max(), item.mean(), item.median(), item.min(), item.std()]))
+    return torch.stack(rows)
+
+
+def dot_and_global_pool5(mol_out, pro_out, mol_batch, pro_batch):   # src_1gp/layer.py:270-283
+    return _pair_stats(mol_out, pro_out, mol_batch, pro_batch, 5)
+
+
+def dot_and_global_pool2(mol_out, pro_out, mol_batch, pro_batch):   # src_2gi_dti_scr/layer.py:270-283
+    return _pair_stats(mol_out, pro_out, mol_batch, pro_batch, 2)

@@ -1,0 +1,103 @@
+"""MI355X drop-in for the reference's model assembly (``src_1gp/model.py``).
+
+``Architecture`` / ``Model`` keep the reference constructor keywords (``model.py:24-33``), the
+sub-module names (checkpoint keys ``mol_lin0.*``, ``mol_conv.*``, ``mol_readout.*``, ``mol_flat.*``,
+``lin_out1.*``) and the call ``model(batch) -> [B, out_dim]`` used by the reference trainers
+(``trainer.py:295``).  ``ArchitectureDTI`` mirrors the two-tower variant
+(``src_2gi_dti_scr/model.py:14-68``).
+"""
+from __future__ import annotations
+
+import torch
+
+from .layer import _None  # noqa: F401
+from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
+from .layer import LinearBlock, MessageBlock, dot_and_global_pool2
+
+
+def model_args(args):
+    """Filter a run.py-style ``Namespace`` down to constructor keywords (model.py:7-15)."""
+    other = ["dataset_root", "dataset", "split", "seed", "gpu", "note", "batch_size", "epochs", "loss", "optim", "k",
+             "lr", "lr_reduce_rate", "lr_reduce_patience", "early_stop_patience", "verbose_patience", "split_seed",
+             "test"]
+    return {k: v for k, v in args.__dict__.items() if k not in other}
+
+
+def _readout(name, hid_dim):
+    return eval("{}(in_channels=hid_dim, processing_steps=3)".format(name), globals(), {"hid_dim": hid_dim})  # noqa: S307
+
+
+class Architecture(torch.nn.Module):
+    def __init__(self, mol_in_dim=15, mol_edge_in_dim=4, hid_dim_alpha=4, e_dim=1024, out_dim=1,
+                 mol_block="_NNConv", message_steps=3, mol_readout="GlobalPool5",
+                 pre_norm="_None", graph_norm="_None", flat_norm="_None", end_norm="_None",
+                 pre_do="_None()", graph_do="Dropout(0.2)", flat_do="_None()", end_do="Dropout(0.2)",
+                 pre_act="RReLU", graph_act="RReLU", flat_act="RReLU", graph_res=True):
+        super().__init__()
+        hid_dim = mol_in_dim * hid_dim_alpha
+        self.mol_lin0 = LinearBlock(mol_in_dim, hid_dim, norm=pre_norm, dropout=pre_do, act=pre_act)
+        self.mol_conv = MessageBlock(hid_dim, hid_dim, mol_edge_in_dim, norm=graph_norm, dropout=graph_do,
+                                     conv=mol_block, act=graph_act, res=graph_res)
+        self.message_steps = message_steps
+        self.mol_readout = _readout(mol_readout, hid_dim)
+        _mol_ro = 5 if mol_readout == "GlobalPool5" else 2
+        self.mol_flat = LinearBlock(_mol_ro * hid_dim, e_dim, norm=flat_norm, dropout=flat_do, act=flat_act)
+        self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
+
+    def forward(self, data_mol):
+        xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)                       # model.py:49
+        hm = None
+        for _ in range(self.message_steps):                                        # model.py:53-54
+            xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
+        # PyG's pools read the graph count back from ``batch``; a collated Batch already knows it
+        num_graphs = getattr(data_mol, "num_graphs", None) or None
+        outm = self.mol_readout(xm, data_mol.batch, num_graphs)                    # model.py:57
+        outm = self.mol_flat(outm)                                                 # model.py:60
+        return self.lin_out1(outm)                                                 # model.py:61
+
+
+Model = Architecture
+
+
+class ArchitectureDTI(torch.nn.Module):
+    """Ligand + protein two-tower model with per-pair fusion (src_2gi_dti_scr/model.py:14-68)."""
+
+    def __init__(self, mol_in_dim=15, pro_in_dim=49, mol_edge_in_dim=4, pro_edge_in_dim=8, hid_dim_alpha=4,
+                 e_dim=1024, out_dim=1, mol_block="_NNConv", pro_block="_GCNConv", message_steps=3,
+                 mol_readout="GlobalPool5", pro_readout="GlobalPool5",
+                 pre_norm="_None", graph_norm="_None", flat_norm="_None", end_norm="_None",
+                 pre_do="_None()", graph_do="Dropout(0.2)", flat_do="_None()", end_do="Dropout(0.2)",
+                 pre_act="RReLU", graph_act="RReLU", flat_act="RReLU", end_act="RReLU", graph_res=True):
+        super().__init__()
+        hid_dim = mol_in_dim * hid_dim_alpha
+        self.mol_lin0 = LinearBlock(mol_in_dim, hid_dim, norm=pre_norm, dropout=pre_do, act=pre_act)
+        self.pro_lin0 = LinearBlock(pro_in_dim, hid_dim, norm=pre_norm, dropout=pre_do, act=pre_act)
+        self.mol_conv = MessageBlock(hid_dim, hid_dim, mol_edge_in_dim, norm=graph_norm, dropout=graph_do,
+                                     conv=mol_block, act=graph_act, res=graph_res)
+        self.pro_conv = MessageBlock(hid_dim, hid_dim, pro_edge_in_dim, norm=graph_norm, dropout=graph_do,
+                                     conv=pro_block, act=graph_act, res=graph_res)
+        self.message_steps = message_steps
+        self.mol_readout = _readout(mol_readout, hid_dim)
+        self.pro_readout = _readout(pro_readout, hid_dim)
+        _mol_ro = 5 if mol_readout == "GlobalPool5" else 2
+        _pro_ro = 5 if pro_readout == "GlobalPool5" else 2
+        self.mol_flat = LinearBlock(_mol_ro * hid_dim, hid_dim, norm=flat_norm, dropout=flat_do, act=flat_act)
+        self.pro_flat = LinearBlock(_pro_ro * hid_dim, hid_dim, norm=flat_norm, dropout=flat_do, act=flat_act)
+        self.lin_out0 = LinearBlock(hid_dim * 2 + message_steps * 2, e_dim, norm=end_norm, dropout=end_do, act=end_act)
+        self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
+
+    def forward(self, data_mol, data_pro):
+        xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)
+        xp = self.pro_lin0(data_pro.x, batch=data_pro.batch)
+        hm, hp = None, None
+        fusion = []
+        for _ in range(self.message_steps):
+            xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
+            xp, hp = self.pro_conv(xp, data_pro.edge_index, data_pro.edge_attr, h=hp, batch=data_pro.batch)
+            fusion.append(dot_and_global_pool2(xm, xp, data_mol.batch, data_pro.batch))
+        nm = getattr(data_mol, "num_graphs", None) or None
+        np_ = getattr(data_pro, "num_graphs", None) or None
+        outm = self.mol_flat(self.mol_readout(xm, data_mol.batch, nm))
+        outp = self.pro_flat(self.pro_readout(xp, data_pro.batch, np_))
+        out = torch.cat([outm, outp, torch.cat(fusion, dim=-1)], dim=-1)
+        return self.lin_out1(self.lin_out0(out))

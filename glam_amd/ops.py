@@ -1,0 +1,319 @@
+"""Functional ops over ``libglam_hip.so`` with autograd (host side of the C ABI).
+
+Every function launches hand-written gfx950 kernels on torch's *current* HIP stream; PyTorch
+only supplies device memory, the stream and the autograd tape.  There is no CPU path.
+
+``GraphIndex`` is the CSR staging of one ``edge_index`` (by target for the forward gather, by
+source — the transpose — for the backward scatter); it is cached per ``edge_index`` tensor
+because the reference re-uses one edge list for every message step (``src_1gp/model.py:53-54``)
+and its train loader does not shuffle (``src_1gp/trainer.py:37-38``).
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import GlamHipError, check, f32c, ptr, require_device, stream
+
+
+# --------------------------------------------------------------------------------------
+# CSR staging
+# --------------------------------------------------------------------------------------
+class GraphIndex:
+    """CSR-by-target ``(rowptr, src, eid)`` and CSR-by-source ``(colptr, dst, eid_t)`` of an
+    int64 ``edge_index[2,E]`` over ``N`` nodes (PyG flow source_to_target: row 0 = source j,
+    row 1 = target i).  int32, device resident, stable inside every segment."""
+
+    def __init__(self, edge_index, num_nodes, validate=True):
+        require_device(edge_index)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise GlamHipError(f"edge_index must be int64 [2,E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+        ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+        self.N, self.E = int(num_nodes), int(ei.size(1))
+        self.device = ei.device
+        lib = _lib.load()
+        dev = ei.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.rowptr = torch.empty(self.N + 1, **i32)
+        self.src = torch.empty(self.E, **i32)
+        self.eid = torch.empty(self.E, **i32)
+        self._ei = ei
+        self._t = None
+        self._err = torch.zeros(1, **i32)
+        ws = torch.empty(lib.glam_csr_workspace_bytes(self.N, self.E), dtype=torch.uint8, device=dev)
+        check(lib.glam_csr_build(ptr(ei), self.N, self.E, 0, ptr(self.rowptr), ptr(self.src), ptr(self.eid),
+                                 ptr(self._err), ptr(ws), ws.numel(), stream()), "glam_csr_build")
+        if validate and int(self._err.item()) != 0:   # same failure class as torch's index_select on CPU
+            raise IndexError(f"edge_index holds node ids outside [0, {self.N})")
+
+    def transpose(self):
+        """CSR by source (built on first backward)."""
+        if self._t is None:
+            lib = _lib.load()
+            i32 = dict(dtype=torch.int32, device=self.device)
+            colptr, dst, eid_t = torch.empty(self.N + 1, **i32), torch.empty(self.E, **i32), torch.empty(self.E, **i32)
+            ws = torch.empty(lib.glam_csr_workspace_bytes(self.N, self.E), dtype=torch.uint8, device=self.device)
+            check(lib.glam_csr_build(ptr(self._ei), self.N, self.E, 1, ptr(colptr), ptr(dst), ptr(eid_t),
+                                     ptr(self._err), ptr(ws), ws.numel(), stream()), "glam_csr_build(T)")
+            self._t = (colptr, dst, eid_t)
+        return self._t
+
+
+_GI_CACHE: dict = {}
+
+
+def graph_index(edge_index, num_nodes):
+    """Cached ``GraphIndex`` for this very tensor object (dropped when the tensor dies or is
+    modified in place)."""
+    key = id(edge_index)
+    hit = _GI_CACHE.get(key)
+    if hit is not None:
+        ref, version, n, gi = hit
+        if ref() is edge_index and version == edge_index._version and n == int(num_nodes):
+            return gi
+    gi = GraphIndex(edge_index, num_nodes)
+    try:
+        ref = weakref.ref(edge_index, lambda _r, k=key, c=_GI_CACHE: c.pop(k, None))
+        _GI_CACHE[key] = (ref, edge_index._version, int(num_nodes), gi)
+    except TypeError:
+        pass
+    return gi
+
+
+class SegmentPtr:
+    """``ptr[B+1]`` (int32) of a sorted ``batch`` vector; ``num_graphs`` optional — when absent it
+    is read back from ``batch[-1]`` exactly like PyG's ``int(batch.max()) + 1`` (one host sync)."""
+
+    def __init__(self, batch, num_graphs=None, validate=True):
+        require_device(batch)
+        if batch.dtype != torch.int64 or batch.dim() != 1:
+            raise GlamHipError("batch must be an int64 vector")
+        self.N = int(batch.numel())
+        if num_graphs is None:
+            num_graphs = int(batch[-1].item()) + 1 if self.N > 0 else 0
+        self.B = int(num_graphs)
+        self.ptr = torch.empty(self.B + 1, dtype=torch.int32, device=batch.device)
+        err = torch.zeros(1, dtype=torch.int32, device=batch.device)
+        check(_lib.load().glam_batch_ptr(ptr(batch.contiguous()), self.N, self.B, ptr(self.ptr), ptr(err), stream()),
+              "glam_batch_ptr")
+        if validate and int(err.item()) != 0:
+            raise IndexError("batch must be non-decreasing with ids in [0, num_graphs)")
+
+
+_SP_CACHE: dict = {}
+
+
+def segment_ptr(batch, num_graphs=None):
+    key = id(batch)
+    hit = _SP_CACHE.get(key)
+    if hit is not None:
+        ref, version, sp = hit
+        if ref() is batch and version == batch._version and (num_graphs is None or sp.B == int(num_graphs)):
+            return sp
+    sp = SegmentPtr(batch, num_graphs)
+    try:
+        ref = weakref.ref(batch, lambda _r, k=key, c=_SP_CACHE: c.pop(k, None))
+        _SP_CACHE[key] = (ref, batch._version, sp)
+    except TypeError:
+        pass
+    return sp
+
+
+# --------------------------------------------------------------------------------------
+# fused gather / attention softmax / scatter-add  (TripletMessage, TripletMessageLight)
+# --------------------------------------------------------------------------------------
+class _TripletAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xw, a_ij, edge_attr, w_edge, M, gi, H, Cp, De, emul, slope):
+        require_device(xw, a_ij, edge_attr, w_edge, M)
+        xw, a_ij, edge_attr, M = f32c(xw, "xw"), f32c(a_ij, "a_ij"), f32c(edge_attr, "edge_attr"), f32c(M, "M")
+        w_edge = f32c(w_edge, "w_edge") if emul else None
+        N, E = gi.N, gi.E
+        if xw.shape != (N, H * Cp) or a_ij.shape != (N, 8) or edge_attr.shape != (E, De) or M.shape != (De, 4):
+            raise GlamHipError(f"triplet_aggregate: shape mismatch xw={tuple(xw.shape)} a_ij={tuple(a_ij.shape)} "
+                               f"edge_attr={tuple(edge_attr.shape)} M={tuple(M.shape)} for N={N} E={E} H={H} Cp={Cp} De={De}")
+        aggr = torch.empty(N, H * Cp, dtype=torch.float32, device=xw.device)
+        stats = torch.empty(N, 8, dtype=torch.float32, device=xw.device)
+        check(_lib.load().glam_triplet_fwd(ptr(xw), ptr(a_ij), ptr(edge_attr), ptr(w_edge), ptr(M), ptr(gi.rowptr),
+                                           ptr(gi.src), ptr(gi.eid), N, E, H, Cp, De, int(emul), float(slope),
+                                           ptr(aggr), ptr(stats), stream()), "glam_triplet_fwd")
+        ctx.save_for_backward(xw, a_ij, edge_attr, w_edge, M, aggr, stats)
+        ctx.gi, ctx.dims = gi, (H, Cp, De, int(emul), float(slope))
+        return aggr
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_aggr):
+        xw, a_ij, edge_attr, w_edge, M, aggr, stats = ctx.saved_tensors
+        gi = ctx.gi
+        H, Cp, De, emul, slope = ctx.dims
+        N, E = gi.N, gi.E
+        lib = _lib.load()
+        d_aggr = f32c(d_aggr, "d_aggr")
+        colptr, dst, eid_t = gi.transpose()
+        dev = xw.device
+        d_xw = torch.empty_like(xw)
+        d_a_ij = torch.empty_like(a_ij)
+        d_w_edge = torch.empty_like(w_edge) if emul else None
+        d_M = torch.empty_like(M)
+        d_ea = torch.zeros_like(edge_attr) if ctx.needs_input_grad[2] else None
+        ws = torch.empty(lib.glam_triplet_bwd_workspace_bytes(N, E, H, Cp, De), dtype=torch.uint8, device=dev)
+        check(lib.glam_triplet_bwd(ptr(xw), ptr(a_ij), ptr(edge_attr), ptr(w_edge), ptr(M), ptr(aggr), ptr(stats),
+                                   ptr(d_aggr), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
+                                   ptr(eid_t), N, E, H, Cp, De, emul, slope, ptr(d_xw), ptr(d_a_ij), ptr(d_w_edge),
+                                   ptr(d_M), ptr(d_ea), ptr(ws), ws.numel(), stream()), "glam_triplet_bwd")
+        return d_xw, d_a_ij, d_ea, d_w_edge, d_M, None, None, None, None, None, None
+
+
+def triplet_aggregate(xw, a_ij, edge_attr, w_edge, M, gi, heads, Cp, slope=0.2):
+    """``aggr[N, H*Cp]`` of TripletMessage (see ``glam_triplet_fwd`` in include/glam_hip.h)."""
+    return _TripletAggregate.apply(xw, a_ij, edge_attr, w_edge, M, gi, heads, Cp, edge_attr.size(1), True, slope)
+
+
+def light_aggregate(xw, a_ij, edge_attr, M, gi, Cp, slope=0.2):
+    """``aggr[N, Cp]`` of TripletMessageLight (single head, message ``alpha * x_j``)."""
+    return _TripletAggregate.apply(xw, a_ij, edge_attr, None, M, gi, 1, Cp, edge_attr.size(1), False, slope)
+
+
+# --------------------------------------------------------------------------------------
+# readouts
+# --------------------------------------------------------------------------------------
+class _Pool5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sp, k):
+        require_device(x)
+        x = f32c(x, "x")
+        N, D = x.shape
+        if N != sp.N:
+            raise GlamHipError(f"pool: x has {N} rows but batch has {sp.N}")
+        out = torch.empty(sp.B, (2 + k) * D, dtype=torch.float32, device=x.device)
+        topk = torch.empty(sp.B, k, dtype=torch.int32, device=x.device)
+        check(_lib.load().glam_pool5_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, k, ptr(out), ptr(topk), stream()),
+              "glam_pool5_fwd")
+        ctx.save_for_backward(topk)
+        ctx.sp, ctx.dims = sp, (N, D, k)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        (topk,) = ctx.saved_tensors
+        N, D, k = ctx.dims
+        sp = ctx.sp
+        d_out = f32c(d_out, "d_out")
+        d_x = torch.empty(N, D, dtype=torch.float32, device=d_out.device)
+        check(_lib.load().glam_pool5_bwd(ptr(d_out), ptr(sp.ptr), ptr(topk), N, sp.B, D, k, ptr(d_x), stream()),
+              "glam_pool5_bwd")
+        return d_x, None, None
+
+
+def pool5(x, sp, k=3):
+    """mean || add || sort-pool(k) readout, ``[B, (2+k)*D]``."""
+    return _Pool5.apply(x, sp, k)
+
+
+_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+
+
+class _SegmentPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sp, mode):
+        require_device(x)
+        x = f32c(x, "x")
+        N, D = x.shape
+        if N != sp.N:
+            raise GlamHipError(f"pool: x has {N} rows but batch has {sp.N}")
+        out = torch.empty(sp.B, D, dtype=torch.float32, device=x.device)
+        argmax = torch.empty(sp.B, D, dtype=torch.int32, device=x.device) if mode == 2 else None
+        check(_lib.load().glam_segment_pool_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, mode, ptr(out), ptr(argmax), stream()),
+              "glam_segment_pool_fwd")
+        ctx.sp, ctx.dims, ctx.argmax = sp, (N, D, mode), argmax
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        N, D, mode = ctx.dims
+        sp = ctx.sp
+        d_out = f32c(d_out, "d_out")
+        d_x = torch.empty(N, D, dtype=torch.float32, device=d_out.device)
+        check(_lib.load().glam_segment_pool_bwd(ptr(d_out), ptr(sp.ptr), ptr(ctx.argmax), N, sp.B, D, mode, ptr(d_x),
+                                                stream()), "glam_segment_pool_bwd")
+        return d_x, None, None
+
+
+def segment_pool(x, sp, reduce="sum"):
+    """``scatter(x, batch, dim=0, reduce)`` over the sorted ``batch`` behind ``sp``."""
+    squeeze = x.dim() == 1
+    out = _SegmentPool.apply(x.unsqueeze(-1) if squeeze else x, sp, _MODES[reduce])
+    return out.squeeze(-1) if squeeze else out
+
+
+class _SegmentAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate, v, sp):
+        require_device(gate, v)
+        gate, v = f32c(gate.reshape(-1), "gate"), f32c(v, "v")
+        N, D = v.shape
+        if gate.numel() != N or N != sp.N:
+            raise GlamHipError("segment_attention: gate / v / batch disagree on the node count")
+        out = torch.empty(sp.B, D, dtype=torch.float32, device=v.device)
+        stats = torch.empty(sp.B, 2, dtype=torch.float32, device=v.device)
+        check(_lib.load().glam_segment_attn_fwd(ptr(gate), ptr(v), ptr(sp.ptr), N, sp.B, D, ptr(out), ptr(stats), stream()),
+              "glam_segment_attn_fwd")
+        ctx.save_for_backward(gate, v, out, stats)
+        ctx.sp = sp
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        gate, v, out, stats = ctx.saved_tensors
+        sp = ctx.sp
+        N, D = v.shape
+        d_out = f32c(d_out, "d_out")
+        d_gate, d_v = torch.empty_like(gate), torch.empty_like(v)
+        check(_lib.load().glam_segment_attn_bwd(ptr(gate), ptr(v), ptr(out), ptr(stats), ptr(d_out), ptr(sp.ptr), N,
+                                                sp.B, D, ptr(d_gate), ptr(d_v), stream()), "glam_segment_attn_bwd")
+        return d_gate, d_v, None
+
+
+def segment_attention(gate, v, sp):
+    """``scatter_add(softmax(gate, batch) * v, batch)`` -> ``[B, D]`` (GlobalAttention / Set2Set)."""
+    return _SegmentAttn.apply(gate, v, sp)
+
+
+class _EdgeReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, msg, gi, mode):
+        require_device(msg)
+        msg = f32c(msg, "msg")
+        E, D = msg.shape
+        if E != gi.E:
+            raise GlamHipError(f"edge_reduce: {E} messages for {gi.E} edges")
+        out = torch.empty(gi.N, D, dtype=torch.float32, device=msg.device)
+        argmax = torch.empty(gi.N, D, dtype=torch.int32, device=msg.device) if mode == 2 else None
+        check(_lib.load().glam_edge_reduce_fwd(ptr(msg), ptr(gi.rowptr), ptr(gi.eid), gi.N, E, D, mode, ptr(out),
+                                               ptr(argmax), stream()), "glam_edge_reduce_fwd")
+        ctx.gi, ctx.dims, ctx.argmax = gi, (E, D, mode), argmax
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        E, D, mode = ctx.dims
+        gi = ctx.gi
+        d_out = f32c(d_out, "d_out")
+        d_msg = torch.empty(E, D, dtype=torch.float32, device=d_out.device)
+        check(_lib.load().glam_edge_reduce_bwd(ptr(d_out), ptr(gi.rowptr), ptr(gi.eid), ptr(ctx.argmax), gi.N, E, D,
+                                               mode, ptr(d_msg), stream()), "glam_edge_reduce_bwd")
+        return d_msg, None, None
+
+
+def edge_reduce(msg, gi, reduce="sum"):
+    """``scatter(msg, edge_index[1], dim=0, dim_size=N, reduce)`` over the CSR-by-target in ``gi``."""
+    squeeze = msg.dim() == 1
+    out = _EdgeReduce.apply(msg.unsqueeze(-1) if squeeze else msg, gi, _MODES[reduce])
+    return out.squeeze(-1) if squeeze else out

@@ -1,0 +1,141 @@
+/*
+ * glam_hip.h — C ABI of libglam_hip.so, the MI355X (gfx950) implementation of the GLAM
+ * message-passing hot path (yvquanli/GLAM src_1gp/layer.py + model.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *   - tensors are dense, row-major, fp32 ("f32") or int32/int64 as typed;
+ *   - `stream` is a hipStream_t passed as void*; every entry point only enqueues work on it
+ *     (no host synchronisation, no allocation), so calls are hipGraph-capturable;
+ *   - return value: 0 = ok, <0 = error (GLAM_E_*); glam_last_error() returns a per-thread message.
+ *     Nothing aborts; the Python mirror turns errors into RuntimeError/IndexError the way the
+ *     reference raises Python exceptions (src_1gp/trainer.py:54, loss.py:56-57).
+ *   - channel padding: node-feature rows are laid out [N, H, Cp] with Cp % 4 == 0 (16-byte
+ *     vector loads); the host mirror zero-pads C = 15/30/45/90 to 16/32/48/92.
+ *   - per-node scalar pairs are packed as [N, 8] f32: slots 0..3 = per-head "i" value,
+ *     slots 4..7 = per-head "j" value (H <= 4).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root).
+ */
+#ifndef GLAM_HIP_H
+#define GLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLAM_ABI_VERSION 1
+
+#define GLAM_OK 0
+#define GLAM_E_INVALID (-1)     /* bad argument (null pointer, negative size, misaligned) */
+#define GLAM_E_UNSUPPORTED (-2) /* shape outside the compiled kernel table */
+#define GLAM_E_HIP (-3)         /* HIP runtime error at launch */
+
+int glam_abi_version(void);
+const char* glam_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * CSR staging of a COO edge list.
+ * Replaces: the per-call index_select/scatter bookkeeping PyG's MessagePassing.propagate does for
+ * `self.propagate(edge_index, ...)` (src_1gp/layer.py:40, :86) — edge_index int64 [2,E], row 0 =
+ * source j, row 1 = target i.
+ *   by = 0: group edges by TARGET (edge_index[1]); nbr[] holds the source of each grouped edge.
+ *   by = 1: group edges by SOURCE (edge_index[0]); nbr[] holds the target (the transpose, used by
+ *           the backward pass to scatter to sources without atomics).
+ * Within a segment edges keep their original order (stable), so results are bit-reproducible.
+ * rowptr int32[N+1], nbr int32[E], eid int32[E] (original edge id of each grouped edge).
+ * err_flag int32[1]: set to 1 by the kernels if any index is outside [0,N) (such edges are
+ * dropped); the caller decides when to read it back.
+ * ws: scratch of at least glam_csr_workspace_bytes(N,E) bytes. */
+size_t glam_csr_workspace_bytes(int64_t N, int64_t E);
+int glam_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int by, int32_t* rowptr, int32_t* nbr,
+                   int32_t* eid, int32_t* err_flag, void* ws, size_t ws_bytes, void* stream);
+
+/* Segment pointer of a sorted graph-id vector: ptr int32[B+1] from batch int64[N] (non-decreasing),
+ * as produced by PyG collation and consumed by global_*_pool(x, batch) (src_1gp/layer.py:202). */
+int glam_batch_ptr(const int64_t* batch, int64_t N, int64_t B, int32_t* ptr, int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused neighbour gather + attention logits + per-target segment softmax + weighted scatter-add.
+ * Replaces: PyG propagate -> TripletMessage.message -> aggregate (src_1gp/layer.py:40-55; softmax
+ * at :51 with the +1e-16 denominator; aggr='add' at :17) when emul=1, and
+ * TripletMessageLight.message -> aggregate (src_1gp/layer.py:88-97) when emul=0.
+ *
+ *   logit[e,h] = leaky_relu(a_ij[dst,h] + sum_k edge_attr[e,k]*M[k,h] + a_ij[src,4+h], slope)
+ *   alpha      = segment softmax of logit over the incoming edges of dst
+ *   emul=1: aggr[n,h,:] = sum_e alpha[e,h] * (sum_k edge_attr[e,k]*w_edge[k,h,:]) * xw[src,h,:]
+ *   emul=0: aggr[n,h,:] = sum_e alpha[e,h] * xw[src,h,:]
+ *
+ * xw f32[N,H,Cp]; a_ij f32[N,8]; edge_attr f32[E,De] (De in {4,8}, zero padded by the host);
+ * w_edge f32[De,H,Cp] (ignored when emul=0); M f32[De,4]; CSR by target (rowptr,src,eid).
+ * Outputs: aggr f32[N,H,Cp]; stats f32[N,8] = per-head segment max (0..3) and exp-sum (4..7), the
+ * only state the backward pass needs to recompute alpha. */
+int glam_triplet_fwd(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                     const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
+                     int64_t E, int H, int Cp, int De, int emul, float slope, float* aggr, float* stats,
+                     void* stream);
+
+/* Backward of glam_triplet_fwd (what torch autograd derives for src_1gp/layer.py:42-55 + PyG softmax /
+ * scatter).  Two launches + one partial reduction, no atomics:
+ *   B1 (by target):  alpha_e f32[E,4], dpre_e f32[E,4] (grad of the pre-activation logit),
+ *                    d_a_ij[:,0:4], d_w_edge f32[De,H,Cp], d_M f32[De,4], optional d_edge_attr f32[E,De];
+ *   B2 (by source, CSR transpose colptr/dst/eid_t):  d_xw f32[N,H,Cp], d_a_ij[:,4:8].
+ * d_edge_attr may be NULL.  ws >= glam_triplet_bwd_workspace_bytes(...) bytes of scratch. */
+size_t glam_triplet_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int De);
+int glam_triplet_bwd(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                     const float* M, const float* aggr, const float* stats, const float* d_aggr,
+                     const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                     const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De,
+                     int emul, float slope, float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M,
+                     float* d_edge_attr, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph readouts over contiguous node segments ptr int32[B+1].
+ * Replaces: global_mean_pool / global_add_pool / global_max_pool / global_sort_pool(k) as called by
+ * GlobalPool5.forward (src_1gp/layer.py:201-203).
+ *   glam_pool5_fwd: out f32[B, (2+k)*D] = mean | add | the k rows with the largest LAST channel in
+ *   descending order (ties: lower node index first; short graphs zero padded); topk_idx int32[B,k]
+ *   (node index or -1) is saved for the backward pass.  k <= 8. */
+int glam_pool5_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int k, float* out,
+                   int32_t* topk_idx, void* stream);
+int glam_pool5_bwd(const float* d_out, const int32_t* ptr, const int32_t* topk_idx, int64_t N, int64_t B,
+                   int D, int k, float* d_x, void* stream);
+
+/* mode 0 = sum, 1 = mean, 2 = max (empty segment -> 0; argmax int32[B,D] saved for backward, may be
+ * NULL for modes 0/1).  Replaces torch_scatter.scatter(x, batch, dim=0, reduce=...) behind PyG's
+ * global_{add,mean,max}_pool. */
+int glam_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode, float* out,
+                          int32_t* argmax, void* stream);
+int glam_segment_pool_bwd(const float* d_out, const int32_t* ptr, const int32_t* argmax, int64_t N, int64_t B,
+                          int D, int mode, float* d_x, void* stream);
+
+/* Segment-softmax attention readout: out[g,:] = sum_{n in g} softmax_g(gate)[n] * v[n,:]
+ * (softmax with the same +1e-16 denominator as PyG's utils.softmax).
+ * Replaces: PyG GlobalAttention.forward behind GlobalLAPool (src_1gp/layer.py:206-220) and the
+ * attention step of Set2Set (src_1gp/model.py:41).  gate f32[N]; v f32[N,D]; out f32[B,D];
+ * stats f32[B,2] = segment max, exp-sum (saved for the backward pass). */
+int glam_segment_attn_fwd(const float* gate, const float* v, const int32_t* ptr, int64_t N, int64_t B, int D,
+                          float* out, float* stats, void* stream);
+int glam_segment_attn_bwd(const float* gate, const float* v, const float* out, const float* stats,
+                          const float* d_out, const int32_t* ptr, int64_t N, int64_t B, int D, float* d_gate,
+                          float* d_v, void* stream);
+
+/* Generic edge -> node reduction over a CSR-by-target:  out[n,:] = reduce_{e in seg(n)} msg[eid[e],:]
+ * mode 0 = sum, 1 = mean, 2 = max (empty segment -> 0; argmax int32[N,D] = winning edge id, saved for
+ * backward, may be NULL for modes 0/1).
+ * Replaces: PyG MessagePassing.aggregate -> torch_scatter.scatter(msg, edge_index[1], dim=0, dim_size=N,
+ * reduce=aggr) for message functions that stay in PyTorch, e.g. NNConv(aggr='mean')
+ * (src_1gp/layer.py:119), GCNConv (src_1gp/layer.py:146). */
+int glam_edge_reduce_fwd(const float* msg, const int32_t* rowptr, const int32_t* eid, int64_t N, int64_t E, int D,
+                         int mode, float* out, int32_t* argmax, void* stream);
+int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_t* eid, const int32_t* argmax,
+                         int64_t N, int64_t E, int D, int mode, float* d_msg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLAM_HIP_H */

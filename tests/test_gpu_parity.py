@@ -1,0 +1,375 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against (1) the golden vectors captured
+from the reference, (2) the CPU oracle on fresh seeds, (3) size-independent properties at the
+BASELINE.json batch size.  fp32 tolerance: 1e-5 (scaled by max(1,|ref|)) as BASELINE.json states;
+gradients 2e-5..5e-5 where several layers stack."""
+import numpy as np
+import pytest
+import torch
+
+import oracle.glam_oracle as O
+from glam_amd import layer, model, ops
+from glam_amd.data import Data, synth_batch, synth_protein_batch
+from tests.conftest import Golden, golden_names, assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _grads(out, cot, tensors):
+    gs = torch.autograd.grad((out * cot).sum(), tensors, allow_unused=True)
+    return [torch.zeros_like(t) if g is None else g for g, t in zip(gs, tensors)]
+
+
+def _dev(d, device):
+    return {k: v.to(device) for k, v in d.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# CSR staging
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["esol", "edge", "protein", "empty"])
+def test_csr_matches_stable_sort(device, case):
+    if case == "esol":
+        b = synth_batch(200, seed=3)
+        ei, N = b.edge_index, b.x.size(0)
+    elif case == "edge":
+        g = Golden("triplet_edge")
+        ei, N = g.inputs["edge_index"], g.inputs["x"].size(0)
+    elif case == "protein":
+        b = synth_protein_batch(3, seed=5)
+        ei, N = b.edge_index, b.x.size(0)
+    else:
+        ei, N = torch.zeros(2, 0, dtype=torch.long), 7
+    gi = ops.GraphIndex(ei.to(device), N)
+    colptr, dstv, eid_t = gi.transpose()
+    for key_row, val_row, (rp, nb, ed) in [(1, 0, (gi.rowptr, gi.src, gi.eid)), (0, 1, (colptr, dstv, eid_t))]:
+        key, val = ei[key_row].numpy(), ei[val_row].numpy()
+        order = np.argsort(key, kind="stable")
+        ref_ptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=N))])
+        assert np.array_equal(rp.cpu().numpy(), ref_ptr)
+        assert np.array_equal(ed.cpu().numpy(), order)
+        assert np.array_equal(nb.cpu().numpy(), val[order])
+
+
+def test_csr_rejects_out_of_range_ids(device):
+    ei = torch.tensor([[0, 1, 5], [1, 0, 2]], device=device)
+    with pytest.raises(IndexError):
+        ops.GraphIndex(ei, 3)
+    with pytest.raises(IndexError):
+        ops.SegmentPtr(torch.tensor([0, 2, 1], device=device), 3)
+
+
+def test_segment_ptr(device):
+    batch = torch.tensor([0, 0, 2, 2, 2, 5], device=device)
+    sp = ops.SegmentPtr(batch)
+    assert sp.B == 6 and sp.ptr.tolist() == [0, 2, 2, 5, 5, 5, 6]
+
+
+# ---------------------------------------------------------------------------------------------
+# TripletMessage / TripletMessageLight against the golden vectors
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("triplet_"))
+def test_triplet_message_golden(device, name):
+    g = Golden(name)
+    conv = layer.TripletMessage(g.meta["C"], g.meta["De"]).to(device)
+    conv.load_state_dict(g.params)
+    x = g.inputs["x"].to(device).requires_grad_(True)
+    ea = g.inputs["edge_attr"].to(device).requires_grad_(True)
+    out = conv(x, g.inputs["edge_index"].to(device), ea)
+    assert_close(out, g.out, TOL, name)
+    names = [n for n, _ in conv.named_parameters()]
+    gs = _grads(out, g.cot.to(device), [x, ea] + [p for _, p in conv.named_parameters()])
+    for n, t in zip(["x", "edge_attr"] + names, gs):
+        assert_close(t, g.grads[n], 2e-5, f"{name}/grad.{n}")
+
+
+@pytest.mark.parametrize("name", golden_names("triplet_"))
+def test_triplet_aggregate_op_golden(device, name):
+    """Op level: the fused kernel alone against the reference's aggregate (before ``update``)."""
+    g = Golden(name)
+    C, De = g.meta["C"], g.meta["De"]
+    conv = layer.TripletMessage(C, De).to(device)
+    conv.load_state_dict(g.params)
+    x, ei, ea = g.inputs["x"].to(device), g.inputs["edge_index"].to(device), g.inputs["edge_attr"].to(device)
+    with torch.no_grad():
+        Wn, Wa, We, M, Ws, Cp, Dp = conv._staged_weights()
+        ea_p = torch.nn.functional.pad(ea, (0, Dp - De))
+        aggr = ops.triplet_aggregate(x @ Wn, x @ Wa, ea_p, We, M, ops.graph_index(ei, x.size(0)), 3, Cp)
+    assert_close(aggr.view(-1, 3, Cp)[:, :, :C], g.grads["__aggr"], TOL, name + "/aggr")
+    if Cp != C:
+        assert (aggr.view(-1, 3, Cp)[:, :, C:] == 0).all()
+
+
+@pytest.mark.parametrize("name", golden_names("light_"))
+def test_triplet_light_golden(device, name):
+    g = Golden(name)
+    conv = layer.TripletMessageLight(g.meta["C"], g.meta["De"]).to(device)
+    conv.load_state_dict(g.params)
+    x = g.inputs["x"].to(device).requires_grad_(True)
+    ea = g.inputs["edge_attr"].to(device).requires_grad_(True)
+    out = conv(x, g.inputs["edge_index"].to(device), ea)
+    assert_close(out, g.out, TOL, name)
+    names = [n for n, _ in conv.named_parameters()]
+    gs = _grads(out, g.cot.to(device), [x, ea] + [p for _, p in conv.named_parameters()])
+    for n, t in zip(["x", "edge_attr"] + names, gs):
+        assert_close(t, g.grads[n], 2e-5, f"{name}/grad.{n}")
+
+
+# ---------------------------------------------------------------------------------------------
+# readouts and norms
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("pool5_"))
+def test_pool5_golden(device, name):
+    g = Golden(name)
+    x = g.inputs["x"].to(device).requires_grad_(True)
+    batch = g.inputs["batch"].to(device)
+    out = layer.GlobalPool5()(x, batch)
+    assert_close(out, g.out, TOL, name)
+    assert_close(_grads(out, g.cot.to(device), [x])[0], g.grads["x"], TOL, name + "/gx")
+    D = x.size(1)
+    assert_close(layer.global_mean_pool(x, batch), g.out[:, :D], TOL, name + "/mean")
+    assert_close(layer.global_add_pool(x, batch), g.out[:, D:2 * D], TOL, name + "/add")
+    assert_close(layer.global_sort_pool(x, batch, 3), g.out[:, 2 * D:], TOL, name + "/sort")
+    mx = layer.global_max_pool(x, batch)
+    assert_close(mx, g.grads["__max"], 0, name + "/max")
+    xo = g.inputs["x"].clone().requires_grad_(True)
+    cot = torch.randn(mx.shape, generator=torch.Generator().manual_seed(1))
+    (gref,) = _grads(O.global_max_pool(xo, g.inputs["batch"], g.meta["B"]), cot, [xo])
+    assert_close(_grads(mx, cot.to(device), [x])[0], gref, 0, name + "/max.gx")
+
+
+@pytest.mark.parametrize("name", golden_names("lapool_"))
+def test_lapool_golden(device, name):
+    g = Golden(name)
+    pool = layer.GlobalLAPool(60).to(device)
+    pool.load_state_dict(g.params)
+    x = g.inputs["x"].to(device).requires_grad_(True)
+    out = pool(x, g.inputs["batch"].to(device))
+    assert_close(out, g.out, TOL, name)
+    names = [n for n, _ in pool.named_parameters()]
+    gs = _grads(out, g.cot.to(device), [x] + [p for _, p in pool.named_parameters()])
+    for n, t in zip(["x"] + names, gs):
+        assert_close(t, g.grads[n], 2e-5, f"{name}/grad.{n}")
+
+
+def test_set2set_golden(device):
+    g = Golden("set2set_esol")
+    s2s = layer.Set2Set(60, processing_steps=3).to(device)
+    s2s.load_state_dict(g.params)
+    x = g.inputs["x"].to(device).requires_grad_(True)
+    out = s2s(x, g.inputs["batch"].to(device))
+    assert_close(out, g.out, TOL, "set2set")
+    names = [n for n, _ in s2s.named_parameters()]
+    gs = _grads(out, g.cot.to(device), [x] + [p for _, p in s2s.named_parameters()])
+    for n, t in zip(["x"] + names, gs):
+        assert_close(t, g.grads[n], 2e-5, f"set2set/grad.{n}")
+
+
+def test_norms_golden(device):
+    g = Golden("norms_edge")
+    x0, b = g.inputs["x"].to(device), g.inputs["batch"].to(device)
+    cot = g.cot.to(device)
+    for nm, fn in [("pair", lambda t: layer._PairNorm(60)(t, b)), ("pair_nobatch", lambda t: layer._PairNorm(60)(t, None)),
+                   ("layer", lambda t: layer._LayerNorm(60).to(device)(t, b)),
+                   ("gsize", lambda t: layer._GraphSizeNorm(60)(t, b))]:
+        x = x0.clone().requires_grad_(True)
+        out = fn(x)
+        assert_close(out, g.grads[f"__out_{nm}"], TOL, nm)
+        assert_close(_grads(out, cot, [x])[0], g.grads[f"__gx_{nm}"], 2e-5, nm + "/gx")
+
+
+# ---------------------------------------------------------------------------------------------
+# MessageBlock / Architecture / train step
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("block_"))
+def test_message_block_golden(device, name):
+    g = Golden(name)
+    m = g.meta
+    blk = layer.MessageBlock(60, 60, 4, norm=m["norm"], dropout="_None()", conv=m["conv"], act=m["act"], res=True)
+    blk.load_state_dict(g.params)
+    blk = blk.to(device).eval()
+    i = _dev(g.inputs, device)
+    x = i["x"].clone().requires_grad_(True)
+    x1, h1 = blk(x, i["edge_index"], i["edge_attr"], h=None, batch=i["batch"])
+    assert_close(x1, g.grads["__x1"], TOL, name + "/x1")
+    x2, h2 = blk(x1, i["edge_index"], i["edge_attr"], h=h1, batch=i["batch"])
+    assert_close(x2, g.out, TOL, name)
+    assert_close(h2.squeeze(0), g.grads["__h"], TOL, name + "/h")
+    names = [n for n, _ in blk.named_parameters()]
+    gs = _grads(x2, g.cot.to(device), [x] + [p for _, p in blk.named_parameters()])
+    for n, t in zip(["x"] + names, gs):
+        assert_close(t, g.grads[n], 3e-5, f"{name}/grad.{n}")
+
+
+@pytest.mark.parametrize("name", golden_names("arch_"))
+def test_architecture_golden(device, name):
+    g = Golden(name)
+    m = g.meta
+    net = model.Architecture(e_dim=m["e_dim"], out_dim=m["out_dim"], message_steps=m["message_steps"],
+                             mol_block=m["mol_block"], mol_readout=m["mol_readout"])
+    net.load_state_dict(g.params)
+    net = net.to(device).eval()
+    i = _dev(g.inputs, device)
+    data = Data(i["x"], i["edge_index"], i["edge_attr"], batch=i["batch"])
+    data.num_graphs = m["B"]
+    out = net(data)
+    assert_close(out, g.out, TOL, name)
+    names = [n for n, _ in net.named_parameters()]
+    gs = _grads(out, g.cot.to(device), [p for _, p in net.named_parameters()])
+    for n, t in zip(names, gs):
+        assert_close(t, g.grads[n], 5e-5, f"{name}/grad.{n}")
+    # three Adam steps exactly as TrainerMolRegression.train_iterations (trainer.py:286-298)
+    net2 = model.Architecture(e_dim=m["e_dim"], out_dim=1, message_steps=m["message_steps"],
+                              mol_block=m["mol_block"], mol_readout=m["mol_readout"])
+    net2.load_state_dict({k: (v if "lin_out1" not in k else v[:1]) for k, v in g.params.items()})
+    net2 = net2.to(device).eval()
+    opt = torch.optim.Adam(net2.parameters(), lr=1e-3)
+    y = i["y"].view(-1)
+    trace = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.MSELoss()(net2(data).view(-1), y)
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad ** 2).sum() for p in net2.parameters()))
+        opt.step()
+        trace.append([loss.item(), gn.item()])
+    ref = g.grads["__train_trace"]
+    assert_close(torch.tensor(trace), ref, 1e-4, name + "/train trace (loss, grad-norm)")
+    assert_close(net2(data), g.grads["__post_out"], 1e-3, name + "/post-step output")
+
+
+def test_dot_and_global_pool_golden(device):
+    g = Golden("dotpool_pairs")
+    i = _dev(g.inputs, device)
+    out2 = layer.dot_and_global_pool2(i["mol_x"], i["pro_x"], i["mol_batch"], i["pro_batch"])
+    assert_close(out2, g.out, TOL, "dot2")
+    out5 = layer.dot_and_global_pool5(i["mol_x"], i["pro_x"], i["mol_batch"], i["pro_batch"])
+    assert_close(out5, g.grads["__out5"], 2e-5, "dot5")
+
+
+# ---------------------------------------------------------------------------------------------
+# fresh seeds against the CPU oracle (sizes the oracle finishes in seconds)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,De,kind", [(60, 4, "mol"), (30, 4, "mol"), (90, 4, "mol"), (60, 8, "protein"), (45, 8, "protein")])
+def test_triplet_vs_oracle_fresh(device, C, De, kind):
+    torch.manual_seed(100 + C + De)
+    b = synth_batch(96, seed=C) if kind == "mol" else synth_protein_batch(3, seed=C, n_min=150, n_max=400)
+    N = b.x.size(0)
+    x0 = torch.randn(N, C)
+    ea0 = b.edge_attr if kind == "mol" else torch.rand(b.edge_index.size(1), De)
+    conv = layer.TripletMessage(C, De)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    ps0 = [p.detach().clone().requires_grad_(True) for p in conv.parameters()]
+    xo = x0.clone().requires_grad_(True)
+    out_ref = O.triplet_message(xo, b.edge_index, ea0, *ps0)
+    cot = torch.randn(out_ref.shape)
+    g_ref = _grads(out_ref, cot, [xo] + ps0)
+    conv = conv.to(device)
+    x = x0.to(device).requires_grad_(True)
+    out = conv(x, b.edge_index.to(device), ea0.to(device))
+    assert_close(out, out_ref, TOL, "out")
+    gs = _grads(out, cot.to(device), [x] + list(conv.parameters()))
+    for n, a, r in zip(["x"] + [n for n, _ in conv.named_parameters()], gs, g_ref):
+        assert_close(a, r, 3e-5, f"grad.{n}")
+
+
+@pytest.mark.parametrize("conv_name", ["_GCNConv", "_GATConv", "_NNConv", "_TripletMessageLight"])
+def test_block_convs_run_and_are_graph_local(device, conv_name):
+    """Every selectable conv (glam.py:63): outputs of graph g do not change when the other graphs
+    of the batch are replaced (no edge crosses graphs)."""
+    torch.manual_seed(5)
+    b1, b2 = synth_batch(4, seed=1), synth_batch(4, seed=2)
+    from glam_amd.data import Batch
+    g0 = synth_batch(1, seed=9)
+    h = torch.randn(g0.x.size(0), 30)
+
+    def run(others):
+        parts = [Data(h, g0.edge_index, g0.edge_attr)]
+        n0 = 0
+        for gidx in range(4):
+            m = others.batch == gidx
+            em = m[others.edge_index[0]]
+            parts.append(Data(torch.randn(int(m.sum()), 30), others.edge_index[:, em] - n0, others.edge_attr[em]))
+            n0 += int(m.sum())
+        bb = Batch.from_data_list(parts).to(device)
+        return blk(bb.x, bb.edge_index, bb.edge_attr, batch=bb.batch)[0][: h.size(0)]
+
+    blk = layer.MessageBlock(30, 30, 4, norm="_None", dropout="_None()", conv=conv_name, act="ReLU", res=True).to(device).eval()
+    a, c = run(b1), run(b2)
+    assert torch.isfinite(a).all()
+    assert_close(a, c, 1e-6, conv_name + " graph locality")
+
+
+# ---------------------------------------------------------------------------------------------
+# properties at the BASELINE.json size (B=1024 ESOL-shaped, C=60, H=3)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big(device):
+    b = synth_batch(1024, seed=0)
+    torch.manual_seed(0)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device)
+    return b.to(device), conv, x
+
+
+def test_full_size_determinism_and_permutation_invariance(big, device):
+    b, conv, x = big
+    x = x.clone().requires_grad_(True)
+    out1 = conv(x, b.edge_index, b.edge_attr)
+    (g1,) = torch.autograd.grad(out1.sum(), [x])
+    x2 = x.detach().clone().requires_grad_(True)
+    out2 = conv(x2, b.edge_index.clone(), b.edge_attr)
+    (g2,) = torch.autograd.grad(out2.sum(), [x2])
+    assert torch.equal(out1, out2) and torch.equal(g1, g2), "CSR segmented reduction must be bit-reproducible"
+    perm = torch.randperm(b.edge_index.size(1), device=device)
+    out3 = conv(x2, b.edge_index[:, perm].contiguous(), b.edge_attr[perm].contiguous())
+    assert_close(out3, out1, TOL, "edge-order permutation invariance")
+
+
+def test_full_size_softmax_partition_of_unity(big, device):
+    """With W_edge rows equal (e_ij constant c) and xw constant 1, aggr = c * sum(alpha) = c for every
+    node with an incoming edge, whatever the logits are."""
+    b, conv, x = big
+    N, E = x.size(0), b.edge_index.size(1)
+    gi = ops.graph_index(b.edge_index, N)
+    xw = torch.ones(N, 180, device=device)
+    a_ij = torch.randn(N, 8, device=device) * 3
+    M = torch.randn(4, 4, device=device)
+    We = torch.full((4, 180), 0.5, device=device)
+    aggr = ops.triplet_aggregate(xw, a_ij, b.edge_attr, We, M, gi, 3, 60)
+    assert_close(aggr, torch.full_like(aggr, 0.5), 1e-6, "sum(alpha) == 1")
+
+
+def test_full_size_linearity_in_xw(big, device):
+    b, conv, x = big
+    N = x.size(0)
+    gi = ops.graph_index(b.edge_index, N)
+    with torch.no_grad():
+        Wn, Wa, We, M, Ws, Cp, Dp = conv._staged_weights()
+        a_ij = x @ Wa
+        u, v = torch.randn(N, 180, device=device), torch.randn(N, 180, device=device)
+        f = lambda t: ops.triplet_aggregate(t, a_ij, b.edge_attr, We, M, gi, 3, 60)
+        assert_close(f(2.0 * u + v), 2.0 * f(u) + f(v), 2e-5, "aggregate is linear in xw for fixed logits")
+
+
+def test_full_size_vs_oracle_sample(big, device):
+    """Whole B=1024 batch through the HIP layer; the oracle recomputes the first 64 graphs (graphs are
+    independent) and must agree on those rows."""
+    b, conv, x = big
+    out = conv(x, b.edge_index, b.edge_attr)
+    n64 = int((b.batch < 64).sum())
+    em = (b.edge_index[0] < n64)
+    ps = [p.detach().cpu() for p in conv.parameters()]
+    ref = O.triplet_message(x[:n64].cpu(), b.edge_index[:, em].cpu(), b.edge_attr[em].cpu(), *ps)
+    assert_close(out[:n64], ref, TOL, "first 64 graphs of the B=1024 batch")
+
+
+def test_full_size_pool5_checksum(big, device):
+    b, conv, x = big
+    out = layer.GlobalPool5()(x, b.batch, 1024)
+    assert_close(out[:, 60:120].sum(0), x.sum(0), 1e-5 * x.size(0) ** 0.5, "sum of per-graph sums == global sum")
+    cnt = torch.bincount(b.batch, minlength=1024).view(-1, 1).float()
+    assert_close(out[:, :60] * cnt, out[:, 60:120], 1e-5, "mean * count == sum")
+    top = out[:, 120:].view(1024, 3, 60)[:, :, -1]
+    assert (top[:, 0] >= top[:, 1]).all() and (top[:, 1] >= top[:, 2]).all(), "sort-pool rows are sorted"
