@@ -164,7 +164,7 @@ def main():
 
     def body():
         out = conv(x, batch.edge_index, batch.edge_attr)
-        grads = torch.autograd.grad((out * cot).sum(), params + [x])
+        grads = torch.autograd.grad(out, params + [x], grad_outputs=cot)   # loss = <out, cot>
         torch.cat([g_.reshape(-1) for g_ in grads], out=flat)
 
     # warm-up on a side stream (stages the CSR + its transpose, which sync once per new batch)

@@ -35,6 +35,18 @@ SIGNATURES = {
     "glam_segment_attn_bwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp, _vp, _vp]),
     "glam_edge_reduce_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "glam_edge_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "glam_ts_gemm_image_bytes": (_sz, [_i32, _i32]),
+    "glam_ts_gemm_make_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "glam_ts_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _vp]),
+    "glam_wgrad_workspace_bytes": (_sz, []),
+    "glam_wgrad_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "glam_triplet_staged_floats": (_sz, [_i32, _i32, _i32]),
+    "glam_triplet_dstaged_floats": (_sz, [_i32, _i32, _i32]),
+    "glam_triplet_stage_params": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
+    "glam_triplet_stage_params_bwd": (_i32, [_vp] * 4 + [_i32] * 5 + [_vp] * 5 + [_vp]),
+    "glam_triplet_layer_fwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
+    "glam_triplet_layer_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
+    "glam_triplet_layer_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
 }
 
 _lib = None

@@ -63,4 +63,7 @@ __device__ __forceinline__ void fma4(float4& acc, float s, float4 a) {
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
+// ts_gemm weight-image column order: position p = cg*64 + t*16 + c holds logical column cg*64 + 4c + t
+__host__ __device__ inline int ts_col_of_pos(int p) { return (p & ~63) + 4 * (p & 15) + ((p >> 4) & 3); }
+
 }  // namespace glam

@@ -1,0 +1,49 @@
+// Internal interfaces between gemm.hip (dense MFMA kernels), triplet.hip (aggregate kernels) and
+// layer.hip (whole-layer sequencing).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+namespace glam {
+
+struct TsArgs {
+    const float* A1; int K1; int lda1;
+    const float* A2; int K2; int lda2;
+    const float* Wimg;                     // LDS image of W (see k_ts_make_image)
+    const float* bias;                     // added to out1 columns, may be null
+    float* out1; int M1; int ldo1;         // columns [0, M1)   (M1 % 4 == 0)
+    float* out2; int M2; int ldo2;         // columns [M1, M1+M2), may be null
+    int N;
+};
+
+struct WgArgs {
+    const float* P1; int I1; int ldp1;
+    const float* P2; int I2; int ldp2;
+    int ones;                              // 1: virtual all-ones column at index I1+I2 (bias gradient)
+    const float* Q; int J; int ldq;        // J % 4 == 0, J <= 64
+    int N; int rows_per_wave;              // multiple of 4
+    float* partial;                        // [ntile_i][nsplit][16 regs][64 lanes]
+    int nsplit;
+};
+
+// see k_final_reduce in gemm.hip
+struct ReduceJob {
+    int kind; const float* partial; int nsplit; int n; int I, J, si, sj; float* out; float* out2; int split_at;
+    int first_block;
+};
+struct ReduceArgs { ReduceJob job[3]; int njobs; };
+
+size_t ts_image_floats(int K, int M);
+int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, float* img, hipStream_t s);
+int launch_ts_gemm(const TsArgs& a, hipStream_t s);
+size_t wgrad_workspace_floats();
+int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job);
+int launch_final_reduce(ReduceArgs ra, hipStream_t s);
+
+int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
+                     const float* aggr, const float* stats, const float* d_aggr, const int32_t* rowptr,
+                     const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
+                     const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
+                     float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
+                     size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out);
+
+}  // namespace glam

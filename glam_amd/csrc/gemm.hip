@@ -1,0 +1,361 @@
+// Dense ends of the TripletMessage layer on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact
+// fp32, bit-equal to an fmaf chain, so the 1e-5 parity bar is untouched).
+//
+// The layer's linears (reference: src_1gp/layer.py:37 `x @ weight_node`, :58-60 `aggr @ weight_scale
+// + bias`, and what autograd derives for them) are all "tall-skinny": N rows (atoms, 2e4..3e5) against
+// weights of at most 192 x 64 / 64 x 192.  Library GEMMs pick tiles for square problems and ran 12-73 us
+// per call here (profiles/r1a_*); two purpose-built kernels replace them:
+//
+//   k_ts_gemm   C[N, M] = [A1 | A2][N, K] @ W[K, M] (+ bias); (K <= 64, M <= 192) or (K <= 192, M <= 64).
+//               W (zero padded, pre-permuted "image") lives in LDS for the whole 8-wave block; a wave owns
+//               16 rows and ALL M columns (MT accumulator tiles, <= 48 AGPRs); its whole A fragment is
+//               loaded up front (one float4 per 16 k-values: lane (r, kq) supplies k = 16g + 4kq + j at
+//               MFMA step j) and the B operands of a 16-k group are one ds_read_b128 per tile.  Two waves
+//               per SIMD overlap one wave's loads / stores with the other's MFMAs.
+//   k_wgrad     G[I, J] = [P1 | P2 | 1]^T[I, N] @ Q[N, J], I <= 192, J <= 64, reduction over rows.
+//               Block = (16-column slab of P, row split); its 4 waves take disjoint row ranges and are
+//               summed through LDS; block partials (4 KB) are combined in a fixed order by k_final_reduce
+//               (deterministic, no atomics), which also folds the aggregate kernel's d_W_edge partials.
+#include "dense.h"
+
+namespace glam {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kTsBlock = 512;   // 8 waves: 2 per SIMD
+
+// Image layout: img[k / 4][p][k % 4] (Kp/4 x MP x 4 floats, zero padded): the B operands a lane needs for the
+// 4 MFMA steps of one 16-k group are ONE 16-byte LDS read (ds_read_b128, conflict free: 16 lanes x 16 B
+// cover all 64 banks and MP*4 words == 0 mod 64 keeps the two k-halves of a read group on disjoint banks).
+// Column order: position p = cg*64 + t*16 + c holds logical column m = cg*64 + 4c + t (ts_col_of_pos), so
+// lane c of a wave owns 4 CONSECUTIVE output columns across the 4 tiles of a 64-column group and the
+// epilogue stores float4 (256 contiguous bytes per 16 lanes).
+// logical W[k][m] = transW ? W[m*ldw + k] : W[k*ldw + m]
+__global__ void __launch_bounds__(kBlock) k_ts_make_image(const float* W, int ldw, int transW, int K, int M, int MT,
+                                                         float* img) {
+    const int MP = MT * 16, Kp = (K + 15) & ~15;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < Kp * MP; idx += gridDim.x * kBlock) {
+        const int j = idx & 3, p = (idx >> 2) % MP, k = (idx >> 2) / MP * 4 + j;
+        const int m = ts_col_of_pos(p);
+        float v = 0.f;
+        if (k < K && m < M) v = transW ? W[(size_t)m * ldw + k] : W[(size_t)k * ldw + m];
+        img[idx] = v;
+    }
+}
+
+template <int MT, int GMAX>
+__global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    constexpr int MP = MT * 16;        // padded column count
+    constexpr int kMaxStage = 16 * GMAX * MP / 4 / kTsBlock;   // float4 per thread for the largest image
+    static_assert(kMaxStage * kTsBlock * 4 == 16 * GMAX * MP, "image must tile the block");
+    const int tid = threadIdx.x;
+    const int K = a.K1 + a.K2, G = (K + 15) >> 4, M = a.M1 + a.M2;
+    const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+    const int ntiles = (a.N + 15) >> 4;
+    constexpr int WPB = kTsBlock / 64;
+
+    // A fragment of a tile: one float4 per 16-k group, every load in flight at once
+    auto load_afrag = [&](int tile, float4 (&af)[GMAX]) {
+        const int row = tile * 16 + c;
+        const bool rok = tile < ntiles && row < a.N;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            const int k0 = 16 * g + 4 * kq;
+            af[g] = f4zero();
+            if (rok) {
+                if (k0 < a.K1) af[g] = ld4(a.A1 + (size_t)row * a.lda1 + k0);
+                else if (k0 < K) af[g] = ld4(a.A2 + (size_t)row * a.lda2 + (k0 - a.K1));
+            }
+        }
+    };
+    int tile = blockIdx.x * WPB + wave;
+    float4 af[GMAX];
+    load_afrag(tile, af);              // flies while the weight image is staged
+
+    // ---- stage the W image into LDS: all loads in flight first, then the LDS stores ----
+    {
+        const int n4 = G * 4 * MP;     // float4 count
+        float4 buf[kMaxStage];
+#pragma unroll
+        for (int i = 0; i < kMaxStage; ++i) {
+            const int idx = tid + i * kTsBlock;
+            if (idx < n4) buf[i] = ld4(a.Wimg + 4 * idx);
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxStage; ++i) {
+            const int idx = tid + i * kTsBlock;
+            if (idx < n4) st4(s_w + 4 * idx, buf[i]);
+        }
+    }
+    __syncthreads();
+
+    const float* wlane = s_w + (kq * MP + c) * 4;
+    for (; tile < ntiles; tile += gridDim.x * WPB) {
+        v4f acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < G) {
+                float4 bv[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) bv[t] = ld4(wlane + g * 16 * MP + t * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float aj = f4get(af[g], j);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, f4get(bv[t], j), acc[t], 0, 0, 0);
+                }
+            }
+        }
+        const int cur = tile;
+        load_afrag(tile + gridDim.x * WPB, af);   // next tile's A fragment flies under the epilogue
+        // C layout: tile column = lane & 15 (-> logical columns cg*64 + 4c + t), row = (lane >> 4) * 4 + i
+#pragma unroll
+        for (int cg = 0; cg < MT / 4; ++cg) {
+            const int m0 = cg * 64 + 4 * c;
+            if (m0 >= M) continue;
+            float4 b = f4zero();
+            if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = cur * 16 + kq * 4 + i;
+                if (rr >= a.N) continue;
+                const float4 v = make_float4(acc[cg * 4 + 0][i] + b.x, acc[cg * 4 + 1][i] + b.y,
+                                             acc[cg * 4 + 2][i] + b.z, acc[cg * 4 + 3][i] + b.w);
+                if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G[I, J] = [P1 | P2 | 1]^T @ Q.  A wave owns a 16 x 64 output slab (4 accumulator tiles) over its own row
+// range: per 4-row step one scalar load feeds the A operand (P[n][i0 + c]) and ONE float4 load the B
+// operands of the 4 column tiles (stride-4 column permutation: tile tj holds columns 4c + tj).
+constexpr int kWgBlock = 1024;        // 16 waves (4 per SIMD): row ranges interleave, loads hide behind MFMAs
+constexpr int kWgWaves = kWgBlock / 64;
+
+__global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
+    __shared__ float s_red[(kWgWaves - 1) * 1024];     // waves 1..15: [16 regs][64 lanes]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+    const int ntile = gridDim.x / a.nsplit;
+    const int itile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+    const int row0 = (split * kWgWaves + wave) * a.rows_per_wave;
+    const int row1 = min(row0 + a.rows_per_wave, a.N);
+    const int pcol = itile * 16 + c, qcol = 4 * c;
+    const int I12 = a.I1 + a.I2;
+    // resolve the P source of this lane's column once
+    const float* pbase = nullptr;
+    int pld = 0;
+    float pconst = 0.f;
+    if (pcol < a.I1) { pbase = a.P1 + pcol; pld = a.ldp1; }
+    else if (pcol < I12) { pbase = a.P2 + (pcol - a.I1); pld = a.ldp2; }
+    else if (a.ones && pcol == I12) pconst = 1.f;
+    const bool qok = qcol < a.J;
+
+    v4f acc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[tj] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int kSteps = 8;             // 32 rows per batch: 16 loads in flight, then 32 MFMAs
+    for (int n0 = row0; n0 < row1; n0 += 4 * kSteps) {
+        float pv[kSteps];
+        float4 qv[kSteps];
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) {
+            const int n = n0 + 4 * st + kq;
+            const bool nok = n < row1;
+            pv[st] = nok ? (pbase ? pbase[(size_t)n * pld] : pconst) : 0.f;
+            qv[st] = (nok && qok) ? ld4(a.Q + (size_t)n * a.ldq + qcol) : f4zero();
+        }
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[st], f4get(qv[st], tj), acc[tj], 0, 0, 0);
+    }
+    // ---- sum the 16 waves lane-for-lane (identical register layouts) in wave order ----
+    if (wave > 0) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[(wave - 1) * 1024 + (tj * 4 + r) * 64 + lane] = acc[tj][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + ((size_t)itile * a.nsplit + split) * 1024;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (tj * 4 + r) * 64 + lane;
+                float sum = acc[tj][r];
+#pragma unroll
+                for (int w = 1; w < kWgWaves; ++w) sum += s_red[(w - 1) * 1024 + o];
+                out[o] = sum;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final fixed-order reduction of up to 3 partial sets in ONE launch.
+//   kind 0 (k_wgrad partials): element offset `o` in [0, ntile*1024) decodes to reg = (o%1024)/64, lane = o%64,
+//          tj = reg/4, r = reg%4, kq = lane/16, c = lane%16  ->  i = 16*tile + 4*kq + r, j = 4*c + tj;
+//          out[i*si + j*sj] = sum_s partial[(tile*nsplit + s)*1024 + o%1024]
+//   kind 1 (flat block partials [nsplit][n]): out[e] (e < split_at) or out2[e - split_at] = sum_s partial[s*n + e]
+__global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
+    __shared__ float s_part[16][17];
+    int jb = 0;
+#pragma unroll
+    for (int q = 1; q < 3; ++q)
+        if (q < ra.njobs && (int)blockIdx.x >= ra.job[q].first_block) jb = q;
+    const ReduceJob& J = ra.job[jb];
+    const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;       // 16 elements x 16 split lanes
+    const int e = ((int)blockIdx.x - J.first_block) * 16 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < J.n) {
+        const float* p;
+        size_t stride;
+        if (J.kind == 0) { p = J.partial + (size_t)(e >> 10) * J.nsplit * 1024 + (e & 1023); stride = 1024; }
+        else { p = J.partial + e; stride = (size_t)J.n; }
+        int s = rl;
+        for (; s + 16 < J.nsplit; s += 32) { s0 += p[(size_t)s * stride]; s1 += p[(size_t)(s + 16) * stride]; }
+        for (; s < J.nsplit; s += 16) s0 += p[(size_t)s * stride];
+    }
+    s_part[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && e < J.n) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += s_part[r][c];
+        if (J.kind == 0) {
+            const int o = e & 1023, reg = o >> 6, lane = o & 63;
+            const int i = (e >> 10) * 16 + (lane >> 4) * 4 + (reg & 3), j = 4 * (lane & 15) + (reg >> 2);
+            if (i < J.I && j < J.J) J.out[(size_t)i * J.si + (size_t)j * J.sj] = s;
+        } else if (e < J.split_at) {
+            if (J.out) J.out[e] = s;
+        } else {
+            J.out2[e - J.split_at] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (shared with layer.hip)
+// ------------------------------------------------------------------------------------------------
+size_t ts_image_floats(int K, int M) {
+    const int Kp = (K + 15) & ~15;
+    return (size_t)Kp * (M <= 64 ? 64 : 192);
+}
+
+static int ts_shape_ok(const char* fn, int K, int M) {
+    if (M <= 0 || K <= 0 || M > 192 || K > 192 || (M > 64 && K > 64))
+        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d (K <= 192 needs M <= 64; M <= 192 needs K <= 64)", fn, K, M);
+    return GLAM_OK;
+}
+
+int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, float* img, hipStream_t s) {
+    if (int rc = ts_shape_ok("ts_gemm image", K, M)) return rc;
+    const int MT = M <= 64 ? 4 : 12;
+    hipLaunchKernelGGL(k_ts_make_image, dim3(grid_for((int64_t)ts_image_floats(K, M), kBlock)), dim3(kBlock), 0, s, W, ldw,
+                       transW, K, M, MT, img);
+    GLAM_LAUNCH_CHECK("ts_make_image");
+    return GLAM_OK;
+}
+
+int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
+    const int M = a.M1 + a.M2, K = a.K1 + a.K2;
+    if (a.N <= 0) return GLAM_OK;
+    if (int rc = ts_shape_ok("ts_gemm", K, M)) return rc;
+    if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3)) || (a.M1 & 3) || (a.M2 & 3) || (a.ldo1 & 3) ||
+        (a.M2 && (a.ldo2 & 3)))
+        return fail(GLAM_E_UNSUPPORTED, "ts_gemm: K=%d+%d M=%d+%d and leading dimensions must be multiples of 4", a.K1, a.K2, a.M1, a.M2);
+    const size_t lds = ts_image_floats(K, M) * sizeof(float);
+    const int ntiles = (a.N + 15) / 16;
+    int grid = (ntiles + 7) / 8;
+    if (grid > 256) grid = 256;          // one 8-wave block per CU, grid-stride over row tiles
+    if (M <= 64) hipLaunchKernelGGL((k_ts_gemm<4, 12>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    else hipLaunchKernelGGL((k_ts_gemm<12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    GLAM_LAUNCH_CHECK("ts_gemm");
+    return GLAM_OK;
+}
+
+constexpr int kWgradBlocks = 256;   // one 4-wave block per CU
+
+size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocks + 12) * 1024; }
+
+// fills the launch geometry of a k_wgrad call and the matching reduce job; launches k_wgrad
+int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
+    const int I = a.I1 + a.I2 + (a.ones ? 1 : 0);
+    if (I > 192 || a.J > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3))
+        return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d J=%d outside the kernel table (I <= 192, J <= 64, J %% 4 == 0)", I, a.J);
+    const int ntile = (I + 15) / 16;
+    int nsplit = kWgradBlocks / ntile;
+    // keep at least 32 rows per wave when the problem is small
+    const int max_split = (int)(((int64_t)a.N + 32 * kWgWaves - 1) / (32 * kWgWaves));
+    if (nsplit > max_split) nsplit = max_split < 1 ? 1 : max_split;
+    int rpw = (int)(((int64_t)a.N + nsplit * kWgWaves - 1) / (nsplit * kWgWaves));
+    rpw = (rpw + 3) & ~3;
+    if (rpw < 4) rpw = 4;
+    a.rows_per_wave = rpw;
+    a.nsplit = nsplit;
+    hipLaunchKernelGGL(k_wgrad, dim3(ntile * nsplit), dim3(kWgBlock), 0, s, a);
+    GLAM_LAUNCH_CHECK("wgrad");
+    *job = ReduceJob{0, a.partial, nsplit, ntile * 1024, I, a.J, si, sj, out, nullptr, 0, 0};
+    return GLAM_OK;
+}
+
+int launch_final_reduce(ReduceArgs ra, hipStream_t s) {
+    int blocks = 0;
+    for (int q = 0; q < ra.njobs; ++q) {
+        ra.job[q].first_block = blocks;
+        blocks += (ra.job[q].n + 15) / 16;
+    }
+    if (blocks == 0) return GLAM_OK;
+    hipLaunchKernelGGL(k_final_reduce, dim3(blocks), dim3(kBlock), 0, s, ra);
+    GLAM_LAUNCH_CHECK("final_reduce");
+    return GLAM_OK;
+}
+
+}  // namespace glam
+
+using namespace glam;
+
+extern "C" size_t glam_ts_gemm_image_bytes(int K, int M) { return ts_image_floats(K, M) * sizeof(float); }
+
+extern "C" int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, float* img, void* stream) {
+    GLAM_REQUIRE(W && img && aligned16(img), "glam_ts_gemm_make_image: null / misaligned pointer");
+    return launch_ts_make_image(W, ldw, transW, K, M, img, (hipStream_t)stream);
+}
+
+extern "C" int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
+                            const float* bias, float* out1, int M1, int ldo1, float* out2, int M2, int ldo2, int64_t N,
+                            void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_ts_gemm: N out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(A1 && Wimg && out1 && (K2 == 0 || A2) && (M2 == 0 || out2), "glam_ts_gemm: null pointer");
+    GLAM_REQUIRE(aligned16(A1) && aligned16(A2) && aligned16(Wimg) && aligned16(out1) && aligned16(out2) && aligned16(bias),
+                 "glam_ts_gemm: pointers must be 16-byte aligned");
+    TsArgs a{A1, K1, lda1, A2, K2, lda2, Wimg, bias, out1, M1, ldo1, out2, M2, ldo2, (int)N};
+    return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" size_t glam_wgrad_workspace_bytes(void) { return wgrad_workspace_floats() * sizeof(float) + 256; }
+
+extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
+                               const float* Q, int J, int ldq, int64_t N, float* out, int stride_i, int stride_j,
+                               void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm: N out of range");
+    GLAM_REQUIRE(P1 && Q && out && ws && (I2 == 0 || P2), "glam_wgrad_gemm: null pointer");
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm: workspace too small");
+    GLAM_REQUIRE(aligned16(Q), "glam_wgrad_gemm: Q must be 16-byte aligned");
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, (int)N, 0, partial, 0};
+    ReduceArgs ra{};
+    ra.njobs = 1;
+    if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, (hipStream_t)stream, &ra.job[0])) return rc;
+    return launch_final_reduce(ra, (hipStream_t)stream);
+}

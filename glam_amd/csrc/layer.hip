@@ -1,0 +1,305 @@
+// Whole TripletMessage layer (reference: src_1gp/layer.py:15-64) as a fixed sequence of launches on one
+// stream, plus the parameter staging kernels.  No host synchronisation, no allocation: hipGraph safe.
+//
+//   forward : k_stage_params -> k_ts_gemm (x @ [W_node | Wa_i | Wa_j] -> xw, a_ij)
+//             -> k_triplet_fwd (gather / softmax / scatter-add -> aggr) -> k_ts_gemm (aggr @ W_scale + bias)
+//   backward: k_ts_gemm (d_aggr = d_out @ W_scale^T) ; k_wgrad ([aggr|1]^T d_out -> d_W_scale, d_bias)
+//             -> k_triplet_bwd_dst / reduce / k_triplet_bwd_src -> k_ts_gemm (d_x = [d_xw|d_a] @ Wcat^T)
+//             ; k_wgrad ([d_xw|d_a]^T x -> d_Wcat) -> k_stage_params_bwd
+//
+// Separable attention: a_i = x @ Wa_i, a_j = x @ Wa_j with
+// Wa_i[k,h] = sum_c W_node[k,h,c] att[h,c], Wa_j[k,h] = sum_c W_node[k,h,c] att[h,2C+c], and
+// M[k,h] = sum_c W_edge[k,h,c] att[h,C+c]; they ride along as 8 extra columns of the node GEMM.
+// All node-feature widths are padded to Cp (multiple of 4) so every row is 16-byte aligned.
+#include "dense.h"
+
+namespace glam {
+
+// layout of the staged-parameter buffer (floats; every offset is a multiple of 4)
+struct Staged {
+    size_t img_node, img_upd, img_dagg, img_dx, we_p, m, bias_p, total;
+};
+static Staged staged_layout(int H, int Cp, int Dp) {
+    const int HC = H * Cp;
+    Staged s;
+    size_t o = 0;
+    s.img_node = o; o += ts_image_floats(Cp, HC + 8);     // x[N,Cp]       @ Wcat[Cp, HC+8]
+    s.img_upd = o;  o += ts_image_floats(HC, Cp);         // aggr[N,HC]    @ Ws_p[HC, Cp]
+    s.img_dagg = o; o += ts_image_floats(Cp, HC);         // d_out[N,Cp]   @ Ws_p^T
+    s.img_dx = o;   o += ts_image_floats(HC + 8, Cp);     // [d_xw|d_a]    @ Wcat^T
+    s.we_p = o;     o += (size_t)Dp * HC;
+    s.m = o;        o += (size_t)Dp * 4;
+    s.bias_p = o;   o += (size_t)Cp;
+    s.total = o;
+    return s;
+}
+// gradient buffer: d_Wcat[Cp, HC+8] | d_WsB[HC+1, Cp] (last row = d_bias) | d_We_p[Dp, HC] | d_M[Dp, 4]
+struct DStaged {
+    size_t d_wcat, d_wsb, d_we_p, d_m, total;
+};
+static DStaged dstaged_layout(int H, int Cp, int Dp) {
+    const int HC = H * Cp;
+    DStaged s;
+    size_t o = 0;
+    s.d_wcat = o; o += (size_t)Cp * (HC + 8);
+    s.d_wsb = o;  o += (size_t)(HC + 1) * Cp; o = (o + 3) & ~(size_t)3;
+    s.d_we_p = o; o += (size_t)Dp * HC;
+    s.d_m = o;    o += (size_t)Dp * 4;
+    s.total = o;
+    return s;
+}
+
+__device__ __forceinline__ float dot_strided(const float* a, const float* b, int n) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        s0 = fmaf(a[i], b[i], s0); s1 = fmaf(a[i + 1], b[i + 1], s1);
+        s2 = fmaf(a[i + 2], b[i + 2], s2); s3 = fmaf(a[i + 3], b[i + 3], s3);
+    }
+    for (; i < n; ++i) s0 = fmaf(a[i], b[i], s0);
+    return (s0 + s1) + (s2 + s3);
+}
+
+struct StageArgs {
+    const float* wn; const float* we; const float* att; const float* wsc; const float* bias;
+    int C, H, De, Cp, Dp;
+    float* base; Staged L;
+};
+
+// logical Wcat[k][m], k < Cp, m < H*Cp + 8
+__device__ __forceinline__ float wcat_val(const StageArgs& a, int k, int m) {
+    const int C = a.C, H = a.H, Cp = a.Cp;
+    if (k >= C) return 0.f;
+    if (m < H * Cp) {
+        const int h = m / Cp, c = m % Cp;
+        return c < C ? a.wn[(size_t)k * H * C + h * C + c] : 0.f;
+    }
+    const int s = m - H * Cp, h = s & 3, side = s >> 2;   // side 0: att[:, 0:C] (target), 1: att[:, 2C:3C] (source)
+    if (h >= H) return 0.f;
+    return dot_strided(a.wn + (size_t)k * H * C + h * C, a.att + (size_t)h * 3 * C + (side ? 2 * C : 0), C);
+}
+// logical Ws_p[k][m], k < H*Cp, m < Cp
+__device__ __forceinline__ float wsp_val(const StageArgs& a, int k, int m) {
+    const int h = k / a.Cp, c = k % a.Cp;
+    return (c < a.C && m < a.C) ? a.wsc[(size_t)(h * a.C + c) * a.C + m] : 0.f;
+}
+
+__global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a) {
+    const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, Dp = a.Dp, HC = H * Cp;
+    const int Kp1 = (Cp + 15) & ~15, Kp2 = (HC + 15) & ~15, Kp4 = (HC + 8 + 15) & ~15;
+    const int P1 = HC + 8 <= 64 ? 64 : 192, P3 = HC <= 64 ? 64 : 192;   // image column count 16*MT
+    const int n1 = Kp1 * P1, n2 = Kp2 * 64, n3 = Kp1 * P3, n4 = Kp4 * 64, n5 = Dp * HC, n6 = Dp * 4, n7 = Cp;
+    const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7;
+    // image element idx -> (k, logical column m): layout [k/4][p][k%4], column order ts_col_of_pos
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+        int i = idx;
+        if (i < n1) {            // node image: K = Cp, M = HC + 8
+            const int k = (i >> 2) / P1 * 4 + (i & 3), m = ts_col_of_pos((i >> 2) % P1);
+            a.base[a.L.img_node + i] = (k < Cp && m < HC + 8) ? wcat_val(a, k, m) : 0.f;
+            continue;
+        }
+        i -= n1;
+        if (i < n2) {            // update image: K = HC, M = Cp
+            const int k = (i >> 2) / 64 * 4 + (i & 3), m = ts_col_of_pos((i >> 2) % 64);
+            a.base[a.L.img_upd + i] = (k < HC && m < Cp) ? wsp_val(a, k, m) : 0.f;
+            continue;
+        }
+        i -= n2;
+        if (i < n3) {            // d_aggr image: K = Cp, M = HC, logical W[k][m] = Ws_p[m][k]
+            const int k = (i >> 2) / P3 * 4 + (i & 3), m = ts_col_of_pos((i >> 2) % P3);
+            a.base[a.L.img_dagg + i] = (k < Cp && m < HC) ? wsp_val(a, m, k) : 0.f;
+            continue;
+        }
+        i -= n3;
+        if (i < n4) {            // d_x image: K = HC + 8, M = Cp, logical W[k][m] = Wcat[m][k]
+            const int k = (i >> 2) / 64 * 4 + (i & 3), m = ts_col_of_pos((i >> 2) % 64);
+            a.base[a.L.img_dx + i] = (k < HC + 8 && m < Cp) ? wcat_val(a, m, k) : 0.f;
+            continue;
+        }
+        i -= n4;
+        if (i < n5) {
+            const int k = i / HC, m = i % HC, h = m / Cp, c = m % Cp;
+            a.base[a.L.we_p + i] = (k < De && c < C) ? a.we[(size_t)k * H * C + h * C + c] : 0.f;
+            continue;
+        }
+        i -= n5;
+        if (i < n6) {
+            const int k = i >> 2, h = i & 3;
+            a.base[a.L.m + i] = (k < De && h < H) ? dot_strided(a.we + (size_t)k * H * C + h * C, a.att + (size_t)h * 3 * C + C, C) : 0.f;
+            continue;
+        }
+        i -= n6;
+        a.base[a.L.bias_p + i] = i < C ? a.bias[i] : 0.f;
+    }
+}
+
+// chain rule of k_stage_params
+__global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, const float* we, const float* att,
+                                                            const float* d_Wcat, const float* d_WsB,
+                                                            const float* d_We_p, const float* d_M, int C, int H,
+                                                            int De, int Cp, int Dp, float* d_wn, float* d_we,
+                                                            float* d_att, float* d_wsc, float* d_bias) {
+    const int MC = H * Cp + 8;
+    const int n_wn = C * H * C, n_we = De * H * C, n_att = H * 3 * C, n_ws = H * C * C, n_b = C;
+    const int total = n_wn + n_we + n_att + n_ws + n_b;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+        if (idx < n_wn) {
+            const int k = idx / (H * C), m = idx % (H * C), h = m / C, c = m % C;
+            const float* dr = d_Wcat + (size_t)k * MC;
+            float v = dr[h * Cp + c];
+            v = fmaf(dr[H * Cp + h], att[(size_t)h * 3 * C + c], v);
+            v = fmaf(dr[H * Cp + 4 + h], att[(size_t)h * 3 * C + 2 * C + c], v);
+            d_wn[idx] = v;
+        } else if (idx < n_wn + n_we) {
+            const int i = idx - n_wn, k = i / (H * C), m = i % (H * C), h = m / C, c = m % C;
+            d_we[i] = fmaf(d_M[k * 4 + h], att[(size_t)h * 3 * C + C + c], d_We_p[(size_t)k * H * Cp + h * Cp + c]);
+        } else if (idx < n_wn + n_we + n_att) {
+            const int i = idx - n_wn - n_we, h = i / (3 * C), t = i % (3 * C), part = t / C, c = t % C;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (part == 1) {
+                for (int k = 0; k < De; ++k) s0 = fmaf(d_M[k * 4 + h], we[(size_t)k * H * C + h * C + c], s0);
+            } else {
+                const float* dcol = d_Wcat + H * Cp + (part == 0 ? 0 : 4) + h;
+                const float* wcol = wn + h * C + c;
+                int k = 0;
+                for (; k + 4 <= C; k += 4) {
+                    s0 = fmaf(dcol[(size_t)(k + 0) * MC], wcol[(size_t)(k + 0) * H * C], s0);
+                    s1 = fmaf(dcol[(size_t)(k + 1) * MC], wcol[(size_t)(k + 1) * H * C], s1);
+                    s2 = fmaf(dcol[(size_t)(k + 2) * MC], wcol[(size_t)(k + 2) * H * C], s2);
+                    s3 = fmaf(dcol[(size_t)(k + 3) * MC], wcol[(size_t)(k + 3) * H * C], s3);
+                }
+                for (; k < C; ++k) s0 = fmaf(dcol[(size_t)k * MC], wcol[(size_t)k * H * C], s0);
+            }
+            d_att[i] = (s0 + s1) + (s2 + s3);
+        } else if (idx < n_wn + n_we + n_att + n_ws) {
+            const int i = idx - n_wn - n_we - n_att, row = i / C, col = i % C, h = row / C, c = row % C;
+            d_wsc[i] = d_WsB[(size_t)(h * Cp + c) * Cp + col];
+        } else {
+            const int i = idx - n_wn - n_we - n_att - n_ws;
+            d_bias[i] = d_WsB[(size_t)H * Cp * Cp + i];
+        }
+    }
+}
+
+}  // namespace glam
+
+using namespace glam;
+
+static int dims_ok(const char* fn, int C, int H, int De, int Cp, int Dp) {
+    if (C <= 0 || H < 1 || H > 4 || De <= 0 || Cp < C || (Cp & 3))
+        return fail(GLAM_E_INVALID, "%s: bad dims C=%d H=%d De=%d Cp=%d", fn, C, H, De, Cp);
+    if ((Dp != 4 && Dp != 8) || De > Dp) return fail(GLAM_E_UNSUPPORTED, "%s: De=%d Dp=%d", fn, De, Dp);
+    if (H * Cp + 8 > 192 || Cp > 64)
+        return fail(GLAM_E_UNSUPPORTED, "%s: H*Cp+8=%d (max 192) / Cp=%d (max 64) outside the dense-kernel table", fn, H * Cp + 8, Cp);
+    return GLAM_OK;
+}
+
+extern "C" size_t glam_triplet_staged_floats(int H, int Cp, int Dp) { return staged_layout(H, Cp, Dp).total; }
+extern "C" size_t glam_triplet_dstaged_floats(int H, int Cp, int Dp) { return dstaged_layout(H, Cp, Dp).total; }
+
+extern "C" int glam_triplet_stage_params(const float* weight_node, const float* weight_edge, const float* att,
+                                         const float* weight_scale, const float* bias, int C, int H, int De, int Cp,
+                                         int Dp, float* staged, void* stream) {
+    if (int rc = dims_ok("glam_triplet_stage_params", C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && weight_scale && bias && staged && aligned16(staged),
+                 "glam_triplet_stage_params: null / misaligned pointer");
+    StageArgs a{weight_node, weight_edge, att, weight_scale, bias, C, H, De, Cp, Dp, staged, staged_layout(H, Cp, Dp)};
+    hipLaunchKernelGGL(k_stage_params, dim3(grid_for((int64_t)a.L.total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    GLAM_LAUNCH_CHECK("glam_triplet_stage_params");
+    return GLAM_OK;
+}
+
+extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const float* weight_edge, const float* att,
+                                             const float* dstaged, int C, int H, int De, int Cp, int Dp,
+                                             float* d_weight_node, float* d_weight_edge, float* d_att,
+                                             float* d_weight_scale, float* d_bias, void* stream) {
+    if (int rc = dims_ok("glam_triplet_stage_params_bwd", C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && dstaged && d_weight_node && d_weight_edge && d_att && d_weight_scale &&
+                     d_bias, "glam_triplet_stage_params_bwd: null pointer");
+    const DStaged L = dstaged_layout(H, Cp, Dp);
+    const int total = C * H * C + De * H * C + H * 3 * C + H * C * C + C;
+    hipLaunchKernelGGL(k_stage_params_bwd, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       weight_node, weight_edge, att, dstaged + L.d_wcat, dstaged + L.d_wsb, dstaged + L.d_we_p,
+                       dstaged + L.d_m, C, H, De, Cp, Dp, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias);
+    GLAM_LAUNCH_CHECK("glam_triplet_stage_params_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                                      const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp,
+                                      int Dp, float slope, float* xw, float* a_ij, float* aggr, float* stats,
+                                      float* out, void* stream) {
+    if (int rc = dims_ok("glam_triplet_layer_fwd", Cp, H, Dp, Cp, Dp)) return rc;
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd: N out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && out, "glam_triplet_layer_fwd: null pointer");
+    GLAM_REQUIRE(aligned16(x) && aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(out) && aligned16(staged),
+                 "glam_triplet_layer_fwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int HC = H * Cp;
+    const Staged L = staged_layout(H, Cp, Dp);
+    TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
+    if (int rc = launch_ts_gemm(g1, s)) return rc;
+    if (int rc = glam_triplet_fwd(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp, Dp, 1,
+                                  slope, aggr, stats, stream))
+        return rc;
+    TsArgs g2{aggr, HC, HC, nullptr, 0, 0, staged + L.img_upd, staged + L.bias_p, out, Cp, Cp, nullptr, 0, 0, (int)N};
+    return launch_ts_gemm(g2, s);
+}
+
+extern "C" size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp) {
+    const size_t HC = (size_t)H * Cp;
+    return (2 * (size_t)N * HC + (size_t)N * 8 + 2 * wgrad_workspace_floats()) * sizeof(float) +
+           glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp) + 1024;
+}
+
+extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                      const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                      int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
+                                      float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = dims_ok("glam_triplet_layer_bwd", Cp, H, Dp, Cp, Dp)) return rc;
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_bwd: N out of range");
+    GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && d_out && d_x && dstaged && ws, "glam_triplet_layer_bwd: null pointer");
+    GLAM_REQUIRE(ws_bytes >= glam_triplet_layer_bwd_workspace_bytes(N, E, H, Cp, Dp), "glam_triplet_layer_bwd: workspace too small");
+    GLAM_REQUIRE(aligned16(x) && aligned16(d_out) && aligned16(aggr) && aligned16(d_x) && aligned16(staged) && aligned16(dstaged),
+                 "glam_triplet_layer_bwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int HC = H * Cp;
+    const Staged L = staged_layout(H, Cp, Dp);
+    const DStaged G = dstaged_layout(H, Cp, Dp);
+    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
+    float* d_aggr = reinterpret_cast<float*>(base);
+    float* d_xw = d_aggr + (size_t)N * HC;
+    float* d_a = d_xw + (size_t)N * HC;
+    float* wg1 = d_a + (size_t)N * 8;
+    float* wg2 = wg1 + wgrad_workspace_floats();
+    void* tws = wg2 + wgrad_workspace_floats();
+    const size_t tws_bytes = ws_bytes - (reinterpret_cast<uintptr_t>(tws) - reinterpret_cast<uintptr_t>(ws));
+    ReduceArgs ra{};
+    ra.njobs = 3;
+
+    // d_aggr = d_out @ Ws_p^T
+    TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
+    if (int rc = launch_ts_gemm(g1, s)) return rc;
+    // d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out   (last row = d_bias); block partials, reduced at the end
+    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, (int)N, 0, wg1, 0};
+    if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, s, &ra.job[0])) return rc;
+    const float* tpart = nullptr;
+    int tnblk = 0;
+    if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
+                                  colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
+                                  dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk))
+        return rc;
+    const int WSZ = Dp * HC;
+    ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
+    // d_x = [d_xw | d_a] @ Wcat^T
+    TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
+    if (int rc = launch_ts_gemm(g2, s)) return rc;
+    // d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a]  computed as ([d_xw|d_a]^T x)^T
+    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, (int)N, 0, wg2, 0};
+    if (int rc = launch_wgrad_partials(w2, dstaged + G.d_wcat, 1, HC + 8, s, &ra.job[2])) return rc;
+    // one fixed-order reduction for the three partial sets (d_W_scale|d_bias, d_W_edge|d_M, d_Wcat)
+    return launch_final_reduce(ra, s);
+}

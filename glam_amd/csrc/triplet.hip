@@ -13,7 +13,7 @@
 // LDS-resident W_edge (De*H*Cp floats) instead of materialising ew[E,H*C].
 // No atomics anywhere: forward reduces a CSR-by-target segment in registers, backward B1 walks the
 // same segments, backward B2 walks the CSR transpose (by source).  Results are bit-reproducible.
-#include "common.h"
+#include "dense.h"
 
 namespace glam {
 
@@ -388,21 +388,32 @@ __global__ void __launch_bounds__(kBlock) k_triplet_bwd_src(BwdSrcArgs a) {
     }
 }
 
-// out[i] = sum_b partial[b][i], fixed order (deterministic)
+// out[i] = sum_b partial[b][i] in a fixed order (deterministic).  A block owns 16 columns; its 256
+// threads are 16 columns x 16 row lanes, each lane sums rows rl, rl+16, ... with 4 independent chains,
+// then the 16 lanes are combined through LDS in index order.
 __global__ void __launch_bounds__(kBlock) k_reduce_partials(const float* partial, int nblk, int P, int WSZ,
                                                            float* d_w_edge, float* d_M) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P) return;
+    __shared__ float s_part[16][17];
+    const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        s0 += partial[(size_t)(b + 0) * P + i]; s1 += partial[(size_t)(b + 1) * P + i];
-        s2 += partial[(size_t)(b + 2) * P + i]; s3 += partial[(size_t)(b + 3) * P + i];
+    if (i < P) {
+        int b = rl;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += partial[(size_t)(b + 0) * P + i]; s1 += partial[(size_t)(b + 16) * P + i];
+            s2 += partial[(size_t)(b + 32) * P + i]; s3 += partial[(size_t)(b + 48) * P + i];
+        }
+        for (; b < nblk; b += 16) s0 += partial[(size_t)b * P + i];
     }
-    for (; b < nblk; ++b) s0 += partial[(size_t)b * P + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (i < WSZ) { if (d_w_edge) d_w_edge[i] = s; }
-    else d_M[i - WSZ] = s;
+    s_part[rl][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && i < P) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += s_part[r][c];
+        if (i < WSZ) { if (d_w_edge) d_w_edge[i] = s; }
+        else d_M[i - WSZ] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -509,23 +520,19 @@ extern "C" size_t glam_triplet_bwd_workspace_bytes(int64_t N, int64_t E, int H, 
     return ((size_t)E * 8 + (size_t)kBwdBlocks * P) * sizeof(float) + 256;
 }
 
-extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
-                                const float* M, const float* aggr, const float* stats, const float* d_aggr,
-                                const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
-                                const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De,
-                                int emul, float slope, float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M,
-                                float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+namespace glam {
+// Backward launches.  reduce_now = true: d_w_edge / d_M are final on return (3 launches);
+// reduce_now = false: the B1 block partials [*nblk_out][P] are left at *partial_out for a merged reduction.
+int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
+                     const float* aggr, const float* stats, const float* d_aggr, const int32_t* rowptr,
+                     const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
+                     const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
+                     float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
+                     size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
-    GLAM_REQUIRE(d_M && (!emul || d_w_edge), "glam_triplet_bwd: null gradient output");
-    hipStream_t s = (hipStream_t)stream;
     const int WSZ = emul ? De * H * Cp : 0;
     const int P = WSZ + De * 4;
-    if (N == 0) {
-        if (emul) (void)hipMemsetAsync(d_w_edge, 0, (size_t)WSZ * 4, s);
-        (void)hipMemsetAsync(d_M, 0, (size_t)De * 16, s);
-        return GLAM_OK;
-    }
     GLAM_REQUIRE(xw && a_ij && M && aggr && stats && d_aggr && rowptr && colptr && d_xw && d_a_ij && ws,
                  "glam_triplet_bwd: null pointer");
     GLAM_REQUIRE(ws_bytes >= glam_triplet_bwd_workspace_bytes(N, E, H, Cp, De), "glam_triplet_bwd: workspace too small");
@@ -544,13 +551,36 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     if (!dispatch<BwdDstOp>(H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
-    hipLaunchKernelGGL(k_reduce_partials, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, nblk, P, WSZ,
-                       d_w_edge, d_M);
-    GLAM_LAUNCH_CHECK("glam_triplet_bwd(reduce)");
+    if (reduce_now) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3((P + 15) / 16), dim3(kBlock), 0, s, partial, nblk, P, WSZ, d_w_edge, d_M);
+        GLAM_LAUNCH_CHECK("glam_triplet_bwd(reduce)");
+    } else {
+        *partial_out = partial;
+        *nblk_out = nblk;
+    }
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij};
     const size_t lds2 = (size_t)WSZ * sizeof(float);
     if (!dispatch<BwdSrcOp>(H, De, emul, sh, b2, (int)N, lds2, s, kMaxBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B2)");
     return GLAM_OK;
+}
+}  // namespace glam
+
+extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                                const float* M, const float* aggr, const float* stats, const float* d_aggr,
+                                const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                                const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De,
+                                int emul, float slope, float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M,
+                                float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(d_M && (!emul || d_w_edge), "glam_triplet_bwd: null gradient output");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (emul) (void)hipMemsetAsync(d_w_edge, 0, (size_t)De * H * Cp * 4, s);
+        (void)hipMemsetAsync(d_M, 0, (size_t)De * 16, s);
+        return GLAM_OK;
+    }
+    return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
+                            H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
+                            nullptr, nullptr);
 }

@@ -104,11 +104,20 @@ class TripletMessage(MessagePassing):
             raise GlamHipError("heads > 4 is outside the compiled kernel table")
         edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         gi = ops.graph_index(edge_index, x.size(0))
+        C, De = self.node_channels, self.edge_channels
+        Cp, Dp = _ceil4(C), _pad_de(De)
+        if Dp != edge_attr.size(1):
+            edge_attr = F.pad(edge_attr, (0, Dp - edge_attr.size(1)))
+        if ops.fused_layer_supported(C, self.heads, De):
+            # whole layer in HIP: staging, MFMA node GEMM, fused aggregate, MFMA update (+ its backward)
+            x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
+            out = ops.triplet_layer(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att[0],
+                                    self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
+            return out[:, :C] if Cp != C else out
+        # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
         Wn, Wa, We, M, Ws, Cp, Dp = self._staged_weights()
         xw = torch.matmul(x, Wn)                                          # layer.py:37
         a_ij = torch.matmul(x, Wa)
-        if Dp != edge_attr.size(1):
-            edge_attr = F.pad(edge_attr, (0, Dp - edge_attr.size(1)))
         aggr = ops.triplet_aggregate(xw, a_ij, edge_attr, We, M, gi, self.heads, Cp, self.negative_slope)
         return self.update(aggr, Ws)
 

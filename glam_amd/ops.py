@@ -177,6 +177,74 @@ def light_aggregate(xw, a_ij, edge_attr, M, gi, Cp, slope=0.2):
     return _TripletAggregate.apply(xw, a_ij, edge_attr, None, M, gi, 1, Cp, edge_attr.size(1), False, slope)
 
 
+def fused_layer_supported(C, heads, De):
+    """Shapes covered by the dense MFMA kernels behind ``glam_triplet_layer_*`` (C <= 60 at 3 heads)."""
+    Cp = (C + 3) // 4 * 4
+    return heads * Cp + 8 <= 192 and Cp <= 64 and De <= 8 and 1 <= heads <= 4
+
+
+class _TripletLayer(torch.autograd.Function):
+    """Whole TripletMessage layer: parameter staging, node GEMM (+ separable attention columns), fused
+    gather/softmax/scatter-add, update GEMM — and the hand-written backward of all of it."""
+
+    @staticmethod
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope):
+        require_device(x_p, ea_p, wn, we, att, wsc, bias)
+        x_p, ea_p = f32c(x_p, "x"), f32c(ea_p, "edge_attr")
+        wn, we, att, wsc, bias = (f32c(t, n) for t, n in ((wn, "weight_node"), (we, "weight_edge"),
+                                                           (att, "weight_triplet_att"), (wsc, "weight_scale"), (bias, "bias")))
+        C, De = wn.size(0), we.size(0)
+        N, Cp = x_p.shape
+        Dp = ea_p.size(1)
+        if gi.N != N or ea_p.size(0) != gi.E or wn.shape != (C, H * C) or wsc.shape != (H * C, C) or Cp != (C + 3) // 4 * 4:
+            raise GlamHipError("triplet_layer: shape mismatch")
+        lib, dev = _lib.load(), x_p.device
+        HC = H * Cp
+        f = dict(dtype=torch.float32, device=dev)
+        staged = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
+        check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(staged),
+                                            stream()), "glam_triplet_stage_params")
+        xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
+        aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
+        check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, gi.E,
+                                         H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
+                                         stream()), "glam_triplet_layer_fwd")
+        ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
+        ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
+        C, H, De, Cp, Dp, slope = ctx.dims
+        gi = ctx.gi
+        N, E = gi.N, gi.E
+        lib, dev = _lib.load(), x_p.device
+        d_out = f32c(d_out, "d_out")
+        colptr, dst, eid_t = gi.transpose()
+        f = dict(dtype=torch.float32, device=dev)
+        dstaged = torch.empty(lib.glam_triplet_dstaged_floats(H, Cp, Dp), **f)
+        d_x = torch.empty_like(x_p)
+        d_ea = torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None
+        ws = torch.empty(lib.glam_triplet_layer_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=dev)
+        check(lib.glam_triplet_layer_bwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
+                                         ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
+                                         ptr(eid_t), N, E, H, Cp, Dp, slope, ptr(d_x), ptr(dstaged), ptr(d_ea), ptr(ws),
+                                         ws.numel(), stream()), "glam_triplet_layer_bwd")
+        d_wn, d_we, d_att = torch.empty_like(wn), torch.empty_like(we), torch.empty_like(att)
+        d_wsc, d_bias = torch.empty(H * C, C, **f), torch.empty(C, **f)
+        check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn),
+                                                ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()),
+              "glam_triplet_stage_params_bwd")
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
+
+
+def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
+    """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
+    return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+
+
 # --------------------------------------------------------------------------------------
 # readouts
 # --------------------------------------------------------------------------------------

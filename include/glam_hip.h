@@ -135,6 +135,59 @@ int glam_edge_reduce_fwd(const float* msg, const int32_t* rowptr, const int32_t*
 int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_t* eid, const int32_t* argmax,
                          int64_t N, int64_t E, int D, int mode, float* d_msg, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense ends of the layer on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32).
+ * Replaces: torch.matmul(x, weight_node) (src_1gp/layer.py:37), torch.matmul(aggr, weight_scale) + bias
+ * (src_1gp/layer.py:58-60) and the matmuls autograd derives from them.
+ *   glam_ts_gemm_make_image: lays a weight W[K, M] (logical W[k][m] = transW ? W[m*ldw+k] : W[k*ldw+m]) out as the
+ *                    LDS image the GEMM blocks copy verbatim (glam_ts_gemm_image_bytes(K, M) bytes).
+ *   glam_ts_gemm:    out[N, M1|M2] = [A1 | A2][N, K1+K2] @ W (+ bias on the M1 columns); all K*, M*, ld* % 4 == 0;
+ *                    K1+K2 <= 192 with M <= 64, or K1+K2 <= 64 with M <= 192.
+ *   glam_wgrad_gemm: out[i*stride_i + j*stride_j] = sum_n [P1 | P2 | 1][n, i] * Q[n, j]  (reduction over the N
+ *                    rows; `ones` appends an all-ones column, i.e. the bias gradient); I <= 192, J <= 64. */
+size_t glam_ts_gemm_image_bytes(int K, int M);
+int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, float* img, void* stream);
+int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
+                 const float* bias, float* out1, int M1, int ldo1, float* out2, int M2, int ldo2, int64_t N,
+                 void* stream);
+size_t glam_wgrad_workspace_bytes(void);
+int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
+                    int J, int ldq, int64_t N, float* out, int stride_i, int stride_j, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole TripletMessage layer (src_1gp/layer.py:36-61) as one enqueue per direction.  All node-feature
+ * widths are the padded Cp (x f32[N,Cp], out f32[N,Cp]; the host mirror pads/slices when C % 4 != 0).
+ *   glam_triplet_stage_params: parameters -> `staged` (glam_triplet_staged_floats floats): the four GEMM weight
+ *     images ([W_node | Wa_i | Wa_j] with the separable-attention columns, W_scale, and their transposes),
+ *     W_edge head-padded, M f32[Dp,4], bias padded.
+ *   glam_triplet_layer_fwd:  x -> (xw, a_ij) -> aggr, stats -> out          (3 launches)
+ *   glam_triplet_layer_bwd:  d_out -> d_x and `dstaged` (glam_triplet_dstaged_floats floats: d_Wcat[Cp,H*Cp+8] |
+ *                            d_WsB[H*Cp+1,Cp] (last row = d_bias) | d_We_p | d_M), optional d_edge_attr
+ *                            (9 launches, no atomics)
+ *   glam_triplet_stage_params_bwd: chain rule from `dstaged` back to weight_node / weight_edge /
+ *                            weight_triplet_att / weight_scale / bias.
+ * Limits: H*Cp + 8 <= 192 and Cp <= 64 (C <= 60 at H = 3). */
+size_t glam_triplet_staged_floats(int H, int Cp, int Dp);
+size_t glam_triplet_dstaged_floats(int H, int Cp, int Dp);
+int glam_triplet_stage_params(const float* weight_node, const float* weight_edge, const float* att,
+                              const float* weight_scale, const float* bias, int C, int H, int De, int Cp, int Dp,
+                              float* staged, void* stream);
+int glam_triplet_stage_params_bwd(const float* weight_node, const float* weight_edge, const float* att,
+                                  const float* dstaged, int C, int H, int De, int Cp, int Dp, float* d_weight_node,
+                                  float* d_weight_edge, float* d_att, float* d_weight_scale, float* d_bias,
+                                  void* stream);
+int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                           const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
+                           float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);
+size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp);
+int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                           const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                           const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                           const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int Dp,
+                           float slope, float* d_x, float* dstaged, float* d_edge_attr, void* ws, size_t ws_bytes,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

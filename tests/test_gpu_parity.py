@@ -373,3 +373,58 @@ def test_full_size_pool5_checksum(big, device):
     assert_close(out[:, :60] * cnt, out[:, 60:120], 1e-5, "mean * count == sum")
     top = out[:, 120:].view(1024, 3, 60)[:, :, -1]
     assert (top[:, 0] >= top[:, 1]).all() and (top[:, 1] >= top[:, 2]).all(), "sort-pool rows are sorted"
+
+
+# ---------------------------------------------------------------------------------------------
+# dense ends: fp32-MFMA tall-skinny GEMM and weight-gradient GEMM against fp64 matmul
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K1,K2,M1,M2,trans,bias", [
+    (1000, 60, 0, 180, 8, 0, False), (1000, 180, 0, 60, 0, 0, True), (333, 60, 0, 180, 0, 1, False),
+    (1, 180, 8, 60, 0, 1, False), (4099, 16, 0, 48, 8, 0, True), (17, 48, 8, 16, 0, 1, False), (0, 60, 0, 60, 0, 0, False),
+    (5000, 64, 0, 184, 8, 0, True), (700, 188, 0, 64, 0, 0, False)])
+def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(N + K1 + M1)
+    A1 = torch.randn(N, K1, generator=g)
+    A2 = torch.randn(N, max(K2, 1), generator=g)[:, :K2].contiguous()
+    K, M = K1 + K2, M1 + M2
+    W = torch.randn(K, M, generator=g)
+    b = torch.randn(M1, generator=g) if bias else None
+    ref = torch.cat([A1, A2], 1).double() @ W.double()
+    if bias:
+        ref[:, :M1] += b.double()
+    Wd = (W.t().contiguous() if trans else W).to(device)
+    ldw = K if trans else M
+    A1d, A2d = A1.to(device), A2.to(device)
+    o1 = torch.full((N, M1), float("nan"), device=device)
+    o2 = torch.full((N, max(M2, 1)), float("nan"), device=device)
+    img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, device=device)
+    assert lib.glam_ts_gemm_make_image(p(Wd), ldw, trans, K, M, p(img), _lib.stream()) == 0, lib.glam_last_error()
+    bd = b.to(device) if bias else None
+    rc = lib.glam_ts_gemm(p(A1d), K1, K1, p(A2d) if K2 else None, K2, K2, p(img), p(bd), p(o1), M1, M1,
+                          p(o2) if M2 else None, M2, max(M2, 4), N, _lib.stream())
+    assert rc == 0, lib.glam_last_error()
+    assert_close(o1, ref[:, :M1], 2e-6, "ts_gemm out1")
+    if M2:
+        assert_close(o2, ref[:, M1:], 2e-6, "ts_gemm out2")
+
+
+@pytest.mark.parametrize("N,I1,I2,ones,J", [(1000, 180, 0, 1, 60), (20400, 180, 8, 0, 60), (7, 48, 8, 0, 16), (1, 16, 0, 1, 16), (5000, 56, 8, 1, 64), (3000, 184, 4, 1, 64)])
+def test_wgrad_gemm(device, N, I1, I2, ones, J):
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(N + I1)
+    P1, P2, Q = torch.randn(N, I1, generator=g), torch.randn(N, max(I2, 1), generator=g)[:, :I2].contiguous(), torch.randn(N, J, generator=g)
+    P = torch.cat([P1, P2] + ([torch.ones(N, 1)] if ones else []), 1)
+    ref = P.double().t() @ Q.double()
+    I = P.size(1)
+    ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    P1d, P2d, Qd = P1.to(device), P2.to(device), Q.to(device)
+    for si, sj, shape in [(J, 1, (I, J)), (1, I, (J, I))]:
+        out = torch.full(shape, float("nan"), device=device)
+        rc = lib.glam_wgrad_gemm(p(P1d), I1, I1, p(P2d) if I2 else None, I2, I2, ones, p(Qd), J, J, N, p(out), si, sj, p(ws),
+                                 ws.numel(), _lib.stream())
+        assert rc == 0, lib.glam_last_error()
+        got = out if si == J else out.t()
+        assert_close(got, ref, 3e-6 * max(1.0, N ** 0.5 / 10), "wgrad")
