@@ -39,6 +39,11 @@ size_t wgrad_workspace_floats();
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job);
 int launch_final_reduce(ReduceArgs ra, hipStream_t s);
 
+bool triplet_fwd_can_fuse_update(int H, int Cp, int De);
+int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                             const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
+                             int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
+                             const float* img_upd, const float* bias_p, float* out, hipStream_t s);
 int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
                      const float* aggr, const float* stats, const float* d_aggr, const int32_t* rowptr,
                      const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,

@@ -15,6 +15,17 @@
 // same segments, backward B2 walks the CSR transpose (by source).  Results are bit-reproducible.
 #include "dense.h"
 
+// occupancy targets (waves per SIMD) the register allocator is held to; tuned on MI355X
+#ifndef GLAM_FWD_WAVES
+#define GLAM_FWD_WAVES 1
+#endif
+#ifndef GLAM_FWD_CH
+#define GLAM_FWD_CH 4
+#endif
+#ifndef GLAM_B1_WAVES
+#define GLAM_B1_WAVES 1
+#endif
+
 namespace glam {
 
 struct FwdArgs {
@@ -22,6 +33,8 @@ struct FwdArgs {
     const int* rowptr; const int* nbr; const int* eid;
     int N; int Cp; float slope;
     float* aggr; float* stats;
+    // optional fused update (G == 16 only): out[N,Cp] = aggr @ W_scale + bias, W_scale as a k_ts_gemm image
+    const float* img_upd; const float* bias_p; float* out;
 };
 
 template <int DE>
@@ -62,7 +75,7 @@ __device__ __forceinline__ float4 edge_chunk(const float* s_w, const float (&ea)
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int H, int G, int ITER, int DE, bool EMUL>
-__global__ void __launch_bounds__(kBlock) k_triplet_fwd(FwdArgs a) {
+__global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const int tid = threadIdx.x;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
@@ -87,45 +100,113 @@ __global__ void __launch_bounds__(kBlock) k_triplet_fwd(FwdArgs a) {
         if (!ok[it]) q[it] = 0;
     }
 
-    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
+    // Edges are processed CH at a time with every load of a chunk in flight together (indices -> {edge
+    // features, a_j, neighbour rows}): a degree <= CH segment (all molecular nodes) costs 3 dependent
+    // memory round trips instead of 2 + 2*deg.
+    constexpr int CH = ITER == 1 ? GLAM_FWD_CH : 2;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const bool fuse_upd = (G == 16) && a.img_upd != nullptr;
+    const int LDT = HC + 4;                                    // LDS row pitch of the 16-node aggr tile
+    float* s_tile = s_w + (EMUL ? DE * HC : 0);
+    float* s_out = s_tile + 16 * LDT;
+    for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
+      const int n = base + tid / G;
+      if (n < a.N) {
         const int beg = a.rowptr[n], end = a.rowptr[n + 1];
         const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
         float ai[H], m[H], ssum[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) { ai[h] = f4get(aiv, h); m[h] = -INFINITY; ssum[h] = 0.f; }
-
-        // pass 1: segment max of the logits (cheap, cached loads only)
-        for (int e = beg; e < end; ++e) {
-            const int s = a.nbr[e], id = a.eid[e];
-            float ea[DE], pre[H];
-            load_edge_attr<DE>(a.edge_attr, id, ea);
-            edge_pre<H, DE>(ai, ld4(a.a_ij + (size_t)s * 8 + 4), ea, Mr, pre);
-#pragma unroll
-            for (int h = 0; h < H; ++h) m[h] = fmaxf(m[h], leaky(pre[h], a.slope));
-        }
-        // pass 2: exp-sum and weighted gather of the neighbour rows
         float4 acc[H][ITER];
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
             for (int it = 0; it < ITER; ++it) acc[h][it] = f4zero();
-        for (int e = beg; e < end; ++e) {
-            const int s = a.nbr[e], id = a.eid[e];
-            float ea[DE], pre[H], p[H];
-            load_edge_attr<DE>(a.edge_attr, id, ea);
-            edge_pre<H, DE>(ai, ld4(a.a_ij + (size_t)s * 8 + 4), ea, Mr, pre);
-            const float* xrow = a.xw + (size_t)s * HC;
+
+        int sidx[CH], eidx[CH];
+        bool val[CH];
+        float ea[CH][DE], lk[CH][H];
+        float4 rows[CH][H][ITER];
+        auto load_idx = [&](int e0) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                val[k] = e0 + k < end;
+                const int e = val[k] ? e0 + k : end - 1;
+                sidx[k] = a.nbr[e];
+                eidx[k] = a.eid[e];
+            }
+        };
+        auto load_rows = [&]() {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it)
+                        rows[k][h][it] = val[k] ? ld4(a.xw + (size_t)sidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+        };
+        auto load_logits = [&]() {
+            float4 aj[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                load_edge_attr<DE>(a.edge_attr, eidx[k], ea[k]);
+                aj[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                float pre[H];
+                edge_pre<H, DE>(ai, aj[k], ea[k], Mr, pre);
+#pragma unroll
+                for (int h = 0; h < H; ++h) lk[k][h] = leaky(pre[h], a.slope);
+            }
+        };
+        auto take_max = [&]() {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    if (val[k]) m[h] = fmaxf(m[h], lk[k][h]);
+        };
+        auto accumulate = [&]() {
+            // head-major: the W_edge chunk of one head (DE float4 from LDS) is live for one head only
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                p[h] = expf(leaky(pre[h], a.slope) - m[h]);
-                ssum[h] += p[h];
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
-                    float4 xj = ld4(xrow + h * Cp + q[it] * 4);
-                    if constexpr (EMUL) xj = edge_chunk<H, DE>(s_w, ea, h, Cp, q[it]) * xj;
-                    fma4(acc[h][it], p[h], xj);
+                    float4 wv[EMUL ? DE : 1];
+                    if constexpr (EMUL) {
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!val[k]) continue;
+                        const float p = expf(lk[k][h] - m[h]);
+                        if (it == 0) ssum[h] += p;
+                        float4 xj = rows[k][h][it];
+                        if constexpr (EMUL) {
+                            float4 e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, ea[k][kk], wv[kk]);
+                            xj = e4 * xj;
+                        }
+                        fma4(acc[h][it], p, xj);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (end - beg <= CH) {
+            if (end > beg) {
+                load_idx(beg);
+                load_rows();
+                load_logits();
+                take_max();
+                accumulate();
+            }
+        } else {
+            for (int e0 = beg; e0 < end; e0 += CH) { load_idx(e0); load_logits(); take_max(); }   // pass 1: segment max
+            for (int e0 = beg; e0 < end; e0 += CH) { load_idx(e0); load_rows(); load_logits(); accumulate(); }
         }
         float* orow = a.aggr + (size_t)n * HC;
 #pragma unroll
@@ -133,7 +214,13 @@ __global__ void __launch_bounds__(kBlock) k_triplet_fwd(FwdArgs a) {
             const float inv = 1.f / (ssum[h] + 1e-16f);
 #pragma unroll
             for (int it = 0; it < ITER; ++it)
-                if (ok[it]) st4(orow + h * Cp + q[it] * 4, inv * acc[h][it]);
+                if (ok[it]) {
+                    const float4 v = inv * acc[h][it];
+                    st4(orow + h * Cp + q[it] * 4, v);
+                    if constexpr (G == 16) {
+                        if (fuse_upd) st4(s_tile + (tid / G) * LDT + h * Cp + q[it] * 4, v);
+                    }
+                }
         }
         if (lg == 0) {
             float4 mv = f4zero(), sv = f4zero();
@@ -143,6 +230,43 @@ __global__ void __launch_bounds__(kBlock) k_triplet_fwd(FwdArgs a) {
             st4(a.stats + (size_t)n * 8, mv);
             st4(a.stats + (size_t)n * 8 + 4, sv);
         }
+      }
+      if constexpr (G == 16) {
+        // ---- fused update: out[16 nodes, Cp] = aggr_tile[16, HC] @ W_scale + bias on the fp32 matrix cores ----
+        // wave w owns output column tile w (logical columns 4c + w); B fragments straight from the L2-resident
+        // weight image (one float4 per 16-k group, all loads in flight), A fragments from the LDS tile.
+        if (fuse_upd) {
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+            const int GK = (HC + 15) >> 4;
+            v4f cacc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int g0 = 0; g0 < GK; g0 += 4) {          // 4 k-groups (64 k values) per batch: 8 loads in flight
+                float4 bf[4], af[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u, k0 = 16 * g + 4 * kq;
+                    bf[u] = g < GK ? ld4(a.img_upd + ((size_t)(4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
+                    af[u] = (g < GK && k0 < HC) ? ld4(s_tile + c * LDT + k0) : f4zero();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[u], j), f4get(bf[u], j), cacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_out[(kq * 4 + i) * 64 + 4 * c + wave] = cacc[i];
+            __syncthreads();
+            const int row = tid >> 4, c4 = (tid & 15) * 4;
+            if (c4 < Cp && base + row < a.N) {
+                float4 v = ld4(s_out + row * 64 + c4);
+                const float4 b = ld4(a.bias_p + c4);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                st4(a.out + (size_t)(base + row) * Cp + c4, v);
+            }
+        }
+      }
     }
 }
 
@@ -159,7 +283,7 @@ struct BwdDstArgs {
 };
 
 template <int H, int G, int ITER, int DE, bool EMUL>
-__global__ void __launch_bounds__(kBlock) k_triplet_bwd_dst(BwdDstArgs a) {
+__global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDstArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int tid = threadIdx.x;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
@@ -220,65 +344,90 @@ __global__ void __launch_bounds__(kBlock) k_triplet_bwd_dst(BwdDstArgs a) {
             // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
             dot[h] = group_sum<G>(part);
         }
-        for (int e = beg; e < end; ++e) {
-            const int s = a.nbr[e], id = a.eid[e];
-            float ea[DE], pre[H], alpha[H], dp[H];
-            load_edge_attr<DE>(a.edge_attr, id, ea);
-            edge_pre<H, DE>(ai, ld4(a.a_ij + (size_t)s * 8 + 4), ea, Mr, pre);
-            const float* xrow = a.xw + (size_t)s * HC;
-            float dea[DE];
+        constexpr int CH = 2;   // edges per chunk: all loads of a chunk in flight together
+        for (int e0 = beg; e0 < end; e0 += CH) {
+            int sidx[CH], eidx[CH];
+            bool val[CH];
+            float eav[CH][DE];
+            float4 ajv[CH], rows[CH][H][ITER];
 #pragma unroll
-            for (int k = 0; k < DE; ++k) dea[k] = 0.f;
+            for (int k = 0; k < CH; ++k) {
+                val[k] = e0 + k < end;
+                const int e = val[k] ? e0 + k : end - 1;
+                sidx[k] = a.nbr[e];
+                eidx[k] = a.eid[e];
+            }
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                alpha[h] = expf(leaky(pre[h], a.slope) - m[h]) * inv[h];
-                float part = 0.f;
+            for (int k = 0; k < CH; ++k) {
 #pragma unroll
-                for (int it = 0; it < ITER; ++it) {
-                    const float4 t = dag[h][it] * ld4(xrow + h * Cp + q[it] * 4);   // d_aggr * x_j
-                    if constexpr (EMUL) {
-                        float4 e4 = f4zero();
+                for (int h = 0; h < H; ++h)
 #pragma unroll
-                        for (int k = 0; k < DE; ++k) {
-                            const float4 w = ld4(s_w + (k * H + h) * Cp + q[it] * 4);
-                            fma4(e4, ea[k], w);
-                            fma4(dw[k][h][it], ea[k] * alpha[h], t);
-                            if (a.d_edge_attr) dea[k] = fmaf(alpha[h], dot4(t, w), dea[k]);
+                    for (int it = 0; it < ITER; ++it)
+                        rows[k][h][it] = val[k] ? ld4(a.xw + (size_t)sidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+                load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
+                ajv[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (!val[k]) continue;
+                const int id = eidx[k];
+                const float (&ea)[DE] = eav[k];
+                float pre[H], alpha[H], dp[H];
+                edge_pre<H, DE>(ai, ajv[k], ea, Mr, pre);
+                float dea[DE];
+#pragma unroll
+                for (int kk = 0; kk < DE; ++kk) dea[kk] = 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    alpha[h] = expf(leaky(pre[h], a.slope) - m[h]) * inv[h];
+                    float part = 0.f;
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        const float4 t = dag[h][it] * rows[k][h][it];   // d_aggr * x_j
+                        if constexpr (EMUL) {
+                            float4 e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) {
+                                const float4 w = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                                fma4(e4, ea[kk], w);
+                                fma4(dw[kk][h][it], ea[kk] * alpha[h], t);
+                                if (a.d_edge_attr) dea[kk] = fmaf(alpha[h], dot4(t, w), dea[kk]);
+                            }
+                            part += dot4(t, e4);
+                        } else {
+                            part += t.x + t.y + t.z + t.w;
                         }
-                        part += dot4(t, e4);
-                    } else {
-                        part += t.x + t.y + t.z + t.w;
+                    }
+                    const float dalpha = group_sum<G>(part);
+                    const float dl = alpha[h] * (dalpha - dot[h]);
+                    dp[h] = pre[h] > 0.f ? dl : dl * a.slope;
+                    dai[h] += dp[h];
+#pragma unroll
+                    for (int kk = 0; kk < DE; ++kk) dM[kk][h] = fmaf(ea[kk], dp[h], dM[kk][h]);
+                }
+                if (a.d_edge_attr) {
+#pragma unroll
+                    for (int kk = 0; kk < DE; ++kk) {
+                        float v = EMUL ? group_sum<G>(dea[kk]) : 0.f;
+#pragma unroll
+                        for (int h = 0; h < H; ++h) v = fmaf(dp[h], Mr[kk][h], v);
+                        dea[kk] = v;
+                    }
+                    if (lg == 0) {
+#pragma unroll
+                        for (int i = 0; i < DE / 4; ++i)
+                            st4(a.d_edge_attr + (size_t)id * DE + 4 * i,
+                                make_float4(dea[4 * i], dea[4 * i + 1], dea[4 * i + 2], dea[4 * i + 3]));
                     }
                 }
-                const float dalpha = group_sum<G>(part);
-                const float dl = alpha[h] * (dalpha - dot[h]);
-                dp[h] = pre[h] > 0.f ? dl : dl * a.slope;
-                dai[h] += dp[h];
-#pragma unroll
-                for (int k = 0; k < DE; ++k) dM[k][h] = fmaf(ea[k], dp[h], dM[k][h]);
-            }
-            if (a.d_edge_attr) {
-#pragma unroll
-                for (int k = 0; k < DE; ++k) {
-                    float v = EMUL ? group_sum<G>(dea[k]) : 0.f;
-#pragma unroll
-                    for (int h = 0; h < H; ++h) v = fmaf(dp[h], Mr[k][h], v);
-                    dea[k] = v;
-                }
                 if (lg == 0) {
+                    float4 av = f4zero(), dv = f4zero();
+                    float* ap = &av.x; float* dpp = &dv.x;
 #pragma unroll
-                    for (int i = 0; i < DE / 4; ++i)
-                        st4(a.d_edge_attr + (size_t)id * DE + 4 * i,
-                            make_float4(dea[4 * i], dea[4 * i + 1], dea[4 * i + 2], dea[4 * i + 3]));
+                    for (int h = 0; h < H; ++h) { ap[h] = alpha[h]; dpp[h] = dp[h]; }
+                    st4(a.alpha_e + (size_t)id * 4, av);
+                    st4(a.dpre_e + (size_t)id * 4, dv);
                 }
-            }
-            if (lg == 0) {
-                float4 av = f4zero(), dv = f4zero();
-                float* ap = &av.x; float* dpp = &dv.x;
-#pragma unroll
-                for (int h = 0; h < H; ++h) { ap[h] = alpha[h]; dpp[h] = dp[h]; }
-                st4(a.alpha_e + (size_t)id * 4, av);
-                st4(a.dpre_e + (size_t)id * 4, dv);
             }
         }
         if (lg == 0) {
@@ -335,7 +484,7 @@ struct BwdSrcArgs {
 };
 
 template <int H, int G, int ITER, int DE, bool EMUL>
-__global__ void __launch_bounds__(kBlock) k_triplet_bwd_src(BwdSrcArgs a) {
+__global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdSrcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const int tid = threadIdx.x;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
@@ -361,22 +510,57 @@ __global__ void __launch_bounds__(kBlock) k_triplet_bwd_src(BwdSrcArgs a) {
         for (int h = 0; h < H; ++h)
 #pragma unroll
             for (int it = 0; it < ITER; ++it) acc[h][it] = f4zero();
-        for (int e = beg; e < end; ++e) {
-            const int n = a.nbr[e], id = a.eid[e];
-            const float4 al = ld4(a.alpha_e + (size_t)id * 4);
-            const float4 dp = ld4(a.dpre_e + (size_t)id * 4);
-            daj.x += dp.x; daj.y += dp.y; daj.z += dp.z; daj.w += dp.w;
-            float ea[DE];
-            if constexpr (EMUL) load_edge_attr<DE>(a.edge_attr, id, ea);
-            const float* grow = a.d_aggr + (size_t)n * HC;
+        constexpr int CH = ITER == 1 ? 4 : 2;   // edges per chunk: all loads of a chunk in flight together
+        for (int e0 = beg; e0 < end; e0 += CH) {
+            int nidx[CH], eidx[CH];
+            bool val[CH];
+            float4 alv[CH], dpv[CH], rows[CH][H][ITER];
+            float eav[CH][DE];
 #pragma unroll
-            for (int h = 0; h < H; ++h)
+            for (int k = 0; k < CH; ++k) {
+                val[k] = e0 + k < end;
+                const int e = val[k] ? e0 + k : end - 1;
+                nidx[k] = a.nbr[e];
+                eidx[k] = a.eid[e];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it)
+                        rows[k][h][it] = val[k] ? ld4(a.d_aggr + (size_t)nidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+                alv[k] = ld4(a.alpha_e + (size_t)eidx[k] * 4);
+                dpv[k] = ld4(a.dpre_e + (size_t)eidx[k] * 4);
+                if constexpr (EMUL) load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (val[k]) { daj.x += dpv[k].x; daj.y += dpv[k].y; daj.z += dpv[k].z; daj.w += dpv[k].w; }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
-                    float4 dg = ld4(grow + h * Cp + q[it] * 4);
-                    if constexpr (EMUL) dg = edge_chunk<H, DE>(s_w, ea, h, Cp, q[it]) * dg;
-                    fma4(acc[h][it], f4get(al, h), dg);
+                    float4 wv[EMUL ? DE : 1];
+                    if constexpr (EMUL) {
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!val[k]) continue;
+                        float4 dg = rows[k][h][it];
+                        if constexpr (EMUL) {
+                            float4 e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, eav[k][kk], wv[kk]);
+                            dg = e4 * dg;
+                        }
+                        fma4(acc[h][it], f4get(alv[k], h), dg);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         float* orow = a.d_xw + (size_t)j * HC;
 #pragma unroll
@@ -507,7 +691,7 @@ extern "C" int glam_triplet_fwd(const float* xw, const float* a_ij, const float*
                  "glam_triplet_fwd: null pointer");
     GLAM_REQUIRE(aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(stats) && aligned16(edge_attr) &&
                      aligned16(w_edge), "glam_triplet_fwd: pointers must be 16-byte aligned");
-    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats};
+    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, nullptr, nullptr, nullptr};
     const size_t lds = emul ? (size_t)De * H * Cp * sizeof(float) : 0;
     if (!dispatch<FwdOp>(H, De, emul, sh, a, (int)N, lds, (hipStream_t)stream, kMaxBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
@@ -521,6 +705,27 @@ extern "C" size_t glam_triplet_bwd_workspace_bytes(int64_t N, int64_t E, int H, 
 }
 
 namespace glam {
+// Forward aggregate with the update GEMM fused in (layer.py:42-61 in one launch).  Returns
+// GLAM_E_UNSUPPORTED when the shape has no fused variant (caller falls back to aggregate + k_ts_gemm).
+bool triplet_fwd_can_fuse_update(int H, int Cp, int De) {
+    Shape sh;
+    return pick_shape(Cp >> 2, &sh) && sh.G == 16 && sh.ITER == 1 && H * Cp <= 192 && Cp <= 64 && (De == 4 || De == 8);
+}
+int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
+                             const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
+                             int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
+                             const float* img_upd, const float* bias_p, float* out, hipStream_t s) {
+    Shape sh;
+    if (int rc = check_dims("glam_triplet_fwd(fused)", N, E, H, Cp, De, &sh)) return rc;
+    if (N == 0) return GLAM_OK;
+    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out};
+    const size_t lds = ((size_t)De * H * Cp + 16 * (size_t)(H * Cp + 4) + 16 * 64) * sizeof(float);
+    if (!dispatch<FwdOp>(H, De, 1, sh, a, (int)N, lds, s, kMaxBlocks, nullptr))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd(fused): no kernel for H=%d De=%d", H, De);
+    GLAM_LAUNCH_CHECK("glam_triplet_fwd(fused)");
+    return GLAM_OK;
+}
+
 // Backward launches.  reduce_now = true: d_w_edge / d_M are final on return (3 launches);
 // reduce_now = false: the B1 block partials [*nblk_out][P] are left at *partial_out for a merged reduction.
 int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
