@@ -61,7 +61,8 @@ def _worker(rank, world, port, mode, q):
 
         step = DataParallelStep(net, loss_fn)
         step(shard)
-        q.put((rank, step.bucket.flat.clone(), [p.detach().clone() for p in net.parameters()]))
+        # plain Python payloads: tensors through an mp.Queue hand over file descriptors the exiting worker may close
+        q.put((rank, step.bucket.flat.tolist(), [p.detach().reshape(-1).tolist() for p in net.parameters()]))
     finally:
         dist.destroy_process_group()
 
@@ -79,15 +80,15 @@ def test_dp_gradients_match_single_process(mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, g0, p0), (_, g1, p1) = res
-    assert torch.equal(g0, g1), "all-reduced buckets must be identical on every rank"
-    for a, b in zip(p0, p1):
-        assert torch.equal(a, b), "replicas must start from rank 0's parameters"
+    assert g0 == g1, "all-reduced buckets must be identical on every rank"
+    assert p0 == p1, "replicas must start from rank 0's parameters"
+    g0 = torch.tensor(g0)
     # single-process reference on the whole batch with rank 0's parameters
     tasks = 1 if mode == "mse" else 3
     net = TinyGraphNet(tasks)
     with torch.no_grad():
         for p, v in zip(net.parameters(), p0):
-            p.copy_(v)
+            p.copy_(torch.tensor(v).view_as(p))
     full = synth_batch(24, seed=5, n_tasks=tasks, task="regression" if mode == "mse" else "classification")
     out = net(full)
     if mode == "mse":
