@@ -50,14 +50,35 @@ static DStaged dstaged_layout(int H, int Cp, int Dp) {
     return s;
 }
 
-__device__ __forceinline__ float dot_strided(const float* a, const float* b, int n) {
+// sum_i a[i*sa] * b[i*sb]; 16 products per step with all 32 loads in flight (these dots sit on the critical
+// path of a latency-bound launch)
+__device__ __forceinline__ float dot_strided(const float* a, int sa, const float* b, int sb, int n) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int i = 0;
-    for (; i + 4 <= n; i += 4) {
-        s0 = fmaf(a[i], b[i], s0); s1 = fmaf(a[i + 1], b[i + 1], s1);
-        s2 = fmaf(a[i + 2], b[i + 2], s2); s3 = fmaf(a[i + 3], b[i + 3], s3);
+    for (; i + 16 <= n; i += 16) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { av[u] = a[(size_t)(i + u) * sa]; bv[u] = b[(size_t)(i + u) * sb]; }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            s0 = fmaf(av[u], bv[u], s0); s1 = fmaf(av[u + 1], bv[u + 1], s1);
+            s2 = fmaf(av[u + 2], bv[u + 2], s2); s3 = fmaf(av[u + 3], bv[u + 3], s3);
+        }
     }
-    for (; i < n; ++i) s0 = fmaf(a[i], b[i], s0);
+    {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const bool okk = i + u < n;
+            av[u] = okk ? a[(size_t)(i + u) * sa] : 0.f;
+            bv[u] = okk ? b[(size_t)(i + u) * sb] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            s0 = fmaf(av[u], bv[u], s0); s1 = fmaf(av[u + 1], bv[u + 1], s1);
+            s2 = fmaf(av[u + 2], bv[u + 2], s2); s3 = fmaf(av[u + 3], bv[u + 3], s3);
+        }
+    }
     return (s0 + s1) + (s2 + s3);
 }
 
@@ -77,7 +98,7 @@ __device__ __forceinline__ float wcat_val(const StageArgs& a, int k, int m) {
     }
     const int s = m - H * Cp, h = s & 3, side = s >> 2;   // side 0: att[:, 0:C] (target), 1: att[:, 2C:3C] (source)
     if (h >= H) return 0.f;
-    return dot_strided(a.wn + (size_t)k * H * C + h * C, a.att + (size_t)h * 3 * C + (side ? 2 * C : 0), C);
+    return dot_strided(a.wn + (size_t)k * H * C + h * C, 1, a.att + (size_t)h * 3 * C + (side ? 2 * C : 0), 1, C);
 }
 // logical Ws_p[k][m], k < H*Cp, m < Cp
 __device__ __forceinline__ float wsp_val(const StageArgs& a, int k, int m) {
@@ -126,7 +147,7 @@ __global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a) {
         i -= n5;
         if (i < n6) {
             const int k = i >> 2, h = i & 3;
-            a.base[a.L.m + i] = (k < De && h < H) ? dot_strided(a.we + (size_t)k * H * C + h * C, a.att + (size_t)h * 3 * C + C, C) : 0.f;
+            a.base[a.L.m + i] = (k < De && h < H) ? dot_strided(a.we + (size_t)k * H * C + h * C, 1, a.att + (size_t)h * 3 * C + C, 1, C) : 0.f;
             continue;
         }
         i -= n6;
@@ -156,22 +177,10 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
             d_we[i] = fmaf(d_M[k * 4 + h], att[(size_t)h * 3 * C + C + c], d_We_p[(size_t)k * H * Cp + h * Cp + c]);
         } else if (idx < n_wn + n_we + n_att) {
             const int i = idx - n_wn - n_we, h = i / (3 * C), t = i % (3 * C), part = t / C, c = t % C;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            if (part == 1) {
-                for (int k = 0; k < De; ++k) s0 = fmaf(d_M[k * 4 + h], we[(size_t)k * H * C + h * C + c], s0);
-            } else {
-                const float* dcol = d_Wcat + H * Cp + (part == 0 ? 0 : 4) + h;
-                const float* wcol = wn + h * C + c;
-                int k = 0;
-                for (; k + 4 <= C; k += 4) {
-                    s0 = fmaf(dcol[(size_t)(k + 0) * MC], wcol[(size_t)(k + 0) * H * C], s0);
-                    s1 = fmaf(dcol[(size_t)(k + 1) * MC], wcol[(size_t)(k + 1) * H * C], s1);
-                    s2 = fmaf(dcol[(size_t)(k + 2) * MC], wcol[(size_t)(k + 2) * H * C], s2);
-                    s3 = fmaf(dcol[(size_t)(k + 3) * MC], wcol[(size_t)(k + 3) * H * C], s3);
-                }
-                for (; k < C; ++k) s0 = fmaf(dcol[(size_t)k * MC], wcol[(size_t)k * H * C], s0);
-            }
-            d_att[i] = (s0 + s1) + (s2 + s3);
+            float v;
+            if (part == 1) v = dot_strided(d_M + h, 4, we + h * C + c, H * C, De);
+            else v = dot_strided(d_Wcat + H * Cp + (part == 0 ? 0 : 4) + h, MC, wn + h * C + c, H * C, C);
+            d_att[i] = v;
         } else if (idx < n_wn + n_we + n_att + n_ws) {
             const int i = idx - n_wn - n_we - n_att, row = i / C, col = i % C, h = row / C, c = row % C;
             d_wsc[i] = d_WsB[(size_t)(h * Cp + c) * Cp + col];

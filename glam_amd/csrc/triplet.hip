@@ -22,6 +22,9 @@
 #ifndef GLAM_FWD_CH
 #define GLAM_FWD_CH 4
 #endif
+#ifndef GLAM_B1_CH
+#define GLAM_B1_CH 4
+#endif
 #ifndef GLAM_B1_WAVES
 #define GLAM_B1_WAVES 1
 #endif
@@ -279,7 +282,7 @@ struct BwdDstArgs {
     const float* aggr; const float* stats; const float* d_aggr;
     const int* rowptr; const int* nbr; const int* eid;
     int N; int Cp; float slope;
-    float* alpha_e; float* dpre_e; float* d_a_ij; float* d_edge_attr; float* partial;
+    float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;
 };
 
 template <int H, int G, int ITER, int DE, bool EMUL>
@@ -344,7 +347,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
             dot[h] = group_sum<G>(part);
         }
-        constexpr int CH = 2;   // edges per chunk: all loads of a chunk in flight together
+        constexpr int CH = ITER == 1 ? GLAM_B1_CH : 2;   // edges per chunk: all loads of a chunk in flight together
         for (int e0 = beg; e0 < end; e0 += CH) {
             int sidx[CH], eidx[CH];
             bool val[CH];
@@ -367,66 +370,64 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
                 load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
                 ajv[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
             }
+            float pre[CH][H], alpha[CH][H], dp[CH][H];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                if (!val[k]) continue;
-                const int id = eidx[k];
-                const float (&ea)[DE] = eav[k];
-                float pre[H], alpha[H], dp[H];
-                edge_pre<H, DE>(ai, ajv[k], ea, Mr, pre);
-                float dea[DE];
+            for (int k = 0; k < CH; ++k) edge_pre<H, DE>(ai, ajv[k], eav[k], Mr, pre[k]);
+            // head-major: the W_edge chunk of one head is live for one head only
 #pragma unroll
-                for (int kk = 0; kk < DE; ++kk) dea[kk] = 0.f;
+            for (int h = 0; h < H; ++h) {
+                float part[CH];
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    alpha[h] = expf(leaky(pre[h], a.slope) - m[h]) * inv[h];
-                    float part = 0.f;
+                for (int k = 0; k < CH; ++k) {
+                    part[k] = 0.f;
+                    alpha[k][h] = expf(leaky(pre[k][h], a.slope) - m[h]) * inv[h];
+                }
 #pragma unroll
-                    for (int it = 0; it < ITER; ++it) {
+                for (int it = 0; it < ITER; ++it) {
+                    float4 wv[EMUL ? DE : 1];
+                    if constexpr (EMUL) {
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!val[k]) continue;
                         const float4 t = dag[h][it] * rows[k][h][it];   // d_aggr * x_j
                         if constexpr (EMUL) {
                             float4 e4 = f4zero();
 #pragma unroll
                             for (int kk = 0; kk < DE; ++kk) {
-                                const float4 w = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
-                                fma4(e4, ea[kk], w);
-                                fma4(dw[kk][h][it], ea[kk] * alpha[h], t);
-                                if (a.d_edge_attr) dea[kk] = fmaf(alpha[h], dot4(t, w), dea[kk]);
+                                fma4(e4, eav[k][kk], wv[kk]);
+                                fma4(dw[kk][h][it], eav[k][kk] * alpha[k][h], t);
                             }
-                            part += dot4(t, e4);
+                            part[k] += dot4(t, e4);
                         } else {
-                            part += t.x + t.y + t.z + t.w;
+                            part[k] += t.x + t.y + t.z + t.w;
                         }
                     }
-                    const float dalpha = group_sum<G>(part);
-                    const float dl = alpha[h] * (dalpha - dot[h]);
-                    dp[h] = pre[h] > 0.f ? dl : dl * a.slope;
-                    dai[h] += dp[h];
-#pragma unroll
-                    for (int kk = 0; kk < DE; ++kk) dM[kk][h] = fmaf(ea[kk], dp[h], dM[kk][h]);
                 }
-                if (a.d_edge_attr) {
 #pragma unroll
-                    for (int kk = 0; kk < DE; ++kk) {
-                        float v = EMUL ? group_sum<G>(dea[kk]) : 0.f;
+                for (int k = 0; k < CH; ++k) {
+                    if (!val[k]) continue;
+                    const float dalpha = group_sum<G>(part[k]);
+                    const float dl = alpha[k][h] * (dalpha - dot[h]);
+                    dp[k][h] = pre[k][h] > 0.f ? dl : dl * a.slope;
+                    dai[h] += dp[k][h];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) v = fmaf(dp[h], Mr[kk][h], v);
-                        dea[kk] = v;
-                    }
-                    if (lg == 0) {
-#pragma unroll
-                        for (int i = 0; i < DE / 4; ++i)
-                            st4(a.d_edge_attr + (size_t)id * DE + 4 * i,
-                                make_float4(dea[4 * i], dea[4 * i + 1], dea[4 * i + 2], dea[4 * i + 3]));
-                    }
+                    for (int kk = 0; kk < DE; ++kk) dM[kk][h] = fmaf(eav[k][kk], dp[k][h], dM[kk][h]);
                 }
-                if (lg == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lg == 0) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (!val[k]) continue;
                     float4 av = f4zero(), dv = f4zero();
                     float* ap = &av.x; float* dpp = &dv.x;
 #pragma unroll
-                    for (int h = 0; h < H; ++h) { ap[h] = alpha[h]; dpp[h] = dp[h]; }
-                    st4(a.alpha_e + (size_t)id * 4, av);
-                    st4(a.dpre_e + (size_t)id * 4, dv);
+                    for (int h = 0; h < H; ++h) { ap[h] = alpha[k][h]; dpp[h] = dp[k][h]; }
+                    st4(a.alpha_e + (size_t)eidx[k] * 4, av);
+                    st4(a.dpre_e + (size_t)eidx[k] * 4, dv);
                 }
             }
         }
@@ -470,6 +471,67 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
     float* out = a.partial + (size_t)blockIdx.x * P;
     for (int i = tid; i < P; i += kBlock)
         out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// optional: gradient w.r.t. edge_attr (edge features are data in every reference configuration, so this
+// only runs when a caller asks for it).  Runs after B1 (needs alpha_e / dpre_e):
+//   d_edge_attr[e,k] = sum_h dpre[e,h] M[k,h] + sum_{h,c} alpha[e,h] d_aggr[dst,h,c] xw[src,h,c] W_edge[k,h,c]
+// ------------------------------------------------------------------------------------------------
+struct BwdDeaArgs {
+    const float* xw; const float* w_edge; const float* M; const float* d_aggr; const float* alpha_e; const float* dpre_e;
+    const int* rowptr; const int* nbr; const int* eid;
+    int N; int Cp;
+    float* d_edge_attr;
+};
+
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock) k_triplet_bwd_dea(BwdDeaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
+        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+        for (int e = beg; e < end; ++e) {
+            const int sidx = a.nbr[e], id = a.eid[e];
+            const float4 al = ld4(a.alpha_e + (size_t)id * 4), dpv = ld4(a.dpre_e + (size_t)id * 4);
+            float dea[DE];
+#pragma unroll
+            for (int kk = 0; kk < DE; ++kk) dea[kk] = 0.f;
+            if constexpr (EMUL) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        const int qq = lg + G * it;
+                        if (qq >= Q) continue;
+                        const float4 t = ld4(a.d_aggr + (size_t)n * HC + h * Cp + qq * 4) *
+                                         ld4(a.xw + (size_t)sidx * HC + h * Cp + qq * 4);
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk)
+                            dea[kk] = fmaf(f4get(al, h), dot4(t, ld4(s_w + (kk * H + h) * Cp + qq * 4)), dea[kk]);
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < DE; ++kk) {
+                float v = EMUL ? group_sum<G>(dea[kk]) : 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) v = fmaf(f4get(dpv, h), a.M[kk * 4 + h], v);
+                dea[kk] = v;
+            }
+            if (lg == 0) {
+#pragma unroll
+                for (int i = 0; i < DE / 4; ++i)
+                    st4(a.d_edge_attr + (size_t)id * DE + 4 * i, make_float4(dea[4 * i], dea[4 * i + 1], dea[4 * i + 2], dea[4 * i + 3]));
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -616,6 +678,12 @@ struct BwdDstOp {
     }
 };
 template <int H, int G, int ITER, int DE, bool EMUL>
+struct BwdDeaOp {
+    static void run(const BwdDeaArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_bwd_dea<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+template <int H, int G, int ITER, int DE, bool EMUL>
 struct BwdSrcOp {
     static void run(const BwdSrcArgs& a, int grid, size_t lds, hipStream_t s) {
         hipLaunchKernelGGL((k_triplet_bwd_src<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
@@ -750,7 +818,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     float* partial = dpre_e + (size_t)E * 4;
 
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
-                  alpha_e, dpre_e, d_a_ij, d_edge_attr, partial};
+                  alpha_e, dpre_e, d_a_ij, partial};
     const size_t lds1 = ((size_t)WSZ + 4 * (size_t)P) * sizeof(float);
     int nblk = 0;
     if (!dispatch<BwdDstOp>(H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
@@ -762,6 +830,12 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     } else {
         *partial_out = partial;
         *nblk_out = nblk;
+    }
+    if (d_edge_attr) {
+        BwdDeaArgs bd{xw, w_edge, M, d_aggr, alpha_e, dpre_e, rowptr, src, eid, (int)N, Cp, d_edge_attr};
+        if (!dispatch<BwdDeaOp>(H, De, emul, sh, bd, (int)N, (size_t)WSZ * sizeof(float), s, kMaxBlocks, nullptr))
+            return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
+        GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
     }
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij};
     const size_t lds2 = (size_t)WSZ * sizeof(float);

@@ -111,7 +111,7 @@ class TripletMessage(MessagePassing):
         if ops.fused_layer_supported(C, self.heads, De):
             # whole layer in HIP: staging, MFMA node GEMM, fused aggregate, MFMA update (+ its backward)
             x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
-            out = ops.triplet_layer(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att[0],
+            out = ops.triplet_layer(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,
                                     self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
             return out[:, :C] if Cp != C else out
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: full Architecture (mol_lin0 -> 3 x MessageBlock(_TripletMessage, GRU) -> GlobalPool5 ->
+mol_flat -> lin_out1) fwd + bwd + Adam step on an ESOL-shaped batch (the reference's train iteration,
+src_1gp/trainer.py:286-298).  Not the headline metric (bench.py is)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from glam_amd import model
+from glam_amd.data import synth_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--norm", default="_None")
+ap.add_argument("--block", default="_TripletMessage")
+ap.add_argument("--no-graph", action="store_true")
+ap.add_argument("--profile", action="store_true")
+args = ap.parse_args()
+dev = torch.device("cuda")
+torch.manual_seed(0)
+net = model.Architecture(mol_block=args.block, message_steps=3, mol_readout="GlobalPool5", graph_norm=args.norm,
+                         graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
+b = synth_batch(args.batch, seed=0).to(dev)
+y = b.y.view(-1)
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+
+def body():
+    opt.zero_grad(set_to_none=True)
+    loss = torch.nn.functional.mse_loss(net(b).view(-1), y)
+    loss.backward()
+    opt.step()
+
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3): body()
+torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+g = None
+if not args.no_graph:
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g): body()
+step = g.replay if g is not None else body
+for _ in range(10): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(args.steps): step()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(json.dumps({"workload": f"Architecture({args.block}, 3 steps, GlobalPool5, e_dim=1024, norm={args.norm}) fwd+bwd+Adam, B={args.batch}",
+                  "launch": "eager" if g is None else "hipGraph", "ms_per_step": dt / args.steps * 1e3,
+                  "molecules_per_s": args.batch * args.steps / dt}))
