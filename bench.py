@@ -45,6 +45,22 @@ def algorithmic_bytes(N, E, H=3, C=60, De=4):
     return {"k_triplet_fwd": fwd, "k_triplet_bwd_dst": b1, "k_triplet_bwd_src": b2}
 
 
+def pmc_traffic(kernel, N):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_hbm_traffic_pmc.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this script, reads doubled per the gfx950 note of
+    MI355X_MICROARCH.md §HBM).  Matched on the launch's thread count; None when no matching measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")
+    try:
+        rows = json.load(open(path))
+    except OSError:
+        return None
+    want = f"grid={(N + 15) // 16 * 256}"
+    for key, row in rows.items():
+        if kernel in key and key.endswith(want):
+            return row["hbm_bytes"]
+    return None
+
+
 def time_kernels(conv, batch, x, reps=200):
     """Average duration of each hand-written aggregate kernel: `reps` back-to-back launches between two
     HIP events on the stream the kernels are launched on (torch's current stream)."""
@@ -228,7 +244,7 @@ def main():
         achieved = ab["k_triplet_fwd"] / (fwd_us * 1e-6) / 1e9
         result["roofline"] = {"kernel": "k_triplet_fwd<3,16,1,4,true> (gather + segment softmax + scatter-add)",
                               "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_triplet_fwd", N),
                               "algorithmic_bytes": ab["k_triplet_fwd"], "avg_launch_us": fwd_us,
                               "workload": f"B={B}"}
         bwd_bytes = ab["k_triplet_bwd_dst"] + ab["k_triplet_bwd_src"]

@@ -135,7 +135,13 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
 // G[I, J] = [P1 | P2 | 1]^T @ Q.  A wave owns a 16 x 64 output slab (4 accumulator tiles) over its own row
 // range: per 4-row step one scalar load feeds the A operand (P[n][i0 + c]) and ONE float4 load the B
 // operands of the 4 column tiles (stride-4 column permutation: tile tj holds columns 4c + tj).
-constexpr int kWgBlock = 1024;        // 16 waves (4 per SIMD): row ranges interleave, loads hide behind MFMAs
+#ifndef GLAM_WG_BLOCK
+#define GLAM_WG_BLOCK 1024
+#endif
+#ifndef GLAM_WG_STEPS
+#define GLAM_WG_STEPS 8
+#endif
+constexpr int kWgBlock = GLAM_WG_BLOCK;        // 16 waves (4 per SIMD): row ranges interleave, loads hide behind MFMAs
 constexpr int kWgWaves = kWgBlock / 64;
 
 __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
@@ -160,7 +166,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) acc[tj] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int kSteps = 8;             // 32 rows per batch: 16 loads in flight, then 32 MFMAs
+    constexpr int kSteps = GLAM_WG_STEPS; // rows/4 per batch: 2*kSteps loads in flight, then 4*kSteps MFMAs
     for (int n0 = row0; n0 < row1; n0 += 4 * kSteps) {
         float pv[kSteps];
         float4 qv[kSteps];

@@ -1,0 +1,10 @@
+// Kernel instantiations of triplet_kernels.h for heads = 3 (one translation unit per head count so that the
+// ~100 template variants compile in parallel).
+#include "triplet_kernels.h"
+
+namespace glam {
+bool triplet_launch_h3(int kind, int De, int emul, Shape sh, const void* args, int nodes, size_t lds, hipStream_t s,
+                        int cap, int* grid_out) {
+    return triplet_launch_impl<3>(kind, De, emul, sh, args, nodes, lds, s, cap, grid_out);
+}
+}  // namespace glam

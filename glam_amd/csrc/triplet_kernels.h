@@ -1,0 +1,724 @@
+// Fused neighbour-gather / attention-logit / segment-softmax / weighted scatter-add kernels for
+// TripletMessage and TripletMessageLight (reference: src_1gp/layer.py:40-55 and :88-97, executed
+// there as PyG propagate -> message -> torch_scatter aggregate).
+//
+// Mapping (gfx950, wave64): a target node is owned by a GROUP of G consecutive lanes (G in
+// {4,8,16}); lane l of the group owns the float4 channel chunks q = l + G*it (it < ITER) of EVERY
+// head, so one 16-byte load per (edge, head, it) streams the neighbour row xw[src,h,:] and a
+// wavefront processes 64/G nodes at once.  Degree-1..4 molecular segments and degree-100 protein
+// segments take the same code path (the group walks its CSR segment serially; groups of one wave
+// diverge only in trip count).  The attention logits are separable:
+//   logit = leaky(a_i[dst] + <edge_attr[e], M> + a_j[src]),
+// so no [E,H,3C] triplet tensor is ever formed; e_ij = edge_attr[e] @ W_edge is recomputed from the
+// LDS-resident W_edge (De*H*Cp floats) instead of materialising ew[E,H*C].
+// No atomics anywhere: forward reduces a CSR-by-target segment in registers, backward B1 walks the
+// same segments, backward B2 walks the CSR transpose (by source).  Results are bit-reproducible.
+#pragma once
+#include "dense.h"
+
+// occupancy targets (waves per SIMD) the register allocator is held to; tuned on MI355X
+#ifndef GLAM_FWD_WAVES
+#define GLAM_FWD_WAVES 1
+#endif
+#ifndef GLAM_FWD_CH
+#define GLAM_FWD_CH 4
+#endif
+#ifndef GLAM_B1_CH
+#define GLAM_B1_CH 4
+#endif
+#ifndef GLAM_B1_WAVES
+#define GLAM_B1_WAVES 1
+#endif
+
+namespace glam {
+
+struct FwdArgs {
+    const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
+    const int* rowptr; const int* nbr; const int* eid;
+    int N; int Cp; float slope;
+    float* aggr; float* stats;
+    // optional fused update (G == 16 only): out[N,Cp] = aggr @ W_scale + bias, W_scale as a k_ts_gemm image
+    const float* img_upd; const float* bias_p; float* out;
+};
+
+template <int DE>
+__device__ __forceinline__ void load_edge_attr(const float* edge_attr, int id, float (&ea)[DE]) {
+    const float* p = edge_attr + (size_t)id * DE;
+#pragma unroll
+    for (int i = 0; i < DE / 4; ++i) {
+        float4 v = ld4(p + 4 * i);
+        ea[4 * i + 0] = v.x; ea[4 * i + 1] = v.y; ea[4 * i + 2] = v.z; ea[4 * i + 3] = v.w;
+    }
+}
+
+// pre-activation attention logit of one edge for every head
+template <int H, int DE>
+__device__ __forceinline__ void edge_pre(const float (&ai)[H], const float4 aj, const float (&ea)[DE],
+                                         const float (&Mr)[DE][H], float (&pre)[H]) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float ee = 0.f;
+#pragma unroll
+        for (int k = 0; k < DE; ++k) ee = fmaf(ea[k], Mr[k][h], ee);
+        pre[h] = ai[h] + ee + f4get(aj, h);
+    }
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// e_ij chunk = sum_k edge_attr[e,k] * W_edge[k,h,chunk]  (W_edge in LDS)
+template <int H, int DE>
+__device__ __forceinline__ float4 edge_chunk(const float* s_w, const float (&ea)[DE], int h, int Cp, int q) {
+    float4 e4 = f4zero();
+#pragma unroll
+    for (int k = 0; k < DE; ++k) fma4(e4, ea[k], ld4(s_w + (k * H + h) * Cp + q * 4));
+    return e4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    float Mr[DE][H];
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) Mr[k][h] = a.M[k * 4 + h];
+
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    int q[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        q[it] = lg + G * it;
+        ok[it] = q[it] < Q;
+        if (!ok[it]) q[it] = 0;
+    }
+
+    // Edges are processed CH at a time with every load of a chunk in flight together (indices -> {edge
+    // features, a_j, neighbour rows}): a degree <= CH segment (all molecular nodes) costs 3 dependent
+    // memory round trips instead of 2 + 2*deg.
+    constexpr int CH = ITER == 1 ? GLAM_FWD_CH : 2;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const bool fuse_upd = (G == 16) && a.img_upd != nullptr;
+    const int LDT = HC + 4;                                    // LDS row pitch of the 16-node aggr tile
+    float* s_tile = s_w + (EMUL ? DE * HC : 0);
+    float* s_out = s_tile + 16 * LDT;
+    for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
+      const int n = base + tid / G;
+      if (n < a.N) {
+        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+        const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
+        float ai[H], m[H], ssum[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { ai[h] = f4get(aiv, h); m[h] = -INFINITY; ssum[h] = 0.f; }
+        float4 acc[H][ITER];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) acc[h][it] = f4zero();
+
+        int sidx[CH], eidx[CH];
+        bool val[CH];
+        float ea[CH][DE], lk[CH][H];
+        float4 rows[CH][H][ITER];
+        auto load_idx = [&](int e0) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                val[k] = e0 + k < end;
+                const int e = val[k] ? e0 + k : end - 1;
+                sidx[k] = a.nbr[e];
+                eidx[k] = a.eid[e];
+            }
+        };
+        auto load_rows = [&]() {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it)
+                        rows[k][h][it] = val[k] ? ld4(a.xw + (size_t)sidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+        };
+        auto load_logits = [&]() {
+            float4 aj[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                load_edge_attr<DE>(a.edge_attr, eidx[k], ea[k]);
+                aj[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                float pre[H];
+                edge_pre<H, DE>(ai, aj[k], ea[k], Mr, pre);
+#pragma unroll
+                for (int h = 0; h < H; ++h) lk[k][h] = leaky(pre[h], a.slope);
+            }
+        };
+        auto take_max = [&]() {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    if (val[k]) m[h] = fmaxf(m[h], lk[k][h]);
+        };
+        auto accumulate = [&]() {
+            // head-major: the W_edge chunk of one head (DE float4 from LDS) is live for one head only
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 wv[EMUL ? DE : 1];
+                    if constexpr (EMUL) {
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!val[k]) continue;
+                        const float p = expf(lk[k][h] - m[h]);
+                        if (it == 0) ssum[h] += p;
+                        float4 xj = rows[k][h][it];
+                        if constexpr (EMUL) {
+                            float4 e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, ea[k][kk], wv[kk]);
+                            xj = e4 * xj;
+                        }
+                        fma4(acc[h][it], p, xj);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (end - beg <= CH) {
+            if (end > beg) {
+                load_idx(beg);
+                load_rows();
+                load_logits();
+                take_max();
+                accumulate();
+            }
+        } else {
+            for (int e0 = beg; e0 < end; e0 += CH) { load_idx(e0); load_logits(); take_max(); }   // pass 1: segment max
+            for (int e0 = beg; e0 < end; e0 += CH) { load_idx(e0); load_rows(); load_logits(); accumulate(); }
+        }
+        float* orow = a.aggr + (size_t)n * HC;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float inv = 1.f / (ssum[h] + 1e-16f);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+                if (ok[it]) {
+                    const float4 v = inv * acc[h][it];
+                    st4(orow + h * Cp + q[it] * 4, v);
+                    if constexpr (G == 16) {
+                        if (fuse_upd) st4(s_tile + (tid / G) * LDT + h * Cp + q[it] * 4, v);
+                    }
+                }
+        }
+        if (lg == 0) {
+            float4 mv = f4zero(), sv = f4zero();
+            float* mp = &mv.x; float* sp = &sv.x;
+#pragma unroll
+            for (int h = 0; h < H; ++h) { mp[h] = (end > beg) ? m[h] : 0.f; sp[h] = ssum[h]; }
+            st4(a.stats + (size_t)n * 8, mv);
+            st4(a.stats + (size_t)n * 8 + 4, sv);
+        }
+      }
+      if constexpr (G == 16) {
+        // ---- fused update: out[16 nodes, Cp] = aggr_tile[16, HC] @ W_scale + bias on the fp32 matrix cores ----
+        // wave w owns output column tile w (logical columns 4c + w); B fragments straight from the L2-resident
+        // weight image (one float4 per 16-k group, all loads in flight), A fragments from the LDS tile.
+        if (fuse_upd) {
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+            const int GK = (HC + 15) >> 4;
+            v4f cacc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int g0 = 0; g0 < GK; g0 += 4) {          // 4 k-groups (64 k values) per batch: 8 loads in flight
+                float4 bf[4], af[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u, k0 = 16 * g + 4 * kq;
+                    bf[u] = g < GK ? ld4(a.img_upd + ((size_t)(4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
+                    af[u] = (g < GK && k0 < HC) ? ld4(s_tile + c * LDT + k0) : f4zero();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[u], j), f4get(bf[u], j), cacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_out[(kq * 4 + i) * 64 + 4 * c + wave] = cacc[i];
+            __syncthreads();
+            const int row = tid >> 4, c4 = (tid & 15) * 4;
+            if (c4 < Cp && base + row < a.N) {
+                float4 v = ld4(s_out + row * 64 + c4);
+                const float4 b = ld4(a.bias_p + c4);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                st4(a.out + (size_t)(base + row) * Cp + c4, v);
+            }
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward B1: walk CSR-by-target.  Per edge: recompute alpha, d_alpha = <d_aggr[dst], e_ij*xw[src]>,
+// softmax + leaky backward -> dpre; accumulate d_a_i per node and d_W_edge / d_M per lane.
+// ------------------------------------------------------------------------------------------------
+struct BwdDstArgs {
+    const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
+    const float* aggr; const float* stats; const float* d_aggr;
+    const int* rowptr; const int* nbr; const int* eid;
+    int N; int Cp; float slope;
+    float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;
+};
+
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    const int WSZ = EMUL ? DE * HC : 0;          // floats of staged W_edge
+    const int P = WSZ + DE * 4;                  // floats of one block partial: d_W_edge | d_M
+    float* s_w = s_mem;
+    float* s_red = s_mem + WSZ;                  // [4 waves][P]
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    float Mr[DE][H];
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) Mr[k][h] = a.M[k * 4 + h];
+
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    int q[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        q[it] = lg + G * it;
+        ok[it] = q[it] < Q;
+        if (!ok[it]) q[it] = 0;
+    }
+
+    float4 dw[EMUL ? DE : 1][H][ITER];
+    float dM[DE][H];
+#pragma unroll
+    for (int k = 0; k < (EMUL ? DE : 1); ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) dw[k][h][it] = f4zero();
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) dM[k][h] = 0.f;
+
+    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
+        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+        const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
+        const float4 mv = ld4(a.stats + (size_t)n * 8), sv = ld4(a.stats + (size_t)n * 8 + 4);
+        float ai[H], m[H], inv[H], dot[H], dai[H];
+        float4 dag[H][ITER];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            ai[h] = f4get(aiv, h); m[h] = f4get(mv, h); inv[h] = 1.f / (f4get(sv, h) + 1e-16f); dai[h] = 0.f;
+            float part = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const size_t off = (size_t)n * HC + h * Cp + q[it] * 4;
+                dag[h][it] = ok[it] ? ld4(a.d_aggr + off) : f4zero();
+                part += dot4(dag[h][it], ld4(a.aggr + off));
+            }
+            // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
+            dot[h] = group_sum<G>(part);
+        }
+        constexpr int CH = ITER == 1 ? GLAM_B1_CH : 2;   // edges per chunk: all loads of a chunk in flight together
+        for (int e0 = beg; e0 < end; e0 += CH) {
+            int sidx[CH], eidx[CH];
+            bool val[CH];
+            float eav[CH][DE];
+            float4 ajv[CH], rows[CH][H][ITER];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                val[k] = e0 + k < end;
+                const int e = val[k] ? e0 + k : end - 1;
+                sidx[k] = a.nbr[e];
+                eidx[k] = a.eid[e];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it)
+                        rows[k][h][it] = val[k] ? ld4(a.xw + (size_t)sidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+                load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
+                ajv[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
+            }
+            float pre[CH][H], alpha[CH][H], dp[CH][H];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) edge_pre<H, DE>(ai, ajv[k], eav[k], Mr, pre[k]);
+            // head-major: the W_edge chunk of one head is live for one head only
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float part[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    part[k] = 0.f;
+                    alpha[k][h] = expf(leaky(pre[k][h], a.slope) - m[h]) * inv[h];
+                }
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 wv[EMUL ? DE : 1];
+                    if constexpr (EMUL) {
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!val[k]) continue;
+                        const float4 t = dag[h][it] * rows[k][h][it];   // d_aggr * x_j
+                        if constexpr (EMUL) {
+                            float4 e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) {
+                                fma4(e4, eav[k][kk], wv[kk]);
+                                fma4(dw[kk][h][it], eav[k][kk] * alpha[k][h], t);
+                            }
+                            part[k] += dot4(t, e4);
+                        } else {
+                            part[k] += t.x + t.y + t.z + t.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (!val[k]) continue;
+                    const float dalpha = group_sum<G>(part[k]);
+                    const float dl = alpha[k][h] * (dalpha - dot[h]);
+                    dp[k][h] = pre[k][h] > 0.f ? dl : dl * a.slope;
+                    dai[h] += dp[k][h];
+#pragma unroll
+                    for (int kk = 0; kk < DE; ++kk) dM[kk][h] = fmaf(eav[k][kk], dp[k][h], dM[kk][h]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lg == 0) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (!val[k]) continue;
+                    float4 av = f4zero(), dv = f4zero();
+                    float* ap = &av.x; float* dpp = &dv.x;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) { ap[h] = alpha[k][h]; dpp[h] = dp[k][h]; }
+                    st4(a.alpha_e + (size_t)eidx[k] * 4, av);
+                    st4(a.dpre_e + (size_t)eidx[k] * 4, dv);
+                }
+            }
+        }
+        if (lg == 0) {
+            float4 dv = f4zero();
+            float* dpp = &dv.x;
+#pragma unroll
+            for (int h = 0; h < H; ++h) dpp[h] = dai[h];
+            st4(a.d_a_ij + (size_t)n * 8, dv);
+        }
+    }
+
+    // ---- block partial of d_W_edge | d_M: wave shuffle across groups, then 4 waves via LDS ----
+    const int wave = tid >> 6, lane = tid & 63;
+    float* red = s_red + wave * P;
+    if constexpr (EMUL) {
+#pragma unroll
+        for (int k = 0; k < DE; ++k)
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 v = dw[k][h][it];
+                    v.x = cross_group_sum<G>(v.x); v.y = cross_group_sum<G>(v.y);
+                    v.z = cross_group_sum<G>(v.z); v.w = cross_group_sum<G>(v.w);
+                    if (lane < G && ok[it]) st4(red + (k * H + h) * Cp + q[it] * 4, v);
+                }
+    }
+#pragma unroll
+    for (int k = 0; k < DE; ++k) {
+        float4 v = f4zero();
+        float* vp = &v.x;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            // every lane of a group holds the same dM; pick lane 0 of each group before the sum
+            vp[h] = cross_group_sum<G>(dM[k][h]);
+        }
+        if (lane == 0) st4(red + WSZ + k * 4, v);
+    }
+    __syncthreads();
+    float* out = a.partial + (size_t)blockIdx.x * P;
+    for (int i = tid; i < P; i += kBlock)
+        out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// optional: gradient w.r.t. edge_attr (edge features are data in every reference configuration, so this
+// only runs when a caller asks for it).  Runs after B1 (needs alpha_e / dpre_e):
+//   d_edge_attr[e,k] = sum_h dpre[e,h] M[k,h] + sum_{h,c} alpha[e,h] d_aggr[dst,h,c] xw[src,h,c] W_edge[k,h,c]
+// ------------------------------------------------------------------------------------------------
+struct BwdDeaArgs {
+    const float* xw; const float* w_edge; const float* M; const float* d_aggr; const float* alpha_e; const float* dpre_e;
+    const int* rowptr; const int* nbr; const int* eid;
+    int N; int Cp;
+    float* d_edge_attr;
+};
+
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock) k_triplet_bwd_dea(BwdDeaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
+        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+        for (int e = beg; e < end; ++e) {
+            const int sidx = a.nbr[e], id = a.eid[e];
+            const float4 al = ld4(a.alpha_e + (size_t)id * 4), dpv = ld4(a.dpre_e + (size_t)id * 4);
+            float dea[DE];
+#pragma unroll
+            for (int kk = 0; kk < DE; ++kk) dea[kk] = 0.f;
+            if constexpr (EMUL) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        const int qq = lg + G * it;
+                        if (qq >= Q) continue;
+                        const float4 t = ld4(a.d_aggr + (size_t)n * HC + h * Cp + qq * 4) *
+                                         ld4(a.xw + (size_t)sidx * HC + h * Cp + qq * 4);
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk)
+                            dea[kk] = fmaf(f4get(al, h), dot4(t, ld4(s_w + (kk * H + h) * Cp + qq * 4)), dea[kk]);
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < DE; ++kk) {
+                float v = EMUL ? group_sum<G>(dea[kk]) : 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) v = fmaf(f4get(dpv, h), a.M[kk * 4 + h], v);
+                dea[kk] = v;
+            }
+            if (lg == 0) {
+#pragma unroll
+                for (int i = 0; i < DE / 4; ++i)
+                    st4(a.d_edge_attr + (size_t)id * DE + 4 * i, make_float4(dea[4 * i], dea[4 * i + 1], dea[4 * i + 2], dea[4 * i + 3]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward B2: walk the CSR transpose (by source).  d_xw[j] = sum_{e: src=j} alpha_e * e_ij * d_aggr[dst],
+// d_a_j[j] = sum dpre_e.
+// ------------------------------------------------------------------------------------------------
+struct BwdSrcArgs {
+    const float* edge_attr; const float* w_edge; const float* d_aggr; const float* alpha_e; const float* dpre_e;
+    const int* colptr; const int* nbr; const int* eid;
+    int N; int Cp;
+    float* d_xw; float* d_a_ij;
+};
+
+template <int H, int G, int ITER, int DE, bool EMUL>
+__global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdSrcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int tid = threadIdx.x;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    if constexpr (EMUL) {
+        for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        __syncthreads();
+    }
+    const int lg = tid % G;
+    constexpr int GPB = kBlock / G;
+    int q[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        q[it] = lg + G * it;
+        ok[it] = q[it] < Q;
+        if (!ok[it]) q[it] = 0;
+    }
+    for (int j = blockIdx.x * GPB + tid / G; j < a.N; j += gridDim.x * GPB) {
+        const int beg = a.colptr[j], end = a.colptr[j + 1];
+        float4 acc[H][ITER];
+        float4 daj = f4zero();
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) acc[h][it] = f4zero();
+        constexpr int CH = ITER == 1 ? 4 : 2;   // edges per chunk: all loads of a chunk in flight together
+        for (int e0 = beg; e0 < end; e0 += CH) {
+            int nidx[CH], eidx[CH];
+            bool val[CH];
+            float4 alv[CH], dpv[CH], rows[CH][H][ITER];
+            float eav[CH][DE];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                val[k] = e0 + k < end;
+                const int e = val[k] ? e0 + k : end - 1;
+                nidx[k] = a.nbr[e];
+                eidx[k] = a.eid[e];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it)
+                        rows[k][h][it] = val[k] ? ld4(a.d_aggr + (size_t)nidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+                alv[k] = ld4(a.alpha_e + (size_t)eidx[k] * 4);
+                dpv[k] = ld4(a.dpre_e + (size_t)eidx[k] * 4);
+                if constexpr (EMUL) load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (val[k]) { daj.x += dpv[k].x; daj.y += dpv[k].y; daj.z += dpv[k].z; daj.w += dpv[k].w; }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    float4 wv[EMUL ? DE : 1];
+                    if constexpr (EMUL) {
+#pragma unroll
+                        for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + q[it] * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if (!val[k]) continue;
+                        float4 dg = rows[k][h][it];
+                        if constexpr (EMUL) {
+                            float4 e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, eav[k][kk], wv[kk]);
+                            dg = e4 * dg;
+                        }
+                        fma4(acc[h][it], f4get(alv[k], h), dg);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float* orow = a.d_xw + (size_t)j * HC;
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+                if (ok[it]) st4(orow + h * Cp + q[it] * 4, acc[h][it]);
+        if (lg == 0) st4(a.d_a_ij + (size_t)j * 8 + 4, daj);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct FwdOp {
+    static void run(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct BwdDstOp {
+    static void run(const BwdDstArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct BwdDeaOp {
+    static void run(const BwdDeaArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_bwd_dea<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+template <int H, int G, int ITER, int DE, bool EMUL>
+struct BwdSrcOp {
+    static void run(const BwdSrcArgs& a, int grid, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((k_triplet_bwd_src<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
+};
+
+struct Shape { int G, ITER; };
+// smallest G*ITER that covers Q = Cp/4 chunks per head
+inline bool pick_shape(int Q, Shape* s) {
+    if (Q <= 4) *s = {4, 1};
+    else if (Q <= 8) *s = {8, 1};
+    else if (Q <= 12) *s = {4, 3};
+    else if (Q <= 16) *s = {16, 1};
+    else if (Q <= 24) *s = {8, 3};
+    else if (Q <= 32) *s = {16, 2};
+    else if (Q <= 64) *s = {16, 4};
+    else return false;
+    return true;
+}
+
+template <template <int, int, int, int, bool> class Op, int H, int DE, bool EMUL, typename Args>
+inline bool dispatch_shape(Shape sh, const Args& a, int nodes, size_t lds, hipStream_t s, int cap, int* grid_out) {
+#define GLAM_CASE(G_, IT_)                                                   \
+    if (sh.G == G_ && sh.ITER == IT_) {                                      \
+        const int grid = grid_for(nodes, kBlock / G_, cap);                  \
+        if (grid_out) *grid_out = grid;                                      \
+        Op<H, G_, IT_, DE, EMUL>::run(a, grid, lds, s);                      \
+        return true;                                                         \
+    }
+    GLAM_CASE(4, 1) GLAM_CASE(8, 1) GLAM_CASE(4, 3) GLAM_CASE(16, 1) GLAM_CASE(8, 3) GLAM_CASE(16, 2) GLAM_CASE(16, 4)
+#undef GLAM_CASE
+    return false;
+}
+
+
+// One translation unit per head count (triplet_h1..h4.hip) instantiates the kernels; these are their entry
+// points: kind 0 = forward, 1 = backward by target (B1), 2 = backward by source (B2), 3 = d_edge_attr.
+enum { kTripletFwd = 0, kTripletBwdDst = 1, kTripletBwdSrc = 2, kTripletBwdDea = 3 };
+#define GLAM_DECLARE_TRIPLET_H(HH)                                                                                  \
+    bool triplet_launch_h##HH(int kind, int De, int emul, Shape sh, const void* args, int nodes, size_t lds,        \
+                              hipStream_t s, int cap, int* grid_out);
+GLAM_DECLARE_TRIPLET_H(1) GLAM_DECLARE_TRIPLET_H(2) GLAM_DECLARE_TRIPLET_H(3) GLAM_DECLARE_TRIPLET_H(4)
+#undef GLAM_DECLARE_TRIPLET_H
+
+template <int HH>
+inline bool triplet_launch_impl(int kind, int De, int emul, Shape sh, const void* args, int nodes, size_t lds, hipStream_t s,
+                                int cap, int* grid_out) {
+#define GLAM_KIND(K_, Op_, Args_)                                                                                         \
+    if (kind == K_) {                                                                                                     \
+        const Args_& a = *static_cast<const Args_*>(args);                                                                \
+        if (emul && De == 4) return dispatch_shape<Op_, HH, 4, true>(sh, a, nodes, lds, s, cap, grid_out);               \
+        if (emul && De == 8) return dispatch_shape<Op_, HH, 8, true>(sh, a, nodes, lds, s, cap, grid_out);               \
+        if constexpr (HH == 1) {  /* TripletMessageLight / GAT: single head, message alpha * x_j */                       \
+            if (!emul && De == 4) return dispatch_shape<Op_, 1, 4, false>(sh, a, nodes, lds, s, cap, grid_out);          \
+            if (!emul && De == 8) return dispatch_shape<Op_, 1, 8, false>(sh, a, nodes, lds, s, cap, grid_out);          \
+        }                                                                                                                 \
+        return false;                                                                                                     \
+    }
+    GLAM_KIND(kTripletFwd, FwdOp, FwdArgs) GLAM_KIND(kTripletBwdDst, BwdDstOp, BwdDstArgs)
+    GLAM_KIND(kTripletBwdSrc, BwdSrcOp, BwdSrcArgs) GLAM_KIND(kTripletBwdDea, BwdDeaOp, BwdDeaArgs)
+#undef GLAM_KIND
+    return false;
+}
+
+}  // namespace glam

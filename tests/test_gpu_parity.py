@@ -428,3 +428,89 @@ def test_wgrad_gemm(device, N, I1, I2, ones, J):
         assert rc == 0, lib.glam_last_error()
         got = out if si == J else out.t()
         assert_close(got, ref, 3e-6 * max(1.0, N ** 0.5 / 10), "wgrad")
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases of the boundary
+# ---------------------------------------------------------------------------------------------
+def test_no_edges_and_no_nodes(device):
+    """A batch of single-atom molecules has E = 0: every output row is the bias (isolated nodes); N = 0 works too."""
+    torch.manual_seed(3)
+    conv = layer.TripletMessage(60, 4).to(device)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(5, 60, device=device, requires_grad=True)
+    ei = torch.zeros(2, 0, dtype=torch.long, device=device)
+    ea = torch.zeros(0, 4, device=device)
+    out = conv(x, ei, ea)
+    assert_close(out, conv.bias.detach().expand(5, 60), 1e-7, "E=0 -> bias")
+    (gx,) = torch.autograd.grad(out.sum(), [x])
+    assert float(gx.abs().max()) == 0.0
+    light = layer.TripletMessageLight(60, 4).to(device)
+    assert_close(light(x, ei, ea), light.bias.detach().expand(5, 60), 1e-7, "light E=0 -> bias")
+    out0 = conv(torch.zeros(0, 60, device=device), ei, ea)
+    assert out0.shape == (0, 60)
+    pooled = layer.GlobalPool5()(x, torch.tensor([0, 0, 2, 2, 2], device=device), 4)   # graphs 1 and 3 are empty
+    assert pooled.shape == (4, 300) and float(pooled[1].abs().max()) == 0.0 and float(pooled[3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("heads,C,De", [(1, 60, 4), (2, 32, 1), (4, 44, 3)])
+def test_other_head_counts_and_edge_widths(device, heads, C, De):
+    torch.manual_seed(heads * 10 + De)
+    b = synth_batch(40, seed=heads)
+    N, E = b.x.size(0), b.edge_index.size(1)
+    x0 = torch.randn(N, C)
+    ea0 = torch.rand(E) if De == 1 else torch.rand(E, De)       # 1-D edge_attr takes the unsqueeze path (layer.py:39)
+    conv = layer.TripletMessage(C, De, heads=heads)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    ps0 = [p.detach().clone().requires_grad_(True) for p in conv.parameters()]
+    xo = x0.clone().requires_grad_(True)
+    ref = O.triplet_message(xo, b.edge_index, ea0.view(E, De), *ps0, heads=heads)
+    cot = torch.randn(ref.shape)
+    g_ref = _grads(ref, cot, [xo] + ps0)
+    conv = conv.to(device)
+    x = x0.to(device).requires_grad_(True)
+    out = conv(x, b.edge_index.to(device), ea0.to(device))
+    assert_close(out, ref, TOL, "out")
+    for n, a, r in zip(["x"] + [n for n, _ in conv.named_parameters()], _grads(out, cot.to(device), [x] + list(conv.parameters())), g_ref):
+        assert_close(a, r, 3e-5, f"grad.{n}")
+
+
+def test_hipgraph_capture_replays_identically(device):
+    """Every entry point only enqueues on the current stream: a captured fwd+bwd step replays bit-identically."""
+    torch.manual_seed(9)
+    b = synth_batch(64, seed=4).to(device)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device, requires_grad=True)
+    cot = torch.randn(b.x.size(0), 60, device=device)
+    params = list(conv.parameters())
+
+    def body():
+        out = conv(x, b.edge_index, b.edge_attr)
+        return [out] + list(torch.autograd.grad(out, params + [x], grad_outputs=cot))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eager = [t.clone() for t in body()]          # also stages the CSR + transpose (one-time host sync)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        captured = body()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for a, c in zip(eager, captured):
+        assert torch.equal(a, c)
+
+
+def test_edge_attr_gradient_optional_path(device):
+    g = Golden("triplet_de8")
+    conv = layer.TripletMessage(60, 8).to(device)
+    conv.load_state_dict(g.params)
+    ea = g.inputs["edge_attr"].to(device).requires_grad_(True)
+    out = conv(g.inputs["x"].to(device), g.inputs["edge_index"].to(device), ea)
+    (gea,) = torch.autograd.grad((out * g.cot.to(device)).sum(), [ea])
+    assert_close(gea, g.grads["edge_attr"], 2e-5, "d_edge_attr via k_triplet_bwd_dea")
