@@ -39,7 +39,9 @@ SIGNATURES = {
     "glam_ts_gemm_make_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "glam_ts_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _vp]),
     "glam_wgrad_workspace_bytes": (_sz, []),
-    "glam_wgrad_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "glam_wgrad_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "glam_gru_gates_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "glam_gru_gates_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "glam_triplet_staged_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_dstaged_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_stage_params": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),

@@ -1,0 +1,68 @@
+// MessageBlock remainder (reference: src_1gp/layer.py:261-263): one step of torch.nn.GRU(C, C) with seq_len 1.
+// The two gate GEMMs run on k_ts_gemm (gemm.hip); this file holds the fused gate math and its backward.
+//   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
+// gi = celu(x) @ W_ih^T + b_ih, gh = h @ W_hh^T + b_hh are [N, 3C] (gate order r | z | n, as torch stores them).
+#include "common.h"
+
+namespace glam {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ void __launch_bounds__(kBlock) k_gru_gates_fwd(const float* gi, const float* gh, const float* h, int N, int C,
+                                                         float* h_new) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const size_t n = i / C, c = i % C, b = n * 3 * C + c;
+        const float r = sigmoidf_(gi[b] + gh[b]);
+        const float z = sigmoidf_(gi[b + C] + gh[b + C]);
+        const float nn = tanhf(gi[b + 2 * C] + r * gh[b + 2 * C]);
+        h_new[i] = (1.f - z) * nn + z * h[i];
+    }
+}
+
+// gates are recomputed from gi / gh (cheaper than saving three [N,C] tensors)
+__global__ void __launch_bounds__(kBlock) k_gru_gates_bwd(const float* gi, const float* gh, const float* h,
+                                                         const float* d_hnew, int N, int C, float* d_gi, float* d_gh,
+                                                         float* d_h) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const size_t n = i / C, c = i % C, b = n * 3 * C + c;
+        const float ghn = gh[b + 2 * C];
+        const float r = sigmoidf_(gi[b] + gh[b]);
+        const float z = sigmoidf_(gi[b + C] + gh[b + C]);
+        const float nn = tanhf(gi[b + 2 * C] + r * ghn);
+        const float g = d_hnew[i];
+        const float d_n = g * (1.f - z), d_z = g * (h[i] - nn);
+        const float d_pn = d_n * (1.f - nn * nn);
+        const float d_pr = d_pn * ghn * r * (1.f - r);
+        const float d_pz = d_z * z * (1.f - z);
+        d_gi[b] = d_pr; d_gi[b + C] = d_pz; d_gi[b + 2 * C] = d_pn;
+        d_gh[b] = d_pr; d_gh[b + C] = d_pz; d_gh[b + 2 * C] = d_pn * r;
+        d_h[i] = g * z;
+    }
+}
+
+}  // namespace glam
+
+using namespace glam;
+
+extern "C" int glam_gru_gates_fwd(const float* gi, const float* gh, const float* h, int64_t N, int C, float* h_new,
+                                  void* stream) {
+    GLAM_REQUIRE(N >= 0 && C > 0 && N * (int64_t)C < (int64_t)INT32_MAX * 64, "glam_gru_gates_fwd: bad sizes");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(gi && gh && h && h_new, "glam_gru_gates_fwd: null pointer");
+    hipLaunchKernelGGL(k_gru_gates_fwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, (int)N, C, h_new);
+    GLAM_LAUNCH_CHECK("glam_gru_gates_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_gates_bwd(const float* gi, const float* gh, const float* h, const float* d_hnew, int64_t N, int C,
+                                  float* d_gi, float* d_gh, float* d_h, void* stream) {
+    GLAM_REQUIRE(N >= 0 && C > 0, "glam_gru_gates_bwd: bad sizes");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(gi && gh && h && d_hnew && d_gi && d_gh && d_h, "glam_gru_gates_bwd: null pointer");
+    hipLaunchKernelGGL(k_gru_gates_bwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, d_hnew,
+                       (int)N, C, d_gi, d_gh, d_h);
+    GLAM_LAUNCH_CHECK("glam_gru_gates_bwd");
+    return GLAM_OK;
+}

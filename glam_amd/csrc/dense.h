@@ -20,6 +20,7 @@ struct WgArgs {
     const float* P2; int I2; int ldp2;
     int ones;                              // 1: virtual all-ones column at index I1+I2 (bias gradient)
     const float* Q; int J; int ldq;        // J % 4 == 0, J <= 64
+    int qones;                             // 1: virtual all-ones column at index J (needs J + 1 <= 64)
     int N; int rows_per_wave;              // multiple of 4
     float* partial;                        // [ntile_i][nsplit][16 regs][64 lanes]
     int nsplit;

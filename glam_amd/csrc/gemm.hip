@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
     else if (pcol < I12) { pbase = a.P2 + (pcol - a.I1); pld = a.ldp2; }
     else if (a.ones && pcol == I12) pconst = 1.f;
     const bool qok = qcol < a.J;
+    const bool qone = a.qones && qcol == a.J;
 
     v4f acc[4];
 #pragma unroll
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
             const int n = n0 + 4 * st + kq;
             const bool nok = n < row1;
             pv[st] = nok ? (pbase ? pbase[(size_t)n * pld] : pconst) : 0.f;
-            qv[st] = (nok && qok) ? ld4(a.Q + (size_t)n * a.ldq + qcol) : f4zero();
+            qv[st] = (nok && qok) ? ld4(a.Q + (size_t)n * a.ldq + qcol) : (nok && qone) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
         }
 #pragma unroll
         for (int st = 0; st < kSteps; ++st)
@@ -296,7 +297,8 @@ size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocks + 12) * 1024; }
 // fills the launch geometry of a k_wgrad call and the matching reduce job; launches k_wgrad
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
     const int I = a.I1 + a.I2 + (a.ones ? 1 : 0);
-    if (I > 192 || a.J > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3))
+    const int Jt = a.J + (a.qones ? 1 : 0);
+    if (I > 192 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3))
         return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d J=%d outside the kernel table (I <= 192, J <= 64, J %% 4 == 0)", I, a.J);
     const int ntile = (I + 15) / 16;
     int nsplit = kWgradBlocks / ntile;
@@ -310,7 +312,7 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
     a.nsplit = nsplit;
     hipLaunchKernelGGL(k_wgrad, dim3(ntile * nsplit), dim3(kWgBlock), 0, s, a);
     GLAM_LAUNCH_CHECK("wgrad");
-    *job = ReduceJob{0, a.partial, nsplit, ntile * 1024, I, a.J, si, sj, out, nullptr, 0, 0};
+    *job = ReduceJob{0, a.partial, nsplit, ntile * 1024, I, Jt, si, sj, out, nullptr, 0, 0};
     return GLAM_OK;
 }
 
@@ -352,14 +354,14 @@ extern "C" int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, 
 extern "C" size_t glam_wgrad_workspace_bytes(void) { return wgrad_workspace_floats() * sizeof(float) + 256; }
 
 extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
-                               const float* Q, int J, int ldq, int64_t N, float* out, int stride_i, int stride_j,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
+                               int stride_j, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm: N out of range");
     GLAM_REQUIRE(P1 && Q && out && ws && (I2 == 0 || P2), "glam_wgrad_gemm: null pointer");
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm: workspace too small");
     GLAM_REQUIRE(aligned16(Q), "glam_wgrad_gemm: Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-    WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, (int)N, 0, partial, 0};
+    WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, (int)N, 0, partial, 0};
     ReduceArgs ra{};
     ra.njobs = 1;
     if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, (hipStream_t)stream, &ra.job[0])) return rc;

@@ -331,7 +331,7 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
         (void)hipEventRecord(side->fork1, s);
         (void)hipStreamWaitEvent(s2, side->fork1, 0);
     }
-    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, (int)N, 0, wg1, 0};
+    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, 0, (int)N, 0, wg1, 0};
     if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, s2, &ra.job[0])) return rc;
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
     TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
@@ -349,7 +349,7 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
         (void)hipEventRecord(side->fork2, s);
         (void)hipStreamWaitEvent(s2, side->fork2, 0);
     }
-    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, (int)N, 0, wg2, 0};
+    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0};
     if (int rc = launch_wgrad_partials(w2, dstaged + G.d_wcat, 1, HC + 8, s2, &ra.job[2])) return rc;
     // d_x = [d_xw | d_a] @ Wcat^T
     TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};

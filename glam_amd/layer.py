@@ -555,7 +555,7 @@ class LinearBlock(torch.nn.Module):
     def forward(self, x, batch=None):
         x = self.norm(x, batch)
         x = self.dropout(x)
-        x = self.linear(x)
+        x = ops.linear(x, self.linear.weight, self.linear.bias)
         return self.act(x)
 
 
@@ -574,16 +574,10 @@ class MessageBlock(torch.nn.Module):
         self.res = res
 
     def _gru_step(self, x, h):
-        """One step of ``self.gru`` (seq_len 1, layer.py:262) on its own parameters."""
+        """One step of ``self.gru`` (seq_len 1, layer.py:262) on its own parameters: two MFMA gate GEMMs + fused
+        gate kernel."""
         g = self.gru
-        gi = F.linear(x, g.weight_ih_l0, g.bias_ih_l0)
-        gh = F.linear(h, g.weight_hh_l0, g.bias_hh_l0)
-        i_r, i_z, i_n = gi.chunk(3, dim=1)
-        h_r, h_z, h_n = gh.chunk(3, dim=1)
-        r = torch.sigmoid(i_r + h_r)
-        z = torch.sigmoid(i_z + h_z)
-        n = torch.tanh(i_n + r * h_n)
-        return (1 - z) * n + z * h
+        return ops.gru_step(x, h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
 
     def forward(self, x, edge_index, edge_attr, h=None, batch=None):
         identity = x

@@ -246,6 +246,108 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
 
 
 # --------------------------------------------------------------------------------------
+# dense linear on the fp32 matrix cores + GRU gate math (MessageBlock remainder)
+# --------------------------------------------------------------------------------------
+def linear_supported(K, M):
+    """Shapes the tall-skinny MFMA kernels cover: (K <= 64, M <= 192) or (K <= 192, M <= 64), with room for the bias
+    ones-column in the weight-gradient kernel."""
+    Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
+    return (Kp <= 60 and Mp <= 192) or (Kp <= 188 and Mp <= 64)
+
+
+class _Linear(torch.autograd.Function):
+    """y[N,M] = x[N,K] @ w[M,K]^T + b on k_ts_gemm; d_x on k_ts_gemm, d_w / d_b on k_wgrad (K, M multiples of 4)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        x, w = f32c(x, "x"), f32c(w, "weight")
+        b = None if b is None else f32c(b, "bias")
+        N, K = x.shape
+        M = w.size(0)
+        lib, dev = _lib.load(), x.device
+        img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, dtype=torch.float32, device=dev)
+        check(lib.glam_ts_gemm_make_image(ptr(w), K, 1, K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+        y = torch.empty(N, M, dtype=torch.float32, device=dev)
+        check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            img = torch.empty(lib.glam_ts_gemm_image_bytes(M, K) // 4, **f)
+            check(lib.glam_ts_gemm_make_image(ptr(w), K, 0, M, K, ptr(img), stream()), "glam_ts_gemm_make_image")
+            dx = torch.empty(N, K, **f)
+            check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
+        if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]
+            check(lib.glam_wgrad_gemm(ptr(x), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), 1, K + 1, ptr(ws), ws.numel(),
+                                      stream()), "glam_wgrad_gemm")
+        else:         # out[m, k] = sum_n dy[n,m] [x|1][n,k]
+            check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(),
+                                      stream()), "glam_wgrad_gemm")
+        dw = dwb[:M, :K]
+        db = dwb[:M, K] if ctx.has_bias else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """``F.linear`` on the hand-written MFMA kernels when the shape is in their table (the layer-sized linears of the
+    path: GRU gates 60->180, input embedding 15->60, ...); larger / odd layers (e.g. the 300->1024 readout MLP) stay
+    on the library GEMM, which is the right tool for them."""
+    M, K = weight.shape
+    if x.dim() != 2 or not linear_supported(K, M):
+        return torch.nn.functional.linear(x, weight, bias)
+    Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
+    if Kp != K:
+        x = torch.nn.functional.pad(x, (0, Kp - K))
+    if Kp != K or Mp != M:
+        weight = torch.nn.functional.pad(weight, (0, Kp - K, 0, Mp - M))
+        bias = None if bias is None else torch.nn.functional.pad(bias, (0, Mp - M))
+    y = _Linear.apply(x, weight, bias)
+    return y[:, :M] if Mp != M else y
+
+
+class _GruGates(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        require_device(gi, gh, h)
+        gi, gh, h = f32c(gi, "gi"), f32c(gh, "gh"), f32c(h, "h")
+        N, C = h.shape
+        h_new = torch.empty_like(h)
+        check(_lib.load().glam_gru_gates_fwd(ptr(gi), ptr(gh), ptr(h), N, C, ptr(h_new), stream()), "glam_gru_gates_fwd")
+        ctx.save_for_backward(gi, gh, h)
+        return h_new
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_hnew):
+        gi, gh, h = ctx.saved_tensors
+        N, C = h.shape
+        d_hnew = f32c(d_hnew, "d_hnew")
+        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        check(_lib.load().glam_gru_gates_bwd(ptr(gi), ptr(gh), ptr(h), ptr(d_hnew), N, C, ptr(d_gi), ptr(d_gh), ptr(d_h),
+                                             stream()), "glam_gru_gates_bwd")
+        return d_gi, d_gh, d_h
+
+
+def gru_step(x, h, w_ih, w_hh, b_ih, b_hh):
+    """One ``torch.nn.GRU(C, C)`` step with seq_len 1 on its own parameters (src_1gp/layer.py:247, :262)."""
+    return _GruGates.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h)
+
+
+# --------------------------------------------------------------------------------------
 # readouts
 # --------------------------------------------------------------------------------------
 class _Pool5(torch.autograd.Function):

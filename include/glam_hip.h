@@ -143,8 +143,9 @@ int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_
  *                    LDS image the GEMM blocks copy verbatim (glam_ts_gemm_image_bytes(K, M) bytes).
  *   glam_ts_gemm:    out[N, M1|M2] = [A1 | A2][N, K1+K2] @ W (+ bias on the M1 columns); all K*, M*, ld* % 4 == 0;
  *                    K1+K2 <= 192 with M <= 64, or K1+K2 <= 64 with M <= 192.
- *   glam_wgrad_gemm: out[i*stride_i + j*stride_j] = sum_n [P1 | P2 | 1][n, i] * Q[n, j]  (reduction over the N
- *                    rows; `ones` appends an all-ones column, i.e. the bias gradient); I <= 192, J <= 64. */
+ *   glam_wgrad_gemm: out[i*stride_i + j*stride_j] = sum_n [P1 | P2 | 1][n, i] * [Q | 1][n, j]  (reduction over the
+ *                    N rows; `ones` / `qones` append an all-ones column on either side, i.e. the bias gradient);
+ *                    I <= 192, J <= 64 (ones columns included). */
 size_t glam_ts_gemm_image_bytes(int K, int M);
 int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, float* img, void* stream);
 int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
@@ -152,8 +153,8 @@ int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int
                  void* stream);
 size_t glam_wgrad_workspace_bytes(void);
 int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
-                    int J, int ldq, int64_t N, float* out, int stride_i, int stride_j, void* ws, size_t ws_bytes,
-                    void* stream);
+                    int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, void* ws,
+                    size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole TripletMessage layer (src_1gp/layer.py:36-61) as one enqueue per direction.  All node-feature
@@ -187,6 +188,14 @@ int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* 
                            const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int Dp,
                            float slope, float* d_x, float* dstaged, float* d_edge_attr, void* ws, size_t ws_bytes,
                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MessageBlock remainder: gate math of one torch.nn.GRU(C, C) step with seq_len 1 (src_1gp/layer.py:247, :262).
+ * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with
+ * glam_ts_gemm) -> h_new f32[N,C].  The backward recomputes the gates from gi / gh. */
+int glam_gru_gates_fwd(const float* gi, const float* gh, const float* h, int64_t N, int C, float* h_new, void* stream);
+int glam_gru_gates_bwd(const float* gi, const float* gh, const float* h, const float* d_hnew, int64_t N, int C,
+                       float* d_gi, float* d_gh, float* d_h, void* stream);
 
 #ifdef __cplusplus
 }

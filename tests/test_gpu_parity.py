@@ -423,7 +423,7 @@ def test_wgrad_gemm(device, N, I1, I2, ones, J):
     P1d, P2d, Qd = P1.to(device), P2.to(device), Q.to(device)
     for si, sj, shape in [(J, 1, (I, J)), (1, I, (J, I))]:
         out = torch.full(shape, float("nan"), device=device)
-        rc = lib.glam_wgrad_gemm(p(P1d), I1, I1, p(P2d) if I2 else None, I2, I2, ones, p(Qd), J, J, N, p(out), si, sj, p(ws),
+        rc = lib.glam_wgrad_gemm(p(P1d), I1, I1, p(P2d) if I2 else None, I2, I2, ones, p(Qd), J, J, 0, N, p(out), si, sj, p(ws),
                                  ws.numel(), _lib.stream())
         assert rc == 0, lib.glam_last_error()
         got = out if si == J else out.t()
@@ -514,3 +514,44 @@ def test_edge_attr_gradient_optional_path(device):
     out = conv(g.inputs["x"].to(device), g.inputs["edge_index"].to(device), ea)
     (gea,) = torch.autograd.grad((out * g.cot.to(device)).sum(), [ea])
     assert_close(gea, g.grads["edge_attr"], 2e-5, "d_edge_attr via k_triplet_bwd_dea")
+
+
+@pytest.mark.parametrize("N,K,M,bias", [(1000, 60, 180, True), (777, 15, 60, True), (500, 180, 60, True), (64, 16, 8, False),
+                                        (300, 57, 33, True), (1024, 300, 1024, True)])
+def test_linear_op_matches_torch(device, N, K, M, bias):
+    """ops.linear (k_ts_gemm / k_wgrad) against F.linear in fp64; the last shape is outside the kernel table and
+    must route to the library GEMM."""
+    g = torch.Generator().manual_seed(K * M)
+    x0, w0 = torch.randn(N, K, generator=g), torch.randn(M, K, generator=g) / K ** 0.5
+    b0 = torch.randn(M, generator=g) if bias else None
+    cot = torch.randn(N, M, generator=g)
+    xr, wr = x0.double().requires_grad_(True), w0.double().requires_grad_(True)
+    br = b0.double().requires_grad_(True) if bias else None
+    ref = torch.nn.functional.linear(xr, wr, br)
+    gr = torch.autograd.grad((ref * cot.double()).sum(), [xr, wr] + ([br] if bias else []))
+    x, w = x0.to(device).requires_grad_(True), w0.to(device).requires_grad_(True)
+    b = b0.to(device).requires_grad_(True) if bias else None
+    out = ops.linear(x, w, b)
+    assert_close(out, ref, 3e-6, "linear fwd")
+    gs = torch.autograd.grad((out * cot.to(device)).sum(), [x, w] + ([b] if bias else []))
+    for n_, a, r in zip(["x", "w", "b"], gs, gr):
+        assert_close(a, r, 1e-5, f"linear grad {n_}")
+
+
+def test_gru_step_matches_torch_gru(device):
+    torch.manual_seed(21)
+    gru = torch.nn.GRU(60, 60)
+    x0, h0 = torch.randn(500, 60), torch.randn(500, 60)
+    xr, hr = x0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+    out_ref, _ = gru(xr.unsqueeze(0), hr.unsqueeze(0))
+    cot = torch.randn(500, 60)
+    g_ref = torch.autograd.grad((out_ref.squeeze(0) * cot).sum(), [xr, hr] + list(gru.parameters()))
+    gd = torch.nn.GRU(60, 60)
+    gd.load_state_dict(gru.state_dict())
+    gd = gd.to(device)
+    x, h = x0.to(device).requires_grad_(True), h0.to(device).requires_grad_(True)
+    out = ops.gru_step(x, h, gd.weight_ih_l0, gd.weight_hh_l0, gd.bias_ih_l0, gd.bias_hh_l0)
+    assert_close(out, out_ref.squeeze(0), 2e-6, "gru fwd")
+    gs = torch.autograd.grad((out * cot.to(device)).sum(), [x, h] + list(gd.parameters()))
+    for n_, a, r in zip(["x", "h", "w_ih", "w_hh", "b_ih", "b_hh"], gs, g_ref):
+        assert_close(a, r, 1e-5, f"gru grad {n_}")

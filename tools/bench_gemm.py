@@ -30,7 +30,7 @@ for N in [16, 4096, 8192, 16384, 20400, 40960, 81920, 328514]:
     ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
     for (I, J) in [(180, 60), (188, 60)]:
         P = torch.randn(N, I, device=dev); Q = torch.randn(N, J, device=dev); out = torch.empty(I + 1, J, device=dev)
-        fn = lambda: lib.glam_wgrad_gemm(p(P), I, I, None, 0, 0, 1, p(Q), J, J, N, p(out), J, 1, p(ws), ws.numel(), st())
+        fn = lambda: lib.glam_wgrad_gemm(p(P), I, I, None, 0, 0, 1, p(Q), J, J, 0, N, p(out), J, 1, p(ws), ws.numel(), st())
         t = timed(fn)
         row.append(f"wg {I}x{J}: {t:7.2f}us {2*N*I*J/t/1e6:6.1f}TF")
     print("  ".join(row))
