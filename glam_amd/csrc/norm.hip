@@ -1,0 +1,170 @@
+// Per-graph normalisations over contiguous node segments (one wavefront per graph, lanes over channels).
+// Reference semantics replaced (PyG 1.7.2 classes wrapped at src_1gp/layer.py:161-194):
+//   mode 0  PairNorm(scale=1, eps=1e-5)(x, batch):   x' = x - mean_n x (per channel);
+//           y = scale * x' / sqrt(eps + mean_n ||x'_n||^2)
+//   mode 1  graph LayerNorm(eps=1e-5)(x, batch) without the affine part:  x' = x - mean_{n,c} x;
+//           y = x' / sqrt(mean_{n,c} x'^2 + eps)        (the per-channel weight/bias stay in the host mirror)
+// Statistics are recomputed in the backward pass from x (saved), so nothing but x is kept.
+#include "common.h"
+
+namespace glam {
+
+constexpr int kWavesPerBlockN = kBlock / 64;
+constexpr int kMaxChunks = 4;   // D <= 256 channels
+
+// sum over the nodes of one graph of column c: 4 loads in flight (graphs are 10-30 nodes, the loop is latency bound)
+__device__ __forceinline__ float colsum(const float* x, int beg, int end, int D, int c) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int n = beg;
+    for (; n + 4 <= end; n += 4) {
+        const float v0 = x[(size_t)n * D + c], v1 = x[(size_t)(n + 1) * D + c];
+        const float v2 = x[(size_t)(n + 2) * D + c], v3 = x[(size_t)(n + 3) * D + c];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; n < end; ++n) s0 += x[(size_t)n * D + c];
+    return (s0 + s1) + (s2 + s3);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_graph_norm_fwd(const float* x, const int* ptr, int B, int D, float scale,
+                                                          float eps, float* y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlockN + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlockN;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        if (end <= beg) continue;
+        const float inv_cnt = 1.f / (float)(end - beg);
+        float mean[kMaxChunks];
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int c = lane + 64 * k;
+            mean[k] = c < D ? colsum(x, beg, end, D, c) * inv_cnt : 0.f;
+        }
+        if (MODE == 1) {   // scalar mean over nodes x channels
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxChunks; ++k) t += (lane + 64 * k < D) ? mean[k] : 0.f;
+            t = group_sum<64>(t) / (float)D;
+#pragma unroll
+            for (int k = 0; k < kMaxChunks; ++k) mean[k] = t;
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+#pragma unroll 4
+                for (int n = beg; n < end; ++n) { const float d = x[(size_t)n * D + c] - mean[k]; sq = fmaf(d, d, sq); }
+            }
+        }
+        sq = group_sum<64>(sq) * inv_cnt;
+        const float a = MODE == 0 ? scale / sqrtf(eps + sq) : 1.f / sqrtf(sq / (float)D + eps);
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+#pragma unroll 4
+                for (int n = beg; n < end; ++n) y[(size_t)n * D + c] = (x[(size_t)n * D + c] - mean[k]) * a;
+            }
+        }
+    }
+}
+
+// d_x = a (g - gbar) - a^3 T x' / M      with x' the centred input, a the scale above,
+//   PairNorm : gbar = per-channel mean of g over the graph's nodes, T = sum <g, x'>, M = cnt, a = scale/sqrt(eps+s)
+//              (d_x = a (g - gbar) - (a^3 / scale^2) T x' / cnt)
+//   LayerNorm: gbar = scalar mean of g, T = sum g x', M = cnt*D
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_graph_norm_bwd(const float* x, const float* gy, const int* ptr, int B, int D,
+                                                          float scale, float eps, float* dx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlockN + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlockN;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        if (end <= beg) continue;
+        const float inv_cnt = 1.f / (float)(end - beg);
+        float mean[kMaxChunks], gbar[kMaxChunks];
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int c = lane + 64 * k;
+            mean[k] = c < D ? colsum(x, beg, end, D, c) * inv_cnt : 0.f;
+            gbar[k] = c < D ? colsum(gy, beg, end, D, c) * inv_cnt : 0.f;
+        }
+        if (MODE == 1) {
+            float s = 0.f, t = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxChunks; ++k)
+                if (lane + 64 * k < D) { s += mean[k]; t += gbar[k]; }
+            s = group_sum<64>(s) / (float)D;
+            t = group_sum<64>(t) / (float)D;
+#pragma unroll
+            for (int k = 0; k < kMaxChunks; ++k) { mean[k] = s; gbar[k] = t; }
+        }
+        float sq = 0.f, T = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+#pragma unroll 4
+                for (int n = beg; n < end; ++n) {
+                    const float d = x[(size_t)n * D + c] - mean[k];
+                    sq = fmaf(d, d, sq);
+                    T = fmaf(gy[(size_t)n * D + c], d, T);
+                }
+            }
+        }
+        sq = group_sum<64>(sq) * inv_cnt;
+        T = group_sum<64>(T);
+        float a, coef;
+        if (MODE == 0) { a = scale / sqrtf(eps + sq); coef = a * a * a / (scale * scale) * T * inv_cnt; }
+        else { a = 1.f / sqrtf(sq / (float)D + eps); coef = a * a * a * T * inv_cnt / (float)D; }
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+#pragma unroll 4
+                for (int n = beg; n < end; ++n) {
+                    const size_t i = (size_t)n * D + c;
+                    dx[i] = a * (gy[i] - gbar[k]) - coef * (x[i] - mean[k]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace glam
+
+using namespace glam;
+
+static int norm_dims(const char* fn, int64_t N, int64_t B, int D, int mode) {
+    if (N < 0 || B < 0 || N >= INT32_MAX || B >= INT32_MAX) return fail(GLAM_E_INVALID, "%s: N/B out of range", fn);
+    if (D <= 0 || D > 64 * kMaxChunks) return fail(GLAM_E_UNSUPPORTED, "%s: D=%d not in 1..%d", fn, D, 64 * kMaxChunks);
+    if (mode != 0 && mode != 1) return fail(GLAM_E_INVALID, "%s: mode=%d", fn, mode);
+    return GLAM_OK;
+}
+
+extern "C" int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode, float scale,
+                                   float eps, float* y, void* stream) {
+    if (int rc = norm_dims("glam_graph_norm_fwd", N, B, D, mode)) return rc;
+    if (N == 0 || B == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && ptr && y, "glam_graph_norm_fwd: null pointer");
+    const dim3 grid(grid_for(B, kWavesPerBlockN)), block(kBlock);
+    if (mode == 0) hipLaunchKernelGGL(k_graph_norm_fwd<0>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
+    else hipLaunchKernelGGL(k_graph_norm_fwd<1>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
+    GLAM_LAUNCH_CHECK("glam_graph_norm_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                                   float scale, float eps, float* dx, void* stream) {
+    if (int rc = norm_dims("glam_graph_norm_bwd", N, B, D, mode)) return rc;
+    if (N == 0 || B == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && gy && ptr && dx, "glam_graph_norm_bwd: null pointer");
+    const dim3 grid(grid_for(B, kWavesPerBlockN)), block(kBlock);
+    if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
+    else hipLaunchKernelGGL(k_graph_norm_bwd<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
+    GLAM_LAUNCH_CHECK("glam_graph_norm_bwd");
+    return GLAM_OK;
+}

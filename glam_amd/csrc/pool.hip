@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd(const float* x, const int*
         int ti[kMaxK];
 #pragma unroll
         for (int r = 0; r < kMaxK; ++r) { tv[r] = -INFINITY; ti[r] = -1; }
+#pragma unroll 4
         for (int n = beg; n < end; ++n) {
             float v = x[(size_t)n * D + (D - 1)];
             int vi = n;
@@ -45,6 +46,7 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd(const float* x, const int*
         const float inv_cnt = 1.f / (float)max(end - beg, 1);
         for (int c = lane; c < D; c += 64) {
             float s = 0.f;
+#pragma unroll 4
             for (int n = beg; n < end; ++n) s += x[(size_t)n * D + c];
             float* o = out + (size_t)g * OD;
             o[c] = s * inv_cnt;

@@ -375,12 +375,7 @@ class LayerNorm(torch.nn.Module):
             x = x - x.mean()
             out = x / (x.std(unbiased=False) + self.eps)
         else:
-            sp = ops.segment_ptr(batch)
-            denom = (sp.ptr[1:] - sp.ptr[:-1]).clamp(min=1).to(x.dtype).mul(x.size(-1)).view(-1, 1)
-            mean = ops.segment_pool(x, sp, "sum").sum(dim=-1, keepdim=True) / denom
-            x = x - mean.index_select(0, batch)
-            var = ops.segment_pool(x * x, sp, "sum").sum(dim=-1, keepdim=True) / denom
-            out = x / (var + self.eps).sqrt().index_select(0, batch)
+            out = ops.graph_standardize(x, ops.segment_ptr(batch), self.eps)
         if self.weight is not None:
             out = out * self.weight + self.bias
         return out
@@ -397,10 +392,7 @@ class PairNorm(torch.nn.Module):
         if batch is None:
             x = x - x.mean(dim=0, keepdim=True)
             return self.scale * x / (self.eps + x.pow(2).sum(-1).mean()).sqrt()
-        sp = ops.segment_ptr(batch)
-        x = x - ops.segment_pool(x, sp, "mean").index_select(0, batch)
-        sq = ops.segment_pool(x.pow(2).sum(-1, keepdim=True), sp, "mean")
-        return self.scale * x / (self.eps + sq.index_select(0, batch)).sqrt()
+        return ops.pair_norm(x, ops.segment_ptr(batch), self.scale, self.eps)
 
 
 class GraphSizeNorm(torch.nn.Module):

@@ -487,3 +487,42 @@ def edge_reduce(msg, gi, reduce="sum"):
     squeeze = msg.dim() == 1
     out = _EdgeReduce.apply(msg.unsqueeze(-1) if squeeze else msg, gi, _MODES[reduce])
     return out.squeeze(-1) if squeeze else out
+
+
+class _GraphNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sp, mode, scale, eps):
+        require_device(x)
+        x = f32c(x, "x")
+        N, D = x.shape
+        if N != sp.N:
+            raise GlamHipError(f"graph_norm: x has {N} rows but batch has {sp.N}")
+        y = torch.zeros_like(x) if sp.B == 0 else torch.empty_like(x)
+        check(_lib.load().glam_graph_norm_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, mode, float(scale), float(eps), ptr(y), stream()),
+              "glam_graph_norm_fwd")
+        ctx.save_for_backward(x)
+        ctx.sp, ctx.cfg = sp, (mode, float(scale), float(eps))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        mode, scale, eps = ctx.cfg
+        sp = ctx.sp
+        N, D = x.shape
+        gy = f32c(gy, "gy")
+        dx = torch.empty_like(x)
+        check(_lib.load().glam_graph_norm_bwd(ptr(x), ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ptr(dx), stream()),
+              "glam_graph_norm_bwd")
+        return dx, None, None, None, None
+
+
+def pair_norm(x, sp, scale=1.0, eps=1e-5):
+    """PyG ``PairNorm(scale, eps=1e-5)(x, batch)`` (one kernel per direction)."""
+    return _GraphNorm.apply(x, sp, 0, scale, eps)
+
+
+def graph_standardize(x, sp, eps=1e-5):
+    """Statistics part of PyG's graph ``LayerNorm(x, batch)``: zero mean / unit variance per graph."""
+    return _GraphNorm.apply(x, sp, 1, 1.0, eps)

@@ -197,6 +197,17 @@ int glam_gru_gates_fwd(const float* gi, const float* gh, const float* h, int64_t
 int glam_gru_gates_bwd(const float* gi, const float* gh, const float* h, const float* d_hnew, int64_t N, int C,
                        float* d_gi, float* d_gh, float* d_h, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-graph normalisation over contiguous node segments ptr int32[B+1] (empty graphs are skipped).
+ * Replaces: PyG PairNorm()(x, batch) behind _PairNorm (src_1gp/layer.py:179-185; mode 0, scale 1, eps 1e-5) and the
+ * statistics of PyG's graph LayerNorm(x, batch) behind _LayerNorm (src_1gp/layer.py:170-176; mode 1: y = (x - mean) /
+ * sqrt(var + eps) over all nodes x channels of a graph; the per-channel affine stays in the host mirror).
+ * D <= 256.  The backward pass recomputes the statistics from x. */
+int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode, float scale, float eps,
+                        float* y, void* stream);
+int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                        float scale, float eps, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
