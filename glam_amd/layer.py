@@ -159,8 +159,16 @@ class TripletMessageLight(MessagePassing):
         Wa = F.pad(Wa.unsqueeze(-1), (0, 3)).reshape(C, 8)
         M = F.pad(att[C:C + De].unsqueeze(-1), (0, 3, 0, Dp - De)).contiguous()     # [Dp, 4]
         Wn = F.pad(self.weight_node, (0, Cp - C)) if Cp != C else self.weight_node
-        xw = torch.matmul(x, Wn)                                                    # layer.py:84
-        a_ij = torch.matmul(x, Wa)
+        if ops.linear_split_supported(Cp, Cp + 8):
+            # node GEMM + separable attention columns in one MFMA launch: [xw | a_i a_j] = x @ [W_node | Wa]
+            x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
+            wt = torch.cat([Wn, Wa], dim=1)
+            if Cp != C:
+                wt = F.pad(wt, (0, 0, 0, Cp - C))
+            xw, a_ij = ops.linear_split(x_p, wt, Cp)                                # layer.py:84
+        else:
+            xw = torch.matmul(x, Wn)
+            a_ij = torch.matmul(x, Wa)
         if Dp != De:
             edge_attr = F.pad(edge_attr, (0, Dp - De))
         aggr = ops.light_aggregate(xw, a_ij, edge_attr, M, gi, Cp, self.negative_slope)

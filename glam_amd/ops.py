@@ -319,6 +319,61 @@ def linear(x, weight, bias=None):
     return y[:, :M] if Mp != M else y
 
 
+class _LinearSplit(torch.autograd.Function):
+    """(y1[N,M1], y2[N,M2]) = x[N,K] @ wt[K, M1+M2] with the two column blocks written to separate tensors
+    (node features + packed attention scalars of the single-head layers).  K, M1, M2 multiples of 4."""
+
+    @staticmethod
+    def forward(ctx, x, wt, M1):
+        require_device(x, wt)
+        x, wt = f32c(x, "x"), f32c(wt, "weight")
+        N, K = x.shape
+        M = wt.size(1)
+        M2 = M - M1
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, **f)
+        check(lib.glam_ts_gemm_make_image(ptr(wt), M, 0, K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+        y1, y2 = torch.empty(N, M1, **f), torch.empty(N, M2, **f)
+        check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), None, ptr(y1), M1, M1, ptr(y2), M2, M2, N, stream()), "glam_ts_gemm")
+        ctx.save_for_backward(x, wt)
+        ctx.M1 = M1
+        return y1, y2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy1, dy2):
+        x, wt = ctx.saved_tensors
+        N, K = x.shape
+        M = wt.size(1)
+        M1 = ctx.M1
+        M2 = M - M1
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        dy1, dy2 = f32c(dy1, "dy1"), f32c(dy2, "dy2")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            img = torch.empty(lib.glam_ts_gemm_image_bytes(M, K) // 4, **f)
+            check(lib.glam_ts_gemm_make_image(ptr(wt), M, 1, M, K, ptr(img), stream()), "glam_ts_gemm_make_image")
+            dx = torch.empty(N, K, **f)
+            check(lib.glam_ts_gemm(ptr(dy1), M1, M1, ptr(dy2), M2, M2, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()),
+                  "glam_ts_gemm")
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        dwt = torch.empty(K, M, **f)     # out[i = m, j = k] written at dwt[k, m]
+        check(lib.glam_wgrad_gemm(ptr(dy1), M1, M1, ptr(dy2), M2, M2, 0, ptr(x), K, K, 0, N, ptr(dwt), 1, M, ptr(ws), ws.numel(),
+                                  stream()), "glam_wgrad_gemm")
+        return dx, dwt, None
+
+
+def linear_split(x, wt, M1):
+    """``x @ wt`` split into the first ``M1`` and the remaining columns (both contiguous)."""
+    return _LinearSplit.apply(x, wt, M1)
+
+
+def linear_split_supported(K, M):
+    return K % 4 == 0 and M % 4 == 0 and K <= 64 and M <= 192      # K is the J side of the weight-gradient kernel
+
+
 class _GruGates(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gi, gh, h):
