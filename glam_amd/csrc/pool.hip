@@ -230,6 +230,54 @@ __global__ void __launch_bounds__(kBlock) k_edge_reduce_bwd(const float* d_out, 
     }
 }
 
+// ---- edge-weighted neighbour sums: S[n,k,:] = (1/deg_n) sum_{e -> n} w[e,k] * x[src_e,:] -----------------------
+// With one-hot edge features this is the per-relation neighbour sum that turns NNConv (per-edge [C,C] weights
+// nn(e_ij), src_1gp/layer.py:115-122) into a 4-relation R-GCN: out = S.view(N, K*C) @ stack_k nn(onehot_k).
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_edge_wsum_fwd(const float* x, const float* w, const int* rowptr,
+                                                         const int* nbr, const int* eid, int N, int D, int mean,
+                                                         float* out) {
+    const size_t total = (size_t)N * D;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int n = (int)(i / D), c = (int)(i % D);
+        const int beg = rowptr[n], end = rowptr[n + 1];
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const float xv = x[(size_t)nbr[e] * D + c];
+            const float* we = w + (size_t)eid[e] * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = fmaf(we[k], xv, acc[k]);
+        }
+        const float sc = mean ? 1.f / (float)max(end - beg, 1) : 1.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[((size_t)n * K + k) * D + c] = acc[k] * sc;
+    }
+}
+
+// d_x[j,:] = sum_{e: src = j} (1/deg_dst) sum_k w[e,k] * d_S[dst_e,k,:]   (walks the CSR transpose)
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd(const float* d_out, const float* w, const int* colptr,
+                                                         const int* dst, const int* eid_t, const int* rowptr, int N,
+                                                         int D, int mean, float* dx) {
+    const size_t total = (size_t)N * D;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int j = (int)(i / D), c = (int)(i % D);
+        float acc = 0.f;
+        for (int e = colptr[j]; e < colptr[j + 1]; ++e) {
+            const int n = dst[e];
+            const float sc = mean ? 1.f / (float)max(rowptr[n + 1] - rowptr[n], 1) : 1.f;
+            const float* we = w + (size_t)eid_t[e] * K;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) t = fmaf(we[k], d_out[((size_t)n * K + k) * D + c], t);
+            acc = fmaf(sc, t, acc);
+        }
+        dx[i] = acc;
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -340,5 +388,35 @@ extern "C" int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, c
     else if (mode == 2) hipLaunchKernelGGL(k_edge_reduce_bwd<2>, grid, block, 0, s, d_out, rowptr, eid, argmax, (int)N, D, d_msg);
     else return fail(GLAM_E_INVALID, "glam_edge_reduce_bwd: mode=%d", mode);
     GLAM_LAUNCH_CHECK("glam_edge_reduce_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t* rowptr, const int32_t* src,
+                                  const int32_t* eid, int64_t N, int64_t E, int D, int K, int mean, float* out,
+                                  void* stream) {
+    if (int rc = pool_dims("glam_edge_wsum_fwd", N, E, D)) return rc;
+    if (K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_fwd: K=%d (pad the edge features to 4 or 8)", K);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && rowptr && out && (E == 0 || (w && src && eid)), "glam_edge_wsum_fwd: null pointer");
+    const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    else hipLaunchKernelGGL(k_edge_wsum_fwd<8>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    GLAM_LAUNCH_CHECK("glam_edge_wsum_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst,
+                                  const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K,
+                                  int mean, float* dx, void* stream) {
+    if (int rc = pool_dims("glam_edge_wsum_bwd", N, E, D)) return rc;
+    if (K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_bwd: K=%d (pad the edge features to 4 or 8)", K);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(d_out && colptr && rowptr && dx && (E == 0 || (w && dst && eid_t)), "glam_edge_wsum_bwd: null pointer");
+    const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    else hipLaunchKernelGGL(k_edge_wsum_bwd<8>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd");
     return GLAM_OK;
 }

@@ -215,9 +215,23 @@ class NNConv(MessagePassing):
 
     def forward(self, x, edge_index, edge_attr, size=None):
         gi = ops.graph_index(edge_index, x.size(0))
-        weight = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
-        msg = torch.bmm(x.index_select(0, edge_index[0]).unsqueeze(1), weight).squeeze(1)
-        out = ops.edge_reduce(msg, gi, self.aggr)
+        De = edge_attr.size(1)
+        if De <= 8 and not edge_attr.requires_grad and ops.rows_are_one_hot(edge_attr):
+            # Bond features are one-hot (src_1gp/dataset.py:82): nn(e_ij) takes only De distinct values, so the layer is a
+            # De-relation R-GCN: per-relation neighbour sums (one HIP kernel) followed by ONE [N, De*C] x [De*C, C] GEMM,
+            # instead of the reference's [E, C*C] per-edge weight tensor (612 MB at B=1024).
+            Dp = _pad_de(De)
+            w_rel = self.nn(torch.eye(De, dtype=x.dtype, device=x.device))              # [De, in*out]
+            w_rel = w_rel.view(De * self.in_channels, self.out_channels)
+            ea = F.pad(edge_attr, (0, Dp - De)) if Dp != De else edge_attr
+            S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"))           # [N, Dp, in]
+            if self.aggr not in ("mean", "add", "sum"):
+                raise GlamHipError("NNConv: only aggr in {'mean', 'add'} is supported")
+            out = torch.matmul(S[:, :De].reshape(x.size(0), De * self.in_channels), w_rel)
+        else:
+            weight = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
+            msg = torch.bmm(x.index_select(0, edge_index[0]).unsqueeze(1), weight).squeeze(1)
+            out = ops.edge_reduce(msg, gi, self.aggr)
         if self.root is not None:
             out = out + torch.matmul(x, self.root)
         if self.bias is not None:

@@ -581,3 +581,55 @@ def pair_norm(x, sp, scale=1.0, eps=1e-5):
 def graph_standardize(x, sp, eps=1e-5):
     """Statistics part of PyG's graph ``LayerNorm(x, batch)``: zero mean / unit variance per graph."""
     return _GraphNorm.apply(x, sp, 1, 1.0, eps)
+
+
+class _EdgeWeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, gi, mean):
+        require_device(x, w)
+        x, w = f32c(x, "x"), f32c(w, "w")
+        N, D = x.shape
+        E, K = w.shape
+        if N != gi.N or E != gi.E:
+            raise GlamHipError("edge_weighted_sum: x / w disagree with the edge list")
+        out = torch.empty(N, K, D, dtype=torch.float32, device=x.device)
+        check(_lib.load().glam_edge_wsum_fwd(ptr(x), ptr(w), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, E, D, K, int(mean),
+                                             ptr(out), stream()), "glam_edge_wsum_fwd")
+        ctx.save_for_backward(w)
+        ctx.gi, ctx.cfg = gi, (N, E, D, K, int(mean))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        (w,) = ctx.saved_tensors
+        gi = ctx.gi
+        N, E, D, K, mean = ctx.cfg
+        d_out = f32c(d_out, "d_out")
+        colptr, dst, eid_t = gi.transpose()
+        dx = torch.empty(N, D, dtype=torch.float32, device=d_out.device)
+        check(_lib.load().glam_edge_wsum_bwd(ptr(d_out), ptr(w), ptr(colptr), ptr(dst), ptr(eid_t), ptr(gi.rowptr), N, E, D, K,
+                                             mean, ptr(dx), stream()), "glam_edge_wsum_bwd")
+        return dx, None, None, None
+
+
+def edge_weighted_sum(x, w, gi, mean=False):
+    """``S[n,k,:] = (1/deg_n) sum_{e->n} w[e,k] * x[src_e,:]`` -> ``[N, K, D]`` (no gradient w.r.t. ``w``: edge data)."""
+    return _EdgeWeightedSum.apply(x, w, gi, mean)
+
+
+_ONEHOT_CACHE: dict = {}
+
+
+def rows_are_one_hot(t):
+    """True iff every row of ``t`` is one-hot (one host sync, cached per tensor object like the CSR staging)."""
+    key = id(t)
+    hit = _ONEHOT_CACHE.get(key)
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    ok = bool((((t == 0) | (t == 1)).all() & (t.sum(dim=1) == 1).all()).item()) if t.numel() else True
+    try:
+        _ONEHOT_CACHE[key] = (weakref.ref(t, lambda _r, k=key, c=_ONEHOT_CACHE: c.pop(k, None)), t._version, ok)
+    except TypeError:
+        pass
+    return ok

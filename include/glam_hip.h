@@ -208,6 +208,16 @@ int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B
 int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
                         float scale, float eps, float* dx, void* stream);
 
+/* Edge-weighted neighbour sums over a CSR-by-target: S[n,k,:] = (mean ? 1/deg_n : 1) * sum_{e -> n} w[eid e, k] *
+ * x[src e, :]  (x f32[N,D], w f32[E,K], K in {4,8}, out f32[N,K,D]).  With one-hot edge features this is the per-relation
+ * neighbour sum that evaluates NNConv(aggr='mean') (src_1gp/layer.py:115-122: per-edge [C,C] weights nn(e_ij)) as a
+ * K-relation R-GCN without the [E, C*C] tensor.  The backward (w.r.t. x) walks the CSR transpose. */
+int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                       int64_t N, int64_t E, int D, int K, int mean, float* out, void* stream);
+int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst,
+                       const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K, int mean,
+                       float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -555,3 +555,30 @@ def test_gru_step_matches_torch_gru(device):
     gs = torch.autograd.grad((out * cot.to(device)).sum(), [x, h] + list(gd.parameters()))
     for n_, a, r in zip(["x", "h", "w_ih", "w_hh", "b_ih", "b_hh"], gs, g_ref):
         assert_close(a, r, 1e-5, f"gru grad {n_}")
+
+
+@pytest.mark.parametrize("onehot", [True, False])
+def test_nnconv_relation_and_general_paths(device, onehot):
+    """NNConv(aggr='mean'): one-hot bonds take the relation-sum (R-GCN) kernel path, arbitrary edge features the
+    per-edge-weight path; both against the oracle, forward and gradients."""
+    torch.manual_seed(31)
+    b = synth_batch(24, seed=8)
+    N, E = b.x.size(0), b.edge_index.size(1)
+    ea0 = b.edge_attr if onehot else torch.rand(E, 4)
+    blk = layer._NNConv(32, 32, 4)
+    x0 = torch.randn(N, 32)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xo = x0.clone().requires_grad_(True)
+    ref = O.nnconv_mean(xo, b.edge_index, ea0, sd["conv.nn.0.weight"], sd["conv.nn.0.bias"], sd["conv.nn.2.weight"],
+                        sd["conv.nn.2.bias"], sd["conv.root"], sd["conv.bias"])
+    cot = torch.randn(ref.shape)
+    names = list(sd)
+    g_ref = _grads(ref, cot, [xo] + [sd[k] for k in names])
+    blk = blk.to(device)
+    x = x0.to(device).requires_grad_(True)
+    out = blk(x, b.edge_index.to(device), ea0.to(device))
+    assert_close(out, ref, TOL, "nnconv out")
+    params = dict(blk.named_parameters())
+    gs = _grads(out, cot.to(device), [x] + [params[k] for k in names])
+    for n_, a, r in zip(["x"] + names, gs, g_ref):
+        assert_close(a, r, 3e-5, f"nnconv grad {n_}")
