@@ -627,4 +627,7 @@ def dot_and_global_pool5(mol_out, pro_out, mol_batch, pro_batch):   # src_1gp/la
 
 
 def dot_and_global_pool2(mol_out, pro_out, mol_batch, pro_batch):   # src_2gi_dti_scr/layer.py:270-283
-    return _pair_stats(mol_out, pro_out, mol_batch, pro_batch, 2)
+    """[max, mean] of the ligand x residue score matrix of every pair: one HIP launch (no per-pair loop / syncs)."""
+    msp = ops.segment_ptr(mol_batch)
+    psp = ops.segment_ptr(pro_batch, msp.B)
+    return ops.pair_pool(mol_out, pro_out, msp, psp)

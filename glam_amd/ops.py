@@ -633,3 +633,36 @@ def rows_are_one_hot(t):
     except TypeError:
         pass
     return ok
+
+
+class _PairPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mol, pro, msp, psp):
+        require_device(mol, pro)
+        mol, pro = f32c(mol, "mol_out"), f32c(pro, "pro_out")
+        if msp.B != psp.B or mol.size(1) != pro.size(1) or mol.size(0) != msp.N or pro.size(0) != psp.N:
+            raise GlamHipError("pair_pool: the two batches disagree (pair count / width / node count)")
+        P, D = msp.B, mol.size(1)
+        out = torch.empty(P, 2, dtype=torch.float32, device=mol.device)
+        arg = torch.empty(P, 2, dtype=torch.int32, device=mol.device)
+        check(_lib.load().glam_pair_pool_fwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), P, D, ptr(out), ptr(arg), stream()),
+              "glam_pair_pool_fwd")
+        ctx.save_for_backward(mol, pro, arg)
+        ctx.sps = (msp, psp)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        mol, pro, arg = ctx.saved_tensors
+        msp, psp = ctx.sps
+        d_out = f32c(d_out, "d_out")
+        d_mol, d_pro = torch.empty_like(mol), torch.empty_like(pro)
+        check(_lib.load().glam_pair_pool_bwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(arg), ptr(d_out), msp.B,
+                                             mol.size(1), ptr(d_mol), ptr(d_pro), stream()), "glam_pair_pool_bwd")
+        return d_mol, d_pro, None, None
+
+
+def pair_pool(mol_out, pro_out, msp, psp):
+    """``[max, mean]`` of ``mol[seg_i] @ pro[seg_i].T`` per pair -> ``[P, 2]`` (dot_and_global_pool2)."""
+    return _PairPool.apply(mol_out, pro_out, msp, psp)

@@ -218,6 +218,16 @@ int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr
                        const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K, int mean,
                        float* dx, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-pair fusion of the two-tower models: out f32[P,2] = [max, mean] of mol[seg_i] @ pro[seg_i]^T for every pair i
+ * (segments mol_ptr / pro_ptr int32[P+1]; empty segment -> 0); argmax int32[P,2] = (ligand row, residue row) of the max.
+ * Replaces: dot_and_global_pool2 (src_2gi_dti_scr/layer.py:270-283: Python loop, .item() syncs, one matmul per pair). */
+int glam_pair_pool_fwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr, int64_t P,
+                       int D, float* out, int32_t* argmax, void* stream);
+int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
+                       const int32_t* argmax, const float* d_out, int64_t P, int D, float* d_mol, float* d_pro,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

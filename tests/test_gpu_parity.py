@@ -241,8 +241,12 @@ def test_architecture_golden(device, name):
 def test_dot_and_global_pool_golden(device):
     g = Golden("dotpool_pairs")
     i = _dev(g.inputs, device)
-    out2 = layer.dot_and_global_pool2(i["mol_x"], i["pro_x"], i["mol_batch"], i["pro_batch"])
+    mx, px = i["mol_x"].clone().requires_grad_(True), i["pro_x"].clone().requires_grad_(True)
+    out2 = layer.dot_and_global_pool2(mx, px, i["mol_batch"], i["pro_batch"])
     assert_close(out2, g.out, TOL, "dot2")
+    gm, gp = _grads(out2, g.cot.to(device), [mx, px])
+    assert_close(gm, g.grads["mol_x"], TOL, "dot2 d_mol")
+    assert_close(gp, g.grads["pro_x"], TOL, "dot2 d_pro")
     out5 = layer.dot_and_global_pool5(i["mol_x"], i["pro_x"], i["mol_batch"], i["pro_batch"])
     assert_close(out5, g.grads["__out5"], 2e-5, "dot5")
 
@@ -582,3 +586,16 @@ def test_nnconv_relation_and_general_paths(device, onehot):
     gs = _grads(out, cot.to(device), [x] + [params[k] for k in names])
     for n_, a, r in zip(["x"] + names, gs, g_ref):
         assert_close(a, r, 3e-5, f"nnconv grad {n_}")
+
+
+def test_two_tower_model_runs(device):
+    """ArchitectureDTI (src_2gi_dti_scr/model.py): ligand + protein towers with the per-pair fusion kernel."""
+    torch.manual_seed(2)
+    mb = synth_batch(6, seed=3).to(device)
+    pb = synth_protein_batch(6, seed=4, n_min=60, n_max=120).to(device)
+    net = model.ArchitectureDTI(mol_block="_TripletMessage", pro_block="_TripletMessage", e_dim=64, message_steps=2,
+                                graph_do="_None()", end_do="_None()").to(device)
+    out = net(mb, pb)
+    assert out.shape == (6, 1) and torch.isfinite(out).all()
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
