@@ -271,7 +271,9 @@ def main():
     for tag, conv, norm, act in [("triplet_relu", "_TripletMessage", "_None", "ReLU"),
                                  ("triplet_pair_rrelu", "_TripletMessage", "_PairNorm", "RReLU"),
                                  ("light_celu", "_TripletMessageLight", "_None", "CELU"),
-                                 ("nnconv_relu", "_NNConv", "_None", "ReLU")]:
+                                 ("nnconv_relu", "_NNConv", "_None", "ReLU"),
+                                 ("gcn_relu", "_GCNConv", "_None", "ReLU"),
+                                 ("gat_leaky", "_GATConv", "_LayerNorm", "LeakyReLU")]:
         b = hidden_batch(5, 60, 51)
         B = 5
         seed(52)

@@ -118,6 +118,41 @@ def nnconv_mean(x, edge_index, edge_attr, nn_w0, nn_b0, nn_w1, nn_b1, root, bias
 
 
 # --------------------------------------------------------------------------------------
+# GCNConv / GATConv with PyG 1.7.2 defaults (wrapped at src_1gp/layer.py:143-158)
+# --------------------------------------------------------------------------------------
+def _with_self_loops(edge_index, N):
+    mask = edge_index[0] != edge_index[1]
+    loop = torch.arange(N, dtype=edge_index.dtype).unsqueeze(0).repeat(2, 1)
+    return torch.cat([edge_index[:, mask], loop], dim=1)
+
+
+def gcn_conv(x, edge_index, weight, bias):
+    """``GCNConv(in, out)``: ``D^-1/2 (A + I) D^-1/2 X W + b`` (add_remaining_self_loops, unit edge weights)."""
+    N = x.size(0)
+    ei = _with_self_loops(edge_index, N)
+    row, col = ei[0], ei[1]
+    deg = scatter(x.new_ones(ei.size(1)), col, N, "sum")
+    dis = deg.pow(-0.5)
+    dis = dis.masked_fill(dis == float("inf"), 0)
+    norm = dis[row] * dis[col]
+    xw = torch.matmul(x, weight)
+    return scatter(norm.view(-1, 1) * xw.index_select(0, row), col, N, "sum") + bias
+
+
+def gat_conv(x, edge_index, lin_weight, att_l, att_r, bias, slope=0.2):
+    """``GATConv(in, out)`` with heads=1: self loops replaced, ``alpha = softmax_i(leaky(a_l[j] + a_r[i]))``."""
+    N = x.size(0)
+    ei = _with_self_loops(edge_index, N)
+    src, dst = ei[0], ei[1]
+    xl = F.linear(x, lin_weight)
+    al = (xl * att_l.view(1, -1)).sum(-1)
+    ar = (xl * att_r.view(1, -1)).sum(-1)
+    alpha = F.leaky_relu(al[src] + ar[dst], slope)
+    alpha = segment_softmax(alpha.view(-1, 1), dst, N)
+    return scatter(alpha * xl.index_select(0, src), dst, N, "sum") + bias
+
+
+# --------------------------------------------------------------------------------------
 # Readouts (src_1gp/layer.py:197-220, model.py:41)
 # --------------------------------------------------------------------------------------
 def global_add_pool(x, batch, num_graphs):
@@ -280,12 +315,17 @@ def message_block(sd, prefix, x, edge_index, edge_attr, h, batch, num_graphs, co
     elif conv == "_NNConv":
         x = nnconv_mean(x, edge_index, edge_attr, sd[p + "nn.0.weight"], sd[p + "nn.0.bias"],
                         sd[p + "nn.2.weight"], sd[p + "nn.2.bias"], sd[p + "root"], sd[p + "bias"])
+    elif conv == "_GCNConv":
+        x = gcn_conv(x, edge_index, sd[p + "weight"], sd[p + "bias"])
+    elif conv == "_GATConv":
+        x = gat_conv(x, edge_index, sd[p + "lin_l.weight"], sd[p + "att_l"], sd[p + "att_r"], sd[p + "bias"])
     else:
         raise ValueError(conv)
-    g = prefix + "gru."
-    x = F.celu(x)                                            # layer.py:261
-    h = gru_step(x, h, sd[g + "weight_ih_l0"], sd[g + "weight_hh_l0"], sd[g + "bias_ih_l0"], sd[g + "bias_hh_l0"])
-    x = h                                                    # layer.py:262-263
+    if conv not in ("_GCNConv", "_GATConv"):                 # layer.py:248: no GRU for GCN / GAT
+        g = prefix + "gru."
+        x = F.celu(x)                                        # layer.py:261
+        h = gru_step(x, h, sd[g + "weight_ih_l0"], sd[g + "weight_hh_l0"], sd[g + "bias_ih_l0"], sd[g + "bias_hh_l0"])
+        x = h                                                # layer.py:262-263
     if res:
         x = x + identity                                     # layer.py:265
     return activation(act, x), h

@@ -186,7 +186,7 @@ def test_message_block_golden(device, name):
     g = Golden(name)
     m = g.meta
     blk = layer.MessageBlock(60, 60, 4, norm=m["norm"], dropout="_None()", conv=m["conv"], act=m["act"], res=True)
-    blk.load_state_dict(g.params)
+    blk.load_state_dict(g.params, strict=False)     # GATConv's shared lin_r alias is not in named_parameters()
     blk = blk.to(device).eval()
     i = _dev(g.inputs, device)
     x = i["x"].clone().requires_grad_(True)

@@ -95,13 +95,16 @@ def test_architecture_state_dict_matches_reference(name):
     net.load_state_dict(g.params)   # reference checkpoints load unchanged
 
 
-@pytest.mark.parametrize("name", ["block_triplet_relu", "block_triplet_pair_rrelu", "block_light_celu", "block_nnconv_relu"])
+@pytest.mark.parametrize("name", ["block_triplet_relu", "block_triplet_pair_rrelu", "block_light_celu", "block_nnconv_relu",
+                                  "block_gcn_relu", "block_gat_leaky"])
 def test_message_block_state_dict_keys(name):
     g = Golden(name)
     m = g.meta
     blk = layer.MessageBlock(60, 60, 4, norm=m["norm"], dropout="_None()", conv=m["conv"], act=m["act"], res=True)
-    assert list(blk.state_dict()) == list(g.params)
-    blk.load_state_dict(g.params)
+    assert [n for n, _ in blk.named_parameters()] == list(g.params)
+    missing = blk.load_state_dict(g.params, strict=False)
+    # the goldens store named_parameters(); PyG's GATConv registers the shared Linear twice (lin_l is lin_r)
+    assert set(missing.missing_keys) <= {"conv.conv.lin_r.weight"} and not missing.unexpected_keys
 
 
 def test_string_dispatch_surface():
