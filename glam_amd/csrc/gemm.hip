@@ -13,8 +13,8 @@
 //               MFMA step j) and the B operands of a 16-k group are one ds_read_b128 per tile.  Two waves
 //               per SIMD overlap one wave's loads / stores with the other's MFMAs.
 //   k_wgrad     G[I, J] = [P1 | P2 | 1]^T[I, N] @ Q[N, J], I <= 192, J <= 64, reduction over rows.
-//               Block = (16-column slab of P, row split); its 4 waves take disjoint row ranges and are
-//               summed through LDS; block partials (4 KB) are combined in a fixed order by k_final_reduce
+//               Block = (16-column slab of P, row split); its 16 waves take disjoint row ranges (loads of one
+//               wave hide behind the MFMAs of the others) and are summed through LDS; block partials (4 KB) are combined in a fixed order by k_final_reduce
 //               (deterministic, no atomics), which also folds the aggregate kernel's d_W_edge partials.
 #include "dense.h"
 
@@ -135,91 +135,56 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
 // G[I, J] = [P1 | P2 | 1]^T @ Q.  A wave owns a 16 x 64 output slab (4 accumulator tiles) over its own row
 // range: per 4-row step one scalar load feeds the A operand (P[n][i0 + c]) and ONE float4 load the B
 // operands of the 4 column tiles (stride-4 column permutation: tile tj holds columns 4c + tj).
-constexpr int kWgChunk = 64;          // rows staged per LDS chunk
+#ifndef GLAM_WG_BLOCK
+#define GLAM_WG_BLOCK 1024
+#endif
+#ifndef GLAM_WG_STEPS
+#define GLAM_WG_STEPS 8
+#endif
+constexpr int kWgBlock = GLAM_WG_BLOCK;        // 16 waves (4 per SIMD): row ranges interleave, loads hide behind MFMAs
+constexpr int kWgWaves = kWgBlock / 64;
 
-// LDS-tiled: the block streams its row range through LDS in 64-row chunks with fully coalesced float4
-// loads (Q: 64 x 64 floats, P slab: 64 x 16 floats).  The loop is latency bound (one block per CU, a chunk is
-// only 16 MFMAs per wave), so global loads run THREE chunks ahead through a ring of register sets; wave w
-// multiplies rows 16w..16w+15 of every chunk (4 MFMA steps x 4 column tiles), operands from LDS:
-// A = P[row][c] (ds_read_b32), B = Q[row][4c..4c+3] (ds_read_b128).
-struct WgStage { float4 q[4]; float4 p; };
-
-__global__ void __launch_bounds__(kBlock) k_wgrad(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_q[kWgChunk * 64];
-    __shared__ __attribute__((aligned(16))) float s_p[kWgChunk * 16];
+__global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
+    __shared__ float s_red[(kWgWaves - 1) * 1024];     // waves 1..15: [16 regs][64 lanes]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
     const int ntile = gridDim.x / a.nsplit;
     const int itile = blockIdx.x % ntile, split = blockIdx.x / ntile;
-    const int row0 = split * a.rows_per_wave;                  // rows_per_wave = rows per BLOCK here
+    const int row0 = (split * kWgWaves + wave) * a.rows_per_wave;
     const int row1 = min(row0 + a.rows_per_wave, a.N);
+    const int pcol = itile * 16 + c, qcol = 4 * c;
     const int I12 = a.I1 + a.I2;
-
-    // staging assignment: Q float4 slots (row = slot / 16, col4 = slot % 16), 4 per thread; P: 1 per thread
-    const int prow = tid >> 2, pcol = itile * 16 + 4 * (tid & 3);
+    // resolve the P source of this lane's column once
     const float* pbase = nullptr;
     int pld = 0;
-    float4 pconst = f4zero();
+    float pconst = 0.f;
     if (pcol < a.I1) { pbase = a.P1 + pcol; pld = a.ldp1; }
     else if (pcol < I12) { pbase = a.P2 + (pcol - a.I1); pld = a.ldp2; }
-    else if (a.ones && pcol == I12) pconst = make_float4(1.f, 0.f, 0.f, 0.f);
-
-    // Loads are UNCONDITIONAL (row / column clamped to a valid address, result zeroed by a select): predicated
-    // loads sit behind exec-mask branches, the compiler then cannot count them and falls back to
-    // s_waitcnt vmcnt(0), which would collapse the 3-chunk prefetch distance to one.
-    const int last_row = a.N - 1;
-    const float* pptr = pbase ? pbase : a.Q;                   // any valid address when the column is virtual
-    const int pstride = pbase ? pld : 0;
-    auto fetch = [&](WgStage& st, int base) {                 // raw loads only; masking happens at stash time
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int slot = tid + u * kBlock, r = base + (slot >> 4), q4 = (slot & 15) * 4;
-            st.q[u] = ld4(a.Q + (size_t)min(r, last_row) * a.ldq + (q4 < a.J ? q4 : 0));
-        }
-        st.p = ld4(pptr + (size_t)min(base + prow, last_row) * pstride);
-    };
+    else if (a.ones && pcol == I12) pconst = 1.f;
+    const bool qok = qcol < a.J;
+    const bool qone = a.qones && qcol == a.J;
 
     v4f acc[4];
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) acc[tj] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const float* qs = s_q + (wave * 16 + kq) * 64 + 4 * c;
-    const float* ps = s_p + (wave * 16 + kq) * 16 + c;
 
-    // one chunk: registers -> LDS (masked), refill the register set 3 chunks ahead, multiply
-    auto step = [&](WgStage& st, int base) {
-        if (base >= row1) return;                              // uniform across the block
+    constexpr int kSteps = GLAM_WG_STEPS; // rows/4 per batch: 2*kSteps loads in flight, then 4*kSteps MFMAs
+    for (int n0 = row0; n0 < row1; n0 += 4 * kSteps) {
+        float pv[kSteps];
+        float4 qv[kSteps];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int slot = tid + u * kBlock, r = base + (slot >> 4), q4 = (slot & 15) * 4;
-            const bool rok = r < row1;
-            const float4 v = (rok && q4 < a.J) ? st.q[u] : (rok && a.qones && q4 == a.J) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
-            st4(&s_q[slot * 4], v);
+        for (int st = 0; st < kSteps; ++st) {
+            const int n = n0 + 4 * st + kq;
+            const bool nok = n < row1;
+            pv[st] = nok ? (pbase ? pbase[(size_t)n * pld] : pconst) : 0.f;
+            qv[st] = (nok && qok) ? ld4(a.Q + (size_t)n * a.ldq + qcol) : (nok && qone) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
         }
-        st4(&s_p[tid * 4], base + prow < row1 ? (pbase ? st.p : pconst) : f4zero());
-        __syncthreads();
-        fetch(st, base + 3 * kWgChunk);
-        float pv[4];
-        float4 qv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { pv[k] = ps[k * 4 * 16]; qv[k] = ld4(qs + k * 4 * 64); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int st = 0; st < kSteps; ++st)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[k], f4get(qv[k], tj), acc[tj], 0, 0, 0);
-        __syncthreads();
-    };
-
-    WgStage r0, r1, r2;
-    fetch(r0, row0);
-    fetch(r1, row0 + kWgChunk);
-    fetch(r2, row0 + 2 * kWgChunk);
-    for (int base = row0; base < row1; base += 3 * kWgChunk) {
-        step(r0, base);
-        step(r1, base + kWgChunk);
-        step(r2, base + 2 * kWgChunk);
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[st], f4get(qv[st], tj), acc[tj], 0, 0, 0);
     }
-    // ---- sum the 4 waves lane-for-lane (identical register layouts) in wave order; reuse s_q as scratch ----
-    float* s_red = s_q;
+    // ---- sum the 16 waves lane-for-lane (identical register layouts) in wave order ----
     if (wave > 0) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -234,7 +199,10 @@ __global__ void __launch_bounds__(kBlock) k_wgrad(WgArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (tj * 4 + r) * 64 + lane;
-                out[o] = ((acc[tj][r] + s_red[o]) + s_red[1024 + o]) + s_red[2048 + o];
+                float sum = acc[tj][r];
+#pragma unroll
+                for (int w = 1; w < kWgWaves; ++w) sum += s_red[(w - 1) * 1024 + o];
+                out[o] = sum;
             }
     }
 }
@@ -332,19 +300,17 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
     const int Jt = a.J + (a.qones ? 1 : 0);
     if (I > 192 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3))
         return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d J=%d outside the kernel table (I <= 192, J <= 64, J %% 4 == 0)", I, a.J);
-    if ((a.I1 & 3) || (a.I2 & 3) || (a.ldp1 & 3) || (a.I2 && (a.ldp2 & 3)))
-        return fail(GLAM_E_UNSUPPORTED, "wgrad: I1=%d I2=%d and their leading dimensions must be multiples of 4", a.I1, a.I2);
     const int ntile = (I + 15) / 16;
     int nsplit = kWgradBlocks / ntile;
-    // at least one 64-row chunk per block when the problem is small
-    const int max_split = (int)(((int64_t)a.N + kWgChunk - 1) / kWgChunk);
+    // keep at least 32 rows per wave when the problem is small
+    const int max_split = (int)(((int64_t)a.N + 32 * kWgWaves - 1) / (32 * kWgWaves));
     if (nsplit > max_split) nsplit = max_split < 1 ? 1 : max_split;
-    int rpb = (int)(((int64_t)a.N + nsplit - 1) / nsplit);
-    rpb = (rpb + 3) & ~3;
-    if (rpb < 4) rpb = 4;
-    a.rows_per_wave = rpb;      // rows per block for the LDS-tiled kernel
+    int rpw = (int)(((int64_t)a.N + nsplit * kWgWaves - 1) / (nsplit * kWgWaves));
+    rpw = (rpw + 3) & ~3;
+    if (rpw < 4) rpw = 4;
+    a.rows_per_wave = rpw;
     a.nsplit = nsplit;
-    hipLaunchKernelGGL(k_wgrad, dim3(ntile * nsplit), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(ntile * nsplit), dim3(kWgBlock), 0, s, a);
     GLAM_LAUNCH_CHECK("wgrad");
     *job = ReduceJob{0, a.partial, nsplit, ntile * 1024, I, Jt, si, sj, out, nullptr, 0, 0};
     return GLAM_OK;
