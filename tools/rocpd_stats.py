@@ -8,11 +8,14 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else "kernel_name"
-rows = db.execute(f"select {name_col}, start, end from kernels").fetchall()
+grid_col = "grid_size" if "grid_size" in cols else ("grid_x" if "grid_x" in cols else None)
+rows = db.execute(f"select {name_col}, start, end, {grid_col or 0} from kernels").fetchall()
 agg = {}
-for name, s, e in rows:
+for name, s, e, grid in rows:
     name = re.sub(r"\(.*", "", name)
     name = re.sub(r"^void ", "", name)
+    if name.startswith("glam::") and grid_col:
+        name = f"{name} [grid={grid}]"        # same kernel at different problem sizes is reported separately
     a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
     d = (e - s) / 1e3
     a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
