@@ -22,8 +22,8 @@ struct WgArgs {
     const float* Q; int J; int ldq;        // J % 4 == 0, J <= 64
     int qones;                             // 1: virtual all-ones column at index J (needs J + 1 <= 64)
     int N; int rows_per_wave;              // multiple of 4
-    float* partial;                        // [ntile_i][nsplit][16 regs][64 lanes]
-    int nsplit;
+    float* partial;                        // [slab][nsplit][64 regs][64 lanes]
+    int nsplit; int ntile;
 };
 
 // see k_final_reduce in gemm.hip
@@ -38,6 +38,8 @@ int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, floa
 int launch_ts_gemm(const TsArgs& a, hipStream_t s);
 size_t wgrad_workspace_floats();
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job);
+int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
+                           int sj_b, ReduceJob* job_b, hipStream_t s);
 int launch_final_reduce(ReduceArgs ra, hipStream_t s);
 
 bool triplet_fwd_can_fuse_update(int H, int Cp, int De);

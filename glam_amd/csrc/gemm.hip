@@ -13,9 +13,10 @@
 //               MFMA step j) and the B operands of a 16-k group are one ds_read_b128 per tile.  Two waves
 //               per SIMD overlap one wave's loads / stores with the other's MFMAs.
 //   k_wgrad     G[I, J] = [P1 | P2 | 1]^T[I, N] @ Q[N, J], I <= 192, J <= 64, reduction over rows.
-//               Block = (16-column slab of P, row split); its 16 waves take disjoint row ranges (loads of one
-//               wave hide behind the MFMAs of the others) and are summed through LDS; block partials (4 KB) are combined in a fixed order by k_final_reduce
-//               (deterministic, no atomics), which also folds the aggregate kernel's d_W_edge partials.
+//               Block = (64-column slab of P, row split); its 8 waves take disjoint row ranges, each holding a
+//               64 x 64 accumulator slab, and are summed through LDS; block partials (16 KB) are combined in a
+//               fixed order by k_final_reduce (deterministic, no atomics), which also folds the aggregate
+//               kernel's d_W_edge partials.
 #include "dense.h"
 
 namespace glam {
@@ -132,86 +133,101 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// G[I, J] = [P1 | P2 | 1]^T @ Q.  A wave owns a 16 x 64 output slab (4 accumulator tiles) over its own row
-// range: per 4-row step one scalar load feeds the A operand (P[n][i0 + c]) and ONE float4 load the B
-// operands of the 4 column tiles (stride-4 column permutation: tile tj holds columns 4c + tj).
-#ifndef GLAM_WG_BLOCK
-#define GLAM_WG_BLOCK 1024
-#endif
+// G[I, J] = [P1 | P2 | 1]^T @ Q.  A wave owns a 64 x 64 output slab (16 accumulator tiles, 64 VGPRs) over its own
+// row range: per 4-row step ONE float4 load of P feeds the A operands of the 4 row tiles and ONE float4 load of Q
+// the B operands of the 4 column tiles (stride-4 permutation on both sides: tile t holds columns 4c + t), i.e.
+// 16 MFMAs per two fully coalesced 256-byte-per-row loads.  Block = (64-column slab of P, row split), 8 waves on
+// disjoint row ranges, summed through LDS in wave order.
 #ifndef GLAM_WG_STEPS
-#define GLAM_WG_STEPS 8
+#define GLAM_WG_STEPS 4
 #endif
-constexpr int kWgBlock = GLAM_WG_BLOCK;        // 16 waves (4 per SIMD): row ranges interleave, loads hide behind MFMAs
+#ifndef GLAM_WG_PAIR_BLOCKS
+#define GLAM_WG_PAIR_BLOCKS 256
+#endif
+constexpr int kWgBlock = 512;
 constexpr int kWgWaves = kWgBlock / 64;
 
-__global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs a) {
-    __shared__ float s_red[(kWgWaves - 1) * 1024];     // waves 1..15: [16 regs][64 lanes]
+// Two independent products may share one launch (blocks [0, first_b) work on job a, the rest on job b).
+struct WgArgs2 { WgArgs a, b; int first_b; };
+
+__global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
+    __shared__ float s_red[kWgWaves * 32 * 64];        // half of the 64 accumulator registers at a time: 64 KB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
-    const int ntile = gridDim.x / a.nsplit;
-    const int itile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+    const bool second = (int)blockIdx.x >= two.first_b;
+    const WgArgs& a = second ? two.b : two.a;
+    // XCD-aware decode (blockIdx % 8 = XCD): the slabs of one row split share an XCD, so Q is fetched into one L2
+    const int bid = second ? blockIdx.x - two.first_b : blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int slab = loc % a.ntile, split = (loc / a.ntile) * 8 + xcd;
+    if (split >= a.nsplit) return;
     const int row0 = (split * kWgWaves + wave) * a.rows_per_wave;
     const int row1 = min(row0 + a.rows_per_wave, a.N);
-    const int pcol = itile * 16 + c, qcol = 4 * c;
+    const int pcol = slab * 64 + 4 * c, qcol = 4 * c;
     const int I12 = a.I1 + a.I2;
-    // resolve the P source of this lane's column once
+    // resolve the P source of this lane's 4 columns once (I1, I2 are multiples of 4: no straddling)
     const float* pbase = nullptr;
     int pld = 0;
-    float pconst = 0.f;
+    float4 pconst = f4zero();
     if (pcol < a.I1) { pbase = a.P1 + pcol; pld = a.ldp1; }
     else if (pcol < I12) { pbase = a.P2 + (pcol - a.I1); pld = a.ldp2; }
-    else if (a.ones && pcol == I12) pconst = 1.f;
+    else if (a.ones && pcol == I12) pconst = make_float4(1.f, 0.f, 0.f, 0.f);
     const bool qok = qcol < a.J;
-    const bool qone = a.qones && qcol == a.J;
+    const float4 qconst = (a.qones && qcol == a.J) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
 
-    v4f acc[4];
+    v4f acc[4][4];
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) acc[tj] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int kSteps = GLAM_WG_STEPS; // rows/4 per batch: 2*kSteps loads in flight, then 4*kSteps MFMAs
+    constexpr int kSteps = GLAM_WG_STEPS;   // rows/4 per batch: 2*kSteps float4 loads in flight, then 16*kSteps MFMAs
     for (int n0 = row0; n0 < row1; n0 += 4 * kSteps) {
-        float pv[kSteps];
-        float4 qv[kSteps];
+        float4 pv[kSteps], qv[kSteps];
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
             const int n = n0 + 4 * st + kq;
             const bool nok = n < row1;
-            pv[st] = nok ? (pbase ? pbase[(size_t)n * pld] : pconst) : 0.f;
-            qv[st] = (nok && qok) ? ld4(a.Q + (size_t)n * a.ldq + qcol) : (nok && qone) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
+            pv[st] = nok ? (pbase ? ld4(pbase + (size_t)n * pld) : pconst) : f4zero();
+            qv[st] = nok ? (qok ? ld4(a.Q + (size_t)n * a.ldq + qcol) : qconst) : f4zero();
         }
 #pragma unroll
         for (int st = 0; st < kSteps; ++st)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[st], f4get(qv[st], tj), acc[tj], 0, 0, 0);
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv[st], ti), f4get(qv[st], tj), acc[ti][tj], 0, 0, 0);
     }
-    // ---- sum the 16 waves lane-for-lane (identical register layouts) in wave order ----
-    if (wave > 0) {
+    // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order; wave w finalises 4 of every 32
+    //      registers.  reg = (ti*4 + tj)*4 + r ----
+    float* out = a.partial + ((size_t)slab * a.nsplit + split) * 4096;
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_red[(wave - 1) * 1024 + (tj * 4 + r) * 64 + lane] = acc[tj][r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float* out = a.partial + ((size_t)itile * a.nsplit + split) * 1024;
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = (tj * 4 + r) * 64 + lane;
-                float sum = acc[tj][r];
-#pragma unroll
-                for (int w = 1; w < kWgWaves; ++w) sum += s_red[(w - 1) * 1024 + o];
-                out[o] = sum;
+                const int tt = half * 8 + t;
+                s_red[(wave * 32 + t * 4 + r) * 64 + lane] = acc[tt >> 2][tt & 3][r];
             }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int reg = wave * 4 + q;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWgWaves; ++w) sum += s_red[(w * 32 + reg) * 64 + lane];
+            out[(half * 32 + reg) * 64 + lane] = sum;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Final fixed-order reduction of up to 3 partial sets in ONE launch.
-//   kind 0 (k_wgrad partials): element offset `o` in [0, ntile*1024) decodes to reg = (o%1024)/64, lane = o%64,
-//          tj = reg/4, r = reg%4, kq = lane/16, c = lane%16  ->  i = 16*tile + 4*kq + r, j = 4*c + tj;
-//          out[i*si + j*sj] = sum_s partial[(tile*nsplit + s)*1024 + o%1024]
+//   kind 0 (k_wgrad partials): element offset `o` in [0, nslab*4096) decodes to reg = (o%4096)/64, lane = o%64,
+//          ti = reg/16, tj = (reg/4)%4, r = reg%4, kq = lane/16, c = lane%16  ->  i = 64*slab + 4*(4*kq + r) + ti,
+//          j = 4*c + tj;  out[i*si + j*sj] = sum_s partial[(slab*nsplit + s)*4096 + o%4096]
 //   kind 1 (flat block partials [nsplit][n]): out[e] (e < split_at) or out2[e - split_at] = sum_s partial[s*n + e]
 __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
     __shared__ float s_part[16][17];
@@ -226,7 +242,7 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
     if (e < J.n) {
         const float* p;
         size_t stride;
-        if (J.kind == 0) { p = J.partial + (size_t)(e >> 10) * J.nsplit * 1024 + (e & 1023); stride = 1024; }
+        if (J.kind == 0) { p = J.partial + (size_t)(e >> 12) * J.nsplit * 4096 + (e & 4095); stride = 4096; }
         else { p = J.partial + e; stride = (size_t)J.n; }
         int s = rl;
         for (; s + 16 < J.nsplit; s += 32) { s0 += p[(size_t)s * stride]; s1 += p[(size_t)(s + 16) * stride]; }
@@ -239,8 +255,8 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += s_part[r][c];
         if (J.kind == 0) {
-            const int o = e & 1023, reg = o >> 6, lane = o & 63;
-            const int i = (e >> 10) * 16 + (lane >> 4) * 4 + (reg & 3), j = 4 * (lane & 15) + (reg >> 2);
+            const int o = e & 4095, reg = o >> 6, lane = o & 63;
+            const int i = (e >> 12) * 64 + 4 * ((lane >> 4) * 4 + (reg & 3)) + (reg >> 4), j = 4 * (lane & 15) + ((reg >> 2) & 3);
             if (i < J.I && j < J.J) J.out[(size_t)i * J.si + (size_t)j * J.sj] = s;
         } else if (e < J.split_at) {
             if (J.out) J.out[e] = s;
@@ -290,29 +306,56 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
     return GLAM_OK;
 }
 
-constexpr int kWgradBlocks = 256;   // one 4-wave block per CU
+constexpr int kWgradBlocks = 256;   // about one 8-wave block per CU
 
-size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocks + 12) * 1024; }
+size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocks + 24) * 4096; }
 
-// fills the launch geometry of a k_wgrad call and the matching reduce job; launches k_wgrad
-int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
+// fills the launch geometry of one product (at most `budget` blocks) and the matching reduce job
+static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {
     const int I = a.I1 + a.I2 + (a.ones ? 1 : 0);
     const int Jt = a.J + (a.qones ? 1 : 0);
-    if (I > 192 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3))
-        return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d J=%d outside the kernel table (I <= 192, J <= 64, J %% 4 == 0)", I, a.J);
-    const int ntile = (I + 15) / 16;
-    int nsplit = kWgradBlocks / ntile;
-    // keep at least 32 rows per wave when the problem is small
-    const int max_split = (int)(((int64_t)a.N + 32 * kWgWaves - 1) / (32 * kWgWaves));
+    if (I > 192 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3) || (a.I1 & 3) || (a.I2 & 3) || (a.ldp1 & 3) ||
+        (a.I2 && (a.ldp2 & 3)))
+        return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d+%d J=%d outside the kernel table (I <= 192, J <= 64, multiples of 4)",
+                    a.I1, a.I2, a.J);
+    const int nslab = (I + 63) / 64;
+    int nsplit = budget / nslab / 8 * 8;         // multiple of 8: one XCD per row split
+    if (nsplit < 8) nsplit = 8;
+    // keep at least 16 rows per wave when the problem is small
+    const int max_split = (int)(((int64_t)a.N + 16 * kWgWaves - 1) / (16 * kWgWaves));
     if (nsplit > max_split) nsplit = max_split < 1 ? 1 : max_split;
     int rpw = (int)(((int64_t)a.N + nsplit * kWgWaves - 1) / (nsplit * kWgWaves));
     rpw = (rpw + 3) & ~3;
     if (rpw < 4) rpw = 4;
     a.rows_per_wave = rpw;
     a.nsplit = nsplit;
-    hipLaunchKernelGGL(k_wgrad, dim3(ntile * nsplit), dim3(kWgBlock), 0, s, a);
+    a.ntile = nslab;
+    *blocks = (nsplit + 7) / 8 * 8 * nslab;
+    *job = ReduceJob{0, a.partial, nsplit, nslab * 4096, I, Jt, si, sj, out, nullptr, 0, 0};
+    return GLAM_OK;
+}
+
+int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
+    int blocks = 0;
+    if (int rc = plan_wgrad(a, out, si, sj, kWgradBlocks, job, &blocks)) return rc;
+    WgArgs2 two{a, a, blocks};
+    hipLaunchKernelGGL(k_wgrad, dim3(blocks), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad");
-    *job = ReduceJob{0, a.partial, nsplit, ntile * 1024, I, Jt, si, sj, out, nullptr, 0, 0};
+    return GLAM_OK;
+}
+
+// two products in one launch; the block budget is shared in proportion to their slab counts
+int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
+                           int sj_b, ReduceJob* job_b, hipStream_t s) {
+    const int ta = (a.I1 + a.I2 + (a.ones ? 1 : 0) + 63) / 64, tb = (b.I1 + b.I2 + (b.ones ? 1 : 0) + 63) / 64;
+    const int total = GLAM_WG_PAIR_BLOCKS;
+    const int ba = ta + tb > 0 ? total * ta / (ta + tb) : total / 2;
+    int na = 0, nb = 0;
+    if (int rc = plan_wgrad(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;
+    if (int rc = plan_wgrad(b, out_b, si_b, sj_b, total - ba, job_b, &nb)) return rc;
+    WgArgs2 two{a, b, na};
+    hipLaunchKernelGGL(k_wgrad, dim3(na + nb), dim3(kWgBlock), 0, s, two);
+    GLAM_LAUNCH_CHECK("wgrad(pair)");
     return GLAM_OK;
 }
 
@@ -361,7 +404,7 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm: workspace too small");
     GLAM_REQUIRE(aligned16(Q) && aligned16(P1) && aligned16(P2), "glam_wgrad_gemm: P / Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-    WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, (int)N, 0, partial, 0};
+    WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, (int)N, 0, partial, 0, 0};
     ReduceArgs ra{};
     ra.njobs = 1;
     if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, (hipStream_t)stream, &ra.job[0])) return rc;

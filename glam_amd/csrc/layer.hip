@@ -12,7 +12,6 @@
 // M[k,h] = sum_c W_edge[k,h,c] att[h,C+c]; they ride along as 8 extra columns of the node GEMM.
 // All node-feature widths are padded to Cp (multiple of 4) so every row is 16-byte aligned.
 #include "dense.h"
-#include <stdlib.h>
 
 namespace glam {
 
@@ -191,36 +190,6 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
     }
 }
 
-// Side stream for the weight-gradient GEMMs: they depend only on saved activations, so they run beside
-// the data-gradient chain (fork/join with events; under hipGraph capture this becomes two parallel
-// branches of the graph).  Created on first use — which must happen outside stream capture, like the
-// CSR staging — one per device per host thread.
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork1 = nullptr, fork2 = nullptr, join = nullptr;
-    bool failed = false;
-};
-static SideStream* side_stream() {
-    static thread_local SideStream tab[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream& ss = tab[dev];
-    if (!ss.stream && !ss.failed) {
-        // measured on MI355X (profiles/r1_notes): forking the hipGraph into two branches costs more than the
-        // overlap wins at B=1024 (183 us vs 160 us per step), so the branch is opt-in
-        const char* on = getenv("GLAM_OVERLAP");
-        if (!(on && on[0] == '1') || hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.fork1, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.fork2, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) {
-            ss.failed = true;
-            ss.stream = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    return ss.stream ? &ss : nullptr;
-}
-
 }  // namespace glam
 
 using namespace glam;
@@ -323,16 +292,6 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
     ReduceArgs ra{};
     ra.njobs = 3;
 
-    SideStream* side = side_stream();
-    hipStream_t s2 = side ? side->stream : s;
-
-    // branch: d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias) needs only saved tensors
-    if (side) {
-        (void)hipEventRecord(side->fork1, s);
-        (void)hipStreamWaitEvent(s2, side->fork1, 0);
-    }
-    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, 0, (int)N, 0, wg1, 0};
-    if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, s2, &ra.job[0])) return rc;
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
     TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
     if (int rc = launch_ts_gemm(g1, s)) return rc;
@@ -344,20 +303,17 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
-    // branch: d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T, beside d_x
-    if (side) {
-        (void)hipEventRecord(side->fork2, s);
-        (void)hipStreamWaitEvent(s2, side->fork2, 0);
-    }
-    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0};
-    if (int rc = launch_wgrad_partials(w2, dstaged + G.d_wcat, 1, HC + 8, s2, &ra.job[2])) return rc;
+    // both weight-gradient products in ONE launch (each is latency bound on its own):
+    //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
+    //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
+    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, 0, (int)N, 0, wg1, 0, 0};
+    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0, 0};
+    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8,
+                                        &ra.job[2], s))
+        return rc;
     // d_x = [d_xw | d_a] @ Wcat^T
     TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
     if (int rc = launch_ts_gemm(g2, s)) return rc;
-    if (side) {
-        (void)hipEventRecord(side->join, s2);
-        (void)hipStreamWaitEvent(s, side->join, 0);
-    }
     // one fixed-order reduction for the three partial sets (d_W_scale|d_bias, d_W_edge|d_M, d_Wcat)
     return launch_final_reduce(ra, s);
 }
