@@ -47,6 +47,11 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
                              const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
                              int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
                              const float* img_upd, const float* bias_p, float* out, hipStream_t s);
+bool tile_fwd_supported(int H, int Cp, int Dp);
+int tile_fwd_launch(const float* x, const float* edge_attr, const float* img_node, const float* img_upd, const float* we_p,
+                    const float* M, const float* bias_p, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                    const int32_t* tile_ptr, int T, int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr,
+                    float* stats, float* out, hipStream_t s);
 int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
                      const float* aggr, const float* stats, const float* d_aggr, const int32_t* rowptr,
                      const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,

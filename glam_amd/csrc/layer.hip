@@ -235,9 +235,9 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
 }
 
 extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                                      const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp,
-                                      int Dp, float slope, float* xw, float* a_ij, float* aggr, float* stats,
-                                      float* out, void* stream) {
+                                      const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T,
+                                      int64_t N, int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij,
+                                      float* aggr, float* stats, float* out, void* stream) {
     if (int rc = dims_ok("glam_triplet_layer_fwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd: N out of range");
     if (N == 0) return GLAM_OK;
@@ -247,6 +247,11 @@ extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, co
     hipStream_t s = (hipStream_t)stream;
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
+    if (tile_ptr) {   // whole layer in one launch, one block per molecule tile
+        GLAM_REQUIRE(T >= 1 && rowptr && (E == 0 || (src && eid && edge_attr)), "glam_triplet_layer_fwd: bad tile plan / CSR");
+        return tile_fwd_launch(x, edge_attr, staged + L.img_node, staged + L.img_upd, staged + L.we_p, staged + L.m,
+                               staged + L.bias_p, rowptr, src, eid, tile_ptr, T, H, Cp, Dp, slope, xw, a_ij, aggr, stats, out, s);
+    }
     TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
     if (int rc = launch_ts_gemm(g1, s)) return rc;
     if (triplet_fwd_can_fuse_update(H, Cp, Dp))   // aggregate + update GEMM in one launch
@@ -258,6 +263,8 @@ extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, co
     TsArgs g2{aggr, HC, HC, nullptr, 0, 0, staged + L.img_upd, staged + L.bias_p, out, Cp, Cp, nullptr, 0, 0, (int)N};
     return launch_ts_gemm(g2, s);
 }
+
+extern "C" int glam_triplet_tile_supported(int H, int Cp, int Dp) { return tile_fwd_supported(H, Cp, Dp) ? 1 : 0; }
 
 extern "C" size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp) {
     const size_t HC = (size_t)H * Cp;

@@ -10,6 +10,7 @@ and its train loader does not shuffle (``src_1gp/trainer.py:37-38``).
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -41,12 +42,32 @@ class GraphIndex:
         self.eid = torch.empty(self.E, **i32)
         self._ei = ei
         self._t = None
+        self._tiles = False            # False: not planned yet; None: no plan (general kernels); else (tile_ptr, T)
         self._err = torch.zeros(1, **i32)
         ws = torch.empty(lib.glam_csr_workspace_bytes(self.N, self.E), dtype=torch.uint8, device=dev)
         check(lib.glam_csr_build(ptr(ei), self.N, self.E, 0, ptr(self.rowptr), ptr(self.src), ptr(self.eid),
                                  ptr(self._err), ptr(ws), ws.numel(), stream()), "glam_csr_build")
         if validate and int(self._err.item()) != 0:   # same failure class as torch's index_select on CPU
             raise IndexError(f"edge_index holds node ids outside [0, {self.N})")
+
+    TILE_TARGET_NODES = 80             # ~N/256 at the ESOL batch of 1024: one tile per CU
+
+    def tile_plan(self):
+        """``(tile_ptr int32[T+1], T)`` for the molecule-tile kernels, or ``None`` when the graph has an edge-closed
+        node range larger than a tile (one host sync, once per batch object)."""
+        if self._tiles is False:
+            self._tiles = None
+            if self.N > 0:
+                lib = _lib.load()
+                T = (self.N + self.TILE_TARGET_NODES - 1) // self.TILE_TARGET_NODES
+                i32 = dict(dtype=torch.int32, device=self.device)
+                tile_ptr, err = torch.empty(T + 1, **i32), torch.zeros(1, **i32)
+                ws = torch.empty(lib.glam_tile_plan_workspace_bytes(self.N), dtype=torch.uint8, device=self.device)
+                check(lib.glam_tile_plan(ptr(self.rowptr), ptr(self.src), self.N, self.E, T, ptr(tile_ptr), ptr(err), ptr(ws),
+                                         ws.numel(), stream()), "glam_tile_plan")
+                if int(err.item()) == 0:
+                    self._tiles = (tile_ptr, T)
+        return self._tiles
 
     def transpose(self):
         """CSR by source (built on first backward)."""
@@ -60,6 +81,8 @@ class GraphIndex:
             self._t = (colptr, dst, eid_t)
         return self._t
 
+
+TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
 
 _GI_CACHE: dict = {}
 
@@ -206,8 +229,13 @@ class _TripletLayer(torch.autograd.Function):
                                             stream()), "glam_triplet_stage_params")
         xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
         aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
-        check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, gi.E,
-                                         H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
+        # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
+        # faster at B=1024 (one tile per CU) but slower beyond, where its barrier-separated phases leave the CU idle
+        # (measurements in DESIGN.md).
+        tiles = gi.tile_plan() if (TILES_ENABLED and lib.glam_triplet_tile_supported(H, Cp, Dp)) else None
+        tile_ptr, T = tiles if tiles is not None else (None, 0)
+        check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
+                                         ptr(tile_ptr), T, N, gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
                                          stream()), "glam_triplet_layer_fwd")
         ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))

@@ -57,6 +57,15 @@ int glam_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int by, int3
 
 /* Segment pointer of a sorted graph-id vector: ptr int32[B+1] from batch int64[N] (non-decreasing),
  * as produced by PyG collation and consumed by global_*_pool(x, batch) (src_1gp/layer.py:202). */
+/* Tile plan for the molecule-tile kernels: tile_ptr int32[T+1], non-decreasing node boundaries with
+ * tile_ptr[0] = 0, tile_ptr[T] = N, such that no edge of the CSR joins two different tiles (boundary t is the
+ * first edge-free cut at or after t*N/T; on molecular batches that is the next molecule start).  *err_flag is
+ * raised when some tile outgrows the kernels' capacity (112 nodes / 512 edges): the caller then keeps the general
+ * path.  Replaces nothing in the reference - it is the precondition that lets src_1gp/layer.py:36-61 run out of
+ * one CU's LDS. */
+size_t glam_tile_plan_workspace_bytes(int64_t N);
+int glam_tile_plan(const int32_t* rowptr, const int32_t* nbr, int64_t N, int64_t E, int32_t T, int32_t* tile_ptr,
+                   int32_t* err_flag, void* ws, size_t ws_bytes, void* stream);
 int glam_batch_ptr(const int64_t* batch, int64_t N, int64_t B, int32_t* ptr, int32_t* err_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -162,7 +171,7 @@ int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, 
  *   glam_triplet_stage_params: parameters -> `staged` (glam_triplet_staged_floats floats): the four GEMM weight
  *     images ([W_node | Wa_i | Wa_j] with the separable-attention columns, W_scale, and their transposes),
  *     W_edge head-padded, M f32[Dp,4], bias padded.
- *   glam_triplet_layer_fwd:  x -> (xw, a_ij) -> aggr, stats -> out          (3 launches)
+ *   glam_triplet_layer_fwd:  x -> (xw, a_ij) -> aggr, stats -> out          (2 launches; ONE with a tile plan)
  *   glam_triplet_layer_bwd:  d_out -> d_x and `dstaged` (glam_triplet_dstaged_floats floats: d_Wcat[Cp,H*Cp+8] |
  *                            d_WsB[H*Cp+1,Cp] (last row = d_bias) | d_We_p | d_M), optional d_edge_attr
  *                            (9 launches, no atomics)
@@ -179,8 +188,12 @@ int glam_triplet_stage_params_bwd(const float* weight_node, const float* weight_
                                   float* d_weight_edge, float* d_att, float* d_weight_scale, float* d_bias,
                                   void* stream);
 int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                           const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
-                           float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);
+                           const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T, int64_t N,
+                           int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr,
+                           float* stats, float* out, void* stream);
+/* 1 when the molecule-tile kernels cover this layer shape (then pass a glam_tile_plan to the layer calls; with
+ * tile_ptr = NULL the general kernels run) */
+int glam_triplet_tile_supported(int H, int Cp, int Dp);
 size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp);
 int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
                            const float* a_ij, const float* aggr, const float* stats, const float* d_out,

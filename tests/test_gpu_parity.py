@@ -599,3 +599,49 @@ def test_two_tower_model_runs(device):
     assert out.shape == (6, 1) and torch.isfinite(out).all()
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize("B,C,heads,De", [(64, 60, 3, 4), (300, 60, 3, 4), (7, 30, 3, 4), (64, 60, 1, 4), (40, 32, 2, 1), (33, 44, 3, 8)])
+def test_tile_path_is_bit_identical_to_the_general_path(device, B, C, heads, De, monkeypatch):
+    """The molecule-tile kernels (one launch per layer, operands in LDS) keep the k order of every GEMM and the edge
+    order of every segment of the general kernels: same bits, forward and backward."""
+    monkeypatch.setattr(ops, "TILES_ENABLED", True)
+    torch.manual_seed(B + C)
+    b = synth_batch(B, seed=B).to(device)
+    N, E = b.x.size(0), b.edge_index.size(1)
+    conv = layer.TripletMessage(C, De, heads=heads).to(device)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    x = torch.randn(N, C, device=device, requires_grad=True)
+    ea = torch.rand(E, De, device=device)
+    cot = torch.randn(N, C, device=device)
+    gi = ops.graph_index(b.edge_index, N)
+    plan = gi.tile_plan()
+    assert plan is not None, "synthetic molecules must be tileable"
+    tile_ptr, T = plan
+    tp = tile_ptr.cpu()
+    assert tp[0] == 0 and tp[-1] == N and (tp[1:] >= tp[:-1]).all() and int((tp[1:] - tp[:-1]).max()) <= 112
+    tile_of = torch.bucketize(torch.arange(N), tp[1:], right=True)
+    src, dst = b.edge_index.cpu()
+    assert (tile_of[src] == tile_of[dst]).all(), "an edge crosses a tile boundary"
+    params = list(conv.parameters())
+
+    def run():
+        out = conv(x, b.edge_index, ea)
+        return [out] + list(torch.autograd.grad(out, params + [x], grad_outputs=cot))
+
+    tiled = run()
+    monkeypatch.setattr(ops, "TILES_ENABLED", False)
+    general = run()
+    for name, a, g in zip(["out"] + [n for n, _ in conv.named_parameters()] + ["x"], tiled, general):
+        assert torch.equal(a, g), f"{name}: tile path differs from the general path (max {float((a - g).abs().max()):.3e})"
+
+
+def test_tile_plan_falls_back_on_large_components(device, monkeypatch):
+    monkeypatch.setattr(ops, "TILES_ENABLED", True)
+    p = synth_protein_batch(2, seed=5, n_min=200, n_max=260).to(device)
+    gi = ops.graph_index(p.edge_index, p.x.size(0))
+    assert gi.tile_plan() is None      # a 200-residue component cannot fit a 112-node tile: general kernels
+    conv = layer.TripletMessage(48, 8).to(device)
+    out = conv(torch.randn(p.x.size(0), 48, device=device), p.edge_index, p.edge_attr)
+    assert torch.isfinite(out).all()
