@@ -156,7 +156,7 @@ def main():
 
     from glam_amd import layer
     from glam_amd.data import synth_batch
-    from glam_amd.parallel import broadcast_parameters
+    from glam_amd.parallel import broadcast_parameters, flat_view
 
     B, C, De, H = args.batch, 60, 4, 3
     batch_cpu = synth_batch(B, seed=rank)                      # every rank: its own B molecules (weak scaling)
@@ -175,13 +175,16 @@ def main():
     cot = cot_cpu.to(dev)
     params = list(conv.parameters())
     n_param = sum(p.numel() for p in params)
-    flat = torch.zeros(n_param + x.numel(), device=dev)        # gradient bucket: params | d_x
-    flat_params = flat[:n_param]
+    flat = torch.zeros(n_param, device=dev)                    # gradient bucket when the grads are not one already
+    live = {}
 
     def body():
         out = conv(x, batch.edge_index, batch.edge_attr)
         grads = torch.autograd.grad(out, params + [x], grad_outputs=cot)   # loss = <out, cot>
-        torch.cat([g_.reshape(-1) for g_ in grads], out=flat)
+        bucket = flat_view(grads[:-1])          # the fused layer hands its 5 parameter gradients back as one buffer
+        if bucket is None:
+            bucket = torch.cat([g_.reshape(-1) for g_ in grads[:-1]], out=flat)
+        live["bucket"], live["d_x"] = bucket, grads[-1]
 
     # warm-up on a side stream (stages the CSR + its transpose, which sync once per new batch)
     side = torch.cuda.Stream()
@@ -204,7 +207,7 @@ def main():
         else:
             body()
         if world > 1:
-            dist.all_reduce(flat_params)                       # ONE bucket, ONE RCCL call per step
+            dist.all_reduce(live["bucket"])                    # ONE bucket, ONE RCCL call per step
 
     def barrier():
         if world > 1:

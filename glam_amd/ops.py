@@ -260,8 +260,11 @@ class _TripletLayer(torch.autograd.Function):
                                          ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                          ptr(eid_t), N, E, H, Cp, Dp, slope, ptr(d_x), ptr(dstaged), ptr(d_ea), ptr(ws),
                                          ws.numel(), stream()), "glam_triplet_layer_bwd")
-        d_wn, d_we, d_att = torch.empty_like(wn), torch.empty_like(we), torch.empty_like(att)
-        d_wsc, d_bias = torch.empty(H * C, C, **f), torch.empty(C, **f)
+        # the five parameter gradients are consecutive views of ONE buffer (parameter order), so a data-parallel
+        # step can all-reduce them as a single bucket without a gather copy (parallel.flat_view)
+        sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
+        flatg = torch.empty(sum(sizes), **f)
+        d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
         check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn),
                                                 ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()),
               "glam_triplet_stage_params_bwd")

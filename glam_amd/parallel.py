@@ -79,6 +79,24 @@ class FlatGradBucket:
             self.flat.mul_(scale)
 
 
+def flat_view(grads):
+    """The single contiguous tensor that ``grads`` are consecutive views of, or ``None``.  The fused layer returns its
+    parameter gradients this way (DDP's gradient-as-bucket-view, without registering hooks): the bucket all-reduce
+    then needs no gather copy, and the reduced values are visible through the individual gradients."""
+    if not grads:
+        return None
+    g0 = grads[0]
+    base = g0._base if g0._base is not None else g0
+    off = g0.storage_offset()
+    for g in grads:
+        gb = g._base if g._base is not None else g
+        if gb is not base or not g.is_contiguous() or g.storage_offset() != off or g.dtype != g0.dtype:
+            return None
+        off += g.numel()
+    total = off - g0.storage_offset()
+    return torch.as_strided(base, (total,), (1,), g0.storage_offset())
+
+
 def broadcast_parameters(module, src=0):
     """Replicas start identical (same seed gives the same init; this makes it unconditional)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -645,3 +645,16 @@ def test_tile_plan_falls_back_on_large_components(device, monkeypatch):
     conv = layer.TripletMessage(48, 8).to(device)
     out = conv(torch.randn(p.x.size(0), 48, device=device), p.edge_index, p.edge_attr)
     assert torch.isfinite(out).all()
+
+
+def test_layer_parameter_gradients_form_one_bucket(device):
+    from glam_amd.parallel import flat_view
+    b = synth_batch(16, seed=1).to(device)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device)
+    out = conv(x, b.edge_index, b.edge_attr)
+    params = list(conv.parameters())
+    grads = torch.autograd.grad(out.sum(), params)
+    fv = flat_view(grads)
+    assert fv is not None and fv.numel() == sum(p.numel() for p in params)
+    assert torch.equal(fv, torch.cat([g.reshape(-1) for g in grads]))

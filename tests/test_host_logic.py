@@ -173,3 +173,16 @@ def test_data_to_drops_device_caches():
     d = Data(torch.zeros(3, 2), torch.zeros(2, 0, dtype=torch.long))
     d._glam_cache = {"x": 1}
     assert not hasattr(d.to("cpu"), "_glam_cache")
+
+
+def test_flat_view_recognises_bucket_views():
+    from glam_amd.parallel import flat_view
+    buf = torch.arange(20, dtype=torch.float32)
+    a, b, c = (t.view(s) for t, s in zip(buf[2:].split([6, 4, 8]), ((2, 3), (4,), (2, 4))))
+    fv = flat_view([a, b, c])
+    assert fv is not None and fv.data_ptr() == a.data_ptr() and fv.numel() == 18
+    fv.mul_(2)
+    assert float(c[1, 3]) == 38.0                       # reductions on the bucket show through the gradients
+    assert flat_view([a, c]) is None                    # gap
+    assert flat_view([a, torch.zeros(4)]) is None       # different storage
+    assert flat_view([]) is None
