@@ -43,22 +43,30 @@ __global__ void __launch_bounds__(kBlock) k_ts_make_image(const float* W, int ld
     }
 }
 
-template <int MT, int GMAX>
+// Work item = (16-row tile, column split): TPI of the MT column tiles.  A 16 x 192 x 64 row tile is 192 MFMAs
+// (6.1k cycles on one SIMD): whole row tiles leave some SIMDs with two and others with none at N ~ 2e4, so the
+// tiles are cut into MT/TPI column items that are dealt round-robin to ALL waves of the grid (consecutive items,
+// i.e. the splits of one row tile, land on neighbouring waves of one CU and share the A rows through L1).
+template <int MT, int GMAX, int TPI>
 __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     constexpr int MP = MT * 16;        // padded column count
+    constexpr int CS = MT / TPI;       // column splits per row tile
     constexpr int kMaxStage = 16 * GMAX * MP / 4 / kTsBlock;   // float4 per thread for the largest image
     static_assert(kMaxStage * kTsBlock * 4 == 16 * GMAX * MP, "image must tile the block");
+    static_assert(TPI == 4 || TPI == 2, "a column item is one or half a 64-column group");
     const int tid = threadIdx.x;
     const int K = a.K1 + a.K2, G = (K + 15) >> 4, M = a.M1 + a.M2;
     const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
     const int ntiles = (a.N + 15) >> 4;
+    const int nitems = ntiles * CS;
     constexpr int WPB = kTsBlock / 64;
+    const int stride = gridDim.x * WPB;
 
     // A fragment of a tile: one float4 per 16-k group, every load in flight at once
-    auto load_afrag = [&](int tile, float4 (&af)[GMAX]) {
-        const int row = tile * 16 + c;
-        const bool rok = tile < ntiles && row < a.N;
+    auto load_afrag = [&](int item, float4 (&af)[GMAX]) {
+        const int row = (item / CS) * 16 + c;
+        const bool rok = item < nitems && row < a.N;
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
             const int k0 = 16 * g + 4 * kq;
@@ -69,9 +77,9 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
             }
         }
     };
-    int tile = blockIdx.x * WPB + wave;
+    int item = blockIdx.x * WPB + wave;
     float4 af[GMAX];
-    load_afrag(tile, af);              // flies while the weight image is staged
+    load_afrag(item, af);              // flies while the weight image is staged
 
     // ---- stage the W image into LDS: all loads in flight first, then the LDS stores ----
     {
@@ -91,42 +99,54 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
     __syncthreads();
 
     const float* wlane = s_w + (kq * MP + c) * 4;
-    for (; tile < ntiles; tile += gridDim.x * WPB) {
-        v4f acc[MT];
+    for (; item < nitems; item += stride) {
+        const int tile = item / CS, cs = item - tile * CS;
+        const int t0 = cs * TPI;       // first column tile of the item
+        v4f acc[TPI];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TPI; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
             if (g < G) {
-                float4 bv[MT];
+                float4 bv[TPI];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) bv[t] = ld4(wlane + g * 16 * MP + t * 64);
+                for (int t = 0; t < TPI; ++t) bv[t] = ld4(wlane + g * 16 * MP + (t0 + t) * 64);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float aj = f4get(af[g], j);
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < TPI; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, f4get(bv[t], j), acc[t], 0, 0, 0);
                 }
             }
         }
-        const int cur = tile;
-        load_afrag(tile + gridDim.x * WPB, af);   // next tile's A fragment flies under the epilogue
+        load_afrag(item + stride, af);   // next item's A fragment flies under the epilogue
         // C layout: tile column = lane & 15 (-> logical columns cg*64 + 4c + t), row = (lane >> 4) * 4 + i
+        const int cg = t0 >> 2, tq = t0 & 3;       // TPI == 4: tq = 0; TPI == 2: tq in {0, 2}
+        const int m0 = cg * 64 + 4 * c + tq;
+        if (m0 < M) {
+            if constexpr (TPI == 4) {
+                float4 b = f4zero();
+                if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
 #pragma unroll
-        for (int cg = 0; cg < MT / 4; ++cg) {
-            const int m0 = cg * 64 + 4 * c;
-            if (m0 >= M) continue;
-            float4 b = f4zero();
-            if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = tile * 16 + kq * 4 + i;
+                    if (rr >= a.N) continue;
+                    const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                    if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                    else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                }
+            } else {
+                float2 b = make_float2(0.f, 0.f);
+                if (a.bias && m0 < a.M1) b = *reinterpret_cast<const float2*>(a.bias + m0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rr = cur * 16 + kq * 4 + i;
-                if (rr >= a.N) continue;
-                const float4 v = make_float4(acc[cg * 4 + 0][i] + b.x, acc[cg * 4 + 1][i] + b.y,
-                                             acc[cg * 4 + 2][i] + b.z, acc[cg * 4 + 3][i] + b.w);
-                if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
-                else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = tile * 16 + kq * 4 + i;
+                    if (rr >= a.N) continue;
+                    const float2 v = make_float2(acc[0][i] + b.x, acc[1][i] + b.y);
+                    if (m0 < a.M1) *reinterpret_cast<float2*>(a.out1 + (size_t)rr * a.ldo1 + m0) = v;
+                    else *reinterpret_cast<float2*>(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1)) = v;
+                }
             }
         }
     }
@@ -298,10 +318,11 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
         return fail(GLAM_E_UNSUPPORTED, "ts_gemm: K=%d+%d M=%d+%d and leading dimensions must be multiples of 4", a.K1, a.K2, a.M1, a.M2);
     const size_t lds = ts_image_floats(K, M) * sizeof(float);
     const int ntiles = (a.N + 15) / 16;
-    int grid = (ntiles + 7) / 8;
-    if (grid > 256) grid = 256;          // one 8-wave block per CU, grid-stride over row tiles
-    if (M <= 64) hipLaunchKernelGGL((k_ts_gemm<4, 12>), dim3(grid), dim3(kTsBlock), lds, s, a);
-    else hipLaunchKernelGGL((k_ts_gemm<12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    const int nitems = ntiles * (M <= 64 ? 2 : 3);
+    int grid = (nitems + 7) / 8;
+    if (grid > 256) grid = 256;          // one 8-wave block per CU, items dealt round-robin over every wave of the grid
+    if (M <= 64) hipLaunchKernelGGL((k_ts_gemm<4, 12, 2>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
     GLAM_LAUNCH_CHECK("ts_gemm");
     return GLAM_OK;
 }
