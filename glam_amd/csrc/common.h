@@ -36,11 +36,21 @@ static inline int grid_for(int64_t work_items, int items_per_block, int cap = kM
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers -------------------------------------------------------------------------
-// Sum over the G consecutive lanes that share a node (G in {4,8,16,64}); every lane gets the total.
+// Sum over the G consecutive lanes that share a node (G in {4,8,16,64}); every lane gets the total.  The butterfly
+// runs on DPP modifiers (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: one v_add_f32_dpp per step) instead of
+// ds_bpermute round trips through the LDS crossbar; fp add commutes, so the sums are bit-equal to the xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(G == 4 || G == 8 || G == 16 || G == 64, "group_sum: lanes per node");
+    v += dpp_move<0xB1>(v);                           // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);                           // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_move<0x141>(v);    // row_half_mirror: lane i <-> 7 - i of each 8
+    if constexpr (G >= 16) v += dpp_move<0x140>(v);   // row_mirror: lane i <-> 15 - i of each 16
+    if constexpr (G == 64) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); }   // across the 4 DPP rows
     return v;
 }
 

@@ -8,3 +8,9 @@ bool triplet_launch_h3(int kind, int De, int emul, Shape sh, const void* args, i
     return triplet_launch_impl<3>(kind, De, emul, sh, args, nodes, lds, s, cap, grid_out);
 }
 }  // namespace glam
+
+#ifdef GLAM_B1_PROF
+extern "C" int glam_debug_b1_prof(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_b1_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -32,6 +32,14 @@
 
 namespace glam {
 
+#ifdef GLAM_B1_PROF   // developer aid (tools/b1_prof.py): where a B1 wave spends its cycles
+__device__ long long g_b1_prof[4096 * 8];
+#define B1_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define B1_STAMP(k) do { B1_WAIT(); const long long now__ = clock64(); prof_acc[k] += now__ - prof_last; prof_last = now__; } while (0)
+#else
+#define B1_STAMP(k) do { } while (0)
+#endif
+
 struct FwdArgs {
     const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
     const int* rowptr; const int* nbr; const int* eid;
@@ -329,10 +337,15 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
 #pragma unroll
         for (int h = 0; h < H; ++h) dM[k][h] = 0.f;
 
+#ifdef GLAM_B1_PROF
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64();
+    const long long prof_t0 = prof_last;
+#endif
     for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
         const int beg = a.rowptr[n], end = a.rowptr[n + 1];
         const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
         const float4 mv = ld4(a.stats + (size_t)n * 8), sv = ld4(a.stats + (size_t)n * 8 + 4);
+        B1_STAMP(0);
         float ai[H], m[H], inv[H], dot[H], dai[H];
         float4 dag[H][ITER];
 #pragma unroll
@@ -348,6 +361,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
             dot[h] = group_sum<G>(part);
         }
+        B1_STAMP(1);
         constexpr int CH = ITER == 1 ? GLAM_B1_CH : 2;   // edges per chunk: all loads of a chunk in flight together
         for (int e0 = beg; e0 < end; e0 += CH) {
             int sidx[CH], eidx[CH];
@@ -361,6 +375,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
                 sidx[k] = a.nbr[e];
                 eidx[k] = a.eid[e];
             }
+            B1_STAMP(2);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
 #pragma unroll
@@ -371,6 +386,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
                 load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
                 ajv[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
             }
+            B1_STAMP(3);
             float pre[CH][H], alpha[CH][H], dp[CH][H];
 #pragma unroll
             for (int k = 0; k < CH; ++k) edge_pre<H, DE>(ai, ajv[k], eav[k], Mr, pre[k]);
@@ -419,6 +435,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            B1_STAMP(4);
             if (lg == 0) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
@@ -439,7 +456,14 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             for (int h = 0; h < H; ++h) dpp[h] = dai[h];
             st4(a.d_a_ij + (size_t)n * 8, dv);
         }
+        B1_STAMP(5);
     }
+#ifdef GLAM_B1_PROF
+    if (tid == 0 && blockIdx.x < 4096) {
+        for (int k = 0; k < 6; ++k) g_b1_prof[blockIdx.x * 8 + k] = prof_acc[k];
+        g_b1_prof[blockIdx.x * 8 + 6] = prof_t0;
+    }
+#endif
 
     // ---- block partial of d_W_edge | d_M: wave shuffle across groups, then 4 waves via LDS ----
     const int wave = tid >> 6, lane = tid & 63;
@@ -472,6 +496,9 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
     float* out = a.partial + (size_t)blockIdx.x * P;
     for (int i = tid; i < P; i += kBlock)
         out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
+#ifdef GLAM_B1_PROF
+    if (tid == 0 && blockIdx.x < 4096) g_b1_prof[blockIdx.x * 8 + 7] = clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
