@@ -128,9 +128,12 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     float* dpre_e = alpha_e + (size_t)E * 4;
     float* partial = dpre_e + (size_t)E * 4;
 
+    // LDS reduction buffer of B1: one row per lane group when that fits beside W_edge (two blocks per CU), else one per wave
+    const int gpb = kBlock / sh.G;
+    const int red_groups = ((size_t)WSZ + (size_t)gpb * P) * sizeof(float) <= 60 * 1024 ? gpb : 4;
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
-                  alpha_e, dpre_e, d_a_ij, partial};
-    const size_t lds1 = ((size_t)WSZ + 4 * (size_t)P) * sizeof(float);
+                  alpha_e, dpre_e, d_a_ij, partial, red_groups};
+    const size_t lds1 = ((size_t)WSZ + (size_t)red_groups * P) * sizeof(float);
     int nblk = 0;
     if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);

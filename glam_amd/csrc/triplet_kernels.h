@@ -292,6 +292,7 @@ struct BwdDstArgs {
     const int* rowptr; const int* nbr; const int* eid;
     int N; int Cp; float slope;
     float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;
+    int red_groups;   // rows of the LDS reduction buffer: kBlock / G (every lane group stores its own partial) or 4
 };
 
 template <int H, int G, int ITER, int DE, bool EMUL>
@@ -465,37 +466,69 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
     }
 #endif
 
-    // ---- block partial of d_W_edge | d_M: wave shuffle across groups, then 4 waves via LDS ----
+    // ---- block partial of d_W_edge | d_M, summed in a fixed order ----
     const int wave = tid >> 6, lane = tid & 63;
-    float* red = s_red + wave * P;
-    if constexpr (EMUL) {
-#pragma unroll
-        for (int k = 0; k < DE; ++k)
-#pragma unroll
-            for (int h = 0; h < H; ++h)
-#pragma unroll
-                for (int it = 0; it < ITER; ++it) {
-                    float4 v = dw[k][h][it];
-                    v.x = cross_group_sum<G>(v.x); v.y = cross_group_sum<G>(v.y);
-                    v.z = cross_group_sum<G>(v.z); v.w = cross_group_sum<G>(v.w);
-                    if (lane < G && ok[it]) st4(red + (k * H + h) * Cp + q[it] * 4, v);
-                }
-    }
-#pragma unroll
-    for (int k = 0; k < DE; ++k) {
-        float4 v = f4zero();
-        float* vp = &v.x;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            // every lane of a group holds the same dM; pick lane 0 of each group before the sum
-            vp[h] = cross_group_sum<G>(dM[k][h]);
-        }
-        if (lane == 0) st4(red + WSZ + k * 4, v);
-    }
-    __syncthreads();
     float* out = a.partial + (size_t)blockIdx.x * P;
-    for (int i = tid; i < P; i += kBlock)
-        out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
+    if (a.red_groups == GPB) {
+        // every lane group parks its own partial in LDS (the host grants GPB rows when they fit): no cross-lane traffic
+        float* red = s_red + (tid / G) * P;
+        if constexpr (EMUL) {
+#pragma unroll
+            for (int k = 0; k < DE; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it)
+                        if (ok[it]) st4(red + (k * H + h) * Cp + q[it] * 4, dw[k][h][it]);
+        }
+        if (lg == 0) {
+#pragma unroll
+            for (int k = 0; k < DE; ++k) {
+                float4 v = f4zero();
+                float* vp = &v.x;
+#pragma unroll
+                for (int h = 0; h < H; ++h) vp[h] = dM[k][h];
+                st4(red + WSZ + k * 4, v);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < P; i += kBlock) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int g = 0; g < GPB; ++g) sum += s_red[g * P + i];
+            out[i] = sum;
+        }
+    } else {
+        // wide layers: wave shuffle across groups, then 4 waves via LDS
+        float* red = s_red + wave * P;
+        if constexpr (EMUL) {
+#pragma unroll
+            for (int k = 0; k < DE; ++k)
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        float4 v = dw[k][h][it];
+                        v.x = cross_group_sum<G>(v.x); v.y = cross_group_sum<G>(v.y);
+                        v.z = cross_group_sum<G>(v.z); v.w = cross_group_sum<G>(v.w);
+                        if (lane < G && ok[it]) st4(red + (k * H + h) * Cp + q[it] * 4, v);
+                    }
+        }
+#pragma unroll
+        for (int k = 0; k < DE; ++k) {
+            float4 v = f4zero();
+            float* vp = &v.x;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                // every lane of a group holds the same dM; pick lane 0 of each group before the sum
+                vp[h] = cross_group_sum<G>(dM[k][h]);
+            }
+            if (lane == 0) st4(red + WSZ + k * 4, v);
+        }
+        __syncthreads();
+        for (int i = tid; i < P; i += kBlock)
+            out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
+    }
 #ifdef GLAM_B1_PROF
     if (tid == 0 && blockIdx.x < 4096) g_b1_prof[blockIdx.x * 8 + 7] = clock64();
 #endif
