@@ -318,10 +318,10 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
         return fail(GLAM_E_UNSUPPORTED, "ts_gemm: K=%d+%d M=%d+%d and leading dimensions must be multiples of 4", a.K1, a.K2, a.M1, a.M2);
     const size_t lds = ts_image_floats(K, M) * sizeof(float);
     const int ntiles = (a.N + 15) / 16;
-    const int nitems = ntiles * (M <= 64 ? 2 : 3);
+    const int nitems = M <= 64 ? ntiles : ntiles * 3;   // K <= 192 x 64 columns: splitting would re-read the long A rows
     int grid = (nitems + 7) / 8;
     if (grid > 256) grid = 256;          // one 8-wave block per CU, items dealt round-robin over every wave of the grid
-    if (M <= 64) hipLaunchKernelGGL((k_ts_gemm<4, 12, 2>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    if (M <= 64) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
     else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
     GLAM_LAUNCH_CHECK("ts_gemm");
     return GLAM_OK;
