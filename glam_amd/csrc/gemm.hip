@@ -47,6 +47,15 @@ __global__ void __launch_bounds__(kBlock) k_ts_make_image(const float* W, int ld
 // (6.1k cycles on one SIMD): whole row tiles leave some SIMDs with two and others with none at N ~ 2e4, so the
 // tiles are cut into MT/TPI column items that are dealt round-robin to ALL waves of the grid (consecutive items,
 // i.e. the splits of one row tile, land on neighbouring waves of one CU and share the A rows through L1).
+#ifdef GLAM_TS_PROF   // developer aid (tools/ts_prof.py)
+__device__ long long g_ts_prof[1024 * 8];
+#define TS_STAMP(k) do { if (tid == 0 && blockIdx.x < 1024) g_ts_prof[blockIdx.x * 8 + (k)] = clock64(); } while (0)
+#define TS_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define TS_STAMP(k) do { } while (0)
+#define TS_DRAIN() do { } while (0)
+#endif
+
 template <int MT, int GMAX, int TPI>
 __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
@@ -79,6 +88,7 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
     };
     int item = blockIdx.x * WPB + wave;
     float4 af[GMAX];
+    TS_STAMP(0);
     load_afrag(item, af);              // flies while the weight image is staged
 
     // ---- stage the W image into LDS: all loads in flight first, then the LDS stores ----
@@ -97,9 +107,13 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
         }
     }
     __syncthreads();
+    TS_STAMP(1);
+    TS_DRAIN();
+    TS_STAMP(2);
 
     const float* wlane = s_w + (kq * MP + c) * 4;
-    for (; item < nitems; item += stride) {
+    int pass = 0;
+    for (; item < nitems; item += stride, ++pass) {
         const int tile = item / CS, cs = item - tile * CS;
         const int t0 = cs * TPI;       // first column tile of the item
         v4f acc[TPI];
@@ -120,6 +134,7 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                 }
             }
         }
+        if (pass == 0) TS_STAMP(3);
         load_afrag(item + stride, af);   // next item's A fragment flies under the epilogue
         // C layout: tile column = lane & 15 (-> logical columns cg*64 + 4c + t), row = (lane >> 4) * 4 + i
         const int cg = t0 >> 2, tq = t0 & 3;       // TPI == 4: tq = 0; TPI == 2: tq in {0, 2}
@@ -150,6 +165,9 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
             }
         }
     }
+    TS_STAMP(4);
+    TS_DRAIN();
+    TS_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,6 +411,12 @@ int launch_final_reduce(ReduceArgs ra, hipStream_t s) {
 }
 
 }  // namespace glam
+
+#ifdef GLAM_TS_PROF
+extern "C" int glam_debug_ts_prof(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_ts_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 using namespace glam;
 
