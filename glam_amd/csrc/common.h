@@ -73,6 +73,19 @@ __device__ __forceinline__ void fma4(float4& acc, float s, float4 a) {
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
+// exp of a non-positive softmax argument (logit - segment max): one multiply + v_exp_f32 instead of the
+// ~18-instruction libm sequence (the aggregate kernels are VALU-issue bound for ~45 % of their time).  Error:
+// |x| * 2^-24 relative from the rounded x*log2(e) plus 1 ulp from the instruction, i.e. < 1e-6 on a softmax weight
+// for |x| <= 16 (the 1e-5 parity tests run on this path); -DGLAM_EXACT_EXP restores expf.  Forward and backward
+// share the function, so the recomputed alpha equals the forward pass's.
+__device__ __forceinline__ float softmax_exp(float x) {
+#ifdef GLAM_EXACT_EXP
+    return expf(x);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
+}
+
 // ts_gemm weight-image column order: position p = cg*64 + t*16 + c holds logical column cg*64 + 4c + t
 __host__ __device__ inline int ts_col_of_pos(int p) { return (p & ~63) + 4 * (p & 15) + ((p >> 4) & 3); }
 

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(kTileBlock) k_tile_fwd(TileFwdArgs a) {
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         if (!val[k]) continue;
-                        const float p = expf(lk[k][h] - m[h]);
+                        const float p = softmax_exp(lk[k][h] - m[h]);
                         ssum[h] += p;
                         float4 e4 = f4zero();
 #pragma unroll

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         if (!val[k]) continue;
-                        const float p = expf(lk[k][h] - m[h]);
+                        const float p = softmax_exp(lk[k][h] - m[h]);
                         if (it == 0) ssum[h] += p;
                         float4 xj = rows[k][h][it];
                         if constexpr (EMUL) {
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     part[k] = 0.f;
-                    alpha[k][h] = expf(leaky(pre[k][h], a.slope) - m[h]) * inv[h];
+                    alpha[k][h] = softmax_exp(leaky(pre[k][h], a.slope) - m[h]) * inv[h];
                 }
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
