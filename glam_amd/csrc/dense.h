@@ -57,6 +57,8 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
-                     size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out);
+                     size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
+                     const float* img_dx, float* d_x);
+bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 
 }  // namespace glam

@@ -304,9 +304,11 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
     if (int rc = launch_ts_gemm(g1, s)) return rc;
     const float* tpart = nullptr;
     int tnblk = 0;
+    const bool fuse_dx = triplet_bwd_can_fuse_dx(H, Cp, Dp);   // d_x = [d_xw | d_a] @ Wcat^T inside B2 (one launch less)
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
-                                  dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk))
+                                  dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
+                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
@@ -319,8 +321,10 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
                                         &ra.job[2], s))
         return rc;
     // d_x = [d_xw | d_a] @ Wcat^T
-    TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
-    if (int rc = launch_ts_gemm(g2, s)) return rc;
+    if (!fuse_dx) {
+        TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
+        if (int rc = launch_ts_gemm(g2, s)) return rc;
+    }
     // one fixed-order reduction for the three partial sets (d_W_scale|d_bias, d_W_edge|d_M, d_Wcat)
     return launch_final_reduce(ra, s);
 }

@@ -105,6 +105,9 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
     return GLAM_OK;
 }
 
+// B2 with the input-gradient GEMM fused in (same shapes as the forward's fused update)
+bool triplet_bwd_can_fuse_dx(int H, int Cp, int De) { return triplet_fwd_can_fuse_update(H, Cp, De) && H * Cp + 8 <= 192; }
+
 // Backward launches.  reduce_now = true: d_w_edge / d_M are final on return (3 launches);
 // reduce_now = false: the B1 block partials [*nblk_out][P] are left at *partial_out for a merged reduction.
 int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
@@ -112,7 +115,8 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
-                     size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out) {
+                     size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
+                     const float* img_dx, float* d_x) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     const int WSZ = emul ? De * H * Cp : 0;
@@ -151,8 +155,12 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
             return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
     }
-    BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij};
-    const size_t lds2 = (size_t)WSZ * sizeof(float);
+    const bool fuse_dx = img_dx && d_x && triplet_bwd_can_fuse_dx(H, Cp, De) && emul;
+    if ((img_dx || d_x) && !fuse_dx) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_x variant for H=%d Cp=%d", H, Cp);
+    BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij,
+                  fuse_dx ? img_dx : nullptr, fuse_dx ? d_x : nullptr};
+    const int KX = H * Cp + 8, LDT = KX + ((68 - (KX & 63)) & 63);
+    const size_t lds2 = ((size_t)WSZ + (fuse_dx ? 16 * (size_t)LDT + 16 * 64 : 0)) * sizeof(float);
     if (!dispatch(kTripletBwdSrc, H, De, emul, sh, b2, (int)N, lds2, s, kMaxBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B2)");
@@ -175,5 +183,5 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr);
+                            nullptr, nullptr, nullptr, nullptr);
 }

@@ -604,6 +604,9 @@ struct BwdSrcArgs {
     const int* colptr; const int* nbr; const int* eid;
     int N; int Cp;
     float* d_xw; float* d_a_ij;
+    // optional fused input gradient (G == 16 only): d_x[N,Cp] = [d_xw | d_a_i | d_a_j] @ Wcat^T, Wcat^T as a k_ts_gemm
+    // image (K = HC + 8, 64 columns); d_a_i is read back from d_a_ij (written by B1)
+    const float* img_dx; float* d_x;
 };
 
 template <int H, int G, int ITER, int DE, bool EMUL>
@@ -625,7 +628,15 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
         ok[it] = q[it] < Q;
         if (!ok[it]) q[it] = 0;
     }
-    for (int j = blockIdx.x * GPB + tid / G; j < a.N; j += gridDim.x * GPB) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const bool fuse_dx = (G == 16) && a.img_dx != nullptr;
+    const int KX = HC + 8;                                      // columns of [d_xw | d_a_i | d_a_j]
+    const int LDT = KX + ((68 - (KX & 63)) & 63);               // LDS row pitch = 4 mod 64 words: conflict-free A reads
+    float* s_tile = s_w + (EMUL ? DE * HC : 0);
+    float* s_out = s_tile + 16 * LDT;
+    for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
+      const int j = base + tid / G;
+      if (j < a.N) {
         const int beg = a.colptr[j], end = a.colptr[j + 1];
         float4 acc[H][ITER];
         float4 daj = f4zero();
@@ -690,8 +701,54 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
         for (int h = 0; h < H; ++h)
 #pragma unroll
             for (int it = 0; it < ITER; ++it)
-                if (ok[it]) st4(orow + h * Cp + q[it] * 4, acc[h][it]);
-        if (lg == 0) st4(a.d_a_ij + (size_t)j * 8 + 4, daj);
+                if (ok[it]) {
+                    st4(orow + h * Cp + q[it] * 4, acc[h][it]);
+                    if constexpr (G == 16) {
+                        if (fuse_dx) st4(s_tile + (tid / G) * LDT + h * Cp + q[it] * 4, acc[h][it]);
+                    }
+                }
+        if (lg == 0) {
+            st4(a.d_a_ij + (size_t)j * 8 + 4, daj);
+            if constexpr (G == 16) {
+                if (fuse_dx) {
+                    st4(s_tile + (tid / G) * LDT + HC, ld4(a.d_a_ij + (size_t)j * 8));
+                    st4(s_tile + (tid / G) * LDT + HC + 4, daj);
+                }
+            }
+        }
+      }
+      if constexpr (G == 16) {
+        // ---- fused input gradient: d_x[16 nodes, Cp] = tile[16, HC+8] @ Wcat^T on the fp32 matrix cores ----
+        // wave w owns output column tile w (logical columns 4c + w); B fragments straight from the L2-resident
+        // weight image, A fragments from the LDS tile (same scheme as the forward pass's fused update).
+        if (fuse_dx) {
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+            const int GK = (KX + 15) >> 4;
+            const bool rok = base + c < a.N;
+            v4f cacc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int g0 = 0; g0 < GK; g0 += 4) {          // 4 k-groups (64 k values) per batch: 8 loads in flight
+                float4 bf[4], af[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u, k0 = 16 * g + 4 * kq;
+                    bf[u] = g < GK ? ld4(a.img_dx + ((size_t)(4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
+                    af[u] = (g < GK && k0 < KX && rok) ? ld4(s_tile + c * LDT + k0) : f4zero();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[u], jj), f4get(bf[u], jj), cacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_out[(kq * 4 + i) * 64 + 4 * c + wave] = cacc[i];
+            __syncthreads();
+            const int row = tid >> 4, c4 = (tid & 15) * 4;
+            if (c4 < Cp && base + row < a.N) st4(a.d_x + (size_t)(base + row) * Cp + c4, ld4(s_out + row * 64 + c4));
+        }
+      }
     }
 }
 
