@@ -190,6 +190,139 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Parameter gradients straight from the partial sets of the backward pass (k_wgrad slabs of the two weight-gradient
+// products, block partials of B1), i.e. the final fixed-order reductions AND the chain rule of k_stage_params in ONE
+// launch (it replaces k_final_reduce -> k_stage_params_bwd).  Block roles:
+//   A  d_weight_scale / d_bias        one thread per element: sum over the splits of product 1 ([aggr|1]^T d_out)
+//   B  d_weight_node row k            one block per k: d_Wa_i[k,:], d_Wa_j[k,:] first (LDS), then
+//                                     d_Wcat[k,h,c] + d_Wa_i[k,h] att_i[h,c] + d_Wa_j[k,h] att_j[h,c]
+//   C  d_weight_triplet_att head h    one block per head: d_Wa_i[:,h], d_Wa_j[:,h], d_M[:,h] into LDS, then the
+//                                     contractions with W_node / W_edge
+//   D  d_weight_edge                  a 16-lane group per element: sum over the B1 blocks + d_M[k,h] att_e[h,c]
+// Every sum runs in a fixed order (splits ascending; lane-strided partial sums + DPP butterfly for the B1 partials).
+struct ParamGradArgs {
+    const float* p1; int ns1;            // product 1 partials: i in [0, HC], j in [0, Cp)
+    const float* p2; int ns2;            // product 2 partials ([d_xw|d_a]^T x): i in [0, HC+8), j in [0, Cp)
+    const float* p3; int ns3; int P;     // B1 block partials [ns3][P]: d_We_p (Dp*HC) | d_M (Dp*4)
+    const float* wn; const float* we; const float* att;
+    int C, H, De, Cp, Dp;
+    float* d_wn; float* d_we; float* d_att; float* d_wsc; float* d_bias;
+    int blocksA, blocksB, blocksC;
+};
+
+// element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (inverse of the decode in k_final_reduce)
+__device__ __forceinline__ int wg_slab_offset(int i, int j) {
+    const int ii = i & 63, ti = ii & 3, t = ii >> 2, kq = t >> 2, r = t & 3, c = j >> 2, tj = j & 3;
+    return (((ti * 4 + tj) * 4 + r) << 6) + kq * 16 + c;
+}
+// loads are issued 32 at a time (a launch of this kernel is a handful of dependent round trips, nothing else)
+__device__ __forceinline__ float wg_sum(const float* partial, int nsplit, int i, int j) {
+    const float* p = partial + (size_t)(i >> 6) * nsplit * 4096 + wg_slab_offset(i, j);
+    float sum = 0.f;
+    for (int s = 0; s < nsplit; s += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = s + u < nsplit ? p[(size_t)(s + u) * 4096] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) sum += v[u];
+    }
+    return sum;
+}
+// sum over the B1 block partials of element e, cooperatively by a 16-lane group (every lane gets the total)
+__device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e, int lg) {
+    float part = 0.f;
+    for (int s = lg; s < ns3; s += 16 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = s + 16 * u < ns3 ? p3[(size_t)(s + 16 * u) * P + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part += v[u];
+    }
+    return group_sum<16>(part);
+}
+
+__global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
+    __shared__ float s_dwa[2][64];
+    __shared__ float s_dm[8];
+    const int tid = threadIdx.x, lg = tid & 15, grp = tid >> 4;
+    const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
+    int b = blockIdx.x;
+    if (b < a.blocksA) {                                    // ---- A: weight_scale, bias
+        const int idx = b * kBlock + tid;
+        if (idx < H * C * C) {
+            const int row = idx / C, col = idx - row * C, h = row / C, c = row - h * C;
+            a.d_wsc[idx] = wg_sum(a.p1, a.ns1, h * Cp + c, col);
+        } else if (idx < H * C * C + C) {
+            const int col = idx - H * C * C;
+            a.d_bias[col] = wg_sum(a.p1, a.ns1, HC, col);
+        }
+        return;
+    }
+    b -= a.blocksA;
+    if (b < a.blocksB) {                                    // ---- B: weight_node row k = b
+        const int k = b;
+        if (tid < 8) {
+            const int h = tid & 3, side = tid >> 2;
+            s_dwa[0][tid] = h < H ? wg_sum(a.p2, a.ns2, HC + side * 4 + h, k) : 0.f;
+        }
+        __syncthreads();
+        if (tid < H * C) {
+            const int h = tid / C, c = tid - h * C;
+            float v = wg_sum(a.p2, a.ns2, h * Cp + c, k);
+            v = fmaf(s_dwa[0][h], a.att[(size_t)h * 3 * C + c], v);
+            v = fmaf(s_dwa[0][4 + h], a.att[(size_t)h * 3 * C + 2 * C + c], v);
+            a.d_wn[(size_t)k * H * C + tid] = v;
+        }
+        return;
+    }
+    b -= a.blocksB;
+    if (b < a.blocksC) {                                    // ---- C: attention vector of head h = b
+        const int h = b;
+        for (int idx = tid; idx < 2 * C; idx += kBlock) {
+            const int side = idx / C, k = idx - side * C;
+            s_dwa[side][k] = wg_sum(a.p2, a.ns2, HC + side * 4 + h, k);
+        }
+        for (int kk = grp; kk < De; kk += kBlock / 16) {
+            const float v = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
+            if (lg == 0) s_dm[kk] = v;
+        }
+        __syncthreads();
+        if (tid < 3 * C) {
+            const int part = tid / C, c = tid - part * C;
+            float v = 0.f;
+            if (part == 1) {
+                for (int kk = 0; kk < De; ++kk) v = fmaf(s_dm[kk], a.we[(size_t)kk * H * C + h * C + c], v);
+            } else {
+                const float* dwa = s_dwa[part == 0 ? 0 : 1];
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                int k = 0;
+                for (; k + 4 <= C; k += 4) {
+                    v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
+                    v1 = fmaf(dwa[k + 1], a.wn[(size_t)(k + 1) * H * C + h * C + c], v1);
+                    v2 = fmaf(dwa[k + 2], a.wn[(size_t)(k + 2) * H * C + h * C + c], v2);
+                    v3 = fmaf(dwa[k + 3], a.wn[(size_t)(k + 3) * H * C + h * C + c], v3);
+                }
+                for (; k < C; ++k) v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
+                v = (v0 + v1) + (v2 + v3);
+            }
+            a.d_att[(size_t)h * 3 * C + tid] = v;
+        }
+        return;
+    }
+    b -= a.blocksC;
+    {                                                       // ---- D: weight_edge, 16 lanes per element
+        const int o = b * (kBlock / 16) + grp;
+        if (o < De * H * C) {
+            const int kk = o / (H * C), m = o - kk * H * C, h = m / C, c = m - h * C;
+            const float dwe = b1_sum16(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, lg);
+            const float dm = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
+            if (lg == 0) a.d_we[o] = fmaf(dm, a.att[(size_t)h * 3 * C + C + c], dwe);
+        }
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -272,15 +405,22 @@ extern "C" size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, i
            glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp) + 1024;
 }
 
-extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
-                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
-                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid,
-                                      const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
-                                      int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
-                                      float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+namespace {
+struct ParamOut {   // raw parameters and their gradient buffers; null d_wn: the caller wants `dstaged` instead
+    const float* wn; const float* we; const float* att; int C, De;
+    float* d_wn; float* d_we; float* d_att; float* d_wsc; float* d_bias;
+};
+}  // namespace
+
+static int layer_bwd_impl(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                          const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                          const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                          const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                          int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
+                          float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po) {
     if (int rc = dims_ok("glam_triplet_layer_bwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_bwd: N out of range");
-    GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && d_out && d_x && dstaged && ws, "glam_triplet_layer_bwd: null pointer");
+    GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && d_out && d_x && (dstaged || po) && ws, "glam_triplet_layer_bwd: null pointer");
     GLAM_REQUIRE(ws_bytes >= glam_triplet_layer_bwd_workspace_bytes(N, E, H, Cp, Dp), "glam_triplet_layer_bwd: workspace too small");
     GLAM_REQUIRE(aligned16(x) && aligned16(d_out) && aligned16(aggr) && aligned16(d_x) && aligned16(staged) && aligned16(dstaged),
                  "glam_triplet_layer_bwd: 16-byte alignment");
@@ -288,6 +428,7 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
     const DStaged G = dstaged_layout(H, Cp, Dp);
+    if (!dstaged) dstaged = reinterpret_cast<float*>(ws);   // never written on the `po` path (offsets below stay in range)
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
     float* d_aggr = reinterpret_cast<float*>(base);
     float* d_xw = d_aggr + (size_t)N * HC;
@@ -325,6 +466,43 @@ extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, co
         TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
         if (int rc = launch_ts_gemm(g2, s)) return rc;
     }
+    if (po) {   // parameter gradients straight from the partial sets: reductions + chain rule in one launch
+        const int C = po->C, De = po->De;
+        ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
+                         po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
+                         (H * C * C + C + kBlock - 1) / kBlock, C, H};
+        const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
+        GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
+        return GLAM_OK;
+    }
     // one fixed-order reduction for the three partial sets (d_W_scale|d_bias, d_W_edge|d_M, d_Wcat)
     return launch_final_reduce(ra, s);
+}
+
+extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                      const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                      int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
+                                      float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(dstaged, "glam_triplet_layer_bwd: null pointer");
+    return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
+                          Dp, slope, d_x, dstaged, d_edge_attr, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                             const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                             const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                             const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                             int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                             const float* weight_node, const float* weight_edge, const float* att, float* d_x,
+                                             float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
+                                             float* d_bias, float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = dims_ok("glam_triplet_layer_bwd_params", C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
+                 "glam_triplet_layer_bwd_params: null pointer");
+    const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
+    return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
+                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po);
 }

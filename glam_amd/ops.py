@@ -252,22 +252,19 @@ class _TripletLayer(torch.autograd.Function):
         d_out = f32c(d_out, "d_out")
         colptr, dst, eid_t = gi.transpose()
         f = dict(dtype=torch.float32, device=dev)
-        dstaged = torch.empty(lib.glam_triplet_dstaged_floats(H, Cp, Dp), **f)
         d_x = torch.empty_like(x_p)
         d_ea = torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None
         ws = torch.empty(lib.glam_triplet_layer_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=dev)
-        check(lib.glam_triplet_layer_bwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
-                                         ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
-                                         ptr(eid_t), N, E, H, Cp, Dp, slope, ptr(d_x), ptr(dstaged), ptr(d_ea), ptr(ws),
-                                         ws.numel(), stream()), "glam_triplet_layer_bwd")
         # the five parameter gradients are consecutive views of ONE buffer (parameter order), so a data-parallel
         # step can all-reduce them as a single bucket without a gather copy (parallel.flat_view)
         sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
         flatg = torch.empty(sum(sizes), **f)
         d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
-        check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn),
-                                                ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()),
-              "glam_triplet_stage_params_bwd")
+        check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
+                                                ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
+                                                ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
+                                                ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(d_ea), ptr(ws),
+                                                ws.numel(), stream()), "glam_triplet_layer_bwd_params")
         return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
 
 

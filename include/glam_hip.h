@@ -202,6 +202,19 @@ int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* 
                            float slope, float* d_x, float* dstaged, float* d_edge_attr, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* glam_triplet_layer_bwd with the parameter chain rule folded in: the gradients of weight_node f32[C,H*C],
+ * weight_edge f32[De,H*C], weight_triplet_att f32[H,3C] (as one buffer), weight_scale f32[H*C,C] and bias f32[C]
+ * come straight out of the backward pass's partial sums (what autograd derives for src_1gp/layer.py:22-61), one
+ * launch instead of glam_triplet_layer_bwd's final reduction + glam_triplet_stage_params_bwd.  7 launches. */
+int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                  const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                  const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                                  const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int C, int H, int De,
+                                  int Cp, int Dp, float slope, const float* weight_node, const float* weight_edge,
+                                  const float* att, float* d_x, float* d_weight_node, float* d_weight_edge, float* d_att,
+                                  float* d_weight_scale, float* d_bias, float* d_edge_attr, void* ws, size_t ws_bytes,
+                                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * MessageBlock remainder: gate math of one torch.nn.GRU(C, C) step with seq_len 1 (src_1gp/layer.py:247, :262).
  * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with
