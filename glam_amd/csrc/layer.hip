@@ -224,9 +224,9 @@ __device__ __forceinline__ float wg_sum(const float* partial, int nsplit, int i,
     for (int s = 0; s < nsplit; s += 32) {
         float v[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = s + u < nsplit ? p[(size_t)(s + u) * 4096] : 0.f;
+        for (int u = 0; u < 32; ++u) v[u] = p[(size_t)min(s + u, nsplit - 1) * 4096];   // clamped: unconditional loads
 #pragma unroll
-        for (int u = 0; u < 32; ++u) sum += v[u];
+        for (int u = 0; u < 32; ++u) sum += s + u < nsplit ? v[u] : 0.f;
     }
     return sum;
 }
@@ -236,9 +236,9 @@ __device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e
     for (int s = lg; s < ns3; s += 16 * 16) {
         float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = s + 16 * u < ns3 ? p3[(size_t)(s + 16 * u) * P + e] : 0.f;
+        for (int u = 0; u < 16; ++u) v[u] = p3[(size_t)min(s + 16 * u, ns3 - 1) * P + e];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) part += v[u];
+        for (int u = 0; u < 16; ++u) part += s + 16 * u < ns3 ? v[u] : 0.f;
     }
     return group_sum<16>(part);
 }
