@@ -86,6 +86,17 @@ __device__ __forceinline__ float softmax_exp(float x) {
 #endif
 }
 
+// Contiguous global -> LDS copy of n4 float4 (n4 % 64 == 0) by a block of BLOCK threads: LDS-DMA, 1 KB per wave
+// instruction, no staging registers.  Completion is tracked by vmcnt: drain it (s_waitcnt vmcnt(0), which
+// __syncthreads() does) before another wave reads the destination.
+template <int BLOCK>
+__device__ __forceinline__ void lds_copy_async(const float* g, float* l, int n4, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int b = wave * 64; b < n4; b += BLOCK)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 4 * (size_t)(b + lane)),
+                                         (__attribute__((address_space(3))) void*)(l + 4 * b), 16, 0, 0);
+}
+
 // ts_gemm weight-image column order: position p = cg*64 + t*16 + c holds logical column cg*64 + 4c + t
 __host__ __device__ inline int ts_col_of_pos(int p) { return (p & ~63) + 4 * (p & 15) + ((p >> 4) & 3); }
 

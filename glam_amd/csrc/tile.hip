@@ -47,13 +47,6 @@ __device__ long long g_tile_prof[8192 * 8];
 // keep draining instead of being waited for as __syncthreads() would
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// contiguous global -> LDS copy of n4 float4 (n4 % 64 == 0), 1 KB per wave instruction, no registers
-__device__ __forceinline__ void lds_copy_async(const float* g, float* l, int n4, int tid) {
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int b = wave * 64; b < n4; b += kTileBlock)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 4 * (size_t)(b + lane)),
-                                         (__attribute__((address_space(3))) void*)(l + 4 * b), 16, 0, 0);
-}
 
 template <int H, int DE>
 __global__ void __launch_bounds__(kTileBlock) k_tile_fwd(TileFwdArgs a) {
@@ -88,7 +81,7 @@ __global__ void __launch_bounds__(kTileBlock) k_tile_fwd(TileFwdArgs a) {
         const int nrt = (nn + 15) >> 4;
         TILE_STAMP(0);
         // ---------------- prologue ----------------
-        lds_copy_async(a.img_node, s_img, G1 * 768, tid);
+        lds_copy_async<kTileBlock>(a.img_node, s_img, G1 * 768, tid);
         // A fragments of this wave's (<= 3) node-GEMM items: in flight together with everything else of the prologue
         float4 afA[3][4];
 #pragma unroll
@@ -151,7 +144,7 @@ __global__ void __launch_bounds__(kTileBlock) k_tile_fwd(TileFwdArgs a) {
         }
         lds_barrier();
         TILE_STAMP(2);
-        lds_copy_async(a.img_upd, s_img, G2 * 256, tid);     // lands during phase B
+        lds_copy_async<kTileBlock>(a.img_upd, s_img, G2 * 256, tid);     // lands during phase B
 
         // ---------------- phase B: gather / softmax / aggregate, all operands in LDS ----------------
         constexpr int CH = 4;

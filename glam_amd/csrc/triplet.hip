@@ -53,6 +53,7 @@ static int check_dims(const char* fn, int64_t N, int64_t E, int H, int Cp, int D
     return GLAM_OK;
 }
 
+constexpr int kFusedBlocks = 512;   // fused-GEMM variants: two blocks per CU, each keeps its weight image in LDS
 constexpr int kBwdBlocks = 512;  // cap on B1 blocks = rows of the d_W_edge partial buffer
 
 }  // namespace glam
@@ -98,8 +99,8 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
     if (int rc = check_dims("glam_triplet_fwd(fused)", N, E, H, Cp, De, &sh)) return rc;
     if (N == 0) return GLAM_OK;
     FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out};
-    const size_t lds = ((size_t)De * H * Cp + 16 * (size_t)(H * Cp + 4) + 16 * 64) * sizeof(float);
-    if (!dispatch(kTripletFwd, H, De, 1, sh, a, (int)N, lds, s, kMaxBlocks, nullptr))
+    const size_t lds = ((size_t)De * H * Cp + 16 * (size_t)(H * Cp + 4) + 16 * 64 + (size_t)((H * Cp + 15) & ~15) * 64) * sizeof(float);
+    if (!dispatch(kTripletFwd, H, De, 1, sh, a, (int)N, lds, s, kFusedBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd(fused): no kernel for H=%d De=%d", H, De);
     GLAM_LAUNCH_CHECK("glam_triplet_fwd(fused)");
     return GLAM_OK;
@@ -160,8 +161,8 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij,
                   fuse_dx ? img_dx : nullptr, fuse_dx ? d_x : nullptr};
     const int KX = H * Cp + 8, LDT = KX + ((68 - (KX & 63)) & 63);
-    const size_t lds2 = ((size_t)WSZ + (fuse_dx ? 16 * (size_t)LDT + 16 * 64 : 0)) * sizeof(float);
-    if (!dispatch(kTripletBwdSrc, H, De, emul, sh, b2, (int)N, lds2, s, kMaxBlocks, nullptr))
+    const size_t lds2 = ((size_t)WSZ + (fuse_dx ? 16 * (size_t)LDT + 16 * 64 + (size_t)((KX + 15) & ~15) * 64 : 0)) * sizeof(float);
+    if (!dispatch(kTripletBwdSrc, H, De, emul, sh, b2, (int)N, lds2, s, fuse_dx ? kFusedBlocks : kMaxBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B2)");
     return GLAM_OK;

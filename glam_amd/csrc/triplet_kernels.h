@@ -121,6 +121,11 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
     const int LDT = HC + 4;                                    // LDS row pitch of the 16-node aggr tile
     float* s_tile = s_w + (EMUL ? DE * HC : 0);
     float* s_out = s_tile + 16 * LDT;
+    float* s_img = s_out + 16 * 64;                            // update-GEMM weight image, resident for the whole block
+    if constexpr (G == 16) {
+        // LDS-DMA: lands while the first tile is aggregated (the barrier before the first MFMA drains vmcnt)
+        if (fuse_upd) lds_copy_async<kBlock>(a.img_upd, s_img, ((HC + 15) >> 4) * 256, tid);
+    }
     for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
       const int n = base + tid / G;
       if (n < a.N) {
@@ -245,8 +250,9 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
       }
       if constexpr (G == 16) {
         // ---- fused update: out[16 nodes, Cp] = aggr_tile[16, HC] @ W_scale + bias on the fp32 matrix cores ----
-        // wave w owns output column tile w (logical columns 4c + w); B fragments straight from the L2-resident
-        // weight image (one float4 per 16-k group, all loads in flight), A fragments from the LDS tile.
+        // wave w owns output column tile w (logical columns 4c + w); B fragments from the LDS-resident weight image
+        // (one ds_read_b128 per 16-k group), A fragments from the LDS tile.  The launch is capped at two blocks per CU
+        // and strides over the 16-node tiles, so the 48 KB image is fetched 512 times instead of once per tile.
         if (fuse_upd) {
             __syncthreads();
             const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
@@ -258,7 +264,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int g = g0 + u, k0 = 16 * g + 4 * kq;
-                    bf[u] = g < GK ? ld4(a.img_upd + ((size_t)(4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
+                    bf[u] = g < GK ? ld4(s_img + ((4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
                     af[u] = (g < GK && k0 < HC) ? ld4(s_tile + c * LDT + k0) : f4zero();
                 }
 #pragma unroll
@@ -634,6 +640,10 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
     const int LDT = KX + ((68 - (KX & 63)) & 63);               // LDS row pitch = 4 mod 64 words: conflict-free A reads
     float* s_tile = s_w + (EMUL ? DE * HC : 0);
     float* s_out = s_tile + 16 * LDT;
+    float* s_img = s_out + 16 * 64;                             // Wcat^T weight image, resident for the whole block
+    if constexpr (G == 16) {
+        if (fuse_dx) lds_copy_async<kBlock>(a.img_dx, s_img, ((KX + 15) >> 4) * 256, tid);
+    }
     for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
       const int j = base + tid / G;
       if (j < a.N) {
@@ -719,8 +729,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
       }
       if constexpr (G == 16) {
         // ---- fused input gradient: d_x[16 nodes, Cp] = tile[16, HC+8] @ Wcat^T on the fp32 matrix cores ----
-        // wave w owns output column tile w (logical columns 4c + w); B fragments straight from the L2-resident
-        // weight image, A fragments from the LDS tile (same scheme as the forward pass's fused update).
+        // wave w owns output column tile w (logical columns 4c + w); B fragments from the LDS-resident weight image,
+        // A fragments from the LDS tile (same scheme as the forward pass's fused update).
         if (fuse_dx) {
             __syncthreads();
             const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
@@ -733,7 +743,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int g = g0 + u, k0 = 16 * g + 4 * kq;
-                    bf[u] = g < GK ? ld4(a.img_dx + ((size_t)(4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
+                    bf[u] = g < GK ? ld4(s_img + ((4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
                     af[u] = (g < GK && k0 < KX && rok) ? ld4(s_tile + c * LDT + k0) : f4zero();
                 }
 #pragma unroll
@@ -758,6 +768,12 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
 template <int H, int G, int ITER, int DE, bool EMUL>
 struct FwdOp {
     static void run(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
+        static bool big_lds = false;      // > 64 KB of dynamic LDS (fused update: resident weight image) is opted into once
+        if (lds > 64 * 1024 && !big_lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_fwd<H, G, ITER, DE, EMUL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            big_lds = true;
+        }
         hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
     }
 };
@@ -776,6 +792,12 @@ struct BwdDeaOp {
 template <int H, int G, int ITER, int DE, bool EMUL>
 struct BwdSrcOp {
     static void run(const BwdSrcArgs& a, int grid, size_t lds, hipStream_t s) {
+        static bool big_lds = false;
+        if (lds > 64 * 1024 && !big_lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_src<H, G, ITER, DE, EMUL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            big_lds = true;
+        }
         hipLaunchKernelGGL((k_triplet_bwd_src<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
     }
 };
