@@ -64,6 +64,17 @@ __device__ __forceinline__ float cross_group_sum(float v) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// base + 32-bit BYTE offset: lets the compiler use the scalar-base + 32-bit-VGPR-offset addressing mode instead of
+// 64-bit pointer arithmetic on the vector ALU (the hosts check that every tensor stays below 4 GiB)
+__device__ __forceinline__ float4 ld4o(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st4o(float* base, unsigned byte_off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ int ldio(const int* base, unsigned byte_off) {
+    return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }

@@ -49,6 +49,10 @@ static int check_dims(const char* fn, int64_t N, int64_t E, int H, int Cp, int D
     if (Cp <= 0 || (Cp & 3)) return fail(GLAM_E_INVALID, "%s: Cp=%d must be a positive multiple of 4", fn, Cp);
     if (De != 4 && De != 8) return fail(GLAM_E_UNSUPPORTED, "%s: De=%d (host must zero-pad edge features to 4 or 8)", fn, De);
     if (H < 1 || H > 4) return fail(GLAM_E_UNSUPPORTED, "%s: heads=%d not in 1..4", fn, H);
+    // the kernels address every tensor with 32-bit byte offsets
+    if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
+        return fail(GLAM_E_UNSUPPORTED, "%s: a tensor of N=%lld x H*Cp=%d (or E=%lld x De) floats exceeds 4 GiB", fn, (long long)N,
+                    H * Cp, (long long)E);
     if (!pick_shape(Cp >> 2, sh)) return fail(GLAM_E_UNSUPPORTED, "%s: Cp=%d exceeds 256 channels per head", fn, Cp);
     return GLAM_OK;
 }

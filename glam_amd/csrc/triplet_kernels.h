@@ -112,6 +112,10 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
         if (!ok[it]) q[it] = 0;
     }
 
+    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;   // 32-bit byte offsets (see ld4o)
+    unsigned chunk_off[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) chunk_off[it] = (unsigned)q[it] * 16u;
     // Edges are processed CH at a time with every load of a chunk in flight together (indices -> {edge
     // features, a_j, neighbour rows}): a degree <= CH segment (all molecular nodes) costs 3 dependent
     // memory round trips instead of 2 + 2*deg.
@@ -129,8 +133,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
     for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
       const int n = base + tid / G;
       if (n < a.N) {
-        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
-        const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
+        const int beg = ldio(a.rowptr, (unsigned)n * 4u), end = ldio(a.rowptr, (unsigned)n * 4u + 4u);
+        const float4 aiv = ld4o(a.a_ij, (unsigned)n * 32u);
         float ai[H], m[H], ssum[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) { ai[h] = f4get(aiv, h); m[h] = -INFINITY; ssum[h] = 0.f; }
@@ -149,25 +153,31 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             for (int k = 0; k < CH; ++k) {
                 val[k] = e0 + k < end;
                 const int e = val[k] ? e0 + k : end - 1;
-                sidx[k] = a.nbr[e];
-                eidx[k] = a.eid[e];
+                sidx[k] = ldio(a.nbr, (unsigned)e * 4u);
+                eidx[k] = ldio(a.eid, (unsigned)e * 4u);
             }
         };
         auto load_rows = [&]() {
+            // rows of invalid slots are loaded from the clamped (valid) index and never used: accumulate skips them
 #pragma unroll
-            for (int k = 0; k < CH; ++k)
+            for (int k = 0; k < CH; ++k) {
+                const unsigned ro = (unsigned)sidx[k] * row_bytes;
 #pragma unroll
                 for (int h = 0; h < H; ++h)
 #pragma unroll
-                    for (int it = 0; it < ITER; ++it)
-                        rows[k][h][it] = val[k] ? ld4(a.xw + (size_t)sidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
+                    for (int it = 0; it < ITER; ++it) rows[k][h][it] = ld4o(a.xw, ro + chunk_off[it] + (unsigned)h * head_bytes);
+            }
         };
         auto load_logits = [&]() {
             float4 aj[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                load_edge_attr<DE>(a.edge_attr, eidx[k], ea[k]);
-                aj[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
+#pragma unroll
+                for (int u = 0; u < DE / 4; ++u) {
+                    const float4 v = ld4o(a.edge_attr, (unsigned)eidx[k] * (unsigned)(DE * 4) + 16u * u);
+                    ea[k][4 * u] = v.x; ea[k][4 * u + 1] = v.y; ea[k][4 * u + 2] = v.z; ea[k][4 * u + 3] = v.w;
+                }
+                aj[k] = ld4o(a.a_ij, (unsigned)sidx[k] * 32u + 16u);
             }
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
@@ -225,7 +235,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             for (int e0 = beg; e0 < end; e0 += CH) { load_idx(e0); load_logits(); take_max(); }   // pass 1: segment max
             for (int e0 = beg; e0 < end; e0 += CH) { load_idx(e0); load_rows(); load_logits(); accumulate(); }
         }
-        float* orow = a.aggr + (size_t)n * HC;
+        const unsigned orow = (unsigned)n * row_bytes;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const float inv = 1.f / (ssum[h] + 1e-16f);
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             for (int it = 0; it < ITER; ++it)
                 if (ok[it]) {
                     const float4 v = inv * acc[h][it];
-                    st4(orow + h * Cp + q[it] * 4, v);
+                    st4o(a.aggr, orow + chunk_off[it] + (unsigned)h * head_bytes, v);
                     if constexpr (G == 16) {
                         if (fuse_upd) st4(s_tile + (tid / G) * LDT + h * Cp + q[it] * 4, v);
                     }
@@ -244,8 +254,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             float* mp = &mv.x; float* sp = &sv.x;
 #pragma unroll
             for (int h = 0; h < H; ++h) { mp[h] = (end > beg) ? m[h] : 0.f; sp[h] = ssum[h]; }
-            st4(a.stats + (size_t)n * 8, mv);
-            st4(a.stats + (size_t)n * 8 + 4, sv);
+            st4o(a.stats, (unsigned)n * 32u, mv);
+            st4o(a.stats, (unsigned)n * 32u + 16u, sv);
         }
       }
       if constexpr (G == 16) {
