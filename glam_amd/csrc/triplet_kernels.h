@@ -341,6 +341,10 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
         if (!ok[it]) q[it] = 0;
     }
 
+    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;   // 32-bit byte offsets (see ld4o)
+    unsigned chunk_off[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) chunk_off[it] = (unsigned)q[it] * 16u;
     float4 dw[EMUL ? DE : 1][H][ITER];
     float dM[DE][H];
 #pragma unroll
@@ -359,9 +363,9 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
     const long long prof_t0 = prof_last;
 #endif
     for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
-        const int beg = a.rowptr[n], end = a.rowptr[n + 1];
-        const float4 aiv = ld4(a.a_ij + (size_t)n * 8);
-        const float4 mv = ld4(a.stats + (size_t)n * 8), sv = ld4(a.stats + (size_t)n * 8 + 4);
+        const int beg = ldio(a.rowptr, (unsigned)n * 4u), end = ldio(a.rowptr, (unsigned)n * 4u + 4u);
+        const float4 aiv = ld4o(a.a_ij, (unsigned)n * 32u);
+        const float4 mv = ld4o(a.stats, (unsigned)n * 32u), sv = ld4o(a.stats, (unsigned)n * 32u + 16u);
         B1_STAMP(0);
         float ai[H], m[H], inv[H], dot[H], dai[H];
         float4 dag[H][ITER];
@@ -371,9 +375,9 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             float part = 0.f;
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const size_t off = (size_t)n * HC + h * Cp + q[it] * 4;
-                dag[h][it] = ok[it] ? ld4(a.d_aggr + off) : f4zero();
-                part += dot4(dag[h][it], ld4(a.aggr + off));
+                const unsigned off = (unsigned)n * row_bytes + (unsigned)h * head_bytes + chunk_off[it];
+                dag[h][it] = ok[it] ? ld4o(a.d_aggr, off) : f4zero();
+                part += dot4(dag[h][it], ld4o(a.aggr, off));
             }
             // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
             dot[h] = group_sum<G>(part);
@@ -389,19 +393,24 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             for (int k = 0; k < CH; ++k) {
                 val[k] = e0 + k < end;
                 const int e = val[k] ? e0 + k : end - 1;
-                sidx[k] = a.nbr[e];
-                eidx[k] = a.eid[e];
+                sidx[k] = ldio(a.nbr, (unsigned)e * 4u);
+                eidx[k] = ldio(a.eid, (unsigned)e * 4u);
             }
             B1_STAMP(2);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
+                const unsigned ro = (unsigned)sidx[k] * row_bytes;
 #pragma unroll
                 for (int h = 0; h < H; ++h)
 #pragma unroll
                     for (int it = 0; it < ITER; ++it)
-                        rows[k][h][it] = val[k] ? ld4(a.xw + (size_t)sidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
-                load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
-                ajv[k] = ld4(a.a_ij + (size_t)sidx[k] * 8 + 4);
+                        rows[k][h][it] = val[k] ? ld4o(a.xw, ro + (unsigned)h * head_bytes + chunk_off[it]) : f4zero();
+#pragma unroll
+                for (int u = 0; u < DE / 4; ++u) {
+                    const float4 v = ld4o(a.edge_attr, (unsigned)eidx[k] * (unsigned)(DE * 4) + 16u * u);
+                    eav[k][4 * u] = v.x; eav[k][4 * u + 1] = v.y; eav[k][4 * u + 2] = v.z; eav[k][4 * u + 3] = v.w;
+                }
+                ajv[k] = ld4o(a.a_ij, (unsigned)sidx[k] * 32u + 16u);
             }
             B1_STAMP(3);
             float pre[CH][H], alpha[CH][H], dp[CH][H];
@@ -461,8 +470,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
                     float* ap = &av.x; float* dpp = &dv.x;
 #pragma unroll
                     for (int h = 0; h < H; ++h) { ap[h] = alpha[k][h]; dpp[h] = dp[k][h]; }
-                    st4(a.alpha_e + (size_t)eidx[k] * 4, av);
-                    st4(a.dpre_e + (size_t)eidx[k] * 4, dv);
+                    st4o(a.alpha_e, (unsigned)eidx[k] * 16u, av);
+                    st4o(a.dpre_e, (unsigned)eidx[k] * 16u, dv);
                 }
             }
         }
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             float* dpp = &dv.x;
 #pragma unroll
             for (int h = 0; h < H; ++h) dpp[h] = dai[h];
-            st4(a.d_a_ij + (size_t)n * 8, dv);
+            st4o(a.d_a_ij, (unsigned)n * 32u, dv);
         }
         B1_STAMP(5);
     }
@@ -644,6 +653,10 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
         ok[it] = q[it] < Q;
         if (!ok[it]) q[it] = 0;
     }
+    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;   // 32-bit byte offsets (see ld4o)
+    unsigned chunk_off[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) chunk_off[it] = (unsigned)q[it] * 16u;
     typedef float v4f __attribute__((ext_vector_type(4)));
     const bool fuse_dx = (G == 16) && a.img_dx != nullptr;
     const int KX = HC + 8;                                      // columns of [d_xw | d_a_i | d_a_j]
@@ -657,7 +670,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
     for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
       const int j = base + tid / G;
       if (j < a.N) {
-        const int beg = a.colptr[j], end = a.colptr[j + 1];
+        const int beg = ldio(a.colptr, (unsigned)j * 4u), end = ldio(a.colptr, (unsigned)j * 4u + 4u);
         float4 acc[H][ITER];
         float4 daj = f4zero();
 #pragma unroll
@@ -674,19 +687,26 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
             for (int k = 0; k < CH; ++k) {
                 val[k] = e0 + k < end;
                 const int e = val[k] ? e0 + k : end - 1;
-                nidx[k] = a.nbr[e];
-                eidx[k] = a.eid[e];
+                nidx[k] = ldio(a.nbr, (unsigned)e * 4u);
+                eidx[k] = ldio(a.eid, (unsigned)e * 4u);
             }
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
+                const unsigned ro = (unsigned)nidx[k] * row_bytes;
 #pragma unroll
                 for (int h = 0; h < H; ++h)
 #pragma unroll
                     for (int it = 0; it < ITER; ++it)
-                        rows[k][h][it] = val[k] ? ld4(a.d_aggr + (size_t)nidx[k] * HC + h * Cp + q[it] * 4) : f4zero();
-                alv[k] = ld4(a.alpha_e + (size_t)eidx[k] * 4);
-                dpv[k] = ld4(a.dpre_e + (size_t)eidx[k] * 4);
-                if constexpr (EMUL) load_edge_attr<DE>(a.edge_attr, eidx[k], eav[k]);
+                        rows[k][h][it] = val[k] ? ld4o(a.d_aggr, ro + (unsigned)h * head_bytes + chunk_off[it]) : f4zero();
+                alv[k] = ld4o(a.alpha_e, (unsigned)eidx[k] * 16u);
+                dpv[k] = ld4o(a.dpre_e, (unsigned)eidx[k] * 16u);
+                if constexpr (EMUL) {
+#pragma unroll
+                    for (int u = 0; u < DE / 4; ++u) {
+                        const float4 v = ld4o(a.edge_attr, (unsigned)eidx[k] * (unsigned)(DE * 4) + 16u * u);
+                        eav[k][4 * u] = v.x; eav[k][4 * u + 1] = v.y; eav[k][4 * u + 2] = v.z; eav[k][4 * u + 3] = v.w;
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < CH; ++k)
@@ -716,22 +736,22 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        float* orow = a.d_xw + (size_t)j * HC;
+        const unsigned orow = (unsigned)j * row_bytes;
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
             for (int it = 0; it < ITER; ++it)
                 if (ok[it]) {
-                    st4(orow + h * Cp + q[it] * 4, acc[h][it]);
+                    st4o(a.d_xw, orow + (unsigned)h * head_bytes + chunk_off[it], acc[h][it]);
                     if constexpr (G == 16) {
                         if (fuse_dx) st4(s_tile + (tid / G) * LDT + h * Cp + q[it] * 4, acc[h][it]);
                     }
                 }
         if (lg == 0) {
-            st4(a.d_a_ij + (size_t)j * 8 + 4, daj);
+            st4o(a.d_a_ij, (unsigned)j * 32u + 16u, daj);
             if constexpr (G == 16) {
                 if (fuse_dx) {
-                    st4(s_tile + (tid / G) * LDT + HC, ld4(a.d_a_ij + (size_t)j * 8));
+                    st4(s_tile + (tid / G) * LDT + HC, ld4o(a.d_a_ij, (unsigned)j * 32u));
                     st4(s_tile + (tid / G) * LDT + HC + 4, daj);
                 }
             }
