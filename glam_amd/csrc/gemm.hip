@@ -236,10 +236,8 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
                 for (int tj = 0; tj < 4; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv[st], ti), f4get(qv[st], tj), acc[ti][tj], 0, 0, 0);
     }
-    // ---- sum the 8 waves (identical register layouts, reg = (ti*4 + tj)*4 + r) in wave order and write the block
-    //      partial in LOGICAL order out[i_local*64 + j] (i_local = 4*(4*kq + r) + ti, j = 4*c + tj), so that whoever
-    //      reduces the partials reads consecutive j with consecutive threads.  The transpose happens in the LDS read
-    //      (4-way bank conflict on 8 reads per element: noise next to the MFMA phase). ----
+    // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order; wave w finalises 4 of every 32
+    //      registers.  reg = (ti*4 + tj)*4 + r ----
     float* out = a.partial + ((size_t)slab * a.nsplit + split) * 4096;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -254,23 +252,20 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // this half holds ti in {2*half, 2*half + 1}: 32 of the 64 rows.  Thread (wave, q, lane) -> row slot ii, column j
-            const int ii = wave * 4 + q, j = lane;
-            const int i_local = (ii >> 1) * 4 + 2 * half + (ii & 1);
-            const int t = ii >> 1, skq = t >> 2, sr = t & 3, sc = j >> 2, stj = j & 3;
-            const int reg = (((ii & 1) * 4 + stj) << 2) + sr, src_lane = skq * 16 + sc;
+            const int reg = wave * 4 + q;
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWgWaves; ++w) sum += s_red[(w * 32 + reg) * 64 + src_lane];
-            out[i_local * 64 + j] = sum;
+            for (int w = 0; w < kWgWaves; ++w) sum += s_red[(w * 32 + reg) * 64 + lane];
+            out[(half * 32 + reg) * 64 + lane] = sum;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Final fixed-order reduction of up to 3 partial sets in ONE launch.
-//   kind 0 (k_wgrad partials, logical order): element offset `o` in [0, nslab*4096) is i = 64*slab + (o%4096)/64,
-//          j = o%64;  out[i*si + j*sj] = sum_s partial[(slab*nsplit + s)*4096 + o%4096]
+//   kind 0 (k_wgrad partials): element offset `o` in [0, nslab*4096) decodes to reg = (o%4096)/64, lane = o%64,
+//          ti = reg/16, tj = (reg/4)%4, r = reg%4, kq = lane/16, c = lane%16  ->  i = 64*slab + 4*(4*kq + r) + ti,
+//          j = 4*c + tj;  out[i*si + j*sj] = sum_s partial[(slab*nsplit + s)*4096 + o%4096]
 //   kind 1 (flat block partials [nsplit][n]): out[e] (e < split_at) or out2[e - split_at] = sum_s partial[s*n + e]
 __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
     __shared__ float s_part[16][17];
@@ -298,8 +293,8 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += s_part[r][c];
         if (J.kind == 0) {
-            const int o = e & 4095;
-            const int i = (e >> 12) * 64 + (o >> 6), j = o & 63;
+            const int o = e & 4095, reg = o >> 6, lane = o & 63;
+            const int i = (e >> 12) * 64 + 4 * ((lane >> 4) * 4 + (reg & 3)) + (reg >> 4), j = 4 * (lane & 15) + ((reg >> 2) & 3);
             if (i < J.I && j < J.J) J.out[(size_t)i * J.si + (size_t)j * J.sj] = s;
         } else if (e < J.split_at) {
             if (J.out) J.out[e] = s;

@@ -196,10 +196,10 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
 // products, block partials of B1), i.e. the final fixed-order reductions AND the chain rule of k_stage_params in ONE
 // launch (it replaces k_final_reduce -> k_stage_params_bwd).  Block roles:
 //   A  d_weight_scale / d_bias        one thread per element: sum over the splits of product 1 ([aggr|1]^T d_out)
-//   B  d_weight_node                  one block per 4 columns (h,c) x all rows k: d_Wa_i, d_Wa_j first (LDS), then
+//   B  d_weight_node row k            one block per k: d_Wa_i[k,:], d_Wa_j[k,:] first (LDS), then
 //                                     d_Wcat[k,h,c] + d_Wa_i[k,h] att_i[h,c] + d_Wa_j[k,h] att_j[h,c]
-//   C  d_weight_triplet_att           one block per (head, 16 elements): d_Wa_i[:,h], d_Wa_j[:,h], d_M[:,h] into LDS,
-//                                     then a 16-lane group per element contracts them with W_node / W_edge
+//   C  d_weight_triplet_att head h    one block per head: d_Wa_i[:,h], d_Wa_j[:,h], d_M[:,h] into LDS, then the
+//                                     contractions with W_node / W_edge
 //   D  d_weight_edge                  a 16-lane group per element: sum over the B1 blocks + d_M[k,h] att_e[h,c]
 // Every sum runs in a fixed order (splits ascending; lane-strided partial sums + DPP butterfly for the B1 partials).
 struct ParamGradArgs {
@@ -212,8 +212,11 @@ struct ParamGradArgs {
     int blocksA, blocksB, blocksC;
 };
 
-// element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (logical order: consecutive j are adjacent)
-__device__ __forceinline__ int wg_slab_offset(int i, int j) { return ((i & 63) << 6) + j; }
+// element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (inverse of the decode in k_final_reduce)
+__device__ __forceinline__ int wg_slab_offset(int i, int j) {
+    const int ii = i & 63, ti = ii & 3, t = ii >> 2, kq = t >> 2, r = t & 3, c = j >> 2, tj = j & 3;
+    return (((ti * 4 + tj) * 4 + r) << 6) + kq * 16 + c;
+}
 // loads are issued 32 at a time (a launch of this kernel is a handful of dependent round trips, nothing else)
 __device__ __forceinline__ float wg_sum(const float* partial, int nsplit, int i, int j) {
     const float* p = partial + (size_t)(i >> 6) * nsplit * 4096 + wg_slab_offset(i, j);
@@ -242,7 +245,6 @@ __device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e
 
 __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
     __shared__ float s_dwa[2][64];
-    __shared__ float s_dwa8[8][64];
     __shared__ float s_dm[8];
     const int tid = threadIdx.x, lg = tid & 15, grp = tid >> 4;
     const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
@@ -259,27 +261,25 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         return;
     }
     b -= a.blocksA;
-    if (b < a.blocksB) {                                    // ---- B: weight_node, 4 columns (h, c) x 64 rows k per block
-        // thread = (column slot, k): consecutive k read consecutive partial elements; the writes (one per thread) scatter
-        const int k = tid & 63, m = b * 4 + (tid >> 6);     // m indexes the H*C unpadded columns
-        for (int e = tid; e < 8 * 64; e += kBlock) {       // d_Wa[side*4 + h][k] for all 8 (side, h): 2 per thread
-            const int sh = e >> 6, kk = e & 63;
-            s_dwa8[sh][kk] = ((sh & 3) < H && kk < C) ? wg_sum(a.p2, a.ns2, HC + sh, kk) : 0.f;
+    if (b < a.blocksB) {                                    // ---- B: weight_node row k = b
+        const int k = b;
+        if (tid < 8) {
+            const int h = tid & 3, side = tid >> 2;
+            s_dwa[0][tid] = h < H ? wg_sum(a.p2, a.ns2, HC + side * 4 + h, k) : 0.f;
         }
         __syncthreads();
-        if (m < H * C && k < C) {
-            const int h = m / C, c = m - h * C;
+        if (tid < H * C) {
+            const int h = tid / C, c = tid - h * C;
             float v = wg_sum(a.p2, a.ns2, h * Cp + c, k);
-            v = fmaf(s_dwa8[h][k], a.att[(size_t)h * 3 * C + c], v);
-            v = fmaf(s_dwa8[4 + h][k], a.att[(size_t)h * 3 * C + 2 * C + c], v);
-            a.d_wn[(size_t)k * H * C + m] = v;
+            v = fmaf(s_dwa[0][h], a.att[(size_t)h * 3 * C + c], v);
+            v = fmaf(s_dwa[0][4 + h], a.att[(size_t)h * 3 * C + 2 * C + c], v);
+            a.d_wn[(size_t)k * H * C + tid] = v;
         }
         return;
     }
     b -= a.blocksB;
-    if (b < a.blocksC) {                                    // ---- C: 16 attention-vector elements of one head
-        const int nchunk = (3 * C + 15) >> 4;
-        const int h = b / nchunk, chunk = b - h * nchunk;
+    if (b < a.blocksC) {                                    // ---- C: attention vector of head h = b
+        const int h = b;
         for (int idx = tid; idx < 2 * C; idx += kBlock) {
             const int side = idx / C, k = idx - side * C;
             s_dwa[side][k] = wg_sum(a.p2, a.ns2, HC + side * 4 + h, k);
@@ -289,24 +289,25 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
             if (lg == 0) s_dm[kk] = v;
         }
         __syncthreads();
-        const int oi = chunk * 16 + grp;                    // a 16-lane group per element: one round trip of loads
-        if (oi < 3 * C) {
-            const int part = oi / C, c = oi - part * C;
+        if (tid < 3 * C) {
+            const int part = tid / C, c = tid - part * C;
             float v = 0.f;
             if (part == 1) {
-                for (int kk = lg; kk < De; kk += 16) v = fmaf(s_dm[kk], a.we[(size_t)kk * H * C + h * C + c], v);
+                for (int kk = 0; kk < De; ++kk) v = fmaf(s_dm[kk], a.we[(size_t)kk * H * C + h * C + c], v);
             } else {
                 const float* dwa = s_dwa[part == 0 ? 0 : 1];
-                float w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) w[u] = a.wn[(size_t)min(lg + 16 * u, C - 1) * H * C + h * C + c];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (lg + 16 * u < C) v = fmaf(dwa[lg + 16 * u], w[u], v);
-                for (int k = lg + 64; k < C; k += 16) v = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v);
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                int k = 0;
+                for (; k + 4 <= C; k += 4) {
+                    v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
+                    v1 = fmaf(dwa[k + 1], a.wn[(size_t)(k + 1) * H * C + h * C + c], v1);
+                    v2 = fmaf(dwa[k + 2], a.wn[(size_t)(k + 2) * H * C + h * C + c], v2);
+                    v3 = fmaf(dwa[k + 3], a.wn[(size_t)(k + 3) * H * C + h * C + c], v3);
+                }
+                for (; k < C; ++k) v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
+                v = (v0 + v1) + (v2 + v3);
             }
-            v = group_sum<16>(v);
-            if (lg == 0) a.d_att[(size_t)h * 3 * C + oi] = v;
+            a.d_att[(size_t)h * 3 * C + tid] = v;
         }
         return;
     }
@@ -469,7 +470,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
         const int C = po->C, De = po->De;
         ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
-                         (H * C * C + C + kBlock - 1) / kBlock, (H * C + 3) / 4, H * ((3 * C + 15) / 16)};
+                         (H * C * C + C + kBlock - 1) / kBlock, C, H};
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
         GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
