@@ -4,12 +4,14 @@ import re, sqlite3, sys
 from collections import defaultdict
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
-q = "select kernel_name, counter_name, value, dispatch_id from counters_collection" if "kernel_name" in cols else None
+gcol = "grid_size" if "grid_size" in cols else "0"
+q = f"select kernel_name, counter_name, value, dispatch_id, {gcol} from counters_collection" if "kernel_name" in cols else None
 if q is None:
     print(cols); sys.exit(1)
 acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(set)
-for name, cn, val, did in db.execute(q):
+for name, cn, val, did, grid in db.execute(q):
     name = re.sub(r"\(.*", "", name); name = re.sub(r"^void ", "", name)
+    if name.startswith("glam::"): name = f"{name} [grid={grid}]"
     acc[name][cn] += val; cnt[name].add(did)
 names = sorted({c for k in acc for c in acc[k]})
 lines = [f"{'kernel':60s} {'n':>5s} " + " ".join(f"{c[:22]:>22s}" for c in names)]
