@@ -658,3 +658,53 @@ def test_layer_parameter_gradients_form_one_bucket(device):
     fv = flat_view(grads)
     assert fv is not None and fv.numel() == sum(p.numel() for p in params)
     assert torch.equal(fv, torch.cat([g.reshape(-1) for g in grads]))
+
+
+@pytest.mark.parametrize("C,H,De", [(60, 3, 4), (30, 2, 4), (44, 4, 8)])
+def test_layer_bwd_both_abi_routes_agree(device, C, H, De):
+    """`glam_triplet_layer_bwd` + `glam_triplet_stage_params_bwd` (padded intermediate) and `glam_triplet_layer_bwd_params`
+    (parameter gradients straight from the partial sums) are the same mathematics in two summation orders."""
+    from glam_amd import _lib
+    from glam_amd._lib import check, ptr, stream
+    lib = _lib.load()
+    torch.manual_seed(C + H)
+    b = synth_batch(48, seed=C).to(device)
+    N, E = b.x.size(0), b.edge_index.size(1)
+    Cp, Dp = (C + 3) // 4 * 4, 4 if De <= 4 else 8
+    HC = H * Cp
+    f = dict(dtype=torch.float32, device=device)
+    wn, we, att = torch.randn(C, H * C, **f) * 0.2, torch.randn(De, H * C, **f) * 0.2, torch.randn(H, 3 * C, **f) * 0.2
+    wsc, bias = torch.randn(H * C, C, **f) * 0.2, torch.randn(C, **f) * 0.1
+    x_p = torch.nn.functional.pad(torch.randn(N, C, **f), (0, Cp - C))
+    ea_p = torch.nn.functional.pad(torch.rand(E, De, **f), (0, Dp - De))
+    d_out = torch.nn.functional.pad(torch.randn(N, C, **f), (0, Cp - C))
+    gi = ops.graph_index(b.edge_index, N)
+    colptr, dst, eid_t = gi.transpose()
+    staged = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
+    check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(staged), stream()), "stage")
+    xw, a_ij, aggr = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, HC, **f)
+    stats, out = torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
+    check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), None, 0, N, E, H, Cp,
+                                     Dp, 0.2, ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out), stream()), "fwd")
+    ws = torch.empty(lib.glam_triplet_layer_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=device)
+
+    def grads():
+        return [torch.empty_like(wn), torch.empty_like(we), torch.empty_like(att), torch.empty_like(wsc), torch.empty_like(bias)]
+
+    # route 1: padded intermediate + chain-rule kernel
+    dstaged = torch.empty(lib.glam_triplet_dstaged_floats(H, Cp, Dp), **f)
+    dx1, g1 = torch.empty_like(x_p), grads()
+    check(lib.glam_triplet_layer_bwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(d_out),
+                                     ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst), ptr(eid_t), N, E, H, Cp, Dp, 0.2,
+                                     ptr(dx1), ptr(dstaged), None, ptr(ws), ws.numel(), stream()), "bwd")
+    check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, *[ptr(t) for t in g1], stream()),
+          "stage_bwd")
+    # route 2: one call
+    dx2, g2 = torch.empty_like(x_p), grads()
+    check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(d_out),
+                                            ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst), ptr(eid_t), N, E, C, H, De,
+                                            Cp, Dp, 0.2, ptr(wn), ptr(we), ptr(att), ptr(dx2), *[ptr(t) for t in g2], None, ptr(ws),
+                                            ws.numel(), stream()), "bwd_params")
+    assert torch.equal(dx1, dx2)
+    for name, a, r in zip(["weight_node", "weight_edge", "att", "weight_scale", "bias"], g2, g1):
+        assert_close(a, r, 2e-5, name)
