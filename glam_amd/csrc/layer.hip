@@ -87,36 +87,75 @@ struct StageArgs {
     float* base; Staged L;
 };
 
-// logical Wcat[k][m], k < Cp, m < H*Cp + 8
-__device__ __forceinline__ float wcat_val(const StageArgs& a, int k, int m) {
+// logical Wcat[k][m], k < Cp, m < H*Cp + 8.  The separable-attention columns (m >= H*Cp, a 60-term contraction each)
+// are produced by the dot blocks of k_stage_params; *is_dot tells the copy loop to leave the element alone.
+__device__ __forceinline__ float wcat_val(const StageArgs& a, int k, int m, bool* is_dot) {
     const int C = a.C, H = a.H, Cp = a.Cp;
+    *is_dot = false;
     if (k >= C) return 0.f;
     if (m < H * Cp) {
         const int h = m / Cp, c = m % Cp;
         return c < C ? a.wn[(size_t)k * H * C + h * C + c] : 0.f;
     }
-    const int s = m - H * Cp, h = s & 3, side = s >> 2;   // side 0: att[:, 0:C] (target), 1: att[:, 2C:3C] (source)
+    const int s = m - H * Cp, h = s & 3;
     if (h >= H) return 0.f;
-    return dot_strided(a.wn + (size_t)k * H * C + h * C, 1, a.att + (size_t)h * 3 * C + (side ? 2 * C : 0), 1, C);
+    *is_dot = true;
+    return 0.f;
 }
+// position of logical column m inside a k_ts_gemm image row (inverse of ts_col_of_pos)
+__device__ __forceinline__ int ts_pos_of_col(int m) { return (m & ~63) + (m & 3) * 16 + ((m >> 2) & 15); }
 // logical Ws_p[k][m], k < H*Cp, m < Cp
 __device__ __forceinline__ float wsp_val(const StageArgs& a, int k, int m) {
     const int h = k / a.Cp, c = k % a.Cp;
     return (c < a.C && m < a.C) ? a.wsc[(size_t)(h * a.C + c) * a.C + m] : 0.f;
 }
 
-__global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a) {
+__global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a, int copy_blocks) {
     const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, Dp = a.Dp, HC = H * Cp;
     const int Kp1 = (Cp + 15) & ~15, Kp2 = (HC + 15) & ~15, Kp4 = (HC + 8 + 15) & ~15;
     const int P1 = HC + 8 <= 64 ? 64 : 192, P3 = HC <= 64 ? 64 : 192;   // image column count 16*MT
+    if ((int)blockIdx.x >= copy_blocks) {
+        // ---- dot blocks: one 16-lane group per contraction (one round trip of loads + a DPP butterfly) ----
+        //   item < 8*C        : Wa[k][s] = sum_c W_node[k,h,c] att[h, side*2C + c]   (s = side*4 + h) -> node image + d_x image
+        //   item >= 8*C       : M[kk][h] = sum_c W_edge[kk,h,c] att[h, C + c]
+        const int lg = threadIdx.x & 15;
+        const int item = ((int)blockIdx.x - copy_blocks) * (kBlock / 16) + (threadIdx.x >> 4);
+        const bool is_m = item >= 8 * C;
+        const int r = is_m ? (item - 8 * C) >> 2 : item >> 3;          // k or kk
+        const int sx = is_m ? (item - 8 * C) & 3 : item & 7, h = sx & 3, side = sx >> 2;
+        if ((is_m && r >= De) || h >= H) return;
+        const float* w = (is_m ? a.we : a.wn) + (size_t)r * H * C + h * C;
+        const float* t = a.att + (size_t)h * 3 * C + (is_m ? C : (side ? 2 * C : 0));
+        float wv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = min(lg + 16 * u, C - 1); wv[u] = w[c]; tv[u] = t[c]; }
+        float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lg + 16 * u < C) v = fmaf(wv[u], tv[u], v);
+        for (int c = lg + 64; c < C; c += 16) v = fmaf(w[c], t[c], v);
+        v = group_sum<16>(v);
+        if (lg == 0) {
+            if (is_m) {
+                a.base[a.L.m + r * 4 + h] = v;
+            } else {
+                const int m = HC + sx;                       // Wcat[k = r][m]
+                a.base[a.L.img_node + ((size_t)(r >> 2) * P1 + ts_pos_of_col(m)) * 4 + (r & 3)] = v;
+                a.base[a.L.img_dx + ((size_t)(m >> 2) * 64 + ts_pos_of_col(r)) * 4 + (m & 3)] = v;   // Wcat^T[m][r]
+            }
+        }
+        return;
+    }
     const int n1 = Kp1 * P1, n2 = Kp2 * 64, n3 = Kp1 * P3, n4 = Kp4 * 64, n5 = Dp * HC, n6 = Dp * 4, n7 = Cp;
     const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7;
     // image element idx -> (k, logical column m): layout [k/4][p][k%4], column order ts_col_of_pos
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += copy_blocks * kBlock) {
         int i = idx;
+        bool is_dot = false;
         if (i < n1) {            // node image: K = Cp, M = HC + 8
             const int k = (i >> 2) / P1 * 4 + (i & 3), m = ts_col_of_pos((i >> 2) % P1);
-            a.base[a.L.img_node + i] = (k < Cp && m < HC + 8) ? wcat_val(a, k, m) : 0.f;
+            const float v = (k < Cp && m < HC + 8) ? wcat_val(a, k, m, &is_dot) : 0.f;
+            if (!is_dot) a.base[a.L.img_node + i] = v;
             continue;
         }
         i -= n1;
@@ -134,7 +173,8 @@ __global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a) {
         i -= n3;
         if (i < n4) {            // d_x image: K = HC + 8, M = Cp, logical W[k][m] = Wcat[m][k]
             const int k = (i >> 2) / 64 * 4 + (i & 3), m = ts_col_of_pos((i >> 2) % 64);
-            a.base[a.L.img_dx + i] = (k < HC + 8 && m < Cp) ? wcat_val(a, m, k) : 0.f;
+            const float v = (k < HC + 8 && m < Cp) ? wcat_val(a, m, k, &is_dot) : 0.f;
+            if (!is_dot) a.base[a.L.img_dx + i] = v;
             continue;
         }
         i -= n4;
@@ -146,7 +186,7 @@ __global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a) {
         i -= n5;
         if (i < n6) {
             const int k = i >> 2, h = i & 3;
-            a.base[a.L.m + i] = (k < De && h < H) ? dot_strided(a.we + (size_t)k * H * C + h * C, 1, a.att + (size_t)h * 3 * C + C, 1, C) : 0.f;
+            if (!(k < De && h < H)) a.base[a.L.m + i] = 0.f;        // the real entries come from the dot blocks
             continue;
         }
         i -= n6;
@@ -346,7 +386,9 @@ extern "C" int glam_triplet_stage_params(const float* weight_node, const float* 
     GLAM_REQUIRE(weight_node && weight_edge && att && weight_scale && bias && staged && aligned16(staged),
                  "glam_triplet_stage_params: null / misaligned pointer");
     StageArgs a{weight_node, weight_edge, att, weight_scale, bias, C, H, De, Cp, Dp, staged, staged_layout(H, Cp, Dp)};
-    hipLaunchKernelGGL(k_stage_params, dim3(grid_for((int64_t)a.L.total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    const int copy_blocks = grid_for((int64_t)a.L.total, kBlock);
+    const int dot_blocks = (8 * C + 4 * Dp + kBlock / 16 - 1) / (kBlock / 16);
+    hipLaunchKernelGGL(k_stage_params, dim3(copy_blocks + dot_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, copy_blocks);
     GLAM_LAUNCH_CHECK("glam_triplet_stage_params");
     return GLAM_OK;
 }
