@@ -88,22 +88,41 @@ class Batch(Data):
 
 class DataLoader:
     """Sequential mini-batch iterator over a list of ``Data`` (the reference's train
-    loader does not shuffle: ``src_1gp/trainer.py:37-38``)."""
+    loader does not shuffle: ``src_1gp/trainer.py:37-38``).
 
-    def __init__(self, dataset, batch_size=32, shuffle=False, seed=0):
+    ``device`` / ``cache``: without shuffling the batch composition repeats every epoch, so the collated batches
+    can be built and moved to the device ONCE and handed out again as the same tensor objects.  The CSR staging of
+    ``ops.graph_index`` is keyed on the ``edge_index`` object, so from the second epoch on a step does no
+    collation, no host-to-device copy, no CSR build and no validation sync."""
+
+    def __init__(self, dataset, batch_size=32, shuffle=False, seed=0, device=None, cache=None):
         self.dataset, self.batch_size, self.shuffle, self.seed = list(dataset), batch_size, shuffle, seed
+        self.device = device
+        self.cache = (not shuffle) if cache is None else bool(cache)
+        if self.cache and shuffle:
+            raise ValueError("DataLoader: cached batches need a fixed order (shuffle=False)")
         self._epoch = 0
+        self._batches = None
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def _collate(self, idx):
+        b = Batch.from_data_list([self.dataset[i] for i in idx])
+        return b if self.device is None else b.to(self.device)
 
     def __iter__(self):
         order = np.arange(len(self.dataset))
         if self.shuffle:
             np.random.default_rng(self.seed + self._epoch).shuffle(order)
         self._epoch += 1
+        if self.cache:
+            if self._batches is None:
+                self._batches = [self._collate(order[s:s + self.batch_size]) for s in range(0, len(order), self.batch_size)]
+            yield from self._batches
+            return
         for s in range(0, len(order), self.batch_size):
-            yield Batch.from_data_list([self.dataset[i] for i in order[s:s + self.batch_size]])
+            yield self._collate(order[s:s + self.batch_size])
 
 
 # --------------------------------------------------------------------------------------

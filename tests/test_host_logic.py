@@ -186,3 +186,19 @@ def test_flat_view_recognises_bucket_views():
     assert flat_view([a, c]) is None                    # gap
     assert flat_view([a, torch.zeros(4)]) is None       # different storage
     assert flat_view([]) is None
+
+
+def test_dataloader_caches_collated_batches_when_order_is_fixed():
+    rng = np.random.default_rng(5)
+    mols = [synth_molecule(rng) for _ in range(7)]
+    loader = DataLoader(mols, batch_size=3)                  # shuffle=False => cached
+    first = list(loader)
+    second = list(loader)
+    assert len(first) == 3 and all(a is b for a, b in zip(first, second))       # same objects: CSR cache keys stay valid
+    assert all(a.edge_index is b.edge_index for a, b in zip(first, second))
+    fresh = list(DataLoader(mols, batch_size=3, cache=False))
+    assert all(torch.equal(a.x, b.x) and torch.equal(a.edge_index, b.edge_index) for a, b in zip(first, fresh))
+    shuffled = DataLoader(mols, batch_size=3, shuffle=True, seed=1)
+    assert [b.num_graphs for b in shuffled] == [3, 3, 1] and shuffled.cache is False
+    with pytest.raises(ValueError):
+        DataLoader(mols, batch_size=3, shuffle=True, cache=True)
