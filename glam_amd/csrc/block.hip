@@ -42,9 +42,94 @@ __global__ void __launch_bounds__(kBlock) k_gru_gates_bwd(const float* gi, const
     }
 }
 
+// ---- the rest of MessageBlock.forward after the GRU (layer.py:263-266) folded into the gate kernel:
+//   h' = GRU gates;  y = h' + identity (res);  out = act(y),  act in {none, ReLU, LeakyReLU(slope), CELU(alpha = 1)}
+enum { kActNone = 0, kActRelu = 1, kActLeaky = 2, kActCelu = 3 };
+
+__device__ __forceinline__ float act_fwd(float y, int act, float slope) {
+    switch (act) {
+        case kActRelu: return fmaxf(y, 0.f);
+        case kActLeaky: return y > 0.f ? y : y * slope;
+        case kActCelu: return fmaxf(y, 0.f) + fminf(0.f, expf(y) - 1.f);
+        default: return y;
+    }
+}
+// d act / d y from the OUTPUT (out > 0 <=> y > 0 for all three; CELU: exp(y) = out + 1 on the negative side)
+__device__ __forceinline__ float act_grad_from_out(float out, int act, float slope) {
+    switch (act) {
+        case kActRelu: return out > 0.f ? 1.f : 0.f;
+        case kActLeaky: return out > 0.f ? 1.f : slope;
+        case kActCelu: return out > 0.f ? 1.f : out + 1.f;
+        default: return 1.f;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const float* gh, const float* h, const float* identity,
+                                                        int N, int C, int act, float slope, float* h_new, float* out) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const size_t n = i / C, c = i % C, b = n * 3 * C + c;
+        const float r = sigmoidf_(gi[b] + gh[b]);
+        const float z = sigmoidf_(gi[b + C] + gh[b + C]);
+        const float nn = tanhf(gi[b + 2 * C] + r * gh[b + 2 * C]);
+        const float hn = (1.f - z) * nn + z * h[i];
+        h_new[i] = hn;
+        out[i] = act_fwd(identity ? hn + identity[i] : hn, act, slope);
+    }
+}
+
+// d_out: gradient of the block output; d_hstate (may be null): gradient arriving at h' through the next step's GRU
+__global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const float* gh, const float* h, const float* out,
+                                                        const float* d_out, const float* d_hstate, int N, int C, int act,
+                                                        float slope, float* d_gi, float* d_gh, float* d_h, float* d_identity) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const size_t n = i / C, c = i % C, b = n * 3 * C + c;
+        const float dy = d_out[i] * act_grad_from_out(out[i], act, slope);
+        if (d_identity) d_identity[i] = dy;
+        const float g = d_hstate ? dy + d_hstate[i] : dy;
+        const float ghn = gh[b + 2 * C];
+        const float r = sigmoidf_(gi[b] + gh[b]);
+        const float z = sigmoidf_(gi[b + C] + gh[b + C]);
+        const float nn = tanhf(gi[b + 2 * C] + r * ghn);
+        const float d_n = g * (1.f - z), d_z = g * (h[i] - nn);
+        const float d_pn = d_n * (1.f - nn * nn);
+        const float d_pr = d_pn * ghn * r * (1.f - r);
+        const float d_pz = d_z * z * (1.f - z);
+        d_gi[b] = d_pr; d_gi[b + C] = d_pz; d_gi[b + 2 * C] = d_pn;
+        d_gh[b] = d_pr; d_gh[b + C] = d_pz; d_gh[b + 2 * C] = d_pn * r;
+        d_h[i] = g * z;
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
+
+extern "C" int glam_gru_tail_fwd(const float* gi, const float* gh, const float* h, const float* identity, int64_t N, int C,
+                                 int act, float slope, float* h_new, float* out, void* stream) {
+    GLAM_REQUIRE(N >= 0 && C > 0 && N * (int64_t)C < (int64_t)INT32_MAX * 64, "glam_gru_tail_fwd: bad sizes");
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_tail_fwd: activation code %d", act);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(gi && gh && h && h_new && out, "glam_gru_tail_fwd: null pointer");
+    hipLaunchKernelGGL(k_gru_tail_fwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, identity,
+                       (int)N, C, act, slope, h_new, out);
+    GLAM_LAUNCH_CHECK("glam_gru_tail_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_tail_bwd(const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                                 const float* d_hstate, int64_t N, int C, int act, float slope, float* d_gi, float* d_gh,
+                                 float* d_h, float* d_identity, void* stream) {
+    GLAM_REQUIRE(N >= 0 && C > 0, "glam_gru_tail_bwd: bad sizes");
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_tail_bwd: activation code %d", act);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(gi && gh && h && out && d_out && d_gi && d_gh && d_h, "glam_gru_tail_bwd: null pointer");
+    hipLaunchKernelGGL(k_gru_tail_bwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
+                       d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity);
+    GLAM_LAUNCH_CHECK("glam_gru_tail_bwd");
+    return GLAM_OK;
+}
 
 extern "C" int glam_gru_gates_fwd(const float* gi, const float* gh, const float* h, int64_t N, int C, float* h_new,
                                   void* stream) {

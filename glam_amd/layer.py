@@ -593,6 +593,19 @@ class MessageBlock(torch.nn.Module):
         g = self.gru
         return ops.gru_step(x, h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
 
+    def _fusable_act(self):
+        """(code, slope) when ``self.act`` is one the gate kernel applies itself, else None."""
+        a = self.act
+        if isinstance(a, _None):
+            return "none", 0.0
+        if type(a) is torch.nn.ReLU:
+            return "relu", 0.0
+        if type(a) is torch.nn.LeakyReLU and a.negative_slope > 0:
+            return "leaky", float(a.negative_slope)
+        if type(a) is torch.nn.CELU and a.alpha == 1.0:
+            return "celu", 0.0
+        return None                                  # RReLU (random in training), PReLU (learnable): stay on torch
+
     def forward(self, x, edge_index, edge_attr, h=None, batch=None):
         identity = x
         if h is None:
@@ -602,6 +615,12 @@ class MessageBlock(torch.nn.Module):
         x = self.conv(x, edge_index, edge_attr)      # layer.py:259
         if self.gru is not None:
             x = torch.celu(x)                        # layer.py:261
+            fa = self._fusable_act()
+            if fa is not None:                       # GRU gates + residual + activation: one launch per direction
+                g = self.gru
+                x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,
+                                     g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1])
+                return x, hn.unsqueeze(0)
             x = self._gru_step(x, h.squeeze(0))
             h = x.unsqueeze(0)
         x = x if self.res is False else x + identity

@@ -425,6 +425,46 @@ class _GruGates(torch.autograd.Function):
         return d_gi, d_gh, d_h
 
 
+class _GruTail(torch.autograd.Function):
+    """GRU gates + residual + activation in one launch per direction; returns (out, h_new)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h, identity, act, slope):
+        require_device(gi, gh, h)
+        gi, gh, h = f32c(gi, "gi"), f32c(gh, "gh"), f32c(h, "h")
+        identity = None if identity is None else f32c(identity, "identity")
+        N, C = h.shape
+        h_new, out = torch.empty_like(h), torch.empty_like(h)
+        check(_lib.load().glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out),
+                                            stream()), "glam_gru_tail_fwd")
+        ctx.save_for_backward(gi, gh, h, out)
+        ctx.cfg = (act, float(slope), identity is not None)
+        return out, h_new
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, d_hstate):
+        gi, gh, h, out = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        N, C = h.shape
+        d_out = f32c(d_out, "d_out")
+        d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
+        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        d_id = torch.empty_like(h) if has_res else None
+        check(_lib.load().glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope,
+                                            ptr(d_gi), ptr(d_gh), ptr(d_h), ptr(d_id), stream()), "glam_gru_tail_bwd")
+        return d_gi, d_gh, d_h, d_id, None, None
+
+
+ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3}
+
+
+def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0):
+    """``h_new = GRU(x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:262-266): the two gate
+    GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
+    return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
+
+
 def gru_step(x, h, w_ih, w_hh, b_ih, b_hh):
     """One ``torch.nn.GRU(C, C)`` step with seq_len 1 on its own parameters (src_1gp/layer.py:247, :262)."""
     return _GruGates.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h)

@@ -220,6 +220,15 @@ int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const 
  * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with
  * glam_ts_gemm) -> h_new f32[N,C].  The backward recomputes the gates from gi / gh. */
 int glam_gru_gates_fwd(const float* gi, const float* gh, const float* h, int64_t N, int C, float* h_new, void* stream);
+/* The same gate math with the rest of MessageBlock.forward folded in (src_1gp/layer.py:263-266): h_new = GRU gates
+ * (the state handed to the next step), out = act(h_new + identity) with identity NULL for res=False and act in
+ * {0 none, 1 ReLU, 2 LeakyReLU(slope), 3 CELU(alpha=1)}.  Backward: d_out is the gradient of `out`, d_hstate (may be
+ * NULL) the gradient reaching h_new through the next step; it returns d_gi, d_gh, d_h and d_identity (if non-NULL). */
+int glam_gru_tail_fwd(const float* gi, const float* gh, const float* h, const float* identity, int64_t N, int C, int act,
+                      float slope, float* h_new, float* out, void* stream);
+int glam_gru_tail_bwd(const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                      const float* d_hstate, int64_t N, int C, int act, float slope, float* d_gi, float* d_gh, float* d_h,
+                      float* d_identity, void* stream);
 int glam_gru_gates_bwd(const float* gi, const float* gh, const float* h, const float* d_hnew, int64_t N, int C,
                        float* d_gi, float* d_gh, float* d_h, void* stream);
 
