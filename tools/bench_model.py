@@ -22,7 +22,7 @@ net = model.Architecture(mol_block=args.block, message_steps=3, mol_readout="Glo
                          graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
 b = synth_batch(args.batch, seed=0).to(dev)
 y = b.y.view(-1)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=os.environ.get("GLAM_FUSED_ADAM", "1") == "1")
 
 def body():
     opt.zero_grad(set_to_none=True)
