@@ -219,14 +219,22 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     constexpr int kSteps = GLAM_WG_STEPS;   // rows/4 per batch: 2*kSteps float4 loads in flight, then 16*kSteps MFMAs
+    // lanes without a P / Q column of their own read (and discard) column 0 of Q
+    const float* psrc = pbase ? pbase : a.Q;
+    if (!pbase) pld = a.ldq;
+    const float* qsrc = a.Q + (qok ? qcol : 0);
+    const int nlast = max(a.N - 1, 0);
     for (int n0 = row0; n0 < row1; n0 += 4 * kSteps) {
         float4 pv[kSteps], qv[kSteps];
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
+            // unconditional loads from a clamped row (no branch per load), masked afterwards
             const int n = n0 + 4 * st + kq;
             const bool nok = n < row1;
-            pv[st] = nok ? (pbase ? ld4(pbase + (size_t)n * pld) : pconst) : f4zero();
-            qv[st] = nok ? (qok ? ld4(a.Q + (size_t)n * a.ldq + qcol) : qconst) : f4zero();
+            const int nc = min(n, nlast);
+            const float4 pl = ld4(psrc + (size_t)nc * pld), ql = ld4(qsrc + (size_t)nc * a.ldq);
+            pv[st] = nok ? (pbase ? pl : pconst) : f4zero();
+            qv[st] = nok ? (qok ? ql : qconst) : f4zero();
         }
 #pragma unroll
         for (int st = 0; st < kSteps; ++st)
