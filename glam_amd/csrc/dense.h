@@ -22,7 +22,7 @@ struct WgArgs {
     const float* Q; int J; int ldq;        // J % 4 == 0, J <= 64
     int qones;                             // 1: virtual all-ones column at index J (needs J + 1 <= 64)
     int N; int rows_per_wave;              // multiple of 4
-    float* partial;                        // [slab][nsplit][64 regs][64 lanes]
+    float* partial;                        // [slab][nsplit][16 tiles][64 lanes][4]
     int nsplit; int ntile;
 };
 

@@ -244,35 +244,38 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
                 for (int tj = 0; tj < 4; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv[st], ti), f4get(qv[st], tj), acc[ti][tj], 0, 0, 0);
     }
-    // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order; wave w finalises 4 of every 32
-    //      registers.  reg = (ti*4 + tj)*4 + r ----
+    // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order.  Accumulator tile t = ti*4 + tj
+    //      of a lane is one float4 (r = 0..3): 8 tiles per half go to LDS as b128 stores [wave][t][lane], thread
+    //      (t, lane) adds the 8 waves' float4 and stores the block partial as out[(t*64 + lane)*4 + r] ----
     float* out = a.partial + ((size_t)slab * a.nsplit + split) * 4096;
+    float4* s_red4 = reinterpret_cast<float4*>(s_red);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tt = half * 8 + t;
-                s_red[(wave * 32 + t * 4 + r) * 64 + lane] = acc[tt >> 2][tt & 3][r];
-            }
+        for (int t = 0; t < 8; ++t) {
+            const int tt = half * 8 + t;
+            const v4f v = acc[tt >> 2][tt & 3];
+            s_red4[(wave * 8 + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
         __syncthreads();
+        {
+            const int t = tid >> 6;                    // 8 tiles x 64 lanes = 512 threads
+            float4 sum = s_red4[t * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int reg = wave * 4 + q;
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < kWgWaves; ++w) sum += s_red[(w * 32 + reg) * 64 + lane];
-            out[(half * 32 + reg) * 64 + lane] = sum;
+            for (int w = 1; w < kWgWaves; ++w) {
+                const float4 v = s_red4[(w * 8 + t) * 64 + lane];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            st4(out + ((half * 8 + t) * 64 + lane) * 4, sum);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Final fixed-order reduction of up to 3 partial sets in ONE launch.
-//   kind 0 (k_wgrad partials): element offset `o` in [0, nslab*4096) decodes to reg = (o%4096)/64, lane = o%64,
-//          ti = reg/16, tj = (reg/4)%4, r = reg%4, kq = lane/16, c = lane%16  ->  i = 64*slab + 4*(4*kq + r) + ti,
+//   kind 0 (k_wgrad partials): element offset `o` in [0, nslab*4096) decodes to r = o%4, lane = (o/4)%64,
+//          t = (o%4096)/256, ti = t/4, tj = t%4, kq = lane/16, c = lane%16  ->  i = 64*slab + 4*(4*kq + r) + ti,
 //          j = 4*c + tj;  out[i*si + j*sj] = sum_s partial[(slab*nsplit + s)*4096 + o%4096]
 //   kind 1 (flat block partials [nsplit][n]): out[e] (e < split_at) or out2[e - split_at] = sum_s partial[s*n + e]
 __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
@@ -301,8 +304,8 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += s_part[r][c];
         if (J.kind == 0) {
-            const int o = e & 4095, reg = o >> 6, lane = o & 63;
-            const int i = (e >> 12) * 64 + 4 * ((lane >> 4) * 4 + (reg & 3)) + (reg >> 4), j = 4 * (lane & 15) + ((reg >> 2) & 3);
+            const int o = e & 4095, r = o & 3, lane = (o >> 2) & 63, t = o >> 8;
+            const int i = (e >> 12) * 64 + 4 * ((lane >> 4) * 4 + r) + (t >> 2), j = 4 * (lane & 15) + (t & 3);
             if (i < J.I && j < J.J) J.out[(size_t)i * J.si + (size_t)j * J.sj] = s;
         } else if (e < J.split_at) {
             if (J.out) J.out[e] = s;

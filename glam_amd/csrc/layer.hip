@@ -255,7 +255,7 @@ struct ParamGradArgs {
 // element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (inverse of the decode in k_final_reduce)
 __device__ __forceinline__ int wg_slab_offset(int i, int j) {
     const int ii = i & 63, ti = ii & 3, t = ii >> 2, kq = t >> 2, r = t & 3, c = j >> 2, tj = j & 3;
-    return (((ti * 4 + tj) * 4 + r) << 6) + kq * 16 + c;
+    return (((ti * 4 + tj) * 64 + kq * 16 + c) << 2) + r;
 }
 // loads are issued 32 at a time (a launch of this kernel is a handful of dependent round trips, nothing else)
 __device__ __forceinline__ float wg_sum(const float* partial, int nsplit, int i, int j) {
