@@ -37,6 +37,9 @@ def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     assert rc == _lib.GLAM_E_INVALID and b"multiple of 4" in lib.glam_last_error()
     rc = lib.glam_triplet_fwd(None, None, None, None, None, None, None, None, 10, 10, 3, 60, 5, 1, 0.2, None, None, None)
     assert rc == _lib.GLAM_E_UNSUPPORTED
+    # tensors beyond the 32-bit byte offsets of the aggregate kernels are refused, not silently wrapped
+    rc = lib.glam_triplet_fwd(None, None, None, None, None, None, None, None, 6_000_000, 10, 3, 60, 4, 1, 0.2, None, None, None)
+    assert rc == _lib.GLAM_E_UNSUPPORTED and b"4 GiB" in lib.glam_last_error()
     rc = lib.glam_pool5_fwd(None, None, 4, 2, 60, 9, None, None, None)
     assert rc == _lib.GLAM_E_UNSUPPORTED
     rc = lib.glam_csr_build(None, 4, 4, 2, None, None, None, None, None, 0, None)
