@@ -846,9 +846,9 @@ struct Shape { int G, ITER; };
 // smallest G*ITER that covers Q = Cp/4 chunks per head
 inline bool pick_shape(int Q, Shape* s) {
     if (Q <= 4) *s = {4, 1};
-    else if (Q <= 8) *s = {8, 1};
-    else if (Q <= 12) *s = {4, 3};
-    else if (Q <= 16) *s = {16, 1};
+    else if (Q <= 8) *s = {8, 1};        // (16 lanes with 8 idle measured slower at C = 30: 106.7 vs 104.4 us/step)
+    else if (Q <= 16) *s = {16, 1};      // Q = 9..12 (C = 45): 16 lanes with 4 idle + the fused GEMM epilogues beat 4 lanes x 3
+                                         // chunks (119 vs 151 us/step)
     else if (Q <= 24) *s = {8, 3};
     else if (Q <= 32) *s = {16, 2};
     else if (Q <= 64) *s = {16, 4};
