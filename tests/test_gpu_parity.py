@@ -737,3 +737,41 @@ def test_gru_tail_matches_torch(device, act, res):
             assert a is None, name
         else:
             assert_close(a, r, 2e-5, f"grad.{name}")
+
+
+def test_graphed_train_step_follows_the_eager_trajectory(device):
+    """One hipGraph per cached batch (first visit eager, second captured, then replayed): same parameters as eager
+    training after three epochs."""
+    import copy
+    from glam_amd.data import DataLoader, synth_molecule
+    from glam_amd.graphs import GraphedTrainStep
+    rng = np.random.default_rng(11)
+    mols = [synth_molecule(rng) for _ in range(24)]
+    torch.manual_seed(5)
+    net0 = model.Architecture(mol_block="_TripletMessage", message_steps=2, mol_readout="GlobalPool5", e_dim=64, graph_norm="_None",
+                              graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device)
+    loss_fn = lambda out, b: torch.nn.functional.mse_loss(out.view(-1), b.y.view(-1))
+    results = []
+    for graphed in (False, True):
+        net = copy.deepcopy(net0)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+        loader = DataLoader(mols, batch_size=8, device=device)          # cached batches: same objects every epoch
+        stepper = GraphedTrainStep(net, opt, loss_fn)
+        losses = []
+        for _epoch in range(3):
+            for b in loader:
+                if graphed:
+                    losses.append(float(stepper(b)))
+                else:
+                    opt.zero_grad(set_to_none=True)
+                    loss = loss_fn(net(b), b)
+                    loss.backward()
+                    opt.step()
+                    losses.append(float(loss))
+        if graphed:
+            assert stepper.graphs() == 3
+        results.append((losses, [p.detach().clone() for p in net.parameters()]))
+    (l_e, p_e), (l_g, p_g) = results
+    assert np.allclose(l_e, l_g, rtol=1e-5, atol=1e-6), (l_e, l_g)
+    for a, r in zip(p_g, p_e):
+        assert_close(a, r, 1e-5, "parameter")
