@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
 from .layer import _None  # noqa: F401
 from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
 from .layer import LinearBlock, MessageBlock, dot_and_global_pool2
@@ -45,6 +47,10 @@ class Architecture(torch.nn.Module):
         self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
 
     def forward(self, data_mol):
+        with ops.weight_scope():     # weight re-layouts are shared by the message_steps applications of the block
+            return self._forward(data_mol)
+
+    def _forward(self, data_mol):
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)                       # model.py:49
         hm = None
         for _ in range(self.message_steps):                                        # model.py:53-54
@@ -87,6 +93,10 @@ class ArchitectureDTI(torch.nn.Module):
         self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
 
     def forward(self, data_mol, data_pro):
+        with ops.weight_scope():
+            return self._forward(data_mol, data_pro)
+
+    def _forward(self, data_mol, data_pro):
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)
         xp = self.pro_lin0(data_pro.x, batch=data_pro.batch)
         hm, hp = None, None

@@ -10,6 +10,7 @@ and its train loader does not shuffle (``src_1gp/trainer.py:37-38``).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import weakref
 
@@ -83,6 +84,46 @@ class GraphIndex:
 
 
 TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
+
+
+# --------------------------------------------------------------------------------------
+# per-forward reuse of staged weights
+# --------------------------------------------------------------------------------------
+class _WeightScope:
+    """Weight re-layouts (GEMM images, the TripletMessage staging buffer) made during ONE model forward, and the
+    transposed images made by its backward.  A MessageBlock is applied ``message_steps`` times per forward with the same
+    parameters (src_1gp/model.py:53-54), so each re-layout is built once per pass instead of once per application.  The
+    scope only lives for one forward (and is kept alive by the autograd nodes for the matching backward): parameters cannot
+    change inside it, so nothing can go stale."""
+
+    def __init__(self):
+        self.fwd, self.bwd = {}, {}
+
+
+_SCOPE = None
+
+
+@contextlib.contextmanager
+def weight_scope():
+    """``with ops.weight_scope():`` around a model forward (``glam_amd.model.Architecture`` does it)."""
+    global _SCOPE
+    prev, _SCOPE = _SCOPE, _WeightScope()
+    try:
+        yield
+    finally:
+        _SCOPE = prev
+
+
+def _scoped(table, key, owner, build):
+    """``build()`` once per (scope table, key); ``owner`` is pinned next to the value so ``id(owner)`` stays unique."""
+    if table is None:
+        return build()
+    hit = table.get(key)
+    if hit is not None and hit[0] is owner:
+        return hit[1]
+    val = build()
+    table[key] = (owner, val)
+    return val
 
 _GI_CACHE: dict = {}
 
@@ -224,9 +265,15 @@ class _TripletLayer(torch.autograd.Function):
         lib, dev = _lib.load(), x_p.device
         HC = H * Cp
         f = dict(dtype=torch.float32, device=dev)
-        staged = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
-        check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(staged),
-                                            stream()), "glam_triplet_stage_params")
+        def build():
+            buf = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
+            check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(buf),
+                                                stream()), "glam_triplet_stage_params")
+            return buf
+
+        # the same conv is applied message_steps times per model forward: one staging per pass (see _WeightScope)
+        staged = _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet", id(wn), id(we), id(att), id(wsc), id(bias)),
+                         wn, build)
         xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
         aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
         # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
@@ -294,12 +341,19 @@ class _Linear(torch.autograd.Function):
         N, K = x.shape
         M = w.size(0)
         lib, dev = _lib.load(), x.device
-        img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, dtype=torch.float32, device=dev)
-        check(lib.glam_ts_gemm_make_image(ptr(w), K, 1, K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+        scope = _SCOPE
+
+        def build():
+            img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, dtype=torch.float32, device=dev)
+            check(lib.glam_ts_gemm_make_image(ptr(w), K, 1, K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+            return img
+
+        img = _scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
         y = torch.empty(N, M, dtype=torch.float32, device=dev)
         check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.scope = scope
         return y
 
     @staticmethod
@@ -313,8 +367,12 @@ class _Linear(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         dx = None
         if ctx.needs_input_grad[0]:
-            img = torch.empty(lib.glam_ts_gemm_image_bytes(M, K) // 4, **f)
-            check(lib.glam_ts_gemm_make_image(ptr(w), K, 0, M, K, ptr(img), stream()), "glam_ts_gemm_make_image")
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(M, K) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), K, 0, M, K, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+
+            img = _scoped(ctx.scope.bwd if ctx.scope else None, ("lin", id(w)), w, build)
             dx = torch.empty(N, K, **f)
             check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
