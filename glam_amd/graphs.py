@@ -64,3 +64,38 @@ class GraphedTrainStep:
 
     def graphs(self):
         return sum(1 for s in self._state.values() if s[2] is not None)
+
+
+class GraphedForward:
+    """Inference counterpart: ``GraphedForward(model)(batch)`` runs ``model(batch)`` under ``torch.no_grad()`` — eagerly on
+    the first visit of a batch object, from a hipGraph afterwards (the evaluation loaders of the reference iterate the same
+    batches after every epoch: ``src_1gp/trainer.py:39-41``).  The returned tensor is the graph's static output: read or
+    copy it before the next call on the same batch.  Parameters may change between calls (training in between): the
+    captured kernels re-read them; the model must be in ``eval()`` mode (or otherwise free of RNG-dependent layers that
+    differ between the modes you compare)."""
+
+    def __init__(self, model, max_graphs=4096):
+        self.model, self.max_graphs = model, max_graphs
+        self._state = {}
+        self._pool = None
+
+    @torch.no_grad()
+    def __call__(self, *batches):
+        key = tuple(id(b) for b in batches)
+        st = self._state.get(key)
+        if st is None or any(r() is not b for r, b in zip(st[0], batches)):
+            if len(self._state) >= self.max_graphs:
+                return self.model(*batches)
+            refs = [weakref.ref(b, lambda _r, k=key, d=self._state: d.pop(k, None)) for b in batches]
+            self._state[key] = [refs, None, None]
+            return self.model(*batches)
+        if st[1] is None:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, pool=self._pool):
+                st[2] = self.model(*batches)
+            if self._pool is None:
+                self._pool = graph.pool()
+            st[1] = graph
+        st[1].replay()
+        return st[2]

@@ -775,3 +775,22 @@ def test_graphed_train_step_follows_the_eager_trajectory(device):
     assert np.allclose(l_e, l_g, rtol=1e-5, atol=1e-6), (l_e, l_g)
     for a, r in zip(p_g, p_e):
         assert_close(a, r, 1e-5, "parameter")
+
+
+def test_graphed_forward_tracks_parameter_updates(device):
+    from glam_amd.graphs import GraphedForward
+    torch.manual_seed(8)
+    net = model.Architecture(mol_block="_TripletMessageLight", message_steps=2, mol_readout="GlobalLAPool", e_dim=32, graph_norm="_PairNorm",
+                             pre_act="ReLU", graph_act="CELU", flat_act="ReLU").to(device).eval()
+    b = synth_batch(12, seed=3).to(device)
+    gf = GraphedForward(net)
+    with torch.no_grad():
+        ref0 = net(b)
+    assert torch.equal(gf(b), ref0)                    # visit 1: eager
+    assert torch.equal(gf(b).clone(), ref0)            # visit 2: captured + replayed
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.01)                               # "training" between evaluations
+        ref1 = net(b)
+    out1 = gf(b).clone()                               # visit 3: replay re-reads the updated parameters
+    assert torch.equal(out1, ref1) and not torch.equal(out1, ref0)
