@@ -452,6 +452,24 @@ extern "C" int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, 
 
 extern "C" size_t glam_wgrad_workspace_bytes(void) { return wgrad_workspace_floats() * sizeof(float) + 256; }
 
+extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
+                                    float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                                    const float* Qb, int Jb, int ldqb, int qones_b, float* out_b, int si_b, int sj_b, int64_t N,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_pair: N out of range");
+    GLAM_REQUIRE(Pa && Qa && out_a && Pb && Qb && out_b && ws, "glam_wgrad_gemm_pair: null pointer");
+    GLAM_REQUIRE(ws_bytes >= 2 * glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_pair: workspace too small (2 x glam_wgrad_workspace_bytes)");
+    GLAM_REQUIRE(aligned16(Qa) && aligned16(Pa) && aligned16(Qb) && aligned16(Pb), "glam_wgrad_gemm_pair: P / Q must be 16-byte aligned");
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    WgArgs a{Pa, Ia, ldpa, nullptr, 0, 0, ones_a, Qa, Ja, ldqa, qones_a, (int)N, 0, partial, 0, 0};
+    WgArgs b{Pb, Ib, ldpb, nullptr, 0, 0, ones_b, Qb, Jb, ldqb, qones_b, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0};
+    ReduceArgs ra{};
+    ra.njobs = 2;
+    if (int rc = launch_wgrad_partials2(a, out_a, si_a, sj_a, &ra.job[0], b, out_b, si_b, sj_b, &ra.job[1], (hipStream_t)stream))
+        return rc;
+    return launch_final_reduce(ra, (hipStream_t)stream);
+}
+
 extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
                                const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
                                int stride_j, void* ws, size_t ws_bytes, void* stream) {

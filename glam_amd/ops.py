@@ -520,7 +520,89 @@ ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3}
 def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0):
     """``h_new = GRU(x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:262-266): the two gate
     GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
+    if gru_block_supported(h.size(1), w_ih, b_ih, b_hh):
+        return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope)
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
+
+
+class _GruBlock(torch.autograd.Function):
+    """The whole GRU step of a MessageBlock as ONE autograd node: both gate GEMMs + gates/residual/activation forward;
+    gate backward + both input-gradient GEMMs + BOTH weight-gradient products in one launch pair backward.  Besides the
+    launches it saves (one weight-gradient launch and one reduction per step) it replaces three Python autograd nodes by
+    one, which is what an eagerly issued training step is bound by."""
+
+    @staticmethod
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope):
+        require_device(x, h, w_ih, w_hh, b_ih, b_hh)
+        x, h = f32c(x, "x"), f32c(h, "h")
+        w_ih, w_hh, b_ih, b_hh = f32c(w_ih, "weight_ih"), f32c(w_hh, "weight_hh"), f32c(b_ih, "bias_ih"), f32c(b_hh, "bias_hh")
+        identity = None if identity is None else f32c(identity, "identity")
+        N, C = h.shape
+        M = 3 * C
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        scope = _SCOPE
+
+        def image(w):
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(C, M) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), C, 1, C, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+            return _scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
+
+        gi, gh = torch.empty(N, M, **f), torch.empty(N, M, **f)
+        st = stream()
+        check(lib.glam_ts_gemm(ptr(x), C, C, None, 0, 0, ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, 0, N, st), "glam_ts_gemm")
+        check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
+        h_new, out = torch.empty_like(h), torch.empty_like(h)
+        check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
+              "glam_gru_tail_fwd")
+        ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
+        ctx.cfg = (act, float(slope), identity is not None)
+        ctx.scope = scope
+        return out, h_new
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, d_hstate):
+        x, h, gi, gh, out, w_ih, w_hh = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        N, C = h.shape
+        M = 3 * C
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        st = stream()
+        d_out = f32c(d_out, "d_out")
+        d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
+        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        d_id = torch.empty_like(h) if has_res else None
+        check(lib.glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope, ptr(d_gi),
+                                    ptr(d_gh), ptr(d_h), ptr(d_id), st), "glam_gru_tail_bwd")
+        scope = ctx.scope
+
+        def image_t(w):
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(M, C) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), C, 0, M, C, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+            return _scoped(scope.bwd if scope else None, ("lin", id(w)), w, build)
+
+        dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
+        check(lib.glam_ts_gemm(ptr(d_gi), M, M, None, 0, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, None, 0, 0, N, st), "glam_ts_gemm")
+        check(lib.glam_ts_gemm(ptr(d_gh), M, M, None, 0, 0, ptr(image_t(w_hh)), None, ptr(dh), C, C, None, 0, 0, N, st), "glam_ts_gemm")
+        dh.add_(d_h)                                  # + the direct z * g path of the gate equations
+        # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
+        ws = torch.empty(2 * lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        dwb_ih, dwb_hh = torch.empty(M + 1, C + 1, **f), torch.empty(M + 1, C + 1, **f)
+        check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, ptr(dwb_ih), C + 1, 1,
+                                       ptr(d_gh), M, M, 0, ptr(h), C, C, 1, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),
+              "glam_wgrad_gemm_pair")
+        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None
+
+
+def gru_block_supported(C, w_ih, b_ih, b_hh):
+    return C % 4 == 0 and linear_supported(C, 3 * C) and 3 * C > 64 and b_ih is not None and b_hh is not None and \
+        tuple(w_ih.shape) == (3 * C, C)
 
 
 def gru_step(x, h, w_ih, w_hh, b_ih, b_hh):

@@ -160,6 +160,13 @@ int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, f
 int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
                  const float* bias, float* out1, int M1, int ldo1, float* out2, int M2, int ldo2, int64_t N,
                  void* stream);
+/* glam_wgrad_gemm_pair: two independent products (same N) in one launch + one reduction: the d_W / d_b of two linears
+ * that are applied side by side (the input and hidden gate linears of the GRU step, src_1gp/layer.py:262).  Workspace:
+ * 2 x glam_wgrad_workspace_bytes(). */
+int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
+                         float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b, const float* Qb,
+                         int Jb, int ldqb, int qones_b, float* out_b, int si_b, int sj_b, int64_t N, void* ws,
+                         size_t ws_bytes, void* stream);
 size_t glam_wgrad_workspace_bytes(void);
 int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
                     int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, void* ws,
