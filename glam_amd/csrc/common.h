@@ -108,6 +108,11 @@ __device__ __forceinline__ void lds_copy_async(const float* g, float* l, int n4,
                                          (__attribute__((address_space(3))) void*)(l + 4 * b), 16, 0, 0);
 }
 
+// CELU(alpha = 1) and its derivative (torch.celu: max(0,x) + min(0, exp(x) - 1))
+__device__ __forceinline__ float celu1(float x) { return x > 0.f ? x : expf(x) - 1.f; }
+__device__ __forceinline__ float celu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
+__device__ __forceinline__ float4 celu4(float4 v) { return make_float4(celu1(v.x), celu1(v.y), celu1(v.z), celu1(v.w)); }
+
 // ts_gemm weight-image column order: position p = cg*64 + t*16 + c holds logical column cg*64 + 4c + t
 __host__ __device__ inline int ts_col_of_pos(int p) { return (p & ~63) + 4 * (p & 15) + ((p >> 4) & 3); }
 

@@ -13,6 +13,9 @@ struct TsArgs {
     float* out1; int M1; int ldo1;         // columns [0, M1)   (M1 % 4 == 0)
     float* out2; int M2; int ldo2;         // columns [M1, M1+M2), may be null
     int N;
+    // optional CELU(alpha = 1) folding for the GRU gate linears of MessageBlock (src_1gp/layer.py:261-262):
+    int a_celu;                            // 1: the GEMM consumes celu(A) instead of A
+    const float* cgrad_src; int ld_cgrad;  // non-null: out1[r, c] *= celu'(cgrad_src[r, c]) (chain rule through a folded CELU)
 };
 
 struct WgArgs {
@@ -24,6 +27,7 @@ struct WgArgs {
     int N; int rows_per_wave;              // multiple of 4
     float* partial;                        // [slab][nsplit][16 tiles][64 lanes][4]
     int nsplit; int ntile;
+    int q_celu;                            // 1: the product uses celu(Q) (weight gradient of a linear fed through a folded CELU)
 };
 
 // see k_final_reduce in gemm.hip

@@ -85,6 +85,10 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                 else if (k0 < K) af[g] = ld4(a.A2 + (size_t)row * a.lda2 + (k0 - a.K1));
             }
         }
+        if (a.a_celu) {
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) af[g] = celu4(af[g]);      // celu(0) = 0: the zero padding stays zero
+        }
     };
     int item = blockIdx.x * WPB + wave;
     float4 af[GMAX];
@@ -147,7 +151,11 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int rr = tile * 16 + kq * 4 + i;
                     if (rr >= a.N) continue;
-                    const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                    float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                    if (a.cgrad_src && m0 < a.M1) {
+                        const float4 xs = ld4(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0);
+                        v.x *= celu1_grad(xs.x); v.y *= celu1_grad(xs.y); v.z *= celu1_grad(xs.z); v.w *= celu1_grad(xs.w);
+                    }
                     if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
                     else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
                 }
@@ -158,7 +166,11 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int rr = tile * 16 + kq * 4 + i;
                     if (rr >= a.N) continue;
-                    const float2 v = make_float2(acc[0][i] + b.x, acc[1][i] + b.y);
+                    float2 v = make_float2(acc[0][i] + b.x, acc[1][i] + b.y);
+                    if (a.cgrad_src && m0 < a.M1) {
+                        const float2 xs = *reinterpret_cast<const float2*>(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0);
+                        v.x *= celu1_grad(xs.x); v.y *= celu1_grad(xs.y);
+                    }
                     if (m0 < a.M1) *reinterpret_cast<float2*>(a.out1 + (size_t)rr * a.ldo1 + m0) = v;
                     else *reinterpret_cast<float2*>(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1)) = v;
                 }
@@ -234,7 +246,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
             const int nc = min(n, nlast);
             const float4 pl = ld4(psrc + (size_t)nc * pld), ql = ld4(qsrc + (size_t)nc * a.ldq);
             pv[st] = nok ? (pbase ? pl : pconst) : f4zero();
-            qv[st] = nok ? (qok ? ql : qconst) : f4zero();
+            qv[st] = nok ? (qok ? (a.q_celu ? celu4(ql) : ql) : qconst) : f4zero();
         }
 #pragma unroll
         for (int st = 0; st < kSteps; ++st)
@@ -452,17 +464,28 @@ extern "C" int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, 
 
 extern "C" size_t glam_wgrad_workspace_bytes(void) { return wgrad_workspace_floats() * sizeof(float) + 256; }
 
+extern "C" int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, const float* Wimg, const float* bias, float* out, int M,
+                                 int ldo, const float* cgrad_src, int ld_cgrad, int64_t N, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_ts_gemm_celu: N out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(A && Wimg && out, "glam_ts_gemm_celu: null pointer");
+    GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias) && aligned16(cgrad_src) && (ld_cgrad & 3) == 0,
+                 "glam_ts_gemm_celu: pointers must be 16-byte aligned");
+    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N, a_celu, cgrad_src, ld_cgrad};
+    return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
 extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
-                                    float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
-                                    const float* Qb, int Jb, int ldqb, int qones_b, float* out_b, int si_b, int sj_b, int64_t N,
-                                    void* ws, size_t ws_bytes, void* stream) {
+                                    int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                                    const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
+                                    int64_t N, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_pair: N out of range");
     GLAM_REQUIRE(Pa && Qa && out_a && Pb && Qb && out_b && ws, "glam_wgrad_gemm_pair: null pointer");
     GLAM_REQUIRE(ws_bytes >= 2 * glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_pair: workspace too small (2 x glam_wgrad_workspace_bytes)");
     GLAM_REQUIRE(aligned16(Qa) && aligned16(Pa) && aligned16(Qb) && aligned16(Pb), "glam_wgrad_gemm_pair: P / Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-    WgArgs a{Pa, Ia, ldpa, nullptr, 0, 0, ones_a, Qa, Ja, ldqa, qones_a, (int)N, 0, partial, 0, 0};
-    WgArgs b{Pb, Ib, ldpb, nullptr, 0, 0, ones_b, Qb, Jb, ldqb, qones_b, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0};
+    WgArgs a{Pa, Ia, ldpa, nullptr, 0, 0, ones_a, Qa, Ja, ldqa, qones_a, (int)N, 0, partial, 0, 0, qcelu_a};
+    WgArgs b{Pb, Ib, ldpb, nullptr, 0, 0, ones_b, Qb, Jb, ldqb, qones_b, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0, qcelu_b};
     ReduceArgs ra{};
     ra.njobs = 2;
     if (int rc = launch_wgrad_partials2(a, out_a, si_a, sj_a, &ra.job[0], b, out_b, si_b, sj_b, &ra.job[1], (hipStream_t)stream))

@@ -614,13 +614,13 @@ class MessageBlock(torch.nn.Module):
         x = self.dropout(x)
         x = self.conv(x, edge_index, edge_attr)      # layer.py:259
         if self.gru is not None:
-            x = torch.celu(x)                        # layer.py:261
             fa = self._fusable_act()
-            if fa is not None:                       # GRU gates + residual + activation: one launch per direction
+            if fa is not None:                       # CELU (layer.py:261) + GRU step + residual + activation: one autograd node
                 g = self.gru
                 x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,
-                                     g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1])
+                                     g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1], celu_in=True)
                 return x, hn.unsqueeze(0)
+            x = torch.celu(x)                        # layer.py:261
             x = self._gru_step(x, h.squeeze(0))
             h = x.unsqueeze(0)
         x = x if self.res is False else x + identity

@@ -517,11 +517,13 @@ class _GruTail(torch.autograd.Function):
 ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3}
 
 
-def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0):
-    """``h_new = GRU(x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:262-266): the two gate
-    GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
+def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False):
+    """``h_new = GRU(celu(x) if celu_in else x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:261-266):
+    the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
     if gru_block_supported(h.size(1), w_ih, b_ih, b_hh):
-        return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope)
+        return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in)
+    if celu_in:
+        x = torch.celu(x)
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
 
 
@@ -532,7 +534,7 @@ class _GruBlock(torch.autograd.Function):
     one, which is what an eagerly issued training step is bound by."""
 
     @staticmethod
-    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope):
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in):
         require_device(x, h, w_ih, w_hh, b_ih, b_hh)
         x, h = f32c(x, "x"), f32c(h, "h")
         w_ih, w_hh, b_ih, b_hh = f32c(w_ih, "weight_ih"), f32c(w_hh, "weight_hh"), f32c(b_ih, "bias_ih"), f32c(b_hh, "bias_hh")
@@ -552,13 +554,15 @@ class _GruBlock(torch.autograd.Function):
 
         gi, gh = torch.empty(N, M, **f), torch.empty(N, M, **f)
         st = stream()
-        check(lib.glam_ts_gemm(ptr(x), C, C, None, 0, 0, ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, 0, N, st), "glam_ts_gemm")
+        # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
+        check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
+              "glam_ts_gemm_celu")
         check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
         h_new, out = torch.empty_like(h), torch.empty_like(h)
         check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
               "glam_gru_tail_fwd")
         ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
-        ctx.cfg = (act, float(slope), identity is not None)
+        ctx.cfg = (act, float(slope), identity is not None, bool(celu_in))
         ctx.scope = scope
         return out, h_new
 
@@ -566,7 +570,7 @@ class _GruBlock(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out, d_hstate):
         x, h, gi, gh, out, w_ih, w_hh = ctx.saved_tensors
-        act, slope, has_res = ctx.cfg
+        act, slope, has_res, celu_in = ctx.cfg
         N, C = h.shape
         M = 3 * C
         lib, dev = _lib.load(), x.device
@@ -588,16 +592,18 @@ class _GruBlock(torch.autograd.Function):
             return _scoped(scope.bwd if scope else None, ("lin", id(w)), w, build)
 
         dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
-        check(lib.glam_ts_gemm(ptr(d_gi), M, M, None, 0, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, None, 0, 0, N, st), "glam_ts_gemm")
+        # with the folded CELU the epilogue multiplies by celu'(x): dx is the gradient of the RAW input
+        check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
+              "glam_ts_gemm_celu")
         check(lib.glam_ts_gemm(ptr(d_gh), M, M, None, 0, 0, ptr(image_t(w_hh)), None, ptr(dh), C, C, None, 0, 0, N, st), "glam_ts_gemm")
         dh.add_(d_h)                                  # + the direct z * g path of the gate equations
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(2 * lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         dwb_ih, dwb_hh = torch.empty(M + 1, C + 1, **f), torch.empty(M + 1, C + 1, **f)
-        check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, ptr(dwb_ih), C + 1, 1,
-                                       ptr(d_gh), M, M, 0, ptr(h), C, C, 1, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),
+        check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
+                                       ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),
               "glam_wgrad_gemm_pair")
-        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None
+        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None, None
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):

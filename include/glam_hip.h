@@ -164,9 +164,14 @@ int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int
  * that are applied side by side (the input and hidden gate linears of the GRU step, src_1gp/layer.py:262).  Workspace:
  * 2 x glam_wgrad_workspace_bytes(). */
 int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
-                         float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b, const float* Qb,
-                         int Jb, int ldqb, int qones_b, float* out_b, int si_b, int sj_b, int64_t N, void* ws,
-                         size_t ws_bytes, void* stream);
+                         int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                         const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
+                         int64_t N, void* ws, size_t ws_bytes, void* stream);
+/* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:
+ * a_celu = 1: out = celu(A) @ W + bias; cgrad_src non-NULL: out[r,c] *= celu'(cgrad_src[r,c]) (the chain rule of the same
+ * fold on the way back); qcelu_* in glam_wgrad_gemm_pair: the weight gradient uses celu(Q). */
+int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, const float* Wimg, const float* bias, float* out, int M,
+                      int ldo, const float* cgrad_src, int ld_cgrad, int64_t N, void* stream);
 size_t glam_wgrad_workspace_bytes(void);
 int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
                     int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, void* ws,

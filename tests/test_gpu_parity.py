@@ -710,13 +710,15 @@ def test_layer_bwd_both_abi_routes_agree(device, C, H, De):
         assert_close(a, r, 2e-5, name)
 
 
+@pytest.mark.parametrize("celu_in", [False, True])
 @pytest.mark.parametrize("act,res", [("ReLU", True), ("LeakyReLU", True), ("CELU", False), ("_None", True)])
-def test_gru_tail_matches_torch(device, act, res):
+def test_gru_tail_matches_torch(device, act, res, celu_in):
     """GRU gates + residual + activation in one launch (layer.py:262-266) vs torch.nn.GRU + torch elementwise."""
     torch.manual_seed(3)
     N, C = 333, 60
     gru = torch.nn.GRU(C, C).to(device)
-    x = torch.randn(N, C, device=device, requires_grad=True)
+    xr = torch.randn(N, C, device=device, requires_grad=True)          # raw conv output
+    x = torch.celu(xr) if celu_in else xr.clone().detach().requires_grad_(True)
     h = torch.randn(N, C, device=device, requires_grad=True)
     ident = torch.randn(N, C, device=device, requires_grad=True)
     cot_o, cot_h = torch.randn(N, C, device=device), torch.randn(N, C, device=device)
@@ -724,11 +726,11 @@ def test_gru_tail_matches_torch(device, act, res):
     y_ref, _ = gru(x.unsqueeze(0), h.unsqueeze(0))
     hn_ref = y_ref.squeeze(0)
     out_ref = fn(hn_ref + ident if res else hn_ref)
-    tensors = [x, h, ident] + list(gru.parameters())
+    tensors = [xr if celu_in else x, h, ident] + list(gru.parameters())
     g_ref = torch.autograd.grad([out_ref, hn_ref], tensors, grad_outputs=[cot_o, cot_h], allow_unused=True)
     code = {"ReLU": "relu", "LeakyReLU": "leaky", "CELU": "celu", "_None": "none"}[act]
-    out, hn = ops.gru_tail(x, h, ident if res else None, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
-                           act=code, slope=0.01)
+    out, hn = ops.gru_tail(xr if celu_in else x, h, ident if res else None, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0,
+                           gru.bias_hh_l0, act=code, slope=0.01, celu_in=celu_in)
     g = torch.autograd.grad([out, hn], tensors, grad_outputs=[cot_o, cot_h], allow_unused=True)
     assert_close(out, out_ref, 2e-6, "out")
     assert_close(hn, hn_ref, 2e-6, "h_new")
