@@ -376,9 +376,9 @@ size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocks + 24) * 4096; }
 static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {
     const int I = a.I1 + a.I2 + (a.ones ? 1 : 0);
     const int Jt = a.J + (a.qones ? 1 : 0);
-    if (I > 192 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3) || (a.I1 & 3) || (a.I2 & 3) || (a.ldp1 & 3) ||
+    if (I > 320 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3) || (a.I1 & 3) || (a.I2 & 3) || (a.ldp1 & 3) ||
         (a.I2 && (a.ldp2 & 3)))
-        return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d+%d J=%d outside the kernel table (I <= 192, J <= 64, multiples of 4)",
+        return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d+%d J=%d outside the kernel table (I <= 320, J <= 64, multiples of 4)",
                     a.I1, a.I2, a.J);
     const int nslab = (I + 63) / 64;
     int nsplit = budget / nslab / 8 * 8;         // multiple of 8: one XCD per row split

@@ -227,13 +227,13 @@ class NNConv(MessagePassing):
             S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"))           # [N, Dp, in]
             if self.aggr not in ("mean", "add", "sum"):
                 raise GlamHipError("NNConv: only aggr in {'mean', 'add'} is supported")
-            out = torch.matmul(S[:, :De].reshape(x.size(0), De * self.in_channels), w_rel)
+            out = ops.matmul_tall(S[:, :De].reshape(x.size(0), De * self.in_channels), w_rel)
         else:
             weight = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
             msg = torch.bmm(x.index_select(0, edge_index[0]).unsqueeze(1), weight).squeeze(1)
             out = ops.edge_reduce(msg, gi, self.aggr)
         if self.root is not None:
-            out = out + torch.matmul(x, self.root)
+            out = out + ops.matmul_tall(x, self.root)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -283,7 +283,7 @@ class GCNConv(MessagePassing):
         dis = deg.pow(-0.5)
         dis = dis.masked_fill(dis == float("inf"), 0)
         norm = dis[ei[0]] * w * dis[ei[1]]
-        xw = torch.matmul(x, self.weight)
+        xw = ops.matmul_tall(x, self.weight)
         out = ops.edge_reduce(norm.view(-1, 1) * xw.index_select(0, ei[0]), gi, "sum")
         return out if self.bias is None else out + self.bias
 

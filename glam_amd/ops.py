@@ -388,6 +388,44 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _MatmulTall(torch.autograd.Function):
+    """``A[N,K] @ W[K,M]`` for tall A and a small weight whose shape is outside the MFMA forward table: the two
+    data-side products stay on the library GEMM, but the WEIGHT gradient ``A^T @ dY`` — a reduction over the N rows for
+    which the library's heuristics pick 32x32 tiles (77 us at N = 20 k, K = 240, M = 60) — runs on ``k_wgrad`` (≈12 us)."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        require_device(a, w)
+        a, w = f32c(a, "a"), f32c(w, "w")
+        ctx.save_for_backward(a, w)
+        return torch.matmul(a, w)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = a.shape
+        M = w.size(1)
+        da = torch.matmul(dy, w.t()) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            lib = _lib.load()
+            ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
+            dw = torch.empty(K, M, dtype=torch.float32, device=a.device)
+            check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 0, ptr(dy), M, M, 0, N, ptr(dw), M, 1, ptr(ws), ws.numel(), stream()),
+                  "glam_wgrad_gemm")
+        return da, dw
+
+
+def matmul_tall(a, w):
+    """``a @ w`` with the weight gradient on the MFMA reduction kernel when it fits (K <= 320, M <= 64, multiples of 4)."""
+    K, M = w.shape
+    if a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and K <= 320 and M <= 64 and a.size(0) >= 64:
+        return _MatmulTall.apply(a, w)
+    return torch.matmul(a, w)
+
+
 def linear(x, weight, bias=None):
     """``F.linear`` on the hand-written MFMA kernels when the shape is in their table (the layer-sized linears of the
     path: GRU gates 60->180, input embedding 15->60, ...); larger / odd layers (e.g. the 300->1024 readout MLP) stay
