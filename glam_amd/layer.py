@@ -313,7 +313,7 @@ class GATConv(MessagePassing):
         Cp = _ceil4(C)
         gi0 = ops.graph_index(edge_index, n)
         ei, gi, _ = _with_self_loops(gi0, edge_index, n, False)
-        xl = self.lin_l(x)
+        xl = ops.linear(x, self.lin_l.weight, self.lin_l.bias)    # MFMA GEMM + k_wgrad (library fallback outside their table)
         a_r = (xl * self.att_r.view(1, C)).sum(-1, keepdim=True)   # target side ("alpha_i")
         a_l = (xl * self.att_l.view(1, C)).sum(-1, keepdim=True)   # source side ("alpha_j")
         a_ij = torch.cat([F.pad(a_r, (0, 3)), F.pad(a_l, (0, 3))], dim=1)
@@ -499,8 +499,11 @@ class GlobalAttention(torch.nn.Module):
     def forward(self, x, batch, size=None):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         sp = ops.segment_ptr(batch, size)
-        gate = self.gate_nn(x).view(-1)
-        v = self.nn(x) if self.nn is not None else x
+        # plain Linear modules (the reference's GlobalLAPool): route them through ops.linear so the N-deep weight gradients
+        # run on k_wgrad; anything else (Sequential gates) is called as is
+        lin = lambda m, t: ops.linear(t, m.weight, m.bias) if type(m) is Linear else m(t)
+        gate = lin(self.gate_nn, x).view(-1)
+        v = lin(self.nn, x) if self.nn is not None else x
         return ops.segment_attention(gate, v, sp)
 
 
