@@ -115,7 +115,8 @@ class TripletMessage(MessagePassing):
                                     self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
             return out[:, :C] if Cp != C else out
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
-        Wn, Wa, We, M, Ws, Cp, Dp = self._staged_weights()
+        Wn, Wa, We, M, Ws, Cp, Dp = ops.scoped_weights(("triplet-derived", id(self.weight_node)), self.weight_node,
+                                                       self._staged_weights)
         xw = torch.matmul(x, Wn)                                          # layer.py:37
         a_ij = torch.matmul(x, Wa)
         aggr = ops.triplet_aggregate(xw, a_ij, edge_attr, We, M, gi, self.heads, Cp, self.negative_slope)
@@ -153,18 +154,23 @@ class TripletMessageLight(MessagePassing):
         Cp, Dp = _ceil4(C), _pad_de(De)
         edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         gi = ops.graph_index(edge_index, x.size(0))
-        att = self.weight_triplet_att[0]
-        att_ij = torch.stack([att[:C], att[C + De:]], dim=-1)                       # [C, 2]
-        Wa = torch.matmul(self.weight_node, att_ij)                                 # [Cin, 2]
-        Wa = F.pad(Wa.unsqueeze(-1), (0, 3)).reshape(C, 8)
-        M = F.pad(att[C:C + De].unsqueeze(-1), (0, 3, 0, Dp - De)).contiguous()     # [Dp, 4]
-        Wn = F.pad(self.weight_node, (0, Cp - C)) if Cp != C else self.weight_node
-        if ops.linear_split_supported(Cp, Cp + 8):
-            # node GEMM + separable attention columns in one MFMA launch: [xw | a_i a_j] = x @ [W_node | Wa]
-            x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
+
+        def derived():      # parameter-only staging, shared by the message_steps applications of the block (ops.weight_scope)
+            att = self.weight_triplet_att[0]
+            att_ij = torch.stack([att[:C], att[C + De:]], dim=-1)                       # [C, 2]
+            Wa = torch.matmul(self.weight_node, att_ij)                                 # [Cin, 2]
+            Wa = F.pad(Wa.unsqueeze(-1), (0, 3)).reshape(C, 8)
+            M = F.pad(att[C:C + De].unsqueeze(-1), (0, 3, 0, Dp - De)).contiguous()     # [Dp, 4]
+            Wn = F.pad(self.weight_node, (0, Cp - C)) if Cp != C else self.weight_node
             wt = torch.cat([Wn, Wa], dim=1)
             if Cp != C:
                 wt = F.pad(wt, (0, 0, 0, Cp - C))
+            return Wn, Wa, M, wt
+
+        Wn, Wa, M, wt = ops.scoped_weights(("light-derived", id(self.weight_node)), self.weight_node, derived)
+        if ops.linear_split_supported(Cp, Cp + 8):
+            # node GEMM + separable attention columns in one MFMA launch: [xw | a_i a_j] = x @ [W_node | Wa]
+            x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
             xw, a_ij = ops.linear_split(x_p, wt, Cp)                                # layer.py:84
         else:
             xw = torch.matmul(x, Wn)

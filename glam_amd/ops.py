@@ -114,6 +114,12 @@ def weight_scope():
         _SCOPE = prev
 
 
+def scoped_weights(key, owner, build):
+    """Derived weights (pure functions of parameters: pads, stacks, small matmuls) built once per model forward when a
+    ``weight_scope`` is active; their autograd subgraph is then also shared by the applications of the block."""
+    return _scoped(_SCOPE.fwd if _SCOPE else None, key, owner, build)
+
+
 def _scoped(table, key, owner, build):
     """``build()`` once per (scope table, key); ``owner`` is pinned next to the value so ``id(owner)`` stays unique."""
     if table is None:
