@@ -227,8 +227,11 @@ class NNConv(MessagePassing):
             # De-relation R-GCN: per-relation neighbour sums (one HIP kernel) followed by ONE [N, De*C] x [De*C, C] GEMM,
             # instead of the reference's [E, C*C] per-edge weight tensor (612 MB at B=1024).
             Dp = _pad_de(De)
-            w_rel = self.nn(torch.eye(De, dtype=x.dtype, device=x.device))              # [De, in*out]
-            w_rel = w_rel.view(De * self.in_channels, self.out_channels)
+            def relation_weights():     # parameter-only: shared by the message_steps applications (ops.weight_scope)
+                w = self.nn(torch.eye(De, dtype=x.dtype, device=x.device))              # [De, in*out]
+                return w.view(De * self.in_channels, self.out_channels)
+
+            w_rel = ops.scoped_weights(("nnconv-rel", id(self), De), self, relation_weights)
             ea = F.pad(edge_attr, (0, Dp - De)) if Dp != De else edge_attr
             S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"))           # [N, Dp, in]
             if self.aggr not in ("mean", "add", "sum"):

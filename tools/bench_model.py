@@ -13,12 +13,13 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--norm", default="_None")
 ap.add_argument("--block", default="_TripletMessage")
+ap.add_argument("--readout", default="GlobalPool5")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
-net = model.Architecture(mol_block=args.block, message_steps=3, mol_readout="GlobalPool5", graph_norm=args.norm,
+net = model.Architecture(mol_block=args.block, message_steps=3, mol_readout=args.readout, graph_norm=args.norm,
                          graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
 b = synth_batch(args.batch, seed=0).to(dev)
 y = b.y.view(-1)
@@ -43,6 +44,6 @@ for _ in range(10): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"workload": f"Architecture({args.block}, 3 steps, GlobalPool5, e_dim=1024, norm={args.norm}) fwd+bwd+Adam, B={args.batch}",
+print(json.dumps({"workload": f"Architecture({args.block}, 3 steps, {args.readout}, e_dim=1024, norm={args.norm}) fwd+bwd+Adam, B={args.batch}",
                   "launch": "eager" if g is None else "hipGraph", "ms_per_step": dt / args.steps * 1e3,
                   "molecules_per_s": args.batch * args.steps / dt}))
