@@ -113,6 +113,48 @@ __device__ __forceinline__ float celu1(float x) { return x > 0.f ? x : expf(x) -
 __device__ __forceinline__ float celu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
 __device__ __forceinline__ float4 celu4(float4 v) { return make_float4(celu1(v.x), celu1(v.y), celu1(v.z), celu1(v.w)); }
 
+// Column sums of rows [r0, r1) of base[., D] into dst[0..D): 16 row groups x 16 float4 column chunks (D % 4 == 0,
+// D <= 64) with every load of a thread independent of the others, then a fixed-order sum of the 16 partials; scalar
+// fallback otherwise.  (A residue segment has hundreds of rows: the obvious one-thread-per-column loop is a serial chain
+// of that many dependent round trips and was 0.7 ms of the two-tower step.)  Ends with a barrier.
+__device__ __forceinline__ void block_colsum(const float* base, int r0, int r1, int D, float* s_part, float* dst) {
+    const int tid = threadIdx.x;
+    if ((D & 3) == 0 && D <= 64) {
+        const int c4 = tid & 15, rg = tid >> 4;
+        float4 acc = f4zero();
+        if (4 * c4 < D) {
+            int r = r0 + rg;
+            for (; r + 48 < r1; r += 64) {
+                const float4 v0 = ld4(base + (size_t)r * D + 4 * c4), v1 = ld4(base + (size_t)(r + 16) * D + 4 * c4),
+                             v2 = ld4(base + (size_t)(r + 32) * D + 4 * c4), v3 = ld4(base + (size_t)(r + 48) * D + 4 * c4);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; r < r1; r += 16) {
+                const float4 v = ld4(base + (size_t)r * D + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        st4(s_part + (rg * 16 + c4) * 4, acc);
+        __syncthreads();
+        if (tid < D) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum += s_part[(g * 16 + (tid >> 2)) * 4 + (tid & 3)];
+            dst[tid] = sum;
+        }
+    } else {
+        for (int c = tid; c < D; c += kBlock) {
+            float sum = 0.f;
+            for (int r = r0; r < r1; ++r) sum += base[(size_t)r * D + c];
+            dst[c] = sum;
+        }
+    }
+    __syncthreads();
+}
+
 // ts_gemm weight-image column order: position p = cg*64 + t*16 + c holds logical column cg*64 + 4c + t
 __host__ __device__ inline int ts_col_of_pos(int p) { return (p & ~63) + 4 * (p & 15) + ((p >> 4) & 3); }
 

@@ -12,24 +12,20 @@ constexpr int kMaxD = 256;
 
 __global__ void __launch_bounds__(kBlock) k_pair_pool_fwd(const float* mol, const float* pro, const int* mptr,
                                                          const int* pptr, int D, float* out, int* arg) {
-    __shared__ float s_mol[kMolTile * kMaxD];
+    __shared__ __attribute__((aligned(16))) float s_mol[kMolTile * kMaxD];
     __shared__ float s_val[kBlock];
     __shared__ int s_idx[kBlock];
     __shared__ float s_sum[2 * kMaxD];
+    __shared__ __attribute__((aligned(16))) float s_part[16 * 16 * 4];
     const int i = blockIdx.x, tid = threadIdx.x;
     const int m0 = mptr[i], m1 = mptr[i + 1], p0 = pptr[i], p1 = pptr[i + 1];
     const int nm = m1 - m0, np = p1 - p0;
     // column sums of both segments (mean)
-    for (int c = tid; c < 2 * D; c += kBlock) {
-        const bool is_pro = c >= D;
-        const float* base = is_pro ? pro : mol;
-        const int cc = is_pro ? c - D : c, r0 = is_pro ? p0 : m0, r1 = is_pro ? p1 : m1;
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += base[(size_t)r * D + cc];
-        s_sum[c] = s;
-    }
+    block_colsum(mol, m0, m1, D, s_part, s_sum);
+    block_colsum(pro, p0, p1, D, s_part, s_sum + D);
     float best = -INFINITY;
     int bidx = 0x7fffffff;          // flattened (a * np + b): first occurrence wins ties, like a flattened argmax
+    const bool vec = (D & 3) == 0 && D <= 64;
     for (int t0 = 0; t0 < nm; t0 += kMolTile) {
         const int tn = min(kMolTile, nm - t0);
         __syncthreads();
@@ -37,11 +33,31 @@ __global__ void __launch_bounds__(kBlock) k_pair_pool_fwd(const float* mol, cons
         __syncthreads();
         for (int b = tid; b < np; b += kBlock) {
             const float* prow = pro + (size_t)(p0 + b) * D;
-            for (int a = 0; a < tn; ++a) {
-                float d = 0.f;
-                for (int c = 0; c < D; ++c) d = fmaf(s_mol[a * D + c], prow[c], d);
-                const int idx = (t0 + a) * np + b;
-                if (d > best || (d == best && idx < bidx)) { best = d; bidx = idx; }
+            if (vec) {
+                // the residue row lives in registers (one set of loads per residue instead of one per ligand row); the ligand
+                // rows are LDS broadcasts.  Same c order as the scalar path: identical dot products and argmax.
+                float4 pr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pr[u] = 4 * u < D ? ld4(prow + 4 * u) : f4zero();
+                for (int a = 0; a < tn; ++a) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        if (4 * u < D) {
+                            const float4 mv = ld4(s_mol + a * D + 4 * u);
+                            d = fmaf(mv.x, pr[u].x, d); d = fmaf(mv.y, pr[u].y, d); d = fmaf(mv.z, pr[u].z, d); d = fmaf(mv.w, pr[u].w, d);
+                        }
+                    }
+                    const int idx = (t0 + a) * np + b;
+                    if (d > best || (d == best && idx < bidx)) { best = d; bidx = idx; }
+                }
+            } else {
+                for (int a = 0; a < tn; ++a) {
+                    float d = 0.f;
+                    for (int c = 0; c < D; ++c) d = fmaf(s_mol[a * D + c], prow[c], d);
+                    const int idx = (t0 + a) * np + b;
+                    if (d > best || (d == best && idx < bidx)) { best = d; bidx = idx; }
+                }
             }
         }
     }
@@ -72,6 +88,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_pool_bwd(const float* mol, cons
                                                          const int* pptr, const int* arg, const float* d_out, int D,
                                                          float* d_mol, float* d_pro) {
     __shared__ float s_sum[2 * kMaxD];
+    __shared__ __attribute__((aligned(16))) float s_part[16 * 16 * 4];
     const int i = blockIdx.x, tid = threadIdx.x;
     const int m0 = mptr[i], m1 = mptr[i + 1], p0 = pptr[i], p1 = pptr[i + 1];
     const int nm = m1 - m0, np = p1 - p0;
@@ -80,15 +97,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_pool_bwd(const float* mol, cons
         for (int k = tid; k < max(np, 0) * D; k += kBlock) d_pro[(size_t)p0 * D + k] = 0.f;
         return;
     }
-    for (int c = tid; c < 2 * D; c += kBlock) {
-        const bool is_pro = c >= D;
-        const float* base = is_pro ? pro : mol;
-        const int cc = is_pro ? c - D : c, r0 = is_pro ? p0 : m0, r1 = is_pro ? p1 : m1;
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += base[(size_t)r * D + cc];
-        s_sum[c] = s;
-    }
-    __syncthreads();
+    block_colsum(mol, m0, m1, D, s_part, s_sum);
+    block_colsum(pro, p0, p1, D, s_part, s_sum + D);
     const float gmax = d_out[2 * i], gmean = d_out[2 * i + 1] / ((float)nm * (float)np);
     const int am = arg[2 * i], ap = arg[2 * i + 1];
     for (int k = tid; k < nm * D; k += kBlock) {

@@ -796,3 +796,39 @@ def test_graphed_forward_tracks_parameter_updates(device):
         ref1 = net(b)
     out1 = gf(b).clone()                               # visit 3: replay re-reads the updated parameters
     assert torch.equal(out1, ref1) and not torch.equal(out1, ref0)
+
+
+@pytest.mark.parametrize("sizes", [[150, 90, 301, 64], [70, 500], [3, 260, 1, 2, 300]])
+def test_pool5_large_graphs_block_kernel(device, sizes):
+    """Protein-sized graphs take the block-per-graph GlobalPool5 kernels (N / B >= 64); ties on the sort channel included."""
+    torch.manual_seed(sum(sizes))
+    N, B, D = sum(sizes), len(sizes), 60
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    x0 = torch.randn(N, D)
+    x0[5:9, D - 1] = 7.0                                  # ties among the top entries of graph 0: lower node index first
+    x0[-1, D - 1] = x0[-2, D - 1]
+    xo = x0.clone().requires_grad_(True)
+    ref = O.global_pool5(xo, batch, B)
+    cot = torch.randn(ref.shape)
+    (g_ref,) = _grads(ref, cot, [xo])
+    x = x0.to(device).requires_grad_(True)
+    out = layer.GlobalPool5()(x, batch.to(device), B)
+    assert_close(out, ref, 2e-5, "pool5")
+    assert_close(_grads(out, cot.to(device), [x])[0], g_ref, 2e-5, "pool5/gx")
+
+
+def test_pair_pool_protein_sized_segments(device):
+    torch.manual_seed(4)
+    nm, npr, D = [20, 13, 28], [410, 97, 655], 60
+    mol, pro = torch.randn(sum(nm), D), torch.randn(sum(npr), D)
+    mb = torch.repeat_interleave(torch.arange(3), torch.tensor(nm))
+    pb = torch.repeat_interleave(torch.arange(3), torch.tensor(npr))
+    mo, po = mol.clone().requires_grad_(True), pro.clone().requires_grad_(True)
+    ref = O.dot_and_global_pool(mo, po, mb, pb, 3, stats=2)
+    cot = torch.randn(ref.shape)
+    g_ref = _grads(ref, cot, [mo, po])
+    m, p = mol.to(device).requires_grad_(True), pro.to(device).requires_grad_(True)
+    out = layer.dot_and_global_pool2(m, p, mb.to(device), pb.to(device))
+    assert_close(out, ref, 2e-5, "pair pool")
+    for a, r, n in zip(_grads(out, cot.to(device), [m, p]), g_ref, ["mol", "pro"]):
+        assert_close(a, r, 2e-5, "pair pool grad " + n)
