@@ -140,25 +140,32 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd_block(const float* x, cons
     }
 }
 
+// grid = (graph, row chunk): a protein's 500 x 60 gradient block is spread over kPool5BwdChunks blocks, rows by 16-row
+// groups and channels by float4 (D % 4 == 0, D <= 64), no per-element division
+constexpr int kPool5BwdChunks = 8;
 __global__ void __launch_bounds__(kBlock) k_pool5_bwd_block(const float* d_out, const int* ptr, const int* topk_idx, int B,
                                                            int D, int K, float* d_x) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
     const int OD = (2 + K) * D;
-    for (int g = blockIdx.x; g < B; g += gridDim.x) {
-        const int beg = ptr[g], end = ptr[g + 1];
-        const float inv_cnt = 1.f / (float)max(end - beg, 1);
-        int ti[kMaxK];
+    const int g = blockIdx.x / kPool5BwdChunks, chunk = blockIdx.x % kPool5BwdChunks;
+    if (g >= B || 4 * c4 >= D) return;
+    const int beg = ptr[g], end = ptr[g + 1];
+    const float inv_cnt = 1.f / (float)max(end - beg, 1);
+    int ti[kMaxK];
 #pragma unroll
-        for (int r = 0; r < kMaxK; ++r) ti[r] = r < K ? topk_idx[(size_t)g * K + r] : -1;
-        const float* go = d_out + (size_t)g * OD;
-        for (int e = tid; e < (end - beg) * D; e += kBlock) {
-            const int n = beg + e / D, c = e % D;
-            float v = go[c] * inv_cnt + go[D + c];
+    for (int r = 0; r < kMaxK; ++r) ti[r] = r < K ? topk_idx[(size_t)g * K + r] : -1;
+    const float* go = d_out + (size_t)g * OD;
+    const float4 gm = ld4(go + 4 * c4), ga = ld4(go + D + 4 * c4);
+    const float4 base = make_float4(gm.x * inv_cnt + ga.x, gm.y * inv_cnt + ga.y, gm.z * inv_cnt + ga.z, gm.w * inv_cnt + ga.w);
+    for (int n = beg + chunk * 16 + rl; n < end; n += kPool5BwdChunks * 16) {
+        float4 v = base;
 #pragma unroll
-            for (int r = 0; r < kMaxK; ++r)
-                if (r < K && ti[r] == n) v += go[(2 + r) * D + c];
-            d_x[(size_t)n * D + c] = v;
-        }
+        for (int r = 0; r < kMaxK; ++r)
+            if (r < K && ti[r] == n) {
+                const float4 t = ld4(go + (2 + r) * D + 4 * c4);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+        st4(d_x + (size_t)n * D + 4 * c4, v);
     }
 }
 
@@ -406,8 +413,8 @@ extern "C" int glam_pool5_bwd(const float* d_out, const int32_t* ptr, const int3
     if (k < 1 || k > kMaxK) return fail(GLAM_E_UNSUPPORTED, "glam_pool5_bwd: k=%d not in 1..%d", k, kMaxK);
     if (B == 0 || N == 0) return GLAM_OK;
     GLAM_REQUIRE(ptr && d_out && topk_idx && d_x, "glam_pool5_bwd: null pointer");
-    if (N / B >= 64)
-        hipLaunchKernelGGL(k_pool5_bwd_block, dim3(grid_for(B, 1)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
+    if (N / B >= 64 && (D & 3) == 0 && D <= 64 && B * (int64_t)kPool5BwdChunks < 65536)
+        hipLaunchKernelGGL(k_pool5_bwd_block, dim3((int)B * kPool5BwdChunks), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
     else
         hipLaunchKernelGGL(k_pool5_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
     GLAM_LAUNCH_CHECK("glam_pool5_bwd");
