@@ -134,6 +134,111 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd(const float* x, const
     }
 }
 
+
+// ---- block-per-graph variants for graphs of hundreds of nodes (proteins): the kernels above walk a graph's nodes serially
+//      per lane; here 256 threads = 16 row groups x 16 float4 channel chunks (D % 4 == 0, D <= 64) ----
+__device__ __forceinline__ float block_sum256(float v, float* s_red) {      // fixed-order tree; returns the total to every thread
+    const int tid = threadIdx.x;
+    s_red[tid] = v;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    const float r = s_red[0];
+    __syncthreads();
+    return r;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_graph_norm_fwd_block(const float* x, const int* ptr, int B, int D, float scale,
+                                                                float eps, float* y) {
+    __shared__ __attribute__((aligned(16))) float s_part[16 * 16 * 4];
+    __shared__ __attribute__((aligned(16))) float s_mean[64];
+    __shared__ float s_red[kBlock];
+    const int tid = threadIdx.x, c4 = tid & 15, rg = tid >> 4;
+    const bool act = 4 * c4 < D;
+    for (int g = blockIdx.x; g < B; g += gridDim.x) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        if (end <= beg) continue;
+        const float inv_cnt = 1.f / (float)(end - beg);
+        block_colsum(x, beg, end, D, s_part, s_mean);
+        float4 mean = f4zero();
+        if (MODE == 1) {
+            float t = 0.f;
+            for (int c = 0; c < D; ++c) t += s_mean[c];
+            t = t * inv_cnt / (float)D;
+            mean = make_float4(t, t, t, t);
+        } else if (act) {
+            mean = inv_cnt * ld4(s_mean + 4 * c4);
+        }
+        float sq = 0.f;
+        if (act)
+            for (int n = beg + rg; n < end; n += 16) {
+                const float4 v = ld4(x + (size_t)n * D + 4 * c4);
+                const float dx0 = v.x - mean.x, dx1 = v.y - mean.y, dx2 = v.z - mean.z, dx3 = v.w - mean.w;
+                sq = fmaf(dx0, dx0, sq); sq = fmaf(dx1, dx1, sq); sq = fmaf(dx2, dx2, sq); sq = fmaf(dx3, dx3, sq);
+            }
+        sq = block_sum256(sq, s_red) * inv_cnt;
+        const float a = MODE == 0 ? scale / sqrtf(eps + sq) : 1.f / sqrtf(sq / (float)D + eps);
+        if (act)
+            for (int n = beg + rg; n < end; n += 16) {
+                const float4 v = ld4(x + (size_t)n * D + 4 * c4);
+                st4(y + (size_t)n * D + 4 * c4, make_float4((v.x - mean.x) * a, (v.y - mean.y) * a, (v.z - mean.z) * a, (v.w - mean.w) * a));
+            }
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_block(const float* x, const float* gy, const int* ptr, int B, int D,
+                                                                float scale, float eps, float* dx) {
+    __shared__ __attribute__((aligned(16))) float s_part[16 * 16 * 4];
+    __shared__ __attribute__((aligned(16))) float s_mean[64];
+    __shared__ __attribute__((aligned(16))) float s_gbar[64];
+    __shared__ float s_red[kBlock];
+    const int tid = threadIdx.x, c4 = tid & 15, rg = tid >> 4;
+    const bool act = 4 * c4 < D;
+    for (int g = blockIdx.x; g < B; g += gridDim.x) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        if (end <= beg) continue;
+        const float inv_cnt = 1.f / (float)(end - beg);
+        block_colsum(x, beg, end, D, s_part, s_mean);
+        block_colsum(gy, beg, end, D, s_part, s_gbar);
+        float4 mean = f4zero(), gbar = f4zero();
+        if (MODE == 1) {
+            float sm = 0.f, tg = 0.f;
+            for (int c = 0; c < D; ++c) { sm += s_mean[c]; tg += s_gbar[c]; }
+            sm = sm * inv_cnt / (float)D; tg = tg * inv_cnt / (float)D;
+            mean = make_float4(sm, sm, sm, sm); gbar = make_float4(tg, tg, tg, tg);
+        } else if (act) {
+            mean = inv_cnt * ld4(s_mean + 4 * c4);
+            gbar = inv_cnt * ld4(s_gbar + 4 * c4);
+        }
+        float sq = 0.f, T = 0.f;
+        if (act)
+            for (int n = beg + rg; n < end; n += 16) {
+                const float4 v = ld4(x + (size_t)n * D + 4 * c4), gv = ld4(gy + (size_t)n * D + 4 * c4);
+                const float d0 = v.x - mean.x, d1 = v.y - mean.y, d2 = v.z - mean.z, d3 = v.w - mean.w;
+                sq = fmaf(d0, d0, sq); sq = fmaf(d1, d1, sq); sq = fmaf(d2, d2, sq); sq = fmaf(d3, d3, sq);
+                T = fmaf(gv.x, d0, T); T = fmaf(gv.y, d1, T); T = fmaf(gv.z, d2, T); T = fmaf(gv.w, d3, T);
+            }
+        sq = block_sum256(sq, s_red) * inv_cnt;
+        T = block_sum256(T, s_red);
+        float a, coef;
+        if (MODE == 0) { a = scale / sqrtf(eps + sq); coef = a * a * a / (scale * scale) * T * inv_cnt; }
+        else { a = 1.f / sqrtf(sq / (float)D + eps); coef = a * a * a * T * inv_cnt / (float)D; }
+        if (act)
+            for (int n = beg + rg; n < end; n += 16) {
+                const float4 v = ld4(x + (size_t)n * D + 4 * c4), gv = ld4(gy + (size_t)n * D + 4 * c4);
+                st4(dx + (size_t)n * D + 4 * c4,
+                    make_float4(a * (gv.x - gbar.x) - coef * (v.x - mean.x), a * (gv.y - gbar.y) - coef * (v.y - mean.y),
+                                a * (gv.z - gbar.z) - coef * (v.z - mean.z), a * (gv.w - gbar.w) - coef * (v.w - mean.w)));
+            }
+        __syncthreads();
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -150,7 +255,15 @@ extern "C" int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N
     if (int rc = norm_dims("glam_graph_norm_fwd", N, B, D, mode)) return rc;
     if (N == 0 || B == 0) return GLAM_OK;
     GLAM_REQUIRE(x && ptr && y, "glam_graph_norm_fwd: null pointer");
-    const dim3 grid(grid_for(B, kWavesPerBlockN)), block(kBlock);
+    const dim3 block(kBlock);
+    if (N / B >= 64 && (D & 3) == 0 && D <= 64) {       // large graphs: a block per graph
+        const dim3 grid(grid_for(B, 1));
+        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_fwd_block<0>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
+        else hipLaunchKernelGGL(k_graph_norm_fwd_block<1>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
+        GLAM_LAUNCH_CHECK("glam_graph_norm_fwd");
+        return GLAM_OK;
+    }
+    const dim3 grid(grid_for(B, kWavesPerBlockN));
     if (mode == 0) hipLaunchKernelGGL(k_graph_norm_fwd<0>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
     else hipLaunchKernelGGL(k_graph_norm_fwd<1>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
     GLAM_LAUNCH_CHECK("glam_graph_norm_fwd");
@@ -162,7 +275,15 @@ extern "C" int glam_graph_norm_bwd(const float* x, const float* gy, const int32_
     if (int rc = norm_dims("glam_graph_norm_bwd", N, B, D, mode)) return rc;
     if (N == 0 || B == 0) return GLAM_OK;
     GLAM_REQUIRE(x && gy && ptr && dx, "glam_graph_norm_bwd: null pointer");
-    const dim3 grid(grid_for(B, kWavesPerBlockN)), block(kBlock);
+    const dim3 block(kBlock);
+    if (N / B >= 64 && (D & 3) == 0 && D <= 64) {
+        const dim3 grid(grid_for(B, 1));
+        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd_block<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
+        else hipLaunchKernelGGL(k_graph_norm_bwd_block<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
+        GLAM_LAUNCH_CHECK("glam_graph_norm_bwd");
+        return GLAM_OK;
+    }
+    const dim3 grid(grid_for(B, kWavesPerBlockN));
     if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
     else hipLaunchKernelGGL(k_graph_norm_bwd<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
     GLAM_LAUNCH_CHECK("glam_graph_norm_bwd");

@@ -832,3 +832,29 @@ def test_pair_pool_protein_sized_segments(device):
     assert_close(out, ref, 2e-5, "pair pool")
     for a, r, n in zip(_grads(out, cot.to(device), [m, p]), g_ref, ["mol", "pro"]):
         assert_close(a, r, 2e-5, "pair pool grad " + n)
+
+
+@pytest.mark.parametrize("kind", ["pair", "layer"])
+def test_graph_norms_on_protein_sized_graphs(device, kind):
+    """N / B >= 64 routes PairNorm / graph LayerNorm to the block-per-graph kernels."""
+    torch.manual_seed(21)
+    sizes = [130, 402, 77, 256]
+    N, B, D = sum(sizes), len(sizes), 60
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    x0 = torch.randn(N, D) * 2 + 0.5
+    xo = x0.clone().requires_grad_(True)
+    if kind == "pair":
+        ref = O.pair_norm(xo, batch, B)
+        mod = layer.PairNorm().to(device)
+    else:
+        w, b_ = torch.rand(D) + 0.5, torch.randn(D) * 0.1
+        ref = O.graph_layer_norm(xo, w, b_, batch, B)
+        mod = layer.LayerNorm(D).to(device)
+        with torch.no_grad():
+            mod.weight.copy_(w); mod.bias.copy_(b_)
+    cot = torch.randn(ref.shape)
+    (g_ref,) = _grads(ref, cot, [xo])
+    x = x0.to(device).requires_grad_(True)
+    out = mod(x, batch.to(device))
+    assert_close(out, ref, 2e-5, kind)
+    assert_close(_grads(out, cot.to(device), [x])[0], g_ref, 5e-5, kind + "/gx")
