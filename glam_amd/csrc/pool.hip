@@ -506,12 +506,13 @@ extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t*
                                   const int32_t* eid, int64_t N, int64_t E, int D, int K, int mean, float* out,
                                   void* stream) {
     if (int rc = pool_dims("glam_edge_wsum_fwd", N, E, D)) return rc;
-    if (K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_fwd: K=%d (pad the edge features to 4 or 8)", K);
+    if (K != 1 && K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_fwd: K=%d (1, or edge features padded to 4 or 8)", K);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(x && rowptr && out && (E == 0 || (w && src && eid)), "glam_edge_wsum_fwd: null pointer");
     const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
-    if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    if (K == 1) hipLaunchKernelGGL(k_edge_wsum_fwd<1>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else hipLaunchKernelGGL(k_edge_wsum_fwd<8>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_fwd");
     return GLAM_OK;
@@ -521,12 +522,13 @@ extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int3
                                   const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K,
                                   int mean, float* dx, void* stream) {
     if (int rc = pool_dims("glam_edge_wsum_bwd", N, E, D)) return rc;
-    if (K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_bwd: K=%d (pad the edge features to 4 or 8)", K);
+    if (K != 1 && K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_bwd: K=%d (1, or edge features padded to 4 or 8)", K);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(d_out && colptr && rowptr && dx && (E == 0 || (w && dst && eid_t)), "glam_edge_wsum_bwd: null pointer");
     const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
-    if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    if (K == 1) hipLaunchKernelGGL(k_edge_wsum_bwd<1>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else hipLaunchKernelGGL(k_edge_wsum_bwd<8>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd");
     return GLAM_OK;

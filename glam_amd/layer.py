@@ -277,23 +277,32 @@ class GCNConv(MessagePassing):
         if self.bias is not None:
             zeros_(self.bias)
 
+    @staticmethod
+    def _norm(ei, gi, w):
+        deg = ops.edge_reduce(w, gi, "sum")
+        dis = deg.pow(-0.5)
+        dis = dis.masked_fill(dis == float("inf"), 0)
+        return dis[ei[0]] * w * dis[ei[1]]
+
     def forward(self, x, edge_index, edge_weight=None):
         n = x.size(0)
         gi0 = ops.graph_index(edge_index, n)
         ei, gi, mask = _with_self_loops(gi0, edge_index, n, True)
-        if edge_weight is None:
-            w = x.new_ones(ei.size(1))
+        if edge_weight is None:        # the reference's call (layer.py:148): the normalisation is a function of the edge list
+            cache = gi.__dict__.setdefault("_derived", {})
+            norm = cache.get("gcn_norm")
+            if norm is None:
+                norm = cache["gcn_norm"] = self._norm(ei, gi, x.new_ones(ei.size(1))).view(-1, 1).contiguous()
         else:  # add_remaining_self_loops: existing loops keep their weight
             loop_w = edge_weight.new_ones(n)
             inv = ~mask
             loop_w[edge_index[0][inv]] = edge_weight[inv]
-            w = torch.cat([edge_weight[mask], loop_w])
-        deg = ops.edge_reduce(w, gi, "sum")
-        dis = deg.pow(-0.5)
-        dis = dis.masked_fill(dis == float("inf"), 0)
-        norm = dis[ei[0]] * w * dis[ei[1]]
+            norm = self._norm(ei, gi, torch.cat([edge_weight[mask], loop_w])).view(-1, 1)
         xw = ops.matmul_tall(x, self.weight)
-        out = ops.edge_reduce(norm.view(-1, 1) * xw.index_select(0, ei[0]), gi, "sum")
+        if norm.requires_grad:         # learnable edge weights: per-edge messages, so that autograd reaches them
+            out = ops.edge_reduce(norm * xw.index_select(0, ei[0]), gi, "sum")
+        else:                          # one gather-scale-sum kernel per direction (K = 1 relation)
+            out = ops.edge_weighted_sum(xw, norm, gi).view(n, -1)
         return out if self.bias is None else out + self.bias
 
 

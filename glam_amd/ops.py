@@ -903,20 +903,23 @@ class _PairPool(torch.autograd.Function):
         P, D = msp.B, mol.size(1)
         out = torch.empty(P, 2, dtype=torch.float32, device=mol.device)
         arg = torch.empty(P, 2, dtype=torch.int32, device=mol.device)
-        check(_lib.load().glam_pair_pool_fwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), P, D, ptr(out), ptr(arg), stream()),
-              "glam_pair_pool_fwd")
-        ctx.save_for_backward(mol, pro, arg)
+        sums = torch.empty(P, 2, D, dtype=torch.float32, device=mol.device)
+        lib = _lib.load()
+        ws = torch.empty(max(lib.glam_pair_pool_workspace_bytes(P, D), 16), dtype=torch.uint8, device=mol.device)
+        check(lib.glam_pair_pool_fwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), P, D, ptr(out), ptr(arg), ptr(sums), ptr(ws),
+                                     ws.numel(), stream()), "glam_pair_pool_fwd")
+        ctx.save_for_backward(mol, pro, arg, sums)
         ctx.sps = (msp, psp)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
-        mol, pro, arg = ctx.saved_tensors
+        mol, pro, arg, sums = ctx.saved_tensors
         msp, psp = ctx.sps
         d_out = f32c(d_out, "d_out")
         d_mol, d_pro = torch.empty_like(mol), torch.empty_like(pro)
-        check(_lib.load().glam_pair_pool_bwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(arg), ptr(d_out), msp.B,
+        check(_lib.load().glam_pair_pool_bwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(arg), ptr(sums), ptr(d_out), msp.B,
                                              mol.size(1), ptr(d_mol), ptr(d_pro), stream()), "glam_pair_pool_bwd")
         return d_mol, d_pro, None, None
 

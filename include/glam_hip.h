@@ -256,7 +256,8 @@ int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int
                         float scale, float eps, float* dx, void* stream);
 
 /* Edge-weighted neighbour sums over a CSR-by-target: S[n,k,:] = (mean ? 1/deg_n : 1) * sum_{e -> n} w[eid e, k] *
- * x[src e, :]  (x f32[N,D], w f32[E,K], K in {4,8}, out f32[N,K,D]).  With one-hot edge features this is the per-relation
+ * x[src e, :]  (x f32[N,D], w f32[E,K], K in {1,4,8}, out f32[N,K,D]; K = 1 with w = the symmetric degree
+ * normalisation is GCNConv's propagate, src_2gi_dti_scr/layer.py:143-149).  With one-hot edge features this is the per-relation
  * neighbour sum that evaluates NNConv(aggr='mean') (src_1gp/layer.py:115-122: per-edge [C,C] weights nn(e_ij)) as a
  * K-relation R-GCN without the [E, C*C] tensor.  The backward (w.r.t. x) walks the CSR transpose. */
 int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
@@ -267,13 +268,16 @@ int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr
 
 /* ---------------------------------------------------------------------------------------------
  * Per-pair fusion of the two-tower models: out f32[P,2] = [max, mean] of mol[seg_i] @ pro[seg_i]^T for every pair i
- * (segments mol_ptr / pro_ptr int32[P+1]; empty segment -> 0); argmax int32[P,2] = (ligand row, residue row) of the max.
+ * (segments mol_ptr / pro_ptr int32[P+1]; empty segment -> 0); argmax int32[P,2] = (ligand row, residue row) of the max;
+ * sums f32[P,2,D] = the column sums of both segments, kept by the caller from the forward to the backward call.
  * Replaces: dot_and_global_pool2 (src_2gi_dti_scr/layer.py:270-283: Python loop, .item() syncs, one matmul per pair). */
+size_t glam_pair_pool_workspace_bytes(int64_t P, int D);
 int glam_pair_pool_fwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr, int64_t P,
-                       int D, float* out, int32_t* argmax, void* stream);
-int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
-                       const int32_t* argmax, const float* d_out, int64_t P, int D, float* d_mol, float* d_pro,
+                       int D, float* out, int32_t* argmax, float* sums, void* workspace, size_t workspace_bytes,
                        void* stream);
+int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
+                       const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D, float* d_mol,
+                       float* d_pro, void* stream);
 
 #ifdef __cplusplus
 }
