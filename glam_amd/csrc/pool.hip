@@ -383,6 +383,65 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd(const float* d_out, co
     }
 }
 
+
+// K = 1, D % 4 == 0 (GCNConv's propagate on residue graphs): a thread per (node, float4 of channels), two edges in flight;
+// same edge order and fma sequence as the scalar kernels.
+__global__ void __launch_bounds__(kBlock) k_edge_wsum1_fwd_v4(const float* x, const float* w, const int* rowptr, const int* nbr,
+                                                             const int* eid, int N, int D, int mean, float* out) {
+    const int D4 = D >> 2;
+    const size_t total = (size_t)N * D4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int n = (int)(i / D4), c = 4 * (int)(i % D4);
+        const int beg = rowptr[n], end = rowptr[n + 1];
+        float4 acc = f4zero();
+        int e = beg;
+        for (; e + 1 < end; e += 2) {
+            const int s0 = nbr[e], s1 = nbr[e + 1];
+            const float w0 = w[eid[e]], w1 = w[eid[e + 1]];
+            const float4 v0 = ld4(x + (size_t)s0 * D + c), v1 = ld4(x + (size_t)s1 * D + c);
+            acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
+            acc.x = fmaf(w1, v1.x, acc.x); acc.y = fmaf(w1, v1.y, acc.y); acc.z = fmaf(w1, v1.z, acc.z); acc.w = fmaf(w1, v1.w, acc.w);
+        }
+        if (e < end) {
+            const float w0 = w[eid[e]];
+            const float4 v0 = ld4(x + (size_t)nbr[e] * D + c);
+            acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
+        }
+        const float sc = mean ? 1.f / (float)max(end - beg, 1) : 1.f;
+        st4(out + (size_t)n * D + c, make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc));
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_edge_wsum1_bwd_v4(const float* d_out, const float* w, const int* colptr, const int* dst,
+                                                             const int* eid_t, const int* rowptr, int N, int D, int mean,
+                                                             float* dx) {
+    const int D4 = D >> 2;
+    const size_t total = (size_t)N * D4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int j = (int)(i / D4), c = 4 * (int)(i % D4);
+        const int beg = colptr[j], end = colptr[j + 1];
+        float4 acc = f4zero();
+        int e = beg;
+        for (; e + 1 < end; e += 2) {
+            const int n0 = dst[e], n1 = dst[e + 1];
+            const float sc0 = mean ? 1.f / (float)max(rowptr[n0 + 1] - rowptr[n0], 1) : 1.f;
+            const float sc1 = mean ? 1.f / (float)max(rowptr[n1 + 1] - rowptr[n1], 1) : 1.f;
+            const float w0 = w[eid_t[e]], w1 = w[eid_t[e + 1]];
+            const float4 g0 = ld4(d_out + (size_t)n0 * D + c), g1 = ld4(d_out + (size_t)n1 * D + c);
+            acc.x = fmaf(sc0, w0 * g0.x, acc.x); acc.y = fmaf(sc0, w0 * g0.y, acc.y); acc.z = fmaf(sc0, w0 * g0.z, acc.z); acc.w = fmaf(sc0, w0 * g0.w, acc.w);
+            acc.x = fmaf(sc1, w1 * g1.x, acc.x); acc.y = fmaf(sc1, w1 * g1.y, acc.y); acc.z = fmaf(sc1, w1 * g1.z, acc.z); acc.w = fmaf(sc1, w1 * g1.w, acc.w);
+        }
+        if (e < end) {
+            const int n0 = dst[e];
+            const float sc0 = mean ? 1.f / (float)max(rowptr[n0 + 1] - rowptr[n0], 1) : 1.f;
+            const float w0 = w[eid_t[e]];
+            const float4 g0 = ld4(d_out + (size_t)n0 * D + c);
+            acc.x = fmaf(sc0, w0 * g0.x, acc.x); acc.y = fmaf(sc0, w0 * g0.y, acc.y); acc.z = fmaf(sc0, w0 * g0.z, acc.z); acc.w = fmaf(sc0, w0 * g0.w, acc.w);
+        }
+        st4(dx + (size_t)j * D + c, acc);
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -511,7 +570,9 @@ extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t*
     GLAM_REQUIRE(x && rowptr && out && (E == 0 || (w && src && eid)), "glam_edge_wsum_fwd: null pointer");
     const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
-    if (K == 1) hipLaunchKernelGGL(k_edge_wsum_fwd<1>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    if (K == 1 && (D & 3) == 0)
+        hipLaunchKernelGGL(k_edge_wsum1_fwd_v4, dim3(grid_for(N * (D / 4), kBlock)), block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_fwd<1>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else hipLaunchKernelGGL(k_edge_wsum_fwd<8>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_fwd");
@@ -527,7 +588,9 @@ extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int3
     GLAM_REQUIRE(d_out && colptr && rowptr && dx && (E == 0 || (w && dst && eid_t)), "glam_edge_wsum_bwd: null pointer");
     const dim3 grid(grid_for(N * D, kBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
-    if (K == 1) hipLaunchKernelGGL(k_edge_wsum_bwd<1>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    if (K == 1 && (D & 3) == 0)
+        hipLaunchKernelGGL(k_edge_wsum1_bwd_v4, dim3(grid_for(N * (D / 4), kBlock)), block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_bwd<1>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else hipLaunchKernelGGL(k_edge_wsum_bwd<8>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd");
