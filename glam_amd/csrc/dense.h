@@ -16,6 +16,7 @@ struct TsArgs {
     // optional CELU(alpha = 1) folding for the GRU gate linears of MessageBlock (src_1gp/layer.py:261-262):
     int a_celu;                            // 1: the GEMM consumes celu(A) instead of A
     const float* cgrad_src; int ld_cgrad;  // non-null: out1[r, c] *= celu'(cgrad_src[r, c]) (chain rule through a folded CELU)
+    int out1_bf16;                         // 1: out1 points at bf16[N, ldo1] (round-to-nearest-even; storage of gathered rows)
 };
 
 struct WgArgs {
@@ -50,7 +51,7 @@ bool triplet_fwd_can_fuse_update(int H, int Cp, int De);
 int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
                              const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
                              int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
-                             const float* img_upd, const float* bias_p, float* out, hipStream_t s);
+                             const float* img_upd, const float* bias_p, float* out, hipStream_t s, int xw_bf16 = 0);
 bool tile_fwd_supported(int H, int Cp, int Dp);
 int tile_fwd_launch(const float* x, const float* edge_attr, const float* img_node, const float* img_upd, const float* we_p,
                     const float* M, const float* bias_p, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
@@ -62,7 +63,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x);
+                     const float* img_dx, float* d_x, int xw_bf16 = 0);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 
 }  // namespace glam

@@ -156,8 +156,10 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                         const float4 xs = ld4(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0);
                         v.x *= celu1_grad(xs.x); v.y *= celu1_grad(xs.y); v.z *= celu1_grad(xs.z); v.w *= celu1_grad(xs.w);
                     }
-                    if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
-                    else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                    if (m0 < a.M1) {
+                        if (a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
+                        else st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                    } else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
                 }
             } else {
                 float2 b = make_float2(0.f, 0.f);

@@ -409,10 +409,10 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
     return GLAM_OK;
 }
 
-extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                                      const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T,
-                                      int64_t N, int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij,
-                                      float* aggr, float* stats, float* out, void* stream) {
+static int layer_fwd_impl(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                          const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T, int64_t N, int64_t E,
+                          int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out,
+                          void* stream, int xw_bf16) {
     if (int rc = dims_ok("glam_triplet_layer_fwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd: N out of range");
     if (N == 0) return GLAM_OK;
@@ -422,21 +422,41 @@ extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, co
     hipStream_t s = (hipStream_t)stream;
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
+    if (xw_bf16 && (tile_ptr || !triplet_fwd_can_fuse_update(H, Cp, Dp)))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_layer_fwd_x16: bf16 row storage needs 36 <= Cp <= 64, H*Cp <= 192 and no tile plan");
     if (tile_ptr) {   // whole layer in one launch, one block per molecule tile
         GLAM_REQUIRE(T >= 1 && rowptr && (E == 0 || (src && eid && edge_attr)), "glam_triplet_layer_fwd: bad tile plan / CSR");
         return tile_fwd_launch(x, edge_attr, staged + L.img_node, staged + L.img_upd, staged + L.we_p, staged + L.m,
                                staged + L.bias_p, rowptr, src, eid, tile_ptr, T, H, Cp, Dp, slope, xw, a_ij, aggr, stats, out, s);
     }
     TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
+    g1.out1_bf16 = xw_bf16;
     if (int rc = launch_ts_gemm(g1, s)) return rc;
     if (triplet_fwd_can_fuse_update(H, Cp, Dp))   // aggregate + update GEMM in one launch
         return triplet_fwd_fused_update(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp,
-                                        Dp, slope, aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
+                                        Dp, slope, aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s, xw_bf16);
     if (int rc = glam_triplet_fwd(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp, Dp, 1,
                                   slope, aggr, stats, stream))
         return rc;
     TsArgs g2{aggr, HC, HC, nullptr, 0, 0, staged + L.img_upd, staged + L.bias_p, out, Cp, Cp, nullptr, 0, 0, (int)N};
     return launch_ts_gemm(g2, s);
+}
+
+extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                                      const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T,
+                                      int64_t N, int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij,
+                                      float* aggr, float* stats, float* out, void* stream) {
+    return layer_fwd_impl(x, edge_attr, staged, rowptr, src, eid, tile_ptr, T, N, E, H, Cp, Dp, slope, xw, a_ij, aggr, stats, out,
+                          stream, 0);
+}
+
+// bf16 STORAGE of the gathered rows (BASELINE config 3): xw16 is bf16[N, H*Cp]; logits, softmax and sums stay fp32
+extern "C" int glam_triplet_layer_fwd_x16(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                                          const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
+                                          float slope, void* xw16, float* a_ij, float* aggr, float* stats, float* out,
+                                          void* stream) {
+    return layer_fwd_impl(x, edge_attr, staged, rowptr, src, eid, nullptr, 0, N, E, H, Cp, Dp, slope,
+                          reinterpret_cast<float*>(xw16), a_ij, aggr, stats, out, stream, 1);
 }
 
 extern "C" int glam_triplet_tile_supported(int H, int Cp, int Dp) { return tile_fwd_supported(H, Cp, Dp) ? 1 : 0; }
@@ -459,7 +479,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                           const int32_t* rowptr, const int32_t* src, const int32_t* eid,
                           const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
                           int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
-                          float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po) {
+                          float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po, int xw_bf16 = 0) {
     if (int rc = dims_ok("glam_triplet_layer_bwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_bwd: N out of range");
     GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && d_out && d_x && (dstaged || po) && ws, "glam_triplet_layer_bwd: null pointer");
@@ -491,7 +511,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
-                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr))
+                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
@@ -547,4 +567,20 @@ extern "C" int glam_triplet_layer_bwd_params(const float* x, const float* edge_a
     const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
     return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
                           Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po);
+}
+
+extern "C" int glam_triplet_layer_bwd_params_x16(const float* x, const float* edge_attr, const float* staged, const void* xw16,
+                                                 const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                                 const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                                 const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                                 int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                                 const float* weight_node, const float* weight_edge, const float* att, float* d_x,
+                                                 float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
+                                                 float* d_bias, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = dims_ok("glam_triplet_layer_bwd_params_x16", C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
+                 "glam_triplet_layer_bwd_params_x16: null pointer");
+    const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
+    return layer_bwd_impl(x, edge_attr, staged, reinterpret_cast<const float*>(xw16), a_ij, aggr, stats, d_out, rowptr, src, eid,
+                          colptr, dst, eid_t, N, E, H, Cp, Dp, slope, d_x, nullptr, nullptr, ws, ws_bytes, stream, &po, 1);
 }

@@ -98,11 +98,11 @@ bool triplet_fwd_can_fuse_update(int H, int Cp, int De) {
 int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
                              const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
                              int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
-                             const float* img_upd, const float* bias_p, float* out, hipStream_t s) {
+                             const float* img_upd, const float* bias_p, float* out, hipStream_t s, int xw_bf16) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_fwd(fused)", N, E, H, Cp, De, &sh)) return rc;
     if (N == 0) return GLAM_OK;
-    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out};
+    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out, xw_bf16};
     const size_t lds = ((size_t)De * H * Cp + 16 * (size_t)(H * Cp + 4) + 16 * 64 + (size_t)((H * Cp + 15) & ~15) * 64) * sizeof(float);
     if (!dispatch(kTripletFwd, H, De, 1, sh, a, (int)N, lds, s, kFusedBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd(fused): no kernel for H=%d De=%d", H, De);
@@ -121,9 +121,11 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x) {
+                     const float* img_dx, float* d_x, int xw_bf16) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
+    if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: bf16 row storage needs 36 <= Cp <= 64, the multi-head message and no d_edge_attr");
     const int WSZ = emul ? De * H * Cp : 0;
     const int P = WSZ + De * 4;
     GLAM_REQUIRE(xw && a_ij && M && aggr && stats && d_aggr && rowptr && colptr && d_xw && d_a_ij && ws,
@@ -141,7 +143,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     const int gpb = kBlock / sh.G;
     const int red_groups = ((size_t)WSZ + (size_t)gpb * P) * sizeof(float) <= 60 * 1024 ? gpb : 4;
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
-                  alpha_e, dpre_e, d_a_ij, partial, red_groups};
+                  alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16};
     const size_t lds1 = ((size_t)WSZ + (size_t)red_groups * P) * sizeof(float);
     int nblk = 0;
     if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))

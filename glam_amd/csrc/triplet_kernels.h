@@ -47,6 +47,7 @@ struct FwdArgs {
     float* aggr; float* stats;
     // optional fused update (G == 16 only): out[N,Cp] = aggr @ W_scale + bias, W_scale as a k_ts_gemm image
     const float* img_upd; const float* bias_p; float* out;
+    int xw_bf16;      // xw holds bf16[N, H*Cp] (storage only; G == 16, ITER == 1 variants)
 };
 
 template <int DE>
@@ -86,8 +87,9 @@ __device__ __forceinline__ float4 edge_chunk(const float* s_w, const float (&ea)
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int H, int G, int ITER, int DE, bool EMUL>
+template <int H, int G, int ITER, int DE, bool EMUL, bool XB = false>
 __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs a) {
+    typedef XwRow<XB> XR;
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const int tid = threadIdx.x;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
@@ -118,9 +120,10 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
     }
 
     const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;   // 32-bit byte offsets (see ld4o)
-    unsigned chunk_off[ITER];
+    const unsigned xrow_bytes = (unsigned)HC * XR::kElem, xhead_bytes = (unsigned)Cp * XR::kElem;   // of the gathered xw rows
+    unsigned chunk_off[ITER], xchunk_off[ITER];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) chunk_off[it] = (unsigned)q[it] * 16u;
+    for (int it = 0; it < ITER; ++it) { chunk_off[it] = (unsigned)q[it] * 16u; xchunk_off[it] = (unsigned)q[it] * 4u * XR::kElem; }
     // Edges are processed CH at a time with every load of a chunk in flight together (indices -> {edge
     // features, a_j, neighbour rows}): a degree <= CH segment (all molecular nodes) costs 3 dependent
     // memory round trips instead of 2 + 2*deg.
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
         int sidx[CH], eidx[CH];
         bool val[CH];
         float ea[CH][DE], lk[CH][H];
-        float4 rows[CH][H][ITER];
+        typename XR::T rows[CH][H][ITER];
         auto load_idx = [&](int e0) {
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
@@ -171,11 +174,11 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             // rows of invalid slots are loaded from the clamped (valid) index and never used: accumulate skips them
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                const unsigned ro = (unsigned)sidx[k] * row_bytes;
+                const unsigned ro = (unsigned)sidx[k] * xrow_bytes;
 #pragma unroll
                 for (int h = 0; h < H; ++h)
 #pragma unroll
-                    for (int it = 0; it < ITER; ++it) rows[k][h][it] = ld4o(a.xw, ro + chunk_off[it] + (unsigned)h * head_bytes);
+                    for (int it = 0; it < ITER; ++it) rows[k][h][it] = XR::load(a.xw, ro + xchunk_off[it] + (unsigned)h * xhead_bytes);
             }
         };
         auto load_logits = [&]() {
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
                         if (!val[k]) continue;
                         const float p = softmax_exp(lk[k][h] - m[h]);
                         if (it == 0) ssum[h] += p;
-                        float4 xj = rows[k][h][it];
+                        float4 xj = XR::get(rows[k][h][it]);
                         if constexpr (EMUL) {
                             float4 e4 = f4zero();
 #pragma unroll
@@ -319,10 +322,12 @@ struct BwdDstArgs {
     int N; int Cp; float slope;
     float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;
     int red_groups;   // rows of the LDS reduction buffer: kBlock / G (every lane group stores its own partial) or 4
+    int xw_bf16;      // see FwdArgs
 };
 
-template <int H, int G, int ITER, int DE, bool EMUL>
+template <int H, int G, int ITER, int DE, bool EMUL, bool XB = false>
 __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDstArgs a) {
+    typedef XwRow<XB> XR;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int tid = threadIdx.x;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
@@ -398,7 +403,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             int sidx[CH], eidx[CH];
             bool val[CH];
             float eav[CH][DE];
-            float4 ajv[CH], rows[CH][H][ITER];
+            float4 ajv[CH];
+            typename XR::T rows[CH][H][ITER];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 val[k] = e0 + k < end;
@@ -409,12 +415,12 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             B1_STAMP(2);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                const unsigned ro = (unsigned)sidx[k] * row_bytes;
+                const unsigned ro = (unsigned)sidx[k] * (row_bytes / 4u * XR::kElem);
 #pragma unroll
                 for (int h = 0; h < H; ++h)
 #pragma unroll
                     for (int it = 0; it < ITER; ++it)
-                        rows[k][h][it] = val[k] ? ld4o(a.xw, ro + (unsigned)h * head_bytes + chunk_off[it]) : f4zero();
+                        rows[k][h][it] = val[k] ? XR::load(a.xw, ro + ((unsigned)h * head_bytes + chunk_off[it]) / 4u * XR::kElem) : XR::zero();
 #pragma unroll
                 for (int u = 0; u < DE / 4; ++u) {
                     const float4 v = ld4o(a.edge_attr, (unsigned)eidx[k] * (unsigned)(DE * 4) + 16u * u);
@@ -445,7 +451,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         if (!val[k]) continue;
-                        const float4 t = dag[h][it] * rows[k][h][it];   // d_aggr * x_j
+                        const float4 t = dag[h][it] * XR::get(rows[k][h][it]);   // d_aggr * x_j
                         if constexpr (EMUL) {
                             float4 e4 = f4zero();
 #pragma unroll
@@ -814,12 +820,30 @@ struct FwdOp {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             big_lds = true;
         }
+        if constexpr (G == 16 && ITER == 1 && EMUL) {
+            if (a.xw_bf16) {
+                static bool big_lds16 = false;
+                if (lds > 64 * 1024 && !big_lds16) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_fwd<H, G, ITER, DE, EMUL, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                    big_lds16 = true;
+                }
+                hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL, true>), dim3(grid), dim3(kBlock), lds, s, a);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
     }
 };
 template <int H, int G, int ITER, int DE, bool EMUL>
 struct BwdDstOp {
     static void run(const BwdDstArgs& a, int grid, size_t lds, hipStream_t s) {
+        if constexpr (G == 16 && ITER == 1 && EMUL) {
+            if (a.xw_bf16) {
+                hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true>), dim3(grid), dim3(kBlock), lds, s, a);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
     }
 };

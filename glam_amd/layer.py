@@ -115,6 +115,8 @@ class TripletMessage(MessagePassing):
                                     self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
             return out[:, :C] if Cp != C else out
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
+        if ops.FEATURE_STORAGE == "bf16":
+            raise GlamHipError("TripletMessage: bf16 row storage covers node_channels 33..64 (the fused kernels)")
         Wn, Wa, We, M, Ws, Cp, Dp = ops.scoped_weights(("triplet-derived", id(self.weight_node)), self.weight_node,
                                                        self._staged_weights)
         xw = torch.matmul(x, Wn)                                          # layer.py:37

@@ -253,6 +253,24 @@ def fused_layer_supported(C, heads, De):
     return heads * Cp + 8 <= 192 and Cp <= 64 and De <= 8 and 1 <= heads <= 4
 
 
+# Storage of the gathered node rows xw[N, H*C] between the node GEMM and the aggregate kernels: "fp32" (the reference's
+# precision, the 1e-5 parity bar) or "bf16" (BASELINE config 3: bf16 storage, fp32 logits / softmax / accumulation).
+FEATURE_STORAGE = os.environ.get("GLAM_STORAGE", "fp32")
+
+
+@contextlib.contextmanager
+def feature_storage(kind):
+    """``with ops.feature_storage("bf16"): model(batch)`` — forward passes inside store gathered rows in bf16."""
+    global FEATURE_STORAGE
+    if kind not in ("fp32", "bf16"):
+        raise GlamHipError(f"feature_storage: {kind!r} is not 'fp32' or 'bf16'")
+    prev, FEATURE_STORAGE = FEATURE_STORAGE, kind
+    try:
+        yield
+    finally:
+        FEATURE_STORAGE = prev
+
+
 class _TripletLayer(torch.autograd.Function):
     """Whole TripletMessage layer: parameter staging, node GEMM (+ separable attention columns), fused
     gather/softmax/scatter-add, update GEMM — and the hand-written backward of all of it."""
@@ -280,8 +298,16 @@ class _TripletLayer(torch.autograd.Function):
         # the same conv is applied message_steps times per model forward: one staging per pass (see _WeightScope)
         staged = _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet", id(wn), id(we), id(att), id(wsc), id(bias)),
                          wn, build)
-        xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
+        x16 = FEATURE_STORAGE == "bf16"
+        xw, a_ij = torch.empty(N, HC, dtype=torch.bfloat16 if x16 else torch.float32, device=dev), torch.empty(N, 8, **f)
         aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
+        if x16:
+            check(lib.glam_triplet_layer_fwd_x16(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, gi.E,
+                                                 H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
+                                                 stream()), "glam_triplet_layer_fwd_x16")
+            ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
+            ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
+            return out
         # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
         # faster at B=1024 (one tile per CU) but slower beyond, where its barrier-separated phases leave the CU idle
         # (measurements in DESIGN.md).
@@ -313,6 +339,15 @@ class _TripletLayer(torch.autograd.Function):
         sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
         flatg = torch.empty(sum(sizes), **f)
         d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
+        if xw.dtype == torch.bfloat16:
+            if d_ea is not None:
+                raise GlamHipError("triplet_layer: bf16 row storage has no edge_attr gradient")
+            check(lib.glam_triplet_layer_bwd_params_x16(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
+                                                        ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
+                                                        ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
+                                                        ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(ws),
+                                                        ws.numel(), stream()), "glam_triplet_layer_bwd_params_x16")
+            return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),

@@ -227,6 +227,23 @@ int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const 
                                   float* d_weight_scale, float* d_bias, float* d_edge_attr, void* ws, size_t ws_bytes,
                                   void* stream);
 
+/* bf16 STORAGE of the gathered rows (BASELINE.json configs[2]: "bf16"; the reference itself is fp32 only): xw16 is
+ * bf16[N, H*Cp], written round-to-nearest-even by the node GEMM's epilogue and widened on load by the aggregate kernels;
+ * attention logits, softmax, sums, every gradient and every other tensor stay f32.  Same call sequence and arguments as
+ * glam_triplet_layer_fwd / glam_triplet_layer_bwd_params otherwise.  36 <= Cp <= 64 and H*Cp + 8 <= 192 (the shapes of
+ * the fused kernels: hid_dim 45 and 60); no tile plan, no edge_attr gradient. */
+int glam_triplet_layer_fwd_x16(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                               const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
+                               float slope, void* xw16, float* a_ij, float* aggr, float* stats, float* out, void* stream);
+int glam_triplet_layer_bwd_params_x16(const float* x, const float* edge_attr, const float* staged, const void* xw16,
+                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                      const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                      int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                      const float* weight_node, const float* weight_edge, const float* att, float* d_x,
+                                      float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
+                                      float* d_bias, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * MessageBlock remainder: gate math of one torch.nn.GRU(C, C) step with seq_len 1 (src_1gp/layer.py:247, :262).
  * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with

@@ -882,3 +882,70 @@ def test_gcn_conv_against_oracle(device, D):
         assert_close(out, ref, TOL, "gcn out")
         for n, a, r in zip(["x", "weight", "bias"], _grads(out, cot.to(device), [x, conv.weight, conv.bias]), g_ref):
             assert_close(a, r, 3e-5, "gcn grad " + n)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 row storage (BASELINE configs[2]; the reference is fp32 only, so parity is defined against the fp32 oracle
+# at bf16 tolerance, and against the oracle with its gathered message rows rounded to bf16 at the fp32 tolerance)
+# ---------------------------------------------------------------------------------------------
+def _triplet_with_bf16_rows(x, edge_index, edge_attr, wn, we, att, wsc, bias, heads=3, slope=0.2):
+    """O.triplet_message with the storage model of the x16 kernels: the MESSAGE reads x_j rounded to bf16
+    (round-to-nearest-even, straight-through gradient); logits, softmax and sums are those of the oracle."""
+    N, C = x.size(0), wn.size(0)
+    xw, ew = x @ wn, edge_attr @ we
+    xq = xw + (xw.detach().bfloat16().float() - xw.detach())
+    src, dst = edge_index[0], edge_index[1]
+    x_i, x_j = xw[dst].view(-1, heads, C), xw[src].view(-1, heads, C)
+    e_ij = ew.view(-1, heads, C)
+    alpha = torch.nn.functional.leaky_relu((torch.cat([x_i, e_ij, x_j], -1) * att).sum(-1), slope)
+    alpha = O.segment_softmax(alpha, dst, N)
+    aggr = O.scatter(alpha.view(-1, heads, 1) * e_ij * xq[src].view(-1, heads, C), dst, N, "sum")
+    return aggr.reshape(N, -1) @ wsc + bias
+
+
+@pytest.mark.parametrize("C,De,kind", [(60, 4, "mol"), (45, 8, "protein")])
+def test_triplet_bf16_row_storage(device, C, De, kind):
+    torch.manual_seed(300 + C)
+    b = synth_batch(96, seed=C) if kind == "mol" else synth_protein_batch(3, seed=C, n_min=150, n_max=400)
+    N = b.x.size(0)
+    # x and weight_node on coarse binary grids: x @ weight_node is then exact in fp32 (<= 17 significant bits), so the host
+    # and the device round the very same xw to bf16 and check (1) is not blurred by rounding-boundary flips
+    x0 = (torch.randn(N, C) * 4).round() / 4
+    ea0 = b.edge_attr if kind == "mol" else torch.rand(b.edge_index.size(1), De)
+    conv = layer.TripletMessage(C, De)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+        conv.weight_node.copy_((conv.weight_node * 64).round() / 64)
+    refs = []
+    for fn in (_triplet_with_bf16_rows, O.triplet_message):
+        ps0 = [p.detach().clone().requires_grad_(True) for p in conv.parameters()]
+        xo = x0.clone().requires_grad_(True)
+        out_ref = fn(xo, b.edge_index, ea0, *ps0)
+        if not refs:
+            cot = torch.randn(out_ref.shape)
+        refs.append((out_ref, _grads(out_ref, cot, [xo] + ps0)))
+    conv = conv.to(device)
+    x = x0.to(device).requires_grad_(True)
+    with ops.feature_storage("bf16"):
+        out = conv(x, b.edge_index.to(device), ea0.to(device))
+    gs = _grads(out, cot.to(device), [x] + list(conv.parameters()))
+    names = ["x"] + [n for n, _ in conv.named_parameters()]
+    # (1) exact storage model: fp32 tolerance
+    assert_close(out, refs[0][0], 2e-5, "x16 out vs storage model")
+    for n, a, r in zip(names, gs, refs[0][1]):
+        assert_close(a, r, 5e-5, f"x16 grad.{n} vs storage model")
+    # (2) the fp32 reference: bf16 tolerance (8 mantissa bits: 2^-9 relative per rounded row element)
+    scale = refs[1][0].abs().max().item()
+    assert (out.cpu() - refs[1][0]).abs().max().item() <= 1e-2 * scale
+    for n, a, r in zip(names, gs, refs[1][1]):
+        assert (a.cpu() - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-6, n
+    # fp32 storage is untouched by the switch being used elsewhere
+    out32 = conv(x, b.edge_index.to(device), ea0.to(device))
+    assert_close(out32, refs[1][0], TOL, "fp32 after bf16")
+
+
+def test_bf16_row_storage_refuses_unsupported_shapes(device):
+    b = synth_batch(4, seed=1).to(device)
+    conv = layer.TripletMessage(30, 4).to(device)          # Cp = 32: no bf16 variant of the 8-lane kernels
+    with ops.feature_storage("bf16"), pytest.raises(ops.GlamHipError):
+        conv(torch.randn(b.x.size(0), 30, device=device), b.edge_index, b.edge_attr)
