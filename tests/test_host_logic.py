@@ -205,3 +205,21 @@ def test_dataloader_caches_collated_batches_when_order_is_fixed():
     assert [b.num_graphs for b in shuffled] == [3, 3, 1] and shuffled.cache is False
     with pytest.raises(ValueError):
         DataLoader(mols, batch_size=3, shuffle=True, cache=True)
+
+
+def test_gpu_manager_surface(monkeypatch):
+    """Search-loop device picker (utils.py:185-246) without nvidia-smi: same keys and choices, fed by the HIP runtime."""
+    from glam_amd.devices import GPUManager
+    if not torch.cuda.is_available():
+        m = GPUManager()
+        assert m.gpu_num == 0 and m.auto_choice(0.5) is None and m.wait_free_gpu() == -1
+    mem = {0: (10 << 30, 288 << 30), 1: (250 << 30, 288 << 30), 2: (200 << 30, 288 << 30)}
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 3)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda i: mem[i])
+    monkeypatch.setattr(torch.cuda, "get_device_name", lambda i: "AMD Instinct MI355X")
+    m = GPUManager(["power.draw"])
+    assert m.gpu_num == 3 and set(m.gpus[0]) == {"index", "gpu_name", "memory.free", "memory.total", "power.draw"}
+    assert m.gpus[1]["memory.free"] == 250 * 1024 and m.auto_choice(0.7) == 1 and m.wait_free_gpu(0.7) == 1
+    mem[1] = (100 << 30, 288 << 30)
+    assert m.auto_choice(0.7) is None and m.auto_choice(0.5) == 2
