@@ -58,6 +58,8 @@ SIGNATURES = {
     "glam_gru_gates_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "glam_triplet_staged_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_dstaged_floats": (_sz, [_i32, _i32, _i32]),
+    "glam_triplet_plain_floats": (_sz, [_i32, _i32, _i32]),
+    "glam_triplet_stage_plain": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
     "glam_triplet_stage_params": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
     "glam_triplet_stage_params_bwd": (_i32, [_vp] * 4 + [_i32] * 5 + [_vp] * 5 + [_vp]),
     "glam_triplet_layer_fwd": (_i32, [_vp] * 7 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),

@@ -464,7 +464,8 @@ extern "C" int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, 
     return launch_ts_gemm(a, (hipStream_t)stream);
 }
 
-extern "C" size_t glam_wgrad_workspace_bytes(void) { return wgrad_workspace_floats() * sizeof(float) + 256; }
+// room for two products: glam_wgrad_gemm_pair, and glam_wgrad_gemm when it splits 64 < J <= 128 into two column chunks
+extern "C" size_t glam_wgrad_workspace_bytes(void) { return 2 * wgrad_workspace_floats() * sizeof(float) + 256; }
 
 extern "C" int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, const float* Wimg, const float* bias, float* out, int M,
                                  int ldo, const float* cgrad_src, int ld_cgrad, int64_t N, void* stream) {
@@ -483,7 +484,7 @@ extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_
                                     int64_t N, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_pair: N out of range");
     GLAM_REQUIRE(Pa && Qa && out_a && Pb && Qb && out_b && ws, "glam_wgrad_gemm_pair: null pointer");
-    GLAM_REQUIRE(ws_bytes >= 2 * glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_pair: workspace too small (2 x glam_wgrad_workspace_bytes)");
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_pair: workspace too small");
     GLAM_REQUIRE(aligned16(Qa) && aligned16(Pa) && aligned16(Qb) && aligned16(Pb), "glam_wgrad_gemm_pair: P / Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     WgArgs a{Pa, Ia, ldpa, nullptr, 0, 0, ones_a, Qa, Ja, ldqa, qones_a, (int)N, 0, partial, 0, 0, qcelu_a};
@@ -503,6 +504,17 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm: workspace too small");
     GLAM_REQUIRE(aligned16(Q) && aligned16(P1) && aligned16(P2), "glam_wgrad_gemm: P / Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    if (J > 64 && J <= 128 && !qones && (J & 3) == 0) {
+        // two column chunks of Q (64 | J - 64) as the two products of one launch: G[:, :64] and G[:, 64:]
+        WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, 64, ldq, 0, (int)N, 0, partial, 0, 0};
+        WgArgs b{P1, I1, ldp1, P2, I2, ldp2, ones, Q + 64, J - 64, ldq, 0, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0};
+        ReduceArgs rb{};
+        rb.njobs = 2;
+        if (int rc = launch_wgrad_partials2(a, out, stride_i, stride_j, &rb.job[0], b, out + (size_t)64 * stride_j, stride_i, stride_j,
+                                            &rb.job[1], (hipStream_t)stream))
+            return rc;
+        return launch_final_reduce(rb, (hipStream_t)stream);
+    }
     WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, (int)N, 0, partial, 0, 0};
     ReduceArgs ra{};
     ra.njobs = 1;

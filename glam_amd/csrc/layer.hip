@@ -194,6 +194,44 @@ __global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a, int copy_b
     }
 }
 
+// Wide layers (H*Cp + 8 > 192, e.g. hid_dim_alpha = 6): the same derived parameters as plain row-major matrices for
+// the library GEMM: Wcat[Cp, HC+8] | Ws_p[HC, Cp] | We_p[Dp, HC] | M[Dp, 4] | bias_p[Cp].  One thread per element; the
+// separable-attention entries are C-term dots (dot_strided keeps 32 loads in flight).
+__global__ void __launch_bounds__(kBlock) k_stage_plain(const float* wn, const float* we, const float* att, const float* wsc,
+                                                       const float* bias, int C, int H, int De, int Cp, int Dp, float* out) {
+    const int HC = H * Cp, MC = HC + 8;
+    const int n1 = Cp * MC, n2 = HC * Cp, n3 = Dp * HC, n4 = Dp * 4, total = n1 + n2 + n3 + n4 + Cp;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+        int i = idx;
+        float v = 0.f;
+        if (i < n1) {
+            const int k = i / MC, m = i % MC;
+            if (k < C) {
+                if (m < HC) {
+                    const int h = m / Cp, c = m % Cp;
+                    if (c < C) v = wn[(size_t)k * H * C + h * C + c];
+                } else {
+                    const int sx = m - HC, h = sx & 3, side = sx >> 2;
+                    if (h < H) v = dot_strided(wn + (size_t)k * H * C + h * C, 1, att + (size_t)h * 3 * C + (side ? 2 * C : 0), 1, C);
+                }
+            }
+        } else if ((i -= n1) < n2) {
+            const int k = i / Cp, m = i % Cp, h = k / Cp, c = k % Cp;
+            if (c < C && m < C) v = wsc[(size_t)(h * C + c) * C + m];
+        } else if ((i -= n2) < n3) {
+            const int k = i / HC, m = i % HC, h = m / Cp, c = m % Cp;
+            if (k < De && c < C) v = we[(size_t)k * H * C + h * C + c];
+        } else if ((i -= n3) < n4) {
+            const int k = i >> 2, h = i & 3;
+            if (k < De && h < H) v = dot_strided(we + (size_t)k * H * C + h * C, 1, att + (size_t)h * 3 * C + C, 1, C);
+        } else {
+            i -= n4;
+            if (i < C) v = bias[i];
+        }
+        out[idx] = v;
+    }
+}
+
 // chain rule of k_stage_params
 __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, const float* we, const float* att,
                                                             const float* d_Wcat, const float* d_WsB,
@@ -376,6 +414,29 @@ static int dims_ok(const char* fn, int C, int H, int De, int Cp, int Dp) {
     return GLAM_OK;
 }
 
+static int dims_plain(const char* fn, int C, int H, int De, int Cp, int Dp) {
+    if (C <= 0 || H < 1 || H > 4 || De <= 0 || Cp < C || (Cp & 3) || Cp > 256)
+        return fail(GLAM_E_INVALID, "%s: bad dims C=%d H=%d De=%d Cp=%d", fn, C, H, De, Cp);
+    if ((Dp != 4 && Dp != 8) || De > Dp) return fail(GLAM_E_UNSUPPORTED, "%s: De=%d Dp=%d", fn, De, Dp);
+    return GLAM_OK;
+}
+
+extern "C" size_t glam_triplet_plain_floats(int H, int Cp, int Dp) {
+    const size_t HC = (size_t)H * Cp;
+    return (size_t)Cp * (HC + 8) + HC * Cp + (size_t)Dp * HC + (size_t)Dp * 4 + Cp;
+}
+
+extern "C" int glam_triplet_stage_plain(const float* weight_node, const float* weight_edge, const float* att,
+                                        const float* weight_scale, const float* bias, int C, int H, int De, int Cp, int Dp,
+                                        float* plain, void* stream) {
+    if (int rc = dims_plain("glam_triplet_stage_plain", C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && weight_scale && bias && plain, "glam_triplet_stage_plain: null pointer");
+    hipLaunchKernelGGL(k_stage_plain, dim3(grid_for((int64_t)glam_triplet_plain_floats(H, Cp, Dp), kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, weight_node, weight_edge, att, weight_scale, bias, C, H, De, Cp, Dp, plain);
+    GLAM_LAUNCH_CHECK("glam_triplet_stage_plain");
+    return GLAM_OK;
+}
+
 extern "C" size_t glam_triplet_staged_floats(int H, int Cp, int Dp) { return staged_layout(H, Cp, Dp).total; }
 extern "C" size_t glam_triplet_dstaged_floats(int H, int Cp, int Dp) { return dstaged_layout(H, Cp, Dp).total; }
 
@@ -397,7 +458,7 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
                                              const float* dstaged, int C, int H, int De, int Cp, int Dp,
                                              float* d_weight_node, float* d_weight_edge, float* d_att,
                                              float* d_weight_scale, float* d_bias, void* stream) {
-    if (int rc = dims_ok("glam_triplet_stage_params_bwd", C, H, De, Cp, Dp)) return rc;
+    if (int rc = dims_plain("glam_triplet_stage_params_bwd", C, H, De, Cp, Dp)) return rc;   // no GEMM image involved: any width
     GLAM_REQUIRE(weight_node && weight_edge && att && dstaged && d_weight_node && d_weight_edge && d_att && d_weight_scale &&
                      d_bias, "glam_triplet_stage_params_bwd: null pointer");
     const DStaged L = dstaged_layout(H, Cp, Dp);

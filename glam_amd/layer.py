@@ -117,12 +117,28 @@ class TripletMessage(MessagePassing):
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
         if ops.FEATURE_STORAGE == "bf16":
             raise GlamHipError("TripletMessage: bf16 row storage covers node_channels 33..64 (the fused kernels)")
+        x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
+        if ops.wide_layer_supported(C, self.heads, De):
+            out = ops.triplet_layer_wide(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,
+                                         self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
+            return out[:, :C] if Cp != C else out
         Wn, Wa, We, M, Ws, Cp, Dp = ops.scoped_weights(("triplet-derived", id(self.weight_node)), self.weight_node,
-                                                       self._staged_weights)
-        xw = torch.matmul(x, Wn)                                          # layer.py:37
-        a_ij = torch.matmul(x, Wa)
+                                                       self._staged_wide)
+        # every N-deep weight gradient of this path runs on k_wgrad (ops.matmul_tall: the library's heuristics give those
+        # products 32x32 tiles, 75 us each); the data-side products stay on the library GEMM
+        xw = ops.matmul_tall(x_p, Wn)                                      # layer.py:37
+        a_ij = ops.matmul_tall(x_p, Wa)
         aggr = ops.triplet_aggregate(xw, a_ij, edge_attr, We, M, gi, self.heads, Cp, self.negative_slope)
-        return self.update(aggr, Ws)
+        return ops.matmul_tall(aggr, Ws)[:, :C] + self.bias                # layer.py:57-61
+
+    def _staged_wide(self):
+        """``_staged_weights`` with the input rows of ``W_node`` / ``W_a`` and the output columns of ``W_scale`` zero-padded
+        to ``Cp`` (the wide path pads ``x`` and slices the output)."""
+        Wn, Wa, We, M, Ws, Cp, Dp = self._staged_weights()
+        if Cp != self.node_channels:
+            Wn, Wa = F.pad(Wn, (0, 0, 0, Cp - self.node_channels)), F.pad(Wa, (0, 0, 0, Cp - self.node_channels))
+            Ws = F.pad(Ws, (0, Cp - self.node_channels))
+        return Wn.contiguous(), Wa.contiguous(), We, M, Ws.contiguous(), Cp, Dp
 
     def update(self, aggr_out, weight_scale=None):                         # layer.py:57-61
         w = self.weight_scale if weight_scale is None else weight_scale

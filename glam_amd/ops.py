@@ -361,6 +361,103 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
     return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
 
 
+class _TripletLayerWide(torch.autograd.Function):
+    """TripletMessage for widths beyond the fused kernels' table (H*Cp + 8 > 192; hid_dim_alpha = 6 of glam.py:60) as ONE
+    autograd node: ``k_stage_plain`` -> library GEMMs for the data-side products -> the aggregate kernels -> ``k_wgrad``
+    for both N-deep weight gradients (written straight into the ``dstaged`` layout) -> ``k_stage_params_bwd``.
+    No per-parameter torch glue on either pass."""
+
+    @staticmethod
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope):
+        require_device(x_p, ea_p, wn, we, att, wsc, bias)
+        x_p, ea_p = f32c(x_p, "x"), f32c(ea_p, "edge_attr")
+        wn, we, att, wsc, bias = (f32c(t, n) for t, n in ((wn, "weight_node"), (we, "weight_edge"),
+                                                           (att, "weight_triplet_att"), (wsc, "weight_scale"), (bias, "bias")))
+        C, De = wn.size(0), we.size(0)
+        N, Cp = x_p.shape
+        Dp = ea_p.size(1)
+        HC = H * Cp
+        if gi.N != N or ea_p.size(0) != gi.E or wn.shape != (C, H * C) or wsc.shape != (H * C, C) or Cp != (C + 3) // 4 * 4:
+            raise GlamHipError("triplet_layer_wide: shape mismatch")
+        lib, dev = _lib.load(), x_p.device
+        f = dict(dtype=torch.float32, device=dev)
+
+        def build():
+            buf = torch.empty(lib.glam_triplet_plain_floats(H, Cp, Dp), **f)
+            check(lib.glam_triplet_stage_plain(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(buf),
+                                               stream()), "glam_triplet_stage_plain")
+            return buf
+
+        plain = _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet-plain", id(wn), id(we), id(att), id(wsc), id(bias)), wn, build)
+        Wcat, Ws_p, We_p, M, bias_p = _plain_views(plain, H, Cp, Dp)
+        xw = torch.matmul(x_p, Wcat[:, :HC])                               # layer.py:37
+        a_ij = torch.matmul(x_p, Wcat[:, HC:])                             # separable attention scalars a_i | a_j
+        aggr, stats = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
+        check(lib.glam_triplet_fwd(ptr(xw), ptr(a_ij), ptr(ea_p), ptr(We_p), ptr(M), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
+                                   N, gi.E, H, Cp, Dp, 1, float(slope), ptr(aggr), ptr(stats), stream()), "glam_triplet_fwd")
+        out = torch.addmm(bias_p, aggr, Ws_p)                              # layer.py:57-61
+        ctx.save_for_backward(x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats)
+        ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats = ctx.saved_tensors
+        C, H, De, Cp, Dp, slope = ctx.dims
+        gi = ctx.gi
+        N, E, HC = gi.N, gi.E, H * Cp
+        lib, dev = _lib.load(), x_p.device
+        f = dict(dtype=torch.float32, device=dev)
+        d_out = f32c(d_out, "d_out")
+        Wcat, Ws_p, We_p, M, _ = _plain_views(plain, H, Cp, Dp)
+        colptr, dst, eid_t = gi.transpose()
+        # dstaged: d_Wcat[Cp, HC+8] | d_WsB[HC+1, Cp] | d_We_p[Dp, HC] | d_M[Dp, 4]   (include/glam_hip.h)
+        o_wsb = Cp * (HC + 8)
+        o_we = (o_wsb + (HC + 1) * Cp + 3) // 4 * 4
+        o_m = o_we + Dp * HC
+        dstaged = torch.empty(lib.glam_triplet_dstaged_floats(H, Cp, Dp), **f)
+        d_aggr = torch.matmul(d_out, Ws_p.t())
+        d_xw, d_a = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
+        d_ea = torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None
+        ws = torch.empty(lib.glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=dev)
+        check(lib.glam_triplet_bwd(ptr(xw), ptr(a_ij), ptr(ea_p), ptr(We_p), ptr(M), ptr(aggr), ptr(stats), ptr(d_aggr),
+                                   ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst), ptr(eid_t), N, E, H, Cp, Dp, 1,
+                                   slope, ptr(d_xw), ptr(d_a), ptr(dstaged[o_we:]), ptr(dstaged[o_m:]), ptr(d_ea), ptr(ws),
+                                   ws.numel(), stream()), "glam_triplet_bwd")
+        d_x = torch.matmul(d_xw, Wcat[:, :HC].t())
+        d_x.addmm_(d_a, Wcat[:, HC:].t())
+        wws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        # d_WsB = [aggr | 1]^T d_out ;  d_Wcat = x^T [d_xw | d_a], computed as ([d_xw | d_a]^T x)^T
+        check(lib.glam_wgrad_gemm(ptr(aggr), HC, HC, None, 0, 0, 1, ptr(d_out), Cp, Cp, 0, N, ptr(dstaged[o_wsb:]), Cp, 1,
+                                  ptr(wws), wws.numel(), stream()), "glam_wgrad_gemm")
+        check(lib.glam_wgrad_gemm(ptr(d_xw), HC, HC, ptr(d_a), 8, 8, 0, ptr(x_p), Cp, Cp, 0, N, ptr(dstaged), 1, HC + 8,
+                                  ptr(wws), wws.numel(), stream()), "glam_wgrad_gemm")
+        sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
+        flatg = torch.empty(sum(sizes), **f)
+        d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
+        check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn), ptr(d_we),
+                                                ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()), "glam_triplet_stage_params_bwd")
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
+
+
+def _plain_views(plain, H, Cp, Dp):
+    HC = H * Cp
+    n1, n2, n3, n4 = Cp * (HC + 8), HC * Cp, Dp * HC, Dp * 4
+    return (plain[:n1].view(Cp, HC + 8), plain[n1:n1 + n2].view(HC, Cp), plain[n1 + n2:n1 + n2 + n3].view(Dp, HC),
+            plain[n1 + n2 + n3:n1 + n2 + n3 + n4].view(Dp, 4), plain[n1 + n2 + n3 + n4:])
+
+
+def wide_layer_supported(C, heads, De):
+    """Widths the one-node wide path covers (k_wgrad: up to 320 + 128 columns): C <= 100 at 3 heads."""
+    Cp = (C + 3) // 4 * 4
+    return heads * Cp + 8 <= 320 and Cp <= 128 and De <= 8 and 1 <= heads <= 4
+
+
+def triplet_layer_wide(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
+    return _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+
+
 # --------------------------------------------------------------------------------------
 # dense linear on the fp32 matrix cores + GRU gate math (MessageBlock remainder)
 # --------------------------------------------------------------------------------------
@@ -454,15 +551,21 @@ class _MatmulTall(torch.autograd.Function):
             lib = _lib.load()
             ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
             dw = torch.empty(K, M, dtype=torch.float32, device=a.device)
-            check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 0, ptr(dy), M, M, 0, N, ptr(dw), M, 1, ptr(ws), ws.numel(), stream()),
-                  "glam_wgrad_gemm")
+            if M <= 128:      # dw = a^T dy: P = a (up to 320 columns), Q = dy (two 64-column chunks beyond 64)
+                check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 0, ptr(dy), M, M, 0, N, ptr(dw), M, 1, ptr(ws), ws.numel(),
+                                          stream()), "glam_wgrad_gemm")
+            else:             # wide output: dw^T = dy^T a, written through transposed strides
+                check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(a), K, K, 0, N, ptr(dw), 1, M, ptr(ws), ws.numel(),
+                                          stream()), "glam_wgrad_gemm")
         return da, dw
 
 
 def matmul_tall(a, w):
-    """``a @ w`` with the weight gradient on the MFMA reduction kernel when it fits (K <= 320, M <= 64, multiples of 4)."""
+    """``a @ w`` with the weight gradient on the MFMA reduction kernel when it fits: one of (K, M) <= 320 and the other
+    <= 128, multiples of 4."""
     K, M = w.shape
-    if a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and K <= 320 and M <= 64 and a.size(0) >= 64:
+    if a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and a.size(0) >= 64 and \
+            ((K <= 320 and M <= 128) or (K <= 128 and M <= 320)):
         return _MatmulTall.apply(a, w)
     return torch.matmul(a, w)
 
@@ -677,7 +780,7 @@ class _GruBlock(torch.autograd.Function):
         check(lib.glam_ts_gemm(ptr(d_gh), M, M, None, 0, 0, ptr(image_t(w_hh)), None, ptr(dh), C, C, None, 0, 0, N, st), "glam_ts_gemm")
         dh.add_(d_h)                                  # + the direct z * g path of the gate equations
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
-        ws = torch.empty(2 * lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         dwb_ih, dwb_hh = torch.empty(M + 1, C + 1, **f), torch.empty(M + 1, C + 1, **f)
         check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
                                        ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),

@@ -154,7 +154,8 @@ int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_
  *                    K1+K2 <= 192 with M <= 64, or K1+K2 <= 64 with M <= 192.
  *   glam_wgrad_gemm: out[i*stride_i + j*stride_j] = sum_n [P1 | P2 | 1][n, i] * [Q | 1][n, j]  (reduction over the
  *                    N rows; `ones` / `qones` append an all-ones column on either side, i.e. the bias gradient);
- *                    I <= 320 (five 64-column slabs), J <= 64 (ones columns included). */
+ *                    I <= 320 (five 64-column slabs), J <= 64 (ones columns included); without qones also
+ *                    64 < J <= 128, computed as two column chunks in one launch. */
 size_t glam_ts_gemm_image_bytes(int K, int M);
 int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, float* img, void* stream);
 int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
@@ -162,7 +163,7 @@ int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int
                  void* stream);
 /* glam_wgrad_gemm_pair: two independent products (same N) in one launch + one reduction: the d_W / d_b of two linears
  * that are applied side by side (the input and hidden gate linears of the GRU step, src_1gp/layer.py:262).  Workspace:
- * 2 x glam_wgrad_workspace_bytes(). */
+ * glam_wgrad_workspace_bytes() (sized for two products). */
 int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
                          int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
                          const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
@@ -199,6 +200,15 @@ int glam_triplet_stage_params_bwd(const float* weight_node, const float* weight_
                                   const float* dstaged, int C, int H, int De, int Cp, int Dp, float* d_weight_node,
                                   float* d_weight_edge, float* d_att, float* d_weight_scale, float* d_bias,
                                   void* stream);
+/* Wide layers (H*Cp + 8 > 192: hid_dim_alpha = 6 of the reference's search space, glam.py:60): the same derived
+ * parameters as plain row-major matrices for library GEMMs, `plain` = Wcat f32[Cp, H*Cp+8] | Ws_p f32[H*Cp, Cp] |
+ * We_p f32[Dp, H*Cp] | M f32[Dp, 4] | bias_p f32[Cp] (glam_triplet_plain_floats floats).  The host mirror sequences
+ * library GEMMs, glam_triplet_fwd / _bwd and glam_wgrad_gemm around it, fills a `dstaged` buffer and calls
+ * glam_triplet_stage_params_bwd (which has no width limit). */
+size_t glam_triplet_plain_floats(int H, int Cp, int Dp);
+int glam_triplet_stage_plain(const float* weight_node, const float* weight_edge, const float* att,
+                             const float* weight_scale, const float* bias, int C, int H, int De, int Cp, int Dp,
+                             float* plain, void* stream);
 int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
                            const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T, int64_t N,
                            int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr,

@@ -949,3 +949,25 @@ def test_bf16_row_storage_refuses_unsupported_shapes(device):
     conv = layer.TripletMessage(30, 4).to(device)          # Cp = 32: no bf16 variant of the 8-lane kernels
     with ops.feature_storage("bf16"), pytest.raises(ops.GlamHipError):
         conv(torch.randn(b.x.size(0), 30, device=device), b.edge_index, b.edge_attr)
+
+
+def test_triplet_four_heads_wide_fallback(device):
+    """heads = 4 at C = 90 (H*Cp + 8 = 376) is beyond the one-node wide path: torch-sequenced fallback (library GEMMs for the
+    data-side products, k_wgrad weight gradients through ops.matmul_tall) around the same aggregate kernels."""
+    torch.manual_seed(77)
+    b = synth_batch(48, seed=3)
+    C, H = 90, 4
+    assert not ops.wide_layer_supported(C, H, 4) and ops.wide_layer_supported(C, 3, 4)
+    x0 = torch.randn(b.x.size(0), C)
+    conv = layer.TripletMessage(C, 4, heads=H)
+    ps0 = [p.detach().clone().requires_grad_(True) for p in conv.parameters()]
+    xo = x0.clone().requires_grad_(True)
+    ref = O.triplet_message(xo, b.edge_index, b.edge_attr, *ps0, heads=H)
+    cot = torch.randn(ref.shape)
+    g_ref = _grads(ref, cot, [xo] + ps0)
+    conv = conv.to(device)
+    x = x0.to(device).requires_grad_(True)
+    out = conv(x, b.edge_index.to(device), b.edge_attr.to(device))
+    assert_close(out, ref, TOL, "out")
+    for n, a, r in zip(["x"] + [n for n, _ in conv.named_parameters()], _grads(out, cot.to(device), [x] + list(conv.parameters())), g_ref):
+        assert_close(a, r, 3e-5, f"grad.{n}")

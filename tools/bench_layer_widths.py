@@ -8,7 +8,7 @@ from glam_amd.data import synth_batch
 
 dev = torch.device("cuda:0")
 b = synth_batch(1024, seed=0).to(dev)
-for alpha in [1, 2, 3, 4, 6]:
+for alpha in ([int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 6]):
     C = 15 * alpha
     torch.manual_seed(0)
     conv = layer.TripletMessage(C, 4).to(dev)
