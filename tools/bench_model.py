@@ -5,7 +5,7 @@ src_1gp/trainer.py:286-298).  Not the headline metric (bench.py is)."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from glam_amd import model
+from glam_amd import model, ops
 from glam_amd.data import synth_batch
 
 ap = argparse.ArgumentParser()
@@ -14,15 +14,19 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--norm", default="_None")
 ap.add_argument("--block", default="_TripletMessage")
 ap.add_argument("--readout", default="GlobalPool5")
+ap.add_argument("--alpha", type=int, default=4, help="hid_dim_alpha (hidden width = 15 * alpha)")
+ap.add_argument("--out-dim", type=int, default=1)
+ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"])
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
-net = model.Architecture(mol_block=args.block, message_steps=3, mol_readout=args.readout, graph_norm=args.norm,
+ops.FEATURE_STORAGE = args.storage
+net = model.Architecture(hid_dim_alpha=args.alpha, out_dim=args.out_dim, mol_block=args.block, message_steps=3, mol_readout=args.readout, graph_norm=args.norm,
                          graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
 b = synth_batch(args.batch, seed=0).to(dev)
-y = b.y.view(-1)
+y = b.y.view(-1) if args.out_dim == 1 else torch.randn(args.batch, args.out_dim, device=dev).view(-1)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=os.environ.get("GLAM_FUSED_ADAM", "1") == "1")
 
 def body():
@@ -44,6 +48,7 @@ for _ in range(10): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"workload": f"Architecture({args.block}, 3 steps, {args.readout}, e_dim=1024, norm={args.norm}) fwd+bwd+Adam, B={args.batch}",
+print(json.dumps({"workload": f"Architecture({args.block}, hid_dim_alpha={args.alpha}, 3 steps, {args.readout}, e_dim=1024, norm={args.norm}, "
+                              f"out_dim={args.out_dim}, rows={args.storage}) fwd+bwd+Adam, B={args.batch}",
                   "launch": "eager" if g is None else "hipGraph", "ms_per_step": dt / args.steps * 1e3,
                   "molecules_per_s": args.batch * args.steps / dt}))
