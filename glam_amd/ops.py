@@ -581,8 +581,11 @@ def linear(x, weight, bias=None):
     if Kp != K:
         x = torch.nn.functional.pad(x, (0, Kp - K))
     if Kp != K or Mp != M:
-        weight = torch.nn.functional.pad(weight, (0, Kp - K, 0, Mp - M))
-        bias = None if bias is None else torch.nn.functional.pad(bias, (0, Mp - M))
+        # padded once per model pass (the block's linears are applied message_steps times), like every derived weight
+        w0, b0 = weight, bias
+        weight, bias = scoped_weights(("lin-pad", id(w0), None if b0 is None else id(b0)), w0, lambda: (
+            torch.nn.functional.pad(w0, (0, Kp - K, 0, Mp - M)),
+            None if b0 is None else torch.nn.functional.pad(b0, (0, Mp - M))))
     y = _Linear.apply(x, weight, bias)
     return y[:, :M] if Mp != M else y
 
