@@ -110,10 +110,9 @@ class TripletMessage(MessagePassing):
             edge_attr = F.pad(edge_attr, (0, Dp - edge_attr.size(1)))
         if ops.fused_layer_supported(C, self.heads, De):
             # whole layer in HIP: staging, MFMA node GEMM, fused aggregate, MFMA update (+ its backward)
-            x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
-            out = ops.triplet_layer(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,
+            out = ops.triplet_layer(ops.pad_cols(x, Cp), edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,
                                     self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
-            return out[:, :C] if Cp != C else out
+            return ops.slice_cols(out, C)                # pad columns are exactly zero (zero-padded W_scale / bias)
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
         if ops.FEATURE_STORAGE == "bf16":
             raise GlamHipError("TripletMessage: bf16 row storage covers node_channels 33..64 (the fused kernels)")

@@ -131,6 +131,43 @@ def _scoped(table, key, owner, build):
     table[key] = (owner, val)
     return val
 
+# ---- zero-padded column layout of odd-width features (hid_dim 15 / 30 / 45 / 90: C % 4 != 0) ----------------------
+# The kernels work on rows of Cp = ceil4(C) floats.  An op that produced a padded [N, Cp] tensor whose pad columns are
+# zero hands the caller the [N, C] VIEW of it (slice_cols) and remembers the padded tensor; when that view comes back as
+# the input of the next op (conv -> GRU -> next message step), pad_cols returns the padded tensor itself instead of
+# copying: the per-step pad / slice glue of the odd widths disappears without changing any module interface.
+_PADDED: dict = {}      # data_ptr -> (weakref(padded tensor), its version counter at registration)
+
+
+def slice_cols(x_p, C):
+    """``x_p[:, :C]`` of a padded tensor whose columns ``C..`` are zero (the caller guarantees it)."""
+    if x_p.size(1) == C:
+        return x_p
+    key = x_p.data_ptr()
+
+    def _drop(ref, k=key):
+        hit = _PADDED.get(k)
+        if hit is not None and hit[0] is ref:
+            _PADDED.pop(k, None)
+    _PADDED[key] = (weakref.ref(x_p, _drop), x_p._version)
+    return x_p[:, :C]
+
+
+def pad_cols(x, Cp):
+    """``x[N, C]`` zero-padded to ``Cp`` columns: the registered padded tensor when ``x`` is its untouched view, else one
+    ``F.pad`` per tensor and model pass."""
+    if x.size(1) == Cp:
+        return x
+    hit = _PADDED.get(x.data_ptr())
+    if hit is not None:
+        base = hit[0]()
+        if base is not None and base._version == hit[1] and x.dim() == 2 and base.shape == (x.size(0), Cp) and \
+                x.stride() == (Cp, 1) and base.data_ptr() == x.data_ptr() and base.dtype == x.dtype:
+            return base
+    C = x.size(1)
+    return _scoped(_SCOPE.fwd if _SCOPE else None, ("pad-cols", id(x), Cp), x, lambda: torch.nn.functional.pad(x, (0, Cp - C)))
+
+
 _GI_CACHE: dict = {}
 
 
@@ -579,7 +616,7 @@ def linear(x, weight, bias=None):
         return torch.nn.functional.linear(x, weight, bias)
     Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
     if Kp != K:
-        x = torch.nn.functional.pad(x, (0, Kp - K))
+        x = pad_cols(x, Kp)
     if Kp != K or Mp != M:
         # padded once per model pass (the block's linears are applied message_steps times), like every derived weight
         w0, b0 = weight, bias
@@ -587,7 +624,7 @@ def linear(x, weight, bias=None):
             torch.nn.functional.pad(w0, (0, Kp - K, 0, Mp - M)),
             None if b0 is None else torch.nn.functional.pad(b0, (0, Mp - M))))
     y = _Linear.apply(x, weight, bias)
-    return y[:, :M] if Mp != M else y
+    return slice_cols(y, M)                    # pad columns are x @ 0 + 0
 
 
 class _LinearSplit(torch.autograd.Function):
@@ -705,8 +742,22 @@ ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3}
 def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False):
     """``h_new = GRU(celu(x) if celu_in else x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:261-266):
     the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
-    if gru_block_supported(h.size(1), w_ih, b_ih, b_hh):
+    C = h.size(1)
+    if gru_block_supported(C, w_ih, b_ih, b_hh):
         return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in)
+    Cp = (C + 3) // 4 * 4
+    if Cp != C and b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_supported(Cp, 3 * Cp) \
+            and 3 * Cp > 64:
+        # odd widths: the same node at Cp with gate-wise zero-padded weights (built once per model pass).  Pad channels
+        # stay exactly zero through the step: gates r = z = 1/2, n = tanh(0) = 0, h' = z * 0 = 0, act(0 + 0) = 0.
+        def build():
+            pw = lambda w: torch.nn.functional.pad(w.view(3, C, C), (0, Cp - C, 0, Cp - C)).reshape(3 * Cp, Cp)
+            pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
+            return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
+        wi, wh, bi, bh = scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build)
+        out_p, hn_p = _GruBlock.apply(pad_cols(x, Cp), pad_cols(h, Cp), None if identity is None else pad_cols(identity, Cp),
+                                      wi, wh, bi, bh, ACT_CODES[act], slope, celu_in)
+        return slice_cols(out_p, C), slice_cols(hn_p, C)
     if celu_in:
         x = torch.celu(x)
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)

@@ -971,3 +971,40 @@ def test_triplet_four_heads_wide_fallback(device):
     assert_close(out, ref, TOL, "out")
     for n, a, r in zip(["x"] + [n for n, _ in conv.named_parameters()], _grads(out, cot.to(device), [x] + list(conv.parameters())), g_ref):
         assert_close(a, r, 3e-5, f"grad.{n}")
+
+
+@pytest.mark.parametrize("alpha,act,block", [(1, "ReLU", "_TripletMessage"), (2, "ReLU", "_TripletMessage"), (3, "CELU", "_TripletMessage"),
+                                             (6, "ReLU", "_TripletMessage"), (3, "ReLU", "_NNConv"), (2, "LeakyReLU", "_TripletMessageLight")])
+def test_architecture_odd_widths_vs_oracle(device, alpha, act, block):
+    """hid_dim_alpha of the search space (glam.py:60) whose hidden width is not a multiple of 4: features travel between the
+    conv and the GRU step as zero-padded rows handed on by reference (ops.pad_cols / slice_cols); outputs and every parameter
+    gradient against the oracle's full model."""
+    torch.manual_seed(40 + alpha)
+    b = synth_batch(24, seed=alpha)
+    net = model.Architecture(hid_dim_alpha=alpha, e_dim=64, out_dim=2, message_steps=3, mol_block=block, mol_readout="GlobalPool5",
+                             graph_norm="_None", pre_act=act, graph_act=act, flat_act=act, graph_do="_None()", end_do="_None()").eval()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref = O.architecture(sd, b, b.num_graphs, message_steps=3, mol_block=block, mol_readout="GlobalPool5", graph_norm="_None",
+                         pre_act=act, graph_act=act, flat_act=act)
+    cot = torch.randn(ref.shape)
+    names = [n for n, _ in net.named_parameters()]
+    g_ref = _grads(ref, cot, [sd[n] for n in names])
+    net = net.to(device)
+    out = net(b.to(device))
+    assert_close(out, ref, 2e-5, "out")
+    for n, a, r in zip(names, _grads(out, cot.to(device), [p for _, p in net.named_parameters()]), g_ref):
+        assert_close(a, r, 1e-4, f"grad.{n}")
+
+
+def test_padded_views_are_not_trusted_after_inplace_writes(device):
+    """ops.pad_cols only reuses a registered padded tensor while nobody wrote to it (version counter)."""
+    xp = torch.zeros(8, 48, device=device)
+    xp[:, :45] = torch.randn(8, 45, device=device)
+    v = ops.slice_cols(xp, 45)
+    assert ops.pad_cols(v, 48) is xp
+    v.add_(1.0)                                             # pad columns may no longer be what the producer left
+    p = ops.pad_cols(v, 48)
+    assert p is not xp and torch.equal(p[:, :45], v) and (p[:, 45:] == 0).all()
+    w = torch.randn(8, 48, device=device)[:, :45]           # a view nobody registered
+    q = ops.pad_cols(w, 48)
+    assert q.data_ptr() != w.data_ptr() and (q[:, 45:] == 0).all()
