@@ -504,10 +504,10 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm: workspace too small");
     GLAM_REQUIRE(aligned16(Q) && aligned16(P1) && aligned16(P2), "glam_wgrad_gemm: P / Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-    if (J > 64 && J <= 128 && !qones && (J & 3) == 0) {
-        // two column chunks of Q (64 | J - 64) as the two products of one launch: G[:, :64] and G[:, 64:]
+    if (J > 64 && J + (qones ? 1 : 0) <= 128 && (J & 3) == 0) {
+        // two column chunks of Q (64 | J - 64 [| 1]) as the two products of one launch: G[:, :64] and G[:, 64:]
         WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, 64, ldq, 0, (int)N, 0, partial, 0, 0};
-        WgArgs b{P1, I1, ldp1, P2, I2, ldp2, ones, Q + 64, J - 64, ldq, 0, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0};
+        WgArgs b{P1, I1, ldp1, P2, I2, ldp2, ones, Q + 64, J - 64, ldq, qones, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0};
         ReduceArgs rb{};
         rb.njobs = 2;
         if (int rc = launch_wgrad_partials2(a, out, stride_i, stride_j, &rb.job[0], b, out + (size_t)64 * stride_j, stride_i, stride_j,

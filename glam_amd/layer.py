@@ -116,11 +116,11 @@ class TripletMessage(MessagePassing):
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
         if ops.FEATURE_STORAGE == "bf16":
             raise GlamHipError("TripletMessage: bf16 row storage covers node_channels 33..64 (the fused kernels)")
-        x_p = F.pad(x, (0, Cp - C)) if Cp != C else x
+        x_p = ops.pad_cols(x, Cp)
         if ops.wide_layer_supported(C, self.heads, De):
             out = ops.triplet_layer_wide(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,
                                          self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
-            return out[:, :C] if Cp != C else out
+            return ops.slice_cols(out, C)
         Wn, Wa, We, M, Ws, Cp, Dp = ops.scoped_weights(("triplet-derived", id(self.weight_node)), self.weight_node,
                                                        self._staged_wide)
         # every N-deep weight gradient of this path runs on k_wgrad (ops.matmul_tall: the library's heuristics give those

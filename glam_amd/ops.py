@@ -607,6 +607,37 @@ def matmul_tall(a, w):
     return torch.matmul(a, w)
 
 
+class _LinearTall(torch.autograd.Function):
+    """``y = x @ w^T + b`` for layer widths beyond the MFMA forward table (e.g. the GRU gate linears 92 -> 276 of
+    hid_dim_alpha = 6): the data-side products on the library GEMM, ``[d_w | d_b] = dy^T [x | 1]`` on ``k_wgrad``."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        x, w, b = f32c(x, "x"), f32c(w, "weight"), f32c(b, "bias")
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        dx = torch.matmul(dy, w) if ctx.needs_input_grad[0] else None
+        lib = _lib.load()
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        dwb = torch.empty(M, K + 1, dtype=torch.float32, device=x.device)
+        check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(), stream()),
+              "glam_wgrad_gemm")
+        return dx, dwb[:, :K], dwb[:, K]
+
+
+def linear_tall_supported(K, M):
+    return K % 4 == 0 and M % 4 == 0 and M <= 320 and K + 1 <= 128
+
+
 def linear(x, weight, bias=None):
     """``F.linear`` on the hand-written MFMA kernels when the shape is in their table (the layer-sized linears of the
     path: GRU gates 60->180, input embedding 15->60, ...); larger / odd layers (e.g. the 300->1024 readout MLP) stay
@@ -757,6 +788,20 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
         wi, wh, bi, bh = scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build)
         out_p, hn_p = _GruBlock.apply(pad_cols(x, Cp), pad_cols(h, Cp), None if identity is None else pad_cols(identity, Cp),
                                       wi, wh, bi, bh, ACT_CODES[act], slope, celu_in)
+        return slice_cols(out_p, C), slice_cols(hn_p, C)
+    if b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_tall_supported(Cp, 3 * Cp) and h.size(0) >= 64:
+        # wide GRU (hid_dim_alpha = 6): library GEMMs for the gate products, k_wgrad for their weight gradients, at Cp
+        def build_wide():
+            pw = lambda w: torch.nn.functional.pad(w.view(3, C, C), (0, Cp - C, 0, Cp - C)).reshape(3 * Cp, Cp)
+            pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
+            return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
+        wi, wh, bi, bh = scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build_wide) if Cp != C else \
+            (w_ih, w_hh, b_ih, b_hh)
+        x_p, h_p = pad_cols(x, Cp), pad_cols(h, Cp)
+        if celu_in:
+            x_p = torch.celu(x_p)
+        out_p, hn_p = _GruTail.apply(_LinearTall.apply(x_p, wi, bi), _LinearTall.apply(h_p, wh, bh), h_p,
+                                     None if identity is None else pad_cols(identity, Cp), ACT_CODES[act], slope)
         return slice_cols(out_p, C), slice_cols(hn_p, C)
     if celu_in:
         x = torch.celu(x)

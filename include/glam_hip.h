@@ -154,8 +154,8 @@ int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_
  *                    K1+K2 <= 192 with M <= 64, or K1+K2 <= 64 with M <= 192.
  *   glam_wgrad_gemm: out[i*stride_i + j*stride_j] = sum_n [P1 | P2 | 1][n, i] * [Q | 1][n, j]  (reduction over the
  *                    N rows; `ones` / `qones` append an all-ones column on either side, i.e. the bias gradient);
- *                    I <= 320 (five 64-column slabs), J <= 64 (ones columns included); without qones also
- *                    64 < J <= 128, computed as two column chunks in one launch. */
+ *                    I <= 320 (five 64-column slabs), J <= 64 (ones columns included); also 64 < J (+ qones) <= 128,
+ *                    computed as two column chunks in one launch. */
 size_t glam_ts_gemm_image_bytes(int K, int M);
 int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, float* img, void* stream);
 int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
