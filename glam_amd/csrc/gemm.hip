@@ -6,7 +6,8 @@
 // weights of at most 192 x 64 / 64 x 192.  Library GEMMs pick tiles for square problems and ran 12-73 us
 // per call here (profiles/r1a_*); two purpose-built kernels replace them:
 //
-//   k_ts_gemm   C[N, M] = [A1 | A2][N, K] @ W[K, M] (+ bias); (K <= 64, M <= 192) or (K <= 192, M <= 64).
+//   k_ts_gemm   C[N, M] = [A1 | A2][N, K] @ W[K, M] (+ bias); (K <= 64, M <= 192), (K <= 192, M <= 64) and two wide variants
+//               (ts_variant).
 //               W (zero padded, pre-permuted "image") lives in LDS for the whole 8-wave block; a wave owns
 //               16 rows and ALL M columns (MT accumulator tiles, <= 48 AGPRs); its whole A fragment is
 //               loaded up front (one float4 per 16 k-values: lane (r, kq) supplies k = 16g + 4kq + j at
@@ -332,20 +333,34 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
 // ------------------------------------------------------------------------------------------------
 // host-side launchers (shared with layer.hip)
 // ------------------------------------------------------------------------------------------------
+// Kernel variants <MT, GMAX> (column tiles of 16, k-groups of 16) by shape; make_image and the GEMM agree through this:
+//   0: M <= 64,  K <= 192   <4, 12>    48 KB image         2: K <= 96,  M <= 320   <20, 6>   120 KB  (hid_dim_alpha = 6:
+//   1: K <= 64,  M <= 192   <12, 4>    48 KB                                                           92 -> 276 + 8)
+// (a <8, 18> variant for K <= 288, M <= 128 was measured at 28.8 us against the library GEMM's 19.2 us for 276 -> 92 at
+//  N = 20.7 k — a 144 KB image per block and 1.26 items per wave — and is not kept)
+static int ts_variant(int K, int M) {
+    if (M <= 0 || K <= 0) return -1;
+    if (M <= 64 && K <= 192) return 0;
+    if (K <= 64 && M <= 192) return 1;
+    if (K <= 96 && M <= 320) return 2;
+    return -1;
+}
+static int ts_mt(int variant) { return variant == 0 ? 4 : variant == 1 ? 12 : 20; }
+
 size_t ts_image_floats(int K, int M) {
-    const int Kp = (K + 15) & ~15;
-    return (size_t)Kp * (M <= 64 ? 64 : 192);
+    const int Kp = (K + 15) & ~15, v = ts_variant(K, M);
+    return (size_t)Kp * 16 * ts_mt(v < 0 ? 1 : v);
 }
 
 static int ts_shape_ok(const char* fn, int K, int M) {
-    if (M <= 0 || K <= 0 || M > 192 || K > 192 || (M > 64 && K > 64))
-        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d (K <= 192 needs M <= 64; M <= 192 needs K <= 64)", fn, K, M);
+    if (ts_variant(K, M) < 0)
+        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d outside the kernel table (K<=192,M<=64 | K<=64,M<=192 | K<=96,M<=320)", fn, K, M);
     return GLAM_OK;
 }
 
 int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, float* img, hipStream_t s) {
     if (int rc = ts_shape_ok("ts_gemm image", K, M)) return rc;
-    const int MT = M <= 64 ? 4 : 12;
+    const int MT = ts_mt(ts_variant(K, M));
     hipLaunchKernelGGL(k_ts_make_image, dim3(grid_for((int64_t)ts_image_floats(K, M), kBlock)), dim3(kBlock), 0, s, W, ldw,
                        transW, K, M, MT, img);
     GLAM_LAUNCH_CHECK("ts_make_image");
@@ -361,11 +376,22 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
         return fail(GLAM_E_UNSUPPORTED, "ts_gemm: K=%d+%d M=%d+%d and leading dimensions must be multiples of 4", a.K1, a.K2, a.M1, a.M2);
     const size_t lds = ts_image_floats(K, M) * sizeof(float);
     const int ntiles = (a.N + 15) / 16;
-    const int nitems = M <= 64 ? ntiles : ntiles * 3;   // K <= 192 x 64 columns: splitting would re-read the long A rows
+    const int variant = ts_variant(K, M);
+    // column splits per row tile (MT / TPI).  K <= 192 x 64 columns: splitting would re-read the long A rows
+    const int nitems = ntiles * (variant == 0 ? 1 : variant == 1 ? 3 : 5);
     int grid = (nitems + 7) / 8;
     if (grid > 256) grid = 256;          // one 8-wave block per CU, items dealt round-robin over every wave of the grid
-    if (M <= 64) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
-    else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    else {
+        if (a.out1_bf16) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: bf16 output is limited to the 48 KB-image variants");
+        static bool big2 = false;      // > 64 KB of dynamic LDS is opted into once
+        if (!big2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ts_gemm<20, 6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            big2 = true;
+        }
+        hipLaunchKernelGGL((k_ts_gemm<20, 6, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    }
     GLAM_LAUNCH_CHECK("ts_gemm");
     return GLAM_OK;
 }

@@ -425,14 +425,23 @@ class _TripletLayerWide(torch.autograd.Function):
                                                stream()), "glam_triplet_stage_plain")
             return buf
 
-        plain = _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet-plain", id(wn), id(we), id(att), id(wsc), id(bias)), wn, build)
+        scope = _SCOPE
+        plain = _scoped(scope.fwd if scope else None, ("triplet-plain", id(wn), id(we), id(att), id(wsc), id(bias)), wn, build)
         Wcat, Ws_p, We_p, M, bias_p = _plain_views(plain, H, Cp, Dp)
-        xw = torch.matmul(x_p, Wcat[:, :HC])                               # layer.py:37
-        a_ij = torch.matmul(x_p, Wcat[:, HC:])                             # separable attention scalars a_i | a_j
-        aggr, stats = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
+        xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
+        aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
+        mfma = _wide_gemms_supported(H, Cp)
+        st = stream()
+        if mfma:     # the 120 KB-image k_ts_gemm variant: xw and a_ij in one launch
+            img1 = _scoped(scope.fwd if scope else None, ("wide-img-node", id(wn)), wn, lambda: _ts_image(Wcat, Cp, HC + 8, False))
+            check(lib.glam_ts_gemm(ptr(x_p), Cp, Cp, None, 0, 0, ptr(img1), None, ptr(xw), HC, HC, ptr(a_ij), 8, 8, N, st), "glam_ts_gemm")
+        else:
+            torch.matmul(x_p, Wcat[:, :HC], out=xw)                        # layer.py:37
+            torch.matmul(x_p, Wcat[:, HC:], out=a_ij)                      # separable attention scalars a_i | a_j
         check(lib.glam_triplet_fwd(ptr(xw), ptr(a_ij), ptr(ea_p), ptr(We_p), ptr(M), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
-                                   N, gi.E, H, Cp, Dp, 1, float(slope), ptr(aggr), ptr(stats), stream()), "glam_triplet_fwd")
-        out = torch.addmm(bias_p, aggr, Ws_p)                              # layer.py:57-61
+                                   N, gi.E, H, Cp, Dp, 1, float(slope), ptr(aggr), ptr(stats), st), "glam_triplet_fwd")
+        torch.addmm(bias_p, aggr, Ws_p, out=out)                           # layer.py:57-61 (276 -> 92: the library GEMM wins)
+        ctx.scope = scope
         ctx.save_for_backward(x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
         return out
@@ -454,7 +463,14 @@ class _TripletLayerWide(torch.autograd.Function):
         o_we = (o_wsb + (HC + 1) * Cp + 3) // 4 * 4
         o_m = o_we + Dp * HC
         dstaged = torch.empty(lib.glam_triplet_dstaged_floats(H, Cp, Dp), **f)
-        d_aggr = torch.matmul(d_out, Ws_p.t())
+        mfma = _wide_gemms_supported(H, Cp)
+        scope = ctx.scope
+        if mfma:
+            img3 = _scoped(scope.bwd if scope else None, ("wide-img-dagg", id(wn)), wn, lambda: _ts_image(Ws_p, Cp, HC, True))
+            d_aggr = torch.empty(N, HC, **f)
+            check(lib.glam_ts_gemm(ptr(d_out), Cp, Cp, None, 0, 0, ptr(img3), None, ptr(d_aggr), HC, HC, None, 0, 0, N, stream()), "glam_ts_gemm")
+        else:
+            d_aggr = torch.matmul(d_out, Ws_p.t())
         d_xw, d_a = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
         d_ea = torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None
         ws = torch.empty(lib.glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=dev)
@@ -478,6 +494,18 @@ class _TripletLayerWide(torch.autograd.Function):
         return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
 
 
+def _wide_gemms_supported(H, Cp):
+    return Cp <= 96 and H * Cp + 8 <= 320
+
+
+def _ts_image(W, K, M, transposed):
+    """k_ts_gemm weight image of the logical ``[K, M]`` matrix ``W`` (or ``W^T`` of the stored ``[M, K]`` matrix)."""
+    lib = _lib.load()
+    img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, dtype=torch.float32, device=W.device)
+    check(lib.glam_ts_gemm_make_image(ptr(W), W.stride(0), int(transposed), K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+    return img
+
+
 def _plain_views(plain, H, Cp, Dp):
     HC = H * Cp
     n1, n2, n3, n4 = Cp * (HC + 8), HC * Cp, Dp * HC, Dp * 4
@@ -499,7 +527,7 @@ def triplet_layer_wide(x_p, ea_p, weight_node, weight_edge, att, weight_scale, b
 # dense linear on the fp32 matrix cores + GRU gate math (MessageBlock remainder)
 # --------------------------------------------------------------------------------------
 def linear_supported(K, M):
-    """Shapes the tall-skinny MFMA kernels cover: (K <= 64, M <= 192) or (K <= 192, M <= 64), with room for the bias
+    """Shapes the tall-skinny MFMA kernels cover in both directions (gemm.hip: ts_variant 0 / 1) with room for the bias
     ones-column in the weight-gradient kernel."""
     Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
     return (Kp <= 60 and Mp <= 192) or (Kp <= 188 and Mp <= 64)
@@ -616,6 +644,14 @@ class _LinearTall(torch.autograd.Function):
         require_device(x, w, b)
         x, w, b = f32c(x, "x"), f32c(w, "weight"), f32c(b, "bias")
         ctx.save_for_backward(x, w)
+        N, K = x.shape
+        M = w.size(0)
+        if K <= 96 and M <= 320:       # the 120 KB-image k_ts_gemm variant (24 vs 29 us for 92 -> 276 at N = 20.7 k)
+            lib = _lib.load()
+            img = _scoped(_SCOPE.fwd if _SCOPE else None, ("lin", id(w)), w, lambda: _ts_image(w, K, M, True))
+            y = torch.empty(N, M, dtype=torch.float32, device=x.device)
+            check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
+            return y
         return torch.addmm(b, x, w.t())
 
     @staticmethod
@@ -888,8 +924,8 @@ class _GruBlock(torch.autograd.Function):
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):
-    return C % 4 == 0 and linear_supported(C, 3 * C) and 3 * C > 64 and b_ih is not None and b_hh is not None and \
-        tuple(w_ih.shape) == (3 * C, C)
+    return C % 4 == 0 and C + 1 <= 64 and linear_supported(C, 3 * C) and 3 * C > 64 and b_ih is not None and b_hh is not None and \
+        tuple(w_ih.shape) == (3 * C, C)        # C + 1 <= 64: both weight gradients in ONE k_wgrad launch
 
 
 def gru_step(x, h, w_ih, w_hh, b_ih, b_hh):
