@@ -116,19 +116,32 @@ def cpu_baseline(batch_cpu, conv_cpu, x_cpu, cot_cpu, budget_s):
         out = O.triplet_message(x, batch_cpu.edge_index, batch_cpu.edge_attr, *ps)
         torch.autograd.grad((out * cot_cpu).sum(), [x] + ps)
 
-    for _ in range(2):
-        step()
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or reps >= 200:
-            break
+    # torch's CPU kernels on this path (index_select / scatter / small GEMMs) do not scale to every core of a big host:
+    # time a few thread counts inside the budget and report the FASTEST as the baseline (with the count it used).
+    avail = torch.get_num_threads()
+    counts = sorted({c for c in (8, 32, avail) if c <= avail})
     B = int(batch_cpu.batch[-1]) + 1
-    return {"value": B * reps / dt, "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} fwd+bwd steps of the same B={B} batch in {dt:.1f} s (oracle/glam_oracle.py, torch CPU fp32)",
-            "ms_per_step": dt / reps * 1e3}
+    runs = {}
+    for c in counts:
+        torch.set_num_threads(c)
+        for _ in range(2):
+            step()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s / len(counts) or reps >= 200:
+                break
+        runs[c] = (reps, dt)
+    torch.set_num_threads(avail)
+    best = min(runs, key=lambda c: runs[c][1] / runs[c][0])
+    reps, dt = runs[best]
+    return {"value": B * reps / dt, "unit": "molecules/s", "cores": best, "kind": "port",
+            "sample": f"{reps} fwd+bwd steps of the same B={B} batch in {dt:.1f} s (oracle/glam_oracle.py, torch CPU fp32); "
+                      f"fastest of {counts} threads on a {os.cpu_count()}-cpu host",
+            "ms_per_step": dt / reps * 1e3,
+            "ms_per_step_by_threads": {str(c): runs[c][1] / runs[c][0] * 1e3 for c in counts}}
 
 
 def main():
