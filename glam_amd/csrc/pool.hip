@@ -64,6 +64,89 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd(const float* x, const int*
     }
 }
 
+// Wave-per-graph, D % 4 == 0 and D <= 64 (every hidden width in padded form; the readout of the default model): the
+// kernel above is a chain of ~3 n/4 dependent round trips per graph (22 us for 20-atom molecules at ANY batch size).
+// Here a lane owns (row group rg = lane / 16, float4 column chunk c4 = lane % 16): all row loads of a graph are in
+// flight together; the top-K rows come from per-lane candidates merged by K rounds of a wave-wide arg-max
+// (value descending, node index ascending on ties: the stable order of the serial kernel).
+__global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const int* ptr, int B, int D, int K, float* out,
+                                                        int* topk_idx) {
+    const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int OD = (2 + K) * D;
+    const bool act = 4 * c4 < D;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        // candidates: lane l holds the top-K of nodes beg + l, beg + l + 64, ...
+        float tv[kMaxK];
+        int ti[kMaxK];
+#pragma unroll
+        for (int r = 0; r < kMaxK; ++r) { tv[r] = -INFINITY; ti[r] = 0x7fffffff; }
+        for (int n = beg + lane; n < end; n += 64) {
+            float v = x[(size_t)n * D + (D - 1)];
+            int vi = n;
+#pragma unroll
+            for (int r = 0; r < kMaxK; ++r) {
+                if (r < K) {
+                    const bool take = v > tv[r] || (v == tv[r] && vi < ti[r]);
+                    if (take) { const float ov = tv[r]; const int oi = ti[r]; tv[r] = v; ti[r] = vi; v = ov; vi = oi; }
+                }
+            }
+        }
+        // column sums: 8 rows of this lane's row group in flight per step
+        float4 acc = f4zero();
+        if (act) {
+            int n = beg + rg;
+            for (; n + 28 < end; n += 32) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld4(x + (size_t)(n + 4 * u) * D + 4 * c4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; n < end; n += 4) {
+                const float4 v = ld4(x + (size_t)n * D + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+        }
+        float* o = out + (size_t)g * OD;
+        const float inv_cnt = 1.f / (float)max(end - beg, 1);
+        if (act && rg == 0) {
+            st4(o + 4 * c4, inv_cnt * acc);
+            st4(o + D + 4 * c4, acc);
+        }
+        // K rounds of wave-wide arg-max over the lanes' best remaining candidate
+#pragma unroll
+        for (int r = 0; r < kMaxK; ++r) {
+            if (r < K) {
+                float bv = tv[0];
+                int bi = ti[0];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(bv, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                const int sel = bi == 0x7fffffff ? -1 : bi;
+                if (sel >= 0 && ti[0] == bi) {           // the owner pops its list
+#pragma unroll
+                    for (int q = 0; q + 1 < kMaxK; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+                    tv[kMaxK - 1] = -INFINITY; ti[kMaxK - 1] = 0x7fffffff;
+                }
+                if (act && rg == (r & 3))
+                    st4(o + (2 + r) * D + 4 * c4, sel >= 0 ? ld4(x + (size_t)sel * D + 4 * c4) : f4zero());
+                if (lane == 0) topk_idx[(size_t)g * K + r] = sel;
+            }
+        }
+    }
+}
+
 // Block-per-graph variant for graphs of hundreds of nodes (proteins): the wave-per-graph kernel above walks a graph's
 // nodes serially, fine for 20 atoms, a chain of 500 dependent round trips for 500 residues (0.55 ms per call with only
 // B = 32 waves on the chip).  256 threads split the rows; D % 4 == 0 and D <= 64.
@@ -460,6 +543,8 @@ extern "C" int glam_pool5_fwd(const float* x, const int32_t* ptr, int64_t N, int
     GLAM_REQUIRE(ptr && out && topk_idx && (N == 0 || x), "glam_pool5_fwd: null pointer");
     if (N / B >= 64 && (D & 3) == 0 && D <= 64)      // large graphs: a block per graph
         hipLaunchKernelGGL(k_pool5_fwd_block, dim3(grid_for(B, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
+    else if ((D & 3) == 0 && D <= 64)
+        hipLaunchKernelGGL(k_pool5_fwd_v4, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
     else
         hipLaunchKernelGGL(k_pool5_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
     GLAM_LAUNCH_CHECK("glam_pool5_fwd");
