@@ -91,7 +91,10 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
             for (int g = 0; g < GMAX; ++g) af[g] = celu4(af[g]);      // celu(0) = 0: the zero padding stays zero
         }
     };
-    int item = blockIdx.x * WPB + wave;
+    // Fewer items than wave slots (small batches; the 64-column variant at any batch): deal them block-minor, so that they
+    // spread over all blocks / CUs first and a SIMD runs one MFMA stream instead of two back to back.
+    const bool spread = nitems < gridDim.x * WPB;
+    int item = spread ? (int)blockIdx.x + wave * (int)gridDim.x : (int)blockIdx.x * WPB + wave;
     float4 af[GMAX];
     TS_STAMP(0);
     load_afrag(item, af);              // flies while the weight image is staged
@@ -379,7 +382,7 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
     const int variant = ts_variant(K, M);
     // column splits per row tile (MT / TPI).  K <= 192 x 64 columns: splitting would re-read the long A rows
     const int nitems = ntiles * (variant == 0 ? 1 : variant == 1 ? 3 : 5);
-    int grid = (nitems + 7) / 8;
+    int grid = nitems < 2048 ? nitems : (nitems + 7) / 8;   // < one item per wave slot: one block per item first (see `spread`)
     if (grid > 256) grid = 256;          // one 8-wave block per CU, items dealt round-robin over every wave of the grid
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
     else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
