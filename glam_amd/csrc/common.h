@@ -113,6 +113,16 @@ __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ void fma4(float4& acc, float s, float4 a) {
     acc.x = fmaf(s, a.x, acc.x); acc.y = fmaf(s, a.y, acc.y); acc.z = fmaf(s, a.z, acc.z); acc.w = fmaf(s, a.w, acc.w);
 }
+// fma4 spelled as two <2 x float> fmas: v_pk_fma_f32 (two fp32 lanes per instruction, same rounding).  The SLP vectoriser
+// finds these pairs by itself in the forward kernel (forcing them there costs registers: 10.4 vs 9.7 us) but leaves B1's
+// inner loop half scalar (231 v_fmac vs 120 v_pk_fma), and B1 is the kernel that is VALU bound.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma4_pk(float4& acc, float s, float4 a) {
+    const v2f sv = {s, s};
+    const v2f lo = __builtin_elementwise_fma(sv, (v2f){a.x, a.y}, (v2f){acc.x, acc.y});
+    const v2f hi = __builtin_elementwise_fma(sv, (v2f){a.z, a.w}, (v2f){acc.z, acc.w});
+    acc = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 

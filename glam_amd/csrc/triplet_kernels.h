@@ -456,8 +456,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
                             float4 e4 = f4zero();
 #pragma unroll
                             for (int kk = 0; kk < DE; ++kk) {
-                                fma4(e4, eav[k][kk], wv[kk]);
-                                fma4(dw[kk][h][it], eav[k][kk] * alpha[k][h], t);
+                                fma4_pk(e4, eav[k][kk], wv[kk]);
+                                fma4_pk(dw[kk][h][it], eav[k][kk] * alpha[k][h], t);
                             }
                             part[k] += dot4(t, e4);
                         } else {
