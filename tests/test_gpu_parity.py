@@ -1008,3 +1008,30 @@ def test_padded_views_are_not_trusted_after_inplace_writes(device):
     w = torch.randn(8, 48, device=device)[:, :45]           # a view nobody registered
     q = ops.pad_cols(w, 48)
     assert q.data_ptr() != w.data_ptr() and (q[:, 45:] == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["pair", "layer"])
+@pytest.mark.parametrize("D", [60, 32])
+def test_graph_norms_mixed_graph_sizes(device, kind, D):
+    """Wave-per-graph norm kernels at padded widths: graphs below and above the 32-node register pass, single-node graphs."""
+    torch.manual_seed(23)
+    sizes = [40, 3, 33, 50, 1, 32, 17]
+    N, B = sum(sizes), len(sizes)
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    x0 = torch.randn(N, D) * 1.5 - 0.3
+    xo = x0.clone().requires_grad_(True)
+    if kind == "pair":
+        ref = O.pair_norm(xo, batch, B)
+        mod = layer.PairNorm().to(device)
+    else:
+        w, b_ = torch.rand(D) + 0.5, torch.randn(D) * 0.1
+        ref = O.graph_layer_norm(xo, w, b_, batch, B)
+        mod = layer.LayerNorm(D).to(device)
+        with torch.no_grad():
+            mod.weight.copy_(w); mod.bias.copy_(b_)
+    cot = torch.randn(ref.shape)
+    (g_ref,) = _grads(ref, cot, [xo])
+    x = x0.to(device).requires_grad_(True)
+    out = mod(x, batch.to(device))
+    assert_close(out, ref, 2e-5, kind)
+    assert_close(_grads(out, cot.to(device), [x])[0], g_ref, 5e-5, kind + "/gx")
