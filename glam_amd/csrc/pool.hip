@@ -467,6 +467,69 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd(const float* d_out, co
 }
 
 
+// K in {4, 8}, D % 4 == 0 (NNConv's relation sums at the padded hidden widths): a thread per (node, float4 of channels),
+// the K weights of an edge as float4 loads, two edges in flight; same edge order and fma sequence as the scalar kernels.
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_edge_wsum_fwd_v4(const float* x, const float* w, const int* rowptr, const int* nbr,
+                                                            const int* eid, int N, int D, int mean, float* out) {
+    const int D4 = D >> 2;
+    const size_t total = (size_t)N * D4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int n = (int)(i / D4), c = 4 * (int)(i % D4);
+        const int beg = rowptr[n], end = rowptr[n + 1];
+        float4 acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = f4zero();
+        int e = beg;
+        for (; e + 1 < end; e += 2) {
+            const int s0 = nbr[e], s1 = nbr[e + 1], i0 = eid[e], i1 = eid[e + 1];
+            float4 w0[K / 4], w1[K / 4];
+#pragma unroll
+            for (int u = 0; u < K / 4; ++u) { w0[u] = ld4(w + (size_t)i0 * K + 4 * u); w1[u] = ld4(w + (size_t)i1 * K + 4 * u); }
+            const float4 v0 = ld4(x + (size_t)s0 * D + c), v1 = ld4(x + (size_t)s1 * D + c);
+#pragma unroll
+            for (int k = 0; k < K; ++k) fma4(acc[k], f4get(w0[k >> 2], k & 3), v0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) fma4(acc[k], f4get(w1[k >> 2], k & 3), v1);
+        }
+        if (e < end) {
+            const int i0 = eid[e];
+            const float4 v0 = ld4(x + (size_t)nbr[e] * D + c);
+#pragma unroll
+            for (int k = 0; k < K; ++k) fma4(acc[k], w[(size_t)i0 * K + k], v0);
+        }
+        const float sc = mean ? 1.f / (float)max(end - beg, 1) : 1.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) st4(out + ((size_t)n * K + k) * D + c, sc * acc[k]);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd_v4(const float* d_out, const float* w, const int* colptr, const int* dst,
+                                                            const int* eid_t, const int* rowptr, int N, int D, int mean,
+                                                            float* dx) {
+    const int D4 = D >> 2;
+    const size_t total = (size_t)N * D4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int j = (int)(i / D4), c = 4 * (int)(i % D4);
+        float4 acc = f4zero();
+        for (int e = colptr[j]; e < colptr[j + 1]; ++e) {
+            const int n = dst[e], id = eid_t[e];
+            const float sc = mean ? 1.f / (float)max(rowptr[n + 1] - rowptr[n], 1) : 1.f;
+            float4 wv[K / 4], g[K];
+#pragma unroll
+            for (int u = 0; u < K / 4; ++u) wv[u] = ld4(w + (size_t)id * K + 4 * u);
+#pragma unroll
+            for (int k = 0; k < K; ++k) g[k] = ld4(d_out + ((size_t)n * K + k) * D + c);
+            float4 t = f4zero();
+#pragma unroll
+            for (int k = 0; k < K; ++k) fma4(t, f4get(wv[k >> 2], k & 3), g[k]);
+            fma4(acc, sc, t);
+        }
+        st4(dx + (size_t)j * D + c, acc);
+    }
+}
+
 // K = 1, D % 4 == 0 (GCNConv's propagate on residue graphs): a thread per (node, float4 of channels), two edges in flight;
 // same edge order and fma sequence as the scalar kernels.
 __global__ void __launch_bounds__(kBlock) k_edge_wsum1_fwd_v4(const float* x, const float* w, const int* rowptr, const int* nbr,
@@ -658,7 +721,11 @@ extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t*
     if (K == 1 && (D & 3) == 0)
         hipLaunchKernelGGL(k_edge_wsum1_fwd_v4, dim3(grid_for(N * (D / 4), kBlock)), block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_fwd<1>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
-    else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    else if ((D & 3) == 0 && aligned16(x) && aligned16(w) && aligned16(out)) {
+        const dim3 g4(grid_for(N * (D / 4), kBlock));
+        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd_v4<4>, g4, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+        else hipLaunchKernelGGL(k_edge_wsum_fwd_v4<8>, g4, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+    } else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else hipLaunchKernelGGL(k_edge_wsum_fwd<8>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_fwd");
     return GLAM_OK;
@@ -676,7 +743,11 @@ extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int3
     if (K == 1 && (D & 3) == 0)
         hipLaunchKernelGGL(k_edge_wsum1_bwd_v4, dim3(grid_for(N * (D / 4), kBlock)), block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_bwd<1>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
-    else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    else if ((D & 3) == 0 && aligned16(d_out) && aligned16(w) && aligned16(dx)) {
+        const dim3 g4(grid_for(N * (D / 4), kBlock));
+        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd_v4<4>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+        else hipLaunchKernelGGL(k_edge_wsum_bwd_v4<8>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+    } else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else hipLaunchKernelGGL(k_edge_wsum_bwd<8>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd");
     return GLAM_OK;
