@@ -385,7 +385,9 @@ def test_full_size_pool5_checksum(big, device):
 @pytest.mark.parametrize("N,K1,K2,M1,M2,trans,bias", [
     (1000, 60, 0, 180, 8, 0, False), (1000, 180, 0, 60, 0, 0, True), (333, 60, 0, 180, 0, 1, False),
     (1, 180, 8, 60, 0, 1, False), (4099, 16, 0, 48, 8, 0, True), (17, 48, 8, 16, 0, 1, False), (0, 60, 0, 60, 0, 0, False),
-    (5000, 64, 0, 184, 8, 0, True), (700, 188, 0, 64, 0, 0, False)])
+    (5000, 64, 0, 184, 8, 0, True), (700, 188, 0, 64, 0, 0, False),
+    # the 120 KB-image variant of the wide layers (K <= 96, M <= 320), and a launch with fewer items than wave slots
+    (20400, 92, 0, 276, 8, 0, False), (900, 92, 0, 276, 0, 1, True), (3, 96, 0, 320, 0, 0, True), (40000, 180, 0, 60, 0, 0, True)])
 def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
@@ -414,7 +416,9 @@ def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
         assert_close(o2, ref[:, M1:], 2e-6, "ts_gemm out2")
 
 
-@pytest.mark.parametrize("N,I1,I2,ones,J", [(1000, 180, 0, 1, 60), (20400, 180, 8, 0, 60), (7, 48, 8, 0, 16), (1, 16, 0, 1, 16), (5000, 56, 8, 1, 64), (3000, 184, 4, 1, 64)])
+@pytest.mark.parametrize("N,I1,I2,ones,J", [(1000, 180, 0, 1, 60), (20400, 180, 8, 0, 60), (7, 48, 8, 0, 16), (1, 16, 0, 1, 16), (5000, 56, 8, 1, 64), (3000, 184, 4, 1, 64),
+                                            # 64 < J <= 128: two column chunks in one launch (wide layers)
+                                            (20400, 276, 8, 0, 92), (5000, 276, 0, 1, 92), (33, 300, 16, 1, 128)])
 def test_wgrad_gemm(device, N, I1, I2, ones, J):
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
@@ -1035,3 +1039,19 @@ def test_graph_norms_mixed_graph_sizes(device, kind, D):
     out = mod(x, batch.to(device))
     assert_close(out, ref, 2e-5, kind)
     assert_close(_grads(out, cot.to(device), [x])[0], g_ref, 5e-5, kind + "/gx")
+
+
+def test_wgrad_gemm_chunked_with_ones_column(device):
+    """[d_W | d_b] = dy^T [x | 1] with 64 < K + 1 <= 128: the ones column rides on the second column chunk."""
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(5)
+    N, M, K = 6000, 276, 92
+    dy, x = torch.randn(N, M, generator=g), torch.randn(N, K, generator=g)
+    ref = dy.double().t() @ torch.cat([x, torch.ones(N, 1)], 1).double()
+    ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    out = torch.full((M, K + 1), float("nan"), device=device)
+    dyd, xd = dy.to(device), x.to(device)
+    rc = lib.glam_wgrad_gemm(p(dyd), M, M, None, 0, 0, 0, p(xd), K, K, 1, N, p(out), K + 1, 1, p(ws), ws.numel(), _lib.stream())
+    assert rc == 0, lib.glam_last_error()
+    assert_close(out, ref, 3e-6 * N ** 0.5 / 10, "chunked wgrad + ones")
