@@ -5,7 +5,7 @@ from glam_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda")
 N = 20700
-for K, M in [(92, 284), (276, 92), (92, 276), (284, 92), (60, 188), (180, 60)]:
+for K, M in [(92, 284), (92, 276), (60, 188), (180, 60)]:   # (276, 92) / (284, 92): no kernel variant (library GEMM wins)
     A = torch.randn(N, K, device=dev); W = torch.randn(K, M, device=dev)
     img = ops._ts_image(W, K, M, False)
     out = torch.empty(N, M, device=dev)
@@ -19,5 +19,3 @@ for K, M in [(92, 284), (276, 92), (92, 276), (284, 92), (60, 188), (180, 60)]:
         for _ in range(100): fn()
         e1.record(); torch.cuda.synchronize()
         print(f"K={K} M={M} {nm}: {e0.elapsed_time(e1)*10:.1f} us", flush=True)
-    ref = A @ W
-    print("   max err", (out - ref).abs().max().item())
