@@ -55,6 +55,10 @@ SIGNATURES = {
     "glam_ts_gemm_celu": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
     "glam_gru_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "glam_gru_tail_bwd": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _f32] + [_vp] * 5),
+    "glam_lstm_cell_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "glam_lstm_cell_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "glam_s2s_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "glam_s2s_attn_bwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp, _vp, _vp]),
     "glam_gru_gates_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "glam_triplet_staged_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_dstaged_floats": (_sz, [_i32, _i32, _i32]),

@@ -102,6 +102,40 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const 
     }
 }
 
+
+// ---- Set2Set readout (reference: model.py:41, PyG Set2Set(C, processing_steps = 3)): gate math of one torch.nn.LSTM
+//      cell step.  gates f32[B, 4C] = W_ih q* + b_ih + W_hh h + b_hh in torch's order i | f | g | o;
+//      c' = sigmoid(f) c + sigmoid(i) tanh(g),  h' = sigmoid(o) tanh(c').  The backward recomputes the gates. ----
+__global__ void __launch_bounds__(kBlock) k_lstm_cell_fwd(const float* gates, const float* c_prev, int B, int C, float* h_new,
+                                                         float* c_new) {
+    const size_t total = (size_t)B * C;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t n = idx / C, c = idx % C, b = n * 4 * C + c;
+        const float i = sigmoidf_(gates[b]), f = sigmoidf_(gates[b + C]), g = tanhf(gates[b + 2 * C]), o = sigmoidf_(gates[b + 3 * C]);
+        const float cn = f * c_prev[idx] + i * g;
+        c_new[idx] = cn;
+        h_new[idx] = o * tanhf(cn);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_lstm_cell_bwd(const float* gates, const float* c_prev, const float* d_h,
+                                                         const float* d_c, int B, int C, float* d_gates, float* d_c_prev) {
+    const size_t total = (size_t)B * C;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t n = idx / C, c = idx % C, b = n * 4 * C + c;
+        const float i = sigmoidf_(gates[b]), f = sigmoidf_(gates[b + C]), g = tanhf(gates[b + 2 * C]), o = sigmoidf_(gates[b + 3 * C]);
+        const float cp = c_prev[idx];
+        const float tc = tanhf(f * cp + i * g);
+        const float dh = d_h ? d_h[idx] : 0.f;
+        const float dc = (d_c ? d_c[idx] : 0.f) + dh * o * (1.f - tc * tc);
+        d_gates[b] = dc * g * i * (1.f - i);
+        d_gates[b + C] = dc * cp * f * (1.f - f);
+        d_gates[b + 2 * C] = dc * i * (1.f - g * g);
+        d_gates[b + 3 * C] = dh * tc * o * (1.f - o);
+        d_c_prev[idx] = dc * f;
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -149,5 +183,27 @@ extern "C" int glam_gru_gates_bwd(const float* gi, const float* gh, const float*
     hipLaunchKernelGGL(k_gru_gates_bwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, d_hnew,
                        (int)N, C, d_gi, d_gh, d_h);
     GLAM_LAUNCH_CHECK("glam_gru_gates_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_lstm_cell_fwd(const float* gates, const float* c_prev, int64_t B, int C, float* h_new, float* c_new,
+                                  void* stream) {
+    GLAM_REQUIRE(B >= 0 && B < INT32_MAX && C > 0, "glam_lstm_cell_fwd: bad dims");
+    if (B == 0) return GLAM_OK;
+    GLAM_REQUIRE(gates && c_prev && h_new && c_new, "glam_lstm_cell_fwd: null pointer");
+    hipLaunchKernelGGL(k_lstm_cell_fwd, dim3(grid_for(B * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gates, c_prev, (int)B, C,
+                       h_new, c_new);
+    GLAM_LAUNCH_CHECK("glam_lstm_cell_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_lstm_cell_bwd(const float* gates, const float* c_prev, const float* d_h, const float* d_c, int64_t B, int C,
+                                  float* d_gates, float* d_c_prev, void* stream) {
+    GLAM_REQUIRE(B >= 0 && B < INT32_MAX && C > 0, "glam_lstm_cell_bwd: bad dims");
+    if (B == 0) return GLAM_OK;
+    GLAM_REQUIRE(gates && c_prev && d_gates && d_c_prev, "glam_lstm_cell_bwd: null pointer");
+    hipLaunchKernelGGL(k_lstm_cell_bwd, dim3(grid_for(B * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gates, c_prev, d_h, d_c,
+                       (int)B, C, d_gates, d_c_prev);
+    GLAM_LAUNCH_CHECK("glam_lstm_cell_bwd");
     return GLAM_OK;
 }

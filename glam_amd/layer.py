@@ -571,7 +571,19 @@ class Set2Set(torch.nn.Module):
         h, c = x.new_zeros(B, C), x.new_zeros(B, C)
         q_star = x.new_zeros(B, 2 * C)
         L = self.lstm
+        Cp = _ceil4(C)
+        fused = ops.query_attention_supported(Cp)
+        if fused:                                    # zero-padded rows (the previous block's padded output by reference)
+            x_p = ops.pad_cols(x, Cp)
+            bias = L.bias_ih_l0 + L.bias_hh_l0
         for _ in range(self.processing_steps):
+            if fused:
+                # two GEMMs, one gate kernel, one attention-read kernel per step (and per direction)
+                gates = torch.addmm(torch.addmm(bias, q_star, L.weight_ih_l0.t()), h, L.weight_hh_l0.t())
+                h, c = ops.lstm_cell(gates, c)
+                r = ops.query_attention(x_p, h if Cp == C else F.pad(h, (0, Cp - C)), sp)
+                q_star = torch.cat([h, r if Cp == C else r[:, :C]], dim=-1)
+                continue
             gates = F.linear(q_star, L.weight_ih_l0, L.bias_ih_l0) + F.linear(h, L.weight_hh_l0, L.bias_hh_l0)
             i, f, g, o = gates.chunk(4, dim=1)
             c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)

@@ -1036,6 +1036,73 @@ class _SegmentAttn(torch.autograd.Function):
         return d_gate, d_v, None
 
 
+class _LstmCell(torch.autograd.Function):
+    """Gate math of one ``torch.nn.LSTM`` cell step (Set2Set): ``(gates[B,4C], c[B,C]) -> (h', c')``, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        require_device(gates, c_prev)
+        gates, c_prev = f32c(gates, "gates"), f32c(c_prev, "c")
+        B, C = c_prev.shape
+        h_new, c_new = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        check(_lib.load().glam_lstm_cell_fwd(ptr(gates), ptr(c_prev), B, C, ptr(h_new), ptr(c_new), stream()), "glam_lstm_cell_fwd")
+        ctx.save_for_backward(gates, c_prev)
+        return h_new, c_new
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_h, d_c):
+        gates, c_prev = ctx.saved_tensors
+        B, C = c_prev.shape
+        d_h = None if d_h is None else f32c(d_h, "d_h")
+        d_c = None if d_c is None else f32c(d_c, "d_c")
+        d_gates, d_cp = torch.empty_like(gates), torch.empty_like(c_prev)
+        check(_lib.load().glam_lstm_cell_bwd(ptr(gates), ptr(c_prev), ptr(d_h), ptr(d_c), B, C, ptr(d_gates), ptr(d_cp), stream()),
+              "glam_lstm_cell_bwd")
+        return d_gates, d_cp
+
+
+def lstm_cell(gates, c_prev):
+    return _LstmCell.apply(gates, c_prev)
+
+
+class _QueryAttention(torch.autograd.Function):
+    """Set2Set's attention read ``r_g = sum_n softmax_n(<x_n, q_g>) x_n`` with the logits formed inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, q, sp):
+        require_device(x, q)
+        x, q = f32c(x, "x"), f32c(q, "q")
+        N, D = x.shape
+        if N != sp.N or q.shape != (sp.B, D):
+            raise GlamHipError("query_attention: x / q disagree with the batch vector")
+        r = torch.empty(sp.B, D, dtype=torch.float32, device=x.device)
+        stats = torch.empty(sp.B, 2, dtype=torch.float32, device=x.device)
+        check(_lib.load().glam_s2s_attn_fwd(ptr(x), ptr(q), ptr(sp.ptr), N, sp.B, D, ptr(r), ptr(stats), stream()), "glam_s2s_attn_fwd")
+        ctx.save_for_backward(x, q, r, stats)
+        ctx.sp = sp
+        return r
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_r):
+        x, q, r, stats = ctx.saved_tensors
+        sp = ctx.sp
+        d_r = f32c(d_r, "d_r")
+        d_x, d_q = torch.empty_like(x), torch.empty_like(q)
+        check(_lib.load().glam_s2s_attn_bwd(ptr(x), ptr(q), ptr(r), ptr(stats), ptr(d_r), ptr(sp.ptr), x.size(0), sp.B, x.size(1),
+                                            ptr(d_x), ptr(d_q), stream()), "glam_s2s_attn_bwd")
+        return d_x, d_q, None
+
+
+def query_attention_supported(D):
+    return D % 4 == 0 and D <= 64
+
+
+def query_attention(x, q, sp):
+    return _QueryAttention.apply(x, q, sp)
+
+
 def segment_attention(gate, v, sp):
     """``scatter_add(softmax(gate, batch) * v, batch)`` -> ``[B, D]`` (GlobalAttention / Set2Set)."""
     return _SegmentAttn.apply(gate, v, sp)

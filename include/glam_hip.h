@@ -306,6 +306,21 @@ int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_pt
                        const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D, float* d_mol,
                        float* d_pro, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Set2Set readout (src_1gp/model.py:41: PyG Set2Set(C, processing_steps = 3)).
+ *   glam_lstm_cell_fwd/bwd: gate math of one torch.nn.LSTM cell step; gates f32[B,4C] = W_ih q* + b_ih + W_hh h + b_hh
+ *     (order i|f|g|o) -> h_new, c_new f32[B,C]; the backward recomputes the gates (d_h / d_c may be NULL = zero).
+ *   glam_s2s_attn_fwd/bwd: e_n = <x_n, q_g>, a = softmax over the nodes of graph g (denominator + 1e-16), r_g = sum_n a_n x_n
+ *     with x f32[N,D], q f32[B,D], ptr int32[B+1] -> r f32[B,D], stats f32[B,2] (segment max, exp-sum); the backward
+ *     returns d_x f32[N,D] and d_q f32[B,D].  D % 4 == 0, D <= 64. */
+int glam_lstm_cell_fwd(const float* gates, const float* c_prev, int64_t B, int C, float* h_new, float* c_new, void* stream);
+int glam_lstm_cell_bwd(const float* gates, const float* c_prev, const float* d_h, const float* d_c, int64_t B, int C,
+                       float* d_gates, float* d_c_prev, void* stream);
+int glam_s2s_attn_fwd(const float* x, const float* q, const int32_t* ptr, int64_t N, int64_t B, int D, float* r,
+                      float* stats, void* stream);
+int glam_s2s_attn_bwd(const float* x, const float* q, const float* r, const float* stats, const float* d_r,
+                      const int32_t* ptr, int64_t N, int64_t B, int D, float* d_x, float* d_q, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1055,3 +1055,27 @@ def test_wgrad_gemm_chunked_with_ones_column(device):
     rc = lib.glam_wgrad_gemm(p(dyd), M, M, None, 0, 0, 0, p(xd), K, K, 1, N, p(out), K + 1, 1, p(ws), ws.numel(), _lib.stream())
     assert rc == 0, lib.glam_last_error()
     assert_close(out, ref, 3e-6 * N ** 0.5 / 10, "chunked wgrad + ones")
+
+
+@pytest.mark.parametrize("C,sizes", [(60, [20, 13, 1, 28]), (45, [7, 40, 33, 2]), (32, [70, 5])])
+def test_set2set_fused_steps_vs_oracle(device, C, sizes):
+    """Set2Set on the fused path (LSTM gate kernel + in-kernel query attention): graphs below and above the 32-node register
+    pass, an odd width (padded rows) — output and every gradient against the oracle."""
+    torch.manual_seed(50 + C)
+    N, B = sum(sizes), len(sizes)
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    ro = layer.Set2Set(C, 3)
+    x0 = torch.randn(N, C)
+    xo = x0.clone().requires_grad_(True)
+    import copy
+    lstm_ref = copy.deepcopy(ro.lstm)
+    names = [n for n, _ in lstm_ref.named_parameters()]
+    ref = O.set2set(xo, batch, B, lstm_ref, steps=3)
+    cot = torch.randn(ref.shape)
+    g_ref = _grads(ref, cot, [xo] + [p for _, p in lstm_ref.named_parameters()])
+    ro = ro.to(device)
+    x = x0.to(device).requires_grad_(True)
+    out = ro(x, batch.to(device), B)
+    assert_close(out, ref, 2e-5, "set2set out")
+    for n, a, r in zip(["x"] + names, _grads(out, cot.to(device), [x] + [p for _, p in ro.lstm.named_parameters()]), g_ref):
+        assert_close(a, r, 5e-5, "set2set grad " + n)
