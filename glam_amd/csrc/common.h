@@ -45,11 +45,12 @@ __device__ __forceinline__ float dpp_move(float v) {
 }
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-    static_assert(G == 4 || G == 8 || G == 16 || G == 64, "group_sum: lanes per node");
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group_sum: lanes per node");
     v += dpp_move<0xB1>(v);                           // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);                           // quad_perm [2,3,0,1]
     if constexpr (G >= 8) v += dpp_move<0x141>(v);    // row_half_mirror: lane i <-> 7 - i of each 8
     if constexpr (G >= 16) v += dpp_move<0x140>(v);   // row_mirror: lane i <-> 15 - i of each 16
+    if constexpr (G == 32) v += __shfl_xor(v, 16, 64);                                    // two DPP rows
     if constexpr (G == 64) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); }   // across the 4 DPP rows
     return v;
 }

@@ -147,6 +147,106 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const i
     }
 }
 
+// ---- GlobalAttention read (reference: GlobalLAPool, src_1gp/layer.py:206-220) for D % 4 == 0, D <= 128: a lane owns
+//      (row group, float4 chunk) with LPR = 16 or 32 lanes per row; all row loads of a pass in flight (the kernels above
+//      are chains of n dependent round trips per graph: 25 / 29 us for 20-atom molecules). ----
+template <int LPR>
+__global__ void __launch_bounds__(kBlock) k_segment_attn_fwd_v4(const float* gate, const float* v, const int* ptr, int B, int D,
+                                                               float* out, float* stats) {
+    constexpr int RG = 64 / LPR, R = 8;                 // row groups per wave, rows per lane and pass
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, rg = lane / LPR;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const bool act = 4 * c4 < D;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        const bool small = end - beg <= RG * R;
+        float4 row[R];
+        float e[R];
+        float m = -INFINITY;
+        for (int b0 = beg; b0 < end; b0 += RG * R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int n = b0 + rg + RG * u;
+                const bool okr = n < end;
+                e[u] = okr ? gate[n] : -INFINITY;
+                row[u] = (act && okr) ? ld4(v + (size_t)n * D + 4 * c4) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < R; ++u) m = fmaxf(m, e[u]);
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (end <= beg) m = 0.f;
+        float ssum = 0.f;
+        float4 acc = f4zero();
+        for (int b0 = beg; b0 < end; b0 += RG * R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int n = b0 + rg + RG * u;
+                const bool okr = n < end;
+                if (!small) {
+                    e[u] = okr ? gate[n] : -INFINITY;
+                    row[u] = (act && okr) ? ld4(v + (size_t)n * D + 4 * c4) : f4zero();
+                }
+                if (okr) {
+                    const float p = expf(e[u] - m);
+                    ssum += p;
+                    fma4(acc, p, row[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            ssum += __shfl_xor(ssum, off);
+            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+        }
+        const float inv = 1.f / (ssum + 1e-16f);
+        if (act && rg == 0) st4(out + (size_t)g * D + 4 * c4, inv * acc);
+        if (lane == 0) { stats[2 * g] = m; stats[2 * g + 1] = ssum; }
+    }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(kBlock) k_segment_attn_bwd_v4(const float* gate, const float* v, const float* out,
+                                                               const float* stats, const float* d_out, const int* ptr, int B,
+                                                               int D, float* d_gate, float* d_v) {
+    constexpr int RG = 64 / LPR, R = 8;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, rg = lane / LPR;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const bool act = 4 * c4 < D;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        const float m = stats[2 * g], inv = 1.f / (stats[2 * g + 1] + 1e-16f);
+        const float4 gv = act ? ld4(d_out + (size_t)g * D + 4 * c4) : f4zero();
+        const float4 ov = act ? ld4(out + (size_t)g * D + 4 * c4) : f4zero();
+        const float dot_out = group_sum<LPR>(dot4(gv, ov));
+        for (int b0 = beg; b0 < end; b0 += RG * R) {
+            float4 row[R];
+            float e[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int n = b0 + rg + RG * u;
+                const bool okr = n < end;
+                e[u] = okr ? gate[n] : 0.f;
+                row[u] = (act && okr) ? ld4(v + (size_t)n * D + 4 * c4) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int n = b0 + rg + RG * u;
+                const float dv = group_sum<LPR>(dot4(gv, row[u]));
+                if (n < end) {
+                    const float a = expf(e[u] - m) * inv;
+                    if (act) st4(d_v + (size_t)n * D + 4 * c4, a * gv);
+                    if (c4 == 0) d_gate[n] = a * (dv - dot_out);
+                }
+            }
+        }
+    }
+}
+
 // ---- Set2Set attention read (PyG Set2Set.forward: e = <x_n, q_g>, a = softmax over the graph, r_g = sum_n a_n x_n) with
 //      the logits computed in the kernel from the per-graph query q[B, D]: no [N, D] gather of q, no [N] logit tensor.
 //      Wave per graph, lane = (row group rg, float4 chunk c4), D % 4 == 0 and D <= 64; 32 nodes per register pass. ----
@@ -773,7 +873,13 @@ extern "C" int glam_segment_attn_fwd(const float* gate, const float* v, const in
     if (int rc = pool_dims("glam_segment_attn_fwd", N, B, D)) return rc;
     if (B == 0) return GLAM_OK;
     GLAM_REQUIRE(ptr && out && stats && (N == 0 || (gate && v)), "glam_segment_attn_fwd: null pointer");
-    hipLaunchKernelGGL(k_segment_attn_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, gate, v, ptr, (int)B, D, out, stats);
+    const dim3 grid(grid_for(B, kWavesPerBlock)), block(kBlock);
+    if ((D & 3) == 0 && D <= 64 && aligned16(v) && aligned16(out))
+        hipLaunchKernelGGL(k_segment_attn_fwd_v4<16>, grid, block, 0, (hipStream_t)stream, gate, v, ptr, (int)B, D, out, stats);
+    else if ((D & 3) == 0 && D <= 128 && aligned16(v) && aligned16(out))
+        hipLaunchKernelGGL(k_segment_attn_fwd_v4<32>, grid, block, 0, (hipStream_t)stream, gate, v, ptr, (int)B, D, out, stats);
+    else
+        hipLaunchKernelGGL(k_segment_attn_fwd, grid, block, 0, (hipStream_t)stream, gate, v, ptr, (int)B, D, out, stats);
     GLAM_LAUNCH_CHECK("glam_segment_attn_fwd");
     return GLAM_OK;
 }
@@ -784,7 +890,14 @@ extern "C" int glam_segment_attn_bwd(const float* gate, const float* v, const fl
     if (int rc = pool_dims("glam_segment_attn_bwd", N, B, D)) return rc;
     if (B == 0 || N == 0) return GLAM_OK;
     GLAM_REQUIRE(ptr && gate && v && out && stats && d_out && d_gate && d_v, "glam_segment_attn_bwd: null pointer");
-    hipLaunchKernelGGL(k_segment_attn_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, gate, v, out, stats, d_out, ptr, (int)B, D, d_gate, d_v);
+    const dim3 grid(grid_for(B, kWavesPerBlock)), block(kBlock);
+    const bool al = aligned16(v) && aligned16(out) && aligned16(d_out) && aligned16(d_v);
+    if ((D & 3) == 0 && D <= 64 && al)
+        hipLaunchKernelGGL(k_segment_attn_bwd_v4<16>, grid, block, 0, (hipStream_t)stream, gate, v, out, stats, d_out, ptr, (int)B, D, d_gate, d_v);
+    else if ((D & 3) == 0 && D <= 128 && al)
+        hipLaunchKernelGGL(k_segment_attn_bwd_v4<32>, grid, block, 0, (hipStream_t)stream, gate, v, out, stats, d_out, ptr, (int)B, D, d_gate, d_v);
+    else
+        hipLaunchKernelGGL(k_segment_attn_bwd, grid, block, 0, (hipStream_t)stream, gate, v, out, stats, d_out, ptr, (int)B, D, d_gate, d_v);
     GLAM_LAUNCH_CHECK("glam_segment_attn_bwd");
     return GLAM_OK;
 }
