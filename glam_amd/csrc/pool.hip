@@ -488,6 +488,38 @@ __global__ void __launch_bounds__(kBlock) k_pool5_bwd(const float* d_out, const 
     }
 }
 
+// D % 4 == 0, D <= 64: float4 rows, four rows of a graph per wave instruction
+__global__ void __launch_bounds__(kBlock) k_pool5_bwd_v4(const float* d_out, const int* ptr, const int* topk_idx, int B, int D,
+                                                        int K, float* d_x) {
+    const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int OD = (2 + K) * D;
+    if (4 * c4 >= D) return;
+    for (int g = wave; g < B; g += nwaves) {
+        const int beg = ptr[g], end = ptr[g + 1];
+        const float inv_cnt = 1.f / (float)max(end - beg, 1);
+        const float* go = d_out + (size_t)g * OD;
+        const float4 gm = ld4(go + 4 * c4), ga = ld4(go + D + 4 * c4);
+        int ti[kMaxK];
+        float4 gk[kMaxK];
+#pragma unroll
+        for (int r = 0; r < kMaxK; ++r) {
+            ti[r] = r < K ? topk_idx[(size_t)g * K + r] : -1;
+            gk[r] = r < K ? ld4(go + (2 + r) * D + 4 * c4) : f4zero();
+        }
+        float4 base = ga;
+        fma4(base, inv_cnt, gm);
+        for (int n = beg + rg; n < end; n += 4) {
+            float4 v = base;
+#pragma unroll
+            for (int r = 0; r < kMaxK; ++r)
+                if (r < K && ti[r] == n) { v.x += gk[r].x; v.y += gk[r].y; v.z += gk[r].z; v.w += gk[r].w; }
+            st4(d_x + (size_t)n * D + 4 * c4, v);
+        }
+    }
+}
+
 // ---- scatter(x, batch, reduce = sum | mean | max) over sorted batch -----------------------------
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_segment_pool_fwd(const float* x, const int* ptr, int B, int D, float* out,
@@ -832,6 +864,8 @@ extern "C" int glam_pool5_bwd(const float* d_out, const int32_t* ptr, const int3
     GLAM_REQUIRE(ptr && d_out && topk_idx && d_x, "glam_pool5_bwd: null pointer");
     if (N / B >= 64 && (D & 3) == 0 && D <= 64 && B * (int64_t)kPool5BwdChunks < 65536)
         hipLaunchKernelGGL(k_pool5_bwd_block, dim3((int)B * kPool5BwdChunks), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
+    else if ((D & 3) == 0 && D <= 64 && aligned16(d_out) && aligned16(d_x))
+        hipLaunchKernelGGL(k_pool5_bwd_v4, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
     else
         hipLaunchKernelGGL(k_pool5_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
     GLAM_LAUNCH_CHECK("glam_pool5_bwd");
