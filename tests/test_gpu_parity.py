@@ -1079,3 +1079,32 @@ def test_set2set_fused_steps_vs_oracle(device, C, sizes):
     assert_close(out, ref, 2e-5, "set2set out")
     for n, a, r in zip(["x"] + names, _grads(out, cot.to(device), [x] + [p for _, p in ro.lstm.named_parameters()]), g_ref):
         assert_close(a, r, 5e-5, "set2set grad " + n)
+
+
+def test_misuse_raises_python_exceptions_and_leaves_the_device_usable(device):
+    """Error behaviour at the boundary (the reference convention is Python exceptions, never an abort)."""
+    b = synth_batch(8, seed=0).to(device)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device)
+    ok = conv(x, b.edge_index, b.edge_attr)
+    with pytest.raises(ops.GlamHipError):
+        conv(x, b.edge_index.int(), b.edge_attr)                      # int64 edge_index only
+    with pytest.raises(ops.GlamHipError):
+        conv(x.double(), b.edge_index, b.edge_attr)                   # fp32 only
+    with pytest.raises(ops.GlamHipError):
+        conv(x, b.edge_index, b.edge_attr[:-3])                       # one edge_attr row per edge
+    with pytest.raises(IndexError):
+        conv(x[:-2], b.edge_index, b.edge_attr)                       # node ids beyond x
+    ei = b.edge_index.clone()
+    ei[1, 0] = -1
+    with pytest.raises(IndexError):
+        conv(x, ei, b.edge_attr)
+    with pytest.raises(ops.GlamHipError):
+        conv(x.cpu(), b.edge_index, b.edge_attr)                      # no CPU fallback
+    with pytest.raises(ops.GlamHipError):
+        layer.TripletMessage(60, 9).to(device)(x, b.edge_index, torch.rand(b.edge_index.size(1), 9, device=device))
+    with pytest.raises(IndexError):
+        layer.GlobalPool5()(x, b.batch.flip(0))                       # batch must be sorted (it is, by collation)
+    xt = torch.randn(60, b.x.size(0), device=device).t()              # non-contiguous input: accepted
+    assert conv(xt, b.edge_index, b.edge_attr).shape == ok.shape
+    assert torch.equal(conv(x, b.edge_index, b.edge_attr), ok)        # the device is still fine
