@@ -164,11 +164,18 @@ def main():
     if world != args.gpus:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Functional check of the multi-rank path on a single-GPU box (not a measurement): GLAM_BENCH_SHARE_GPU=1 puts every rank
+    # on device 0 and uses gloo, since RCCL refuses two ranks on one device.
+    share = os.environ.get("GLAM_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     from glam_amd import layer, ops
     from glam_amd.data import synth_batch
