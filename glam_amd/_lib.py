@@ -45,6 +45,7 @@ SIGNATURES = {
     "glam_pair_pool_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),
     "glam_ts_gemm_image_bytes": (_sz, [_i32, _i32]),
     "glam_ts_gemm_make_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "glam_ts_gemm_make_image_quad": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "glam_ts_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _vp]),
     "glam_wgrad_workspace_bytes": (_sz, []),
     "glam_wgrad_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),

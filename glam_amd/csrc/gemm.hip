@@ -44,6 +44,26 @@ __global__ void __launch_bounds__(kBlock) k_ts_make_image(const float* W, int ld
     }
 }
 
+// Up to four images in one launch (the forward and transposed images of a GRU's two gate matrices change together after
+// every optimizer step): job j owns blocks [first[j], first[j+1]).
+struct ImageJob { const float* W; int ldw, transW, K, M, MT; float* img; int first; };
+struct ImageJobs { ImageJob job[4]; int njobs; };
+__global__ void __launch_bounds__(kBlock) k_ts_make_images(ImageJobs js) {
+    int jb = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < js.njobs && (int)blockIdx.x >= js.job[q].first) jb = q;
+    const ImageJob& J = js.job[jb];
+    const int MP = J.MT * 16, Kp = (J.K + 15) & ~15;
+    const int idx = ((int)blockIdx.x - J.first) * kBlock + threadIdx.x;
+    if (idx >= Kp * MP) return;
+    const int j = idx & 3, p = (idx >> 2) % MP, k = (idx >> 2) / MP * 4 + j;
+    const int m = ts_col_of_pos(p);
+    float v = 0.f;
+    if (k < J.K && m < J.M) v = J.transW ? J.W[(size_t)m * J.ldw + k] : J.W[(size_t)k * J.ldw + m];
+    J.img[idx] = v;
+}
+
 // Work item = (16-row tile, column split): TPI of the MT column tiles.  A 16 x 192 x 64 row tile is 192 MFMAs
 // (6.1k cycles on one SIMD): whole row tiles leave some SIMDs with two and others with none at N ~ 2e4, so the
 // tiles are cut into MT/TPI column items that are dealt round-robin to ALL waves of the grid (consecutive items,
@@ -549,4 +569,27 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
     ra.njobs = 1;
     if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, (hipStream_t)stream, &ra.job[0])) return rc;
     return launch_final_reduce(ra, (hipStream_t)stream);
+}
+
+// The four weight images of one linear pair y_a = x W_a^T, y_b = h W_b^T (W_* f32[M, K] as torch stores them) in ONE launch:
+// forward images (logical [K, M] = W^T) and input-gradient images (logical [M, K] = W).
+extern "C" int glam_ts_gemm_make_image_quad(const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,
+                                            float* img_a_bwd, float* img_b_bwd, void* stream) {
+    GLAM_REQUIRE(Wa && Wb && img_a_fwd && img_b_fwd && img_a_bwd && img_b_bwd, "glam_ts_gemm_make_image_quad: null pointer");
+    if (int rc = ts_shape_ok("ts_gemm image quad", K, M)) return rc;
+    if (int rc = ts_shape_ok("ts_gemm image quad", M, K)) return rc;
+    ImageJobs js{};
+    js.njobs = 4;
+    const float* W[4] = {Wa, Wb, Wa, Wb};
+    float* img[4] = {img_a_fwd, img_b_fwd, img_a_bwd, img_b_bwd};
+    int blocks = 0;
+    for (int q = 0; q < 4; ++q) {
+        const bool fwd = q < 2;
+        const int Kq = fwd ? K : M, Mq = fwd ? M : K;
+        js.job[q] = ImageJob{W[q], K, fwd ? 1 : 0, Kq, Mq, ts_mt(ts_variant(Kq, Mq)), img[q], blocks};
+        blocks += (int)((ts_image_floats(Kq, Mq) + kBlock - 1) / kBlock);
+    }
+    hipLaunchKernelGGL(k_ts_make_images, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, js);
+    GLAM_LAUNCH_CHECK("glam_ts_gemm_make_image_quad");
+    return GLAM_OK;
 }

@@ -871,6 +871,18 @@ class _GruBlock(torch.autograd.Function):
 
         gi, gh = torch.empty(N, M, **f), torch.empty(N, M, **f)
         st = stream()
+        if scope is not None:
+            # all four images of the step (forward and input-gradient images of both gate matrices) in ONE launch, shared by the
+            # message_steps applications of the block through the scope tables
+            ka, kb = ("lin", id(w_ih)), ("lin", id(w_hh))
+            ha, hb = scope.fwd.get(ka), scope.fwd.get(kb)
+            if not (ha is not None and ha[0] is w_ih and hb is not None and hb[0] is w_hh):
+                nf, nb = lib.glam_ts_gemm_image_bytes(C, M) // 4, lib.glam_ts_gemm_image_bytes(M, C) // 4
+                ia, ib, ta, tb = torch.empty(nf, **f), torch.empty(nf, **f), torch.empty(nb, **f), torch.empty(nb, **f)
+                check(lib.glam_ts_gemm_make_image_quad(ptr(w_ih), ptr(w_hh), C, M, ptr(ia), ptr(ib), ptr(ta), ptr(tb), st),
+                      "glam_ts_gemm_make_image_quad")
+                scope.fwd[ka], scope.fwd[kb] = (w_ih, ia), (w_hh, ib)
+                scope.bwd[ka], scope.bwd[kb] = (w_ih, ta), (w_hh, tb)
         # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
         check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
               "glam_ts_gemm_celu")

@@ -158,6 +158,10 @@ int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, const int32_
  *                    computed as two column chunks in one launch. */
 size_t glam_ts_gemm_image_bytes(int K, int M);
 int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, float* img, void* stream);
+/* The four images of a linear pair (W_a, W_b f32[M,K] as torch.nn stores them; e.g. a GRU's weight_ih / weight_hh) in one
+ * launch: forward images (x @ W^T: glam_ts_gemm_image_bytes(K, M)) and input-gradient images (dy @ W: ..._bytes(M, K)). */
+int glam_ts_gemm_make_image_quad(const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,
+                                 float* img_a_bwd, float* img_b_bwd, void* stream);
 int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
                  const float* bias, float* out1, int M1, int ldo1, float* out2, int M2, int ldo2, int64_t N,
                  void* stream);
