@@ -56,6 +56,8 @@ SIGNATURES = {
     "glam_ts_gemm_celu": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
     "glam_gru_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "glam_gru_tail_bwd": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _f32] + [_vp] * 5),
+    "glam_bias_res_act_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "glam_bias_res_act_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
     "glam_lstm_cell_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_lstm_cell_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_s2s_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),

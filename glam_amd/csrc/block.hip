@@ -103,6 +103,24 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const 
 }
 
 
+// ---- block tail without a GRU (GCN / GAT blocks, src_1gp/layer.py:248, 263-266): out = act(y + bias + identity) ----
+__global__ void __launch_bounds__(kBlock) k_bias_res_act_fwd(const float* y, const float* bias, const float* identity, int N, int C,
+                                                            int act, float slope, float* out) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        float v = y[i];
+        if (bias) v += bias[i % C];
+        if (identity) v += identity[i];
+        out[i] = act_fwd(v, act, slope);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_bias_res_act_bwd(const float* out, const float* d_out, int N, int C, int act, float slope,
+                                                            float* d_y) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
+        d_y[i] = d_out[i] * act_grad_from_out(out[i], act, slope);
+}
+
 // ---- Set2Set readout (reference: model.py:41, PyG Set2Set(C, processing_steps = 3)): gate math of one torch.nn.LSTM
 //      cell step.  gates f32[B, 4C] = W_ih q* + b_ih + W_hh h + b_hh in torch's order i | f | g | o;
 //      c' = sigmoid(f) c + sigmoid(i) tanh(g),  h' = sigmoid(o) tanh(c').  The backward recomputes the gates. ----
@@ -205,5 +223,27 @@ extern "C" int glam_lstm_cell_bwd(const float* gates, const float* c_prev, const
     hipLaunchKernelGGL(k_lstm_cell_bwd, dim3(grid_for(B * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gates, c_prev, d_h, d_c,
                        (int)B, C, d_gates, d_c_prev);
     GLAM_LAUNCH_CHECK("glam_lstm_cell_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_bias_res_act_fwd(const float* y, const float* bias, const float* identity, int64_t N, int C, int act, float slope,
+                                     float* out, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX && C > 0 && act >= 0 && act <= 3, "glam_bias_res_act_fwd: bad arguments");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(y && out, "glam_bias_res_act_fwd: null pointer");
+    hipLaunchKernelGGL(k_bias_res_act_fwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, bias, identity, (int)N, C,
+                       act, slope, out);
+    GLAM_LAUNCH_CHECK("glam_bias_res_act_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_bias_res_act_bwd(const float* out, const float* d_out, int64_t N, int C, int act, float slope, float* d_y,
+                                     void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX && C > 0 && act >= 0 && act <= 3, "glam_bias_res_act_bwd: bad arguments");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(out && d_out && d_y, "glam_bias_res_act_bwd: null pointer");
+    hipLaunchKernelGGL(k_bias_res_act_bwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, d_out, (int)N, C, act,
+                       slope, d_y);
+    GLAM_LAUNCH_CHECK("glam_bias_res_act_bwd");
     return GLAM_OK;
 }

@@ -301,7 +301,7 @@ class GCNConv(MessagePassing):
         dis = dis.masked_fill(dis == float("inf"), 0)
         return dis[ei[0]] * w * dis[ei[1]]
 
-    def forward(self, x, edge_index, edge_weight=None):
+    def forward(self, x, edge_index, edge_weight=None, add_bias=True):
         n = x.size(0)
         gi0 = ops.graph_index(edge_index, n)
         ei, gi, mask = _with_self_loops(gi0, edge_index, n, True)
@@ -320,7 +320,7 @@ class GCNConv(MessagePassing):
             out = ops.edge_reduce(norm * xw.index_select(0, ei[0]), gi, "sum")
         else:                          # one gather-scale-sum kernel per direction (K = 1 relation)
             out = ops.edge_weighted_sum(xw, norm, gi).view(n, -1)
-        return out if self.bias is None else out + self.bias
+        return out if (self.bias is None or not add_bias) else out + self.bias
 
 
 class GATConv(MessagePassing):
@@ -343,7 +343,7 @@ class GATConv(MessagePassing):
         if self.bias is not None:
             zeros_(self.bias)
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, add_bias=True):
         n, C = x.size(0), self.out_channels
         Cp = _ceil4(C)
         gi0 = ops.graph_index(edge_index, n)
@@ -357,7 +357,7 @@ class GATConv(MessagePassing):
         zeros_e = x.new_zeros(ei.size(1), 4)
         aggr = ops.light_aggregate(xl, a_ij, zeros_e, x.new_zeros(4, 4), gi, Cp, self.negative_slope)
         out = aggr[:, :C] if Cp != C else aggr
-        return out if self.bias is None else out + self.bias
+        return out if (self.bias is None or not add_bias) else out + self.bias
 
 
 class _NNConv(torch.nn.Module):  # layer.py:115-122
@@ -662,6 +662,12 @@ class MessageBlock(torch.nn.Module):
             h = x.unsqueeze(0)                       # layer.py:254 (pre-norm x seeds the GRU state)
         x = self.norm(x, batch)
         x = self.dropout(x)
+        if self.gru is None and isinstance(self.conv, (_GCNConv, _GATConv)) and self._fusable_act() is not None:
+            # no GRU (layer.py:248): conv bias + residual + activation as one launch per direction
+            fa = self._fusable_act()
+            c = self.conv.conv
+            y = c(x, edge_index, add_bias=False)
+            return ops.bias_res_act(y, c.bias, None if self.res is False else identity, fa[0], fa[1]), h
         x = self.conv(x, edge_index, edge_attr)      # layer.py:259
         if self.gru is not None:
             fa = self._fusable_act()

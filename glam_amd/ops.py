@@ -1048,6 +1048,39 @@ class _SegmentAttn(torch.autograd.Function):
         return d_gate, d_v, None
 
 
+class _BiasResAct(torch.autograd.Function):
+    """``act(y + bias + identity)``: the tail of a MessageBlock whose conv has no GRU (GCN / GAT), one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, y, bias, identity, act, slope):
+        require_device(y, bias, identity)
+        y = f32c(y, "y")
+        bias = None if bias is None else f32c(bias, "bias")
+        identity = None if identity is None else f32c(identity, "identity")
+        N, C = y.shape
+        out = torch.empty_like(y)
+        check(_lib.load().glam_bias_res_act_fwd(ptr(y), ptr(bias), ptr(identity), N, C, act, float(slope), ptr(out), stream()),
+              "glam_bias_res_act_fwd")
+        ctx.save_for_backward(out)
+        ctx.cfg = (act, float(slope), bias is not None, identity is not None)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        (out,) = ctx.saved_tensors
+        act, slope, has_bias, has_id = ctx.cfg
+        d_out = f32c(d_out, "d_out")
+        N, C = out.shape
+        d_y = torch.empty_like(out)
+        check(_lib.load().glam_bias_res_act_bwd(ptr(out), ptr(d_out), N, C, act, slope, ptr(d_y), stream()), "glam_bias_res_act_bwd")
+        return d_y, (d_y.sum(0) if has_bias else None), (d_y if has_id else None), None, None
+
+
+def bias_res_act(y, bias, identity, act="none", slope=0.0):
+    return _BiasResAct.apply(y, bias, identity, ACT_CODES[act], slope)
+
+
 class _LstmCell(torch.autograd.Function):
     """Gate math of one ``torch.nn.LSTM`` cell step (Set2Set): ``(gates[B,4C], c[B,C]) -> (h', c')``, one launch each way."""
 

@@ -310,6 +310,14 @@ int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_pt
                        const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D, float* d_mol,
                        float* d_pro, void* stream);
 
+/* Block tail of the convs without a GRU (GCNConv / GATConv blocks, src_1gp/layer.py:248 and :263-266) in one launch per
+ * direction: out = act(y + bias + identity) (bias / identity may be NULL; act codes as glam_gru_tail_fwd); the backward
+ * returns d_y = d_out * act'(out) (= d_identity; d_bias is its column sum). */
+int glam_bias_res_act_fwd(const float* y, const float* bias, const float* identity, int64_t N, int C, int act, float slope,
+                          float* out, void* stream);
+int glam_bias_res_act_bwd(const float* out, const float* d_out, int64_t N, int C, int act, float slope, float* d_y,
+                          void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Set2Set readout (src_1gp/model.py:41: PyG Set2Set(C, processing_steps = 3)).
  *   glam_lstm_cell_fwd/bwd: gate math of one torch.nn.LSTM cell step; gates f32[B,4C] = W_ih q* + b_ih + W_hh h + b_hh
