@@ -713,7 +713,8 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd(const float* d_out, co
 // the K weights of an edge as float4 loads, two edges in flight; same edge order and fma sequence as the scalar kernels.
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_edge_wsum_fwd_v4(const float* x, const float* w, const int* rowptr, const int* nbr,
-                                                            const int* eid, int N, int D, int mean, float* out) {
+                                                            const int* eid, int N, int D, int mean, int self_slot, float* out) {
+    const int KS = K + self_slot;     // self_slot: slot K of every node is its own row x[n] (NNConv's root term as one more relation)
     const int D4 = D >> 2;
     const size_t total = (size_t)N * D4;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
@@ -742,19 +743,20 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_fwd_v4(const float* x, con
         }
         const float sc = mean ? 1.f / (float)max(end - beg, 1) : 1.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) st4(out + ((size_t)n * K + k) * D + c, sc * acc[k]);
+        for (int k = 0; k < K; ++k) st4(out + ((size_t)n * KS + k) * D + c, sc * acc[k]);
+        if (self_slot) st4(out + ((size_t)n * KS + K) * D + c, ld4(x + (size_t)n * D + c));
     }
 }
 
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd_v4(const float* d_out, const float* w, const int* colptr, const int* dst,
                                                             const int* eid_t, const int* rowptr, int N, int D, int mean,
-                                                            float* dx) {
-    const int D4 = D >> 2;
+                                                            int self_slot, float* dx) {
+    const int D4 = D >> 2, KS = K + self_slot;
     const size_t total = (size_t)N * D4;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         const int j = (int)(i / D4), c = 4 * (int)(i % D4);
-        float4 acc = f4zero();
+        float4 acc = self_slot ? ld4(d_out + ((size_t)j * KS + K) * D + c) : f4zero();
         for (int e = colptr[j]; e < colptr[j + 1]; ++e) {
             const int n = dst[e], id = eid_t[e];
             const float sc = mean ? 1.f / (float)max(rowptr[n + 1] - rowptr[n], 1) : 1.f;
@@ -762,7 +764,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd_v4(const float* d_out,
 #pragma unroll
             for (int u = 0; u < K / 4; ++u) wv[u] = ld4(w + (size_t)id * K + 4 * u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) g[k] = ld4(d_out + ((size_t)n * K + k) * D + c);
+            for (int k = 0; k < K; ++k) g[k] = ld4(d_out + ((size_t)n * KS + k) * D + c);
             float4 t = f4zero();
 #pragma unroll
             for (int k = 0; k < K; ++k) fma4(t, f4get(wv[k >> 2], k & 3), g[k]);
@@ -967,9 +969,11 @@ extern "C" int glam_edge_reduce_bwd(const float* d_out, const int32_t* rowptr, c
 }
 
 extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t* rowptr, const int32_t* src,
-                                  const int32_t* eid, int64_t N, int64_t E, int D, int K, int mean, float* out,
+                                  const int32_t* eid, int64_t N, int64_t E, int D, int K, int mean, int self_slot, float* out,
                                   void* stream) {
     if (int rc = pool_dims("glam_edge_wsum_fwd", N, E, D)) return rc;
+    if (self_slot && !((K == 4 || K == 8) && (D & 3) == 0 && aligned16(x) && aligned16(w) && aligned16(out)))
+        return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_fwd: self_slot needs K in {4, 8}, D %% 4 == 0 and 16-byte aligned tensors");
     if (K != 1 && K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_fwd: K=%d (1, or edge features padded to 4 or 8)", K);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(x && rowptr && out && (E == 0 || (w && src && eid)), "glam_edge_wsum_fwd: null pointer");
@@ -980,8 +984,8 @@ extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t*
     else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_fwd<1>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else if ((D & 3) == 0 && aligned16(x) && aligned16(w) && aligned16(out)) {
         const dim3 g4(grid_for(N * (D / 4), kBlock));
-        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd_v4<4>, g4, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
-        else hipLaunchKernelGGL(k_edge_wsum_fwd_v4<8>, g4, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
+        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd_v4<4>, g4, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, self_slot, out);
+        else hipLaunchKernelGGL(k_edge_wsum_fwd_v4<8>, g4, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, self_slot, out);
     } else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_fwd<4>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     else hipLaunchKernelGGL(k_edge_wsum_fwd<8>, grid, block, 0, s, x, w, rowptr, src, eid, (int)N, D, mean, out);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_fwd");
@@ -990,8 +994,10 @@ extern "C" int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t*
 
 extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst,
                                   const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K,
-                                  int mean, float* dx, void* stream) {
+                                  int mean, int self_slot, float* dx, void* stream) {
     if (int rc = pool_dims("glam_edge_wsum_bwd", N, E, D)) return rc;
+    if (self_slot && !((K == 4 || K == 8) && (D & 3) == 0 && aligned16(d_out) && aligned16(w) && aligned16(dx)))
+        return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_bwd: self_slot needs K in {4, 8}, D %% 4 == 0 and 16-byte aligned tensors");
     if (K != 1 && K != 4 && K != 8) return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_bwd: K=%d (1, or edge features padded to 4 or 8)", K);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(d_out && colptr && rowptr && dx && (E == 0 || (w && dst && eid_t)), "glam_edge_wsum_bwd: null pointer");
@@ -1002,8 +1008,8 @@ extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int3
     else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_bwd<1>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else if ((D & 3) == 0 && aligned16(d_out) && aligned16(w) && aligned16(dx)) {
         const dim3 g4(grid_for(N * (D / 4), kBlock));
-        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd_v4<4>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
-        else hipLaunchKernelGGL(k_edge_wsum_bwd_v4<8>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
+        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd_v4<4>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot, dx);
+        else hipLaunchKernelGGL(k_edge_wsum_bwd_v4<8>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot, dx);
     } else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else hipLaunchKernelGGL(k_edge_wsum_bwd<8>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd");

@@ -250,9 +250,19 @@ class NNConv(MessagePassing):
 
             w_rel = ops.scoped_weights(("nnconv-rel", id(self), De), self, relation_weights)
             ea = F.pad(edge_attr, (0, Dp - De)) if Dp != De else edge_attr
-            S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"))           # [N, Dp, in]
             if self.aggr not in ("mean", "add", "sum"):
                 raise GlamHipError("NNConv: only aggr in {'mean', 'add'} is supported")
+            C = self.in_channels
+            if self.root is not None and ops.self_slot_supported(Dp, C) and (Dp + 1) * C + 1 <= 320 and self.out_channels % 4 == 0:
+                # the root term x_i @ root as one more relation (the node's own row in slot Dp of the relation sums): the whole
+                # layer is ONE [N, (Dp+1) C] x [(Dp+1) C, out] GEMM with the bias in its epilogue, and one k_wgrad launch back
+                def stacked():
+                    w = w_rel if Dp == De else F.pad(w_rel.view(De, C, -1), (0, 0, 0, 0, 0, Dp - De)).reshape(Dp * C, -1)
+                    return torch.cat([w, self.root], dim=0).contiguous()
+                w_all = ops.scoped_weights(("nnconv-stack", id(self), De), self, stacked)
+                S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"), self_slot=True)      # [N, Dp + 1, in]
+                return ops.matmul_tall(S.view(x.size(0), (Dp + 1) * C), w_all, self.bias)
+            S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"))           # [N, Dp, in]
             out = ops.matmul_tall(S[:, :De].reshape(x.size(0), De * self.in_channels), w_rel)
         else:
             weight = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)

@@ -592,16 +592,18 @@ class _Linear(torch.autograd.Function):
 
 
 class _MatmulTall(torch.autograd.Function):
-    """``A[N,K] @ W[K,M]`` for tall A and a small weight whose shape is outside the MFMA forward table: the two
+    """``A[N,K] @ W[K,M] (+ bias)`` for tall A and a small weight whose shape is outside the MFMA forward table: the two
     data-side products stay on the library GEMM, but the WEIGHT gradient ``A^T @ dY`` — a reduction over the N rows for
-    which the library's heuristics pick 32x32 tiles (77 us at N = 20 k, K = 240, M = 60) — runs on ``k_wgrad`` (≈12 us)."""
+    which the library's heuristics pick 32x32 tiles (77 us at N = 20 k, K = 240, M = 60) — runs on ``k_wgrad`` (≈12 us),
+    the bias gradient riding on its ones column."""
 
     @staticmethod
-    def forward(ctx, a, w):
-        require_device(a, w)
+    def forward(ctx, a, w, bias):
+        require_device(a, w, bias)
         a, w = f32c(a, "a"), f32c(w, "w")
         ctx.save_for_backward(a, w)
-        return torch.matmul(a, w)
+        ctx.has_bias = bias is not None
+        return torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -611,10 +613,15 @@ class _MatmulTall(torch.autograd.Function):
         N, K = a.shape
         M = w.size(1)
         da = torch.matmul(dy, w.t()) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.has_bias:
             lib = _lib.load()
             ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
+            if ctx.has_bias:   # [dw ; db] = [a | 1]^T dy   (K + 1 <= 320, M <= 128: matmul_tall's bias condition)
+                dwb = torch.empty(K + 1, M, dtype=torch.float32, device=a.device)
+                check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), M, 1, ptr(ws), ws.numel(),
+                                          stream()), "glam_wgrad_gemm")
+                return da, dwb[:K], dwb[K]
             dw = torch.empty(K, M, dtype=torch.float32, device=a.device)
             if M <= 128:      # dw = a^T dy: P = a (up to 320 columns), Q = dy (two 64-column chunks beyond 64)
                 check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 0, ptr(dy), M, M, 0, N, ptr(dw), M, 1, ptr(ws), ws.numel(),
@@ -622,17 +629,21 @@ class _MatmulTall(torch.autograd.Function):
             else:             # wide output: dw^T = dy^T a, written through transposed strides
                 check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(a), K, K, 0, N, ptr(dw), 1, M, ptr(ws), ws.numel(),
                                           stream()), "glam_wgrad_gemm")
-        return da, dw
+        return da, dw, db
 
 
-def matmul_tall(a, w):
-    """``a @ w`` with the weight gradient on the MFMA reduction kernel when it fits: one of (K, M) <= 320 and the other
-    <= 128, multiples of 4."""
+def matmul_tall(a, w, bias=None):
+    """``a @ w (+ bias)`` with the weight gradient on the MFMA reduction kernel when it fits: one of (K, M) <= 320 and the other
+    <= 128, multiples of 4 (with a bias: K + 1 <= 320 and M <= 128)."""
     K, M = w.shape
-    if a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and a.size(0) >= 64 and \
-            ((K <= 320 and M <= 128) or (K <= 128 and M <= 320)):
-        return _MatmulTall.apply(a, w)
-    return torch.matmul(a, w)
+    ok = a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and a.size(0) >= 64
+    if ok and bias is not None and K + 1 <= 320 and M <= 128:
+        return _MatmulTall.apply(a, w, bias)
+    if ok and ((K <= 320 and M <= 128) or (K <= 128 and M <= 320)):
+        out = _MatmulTall.apply(a, w, None)
+        return out if bias is None else out + bias
+    out = torch.matmul(a, w)
+    return out if bias is None else out + bias
 
 
 class _LinearTall(torch.autograd.Function):
@@ -1228,18 +1239,18 @@ def graph_standardize(x, sp, eps=1e-5):
 
 class _EdgeWeightedSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, gi, mean):
+    def forward(ctx, x, w, gi, mean, self_slot):
         require_device(x, w)
         x, w = f32c(x, "x"), f32c(w, "w")
         N, D = x.shape
         E, K = w.shape
         if N != gi.N or E != gi.E:
             raise GlamHipError("edge_weighted_sum: x / w disagree with the edge list")
-        out = torch.empty(N, K, D, dtype=torch.float32, device=x.device)
+        out = torch.empty(N, K + int(self_slot), D, dtype=torch.float32, device=x.device)
         check(_lib.load().glam_edge_wsum_fwd(ptr(x), ptr(w), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, E, D, K, int(mean),
-                                             ptr(out), stream()), "glam_edge_wsum_fwd")
+                                             int(self_slot), ptr(out), stream()), "glam_edge_wsum_fwd")
         ctx.save_for_backward(w)
-        ctx.gi, ctx.cfg = gi, (N, E, D, K, int(mean))
+        ctx.gi, ctx.cfg = gi, (N, E, D, K, int(mean), int(self_slot))
         return out
 
     @staticmethod
@@ -1247,18 +1258,23 @@ class _EdgeWeightedSum(torch.autograd.Function):
     def backward(ctx, d_out):
         (w,) = ctx.saved_tensors
         gi = ctx.gi
-        N, E, D, K, mean = ctx.cfg
+        N, E, D, K, mean, self_slot = ctx.cfg
         d_out = f32c(d_out, "d_out")
         colptr, dst, eid_t = gi.transpose()
         dx = torch.empty(N, D, dtype=torch.float32, device=d_out.device)
         check(_lib.load().glam_edge_wsum_bwd(ptr(d_out), ptr(w), ptr(colptr), ptr(dst), ptr(eid_t), ptr(gi.rowptr), N, E, D, K,
-                                             mean, ptr(dx), stream()), "glam_edge_wsum_bwd")
-        return dx, None, None, None
+                                             mean, self_slot, ptr(dx), stream()), "glam_edge_wsum_bwd")
+        return dx, None, None, None, None
 
 
-def edge_weighted_sum(x, w, gi, mean=False):
-    """``S[n,k,:] = (1/deg_n) sum_{e->n} w[e,k] * x[src_e,:]`` -> ``[N, K, D]`` (no gradient w.r.t. ``w``: edge data)."""
-    return _EdgeWeightedSum.apply(x, w, gi, mean)
+def edge_weighted_sum(x, w, gi, mean=False, self_slot=False):
+    """``S[n,k,:] = (1/deg_n) sum_{e->n} w[e,k] * x[src_e,:]`` -> ``[N, K, D]`` (no gradient w.r.t. ``w``: edge data);
+    ``self_slot``: ``[N, K+1, D]`` with ``S[n,K,:] = x[n,:]`` (K in {4, 8}, D % 4 == 0)."""
+    return _EdgeWeightedSum.apply(x, w, gi, mean, self_slot)
+
+
+def self_slot_supported(K, D):
+    return K in (4, 8) and D % 4 == 0
 
 
 _ONEHOT_CACHE: dict = {}

@@ -292,10 +292,12 @@ int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int
  * neighbour sum that evaluates NNConv(aggr='mean') (src_1gp/layer.py:115-122: per-edge [C,C] weights nn(e_ij)) as a
  * K-relation R-GCN without the [E, C*C] tensor.  The backward (w.r.t. x) walks the CSR transpose. */
 int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
-                       int64_t N, int64_t E, int D, int K, int mean, float* out, void* stream);
+                       int64_t N, int64_t E, int D, int K, int mean, int self_slot, float* out, void* stream);
 int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst,
                        const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K, int mean,
-                       float* dx, void* stream);
+                       int self_slot, float* dx, void* stream);
+/* self_slot = 1 (K in {4, 8}, D % 4 == 0): out is f32[N, K+1, D] and slot K of node n is x[n] itself — NNConv's root term
+ * x_i @ root (src_1gp/layer.py:119) as one more relation, so that the layer is ONE GEMM [N, (K+1) D] x [(K+1) D, out]. */
 
 /* ---------------------------------------------------------------------------------------------
  * Per-pair fusion of the two-tower models: out f32[P,2] = [max, mean] of mol[seg_i] @ pro[seg_i]^T for every pair i
