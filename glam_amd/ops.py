@@ -603,6 +603,7 @@ class _MatmulTall(torch.autograd.Function):
         a, w = f32c(a, "a"), f32c(w, "w")
         ctx.save_for_backward(a, w)
         ctx.has_bias = bias is not None
+        ctx.scope = _SCOPE
         return torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
 
     @staticmethod
@@ -612,7 +613,18 @@ class _MatmulTall(torch.autograd.Function):
         dy = f32c(dy, "dy")
         N, K = a.shape
         M = w.size(1)
-        da = torch.matmul(dy, w.t()) if ctx.needs_input_grad[0] else None
+        da = None
+        if ctx.needs_input_grad[0]:
+            if M <= 96 and K <= 320 and K > 64:
+                # dy[N, M] @ w^T[M, K] with a wide output: the 120 KB-image k_ts_gemm variant (the library GEMM picks 16x256
+                # tiles for this shape: 44 us for 60 -> 300 at N = 20 k)
+                lib = _lib.load()
+                scope = ctx.scope
+                img = _scoped(scope.bwd if scope else None, ("tall-dx", id(w)), w, lambda: _ts_image(w, M, K, True))
+                da = torch.empty(N, K, dtype=torch.float32, device=a.device)
+                check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(da), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+            else:
+                da = torch.matmul(dy, w.t())
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.has_bias:
             lib = _lib.load()
