@@ -108,10 +108,16 @@ def weight_scope():
     """``with ops.weight_scope():`` around a model forward (``glam_amd.model.Architecture`` does it)."""
     global _SCOPE
     prev, _SCOPE = _SCOPE, _WeightScope()
+    scope = _SCOPE
     try:
         yield
     finally:
         _SCOPE = prev
+        # The forward table is only read while the forward runs.  Some of its entries carry autograd history that leads back
+        # to nodes holding this scope (for their backward images): dropping the table here leaves no reference cycle, so the
+        # pass's activations are released when its backward finishes, not whenever Python's cycle collector next runs (a
+        # collection in the middle of a later hipGraph capture brings the capture down).
+        scope.fwd.clear()
 
 
 def scoped_weights(key, owner, build):
@@ -290,6 +296,46 @@ def fused_layer_supported(C, heads, De):
     return heads * Cp + 8 <= 192 and Cp <= 64 and De <= 8 and 1 <= heads <= 4
 
 
+# ---- gradient carry of a block's parameters ---------------------------------------------------------------------------
+# A MessageBlock applies the SAME parameters message_steps times per forward (src_1gp/model.py:53-54), so autograd would sum
+# message_steps gradients per parameter tensor: 17 small add kernels per training step of the default model.  Inside a
+# weight_scope the parameters instead enter the graph once, through a `_ParamBundle` node whose output (an uninitialised
+# flat tensor — only its GRADIENT matters) is threaded through the applications as an extra input / output: application k's
+# backward receives the gradients accumulated by the later applications, adds its own flat gradient buffer (one add), and
+# hands the sum on; the bundle's backward splits the total into per-parameter views.  Works for .backward() and
+# autograd.grad alike; outside a scope (or without grad) the ops return per-parameter gradients as before.
+GRAD_CARRY = os.environ.get("GLAM_GRAD_CARRY", "1") == "1"
+
+
+class _ParamBundle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, split, total, *params):
+        ctx.split = split
+        return torch.empty(total, dtype=torch.float32, device=params[0].device)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_flat):
+        return (None, None) + tuple(ctx.split(d_flat))
+
+
+def _carry_for(key, params, total, split):
+    """The scope's carry tensor for this parameter set (created on the block's first application of the pass), or None
+    when gradients are off / there is no scope."""
+    scope = _SCOPE
+    if scope is None or not GRAD_CARRY or not torch.is_grad_enabled() or not any(p.requires_grad for p in params):
+        return None
+    hit = scope.fwd.get(key)
+    if hit is not None and hit[0] is params[0]:
+        return hit[1]
+    return _ParamBundle.apply(split, total, *params)
+
+
+def _carry_store(key, owner, carry):
+    if _SCOPE is not None and carry is not None:
+        _SCOPE.fwd[key] = (owner, carry)
+
+
 # Storage of the gathered node rows xw[N, H*C] between the node GEMM and the aggregate kernels: "fp32" (the reference's
 # precision, the 1e-5 parity bar) or "bf16" (BASELINE config 3: bf16 storage, fp32 logits / softmax / accumulation).
 FEATURE_STORAGE = os.environ.get("GLAM_STORAGE", "fp32")
@@ -313,7 +359,7 @@ class _TripletLayer(torch.autograd.Function):
     gather/softmax/scatter-add, update GEMM — and the hand-written backward of all of it."""
 
     @staticmethod
-    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope):
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None):
         require_device(x_p, ea_p, wn, we, att, wsc, bias)
         x_p, ea_p = f32c(x_p, "x"), f32c(ea_p, "edge_attr")
         wn, we, att, wsc, bias = (f32c(t, n) for t, n in ((wn, "weight_node"), (we, "weight_edge"),
@@ -326,6 +372,7 @@ class _TripletLayer(torch.autograd.Function):
         lib, dev = _lib.load(), x_p.device
         HC = H * Cp
         f = dict(dtype=torch.float32, device=dev)
+        ctx.carried = carry is not None
         def build():
             buf = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
             check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(buf),
@@ -344,7 +391,7 @@ class _TripletLayer(torch.autograd.Function):
                                                  stream()), "glam_triplet_layer_fwd_x16")
             ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
             ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
-            return out
+            return (out, carry.view(-1)) if ctx.carried else out
         # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
         # faster at B=1024 (one tile per CU) but slower beyond, where its barrier-separated phases leave the CU idle
         # (measurements in DESIGN.md).
@@ -355,11 +402,11 @@ class _TripletLayer(torch.autograd.Function):
                                          stream()), "glam_triplet_layer_fwd")
         ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
-        return out
+        return (out, carry.view(-1)) if ctx.carried else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, d_carry=None):
         x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
@@ -384,18 +431,34 @@ class _TripletLayer(torch.autograd.Function):
                                                         ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
                                                         ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(ws),
                                                         ws.numel(), stream()), "glam_triplet_layer_bwd_params_x16")
-            return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
+            if ctx.carried:
+                return d_x, None, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
+            return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
                                                 ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(d_ea), ptr(ws),
                                                 ws.numel(), stream()), "glam_triplet_layer_bwd_params")
-        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
+        if ctx.carried:
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
 
 
 def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
     """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
-    return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+    params = (weight_node, weight_edge, att, weight_scale, bias)
+    C = weight_node.size(0)
+    sizes = [weight_node.numel(), weight_edge.numel(), att.numel(), heads * C * C, C]
+    shapes = (weight_node.shape, weight_edge.shape, att.shape, (heads * C, C), (C,))
+    key = ("carry-triplet", id(weight_node))
+    carry = _carry_for(key, params, sum(sizes), lambda flat: [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)])
+    if carry is None:
+        return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+    # the parameters still enter as inputs (the kernels read them, and the scope's staging cache is keyed on them), but this
+    # node returns no gradient for them: it flows through `carry`
+    out, carry = _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry)
+    _carry_store(key, weight_node, carry)
+    return out
 
 
 class _TripletLayerWide(torch.autograd.Function):
