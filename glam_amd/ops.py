@@ -897,7 +897,7 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
     C = h.size(1)
     if gru_block_supported(C, w_ih, b_ih, b_hh):
-        return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in)
+        return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in)
     Cp = (C + 3) // 4 * 4
     if Cp != C and b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_supported(Cp, 3 * Cp) \
             and 3 * Cp > 64:
@@ -908,8 +908,8 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
             pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
             return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
         wi, wh, bi, bh = scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build)
-        out_p, hn_p = _GruBlock.apply(pad_cols(x, Cp), pad_cols(h, Cp), None if identity is None else pad_cols(identity, Cp),
-                                      wi, wh, bi, bh, ACT_CODES[act], slope, celu_in)
+        out_p, hn_p = _gru_block(pad_cols(x, Cp), pad_cols(h, Cp), None if identity is None else pad_cols(identity, Cp),
+                                 wi, wh, bi, bh, ACT_CODES[act], slope, celu_in)
         return slice_cols(out_p, C), slice_cols(hn_p, C)
     if b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_tall_supported(Cp, 3 * Cp) and h.size(0) >= 64:
         # wide GRU (hid_dim_alpha = 6): library GEMMs for the gate products, k_wgrad for their weight gradients, at Cp
@@ -930,6 +930,21 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
 
 
+def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in):
+    """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
+    M, C = w_ih.shape
+    def split(flat):
+        d = flat.view(2, M + 1, C + 1)
+        return d[0, :M, :C], d[1, :M, :C], d[0, :M, C], d[1, :M, C]
+    key = ("carry-gru", id(w_ih))
+    carry = _carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * (M + 1) * (C + 1), split)
+    if carry is None:
+        return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in)
+    out, h_new, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry)
+    _carry_store(key, w_ih, carry)
+    return out, h_new
+
+
 class _GruBlock(torch.autograd.Function):
     """The whole GRU step of a MessageBlock as ONE autograd node: both gate GEMMs + gates/residual/activation forward;
     gate backward + both input-gradient GEMMs + BOTH weight-gradient products in one launch pair backward.  Besides the
@@ -937,7 +952,7 @@ class _GruBlock(torch.autograd.Function):
     one, which is what an eagerly issued training step is bound by."""
 
     @staticmethod
-    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in):
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None):
         require_device(x, h, w_ih, w_hh, b_ih, b_hh)
         x, h = f32c(x, "x"), f32c(h, "h")
         w_ih, w_hh, b_ih, b_hh = f32c(w_ih, "weight_ih"), f32c(w_hh, "weight_hh"), f32c(b_ih, "bias_ih"), f32c(b_hh, "bias_hh")
@@ -979,11 +994,12 @@ class _GruBlock(torch.autograd.Function):
         ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
         ctx.cfg = (act, float(slope), identity is not None, bool(celu_in))
         ctx.scope = scope
-        return out, h_new
+        ctx.carried = carry is not None
+        return (out, h_new, carry.view(-1)) if ctx.carried else (out, h_new)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out, d_hstate):
+    def backward(ctx, d_out, d_hstate, d_carry=None):
         x, h, gi, gh, out, w_ih, w_hh = ctx.saved_tensors
         act, slope, has_res, celu_in = ctx.cfg
         N, C = h.shape
@@ -1014,11 +1030,15 @@ class _GruBlock(torch.autograd.Function):
         dh.add_(d_h)                                  # + the direct z * g path of the gate equations
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
-        dwb_ih, dwb_hh = torch.empty(M + 1, C + 1, **f), torch.empty(M + 1, C + 1, **f)
+        dwb = torch.empty(2, M + 1, C + 1, **f)          # one buffer: the gradient carry adds it with one kernel
+        dwb_ih, dwb_hh = dwb[0], dwb[1]
         check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
                                        ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),
               "glam_wgrad_gemm_pair")
-        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None, None
+        if ctx.carried:
+            flat = dwb.view(-1)
+            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry))
+        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None, None, None
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):
