@@ -1108,3 +1108,31 @@ def test_misuse_raises_python_exceptions_and_leaves_the_device_usable(device):
     xt = torch.randn(60, b.x.size(0), device=device).t()              # non-contiguous input: accepted
     assert conv(xt, b.edge_index, b.edge_attr).shape == ok.shape
     assert torch.equal(conv(x, b.edge_index, b.edge_attr), ok)        # the device is still fine
+
+
+def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device):
+    """Inside a weight scope the shared block's parameter gradients travel from application to application as one flat
+    buffer (ops._ParamBundle); same sums in the same order as autograd's per-tensor accumulation."""
+    torch.manual_seed(9)
+    b = synth_batch(48, seed=2).to(device)
+    net = model.Architecture(message_steps=3, mol_block="_TripletMessage", graph_norm="_None", graph_do="_None()", end_do="_None()",
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device).eval()
+    params = [p for _, p in net.named_parameters()]
+    grads = {}
+    for flag in (True, False):
+        ops.GRAD_CARRY = flag
+        try:
+            out = net(b)
+            grads[flag] = torch.autograd.grad(out.sum(), params)
+        finally:
+            ops.GRAD_CARRY = True
+    for (n, _), a, r in zip(net.named_parameters(), grads[True], grads[False]):
+        assert torch.equal(a, r), n
+    # .backward(): the carried gradients land in .grad as views of one buffer per parameter set (no copies)
+    net.zero_grad(set_to_none=True)
+    net(b).sum().backward()
+    conv = net.mol_conv.conv.conv
+    ptrs = [p.grad.data_ptr() for p in (conv.weight_node, conv.weight_edge, conv.weight_triplet_att, conv.weight_scale, conv.bias)]
+    assert ptrs == sorted(ptrs) and ptrs[-1] - ptrs[0] < 4 * sum(p.numel() for p in conv.parameters())
+    for (n, p), r in zip(net.named_parameters(), grads[False]):
+        assert torch.equal(p.grad, r), n
