@@ -1136,3 +1136,29 @@ def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device):
     assert ptrs == sorted(ptrs) and ptrs[-1] - ptrs[0] < 4 * sum(p.numel() for p in conv.parameters())
     for (n, p), r in zip(net.named_parameters(), grads[False]):
         assert torch.equal(p.grad, r), n
+
+
+def test_sharded_gradients_sum_to_the_single_device_gradient(device):
+    """the correctness oracle of the data-parallel path is the single-device run on the concatenated batch.
+    Two node-balanced graph shards through DataParallelStep (one process: the all-reduce is the identity) summed by hand
+    against one backward on the full batch, on the HIP path."""
+    from glam_amd.parallel import DataParallelStep, shard_batch
+    torch.manual_seed(0)
+    net = model.Architecture(message_steps=3, mol_block="_TripletMessage", graph_norm="_None", graph_do="_None()", end_do="_None()",
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device).eval()
+    full = synth_batch(64, seed=5)
+    mse = torch.nn.functional.mse_loss
+    net.zero_grad(set_to_none=True)
+    b = full.to(device)
+    mse(net(b).view(-1), b.y.view(-1)).backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    step = DataParallelStep(net, lambda out, s: (mse(out.view(-1), s.y.view(-1), reduction="sum") / 64, 1.0))
+    tot = None
+    for r in range(2):
+        step(shard_batch(full, r, 2).to(device))
+        g = step.bucket.flat.clone()
+        tot = g if tot is None else tot + g
+    off = 0
+    for (n, p), r_ in zip(net.named_parameters(), ref):
+        assert_close(tot[off:off + p.numel()].view_as(p), r_, 2e-5, "sharded grad " + n)
+        off += p.numel()
