@@ -1162,3 +1162,40 @@ def test_sharded_gradients_sum_to_the_single_device_gradient(device):
     for (n, p), r_ in zip(net.named_parameters(), ref):
         assert_close(tot[off:off + p.numel()].view_as(p), r_, 2e-5, "sharded grad " + n)
         off += p.numel()
+
+
+def test_readouts_and_norms_with_empty_and_tiny_graphs(device):
+    """Graph ids that skip values (empty graphs), single-node graphs and graphs with fewer than k = 3 nodes through the
+    wave-per-graph kernels at a padded width: GlobalPool5, PairNorm, Set2Set and GlobalLAPool against the oracle."""
+    torch.manual_seed(61)
+    C = 60
+    sizes = {0: 5, 2: 1, 3: 2, 5: 34, 6: 3}          # graphs 1 and 4 are empty; B = 8 with a trailing empty graph
+    B = 8
+    batch = torch.cat([torch.full((n,), g) for g, n in sizes.items()])
+    N = batch.numel()
+    x0 = torch.randn(N, C)
+    bd = batch.to(device)
+
+    def compare(ref_fn, dev_fn, what, extra=()):
+        xo = x0.clone().requires_grad_(True)
+        ref = ref_fn(xo)
+        cot = torch.randn(ref.shape)
+        (g_ref,) = _grads(ref, cot, [xo])
+        x = x0.to(device).requires_grad_(True)
+        out = dev_fn(x)
+        assert_close(out, ref, 2e-5, what)
+        assert_close(_grads(out, cot.to(device), [x])[0], g_ref, 5e-5, what + " d_x")
+
+    compare(lambda x: O.global_pool5(x, batch, B), lambda x: layer.GlobalPool5()(x, bd, B), "pool5")
+    compare(lambda x: O.pair_norm(x, batch, B), lambda x: ops.pair_norm(x, ops.segment_ptr(bd, B)), "pair_norm")
+    ro = layer.Set2Set(C, 3)
+    import copy
+    lstm_ref = copy.deepcopy(ro.lstm)
+    ro = ro.to(device)
+    compare(lambda x: O.set2set(x, batch, B, lstm_ref, steps=3), lambda x: ro(x, bd, B), "set2set")
+    la = layer.GlobalLAPool(C)
+    sd = {k: v.detach().clone() for k, v in la.state_dict().items()}
+    la = la.to(device)
+    compare(lambda x: O.global_attention(x, batch, B, sd["pool.gate_nn.weight"], sd["pool.gate_nn.bias"], sd["pool.nn.weight"],
+                                         sd["pool.nn.bias"]),
+            lambda x: la(x, bd, B), "lapool")
