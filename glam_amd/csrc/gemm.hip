@@ -472,6 +472,16 @@ int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob
     return GLAM_OK;
 }
 
+// N = 0 (an empty batch / shard): the products are all-zero matrices
+__global__ void __launch_bounds__(kBlock) k_zero_strided(float* out, int I, int J, int si, int sj) {
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < I * J; e += gridDim.x * kBlock) out[(size_t)(e / J) * si + (size_t)(e % J) * sj] = 0.f;
+}
+static int zero_product(float* out, int I, int J, int si, int sj, hipStream_t s) {
+    if (I * J > 0) hipLaunchKernelGGL(k_zero_strided, dim3(grid_for((int64_t)I * J, kBlock)), dim3(kBlock), 0, s, out, I, J, si, sj);
+    GLAM_LAUNCH_CHECK("wgrad(N = 0)");
+    return GLAM_OK;
+}
+
 int launch_final_reduce(ReduceArgs ra, hipStream_t s) {
     int blocks = 0;
     for (int q = 0; q < ra.njobs; ++q) {
@@ -532,6 +542,11 @@ extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_
                                     const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
                                     int64_t N, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_pair: N out of range");
+    if (N == 0) {
+        GLAM_REQUIRE(out_a && out_b, "glam_wgrad_gemm_pair: null pointer");
+        if (int rc = zero_product(out_a, Ia + (ones_a ? 1 : 0), Ja + (qones_a ? 1 : 0), si_a, sj_a, (hipStream_t)stream)) return rc;
+        return zero_product(out_b, Ib + (ones_b ? 1 : 0), Jb + (qones_b ? 1 : 0), si_b, sj_b, (hipStream_t)stream);
+    }
     GLAM_REQUIRE(Pa && Qa && out_a && Pb && Qb && out_b && ws, "glam_wgrad_gemm_pair: null pointer");
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_pair: workspace too small");
     GLAM_REQUIRE(aligned16(Qa) && aligned16(Pa) && aligned16(Qb) && aligned16(Pb), "glam_wgrad_gemm_pair: P / Q must be 16-byte aligned");
@@ -549,6 +564,10 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
                                const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
                                int stride_j, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm: N out of range");
+    if (N == 0) {
+        GLAM_REQUIRE(out, "glam_wgrad_gemm: null pointer");
+        return zero_product(out, I1 + I2 + (ones ? 1 : 0), J + (qones ? 1 : 0), stride_i, stride_j, (hipStream_t)stream);
+    }
     GLAM_REQUIRE(P1 && Q && out && ws && (I2 == 0 || P2), "glam_wgrad_gemm: null pointer");
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm: workspace too small");
     GLAM_REQUIRE(aligned16(Q) && aligned16(P1) && aligned16(P2), "glam_wgrad_gemm: P / Q must be 16-byte aligned");

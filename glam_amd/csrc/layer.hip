@@ -603,6 +603,18 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     return launch_final_reduce(ra, s);
 }
 
+// an empty batch (N = 0, e.g. an empty shard of a data-parallel step): every parameter gradient is zero
+static int zero_param_grads(int C, int H, int De, float* d_wn, float* d_we, float* d_att, float* d_wsc, float* d_bias, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(d_wn, 0, (size_t)C * H * C * sizeof(float), s);
+    (void)hipMemsetAsync(d_we, 0, (size_t)De * H * C * sizeof(float), s);
+    (void)hipMemsetAsync(d_att, 0, (size_t)H * 3 * C * sizeof(float), s);
+    (void)hipMemsetAsync(d_wsc, 0, (size_t)H * C * C * sizeof(float), s);
+    (void)hipMemsetAsync(d_bias, 0, (size_t)C * sizeof(float), s);
+    GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd_params(N = 0)");
+    return GLAM_OK;
+}
+
 extern "C" int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
                                       const float* a_ij, const float* aggr, const float* stats, const float* d_out,
                                       const int32_t* rowptr, const int32_t* src, const int32_t* eid,
@@ -625,6 +637,7 @@ extern "C" int glam_triplet_layer_bwd_params(const float* x, const float* edge_a
     if (int rc = dims_ok("glam_triplet_layer_bwd_params", C, H, De, Cp, Dp)) return rc;
     GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
                  "glam_triplet_layer_bwd_params: null pointer");
+    if (N == 0) return zero_param_grads(C, H, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, stream);
     const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
     return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
                           Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po);
@@ -641,6 +654,7 @@ extern "C" int glam_triplet_layer_bwd_params_x16(const float* x, const float* ed
     if (int rc = dims_ok("glam_triplet_layer_bwd_params_x16", C, H, De, Cp, Dp)) return rc;
     GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
                  "glam_triplet_layer_bwd_params_x16: null pointer");
+    if (N == 0) return zero_param_grads(C, H, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, stream);
     const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
     return layer_bwd_impl(x, edge_attr, staged, reinterpret_cast<const float*>(xw16), a_ij, aggr, stats, d_out, rowptr, src, eid,
                           colptr, dst, eid_t, N, E, H, Cp, Dp, slope, d_x, nullptr, nullptr, ws, ws_bytes, stream, &po, 1);

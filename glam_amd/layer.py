@@ -329,7 +329,7 @@ class GCNConv(MessagePassing):
         if norm.requires_grad:         # learnable edge weights: per-edge messages, so that autograd reaches them
             out = ops.edge_reduce(norm * xw.index_select(0, ei[0]), gi, "sum")
         else:                          # one gather-scale-sum kernel per direction (K = 1 relation)
-            out = ops.edge_weighted_sum(xw, norm, gi).view(n, -1)
+            out = ops.edge_weighted_sum(xw, norm, gi).view(n, xw.size(1))
         return out if (self.bias is None or not add_bias) else out + self.bias
 
 

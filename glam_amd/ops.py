@@ -519,6 +519,10 @@ class _TripletLayerWide(torch.autograd.Function):
         lib, dev = _lib.load(), x_p.device
         f = dict(dtype=torch.float32, device=dev)
         d_out = f32c(d_out, "d_out")
+        if N == 0:        # an empty batch: every gradient is zero
+            z = lambda t: torch.zeros_like(t)
+            return (torch.zeros_like(x_p), torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None, z(wn), z(we), z(att),
+                    torch.zeros(H * C, C, **f), torch.zeros(C, **f), None, None, None)
         Wcat, Ws_p, We_p, M, _ = _plain_views(plain, H, Cp, Dp)
         colptr, dst, eid_t = gi.transpose()
         # dstaged: d_Wcat[Cp, HC+8] | d_WsB[HC+1, Cp] | d_We_p[Dp, HC] | d_M[Dp, 4]   (include/glam_hip.h)

@@ -78,7 +78,7 @@ def triplet_message(x, edge_index, edge_attr, weight_node, weight_edge, weight_t
     xw = torch.matmul(x, weight_node)                       # layer.py:37
     ew = torch.matmul(edge_attr, weight_edge)               # layer.py:38
     aggr = triplet_aggregate(xw, edge_index, ew, weight_triplet_att, heads, slope)
-    out = torch.matmul(aggr.reshape(x.size(0), -1), weight_scale)   # layer.py:58-59
+    out = torch.matmul(aggr.reshape(x.size(0), weight_scale.size(0)), weight_scale)   # layer.py:58-59 (explicit width: N = 0 is legal)
     return out + bias                                       # layer.py:60
 
 

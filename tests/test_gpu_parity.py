@@ -1199,3 +1199,31 @@ def test_readouts_and_norms_with_empty_and_tiny_graphs(device):
     compare(lambda x: O.global_attention(x, batch, B, sd["pool.gate_nn.weight"], sd["pool.gate_nn.bias"], sd["pool.nn.weight"],
                                          sd["pool.nn.bias"]),
             lambda x: la(x, bd, B), "lapool")
+
+
+@pytest.mark.parametrize("C", [45, 60, 90])
+def test_empty_batch_forward_and_backward(device, C):
+    """N = 0 (an empty shard of a data-parallel step) on every width class: outputs are empty, parameter gradients zero."""
+    conv = layer.TripletMessage(C, 4).to(device)
+    x = torch.zeros(0, C, device=device, requires_grad=True)
+    out = conv(x, torch.zeros(2, 0, dtype=torch.long, device=device), torch.zeros(0, 4, device=device))
+    assert out.shape == (0, C)
+    gs = torch.autograd.grad(out.sum(), [x] + list(conv.parameters()), allow_unused=True)
+    for g_ in gs[1:]:
+        assert g_ is None or float(g_.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("block,readout", [("_TripletMessage", "GlobalPool5"), ("_NNConv", "Set2Set"), ("_GCNConv", "GlobalLAPool"),
+                                           ("_TripletMessageLight", "GlobalPool5"), ("_GATConv", "GlobalPool5")])
+def test_full_model_on_an_empty_shard(device, block, readout):
+    """More ranks than graphs: a data-parallel rank may own nothing.  The whole model runs on the empty shard — output
+    [0, out_dim], every parameter gradient exactly zero — so that the gradient all-reduce stays collective."""
+    from glam_amd.parallel import shard_batch
+    full = synth_batch(4, seed=0)
+    shard = next(sh for sh in (shard_batch(full, r, 8) for r in range(8)) if sh.num_graphs == 0).to(device)
+    net = model.Architecture(mol_block=block, mol_readout=readout, graph_norm="_PairNorm", graph_do="_None()", end_do="_None()",
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device)
+    out = net(shard)
+    assert out.shape == (0, 1)
+    out.sum().backward()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in net.parameters() if p.grad is not None)
