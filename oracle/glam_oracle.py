@@ -326,8 +326,8 @@ def message_block(sd, prefix, x, edge_index, edge_attr, h, batch, num_graphs, co
         x = F.celu(x)                                        # layer.py:261
         h = gru_step(x, h, sd[g + "weight_ih_l0"], sd[g + "weight_hh_l0"], sd[g + "bias_ih_l0"], sd[g + "bias_hh_l0"])
         x = h                                                # layer.py:262-263
-    if res:
-        x = x + identity                                     # layer.py:265
+    if res is not False:                                     # layer.py:265 tests `self.res is False`: graph_res = 0 (an int,
+        x = x + identity                                     # run.py:38 / glam.py:81) still adds the residual, as in the reference
     return activation(act, x), h
 
 

@@ -1227,3 +1227,18 @@ def test_full_model_on_an_empty_shard(device, block, readout):
     assert out.shape == (0, 1)
     out.sum().backward()
     assert all(float(p.grad.abs().max()) == 0.0 for p in net.parameters() if p.grad is not None)
+
+
+def test_graph_res_zero_keeps_the_residual_like_the_reference(device):
+    """src_1gp/layer.py:265 tests ``self.res is False``: ``graph_res=0`` (the int that run.py:38 / glam.py:81 pass) is not
+    ``False``, so the reference still adds the residual; only the literal ``False`` removes it.  Mirrored, not "fixed"."""
+    torch.manual_seed(3)
+    b = synth_batch(6, seed=1).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device)
+    outs = []
+    for res in (True, 1, 0, False):                    # (a dict would merge the keys 0 / False and 1 / True)
+        torch.manual_seed(11)
+        blk = layer.MessageBlock(60, 60, 4, norm="_None", dropout="_None()", conv="_TripletMessage", act="ReLU", res=res).to(device).eval()
+        outs.append(blk(x, b.edge_index, b.edge_attr, batch=b.batch)[0])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not torch.equal(outs[0], outs[3])

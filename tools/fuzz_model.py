@@ -1,0 +1,50 @@
+"""Randomised full-model parity sweep (HIP path vs the CPU oracle): widths, convs, norms, readouts, activations, residuals.
+usage: python tools/fuzz_model.py [n_cases] [seed]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from glam_amd import model
+from glam_amd.data import synth_batch
+import oracle.glam_oracle as O
+
+dev = torch.device("cuda")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n_cases):
+    cfg = dict(alpha=int(rng.choice([1, 2, 3, 4, 6])), block=str(rng.choice(["_TripletMessage", "_NNConv", "_TripletMessageLight", "_GCNConv", "_GATConv"])),
+               readout=str(rng.choice(["GlobalPool5", "GlobalLAPool"])), norm=str(rng.choice(["_None", "_PairNorm", "_LayerNorm"])),
+               act=str(rng.choice(["ReLU", "CELU", "LeakyReLU", "_None"])), res=int(rng.integers(0, 2)), steps=int(rng.integers(1, 4)),
+               B=int(rng.integers(1, 13)), out_dim=int(rng.choice([1, 2, 12])))
+    try:
+        torch.manual_seed(1000 + case)
+        b = synth_batch(cfg["B"], seed=case)
+        net = model.Architecture(hid_dim_alpha=cfg["alpha"], e_dim=64, out_dim=cfg["out_dim"], message_steps=cfg["steps"], mol_block=cfg["block"],
+                                 mol_readout=cfg["readout"], graph_norm=cfg["norm"], pre_act=cfg["act"], graph_act=cfg["act"], flat_act=cfg["act"],
+                                 graph_res=cfg["res"], graph_do="_None()", end_do="_None()").eval()
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        ref = O.architecture(sd, b, b.num_graphs, message_steps=cfg["steps"], mol_block=cfg["block"], mol_readout=cfg["readout"],
+                             graph_norm=cfg["norm"], pre_act=cfg["act"], graph_act=cfg["act"], flat_act=cfg["act"], graph_res=cfg["res"])
+        cot = torch.randn(ref.shape)
+        names = [n for n, _ in net.named_parameters()]
+        g_ref = torch.autograd.grad((ref * cot).sum(), [sd[n] for n in names], allow_unused=True)
+        net = net.to(dev)
+        out = net(b.to(dev))
+        scale = max(1.0, ref.abs().max().item())
+        err = (out.cpu() - ref).abs().max().item()
+        assert err <= 3e-5 * scale, f"out {err:.2e} > {3e-5 * scale:.2e}"
+        gs = torch.autograd.grad((out * cot.to(dev)).sum(), [p for _, p in net.named_parameters()], allow_unused=True)
+        for n, a, r in zip(names, gs, g_ref):
+            if r is None:
+                assert a is None or float(a.abs().max()) == 0.0, n
+                continue
+            assert a is not None, n + " missing"
+            e = (a.cpu() - r).abs().max().item()
+            lim = 2e-4 * max(1.0, r.abs().max().item())
+            assert e <= lim, f"grad {n}: {e:.2e} > {lim:.2e}"
+        print("ok  ", cfg, flush=True)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print("FAIL", cfg, "->", type(e).__name__, str(e)[:200], flush=True)
+print(f"{n_cases - bad}/{n_cases} cases passed")
+sys.exit(1 if bad else 0)
