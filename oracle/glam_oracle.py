@@ -354,3 +354,24 @@ def architecture(sd, data, num_graphs, message_steps=3, mol_block="_TripletMessa
         raise ValueError(mol_readout)
     out = linear_block(sd, "mol_flat.", out, flat_act)                           # model.py:60
     return linear_block(sd, "lin_out1.", out, "_None")                           # model.py:61
+
+
+def architecture_dti(sd, mol, pro, num_pairs, message_steps=3, mol_block="_NNConv", pro_block="_GCNConv", graph_norm="_None",
+                     pre_act="RReLU", graph_act="RReLU", flat_act="RReLU", end_act="RReLU", graph_res=True):
+    """Two-tower ``Architecture.forward`` (src_2gi_dti_scr/model.py:45-68), eval mode, GlobalPool5 readouts: ligand and
+    protein towers stepped side by side, ``dot_and_global_pool2`` of the two node sets after every message step, readouts,
+    ``lin_out0`` on ``[outm | outp | fusion]``, ``lin_out1``."""
+    xm = linear_block(sd, "mol_lin0.", mol.x, pre_act)                           # :47
+    xp = linear_block(sd, "pro_lin0.", pro.x, pre_act)                           # :48
+    hm = hp = None
+    fusion = []
+    for _ in range(message_steps):                                               # :53-56
+        xm, hm = message_block(sd, "mol_conv.", xm, mol.edge_index, mol.edge_attr, hm, mol.batch, num_pairs, conv=mol_block,
+                               norm=graph_norm, act=graph_act, res=graph_res)
+        xp, hp = message_block(sd, "pro_conv.", xp, pro.edge_index, pro.edge_attr, hp, pro.batch, num_pairs, conv=pro_block,
+                               norm=graph_norm, act=graph_act, res=graph_res)
+        fusion.append(dot_and_global_pool(xm, xp, mol.batch, pro.batch, num_pairs, stats=2))
+    outm = linear_block(sd, "mol_flat.", global_pool5(xm, mol.batch, num_pairs), flat_act)    # :59-60
+    outp = linear_block(sd, "pro_flat.", global_pool5(xp, pro.batch, num_pairs), flat_act)    # :61-62
+    out = torch.cat([outm, outp, torch.cat(fusion, dim=-1)], dim=-1)             # :65
+    return linear_block(sd, "lin_out1.", linear_block(sd, "lin_out0.", out, end_act), "_None")

@@ -1242,3 +1242,29 @@ def test_graph_res_zero_keeps_the_residual_like_the_reference(device):
         outs.append(blk(x, b.edge_index, b.edge_attr, batch=b.batch)[0])
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert not torch.equal(outs[0], outs[3])
+
+
+@pytest.mark.parametrize("mol_block,pro_block,norm", [("_NNConv", "_GCNConv", "_None"), ("_TripletMessage", "_TripletMessage", "_PairNorm"),
+                                                     ("_NNConv", "_GATConv", "_LayerNorm")])
+def test_two_tower_model_vs_oracle(device, mol_block, pro_block, norm):
+    """ArchitectureDTI (BASELINE config 5) against the oracle's restatement of src_2gi_dti_scr/model.py:45-68: output and
+    every parameter gradient, protein graphs large enough for the block-per-graph kernels."""
+    torch.manual_seed(12)
+    mb = synth_batch(5, seed=3)
+    pb = synth_protein_batch(5, seed=4, n_min=40, n_max=130)
+    net = model.ArchitectureDTI(mol_block=mol_block, pro_block=pro_block, e_dim=64, message_steps=2, graph_norm=norm,
+                                pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU", graph_do="_None()", end_do="_None()").eval()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref = O.architecture_dti(sd, mb, pb, 5, message_steps=2, mol_block=mol_block, pro_block=pro_block, graph_norm=norm,
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU")
+    cot = torch.randn(ref.shape)
+    names = [n for n, _ in net.named_parameters()]
+    g_ref = torch.autograd.grad((ref * cot).sum(), [sd[n] for n in names], allow_unused=True)
+    net = net.to(device)
+    out = net(mb.to(device), pb.to(device))
+    assert_close(out, ref, 3e-5, "dti out")
+    gs = torch.autograd.grad((out * cot.to(device)).sum(), [p for _, p in net.named_parameters()], allow_unused=True)
+    for n, a, r in zip(names, gs, g_ref):
+        if r is None:
+            continue
+        assert_close(a, r, 2e-4, "dti grad " + n)
