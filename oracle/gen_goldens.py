@@ -125,7 +125,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(4)
     layer, model = load_reference("src_1gp")
-    layer2, _ = load_reference("src_2gi_dti_scr")
+    layer2, model2 = load_reference("src_2gi_dti_scr")
     worst = 0.0
 
     # ---- TripletMessage: channel sweep on ESOL-shaped batches + edge cases ----------------
@@ -345,6 +345,28 @@ def main():
     save("dotpool_pairs", {"kind": "dot_and_global_pool", "B": 4},
          {"mol_x": mb.x, "pro_x": pb.x, "mol_batch": mb.batch, "pro_batch": pb.batch}, {}, out2, cot,
          {"mol_x": gm, "pro_x": gp, "__out5": out5})
+
+    # ---- two-tower model (src_2gi_dti_scr/model.py:14-68), the reference's default blocks ----------
+    print("Architecture (two towers: ligand + protein)")
+    seed(91)
+    kw = dict(mol_block="_NNConv", pro_block="_GCNConv", graph_norm="_None", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU",
+              end_act="ReLU")
+    net = model2.Architecture(e_dim=64, message_steps=2, graph_do="_None()", end_do="_None()", **kw).eval()
+    mb = synth_batch(4, seed=81)
+    pb = synth_protein_batch(4, seed=82, n_min=30, n_max=90)
+    names = [n for n, _ in net.named_parameters()]
+    out = net(mb, pb)
+    cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(15))
+    gs = grads_of(out, cot, [p for _, p in net.named_parameters()])
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    o_ref = O.architecture_dti(sd, mb, pb, 4, message_steps=2, **kw)
+    worst = max(worst, check("dti out", o_ref, out, 5e-6))
+    for n, g_o, g_r in zip(names, grads_of(o_ref, cot, [sd[n] for n in names]), gs):
+        worst = max(worst, check("dti grad " + n, g_o, g_r, 2e-5))
+    save("dti_nnconv_gcn", {"kind": "ArchitectureDTI", "B": 4, "e_dim": 64, "message_steps": 2, **kw},
+         {"mol_x": mb.x, "mol_edge_index": mb.edge_index, "mol_edge_attr": mb.edge_attr, "mol_batch": mb.batch,
+          "pro_x": pb.x, "pro_edge_index": pb.edge_index, "pro_edge_attr": pb.edge_attr, "pro_batch": pb.batch},
+         {k: v for k, v in net.state_dict().items()}, out, cot, dict(zip(names, gs)))
 
     print(f"oracle pinned against the reference: worst scaled max|d| = {worst:.3e}")
 

@@ -1268,3 +1268,24 @@ def test_two_tower_model_vs_oracle(device, mol_block, pro_block, norm):
         if r is None:
             continue
         assert_close(a, r, 2e-4, "dti grad " + n)
+
+
+def test_two_tower_architecture_golden(device):
+    """ArchitectureDTI on the HIP path against the vectors captured from the reference's own two-tower model
+    (src_2gi_dti_scr/model.py run over the PyG stand-in, oracle/gen_goldens.py)."""
+    g = Golden("dti_nnconv_gcn")
+    m = g.meta
+    net = model.ArchitectureDTI(e_dim=m["e_dim"], message_steps=m["message_steps"], mol_block=m["mol_block"], pro_block=m["pro_block"],
+                                graph_norm=m["graph_norm"], pre_act=m["pre_act"], graph_act=m["graph_act"], flat_act=m["flat_act"],
+                                end_act=m["end_act"], graph_do="_None()", end_do="_None()")
+    net.load_state_dict(g.params)
+    net = net.to(device).eval()
+    i = _dev(g.inputs, device)
+    mol = Data(i["mol_x"], i["mol_edge_index"], i["mol_edge_attr"], batch=i["mol_batch"])
+    pro = Data(i["pro_x"], i["pro_edge_index"], i["pro_edge_attr"], batch=i["pro_batch"])
+    mol.num_graphs = pro.num_graphs = m["B"]
+    out = net(mol, pro)
+    assert_close(out, g.out, 2e-5, "dti out")
+    names = [n for n, _ in net.named_parameters()]
+    for n, t in zip(names, _grads(out, g.cot.to(device), [p for _, p in net.named_parameters()])):
+        assert_close(t, g.grads[n], 1e-4, f"dti/grad.{n}")
