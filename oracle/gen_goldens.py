@@ -297,7 +297,9 @@ def main():
     # ---- Architecture (eval mode) + 3 Adam steps ----------------------------------------------
     print("Architecture")
     for tag, kw in [("triplet_pool5", dict(mol_block="_TripletMessage", mol_readout="GlobalPool5")),
-                    ("light_lapool", dict(mol_block="_TripletMessageLight", mol_readout="GlobalLAPool"))]:
+                    ("light_lapool", dict(mol_block="_TripletMessageLight", mol_readout="GlobalLAPool")),
+                    # the reference's own defaults (run.py:21,25,28): NNConv blocks, PairNorm, GlobalPool5
+                    ("nnconv_pairnorm_pool5", dict(mol_block="_NNConv", mol_readout="GlobalPool5", graph_norm="_PairNorm"))]:
         b = synth_batch(8, seed=61)
         B = 8
         seed(62)
@@ -308,7 +310,7 @@ def main():
         ps = [p for _, p in net.named_parameters()]
         gs = grads_of(out, cot, ps)
         sd = {k: v.detach() for k, v in net.state_dict().items()}
-        oo = O.architecture(sd, b, B, 3, kw["mol_block"], kw["mol_readout"])
+        oo = O.architecture(sd, b, B, 3, kw["mol_block"], kw["mol_readout"], graph_norm=kw.get("graph_norm", "_None"))
         worst = max(worst, check(f"arch/{tag}", oo, out, 1e-5))
         # three optimiser steps exactly as TrainerMolRegression.train_iterations
         # (src_1gp/trainer.py:286-298) but in eval mode (no dropout / RReLU noise)

@@ -206,7 +206,7 @@ def test_architecture_golden(device, name):
     g = Golden(name)
     m = g.meta
     net = model.Architecture(e_dim=m["e_dim"], out_dim=m["out_dim"], message_steps=m["message_steps"],
-                             mol_block=m["mol_block"], mol_readout=m["mol_readout"])
+                             mol_block=m["mol_block"], mol_readout=m["mol_readout"], graph_norm=m.get("graph_norm", "_None"))
     net.load_state_dict(g.params)
     net = net.to(device).eval()
     i = _dev(g.inputs, device)
@@ -220,7 +220,7 @@ def test_architecture_golden(device, name):
         assert_close(t, g.grads[n], 5e-5, f"{name}/grad.{n}")
     # three Adam steps exactly as TrainerMolRegression.train_iterations (trainer.py:286-298)
     net2 = model.Architecture(e_dim=m["e_dim"], out_dim=1, message_steps=m["message_steps"],
-                              mol_block=m["mol_block"], mol_readout=m["mol_readout"])
+                              mol_block=m["mol_block"], mol_readout=m["mol_readout"], graph_norm=m.get("graph_norm", "_None"))
     net2.load_state_dict({k: (v if "lin_out1" not in k else v[:1]) for k, v in g.params.items()})
     net2 = net2.to(device).eval()
     opt = torch.optim.Adam(net2.parameters(), lr=1e-3)
