@@ -252,43 +252,45 @@ __global__ void __launch_bounds__(kBlock) k_segment_attn_bwd_v4(const float* gat
 //      Wave per graph, lane = (row group rg, float4 chunk c4), D % 4 == 0 and D <= 64; 32 nodes per register pass. ----
 constexpr int kS2sRows = 8;
 
+template <int LPR>     // lanes per row: 16 (D <= 64) or 32 (D <= 128)
 __global__ void __launch_bounds__(kBlock) k_s2s_attn_fwd(const float* x, const float* q, const int* ptr, int B, int D, float* r,
                                                         float* stats) {
-    const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
+    constexpr int RG = 64 / LPR;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, rg = lane / LPR;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
     const bool act = 4 * c4 < D;
     for (int g = wave; g < B; g += nwaves) {
         const int beg = ptr[g], end = ptr[g + 1];
         const float4 qv = act ? ld4(q + (size_t)g * D + 4 * c4) : f4zero();
-        const bool small = end - beg <= 4 * kS2sRows;
+        const bool small = end - beg <= RG * kS2sRows;
         float4 row[kS2sRows];
         float e[kS2sRows];
         float m = -INFINITY;
-        for (int b0 = beg; b0 < end; b0 += 4 * kS2sRows) {
+        for (int b0 = beg; b0 < end; b0 += RG * kS2sRows) {
 #pragma unroll
             for (int u = 0; u < kS2sRows; ++u) {
-                const int n = b0 + rg + 4 * u;
+                const int n = b0 + rg + RG * u;
                 row[u] = (act && n < end) ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
             }
 #pragma unroll
             for (int u = 0; u < kS2sRows; ++u) {
-                e[u] = group_sum<16>(dot4(row[u], qv));
-                if (b0 + rg + 4 * u < end) m = fmaxf(m, e[u]);
+                e[u] = group_sum<LPR>(dot4(row[u], qv));
+                if (b0 + rg + RG * u < end) m = fmaxf(m, e[u]);
             }
         }
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+        for (int off = LPR; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
         if (end <= beg) m = 0.f;
         float ssum = 0.f;
         float4 acc = f4zero();
-        for (int b0 = beg; b0 < end; b0 += 4 * kS2sRows) {
+        for (int b0 = beg; b0 < end; b0 += RG * kS2sRows) {
 #pragma unroll
             for (int u = 0; u < kS2sRows; ++u) {
-                const int n = b0 + rg + 4 * u;
+                const int n = b0 + rg + RG * u;
                 if (!small) {
                     row[u] = (act && n < end) ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
-                    e[u] = group_sum<16>(dot4(row[u], qv));
+                    e[u] = group_sum<LPR>(dot4(row[u], qv));
                 }
                 if (n < end) {
                     const float p = expf(e[u] - m);
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(kBlock) k_s2s_attn_fwd(const float* x, const f
             }
         }
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
+        for (int off = LPR; off < 64; off <<= 1) {
             ssum += __shfl_xor(ssum, off);
             acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
             acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
@@ -310,9 +312,11 @@ __global__ void __launch_bounds__(kBlock) k_s2s_attn_fwd(const float* x, const f
 }
 
 // d_x_n = a_n d_r + de_n q,  d_q = sum_n de_n x_n,  de_n = a_n (<d_r, x_n> - <d_r, r>)
+template <int LPR>
 __global__ void __launch_bounds__(kBlock) k_s2s_attn_bwd(const float* x, const float* q, const float* r, const float* stats,
                                                         const float* d_r, const int* ptr, int B, int D, float* d_x, float* d_q) {
-    const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
+    constexpr int RG = 64 / LPR;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, rg = lane / LPR;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
     const bool act = 4 * c4 < D;
@@ -322,20 +326,20 @@ __global__ void __launch_bounds__(kBlock) k_s2s_attn_bwd(const float* x, const f
         const float4 gv = act ? ld4(d_r + (size_t)g * D + 4 * c4) : f4zero();
         const float4 rv = act ? ld4(r + (size_t)g * D + 4 * c4) : f4zero();
         const float m = stats[2 * g], inv = 1.f / (stats[2 * g + 1] + 1e-16f);
-        const float dot_out = group_sum<16>(dot4(gv, rv));
+        const float dot_out = group_sum<LPR>(dot4(gv, rv));
         float4 dq = f4zero();
-        for (int b0 = beg; b0 < end; b0 += 4 * kS2sRows) {
+        for (int b0 = beg; b0 < end; b0 += RG * kS2sRows) {
             float4 row[kS2sRows];
 #pragma unroll
             for (int u = 0; u < kS2sRows; ++u) {
-                const int n = b0 + rg + 4 * u;
+                const int n = b0 + rg + RG * u;
                 row[u] = (act && n < end) ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
             }
 #pragma unroll
             for (int u = 0; u < kS2sRows; ++u) {
-                const int n = b0 + rg + 4 * u;
-                const float e = group_sum<16>(dot4(row[u], qv));
-                const float da = group_sum<16>(dot4(row[u], gv));
+                const int n = b0 + rg + RG * u;
+                const float e = group_sum<LPR>(dot4(row[u], qv));
+                const float da = group_sum<LPR>(dot4(row[u], gv));
                 if (n < end) {
                     const float a = expf(e - m) * inv;
                     const float de = a * (da - dot_out);
@@ -349,7 +353,7 @@ __global__ void __launch_bounds__(kBlock) k_s2s_attn_bwd(const float* x, const f
             }
         }
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
+        for (int off = LPR; off < 64; off <<= 1) {
             dq.x += __shfl_xor(dq.x, off); dq.y += __shfl_xor(dq.y, off);
             dq.z += __shfl_xor(dq.z, off); dq.w += __shfl_xor(dq.w, off);
         }
@@ -1019,11 +1023,12 @@ extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int3
 extern "C" int glam_s2s_attn_fwd(const float* x, const float* q, const int32_t* ptr, int64_t N, int64_t B, int D, float* r,
                                  float* stats, void* stream) {
     if (int rc = pool_dims("glam_s2s_attn_fwd", N, B, D)) return rc;
-    if ((D & 3) || D > 64) return fail(GLAM_E_UNSUPPORTED, "glam_s2s_attn_fwd: D=%d (multiple of 4, <= 64)", D);
+    if ((D & 3) || D > 128) return fail(GLAM_E_UNSUPPORTED, "glam_s2s_attn_fwd: D=%d (multiple of 4, <= 128)", D);
     if (B == 0) return GLAM_OK;
     GLAM_REQUIRE(ptr && q && r && stats && (N == 0 || x), "glam_s2s_attn_fwd: null pointer");
     GLAM_REQUIRE(aligned16(x) && aligned16(q) && aligned16(r), "glam_s2s_attn_fwd: 16-byte alignment");
-    hipLaunchKernelGGL(k_s2s_attn_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, q, ptr, (int)B, D, r, stats);
+    if (D <= 64) hipLaunchKernelGGL(k_s2s_attn_fwd<16>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, q, ptr, (int)B, D, r, stats);
+    else hipLaunchKernelGGL(k_s2s_attn_fwd<32>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, q, ptr, (int)B, D, r, stats);
     GLAM_LAUNCH_CHECK("glam_s2s_attn_fwd");
     return GLAM_OK;
 }
@@ -1031,13 +1036,15 @@ extern "C" int glam_s2s_attn_fwd(const float* x, const float* q, const int32_t* 
 extern "C" int glam_s2s_attn_bwd(const float* x, const float* q, const float* r, const float* stats, const float* d_r,
                                  const int32_t* ptr, int64_t N, int64_t B, int D, float* d_x, float* d_q, void* stream) {
     if (int rc = pool_dims("glam_s2s_attn_bwd", N, B, D)) return rc;
-    if ((D & 3) || D > 64) return fail(GLAM_E_UNSUPPORTED, "glam_s2s_attn_bwd: D=%d (multiple of 4, <= 64)", D);
+    if ((D & 3) || D > 128) return fail(GLAM_E_UNSUPPORTED, "glam_s2s_attn_bwd: D=%d (multiple of 4, <= 128)", D);
     if (B == 0) return GLAM_OK;
     GLAM_REQUIRE(ptr && q && r && stats && d_r && d_q && (N == 0 || (x && d_x)), "glam_s2s_attn_bwd: null pointer");
     GLAM_REQUIRE(aligned16(x) && aligned16(q) && aligned16(r) && aligned16(d_r) && aligned16(d_x) && aligned16(d_q),
                  "glam_s2s_attn_bwd: 16-byte alignment");
-    hipLaunchKernelGGL(k_s2s_attn_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, q, r, stats, d_r, ptr,
-                       (int)B, D, d_x, d_q);
+    if (D <= 64) hipLaunchKernelGGL(k_s2s_attn_bwd<16>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, q, r, stats, d_r, ptr,
+                                    (int)B, D, d_x, d_q);
+    else hipLaunchKernelGGL(k_s2s_attn_bwd<32>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, q, r, stats, d_r, ptr,
+                            (int)B, D, d_x, d_q);
     GLAM_LAUNCH_CHECK("glam_s2s_attn_bwd");
     return GLAM_OK;
 }

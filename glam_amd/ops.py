@@ -1251,7 +1251,7 @@ class _QueryAttention(torch.autograd.Function):
 
 
 def query_attention_supported(D):
-    return D % 4 == 0 and D <= 64
+    return D % 4 == 0 and D <= 128
 
 
 def query_attention(x, q, sp):

@@ -326,7 +326,7 @@ int glam_bias_res_act_bwd(const float* out, const float* d_out, int64_t N, int C
  *     (order i|f|g|o) -> h_new, c_new f32[B,C]; the backward recomputes the gates (d_h / d_c may be NULL = zero).
  *   glam_s2s_attn_fwd/bwd: e_n = <x_n, q_g>, a = softmax over the nodes of graph g (denominator + 1e-16), r_g = sum_n a_n x_n
  *     with x f32[N,D], q f32[B,D], ptr int32[B+1] -> r f32[B,D], stats f32[B,2] (segment max, exp-sum); the backward
- *     returns d_x f32[N,D] and d_q f32[B,D].  D % 4 == 0, D <= 64. */
+ *     returns d_x f32[N,D] and d_q f32[B,D].  D % 4 == 0, D <= 128. */
 int glam_lstm_cell_fwd(const float* gates, const float* c_prev, int64_t B, int C, float* h_new, float* c_new, void* stream);
 int glam_lstm_cell_bwd(const float* gates, const float* c_prev, const float* d_h, const float* d_c, int64_t B, int C,
                        float* d_gates, float* d_c_prev, void* stream);

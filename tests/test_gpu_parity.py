@@ -1057,7 +1057,7 @@ def test_wgrad_gemm_chunked_with_ones_column(device):
     assert_close(out, ref, 3e-6 * N ** 0.5 / 10, "chunked wgrad + ones")
 
 
-@pytest.mark.parametrize("C,sizes", [(60, [20, 13, 1, 28]), (45, [7, 40, 33, 2]), (32, [70, 5])])
+@pytest.mark.parametrize("C,sizes", [(60, [20, 13, 1, 28]), (45, [7, 40, 33, 2]), (32, [70, 5]), (90, [19, 3, 40])])
 def test_set2set_fused_steps_vs_oracle(device, C, sizes):
     """Set2Set on the fused path (LSTM gate kernel + in-kernel query attention): graphs below and above the 32-node register
     pass, an odd width (padded rows) — output and every gradient against the oracle."""
