@@ -41,7 +41,9 @@ class GraphIndex:
         self.rowptr = torch.empty(self.N + 1, **i32)
         self.src = torch.empty(self.E, **i32)
         self.eid = torch.empty(self.E, **i32)
-        self._ei = ei
+        # a WEAK reference: the index lives in a cache keyed on this tensor, and holding the tensor here would keep both
+        # alive for ever (a loader that builds new batch objects every step leaked one CSR per step)
+        self._ei_ref = weakref.ref(ei)
         self._t = None
         self._tiles = False            # False: not planned yet; None: no plan (general kernels); else (tile_ptr, T)
         self._err = torch.zeros(1, **i32)
@@ -77,7 +79,14 @@ class GraphIndex:
             i32 = dict(dtype=torch.int32, device=self.device)
             colptr, dst, eid_t = torch.empty(self.N + 1, **i32), torch.empty(self.E, **i32), torch.empty(self.E, **i32)
             ws = torch.empty(lib.glam_csr_workspace_bytes(self.N, self.E), dtype=torch.uint8, device=self.device)
-            check(lib.glam_csr_build(ptr(self._ei), self.N, self.E, 1, ptr(colptr), ptr(dst), ptr(eid_t),
+            ei = self._ei_ref()
+            if ei is None:     # the caller dropped edge_index before the first backward: the by-target CSR holds the same edges
+                deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
+                dst64 = torch.repeat_interleave(torch.arange(self.N, device=self.device), deg, output_size=self.E)
+                ei = torch.empty(2, self.E, dtype=torch.int64, device=self.device)
+                ei[0, self.eid.long()] = self.src.long()
+                ei[1, self.eid.long()] = dst64
+            check(lib.glam_csr_build(ptr(ei), self.N, self.E, 1, ptr(colptr), ptr(dst), ptr(eid_t),
                                      ptr(self._err), ptr(ws), ws.numel(), stream()), "glam_csr_build(T)")
             self._t = (colptr, dst, eid_t)
         return self._t

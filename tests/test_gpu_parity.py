@@ -1289,3 +1289,24 @@ def test_two_tower_architecture_golden(device):
     names = [n for n, _ in net.named_parameters()]
     for n, t in zip(names, _grads(out, g.cot.to(device), [p for _, p in net.named_parameters()])):
         assert_close(t, g.grads[n], 1e-4, f"dti/grad.{n}")
+
+
+def test_graph_index_does_not_pin_edge_index_and_survives_its_death(device):
+    """The cached CSR must not keep ``edge_index`` (and itself) alive — a loader that builds new batches every step would
+    leak one staging per step — and a backward whose ``edge_index`` was dropped after the forward still gets its transpose."""
+    import gc, weakref
+    b = synth_batch(5, seed=8).to(device)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device, requires_grad=True)
+    ref_out = conv(x, b.edge_index, b.edge_attr)
+    (ref_g,) = torch.autograd.grad(ref_out.sum(), [x])
+    ei = b.edge_index.clone()
+    wr = weakref.ref(ei)
+    n_before = len(ops._GI_CACHE)
+    out = conv(x, ei, b.edge_attr)
+    assert len(ops._GI_CACHE) == n_before + 1
+    del ei
+    gc.collect()
+    assert wr() is None and len(ops._GI_CACHE) == n_before          # tensor and cache entry are gone
+    (g,) = torch.autograd.grad(out.sum(), [x])                        # transpose rebuilt from the by-target CSR
+    assert torch.equal(out, ref_out) and torch.equal(g, ref_g)
