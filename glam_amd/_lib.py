@@ -137,6 +137,11 @@ def require_device(*tensors):
                                "there is no CPU fallback — move the batch and the model to 'cuda'.")
         if dev is None:
             dev = t.device
+            # the kernels are enqueued on the CURRENT device's stream: one process per GPU (torch.cuda.set_device(local_rank)),
+            # never silently on another device's stream
+            if dev.index is not None and dev.index != torch.cuda.current_device():
+                raise GlamHipError(f"tensors live on {dev} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                                   "call torch.cuda.set_device(...) (one process per GPU)")
         elif t.device != dev:
             raise GlamHipError(f"tensors on different devices: {dev} vs {t.device}")
     return dev

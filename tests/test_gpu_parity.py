@@ -1310,3 +1310,26 @@ def test_graph_index_does_not_pin_edge_index_and_survives_its_death(device):
     assert wr() is None and len(ops._GI_CACHE) == n_before          # tensor and cache entry are gone
     (g,) = torch.autograd.grad(out.sum(), [x])                        # transpose rebuilt from the by-target CSR
     assert torch.equal(out, ref_out) and torch.equal(g, ref_g)
+
+
+def test_side_stream_gives_identical_results(device):
+    """Every entry point enqueues on torch's current stream: the same step on a side stream, bit for bit."""
+    torch.manual_seed(0)
+    net = model.Architecture(graph_norm="_PairNorm", graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU",
+                             flat_act="ReLU").to(device)
+    b = synth_batch(48, seed=1).to(device)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        out = net(b)
+        out.sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    ref_out, ref_g = run()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out, g = run()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out) and all(torch.equal(a, r) for a, r in zip(g, ref_g))
