@@ -17,6 +17,7 @@ ap.add_argument("--readout", default="GlobalPool5")
 ap.add_argument("--alpha", type=int, default=4, help="hid_dim_alpha (hidden width = 15 * alpha)")
 ap.add_argument("--out-dim", type=int, default=1)
 ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--loss", default="mse", choices=["mse", "bcel"], help="bcel: masked BCEWithLogits over labels >= 0 (trainer.py:244-245)")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
@@ -29,9 +30,19 @@ b = synth_batch(args.batch, seed=0).to(dev)
 y = b.y.view(-1) if args.out_dim == 1 else torch.randn(args.batch, args.out_dim, device=dev).view(-1)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=os.environ.get("GLAM_FUSED_ADAM", "1") == "1")
 
+if args.loss == "bcel":      # multi-task labels in {-1 (missing), 0, 1} (dataset.py:138)
+    y = torch.randint(-1, 2, (args.batch * args.out_dim,), device=dev).float()
+
+def loss_of(out):
+    if args.loss == "mse":
+        return torch.nn.functional.mse_loss(out, y)
+    # mean over the valid labels only, without the data-dependent boolean indexing of the reference (not capturable)
+    valid = (y >= 0).float()
+    return (torch.nn.functional.binary_cross_entropy_with_logits(out, y.clamp(min=0), reduction="none") * valid).sum() / valid.sum().clamp(min=1)
+
 def body():
     opt.zero_grad(set_to_none=True)
-    loss = torch.nn.functional.mse_loss(net(b).view(-1), y)
+    loss = loss_of(net(b).view(-1))
     loss.backward()
     opt.step()
 
@@ -49,6 +60,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"workload": f"Architecture({args.block}, hid_dim_alpha={args.alpha}, 3 steps, {args.readout}, e_dim=1024, norm={args.norm}, "
-                              f"out_dim={args.out_dim}, rows={args.storage}) fwd+bwd+Adam, B={args.batch}",
+                              f"out_dim={args.out_dim}, rows={args.storage}, loss={args.loss}) fwd+bwd+Adam, B={args.batch}",
                   "launch": "eager" if g is None else "hipGraph", "ms_per_step": dt / args.steps * 1e3,
                   "molecules_per_s": args.batch * args.steps / dt}))
