@@ -296,7 +296,7 @@ def main():
                                         "bwd_achieved": (abb["k_triplet_bwd_dst"] + abb["k_triplet_bwd_src"]) /
                                                         (ktb["triplet_bwd(B1+reduce+B2)"] * 1e-6) / 1e9}
             del big, xb
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:     # rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in the barrier
             result["cpu_baseline"] = cpu_baseline(batch_cpu, conv_cpu, x_cpu, cot_cpu, args.cpu_seconds)
             result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
         print(json.dumps(result))
