@@ -1,5 +1,5 @@
 import sys, os, copy
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from glam_amd import layer
 from glam_amd.data import synth_batch

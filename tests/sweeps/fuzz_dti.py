@@ -1,7 +1,7 @@
 """Randomised two-tower parity sweep (ArchitectureDTI on the HIP path vs the oracle): tower blocks, norms, pair counts and
-protein-size mixes on both sides of the block-per-graph / wave-per-graph dispatch.  usage: python tools/fuzz_dti.py [n] [seed]"""
+protein-size mixes on both sides of the block-per-graph / wave-per-graph dispatch.  usage: python tests/sweeps/fuzz_dti.py [n] [seed]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from glam_amd import model
 from glam_amd.data import synth_batch, synth_protein_batch

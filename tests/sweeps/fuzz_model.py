@@ -1,7 +1,7 @@
 """Randomised full-model parity sweep (HIP path vs the CPU oracle): widths, convs, norms, readouts, activations, residuals.
-usage: python tools/fuzz_model.py [n_cases] [seed]"""
+usage: python tests/sweeps/fuzz_model.py [n_cases] [seed]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from glam_amd import model
 from glam_amd.data import synth_batch

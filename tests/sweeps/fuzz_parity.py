@@ -1,7 +1,7 @@
 """Randomised parity sweep (HIP path vs the CPU oracle) over graph-size mixes, widths, heads and readouts.
-usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+usage: python tests/sweeps/fuzz_parity.py [n_cases] [seed]"""
 import sys, os, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from glam_amd import layer, ops
 from glam_amd.data import Batch, Data
