@@ -66,23 +66,78 @@ class Batch(Data):
 
     @classmethod
     def from_data_list(cls, data_list):
-        xs, eis, eas, ys, bs = [], [], [], [], []
-        offset = 0
-        for g, d in enumerate(data_list):
-            n = d.x.size(0)
-            xs.append(d.x)
-            eis.append(d.edge_index + offset)
-            if d.edge_attr is not None:
-                eas.append(d.edge_attr)
-            if d.y is not None:
-                ys.append(d.y)
-            bs.append(torch.full((n,), g, dtype=torch.long))
-            offset += n
-        out = cls(x=torch.cat(xs, 0), edge_index=torch.cat(eis, 1),
-                  edge_attr=torch.cat(eas, 0) if eas else None,
-                  y=torch.cat(ys, 0) if ys else None, batch=torch.cat(bs, 0))
-        out.num_graphs = len(data_list)
-        out.ptr = torch.tensor([0] + [d.x.size(0) for d in data_list]).cumsum(0)
+        """PyG ``Batch.from_data_list`` semantics: concatenate ``x`` / ``edge_attr`` / ``y``, offset ``edge_index`` by the
+        running node count, build ``batch``.  Vectorised: one ``repeat_interleave`` each for the offsets and the batch vector
+        (a Python loop of per-graph tensor ops cost 40 ms per 1 024 molecules, 40x the device step)."""
+        B = len(data_list)
+        ns = torch.tensor([d.x.size(0) for d in data_list], dtype=torch.long)
+        es = torch.tensor([d.edge_index.size(1) for d in data_list], dtype=torch.long)
+        node_off = ns.cumsum(0) - ns
+        ei = torch.cat([d.edge_index for d in data_list], 1) if B else torch.zeros(2, 0, dtype=torch.long)
+        ei = ei + torch.repeat_interleave(node_off, es, output_size=int(ei.size(1))).unsqueeze(0)
+        eas = [d.edge_attr for d in data_list if d.edge_attr is not None]
+        ys = [d.y for d in data_list if d.y is not None]
+        n_total = int(ns.sum()) if B else 0
+        out = cls(x=torch.cat([d.x for d in data_list], 0), edge_index=ei,
+                  edge_attr=torch.cat(eas, 0) if eas else None, y=torch.cat(ys, 0) if ys else None,
+                  batch=torch.repeat_interleave(torch.arange(B), ns, output_size=n_total))
+        out.num_graphs = B
+        out.ptr = torch.cat([ns.new_zeros(1), ns.cumsum(0)])
+        return out
+
+
+class PackedDataset:
+    """All graphs of a dataset in flat tensors (node / edge prefix sums), so that collating ANY set of graph ids is a
+    handful of vectorised gathers instead of ``len(ids)`` small concatenations (with the device step
+    at ~1 ms for 1 024 molecules, host collation is what caps a shuffling loader)."""
+
+    def __init__(self, data_list):
+        data_list = list(data_list)
+        self.n = len(data_list)
+        ns = torch.tensor([d.x.size(0) for d in data_list], dtype=torch.long)
+        es = torch.tensor([d.edge_index.size(1) for d in data_list], dtype=torch.long)
+        self.ns, self.es = ns, es
+        self.node_ptr = torch.cat([ns.new_zeros(1), ns.cumsum(0)])
+        self.edge_ptr = torch.cat([es.new_zeros(1), es.cumsum(0)])
+        self.x = torch.cat([d.x for d in data_list], 0)
+        self.ei = torch.cat([d.edge_index for d in data_list], 1)            # graph-local node ids
+        has_ea = [d.edge_attr is not None for d in data_list]
+        has_y = [d.y is not None for d in data_list]
+        if any(has_ea) != all(has_ea) or any(has_y) != all(has_y):
+            raise ValueError("PackedDataset: edge_attr / y must be present for all graphs or for none")
+        self.ea = torch.cat([d.edge_attr for d in data_list], 0) if all(has_ea) and data_list else None
+        self.y = torch.cat([d.y for d in data_list], 0) if all(has_y) and data_list else None
+        self.y_rows = None if self.y is None else torch.tensor([d.y.size(0) for d in data_list], dtype=torch.long)
+        if self.y_rows is not None and not bool((self.y_rows == 1).all()):
+            self.y_ptr = torch.cat([self.y_rows.new_zeros(1), self.y_rows.cumsum(0)])
+        else:
+            self.y_ptr = None
+
+    @staticmethod
+    def _ranges(starts, lens, total):
+        """Concatenation of ``arange(s, s + l)`` for every (s, l): one repeat_interleave + one arange."""
+        off = lens.cumsum(0) - lens
+        return torch.repeat_interleave(starts - off, lens, output_size=total) + torch.arange(total)
+
+    def collate(self, ids):
+        ids = torch.as_tensor(ids, dtype=torch.long)
+        B = int(ids.numel())
+        ns, es = self.ns[ids], self.es[ids]
+        n_total, e_total = int(ns.sum()), int(es.sum())
+        nodes = self._ranges(self.node_ptr[ids], ns, n_total)
+        edges = self._ranges(self.edge_ptr[ids], es, e_total)
+        node_off = ns.cumsum(0) - ns
+        ei = self.ei[:, edges] + torch.repeat_interleave(node_off, es, output_size=e_total).unsqueeze(0)
+        if self.y is None:
+            y = None
+        elif self.y_ptr is None:
+            y = self.y[ids]
+        else:
+            y = self.y[self._ranges(self.y_ptr[ids], self.y_rows[ids], int(self.y_rows[ids].sum()))]
+        out = Batch(x=self.x[nodes], edge_index=ei, edge_attr=None if self.ea is None else self.ea[edges], y=y,
+                    batch=torch.repeat_interleave(torch.arange(B), ns, output_size=n_total))
+        out.num_graphs = B
+        out.ptr = torch.cat([ns.new_zeros(1), ns.cumsum(0)])
         return out
 
 
@@ -103,12 +158,18 @@ class DataLoader:
             raise ValueError("DataLoader: cached batches need a fixed order (shuffle=False)")
         self._epoch = 0
         self._batches = None
+        self._packed = None
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
     def _collate(self, idx):
-        b = Batch.from_data_list([self.dataset[i] for i in idx])
+        if self._packed is None:
+            try:
+                self._packed = PackedDataset(self.dataset)
+            except (ValueError, AttributeError, RuntimeError):    # heterogeneous records: per-batch concatenation
+                self._packed = False
+        b = self._packed.collate(idx) if self._packed else Batch.from_data_list([self.dataset[i] for i in idx])
         return b if self.device is None else b.to(self.device)
 
     def __iter__(self):

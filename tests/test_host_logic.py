@@ -223,3 +223,30 @@ def test_gpu_manager_surface(monkeypatch):
     assert m.gpus[1]["memory.free"] == 250 * 1024 and m.auto_choice(0.7) == 1 and m.wait_free_gpu(0.7) == 1
     mem[1] = (100 << 30, 288 << 30)
     assert m.auto_choice(0.7) is None and m.auto_choice(0.5) == 2
+
+
+def test_packed_dataset_collates_like_from_data_list():
+    """Vectorised collation (flat dataset + gathers) == PyG-style concatenation, for contiguous and shuffled graph ids,
+    single-row and multi-row labels, graphs without edges; the DataLoader uses it for every batch."""
+    import numpy as np
+    from glam_amd.data import Batch, Data, DataLoader, PackedDataset, synth_molecule
+    rng = np.random.default_rng(3)
+    mols = [synth_molecule(rng) for _ in range(40)]
+    mols[7] = Data(mols[7].x[:1], torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, 4), y=mols[7].y)     # single atom, no bonds
+    pk = PackedDataset(mols)
+    for ids in (np.arange(0, 16), np.arange(30, 40), rng.permutation(40)[:13], np.array([7]), np.array([], dtype=np.int64)):
+        a = Batch.from_data_list([mols[i] for i in ids]) if len(ids) else None
+        b = pk.collate(ids)
+        if a is None:
+            assert b.x.size(0) == 0 and b.edge_index.size(1) == 0 and b.num_graphs == 0
+            continue
+        for k in ("x", "edge_index", "edge_attr", "y", "batch", "ptr"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), k
+        assert a.num_graphs == b.num_graphs
+    for m in mols:                                              # two label rows per graph
+        m.y = torch.randn(2, 3)
+    pk2 = PackedDataset(mols)
+    ids = rng.permutation(40)[:9]
+    assert torch.equal(pk2.collate(ids).y, Batch.from_data_list([mols[i] for i in ids]).y)
+    got = [b.x.size(0) for b in DataLoader(mols, batch_size=16, shuffle=True, seed=5)]
+    assert sum(got) == sum(m.x.size(0) for m in mols) and len(got) == 3
