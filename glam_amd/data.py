@@ -86,6 +86,25 @@ class Batch(Data):
         return out
 
 
+class _few_threads:
+    """Host-side collation is dozens of tiny tensor ops: with torch's default of one intra-op thread per core they spend
+    their time waking a 100+ thread pool (6 ms instead of 0.2 ms per 32-molecule batch on a 128-core host).  Same remedy
+    as ``torch.utils.data`` workers: a small thread count while collating, restored afterwards."""
+
+    def __init__(self, n=4):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > self.n:
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
 class PackedDataset:
     """All graphs of a dataset in flat tensors (node / edge prefix sums), so that collating ANY set of graph ids is a
     handful of vectorised gathers instead of ``len(ids)`` small concatenations (with the device step
@@ -169,8 +188,9 @@ class DataLoader:
                 self._packed = PackedDataset(self.dataset)
             except (ValueError, AttributeError, RuntimeError):    # heterogeneous records: per-batch concatenation
                 self._packed = False
-        b = self._packed.collate(idx) if self._packed else Batch.from_data_list([self.dataset[i] for i in idx])
-        return b if self.device is None else b.to(self.device)
+        with _few_threads():
+            b = self._packed.collate(idx) if self._packed else Batch.from_data_list([self.dataset[i] for i in idx])
+            return b if self.device is None else b.to(self.device)
 
     def __iter__(self):
         order = np.arange(len(self.dataset))
