@@ -52,7 +52,16 @@ class Data:
             setattr(out, k, v.to(device, non_blocking=non_blocking))
         # device-side staging caches (CSR) are per-object and per-device
         out.__dict__.pop("_glam_cache", None)
+        out._apply_marks()
         return out
+
+    def _apply_marks(self):
+        """Validation facts established on the host (PackedDataset) ride on the tensors so that the device-side staging needs
+        no read-back: ``edge_index`` / ``batch`` ids valid by construction, ``edge_attr`` rows one-hot or not."""
+        for field, (attr, value) in getattr(self, "_glam_marks", {}).items():
+            t = getattr(self, field, None)
+            if torch.is_tensor(t):
+                setattr(t, attr, value)
 
     def __repr__(self):
         body = ", ".join(f"{k}={list(v.shape)}" for k, v in self._tensor_items())
@@ -127,6 +136,11 @@ class PackedDataset:
         self.ea = torch.cat([d.edge_attr for d in data_list], 0) if all(has_ea) and data_list else None
         self.y = torch.cat([d.y for d in data_list], 0) if all(has_y) and data_list else None
         self.y_rows = None if self.y is None else torch.tensor([d.y.size(0) for d in data_list], dtype=torch.long)
+        # host-side validation, once: what the device-side staging would otherwise read back for every new batch
+        loc_n = torch.repeat_interleave(ns, es, output_size=int(self.ei.size(1)))
+        self.valid_ids = bool(((self.ei >= 0) & (self.ei < loc_n.unsqueeze(0))).all()) if self.ei.numel() else True
+        self.onehot = None if self.ea is None else \
+            (bool((((self.ea == 0) | (self.ea == 1)).all() & (self.ea.sum(dim=1) == 1).all())) if self.ea.numel() else True)
         if self.y_rows is not None and not bool((self.y_rows == 1).all()):
             self.y_ptr = torch.cat([self.y_rows.new_zeros(1), self.y_rows.cumsum(0)])
         else:
@@ -157,6 +171,10 @@ class PackedDataset:
                     batch=torch.repeat_interleave(torch.arange(B), ns, output_size=n_total))
         out.num_graphs = B
         out.ptr = torch.cat([ns.new_zeros(1), ns.cumsum(0)])
+        out._glam_marks = {"edge_index": ("_glam_trusted", True), "batch": ("_glam_trusted", True)} if self.valid_ids else {}
+        if self.onehot is not None:
+            out._glam_marks["edge_attr"] = ("_glam_onehot", self.onehot)
+        out._apply_marks()
         return out
 
 

@@ -250,3 +250,23 @@ def test_packed_dataset_collates_like_from_data_list():
     assert torch.equal(pk2.collate(ids).y, Batch.from_data_list([mols[i] for i in ids]).y)
     got = [b.x.size(0) for b in DataLoader(mols, batch_size=16, shuffle=True, seed=5)]
     assert sum(got) == sum(m.x.size(0) for m in mols) and len(got) == 3
+
+
+def test_loader_batches_carry_host_side_validation_marks():
+    """PackedDataset validates ids / one-hot rows once on the host; the marks ride on the collated tensors (and survive
+    ``.to()``), so the device-side staging reads nothing back for loader-built batches."""
+    import numpy as np
+    from glam_amd.data import DataLoader, PackedDataset, synth_molecule
+    rng = np.random.default_rng(1)
+    mols = [synth_molecule(rng) for _ in range(10)]
+    b = next(iter(DataLoader(mols, batch_size=4, shuffle=True, seed=2)))
+    b2 = b.to("cpu")
+    for t in (b.edge_index, b.batch, b2.edge_index, b2.batch):
+        assert getattr(t, "_glam_trusted", False) is True
+    assert b2.edge_attr._glam_onehot is True
+    mols[3].edge_attr = mols[3].edge_attr * 0.5                       # not one-hot any more
+    assert PackedDataset(mols).collate(np.arange(4)).edge_attr._glam_onehot is False
+    mols[5].edge_index = mols[5].edge_index.clone()
+    mols[5].edge_index[0, 0] = 99                                      # an id outside its graph: no trust mark, the device checks
+    bad = PackedDataset(mols).collate(np.arange(4, 8))
+    assert not getattr(bad.edge_index, "_glam_trusted", False)
