@@ -60,8 +60,8 @@ class Data:
         no read-back: ``edge_index`` / ``batch`` ids valid by construction, ``edge_attr`` rows one-hot or not."""
         for field, (attr, value) in getattr(self, "_glam_marks", {}).items():
             t = getattr(self, field, None)
-            if torch.is_tensor(t):
-                setattr(t, attr, value)
+            if torch.is_tensor(t):      # tied to the tensor's version counter: an in-place write voids the mark
+                setattr(t, attr, t._version if attr == "_glam_trusted" else (value, t._version))
 
     def __repr__(self):
         body = ", ".join(f"{k}={list(v.shape)}" for k, v in self._tensor_items())

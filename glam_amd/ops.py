@@ -50,9 +50,10 @@ class GraphIndex:
         ws = torch.empty(lib.glam_csr_workspace_bytes(self.N, self.E), dtype=torch.uint8, device=dev)
         check(lib.glam_csr_build(ptr(ei), self.N, self.E, 0, ptr(self.rowptr), ptr(self.src), ptr(self.eid),
                                  ptr(self._err), ptr(ws), ws.numel(), stream()), "glam_csr_build")
-        # tensors built by glam_amd.data's collation carry a trust mark (ids valid by construction, checked once on the host when
-        # the dataset was packed): no read-back, so a loop over fresh batches has no host sync per step
-        if validate and not getattr(edge_index, "_glam_trusted", False) and int(self._err.item()) != 0:   # same failure class as torch's index_select on CPU
+        # tensors built by glam_amd.data's collation carry a trust mark — the tensor's version counter at marking time: ids valid by
+        # construction (checked once on the host when the dataset was packed) and not written since: no read-back, so a loop over
+        # fresh batches has no host sync per step
+        if validate and getattr(edge_index, "_glam_trusted", None) != edge_index._version and int(self._err.item()) != 0:   # same failure class as torch's index_select on CPU
             raise IndexError(f"edge_index holds node ids outside [0, {self.N})")
 
     TILE_TARGET_NODES = 80             # ~N/256 at the ESOL batch of 1024: one tile per CU
@@ -222,7 +223,7 @@ class SegmentPtr:
         err = torch.zeros(1, dtype=torch.int32, device=batch.device)
         check(_lib.load().glam_batch_ptr(ptr(batch.contiguous()), self.N, self.B, ptr(self.ptr), ptr(err), stream()),
               "glam_batch_ptr")
-        if validate and not getattr(batch, "_glam_trusted", False) and int(err.item()) != 0:
+        if validate and getattr(batch, "_glam_trusted", None) != batch._version and int(err.item()) != 0:
             raise IndexError("batch must be non-decreasing with ids in [0, num_graphs)")
 
 
@@ -1396,8 +1397,8 @@ def rows_are_one_hot(t):
     hit = _ONEHOT_CACHE.get(key)
     if hit is not None and hit[0]() is t and hit[1] == t._version:
         return hit[2]
-    mark = getattr(t, "_glam_onehot", None)      # known from the host side (glam_amd.data.PackedDataset): no read-back
-    ok = bool(mark) if mark is not None else \
+    mark = getattr(t, "_glam_onehot", None)      # (flag, tensor version) known from the host side (data.PackedDataset): no read-back
+    ok = bool(mark[0]) if (mark is not None and mark[1] == t._version) else \
         (bool((((t == 0) | (t == 1)).all() & (t.sum(dim=1) == 1).all()).item()) if t.numel() else True)
     try:
         _ONEHOT_CACHE[key] = (weakref.ref(t, lambda _r, k=key, c=_ONEHOT_CACHE: c.pop(k, None)), t._version, ok)

@@ -262,11 +262,13 @@ def test_loader_batches_carry_host_side_validation_marks():
     b = next(iter(DataLoader(mols, batch_size=4, shuffle=True, seed=2)))
     b2 = b.to("cpu")
     for t in (b.edge_index, b.batch, b2.edge_index, b2.batch):
-        assert getattr(t, "_glam_trusted", False) is True
-    assert b2.edge_attr._glam_onehot is True
+        assert getattr(t, "_glam_trusted", None) == t._version
+    assert b2.edge_attr._glam_onehot == (True, b2.edge_attr._version)
+    b2.edge_index[0, 0] = 0                                            # an in-place write voids the mark
+    assert b2.edge_index._glam_trusted != b2.edge_index._version
     mols[3].edge_attr = mols[3].edge_attr * 0.5                       # not one-hot any more
-    assert PackedDataset(mols).collate(np.arange(4)).edge_attr._glam_onehot is False
+    assert PackedDataset(mols).collate(np.arange(4)).edge_attr._glam_onehot[0] is False
     mols[5].edge_index = mols[5].edge_index.clone()
     mols[5].edge_index[0, 0] = 99                                      # an id outside its graph: no trust mark, the device checks
     bad = PackedDataset(mols).collate(np.arange(4, 8))
-    assert not getattr(bad.edge_index, "_glam_trusted", False)
+    assert getattr(bad.edge_index, "_glam_trusted", None) is None
