@@ -133,7 +133,9 @@ __global__ void __launch_bounds__(kBlock) k_batch_ptr(const int64_t* batch, int 
     for (int n = blockIdx.x * kBlock + threadIdx.x; n <= N; n += gridDim.x * kBlock) {
         const int64_t prev = n > 0 ? batch[n - 1] : -1;
         const int64_t cur = n < N ? batch[n] : B;
-        if (cur < prev || cur < 0 || cur > B || (n < N && cur >= B)) { *err = 1; continue; }
+        // prev is checked too: thread n-1 flags a bad batch[n-1] as ITS cur, but this thread would still run the fill loop
+        // from prev + 1 — below ptr[0] for a negative id, past ptr[B] for one >= B
+        if (cur < prev || cur < 0 || cur > B || (n < N && cur >= B) || prev < -1 || prev >= B) { *err = 1; continue; }
         for (int64_t g = prev + 1; g <= cur; ++g) ptr[g] = n;
     }
 }

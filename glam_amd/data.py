@@ -25,6 +25,19 @@ import torch
 _ATOMIC_NUMBERS = np.array([1, 6, 7, 8, 9, 16, 17, 35, 53], dtype=np.float32)
 
 
+def _carry_marks(src, dst):
+    """Copy the host-side validation marks of ``src`` onto its device copy ``dst`` — only the marks that are still valid
+    for ``src`` (made at its current version counter): a tensor written in place after validation, or a different tensor
+    assigned to the field, carries nothing over and is validated on the device like any foreign tensor."""
+    if dst is src:
+        return
+    if getattr(src, "_glam_trusted", None) == src._version:
+        dst._glam_trusted = dst._version
+    oh = getattr(src, "_glam_onehot", None)
+    if oh is not None and oh[1] == src._version:
+        dst._glam_onehot = (oh[0], dst._version)
+
+
 class Data:
     """Minimal attribute bag with the fields the reference model reads
     (``model.py:47-57``: ``x, edge_index, edge_attr, batch``) plus ``y``."""
@@ -49,16 +62,19 @@ class Data:
         out = self.__class__.__new__(self.__class__)
         out.__dict__.update(self.__dict__)
         for k, v in self._tensor_items():
-            setattr(out, k, v.to(device, non_blocking=non_blocking))
+            moved = v.to(device, non_blocking=non_blocking)
+            _carry_marks(v, moved)
+            setattr(out, k, moved)
         # device-side staging caches (CSR) are per-object and per-device
         out.__dict__.pop("_glam_cache", None)
-        out._apply_marks()
         return out
 
     def _apply_marks(self):
-        """Validation facts established on the host (PackedDataset) ride on the tensors so that the device-side staging needs
-        no read-back: ``edge_index`` / ``batch`` ids valid by construction, ``edge_attr`` rows one-hot or not."""
-        for field, (attr, value) in getattr(self, "_glam_marks", {}).items():
+        """Validation facts established on the host (PackedDataset.collate, on the tensors it has just built) ride on the
+        tensors so that the device-side staging needs no read-back: ``edge_index`` / ``batch`` ids valid by construction,
+        ``edge_attr`` rows one-hot or not.  Called once, by the collation that built the tensors; ``to()`` never re-derives a
+        mark from the field name — it copies the mark of the very tensor it moves, and only while that mark is still valid."""
+        for field, (attr, value) in self.__dict__.pop("_glam_marks", {}).items():
             t = getattr(self, field, None)
             if torch.is_tensor(t):      # tied to the tensor's version counter: an in-place write voids the mark
                 setattr(t, attr, t._version if attr == "_glam_trusted" else (value, t._version))

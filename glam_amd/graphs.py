@@ -24,14 +24,49 @@ import torch
 
 
 class GraphedTrainStep:
+    """See the module docstring.  Hyper-parameters: a captured optimizer launch bakes Python floats in as constants, and the
+    reference drives ``lr`` with ``ReduceLROnPlateau`` (``src_1gp/trainer.py:55,85``), which assigns a new float to
+    ``param_group['lr']``.  So the learning rate of every group lives in a DEVICE TENSOR that the captured launches read;
+    before every step the group's current value (a float a scheduler wrote, or a tensor) is copied into it — replayed steps
+    follow the scheduler exactly like eager ones.  ``betas`` / ``eps`` / ``weight_decay`` / flags are snapshotted; if they ever
+    change, every graph is dropped and re-captured on its next visit.
+
+    The returned loss is a fresh tensor (a clone of the graph's static output).  After a replay ``p.grad`` refers to the
+    gradient buffers of the graph captured LAST, not necessarily the one replayed: inspect or clip gradients in eager mode."""
+
     def __init__(self, model, optimizer, loss_fn, max_graphs=4096):
         for g in optimizer.param_groups:
-            if g.get("capturable") is False and not g.get("fused"):
-                raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True (or fused=True, capturable=True)")
+            if not g.get("capturable", False):
+                raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True "
+                                 "(e.g. Adam(..., capturable=True, fused=True)); fused=True alone is not enough")
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.max_graphs = max_graphs
         self._state = {}      # id(batch) -> [weakref, visits, graph, static_loss]
         self._pool = None
+        self._lr = [None] * len(optimizer.param_groups)
+        self._hyper = None
+
+    _BAKED = ("betas", "eps", "weight_decay", "amsgrad", "maximize", "momentum", "dampening", "nesterov", "alpha", "centered")
+
+    def _sync_hyper(self):
+        for i, g in enumerate(self.optimizer.param_groups):
+            lr, t = g["lr"], self._lr[i]
+            if t is None:
+                dev = g["params"][0].device
+                t = self._lr[i] = (lr.detach().to(device=dev, dtype=torch.float32).clone() if torch.is_tensor(lr)
+                                   else torch.tensor(float(lr), dtype=torch.float32, device=dev))
+                g["lr"] = t
+            elif lr is not t:                 # a scheduler (or the user) assigned a new value since the last step
+                if torch.is_tensor(lr):
+                    t.copy_(lr)
+                else:
+                    t.fill_(float(lr))
+                g["lr"] = t
+        snap = tuple(tuple((k, g[k]) for k in self._BAKED if k in g) for g in self.optimizer.param_groups)
+        if self._hyper is not None and snap != self._hyper:
+            for st in self._state.values():   # constants of the captured optimizer launches changed: capture again
+                st[2] = st[3] = None
+        self._hyper = snap
 
     def _step(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
@@ -42,6 +77,7 @@ class GraphedTrainStep:
 
     def __call__(self, batch):
         """One optimizer step on ``batch``; returns the (device) loss tensor of this step."""
+        self._sync_hyper()
         key = id(batch)
         st = self._state.get(key)
         if st is None or st[0]() is not batch:
@@ -60,7 +96,7 @@ class GraphedTrainStep:
                 self._pool = graph.pool()                 # all graphs share one memory pool: they never run concurrently
             st[2] = graph
         st[2].replay()
-        return st[3]
+        return st[3].clone()                              # static outputs of different graphs may alias in the shared pool
 
     def graphs(self):
         return sum(1 for s in self._state.values() if s[2] is not None)
@@ -69,8 +105,8 @@ class GraphedTrainStep:
 class GraphedForward:
     """Inference counterpart: ``GraphedForward(model)(batch)`` runs ``model(batch)`` under ``torch.no_grad()`` — eagerly on
     the first visit of a batch object, from a hipGraph afterwards (the evaluation loaders of the reference iterate the same
-    batches after every epoch: ``src_1gp/trainer.py:39-41``).  The returned tensor is the graph's static output: read or
-    copy it before the next call on the same batch.  Parameters may change between calls (training in between): the
+    batches after every epoch: ``src_1gp/trainer.py:39-41``).  The returned tensor is a clone of the graph's static output (the graphs share one memory
+    pool, so static outputs of different batches may alias).  Parameters may change between calls (training in between): the
     captured kernels re-read them; the model must be in ``eval()`` mode (or otherwise free of RNG-dependent layers that
     differ between the modes you compare)."""
 
@@ -98,4 +134,4 @@ class GraphedForward:
                 self._pool = graph.pool()
             st[1] = graph
         st[1].replay()
-        return st[2]
+        return st[2].clone()

@@ -219,6 +219,8 @@ class SegmentPtr:
         if num_graphs is None:
             num_graphs = int(batch[-1].item()) + 1 if self.N > 0 else 0
         self.B = int(num_graphs)
+        if self.B < 0 or self.B >= 2 ** 31 - 1:      # an unchecked batch[-1] (negative / huge id) must not size the ptr buffer
+            raise IndexError(f"batch must be non-decreasing with ids in [0, num_graphs) (num_graphs = {self.B})")
         self.ptr = torch.empty(self.B + 1, dtype=torch.int32, device=batch.device)
         err = torch.zeros(1, dtype=torch.int32, device=batch.device)
         check(_lib.load().glam_batch_ptr(ptr(batch.contiguous()), self.N, self.B, ptr(self.ptr), ptr(err), stream()),

@@ -50,3 +50,31 @@ def assert_close(a, b, tol, what=""):
     err = (a - b).abs().max().item()
     scale = max(1.0, b.abs().max().item())
     assert err <= tol * scale, f"{what}: max|d|={err:.3e} > {tol:.1e} * {scale:.3g}"
+
+
+EPS32 = 2.0 ** -23
+
+
+def assert_fp32_parity(got, ref64, ref32, what="", k=8.0, out_tol=None):
+    """fp32 parity bound derived from the fp64 twin of the oracle, per quantity.
+
+    ``noise = max|ref32 - ref64|`` is the rounding error the fp32 ORACLE itself makes on this very quantity (same inputs,
+    same algorithm, fp64 vs fp32): it grows with the depth of the computation and with the length of the sums behind the
+    quantity (a weight gradient at B = 1024 sums 20 k rows), which is exactly what a fixed tolerance ladder guessed at.  An
+    fp32 implementation that contracts in another order (MFMA tiles, CSR segment sums, fixed-order block partials) draws a
+    different sample of the same error, so it must sit within ``k * max(noise, 4 ulp(scale))`` of the fp64 value; k = 8 is the
+    slack for max-norms of two independent samples over up to ~1e6 elements.  ``out_tol`` adds BASELINE.json's absolute bar
+    for forward outputs (1e-5, scaled by max(1, |ref|)).  Returns (err, bound) for reporting."""
+    g = got.detach().cpu().double()
+    r64, r32 = ref64.detach().cpu().double(), ref32.detach().cpu().double()
+    assert g.shape == r64.shape, f"{what}: shape {tuple(g.shape)} vs {tuple(r64.shape)}"
+    if g.numel() == 0:
+        return 0.0, 0.0
+    scale = r64.abs().max().item()
+    noise = (r32 - r64).abs().max().item()
+    bound = k * max(noise, 4 * EPS32 * scale)
+    err = (g - r64).abs().max().item()
+    assert err <= bound, f"{what}: max|d| = {err:.3e} > {k:g} x fp64-twin noise floor = {bound:.3e} (noise {noise:.3e}, scale {scale:.3g})"
+    if out_tol is not None:
+        assert err <= out_tol * max(1.0, scale), f"{what}: max|d| = {err:.3e} > {out_tol:.0e} * max(1, {scale:.3g})"
+    return err, bound

@@ -783,6 +783,51 @@ def test_graphed_train_step_follows_the_eager_trajectory(device):
         assert_close(a, r, 1e-5, "parameter")
 
 
+def test_graphed_train_step_follows_lr_schedulers(device):
+    """The reference drives lr with ReduceLROnPlateau (src_1gp/trainer.py:55,85), which assigns a new FLOAT to
+    param_group['lr'] between epochs: replayed graphs must step with the new rate (lr lives in a device tensor the captured
+    optimizer launch reads), i.e. follow the eager trajectory through two reductions."""
+    import copy
+    from glam_amd.data import DataLoader, synth_molecule
+    from glam_amd.graphs import GraphedTrainStep
+    rng = np.random.default_rng(12)
+    mols = [synth_molecule(rng) for _ in range(16)]
+    torch.manual_seed(6)
+    net0 = model.Architecture(mol_block="_TripletMessage", message_steps=2, mol_readout="GlobalPool5", e_dim=64, graph_norm="_None",
+                              graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device)
+    loss_fn = lambda out, b: torch.nn.functional.mse_loss(out.view(-1), b.y.view(-1))
+    results = []
+    for graphed in (False, True):
+        net = copy.deepcopy(net0)
+        # learning rates that are powers of two: the float the eager optimizer multiplies by and the fp32 device tensor the
+        # graphed one reads are then the same number, and the two trajectories can be compared bit for bit (Adam's
+        # m / sqrt(v) amplifies a 1e-8 difference in lr to O(lr) on parameters whose gradient is ~0)
+        opt = torch.optim.Adam(net.parameters(), lr=2.0 ** -7, capturable=True)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.125, patience=0)
+        loader = DataLoader(mols, batch_size=8, device=device)
+        stepper = GraphedTrainStep(net, opt, loss_fn)
+        lrs = []
+        for epoch in range(5):
+            for b in loader:
+                if graphed:
+                    stepper(b)
+                else:
+                    opt.zero_grad(set_to_none=True)
+                    loss_fn(net(b), b).backward()
+                    opt.step()
+            sched.step(1.0)                      # a constant metric: "no improvement" from the second epoch on -> lr / 8 each time
+            if epoch == 3:                       # and a plain float assignment, as older schedulers / user code do
+                opt.param_groups[0]["lr"] = 2.0 ** -20
+            lrs.append(float(opt.param_groups[0]["lr"]))
+        results.append((lrs, [p.detach().clone() for p in net.parameters()]))
+    (lr_e, p_e), (lr_g, p_g) = results
+    assert lr_e == lr_g and lr_e[-1] < 1e-4 < lr_e[0], (lr_e, lr_g)
+    for a, r in zip(p_g, p_e):
+        assert_close(a, r, 1e-5, "parameter after lr reductions")
+    with pytest.raises(ValueError):
+        GraphedTrainStep(net0, torch.optim.Adam(net0.parameters(), lr=1e-3, fused=True), loss_fn)   # fused without capturable
+
+
 def test_graphed_forward_tracks_parameter_updates(device):
     from glam_amd.graphs import GraphedForward
     torch.manual_seed(8)
@@ -1105,6 +1150,16 @@ def test_misuse_raises_python_exceptions_and_leaves_the_device_usable(device):
         layer.TripletMessage(60, 9).to(device)(x, b.edge_index, torch.rand(b.edge_index.size(1), 9, device=device))
     with pytest.raises(IndexError):
         layer.GlobalPool5()(x, b.batch.flip(0))                       # batch must be sorted (it is, by collation)
+    # negative / huge graph ids anywhere in `batch`: IndexError, and no write outside the ptr buffer (k_batch_ptr used to run its
+    # fill loop from prev + 1 < 0 on the element AFTER a negative id)
+    canary = torch.zeros(4096, dtype=torch.int32, device=device)
+    for pos, val in ((0, -5), (3, -(2 ** 40)), (b.batch.numel() - 1, -1), (b.batch.numel() - 1, 2 ** 40), (2, 2 ** 33)):
+        bad = b.batch.clone()
+        bad[pos] = val
+        with pytest.raises(IndexError):
+            ops.SegmentPtr(bad, 8 if pos != b.batch.numel() - 1 else None)
+    torch.cuda.synchronize()
+    assert int(canary.abs().sum()) == 0
     xt = torch.randn(60, b.x.size(0), device=device).t()              # non-contiguous input: accepted
     assert conv(xt, b.edge_index, b.edge_attr).shape == ok.shape
     assert torch.equal(conv(x, b.edge_index, b.edge_attr), ok)        # the device is still fine

@@ -272,3 +272,33 @@ def test_loader_batches_carry_host_side_validation_marks():
     mols[5].edge_index[0, 0] = 99                                      # an id outside its graph: no trust mark, the device checks
     bad = PackedDataset(mols).collate(np.arange(4, 8))
     assert getattr(bad.edge_index, "_glam_trusted", None) is None
+
+
+def test_validation_marks_do_not_survive_a_write_or_a_replacement_across_to():
+    """``Data.to()`` copies the mark of the very tensor it moves, and only while that mark is valid: a tensor written in
+    place after collation, or a different tensor assigned to the field, arrives on the device unmarked (so the device-side
+    staging validates it: R-GCN one-hot path not taken on scaled features, bad ids raise IndexError)."""
+    import numpy as np
+    from glam_amd.data import PackedDataset, synth_molecule
+    rng = np.random.default_rng(4)
+    mols = [synth_molecule(rng) for _ in range(6)]
+    pk = PackedDataset(mols)
+    meta = torch.device("meta")                                        # a real copy (new tensor objects) without a GPU
+
+    b = pk.collate(np.arange(6))
+    ok = b.to(meta)
+    assert ok.edge_index._glam_trusted == ok.edge_index._version and ok.batch._glam_trusted == ok.batch._version
+    assert ok.edge_attr._glam_onehot == (True, ok.edge_attr._version)
+
+    b = pk.collate(np.arange(6))
+    b.edge_attr.mul_(0.5)                                              # write, then to(): no one-hot mark on the copy
+    moved = b.to(meta)
+    assert getattr(moved.edge_attr, "_glam_onehot", None) is None
+    assert moved.edge_index._glam_trusted == moved.edge_index._version   # untouched fields keep theirs
+
+    b = pk.collate(np.arange(6))
+    b.edge_index = torch.full((2, 3), 10 ** 6)                         # replace, then to(): the new tensor was never validated
+    b.batch = b.batch.clone()
+    moved = b.to(meta)
+    assert getattr(moved.edge_index, "_glam_trusted", None) is None
+    assert getattr(moved.batch, "_glam_trusted", None) is None
