@@ -3,24 +3,34 @@
 ESOL-shaped batch of 1024 molecules (BASELINE.json configs[1]), fp32, inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = forward + backward of the layer over one batch (loss = <out, cotangent>), gradients of the
-5 parameters gathered into one flat bucket; with N>1 every rank owns its own 1024-molecule batch
-(weak scaling, graphs shard with no data-path collective) and the step ends with ONE RCCL
-all-reduce of that bucket.  The step is captured once into a hipGraph (launch-bound regime:
-~20 kernels of 2-6 us) and replayed; ``--no-graph`` times eager launches instead.
+N > 1: run as written, bench.py starts its own N ranks (fresh child interpreters, one per GPU, started
+BEFORE this process touches a GPU); under ``python -m torch.distributed.run --nproc-per-node N ...`` it
+joins the ranks the launcher made (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
+A step = forward + backward of the layer over one batch (loss = <out, cotangent>), the 5 parameter
+gradients in one flat bucket; with N > 1 every rank owns its own 1024-molecule batch (weak scaling,
+graphs shard with no data-path collective) and the step ends with ONE RCCL all-reduce of that bucket.
+The step — including the all-reduce — is captured once into a hipGraph (launch-bound regime: 8 kernels
+of 5-17 us) and replayed; ``--no-graph`` times eager launches instead.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant hand-written kernel: algorithmic bytes / avg launch duration (HIP events on
-                the launching stream, back-to-back launches) vs the 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (reference-shaped port, oracle/glam_oracle.py) timed on this host
+  roofline          the scatter-aggregate kernel THE TIMED STEP LAUNCHES (gather + segment softmax + scatter-add with
+                    the update GEMM fused in): algorithmic bytes / its average duration vs the HBM peak
+  roofline_kernels  every kernel of the step: durations from per-dispatch begin/end timestamps (glam_prof_*:
+                    hipExtLaunchKernel events, the figures a rocprofv3 kernel trace reports) taken in THIS run from
+                    eager executions of the very function the graph captured; bytes / flops per DESIGN.md §4
+  roofline_isolated the aggregate kernel alone (no fused GEMM), SURVEY.md §8(d)'s B_fwd formula
+  roofline_large    the same kernels at B = 16 384 (working set beyond the 256 MiB LLC)
+  cpu_baseline      the CPU oracle (reference-shaped port, oracle/glam_oracle.py) timed on this host
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,40 +40,69 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md (spec); 6290 GB/s measured-achievable
+# /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E spec, ~6.29 TB/s measured-achievable; 157.3 TF dense fp32 MFMA
+HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6290.0
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def algorithmic_bytes(N, E, H=3, C=60, De=4):
-    """Compulsory HBM bytes per launch, fp32 + int32 CSR, every tensor once."""
-    HC = H * C
-    fwd = 4 * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H)
-    # B1 (by target): xw gather, aggr, d_aggr rows, edge_attr, src/eid, rowptr, a_ij, stats in;
-    #                 alpha_e/dpre_e [E,H] and d_a_i out
-    b1 = 4 * (3 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H + 2 * E * H + N * H)
-    # B2 (by source): d_aggr gather, edge_attr, dst/eid, colptr, alpha_e/dpre_e in; d_xw, d_a_j out
-    b2 = 4 * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * E * H + N * H)
-    return {"k_triplet_fwd": fwd, "k_triplet_bwd_dst": b1, "k_triplet_bwd_src": b2}
+def step_kernel_model(N, E, H=3, C=60, De=4):
+    """Algorithmic (compulsory) HBM bytes and dense flops per launch of every kernel of the step: fp32 + int32 CSR, every
+    tensor once.  Keys are the labels glam_prof_* reports."""
+    HC, f = H * C, 4
+    img = lambda K, M: ((K + 15) // 16 * 16) * (64 if M <= 64 else 192) * f      # weight image of a k_ts_gemm launch
+    agg_fwd = f * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H)        # xw, aggr, edge_attr, src+eid, rowptr, a_ij, stats
+    b1 = f * (3 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H + 2 * E * H + N * H)
+    b2 = f * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * E * H + N * H)
+    return {
+        "k_stage_params": {"bound": "latency", "bytes": f * (C * HC + De * HC + 3 * HC + HC * C + C) + img(C, HC + 8) + img(HC, C) + img(C, HC) + img(HC + 8, C)},
+        "k_ts_gemm<12, 4, 4>": {"bound": "mfma", "flops": 2 * N * C * (HC + 8), "bytes": f * N * (C + HC + 8) + img(C, HC + 8),
+                                "note": "two launches per step: x @ [W_node | Wa] (flops as given) and d_out @ W_scale^T (2*N*C*HC)"},
+        "k_triplet_fwd+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C},
+        "k_triplet_fwd": {"bound": "hbm", "bytes": agg_fwd},
+        "k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1},
+        "k_triplet_bwd_src+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C},
+        "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
+        "k_reduce_partials": {"bound": "latency", "bytes": 0},
+        "k_wgrad": {"bound": "mfma", "flops": 2 * N * (HC + 1) * C + 2 * N * (HC + 8) * C,
+                    "bytes": f * N * (HC + C) + f * N * (HC + 8 + C)},
+        "k_param_grads": {"bound": "latency", "bytes": 0},
+    }
 
 
-def pmc_traffic(kernel, N):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_hbm_traffic_pmc.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this script, reads doubled per the gfx950 note of
-    MI355X_MICROARCH.md §HBM).  Matched on the launch's thread count; None when no matching measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")
-    try:
-        rows = json.load(open(path))
-    except OSError:
-        return None
-    want = f"grid={(N + 15) // 16 * 256}"
-    for key, row in rows.items():
-        if kernel in key and key.endswith(want):
-            return row["hbm_bytes"]
-    return None
+def rate(model, us):
+    """roofline entry of one kernel from its model row and average duration."""
+    out = {"avg_us": us, "bound": model["bound"]}
+    if "bytes" in model and model["bytes"]:
+        gbs = model["bytes"] / (us * 1e-6) / 1e9
+        out.update(algorithmic_bytes=model["bytes"], achieved_GBs=gbs, frac_hbm_peak=gbs / HBM_PEAK_GBS,
+                   frac_hbm_achievable=gbs / HBM_ACHIEVABLE_GBS)
+    if "flops" in model:
+        tf = model["flops"] / (us * 1e-6) / 1e12
+        out.update(flops=model["flops"], achieved_TFLOPs=tf, frac_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
+    return out
 
 
-def time_kernels(conv, batch, x, reps=200):
-    """Average duration of each hand-written aggregate kernel: `reps` back-to-back launches between two
-    HIP events on the stream the kernels are launched on (torch's current stream)."""
+def profile_step(body, reps):
+    """Average per-dispatch duration of every kernel `body` launches: {label: (avg_us, launches per body call)}."""
+    from glam_amd import _lib
+    for _ in range(3):
+        body()
+    torch.cuda.synchronize()
+    with _lib.kernel_timer(capacity=64 * reps) as kt:
+        for _ in range(reps):
+            body()
+    torch.cuda.synchronize()
+    acc = {}
+    for name, grid, us in kt.records():
+        a = acc.setdefault(name, [0.0, 0, grid])
+        a[0] += us
+        a[1] += 1
+    return {k: {"avg_us": v[0] / v[1], "launches_per_step": v[1] / reps, "grid": v[2]} for k, v in acc.items()}
+
+
+def time_isolated_aggregate(conv, batch, x, reps):
+    """The aggregate kernels on their own (glam_triplet_fwd / glam_triplet_bwd: no fused GEMM epilogues)."""
     from glam_amd import _lib, ops
     lib = _lib.load()
     p, st = _lib.ptr, _lib.stream
@@ -81,30 +120,13 @@ def time_kernels(conv, batch, x, reps=200):
         d_we, d_M = torch.empty_like(We), torch.empty_like(M)
         ws = torch.empty(lib.glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=x.device)
 
-    def fwd():
+    def body():
         lib.glam_triplet_fwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(gi.rowptr), p(gi.src), p(gi.eid), N, E, H, Cp, Dp, 1,
                              0.2, p(aggr), p(stats), st())
-
-    def bwd():
         lib.glam_triplet_bwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(aggr), p(stats), p(d_aggr), p(gi.rowptr), p(gi.src),
                              p(gi.eid), p(colptr), p(dst), p(eid_t), N, E, H, Cp, Dp, 1, 0.2, p(d_xw), p(d_a), p(d_we),
                              p(d_M), None, p(ws), ws.numel(), st())
-
-    def timed(fn):
-        for _ in range(10):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / reps   # us per call
-
-    t_fwd = timed(fwd)
-    t_bwd = timed(bwd)       # B1 + partial reduce + B2 (split by the rocprof trace in profiles/)
-    return {"k_triplet_fwd": t_fwd, "triplet_bwd(B1+reduce+B2)": t_bwd}
+    return profile_step(body, reps)
 
 
 def cpu_baseline(batch_cpu, conv_cpu, x_cpu, cot_cpu, budget_s):
@@ -144,6 +166,32 @@ def cpu_baseline(batch_cpu, conv_cpu, x_cpu, cot_cpu, budget_s):
             "ms_per_step_by_threads": {str(c): runs[c][1] / runs[c][0] * 1e3 for c in counts}}
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` run as written: start the N ranks ourselves.  This process has made no GPU call yet
+    (``device_count`` does not initialise the runtime) and never will: it only waits for its children — fresh interpreters,
+    each of which binds ONE device — and returns the worst exit code.  Rank 0 inherits our stdout for the JSON line."""
+    share = os.environ.get("GLAM_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s) (GLAM_BENCH_SHARE_GPU=1 runs a functional check of the "
+              f"multi-rank path on one device over gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,18 +199,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--eager-allreduce", action="store_true", help="keep the gradient all-reduce outside the captured graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--large-batch", type=int, default=16384, help="extra roofline point beyond the LLC (0 = skip)")
+    ap.add_argument("--prof-reps", type=int, default=30, help="eager profiled steps behind roofline_kernels")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
                     help="storage of the gathered rows xw (bf16 = BASELINE configs[2] mode: bf16 rows, fp32 arithmetic; "
                          "the headline metric is fp32)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     # Functional check of the multi-rank path on a single-GPU box (not a measurement): GLAM_BENCH_SHARE_GPU=1 puts every rank
     # on device 0 and uses gloo, since RCCL refuses two ranks on one device.
@@ -202,36 +255,61 @@ def main():
     flat = torch.zeros(n_param, device=dev)                    # gradient bucket when the grads are not one already
     live = {}
 
-    def body():
+    def compute():
         out = conv(x, batch.edge_index, batch.edge_attr)
         grads = torch.autograd.grad(out, params + [x], grad_outputs=cot)   # loss = <out, cot>
         bucket = flat_view(grads[:-1])          # the fused layer hands its 5 parameter gradients back as one buffer
         if bucket is None:
             bucket = torch.cat([g_.reshape(-1) for g_ in grads[:-1]], out=flat)
         live["bucket"], live["d_x"] = bucket, grads[-1]
+        return bucket
 
-    # warm-up on a side stream (stages the CSR + its transpose, which sync once per new batch)
+    def compute_and_reduce():
+        dist.all_reduce(compute())              # ONE bucket, ONE RCCL call per step
+
+    # warm-up on a side stream (stages the CSR + its transpose, which sync once per new batch; creates the RCCL communicator)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):
-            body()
+            compute_and_reduce() if world > 1 else compute()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
 
-    graph = None
+    # ---- capture: the whole step, collective included, is ONE graph launch per rank ----
+    graph, ar_in_graph = None, False
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            body()
+        want_ar = world > 1 and not share and not args.eager_allreduce
+        if want_ar:
+            ok = 1
+            try:
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    compute_and_reduce()
+                graph, ar_in_graph = g_, True
+            except Exception as exc:            # noqa: BLE001 - a runtime that cannot capture the collective: fall back, loudly
+                print(f"bench.py[rank {rank}]: capturing the all-reduce failed ({type(exc).__name__}: {exc}); "
+                      f"replaying the compute graph and issuing the all-reduce eagerly", file=sys.stderr)
+                ok = 0
+                torch.cuda.synchronize()
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same route
+            if int(flag.item()) == 0:
+                graph, ar_in_graph = None, False
+        if graph is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                compute()
 
     def step():
         if graph is not None:
             graph.replay()
+            if world > 1 and not ar_in_graph:
+                dist.all_reduce(live["bucket"])
+        elif world > 1:
+            compute_and_reduce()
         else:
-            body()
-        if world > 1:
-            dist.all_reduce(live["bucket"])                    # ONE bucket, ONE RCCL call per step
+            compute()
 
     def barrier():
         if world > 1:
@@ -253,6 +331,8 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
 
+    launch = "eager" if graph is None else ("hipGraph replay" + (" (all-reduce captured in the graph)" if ar_in_graph else
+                                                                 (" + eager all-reduce" if world > 1 else "")))
     result = {
         "metric": "molecules/sec fwd+bwd on ESOL-shaped batches", "value": value, "unit": "molecules/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -260,46 +340,72 @@ def main():
         "dtype": "f32" if args.storage == "fp32" else "bf16 rows / f32 arithmetic", "data": "synthetic",
         "config": {"workload": f"ESOL-shaped batch={B}/GPU (N={N} atoms, E={E} directed bonds), single "
                                f"TripletMessage({C},{De},heads={H}) layer fwd+bwd, fp32",
-                   "launch": "eager" if graph is None else "hipGraph replay", "parallelism": f"dp{world}",
-                   "global_batch": B * world},
+                   "launch": launch, "parallelism": f"dp{world}", "global_batch": B * world,
+                   "collective": None if world == 1 else ("gloo (GLAM_BENCH_SHARE_GPU functional check)" if share else
+                                                          f"RCCL all-reduce of one {n_param}-float bucket, {world} ranks")},
     }
 
     if rank == 0 and args.storage != "fp32":
-        result["roofline"] = None                  # the roofline leg times the fp32 aggregate kernel: headline mode only
-        print(json.dumps(result))
+        result["roofline"] = None                  # the roofline legs describe the fp32 kernels: headline mode only
+        print(json.dumps(result), flush=True)
     elif rank == 0:
-        # ---- roofline of the hand-written kernels (after the timed region, same process/stream) ----
-        kt = time_kernels(conv, batch, x.detach())
-        ab = algorithmic_bytes(N, E, H, C, De)
-        fwd_us = kt["k_triplet_fwd"]
-        achieved = ab["k_triplet_fwd"] / (fwd_us * 1e-6) / 1e9
-        result["roofline"] = {"kernel": "k_triplet_fwd<3,16,1,4,true> (gather + segment softmax + scatter-add)",
-                              "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_triplet_fwd", N),
-                              "algorithmic_bytes": ab["k_triplet_fwd"], "avg_launch_us": fwd_us,
-                              "workload": f"B={B}"}
-        bwd_bytes = ab["k_triplet_bwd_dst"] + ab["k_triplet_bwd_src"]
-        result["roofline_bwd"] = {"kernels": "k_triplet_bwd_dst + k_reduce_partials + k_triplet_bwd_src",
-                                  "algorithmic_bytes": bwd_bytes, "avg_launch_us": kt["triplet_bwd(B1+reduce+B2)"],
-                                  "achieved": bwd_bytes / (kt["triplet_bwd(B1+reduce+B2)"] * 1e-6) / 1e9, "unit": "GB/s"}
+        # ---- roofline: per-dispatch durations of the kernels the timed step launches (same process, same stream, the function
+        #      the graph captured, issued eagerly so that every launch can carry its own begin / end events) ----
+        model = step_kernel_model(N, E, H, C, De)
+        prof = profile_step(compute, args.prof_reps)
+        kernels = {}
+        for name, rec in sorted(prof.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
+            row = dict(rec)
+            m = model.get(name)
+            if m is not None:
+                row.update(rate(m, rec["avg_us"]))
+                if "note" in m:
+                    row["note"] = m["note"]
+            kernels[name] = row
+        step_kernel_us = sum(r["avg_us"] * r["launches_per_step"] for r in prof.values())
+        dom = "k_triplet_fwd+update"
+        if dom in kernels:
+            k = kernels[dom]
+            result["roofline"] = {"kernel": "k_triplet_fwd<3,16,1,4,true> with the update GEMM fused (what the step launches: gather + "
+                                            "segment softmax + scatter-add + aggr @ W_scale + bias)",
+                                  "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": k["frac_hbm_peak"], "frac_of_achievable_6290": k["frac_hbm_achievable"],
+                                  "traffic": None, "algorithmic_bytes": k["algorithmic_bytes"], "avg_launch_us": k["avg_us"],
+                                  "grid": k["grid"], "workload": f"B={B}",
+                                  "traffic_note": "PMC traffic is not collectable inside an unprofiled run: see profiles/ (FETCH_SIZE / "
+                                                  "WRITE_SIZE passes of this command) and DESIGN.md §4"}
+        result["roofline_kernels"] = {"source": f"glam_prof_* per-dispatch timestamps, {args.prof_reps} eager executions of the captured step function "
+                                                "after the timed region", "sum_kernel_us_per_step": step_kernel_us, "kernels": kernels}
+        iso = time_isolated_aggregate(conv, batch, x.detach(), args.prof_reps)
+        result["roofline_isolated"] = {n: dict(r, **rate(model[n], r["avg_us"])) for n, r in iso.items() if n in model}
         if args.large_batch and world == 1:
             big_cpu = synth_batch(args.large_batch, seed=7)
             big = big_cpu.to(dev)
-            xb = torch.randn(big.x.size(0), C, device=dev)
-            ktb = time_kernels(conv, big, xb, reps=50)
-            abb = algorithmic_bytes(big.x.size(0), big.edge_index.size(1), H, C, De)
-            a2 = abb["k_triplet_fwd"] / (ktb["k_triplet_fwd"] * 1e-6) / 1e9
-            result["roofline_large"] = {"workload": f"B={args.large_batch} (N={big.x.size(0)}, beyond the 256 MiB LLC)",
-                                        "kernel": "k_triplet_fwd", "achieved": a2, "frac": a2 / HBM_PEAK_GBS,
-                                        "avg_launch_us": ktb["k_triplet_fwd"], "algorithmic_bytes": abb["k_triplet_fwd"],
-                                        "bwd_avg_launch_us": ktb["triplet_bwd(B1+reduce+B2)"],
-                                        "bwd_achieved": (abb["k_triplet_bwd_dst"] + abb["k_triplet_bwd_src"]) /
-                                                        (ktb["triplet_bwd(B1+reduce+B2)"] * 1e-6) / 1e9}
-            del big, xb
+            Nb, Eb = big.x.size(0), big.edge_index.size(1)
+            xb = torch.randn(Nb, C, device=dev).requires_grad_(True)
+            cb = torch.randn(Nb, C, device=dev)
+
+            def compute_big():
+                out = conv(xb, big.edge_index, big.edge_attr)
+                live["big"] = torch.autograd.grad(out, params + [xb], grad_outputs=cb)
+
+            mb = step_kernel_model(Nb, Eb, H, C, De)
+            pb = profile_step(compute_big, max(5, args.prof_reps // 3))
+            ib = time_isolated_aggregate(conv, big, xb.detach(), max(5, args.prof_reps // 3))
+            rl = {"workload": f"B={args.large_batch} (N={Nb}, E={Eb}: every [N,180] tensor is {Nb * 720 / 2 ** 20:.0f} MiB, beyond the 256 MiB LLC)",
+                  "step_kernels": {n: dict(r, **(rate(mb[n], r["avg_us"]) if n in mb else {})) for n, r in pb.items()},
+                  "isolated": {n: dict(r, **rate(mb[n], r["avg_us"])) for n, r in ib.items() if n in mb}}
+            if "k_triplet_fwd" in rl["isolated"]:
+                ki = rl["isolated"]["k_triplet_fwd"]
+                rl.update(kernel="k_triplet_fwd (aggregate only)", achieved=ki["achieved_GBs"], frac=ki["frac_hbm_peak"],
+                          avg_launch_us=ki["avg_us"], algorithmic_bytes=ki["algorithmic_bytes"])
+            result["roofline_large"] = rl
+            del big, xb, cb
+            live.pop("big", None)
         if args.cpu_seconds > 0 and world == 1:     # rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in the barrier
             result["cpu_baseline"] = cpu_baseline(batch_cpu, conv_cpu, x_cpu, cot_cpu, args.cpu_seconds)
             result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -21,6 +21,9 @@ _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctyp
 SIGNATURES = {
     "glam_abi_version": (_i32, []),
     "glam_last_error": (ctypes.c_char_p, []),
+    "glam_prof_begin": (_i32, [_i32]),
+    "glam_prof_end": (_i32, []),
+    "glam_prof_read": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]),
     "glam_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "glam_csr_build": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_tile_plan_workspace_bytes": (_sz, [_i64]),
@@ -108,6 +111,30 @@ def check(rc, what):
         return
     msg = load().glam_last_error().decode("utf-8", "replace")
     raise GlamHipError(f"{what} failed (code {rc}): {msg}")
+
+
+class kernel_timer:
+    """``with kernel_timer() as kt: <eager calls>`` then ``kt.records()`` -> ``[(kernel name, grid blocks, microseconds), ...]`` in
+    launch order: per-dispatch begin / end timestamps of every kernel the library launched inside the block (``glam_prof_*``)."""
+
+    def __init__(self, capacity=4096):
+        self.capacity, self.n = capacity, 0
+
+    def __enter__(self):
+        check(load().glam_prof_begin(self.capacity), "glam_prof_begin")
+        return self
+
+    def __exit__(self, *exc):
+        self.n = load().glam_prof_end()
+        return False
+
+    def records(self):
+        lib, out = load(), []
+        name, grid, us = ctypes.create_string_buffer(128), ctypes.c_int32(), ctypes.c_float()
+        for i in range(self.n):
+            check(lib.glam_prof_read(i, name, 128, ctypes.byref(grid), ctypes.byref(us)), "glam_prof_read")
+            out.append((name.value.decode(), int(grid.value), float(us.value)))
+        return out
 
 
 def ptr(t):

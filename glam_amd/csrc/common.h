@@ -8,9 +8,32 @@
 
 #include "../../include/glam_hip.h"
 
+#include <hip/hip_ext.h>
+
 namespace glam {
 
 int fail(int code, const char* fmt, ...);
+
+// ---- per-launch kernel timing (glam_prof_* in include/glam_hip.h) ----------------------------------------------------------
+// Every kernel of the library is launched through hipLaunchKernelGGL.  While profiling is on, the same launch goes through
+// hipExtLaunchKernelGGL with a (start, stop) event pair bound to THAT dispatch: the runtime stamps them with the dispatch's
+// own begin / end timestamps — the figures a rocprofv3 kernel trace reports — so bench.py can quote the duration of each
+// kernel of the very step it timed.  Off (the default): one predictable branch, the plain launch, hipGraph-capturable.
+extern bool g_prof_on;
+extern const char* g_prof_label;      // optional name for the NEXT timed launch (template launches stringify unresolved)
+#define GLAM_PROF_LABEL(text) do { if (__builtin_expect(::glam::g_prof_on, 0)) ::glam::g_prof_label = (text); } while (0)
+bool prof_slot(const char* kernel, unsigned grid, hipEvent_t* start, hipEvent_t* stop);
+
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                  \
+    do {                                                                                                                     \
+        hipEvent_t e0__, e1__;                                                                                               \
+        if (__builtin_expect(::glam::g_prof_on, 0) && ::glam::prof_slot(#kernelName, dim3(numBlocks).x, &e0__, &e1__))       \
+            hipExtLaunchKernelGGL(kernelName, dim3(numBlocks), dim3(numThreads), (memPerBlock), (streamId), e0__, e1__, 0,    \
+                                  __VA_ARGS__);                                                                              \
+        else                                                                                                                 \
+            kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                               \
+    } while (0)
 
 #define GLAM_LAUNCH_CHECK(name)                                                    \
     do {                                                                           \

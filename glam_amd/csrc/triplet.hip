@@ -77,6 +77,7 @@ extern "C" int glam_triplet_fwd(const float* xw, const float* a_ij, const float*
                      aligned16(w_edge), "glam_triplet_fwd: pointers must be 16-byte aligned");
     FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, nullptr, nullptr, nullptr};
     const size_t lds = emul ? (size_t)De * H * Cp * sizeof(float) : 0;
+    GLAM_PROF_LABEL("k_triplet_fwd");
     if (!dispatch(kTripletFwd, H, De, emul, sh, a, (int)N, lds, (hipStream_t)stream, kMaxBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_fwd");
@@ -104,6 +105,7 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
     if (N == 0) return GLAM_OK;
     FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out, xw_bf16};
     const size_t lds = ((size_t)De * H * Cp + 16 * (size_t)(H * Cp + 4) + 16 * 64 + (size_t)((H * Cp + 15) & ~15) * 64) * sizeof(float);
+    GLAM_PROF_LABEL("k_triplet_fwd+update");
     if (!dispatch(kTripletFwd, H, De, 1, sh, a, (int)N, lds, s, kFusedBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd(fused): no kernel for H=%d De=%d", H, De);
     GLAM_LAUNCH_CHECK("glam_triplet_fwd(fused)");
@@ -146,6 +148,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                   alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16};
     const size_t lds1 = ((size_t)WSZ + (size_t)red_groups * P) * sizeof(float);
     int nblk = 0;
+    GLAM_PROF_LABEL("k_triplet_bwd_dst");
     if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
@@ -158,6 +161,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     }
     if (d_edge_attr) {
         BwdDeaArgs bd{xw, w_edge, M, d_aggr, alpha_e, dpre_e, rowptr, src, eid, (int)N, Cp, d_edge_attr};
+        GLAM_PROF_LABEL("k_triplet_bwd_dea");
         if (!dispatch(kTripletBwdDea, H, De, emul, sh, bd, (int)N, (size_t)WSZ * sizeof(float), s, kMaxBlocks, nullptr))
             return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
@@ -168,6 +172,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                   fuse_dx ? img_dx : nullptr, fuse_dx ? d_x : nullptr};
     const int KX = H * Cp + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t lds2 = ((size_t)WSZ + (fuse_dx ? 16 * (size_t)LDT + 16 * 64 + (size_t)((KX + 15) & ~15) * 64 : 0)) * sizeof(float);
+    GLAM_PROF_LABEL(fuse_dx ? "k_triplet_bwd_src+dx" : "k_triplet_bwd_src");
     if (!dispatch(kTripletBwdSrc, H, De, emul, sh, b2, (int)N, lds2, s, fuse_dx ? kFusedBlocks : kMaxBlocks, nullptr))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B2)");

@@ -38,6 +38,18 @@ extern "C" {
 int glam_abi_version(void);
 const char* glam_last_error(void);
 
+/* Per-launch kernel timing (measurement aid of bench.py; the reference has no profiling hooks at all —
+ * only wall-clock suffixes in its log lines, src_1gp/trainer.py:140-147).
+ * Between glam_prof_begin(capacity) and glam_prof_end() every kernel this library launches is bound to a
+ * (start, stop) event pair stamped with the dispatch's own begin / end timestamps — what a rocprofv3 kernel trace
+ * reports.  Timed launches are NOT hipGraph-capturable: profile eager calls only.  glam_prof_end() returns the
+ * number of launches recorded (at most `capacity`; launches beyond it go out untimed).  glam_prof_read(i, ...)
+ * waits for launch i and returns its kernel name (host buffer), grid size in blocks and duration in microseconds.
+ * Process-global, not thread-safe: one profiling session at a time. */
+int glam_prof_begin(int capacity);
+int glam_prof_end(void);
+int glam_prof_read(int i, char* name_host, int name_cap, int32_t* grid_host, float* usec_host);
+
 /* ---------------------------------------------------------------------------------------------
  * CSR staging of a COO edge list.
  * Replaces: the per-call index_select/scatter bookkeeping PyG's MessagePassing.propagate does for
