@@ -46,6 +46,8 @@ SIGNATURES = {
     "glam_pair_pool_workspace_bytes": (_sz, [_i64, _i32]),
     "glam_pair_pool_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_pair_pool_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),
+    "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "glam_pair_pool5_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),
     "glam_ts_gemm_image_bytes": (_sz, [_i32, _i32]),
     "glam_ts_gemm_make_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "glam_ts_gemm_make_image_quad": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

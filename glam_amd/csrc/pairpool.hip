@@ -258,9 +258,230 @@ __global__ void __launch_bounds__(kBlock) k_pair_pool_bwd(const float* mol, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dot_and_global_pool5 (src_1gp/layer.py:270-283): out[i] = [max, mean, median, min, std] of S_i = mol[seg_i] @ pro[seg_i]^T.
+// The reference loops over pairs in Python (matmul + five reductions + .item() syncs per pair).  Here: one block per pair, no
+// score matrix in memory — every pass recomputes the scores with the same instruction sequence (bit-identical values in every
+// pass): a 16-lane group owns a residue row (its float4 chunks in registers), walks the ligand rows staged in LDS and forms
+// s = <mol_a, pro_b> with a DPP butterfly.
+//   pass 1  max / min with first-occurrence arg (flattened a * np + b order, like a flattened argmax);  mean from the column
+//           sums: sum(S) = <sum_a mol_a, sum_b pro_b>
+//   pass 2  sum (s - mean)^2 in a fixed order -> unbiased std (torch.std default)
+//   pass 3..6  exact lower median (torch.median of a flattened tensor: rank (n - 1) / 2) by radix select on the order-preserving
+//           integer image of the float, 8 bits per pass (LDS histogram, integer atomics: order independent)
+//   pass 7  first flattened index holding the median value (for the backward pass)
+constexpr int kP5Groups = kBlock / 16;
+
+__device__ __forceinline__ unsigned p5_key(float v) {        // monotone float -> uint map
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float p5_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// f(flat index a * np + b, score) for every score of the pair, called by ALL 16 lanes of the owning group (same value in each);
+// contains block barriers: every thread of the block must call it.
+template <typename F>
+__device__ __forceinline__ void p5_for_each_score(const float* mol, const float* pro, int m0, int nm, int p0, int np, int D,
+                                                  float* s_mol, F&& f) {
+    const int tid = threadIdx.x, lg = tid & 15, gid = tid >> 4, Q = D >> 2;
+    const bool ok0 = lg < Q, ok1 = lg + 16 < Q;
+    for (int t0 = 0; t0 < nm; t0 += kMolTile) {
+        const int tn = min(kMolTile, nm - t0);
+        __syncthreads();
+        for (int k = tid; k < tn * D; k += kBlock) s_mol[k] = mol[(size_t)(m0 + t0) * D + k];
+        __syncthreads();
+        for (int b = gid; b < np; b += kP5Groups) {
+            const float* prow = pro + (size_t)(p0 + b) * D;
+            const float4 pr0 = ok0 ? ld4(prow + 4 * lg) : f4zero(), pr1 = ok1 ? ld4(prow + 4 * (lg + 16)) : f4zero();
+            for (int a = 0; a < tn; ++a) {
+                float part = ok0 ? dot4(ld4(s_mol + a * D + 4 * lg), pr0) : 0.f;
+                if (ok1) part += dot4(ld4(s_mol + a * D + 4 * (lg + 16)), pr1);
+                f((t0 + a) * np + b, group_sum<16>(part));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_pair_stats5(const float* mol, const float* pro, const int* mptr, const int* pptr,
+                                                       int D, float* out, int* arg) {
+    __shared__ __attribute__((aligned(16))) float s_mol[kMolTile * 128];
+    __shared__ float s_sum[2 * 128];
+    __shared__ __attribute__((aligned(16))) float s_part[16 * 16 * 4];
+    __shared__ float s_gv[2][kP5Groups];
+    __shared__ int s_gi[2][kP5Groups];
+    __shared__ int s_hist[256];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_rank;
+    __shared__ float s_mean;
+    const int i = blockIdx.x, tid = threadIdx.x, lg = tid & 15, gid = tid >> 4;
+    const int m0 = mptr[i], m1 = mptr[i + 1], p0 = pptr[i], p1 = pptr[i + 1];
+    const int nm = m1 - m0, np = p1 - p0;
+    if (nm <= 0 || np <= 0) {          // the reference raises on an empty pair; a sharded batch may hold one: zeros
+        if (tid < 5) out[5 * i + tid] = 0.f;
+        if (tid < 6) arg[6 * i + tid] = -1;
+        return;
+    }
+    const float n = (float)nm * (float)np;
+    if ((D & 3) == 0 && D <= 64) {
+        block_colsum(mol, m0, m1, D, s_part, s_sum);
+        block_colsum(pro, p0, p1, D, s_part, s_sum + 128);
+    } else {
+        for (int c = tid; c < D; c += kBlock) {
+            float a = 0.f, b = 0.f;
+            for (int r = m0; r < m1; ++r) a += mol[(size_t)r * D + c];
+            for (int r = p0; r < p1; ++r) b += pro[(size_t)r * D + c];
+            s_sum[c] = a; s_sum[128 + c] = b;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int c = 0; c < D; ++c) tot = fmaf(s_sum[c], s_sum[128 + c], tot);
+        s_mean = tot / n;
+    }
+    // ---- pass 1: max / min ----
+    float vmax = -INFINITY, vmin = INFINITY;
+    int imax = 0x7fffffff, imin = 0x7fffffff;
+    p5_for_each_score(mol, pro, m0, nm, p0, np, D, s_mol, [&](int idx, float v) {
+        if (v > vmax || (v == vmax && idx < imax)) { vmax = v; imax = idx; }
+        if (v < vmin || (v == vmin && idx < imin)) { vmin = v; imin = idx; }
+    });
+    if (lg == 0) { s_gv[0][gid] = vmax; s_gi[0][gid] = imax; s_gv[1][gid] = vmin; s_gi[1][gid] = imin; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int g = 0; g < kP5Groups; ++g) {
+            if (s_gv[0][g] > vmax || (s_gv[0][g] == vmax && s_gi[0][g] < imax)) { vmax = s_gv[0][g]; imax = s_gi[0][g]; }
+            if (s_gv[1][g] < vmin || (s_gv[1][g] == vmin && s_gi[1][g] < imin)) { vmin = s_gv[1][g]; imin = s_gi[1][g]; }
+        }
+        out[5 * i + 0] = vmax; out[5 * i + 1] = s_mean; out[5 * i + 3] = vmin;
+        arg[6 * i + 0] = m0 + imax / np; arg[6 * i + 1] = p0 + imax % np;
+        arg[6 * i + 4] = m0 + imin / np; arg[6 * i + 5] = p0 + imin % np;
+    }
+    __syncthreads();
+    // ---- pass 2: unbiased variance about the mean ----
+    const float mean = s_mean;
+    float ssq = 0.f;
+    p5_for_each_score(mol, pro, m0, nm, p0, np, D, s_mol, [&](int, float v) { const float d = v - mean; ssq = fmaf(d, d, ssq); });
+    if (lg == 0) s_gv[0][gid] = ssq;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int g = 0; g < kP5Groups; ++g) t += s_gv[0][g];
+        out[5 * i + 4] = sqrtf(t / (n - 1.f));            // n == 1: 0 / 0 = NaN, as torch.std
+        s_prefix = 0u;
+        s_rank = (nm * np - 1) / 2;                        // lower median (torch.median of the flattened scores)
+    }
+    // ---- passes 3..6: radix select ----
+    for (int pass = 0; pass < 4; ++pass) {
+        s_hist[tid] = 0;                                   // kBlock == 256 bins
+        __syncthreads();
+        const int shift = 24 - 8 * pass;
+        const unsigned prefix = s_prefix;
+        p5_for_each_score(mol, pro, m0, nm, p0, np, D, s_mol, [&](int, float v) {
+            const unsigned k = p5_key(v);
+            if (lg == 0 && (pass == 0 || (k >> (shift + 8)) == prefix)) atomicAdd(&s_hist[(k >> shift) & 255u], 1);
+        });
+        __syncthreads();
+        if (tid == 0) {
+            int r = s_rank, bin = 0;
+            for (; bin < 255; ++bin) {
+                if (r < s_hist[bin]) break;
+                r -= s_hist[bin];
+            }
+            s_rank = r;
+            s_prefix = (prefix << 8) | (unsigned)bin;
+        }
+        __syncthreads();
+    }
+    // ---- pass 7: first flattened index of the median value ----
+    const unsigned medkey = s_prefix;
+    int imed = 0x7fffffff;
+    p5_for_each_score(mol, pro, m0, nm, p0, np, D, s_mol, [&](int idx, float v) { if (p5_key(v) == medkey && idx < imed) imed = idx; });
+    if (lg == 0) s_gi[0][gid] = imed;
+    __syncthreads();
+    if (tid == 0) {
+        for (int g = 0; g < kP5Groups; ++g) imed = min(imed, s_gi[0][g]);
+        out[5 * i + 2] = p5_unkey(medkey);
+        arg[6 * i + 2] = m0 + imed / np; arg[6 * i + 3] = p0 + imed % np;
+    }
+}
+
+// Backward of the five statistics: dS[a,b] = g_mean / n + g_std (S[a,b] - mean) / ((n - 1) std) + g_max [arg max] + g_med [arg med]
+// + g_min [arg min];  d_mol[a] = sum_b dS[a,b] pro[b],  d_pro[b] = sum_a dS[a,b] mol[a].  A 16-lane group owns an output row and
+// walks the rows of the other side in index order (deterministic), recomputing each score.
+__global__ void __launch_bounds__(kBlock) k_pair_stats5_bwd(const float* mol, const float* pro, const int* mptr, const int* pptr,
+                                                           const float* out, const int* arg, const float* d_out, int D,
+                                                           float* d_mol, float* d_pro) {
+    const int i = blockIdx.x, tid = threadIdx.x, lg = tid & 15, gid = tid >> 4, Q = D >> 2;
+    const int m0 = mptr[i], m1 = mptr[i + 1], p0 = pptr[i], p1 = pptr[i + 1];
+    const int nm = m1 - m0, np = p1 - p0;
+    const bool ok0 = lg < Q, ok1 = lg + 16 < Q;
+    if (nm <= 0 || np <= 0) {
+        for (int k = tid; k < max(nm, 0) * D; k += kBlock) d_mol[(size_t)m0 * D + k] = 0.f;
+        for (int k = tid; k < max(np, 0) * D; k += kBlock) d_pro[(size_t)p0 * D + k] = 0.f;
+        return;
+    }
+    const float n = (float)nm * (float)np, mean = out[5 * i + 1], sd = out[5 * i + 4];
+    const float gmax = d_out[5 * i], gmean = d_out[5 * i + 1] / n, gmed = d_out[5 * i + 2], gmin = d_out[5 * i + 3];
+    const float cstd = d_out[5 * i + 4] / ((n - 1.f) * sd);
+    const int amax = arg[6 * i], bmax = arg[6 * i + 1], amed = arg[6 * i + 2], bmed = arg[6 * i + 3], amin = arg[6 * i + 4],
+              bmin = arg[6 * i + 5];
+    auto sweep = [&](const float* own, int o0, int o1, const float* oth, int t0, int t1, float* d_own, bool own_is_mol) {
+        for (int r = o0 + gid; r < o1; r += kP5Groups) {
+            const float* orow = own + (size_t)r * D;
+            const float4 x0 = ok0 ? ld4(orow + 4 * lg) : f4zero(), x1 = ok1 ? ld4(orow + 4 * (lg + 16)) : f4zero();
+            float4 acc0 = f4zero(), acc1 = f4zero();
+            for (int t = t0; t < t1; ++t) {
+                const float* trow = oth + (size_t)t * D;
+                const float4 y0 = ok0 ? ld4(trow + 4 * lg) : f4zero(), y1 = ok1 ? ld4(trow + 4 * (lg + 16)) : f4zero();
+                // the same expression as the forward pass: part = dot4(mol chunk, pro chunk) (+ second chunk)
+                float part = ok0 ? (own_is_mol ? dot4(x0, y0) : dot4(y0, x0)) : 0.f;
+                if (ok1) part += own_is_mol ? dot4(x1, y1) : dot4(y1, x1);
+                const float sc = group_sum<16>(part);
+                const int a = own_is_mol ? r : t, b = own_is_mol ? t : r;
+                float w = fmaf(cstd, sc - mean, gmean);
+                if (a == amax && b == bmax) w += gmax;
+                if (a == amed && b == bmed) w += gmed;
+                if (a == amin && b == bmin) w += gmin;
+                fma4(acc0, w, y0);
+                fma4(acc1, w, y1);
+            }
+            if (ok0) st4(d_own + (size_t)r * D + 4 * lg, acc0);
+            if (ok1) st4(d_own + (size_t)r * D + 4 * (lg + 16), acc1);
+        }
+    };
+    sweep(pro, p0, p1, mol, m0, m1, d_pro, false);
+    sweep(mol, m0, m1, pro, p0, p1, d_mol, true);
+}
+
 }  // namespace glam
 
 using namespace glam;
+
+extern "C" int glam_pair_pool5_fwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr, int64_t P,
+                                   int D, float* out, int32_t* arg, void* stream) {
+    GLAM_REQUIRE(P >= 0 && P < INT32_MAX, "glam_pair_pool5_fwd: P out of range");
+    if (D <= 0 || D > 128 || (D & 3)) return fail(GLAM_E_UNSUPPORTED, "glam_pair_pool5_fwd: D=%d must be a multiple of 4 in 4..128", D);
+    if (P == 0) return GLAM_OK;
+    GLAM_REQUIRE(mol && pro && mol_ptr && pro_ptr && out && arg && aligned16(mol) && aligned16(pro), "glam_pair_pool5_fwd: null / misaligned pointer");
+    hipLaunchKernelGGL(k_pair_stats5, dim3((int)P), dim3(kBlock), 0, (hipStream_t)stream, mol, pro, mol_ptr, pro_ptr, D, out, arg);
+    GLAM_LAUNCH_CHECK("glam_pair_pool5_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_pair_pool5_bwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
+                                   const float* out, const int32_t* arg, const float* d_out, int64_t P, int D, float* d_mol,
+                                   float* d_pro, void* stream) {
+    GLAM_REQUIRE(P >= 0 && P < INT32_MAX, "glam_pair_pool5_bwd: P out of range");
+    if (D <= 0 || D > 128 || (D & 3)) return fail(GLAM_E_UNSUPPORTED, "glam_pair_pool5_bwd: D=%d must be a multiple of 4 in 4..128", D);
+    if (P == 0) return GLAM_OK;
+    GLAM_REQUIRE(mol && pro && mol_ptr && pro_ptr && out && arg && d_out && d_mol && d_pro && aligned16(mol) && aligned16(pro) &&
+                     aligned16(d_mol) && aligned16(d_pro), "glam_pair_pool5_bwd: null / misaligned pointer");
+    hipLaunchKernelGGL(k_pair_stats5_bwd, dim3((int)P), dim3(kBlock), 0, (hipStream_t)stream, mol, pro, mol_ptr, pro_ptr, out, arg,
+                       d_out, D, d_mol, d_pro);
+    GLAM_LAUNCH_CHECK("glam_pair_pool5_bwd");
+    return GLAM_OK;
+}
 
 static bool pair_split(int D) { return (D & 3) == 0 && D <= 64; }
 

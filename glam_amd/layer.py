@@ -694,21 +694,15 @@ class MessageBlock(torch.nn.Module):
         return x, h
 
 
-def _pair_stats(mol_out, pro_out, mol_batch, pro_batch, stats):
-    mol_ptr = ops.segment_ptr(mol_batch).ptr.tolist()
-    pro_ptr = ops.segment_ptr(pro_batch).ptr.tolist()
-    rows = []
-    for i in range(len(mol_ptr) - 1):
-        item = torch.matmul(mol_out[mol_ptr[i]:mol_ptr[i + 1]], pro_out[pro_ptr[i]:pro_ptr[i + 1]].T)
-        if stats == 2:
-            rows.append(torch.stack([item.max(), item.mean()]))
-        else:
-            rows.append(torch.stack([item.max(), item.mean(), item.median(), item.min(), item.std()]))
-    return torch.stack(rows)
-
-
 def dot_and_global_pool5(mol_out, pro_out, mol_batch, pro_batch):   # src_1gp/layer.py:270-283
-    return _pair_stats(mol_out, pro_out, mol_batch, pro_batch, 5)
+    """[max, mean, median, min, std] of the ligand x residue score matrix of every pair: one HIP launch per direction (the
+    reference loops over pairs in Python with a matmul, five reductions and .item() syncs each)."""
+    msp = ops.segment_ptr(mol_batch)
+    psp = ops.segment_ptr(pro_batch, msp.B)
+    Cp = _ceil4(mol_out.size(1))
+    if Cp > 128:
+        raise GlamHipError(f"dot_and_global_pool5: width {mol_out.size(1)} > 128 is outside the compiled kernel table")
+    return ops.pair_pool5(ops.pad_cols(mol_out, Cp), ops.pad_cols(pro_out, Cp), msp, psp)
 
 
 def dot_and_global_pool2(mol_out, pro_out, mol_batch, pro_batch):   # src_2gi_dti_scr/layer.py:270-283

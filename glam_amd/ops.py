@@ -1443,3 +1443,37 @@ class _PairPool(torch.autograd.Function):
 def pair_pool(mol_out, pro_out, msp, psp):
     """``[max, mean]`` of ``mol[seg_i] @ pro[seg_i].T`` per pair -> ``[P, 2]`` (dot_and_global_pool2)."""
     return _PairPool.apply(mol_out, pro_out, msp, psp)
+
+
+class _PairPool5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mol, pro, msp, psp):
+        require_device(mol, pro)
+        mol, pro = f32c(mol, "mol_out"), f32c(pro, "pro_out")
+        if msp.B != psp.B or mol.size(1) != pro.size(1) or mol.size(0) != msp.N or pro.size(0) != psp.N:
+            raise GlamHipError("pair_pool5: the two batches disagree (pair count / width / node count)")
+        P, D = msp.B, mol.size(1)
+        out = torch.empty(P, 5, dtype=torch.float32, device=mol.device)
+        arg = torch.empty(P, 6, dtype=torch.int32, device=mol.device)
+        check(_lib.load().glam_pair_pool5_fwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), P, D, ptr(out), ptr(arg), stream()),
+              "glam_pair_pool5_fwd")
+        ctx.save_for_backward(mol, pro, out, arg)
+        ctx.sps = (msp, psp)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        mol, pro, out, arg = ctx.saved_tensors
+        msp, psp = ctx.sps
+        d_out = f32c(d_out, "d_out")
+        d_mol, d_pro = torch.empty_like(mol), torch.empty_like(pro)
+        check(_lib.load().glam_pair_pool5_bwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(out), ptr(arg), ptr(d_out), msp.B,
+                                              mol.size(1), ptr(d_mol), ptr(d_pro), stream()), "glam_pair_pool5_bwd")
+        return d_mol, d_pro, None, None
+
+
+def pair_pool5(mol_out, pro_out, msp, psp):
+    """``[max, mean, median, min, std]`` of ``mol[seg_i] @ pro[seg_i].T`` per pair -> ``[P, 5]`` (dot_and_global_pool5);
+    widths that are multiples of 4 up to 128 (``pad_cols`` the operands first: zero columns do not change a score)."""
+    return _PairPool5.apply(mol_out, pro_out, msp, psp)

@@ -324,6 +324,18 @@ int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_pt
                        const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D, float* d_mol,
                        float* d_pro, void* stream);
 
+/* dot_and_global_pool5 (src_1gp/layer.py:270-283): for every pair i, [max, mean, median, min, std] of
+ * S_i = mol[seg_i] @ pro[seg_i]^T — the reference's Python loop of matmul + max / mean / median / min / std per pair
+ * (median = torch.median of the flattened scores: the LOWER median; std unbiased).  One block per pair, the score matrix is
+ * never materialised.  D % 4 == 0, D <= 128 (the host zero-pads odd widths).  out f32[P,5]; arg int32[P,6] = global row
+ * indices (a, b) of the max, the median and the min element (first occurrence in flattened order), kept for the backward pass.
+ * An empty pair yields zeros / -1. */
+int glam_pair_pool5_fwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr, int64_t P,
+                        int D, float* out, int32_t* arg, void* stream);
+int glam_pair_pool5_bwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
+                        const float* out, const int32_t* arg, const float* d_out, int64_t P, int D, float* d_mol,
+                        float* d_pro, void* stream);
+
 /* Block tail of the convs without a GRU (GCNConv / GATConv blocks, src_1gp/layer.py:248 and :263-266) in one launch per
  * direction: out = act(y + bias + identity) (bias / identity may be NULL; act codes as glam_gru_tail_fwd); the backward
  * returns d_y = d_out * act'(out) (= d_identity; d_bias is its column sum). */

@@ -341,12 +341,19 @@ def main():
     out2 = layer2.dot_and_global_pool2(mo, po, mb.batch, pb.batch)
     cot = torch.randn(out2.shape, generator=torch.Generator().manual_seed(14))
     gm, gp = grads_of(out2, cot, [mo, po])
-    out5 = layer.dot_and_global_pool5(mb.x, pb.x, mb.batch, pb.batch)
+    m5 = mb.x.clone().requires_grad_(True)
+    p5 = pb.x.clone().requires_grad_(True)
+    out5 = layer.dot_and_global_pool5(m5, p5, mb.batch, pb.batch)          # src_1gp/layer.py:270-283, executed as is
+    cot5 = torch.randn(out5.shape, generator=torch.Generator().manual_seed(15))
+    g5m, g5p = grads_of(out5, cot5, [m5, p5])
+    mo5, po5 = mb.x.clone().requires_grad_(True), pb.x.clone().requires_grad_(True)
+    oo5 = O.dot_and_global_pool(mo5, po5, mb.batch, pb.batch, 4, 5)
+    go5m, go5p = grads_of(oo5, cot5, [mo5, po5])
     worst = max(worst, check("dot2", O.dot_and_global_pool(mb.x, pb.x, mb.batch, pb.batch, 4, 2), out2),
-                check("dot5", O.dot_and_global_pool(mb.x, pb.x, mb.batch, pb.batch, 4, 5), out5, 1e-5))
+                check("dot5", oo5, out5, 1e-5), check("dot5/g_mol", go5m, g5m, 1e-5), check("dot5/g_pro", go5p, g5p, 1e-5))
     save("dotpool_pairs", {"kind": "dot_and_global_pool", "B": 4},
          {"mol_x": mb.x, "pro_x": pb.x, "mol_batch": mb.batch, "pro_batch": pb.batch}, {}, out2, cot,
-         {"mol_x": gm, "pro_x": gp, "__out5": out5})
+         {"mol_x": gm, "pro_x": gp, "__out5": out5.detach(), "__cot5": cot5, "__g5_mol": g5m, "__g5_pro": g5p})
 
     # ---- two-tower model (src_2gi_dti_scr/model.py:14-68), the reference's default blocks ----------
     print("Architecture (two towers: ligand + protein)")

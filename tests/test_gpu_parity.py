@@ -247,8 +247,12 @@ def test_dot_and_global_pool_golden(device):
     gm, gp = _grads(out2, g.cot.to(device), [mx, px])
     assert_close(gm, g.grads["mol_x"], TOL, "dot2 d_mol")
     assert_close(gp, g.grads["pro_x"], TOL, "dot2 d_pro")
-    out5 = layer.dot_and_global_pool5(i["mol_x"], i["pro_x"], i["mol_batch"], i["pro_batch"])
-    assert_close(out5, g.grads["__out5"], 2e-5, "dot5")
+    m5, p5 = i["mol_x"].clone().requires_grad_(True), i["pro_x"].clone().requires_grad_(True)
+    out5 = layer.dot_and_global_pool5(m5, p5, i["mol_batch"], i["pro_batch"])      # [max, mean, median, min, std]
+    assert_close(out5, g.grads["__out5"], TOL, "dot5")
+    g5m, g5p = _grads(out5, g.grads["__cot5"].to(device), [m5, p5])
+    assert_close(g5m, g.grads["__g5_mol"], 2e-5, "dot5 d_mol")
+    assert_close(g5p, g.grads["__g5_pro"], 2e-5, "dot5 d_pro")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -864,6 +868,33 @@ def test_pool5_large_graphs_block_kernel(device, sizes):
     out = layer.GlobalPool5()(x, batch.to(device), B)
     assert_close(out, ref, 2e-5, "pool5")
     assert_close(_grads(out, cot.to(device), [x])[0], g_ref, 2e-5, "pool5/gx")
+
+
+@pytest.mark.parametrize("D", [60, 45, 92])
+def test_pair_pool5_protein_sized_segments_vs_oracle(device, D):
+    """dot_and_global_pool5 on ligand x protein sized pairs (410 / 97 / 655 residues), an even and an odd score count (lower
+    median), a one-atom ligand, widths that need zero padding (45 -> 48) and two chunks per lane (92): the five statistics and
+    their gradients against the oracle's per-pair loop."""
+    torch.manual_seed(40 + D)
+    nm, npr = [20, 13, 1, 28], [410, 97, 33, 655]
+    mol, pro = torch.randn(sum(nm), D), torch.randn(sum(npr), D)
+    mb = torch.repeat_interleave(torch.arange(4), torch.tensor(nm))
+    pb = torch.repeat_interleave(torch.arange(4), torch.tensor(npr))
+    mo, po = mol.clone().requires_grad_(True), pro.clone().requires_grad_(True)
+    ref = O.dot_and_global_pool(mo, po, mb, pb, 4, stats=5)
+    cot = torch.randn(ref.shape)
+    g_ref = _grads(ref, cot, [mo, po])
+    m, p = mol.to(device).requires_grad_(True), pro.to(device).requires_grad_(True)
+    out = layer.dot_and_global_pool5(m, p, mb.to(device), pb.to(device))
+    assert_close(out, ref, 2e-5, "pool5 stats")
+    gm, gp = _grads(out, cot.to(device), [m, p])
+    assert_close(gm, g_ref[0], 3e-5, "pool5 d_mol")
+    assert_close(gp, g_ref[1], 3e-5, "pool5 d_pro")
+    out2 = layer.dot_and_global_pool5(m, p, mb.to(device), pb.to(device))
+    assert torch.equal(out, out2), "bit-reproducible"
+    # the median is an ELEMENT of the score matrix (exact selection, not an interpolation)
+    S0 = (mol[:20] @ pro[:410].T).flatten()
+    assert (S0 - out[0, 2].cpu()).abs().min().item() <= 1e-5 * max(1.0, S0.abs().max().item())
 
 
 def test_pair_pool_protein_sized_segments(device):
