@@ -39,19 +39,93 @@ def _pad_de(de):
 # --------------------------------------------------------------------------------------
 # MessagePassing surface (PyG base class the reference derives from, layer.py:9)
 # --------------------------------------------------------------------------------------
+_PROPAGATING = None     # (GraphIndex, target-index tensor) of the propagate() call in flight: lets softmax() reuse its CSR
+
+
+def softmax(src, index, ptr=None, num_nodes=None):
+    """PyG 1.7.2 ``utils.softmax``: per column, softmax over the entries that share ``index`` (max-shifted, denominator
+    ``+ 1e-16``).  Segment max / sum run on the HIP segment-reduction kernels (CSR by ``index``)."""
+    if ptr is not None:
+        raise GlamHipError("softmax(ptr=...) is not used by the reference (it passes ptr=None)")
+    N = int(num_nodes) if num_nodes is not None else (int(index.max().item()) + 1 if index.numel() else 0)
+    if _PROPAGATING is not None and _PROPAGATING[1] is index and _PROPAGATING[0].N == N:
+        gi = _PROPAGATING[0]
+    else:
+        gi = ops.graph_index(torch.stack([index, index]), N)
+    flat = src.reshape(src.size(0), -1)
+    m = ops.edge_reduce(flat.detach(), gi, "max").index_select(0, index)       # the shift cancels in the quotient: no gradient
+    p = torch.exp(flat - m)
+    s_ = ops.edge_reduce(p, gi, "sum").index_select(0, index)
+    return (p / (s_ + 1e-16)).view_as(src)
+
+
 class MessagePassing(torch.nn.Module):
-    """Carrier of the PyG constructor surface (``aggr``, ``flow``, ``node_dim``).  The
-    gather -> message -> aggregate -> update pipeline PyG's ``propagate`` runs op by op is one
-    fused kernel here, so subclasses implement ``forward`` directly."""
+    """PyG 1.7.2 ``MessagePassing`` surface the reference derives from (layer.py:9): constructor (``aggr``, ``flow``,
+    ``node_dim``), ``propagate``, ``message``, ``update``.
+
+    ``propagate(edge_index, size=None, **kwargs)`` runs the PyG pipeline — collect (``name_j`` = ``kwargs[name]`` gathered at
+    ``edge_index[0]``, ``name_i`` at ``edge_index[1]``, ``edge_index_i/_j``, ``size_i/_j``, everything else passed through) ->
+    ``message`` -> aggregate at the targets (HIP CSR segment reduction: ``add`` / ``mean`` / ``max``, no atomics) -> ``update`` —
+    for any subclass that defines ``message`` / ``update`` the PyG way.  The reference's own convs never take this op-by-op
+    route here: ``TripletMessage`` / ``TripletMessageLight`` override ``propagate`` and hand the whole pipeline to the fused
+    kernels (their ``forward`` calls it with the raw inputs)."""
 
     def __init__(self, aggr="add", flow="source_to_target", node_dim=0, **kwargs):
         super().__init__()
         if flow != "source_to_target":
             raise ValueError("only flow='source_to_target' is supported (the reference never changes it)")
+        if aggr not in ("add", "sum", "mean", "max"):
+            raise ValueError(f"aggr={aggr!r}: expected 'add', 'mean' or 'max'")
+        if node_dim != 0:
+            raise ValueError("only node_dim=0 is supported (the reference's convs all use it)")
         self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
 
-    def message(self, *args, **kwargs):
-        raise NotImplementedError("message() is fused into the HIP aggregate kernel; call forward()")
+    def _collect(self, edge_index, size, kwargs):
+        import inspect
+        names = [n for n in inspect.signature(self.message).parameters if n not in ("self",)]
+        n_nodes = size if isinstance(size, int) else (size[1] if size is not None else None)
+        for v in kwargs.values():
+            if n_nodes is None and torch.is_tensor(v) and v.dim() >= 1:
+                n_nodes = v.size(0)                    # PyG: the node count is the size of the first lifted tensor
+                break
+        args = {}
+        for name in names:
+            if name == "edge_index_i":
+                args[name] = edge_index[1]
+            elif name == "edge_index_j":
+                args[name] = edge_index[0]
+            elif name in ("size_i", "size_j"):
+                args[name] = n_nodes
+            elif name.endswith("_i") and name[:-2] in kwargs:
+                args[name] = kwargs[name[:-2]].index_select(0, edge_index[1])
+            elif name.endswith("_j") and name[:-2] in kwargs:
+                args[name] = kwargs[name[:-2]].index_select(0, edge_index[0])
+            elif name in kwargs:
+                args[name] = kwargs[name]
+            else:
+                raise TypeError(f"propagate(): message() needs '{name}' but it was not passed")
+        return args, n_nodes
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        global _PROPAGATING
+        ops.require_device(edge_index)
+        args, n_nodes = self._collect(edge_index, size, kwargs)
+        if n_nodes is None:
+            raise GlamHipError("propagate(): cannot infer the node count; pass size=N")
+        gi = ops.graph_index(edge_index, n_nodes)
+        prev, _PROPAGATING = _PROPAGATING, (gi, args.get("edge_index_i"))
+        try:
+            msg = self.message(**args)
+        finally:
+            _PROPAGATING = prev
+        out = ops.edge_reduce(msg.reshape(msg.size(0), -1), gi, "sum" if self.aggr == "add" else self.aggr)
+        return self.update(out.view((n_nodes,) + tuple(msg.shape[1:])))
+
+    def message(self, x_j):
+        return x_j
+
+    def update(self, aggr_out):
+        return aggr_out
 
 
 # --------------------------------------------------------------------------------------
@@ -100,9 +174,39 @@ class TripletMessage(MessagePassing):
         return Wn.reshape(C, H * Cp), Wa, We.reshape(Dp, H * Cp).contiguous(), M.contiguous(), Ws, Cp, Dp
 
     def forward(self, x, edge_index, edge_attr, size=None):
+        # layer.py:36-40 hands `x @ weight_node` and `edge_attr @ weight_edge` to propagate(); here the two products are part of
+        # the fused pipeline, so propagate() receives the raw tensors (it accepts both forms)
+        return self.propagate(edge_index, x=x, edge_attr=edge_attr, size=size)
+
+    def propagate(self, edge_index, size=None, x=None, edge_attr=None, **kwargs):
+        """``x[N, C]`` with ``edge_attr[E, De]`` (raw inputs): the whole layer in the fused kernels.  ``x[N, H*C]`` with
+        ``edge_attr[E, H*C]`` (already multiplied by ``weight_node`` / ``weight_edge``, the tensors the reference's forward passes,
+        layer.py:37-40): PyG's collect -> message -> aggregate -> update pipeline on those tensors."""
+        if x is None or edge_attr is None or kwargs:
+            raise GlamHipError("TripletMessage.propagate(edge_index, x=..., edge_attr=..., size=None)")
+        edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        HC = self.heads * self.node_channels
+        if x.size(1) == HC and edge_attr.size(1) == HC and not (self.heads == 1 and edge_attr.size(1) == self.edge_channels):
+            return MessagePassing.propagate(self, edge_index, size=size, x=x, edge_attr=edge_attr)
+        if x.size(1) != self.node_channels or edge_attr.size(1) != self.edge_channels:
+            raise GlamHipError(f"TripletMessage.propagate: x has {x.size(1)} and edge_attr {edge_attr.size(1)} columns; expected "
+                               f"({self.node_channels}, {self.edge_channels}) raw or ({HC}, {HC}) transformed")
+        return self._fused(x, edge_index, edge_attr)
+
+    def message(self, x_j, x_i, edge_index_i, edge_attr, size_i):                       # layer.py:42-55
+        """Per-edge messages ``alpha * e_ij * x_j`` [E, H, C] from the lifted, already transformed tensors; the logit of
+        (edge, head) is the three-part dot product <x_i, att_i> + <e_ij, att_e> + <x_j, att_j> (the concatenation the reference
+        forms is never built)."""
+        H, C = self.heads, self.node_channels
+        xj, xi, e = x_j.view(-1, H, C), x_i.view(-1, H, C), edge_attr.view(-1, H, C)
+        att = self.weight_triplet_att[0]                                                # [H, 3C]
+        logit = (xi * att[:, :C]).sum(-1) + (e * att[:, C:2 * C]).sum(-1) + (xj * att[:, 2 * C:]).sum(-1)
+        alpha = softmax(F.leaky_relu(logit, self.negative_slope), edge_index_i, ptr=None, num_nodes=size_i)
+        return alpha.unsqueeze(-1) * e * xj
+
+    def _fused(self, x, edge_index, edge_attr):
         if self.heads > 4:
             raise GlamHipError("heads > 4 is outside the compiled kernel table")
-        edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         gi = ops.graph_index(edge_index, x.size(0))
         C, De = self.node_channels, self.edge_channels
         Cp, Dp = _ceil4(C), _pad_de(De)
@@ -139,10 +243,8 @@ class TripletMessage(MessagePassing):
             Ws = F.pad(Ws, (0, Cp - self.node_channels))
         return Wn.contiguous(), Wa.contiguous(), We, M, Ws.contiguous(), Cp, Dp
 
-    def update(self, aggr_out, weight_scale=None):                         # layer.py:57-61
-        w = self.weight_scale if weight_scale is None else weight_scale
-        aggr_out = aggr_out.view(-1, w.size(0))
-        return torch.matmul(aggr_out, w) + self.bias
+    def update(self, aggr_out):                                                          # layer.py:57-61
+        return torch.addmm(self.bias, aggr_out.reshape(-1, self.weight_scale.size(0)), self.weight_scale)
 
     def extra_repr(self):
         return "{node_channels}, {node_channels}, heads={heads}".format(**self.__dict__)
@@ -167,9 +269,29 @@ class TripletMessageLight(MessagePassing):
         zeros_(self.bias)
 
     def forward(self, x, edge_index, edge_attr, size=None):
+        return self.propagate(edge_index, x=x, edge_attr=edge_attr, size=size, _raw=True)
+
+    def propagate(self, edge_index, size=None, x=None, edge_attr=None, _raw=False, **kwargs):
+        """``_raw=True`` (what ``forward`` passes): ``x`` is the layer input and the whole layer runs in the fused kernels.
+        Otherwise ``x`` is ``x @ weight_node`` as in the reference's forward (layer.py:84-86; both forms have C columns, hence
+        the flag) and PyG's collect -> message -> aggregate -> update pipeline runs on it."""
+        if x is None or edge_attr is None or kwargs:
+            raise GlamHipError("TripletMessageLight.propagate(edge_index, x=..., edge_attr=..., size=None)")
+        edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        if not _raw:
+            return MessagePassing.propagate(self, edge_index, size=size, x=x, edge_attr=edge_attr)
+        return self._fused(x, edge_index, edge_attr)
+
+    def message(self, x_j, x_i, edge_index_i, edge_attr, size_i):                       # layer.py:88-97
+        C, De = self.node_channels, self.edge_channels
+        att = self.weight_triplet_att[0]                                                # [2C + De]: x_i | e_ij | x_j
+        logit = x_i @ att[:C] + edge_attr @ att[C:C + De] + x_j @ att[C + De:]
+        alpha = softmax(F.leaky_relu(logit, self.negative_slope), edge_index_i, ptr=None, num_nodes=size_i)
+        return alpha.unsqueeze(-1) * x_j
+
+    def _fused(self, x, edge_index, edge_attr):
         C, De = self.node_channels, self.edge_channels
         Cp, Dp = _ceil4(C), _pad_de(De)
-        edge_attr = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
         gi = ops.graph_index(edge_index, x.size(0))
 
         def derived():      # parameter-only staging, shared by the message_steps applications of the block (ops.weight_scope)
