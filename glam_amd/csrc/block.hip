@@ -2,7 +2,7 @@
 // The two gate GEMMs run on k_ts_gemm (gemm.hip); this file holds the fused gate math and its backward.
 //   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
 // gi = celu(x) @ W_ih^T + b_ih, gh = h @ W_hh^T + b_hh are [N, 3C] (gate order r | z | n, as torch stores them).
-#include "common.h"
+#include "rng.h"
 
 namespace glam {
 
@@ -44,7 +44,21 @@ __global__ void __launch_bounds__(kBlock) k_gru_gates_bwd(const float* gi, const
 
 // ---- the rest of MessageBlock.forward after the GRU (layer.py:263-266) folded into the gate kernel:
 //   h' = GRU gates;  y = h' + identity (res);  out = act(y),  act in {none, ReLU, LeakyReLU(slope), CELU(alpha = 1)}
-enum { kActNone = 0, kActRelu = 1, kActLeaky = 2, kActCelu = 3 };
+//   training mode of the reference's default configuration (model.py:30-31): act = RReLU (slope ~ U(lo, hi) per element where
+//   y <= 0, torch.nn.RReLU) and an optional SECOND output out_drop = Dropout(p)(out) — the input of the next message step's
+//   conv (layer.py:256) — both drawn from the device-side Philox stream of rng.h; the backward kernels regenerate the numbers.
+enum { kActNone = 0, kActRelu = 1, kActLeaky = 2, kActCelu = 3, kActRRelu = 4 };
+
+struct TailRng { long long* state; long long* eff; float lo, hi, p; float* out_drop; };               // forward
+struct TailRngB { const long long* eff; float lo, hi, p; const float* d_out_drop; };                   // backward
+
+__device__ __forceinline__ float rrelu_slope(const Philox& ph, size_t i, float lo, float hi) {
+    return fmaf(hi - lo, u01(philox_word(philox4(ph, i >> 2), (int)(i & 3))), lo);
+}
+// Dropout(p) multiplier of element i: 0 with probability p, else 1 / (1 - p)   (second Philox stream: bit 62 of the counter)
+__device__ __forceinline__ float drop_scale(const Philox& ph, size_t i, float p) {
+    return u01(philox_word(philox4(ph, (i >> 2) | (1ull << 62)), (int)(i & 3))) >= p ? 1.f / (1.f - p) : 0.f;
+}
 
 __device__ __forceinline__ float act_fwd(float y, int act, float slope) {
     switch (act) {
@@ -64,9 +78,12 @@ __device__ __forceinline__ float act_grad_from_out(float out, int act, float slo
     }
 }
 
+template <bool RNG>
 __global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const float* gh, const float* h, const float* identity,
-                                                        int N, int C, int act, float slope, float* h_new, float* out) {
+                                                        int N, int C, int act, float slope, float* h_new, float* out, TailRng rg) {
     const size_t total = (size_t)N * C;
+    Philox ph{};
+    if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
         const float r = sigmoidf_(gi[b] + gh[b]);
@@ -74,18 +91,35 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const 
         const float nn = tanhf(gi[b + 2 * C] + r * gh[b + 2 * C]);
         const float hn = (1.f - z) * nn + z * h[i];
         h_new[i] = hn;
-        out[i] = act_fwd(identity ? hn + identity[i] : hn, act, slope);
+        const float y = identity ? hn + identity[i] : hn;
+        float o;
+        if (RNG && act == kActRRelu) o = y > 0.f ? y : y * rrelu_slope(ph, i, rg.lo, rg.hi);
+        else o = act_fwd(y, act, slope);
+        out[i] = o;
+        if constexpr (RNG) { if (rg.out_drop) rg.out_drop[i] = o * drop_scale(ph, i, rg.p); }
     }
+    if constexpr (RNG) rng_end(rg.state, ph);
 }
 
 // d_out: gradient of the block output; d_hstate (may be null): gradient arriving at h' through the next step's GRU
+template <bool RNG>
 __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const float* gh, const float* h, const float* out,
                                                         const float* d_out, const float* d_hstate, int N, int C, int act,
-                                                        float slope, float* d_gi, float* d_gh, float* d_h, float* d_identity) {
+                                                        float slope, float* d_gi, float* d_gh, float* d_h, float* d_identity,
+                                                        TailRngB rg) {
     const size_t total = (size_t)N * C;
+    Philox ph{};
+    if constexpr (RNG) ph = philox_init(rg.eff);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
-        const float dy = d_out[i] * act_grad_from_out(out[i], act, slope);
+        float dy;
+        if constexpr (RNG) {
+            float g = d_out ? d_out[i] : 0.f;
+            if (rg.d_out_drop) g = fmaf(rg.d_out_drop[i], drop_scale(ph, i, rg.p), g);
+            dy = g * (act == kActRRelu ? (out[i] > 0.f ? 1.f : rrelu_slope(ph, i, rg.lo, rg.hi)) : act_grad_from_out(out[i], act, slope));
+        } else {
+            dy = d_out[i] * act_grad_from_out(out[i], act, slope);
+        }
         if (d_identity) d_identity[i] = dy;
         const float g = d_hstate ? dy + d_hstate[i] : dy;
         const float ghn = gh[b + 2 * C];
@@ -104,21 +138,41 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const 
 
 
 // ---- block tail without a GRU (GCN / GAT blocks, src_1gp/layer.py:248, 263-266): out = act(y + bias + identity) ----
+template <bool RNG>
 __global__ void __launch_bounds__(kBlock) k_bias_res_act_fwd(const float* y, const float* bias, const float* identity, int N, int C,
-                                                            int act, float slope, float* out) {
+                                                            int act, float slope, float* out, TailRng rg) {
     const size_t total = (size_t)N * C;
+    Philox ph{};
+    if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         float v = y[i];
         if (bias) v += bias[i % C];
         if (identity) v += identity[i];
-        out[i] = act_fwd(v, act, slope);
+        float o;
+        if (RNG && act == kActRRelu) o = v > 0.f ? v : v * rrelu_slope(ph, i, rg.lo, rg.hi);
+        else o = act_fwd(v, act, slope);
+        if (out) out[i] = o;
+        if constexpr (RNG) { if (rg.out_drop) rg.out_drop[i] = o * drop_scale(ph, i, rg.p); }
     }
+    if constexpr (RNG) rng_end(rg.state, ph);
 }
+// `out` may be null for act == none (a pure Dropout): the activation derivative is then 1
+template <bool RNG>
 __global__ void __launch_bounds__(kBlock) k_bias_res_act_bwd(const float* out, const float* d_out, int N, int C, int act, float slope,
-                                                            float* d_y) {
+                                                            float* d_y, TailRngB rg) {
     const size_t total = (size_t)N * C;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
-        d_y[i] = d_out[i] * act_grad_from_out(out[i], act, slope);
+    Philox ph{};
+    if constexpr (RNG) ph = philox_init(rg.eff);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        if constexpr (RNG) {
+            float g = d_out ? d_out[i] : 0.f;
+            if (rg.d_out_drop) g = fmaf(rg.d_out_drop[i], drop_scale(ph, i, rg.p), g);
+            const float o = out ? out[i] : 1.f;
+            d_y[i] = g * (act == kActRRelu ? (o > 0.f ? 1.f : rrelu_slope(ph, i, rg.lo, rg.hi)) : act_grad_from_out(o, act, slope));
+        } else {
+            d_y[i] = d_out[i] * act_grad_from_out(out[i], act, slope);
+        }
+    }
 }
 
 // ---- Set2Set readout (reference: model.py:41, PyG Set2Set(C, processing_steps = 3)): gate math of one torch.nn.LSTM
@@ -164,8 +218,8 @@ extern "C" int glam_gru_tail_fwd(const float* gi, const float* gh, const float* 
     if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_tail_fwd: activation code %d", act);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(gi && gh && h && h_new && out, "glam_gru_tail_fwd: null pointer");
-    hipLaunchKernelGGL(k_gru_tail_fwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, identity,
-                       (int)N, C, act, slope, h_new, out);
+    hipLaunchKernelGGL(k_gru_tail_fwd<false>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, identity,
+                       (int)N, C, act, slope, h_new, out, TailRng{});
     GLAM_LAUNCH_CHECK("glam_gru_tail_fwd");
     return GLAM_OK;
 }
@@ -177,8 +231,8 @@ extern "C" int glam_gru_tail_bwd(const float* gi, const float* gh, const float* 
     if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_tail_bwd: activation code %d", act);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(gi && gh && h && out && d_out && d_gi && d_gh && d_h, "glam_gru_tail_bwd: null pointer");
-    hipLaunchKernelGGL(k_gru_tail_bwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
-                       d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity);
+    hipLaunchKernelGGL(k_gru_tail_bwd<false>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
+                       d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, TailRngB{});
     GLAM_LAUNCH_CHECK("glam_gru_tail_bwd");
     return GLAM_OK;
 }
@@ -231,8 +285,8 @@ extern "C" int glam_bias_res_act_fwd(const float* y, const float* bias, const fl
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX && C > 0 && act >= 0 && act <= 3, "glam_bias_res_act_fwd: bad arguments");
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(y && out, "glam_bias_res_act_fwd: null pointer");
-    hipLaunchKernelGGL(k_bias_res_act_fwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, bias, identity, (int)N, C,
-                       act, slope, out);
+    hipLaunchKernelGGL(k_bias_res_act_fwd<false>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, bias, identity, (int)N, C,
+                       act, slope, out, TailRng{});
     GLAM_LAUNCH_CHECK("glam_bias_res_act_fwd");
     return GLAM_OK;
 }
@@ -242,8 +296,73 @@ extern "C" int glam_bias_res_act_bwd(const float* out, const float* d_out, int64
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX && C > 0 && act >= 0 && act <= 3, "glam_bias_res_act_bwd: bad arguments");
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(out && d_out && d_y, "glam_bias_res_act_bwd: null pointer");
-    hipLaunchKernelGGL(k_bias_res_act_bwd, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, d_out, (int)N, C, act,
-                       slope, d_y);
+    hipLaunchKernelGGL(k_bias_res_act_bwd<false>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, d_out, (int)N, C, act,
+                       slope, d_y, TailRngB{});
     GLAM_LAUNCH_CHECK("glam_bias_res_act_bwd");
+    return GLAM_OK;
+}
+
+// ---- training-mode variants: RReLU / Dropout from the device-side Philox stream (rng.h) ----
+static int rng_args_ok(const char* fn, int act, float lo, float hi, float p) {
+    if (act < kActNone || act > kActRRelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);
+    if (act == kActRRelu && !(lo > 0.f && lo <= hi)) return fail(GLAM_E_INVALID, "%s: RReLU needs 0 < lower <= upper (got %g, %g)", fn, lo, hi);
+    if (!(p >= 0.f && p < 1.f)) return fail(GLAM_E_INVALID, "%s: dropout p = %g outside [0, 1)", fn, p);
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_tail_rng_fwd(const float* gi, const float* gh, const float* h, const float* identity, int64_t N, int C,
+                                     int act, float slope, float rr_lower, float rr_upper, float drop_p, int64_t* rng_state,
+                                     int64_t* rng_eff, float* h_new, float* out, float* out_drop, void* stream) {
+    GLAM_REQUIRE(N >= 0 && C > 0 && N * (int64_t)C < (int64_t)INT32_MAX * 64, "glam_gru_tail_rng_fwd: bad sizes");
+    if (int rc = rng_args_ok("glam_gru_tail_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(gi && gh && h && h_new && out && rng_state && rng_eff, "glam_gru_tail_rng_fwd: null pointer");
+    TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop};
+    hipLaunchKernelGGL(k_gru_tail_fwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, identity,
+                       (int)N, C, act, slope, h_new, out, rg);
+    GLAM_LAUNCH_CHECK("glam_gru_tail_rng_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_tail_rng_bwd(const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                                     const float* d_out_drop, const float* d_hstate, int64_t N, int C, int act, float slope,
+                                     float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff, float* d_gi, float* d_gh,
+                                     float* d_h, float* d_identity, void* stream) {
+    GLAM_REQUIRE(N >= 0 && C > 0, "glam_gru_tail_rng_bwd: bad sizes");
+    if (int rc = rng_args_ok("glam_gru_tail_rng_bwd", act, rr_lower, rr_upper, drop_p)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(gi && gh && h && out && (d_out || d_out_drop) && d_gi && d_gh && d_h && rng_eff, "glam_gru_tail_rng_bwd: null pointer");
+    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop};
+    hipLaunchKernelGGL(k_gru_tail_bwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
+                       d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, rg);
+    GLAM_LAUNCH_CHECK("glam_gru_tail_rng_bwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_bias_res_act_rng_fwd(const float* y, const float* bias, const float* identity, int64_t N, int C, int act,
+                                         float slope, float rr_lower, float rr_upper, float drop_p, int64_t* rng_state,
+                                         int64_t* rng_eff, float* out, float* out_drop, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX && C > 0, "glam_bias_res_act_rng_fwd: bad sizes");
+    if (int rc = rng_args_ok("glam_bias_res_act_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(y && (out || (out_drop && act == kActNone)) && rng_state && rng_eff, "glam_bias_res_act_rng_fwd: null pointer");
+    TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop};
+    hipLaunchKernelGGL(k_bias_res_act_fwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, bias, identity,
+                       (int)N, C, act, slope, out, rg);
+    GLAM_LAUNCH_CHECK("glam_bias_res_act_rng_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_bias_res_act_rng_bwd(const float* out, const float* d_out, const float* d_out_drop, int64_t N, int C, int act,
+                                         float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
+                                         float* d_y, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX && C > 0, "glam_bias_res_act_rng_bwd: bad sizes");
+    if (int rc = rng_args_ok("glam_bias_res_act_rng_bwd", act, rr_lower, rr_upper, drop_p)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE((out || act == kActNone) && (d_out || d_out_drop) && d_y && rng_eff, "glam_bias_res_act_rng_bwd: null pointer");
+    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop};
+    hipLaunchKernelGGL(k_bias_res_act_bwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, d_out, (int)N,
+                       C, act, slope, d_y, rg);
+    GLAM_LAUNCH_CHECK("glam_bias_res_act_rng_bwd");
     return GLAM_OK;
 }

@@ -1,0 +1,64 @@
+// Counter-based random numbers for the training-mode layers of the reference's default configuration
+// (src_1gp/model.py:30-31: RReLU activations and Dropout(0.2)): Philox4x32-10 (Salmon et al., SC'11 — the public algorithm
+// torch's CUDA generator also uses), keyed by a 64-bit seed, counter = (element-quad index, per-launch offset).
+//
+// hipGraph-safe stream position: the (seed, offset) pair lives in DEVICE memory (`state`: int64 seed, int64 offset, then a
+// 32-bit ticket).  Every RNG-consuming launch reads the pair first, uses `offset` as its private stream id, and the LAST block
+// of the launch to finish (ticket counter) stores offset + 1 for the next launch — no host round trip, no extra launch, and a
+// replayed graph continues the sequence exactly where the previous replay (or eager step) left it.  Block 0 also records the pair
+// it used in `eff` (int64[2]) so that the backward kernel regenerates the very same numbers instead of reading saved masks.
+#pragma once
+#include "common.h"
+
+namespace glam {
+
+struct Philox {
+    unsigned k0, k1;
+    unsigned o0, o1;     // per-launch offset (counter words 2, 3)
+};
+
+__device__ __forceinline__ Philox philox_init(const long long* pair) {
+    const unsigned long long seed = (unsigned long long)pair[0], off = (unsigned long long)pair[1];
+    return Philox{(unsigned)seed, (unsigned)(seed >> 32), (unsigned)off, (unsigned)(off >> 32)};
+}
+
+// four uniform 32-bit words for element quad `q`
+__device__ __forceinline__ uint4 philox4(const Philox& p, unsigned long long q) {
+    unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = p.o0, c3 = p.o1;
+    unsigned k0 = p.k0, k1 = p.k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// uniform in [0, 1): 24 random bits (every value exactly representable)
+__device__ __forceinline__ float u01(unsigned w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ unsigned philox_word(const uint4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+// forward prologue: the pair this launch uses; block 0 records it for the backward pass
+__device__ __forceinline__ Philox rng_begin(const long long* state, long long* eff) {
+    const long long seed = state[0], off = state[1];
+    if (eff && blockIdx.x == 0 && threadIdx.x == 0) { eff[0] = seed; eff[1] = off; }
+    const long long pair[2] = {seed, off};
+    return philox_init(pair);
+}
+// forward epilogue: the last block to arrive advances the stream position (every block has read `state` by then)
+__device__ __forceinline__ void rng_end(long long* state, const Philox& p) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned* ticket = reinterpret_cast<unsigned*>(state + 2);
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            state[1] = (long long)((((unsigned long long)p.o1 << 32) | p.o0) + 1ull);
+            *ticket = 0u;
+            __threadfence();
+        }
+    }
+}
+
+}  // namespace glam

@@ -740,6 +740,26 @@ def _act(name):
     return _build(name + "()")
 
 
+def _apply_dropout(mod, x):
+    """``mod(x)`` for the block's dropout slot.  A training-mode ``torch.nn.Dropout`` runs on the device-side Philox stream
+    (``ops.dropout``: hipGraph-safe, no mask tensor) — or costs nothing when the kernel that produced ``x`` already wrote the
+    dropped twin (``ops.take_dropped``)."""
+    if type(mod) is Dropout and mod.training and mod.p > 0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        if mod.p >= 1:
+            return torch.zeros_like(x)
+        twin = ops.take_dropped(x, mod.p)
+        return twin if twin is not None else ops.dropout(x, mod.p)
+    return mod(x)
+
+
+def _apply_act(mod, x):
+    """``mod(x)`` for an activation slot; training-mode RReLU (the reference's default, model.py:31) draws its slopes from the
+    device-side Philox stream."""
+    if type(mod) is RReLU and mod.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        return ops.rrelu(x, mod.lower, mod.upper)
+    return mod(x)
+
+
 class LinearBlock(torch.nn.Module):
     def __init__(self, in_dim=32, out_dim=64, norm="_None", dropout="_None()", act="ReLU()"):
         super().__init__()
@@ -750,9 +770,9 @@ class LinearBlock(torch.nn.Module):
 
     def forward(self, x, batch=None):
         x = self.norm(x, batch)
-        x = self.dropout(x)
+        x = _apply_dropout(self.dropout, x)
         x = ops.linear(x, self.linear.weight, self.linear.bias)
-        return self.act(x)
+        return _apply_act(self.act, x)
 
 
 class MessageBlock(torch.nn.Module):
@@ -776,35 +796,49 @@ class MessageBlock(torch.nn.Module):
         return ops.gru_step(x, h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
 
     def _fusable_act(self):
-        """(code, slope) when ``self.act`` is one the gate kernel applies itself, else None."""
+        """(code, slope, rng) when ``self.act`` is one the tail kernels apply themselves, else None.  ``rng`` is
+        ``(rr_lower, rr_upper, drop_p)`` in training mode when the kernel has random numbers to draw: RReLU slopes, and — when
+        nothing sits between this block's output and the next application's dropout (``norm`` is ``_None``) — the Dropout mask
+        of the next message step (layer.py:255-256), written as a second output."""
         a = self.act
+        d = self.dropout
+        drop_p = float(d.p) if (type(d) is Dropout and self.training and 0 < d.p < 1 and isinstance(self.norm, _None)) else 0.0
+        rng = (1.0, 1.0, drop_p) if drop_p > 0 else None
         if isinstance(a, _None):
-            return "none", 0.0
+            return "none", 0.0, rng
         if type(a) is torch.nn.ReLU:
-            return "relu", 0.0
+            return "relu", 0.0, rng
         if type(a) is torch.nn.LeakyReLU and a.negative_slope > 0:
-            return "leaky", float(a.negative_slope)
+            return "leaky", float(a.negative_slope), rng
         if type(a) is torch.nn.CELU and a.alpha == 1.0:
-            return "celu", 0.0
-        return None                                  # RReLU (random in training), PReLU (learnable): stay on torch
+            return "celu", 0.0, rng
+        if type(a) is RReLU and 0 < a.lower <= a.upper:
+            if self.training:
+                return "rrelu", 0.0, (float(a.lower), float(a.upper), drop_p)
+            return "leaky", (float(a.lower) + float(a.upper)) / 2, None      # eval: the fixed mean slope
+        return None                                  # PReLU (learnable slope): stays on torch
 
     def forward(self, x, edge_index, edge_attr, h=None, batch=None):
         identity = x
         if h is None:
             h = x.unsqueeze(0)                       # layer.py:254 (pre-norm x seeds the GRU state)
         x = self.norm(x, batch)
-        x = self.dropout(x)
-        if self.gru is None and isinstance(self.conv, (_GCNConv, _GATConv)) and self._fusable_act() is not None:
+        x = _apply_dropout(self.dropout, x)
+        fa = self._fusable_act()
+        if self.gru is None and isinstance(self.conv, (_GCNConv, _GATConv)) and fa is not None:
             # no GRU (layer.py:248): conv bias + residual + activation as one launch per direction
-            fa = self._fusable_act()
             c = self.conv.conv
             y = c(x, edge_index, add_bias=False)
-            return ops.bias_res_act(y, c.bias, None if self.res is False else identity, fa[0], fa[1]), h
+            return ops.bias_res_act(y, c.bias, None if self.res is False else identity, fa[0], fa[1], rng=fa[2]), h
         x = self.conv(x, edge_index, edge_attr)      # layer.py:259
         if self.gru is not None:
-            fa = self._fusable_act()
-            if fa is not None:                       # CELU (layer.py:261) + GRU step + residual + activation: one autograd node
-                g = self.gru
+            g = self.gru
+            if fa is not None and (fa[2] is None or ops.gru_block_supported(x.size(1), g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0)):
+                # CELU (layer.py:261) + GRU step + residual + activation: one autograd node
+                x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,
+                                     g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1], celu_in=True, rng=fa[2])
+                return x, hn.unsqueeze(0)
+            if fa is not None and fa[0] != "rrelu":  # odd widths in training mode: fused tail without the dropped twin
                 x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,
                                      g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1], celu_in=True)
                 return x, hn.unsqueeze(0)
@@ -812,7 +846,7 @@ class MessageBlock(torch.nn.Module):
             x = self._gru_step(x, h.squeeze(0))
             h = x.unsqueeze(0)
         x = x if self.res is False else x + identity
-        x = self.act(x)
+        x = _apply_act(self.act, x)
         return x, h
 
 

@@ -605,6 +605,57 @@ def triplet_layer_wide(x_p, ea_p, weight_node, weight_edge, att, weight_scale, b
 
 
 # --------------------------------------------------------------------------------------
+# device-side random stream of the training-mode layers (RReLU slopes, Dropout masks): csrc/rng.h
+# --------------------------------------------------------------------------------------
+_RNG_STATE: dict = {}
+
+
+def rng_state(device):
+    """``int64[3]`` on ``device``: Philox seed, stream offset (advanced by every RNG-consuming launch, on the device), scratch.
+    Created on first use from ``torch.initial_seed()`` — so the reference's ``seed_torch`` (``utils.py:22-28``) also fixes this
+    stream — and OUTSIDE any hipGraph capture (``GraphedTrainStep`` runs the first visit of a batch eagerly)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _RNG_STATE.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise GlamHipError("the RNG state must exist before a hipGraph capture: run one eager training-mode forward first "
+                               "(or call glam_amd.ops.manual_seed)")
+        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & (2 ** 63 - 1), 0, 0], dtype=torch.int64, device=device)
+    return st
+
+
+def manual_seed(seed, device=None):
+    """Restart the device-side stream of RReLU / Dropout numbers at ``(seed, offset 0)``."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = rng_state(device)
+    st.copy_(torch.tensor([int(seed) & (2 ** 63 - 1), 0, 0], dtype=torch.int64))
+    return st
+
+
+# A tail kernel that also wrote Dropout(p)(out) — the input of the NEXT message step's conv (layer.py:255-259) — registers the
+# pair here; the block's dropout call on that very tensor then returns the twin instead of launching a kernel.
+_DROPPED: dict = {}      # data_ptr(out) -> (weakref(out), out._version, out_drop, p)
+
+
+def register_dropped(out, out_drop, p):
+    key = out.data_ptr()
+
+    def _gone(ref, k=key):
+        hit = _DROPPED.get(k)
+        if hit is not None and hit[0] is ref:
+            _DROPPED.pop(k, None)
+    _DROPPED[key] = (weakref.ref(out, _gone), out._version, out_drop, float(p))
+
+
+def take_dropped(x, p):
+    hit = _DROPPED.get(x.data_ptr())
+    if hit is not None and hit[0]() is x and hit[1] == x._version and hit[3] == float(p):
+        _DROPPED.pop(x.data_ptr(), None)
+        return hit[2]
+    return None
+
+
+# --------------------------------------------------------------------------------------
 # dense linear on the fp32 matrix cores + GRU gate math (MessageBlock remainder)
 # --------------------------------------------------------------------------------------
 def linear_supported(K, M):
@@ -907,15 +958,21 @@ class _GruTail(torch.autograd.Function):
         return d_gi, d_gh, d_h, d_id, None, None
 
 
-ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3}
+ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3, "rrelu": 4}
 
 
-def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False):
+def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False, rng=None):
     """``h_new = GRU(celu(x) if celu_in else x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:261-266):
-    the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``."""
+    the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``.
+    ``rng = (rr_lower, rr_upper, drop_p)`` (training mode of the reference's defaults): ``act == "rrelu"`` draws its slopes in
+    the kernel and, with ``drop_p > 0``, the kernel also writes ``Dropout(drop_p)(out)`` and registers it as the dropped twin
+    of ``out`` (``take_dropped``) — available on the one-node path (C % 4 == 0, C <= 60); elsewhere the caller applies
+    ``ops.rrelu`` / ``ops.dropout`` itself (``rng`` must then be None)."""
     C = h.size(1)
+    if rng is not None and not gru_block_supported(C, w_ih, b_ih, b_hh):
+        raise GlamHipError("gru_tail(rng=...) needs the one-node GRU block (C % 4 == 0, C <= 60)")
     if gru_block_supported(C, w_ih, b_ih, b_hh):
-        return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in)
+        return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in, rng)
     Cp = (C + 3) // 4 * 4
     if Cp != C and b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_supported(Cp, 3 * Cp) \
             and 3 * Cp > 64:
@@ -948,7 +1005,7 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
 
 
-def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in):
+def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
     """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
     M, C = w_ih.shape
     def split(flat):
@@ -956,10 +1013,11 @@ def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in):
         return d[0, :M, :C], d[1, :M, :C], d[0, :M, C], d[1, :M, C]
     key = ("carry-gru", id(w_ih))
     carry = _carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * (M + 1) * (C + 1), split)
-    if carry is None:
-        return _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in)
-    out, h_new, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry)
-    _carry_store(key, w_ih, carry)
+    out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng)
+    if carry is not None:
+        _carry_store(key, w_ih, carry)
+    if out_drop is not None:
+        register_dropped(out, out_drop, rng[2])
     return out, h_new
 
 
@@ -970,7 +1028,7 @@ class _GruBlock(torch.autograd.Function):
     one, which is what an eagerly issued training step is bound by."""
 
     @staticmethod
-    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None):
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None):
         require_device(x, h, w_ih, w_hh, b_ih, b_hh)
         x, h = f32c(x, "x"), f32c(h, "h")
         w_ih, w_hh, b_ih, b_hh = f32c(w_ih, "weight_ih"), f32c(w_hh, "weight_hh"), f32c(b_ih, "bias_ih"), f32c(b_hh, "bias_hh")
@@ -1007,30 +1065,51 @@ class _GruBlock(torch.autograd.Function):
               "glam_ts_gemm_celu")
         check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
         h_new, out = torch.empty_like(h), torch.empty_like(h)
-        check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
-              "glam_gru_tail_fwd")
+        out_drop, eff = None, None
+        if rng is None:
+            if act == ACT_CODES["rrelu"]:
+                raise GlamHipError("gru block: act 'rrelu' needs rng=(lower, upper, drop_p)")
+            check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
+                  "glam_gru_tail_fwd")
+        else:     # training mode: RReLU slopes / the next conv's Dropout mask drawn inside the launch
+            lo, hi, p = (float(v) for v in rng)
+            eff = torch.empty(2, dtype=torch.int64, device=dev)
+            out_drop = torch.empty_like(h) if p > 0 else None
+            check(lib.glam_gru_tail_rng_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), lo, hi, p,
+                                            ptr(rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
         ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
-        ctx.cfg = (act, float(slope), identity is not None, bool(celu_in))
+        ctx.eff = eff
+        ctx.cfg = (act, float(slope), identity is not None, bool(celu_in), None if rng is None else tuple(float(v) for v in rng))
         ctx.scope = scope
         ctx.carried = carry is not None
-        return (out, h_new, carry.view(-1)) if ctx.carried else (out, h_new)
+        return out, h_new, out_drop, (carry.view(-1) if ctx.carried else None)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out, d_hstate, d_carry=None):
+    def backward(ctx, d_out, d_hstate, d_out_drop=None, d_carry=None):
         x, h, gi, gh, out, w_ih, w_hh = ctx.saved_tensors
-        act, slope, has_res, celu_in = ctx.cfg
+        act, slope, has_res, celu_in, rng = ctx.cfg
         N, C = h.shape
         M = 3 * C
         lib, dev = _lib.load(), x.device
         f = dict(dtype=torch.float32, device=dev)
         st = stream()
-        d_out = f32c(d_out, "d_out")
+        d_out = None if d_out is None else f32c(d_out, "d_out")
+        d_out_drop = None if d_out_drop is None else f32c(d_out_drop, "d_out_drop")
         d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
         d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
         d_id = torch.empty_like(h) if has_res else None
-        check(lib.glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope, ptr(d_gi),
-                                    ptr(d_gh), ptr(d_h), ptr(d_id), st), "glam_gru_tail_bwd")
+        if rng is None:
+            if d_out is None:
+                d_out = torch.zeros_like(h)
+            check(lib.glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope, ptr(d_gi),
+                                        ptr(d_gh), ptr(d_h), ptr(d_id), st), "glam_gru_tail_bwd")
+        else:
+            if d_out is None and d_out_drop is None:
+                d_out = torch.zeros_like(h)
+            check(lib.glam_gru_tail_rng_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), N, C, act, slope,
+                                            rng[0], rng[1], rng[2], ptr(ctx.eff), ptr(d_gi), ptr(d_gh), ptr(d_h), ptr(d_id), st),
+                  "glam_gru_tail_rng_bwd")
         scope = ctx.scope
 
         def image_t(w):
@@ -1055,8 +1134,8 @@ class _GruBlock(torch.autograd.Function):
               "glam_wgrad_gemm_pair")
         if ctx.carried:
             flat = dwb.view(-1)
-            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry))
-        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None, None, None
+            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None
+        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None, None, None, None
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):
@@ -1173,36 +1252,78 @@ class _SegmentAttn(torch.autograd.Function):
 
 
 class _BiasResAct(torch.autograd.Function):
-    """``act(y + bias + identity)``: the tail of a MessageBlock whose conv has no GRU (GCN / GAT), one launch per direction."""
+    """``act(y + bias + identity)``: the tail of a MessageBlock whose conv has no GRU (GCN / GAT), one launch per direction.
+    ``rng = (rr_lower, rr_upper, drop_p)``: training-mode RReLU (``act == 4``) and / or a second output ``Dropout(drop_p)(out)``
+    from the device-side Philox stream; ``want_out=False`` with ``act == 0`` is a plain Dropout.  Returns ``(out, out_drop)``."""
 
     @staticmethod
-    def forward(ctx, y, bias, identity, act, slope):
+    def forward(ctx, y, bias, identity, act, slope, rng=None, want_out=True):
         require_device(y, bias, identity)
         y = f32c(y, "y")
         bias = None if bias is None else f32c(bias, "bias")
         identity = None if identity is None else f32c(identity, "identity")
         N, C = y.shape
-        out = torch.empty_like(y)
-        check(_lib.load().glam_bias_res_act_fwd(ptr(y), ptr(bias), ptr(identity), N, C, act, float(slope), ptr(out), stream()),
-              "glam_bias_res_act_fwd")
-        ctx.save_for_backward(out)
-        ctx.cfg = (act, float(slope), bias is not None, identity is not None)
-        return out
+        out = torch.empty_like(y) if want_out else None
+        out_drop, eff = None, None
+        if rng is None:
+            if act == ACT_CODES["rrelu"] or not want_out:
+                raise GlamHipError("bias_res_act: 'rrelu' / dropout-only need rng=(lower, upper, drop_p)")
+            check(_lib.load().glam_bias_res_act_fwd(ptr(y), ptr(bias), ptr(identity), N, C, act, float(slope), ptr(out), stream()),
+                  "glam_bias_res_act_fwd")
+        else:
+            lo, hi, p = (float(v) for v in rng)
+            eff = torch.empty(2, dtype=torch.int64, device=y.device)
+            out_drop = torch.empty_like(y) if p > 0 else None
+            check(_lib.load().glam_bias_res_act_rng_fwd(ptr(y), ptr(bias), ptr(identity), N, C, act, float(slope), lo, hi, p,
+                                                        ptr(rng_state(y.device)), ptr(eff), ptr(out), ptr(out_drop), stream()),
+                  "glam_bias_res_act_rng_fwd")
+        ctx.save_for_backward(*([out] if out is not None else []))
+        ctx.eff = eff
+        ctx.shape = (N, C)
+        ctx.cfg = (act, float(slope), bias is not None, identity is not None, None if rng is None else tuple(float(v) for v in rng))
+        return out, out_drop
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out):
-        (out,) = ctx.saved_tensors
-        act, slope, has_bias, has_id = ctx.cfg
-        d_out = f32c(d_out, "d_out")
-        N, C = out.shape
-        d_y = torch.empty_like(out)
-        check(_lib.load().glam_bias_res_act_bwd(ptr(out), ptr(d_out), N, C, act, slope, ptr(d_y), stream()), "glam_bias_res_act_bwd")
-        return d_y, (d_y.sum(0) if has_bias else None), (d_y if has_id else None), None, None
+    def backward(ctx, d_out, d_out_drop=None):
+        out = ctx.saved_tensors[0] if ctx.saved_tensors else None
+        act, slope, has_bias, has_id, rng = ctx.cfg
+        N, C = ctx.shape
+        d_out = None if d_out is None else f32c(d_out, "d_out")
+        d_out_drop = None if d_out_drop is None else f32c(d_out_drop, "d_out_drop")
+        ref = d_out if d_out is not None else d_out_drop
+        d_y = torch.empty_like(ref)
+        if rng is None:
+            check(_lib.load().glam_bias_res_act_bwd(ptr(out), ptr(d_out), N, C, act, slope, ptr(d_y), stream()), "glam_bias_res_act_bwd")
+        else:
+            check(_lib.load().glam_bias_res_act_rng_bwd(ptr(out), ptr(d_out), ptr(d_out_drop), N, C, act, slope, rng[0], rng[1], rng[2],
+                                                        ptr(ctx.eff), ptr(d_y), stream()), "glam_bias_res_act_rng_bwd")
+        return d_y, (d_y.sum(0) if has_bias else None), (d_y if has_id else None), None, None, None, None
 
 
-def bias_res_act(y, bias, identity, act="none", slope=0.0):
-    return _BiasResAct.apply(y, bias, identity, ACT_CODES[act], slope)
+def bias_res_act(y, bias, identity, act="none", slope=0.0, rng=None):
+    out, out_drop = _BiasResAct.apply(y, bias, identity, ACT_CODES[act], slope, rng, True)
+    if out_drop is not None:
+        register_dropped(out, out_drop, rng[2])
+    return out
+
+
+def rrelu(x, lower=1.0 / 8, upper=1.0 / 3, drop_p=0.0):
+    """Training-mode ``torch.nn.RReLU(lower, upper)`` on the device-side Philox stream (one launch per direction, slopes
+    regenerated in the backward); ``drop_p > 0`` also writes the dropped twin for a ``Dropout(drop_p)`` that follows."""
+    shape = x.shape
+    out, out_drop = _BiasResAct.apply(x.reshape(-1, shape[-1]), None, None, ACT_CODES["rrelu"], 0.0, (lower, upper, drop_p), True)
+    out = out.view(shape)
+    if out_drop is not None:
+        register_dropped(out, out_drop.view(shape), drop_p)
+    return out
+
+
+def dropout(x, p):
+    """Training-mode ``torch.nn.Dropout(p)``: ``x * mask / (1 - p)``; the mask is regenerated in the backward (no mask tensor)."""
+    shape = x.shape
+    _, out_drop = _BiasResAct.apply(x.reshape(-1, shape[-1]), None, None, ACT_CODES["none"], 0.0, (1.0, 1.0, float(p)), False)
+    return out_drop.view(shape)
 
 
 class _LstmCell(torch.autograd.Function):

@@ -324,6 +324,30 @@ int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_pt
                        const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D, float* d_mol,
                        float* d_pro, void* stream);
 
+/* Training-mode block tails of the reference's DEFAULT configuration (src_1gp/model.py:30-31, run.py:35-37: RReLU activations,
+ * Dropout(0.2) in front of every conv) — the same launches as glam_gru_tail_* / glam_bias_res_act_* with two additions:
+ *   act = 4: torch.nn.RReLU in training mode, out = y > 0 ? y : a * y with a ~ U(rr_lower, rr_upper) per element;
+ *   out_drop (may be NULL): a second output Dropout(drop_p)(out) = out * mask / (1 - p), the next conv's input (layer.py:256).
+ * Random numbers: Philox4x32-10 keyed by rng_state[0] (seed), stream position rng_state[1] (offset), both int64 in DEVICE memory
+ * followed by one int64 of scratch (ticket): rng_state int64[3], zero the scratch once.  Every launch uses the offset it finds
+ * and the last block to finish stores offset + 1 — hipGraph replays continue the sequence with no host involvement.  rng_eff
+ * int64[2] receives the (seed, offset) pair the launch used; the backward entry points regenerate slopes and masks from it (no
+ * mask tensors).  d_out / d_out_drop: gradients of the two outputs (either may be NULL). glam_bias_res_act_rng_fwd accepts
+ * out = NULL for act = 0 (a plain Dropout). */
+int glam_gru_tail_rng_fwd(const float* gi, const float* gh, const float* h, const float* identity, int64_t N, int C, int act,
+                          float slope, float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff,
+                          float* h_new, float* out, float* out_drop, void* stream);
+int glam_gru_tail_rng_bwd(const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                          const float* d_out_drop, const float* d_hstate, int64_t N, int C, int act, float slope, float rr_lower,
+                          float rr_upper, float drop_p, const int64_t* rng_eff, float* d_gi, float* d_gh, float* d_h,
+                          float* d_identity, void* stream);
+int glam_bias_res_act_rng_fwd(const float* y, const float* bias, const float* identity, int64_t N, int C, int act, float slope,
+                              float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* out,
+                              float* out_drop, void* stream);
+int glam_bias_res_act_rng_bwd(const float* out, const float* d_out, const float* d_out_drop, int64_t N, int C, int act,
+                              float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff, float* d_y,
+                              void* stream);
+
 /* dot_and_global_pool5 (src_1gp/layer.py:270-283): for every pair i, [max, mean, median, min, std] of
  * S_i = mol[seg_i] @ pro[seg_i]^T — the reference's Python loop of matmul + max / mean / median / min / std per pair
  * (median = torch.median of the flattened scores: the LOWER median; std unbiased).  One block per pair, the score matrix is

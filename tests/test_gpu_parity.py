@@ -1483,3 +1483,133 @@ def test_message_passing_propagate_message_update_surface(device):
         assert_close(_grads(out, cot.to(device), [x])[0], _grads(ref, cot, [xo])[0], 2e-5, f"user subclass aggr={aggr} grad")
     with pytest.raises(TypeError):
         EdgeGated("add").propagate(ei, x=x0.to(device))              # message() needs `gate`
+
+
+# ---------------------------------------------------------------------------------------------
+# training mode of the reference's DEFAULT configuration (model.py:30-31: RReLU x 3, Dropout(0.2)): statistical parity
+# ---------------------------------------------------------------------------------------------
+def test_rrelu_and_dropout_device_stream_statistics(device):
+    """torch.nn.RReLU(1/8, 1/3) in training mode multiplies every non-positive input by a ~ U(lower, upper); Dropout(p) zeroes with
+    probability p and scales the rest by 1 / (1 - p).  The HIP ops draw from a device-side Philox stream: the numbers differ
+    from torch's generator, so parity is statistical (moments, range, uniformity, independence between launches), the
+    backward must use exactly the numbers of its forward, and a re-seeded stream must replay."""
+    n = 1 << 20
+    x = torch.full((n // 64, 64), -1.0, device=device, requires_grad=True)
+    ops.manual_seed(1234)
+    out = ops.rrelu(x)
+    a = (-out).detach().flatten().double().cpu()                      # the slopes
+    lo, hi = 1 / 8, 1 / 3
+    assert a.min() >= lo and a.max() <= hi
+    assert abs(a.mean().item() - (lo + hi) / 2) < 3e-4                # sigma of the mean = 0.06 / 1024 = 6e-5
+    assert abs(a.var().item() - (hi - lo) ** 2 / 12) < 3e-5
+    hist = torch.histc(a.float(), bins=16, min=lo, max=hi)
+    chi2 = ((hist - n / 16) ** 2 / (n / 16)).sum().item()
+    assert chi2 < 50, chi2                                            # 15 degrees of freedom: P(chi2 > 50) ~ 1e-5
+    assert abs(torch.corrcoef(torch.stack([a[:-1], a[1:]]))[0, 1].item()) < 5e-3       # neighbours are independent
+    (g,) = torch.autograd.grad(out.sum(), [x])
+    assert torch.equal(g.flatten().double().cpu(), a), "backward regenerates the slopes of its forward"
+    out2 = ops.rrelu(x)                                               # next launch: a different stream position
+    assert (out2 != out).float().mean().item() > 0.99
+    assert abs(torch.corrcoef(torch.stack([a, (-out2).detach().flatten().double().cpu()]))[0, 1].item()) < 5e-3
+    ops.manual_seed(1234)
+    assert torch.equal(ops.rrelu(x), out), "same seed, same stream position: same numbers"
+    xp = torch.rand(1000, 60, device=device) + 0.1                    # positive inputs pass through untouched
+    assert torch.equal(ops.rrelu(xp), xp)
+
+    y = torch.randn(n // 64, 64, device=device, requires_grad=True)
+    for p in (0.2, 0.5):
+        d = ops.dropout(y, p)
+        keep = (d != 0).double().mean().item()
+        assert abs(keep - (1 - p)) < 2e-3, (p, keep)
+        m = d.detach() != 0
+        assert_close(d.detach()[m], (y.detach() / (1 - p))[m], 1e-6, "kept values are scaled by 1 / (1 - p)")
+        (gd,) = torch.autograd.grad(d.sum(), [y])
+        assert torch.equal(gd != 0, m) and abs(gd[m].mean().item() - 1 / (1 - p)) < 1e-6, "backward uses the forward's mask"
+    # eval mode is deterministic and equals torch
+    mod = torch.nn.RReLU().eval()
+    blk = layer.LinearBlock(64, 64, act="RReLU").to(device).eval()
+    assert_close(blk(y.detach()), mod(torch.nn.functional.linear(y.detach(), blk.linear.weight, blk.linear.bias)), 1e-5, "eval RReLU")
+
+
+def test_default_config_training_step_uses_the_fused_tails(device, monkeypatch):
+    """Architecture() with NO overrides except the conv (model.py:24-33 defaults: RReLU x 3, graph_do = end_do = Dropout(0.2)) in
+    train(): the block tail draws the RReLU slopes and writes the next step's dropped input itself (one standalone dropout
+    launch for the first message step only, no torch RNG kernels); the analytic gradient matches a central difference of the
+    re-seeded forward; eval() still equals the oracle."""
+    torch.manual_seed(3)
+    b = synth_batch(48, seed=8).to(device)
+    net = model.Architecture(mol_block="_TripletMessage", e_dim=128).to(device)
+    calls = {"dropout": 0, "rrelu": 0}
+    real_drop, real_rrelu = ops.dropout, ops.rrelu
+    monkeypatch.setattr(ops, "dropout", lambda x, p: (calls.__setitem__("dropout", calls["dropout"] + 1), real_drop(x, p))[1])
+    monkeypatch.setattr(ops, "rrelu", lambda *a, **k: (calls.__setitem__("rrelu", calls["rrelu"] + 1), real_rrelu(*a, **k))[1])
+    net.train()
+    ops.manual_seed(99)
+    out = net(b)
+    # standalone launches: dropout before message step 1 and before lin_out1 (end_do); RReLU after mol_lin0 and mol_flat
+    assert calls == {"dropout": 2, "rrelu": 2}, calls
+    loss = out.square().mean()
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    ops.manual_seed(99)
+    assert torch.equal(net(b), out), "re-seeded stream replays the training-mode forward"
+    ops.manual_seed(98)
+    assert not torch.equal(net(b), out)
+    # directional derivative along a random parameter direction (same seed on both sides: the masks are those of `out`)
+    torch.manual_seed(4)
+    vs = [torch.randn_like(p) * p.abs().mean() for p in net.parameters()]
+    eps = 1e-2
+
+    def loss_at(sign):
+        with torch.no_grad():
+            for p, v in zip(net.parameters(), vs):
+                p.add_(v, alpha=sign * eps)
+            ops.manual_seed(99)
+            val = net(b).double().square().mean().item()
+            for p, v in zip(net.parameters(), vs):
+                p.sub_(v, alpha=sign * eps)
+        return val
+    fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)
+    an = sum((g.double() * v.double()).sum().item() for g, v in zip(grads, vs))
+    assert abs(fd - an) <= 3e-2 * max(abs(an), abs(fd)) + 1e-6, (fd, an)
+    # eval mode: deterministic, equals the oracle (RReLU -> its mean slope, dropout off)
+    net.eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = O.architecture(sd, b.to("cpu"), b.num_graphs, message_steps=3, mol_block="_TripletMessage", mol_readout="GlobalPool5")
+    assert_close(net(b), ref, 2e-5, "eval output")
+
+
+def test_default_config_graphed_training_follows_the_eager_stream(device):
+    """RReLU / Dropout numbers come from a stream position kept in device memory and advanced by the kernels themselves: replayed
+    hipGraphs continue the stream exactly like eager steps, so the graphed and the eager run of the default (training-mode)
+    configuration from one seed produce the same losses and parameters — and a batch sees fresh masks on every visit."""
+    import copy
+    from glam_amd.data import DataLoader, synth_molecule
+    from glam_amd.graphs import GraphedTrainStep
+    rng = np.random.default_rng(13)
+    mols = [synth_molecule(rng) for _ in range(16)]
+    torch.manual_seed(9)
+    net0 = model.Architecture(mol_block="_TripletMessage", e_dim=64).to(device).train()
+    loss_fn = lambda out, b: torch.nn.functional.mse_loss(out.view(-1), b.y.view(-1))
+    results = []
+    for graphed in (False, True):
+        net = copy.deepcopy(net0)
+        opt = torch.optim.Adam(net.parameters(), lr=2.0 ** -10, capturable=True)
+        loader = DataLoader(mols, batch_size=8, device=device)
+        stepper = GraphedTrainStep(net, opt, loss_fn)
+        ops.manual_seed(77)
+        losses = []
+        for _epoch in range(4):
+            for b in loader:
+                if graphed:
+                    losses.append(float(stepper(b)))
+                else:
+                    opt.zero_grad(set_to_none=True)
+                    loss = loss_fn(net(b), b)
+                    loss.backward()
+                    opt.step()
+                    losses.append(float(loss.detach()))
+        results.append((losses, [p.detach().clone() for p in net.parameters()]))
+    (l_e, p_e), (l_g, p_g) = results
+    assert np.allclose(l_e, l_g, rtol=1e-5, atol=1e-6), (l_e, l_g)
+    for a, r in zip(p_g, p_e):
+        assert_close(a, r, 1e-5, "parameter")

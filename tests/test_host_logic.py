@@ -121,8 +121,11 @@ def test_string_dispatch_surface():
         net = model.Architecture(mol_block="_TripletMessage", mol_readout=ro, e_dim=32)
         assert net.mol_flat.linear.in_features == (300 if ro == "GlobalPool5" else 120)
     assert layer.TripletMessage(60, 4).extra_repr() == "60, 60, heads=3"
-    with pytest.raises(NotImplementedError):
-        layer.TripletMessage(60, 4).message()
+    import inspect
+    for cls in (layer.TripletMessage, layer.TripletMessageLight):     # PyG lifts by these names (layer.py:42, :88)
+        assert list(inspect.signature(cls.message).parameters)[1:] == ["x_j", "x_i", "edge_index_i", "edge_attr", "size_i"]
+        assert list(inspect.signature(cls.update).parameters)[1:] == ["aggr_out"]
+        assert callable(cls.propagate)
 
 
 def test_collation_matches_pyg_semantics():
