@@ -18,14 +18,26 @@ ap.add_argument("--alpha", type=int, default=4, help="hid_dim_alpha (hidden widt
 ap.add_argument("--out-dim", type=int, default=1)
 ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"])
 ap.add_argument("--loss", default="mse", choices=["mse", "bcel"], help="bcel: masked BCEWithLogits over labels >= 0 (trainer.py:244-245)")
+ap.add_argument("--preset", default="relu", choices=["relu", "model_default", "run_default"],
+                help="relu: deterministic ReLU / no dropout (parity configuration); model_default: Architecture() keyword defaults "
+                     "(model.py:24-33: RReLU x 3, graph_do = end_do = Dropout(0.2), no graph norm) in train(); run_default: run.py:21-38 "
+                     "(_NNConv unless --block is given, _PairNorm, flat_do = end_do = Dropout(0.2), RReLU x 3) in train()")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
 ops.FEATURE_STORAGE = args.storage
-net = model.Architecture(hid_dim_alpha=args.alpha, out_dim=args.out_dim, mol_block=args.block, message_steps=3, mol_readout=args.readout, graph_norm=args.norm,
-                         graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
+if args.preset == "relu":
+    net = model.Architecture(hid_dim_alpha=args.alpha, out_dim=args.out_dim, mol_block=args.block, message_steps=3, mol_readout=args.readout, graph_norm=args.norm,
+                             graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
+elif args.preset == "model_default":
+    net = model.Architecture(hid_dim_alpha=args.alpha, out_dim=args.out_dim, mol_block=args.block, mol_readout=args.readout).to(dev).train()
+else:
+    blk = args.block if "--block" in sys.argv else "_NNConv"
+    net = model.Architecture(hid_dim_alpha=args.alpha, out_dim=args.out_dim, mol_block=blk, mol_readout=args.readout, graph_norm="_PairNorm",
+                             graph_do="_None()", flat_do="Dropout(0.2)", end_do="Dropout(0.2)", graph_res=1).to(dev).train()
+    args.block, args.norm = blk, "_PairNorm"
 b = synth_batch(args.batch, seed=0).to(dev)
 y = b.y.view(-1) if args.out_dim == 1 else torch.randn(args.batch, args.out_dim, device=dev).view(-1)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=os.environ.get("GLAM_FUSED_ADAM", "1") == "1")
@@ -60,6 +72,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"workload": f"Architecture({args.block}, hid_dim_alpha={args.alpha}, 3 steps, {args.readout}, e_dim=1024, norm={args.norm}, "
-                              f"out_dim={args.out_dim}, rows={args.storage}, loss={args.loss}) fwd+bwd+Adam, B={args.batch}",
+                              f"out_dim={args.out_dim}, rows={args.storage}, loss={args.loss}, preset={args.preset}) fwd+bwd+Adam, B={args.batch}",
                   "launch": "eager" if g is None else "hipGraph", "ms_per_step": dt / args.steps * 1e3,
                   "molecules_per_s": args.batch * args.steps / dt}))
