@@ -49,16 +49,17 @@ __global__ void __launch_bounds__(kBlock) k_gru_gates_bwd(const float* gi, const
 //   conv (layer.py:256) — both drawn from the device-side Philox stream of rng.h; the backward kernels regenerate the numbers.
 enum { kActNone = 0, kActRelu = 1, kActLeaky = 2, kActCelu = 3, kActRRelu = 4 };
 
-struct TailRng { long long* state; long long* eff; float lo, hi, p; float* out_drop; };               // forward
-struct TailRngB { const long long* eff; float lo, hi, p; const float* d_out_drop; };                   // backward
+struct TailRng { long long* state; long long* eff; float lo, hi, p; float* out_drop; int vec; };      // forward; vec: C % 4 == 0 and
+                                                                                                        // every pointer 16-byte aligned
+struct TailRngB { const long long* eff; float lo, hi, p; const float* d_out_drop; int vec; };          // backward
 
-__device__ __forceinline__ float rrelu_slope(const Philox& ph, size_t i, float lo, float hi) {
-    return fmaf(hi - lo, u01(philox_word(philox4(ph, i >> 2), (int)(i & 3))), lo);
-}
-// Dropout(p) multiplier of element i: 0 with probability p, else 1 / (1 - p)   (second Philox stream: bit 62 of the counter)
-__device__ __forceinline__ float drop_scale(const Philox& ph, size_t i, float p) {
-    return u01(philox_word(philox4(ph, (i >> 2) | (1ull << 62)), (int)(i & 3))) >= p ? 1.f / (1.f - p) : 0.f;
-}
+// One Philox word per element: the RReLU slope comes from its high 16 bits, the Dropout decision from its low 16 bits
+// (independent halves of one uniform word).  Word of element i = philox4(i / 4)[i % 4], whatever thread computes it: the
+// vectorised paths below draw one Philox block per FOUR consecutive elements, the scalar paths one per element.
+__device__ __forceinline__ float rrelu_slope_w(unsigned w, float lo, float hi) { return fmaf(hi - lo, (float)(w >> 16) * (1.f / 65536.f), lo); }
+__device__ __forceinline__ float drop_scale_w(unsigned w, float p) { return (float)(w & 0xffffu) * (1.f / 65536.f) >= p ? 1.f / (1.f - p) : 0.f; }
+__device__ __forceinline__ unsigned rng_word(const Philox& ph, size_t i) { return philox_word(philox4(ph, i >> 2), (int)(i & 3)); }
+__device__ __forceinline__ float4 ld4c(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 __device__ __forceinline__ float act_fwd(float y, int act, float slope) {
     switch (act) {
@@ -84,6 +85,34 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const 
     const size_t total = (size_t)N * C;
     Philox ph{};
     if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
+    if constexpr (RNG) {
+        if (rg.vec) {              // four consecutive channels of one row per thread: one Philox block, float4 traffic
+            for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < total / 4; q += (size_t)gridDim.x * kBlock) {
+                const size_t i = 4 * q, n = i / C, c = i % C, b = n * 3 * C + c;
+                const float4 ir = ld4c(gi + b), iz = ld4c(gi + b + C), in = ld4c(gi + b + 2 * C);
+                const float4 hr = ld4c(gh + b), hz = ld4c(gh + b + C), hnn = ld4c(gh + b + 2 * C);
+                const float4 hv = ld4c(h + i), idv = identity ? ld4c(identity + i) : f4zero();
+                const uint4 w4 = philox4(ph, q);
+                float4 hn4, o4, od4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = sigmoidf_(f4get(ir, j) + f4get(hr, j));
+                    const float z = sigmoidf_(f4get(iz, j) + f4get(hz, j));
+                    const float nn = tanhf(f4get(in, j) + r * f4get(hnn, j));
+                    const float hn = (1.f - z) * nn + z * f4get(hv, j);
+                    const float y = hn + f4get(idv, j);
+                    const unsigned w = philox_word(w4, j);
+                    const float o = act == kActRRelu ? (y > 0.f ? y : y * rrelu_slope_w(w, rg.lo, rg.hi)) : act_fwd(y, act, slope);
+                    (&hn4.x)[j] = hn; (&o4.x)[j] = o; (&od4.x)[j] = o * drop_scale_w(w, rg.p);
+                }
+                st4(h_new + i, hn4);
+                st4(out + i, o4);
+                if (rg.out_drop) st4(rg.out_drop + i, od4);
+            }
+            rng_end(rg.state, ph);
+            return;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
         const float r = sigmoidf_(gi[b] + gh[b]);
@@ -93,10 +122,12 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const 
         h_new[i] = hn;
         const float y = identity ? hn + identity[i] : hn;
         float o;
-        if (RNG && act == kActRRelu) o = y > 0.f ? y : y * rrelu_slope(ph, i, rg.lo, rg.hi);
+        unsigned w = 0u;
+        if constexpr (RNG) w = rng_word(ph, i);
+        if (RNG && act == kActRRelu) o = y > 0.f ? y : y * rrelu_slope_w(w, rg.lo, rg.hi);
         else o = act_fwd(y, act, slope);
         out[i] = o;
-        if constexpr (RNG) { if (rg.out_drop) rg.out_drop[i] = o * drop_scale(ph, i, rg.p); }
+        if constexpr (RNG) { if (rg.out_drop) rg.out_drop[i] = o * drop_scale_w(w, rg.p); }
     }
     if constexpr (RNG) rng_end(rg.state, ph);
 }
@@ -114,9 +145,10 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const 
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
         float dy;
         if constexpr (RNG) {
+            const unsigned w = rng_word(ph, i);
             float g = d_out ? d_out[i] : 0.f;
-            if (rg.d_out_drop) g = fmaf(rg.d_out_drop[i], drop_scale(ph, i, rg.p), g);
-            dy = g * (act == kActRRelu ? (out[i] > 0.f ? 1.f : rrelu_slope(ph, i, rg.lo, rg.hi)) : act_grad_from_out(out[i], act, slope));
+            if (rg.d_out_drop) g = fmaf(rg.d_out_drop[i], drop_scale_w(w, rg.p), g);
+            dy = g * (act == kActRRelu ? (out[i] > 0.f ? 1.f : rrelu_slope_w(w, rg.lo, rg.hi)) : act_grad_from_out(out[i], act, slope));
         } else {
             dy = d_out[i] * act_grad_from_out(out[i], act, slope);
         }
@@ -144,15 +176,40 @@ __global__ void __launch_bounds__(kBlock) k_bias_res_act_fwd(const float* y, con
     const size_t total = (size_t)N * C;
     Philox ph{};
     if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
+    if constexpr (RNG) {
+        if (rg.vec) {
+            for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < total / 4; q += (size_t)gridDim.x * kBlock) {
+                const size_t i = 4 * q;
+                float4 v = ld4c(y + i);
+                if (bias) { const float4 bv = ld4c(bias + i % C); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                if (identity) { const float4 iv = ld4c(identity + i); v.x += iv.x; v.y += iv.y; v.z += iv.z; v.w += iv.w; }
+                const uint4 w4 = philox4(ph, q);
+                float4 o4, od4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned w = philox_word(w4, j);
+                    const float vj = f4get(v, j);
+                    const float o = act == kActRRelu ? (vj > 0.f ? vj : vj * rrelu_slope_w(w, rg.lo, rg.hi)) : act_fwd(vj, act, slope);
+                    (&o4.x)[j] = o; (&od4.x)[j] = o * drop_scale_w(w, rg.p);
+                }
+                if (out) st4(out + i, o4);
+                if (rg.out_drop) st4(rg.out_drop + i, od4);
+            }
+            rng_end(rg.state, ph);
+            return;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         float v = y[i];
         if (bias) v += bias[i % C];
         if (identity) v += identity[i];
         float o;
-        if (RNG && act == kActRRelu) o = v > 0.f ? v : v * rrelu_slope(ph, i, rg.lo, rg.hi);
+        unsigned w = 0u;
+        if constexpr (RNG) w = rng_word(ph, i);
+        if (RNG && act == kActRRelu) o = v > 0.f ? v : v * rrelu_slope_w(w, rg.lo, rg.hi);
         else o = act_fwd(v, act, slope);
         if (out) out[i] = o;
-        if constexpr (RNG) { if (rg.out_drop) rg.out_drop[i] = o * drop_scale(ph, i, rg.p); }
+        if constexpr (RNG) { if (rg.out_drop) rg.out_drop[i] = o * drop_scale_w(w, rg.p); }
     }
     if constexpr (RNG) rng_end(rg.state, ph);
 }
@@ -162,13 +219,33 @@ __global__ void __launch_bounds__(kBlock) k_bias_res_act_bwd(const float* out, c
                                                             float* d_y, TailRngB rg) {
     const size_t total = (size_t)N * C;
     Philox ph{};
-    if constexpr (RNG) ph = philox_init(rg.eff);
+    if constexpr (RNG) {
+        ph = philox_init(rg.eff);
+        if (rg.vec) {
+            for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < total / 4; q += (size_t)gridDim.x * kBlock) {
+                const size_t i = 4 * q;
+                const float4 g0 = d_out ? ld4c(d_out + i) : f4zero(), gd = rg.d_out_drop ? ld4c(rg.d_out_drop + i) : f4zero();
+                const float4 o4 = out ? ld4c(out + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const uint4 w4 = philox4(ph, q);
+                float4 r4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned w = philox_word(w4, j);
+                    const float g = fmaf(f4get(gd, j), drop_scale_w(w, rg.p), f4get(g0, j)), o = f4get(o4, j);
+                    (&r4.x)[j] = g * (act == kActRRelu ? (o > 0.f ? 1.f : rrelu_slope_w(w, rg.lo, rg.hi)) : act_grad_from_out(o, act, slope));
+                }
+                st4(d_y + i, r4);
+            }
+            return;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         if constexpr (RNG) {
+            const unsigned w = rng_word(ph, i);
             float g = d_out ? d_out[i] : 0.f;
-            if (rg.d_out_drop) g = fmaf(rg.d_out_drop[i], drop_scale(ph, i, rg.p), g);
+            if (rg.d_out_drop) g = fmaf(rg.d_out_drop[i], drop_scale_w(w, rg.p), g);
             const float o = out ? out[i] : 1.f;
-            d_y[i] = g * (act == kActRRelu ? (o > 0.f ? 1.f : rrelu_slope(ph, i, rg.lo, rg.hi)) : act_grad_from_out(o, act, slope));
+            d_y[i] = g * (act == kActRRelu ? (o > 0.f ? 1.f : rrelu_slope_w(w, rg.lo, rg.hi)) : act_grad_from_out(o, act, slope));
         } else {
             d_y[i] = d_out[i] * act_grad_from_out(out[i], act, slope);
         }
@@ -303,6 +380,10 @@ extern "C" int glam_bias_res_act_bwd(const float* out, const float* d_out, int64
 }
 
 // ---- training-mode variants: RReLU / Dropout from the device-side Philox stream (rng.h) ----
+// RNG launches take one same-address device-scope atomic per block (the stream-position ticket, ~10 ns each at the coherent
+// point): 512 grid-striding blocks instead of 2048 keep that tail at a few microseconds.
+constexpr int kRngBlocks = 512;
+
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p) {
     if (act < kActNone || act > kActRRelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);
     if (act == kActRRelu && !(lo > 0.f && lo <= hi)) return fail(GLAM_E_INVALID, "%s: RReLU needs 0 < lower <= upper (got %g, %g)", fn, lo, hi);
@@ -317,8 +398,10 @@ extern "C" int glam_gru_tail_rng_fwd(const float* gi, const float* gh, const flo
     if (int rc = rng_args_ok("glam_gru_tail_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(gi && gh && h && h_new && out && rng_state && rng_eff, "glam_gru_tail_rng_fwd: null pointer");
-    TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop};
-    hipLaunchKernelGGL(k_gru_tail_fwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, identity,
+    const int vec = (C & 3) == 0 && aligned16(gi) && aligned16(gh) && aligned16(h) && aligned16(identity) && aligned16(h_new) &&
+                    aligned16(out) && aligned16(out_drop);
+    TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, vec};
+    hipLaunchKernelGGL(k_gru_tail_fwd<true>, dim3(grid_for(N * C, kBlock, kRngBlocks)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, identity,
                        (int)N, C, act, slope, h_new, out, rg);
     GLAM_LAUNCH_CHECK("glam_gru_tail_rng_fwd");
     return GLAM_OK;
@@ -332,7 +415,7 @@ extern "C" int glam_gru_tail_rng_bwd(const float* gi, const float* gh, const flo
     if (int rc = rng_args_ok("glam_gru_tail_rng_bwd", act, rr_lower, rr_upper, drop_p)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(gi && gh && h && out && (d_out || d_out_drop) && d_gi && d_gh && d_h && rng_eff, "glam_gru_tail_rng_bwd: null pointer");
-    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop};
+    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, 0};
     hipLaunchKernelGGL(k_gru_tail_bwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
                        d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, rg);
     GLAM_LAUNCH_CHECK("glam_gru_tail_rng_bwd");
@@ -346,8 +429,9 @@ extern "C" int glam_bias_res_act_rng_fwd(const float* y, const float* bias, cons
     if (int rc = rng_args_ok("glam_bias_res_act_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(y && (out || (out_drop && act == kActNone)) && rng_state && rng_eff, "glam_bias_res_act_rng_fwd: null pointer");
-    TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop};
-    hipLaunchKernelGGL(k_bias_res_act_fwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, bias, identity,
+    const int vec = (C & 3) == 0 && aligned16(y) && aligned16(bias) && aligned16(identity) && aligned16(out) && aligned16(out_drop);
+    TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, vec};
+    hipLaunchKernelGGL(k_bias_res_act_fwd<true>, dim3(grid_for(N * C, kBlock, kRngBlocks)), dim3(kBlock), 0, (hipStream_t)stream, y, bias, identity,
                        (int)N, C, act, slope, out, rg);
     GLAM_LAUNCH_CHECK("glam_bias_res_act_rng_fwd");
     return GLAM_OK;
@@ -360,7 +444,8 @@ extern "C" int glam_bias_res_act_rng_bwd(const float* out, const float* d_out, c
     if (int rc = rng_args_ok("glam_bias_res_act_rng_bwd", act, rr_lower, rr_upper, drop_p)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE((out || act == kActNone) && (d_out || d_out_drop) && d_y && rng_eff, "glam_bias_res_act_rng_bwd: null pointer");
-    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop};
+    const int vec = (C & 3) == 0 && aligned16(out) && aligned16(d_out) && aligned16(d_out_drop) && aligned16(d_y);
+    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, vec};
     hipLaunchKernelGGL(k_bias_res_act_bwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, d_out, (int)N,
                        C, act, slope, d_y, rg);
     GLAM_LAUNCH_CHECK("glam_bias_res_act_rng_bwd");
