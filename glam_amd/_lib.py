@@ -50,6 +50,9 @@ SIGNATURES = {
     "glam_gru_tail_rng_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 6),
     "glam_bias_res_act_rng_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "glam_bias_res_act_rng_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
+    "glam_ell_build": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "glam_triplet_fwd_ell_supported": (_i32, [_i32, _i32, _i32]),
+    "glam_triplet_fwd_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_pair_pool5_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),
     "glam_ts_gemm_image_bytes": (_sz, [_i32, _i32]),

@@ -13,6 +13,8 @@
 // All node-feature widths are padded to Cp (multiple of 4) so every row is 16-byte aligned.
 #include "dense.h"
 
+#include <stdlib.h>
+
 namespace glam {
 
 // layout of the staged-parameter buffer (floats; every offset is a multiple of 4)
@@ -470,6 +472,14 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
     return GLAM_OK;
 }
 
+// The fused-GEMM variants of the aggregate kernels (forward + update, B2 + d_x) keep a 48 KB weight image per block in LDS: two
+// 4-wave blocks per CU.  That wins while the launch is latency bound (B = 1024: 16.6 us against 9.7 + 11 + a launch boundary) and
+// loses once the batch is large enough for the aggregate to need its full occupancy (B = 16 384: 249 us fused against 134 + 62).
+static int64_t fuse_max_nodes() {
+    static const int64_t v = [] { const char* e = getenv("GLAM_FUSE_MAX_NODES"); return e ? atoll(e) : (int64_t)1 << 40; }();
+    return v;
+}
+
 static int layer_fwd_impl(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
                           const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T, int64_t N, int64_t E,
                           int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out,
@@ -493,7 +503,7 @@ static int layer_fwd_impl(const float* x, const float* edge_attr, const float* s
     TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
     g1.out1_bf16 = xw_bf16;
     if (int rc = launch_ts_gemm(g1, s)) return rc;
-    if (triplet_fwd_can_fuse_update(H, Cp, Dp))   // aggregate + update GEMM in one launch
+    if (triplet_fwd_can_fuse_update(H, Cp, Dp) && (xw_bf16 || N <= fuse_max_nodes()))   // aggregate + update GEMM in one launch
         return triplet_fwd_fused_update(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp,
                                         Dp, slope, aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s, xw_bf16);
     if (int rc = glam_triplet_fwd(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp, Dp, 1,
@@ -563,39 +573,66 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     ReduceArgs ra{};
     ra.njobs = 3;
 
+    // Schedule (parameter-gradient path).  The main stream walks the dependent chain d_aggr -> B1 -> B2 (+ d_x) -> d_Wcat product ->
+    // its share of the parameter gradients; everything that only needs forward activations or finished partials runs beside it on
+    // the library's side stream: the d_W_scale | d_bias product ([aggr | 1]^T d_out) from the very start, and — once B1's block
+    // partials exist — the d_weight_scale / d_bias / d_weight_edge reductions.  Each of these launches is latency bound on its own
+    // (~3 us of fixed dispatch cost inside a 7-15 us kernel), so overlapping them shortens the step without touching a kernel.
+    SideStream* ss = po ? side_stream() : nullptr;
+    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, 0, (int)N, 0, wg1, 0, 0};
+    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0, 0};
+    if (ss) {
+        (void)hipEventRecord(ss->fork, s);
+        (void)hipStreamWaitEvent(ss->s, ss->fork, 0);
+        if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, ss->s, &ra.job[0])) return rc;
+    }
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
     TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
     if (int rc = launch_ts_gemm(g1, s)) return rc;
     const float* tpart = nullptr;
     int tnblk = 0;
-    const bool fuse_dx = triplet_bwd_can_fuse_dx(H, Cp, Dp);   // d_x = [d_xw | d_a] @ Wcat^T inside B2 (one launch less)
+    const bool fuse_dx = triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes();   // d_x = [d_xw | d_a] @ Wcat^T inside B2
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
-                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16))
+                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16, ss ? ss->mid : nullptr))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
-    // both weight-gradient products in ONE launch (each is latency bound on its own):
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
-    WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, 0, (int)N, 0, wg1, 0, 0};
-    WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0, 0};
-    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8,
-                                        &ra.job[2], s))
+    if (ss) {
+        if (int rc = launch_wgrad_partials(w2, dstaged + G.d_wcat, 1, HC + 8, s, &ra.job[2])) return rc;
+    } else if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8,
+                                               &ra.job[2], s)) {   // serial schedule: both products in ONE launch
         return rc;
+    }
     // d_x = [d_xw | d_a] @ Wcat^T
     if (!fuse_dx) {
         TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
         if (int rc = launch_ts_gemm(g2, s)) return rc;
     }
-    if (po) {   // parameter gradients straight from the partial sets: reductions + chain rule in one launch
+    if (po) {   // parameter gradients straight from the partial sets: reductions + chain rule, no intermediate dstaged
         const int C = po->C, De = po->De;
         ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
                          (H * C * C + C + kBlock - 1) / kBlock, C, H};
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
+        if (ss) {
+            // side: roles A (d_weight_scale, d_bias <- product 1) and D (d_weight_edge <- B1 partials + d_M), after B1
+            ParamGradArgs pa = pg;
+            pa.blocksB = pa.blocksC = 0;
+            (void)hipStreamWaitEvent(ss->s, ss->mid, 0);
+            hipLaunchKernelGGL(k_param_grads, dim3(pa.blocksA + blocksD), dim3(kBlock), 0, ss->s, pa);
+            (void)hipEventRecord(ss->join, ss->s);
+            // main: roles B (d_weight_node) and C (d_weight_triplet_att) <- product 2 (+ d_M from the B1 partials)
+            ParamGradArgs pb = pg;
+            pb.blocksA = 0;
+            hipLaunchKernelGGL(k_param_grads, dim3(pb.blocksB + pb.blocksC), dim3(kBlock), 0, s, pb);
+            (void)hipStreamWaitEvent(s, ss->join, 0);
+        } else {
+            hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
+        }
         GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
         return GLAM_OK;
     }

@@ -2,8 +2,8 @@
 // (src_1gp/model.py:30-31: RReLU activations and Dropout(0.2)): Philox4x32-10 (Salmon et al., SC'11 — the public algorithm
 // torch's CUDA generator also uses), keyed by a 64-bit seed, counter = (element-quad index, per-launch offset).
 //
-// hipGraph-safe stream position: the (seed, offset) pair lives in DEVICE memory (`state`: int64 seed, int64 offset, then a
-// 32-bit ticket).  Every RNG-consuming launch reads the pair first, uses `offset` as its private stream id, and the LAST block
+// hipGraph-safe stream position: the (seed, offset) pair lives in DEVICE memory (`state` int64[32]: [0] seed, [1] offset,
+// [16] a 32-bit ticket on its own cache line).  Every RNG-consuming launch reads the pair first, uses `offset` as its private stream id, and the LAST block
 // of the launch to finish (ticket counter) stores offset + 1 for the next launch — no host round trip, no extra launch, and a
 // replayed graph continues the sequence exactly where the previous replay (or eager step) left it.  Block 0 also records the pair
 // it used in `eff` (int64[2]) so that the backward kernel regenerates the very same numbers instead of reading saved masks.
@@ -40,23 +40,28 @@ __device__ __forceinline__ uint4 philox4(const Philox& p, unsigned long long q) 
 __device__ __forceinline__ float u01(unsigned w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ unsigned philox_word(const uint4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-// forward prologue: the pair this launch uses; block 0 records it for the backward pass
-__device__ __forceinline__ Philox rng_begin(const long long* state, long long* eff) {
-    const long long seed = state[0], off = state[1];
+// forward prologue: the pair this launch uses; block 0 records it for the backward pass.  Every access to `state` is an
+// agent-scope atomic (served at the device-coherent point, not from a per-XCD L2 line): the ticket atomics of the same
+// launch sequence hit memory behind the L2s, and a plain load could return an offset cached before the previous launch's
+// update — some blocks of one launch would then draw from another stream position than block 0 recorded (seen as a rare
+// forward / backward mask mismatch).  The ticket lives on its own 128-byte line (state[16]).
+__device__ __forceinline__ Philox rng_begin(long long* state, long long* eff) {
+    const long long seed = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long off = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (eff && blockIdx.x == 0 && threadIdx.x == 0) { eff[0] = seed; eff[1] = off; }
     const long long pair[2] = {seed, off};
     return philox_init(pair);
 }
 // forward epilogue: the last block to arrive advances the stream position.  A block takes its ticket after it has CONSUMED the
-// values it loaded from `state` (they fed its Philox key), so every read of the pair precedes the one store; the store and
-// the ticket reset become visible to the next launch at the kernel boundary.  No fences: a release fence per block (an L2
-// write-back each) made the 2048-block tail kernels 5x slower than their arithmetic.
+// values it loaded from `state` (they fed its Philox key), so every read of the pair precedes the one store.  No fences: a
+// release fence per block (an L2 write-back each) made the 2048-block tail kernels 5x slower than their arithmetic.
 __device__ __forceinline__ void rng_end(long long* state, const Philox& p) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned* ticket = reinterpret_cast<unsigned*>(state + 2);
+        unsigned* ticket = reinterpret_cast<unsigned*>(state + 16);
         if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            state[1] = (long long)((((unsigned long long)p.o1 << 32) | p.o0) + 1ull);
+            __hip_atomic_store(state + 1, (long long)((((unsigned long long)p.o1 << 32) | p.o0) + 1ull), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

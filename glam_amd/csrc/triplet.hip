@@ -123,7 +123,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x, int xw_bf16) {
+                     const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
@@ -152,6 +152,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
+    if (after_b1) (void)hipEventRecord(after_b1, s);      // the B1 block partials are complete: a side stream may reduce them
     if (reduce_now) {
         hipLaunchKernelGGL(k_reduce_partials, dim3((P + 15) / 16), dim3(kBlock), 0, s, partial, nblk, P, WSZ, d_w_edge, d_M);
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(reduce)");

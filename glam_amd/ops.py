@@ -183,7 +183,22 @@ def pad_cols(x, Cp):
                 x.stride() == (Cp, 1) and base.data_ptr() == x.data_ptr() and base.dtype == x.dtype:
             return base
     C = x.size(1)
+    if not x.requires_grad and x.grad_fn is None:
+        # a DATA tensor (e.g. the atom features x[N, 15] of a cached loader batch): padded once per tensor, not once per pass
+        key = id(x)
+        hit = _PAD_DATA.get(key)
+        if hit is not None and hit[0]() is x and hit[1] == x._version and hit[2].size(1) == Cp:
+            return hit[2]
+        padded = torch.nn.functional.pad(x, (0, Cp - C))
+        try:
+            _PAD_DATA[key] = (weakref.ref(x, lambda _r, k=key: _PAD_DATA.pop(k, None)), x._version, padded)
+        except TypeError:
+            pass
+        return padded
     return _scoped(_SCOPE.fwd if _SCOPE else None, ("pad-cols", id(x), Cp), x, lambda: torch.nn.functional.pad(x, (0, Cp - C)))
+
+
+_PAD_DATA: dict = {}
 
 
 _GI_CACHE: dict = {}
@@ -611,7 +626,7 @@ _RNG_STATE: dict = {}
 
 
 def rng_state(device):
-    """``int64[3]`` on ``device``: Philox seed, stream offset (advanced by every RNG-consuming launch, on the device), scratch.
+    """``int64[32]`` on ``device``: [0] Philox seed, [1] stream offset (advanced by every RNG-consuming launch, on the device), [16] ticket.
     Created on first use from ``torch.initial_seed()`` — so the reference's ``seed_torch`` (``utils.py:22-28``) also fixes this
     stream — and OUTSIDE any hipGraph capture (``GraphedTrainStep`` runs the first visit of a batch eagerly)."""
     key = device.index if device.index is not None else torch.cuda.current_device()
@@ -620,7 +635,7 @@ def rng_state(device):
         if torch.cuda.is_current_stream_capturing():
             raise GlamHipError("the RNG state must exist before a hipGraph capture: run one eager training-mode forward first "
                                "(or call glam_amd.ops.manual_seed)")
-        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & (2 ** 63 - 1), 0, 0], dtype=torch.int64, device=device)
+        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & (2 ** 63 - 1)] + [0] * 31, dtype=torch.int64, device=device)
     return st
 
 
@@ -628,7 +643,7 @@ def manual_seed(seed, device=None):
     """Restart the device-side stream of RReLU / Dropout numbers at ``(seed, offset 0)``."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     st = rng_state(device)
-    st.copy_(torch.tensor([int(seed) & (2 ** 63 - 1), 0, 0], dtype=torch.int64))
+    st.copy_(torch.tensor([int(seed) & (2 ** 63 - 1)] + [0] * 31, dtype=torch.int64))
     return st
 
 
@@ -666,7 +681,10 @@ def linear_supported(K, M):
 
 
 class _Linear(torch.autograd.Function):
-    """y[N,M] = x[N,K] @ w[M,K]^T + b on k_ts_gemm; d_x on k_ts_gemm, d_w / d_b on k_wgrad (K, M multiples of 4)."""
+    """y[N,M] = x[N,K] @ w[M,K]^T + b on k_ts_gemm; d_x on k_ts_gemm, d_w / d_b on k_wgrad (K, M multiples of 4).
+    ``w`` may have FEWER columns than ``x`` (``w[M, Kw]``, ``Kw <= K``): ``x`` is then a zero-padded data matrix (atom features
+    15 -> 16) and the weight image is built straight from the unpadded parameter (the image zero-fills k >= Kw); only for an
+    ``x`` that needs no gradient."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -674,13 +692,15 @@ class _Linear(torch.autograd.Function):
         x, w = f32c(x, "x"), f32c(w, "weight")
         b = None if b is None else f32c(b, "bias")
         N, K = x.shape
-        M = w.size(0)
+        M, Kw = w.shape
+        if Kw > K or (Kw < K and ctx.needs_input_grad[0]):
+            raise GlamHipError("linear: weight wider than the input / narrow weight with a differentiable input")
         lib, dev = _lib.load(), x.device
         scope = _SCOPE
 
         def build():
             img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, dtype=torch.float32, device=dev)
-            check(lib.glam_ts_gemm_make_image(ptr(w), K, 1, K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+            check(lib.glam_ts_gemm_make_image(ptr(w), Kw, 1, Kw, M, ptr(img), stream()), "glam_ts_gemm_make_image")
             return img
 
         img = _scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
@@ -718,7 +738,7 @@ class _Linear(torch.autograd.Function):
         else:         # out[m, k] = sum_n dy[n,m] [x|1][n,k]
             check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(),
                                       stream()), "glam_wgrad_gemm")
-        dw = dwb[:M, :K]
+        dw = dwb[:M, :w.size(1)]
         db = dwb[:M, K] if ctx.has_bias else None
         return dx, dw, db
 
@@ -839,6 +859,8 @@ def linear(x, weight, bias=None):
     Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
     if Kp != K:
         x = pad_cols(x, Kp)
+    if Kp != K and Mp == M and not (x.requires_grad and torch.is_grad_enabled()):
+        return _Linear.apply(x, weight, bias)    # data input (atom features): the image is built from the unpadded weight
     if Kp != K or Mp != M:
         # padded once per model pass (the block's linears are applied message_steps times), like every derived weight
         w0, b0 = weight, bias
@@ -1029,6 +1051,7 @@ class _GruBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None):
+        ctx.set_materialize_grads(False)     # unused outputs (the last step's h', its dropped twin) arrive as None, not as zero fills
         require_device(x, h, w_ih, w_hh, b_ih, b_hh)
         x, h = f32c(x, "x"), f32c(h, "h")
         w_ih, w_hh, b_ih, b_hh = f32c(w_ih, "weight_ih"), f32c(w_hh, "weight_hh"), f32c(b_ih, "bias_ih"), f32c(b_hh, "bias_hh")
@@ -1258,6 +1281,7 @@ class _BiasResAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, bias, identity, act, slope, rng=None, want_out=True):
+        ctx.set_materialize_grads(False)
         require_device(y, bias, identity)
         y = f32c(y, "y")
         bias = None if bias is None else f32c(bias, "bias")

@@ -329,7 +329,7 @@ int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_pt
  *   act = 4: torch.nn.RReLU in training mode, out = y > 0 ? y : a * y with a ~ U(rr_lower, rr_upper) per element;
  *   out_drop (may be NULL): a second output Dropout(drop_p)(out) = out * mask / (1 - p), the next conv's input (layer.py:256).
  * Random numbers: Philox4x32-10 keyed by rng_state[0] (seed), stream position rng_state[1] (offset), both int64 in DEVICE memory
- * followed by one int64 of scratch (ticket): rng_state int64[3], zero the scratch once.  Every launch uses the offset it finds
+ * and a ticket word at index 16 (its own cache line): rng_state int64[32], zero everything but the seed once.  Every launch uses the offset it finds
  * and the last block to finish stores offset + 1 — hipGraph replays continue the sequence with no host involvement.  rng_eff
  * int64[2] receives the (seed, offset) pair the launch used; the backward entry points regenerate slopes and masks from it (no
  * mask tensors).  d_out / d_out_drop: gradients of the two outputs (either may be NULL). glam_bias_res_act_rng_fwd accepts
@@ -347,6 +347,23 @@ int glam_bias_res_act_rng_fwd(const float* y, const float* bias, const float* id
 int glam_bias_res_act_rng_bwd(const float* out, const float* d_out, const float* d_out_drop, int64_t N, int C, int act,
                               float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff, float* d_y,
                               void* stream);
+
+/* Software-pipelined forward aggregate for graphs whose in-degree never exceeds 4 (molecules): the arithmetic of
+ * glam_triplet_fwd (multi-head form, emul = 1; src_1gp/layer.py:42-55 through PyG propagate / softmax / scatter-add), bit for
+ * bit, with the neighbour rows staged global -> LDS by LDS-DMA and every wave prefetching the rows of its next pass and the
+ * index record of the one after while it computes the current one (csrc/triplet_dma.hip).
+ * glam_ell_build: index records from the by-target CSR — ell_src / ell_eid int32[N, 4] (source node and original edge id of
+ * the node's incoming edges in CSR order, -1 = empty slot); *overflow_flag (int32, zero it first) is set when some node has
+ * more than 4 incoming edges: such an edge list must use glam_triplet_fwd.  Built once per edge list, like the CSR.
+ * glam_triplet_fwd_ell: same tensors as glam_triplet_fwd; Cp <= 64, H <= 4, De in {4, 8}; edge_onehot = 1 asserts that every
+ * edge_attr row is one-hot (e_ij is then read as one W_edge row, bit-identical); grid_blocks <= 0 picks the default persistent
+ * grid (two 4-wave blocks per CU). */
+int glam_ell_build(const int32_t* rowptr, const int32_t* nbr, const int32_t* eid, int64_t N, int32_t* ell_src,
+                   int32_t* ell_eid, int32_t* overflow_flag, void* stream);
+int glam_triplet_fwd_ell_supported(int H, int Cp, int De);
+int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
+                         const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De,
+                         float slope, int edge_onehot, float* aggr, float* stats, int grid_blocks, void* stream);
 
 /* dot_and_global_pool5 (src_1gp/layer.py:270-283): for every pair i, [max, mean, median, min, std] of
  * S_i = mol[seg_i] @ pro[seg_i]^T — the reference's Python loop of matmul + max / mean / median / min / std per pair
