@@ -19,9 +19,20 @@
 // node by node without prefetch.  Results are bit-identical to k_triplet_fwd (same operation order per lane).
 #include "triplet_kernels.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace glam {
 
-constexpr int kEC = 12;                  // edge rows per pass buffer
+#ifdef GLAM_DMA_PROF
+__device__ long long g_dma_prof[64 * 8];
+#define DSTAMP(k) do { const long long now__ = clock64(); pacc[k] += now__ - plast; plast = now__; } while (0)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
+
+constexpr int kEC = 11;                  // edge rows per pass buffer (11 x 45 chunks fit the 8 x 64-lane staging pieces of the default width)
+constexpr int kMetaSlots = 16;           // a_j / edge_attr slots of the one-piece side table (>= kEC, all written every pass)
 
 struct FwdDmaArgs {
     const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
@@ -30,19 +41,21 @@ struct FwdDmaArgs {
     float* aggr; float* stats;
 };
 
-struct PassMeta { int deg; int off; int tot; };
+struct PassMeta { int deg; int off; int tot; int dmax; };   // per lane: its node's degree, packed slot offset; wave-wide edge
+                                                            // count and largest degree (wave-uniform)
 
-// One LDS-DMA piece: 64 lanes x 16 bytes, lane l lands at lds_base + 16 l (lds_base wave-uniform, in M0).  Written as inline
-// assembly on purpose: through the builtin the compiler knows the instruction writes LDS and — unable to prove that the pass
-// buffer being READ is not the one being staged — drains vmcnt(0) in front of the next ds_read, which serialises the gather with
-// the arithmetic it is meant to hide behind (198 vs 148 us for the register-staged kernel at B = 16 384).  The pipeline below
-// orders every read behind its own counted s_waitcnt instead.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory", "m0");
+// One LDS-DMA piece: 64 lanes x 16 bytes, lane l lands at lds_base + 16 l (lds_base wave-uniform, in M0); source = 64-bit
+// wave-uniform base (SGPR pair) + per-lane unsigned 32-bit byte offset.  Written as inline assembly on purpose: through the
+// builtin the compiler knows the instruction writes LDS and — unable to prove that the pass buffer being READ is not the one
+// being staged — drains vmcnt(0) in front of the next ds_read, which serialises the gather with the arithmetic it is meant to
+// hide behind (198 vs 148 us for the register-staged kernel at B = 16 384).  The pipeline below orders every read behind its
+// own counted s_waitcnt instead.
+__device__ __forceinline__ void dma16(const void* gbase, unsigned byte_off, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(gbase), "s"(lds_base) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)p);
-}     // per lane: its node's degree, packed slot offset; wave-wide edge count
+}
 
 // QQ: compile-time chunks per head (Cp / 4) — the staging loop divides by the row length; 0 = run-time.  ONEHOT: every edge_attr
 // row is one-hot (bond types, src_1gp/dataset.py:82): e_ij is then exactly one W_edge row (sum_k ea_k W_k with ea in {0, 1}
@@ -52,14 +65,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane >> 4, q = lane & 15;
     const int Cp = QQ ? 4 * QQ : a.Cp, Q = QQ ? QQ : (Cp >> 2), HC = H * Cp, HQ = H * Q;
-    const int RC = HQ + 1 + DE / 4;                       // 16-byte chunks per staged edge row
     const int WSZ = DE * HC;
+    constexpr int NI = QQ ? (kEC * H * QQ + 63) / 64 : (kEC * H * 16 + 63) / 64;   // staging pieces of the row region
+    // per-wave LDS: 2 x [rows: NI x 64 chunks | meta: a_j x 16, edge_attr x 16 x DE/4, a_i x 4 (one 64-lane piece)] | src table
+    constexpr int kRowF = NI * 64 * 4, kMetaF = 64 * 4, kBufF = kRowF + kMetaF;
     float* s_w = smem;
-    const int buf_floats = kEC * RC * 4;
-    float* wbase = smem + WSZ + wave * (2 * buf_floats + 2 * 16 + kEC * 2);
-    float* s_buf0 = wbase;
-    float* s_node0 = wbase + 2 * buf_floats;              // [2][4 nodes][4 floats] a_i rows
-    int* s_idx = reinterpret_cast<int*>(s_node0 + 2 * 16);   // [kEC][2] (src, eid) of the pass being staged
+    float* wbase = smem + WSZ + wave * (2 * kBufF + kMetaSlots);
+    int* s_src = reinterpret_cast<int*>(wbase + 2 * kBufF);             // [16] source node of every packed slot of the pass being staged
 
     for (int i = tid; i < WSZ / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
     __syncthreads();                                      // the only block-wide barrier: waves are independent from here on
@@ -73,6 +85,20 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
     const int gw = blockIdx.x * (kBlock / 64) + wave, GW = gridDim.x * (kBlock / 64);
     const bool qok = q < Q;
     const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;
+    // pass-independent part of the staging addresses: piece i, this lane -> (packed slot, byte offset inside the xw row)
+    int st_slot[NI];
+    unsigned st_coff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g = i * 64 + lane;
+        st_slot[i] = g / HQ;
+        st_coff[i] = (unsigned)(g - st_slot[i] * HQ) * 16u;
+    }
+    // the side-table piece: lanes 0..15 a_j of slot l, 16..16+16*DE/4-1 edge_attr chunks, then 4 lanes a_i of the pass's nodes
+    constexpr int kEaLanes = kMetaSlots * (DE / 4);
+    const int mt_kind = lane < kMetaSlots ? 0 : lane < kMetaSlots + kEaLanes ? 1 : lane < kMetaSlots + kEaLanes + 4 ? 2 : 3;
+    const int mt_slot = mt_kind == 0 ? lane : mt_kind == 1 ? (lane - kMetaSlots) / (DE / 4) : 0;
+    const unsigned mt_sub = mt_kind == 1 ? (unsigned)((lane - kMetaSlots) % (DE / 4)) * 16u : 0u;
 
     // ---- pipeline stages ---------------------------------------------------------------------------------------------
     // lane q < 4 of a group holds slot q of its node's record: (source node, original edge id), -1 = empty
@@ -89,40 +115,34 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
         PassMeta pm;
         pm.deg = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
         pm.off = j == 0 ? 0 : j == 1 ? d0 : j == 2 ? d0 + d1 : d0 + d1 + d2;
-        pm.tot = d0 + d1 + d2 + d3;
-        if (pm.tot > kEC) return pm;                      // overflow: the caller stages it node by node
-        if (q < pm.deg) {                                 // occupied slots are the first `deg` ones: publish the group's edges
-            s_idx[2 * (pm.off + q)] = rs;
-            s_idx[2 * (pm.off + q) + 1] = re;
-        }
+        pm.tot = __builtin_amdgcn_readfirstlane(d0 + d1 + d2 + d3);
+        pm.dmax = __builtin_amdgcn_readfirstlane(max(max(d0, d1), max(d2, d3)));   // provably scalar: the slot loops branch on it
+        if (pm.tot > kEC || pm.tot == 0) return pm;       // overflow: the caller stages it node by node; nothing to stage
+        // the side-table piece needs (src, eid) of slot `mt_slot`: fetch them from the owning lanes while the table is written
+        if (q < pm.deg) s_src[pm.off + q] = rs;           // occupied slots are the first `deg` ones of a group
+        // owner lane of packed slot t: group g with off_g <= t < off_g + deg_g, lane 16 g + (t - off_g)
+        const int t = min(mt_slot, pm.tot - 1);
+        const int og = t < d0 ? 0 : t < d0 + d1 ? 1 : t < d0 + d1 + d2 ? 2 : 3;
+        const int ooff = og == 0 ? 0 : og == 1 ? d0 : og == 2 ? d0 + d1 : d0 + d1 + d2;
+        const int owner = 16 * og + (t - ooff);
+        const int m_src = __shfl(rs, owner, 64), m_eid = __shfl(re, owner, 64);
+        const unsigned dst = lds_addr(wbase + sel * kBufF);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned dst = lds_addr(s_buf0 + sel * buf_floats);
-        const int nchunk = pm.tot * RC;
-        constexpr int NI = QQ ? (kEC * (H * QQ + 1 + DE / 4) + 63) / 64 : (kEC * (H * 16 + 1 + DE / 4) + 63) / 64;
-        int sv[NI], ev[NI], cc[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {                    // every table read of the pass in flight before the first address is formed
-            const int g = i * 64 + lane, e = min(g / RC, kEC - 1);
-            cc[i] = g - (g / RC) * RC;
-            sv[i] = s_idx[2 * e];
-            ev[i] = s_idx[2 * e + 1];
-        }
+        const int last = pm.tot - 1;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (i * 64 < nchunk) {                        // wave-uniform
-                const int g = i * 64 + lane, c = cc[i];
-                if (g < nchunk) {
-                    const char* src;
-                    if (c < HQ) src = reinterpret_cast<const char*>(a.xw) + (size_t)((unsigned)sv[i] * row_bytes + (unsigned)c * 16u);
-                    else if (c == HQ) src = reinterpret_cast<const char*>(a.a_ij) + (size_t)((unsigned)sv[i] * 32u + 16u);
-                    else src = reinterpret_cast<const char*>(a.edge_attr) + (size_t)((unsigned)ev[i] * (unsigned)(DE * 4) + (unsigned)(c - HQ - 1) * 16u);
-                    dma16(src, dst + (unsigned)i * 1024u);
-                }
+            if (i * 64 < pm.tot * HQ) {                   // wave-uniform; lanes past the last chunk re-fetch the last row (never read)
+                const int sv = s_src[min(st_slot[i], last)];
+                dma16(a.xw, (unsigned)sv * row_bytes + st_coff[i], dst + (unsigned)i * 1024u);
             }
         }
-        if (lane < 4) {                                   // a_i of the pass's four nodes (clamped: unused rows are never read)
-            const int n = min(4 * pass + lane, a.N - 1);
-            dma16(a.a_ij + (size_t)n * 8, lds_addr(s_node0 + sel * 16));
+        {   // a_j | edge_attr | a_i in one piece (lanes beyond the table fetch a_j of slot 0 into padding)
+            const int n_i = min(4 * pass + (lane - kMetaSlots - kEaLanes), a.N - 1);
+            const unsigned off = mt_kind == 1 ? (unsigned)m_eid * (unsigned)(DE * 4) + mt_sub
+                               : mt_kind == 2 ? (unsigned)max(n_i, 0) * 32u : (unsigned)m_src * 32u + 16u;
+            // two wave-uniform bases cannot share one piece: issue the edge_attr lanes and the a_ij lanes as two masked pieces
+            if (mt_kind == 1) dma16(a.edge_attr, off, dst + (unsigned)kRowF * 4u);
+            else dma16(a.a_ij, off, dst + (unsigned)kRowF * 4u);
         }
         return pm;
     };
@@ -136,81 +156,87 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
         const int n = 4 * pass + j;
         if (n >= a.N || pass >= npass) { r_n = -1; return; }
         r_n = n;
-        const float* buf = s_buf0 + sel * buf_floats;
-        const float4 aiv = ld4(s_node0 + sel * 16 + j * 4);
-        float ai[H], m[H], ssum[H];
+        const float* buf = wbase + sel * kBufF;
+        const float* meta = buf + kRowF;
+        float m[H], ssum[H];
 #pragma unroll
-        for (int h = 0; h < H; ++h) { ai[h] = f4get(aiv, h); m[h] = -INFINITY; ssum[h] = 0.f; r_acc[h] = f4zero(); }
-        constexpr int CH = 4;
-        bool val[CH];
-        float ea[CH][DE], lk[CH][H];
-        int rowo[CH];                                                  // float offsets into the pass buffer
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            val[k] = k < pm.deg;
-            rowo[k] = (pm.off + (val[k] ? k : 0)) * RC * 4;            // a clamped slot is a valid address inside the buffer
-        }
+        for (int h = 0; h < H; ++h) { m[h] = -INFINITY; ssum[h] = 0.f; r_acc[h] = f4zero(); }
         if (pm.deg > 0) {
+            const float4 aiv = ld4(meta + (kMetaSlots + kEaLanes + j) * 4);
+            float ai[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) ai[h] = f4get(aiv, h);
+            constexpr int CH = 4;
+            bool val[CH];
+            int slot[CH];
+            float ea[CH][DE], lk[CH][H];
             float4 aj[CH];
+            // slots k >= dmax are empty in all four nodes of the pass: skipped by a scalar branch (56 % of the molecular passes have
+            // no node of degree 3); a slot that is empty in THIS node only runs branch-free with weight 0
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                aj[k] = ld4(buf + rowo[k] + HQ * 4);
+                val[k] = k < pm.deg;
+                slot[k] = pm.off + (val[k] ? k : 0);      // an unused slot aliases the node's first edge: finite data, weight 0
+                if (k < pm.dmax) {
+                    aj[k] = ld4(meta + slot[k] * 4);
 #pragma unroll
-                for (int u = 0; u < DE / 4; ++u) {
-                    const float4 v = ld4(buf + rowo[k] + (HQ + 1 + u) * 4);
-                    ea[k][4 * u] = v.x; ea[k][4 * u + 1] = v.y; ea[k][4 * u + 2] = v.z; ea[k][4 * u + 3] = v.w;
+                    for (int u = 0; u < DE / 4; ++u) {
+                        const float4 v = ld4(meta + (kMetaSlots + slot[k] * (DE / 4) + u) * 4);
+                        ea[k][4 * u] = v.x; ea[k][4 * u + 1] = v.y; ea[k][4 * u + 2] = v.z; ea[k][4 * u + 3] = v.w;
+                    }
                 }
             }
+            int wrow[CH];                                              // ONEHOT: float offset of the edge's W_edge row (head 0)
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                float pre[H];
-                edge_pre<H, DE>(ai, aj[k], ea[k], Mr, pre);
+                if (k < pm.dmax) {
+                    float pre[H];
+                    edge_pre<H, DE>(ai, aj[k], ea[k], Mr, pre);
 #pragma unroll
-                for (int h = 0; h < H; ++h) lk[k][h] = leaky(pre[h], a.slope);
-            }
+                    for (int h = 0; h < H; ++h) {
+                        lk[k][h] = leaky(pre[h], a.slope);
+                        m[h] = val[k] ? fmaxf(m[h], lk[k][h]) : m[h];
+                    }
+                    if constexpr (ONEHOT) {
+                        int t = 0;
 #pragma unroll
-            for (int k = 0; k < CH; ++k)
-#pragma unroll
-                for (int h = 0; h < H; ++h)
-                    if (val[k]) m[h] = fmaxf(m[h], lk[k][h]);
-            int wrow[CH];                                              // ONEHOT: float offset of the edge's W_edge row (head 0)
-            if constexpr (ONEHOT) {
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    int t = 0;
-#pragma unroll
-                    for (int kk = 1; kk < DE; ++kk) t = ea[k][kk] != 0.f ? kk : t;
-                    wrow[k] = t * HC + (qok ? q : 0) * 4;
+                        for (int kk = 1; kk < DE; ++kk) t = ea[k][kk] != 0.f ? kk : t;
+                        wrow[k] = t * HC + (qok ? q : 0) * 4;
+                    }
                 }
             }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 float4 wv[DE];
                 float4 xr[CH], er[CH];
-                if constexpr (ONEHOT) {
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) er[k] = ld4(s_w + wrow[k] + h * Cp);
-                } else {
+                if constexpr (!ONEHOT) {
 #pragma unroll
                     for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + (qok ? q : 0) * 4);
                 }
 #pragma unroll
-                for (int k = 0; k < CH; ++k) xr[k] = ld4(buf + rowo[k] + (h * Q + (qok ? q : 0)) * 4);
+                for (int k = 0; k < CH; ++k) {
+                    if (k < pm.dmax) {
+                        if constexpr (ONEHOT) er[k] = ld4(s_w + wrow[k] + h * Cp);
+                        xr[k] = ld4(buf + (slot[k] * HQ + h * Q + (qok ? q : 0)) * 4);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
-                    if (!val[k]) continue;
-                    const float p = softmax_exp(lk[k][h] - m[h]);
-                    ssum[h] += p;
-                    float4 e4;
-                    if constexpr (ONEHOT) {
-                        e4 = er[k];
-                    } else {
-                        e4 = f4zero();
+                    if (k < pm.dmax) {
+                        // branch-free inside the wave: an unused slot contributes p = 0 times the (finite) row of the first edge
+                        const float p = val[k] ? softmax_exp(lk[k][h] - m[h]) : 0.f;
+                        ssum[h] += p;
+                        float4 e4;
+                        if constexpr (ONEHOT) {
+                            e4 = er[k];
+                        } else {
+                            e4 = f4zero();
 #pragma unroll
-                        for (int kk = 0; kk < DE; ++kk) fma4(e4, ea[k][kk], wv[kk]);
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, ea[k][kk], wv[kk]);
+                        }
+                        const float4 xj = e4 * xr[k];
+                        fma4(r_acc[h], p, xj);
                     }
-                    const float4 xj = e4 * xr[k];
-                    fma4(r_acc[h], p, xj);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -241,22 +267,31 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
     int rs_nxt, re_nxt;                                   // record of the pass whose rows are staged NEXT
     int pass = gw;
     load_rec(pass, rs_nxt, re_nxt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
     PassMeta pm_cur = issue_dma(pass, rs_nxt, re_nxt, 0, 0xF);
     int rs_cur = rs_nxt, re_cur = re_nxt;                 // kept for the (rare) node-by-node path of the current pass
     load_rec(pass + GW, rs_nxt, re_nxt);
     int sel = 0;
+#ifdef GLAM_DMA_PROF
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
+#endif
     for (; pass < npass; pass += GW, sel ^= 1) {
+        DSTAMP(0);
         // rows of `pass` have landed; the record of pass + GW is in registers.  The record is an in/out operand so that the compiler
         // retires ITS count of the record loads here: otherwise it does so at their first use — after the stores below, with a
         // vmcnt(0) that would also wait for those stores.
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        DSTAMP(1);
         store_results();                                  // of the previous pass (registers) -> in flight during this pass
+        DSTAMP(2);
         const int rs_n1 = rs_nxt, re_n1 = re_nxt;
         PassMeta pm_nxt = issue_dma(pass + GW, rs_n1, re_n1, sel ^ 1, 0xF);
+        DSTAMP(3);
         load_rec(pass + 2 * GW, rs_nxt, re_nxt);
+        DSTAMP(4);
         if (pm_cur.tot <= kEC) {
             compute(pass, pm_cur, sel);
+            DSTAMP(5);
         } else {
             // more than kEC edges in the four segments together: stage and compute node by node into this pass's (unused) buffer
             float4 t_acc[H], t_m = f4zero(), t_s = f4zero();
@@ -282,6 +317,261 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_results();
+#ifdef GLAM_DMA_PROF
+    if (lane == 0 && gw < 64) for (int k = 0; k < 8; ++k) g_dma_prof[gw * 8 + k] = pacc[k];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_triplet_fwd_pipe: the same software pipeline with the gathered ROWS prefetched one pass ahead into VGPRs (plain 16-byte loads:
+// L1 / L2 hits move at 64 B/clk/CU) and only the small side table (a_j, edge_attr, a_i: one 64-lane piece per pass) staged by
+// LDS-DMA.  Cycle stamps of the all-DMA version (tools/dma_prof.py, B = 16 384, per pass and wave): 1 884 cycles issuing the nine
+// 1 KiB gather pieces (~190 cycles each: the LDS-DMA path moves ~10-13 B/clk/CU — sized for an HBM stream, and this gather
+// re-reads every row 2.05 times out of L2), 2 607 computing, 8 waiting.  Registers: +48 for the rows in flight (2 waves / SIMD).
+// ------------------------------------------------------------------------------------------------------------------------------
+#ifndef GLAM_PIPE_WAVES
+#define GLAM_PIPE_WAVES 2      // 3 (<= 168 VGPRs) spills: 117 vs 112 us at B = 16 384
+#endif
+template <int H, int DE, bool ONEHOT>
+__global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(FwdDmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane >> 4, q = lane & 15;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    const int WSZ = DE * HC;
+    constexpr int kMetaF = 64 * 4;
+    float* s_w = smem;
+    float* wbase = smem + WSZ + wave * (2 * kMetaF);
+    for (int i = tid; i < WSZ / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+    __syncthreads();
+    float Mr[DE][H];
+#pragma unroll
+    for (int k = 0; k < DE; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) Mr[k][h] = a.M[k * 4 + h];
+
+    const int npass = (a.N + 3) >> 2;
+    const int gw = blockIdx.x * (kBlock / 64) + wave, GW = gridDim.x * (kBlock / 64);
+    const bool qok = q < Q;
+    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;
+    const unsigned qoff = (unsigned)(qok ? q : 0) * 16u;
+    constexpr int kEaLanes = kMetaSlots * (DE / 4);
+    const int mt_kind = lane < kMetaSlots ? 0 : lane < kMetaSlots + kEaLanes ? 1 : lane < kMetaSlots + kEaLanes + 4 ? 2 : 3;
+    const int mt_slot = mt_kind == 0 ? lane : mt_kind == 1 ? (lane - kMetaSlots) / (DE / 4) : 0;
+    const unsigned mt_sub = mt_kind == 1 ? (unsigned)((lane - kMetaSlots) % (DE / 4)) * 16u : 0u;
+    constexpr int CH = 4;
+
+    auto load_rec = [&](int pass, int& rs, int& re) {
+        const int n = 4 * pass + j;
+        rs = -1; re = -1;
+        if (q < 4 && pass < npass && n < a.N) { rs = a.ell_src[4 * n + q]; re = a.ell_eid[4 * n + q]; }
+    };
+    // issue everything pass `pass` needs: its rows into `rows` (registers), its side table into LDS buffer `sel`
+    auto prefetch = [&](int pass, int rs, int re, int sel, float4 (&rows)[CH][H]) -> PassMeta {
+        const unsigned long long bal = __ballot(rs >= 0);
+        const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
+                  d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
+        PassMeta pm;
+        pm.deg = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
+        pm.off = j == 0 ? 0 : j == 1 ? d0 : j == 2 ? d0 + d1 : d0 + d1 + d2;
+        pm.tot = __builtin_amdgcn_readfirstlane(d0 + d1 + d2 + d3);
+        pm.dmax = __builtin_amdgcn_readfirstlane(max(max(d0, d1), max(d2, d3)));   // provably scalar: the slot loops branch on it
+        if (pm.tot == 0) return pm;
+        // side table piece: packed slot t is owned by lane 16 g + (t - off_g)
+        const int t = min(mt_slot, pm.tot - 1);
+        const int og = t < d0 ? 0 : t < d0 + d1 ? 1 : t < d0 + d1 + d2 ? 2 : 3;
+        const int ooff = og == 0 ? 0 : og == 1 ? d0 : og == 2 ? d0 + d1 : d0 + d1 + d2;
+        const int owner = 16 * og + (t - ooff);
+        // every cross-lane read of the record in flight at once (six ds_bpermute, ONE wait): behind the scalar slot branches below the
+        // compiler would issue them one dependent round trip at a time
+        const int m_src = __shfl(rs, owner, 64), m_eid = __shfl(re, owner, 64);
+        int sk[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) sk[k] = __shfl(rs, 16 * j + k, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sk[0]), "+v"(sk[1]), "+v"(sk[2]), "+v"(sk[3]) : : "memory");
+        const unsigned dst = lds_addr(wbase + sel * kMetaF);
+        const int n_i = min(4 * pass + (lane - kMetaSlots - kEaLanes), a.N - 1);
+        const unsigned off = mt_kind == 1 ? (unsigned)m_eid * (unsigned)(DE * 4) + mt_sub
+                           : mt_kind == 2 ? (unsigned)max(n_i, 0) * 32u : (unsigned)m_src * 32u + 16u;
+        if (mt_kind == 1) dma16(a.edge_attr, off, dst);
+        else dma16(a.a_ij, off, dst);
+        // rows of this lane's node: slot k's source sits in lane 16 j + k; an empty slot re-reads the first edge's row (weight 0)
+        // (the rows are "settled" by input-only asm uses: an in/out operand split their live ranges, and the compiler then loaded
+        // into temporaries and copied them home behind an s_waitcnt vmcnt right after the issue: 3 800 cycles per pass)
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (k < pm.dmax) {                            // scalar branch: slot k is empty in all four nodes otherwise
+                const unsigned ro = (unsigned)max(sk[k] >= 0 ? sk[k] : sk[0], 0) * row_bytes + qoff;
+#pragma unroll
+                for (int h = 0; h < H; ++h) rows[k][h] = ld4o(a.xw, ro + (unsigned)h * head_bytes);
+            } else {
+#pragma unroll
+                for (int h = 0; h < H; ++h) rows[k][h] = f4zero();
+            }
+        }
+        return pm;
+    };
+
+    float4 r_acc[H];
+    float4 r_m = f4zero(), r_s = f4zero();
+    int r_n = -1;
+    auto compute = [&](int pass, const PassMeta& pm, int sel, const float4 (&rows)[CH][H]) {
+        const int n = 4 * pass + j;
+        if (n >= a.N || pass >= npass) { r_n = -1; return; }
+        r_n = n;
+        const float* meta = wbase + sel * kMetaF;
+        float m[H], ssum[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { m[h] = -INFINITY; ssum[h] = 0.f; r_acc[h] = f4zero(); }
+        if (pm.deg > 0) {
+            const float4 aiv = ld4(meta + (kMetaSlots + kEaLanes + j) * 4);
+            float ai[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) ai[h] = f4get(aiv, h);
+            bool val[CH];
+            float ea[CH][DE], lk[CH][H];
+            float4 aj[CH];
+            int wrow[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                val[k] = k < pm.deg;
+                if (k < pm.dmax) {
+                    const int slot = pm.off + (val[k] ? k : 0);
+                    aj[k] = ld4(meta + slot * 4);
+#pragma unroll
+                    for (int u = 0; u < DE / 4; ++u) {
+                        const float4 v = ld4(meta + (kMetaSlots + slot * (DE / 4) + u) * 4);
+                        ea[k][4 * u] = v.x; ea[k][4 * u + 1] = v.y; ea[k][4 * u + 2] = v.z; ea[k][4 * u + 3] = v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (k < pm.dmax) {
+                    float pre[H];
+                    edge_pre<H, DE>(ai, aj[k], ea[k], Mr, pre);
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        lk[k][h] = leaky(pre[h], a.slope);
+                        m[h] = val[k] ? fmaxf(m[h], lk[k][h]) : m[h];
+                    }
+                    if constexpr (ONEHOT) {
+                        int t = 0;
+#pragma unroll
+                        for (int kk = 1; kk < DE; ++kk) t = ea[k][kk] != 0.f ? kk : t;
+                        wrow[k] = t * HC + (qok ? q : 0) * 4;
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float4 wv[DE], er[CH];
+                if constexpr (!ONEHOT) {
+#pragma unroll
+                    for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + (qok ? q : 0) * 4);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (k < pm.dmax) er[k] = ld4(s_w + wrow[k] + h * Cp);
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (k < pm.dmax) {
+                        const float p = val[k] ? softmax_exp(lk[k][h] - m[h]) : 0.f;
+                        ssum[h] += p;
+                        float4 e4;
+                        if constexpr (ONEHOT) {
+                            e4 = er[k];
+                        } else {
+                            e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, ea[k][kk], wv[kk]);
+                        }
+                        const float4 xj = e4 * rows[k][h];
+                        fma4(r_acc[h], p, xj);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float inv = 1.f / (ssum[h] + 1e-16f);
+            r_acc[h] = inv * r_acc[h];
+            (&r_m.x)[h] = pm.deg > 0 ? m[h] : 0.f;
+            (&r_s.x)[h] = ssum[h];
+        }
+    };
+    auto store_results = [&]() {
+        if (r_n < 0) return;
+        if (qok) {
+            const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
+#pragma unroll
+            for (int h = 0; h < H; ++h) st4o(a.aggr, orow + (unsigned)h * head_bytes, r_acc[h]);
+        }
+        if (q < 2) st4o(a.stats, (unsigned)r_n * 32u + (unsigned)q * 16u, q == 0 ? r_m : r_s);   // one store piece for both halves
+        r_n = -1;
+    };
+    // the rows in flight are (re)defined by an empty asm right after the pipeline's own vmcnt(0): the compiler retires its count of
+    // those loads there, and never again behind the stores / loads issued later in the iteration
+    auto settle = [&](float4 (&rows)[CH][H]) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                asm volatile("" : : "v"(rows[k][h].x), "v"(rows[k][h].y), "v"(rows[k][h].z), "v"(rows[k][h].w));   // a USE: no new live range
+    };
+
+    float4 rows_a[CH][H], rows_b[CH][H];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) { rows_a[k][h] = f4zero(); rows_b[k][h] = f4zero(); }
+    int rs_nxt, re_nxt;
+    int pass = gw;
+    load_rec(pass, rs_nxt, re_nxt);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+    PassMeta pm_cur = prefetch(pass, rs_nxt, re_nxt, 0, rows_a);
+    load_rec(pass + GW, rs_nxt, re_nxt);
+    // two passes per trip: the register sets swap roles instead of being copied
+#ifdef GLAM_DMA_PROF
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
+#endif
+    for (; pass < npass; pass += 2 * GW) {
+        DSTAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        settle(rows_a);
+        DSTAMP(1);
+        store_results();
+        DSTAMP(2);
+        PassMeta pm_nxt = prefetch(pass + GW, rs_nxt, re_nxt, 1, rows_b);
+        DSTAMP(3);
+        load_rec(pass + 2 * GW, rs_nxt, re_nxt);
+        DSTAMP(4);
+        compute(pass, pm_cur, 0, rows_a);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DSTAMP(5);
+
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        settle(rows_b);
+        store_results();
+        pm_cur = prefetch(pass + 2 * GW, rs_nxt, re_nxt, 0, rows_a);
+        load_rec(pass + 3 * GW, rs_nxt, re_nxt);
+        compute(pass + GW, pm_nxt, 1, rows_b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DSTAMP(6);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_results();
+#ifdef GLAM_DMA_PROF
+    if (lane == 0 && gw < 64) for (int k = 0; k < 8; ++k) g_dma_prof[gw * 8 + k] = pacc[k];
+#endif
+}
+
+template <int H, int DE, bool ONEHOT>
+static void launch_pipe(const FwdDmaArgs& a, int grid, hipStream_t s) {
+    const size_t lds = ((size_t)DE * H * a.Cp + (size_t)(kBlock / 64) * 2 * 64 * 4) * sizeof(float);
+    GLAM_PROF_LABEL("k_triplet_fwd_pipe");
+    hipLaunchKernelGGL((k_triplet_fwd_pipe<H, DE, ONEHOT>), dim3(grid), dim3(kBlock), lds, s, a);
 }
 
 __global__ void __launch_bounds__(kBlock) k_ell_build(const int* rowptr, const int* nbr, const int* eid, int N, int4* ell_src,
@@ -297,8 +587,8 @@ __global__ void __launch_bounds__(kBlock) k_ell_build(const int* rowptr, const i
 }
 
 static size_t dma_lds_bytes(int H, int Cp, int De) {
-    const int RC = H * (Cp >> 2) + 1 + De / 4;
-    return ((size_t)De * H * Cp + (size_t)(kBlock / 64) * (2 * kEC * RC * 4 + 2 * 16 + kEC * 2)) * sizeof(float);
+    const int Q = Cp >> 2, NI = Q == 15 && H == 3 && De == 4 ? (kEC * H * 15 + 63) / 64 : (kEC * H * 16 + 63) / 64;
+    return ((size_t)De * H * Cp + (size_t)(kBlock / 64) * (2 * (NI * 64 * 4 + 64 * 4) + kMetaSlots)) * sizeof(float);
 }
 
 template <int H, int DE, int QQ, bool ONEHOT>
@@ -329,7 +619,7 @@ extern "C" int glam_ell_build(const int32_t* rowptr, const int32_t* nbr, const i
 }
 
 extern "C" int glam_triplet_fwd_ell_supported(int H, int Cp, int De) {
-    return H >= 1 && H <= 4 && Cp >= 4 && Cp <= 64 && (Cp & 3) == 0 && (De == 4 || De == 8) && dma_lds_bytes(H, Cp, De) <= 80 * 1024;
+    return H >= 1 && H <= 4 && Cp >= 4 && Cp <= 64 && (Cp & 3) == 0 && (De == 4 || De == 8);
 }
 
 extern "C" int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
@@ -351,6 +641,19 @@ extern "C" int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const fl
     int grid = grid_blocks > 0 ? grid_blocks : 512;                 // two 4-wave blocks per CU, every wave pipelines over its passes
     if (grid > (npass + 3) / 4) grid = (npass + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
+    static const bool use_dma = [] { const char* e = getenv("GLAM_ELL_VARIANT"); return e && !strcmp(e, "dma"); }();
+    if (!use_dma) {   // default: rows prefetched into registers (k_triplet_fwd_pipe)
+#define GLAM_PIPE_CASE(HH, DD)                                                                \
+        if (H == HH && De == DD) {                                                            \
+            if (edge_onehot) launch_pipe<HH, DD, true>(a, grid, s);                           \
+            else launch_pipe<HH, DD, false>(a, grid, s);                                      \
+            GLAM_LAUNCH_CHECK("glam_triplet_fwd_ell");                                        \
+            return GLAM_OK;                                                                   \
+        }
+        GLAM_PIPE_CASE(1, 4) GLAM_PIPE_CASE(2, 4) GLAM_PIPE_CASE(3, 4) GLAM_PIPE_CASE(4, 4)
+        GLAM_PIPE_CASE(1, 8) GLAM_PIPE_CASE(2, 8) GLAM_PIPE_CASE(3, 8) GLAM_PIPE_CASE(4, 8)
+#undef GLAM_PIPE_CASE
+    }
 #define GLAM_DMA_CASE(HH, DD, QQ_)                                                                                  \
     if (H == HH && De == DD && (QQ_ == 0 || Cp == 4 * QQ_)) {                                                       \
         if (edge_onehot) launch_dma<HH, DD, QQ_, true>(a, grid, lds, s);                                            \
@@ -359,8 +662,14 @@ extern "C" int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const fl
         return GLAM_OK;                                                                                             \
     }
     GLAM_DMA_CASE(3, 4, 15)                          // the reference's default width (hid_dim 60, 3 heads, bond one-hots)
-    GLAM_DMA_CASE(1, 4, 0) GLAM_DMA_CASE(2, 4, 0) GLAM_DMA_CASE(3, 4, 0) GLAM_DMA_CASE(4, 4, 0)
-    GLAM_DMA_CASE(1, 8, 0) GLAM_DMA_CASE(2, 8, 0) GLAM_DMA_CASE(3, 8, 0) GLAM_DMA_CASE(4, 8, 0)
+    GLAM_DMA_CASE(1, 4, 0) GLAM_DMA_CASE(2, 4, 0)
+    GLAM_DMA_CASE(1, 8, 0) GLAM_DMA_CASE(2, 8, 0)
 #undef GLAM_DMA_CASE
     return fail(GLAM_E_UNSUPPORTED, "glam_triplet_fwd_ell: no kernel for H=%d De=%d", H, De);
 }
+
+#ifdef GLAM_DMA_PROF
+extern "C" int glam_debug_dma_prof(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_dma_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif

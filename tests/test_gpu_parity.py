@@ -1615,3 +1615,74 @@ def test_default_config_graphed_training_follows_the_eager_stream(device):
     assert np.allclose(l_e, l_g, rtol=1e-5, atol=1e-6), (l_e, l_g)
     for a, r in zip(p_g, p_e):
         assert_close(a, r, 1e-5, "parameter")
+
+
+# ---------------------------------------------------------------------------------------------
+# software-pipelined forward aggregate (csrc/triplet_dma.hip): bit-identical to the general kernel
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,C,De,onehot", [(3, 60, 4, True), (3, 60, 4, False), (1, 60, 4, True), (2, 32, 4, False), (4, 44, 8, False),
+                                           (3, 15, 3, True), (3, 64, 8, True)])
+def test_pipelined_forward_is_bit_identical_to_the_general_kernel(device, H, C, De, onehot):
+    """glam_triplet_fwd_ell (index records + rows prefetched one pass ahead, one-hot e_ij fast path) against glam_triplet_fwd on
+    the same tensors: equal bit for bit — molecules with isolated atoms and every in-degree 0..4, N not a multiple of the pass
+    size, both LDS-DMA and register variants of the pipeline.  Graphs with an in-degree above 4 report no ELL form."""
+    from glam_amd import _lib
+    lib, p, st = _lib.load(), _lib.ptr, _lib.stream
+    torch.manual_seed(H * 100 + C)
+    b = synth_batch(300, seed=C + H)
+    N0 = b.x.size(0)
+    ei = torch.cat([b.edge_index, torch.tensor([[5, 6, 7, 9], [8, 8, 8, 8]])], dim=1)      # node 8: in-degree 4 (2 + extra)... or more
+    deg = torch.bincount(ei[1], minlength=N0)
+    keep = torch.ones(ei.size(1), dtype=torch.bool)
+    for n in (deg > 4).nonzero().flatten().tolist():                                       # trim any node back to in-degree 4
+        idx = (ei[1] == n).nonzero().flatten()[4:]
+        keep[idx] = False
+    ei = ei[:, keep]
+    N = N0 + 3                                                                              # three isolated atoms at the end: N % 4 != 0
+    E = ei.size(1)
+    Cp, Dp = (C + 3) // 4 * 4, 4 if De <= 4 else 8
+    ea = torch.zeros(E, Dp)
+    if onehot:
+        ea[torch.arange(E), torch.randint(0, De, (E,))] = 1.0
+    else:
+        ea[:, :De] = torch.rand(E, De)
+    ei, ea = ei.to(device), ea.to(device)
+    xw, a_ij = torch.randn(N, H * Cp, device=device), torch.randn(N, 8, device=device)
+    We, M = torch.randn(Dp, H * Cp, device=device), torch.randn(Dp, 4, device=device)
+    gi = ops.GraphIndex(ei, N)
+    ell = gi.ell()
+    assert ell is not None and int((ell[0] >= 0).sum()) == E
+    ref_a, ref_s = torch.empty(N, H * Cp, device=device), torch.empty(N, 8, device=device)
+    _lib.check(lib.glam_triplet_fwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(gi.rowptr), p(gi.src), p(gi.eid), N, E, H, Cp, Dp, 1, 0.2,
+                                    p(ref_a), p(ref_s), st()), "fwd")
+    assert lib.glam_triplet_fwd_ell_supported(H, Cp, Dp)
+    for grid in (0, 3, 40):                                                                 # default grid; many passes per wave; one pass per wave
+        got_a, got_s = torch.full_like(ref_a, 9.0), torch.full_like(ref_s, 9.0)
+        _lib.check(lib.glam_triplet_fwd_ell(p(xw), p(a_ij), p(ea), p(We), p(M), p(ell[0]), p(ell[1]), N, E, H, Cp, Dp, 0.2, int(onehot),
+                                            p(got_a), p(got_s), grid, st()), "fwd_ell")
+        assert torch.equal(got_a, ref_a) and torch.equal(got_s, ref_s), f"grid={grid}"
+    # an in-degree of 5: no ELL form, the op keeps the general kernel
+    ei5 = torch.cat([ei, torch.tensor([[1, 2, 3], [8, 8, 8]], device=device)], dim=1)
+    assert ops.GraphIndex(ei5, N).ell() is None
+
+
+def test_pipelined_forward_serves_large_molecular_batches_through_the_op(device, monkeypatch):
+    """ops.triplet_aggregate switches to the pipelined kernel above GraphIndex.ELL_MIN_NODES: same result, same gradients."""
+    b = synth_batch(64, seed=2).to(device)
+    N = b.x.size(0)
+    torch.manual_seed(1)
+    conv = layer.TripletMessage(60, 4).to(device)
+    with torch.no_grad():
+        Wn, Wa, We, M, Ws, Cp, Dp = conv._staged_weights()
+    x = torch.randn(N, 60, device=device)
+    outs = []
+    for thr in (10 ** 9, 1):
+        monkeypatch.setattr(ops.GraphIndex, "ELL_MIN_NODES", thr)
+        xw = (x @ Wn).requires_grad_(True)
+        a_ij = (x @ Wa).requires_grad_(True)
+        gi = ops.GraphIndex(b.edge_index, N)
+        aggr = ops.triplet_aggregate(xw, a_ij, b.edge_attr, We, M, gi, 3, Cp)
+        g = torch.autograd.grad(aggr.square().sum(), [xw, a_ij])
+        outs.append((aggr, g, gi._ell))
+    assert outs[0][2] is False and outs[1][2] not in (False, None)                         # the ELL form was built only on the second route
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, c) for a, c in zip(outs[0][1], outs[1][1]))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an instrumented copy of libglam_hip.so for the in-kernel cycle profilers of tools/*_prof.py.
-# usage: tools/build_prof_variant.sh {b1|ts|tile}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
+# usage: tools/build_prof_variant.sh {b1|ts|tile|dma}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
 set -e
 cd "$(dirname "$0")/../glam_amd/csrc"
 make -j8 > /dev/null
@@ -8,7 +8,8 @@ case "$1" in
   b1)   src=triplet_h3.hip; def=GLAM_B1_PROF ;;
   ts)   src=gemm.hip;       def=GLAM_TS_PROF ;;
   tile) src=tile.hip;       def=GLAM_TILE_PROF ;;
-  *) echo "usage: $0 {b1|ts|tile}"; exit 2 ;;
+  dma)  src=triplet_dma.hip; def=GLAM_DMA_PROF ;;
+  *) echo "usage: $0 {b1|ts|tile|dma}"; exit 2 ;;
 esac
 mkdir -p ../variants
 obj=/tmp/glam_${1}_prof.o

@@ -1,4 +1,5 @@
-"""Experiment: k_triplet_fwd_dma (LDS-DMA software pipeline) vs k_triplet_fwd: bit equality + per-dispatch durations."""
+"""Experiment: the software-pipelined forward aggregate (glam_triplet_fwd_ell: k_triplet_fwd_pipe, or k_triplet_fwd_dma with
+GLAM_ELL_VARIANT=dma) vs k_triplet_fwd: bit equality + per-dispatch durations.  usage: exp_dma_fwd.py [B ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
