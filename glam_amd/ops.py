@@ -501,8 +501,19 @@ class _TripletLayer(torch.autograd.Function):
         return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
 
 
+# GLAM_TORCH_EXT=1: the layer goes through the torch-extension operator (torch.ops.glam.triplet_layer: C++ autograd node, no ctypes
+# marshalling, no Python autograd.Function) — the route for EAGERLY issued steps; the default Python node keeps the per-pass
+# weight staging and the gradient carry of a weight_scope, which a captured hipGraph replays for free.
+USE_TORCH_EXT = os.environ.get("GLAM_TORCH_EXT", "0") == "1"
+
+
 def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
     """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
+    if USE_TORCH_EXT and FEATURE_STORAGE == "fp32" and gi.N > 0:
+        from . import torch_ext
+        t_ptr = gi.transpose() if torch.is_grad_enabled() else (gi.rowptr, gi.src, gi.eid)     # any int32 tensors when no backward follows
+        return torch_ext.load().triplet_layer(f32c(x_p, "x"), f32c(ea_p, "edge_attr"), weight_node, weight_edge, att, weight_scale, bias,
+                                              gi.rowptr, gi.src, gi.eid, t_ptr[0], t_ptr[1], t_ptr[2], heads, float(slope))
     params = (weight_node, weight_edge, att, weight_scale, bias)
     C = weight_node.size(0)
     sizes = [weight_node.numel(), weight_edge.numel(), att.numel(), heads * C * C, C]

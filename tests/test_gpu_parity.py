@@ -1686,3 +1686,72 @@ def test_pipelined_forward_serves_large_molecular_batches_through_the_op(device,
         outs.append((aggr, g, gi._ell))
     assert outs[0][2] is False and outs[1][2] not in (False, None)                         # the ELL form was built only on the second route
     assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, c) for a, c in zip(outs[0][1], outs[1][1]))
+
+
+# ---------------------------------------------------------------------------------------------
+# torch-extension front end (torch.ops.glam.*): same kernels behind at::Tensor operators with C++ autograd nodes
+# ---------------------------------------------------------------------------------------------
+def test_torch_extension_ops_match_the_ctypes_route(device, monkeypatch):
+    from glam_amd import torch_ext
+    G = torch_ext.load()
+    torch.manual_seed(31)
+    b = synth_batch(40, seed=31).to(device)
+    N, E = b.x.size(0), b.edge_index.size(1)
+    # CSR staging: both directions against GraphIndex
+    gi = ops.GraphIndex(b.edge_index, N)
+    rp, nb, ed, err = G.csr_from_edge_index(b.edge_index, N, 0)
+    cp, ds, et, _ = G.csr_from_edge_index(b.edge_index, N, 1)
+    colptr, dstv, eid_t = gi.transpose()
+    for a_, r_ in ((rp, gi.rowptr), (nb, gi.src), (ed, gi.eid), (cp, colptr), (ds, dstv), (et, eid_t)):
+        assert torch.equal(a_, r_)
+    assert int(err) == 0 and int(G.csr_from_edge_index(b.edge_index, N - 5, 0)[3]) == 1
+    ptr, perr = G.batch_ptr(b.batch, 40)
+    assert torch.equal(ptr, ops.segment_ptr(b.batch, 40).ptr) and int(perr) == 0
+    # whole layer: output and all six gradients, bit for bit (same launches)
+    conv = layer.TripletMessage(60, 4).to(device)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    x0 = torch.randn(N, 60, device=device)
+    cot = torch.randn(N, 60, device=device)
+    res = []
+    for ext in (False, True):
+        monkeypatch.setattr(ops, "USE_TORCH_EXT", ext)
+        x = x0.clone().requires_grad_(True)
+        out = conv(x, b.edge_index, b.edge_attr)
+        res.append((out, torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)))
+    assert type(res[1][0].grad_fn).__name__ != type(res[0][0].grad_fn).__name__          # a C++ node on the extension route
+    assert torch.equal(res[0][0], res[1][0])
+    for a_, r_ in zip(res[1][1], res[0][1]):
+        assert torch.equal(a_, r_)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    # aggregate op (multi-head and light form)
+    with torch.no_grad():
+        Wn, Wa, We, M, Ws, Cp, Dp = conv._staged_weights()
+    xw, a_ij = (x0 @ Wn).requires_grad_(True), (x0 @ Wa).requires_grad_(True)
+    ref = ops.triplet_aggregate(xw, a_ij, b.edge_attr, We, M, gi, 3, Cp)
+    got = G.triplet_aggregate(xw, a_ij, b.edge_attr, We, M, gi.rowptr, gi.src, gi.eid, colptr, dstv, eid_t, 3, 0.2)
+    assert torch.equal(ref, got)
+    c2 = torch.randn_like(ref)
+    for a_, r_ in zip(torch.autograd.grad(got, [xw, a_ij], grad_outputs=c2), torch.autograd.grad(ref, [xw, a_ij], grad_outputs=c2)):
+        assert torch.equal(a_, r_)
+    xl = torch.randn(N, 60, device=device)
+    refl = ops.light_aggregate(xl, a_ij.detach(), b.edge_attr, M, gi, 60)
+    assert torch.equal(refl, G.triplet_aggregate(xl, a_ij.detach(), b.edge_attr, None, M, gi.rowptr, gi.src, gi.eid, colptr, dstv, eid_t, 1, 0.2))
+    # readouts
+    sp = ops.segment_ptr(b.batch, 40)
+    h = torch.randn(N, 60, device=device, requires_grad=True)
+    for mode, name in ((0, "sum"), (1, "mean"), (2, "max")):
+        r_, g_ = ops.segment_pool(h, sp, name), G.segment_pool(h, sp.ptr, mode)
+        assert torch.equal(r_, g_)
+        assert torch.equal(torch.autograd.grad(r_.sum(), [h])[0], torch.autograd.grad(g_.sum(), [h])[0])
+    gate = torch.randn(N, device=device, requires_grad=True)
+    assert torch.equal(ops.segment_attention(gate, h, sp), G.segment_softmax_aggregate(gate, h, sp.ptr))
+    p5 = ops.pool5(h, sp, 3)
+    assert torch.equal(p5, G.global_pool5(h, sp.ptr, 3)) and torch.equal(p5[:, 120:], G.sort_pool_topk_last(h, sp.ptr, 3))
+    assert torch.equal(torch.autograd.grad(p5.square().sum(), [h])[0], torch.autograd.grad(G.global_pool5(h, sp.ptr, 3).square().sum(), [h])[0])
+    # misuse: RuntimeError (TORCH_CHECK), the device stays usable
+    with pytest.raises(RuntimeError):
+        G.segment_pool(h.double(), sp.ptr, 0)
+    with pytest.raises(RuntimeError):
+        G.triplet_layer(x0[:, :30].contiguous(), b.edge_attr, *conv.parameters(), gi.rowptr, gi.src, gi.eid, colptr, dstv, eid_t, 3, 0.2)
+    assert torch.isfinite(G.segment_pool(h, sp.ptr, 0)).all()

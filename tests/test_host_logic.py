@@ -305,3 +305,19 @@ def test_validation_marks_do_not_survive_a_write_or_a_replacement_across_to():
     moved = b.to(meta)
     assert getattr(moved.edge_index, "_glam_trusted", None) is None
     assert getattr(moved.batch, "_glam_trusted", None) is None
+
+
+def test_torch_extension_registers_the_boundary_ops_and_refuses_cpu_tensors():
+    """the hot path is exposed through a torch extension (TORCH_LIBRARY(glam)): every operator of the list is
+    registered with torch's dispatcher from the in-tree _glam_torch.so, and a CPU tensor is a RuntimeError (TORCH_CHECK), never a
+    silent CPU computation."""
+    from glam_amd import torch_ext
+    ns = torch_ext.load()
+    for name in torch_ext.OPS:
+        assert hasattr(ns, name), name
+    sch = str(ns.triplet_layer.default._schema)
+    assert "weight_triplet_att" in sch and "int heads" in sch
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ns.csr_from_edge_index(torch.zeros(2, 3, dtype=torch.long), 4, 0)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ns.segment_pool(torch.zeros(4, 8), torch.zeros(3, dtype=torch.int32), 0)
