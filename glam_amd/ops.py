@@ -76,7 +76,14 @@ class GraphIndex:
                     self._tiles = (tile_ptr, T)
         return self._tiles
 
-    ELL_MIN_NODES = int(os.environ.get("GLAM_ELL_MIN_NODES", "120000"))
+    # the pipelined forward pays off once xw + aggr (2 * N * H * Cp * 4 bytes) no longer fit the 256 MiB LLC (measured crossover:
+    # B = 8 192 -> 0.59 general vs 0.55 pipelined; B = 16 384 -> 0.44-0.48 vs 0.56-0.64 of the HBM peak); ELL_MIN_NODES overrides
+    ELL_MIN_NODES = int(os.environ.get("GLAM_ELL_MIN_NODES", "-1"))
+    LLC_BYTES = 256 << 20
+
+    @classmethod
+    def wants_ell(cls, N, H, Cp):
+        return N >= cls.ELL_MIN_NODES if cls.ELL_MIN_NODES >= 0 else 2 * N * H * Cp * 4 > cls.LLC_BYTES
 
     def ell(self):
         """``(ell_src, ell_eid)`` int32 ``[N, 4]`` index records of the software-pipelined forward aggregate (``glam_ell_build``),
@@ -300,7 +307,7 @@ class _TripletAggregate(torch.autograd.Function):
         lib = _lib.load()
         # Batches whose working set leaves the 256 MiB LLC: the software-pipelined kernel (bit-identical; 0.56 vs 0.44 of the HBM
         # peak at B = 16 384).  Below that the general kernel's three waves per SIMD win (9.4 vs 10.4 us at B = 1 024).
-        ell = gi.ell() if (emul and N >= GraphIndex.ELL_MIN_NODES and lib.glam_triplet_fwd_ell_supported(H, Cp, De)) else None
+        ell = gi.ell() if (emul and GraphIndex.wants_ell(N, H, Cp) and lib.glam_triplet_fwd_ell_supported(H, Cp, De)) else None
         if ell is not None:
             check(lib.glam_triplet_fwd_ell(ptr(xw), ptr(a_ij), ptr(edge_attr), ptr(w_edge), ptr(M), ptr(ell[0]), ptr(ell[1]), N, E, H, Cp, De,
                                            float(slope), int(rows_are_one_hot(edge_attr)), ptr(aggr), ptr(stats), 0, stream()),

@@ -33,3 +33,28 @@ for B in (32, 1024):
     for ext in (False, True):
         ops.USE_TORCH_EXT = ext
         print(f"B={B:5d} torch_ext={int(ext)}: layer fwd+bwd {timeit(layer_step):7.1f} us/step eager   full model step {timeit(model_step, 100):8.1f} us eager")
+
+# leanest eager step: the extension operator called directly (no Module / propagate / ops dispatch in between)
+from glam_amd import torch_ext
+G = torch_ext.load()
+b = synth_batch(1024, seed=0).to(dev)
+N = b.x.size(0)
+conv = layer.TripletMessage(60, 4).to(dev)
+x = torch.randn(N, 60, device=dev, requires_grad=True)
+cot = torch.randn(N, 60, device=dev)
+gi = ops.graph_index(b.edge_index, N)
+colptr, dst, eid_t = gi.transpose()
+ps = list(conv.parameters())
+args = (b.edge_attr, *ps, gi.rowptr, gi.src, gi.eid, colptr, dst, eid_t, 3, 0.2)
+tl = G.triplet_layer
+def lean():
+    out = tl(x, *args)
+    torch.autograd.grad(out, ps + [x], grad_outputs=cot)
+print(f"B= 1024 direct torch.ops.glam.triplet_layer fwd+bwd: {timeit(lean, 500):7.1f} us/step eager")
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(3): lean()
+torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+with torch.cuda.graph(g): lean()
+print(f"B= 1024 same step captured in a hipGraph:            {timeit(g.replay, 500):7.1f} us/step")
