@@ -59,6 +59,8 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "k_ts_gemm<12, 4, 4>": {"bound": "mfma", "flops": 2 * N * C * (HC + 8), "bytes": f * N * (C + HC + 8) + img(C, HC + 8),
                                 "note": "two launches per step: x @ [W_node | Wa] (flops as given) and d_out @ W_scale^T (2*N*C*HC)"},
         "k_triplet_fwd+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C},
+        "k_triplet_fwd_pipe+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
+                                      "note": "software-pipelined aggregate + update epilogue: the op's choice beyond the LLC"},
         "k_triplet_fwd": {"bound": "hbm", "bytes": agg_fwd},
         "k_triplet_fwd_pipe": {"bound": "hbm", "bytes": agg_fwd,
                                "note": "software-pipelined forward aggregate (csrc/triplet_dma.hip), same arithmetic and SURVEY §8(d) byte model"},

@@ -52,6 +52,9 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
                              const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
                              int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
                              const float* img_upd, const float* bias_p, float* out, hipStream_t s, int xw_bf16 = 0);
+int triplet_fwd_pipe_fused(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
+                           const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, float slope,
+                           int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s);
 bool tile_fwd_supported(int H, int Cp, int Dp);
 int tile_fwd_launch(const float* x, const float* edge_attr, const float* img_node, const float* img_upd, const float* we_p,
                     const float* M, const float* bias_p, const int32_t* rowptr, const int32_t* src, const int32_t* eid,

@@ -521,6 +521,29 @@ extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, co
                           stream, 0);
 }
 
+// Molecular graphs (in-degree <= 4, ELL index records from glam_ell_build): node GEMM, then the software-pipelined aggregate with
+// the update GEMM as its epilogue (csrc/triplet_dma.hip) — same outputs as glam_triplet_layer_fwd, bit for bit.
+extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
+                                          const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp,
+                                          float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream) {
+    if (int rc = dims_ok("glam_triplet_layer_fwd_ell", Cp, H, Dp, Cp, Dp)) return rc;
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd_ell: N out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && staged && ell_src && ell_eid && xw && a_ij && aggr && stats && out && (E == 0 || edge_attr),
+                 "glam_triplet_layer_fwd_ell: null pointer");
+    GLAM_REQUIRE(aligned16(x) && aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(out) && aligned16(staged) &&
+                     aligned16(edge_attr) && aligned16(stats), "glam_triplet_layer_fwd_ell: 16-byte alignment");
+    if (!triplet_fwd_can_fuse_update(H, Cp, Dp))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_layer_fwd_ell: no fused update for H=%d Cp=%d (36 <= Cp <= 64, H*Cp <= 192)", H, Cp);
+    hipStream_t s = (hipStream_t)stream;
+    const int HC = H * Cp;
+    const Staged L = staged_layout(H, Cp, Dp);
+    TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
+    if (int rc = launch_ts_gemm(g1, s)) return rc;
+    return triplet_fwd_pipe_fused(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
+                                  aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
+}
+
 // bf16 STORAGE of the gathered rows (BASELINE config 3): xw16 is bf16[N, H*Cp]; logits, softmax and sums stay fp32
 extern "C" int glam_triplet_layer_fwd_x16(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
                                           const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,

@@ -39,6 +39,7 @@ struct FwdDmaArgs {
     const int* ell_src; const int* ell_eid;      // [N][4] each
     int N; int Cp; float slope;
     float* aggr; float* stats;
+    const float* img_upd; const float* bias_p; float* out;     // fused update epilogue (k_triplet_fwd_pipe<..., FUSE = true>)
 };
 
 struct PassMeta { int deg; int off; int tot; int dmax; };   // per lane: its node's degree, packed slot offset; wave-wide edge
@@ -332,7 +333,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_triplet_fwd_dma(FwdDmaArgs a) {
 #ifndef GLAM_PIPE_WAVES
 #define GLAM_PIPE_WAVES 2      // 3 (<= 168 VGPRs) spills: 117 vs 112 us at B = 16 384
 #endif
-template <int H, int DE, bool ONEHOT>
+// FUSE: the update GEMM out[16 nodes, Cp] = aggr_tile @ W_scale + bias as an MFMA epilogue per 16-node tile (the four waves of a block
+// walk the same tile: pass = 4 * tile + wave), weight image resident in LDS — the step's forward kernel with the pipeline inside: the
+// next tile's index record, rows and side table are in flight during the current tile's arithmetic AND its epilogue.
+template <int H, int DE, bool ONEHOT, bool FUSE>
 __global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(FwdDmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane >> 4, q = lane & 15;
@@ -341,6 +345,12 @@ __global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(Fw
     constexpr int kMetaF = 64 * 4;
     float* s_w = smem;
     float* wbase = smem + WSZ + wave * (2 * kMetaF);
+    // FUSE: 16-node aggr tile, output staging tile and the update GEMM's weight image behind the per-wave side tables
+    const int LDT = HC + 4;
+    float* s_tile = smem + WSZ + (kBlock / 64) * 2 * kMetaF;
+    float* s_out = s_tile + 16 * LDT;
+    float* s_img = s_out + 16 * 64;
+    if constexpr (FUSE) lds_copy_async<kBlock>(a.img_upd, s_img, ((HC + 15) >> 4) * 256, tid);   // drained by the barrier below
     for (int i = tid; i < WSZ / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
     __syncthreads();
     float Mr[DE][H];
@@ -501,7 +511,57 @@ __global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(Fw
             (&r_s.x)[h] = ssum[h];
         }
     };
+    // FUSE: the tile's row of this node goes to LDS for the epilogue (rows past N / without edges are zero: out = bias)
+    auto publish_tile = [&]() {
+        if (qok) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) st4(s_tile + (wave * 4 + j) * LDT + h * Cp + q * 4, r_n >= 0 ? r_acc[h] : f4zero());
+        }
+    };
+    float4 o_hold = f4zero();
+    int o_row = -1;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    auto epilogue = [&](int tile) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // raw barrier: the prefetch of the next tile stays in flight across it
+        const int c = lane & 15, kq = lane >> 4;
+        const int GK = (HC + 15) >> 4;
+        v4f cacc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int g0 = 0; g0 < GK; g0 += 4) {
+            float4 bf[4], af[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u, k0 = 16 * g + 4 * kq;
+                bf[u] = g < GK ? ld4(s_img + ((4 * g + kq) * 64 + wave * 16 + c) * 4) : f4zero();
+                af[u] = (g < GK && k0 < HC) ? ld4(s_tile + c * LDT + k0) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[u], jj), f4get(bf[u], jj), cacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_out[(kq * 4 + i) * 64 + 4 * c + wave] = cacc[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int row = tid >> 4, c4 = (tid & 15) * 4;
+        o_row = -1;
+        if (c4 < Cp && 16 * tile + row < a.N) {
+            float4 v = ld4(s_out + row * 64 + c4);
+            const float4 bb = ld4(a.bias_p + c4);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            o_hold = v;
+            o_row = 16 * tile + row;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     auto store_results = [&]() {
+        if constexpr (FUSE) {
+            if (o_row >= 0) st4(a.out + (size_t)o_row * Cp + (tid & 15) * 4, o_hold);
+            o_row = -1;
+        }
         if (r_n < 0) return;
         if (qok) {
             const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
@@ -536,7 +596,8 @@ __global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(Fw
 #ifdef GLAM_DMA_PROF
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
-    for (; pass < npass; pass += 2 * GW) {
+    const int pass_end = ((a.N + 15) >> 4) << 2;         // whole 16-node tiles: the four waves of a block leave the loop together
+    for (; pass - wave < pass_end; pass += 2 * GW) {
         DSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
         settle(rows_a);
@@ -548,6 +609,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(Fw
         load_rec(pass + 2 * GW, rs_nxt, re_nxt);
         DSTAMP(4);
         compute(pass, pm_cur, 0, rows_a);
+        if constexpr (FUSE) { publish_tile(); epilogue(pass >> 2); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         DSTAMP(5);
 
@@ -556,7 +618,10 @@ __global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_fwd_pipe(Fw
         store_results();
         pm_cur = prefetch(pass + 2 * GW, rs_nxt, re_nxt, 0, rows_a);
         load_rec(pass + 3 * GW, rs_nxt, re_nxt);
-        compute(pass + GW, pm_nxt, 1, rows_b);
+        if (pass + GW - wave < pass_end) {                // block-uniform: both barriers of the second tile or none
+            compute(pass + GW, pm_nxt, 1, rows_b);
+            if constexpr (FUSE) { publish_tile(); epilogue((pass + GW) >> 2); }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         DSTAMP(6);
     }
@@ -571,7 +636,45 @@ template <int H, int DE, bool ONEHOT>
 static void launch_pipe(const FwdDmaArgs& a, int grid, hipStream_t s) {
     const size_t lds = ((size_t)DE * H * a.Cp + (size_t)(kBlock / 64) * 2 * 64 * 4) * sizeof(float);
     GLAM_PROF_LABEL("k_triplet_fwd_pipe");
-    hipLaunchKernelGGL((k_triplet_fwd_pipe<H, DE, ONEHOT>), dim3(grid), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((k_triplet_fwd_pipe<H, DE, ONEHOT, false>), dim3(grid), dim3(kBlock), lds, s, a);
+}
+
+template <int H, int DE, bool ONEHOT>
+static void launch_pipe_fused(const FwdDmaArgs& a, int grid, hipStream_t s) {
+    const int HC = H * a.Cp;
+    const size_t lds = ((size_t)DE * HC + (size_t)(kBlock / 64) * 2 * 64 * 4 + 16 * (size_t)(HC + 4) + 16 * 64 + (size_t)((HC + 15) & ~15) * 64) * sizeof(float);
+    static bool big = false;
+    if (!big) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_fwd_pipe<H, DE, ONEHOT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        big = true;
+    }
+    GLAM_PROF_LABEL("k_triplet_fwd_pipe+update");
+    hipLaunchKernelGGL((k_triplet_fwd_pipe<H, DE, ONEHOT, true>), dim3(grid), dim3(kBlock), lds, s, a);
+}
+
+// forward aggregate + update GEMM for molecular graphs (called by layer.hip when the caller supplied ELL records)
+int triplet_fwd_pipe_fused(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
+                           const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, float slope,
+                           int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s) {
+    if (N == 0) return GLAM_OK;
+    if (!(H >= 1 && H <= 4 && (De == 4 || De == 8) && (Cp >> 2) > 8 && (Cp >> 2) <= 16 && H * Cp <= 192))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_fwd_pipe_fused: H=%d Cp=%d De=%d outside the fused table (36 <= Cp <= 64, H*Cp <= 192)", H, Cp, De);
+    if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_fwd_pipe_fused: a tensor exceeds 4 GiB (32-bit offsets)");
+    FwdDmaArgs a{xw, a_ij, edge_attr, w_edge, M, ell_src, ell_eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out};
+    const int ntiles = (int)((N + 15) / 16);
+    const int grid = ntiles < 512 ? ntiles : 512;         // two blocks per CU (LDS-resident weight image)
+#define GLAM_PF_CASE(HH, DD)                                                     \
+    if (H == HH && De == DD) {                                                   \
+        if (edge_onehot) launch_pipe_fused<HH, DD, true>(a, grid, s);            \
+        else launch_pipe_fused<HH, DD, false>(a, grid, s);                       \
+        GLAM_LAUNCH_CHECK("triplet_fwd_pipe_fused");                             \
+        return GLAM_OK;                                                          \
+    }
+    GLAM_PF_CASE(1, 4) GLAM_PF_CASE(2, 4) GLAM_PF_CASE(3, 4) GLAM_PF_CASE(4, 4)
+    GLAM_PF_CASE(1, 8) GLAM_PF_CASE(2, 8) GLAM_PF_CASE(3, 8) GLAM_PF_CASE(4, 8)
+#undef GLAM_PF_CASE
+    return fail(GLAM_E_UNSUPPORTED, "triplet_fwd_pipe_fused: no kernel for H=%d De=%d", H, De);
 }
 
 __global__ void __launch_bounds__(kBlock) k_ell_build(const int* rowptr, const int* nbr, const int* eid, int N, int4* ell_src,
@@ -635,7 +738,7 @@ extern "C" int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const fl
     GLAM_REQUIRE(aligned16(xw) && aligned16(a_ij) && aligned16(edge_attr) && aligned16(w_edge) && aligned16(aggr) && aligned16(stats) &&
                      aligned16(ell_src) && aligned16(ell_eid), "glam_triplet_fwd_ell: pointers must be 16-byte aligned");
     FwdDmaArgs a{xw, a_ij, edge_attr, w_edge, M, ell_src, ell_eid,
-                 (int)N, Cp, slope, aggr, stats};
+                 (int)N, Cp, slope, aggr, stats, nullptr, nullptr, nullptr};
     const size_t lds = dma_lds_bytes(H, Cp, De);
     const int npass = (int)((N + 3) / 4);
     int grid = grid_blocks > 0 ? grid_blocks : 512;                 // two 4-wave blocks per CU, every wave pipelines over its passes

@@ -122,6 +122,10 @@ class GraphIndex:
 
 
 TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
+# Fused forward with the software pipeline inside (csrc/triplet_dma.hip, FUSE = true), for molecular graphs: "auto" = beyond the LLC
+# (B = 16 384: 195 vs 240 us), "1" = always (B = 1 024: 18.2 vs 16.4 us — the general fused kernel wins while the batch is cache
+# resident), "0" = never.
+PIPE_FUSED = os.environ.get("GLAM_PIPE_FUSED", "auto")
 
 
 # --------------------------------------------------------------------------------------
@@ -459,6 +463,15 @@ class _TripletLayer(torch.autograd.Function):
         # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
         # faster at B=1024 (one tile per CU) but slower beyond, where its barrier-separated phases leave the CU idle
         # (measurements in DESIGN.md).
+        want_pf = PIPE_FUSED in ("1", True) or (PIPE_FUSED == "auto" and GraphIndex.wants_ell(N, H, Cp))
+        ell = gi.ell() if (want_pf and not TILES_ENABLED and Cp > 32) else None
+        if ell is not None:     # molecular graph: the software-pipelined aggregate with the update GEMM as its epilogue (bit-identical)
+            check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), int(rows_are_one_hot(ea_p)), N,
+                                                 gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out), stream()),
+                  "glam_triplet_layer_fwd_ell")
+            ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
+            ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
+            return (out, carry.view(-1)) if ctx.carried else out
         tiles = gi.tile_plan() if (TILES_ENABLED and lib.glam_triplet_tile_supported(H, Cp, Dp)) else None
         tile_ptr, T = tiles if tiles is not None else (None, 0)
         check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),

@@ -365,6 +365,13 @@ int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_a
                          const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De,
                          float slope, int edge_onehot, float* aggr, float* stats, int grid_blocks, void* stream);
 
+/* glam_triplet_layer_fwd for edge lists with an ELL form (glam_ell_build, in-degree <= 4): node GEMM + the software-pipelined
+ * aggregate with the update GEMM as its epilogue.  Same tensors and results (bit for bit) as glam_triplet_layer_fwd; 36 <= Cp <= 64,
+ * H * Cp <= 192.  edge_onehot as in glam_triplet_fwd_ell. */
+int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
+                               const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp, float slope,
+                               float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);
+
 /* dot_and_global_pool5 (src_1gp/layer.py:270-283): for every pair i, [max, mean, median, min, std] of
  * S_i = mol[seg_i] @ pro[seg_i]^T — the reference's Python loop of matmul + max / mean / median / min / std per pair
  * (median = torch.median of the flattened scores: the LOWER median; std unbiased).  One block per pair, the score matrix is
