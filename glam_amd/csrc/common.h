@@ -174,6 +174,20 @@ __device__ __forceinline__ void lds_copy_async(const float* g, float* l, int n4,
                                          (__attribute__((address_space(3))) void*)(l + 4 * b), 16, 0, 0);
 }
 
+// One LDS-DMA piece issued by hand: lane l's 16 bytes from gbase + byte_off land at lds_base + 16 l (wave-uniform base, in M0).
+// Inline asm because the builtin makes the compiler drain vmcnt before every later LDS read; the piece is invisible to its
+// waitcnt bookkeeping, which only makes its own vmcnt(n) waits conservative (loads return in order) — the consumer must
+// s_waitcnt vmcnt(0) + barrier before reading the destination.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // "m0 is a reserved register": it is the instruction's LDS base operand
+__device__ __forceinline__ void dma16(const void* gbase, unsigned byte_off, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(gbase), "s"(lds_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)p);
+}
+
 // CELU(alpha = 1) and its derivative (torch.celu: max(0,x) + min(0, exp(x) - 1))
 __device__ __forceinline__ float celu1(float x) { return x > 0.f ? x : expf(x) - 1.f; }
 __device__ __forceinline__ float celu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }

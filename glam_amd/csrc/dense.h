@@ -66,8 +66,10 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x, int xw_bf16 = 0, hipEvent_t after_b1 = nullptr);
+                     const float* img_dx, float* d_x, int xw_bf16 = 0, hipEvent_t after_b1 = nullptr,
+                     const float* img_dagg = nullptr, const float* d_out = nullptr);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
+bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De);
 
 // A library-owned side stream per device, for work inside ONE entry point that does not depend on the main chain (e.g. the
 // weight-gradient product that only needs forward activations while the main stream walks d_aggr -> B1 -> B2).  Fork / join

@@ -610,15 +610,21 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
         if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, ss->s, &ra.job[0])) return rc;
     }
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
-    TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
-    if (int rc = launch_ts_gemm(g1, s)) return rc;
+    // (inside B1 where a fused variant exists: one launch and one [N, HC] round trip less)
+    static const bool fuse_dagg_on = [] { const char* e = getenv("GLAM_FUSE_DAGG"); return !e || atoi(e) != 0; }();
+    const bool fuse_dagg = fuse_dagg_on && !xw_bf16 && triplet_bwd_can_fuse_dagg(H, Cp, Dp);
+    if (!fuse_dagg) {
+        TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
+        if (int rc = launch_ts_gemm(g1, s)) return rc;
+    }
     const float* tpart = nullptr;
     int tnblk = 0;
     const bool fuse_dx = triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes();   // d_x = [d_xw | d_a] @ Wcat^T inside B2
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
-                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16, ss ? ss->mid : nullptr))
+                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16, ss ? ss->mid : nullptr,
+                                  fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};

@@ -114,6 +114,8 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
 
 // B2 with the input-gradient GEMM fused in (same shapes as the forward's fused update)
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De) { return triplet_fwd_can_fuse_update(H, Cp, De) && H * Cp + 8 <= 192; }
+// B1 with d_aggr = d_out @ W_scale^T fused in as a per-tile prologue
+bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De) { return triplet_fwd_can_fuse_update(H, Cp, De); }
 
 // Backward launches.  reduce_now = true: d_w_edge / d_M are final on return (3 launches);
 // reduce_now = false: the B1 block partials [*nblk_out][P] are left at *partial_out for a merged reduction.
@@ -123,7 +125,8 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1) {
+                     const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1, const float* img_dagg,
+                     const float* d_out) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
@@ -144,11 +147,17 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     // LDS reduction buffer of B1: one row per lane group when that fits beside W_edge (two blocks per CU), else one per wave
     const int gpb = kBlock / sh.G;
     const int red_groups = ((size_t)WSZ + (size_t)gpb * P) * sizeof(float) <= 60 * 1024 ? gpb : 4;
+    // d_aggr = d_out @ W_scale^T computed tile by tile inside B1 (d_aggr is then written, not read)
+    const bool fuse_dagg = img_dagg && d_out && triplet_bwd_can_fuse_dagg(H, Cp, De) && emul && !xw_bf16;
+    if ((img_dagg || d_out) && !fuse_dagg) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_aggr variant for H=%d Cp=%d", H, Cp);
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
-                  alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16};
-    const size_t lds1 = ((size_t)WSZ + (size_t)red_groups * P) * sizeof(float);
+                  alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16,
+                  fuse_dagg ? img_dagg : nullptr, fuse_dagg ? d_out : nullptr, fuse_dagg ? const_cast<float*>(d_aggr) : nullptr};
+    const size_t red_floats = (size_t)red_groups * P;
+    const size_t img_floats = (size_t)((Cp + 15) & ~15) * (H * Cp <= 64 ? 64 : 192) + 16 * (size_t)(H * Cp + 4) + 16 * 64;   // image, d_aggr tile, A tile
+    const size_t lds1 = ((size_t)WSZ + (fuse_dagg && img_floats > red_floats ? img_floats : red_floats)) * sizeof(float);
     int nblk = 0;
-    GLAM_PROF_LABEL("k_triplet_bwd_dst");
+    GLAM_PROF_LABEL(fuse_dagg ? "d_aggr+k_triplet_bwd_dst" : "k_triplet_bwd_dst");
     if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
@@ -196,5 +205,5 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
 }

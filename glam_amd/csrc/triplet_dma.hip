@@ -51,13 +51,6 @@ struct PassMeta { int deg; int off; int tot; int dmax; };   // per lane: its nod
 // being staged — drains vmcnt(0) in front of the next ds_read, which serialises the gather with the arithmetic it is meant to
 // hide behind (198 vs 148 us for the register-staged kernel at B = 16 384).  The pipeline below orders every read behind its
 // own counted s_waitcnt instead.
-__device__ __forceinline__ void dma16(const void* gbase, unsigned byte_off, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(gbase), "s"(lds_base) : "memory", "m0");
-}
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)p);
-}
-
 // QQ: compile-time chunks per head (Cp / 4) — the staging loop divides by the row length; 0 = run-time.  ONEHOT: every edge_attr
 // row is one-hot (bond types, src_1gp/dataset.py:82): e_ij is then exactly one W_edge row (sum_k ea_k W_k with ea in {0, 1}
 // adds zeros: bit-identical) and is read from LDS instead of being contracted.

@@ -33,8 +33,12 @@
 namespace glam {
 
 #ifdef GLAM_B1_PROF   // developer aid (tools/b1_prof.py): where a B1 wave spends its cycles
-__device__ long long g_b1_prof[4096 * 8];
+__device__ long long g_b1_prof[4096 * 16];
+#if GLAM_B1_PROF == 2     // stamps without draining the queues: the overlapped picture
+#define B1_WAIT() do { } while (0)
+#else
 #define B1_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 #define B1_STAMP(k) do { B1_WAIT(); const long long now__ = clock64(); prof_acc[k] += now__ - prof_last; prof_last = now__; } while (0)
 #else
 #define B1_STAMP(k) do { } while (0)
@@ -323,19 +327,63 @@ struct BwdDstArgs {
     float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;
     int red_groups;   // rows of the LDS reduction buffer: kBlock / G (every lane group stores its own partial) or 4
     int xw_bf16;      // see FwdArgs
+    // optional fused prologue (FD variants: G == 16, ITER == 1): d_aggr[16-node tile] = d_out[tile, Cp] @ W_scale^T on the fp32
+    // matrix cores, W_scale^T as a k_ts_gemm image (K = Cp, M = H*Cp).  d_aggr is then an OUTPUT (B2 reads it back).
+    const float* img_dagg; const float* d_out; float* d_aggr_w;
 };
 
-template <int H, int G, int ITER, int DE, bool EMUL, bool XB = false>
-__global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDstArgs a) {
+template <int H, int G, int ITER, int DE, bool EMUL, bool XB = false, bool FD = false>
+__global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDstArgs a) {
     typedef XwRow<XB> XR;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    static_assert(!FD || (G == 16 && ITER == 1), "the fused d_aggr prologue maps one 16-lane group to one MFMA tile row");
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int tid = threadIdx.x;
+#ifdef GLAM_B1_PROF
+    const long long prof_k0 = clock64();
+#endif
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
     const int WSZ = EMUL ? DE * HC : 0;          // floats of staged W_edge
     const int P = WSZ + DE * 4;                  // floats of one block partial: d_W_edge | d_M
+    constexpr int GPB = kBlock / G;
     float* s_w = s_mem;
     float* s_red = s_mem + WSZ;                  // [4 waves][P]
-    if constexpr (EMUL) {
+    // FD: the weight image, the 16-node d_aggr tile and the A tile share the space of the reduction buffer, which is only used
+    // after the node loop (every wave has passed the loop's last barrier by then)
+    const int MP = HC <= 64 ? 64 : 192, GK = (Cp + 15) >> 4, LDT = HC + 4;
+    float* s_img = s_red;
+    float* s_tile = s_img + GK * 16 * MP;
+    float* s_a = s_tile + 16 * LDT;              // d_out rows of the NEXT tile, [16][16 chunks], chunk j of row r at (j - r) & 15
+    // The A operand (16 rows of d_out = 4 KB) is one LDS-DMA piece per wave, issued one tile ahead: no registers, and the round
+    // trip hides under the previous tile's edge phase.  Rotating the chunks by the row index makes the fragment reads
+    // (16 lanes = 16 rows, same logical chunk) hit 16 different bank groups.
+    auto fetch_a = [&](int base) {
+        const int wave = tid >> 6, lane = tid & 63, r = wave * 4 + (lane >> 4), j = lane & 15;
+        const int row = min(base + r, a.N - 1), ch = (j + r) & 15;
+        if (4 * ch < Cp) dma16(a.d_out, ((unsigned)row * (unsigned)Cp + 4u * ch) * 4u, lds_addr(s_a + wave * 256));
+    };
+    if constexpr (FD) {
+        fetch_a((int)blockIdx.x * GPB);
+        // image: global -> registers -> LDS with every load in flight at once (an LDS-DMA copy of 48 KB takes ~2x as long and
+        // the first tile's MFMAs wait for it)
+        constexpr int kMaxImg4 = 4 * 16 * 192 / 4 / kBlock;     // float4 per thread of the largest image (Cp = 64, H = 3)
+        const int n4 = GK * 4 * MP;
+        float4 buf[kMaxImg4];
+#pragma unroll
+        for (int i = 0; i < kMaxImg4; ++i) {
+            const int idx = tid + i * kBlock;
+            if (idx < n4) buf[i] = ld4(a.img_dagg + 4 * idx);
+        }
+        if constexpr (EMUL) {
+            for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxImg4; ++i) {
+            const int idx = tid + i * kBlock;
+            if (idx < n4) st4(s_img + 4 * idx, buf[i]);
+        }
+        __syncthreads();
+    } else if constexpr (EMUL) {
         for (int i = tid; i < DE * HC / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
         __syncthreads();
     }
@@ -346,7 +394,6 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
         for (int h = 0; h < H; ++h) Mr[k][h] = a.M[k * 4 + h];
 
     const int lg = tid % G;
-    constexpr int GPB = kBlock / G;
     int q[ITER];
     bool ok[ITER];
 #pragma unroll
@@ -374,25 +421,92 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
         for (int h = 0; h < H; ++h) dM[k][h] = 0.f;
 
 #ifdef GLAM_B1_PROF
-    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64();
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64();
     const long long prof_t0 = prof_last;
 #endif
-    for (int n = blockIdx.x * GPB + tid / G; n < a.N; n += gridDim.x * GPB) {
-        const int beg = ldio(a.rowptr, (unsigned)n * 4u), end = ldio(a.rowptr, (unsigned)n * 4u + 4u);
-        const float4 aiv = ld4o(a.a_ij, (unsigned)n * 32u);
-        const float4 mv = ld4o(a.stats, (unsigned)n * 32u), sv = ld4o(a.stats, (unsigned)n * 32u + 16u);
+    for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
+      const int n = base + tid / G;
+      if constexpr (!FD) { if (n >= a.N) break; }
+      if constexpr (FD) {
+        B1_STAMP(8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's piece of the A tile has landed (issued a tile ago)
+        B1_STAMP(9);
+        __syncthreads();
+        B1_STAMP(10);
+      }
+      // the node's own loads: with FD they fly under the MFMA phase
+      const int nc = min(n, a.N - 1);
+      const int beg = ldio(a.rowptr, (unsigned)nc * 4u), end = ldio(a.rowptr, (unsigned)nc * 4u + 4u);
+      const float4 aiv = ld4o(a.a_ij, (unsigned)nc * 32u);
+      const float4 mv = ld4o(a.stats, (unsigned)nc * 32u), sv = ld4o(a.stats, (unsigned)nc * 32u + 16u);
+      float4 dag[H][ITER], agr[H][ITER];
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) {
+              const unsigned off = (unsigned)nc * row_bytes + (unsigned)h * head_bytes + chunk_off[it];
+              agr[h][it] = ld4o(a.aggr, off);
+              if constexpr (!FD) dag[h][it] = ok[it] ? ld4o(a.d_aggr, off) : f4zero();
+          }
+      if constexpr (FD) {
+        // ---- d_aggr tile = d_out[base .. base+16, :] @ W_scale^T: wave w owns column tile t = w of every 64-column group ----
+        const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+        float4 af[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = 4 * g + kq;                          // logical 16-byte chunk of row c
+            af[g] = (base + c < a.N && 4 * ch < Cp) ? ld4(s_a + c * 64 + ((ch - c) & 15) * 4) : f4zero();
+        }
+        // k-group outer, column group inner: H independent accumulator chains keep the matrix pipe busy (one chain of 16
+        // dependent MFMAs stalls on its own latency), and only H B operands are live at a time
+        v4f acc[H];
+#pragma unroll
+        for (int cg = 0; cg < H; ++cg) acc[cg] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < GK) {
+                float4 bv[H];
+#pragma unroll
+                for (int cg = 0; cg < H; ++cg)
+                    bv[cg] = cg * 64 < HC ? ld4(s_img + ((4 * g + kq) * MP + cg * 64 + wave * 16 + c) * 4) : f4zero();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cg = 0; cg < H; ++cg)
+                        acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], j), f4get(bv[cg], j), acc[cg], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cg = 0; cg < H; ++cg) {
+            const int mcol = cg * 64 + 4 * c + wave;
+            if (mcol < HC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_tile[(kq * 4 + i) * LDT + mcol] = acc[cg][i];
+            }
+        }
+        B1_STAMP(11);
+        __syncthreads();
+        B1_STAMP(12);
+#pragma unroll
+        for (int h = 0; h < H; ++h) dag[h][0] = ok[0] ? ld4(s_tile + (tid / G) * LDT + h * Cp + q[0] * 4) : f4zero();
+        __syncthreads();
+        if (base + (int)gridDim.x * GPB < a.N) fetch_a(base + (int)gridDim.x * GPB);   // next tile's A rows (block-uniform)
+        B1_STAMP(13);
+      }
+      if (n < a.N) {
         B1_STAMP(0);
         float ai[H], m[H], inv[H], dot[H], dai[H];
-        float4 dag[H][ITER];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             ai[h] = f4get(aiv, h); m[h] = f4get(mv, h); inv[h] = 1.f / (f4get(sv, h) + 1e-16f); dai[h] = 0.f;
             float part = 0.f;
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const unsigned off = (unsigned)n * row_bytes + (unsigned)h * head_bytes + chunk_off[it];
-                dag[h][it] = ok[it] ? ld4o(a.d_aggr, off) : f4zero();
-                part += dot4(dag[h][it], ld4o(a.aggr, off));
+                if constexpr (FD) {
+                    const unsigned off = (unsigned)n * row_bytes + (unsigned)h * head_bytes + chunk_off[it];
+                    if (ok[it]) st4o(a.d_aggr_w, off, dag[h][it]);
+                }
+                part += dot4(dag[h][it], agr[h][it]);
             }
             // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
             dot[h] = group_sum<G>(part);
@@ -499,11 +613,14 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             st4o(a.d_a_ij, (unsigned)n * 32u, dv);
         }
         B1_STAMP(5);
+      }
     }
 #ifdef GLAM_B1_PROF
     if (tid == 0 && blockIdx.x < 4096) {
-        for (int k = 0; k < 6; ++k) g_b1_prof[blockIdx.x * 8 + k] = prof_acc[k];
-        g_b1_prof[blockIdx.x * 8 + 6] = prof_t0;
+        for (int k = 0; k < 6; ++k) g_b1_prof[blockIdx.x * 16 + k] = prof_acc[k];
+        for (int k = 8; k < 14; ++k) g_b1_prof[blockIdx.x * 16 + k] = prof_acc[k];
+        g_b1_prof[blockIdx.x * 16 + 6] = prof_t0;
+        g_b1_prof[blockIdx.x * 16 + 14] = prof_k0;
     }
 #endif
 
@@ -571,7 +688,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDs
             out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
     }
 #ifdef GLAM_B1_PROF
-    if (tid == 0 && blockIdx.x < 4096) g_b1_prof[blockIdx.x * 8 + 7] = clock64();
+    if (tid == 0 && blockIdx.x < 4096) g_b1_prof[blockIdx.x * 16 + 7] = clock64();
 #endif
 }
 
@@ -839,6 +956,16 @@ template <int H, int G, int ITER, int DE, bool EMUL>
 struct BwdDstOp {
     static void run(const BwdDstArgs& a, int grid, size_t lds, hipStream_t s) {
         if constexpr (G == 16 && ITER == 1 && EMUL) {
+            if (a.img_dagg) {
+                static bool big_lds = false;
+                if (lds > 64 * 1024 && !big_lds) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                    big_lds = true;
+                }
+                hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>), dim3(grid), dim3(kBlock), lds, s, a);
+                return;
+            }
             if (a.xw_bf16) {
                 hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true>), dim3(grid), dim3(kBlock), lds, s, a);
                 return;

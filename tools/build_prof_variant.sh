@@ -1,15 +1,16 @@
 #!/bin/bash
 # Builds an instrumented copy of libglam_hip.so for the in-kernel cycle profilers of tools/*_prof.py.
-# usage: tools/build_prof_variant.sh {b1|ts|tile|dma}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
+# usage: tools/build_prof_variant.sh {b1|b1n|ts|tile|dma}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
 set -e
 cd "$(dirname "$0")/../glam_amd/csrc"
 make -j8 > /dev/null
 case "$1" in
-  b1)   src=triplet_h3.hip; def=GLAM_B1_PROF ;;
+  b1)   src=triplet_h3.hip; def=GLAM_B1_PROF=1 ;;      # stamps drain the queues: where the latency is
+  b1n)  src=triplet_h3.hip; def=GLAM_B1_PROF=2 ;;      # stamps do not drain: the overlapped picture
   ts)   src=gemm.hip;       def=GLAM_TS_PROF ;;
   tile) src=tile.hip;       def=GLAM_TILE_PROF ;;
   dma)  src=triplet_dma.hip; def=GLAM_DMA_PROF ;;
-  *) echo "usage: $0 {b1|ts|tile|dma}"; exit 2 ;;
+  *) echo "usage: $0 {b1|b1n|ts|tile|dma}"; exit 2 ;;
 esac
 mkdir -p ../variants
 obj=/tmp/glam_${1}_prof.o
