@@ -33,7 +33,7 @@
 namespace glam {
 
 #ifdef GLAM_B1_PROF   // developer aid (tools/b1_prof.py): where a B1 wave spends its cycles
-__device__ long long g_b1_prof[4096 * 16];
+__device__ long long g_b1_prof[1024 * 32];
 #if GLAM_B1_PROF == 2     // stamps without draining the queues: the overlapped picture
 #define B1_WAIT() do { } while (0)
 #else
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
         for (int h = 0; h < H; ++h) dM[k][h] = 0.f;
 
 #ifdef GLAM_B1_PROF
-    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64();
+    long long prof_acc[32] = {}, prof_last = clock64();
     const long long prof_t0 = prof_last;
 #endif
     for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
       if constexpr (FD) {
         // ---- d_aggr tile = d_out[base .. base+16, :] @ W_scale^T: wave w owns column tile t = w of every 64-column group ----
         const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+        B1_STAMP(16);
         float4 af[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -462,6 +463,7 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
         v4f acc[H];
 #pragma unroll
         for (int cg = 0; cg < H; ++cg) acc[cg] = (v4f){0.f, 0.f, 0.f, 0.f};
+        B1_STAMP(17);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < GK) {
@@ -476,6 +478,10 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
                         acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], j), f4get(bv[cg], j), acc[cg], 0, 0, 0);
             }
         }
+#ifdef GLAM_B1_PROF
+        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[H - 1]));   // the stamp waits for the matrix pipe
+#endif
+        B1_STAMP(18);
 #pragma unroll
         for (int cg = 0; cg < H; ++cg) {
             const int mcol = cg * 64 + 4 * c + wave;
@@ -616,11 +622,10 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
       }
     }
 #ifdef GLAM_B1_PROF
-    if (tid == 0 && blockIdx.x < 4096) {
-        for (int k = 0; k < 6; ++k) g_b1_prof[blockIdx.x * 16 + k] = prof_acc[k];
-        for (int k = 8; k < 14; ++k) g_b1_prof[blockIdx.x * 16 + k] = prof_acc[k];
-        g_b1_prof[blockIdx.x * 16 + 6] = prof_t0;
-        g_b1_prof[blockIdx.x * 16 + 14] = prof_k0;
+    if (tid == 0 && blockIdx.x < 1024) {
+        for (int k = 0; k < 32; ++k) g_b1_prof[blockIdx.x * 32 + k] = prof_acc[k];
+        g_b1_prof[blockIdx.x * 32 + 6] = prof_t0;
+        g_b1_prof[blockIdx.x * 32 + 14] = prof_k0;
     }
 #endif
 
@@ -688,7 +693,7 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
             out[i] = (s_red[i] + s_red[P + i]) + (s_red[2 * P + i] + s_red[3 * P + i]);
     }
 #ifdef GLAM_B1_PROF
-    if (tid == 0 && blockIdx.x < 4096) g_b1_prof[blockIdx.x * 16 + 7] = clock64();
+    if (tid == 0 && blockIdx.x < 1024) g_b1_prof[blockIdx.x * 32 + 7] = clock64();
 #endif
 }
 

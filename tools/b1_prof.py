@@ -19,11 +19,13 @@ for _ in range(5):
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 nb = 512
-buf = (ctypes.c_longlong * (nb * 16))()
-assert raw.glam_debug_b1_prof(buf, nb * 16) == 0
-st = np.array(buf[:], dtype=np.int64).reshape(nb, 16)
+buf = (ctypes.c_longlong * (nb * 32))()
+assert raw.glam_debug_b1_prof(buf, nb * 32) == 0
+st = np.array(buf[:], dtype=np.int64).reshape(nb, 32)
+st = st[st[:, 7] != 0]
 names = {0: "rowptr/a_i/stats (+MFMA-phase tail)", 1: "d_aggr,aggr rows + dot", 2: "indices", 3: "neighbour rows/ea/a_j", 4: "compute",
-         5: "stores", 8: "loop top", 9: "wait vmcnt(0) (A tile, stores)", 10: "barrier 0", 11: "node loads issue, A reads, MFMA, tile writes",
+         5: "stores", 8: "loop top", 9: "wait vmcnt(0) (A tile, stores)", 10: "barrier 0", 16: "node loads issue", 17: "A fragment reads",
+         18: "B reads + MFMAs", 11: "tile writes",
          12: "barrier 1", 13: "dag reads, barrier 2, next A fetch"}
 for i, n in names.items():
     print(f"  {n:46s} mean {st[:, i].mean():8.0f}  max {st[:, i].max():8.0f}")
