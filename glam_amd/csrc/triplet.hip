@@ -158,8 +158,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     const size_t lds1 = ((size_t)WSZ + (fuse_dagg && img_floats > red_floats ? img_floats : red_floats)) * sizeof(float);
     int nblk = 0;
     GLAM_PROF_LABEL(fuse_dagg ? "d_aggr+k_triplet_bwd_dst" : "k_triplet_bwd_dst");
-    static const int b1_cap = [] { const char* e = getenv("GLAM_B1_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v < kBwdBlocks ? v : kBwdBlocks; }();
-    if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, b1_cap, &nblk))
+    if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
     if (after_b1) (void)hipEventRecord(after_b1, s);      // the B1 block partials are complete: a side stream may reduce them
