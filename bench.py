@@ -57,7 +57,7 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
     return {
         "k_stage_params": {"bound": "latency", "bytes": f * (C * HC + De * HC + 3 * HC + HC * C + C) + img(C, HC + 8) + img(HC, C) + img(C, HC) + img(HC + 8, C)},
         "k_ts_gemm<12, 4, 4>": {"bound": "mfma", "flops": 2 * N * C * (HC + 8), "bytes": f * N * (C + HC + 8) + img(C, HC + 8),
-                                "note": "two launches per step: x @ [W_node | Wa] (flops as given) and d_out @ W_scale^T (2*N*C*HC)"},
+                                "note": "x @ [W_node | Wa]; a second launch per step (d_out @ W_scale^T, 2*N*C*HC flops) only where B1 has no fused variant"},
         "k_triplet_fwd+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C},
         "k_triplet_fwd_pipe+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
                                       "note": "software-pipelined aggregate + update epilogue: the op's choice beyond the LLC"},
@@ -65,6 +65,10 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "k_triplet_fwd_pipe": {"bound": "hbm", "bytes": agg_fwd,
                                "note": "software-pipelined forward aggregate (csrc/triplet_dma.hip), same arithmetic and SURVEY §8(d) byte model"},
         "k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1},
+        # B1 with d_aggr = d_out @ W_scale^T as a per-tile MFMA prologue: d_aggr is written instead of read (same bytes), d_out and the
+        # weight image are read in addition
+        "d_aggr+k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
+                                     "note": "backward by target with the d_aggr GEMM fused in (one launch and one kernel boundary less)"},
         "k_triplet_bwd_src+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
         "k_reduce_partials": {"bound": "latency", "bytes": 0},
