@@ -388,6 +388,12 @@ def main():
                                   "grid": k["grid"], "workload": f"B={B}",
                                   "traffic_note": "PMC traffic is not collectable inside an unprofiled run: see profiles/ (FETCH_SIZE / "
                                                   "WRITE_SIZE passes of this command) and DESIGN.md §4"}
+            # the scatter-aggregate forward is the kernel BASELINE.json's metric names; by time the largest launch of the step may be
+            # another one (the backward-by-target kernel since it absorbed the d_aggr GEMM): name it and its own fraction
+            big = next(iter(kernels))
+            result["roofline"]["largest_launch_of_the_step"] = {
+                "kernel": big, "avg_launch_us": kernels[big]["avg_us"], "frac_hbm_peak": kernels[big].get("frac_hbm_peak"),
+                "frac_mfma_f32_peak": kernels[big].get("frac_mfma_f32_peak")}
         result["roofline_kernels"] = {"source": f"glam_prof_* per-dispatch timestamps, {args.prof_reps} eager executions of the captured step function "
                                                 "after the timed region", "sum_kernel_us_per_step": step_kernel_us, "kernels": kernels}
         iso = time_isolated_aggregate(conv, batch, x.detach(), args.prof_reps)
