@@ -48,7 +48,9 @@ class Architecture(torch.nn.Module):
 
     def forward(self, data_mol):
         with ops.weight_scope():     # weight re-layouts are shared by the message_steps applications of the block
-            return self._forward(data_mol)
+            out = self._forward(data_mol)
+        ops.poll_checks()            # deferred id checks of foreign batches (GLAM_VALIDATE=deferred) whose flag has come back
+        return out
 
     def _forward(self, data_mol):
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)                       # model.py:49

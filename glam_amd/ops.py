@@ -10,6 +10,7 @@ and its train loader does not shuffle (``src_1gp/trainer.py:37-38``).
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import os
 import weakref
@@ -23,6 +24,57 @@ from ._lib import GlamHipError, check, f32c, ptr, require_device, stream
 # --------------------------------------------------------------------------------------
 # CSR staging
 # --------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------
+# id validation of foreign batches
+# --------------------------------------------------------------------------------------
+# Tensors collated by glam_amd.data carry trust marks and are never read back.  Anything else (a PyG ``Batch``, hand-built
+# tensors) has its node / graph ids range-checked ON THE DEVICE while the CSR / ptr is built (bad entries are dropped there: no
+# out-of-bounds access either way); what remains is when the host learns about a raised flag:
+#   "sync"      (default) read the flag back at once: IndexError at the call that staged the tensor, like torch's own index checks
+#               on CPU — one host sync per NEW tensor (cached afterwards);
+#   "deferred"  copy the flag to pinned host memory asynchronously and raise at the next staging call, at ``check_pending()`` or at
+#               the end of ``Architecture.forward`` once the copy has landed — no host sync on the step (CUDA's own convention for
+#               device-side errors: reported late, never lost as long as the program keeps calling into the library);
+#   "off"       never look (the reference on a GPU: a device-side assert or silent garbage).
+VALIDATE = os.environ.get("GLAM_VALIDATE", "sync")
+_PENDING: collections.deque = collections.deque()
+_PINNED_FLAGS: list = []
+
+
+def _check_flag(err, message):
+    if VALIDATE == "off":
+        return
+    if VALIDATE == "deferred" and not torch.cuda.is_current_stream_capturing():
+        host = _PINNED_FLAGS.pop() if _PINNED_FLAGS else torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(err, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _PENDING.append((ev, host, message))
+        return
+    if int(err.item()) != 0:
+        raise IndexError(message)
+
+
+def poll_checks(block=False):
+    """Raise the IndexError of a deferred id check whose flag has come back (``block``: wait for all of them)."""
+    while _PENDING:
+        ev, host, message = _PENDING[0]
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        _PENDING.popleft()
+        bad = int(host[0]) != 0
+        _PINNED_FLAGS.append(host)
+        if bad:
+            raise IndexError(message + " (deferred check, GLAM_VALIDATE=deferred: raised after the call that staged the tensor)")
+
+
+def check_pending():
+    """Wait for every outstanding deferred id check and raise if one failed."""
+    poll_checks(block=True)
+
+
 class GraphIndex:
     """CSR-by-target ``(rowptr, src, eid)`` and CSR-by-source ``(colptr, dst, eid_t)`` of an
     int64 ``edge_index[2,E]`` over ``N`` nodes (PyG flow source_to_target: row 0 = source j,
@@ -54,8 +106,9 @@ class GraphIndex:
         # tensors built by glam_amd.data's collation carry a trust mark — the tensor's version counter at marking time: ids valid by
         # construction (checked once on the host when the dataset was packed) and not written since: no read-back, so a loop over
         # fresh batches has no host sync per step
-        if validate and getattr(edge_index, "_glam_trusted", None) != edge_index._version and int(self._err.item()) != 0:   # same failure class as torch's index_select on CPU
-            raise IndexError(f"edge_index holds node ids outside [0, {self.N})")
+        poll_checks()
+        if validate and getattr(edge_index, "_glam_trusted", None) != edge_index._version:   # same failure class as torch's index_select on CPU
+            _check_flag(self._err, f"edge_index holds node ids outside [0, {self.N})")
 
     TILE_TARGET_NODES = 80             # ~N/256 at the ESOL batch of 1024: one tile per CU
 
@@ -270,8 +323,9 @@ class SegmentPtr:
         err = torch.zeros(1, dtype=torch.int32, device=batch.device)
         check(_lib.load().glam_batch_ptr(ptr(batch.contiguous()), self.N, self.B, ptr(self.ptr), ptr(err), stream()),
               "glam_batch_ptr")
-        if validate and getattr(batch, "_glam_trusted", None) != batch._version and int(err.item()) != 0:
-            raise IndexError("batch must be non-decreasing with ids in [0, num_graphs)")
+        poll_checks()
+        if validate and getattr(batch, "_glam_trusted", None) != batch._version:
+            _check_flag(err, "batch must be non-decreasing with ids in [0, num_graphs)")
 
 
 _SP_CACHE: dict = {}

@@ -59,6 +59,41 @@ def test_csr_rejects_out_of_range_ids(device):
         ops.SegmentPtr(torch.tensor([0, 2, 1], device=device), 3)
 
 
+def test_deferred_id_validation_reports_late_but_never_loses_the_error(device, monkeypatch):
+    """GLAM_VALIDATE=deferred: staging a foreign tensor does not sync; a raised flag surfaces at check_pending() (or at the next
+    staging call once the copy has landed); valid tensors stay silent; 'off' never looks; bad edges are dropped on the device."""
+    monkeypatch.setattr(ops, "VALIDATE", "deferred")
+    ops.check_pending()
+    good = torch.tensor([[0, 1, 2], [1, 0, 1]], device=device)
+    ops.GraphIndex(good, 3)
+    ops.check_pending()                                         # nothing to report
+    bad = torch.tensor([[0, 1, 5], [1, 0, 2]], device=device)
+    gi = ops.GraphIndex(bad, 3)                                 # no exception here
+    assert gi.rowptr.tolist() == [0, 1, 2, 2], "the out-of-range edge is dropped, the rest is staged"
+    with pytest.raises(IndexError, match="deferred"):
+        ops.check_pending()
+    ops.check_pending()                                         # reported once
+    ops.SegmentPtr(torch.tensor([0, 2, 1], device=device), 3)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="batch must be non-decreasing"):
+        ops.GraphIndex(good.clone(), 3)                         # the next staging call polls
+    # a whole model pass over a foreign (unmarked) batch: no flag, no exception, same numbers as the validated path
+    b = synth_batch(16, seed=3).to(device)
+    plain = type(b)()
+    for k in ("x", "edge_index", "edge_attr", "batch", "y"):
+        setattr(plain, k, getattr(b, k).clone())
+    plain.num_graphs = b.num_graphs
+    torch.manual_seed(0)
+    net = model.Architecture(mol_in_dim=15, mol_edge_in_dim=4, mol_block="_TripletMessage", message_steps=2).to(device).eval()
+    out_deferred = net(plain)
+    ops.check_pending()
+    monkeypatch.setattr(ops, "VALIDATE", "sync")
+    assert torch.equal(net(b), out_deferred)
+    monkeypatch.setattr(ops, "VALIDATE", "off")
+    ops.GraphIndex(bad.clone(), 3)
+    ops.check_pending()
+
+
 def test_segment_ptr(device):
     batch = torch.tensor([0, 0, 2, 2, 2, 5], device=device)
     sp = ops.SegmentPtr(batch)
