@@ -1,0 +1,173 @@
+// Linear layers with a handful of outputs: y[N, M] = x[N, K] @ w[M, K]^T + b, M <= 16 (the model's output head
+// `lin_out1 = LinearBlock(e_dim, out_dim)`, reference src_1gp/model.py:47,61 — out_dim = 1 for the regression sets, 2 / 12 for
+// the multi-task ones).  A GEMM library treats this as a matrix product with one 16- or 256-wide tile column: 33 us forward and
+// 11 + 7 + 4 us backward for [1024, 1024] x [1024, 1] on this stack (profiles/r2d_kernel_stats_model_*.txt) — it is a row dot
+// product, i.e. 4 MB of reads.
+//   forward   one wave per row: lanes stride the row in float4, M accumulators, DPP / shuffle sum; w rows come from L1/L2.
+//   backward  block = (64-column chunk, row split): 16 column lanes x 16 row lanes; every thread walks its rows once, writing
+//             d_x[n, chunk] = sum_m dy[n, m] w[m, chunk] and accumulating d_w[m, chunk] += dy[n, m] x[n, chunk]; the 16 row lanes
+//             are summed through LDS in lane order, the row splits by a second launch in split order (no atomics: bit-reproducible).
+#include "common.h"
+
+namespace glam {
+
+constexpr int kNarrowMaxM = 16;
+constexpr int kNarrowSplits = 16;      // row splits of the backward (partials [splits][M + 1][K])
+
+template <int MT>
+__global__ void __launch_bounds__(kBlock) k_linear_narrow_fwd(const float* x, const float* w, const float* b, int N, int K, int M, float* y) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int n = blockIdx.x * (kBlock / 64) + wave; n < N; n += gridDim.x * (kBlock / 64)) {
+        float acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+        const float* xr = x + (size_t)n * K;
+        for (int k = 4 * lane; k < K; k += 256) {
+            const float4 xv = ld4(xr + k);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < M) {
+                    const float4 wv = ld4(w + (size_t)m * K + k);
+                    acc[m] = fmaf(xv.x, wv.x, acc[m]); acc[m] = fmaf(xv.y, wv.y, acc[m]);
+                    acc[m] = fmaf(xv.z, wv.z, acc[m]); acc[m] = fmaf(xv.w, wv.w, acc[m]);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = group_sum<64>(acc[m]);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < M) y[(size_t)n * M + m] = acc[m] + (b ? b[m] : 0.f);
+        }
+    }
+}
+
+// partial[split][m][k] (m < M: d_w, m == M: column 0 holds d_b's partial, written by the blocks of column chunk 0)
+template <int MT>
+__global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, const float* w, const float* dy, int N, int K, int M,
+                                                             float* dx, float* partial) {
+    __shared__ float4 s_red[16][17];            // [row lane][column lane] (+1: bank spread), one output row at a time
+    __shared__ float s_db[16][MT];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int chunk = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int k = chunk * 64 + 4 * cl;
+    const bool kok = k < K;
+    const int rows_per = (N + nsplit - 1) / nsplit;
+    const int r0 = split * rows_per, r1 = min(r0 + rows_per, N);
+    float4 wv[MT], acc[MT];
+    float dbs[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        wv[m] = (kok && m < M && dx) ? ld4(w + (size_t)m * K + k) : f4zero();
+        acc[m] = f4zero();
+        dbs[m] = 0.f;
+    }
+    for (int n = r0 + rl; n < r1; n += 16) {
+        const float4 xv = kok ? ld4(x + (size_t)n * K + k) : f4zero();
+        float4 dxv = f4zero();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (m < M) {
+                const float g = dy[(size_t)n * M + m];
+                fma4(acc[m], g, xv);
+                fma4(dxv, g, wv[m]);
+                dbs[m] += g;
+            }
+        if (dx && kok) st4(dx + (size_t)n * K + k, dxv);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < M) {                            // uniform: the barriers inside are reached by the whole block
+            s_red[rl][cl] = acc[m];
+            if (cl == 0) s_db[rl][m] = dbs[m];
+            __syncthreads();
+            if (rl == 0 && kok) {               // the 16 row lanes in lane order
+                float4 s = f4zero();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float4 v = s_red[r][cl]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+                st4(partial + ((size_t)split * (M + 1) + m) * K + k, s);
+            }
+            __syncthreads();
+        }
+    }
+    if (chunk == 0 && threadIdx.x < M) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += s_db[r][threadIdx.x];
+        partial[((size_t)split * (M + 1) + M) * K + threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_linear_narrow_reduce(const float* partial, int nsplit, int K, int M, float* dw, float* db) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < M * K) {
+        const int m = idx / K, k = idx - m * K;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * (M + 1) + m) * K + k];
+        dw[idx] = s;
+    } else if (db && idx < M * K + M) {
+        const int m = idx - M * K;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * (M + 1) + M) * K + m];
+        db[m] = s;
+    }
+}
+
+}  // namespace glam
+
+using namespace glam;
+
+static int narrow_dims(const char* fn, int64_t N, int K, int M) {
+    if (N < 0 || N > INT32_MAX) return fail(GLAM_E_INVALID, "%s: N out of range", fn);
+    if (K < 16 || (K & 3)) return fail(GLAM_E_UNSUPPORTED, "%s: K=%d must be a multiple of 4, at least 16", fn, K);
+    if (M < 1 || M > kNarrowMaxM) return fail(GLAM_E_UNSUPPORTED, "%s: M=%d not in 1..%d", fn, M, kNarrowMaxM);
+    return GLAM_OK;
+}
+
+extern "C" int glam_linear_narrow_supported(int K, int M) { return K >= 16 && (K & 3) == 0 && M >= 1 && M <= kNarrowMaxM; }
+
+extern "C" int glam_linear_narrow_fwd(const float* x, const float* w, const float* b, int64_t N, int K, int M, float* y, void* stream) {
+    if (int rc = narrow_dims("glam_linear_narrow_fwd", N, K, M)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && w && y, "glam_linear_narrow_fwd: null pointer");
+    GLAM_REQUIRE(aligned16(x) && aligned16(w), "glam_linear_narrow_fwd: x and w must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(N, kBlock / 64);
+    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_fwd<1>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
+    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_fwd<2>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
+    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_fwd<4>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
+    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_fwd<8>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
+    else hipLaunchKernelGGL((k_linear_narrow_fwd<16>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
+    GLAM_LAUNCH_CHECK("glam_linear_narrow_fwd");
+    return GLAM_OK;
+}
+
+extern "C" size_t glam_linear_narrow_bwd_workspace_bytes(int K, int M) {
+    return (size_t)kNarrowSplits * (size_t)(M + 1) * (size_t)K * sizeof(float);
+}
+
+extern "C" int glam_linear_narrow_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw,
+                                      float* db, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = narrow_dims("glam_linear_narrow_bwd", N, K, M)) return rc;
+    GLAM_REQUIRE(dw && ws && ws_bytes >= glam_linear_narrow_bwd_workspace_bytes(K, M), "glam_linear_narrow_bwd: null output / workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        (void)hipMemsetAsync(dw, 0, (size_t)M * K * sizeof(float), s);
+        if (db) (void)hipMemsetAsync(db, 0, (size_t)M * sizeof(float), s);
+        return GLAM_OK;
+    }
+    GLAM_REQUIRE(x && w && dy, "glam_linear_narrow_bwd: null pointer");
+    GLAM_REQUIRE(aligned16(x) && aligned16(w) && aligned16(dx) && aligned16(ws), "glam_linear_narrow_bwd: pointers must be 16-byte aligned");
+    float* partial = static_cast<float*>(ws);
+    const int nsplit = (int)(N < kNarrowSplits * 16 ? (N + 15) / 16 : kNarrowSplits);
+    const dim3 grid((K + 63) / 64, nsplit);
+    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_bwd<1>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
+    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_bwd<2>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
+    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_bwd<4>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
+    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_bwd<8>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
+    else hipLaunchKernelGGL((k_linear_narrow_bwd<16>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
+    GLAM_LAUNCH_CHECK("glam_linear_narrow_bwd");
+    hipLaunchKernelGGL(k_linear_narrow_reduce, dim3((M * K + M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, nsplit, K, M, dw, db);
+    GLAM_LAUNCH_CHECK("glam_linear_narrow_bwd(reduce)");
+    return GLAM_OK;
+}

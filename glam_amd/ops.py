@@ -962,11 +962,52 @@ def linear_tall_supported(K, M):
     return K % 4 == 0 and M % 4 == 0 and M <= 320 and K + 1 <= 128
 
 
+class _LinearNarrow(torch.autograd.Function):
+    """``y[N, M] = x[N, K] @ w[M, K]^T + b`` for a handful of outputs (M <= 16: the model's output head, out_dim 1 / 2 / 12): row dot
+    products on ``glam_linear_narrow_fwd``; backward ``d_x``, ``d_w``, ``d_b`` in one pass over ``x`` + a fixed-order reduction
+    (``glam_linear_narrow_bwd``) — the GEMM library took 33 + 22 us for 1024 x 1024 -> 1, this takes a few us each way."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        x, w = f32c(x, "x"), f32c(w, "weight")
+        b = None if b is None else f32c(b, "bias")
+        N, K = x.shape
+        M = w.size(0)
+        y = torch.empty(N, M, dtype=torch.float32, device=x.device)
+        check(_lib.load().glam_linear_narrow_fwd(ptr(x), ptr(w), ptr(b), N, K, M, ptr(y), stream()), "glam_linear_narrow_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        lib = _lib.load()
+        f = dict(dtype=torch.float32, device=x.device)
+        dx = torch.empty(N, K, **f) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(M, K, **f)
+        db = torch.empty(M, **f) if ctx.has_bias else None
+        ws = torch.empty(lib.glam_linear_narrow_bwd_workspace_bytes(K, M), dtype=torch.uint8, device=x.device)
+        check(lib.glam_linear_narrow_bwd(ptr(x), ptr(w), ptr(dy), N, K, M, ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(), stream()),
+              "glam_linear_narrow_bwd")
+        return dx, dw, db
+
+
 def linear(x, weight, bias=None):
-    """``F.linear`` on the hand-written MFMA kernels when the shape is in their table (the layer-sized linears of the
-    path: GRU gates 60->180, input embedding 15->60, ...); larger / odd layers (e.g. the 300->1024 readout MLP) stay
-    on the library GEMM, which is the right tool for them."""
+    """``F.linear`` on the hand-written kernels when the shape is in their table (the layer-sized linears of the
+    path: GRU gates 60->180, input embedding 15->60, ... on the MFMA kernels; heads with <= 16 outputs as row dot products);
+    larger / odd layers (e.g. the 300->1024 readout MLP) stay on the library GEMM, which is the right tool for them."""
     M, K = weight.shape
+    if x.dim() == 2 and x.is_cuda and M <= 16 and K >= 64 and K % 4 == 0 and not linear_supported(K, M):
+        return _LinearNarrow.apply(x, weight, bias)
     if x.dim() != 2 or not linear_supported(K, M):
         return torch.nn.functional.linear(x, weight, bias)
     Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4

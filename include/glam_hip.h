@@ -407,6 +407,17 @@ int glam_s2s_attn_fwd(const float* x, const float* q, const int32_t* ptr, int64_
 int glam_s2s_attn_bwd(const float* x, const float* q, const float* r, const float* stats, const float* d_r,
                       const int32_t* ptr, int64_t N, int64_t B, int D, float* d_x, float* d_q, void* stream);
 
+/* ---- narrow-output linear (the model's output head) -------------------------------------------------------------------
+ * y[N, M] = x[N, K] @ w[M, K]^T + b for M <= 16, K % 4 == 0: replaces torch.nn.functional.linear / its autograd for
+ * `lin_out1 = LinearBlock(e_dim, out_dim)` (reference src_1gp/model.py:47,61; layer.py:223-237), where a GEMM library spends
+ * 33 us forward + 22 us backward on what is a row dot product.  b, dx, db may be NULL.  Backward: dx[N, K], dw[M, K], db[M];
+ * ws >= glam_linear_narrow_bwd_workspace_bytes(K, M), 16-byte aligned.  Deterministic (fixed-order sums, no atomics). */
+int glam_linear_narrow_supported(int K, int M);
+int glam_linear_narrow_fwd(const float* x, const float* w, const float* b, int64_t N, int K, int M, float* y, void* stream);
+size_t glam_linear_narrow_bwd_workspace_bytes(int K, int M);
+int glam_linear_narrow_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw, float* db,
+                           void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import torch
 import oracle.glam_oracle as O
 from glam_amd import layer, model, ops
 from glam_amd.data import Data, synth_batch, synth_protein_batch
-from tests.conftest import Golden, golden_names, assert_close
+from tests.conftest import Golden, golden_names, assert_close, assert_fp32_parity
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -1815,3 +1815,51 @@ def test_pipelined_fused_forward_equals_the_general_fused_kernel(device, monkeyp
     monkeypatch.setattr(ops, "PIPE_FUSED", "1")
     with ops.feature_storage("bf16"):
         assert torch.isfinite(conv(x0, b.edge_index, b.edge_attr)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# narrow-output linear (the model's output head, model.py:47,61): row dot products instead of a library GEMM
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K,M,bias", [(1024, 1024, 1, True), (1024, 1024, 2, True), (37, 300, 12, True), (1, 64, 16, False),
+                                        (2039, 1024, 1, True), (640, 1024, 5, False)])
+def test_narrow_linear_against_the_fp64_twin(device, N, K, M, bias):
+    from tests.conftest import assert_fp32_parity
+    g = torch.Generator().manual_seed(N * 7 + K + M)
+    x = torch.randn(N, K, generator=g)
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    b = torch.randn(M, generator=g) if bias else None
+    cot = torch.randn(N, M, generator=g)
+
+    def run(dt, dev, fn):
+        xs = x.detach().clone().to(dev, dt).requires_grad_(True)
+        ws = w.detach().clone().to(dev, dt).requires_grad_(True)
+        bs = None if b is None else b.detach().clone().to(dev, dt).requires_grad_(True)
+        y = fn(xs, ws, bs)
+        y.backward(cot.to(dev, dt))
+        return [y, xs.grad, ws.grad] + ([] if bs is None else [bs.grad])
+
+    ref64 = run(torch.float64, "cpu", torch.nn.functional.linear)
+    ref32 = run(torch.float32, "cpu", torch.nn.functional.linear)
+    assert ops._lib.load().glam_linear_narrow_supported(K, M)
+    got = run(torch.float32, device, ops.linear)
+    for name, a, r64, r32 in zip(["y", "d_x", "d_w", "d_b"], got, ref64, ref32):
+        assert_fp32_parity(a, r64, r32, f"narrow linear {N}x{K}->{M} {name}", out_tol=1e-5 if name == "y" else None)
+    # bit-reproducible (fixed-order sums), and an input without gradient skips d_x
+    again = run(torch.float32, device, ops.linear)
+    assert all(torch.equal(a, c) for a, c in zip(got, again))
+    xs = x.detach().clone().to(device)
+    ws = w.detach().clone().to(device).requires_grad_(True)
+    ops.linear(xs, ws, None if b is None else b.to(device)).backward(cot.to(device))
+    assert torch.equal(ws.grad, got[2])
+
+
+def test_narrow_linear_is_what_the_output_head_runs(device, monkeypatch):
+    calls = []
+    real = ops._LinearNarrow.apply
+    monkeypatch.setattr(ops._LinearNarrow, "apply", staticmethod(lambda *a: (calls.append(a[1].shape), real(*a))[1]))
+    b = synth_batch(8, seed=1).to(device)
+    net = model.Architecture(mol_block="_TripletMessage", out_dim=2).to(device).eval()
+    out = net(b)
+    assert out.shape == (8, 2) and calls == [torch.Size([2, 1024])]
+    raw = ops._lib.load()
+    assert not raw.glam_linear_narrow_supported(1024, 17) and not raw.glam_linear_narrow_supported(1022, 1)

@@ -39,3 +39,14 @@ print(f"preset={preset}: aten ops with device time, per step")
 for e in rows[:40]:
     stack = " <- ".join(s.split("/")[-1] for s in e.stack[:3]) if e.stack else ""
     print(f"{e.key:32s} n/step={e.count / R:5.1f} dev_us/step={e.device_time_total / R:8.1f}   {stack[:150]}")
+
+# second view: the same ops grouped by input shapes (tells parameter-gradient accumulation from activation-gradient sums)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
+    for _ in range(R):
+        body()
+    torch.cuda.synchronize()
+rows = [e for e in prof2.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0]
+rows.sort(key=lambda e: -e.device_time_total)
+print("by input shape:")
+for e in rows[:40]:
+    print(f"{e.key:28s} n/step={e.count / R:5.1f} dev_us/step={e.device_time_total / R:8.1f}   {str(e.input_shapes)[:120]}")
