@@ -71,6 +71,8 @@ SIGNATURES = {
     "glam_gru_gates_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "glam_wgrad_gemm_pair": (_i32, ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32] * 2) + [_i64, _vp, _sz, _vp]),
     "glam_ts_gemm_celu": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
+    "glam_ts_gemm_add": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
+    "glam_wgrad_gemm_pair_acc": (_i32, ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32] * 2) + [_i64, _vp, _sz, _vp, _vp, _vp]),
     "glam_gru_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "glam_gru_tail_bwd": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _f32] + [_vp] * 5),
     "glam_bias_res_act_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "glam_triplet_layer_bwd_params_x16": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 10 + [_sz, _vp]),
     "glam_triplet_layer_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "glam_triplet_layer_bwd_params": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 11 + [_sz, _vp]),
+    "glam_triplet_layer_bwd_params_acc": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 16 + [_sz, _vp]),
     "glam_triplet_layer_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
 }
 

@@ -17,6 +17,7 @@ struct TsArgs {
     int a_celu;                            // 1: the GEMM consumes celu(A) instead of A
     const float* cgrad_src; int ld_cgrad;  // non-null: out1[r, c] *= celu'(cgrad_src[r, c]) (chain rule through a folded CELU)
     int out1_bf16;                         // 1: out1 points at bf16[N, ldo1] (round-to-nearest-even; storage of gathered rows)
+    const float* addend; int ld_add;       // non-null: out1[r, c] += addend[r, c] last (a second gradient path into the same tensor)
 };
 
 struct WgArgs {
@@ -35,6 +36,7 @@ struct WgArgs {
 struct ReduceJob {
     int kind; const float* partial; int nsplit; int n; int I, J, si, sj; float* out; float* out2; int split_at;
     int first_block;
+    const float* addend;                   // kind 0, non-null: out[i, j] = sum + addend[i, j] (same strides: a gradient carry)
 };
 struct ReduceArgs { ReduceJob job[3]; int njobs; };
 

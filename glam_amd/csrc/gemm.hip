@@ -180,6 +180,10 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                         const float4 xs = ld4(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0);
                         v.x *= celu1_grad(xs.x); v.y *= celu1_grad(xs.y); v.z *= celu1_grad(xs.z); v.w *= celu1_grad(xs.w);
                     }
+                    if (a.addend && m0 < a.M1) {
+                        const float4 ad = ld4(a.addend + (size_t)rr * a.ld_add + m0);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
                     if (m0 < a.M1) {
                         if (a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
                         else st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
@@ -196,6 +200,10 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
                     if (a.cgrad_src && m0 < a.M1) {
                         const float2 xs = *reinterpret_cast<const float2*>(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0);
                         v.x *= celu1_grad(xs.x); v.y *= celu1_grad(xs.y);
+                    }
+                    if (a.addend && m0 < a.M1) {
+                        const float2 ad = *reinterpret_cast<const float2*>(a.addend + (size_t)rr * a.ld_add + m0);
+                        v.x += ad.x; v.y += ad.y;
                     }
                     if (m0 < a.M1) *reinterpret_cast<float2*>(a.out1 + (size_t)rr * a.ldo1 + m0) = v;
                     else *reinterpret_cast<float2*>(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1)) = v;
@@ -344,7 +352,10 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
         if (J.kind == 0) {
             const int o = e & 4095, r = o & 3, lane = (o >> 2) & 63, t = o >> 8;
             const int i = (e >> 12) * 64 + 4 * ((lane >> 4) * 4 + r) + (t >> 2), j = 4 * (lane & 15) + (t & 3);
-            if (i < J.I && j < J.J) J.out[(size_t)i * J.si + (size_t)j * J.sj] = s;
+            if (i < J.I && j < J.J) {
+                const size_t o2 = (size_t)i * J.si + (size_t)j * J.sj;
+                J.out[o2] = J.addend ? s + J.addend[o2] : s;
+            }
         } else if (e < J.split_at) {
             if (J.out) J.out[e] = s;
         } else {
@@ -537,27 +548,59 @@ extern "C" int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, con
     return launch_ts_gemm(a, (hipStream_t)stream);
 }
 
-extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
-                                    int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
-                                    const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
-                                    int64_t N, void* ws, size_t ws_bytes, void* stream) {
-    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_pair: N out of range");
+// out[N, M] = A[N, K] @ W + bias + addend: the GRU backward's d_h = d_gh @ W_hh^T + (the direct z * g path), one launch
+extern "C" int glam_ts_gemm_add(const float* A, int K, int lda, const float* Wimg, const float* bias, float* out, int M, int ldo,
+                                const float* addend, int ld_add, int64_t N, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_ts_gemm_add: N out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(A && Wimg && out && addend, "glam_ts_gemm_add: null pointer");
+    GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias) && aligned16(addend) && (ld_add & 3) == 0,
+                 "glam_ts_gemm_add: pointers must be 16-byte aligned");
+    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N, 0, nullptr, 0, 0, addend, ld_add};
+    return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
+static int wgrad_pair_impl(const char* fn, const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
+                           int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                           const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
+                           int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, hipStream_t s) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
     if (N == 0) {
-        GLAM_REQUIRE(out_a && out_b, "glam_wgrad_gemm_pair: null pointer");
-        if (int rc = zero_product(out_a, Ia + (ones_a ? 1 : 0), Ja + (qones_a ? 1 : 0), si_a, sj_a, (hipStream_t)stream)) return rc;
-        return zero_product(out_b, Ib + (ones_b ? 1 : 0), Jb + (qones_b ? 1 : 0), si_b, sj_b, (hipStream_t)stream);
+        GLAM_REQUIRE(out_a && out_b, "%s: null pointer", fn);
+        GLAM_REQUIRE(!add_a && !add_b, "%s: N = 0 with an addend is not supported (add on the host side)", fn);
+        if (int rc = zero_product(out_a, Ia + (ones_a ? 1 : 0), Ja + (qones_a ? 1 : 0), si_a, sj_a, s)) return rc;
+        return zero_product(out_b, Ib + (ones_b ? 1 : 0), Jb + (qones_b ? 1 : 0), si_b, sj_b, s);
     }
-    GLAM_REQUIRE(Pa && Qa && out_a && Pb && Qb && out_b && ws, "glam_wgrad_gemm_pair: null pointer");
-    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_pair: workspace too small");
-    GLAM_REQUIRE(aligned16(Qa) && aligned16(Pa) && aligned16(Qb) && aligned16(Pb), "glam_wgrad_gemm_pair: P / Q must be 16-byte aligned");
+    GLAM_REQUIRE(Pa && Qa && out_a && Pb && Qb && out_b && ws, "%s: null pointer", fn);
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace too small", fn);
+    GLAM_REQUIRE(aligned16(Qa) && aligned16(Pa) && aligned16(Qb) && aligned16(Pb), "%s: P / Q must be 16-byte aligned", fn);
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     WgArgs a{Pa, Ia, ldpa, nullptr, 0, 0, ones_a, Qa, Ja, ldqa, qones_a, (int)N, 0, partial, 0, 0, qcelu_a};
     WgArgs b{Pb, Ib, ldpb, nullptr, 0, 0, ones_b, Qb, Jb, ldqb, qones_b, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0, qcelu_b};
     ReduceArgs ra{};
     ra.njobs = 2;
-    if (int rc = launch_wgrad_partials2(a, out_a, si_a, sj_a, &ra.job[0], b, out_b, si_b, sj_b, &ra.job[1], (hipStream_t)stream))
-        return rc;
-    return launch_final_reduce(ra, (hipStream_t)stream);
+    if (int rc = launch_wgrad_partials2(a, out_a, si_a, sj_a, &ra.job[0], b, out_b, si_b, sj_b, &ra.job[1], s)) return rc;
+    ra.job[0].addend = add_a;
+    ra.job[1].addend = add_b;
+    return launch_final_reduce(ra, s);
+}
+
+extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
+                                    int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                                    const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
+                                    int64_t N, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_pair_impl("glam_wgrad_gemm_pair", Pa, Ia, ldpa, ones_a, Qa, Ja, ldqa, qones_a, qcelu_a, out_a, si_a, sj_a, Pb, Ib, ldpb,
+                           ones_b, Qb, Jb, ldqb, qones_b, qcelu_b, out_b, si_b, sj_b, N, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// the same with out_x[i, j] = product + add_x[i, j] (addends laid out like the outputs; either may be NULL): the gradient carry of
+// parameters shared by several applications of a block is summed by the reduction that writes the gradient
+extern "C" int glam_wgrad_gemm_pair_acc(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
+                                        int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                                        const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
+                                        int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, void* stream) {
+    return wgrad_pair_impl("glam_wgrad_gemm_pair_acc", Pa, Ia, ldpa, ones_a, Qa, Ja, ldqa, qones_a, qcelu_a, out_a, si_a, sj_a, Pb, Ib,
+                           ldpb, ones_b, Qb, Jb, ldqb, qones_b, qcelu_b, out_b, si_b, sj_b, N, ws, ws_bytes, add_a, add_b, (hipStream_t)stream);
 }
 
 extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,

@@ -290,6 +290,9 @@ struct ParamGradArgs {
     int C, H, De, Cp, Dp;
     float* d_wn; float* d_we; float* d_att; float* d_wsc; float* d_bias;
     int blocksA, blocksB, blocksC;
+    // optional addends, laid out like the outputs (the gradient carry of a layer applied message_steps times: summed here instead
+    // of by a separate add launch)
+    const float* c_wn; const float* c_we; const float* c_att; const float* c_wsc; const float* c_bias;
 };
 
 // element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (inverse of the decode in k_final_reduce)
@@ -333,10 +336,10 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         const int idx = b * kBlock + tid;
         if (idx < H * C * C) {
             const int row = idx / C, col = idx - row * C, h = row / C, c = row - h * C;
-            a.d_wsc[idx] = wg_sum(a.p1, a.ns1, h * Cp + c, col);
+            a.d_wsc[idx] = wg_sum(a.p1, a.ns1, h * Cp + c, col) + (a.c_wsc ? a.c_wsc[idx] : 0.f);
         } else if (idx < H * C * C + C) {
             const int col = idx - H * C * C;
-            a.d_bias[col] = wg_sum(a.p1, a.ns1, HC, col);
+            a.d_bias[col] = wg_sum(a.p1, a.ns1, HC, col) + (a.c_bias ? a.c_bias[col] : 0.f);
         }
         return;
     }
@@ -353,7 +356,7 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
             float v = wg_sum(a.p2, a.ns2, h * Cp + c, k);
             v = fmaf(s_dwa[0][h], a.att[(size_t)h * 3 * C + c], v);
             v = fmaf(s_dwa[0][4 + h], a.att[(size_t)h * 3 * C + 2 * C + c], v);
-            a.d_wn[(size_t)k * H * C + tid] = v;
+            a.d_wn[(size_t)k * H * C + tid] = v + (a.c_wn ? a.c_wn[(size_t)k * H * C + tid] : 0.f);
         }
         return;
     }
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
                 for (; k < C; ++k) v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
                 v = (v0 + v1) + (v2 + v3);
             }
-            a.d_att[(size_t)h * 3 * C + tid] = v;
+            a.d_att[(size_t)h * 3 * C + tid] = v + (a.c_att ? a.c_att[(size_t)h * 3 * C + tid] : 0.f);
         }
         return;
     }
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
             const int kk = o / (H * C), m = o - kk * H * C, h = m / C, c = m - h * C;
             const float dwe = b1_sum16(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, lg);
             const float dm = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
-            if (lg == 0) a.d_we[o] = fmaf(dm, a.att[(size_t)h * 3 * C + C + c], dwe);
+            if (lg == 0) a.d_we[o] = fmaf(dm, a.att[(size_t)h * 3 * C + C + c], dwe) + (a.c_we ? a.c_we[o] : 0.f);
         }
     }
 }
@@ -565,6 +568,7 @@ namespace {
 struct ParamOut {   // raw parameters and their gradient buffers; null d_wn: the caller wants `dstaged` instead
     const float* wn; const float* we; const float* att; int C, De;
     float* d_wn; float* d_we; float* d_att; float* d_wsc; float* d_bias;
+    const float* c_wn; const float* c_we; const float* c_att; const float* c_wsc; const float* c_bias;   // optional addends (carry)
 };
 }  // namespace
 
@@ -645,7 +649,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
         const int C = po->C, De = po->De;
         ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
-                         (H * C * C + C + kBlock - 1) / kBlock, C, H};
+                         (H * C * C + C + kBlock - 1) / kBlock, C, H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
         if (ss) {
             // side: roles A (d_weight_scale, d_bias <- product 1) and D (d_weight_edge <- B1 partials + d_M), after B1
@@ -705,6 +709,29 @@ extern "C" int glam_triplet_layer_bwd_params(const float* x, const float* edge_a
                  "glam_triplet_layer_bwd_params: null pointer");
     if (N == 0) return zero_param_grads(C, H, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, stream);
     const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
+    return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
+                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po);
+}
+
+// The same with addends for the five parameter gradients (each laid out like its output, any of them NULL): out = gradient + addend.
+// A layer applied message_steps times with shared weights (src_1gp/model.py:53-54) hands the gradient accumulated by its later
+// applications in here, so that the sum costs no launch of its own.
+extern "C" int glam_triplet_layer_bwd_params_acc(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                                 const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                                 const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                                 const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                                 int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                                 const float* weight_node, const float* weight_edge, const float* att, float* d_x,
+                                                 float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
+                                                 float* d_bias, const float* add_weight_node, const float* add_weight_edge,
+                                                 const float* add_att, const float* add_weight_scale, const float* add_bias,
+                                                 float* d_edge_attr, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = dims_ok("glam_triplet_layer_bwd_params_acc", C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
+                 "glam_triplet_layer_bwd_params_acc: null pointer");
+    GLAM_REQUIRE(N > 0, "glam_triplet_layer_bwd_params_acc: N = 0 (add on the host side)");
+    const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias,
+                      add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
     return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
                           Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po);
 }

@@ -565,6 +565,17 @@ class _TripletLayer(torch.autograd.Function):
             if ctx.carried:
                 return d_x, None, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
             return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
+        if ctx.carried and d_carry is not None and N > 0:
+            # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
+            d_carry = f32c(d_carry, "d_carry")
+            c_wn, c_we, c_att, c_wsc, c_bias = d_carry.split(sizes)
+            check(lib.glam_triplet_layer_bwd_params_acc(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
+                                                        ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
+                                                        ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
+                                                        ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(c_wn), ptr(c_we),
+                                                        ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(d_ea), ptr(ws), ws.numel(), stream()),
+                  "glam_triplet_layer_bwd_params_acc")
+            return d_x, d_ea, None, None, None, None, None, None, None, None, flatg
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
@@ -1300,12 +1311,19 @@ class _GruBlock(torch.autograd.Function):
         # with the folded CELU the epilogue multiplies by celu'(x): dx is the gradient of the RAW input
         check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
               "glam_ts_gemm_celu")
-        check(lib.glam_ts_gemm(ptr(d_gh), M, M, None, 0, 0, ptr(image_t(w_hh)), None, ptr(dh), C, C, None, 0, 0, N, st), "glam_ts_gemm")
-        dh.add_(d_h)                                  # + the direct z * g path of the gate equations
+        # d_h = d_gh @ W_hh^T + the direct z * g path of the gate equations (the addend of the GEMM's epilogue)
+        check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         dwb = torch.empty(2, M + 1, C + 1, **f)          # one buffer: the gradient carry adds it with one kernel
         dwb_ih, dwb_hh = dwb[0], dwb[1]
+        if ctx.carried and d_carry is not None and N > 0:
+            # the carry (same [2, M + 1, C + 1] layout) is added by the reduction that writes the gradients
+            dc = f32c(d_carry, "d_carry").view(2, M + 1, C + 1)
+            check(lib.glam_wgrad_gemm_pair_acc(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
+                                               ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(),
+                                               ptr(dc[0]), ptr(dc[1]), st), "glam_wgrad_gemm_pair_acc")
+            return dx, dh, d_id, None, None, None, None, None, None, None, dwb.view(-1), None
         check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
                                        ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),
               "glam_wgrad_gemm_pair")

@@ -184,11 +184,21 @@ int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const fl
                          int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
                          const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
                          int64_t N, void* ws, size_t ws_bytes, void* stream);
+/* the same with out_x[i, j] = product + add_x[i, j] (addends laid out like the outputs, either may be NULL; N > 0 when one is
+ * given): the gradient carry of the GRU weights shared by the message steps (src_1gp/layer.py:247, model.py:53-54). */
+int glam_wgrad_gemm_pair_acc(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
+                         int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
+                         const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
+                         int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, void* stream);
 /* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:
  * a_celu = 1: out = celu(A) @ W + bias; cgrad_src non-NULL: out[r,c] *= celu'(cgrad_src[r,c]) (the chain rule of the same
  * fold on the way back); qcelu_* in glam_wgrad_gemm_pair: the weight gradient uses celu(Q). */
 int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, const float* Wimg, const float* bias, float* out, int M,
                       int ldo, const float* cgrad_src, int ld_cgrad, int64_t N, void* stream);
+/* out[N, M] = A[N, K] @ W + bias + addend[N, M] (row pitch ld_add, a multiple of 4): a second gradient path into the same tensor
+ * (the GRU backward's d_h = d_gh @ W_hh^T + the direct z * g term) without an add launch. */
+int glam_ts_gemm_add(const float* A, int K, int lda, const float* Wimg, const float* bias, float* out, int M, int ldo,
+                     const float* addend, int ld_add, int64_t N, void* stream);
 size_t glam_wgrad_workspace_bytes(void);
 int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
                     int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, void* ws,
@@ -252,6 +262,19 @@ int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const 
                                   const float* att, float* d_x, float* d_weight_node, float* d_weight_edge, float* d_att,
                                   float* d_weight_scale, float* d_bias, float* d_edge_attr, void* ws, size_t ws_bytes,
                                   void* stream);
+
+/* glam_triplet_layer_bwd_params with addends for the five parameter gradients (each laid out like its output, any of them
+ * NULL): out = gradient + addend.  The block is applied message_steps times with shared weights (src_1gp/model.py:53-54); the
+ * gradient already accumulated by its later applications enters here instead of through a separate add launch.  N > 0. */
+int glam_triplet_layer_bwd_params_acc(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                                      const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int C, int H, int De,
+                                      int Cp, int Dp, float slope, const float* weight_node, const float* weight_edge,
+                                      const float* att, float* d_x, float* d_weight_node, float* d_weight_edge, float* d_att,
+                                      float* d_weight_scale, float* d_bias, const float* add_weight_node,
+                                      const float* add_weight_edge, const float* add_att, const float* add_weight_scale,
+                                      const float* add_bias, float* d_edge_attr, void* ws, size_t ws_bytes, void* stream);
 
 /* bf16 STORAGE of the gathered rows (BASELINE.json configs[2]: "bf16"; the reference itself is fp32 only): xw16 is
  * bf16[N, H*Cp], written round-to-nearest-even by the node GEMM's epilogue and widened on load by the aggregate kernels;
