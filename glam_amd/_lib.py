@@ -55,6 +55,8 @@ SIGNATURES = {
     "glam_triplet_fwd_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "glam_triplet_layer_fwd_ell": (_i32, [_vp] * 5 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "glam_colsum_workspace_bytes": (_sz, [_i32]),
+    "glam_colsum": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "glam_linear_narrow_supported": (_i32, [_i32, _i32]),
     "glam_linear_narrow_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "glam_linear_narrow_bwd_workspace_bytes": (_sz, [_i32, _i32]),
@@ -72,7 +74,7 @@ SIGNATURES = {
     "glam_wgrad_gemm_pair": (_i32, ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32] * 2) + [_i64, _vp, _sz, _vp]),
     "glam_ts_gemm_celu": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
     "glam_ts_gemm_add": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
-    "glam_wgrad_gemm_pair_acc": (_i32, ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32] * 2) + [_i64, _vp, _sz, _vp, _vp, _vp]),
+    "glam_wgrad_gemm_pair_split": (_i32, ([_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp] * 2) + [_i64, _vp, _sz] + [_vp] * 5),
     "glam_gru_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "glam_gru_tail_bwd": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _f32] + [_vp] * 5),
     "glam_bias_res_act_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),

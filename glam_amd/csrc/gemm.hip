@@ -353,8 +353,12 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
             const int o = e & 4095, r = o & 3, lane = (o >> 2) & 63, t = o >> 8;
             const int i = (e >> 12) * 64 + 4 * ((lane >> 4) * 4 + r) + (t >> 2), j = 4 * (lane & 15) + (t & 3);
             if (i < J.I && j < J.J) {
-                const size_t o2 = (size_t)i * J.si + (size_t)j * J.sj;
-                J.out[o2] = J.addend ? s + J.addend[o2] : s;
+                if (J.out_b && j == J.J - 1) {
+                    J.out_b[i] = J.add_b ? s + J.add_b[i] : s;
+                } else {
+                    const size_t o2 = (size_t)i * J.si + (size_t)j * J.sj;
+                    J.out[o2] = J.addend ? s + J.addend[o2] : s;
+                }
             }
         } else if (e < J.split_at) {
             if (J.out) J.out[e] = s;
@@ -563,7 +567,9 @@ extern "C" int glam_ts_gemm_add(const float* A, int K, int lda, const float* Wim
 static int wgrad_pair_impl(const char* fn, const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
                            int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
                            const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
-                           int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, hipStream_t s) {
+                           int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, hipStream_t s,
+                           float* bias_a = nullptr, const float* addb_a = nullptr, float* bias_b = nullptr,
+                           const float* addb_b = nullptr) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
     if (N == 0) {
         GLAM_REQUIRE(out_a && out_b, "%s: null pointer", fn);
@@ -582,6 +588,8 @@ static int wgrad_pair_impl(const char* fn, const float* Pa, int Ia, int ldpa, in
     if (int rc = launch_wgrad_partials2(a, out_a, si_a, sj_a, &ra.job[0], b, out_b, si_b, sj_b, &ra.job[1], s)) return rc;
     ra.job[0].addend = add_a;
     ra.job[1].addend = add_b;
+    ra.job[0].out_b = bias_a; ra.job[0].add_b = addb_a;
+    ra.job[1].out_b = bias_b; ra.job[1].add_b = addb_b;
     return launch_final_reduce(ra, s);
 }
 
@@ -593,14 +601,25 @@ extern "C" int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_
                            ones_b, Qb, Jb, ldqb, qones_b, qcelu_b, out_b, si_b, sj_b, N, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream);
 }
 
-// the same with out_x[i, j] = product + add_x[i, j] (addends laid out like the outputs; either may be NULL): the gradient carry of
-// parameters shared by several applications of a block is summed by the reduction that writes the gradient
-extern "C" int glam_wgrad_gemm_pair_acc(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
-                                        int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
-                                        const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
-                                        int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, void* stream) {
-    return wgrad_pair_impl("glam_wgrad_gemm_pair_acc", Pa, Ia, ldpa, ones_a, Qa, Ja, ldqa, qones_a, qcelu_a, out_a, si_a, sj_a, Pb, Ib,
-                           ldpb, ones_b, Qb, Jb, ldqb, qones_b, qcelu_b, out_b, si_b, sj_b, N, ws, ws_bytes, add_a, add_b, (hipStream_t)stream);
+// [d_W | d_b] of two linears y = [x | 1] W^T in one launch + one reduction, weights and biases into SEPARATE contiguous tensors:
+// dw_x[I, J] = P_x^T Q_x, db_x[I] = column sums of P_x (the ones column of [Q | 1]); optional addends laid out like the outputs.
+extern "C" int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, const float* Qa, int Ja, int ldqa, int qcelu_a, float* dw_a,
+                                          float* db_a, const float* Pb, int Ib, int ldpb, const float* Qb, int Jb, int ldqb, int qcelu_b,
+                                          float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes, const float* add_w_a,
+                                          const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream) {
+    GLAM_REQUIRE(dw_a && db_a && dw_b && db_b, "glam_wgrad_gemm_pair_split: null output");
+    if (N == 0) {
+        GLAM_REQUIRE(!add_w_a && !add_b_a && !add_w_b && !add_b_b, "glam_wgrad_gemm_pair_split: N = 0 with an addend (add on the host side)");
+        hipStream_t s = (hipStream_t)stream;
+        (void)hipMemsetAsync(dw_a, 0, (size_t)Ia * Ja * sizeof(float), s);
+        (void)hipMemsetAsync(db_a, 0, (size_t)Ia * sizeof(float), s);
+        (void)hipMemsetAsync(dw_b, 0, (size_t)Ib * Jb * sizeof(float), s);
+        (void)hipMemsetAsync(db_b, 0, (size_t)Ib * sizeof(float), s);
+        return GLAM_OK;
+    }
+    return wgrad_pair_impl("glam_wgrad_gemm_pair_split", Pa, Ia, ldpa, 0, Qa, Ja, ldqa, 1, qcelu_a, dw_a, Ja, 1, Pb, Ib, ldpb, 0, Qb, Jb,
+                           ldqb, 1, qcelu_b, dw_b, Jb, 1, N, ws, ws_bytes, add_w_a, add_w_b, (hipStream_t)stream, db_a, add_b_a, db_b,
+                           add_b_b);
 }
 
 extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,

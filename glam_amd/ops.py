@@ -1012,6 +1012,35 @@ class _LinearNarrow(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearLib(torch.autograd.Function):
+    """``F.linear`` with the matrix products on the GEMM library (layers outside the MFMA kernels' table: the 300 -> 1024 readout MLP)
+    and the bias gradient on ``glam_colsum`` (torch's generic column reduction takes 14 us for [1024, 1024]; this takes a few)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(dy.t(), x) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            lib = _lib.load()
+            N, D = dy.shape
+            db = torch.empty(D, dtype=torch.float32, device=dy.device)
+            ws = torch.empty(lib.glam_colsum_workspace_bytes(D) if N > 2048 else 16, dtype=torch.uint8, device=dy.device)
+            check(lib.glam_colsum(ptr(dy), N, D, D, ptr(db), ptr(ws), ws.numel(), stream()), "glam_colsum")
+        return dx, dw, db
+
+
 def linear(x, weight, bias=None):
     """``F.linear`` on the hand-written kernels when the shape is in their table (the layer-sized linears of the
     path: GRU gates 60->180, input embedding 15->60, ... on the MFMA kernels; heads with <= 16 outputs as row dot products);
@@ -1020,6 +1049,8 @@ def linear(x, weight, bias=None):
     if x.dim() == 2 and x.is_cuda and M <= 16 and K >= 64 and K % 4 == 0 and not linear_supported(K, M):
         return _LinearNarrow.apply(x, weight, bias)
     if x.dim() != 2 or not linear_supported(K, M):
+        if x.dim() == 2 and x.is_cuda and bias is not None and M % 4 == 0 and x.dtype == torch.float32 and weight.dtype == torch.float32:
+            return _LinearLib.apply(x, weight, bias)
         return torch.nn.functional.linear(x, weight, bias)
     Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
     if Kp != K:
@@ -1195,11 +1226,11 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
 def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
     """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
     M, C = w_ih.shape
-    def split(flat):
-        d = flat.view(2, M + 1, C + 1)
-        return d[0, :M, :C], d[1, :M, :C], d[0, :M, C], d[1, :M, C]
+    def split(flat):      # [d_w_ih | d_b_ih | d_w_hh | d_b_hh], every piece contiguous: autograd takes the views without a copy
+        w1, b1, w2, b2 = flat.split([M * C, M, M * C, M])
+        return w1.view(M, C), w2.view(M, C), b1, b2
     key = ("carry-gru", id(w_ih))
-    carry = _carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * (M + 1) * (C + 1), split)
+    carry = _carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * M * (C + 1), split)
     out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng)
     if carry is not None:
         _carry_store(key, w_ih, carry)
@@ -1315,22 +1346,19 @@ class _GruBlock(torch.autograd.Function):
         check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
-        dwb = torch.empty(2, M + 1, C + 1, **f)          # one buffer: the gradient carry adds it with one kernel
-        dwb_ih, dwb_hh = dwb[0], dwb[1]
+        # one buffer [d_w_ih | d_b_ih | d_w_hh | d_b_hh], contiguous pieces; a gradient carry (same layout) is added by the reduction
+        flat = torch.empty(2 * M * (C + 1), **f)
+        dw_ih, db_ih, dw_hh, db_hh = flat.split([M * C, M, M * C, M])
+        dc = [None] * 4
         if ctx.carried and d_carry is not None and N > 0:
-            # the carry (same [2, M + 1, C + 1] layout) is added by the reduction that writes the gradients
-            dc = f32c(d_carry, "d_carry").view(2, M + 1, C + 1)
-            check(lib.glam_wgrad_gemm_pair_acc(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
-                                               ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(),
-                                               ptr(dc[0]), ptr(dc[1]), st), "glam_wgrad_gemm_pair_acc")
-            return dx, dh, d_id, None, None, None, None, None, None, None, dwb.view(-1), None
-        check(lib.glam_wgrad_gemm_pair(ptr(d_gi), M, M, 0, ptr(x), C, C, 1, int(celu_in), ptr(dwb_ih), C + 1, 1,
-                                       ptr(d_gh), M, M, 0, ptr(h), C, C, 1, 0, ptr(dwb_hh), C + 1, 1, N, ptr(ws), ws.numel(), st),
-              "glam_wgrad_gemm_pair")
+            dc = f32c(d_carry, "d_carry").split([M * C, M, M * C, M])
+            d_carry = None
+        check(lib.glam_wgrad_gemm_pair_split(ptr(d_gi), M, M, ptr(x), C, C, int(celu_in), ptr(dw_ih), ptr(db_ih),
+                                             ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
+                                             ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
         if ctx.carried:
-            flat = dwb.view(-1)
             return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None
-        return dx, dh, d_id, dwb_ih[:M, :C], dwb_hh[:M, :C], dwb_ih[:M, C], dwb_hh[:M, C], None, None, None, None, None
+        return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):

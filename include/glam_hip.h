@@ -184,12 +184,13 @@ int glam_wgrad_gemm_pair(const float* Pa, int Ia, int ldpa, int ones_a, const fl
                          int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
                          const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
                          int64_t N, void* ws, size_t ws_bytes, void* stream);
-/* the same with out_x[i, j] = product + add_x[i, j] (addends laid out like the outputs, either may be NULL; N > 0 when one is
- * given): the gradient carry of the GRU weights shared by the message steps (src_1gp/layer.py:247, model.py:53-54). */
-int glam_wgrad_gemm_pair_acc(const float* Pa, int Ia, int ldpa, int ones_a, const float* Qa, int Ja, int ldqa, int qones_a,
-                         int qcelu_a, float* out_a, int si_a, int sj_a, const float* Pb, int Ib, int ldpb, int ones_b,
-                         const float* Qb, int Jb, int ldqb, int qones_b, int qcelu_b, float* out_b, int si_b, int sj_b,
-                         int64_t N, void* ws, size_t ws_bytes, const float* add_a, const float* add_b, void* stream);
+/* [d_W | d_b] of two linears y = [x | 1] W^T (the GRU's gate linears, src_1gp/layer.py:247) in one launch + one reduction with
+ * weights and biases in SEPARATE contiguous outputs: dw_x f32[I, J] = P_x^T Q_x, db_x f32[I] = column sums of P_x; optional
+ * addends laid out like the outputs (gradient carry; N > 0 when one is given).  qcelu_x: Q_x is consumed as celu(Q_x). */
+int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, const float* Qa, int Ja, int ldqa, int qcelu_a, float* dw_a,
+                               float* db_a, const float* Pb, int Ib, int ldpb, const float* Qb, int Jb, int ldqb, int qcelu_b,
+                               float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes, const float* add_w_a,
+                               const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 /* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:
  * a_celu = 1: out = celu(A) @ W + bias; cgrad_src non-NULL: out[r,c] *= celu'(cgrad_src[r,c]) (the chain rule of the same
  * fold on the way back); qcelu_* in glam_wgrad_gemm_pair: the weight gradient uses celu(Q). */
@@ -440,6 +441,12 @@ int glam_linear_narrow_fwd(const float* x, const float* w, const float* b, int64
 size_t glam_linear_narrow_bwd_workspace_bytes(int K, int M);
 int glam_linear_narrow_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw, float* db,
                            void* ws, size_t ws_bytes, void* stream);
+
+/* Column sums out[D] = sum_n x[n, 0..D) of a row-major f32[N, ld] matrix (D, ld multiples of 4): the bias gradient of a linear whose
+ * matrix products stay on the GEMM library (the 300 -> 1024 readout MLP, src_1gp/model.py:44-46).  ws (>= glam_colsum_workspace_bytes)
+ * is only touched for N > 2048.  Fixed summation order. */
+size_t glam_colsum_workspace_bytes(int D);
+int glam_colsum(const float* x, int64_t N, int D, int ld, float* out, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

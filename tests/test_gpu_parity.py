@@ -1863,3 +1863,35 @@ def test_narrow_linear_is_what_the_output_head_runs(device, monkeypatch):
     assert out.shape == (8, 2) and calls == [torch.Size([2, 1024])]
     raw = ops._lib.load()
     assert not raw.glam_linear_narrow_supported(1024, 17) and not raw.glam_linear_narrow_supported(1022, 1)
+
+
+@pytest.mark.parametrize("N,D", [(1024, 1024), (5000, 300), (1, 64), (40000, 64), (0, 8)])
+def test_colsum_and_the_library_linear_node(device, N, D):
+    from tests.conftest import assert_fp32_parity
+    g = torch.Generator().manual_seed(N + D)
+    x = torch.randn(N, D, generator=g)
+    raw = ops._lib.load()
+    xd, out = x.to(device), torch.full((D,), float("nan"), device=device)
+    ws = torch.empty(max(raw.glam_colsum_workspace_bytes(D), 16), dtype=torch.uint8, device=device)
+    ops.check(raw.glam_colsum(ops.ptr(xd), N, D, D, ops.ptr(out), ops.ptr(ws), ws.numel(), ops.stream()), "glam_colsum")
+    assert_fp32_parity(out, x.double().sum(0), x.sum(0), f"colsum {N}x{D}")
+    out2 = torch.empty_like(out)
+    ops.check(raw.glam_colsum(ops.ptr(xd), N, D, D, ops.ptr(out2), ops.ptr(ws), ws.numel(), ops.stream()), "glam_colsum")
+    assert torch.equal(out, out2)
+    if N == 0:
+        return
+    # the readout MLP's linear (K = 300 > 192: matrix products on the library): same numbers as F.linear, bias gradient from colsum
+    K = 300
+    a = torch.randn(min(N, 2048), K, generator=g)
+    w, b = torch.randn(D, K, generator=g) / K ** 0.5, torch.randn(D, generator=g)
+    cot = torch.randn(a.size(0), D, generator=g)
+
+    def run(dt, dev, fn):
+        t = [v.detach().clone().to(dev, dt).requires_grad_(True) for v in (a, w, b)]
+        fn(*t).backward(cot.to(dev, dt))
+        return [v.grad for v in t]
+
+    ref64, ref32 = run(torch.float64, "cpu", torch.nn.functional.linear), run(torch.float32, "cpu", torch.nn.functional.linear)
+    got = run(torch.float32, device, ops.linear)
+    for name, v, r64, r32 in zip(["d_x", "d_w", "d_b"], got, ref64, ref32):
+        assert_fp32_parity(v, r64, r32, f"library linear {a.size(0)}x{K}->{D} {name}")
