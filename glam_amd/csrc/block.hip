@@ -380,9 +380,10 @@ extern "C" int glam_bias_res_act_bwd(const float* out, const float* d_out, int64
 }
 
 // ---- training-mode variants: RReLU / Dropout from the device-side Philox stream (rng.h) ----
-// RNG launches take one same-address device-scope atomic per block (the stream-position ticket, ~10 ns each at the coherent
-// point): 512 grid-striding blocks instead of 2048 keep that tail at a few microseconds.
-constexpr int kRngBlocks = 512;
+// RNG launches take one device-scope atomic per block for the stream-position ticket (~10 ns each when they hit one address: a single
+// counter made a 2048-block launch 20 us, a 512-block one 5 us longer than its arithmetic; the two-level ticket of rng.h keeps every
+// same-address chain at grid / 16 + 16 operations, so the grid no longer needs a special cap).
+constexpr int kRngBlocks = 2048;
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p) {
     if (act < kActNone || act > kActRRelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);

@@ -2,8 +2,8 @@
 // (src_1gp/model.py:30-31: RReLU activations and Dropout(0.2)): Philox4x32-10 (Salmon et al., SC'11 — the public algorithm
 // torch's CUDA generator also uses), keyed by a 64-bit seed, counter = (element-quad index, per-launch offset).
 //
-// hipGraph-safe stream position: the (seed, offset) pair lives in DEVICE memory (`state` int64[32]: [0] seed, [1] offset,
-// [16] a 32-bit ticket on its own cache line).  Every RNG-consuming launch reads the pair first, uses `offset` as its private stream id, and the LAST block
+// hipGraph-safe stream position: the (seed, offset) pair lives in DEVICE memory (`state` int64[kRngStateWords = 288]: [0] seed, [1] offset,
+// [16] a 32-bit ticket and [32 + 16 s] sixteen sub-tickets, each on its own cache line).  Every RNG-consuming launch reads the pair first, uses `offset` as its private stream id, and the LAST block
 // of the launch to finish (ticket counter) stores offset + 1 for the next launch — no host round trip, no extra launch, and a
 // replayed graph continues the sequence exactly where the previous replay (or eager step) left it.  Block 0 also records the pair
 // it used in `eff` (int64[2]) so that the backward kernel regenerates the very same numbers instead of reading saved masks.
@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned philox_word(const uint4& v, int j) { return 
 // agent-scope atomic (served at the device-coherent point, not from a per-XCD L2 line): the ticket atomics of the same
 // launch sequence hit memory behind the L2s, and a plain load could return an offset cached before the previous launch's
 // update — some blocks of one launch would then draw from another stream position than block 0 recorded (seen as a rare
-// forward / backward mask mismatch).  The ticket lives on its own 128-byte line (state[16]).
+// forward / backward mask mismatch).  The tickets live on their own 128-byte lines (state[16], state[32 + 16 s]).
 __device__ __forceinline__ Philox rng_begin(long long* state, long long* eff) {
     const long long seed = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long off = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -58,11 +58,20 @@ __device__ __forceinline__ Philox rng_begin(long long* state, long long* eff) {
 __device__ __forceinline__ void rng_end(long long* state, const Philox& p) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned* ticket = reinterpret_cast<unsigned*>(state + 16);
-        if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(state + 1, (long long)((((unsigned long long)p.o1 << 32) | p.o0) + 1ull), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Two-level ticket: block b first checks in at sub-counter b % 16 (each on its own 128-byte line: state[32 + 16 s]); the last
+        // block of a sub-group checks in at the main ticket (state[16]).  One counter for all blocks serialised ~10 ns per block at the
+        // coherent point — 5 us of a 512-block launch; now at most grid / 16 + 16 same-address operations are in any chain.
+        const unsigned g = gridDim.x, sidx = blockIdx.x & 15u;
+        const unsigned in_sub = (g - sidx + 15u) >> 4, nsub = g < 16u ? g : 16u;
+        unsigned* sub = reinterpret_cast<unsigned*>(state + 32 + 16 * sidx);
+        if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1) {
+            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* ticket = reinterpret_cast<unsigned*>(state + 16);
+            if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1) {
+                __hip_atomic_store(state + 1, (long long)((((unsigned long long)p.o1 << 32) | p.o0) + 1ull), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

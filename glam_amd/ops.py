@@ -747,10 +747,12 @@ def triplet_layer_wide(x_p, ea_p, weight_node, weight_edge, att, weight_scale, b
 # device-side random stream of the training-mode layers (RReLU slopes, Dropout masks): csrc/rng.h
 # --------------------------------------------------------------------------------------
 _RNG_STATE: dict = {}
+RNG_STATE_WORDS = 288          # include/glam_hip.h: GLAM_RNG_STATE_WORDS
 
 
 def rng_state(device):
-    """``int64[32]`` on ``device``: [0] Philox seed, [1] stream offset (advanced by every RNG-consuming launch, on the device), [16] ticket.
+    """``int64[288]`` on ``device``: [0] Philox seed, [1] stream offset (advanced by every RNG-consuming launch, on the device), [16] and
+    [32 + 16 s] tickets (include/glam_hip.h: GLAM_RNG_STATE_WORDS).
     Created on first use from ``torch.initial_seed()`` — so the reference's ``seed_torch`` (``utils.py:22-28``) also fixes this
     stream — and OUTSIDE any hipGraph capture (``GraphedTrainStep`` runs the first visit of a batch eagerly)."""
     key = device.index if device.index is not None else torch.cuda.current_device()
@@ -759,7 +761,7 @@ def rng_state(device):
         if torch.cuda.is_current_stream_capturing():
             raise GlamHipError("the RNG state must exist before a hipGraph capture: run one eager training-mode forward first "
                                "(or call glam_amd.ops.manual_seed)")
-        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & (2 ** 63 - 1)] + [0] * 31, dtype=torch.int64, device=device)
+        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & (2 ** 63 - 1)] + [0] * (RNG_STATE_WORDS - 1), dtype=torch.int64, device=device)
     return st
 
 
@@ -767,7 +769,7 @@ def manual_seed(seed, device=None):
     """Restart the device-side stream of RReLU / Dropout numbers at ``(seed, offset 0)``."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     st = rng_state(device)
-    st.copy_(torch.tensor([int(seed) & (2 ** 63 - 1)] + [0] * 31, dtype=torch.int64))
+    st.copy_(torch.tensor([int(seed) & (2 ** 63 - 1)] + [0] * (RNG_STATE_WORDS - 1), dtype=torch.int64))
     return st
 
 

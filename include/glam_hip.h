@@ -353,11 +353,13 @@ int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_pt
  *   act = 4: torch.nn.RReLU in training mode, out = y > 0 ? y : a * y with a ~ U(rr_lower, rr_upper) per element;
  *   out_drop (may be NULL): a second output Dropout(drop_p)(out) = out * mask / (1 - p), the next conv's input (layer.py:256).
  * Random numbers: Philox4x32-10 keyed by rng_state[0] (seed), stream position rng_state[1] (offset), both int64 in DEVICE memory
- * and a ticket word at index 16 (its own cache line): rng_state int64[32], zero everything but the seed once.  Every launch uses the offset it finds
+ * and ticket words at index 16 and 32 + 16 s, s < 16 (each on its own cache line): rng_state int64[GLAM_RNG_STATE_WORDS = 288], zero
+ * everything but the seed once.  Every launch uses the offset it finds
  * and the last block to finish stores offset + 1 — hipGraph replays continue the sequence with no host involvement.  rng_eff
  * int64[2] receives the (seed, offset) pair the launch used; the backward entry points regenerate slopes and masks from it (no
  * mask tensors).  d_out / d_out_drop: gradients of the two outputs (either may be NULL). glam_bias_res_act_rng_fwd accepts
  * out = NULL for act = 0 (a plain Dropout). */
+#define GLAM_RNG_STATE_WORDS 288
 int glam_gru_tail_rng_fwd(const float* gi, const float* gh, const float* h, const float* identity, int64_t N, int C, int act,
                           float slope, float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff,
                           float* h_new, float* out, float* out_drop, void* stream);
