@@ -126,12 +126,18 @@ __global__ void __launch_bounds__(kBlock) k_colsum(const float* x, int N, int D,
     float4 a0 = f4zero(), a1 = f4zero();
     int n = r0 + rl;
     if (kok) {
-        for (; n + 16 < r1; n += 32) {
-            const float4 v0 = ld4(x + (size_t)n * ld + k), v1 = ld4(x + (size_t)(n + 16) * ld + k);
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        // eight row loads in flight per thread (two were not enough: 16 blocks x 64 dependent iterations took 12 us for [1024, 1024])
+        for (; n + 7 * 16 < r1; n += 8 * 16) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld4(x + (size_t)(n + 16 * u) * ld + k);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
+                a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+            }
         }
-        if (n < r1) { const float4 v0 = ld4(x + (size_t)n * ld + k); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
+        for (; n < r1; n += 16) { const float4 v0 = ld4(x + (size_t)n * ld + k); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
     }
     s_red[rl][cl] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
     __syncthreads();
@@ -163,7 +169,7 @@ extern "C" int glam_colsum(const float* x, int64_t N, int D, int ld, float* out,
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) { (void)hipMemsetAsync(out, 0, (size_t)D * sizeof(float), s); return GLAM_OK; }
     GLAM_REQUIRE(x && aligned16(x), "glam_colsum: null / misaligned input");
-    const int nsplit = (int)(N <= 2048 ? 1 : (N + 2047) / 2048 > kNarrowSplits ? kNarrowSplits : (N + 2047) / 2048);
+    const int nsplit = (int)(N <= 2048 ? 1 : (N + 2047) / 2048 > kNarrowSplits ? kNarrowSplits : (N + 2047) / 2048);   // (keep in step with ops._LinearLib)
     if (nsplit > 1) GLAM_REQUIRE(ws && aligned16(ws) && ws_bytes >= glam_colsum_workspace_bytes(D), "glam_colsum: workspace too small");
     float* dst = nsplit > 1 ? static_cast<float*>(ws) : out;
     hipLaunchKernelGGL(k_colsum, dim3((D + 63) / 64, nsplit), dim3(kBlock), 0, s, x, (int)N, D, ld, dst, nsplit > 1 ? 1 : 0);

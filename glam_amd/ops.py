@@ -495,6 +495,7 @@ class _TripletLayer(torch.autograd.Function):
         HC = H * Cp
         f = dict(dtype=torch.float32, device=dev)
         ctx.carried = carry is not None
+        ctx.set_materialize_grads(False)     # the carry of the block's LAST application has no gradient yet: None, not a zero fill
         def build():
             buf = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
             check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(buf),
@@ -538,6 +539,8 @@ class _TripletLayer(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out, d_carry=None):
+        if d_out is None:                    # the layer's output was not used: only the carry (if any) passes through
+            return (None,) * 10 + (d_carry,)
         x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
