@@ -74,6 +74,7 @@ SIGNATURES = {
     "glam_wgrad_gemm_pair": (_i32, ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32] * 2) + [_i64, _vp, _sz, _vp]),
     "glam_ts_gemm_celu": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
     "glam_ts_gemm_add": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),
+    "glam_ts_gemm_pair": (_i32, ([_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32] * 2) + [_i64, _vp]),
     "glam_wgrad_gemm_pair_split": (_i32, ([_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp] * 2) + [_i64, _vp, _sz] + [_vp] * 5),
     "glam_gru_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "glam_gru_tail_bwd": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _f32] + [_vp] * 5),

@@ -77,9 +77,19 @@ __device__ long long g_ts_prof[1024 * 8];
 #define TS_DRAIN() do { } while (0)
 #endif
 
+// Two independent products of the same kernel variant may share one launch (the GRU's two gate linears, and the two input-gradient
+// products of its backward): blocks [0, first_b) work on job a, the rest on job b, each with its own weight image.  Besides the
+// dispatch it saves, the 48 KB-image variants then have two blocks (16 waves) per CU: one product's loads and stores run under
+// the other's MFMAs.
+struct TsArgs2 { TsArgs a, b; int first_b; };
+
 template <int MT, int GMAX, int TPI>
-__global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
+__global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const bool second = (int)blockIdx.x >= two.first_b;
+    const TsArgs& a = second ? two.b : two.a;
+    const int bid = second ? (int)blockIdx.x - two.first_b : (int)blockIdx.x;          // block index / count inside the job
+    const int nblk = second ? (int)gridDim.x - two.first_b : two.first_b;
     constexpr int MP = MT * 16;        // padded column count
     constexpr int CS = MT / TPI;       // column splits per row tile
     constexpr int kMaxStage = 16 * GMAX * MP / 4 / kTsBlock;   // float4 per thread for the largest image
@@ -91,7 +101,7 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
     const int ntiles = (a.N + 15) >> 4;
     const int nitems = ntiles * CS;
     constexpr int WPB = kTsBlock / 64;
-    const int stride = gridDim.x * WPB;
+    const int stride = nblk * WPB;
 
     // A fragment of a tile: one float4 per 16-k group, every load in flight at once
     auto load_afrag = [&](int item, float4 (&af)[GMAX]) {
@@ -113,8 +123,8 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs a) {
     };
     // Fewer items than wave slots (small batches; the 64-column variant at any batch): deal them block-minor, so that they
     // spread over all blocks / CUs first and a SIMD runs one MFMA stream instead of two back to back.
-    const bool spread = nitems < gridDim.x * WPB;
-    int item = spread ? (int)blockIdx.x + wave * (int)gridDim.x : (int)blockIdx.x * WPB + wave;
+    const bool spread = nitems < nblk * WPB;
+    int item = spread ? bid + wave * nblk : bid * WPB + wave;
     float4 af[GMAX];
     TS_STAMP(0);
     load_afrag(item, af);              // flies while the weight image is staged
@@ -405,34 +415,50 @@ int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, floa
     return GLAM_OK;
 }
 
-int launch_ts_gemm(const TsArgs& a, hipStream_t s) {
+static int ts_plan(const TsArgs& a, int* variant, int* grid) {
     const int M = a.M1 + a.M2, K = a.K1 + a.K2;
-    if (a.N <= 0) return GLAM_OK;
     if (int rc = ts_shape_ok("ts_gemm", K, M)) return rc;
     if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3)) || (a.M1 & 3) || (a.M2 & 3) || (a.ldo1 & 3) ||
         (a.M2 && (a.ldo2 & 3)))
         return fail(GLAM_E_UNSUPPORTED, "ts_gemm: K=%d+%d M=%d+%d and leading dimensions must be multiples of 4", a.K1, a.K2, a.M1, a.M2);
-    const size_t lds = ts_image_floats(K, M) * sizeof(float);
     const int ntiles = (a.N + 15) / 16;
-    const int variant = ts_variant(K, M);
+    *variant = ts_variant(K, M);
     // column splits per row tile (MT / TPI).  K <= 192 x 64 columns: splitting would re-read the long A rows
-    const int nitems = ntiles * (variant == 0 ? 1 : variant == 1 ? 3 : 5);
-    int grid = nitems < 2048 ? nitems : (nitems + 7) / 8;   // < one item per wave slot: one block per item first (see `spread`)
-    if (grid > 256) grid = 256;          // one 8-wave block per CU, items dealt round-robin over every wave of the grid
-    if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
-    else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+    const int nitems = ntiles * (*variant == 0 ? 1 : *variant == 1 ? 3 : 5);
+    int g = nitems < 2048 ? nitems : (nitems + 7) / 8;   // < one item per wave slot: one block per item first (see `spread`)
+    if (g > 256) g = 256;                // one 8-wave block per CU, items dealt round-robin over every wave of the grid
+    *grid = g;
+    return GLAM_OK;
+}
+
+// b == nullptr: one product; otherwise two products of the SAME variant in one launch
+int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
+    if (a.N <= 0) return GLAM_OK;
+    int variant = -1, grid_a = 0, grid_b = 0;
+    if (int rc = ts_plan(a, &variant, &grid_a)) return rc;
+    TsArgs2 two{a, b ? *b : a, grid_a};
+    if (b) {
+        int vb = -1;
+        if (int rc = ts_plan(*b, &vb, &grid_b)) return rc;
+        if (vb != variant || b->N != a.N) return fail(GLAM_E_UNSUPPORTED, "ts_gemm pair: the two products must share N and the kernel variant");
+    }
+    const size_t lds = ts_image_floats(a.K1 + a.K2, a.M1 + a.M2) * sizeof(float);
+    const int grid = grid_a + grid_b;
+    if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
+    else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else {
-        if (a.out1_bf16) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: bf16 output is limited to the 48 KB-image variants");
+        if (a.out1_bf16 || (b && b->out1_bf16)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: bf16 output is limited to the 48 KB-image variants");
         static bool big2 = false;      // > 64 KB of dynamic LDS is opted into once
         if (!big2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ts_gemm<20, 6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             big2 = true;
         }
-        hipLaunchKernelGGL((k_ts_gemm<20, 6, 4>), dim3(grid), dim3(kTsBlock), lds, s, a);
+        hipLaunchKernelGGL((k_ts_gemm<20, 6, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     }
     GLAM_LAUNCH_CHECK("ts_gemm");
     return GLAM_OK;
 }
+int launch_ts_gemm(const TsArgs& a, hipStream_t s) { return launch_ts_gemm2(a, nullptr, s); }
 
 constexpr int kWgradBlocks = 256;   // about one 8-wave block per CU
 
@@ -550,6 +576,25 @@ extern "C" int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, con
                  "glam_ts_gemm_celu: pointers must be 16-byte aligned");
     TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N, a_celu, cgrad_src, ld_cgrad};
     return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
+// Two products of one kernel variant in ONE launch, every per-product option of the single entry points available to each:
+//   out_x[N, M_x] = act_x(A_x)[N, K_x] @ W_x (+ bias_x) (* celu'(cgrad_x)) (+ addend_x),  act = CELU when a_celu_x
+extern "C" int glam_ts_gemm_pair(const float* Aa, int Ka, int lda, int a_celu_a, const float* Wimg_a, const float* bias_a, float* out_a,
+                                 int Ma, int ldo_a, const float* cgrad_a, int ld_cgrad_a, const float* addend_a, int ld_add_a,
+                                 const float* Ab, int Kb, int ldb, int a_celu_b, const float* Wimg_b, const float* bias_b, float* out_b,
+                                 int Mb, int ldo_b, const float* cgrad_b, int ld_cgrad_b, const float* addend_b, int ld_add_b,
+                                 int64_t N, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_ts_gemm_pair: N out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(Aa && Wimg_a && out_a && Ab && Wimg_b && out_b, "glam_ts_gemm_pair: null pointer");
+    GLAM_REQUIRE(aligned16(Aa) && aligned16(Wimg_a) && aligned16(out_a) && aligned16(bias_a) && aligned16(cgrad_a) && aligned16(addend_a) &&
+                     aligned16(Ab) && aligned16(Wimg_b) && aligned16(out_b) && aligned16(bias_b) && aligned16(cgrad_b) && aligned16(addend_b) &&
+                     !(ld_cgrad_a & 3) && !(ld_cgrad_b & 3) && !(ld_add_a & 3) && !(ld_add_b & 3),
+                 "glam_ts_gemm_pair: pointers must be 16-byte aligned, leading dimensions multiples of 4");
+    TsArgs a{Aa, Ka, lda, nullptr, 0, 0, Wimg_a, bias_a, out_a, Ma, ldo_a, nullptr, 0, 0, (int)N, a_celu_a, cgrad_a, ld_cgrad_a, 0, addend_a, ld_add_a};
+    TsArgs b{Ab, Kb, ldb, nullptr, 0, 0, Wimg_b, bias_b, out_b, Mb, ldo_b, nullptr, 0, 0, (int)N, a_celu_b, cgrad_b, ld_cgrad_b, 0, addend_b, ld_add_b};
+    return launch_ts_gemm2(a, &b, (hipStream_t)stream);
 }
 
 // out[N, M] = A[N, K] @ W + bias + addend: the GRU backward's d_h = d_gh @ W_hh^T + (the direct z * g path), one launch

@@ -1228,6 +1228,9 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
 
 
+GEMM_PAIR = os.environ.get("GLAM_GEMM_PAIR", "1") == "1"     # A/B knob: the GRU's two products per direction in one launch
+
+
 def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
     """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
     M, C = w_ih.shape
@@ -1285,9 +1288,16 @@ class _GruBlock(torch.autograd.Function):
                 scope.fwd[ka], scope.fwd[kb] = (w_ih, ia), (w_hh, ib)
                 scope.bwd[ka], scope.bwd[kb] = (w_ih, ta), (w_hh, tb)
         # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
-        check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
-              "glam_ts_gemm_celu")
-        check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
+        if GEMM_PAIR:     # both gate linears in ONE launch (two products of the same kernel variant share the CUs)
+            img_a, img_b = image(w_ih), image(w_hh)     # both alive until the launch is enqueued (outside a scope they are temporaries:
+            #                                             the allocator would hand the first one's memory to the second)
+            check(lib.glam_ts_gemm_pair(ptr(x), C, C, int(celu_in), ptr(img_a), ptr(b_ih), ptr(gi), M, M, None, 0, None, 0,
+                                        ptr(h), C, C, 0, ptr(img_b), ptr(b_hh), ptr(gh), M, M, None, 0, None, 0, N, st),
+                  "glam_ts_gemm_pair")
+        else:
+            check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
+                  "glam_ts_gemm_celu")
+            check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
         h_new, out = torch.empty_like(h), torch.empty_like(h)
         out_drop, eff = None, None
         if rng is None:
@@ -1345,10 +1355,16 @@ class _GruBlock(torch.autograd.Function):
 
         dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
         # with the folded CELU the epilogue multiplies by celu'(x): dx is the gradient of the RAW input
-        check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
-              "glam_ts_gemm_celu")
-        # d_h = d_gh @ W_hh^T + the direct z * g path of the gate equations (the addend of the GEMM's epilogue)
-        check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")
+        # d_h = d_gh @ W_hh^T + the direct z * g path of the gate equations (the addend of the GEMM's epilogue); both products in one launch
+        if GEMM_PAIR:
+            img_a, img_b = image_t(w_ih), image_t(w_hh)
+            check(lib.glam_ts_gemm_pair(ptr(d_gi), M, M, 0, ptr(img_a), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, None, 0,
+                                        ptr(d_gh), M, M, 0, ptr(img_b), None, ptr(dh), C, C, None, 0, ptr(d_h), C, N, st),
+                  "glam_ts_gemm_pair")
+        else:
+            check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
+                  "glam_ts_gemm_celu")
+            check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         # one buffer [d_w_ih | d_b_ih | d_w_hh | d_b_hh], contiguous pieces; a gradient carry (same layout) is added by the reduction

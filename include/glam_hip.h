@@ -200,6 +200,14 @@ int glam_ts_gemm_celu(const float* A, int K, int lda, int a_celu, const float* W
  * (the GRU backward's d_h = d_gh @ W_hh^T + the direct z * g term) without an add launch. */
 int glam_ts_gemm_add(const float* A, int K, int lda, const float* Wimg, const float* bias, float* out, int M, int ldo,
                      const float* addend, int ld_add, int64_t N, void* stream);
+/* Two products that share N and the kernel variant in ONE launch (the GRU's gate linears gi = celu(x) W_ih^T + b_ih and
+ * gh = h W_hh^T + b_hh of src_1gp/layer.py:261-262, and the two input-gradient products of their backward), each with every option of
+ * glam_ts_gemm_celu / glam_ts_gemm_add: out_x = act_x(A_x) @ W_x (+ bias_x) (* celu'(cgrad_x)) (+ addend_x).  Besides the dispatch it
+ * saves, the second product's blocks share the CUs with the first's (two 8-wave blocks per CU for the 48 KB-image variants). */
+int glam_ts_gemm_pair(const float* Aa, int Ka, int lda, int a_celu_a, const float* Wimg_a, const float* bias_a, float* out_a, int Ma,
+                      int ldo_a, const float* cgrad_a, int ld_cgrad_a, const float* addend_a, int ld_add_a, const float* Ab, int Kb,
+                      int ldb, int a_celu_b, const float* Wimg_b, const float* bias_b, float* out_b, int Mb, int ldo_b,
+                      const float* cgrad_b, int ld_cgrad_b, const float* addend_b, int ld_add_b, int64_t N, void* stream);
 size_t glam_wgrad_workspace_bytes(void);
 int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
                     int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, void* ws,

@@ -1895,3 +1895,30 @@ def test_colsum_and_the_library_linear_node(device, N, D):
     got = run(torch.float32, device, ops.linear)
     for name, v, r64, r32 in zip(["d_x", "d_w", "d_b"], got, ref64, ref32):
         assert_fp32_parity(v, r64, r32, f"library linear {a.size(0)}x{K}->{D} {name}")
+
+
+@pytest.mark.parametrize("N", [105, 20400])
+@pytest.mark.parametrize("K,M", [(60, 180), (180, 60)])
+def test_ts_gemm_pair_equals_two_launches(device, N, K, M):
+    """Two products in one launch (the GRU's gate linears / their input gradients) are bit-identical to the two single launches, with every
+    per-product option: CELU on the operand, bias, CELU' of a source on the output, an addend."""
+    raw, p, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + K)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    x, h, wa, wb, ba, bb, src, add = r(N, K), r(N, K), r(M, K), r(M, K), r(M), r(M), r(N, M), r(N, M)
+    nb = raw.glam_ts_gemm_image_bytes(K, M) // 4
+    ia, ib = torch.empty(nb, device=device), torch.empty(nb, device=device)
+    ops.check(raw.glam_ts_gemm_make_image(p(wa), K, 1, K, M, p(ia), st()), "image")
+    ops.check(raw.glam_ts_gemm_make_image(p(wb), K, 1, K, M, p(ib), st()), "image")
+    o1, o2, q1, q2 = (torch.empty(N, M, device=device) for _ in range(4))
+    ops.check(raw.glam_ts_gemm_celu(p(x), K, K, 1, p(ia), p(ba), p(o1), M, M, p(src), M, N, st()), "celu")
+    ops.check(raw.glam_ts_gemm_add(p(h), K, K, p(ib), p(bb), p(o2), M, M, p(add), M, N, st()), "add")
+    ops.check(raw.glam_ts_gemm_pair(p(x), K, K, 1, p(ia), p(ba), p(q1), M, M, p(src), M, None, 0,
+                                    p(h), K, K, 0, p(ib), p(bb), p(q2), M, M, None, 0, p(add), M, N, st()), "pair")
+    assert torch.equal(o1, q1) and torch.equal(o2, q2)
+    ref = torch.nn.functional.linear(h.double().cpu(), wb.double().cpu(), bb.double().cpu()) + add.double().cpu()
+    assert (q2.double().cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    # the two products must share N and the kernel variant
+    img_other = torch.empty(raw.glam_ts_gemm_image_bytes(M, K) // 4, device=device)
+    assert raw.glam_ts_gemm_pair(p(x), K, K, 0, p(ia), None, p(q1), M, M, None, 0, None, 0,
+                                 p(o1), M, M, 0, p(img_other), None, p(torch.empty(N, K, device=device)), K, K, None, 0, None, 0, N, st()) != 0
