@@ -87,7 +87,8 @@ template <int MT, int GMAX, int TPI>
 __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const bool second = (int)blockIdx.x >= two.first_b;
-    const TsArgs& a = second ? two.b : two.a;
+    const TsArgs a = second ? two.b : two.a;      // by value: every field a scalar select (a reference made the compiler re-read the
+    //                                               argument block and cost the single-product launch 1.5 us)
     const int bid = second ? (int)blockIdx.x - two.first_b : (int)blockIdx.x;          // block index / count inside the job
     const int nblk = second ? (int)gridDim.x - two.first_b : two.first_b;
     constexpr int MP = MT * 16;        // padded column count
