@@ -616,7 +616,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
     // (inside B1 where a fused variant exists: one launch and one [N, HC] round trip less)
     static const bool fuse_dagg_on = [] { const char* e = getenv("GLAM_FUSE_DAGG"); return !e || atoi(e) != 0; }();
-    const bool fuse_dagg = fuse_dagg_on && !xw_bf16 && triplet_bwd_can_fuse_dagg(H, Cp, Dp);
+    const bool fuse_dagg = fuse_dagg_on && triplet_bwd_can_fuse_dagg(H, Cp, Dp);
     if (!fuse_dagg) {
         TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};
         if (int rc = launch_ts_gemm(g1, s)) return rc;

@@ -148,7 +148,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     const int gpb = kBlock / sh.G;
     const int red_groups = ((size_t)WSZ + (size_t)gpb * P) * sizeof(float) <= 60 * 1024 ? gpb : 4;
     // d_aggr = d_out @ W_scale^T computed tile by tile inside B1 (d_aggr is then written, not read)
-    const bool fuse_dagg = img_dagg && d_out && triplet_bwd_can_fuse_dagg(H, Cp, De) && emul && !xw_bf16;
+    const bool fuse_dagg = img_dagg && d_out && triplet_bwd_can_fuse_dagg(H, Cp, De) && emul;
     if ((img_dagg || d_out) && !fuse_dagg) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_aggr variant for H=%d Cp=%d", H, Cp);
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
                   alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16,

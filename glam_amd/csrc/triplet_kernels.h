@@ -966,9 +966,12 @@ struct BwdDstOp {
                 if (lds > 64 * 1024 && !big_lds) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
                     big_lds = true;
                 }
-                hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>), dim3(grid), dim3(kBlock), lds, s, a);
+                if (a.xw_bf16) hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true, true>), dim3(grid), dim3(kBlock), lds, s, a);
+                else hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>), dim3(grid), dim3(kBlock), lds, s, a);
                 return;
             }
             if (a.xw_bf16) {
