@@ -55,6 +55,11 @@ SIGNATURES = {
     "glam_triplet_fwd_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "glam_triplet_layer_fwd_ell": (_i32, [_vp] * 5 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "glam_gru_fused_supported": (_i32, [_i32]),
+    "glam_gru_fused_image_bytes": (_sz, []),
+    "glam_gru_fused_make_images": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "glam_gru_fused_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5),
+    "glam_gru_fused_rng_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8),
     "glam_colsum_workspace_bytes": (_sz, [_i32]),
     "glam_colsum": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "glam_linear_narrow_supported": (_i32, [_i32, _i32]),

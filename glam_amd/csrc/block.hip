@@ -3,6 +3,7 @@
 //   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
 // gi = celu(x) @ W_ih^T + b_ih, gh = h @ W_hh^T + b_hh are [N, 3C] (gate order r | z | n, as torch stores them).
 #include "rng.h"
+#include "dense.h"
 
 namespace glam {
 
@@ -285,9 +286,221 @@ __global__ void __launch_bounds__(kBlock) k_lstm_cell_bwd(const float* gates, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The GRU step of a MessageBlock (src_1gp/layer.py:261-266) in ONE launch: both gate linears on the fp32 matrix cores and the gate
+// math, residual, activation (+ RReLU / Dropout) in their epilogue.  As separate launches the pair of gate GEMMs wrote gi and gh
+// (2 x [N, 3C]) and the tail kernel read them back: ~16 + 12 us per application at B = 1024.
+//   weight images: K = C (<= 64) x 192 columns with every gate padded to 64 (position p = gate*64 + t*16 + c holds channel 4c + t of
+//   that gate), so lane (c, kq) of a wave ends up with the r, z, n pre-activations of the SAME four channels 4c..4c+3 for its four rows
+//   kq*4 + i: the gate equations run in registers.  Work item = one 16-row tile, all three gates of both products (384 MFMAs);
+//   block = 8 waves with both images (96 KB) in LDS, one block per CU.  gi and gh are still written (the backward recomputes the
+//   gates from them), in the unpadded [N, 3C] layout.  Same arithmetic, same order as glam_ts_gemm + glam_gru_tail_*: bit-identical.
+constexpr int kGruBlock = 512;
+constexpr int kGruImgFloats = 64 * 192;
+
+struct GruFusedArgs {
+    const float* x; const float* h; const float* identity; const float* img_ih; const float* img_hh; const float* b_ih; const float* b_hh;
+    float* gi; float* gh; float* h_new; float* out;
+    int N, C, celu_in, act; float slope;
+};
+
+__global__ void __launch_bounds__(kBlock) k_gru_fused_images(const float* w_ih, const float* w_hh, int C, float* img_ih, float* img_hh) {
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < 2 * kGruImgFloats; idx += gridDim.x * kBlock) {
+        const int which = idx >= kGruImgFloats, e = idx - which * kGruImgFloats;
+        const int j = e & 3, p = (e >> 2) % 192, k = (e >> 2) / 192 * 4 + j;
+        const int m = ts_col_of_pos(p), gate = m >> 6, ch = m & 63;
+        const float* w = which ? w_hh : w_ih;
+        (which ? img_hh : img_ih)[e] = (k < C && ch < C) ? w[(size_t)(gate * C + ch) * C + k] : 0.f;
+    }
+}
+
+template <bool RNG>
+__global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, TailRng rg) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float s_img[];          // [2][64 * 192]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
+    const int C = a.C, GK = (C + 15) >> 4, ntiles = (a.N + 15) >> 4;
+    constexpr int WPB = kGruBlock / 64;
+    Philox ph{};
+    if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
+    // fewer tiles than wave slots: one tile per block first (a SIMD then runs one MFMA stream, not two)
+    const bool spread = ntiles < (int)gridDim.x * WPB;
+    const int stride = gridDim.x * WPB;
+    int tile = spread ? (int)blockIdx.x + wave * (int)gridDim.x : (int)blockIdx.x * WPB + wave;
+    auto load_a = [&](int t, float4 (&ax)[4], float4 (&ah)[4]) {
+        const int row = t * 16 + c;
+        const bool rok = t < ntiles && row < a.N;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k0 = 16 * g + 4 * kq;
+            ax[g] = f4zero(); ah[g] = f4zero();
+            if (rok && k0 < C) { ax[g] = ld4(a.x + (size_t)row * C + k0); ah[g] = ld4(a.h + (size_t)row * C + k0); }
+        }
+        if (a.celu_in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ax[g] = celu4(ax[g]);
+        }
+    };
+    float4 ax[4], ah[4];
+    load_a(tile, ax, ah);                      // flies while the images are staged
+    {
+        constexpr int kStage = 2 * kGruImgFloats / 4 / kGruBlock;       // 12 float4 per thread
+        float4 buf[kStage];
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int idx = tid + i * kGruBlock;                        // float4 index over [ih | hh]
+            buf[i] = idx < kGruImgFloats / 4 ? ld4(a.img_ih + 4 * idx) : ld4(a.img_hh + 4 * (idx - kGruImgFloats / 4));
+        }
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) st4(s_img + 4 * (tid + i * kGruBlock), buf[i]);
+    }
+    __syncthreads();
+    const float* wl_a = s_img + (kq * 192 + c) * 4;
+    const float* wl_b = wl_a + kGruImgFloats;
+    for (; tile < ntiles; tile += stride) {
+        v4f acc_a[3][4], acc_b[3][4];
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { acc_a[g3][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc_b[g3][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < GK) {
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    float4 ba[4], bb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        ba[t] = ld4(wl_a + g * 16 * 192 + (g3 * 64 + t * 16) * 4);
+                        bb[t] = ld4(wl_b + g * 16 * 192 + (g3 * 64 + t * 16) * 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xa = f4get(ax[g], j), xh = f4get(ah[g], j);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc_a[g3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f4get(ba[t], j), acc_a[g3][t], 0, 0, 0);
+                            acc_b[g3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xh, f4get(bb[t], j), acc_b[g3][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        const int cur = tile;
+        load_a(tile + stride, ax, ah);         // the next tile's operands fly under the epilogue
+        // ---- epilogue: lane (c, kq) owns channels 4c..4c+3 of rows kq*4 + i ----
+        const int ch = 4 * c;
+        if (ch < C) {
+            float4 bi[3], bh[3];
+#pragma unroll
+            for (int g3 = 0; g3 < 3; ++g3) { bi[g3] = ld4(a.b_ih + g3 * C + ch); bh[g3] = ld4(a.b_hh + g3 * C + ch); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = cur * 16 + kq * 4 + i;
+                if (row >= a.N) continue;
+                float4 gi4[3], gh4[3];
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    gi4[g3] = make_float4(acc_a[g3][0][i] + bi[g3].x, acc_a[g3][1][i] + bi[g3].y, acc_a[g3][2][i] + bi[g3].z, acc_a[g3][3][i] + bi[g3].w);
+                    gh4[g3] = make_float4(acc_b[g3][0][i] + bh[g3].x, acc_b[g3][1][i] + bh[g3].y, acc_b[g3][2][i] + bh[g3].z, acc_b[g3][3][i] + bh[g3].w);
+                    st4(a.gi + (size_t)row * 3 * C + g3 * C + ch, gi4[g3]);
+                    st4(a.gh + (size_t)row * 3 * C + g3 * C + ch, gh4[g3]);
+                }
+                const size_t e = (size_t)row * C + ch;
+                const float4 hv = ld4(a.h + e), idv = a.identity ? ld4(a.identity + e) : f4zero();
+                uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (RNG) w4 = philox4(ph, e >> 2);
+                float4 hn4, o4, od4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = sigmoidf_(f4get(gi4[0], j) + f4get(gh4[0], j));
+                    const float z = sigmoidf_(f4get(gi4[1], j) + f4get(gh4[1], j));
+                    const float nn = tanhf(f4get(gi4[2], j) + r * f4get(gh4[2], j));
+                    const float hn = (1.f - z) * nn + z * f4get(hv, j);
+                    const float y = a.identity ? hn + f4get(idv, j) : hn;
+                    const unsigned w = philox_word(w4, j);
+                    const float o = (RNG && a.act == kActRRelu) ? (y > 0.f ? y : y * rrelu_slope_w(w, rg.lo, rg.hi)) : act_fwd(y, a.act, a.slope);
+                    (&hn4.x)[j] = hn; (&o4.x)[j] = o;
+                    if constexpr (RNG) (&od4.x)[j] = o * drop_scale_w(w, rg.p);
+                }
+                st4(a.h_new + e, hn4);
+                st4(a.out + e, o4);
+                if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
+            }
+        }
+    }
+    if constexpr (RNG) rng_end(rg.state, ph);
+}
+
 }  // namespace glam
 
 using namespace glam;
+
+static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+
+static int gru_fused_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_t s) {
+    static bool big = false;       // 96 KB of dynamic LDS is opted into once
+    if (!big) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fused_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGruImgFloats * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fused_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGruImgFloats * 4);
+        big = true;
+    }
+    const int ntiles = (a.N + 15) / 16;
+    int grid = ntiles < 2048 ? ntiles : (ntiles + 7) / 8;
+    if (grid > 256) grid = 256;
+    const size_t lds = 2 * kGruImgFloats * sizeof(float);
+    if (rg) hipLaunchKernelGGL(k_gru_fused_fwd<true>, dim3(grid), dim3(kGruBlock), lds, s, a, *rg);
+    else hipLaunchKernelGGL(k_gru_fused_fwd<false>, dim3(grid), dim3(kGruBlock), lds, s, a, TailRng{});
+    GLAM_LAUNCH_CHECK("glam_gru_fused_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_fused_supported(int C) { return C >= 4 && C <= 64 && (C & 3) == 0; }
+extern "C" size_t glam_gru_fused_image_bytes(void) { return (size_t)kGruImgFloats * sizeof(float); }
+
+extern "C" int glam_gru_fused_make_images(const float* w_ih, const float* w_hh, int C, float* img_ih, float* img_hh, void* stream) {
+    GLAM_REQUIRE(glam_gru_fused_supported(C), "glam_gru_fused_make_images: C=%d must be a multiple of 4, at most 64", C);
+    GLAM_REQUIRE(w_ih && w_hh && img_ih && img_hh && aligned16(img_ih) && aligned16(img_hh), "glam_gru_fused_make_images: null / misaligned pointer");
+    hipLaunchKernelGGL(k_gru_fused_images, dim3((2 * kGruImgFloats + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, w_ih, w_hh, C,
+                       img_ih, img_hh);
+    GLAM_LAUNCH_CHECK("glam_gru_fused_make_images");
+    return GLAM_OK;
+}
+
+static int gru_fused_args_ok(const char* fn, const GruFusedArgs& a, int64_t N) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
+    if (!glam_gru_fused_supported(a.C)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4, at most 64", fn, a.C);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(a.x && a.h && a.img_ih && a.img_hh && a.b_ih && a.b_hh && a.gi && a.gh && a.h_new && a.out, "%s: null pointer", fn);
+    GLAM_REQUIRE(aligned16(a.x) && aligned16(a.h) && aligned16(a.identity) && aligned16(a.img_ih) && aligned16(a.img_hh) && aligned16(a.b_ih) &&
+                     aligned16(a.b_hh) && aligned16(a.gi) && aligned16(a.gh) && aligned16(a.h_new) && aligned16(a.out),
+                 "%s: pointers must be 16-byte aligned", fn);
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_fused_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                                  const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi,
+                                  float* gh, float* h_new, float* out, void* stream) {
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_fused_fwd: activation code %d", act);
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope};
+    if (int rc = gru_fused_args_ok("glam_gru_fused_fwd", a, N)) return rc;
+    if (N == 0) return GLAM_OK;
+    return gru_fused_launch(a, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int glam_gru_fused_rng_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                                      const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope,
+                                      float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi,
+                                      float* gh, float* h_new, float* out, float* out_drop, void* stream) {
+    if (int rc = rng_args_ok("glam_gru_fused_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope};
+    if (int rc = gru_fused_args_ok("glam_gru_fused_rng_fwd", a, N)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(rng_state && rng_eff && aligned16(out_drop), "glam_gru_fused_rng_fwd: null RNG state / misaligned out_drop");
+    const TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, 1};
+    return gru_fused_launch(a, &rg, (hipStream_t)stream);
+}
+
 
 extern "C" int glam_gru_tail_fwd(const float* gi, const float* gh, const float* h, const float* identity, int64_t N, int C,
                                  int act, float slope, float* h_new, float* out, void* stream) {

@@ -1229,6 +1229,11 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
 
 
 GEMM_PAIR = os.environ.get("GLAM_GEMM_PAIR", "1") == "1"     # A/B knob: the GRU's two products per direction in one launch
+# Opt-in (GLAM_GRU_FUSED=1): gate GEMMs + gate math + tail of the forward GRU step in ONE launch (glam_gru_fused_fwd, bit-identical,
+# tested).  Measured 30.3 us per application at B = 1024 against 16 (pair of gate GEMMs) + 12 (tail): its work item — a 16-row tile x
+# both products x all three gates, 384 MFMAs and 44 vector-memory instructions of epilogue per lane — is too coarse for 1 458 tiles on
+# 2 048 wave slots at two waves per SIMD.  Off until the item is cut finer.
+GRU_FUSED = os.environ.get("GLAM_GRU_FUSED", "0") == "1"
 
 
 def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
@@ -1287,30 +1292,47 @@ class _GruBlock(torch.autograd.Function):
                       "glam_ts_gemm_make_image_quad")
                 scope.fwd[ka], scope.fwd[kb] = (w_ih, ia), (w_hh, ib)
                 scope.bwd[ka], scope.bwd[kb] = (w_ih, ta), (w_hh, tb)
-        # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
-        if GEMM_PAIR:     # both gate linears in ONE launch (two products of the same kernel variant share the CUs)
-            img_a, img_b = image(w_ih), image(w_hh)     # both alive until the launch is enqueued (outside a scope they are temporaries:
-            #                                             the allocator would hand the first one's memory to the second)
-            check(lib.glam_ts_gemm_pair(ptr(x), C, C, int(celu_in), ptr(img_a), ptr(b_ih), ptr(gi), M, M, None, 0, None, 0,
-                                        ptr(h), C, C, 0, ptr(img_b), ptr(b_hh), ptr(gh), M, M, None, 0, None, 0, N, st),
-                  "glam_ts_gemm_pair")
-        else:
-            check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
-                  "glam_ts_gemm_celu")
-            check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
         h_new, out = torch.empty_like(h), torch.empty_like(h)
         out_drop, eff = None, None
-        if rng is None:
-            if act == ACT_CODES["rrelu"]:
-                raise GlamHipError("gru block: act 'rrelu' needs rng=(lower, upper, drop_p)")
-            check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
-                  "glam_gru_tail_fwd")
-        else:     # training mode: RReLU slopes / the next conv's Dropout mask drawn inside the launch
+        if rng is None and act == ACT_CODES["rrelu"]:
+            raise GlamHipError("gru block: act 'rrelu' needs rng=(lower, upper, drop_p)")
+        if rng is not None:
             lo, hi, p = (float(v) for v in rng)
             eff = torch.empty(2, dtype=torch.int64, device=dev)
             out_drop = torch.empty_like(h) if p > 0 else None
-            check(lib.glam_gru_tail_rng_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), lo, hi, p,
-                                            ptr(rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
+        # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
+        if GRU_FUSED and N > 0 and lib.glam_gru_fused_supported(C):
+            # both gate linears + gates + residual + activation (+ RReLU / Dropout) in ONE launch (bit-identical to the sequence below)
+            def build_fused():
+                nb = lib.glam_gru_fused_image_bytes() // 4
+                buf = torch.empty(2, nb, **f)
+                check(lib.glam_gru_fused_make_images(ptr(w_ih), ptr(w_hh), C, ptr(buf[0]), ptr(buf[1]), st), "glam_gru_fused_make_images")
+                return buf
+            imgs = _scoped(scope.fwd if scope else None, ("gru-fused", id(w_ih), id(w_hh)), w_ih, build_fused)
+            if rng is None:
+                check(lib.glam_gru_fused_fwd(ptr(x), ptr(h), ptr(identity), ptr(imgs[0]), ptr(imgs[1]), ptr(b_ih), ptr(b_hh), N, C,
+                                             int(celu_in), act, float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), st), "glam_gru_fused_fwd")
+            else:
+                check(lib.glam_gru_fused_rng_fwd(ptr(x), ptr(h), ptr(identity), ptr(imgs[0]), ptr(imgs[1]), ptr(b_ih), ptr(b_hh), N, C,
+                                                 int(celu_in), act, float(slope), lo, hi, p, ptr(rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
+                                                 ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_fused_rng_fwd")
+        else:
+            if GEMM_PAIR:     # both gate linears in ONE launch (two products of the same kernel variant share the CUs)
+                img_a, img_b = image(w_ih), image(w_hh)     # both alive until the launch is enqueued (outside a scope they are temporaries:
+                #                                             the allocator would hand the first one's memory to the second)
+                check(lib.glam_ts_gemm_pair(ptr(x), C, C, int(celu_in), ptr(img_a), ptr(b_ih), ptr(gi), M, M, None, 0, None, 0,
+                                            ptr(h), C, C, 0, ptr(img_b), ptr(b_hh), ptr(gh), M, M, None, 0, None, 0, N, st),
+                      "glam_ts_gemm_pair")
+            else:
+                check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
+                      "glam_ts_gemm_celu")
+                check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
+            if rng is None:
+                check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
+                      "glam_gru_tail_fwd")
+            else:     # training mode: RReLU slopes / the next conv's Dropout mask drawn inside the launch
+                check(lib.glam_gru_tail_rng_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), lo, hi, p,
+                                                ptr(rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
         ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
         ctx.eff = eff
         ctx.cfg = (act, float(slope), identity is not None, bool(celu_in), None if rng is None else tuple(float(v) for v in rng))

@@ -441,6 +441,24 @@ int glam_s2s_attn_fwd(const float* x, const float* q, const int32_t* ptr, int64_
 int glam_s2s_attn_bwd(const float* x, const float* q, const float* r, const float* stats, const float* d_r,
                       const int32_t* ptr, int64_t N, int64_t B, int D, float* d_x, float* d_q, void* stream);
 
+/* ---- the GRU step of a MessageBlock in one launch -------------------------------------------------------------------------
+ * src_1gp/layer.py:261-266: x = celu(conv out); x, h = GRU(x, h) (one step, seq_len 1); x = act(x + identity).  Both gate linears
+ * (gi = celu(x) W_ih^T + b_ih, gh = h W_hh^T + b_hh) on the fp32 matrix cores with the gate math, residual and activation in their
+ * epilogue: the same results, bit for bit, as glam_ts_gemm_pair + glam_gru_tail_fwd (resp. glam_gru_tail_rng_fwd), without the round
+ * trip of gi / gh between them (both are still written: the backward, glam_gru_tail_*_bwd, recomputes the gates from them).
+ * C a multiple of 4, at most 64.  Images: glam_gru_fused_make_images (two buffers of glam_gru_fused_image_bytes(), rebuilt whenever
+ * the weights change).  act codes / RNG arguments as glam_gru_tail_fwd / glam_gru_tail_rng_fwd. */
+int glam_gru_fused_supported(int C);
+size_t glam_gru_fused_image_bytes(void);
+int glam_gru_fused_make_images(const float* w_ih, const float* w_hh, int C, float* img_ih, float* img_hh, void* stream);
+int glam_gru_fused_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                       const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
+                       float* h_new, float* out, void* stream);
+int glam_gru_fused_rng_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                           const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
+                           float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
+                           float* out, float* out_drop, void* stream);
+
 /* ---- narrow-output linear (the model's output head) -------------------------------------------------------------------
  * y[N, M] = x[N, K] @ w[M, K]^T + b for M <= 16, K % 4 == 0: replaces torch.nn.functional.linear / its autograd for
  * `lin_out1 = LinearBlock(e_dim, out_dim)` (reference src_1gp/model.py:47,61; layer.py:223-237), where a GEMM library spends

@@ -1922,3 +1922,27 @@ def test_ts_gemm_pair_equals_two_launches(device, N, K, M):
     img_other = torch.empty(raw.glam_ts_gemm_image_bytes(M, K) // 4, device=device)
     assert raw.glam_ts_gemm_pair(p(x), K, K, 0, p(ia), None, p(q1), M, M, None, 0, None, 0,
                                  p(o1), M, M, 0, p(img_other), None, p(torch.empty(N, K, device=device)), K, K, None, 0, None, 0, N, st()) != 0
+
+
+@pytest.mark.parametrize("C,train", [(60, False), (60, True), (32, False), (48, True)])
+def test_fused_gru_forward_is_bit_identical_to_the_two_launch_sequence(device, monkeypatch, C, train):
+    """Opt-in glam_gru_fused_fwd (gate GEMMs + gates + residual + activation (+ RReLU / Dropout) in one launch) against the default
+    glam_ts_gemm_pair + glam_gru_tail_*: same outputs, same gradients, same RNG stream."""
+    b = synth_batch(24, seed=C).to(device)
+    blk = layer.MessageBlock(C, C, 4, norm="_None", dropout="Dropout(0.2)" if train else "_None()", conv="_TripletMessage",
+                             act="RReLU" if train else "CELU", res=True).to(device)
+    blk.train(train)
+    x0 = torch.randn(b.x.size(0), C, device=device)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "GRU_FUSED", fused)
+        ops.manual_seed(11, device)
+        x = x0.clone().requires_grad_(True)
+        with ops.weight_scope():
+            x1, h1 = blk(x, b.edge_index, b.edge_attr, h=None, batch=b.batch)
+            x2, h2 = blk(x1, b.edge_index, b.edge_attr, h=h1, batch=b.batch)
+            gs = torch.autograd.grad((x2 * x2).sum() + h2.sum(), [x] + list(blk.parameters()))
+        res.append([x1, x2, h2] + list(gs))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+    assert not ops._lib.load().glam_gru_fused_supported(66) and not ops._lib.load().glam_gru_fused_supported(0)
