@@ -314,6 +314,13 @@ __global__ void __launch_bounds__(kBlock) k_gru_fused_images(const float* w_ih, 
     }
 }
 
+#ifdef GLAM_GRU_PROF   // developer aid (tools/gru_prof.py): cycle stamps of wave 0 of every block
+__device__ long long g_gru_prof[256 * 8];
+#define GRU_STAMP(k) do { if (tid == 0 && blockIdx.x < 256) g_gru_prof[blockIdx.x * 8 + (k)] = clock64(); } while (0)
+#else
+#define GRU_STAMP(k) do { } while (0)
+#endif
+
 template <bool RNG>
 __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, TailRng rg) {
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -342,6 +349,7 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
         }
     };
     float4 ax[4], ah[4];
+    GRU_STAMP(0);
     load_a(tile, ax, ah);                      // flies while the images are staged
     {
         constexpr int kStage = 2 * kGruImgFloats / 4 / kGruBlock;       // 12 float4 per thread
@@ -355,6 +363,8 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
         for (int i = 0; i < kStage; ++i) st4(s_img + 4 * (tid + i * kGruBlock), buf[i]);
     }
     __syncthreads();
+    GRU_STAMP(1);
+    int pass_no = 0;
     const float* wl_a = s_img + (kq * 192 + c) * 4;
     const float* wl_b = wl_a + kGruImgFloats;
     for (; tile < ntiles; tile += stride) {
@@ -386,6 +396,10 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
                 }
             }
         }
+#ifdef GLAM_GRU_PROF
+        asm volatile("s_nop 0" :: "v"(acc_a[0][0]), "v"(acc_b[2][3]));
+#endif
+        if (pass_no == 0) GRU_STAMP(2);
         const int cur = tile;
         load_a(tile + stride, ax, ah);         // the next tile's operands fly under the epilogue
         // ---- epilogue: lane (c, kq) owns channels 4c..4c+3 of rows kq*4 + i ----
@@ -428,7 +442,14 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
                 if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
             }
         }
+        if (pass_no == 0) GRU_STAMP(3);
+        ++pass_no;
     }
+    GRU_STAMP(4);
+#ifdef GLAM_GRU_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GRU_STAMP(5);
     if constexpr (RNG) rng_end(rg.state, ph);
 }
 
@@ -437,6 +458,11 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
 using namespace glam;
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+#ifdef GLAM_GRU_PROF
+extern "C" int glam_debug_gru_prof(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 static int gru_fused_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_t s) {
     static bool big = false;       // 96 KB of dynamic LDS is opted into once
