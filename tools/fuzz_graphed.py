@@ -25,7 +25,7 @@ for case in range(n_cases):
         finals = []
         for graphed in (False, True):
             net = copy.deepcopy(net0)
-            opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)
+            opt = torch.optim.Adam(net.parameters(), lr=2.0 ** -10, capturable=True, fused=True)   # exactly representable: the graphed stepper keeps lr in an fp32 device tensor, the eager loop in a Python float
             stepper = GraphedTrainStep(net, opt, loss_fn)
             for epoch in range(4):
                 for b in batches:
