@@ -7,7 +7,18 @@
 
 namespace glam {
 
+// Gate non-linearities on the hardware transcendental unit: v_exp_f32 (softmax_exp: |x| 2^-24 relative from the rounded x log2(e)
+// plus 1 ulp) and v_rcp_f32 (1 ulp) — absolute error < 3e-7 on a gate in [0, 1] / [-1, 1], far inside the 1e-5 parity bar the block
+// goldens run at.  The libm sequences (expf + IEEE divide, tanhf: ~380 vector instructions per element with the three gates) made the
+// GRU tail kernels VALU bound: the forward tail processed 6 cycles per element per CU, the same rate as the fused kernel's epilogue.
+// Forward and backward share the functions, so the recomputed gates equal the forward pass's.  -DGLAM_EXACT_EXP restores libm.
+#ifdef GLAM_EXACT_EXP
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float tanh_(float v) { return tanhf(v); }
+#else
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.f + softmax_exp(-v)); }
+__device__ __forceinline__ float tanh_(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + softmax_exp(2.f * v)); }
+#endif
 
 __global__ void __launch_bounds__(kBlock) k_gru_gates_fwd(const float* gi, const float* gh, const float* h, int N, int C,
                                                          float* h_new) {
@@ -16,7 +27,7 @@ __global__ void __launch_bounds__(kBlock) k_gru_gates_fwd(const float* gi, const
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
         const float r = sigmoidf_(gi[b] + gh[b]);
         const float z = sigmoidf_(gi[b + C] + gh[b + C]);
-        const float nn = tanhf(gi[b + 2 * C] + r * gh[b + 2 * C]);
+        const float nn = tanh_(gi[b + 2 * C] + r * gh[b + 2 * C]);
         h_new[i] = (1.f - z) * nn + z * h[i];
     }
 }
@@ -31,7 +42,7 @@ __global__ void __launch_bounds__(kBlock) k_gru_gates_bwd(const float* gi, const
         const float ghn = gh[b + 2 * C];
         const float r = sigmoidf_(gi[b] + gh[b]);
         const float z = sigmoidf_(gi[b + C] + gh[b + C]);
-        const float nn = tanhf(gi[b + 2 * C] + r * ghn);
+        const float nn = tanh_(gi[b + 2 * C] + r * ghn);
         const float g = d_hnew[i];
         const float d_n = g * (1.f - z), d_z = g * (h[i] - nn);
         const float d_pn = d_n * (1.f - nn * nn);
@@ -99,7 +110,7 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const 
                 for (int j = 0; j < 4; ++j) {
                     const float r = sigmoidf_(f4get(ir, j) + f4get(hr, j));
                     const float z = sigmoidf_(f4get(iz, j) + f4get(hz, j));
-                    const float nn = tanhf(f4get(in, j) + r * f4get(hnn, j));
+                    const float nn = tanh_(f4get(in, j) + r * f4get(hnn, j));
                     const float hn = (1.f - z) * nn + z * f4get(hv, j);
                     const float y = hn + f4get(idv, j);
                     const unsigned w = philox_word(w4, j);
@@ -118,7 +129,7 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_fwd(const float* gi, const 
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
         const float r = sigmoidf_(gi[b] + gh[b]);
         const float z = sigmoidf_(gi[b + C] + gh[b + C]);
-        const float nn = tanhf(gi[b + 2 * C] + r * gh[b + 2 * C]);
+        const float nn = tanh_(gi[b + 2 * C] + r * gh[b + 2 * C]);
         const float hn = (1.f - z) * nn + z * h[i];
         h_new[i] = hn;
         const float y = identity ? hn + identity[i] : hn;
@@ -158,7 +169,7 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const 
         const float ghn = gh[b + 2 * C];
         const float r = sigmoidf_(gi[b] + gh[b]);
         const float z = sigmoidf_(gi[b + C] + gh[b + C]);
-        const float nn = tanhf(gi[b + 2 * C] + r * ghn);
+        const float nn = tanh_(gi[b + 2 * C] + r * ghn);
         const float d_n = g * (1.f - z), d_z = g * (h[i] - nn);
         const float d_pn = d_n * (1.f - nn * nn);
         const float d_pr = d_pn * ghn * r * (1.f - r);
@@ -261,10 +272,10 @@ __global__ void __launch_bounds__(kBlock) k_lstm_cell_fwd(const float* gates, co
     const size_t total = (size_t)B * C;
     for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
         const size_t n = idx / C, c = idx % C, b = n * 4 * C + c;
-        const float i = sigmoidf_(gates[b]), f = sigmoidf_(gates[b + C]), g = tanhf(gates[b + 2 * C]), o = sigmoidf_(gates[b + 3 * C]);
+        const float i = sigmoidf_(gates[b]), f = sigmoidf_(gates[b + C]), g = tanh_(gates[b + 2 * C]), o = sigmoidf_(gates[b + 3 * C]);
         const float cn = f * c_prev[idx] + i * g;
         c_new[idx] = cn;
-        h_new[idx] = o * tanhf(cn);
+        h_new[idx] = o * tanh_(cn);
     }
 }
 
@@ -273,9 +284,9 @@ __global__ void __launch_bounds__(kBlock) k_lstm_cell_bwd(const float* gates, co
     const size_t total = (size_t)B * C;
     for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
         const size_t n = idx / C, c = idx % C, b = n * 4 * C + c;
-        const float i = sigmoidf_(gates[b]), f = sigmoidf_(gates[b + C]), g = tanhf(gates[b + 2 * C]), o = sigmoidf_(gates[b + 3 * C]);
+        const float i = sigmoidf_(gates[b]), f = sigmoidf_(gates[b + C]), g = tanh_(gates[b + 2 * C]), o = sigmoidf_(gates[b + 3 * C]);
         const float cp = c_prev[idx];
-        const float tc = tanhf(f * cp + i * g);
+        const float tc = tanh_(f * cp + i * g);
         const float dh = d_h ? d_h[idx] : 0.f;
         const float dc = (d_c ? d_c[idx] : 0.f) + dh * o * (1.f - tc * tc);
         d_gates[b] = dc * g * i * (1.f - i);
@@ -364,6 +375,10 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
     }
     __syncthreads();
     GRU_STAMP(1);
+    // The two waves of a SIMD would issue their MFMAs alternately, finish them together and then meet again in the store-bound
+    // epilogue (every CU of the chip at once: the phase ran at the chip's write bandwidth).  Priority staggers them: the first
+    // four waves take the matrix pipe first and store while the other four multiply.
+    if (wave < 4) __builtin_amdgcn_s_setprio(3);
     int pass_no = 0;
     const float* wl_a = s_img + (kq * 192 + c) * 4;
     const float* wl_b = wl_a + kGruImgFloats;
@@ -401,13 +416,21 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
 #endif
         if (pass_no == 0) GRU_STAMP(2);
         const int cur = tile;
-        load_a(tile + stride, ax, ah);         // the next tile's operands fly under the epilogue
-        // ---- epilogue: lane (c, kq) owns channels 4c..4c+3 of rows kq*4 + i ----
+        // ---- epilogue: lane (c, kq) owns channels 4c..4c+3 of rows kq*4 + i.  Every load first, then nothing but arithmetic and
+        //      stores: a load issued between stores makes the compiler wait for vmcnt(0), i.e. for the previous row's stores to
+        //      complete (4 x ~4k cycles: the first version's epilogue took 19-23k cycles) ----
         const int ch = 4 * c;
         if (ch < C) {
-            float4 bi[3], bh[3];
+            float4 bi[3], bh[3], hv[4], idv[4];
 #pragma unroll
             for (int g3 = 0; g3 < 3; ++g3) { bi[g3] = ld4(a.b_ih + g3 * C + ch); bh[g3] = ld4(a.b_hh + g3 * C + ch); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = min(cur * 16 + kq * 4 + i, a.N - 1);
+                const size_t e = (size_t)row * C + ch;
+                hv[i] = ld4(a.h + e);
+                idv[i] = a.identity ? ld4(a.identity + e) : f4zero();
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = cur * 16 + kq * 4 + i;
@@ -421,7 +444,6 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
                     st4(a.gh + (size_t)row * 3 * C + g3 * C + ch, gh4[g3]);
                 }
                 const size_t e = (size_t)row * C + ch;
-                const float4 hv = ld4(a.h + e), idv = a.identity ? ld4(a.identity + e) : f4zero();
                 uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
                 if constexpr (RNG) w4 = philox4(ph, e >> 2);
                 float4 hn4, o4, od4;
@@ -429,9 +451,9 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
                 for (int j = 0; j < 4; ++j) {
                     const float r = sigmoidf_(f4get(gi4[0], j) + f4get(gh4[0], j));
                     const float z = sigmoidf_(f4get(gi4[1], j) + f4get(gh4[1], j));
-                    const float nn = tanhf(f4get(gi4[2], j) + r * f4get(gh4[2], j));
-                    const float hn = (1.f - z) * nn + z * f4get(hv, j);
-                    const float y = a.identity ? hn + f4get(idv, j) : hn;
+                    const float nn = tanh_(f4get(gi4[2], j) + r * f4get(gh4[2], j));
+                    const float hn = (1.f - z) * nn + z * f4get(hv[i], j);
+                    const float y = a.identity ? hn + f4get(idv[i], j) : hn;
                     const unsigned w = philox_word(w4, j);
                     const float o = (RNG && a.act == kActRRelu) ? (y > 0.f ? y : y * rrelu_slope_w(w, rg.lo, rg.hi)) : act_fwd(y, a.act, a.slope);
                     (&hn4.x)[j] = hn; (&o4.x)[j] = o;
@@ -442,6 +464,7 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
                 if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
             }
         }
+        load_a(tile + stride, ax, ah);         // the next tile's operands (after the stores: see above)
         if (pass_no == 0) GRU_STAMP(3);
         ++pass_no;
     }

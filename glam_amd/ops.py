@@ -1229,12 +1229,16 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
 
 
 GEMM_PAIR = os.environ.get("GLAM_GEMM_PAIR", "1") == "1"     # A/B knob: the GRU's two products per direction in one launch
-# Opt-in (GLAM_GRU_FUSED=1): gate GEMMs + gate math + tail of the forward GRU step in ONE launch (glam_gru_fused_fwd, bit-identical,
-# tested).  Measured 30.3 us per application at B = 1024 against 16 (pair of gate GEMMs) + 12 (tail): its work item — a 16-row tile x
-# both products x all three gates, 384 MFMAs and 44 vector-memory instructions of epilogue per lane — is too coarse for 1 458 tiles on
-# 2 048 wave slots at two waves per SIMD.  Off until the item is cut finer.
-GRU_FUSED = os.environ.get("GLAM_GRU_FUSED", "0") == "1"
+# Gate GEMMs + gate math + tail of the forward GRU step in ONE launch (glam_gru_fused_fwd, bit-identical to the pair launch + tail
+# kernel, tested).  Its work item is coarse (a 16-row tile x both products x all three gates) and its epilogue runs at the chip's write
+# bandwidth, so it pays once a wave has several tiles to pipeline: model step at B = 8 192 3.90 vs 4.08 ms, B = 1 024 0.807 vs 0.814 ms,
+# B = 32 0.384 vs 0.370 ms (the 96 KB of weight images per block dominate).  "auto": from GRU_FUSED_MIN_NODES nodes on.
+GRU_FUSED = os.environ.get("GLAM_GRU_FUSED", "auto")
+GRU_FUSED_MIN_NODES = 16384
 
+
+def _want_gru_fused(N):
+    return GRU_FUSED in ("1", True) or (GRU_FUSED == "auto" and N >= GRU_FUSED_MIN_NODES)
 
 def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
     """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
@@ -1301,7 +1305,7 @@ class _GruBlock(torch.autograd.Function):
             eff = torch.empty(2, dtype=torch.int64, device=dev)
             out_drop = torch.empty_like(h) if p > 0 else None
         # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
-        if GRU_FUSED and N > 0 and lib.glam_gru_fused_supported(C):
+        if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
             # both gate linears + gates + residual + activation (+ RReLU / Dropout) in ONE launch (bit-identical to the sequence below)
             def build_fused():
                 nb = lib.glam_gru_fused_image_bytes() // 4

@@ -1934,7 +1934,7 @@ def test_fused_gru_forward_is_bit_identical_to_the_two_launch_sequence(device, m
     blk.train(train)
     x0 = torch.randn(b.x.size(0), C, device=device)
     res = []
-    for fused in (False, True):
+    for fused in ("0", "1"):
         monkeypatch.setattr(ops, "GRU_FUSED", fused)
         ops.manual_seed(11, device)
         x = x0.clone().requires_grad_(True)

@@ -6,7 +6,7 @@ import torch
 from glam_amd import _lib, layer, ops
 from glam_amd.data import synth_batch
 
-ops.GRU_FUSED = True
+ops.GRU_FUSED = "1"
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 b = synth_batch(B, seed=0).to(dev)
