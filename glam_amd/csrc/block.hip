@@ -153,6 +153,53 @@ __global__ void __launch_bounds__(kBlock) k_gru_tail_bwd(const float* gi, const 
     const size_t total = (size_t)N * C;
     Philox ph{};
     if constexpr (RNG) ph = philox_init(rg.eff);
+    if (rg.vec) {
+        // four consecutive channels of one row per thread: every load first (10 x 16 bytes), then 8 float4 stores (the scalar loop
+        // below issues 4 x the instructions and, on its second trip, waits for the first trip's stores before it may load)
+        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < total / 4; q += (size_t)gridDim.x * kBlock) {
+            const size_t i = 4 * q, n = i / C, c = i % C, b = n * 3 * C + c;
+            const float4 ir = ld4c(gi + b), iz = ld4c(gi + b + C), in = ld4c(gi + b + 2 * C);
+            const float4 hr = ld4c(gh + b), hz = ld4c(gh + b + C), hnn = ld4c(gh + b + 2 * C);
+            const float4 hv = ld4c(h + i), ov = ld4c(out + i);
+            const float4 go = d_out ? ld4c(d_out + i) : f4zero();
+            const float4 gs = d_hstate ? ld4c(d_hstate + i) : f4zero();
+            float4 gd = f4zero();
+            if constexpr (RNG) { if (rg.d_out_drop) gd = ld4c(rg.d_out_drop + i); }
+            uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (RNG) w4 = philox4(ph, q);
+            float4 dy4, pr4, pz4, pn4, pnr4, dh4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float dy;
+                if constexpr (RNG) {
+                    const unsigned w = philox_word(w4, j);
+                    float g = f4get(go, j);
+                    if (rg.d_out_drop) g = fmaf(f4get(gd, j), drop_scale_w(w, rg.p), g);
+                    dy = g * (act == kActRRelu ? (f4get(ov, j) > 0.f ? 1.f : rrelu_slope_w(w, rg.lo, rg.hi)) : act_grad_from_out(f4get(ov, j), act, slope));
+                } else {
+                    dy = f4get(go, j) * act_grad_from_out(f4get(ov, j), act, slope);
+                }
+                const float g = d_hstate ? dy + f4get(gs, j) : dy;
+                const float ghn = f4get(hnn, j);
+                const float r = sigmoidf_(f4get(ir, j) + f4get(hr, j));
+                const float z = sigmoidf_(f4get(iz, j) + f4get(hz, j));
+                const float nn = tanh_(f4get(in, j) + r * ghn);
+                const float d_n = g * (1.f - z), d_z = g * (f4get(hv, j) - nn);
+                const float d_pn = d_n * (1.f - nn * nn);
+                (&dy4.x)[j] = dy;
+                (&pr4.x)[j] = d_pn * ghn * r * (1.f - r);
+                (&pz4.x)[j] = d_z * z * (1.f - z);
+                (&pn4.x)[j] = d_pn;
+                (&pnr4.x)[j] = d_pn * r;
+                (&dh4.x)[j] = g * z;
+            }
+            if (d_identity) st4(d_identity + i, dy4);
+            st4(d_gi + b, pr4); st4(d_gi + b + C, pz4); st4(d_gi + b + 2 * C, pn4);
+            st4(d_gh + b, pr4); st4(d_gh + b + C, pz4); st4(d_gh + b + 2 * C, pnr4);
+            st4(d_h + i, dh4);
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
         const size_t n = i / C, c = i % C, b = n * 3 * C + c;
         float dy;
@@ -570,8 +617,11 @@ extern "C" int glam_gru_tail_bwd(const float* gi, const float* gh, const float* 
     if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_tail_bwd: activation code %d", act);
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(gi && gh && h && out && d_out && d_gi && d_gh && d_h, "glam_gru_tail_bwd: null pointer");
-    hipLaunchKernelGGL(k_gru_tail_bwd<false>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
-                       d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, TailRngB{});
+    TailRngB rg{};
+    rg.vec = (C & 3) == 0 && aligned16(gi) && aligned16(gh) && aligned16(h) && aligned16(out) && aligned16(d_out) && aligned16(d_hstate) &&
+             aligned16(d_gi) && aligned16(d_gh) && aligned16(d_h) && aligned16(d_identity);
+    hipLaunchKernelGGL(k_gru_tail_bwd<false>, dim3(grid_for(rg.vec ? N * C / 4 : N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h,
+                       out, d_out, d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, rg);
     GLAM_LAUNCH_CHECK("glam_gru_tail_bwd");
     return GLAM_OK;
 }
@@ -678,9 +728,11 @@ extern "C" int glam_gru_tail_rng_bwd(const float* gi, const float* gh, const flo
     if (int rc = rng_args_ok("glam_gru_tail_rng_bwd", act, rr_lower, rr_upper, drop_p)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(gi && gh && h && out && (d_out || d_out_drop) && d_gi && d_gh && d_h && rng_eff, "glam_gru_tail_rng_bwd: null pointer");
-    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, 0};
-    hipLaunchKernelGGL(k_gru_tail_bwd<true>, dim3(grid_for(N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out, d_out,
-                       d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, rg);
+    const int vec = (C & 3) == 0 && aligned16(gi) && aligned16(gh) && aligned16(h) && aligned16(out) && aligned16(d_out) && aligned16(d_out_drop) &&
+                    aligned16(d_hstate) && aligned16(d_gi) && aligned16(d_gh) && aligned16(d_h) && aligned16(d_identity);
+    TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, vec};
+    hipLaunchKernelGGL(k_gru_tail_bwd<true>, dim3(grid_for(vec ? N * C / 4 : N * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gi, gh, h, out,
+                       d_out, d_hstate, (int)N, C, act, slope, d_gi, d_gh, d_h, d_identity, rg);
     GLAM_LAUNCH_CHECK("glam_gru_tail_rng_bwd");
     return GLAM_OK;
 }
