@@ -182,23 +182,40 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
             if constexpr (TPI == 4) {
                 float4 b = f4zero();
                 if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
+                const bool use_cg = a.cgrad_src && m0 < a.M1, use_ad = a.addend && m0 < a.M1;
+                if (a.cgrad_src || a.addend) {     // wave-uniform: the plain product keeps its lean epilogue (and its registers)
+                    // every load of the epilogue before its first store (a load issued between stores waits for vmcnt(0), i.e. for
+                    // the previous row's store to land)
+                    float4 xs[4], ad[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rr = tile * 16 + kq * 4 + i;
-                    if (rr >= a.N) continue;
-                    float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
-                    if (a.cgrad_src && m0 < a.M1) {
-                        const float4 xs = ld4(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0);
-                        v.x *= celu1_grad(xs.x); v.y *= celu1_grad(xs.y); v.z *= celu1_grad(xs.z); v.w *= celu1_grad(xs.w);
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = min(tile * 16 + kq * 4 + i, a.N - 1);
+                        xs[i] = use_cg ? ld4(a.cgrad_src + (size_t)rr * a.ld_cgrad + m0) : f4zero();
+                        ad[i] = use_ad ? ld4(a.addend + (size_t)rr * a.ld_add + m0) : f4zero();
                     }
-                    if (a.addend && m0 < a.M1) {
-                        const float4 ad = ld4(a.addend + (size_t)rr * a.ld_add + m0);
-                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = tile * 16 + kq * 4 + i;
+                        if (rr >= a.N) continue;
+                        float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                        if (use_cg) {
+                            v.x *= celu1_grad(xs[i].x); v.y *= celu1_grad(xs[i].y); v.z *= celu1_grad(xs[i].z); v.w *= celu1_grad(xs[i].w);
+                        }
+                        if (use_ad) { v.x += ad[i].x; v.y += ad[i].y; v.z += ad[i].z; v.w += ad[i].w; }
+                        if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                        else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
                     }
-                    if (m0 < a.M1) {
-                        if (a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
-                        else st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
-                    } else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = tile * 16 + kq * 4 + i;
+                        if (rr >= a.N) continue;
+                        const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                        if (m0 < a.M1) {
+                            if (a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
+                            else st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                        } else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                    }
                 }
             } else {
                 float2 b = make_float2(0.f, 0.f);
