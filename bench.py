@@ -209,8 +209,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=10000)     # ~1 s of replayed steps: long enough for an SMI sampler to see the GPU busy
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--eager-allreduce", action="store_true", help="keep the gradient all-reduce outside the captured graph")

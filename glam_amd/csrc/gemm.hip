@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     __shared__ float s_red[kWgWaves * 32 * 64];        // half of the 64 accumulator registers at a time: 64 KB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
     const bool second = (int)blockIdx.x >= two.first_b;
-    const WgArgs& a = second ? two.b : two.a;
+    const WgArgs a = second ? two.b : two.a;      // by value (scalar selects): a reference made the compiler re-read the argument block
     // XCD-aware decode (blockIdx % 8 = XCD): the slabs of one row split share an XCD, so Q is fetched into one L2
     const int bid = second ? blockIdx.x - two.first_b : blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
