@@ -71,6 +71,10 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
                                      "note": "backward by target with the d_aggr GEMM fused in (one launch and one kernel boundary less)"},
         "k_triplet_bwd_src+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
+        "k_triplet_bwd_src_pipe": {"bound": "hbm", "bytes": b2,
+                                   "note": "software-pipelined backward by source (ELL records): the op's choice beyond the LLC, followed by the d_x GEMM"},
+        "k_ts_gemm<4, 12, 4>": {"bound": "mfma", "flops": 2 * N * (HC + 8) * C, "bytes": f * N * (HC + 8 + C) + img(HC + 8, C),
+                                "note": "d_x = [d_xw | d_a] @ Wcat^T as its own launch (beyond the LLC, behind the pipelined B2)"},
         "k_reduce_partials": {"bound": "latency", "bytes": 0},
         "k_wgrad": {"bound": "mfma", "flops": 2 * N * (HC + 1) * C + 2 * N * (HC + 8) * C,
                     "bytes": f * N * (HC + C) + f * N * (HC + 8 + C)},
@@ -129,7 +133,9 @@ def time_isolated_aggregate(conv, batch, x, reps):
         ws = torch.empty(lib.glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=x.device)
 
     ell = gi.ell()      # index records of the software-pipelined forward (molecules: in-degree <= 4)
+    ell_t = gi.ell_t()  # ... and by source, for the pipelined backward B2
     onehot = int(ops.rows_are_one_hot(ea))
+    alpha_e, dpre_e = torch.rand(E, 4, device=x.device), torch.randn(E, 4, device=x.device)
 
     def body():
         lib.glam_triplet_fwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(gi.rowptr), p(gi.src), p(gi.eid), N, E, H, Cp, Dp, 1,
@@ -140,6 +146,9 @@ def time_isolated_aggregate(conv, batch, x, reps):
         lib.glam_triplet_bwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(aggr), p(stats), p(d_aggr), p(gi.rowptr), p(gi.src),
                              p(gi.eid), p(colptr), p(dst), p(eid_t), N, E, H, Cp, Dp, 1, 0.2, p(d_xw), p(d_a), p(d_we),
                              p(d_M), None, p(ws), ws.numel(), st())
+        if ell_t is not None:
+            lib.glam_triplet_bwd_src_ell(p(d_aggr), p(alpha_e), p(dpre_e), p(ea), p(We), p(ell_t[0]), p(ell_t[1]), N, E, H, Cp, Dp, onehot,
+                                         p(d_xw), p(d_a), 0, st())
     return profile_step(body, reps)
 
 

@@ -101,7 +101,8 @@ SIGNATURES = {
     "glam_triplet_layer_bwd_params_x16": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 10 + [_sz, _vp]),
     "glam_triplet_layer_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "glam_triplet_layer_bwd_params": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 11 + [_sz, _vp]),
-    "glam_triplet_layer_bwd_params_acc": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 16 + [_sz, _vp]),
+    "glam_triplet_layer_bwd_params_acc": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 16 + [_i32, _vp, _vp, _sz, _vp]),
+    "glam_triplet_bwd_src_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "glam_triplet_layer_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
 }
 

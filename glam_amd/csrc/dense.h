@@ -73,7 +73,12 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, int xw_bf16 = 0, hipEvent_t after_b1 = nullptr,
-                     const float* img_dagg = nullptr, const float* d_out = nullptr);
+                     const float* img_dagg = nullptr, const float* d_out = nullptr, const int32_t* ell_dst = nullptr,
+                     const int32_t* ell_eid_t = nullptr, int edge_onehot = 0);
+// B2 over ELL records by source (triplet_dma.hip: software-pipelined, bit-identical to k_triplet_bwd_src)
+int triplet_bwd_src_pipe(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
+                         const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
+                         float* d_xw, float* d_a_ij, int grid_blocks, hipStream_t s);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De);
 

@@ -126,7 +126,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1, const float* img_dagg,
-                     const float* d_out) {
+                     const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
@@ -176,6 +176,12 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
             return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
     }
+    if (ell_dst && ell_eid_t && emul && Cp <= 64) {
+        // molecular graphs beyond the LLC: the software-pipelined B2 over ELL records by source (no fused d_x: the caller runs the GEMM)
+        if (img_dx || d_x) return fail(GLAM_E_INVALID, "glam_triplet_bwd: the ELL route of B2 has no fused d_x");
+        return triplet_bwd_src_pipe(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
+                                    d_a_ij, 0, s);
+    }
     const bool fuse_dx = img_dx && d_x && triplet_bwd_can_fuse_dx(H, Cp, De) && emul;
     if ((img_dx || d_x) && !fuse_dx) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_x variant for H=%d Cp=%d", H, Cp);
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij,
@@ -205,5 +211,20 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+// B2 alone over ELL records by source (tests, isolated timing): d_xw[N, H*Cp], d_a_ij[N, 8] (the a_j half, columns 4..7, is written)
+extern "C" int glam_triplet_bwd_src_ell(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr,
+                                        const float* w_edge, const int32_t* ell_dst, const int32_t* ell_eid_t, int64_t N, int64_t E, int H,
+                                        int Cp, int De, int edge_onehot, float* d_xw, float* d_a_ij, int grid_blocks, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX && E >= 0, "glam_triplet_bwd_src_ell: N / E out of range");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(d_aggr && alpha_e && dpre_e && w_edge && ell_dst && ell_eid_t && d_xw && d_a_ij && (E == 0 || edge_attr),
+                 "glam_triplet_bwd_src_ell: null pointer");
+    GLAM_REQUIRE(aligned16(d_aggr) && aligned16(alpha_e) && aligned16(dpre_e) && aligned16(edge_attr) && aligned16(w_edge) &&
+                     aligned16(ell_dst) && aligned16(ell_eid_t) && aligned16(d_xw) && aligned16(d_a_ij),
+                 "glam_triplet_bwd_src_ell: pointers must be 16-byte aligned");
+    return triplet_bwd_src_pipe(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw, d_a_ij,
+                                grid_blocks, (hipStream_t)stream);
 }

@@ -670,6 +670,243 @@ int triplet_fwd_pipe_fused(const float* xw, const float* a_ij, const float* edge
     return fail(GLAM_E_UNSUPPORTED, "triplet_fwd_pipe_fused: no kernel for H=%d De=%d", H, De);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_triplet_bwd_src_pipe: backward B2 (d_xw[j] = sum over the out-edges of j of alpha_e * e_ij * d_aggr[dst], d_a_j[j] = sum dpre_e;
+// the general kernel is k_triplet_bwd_src) with the data flow of k_triplet_fwd_pipe: ELL records BY SOURCE (dst[4] | eid[4] per
+// node, glam_ell_build on the CSR transpose), the d_aggr rows of the next pass prefetched into registers, the per-edge scalars
+// (alpha_e | dpre_e | edge_attr: three masked LDS-DMA pieces into one 1 KB side table) staged one pass ahead, results stored one
+// pass late.  No softmax, so a pass is cheaper than the forward's.  Same arithmetic in the same order: bit-identical.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct SrcPipeArgs {
+    const float* d_aggr; const float* alpha_e; const float* dpre_e; const float* edge_attr; const float* w_edge;
+    const int* ell_dst; const int* ell_eid;      // [N][4] each, by source
+    int N; int Cp;
+    float* d_xw; float* d_a_ij;
+};
+
+template <int H, int DE, bool ONEHOT>
+__global__ void __launch_bounds__(kBlock, GLAM_PIPE_WAVES) k_triplet_bwd_src_pipe(SrcPipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane >> 4, q = lane & 15;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    const int WSZ = DE * HC;
+    constexpr int kMetaF = 64 * 4;
+    float* s_w = smem;
+    float* wbase = smem + WSZ + wave * (2 * kMetaF);
+    for (int i = tid; i < WSZ / 4; i += kBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+    __syncthreads();
+
+    const int npass = (a.N + 3) >> 2;
+    const int gw = blockIdx.x * (kBlock / 64) + wave, GW = gridDim.x * (kBlock / 64);
+    const bool qok = q < Q;
+    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;
+    const unsigned qoff = (unsigned)(qok ? q : 0) * 16u;
+    // side table: lanes [0, 16) alpha_e of packed slot t, [16, 32) dpre_e, [32, 32 + 16 * DE / 4) edge_attr
+    constexpr int kEaLanes = kMetaSlots * (DE / 4);
+    const int mt_kind = lane < 16 ? 0 : lane < 32 ? 1 : lane < 32 + kEaLanes ? 2 : 3;
+    const int mt_slot = mt_kind == 0 ? lane : mt_kind == 1 ? lane - 16 : mt_kind == 2 ? (lane - 32) / (DE / 4) : 0;
+    const unsigned mt_sub = mt_kind == 2 ? (unsigned)((lane - 32) % (DE / 4)) * 16u : 0u;
+    constexpr int CH = 4;
+
+    auto load_rec = [&](int pass, int& rs, int& re) {
+        const int n = 4 * pass + j;
+        rs = -1; re = -1;
+        if (q < 4 && pass < npass && n < a.N) { rs = a.ell_dst[4 * n + q]; re = a.ell_eid[4 * n + q]; }
+    };
+    auto prefetch = [&](int pass, int rs, int re, int sel, float4 (&rows)[CH][H]) -> PassMeta {
+        const unsigned long long bal = __ballot(rs >= 0);
+        const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
+                  d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
+        PassMeta pm;
+        pm.deg = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
+        pm.off = j == 0 ? 0 : j == 1 ? d0 : j == 2 ? d0 + d1 : d0 + d1 + d2;
+        pm.tot = __builtin_amdgcn_readfirstlane(d0 + d1 + d2 + d3);
+        pm.dmax = __builtin_amdgcn_readfirstlane(max(max(d0, d1), max(d2, d3)));
+        if (pm.tot == 0) return pm;
+        const int t = min(mt_slot, pm.tot - 1);
+        const int og = t < d0 ? 0 : t < d0 + d1 ? 1 : t < d0 + d1 + d2 ? 2 : 3;
+        const int ooff = og == 0 ? 0 : og == 1 ? d0 : og == 2 ? d0 + d1 : d0 + d1 + d2;
+        const int owner = 16 * og + (t - ooff);
+        const int m_eid = __shfl(re, owner, 64);
+        int sk[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) sk[k] = __shfl(rs, 16 * j + k, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sk[0]), "+v"(sk[1]), "+v"(sk[2]), "+v"(sk[3]) : : "memory");
+        const unsigned dst = lds_addr(wbase + sel * kMetaF);
+        // three wave-uniform bases: three masked pieces into the same 1 KB buffer (lane l always lands at dst + 16 l)
+        if (mt_kind == 0) dma16(a.alpha_e, (unsigned)m_eid * 16u, dst);
+        else if (mt_kind == 1) dma16(a.dpre_e, (unsigned)m_eid * 16u, dst);
+        else if (mt_kind == 2) dma16(a.edge_attr, (unsigned)m_eid * (unsigned)(DE * 4) + mt_sub, dst);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (k < pm.dmax) {                            // scalar branch: slot k is empty in all four nodes otherwise
+                const unsigned ro = (unsigned)max(sk[k] >= 0 ? sk[k] : sk[0], 0) * row_bytes + qoff;
+#pragma unroll
+                for (int h = 0; h < H; ++h) rows[k][h] = ld4o(a.d_aggr, ro + (unsigned)h * head_bytes);
+            } else {
+#pragma unroll
+                for (int h = 0; h < H; ++h) rows[k][h] = f4zero();
+            }
+        }
+        return pm;
+    };
+
+    float4 r_acc[H];
+    float4 r_da = f4zero();
+    int r_n = -1;
+    auto compute = [&](int pass, const PassMeta& pm, int sel, const float4 (&rows)[CH][H]) {
+        const int n = 4 * pass + j;
+        if (n >= a.N || pass >= npass) { r_n = -1; return; }
+        r_n = n;
+        const float* meta = wbase + sel * kMetaF;
+#pragma unroll
+        for (int h = 0; h < H; ++h) r_acc[h] = f4zero();
+        r_da = f4zero();
+        if (pm.deg > 0) {
+            bool val[CH];
+            float ea[CH][DE];
+            float4 al[CH], dp[CH];
+            int wrow[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                val[k] = k < pm.deg;
+                if (k < pm.dmax) {
+                    const int slot = pm.off + (val[k] ? k : 0);
+                    al[k] = ld4(meta + slot * 4);
+                    dp[k] = ld4(meta + (16 + slot) * 4);
+#pragma unroll
+                    for (int u = 0; u < DE / 4; ++u) {
+                        const float4 v = ld4(meta + (32 + slot * (DE / 4) + u) * 4);
+                        ea[k][4 * u] = v.x; ea[k][4 * u + 1] = v.y; ea[k][4 * u + 2] = v.z; ea[k][4 * u + 3] = v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (k < pm.dmax) {
+                    if (!val[k]) { al[k] = f4zero(); dp[k] = f4zero(); }      // an empty slot runs with weight 0 on a finite row
+                    r_da.x += dp[k].x; r_da.y += dp[k].y; r_da.z += dp[k].z; r_da.w += dp[k].w;
+                    if constexpr (ONEHOT) {
+                        int t = 0;
+#pragma unroll
+                        for (int kk = 1; kk < DE; ++kk) t = ea[k][kk] != 0.f ? kk : t;
+                        wrow[k] = t * HC + (qok ? q : 0) * 4;
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float4 wv[DE], er[CH];
+                if constexpr (!ONEHOT) {
+#pragma unroll
+                    for (int kk = 0; kk < DE; ++kk) wv[kk] = ld4(s_w + (kk * H + h) * Cp + (qok ? q : 0) * 4);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (k < pm.dmax) er[k] = ld4(s_w + wrow[k] + h * Cp);
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (k < pm.dmax) {
+                        float4 e4;
+                        if constexpr (ONEHOT) {
+                            e4 = er[k];
+                        } else {
+                            e4 = f4zero();
+#pragma unroll
+                            for (int kk = 0; kk < DE; ++kk) fma4(e4, ea[k][kk], wv[kk]);
+                        }
+                        const float4 dg = e4 * rows[k][h];
+                        fma4(r_acc[h], f4get(al[k], h), dg);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto store_results = [&]() {
+        if (r_n < 0) return;
+        if (qok) {
+            const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
+#pragma unroll
+            for (int h = 0; h < H; ++h) st4o(a.d_xw, orow + (unsigned)h * head_bytes, r_acc[h]);
+        }
+        if (q == 0) st4o(a.d_a_ij, (unsigned)r_n * 32u + 16u, r_da);
+        r_n = -1;
+    };
+    auto settle = [&](float4 (&rows)[CH][H]) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                asm volatile("" : : "v"(rows[k][h].x), "v"(rows[k][h].y), "v"(rows[k][h].z), "v"(rows[k][h].w));
+    };
+
+    float4 rows_a[CH][H], rows_b[CH][H];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) { rows_a[k][h] = f4zero(); rows_b[k][h] = f4zero(); }
+    int rs_nxt, re_nxt;
+    int pass = gw;
+    load_rec(pass, rs_nxt, re_nxt);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+    PassMeta pm_cur = prefetch(pass, rs_nxt, re_nxt, 0, rows_a);
+    load_rec(pass + GW, rs_nxt, re_nxt);
+    for (; pass < npass; pass += 2 * GW) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        settle(rows_a);
+        store_results();
+        PassMeta pm_nxt = prefetch(pass + GW, rs_nxt, re_nxt, 1, rows_b);
+        load_rec(pass + 2 * GW, rs_nxt, re_nxt);
+        compute(pass, pm_cur, 0, rows_a);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        settle(rows_b);
+        store_results();
+        pm_cur = prefetch(pass + 2 * GW, rs_nxt, re_nxt, 0, rows_a);
+        load_rec(pass + 3 * GW, rs_nxt, re_nxt);
+        compute(pass + GW, pm_nxt, 1, rows_b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_results();
+}
+
+template <int H, int DE, bool ONEHOT>
+static void launch_src_pipe(const SrcPipeArgs& a, int grid, hipStream_t s) {
+    const size_t lds = ((size_t)DE * H * a.Cp + (size_t)(kBlock / 64) * 2 * 64 * 4) * sizeof(float);
+    GLAM_PROF_LABEL("k_triplet_bwd_src_pipe");
+    hipLaunchKernelGGL((k_triplet_bwd_src_pipe<H, DE, ONEHOT>), dim3(grid), dim3(kBlock), lds, s, a);
+}
+
+// B2 over ELL records by source (called by triplet_bwd_impl when the caller supplied them)
+int triplet_bwd_src_pipe(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
+                         const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
+                         float* d_xw, float* d_a_ij, int grid_blocks, hipStream_t s) {
+    if (N == 0) return GLAM_OK;
+    if (!(H >= 1 && H <= 4 && (De == 4 || De == 8) && Cp <= 64 && (Cp & 3) == 0))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_pipe: H=%d Cp=%d De=%d outside the kernel table", H, Cp, De);
+    if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_pipe: a tensor exceeds 4 GiB (32-bit offsets)");
+    SrcPipeArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij};
+    const int npass = (int)((N + 3) / 4);
+    int grid = grid_blocks > 0 ? grid_blocks : 512;
+    if (grid > (npass + 3) / 4) grid = (npass + 3) / 4;
+#define GLAM_SP_CASE(HH, DD)                                                     \
+    if (H == HH && De == DD) {                                                   \
+        if (edge_onehot) launch_src_pipe<HH, DD, true>(a, grid, s);              \
+        else launch_src_pipe<HH, DD, false>(a, grid, s);                         \
+        GLAM_LAUNCH_CHECK("triplet_bwd_src_pipe");                               \
+        return GLAM_OK;                                                          \
+    }
+    GLAM_SP_CASE(1, 4) GLAM_SP_CASE(2, 4) GLAM_SP_CASE(3, 4) GLAM_SP_CASE(4, 4)
+    GLAM_SP_CASE(1, 8) GLAM_SP_CASE(2, 8) GLAM_SP_CASE(3, 8) GLAM_SP_CASE(4, 8)
+#undef GLAM_SP_CASE
+    return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_pipe: no kernel for H=%d De=%d", H, De);
+}
+
 __global__ void __launch_bounds__(kBlock) k_ell_build(const int* rowptr, const int* nbr, const int* eid, int N, int4* ell_src,
                                                      int4* ell_eid, int* overflow) {   // one int4 per node and table
     for (int n = blockIdx.x * kBlock + threadIdx.x; n < N; n += gridDim.x * kBlock) {

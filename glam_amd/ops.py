@@ -99,6 +99,7 @@ class GraphIndex:
         self._t = None
         self._tiles = False            # False: not planned yet; None: no plan (general kernels); else (tile_ptr, T)
         self._ell = False              # False: not built yet; None: in-degree > 4 somewhere; else (ell_src, ell_eid)
+        self._ell_t = False            # the same by source (out-degree), for the pipelined backward B2
         self._err = torch.zeros(1, **i32)
         ws = torch.empty(lib.glam_csr_workspace_bytes(self.N, self.E), dtype=torch.uint8, device=dev)
         check(lib.glam_csr_build(ptr(ei), self.N, self.E, 0, ptr(self.rowptr), ptr(self.src), ptr(self.eid),
@@ -154,6 +155,21 @@ class GraphIndex:
                     self._ell = (es, ee)
         return self._ell
 
+    def ell_t(self):
+        """``(ell_dst, ell_eid_t)`` int32 ``[N, 4]``: the ELL records BY SOURCE of the software-pipelined backward B2 (``glam_ell_build`` on
+        the CSR transpose), or ``None`` when some node has more than 4 outgoing edges (one host sync, once per edge list)."""
+        if self._ell_t is False:
+            self._ell_t = None
+            if self.N > 0:
+                lib = _lib.load()
+                colptr, dst, eid_t = self.transpose()
+                i32 = dict(dtype=torch.int32, device=self.device)
+                es, ee, ovf = torch.empty(self.N, 4, **i32), torch.empty(self.N, 4, **i32), torch.zeros(1, **i32)
+                check(lib.glam_ell_build(ptr(colptr), ptr(dst), ptr(eid_t), self.N, ptr(es), ptr(ee), ptr(ovf), stream()), "glam_ell_build(T)")
+                if int(ovf.item()) == 0:
+                    self._ell_t = (es, ee)
+        return self._ell_t
+
     def transpose(self):
         """CSR by source (built on first backward)."""
         if self._t is None:
@@ -175,6 +191,7 @@ class GraphIndex:
 
 
 TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
+BWD_ELL = os.environ.get("GLAM_BWD_ELL", "1") == "1"       # A/B knob: pipelined B2 beyond the LLC
 # Fused forward with the software pipeline inside (csrc/triplet_dma.hip, FUSE = true), for molecular graphs: "auto" = beyond the LLC
 # (B = 16 384: 195 vs 240 us), "1" = always (B = 1 024: 18.2 vs 16.4 us — the general fused kernel wins while the batch is cache
 # resident), "0" = never.
@@ -568,17 +585,24 @@ class _TripletLayer(torch.autograd.Function):
             if ctx.carried:
                 return d_x, None, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
             return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
-        if ctx.carried and d_carry is not None and N > 0:
+        # beyond the LLC, molecular graphs: the software-pipelined B2 over ELL records by source (bit-identical)
+        ell_t = gi.ell_t() if (N > 0 and BWD_ELL and GraphIndex.wants_ell(N, H, Cp) and d_ea is None) else None
+        have_carry = ctx.carried and d_carry is not None and N > 0
+        if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
-            d_carry = f32c(d_carry, "d_carry")
-            c_wn, c_we, c_att, c_wsc, c_bias = d_carry.split(sizes)
+            c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
+            c_wn, c_we, c_att, c_wsc, c_bias = c_parts
             check(lib.glam_triplet_layer_bwd_params_acc(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                         ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                         ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
                                                         ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(c_wn), ptr(c_we),
-                                                        ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(d_ea), ptr(ws), ws.numel(), stream()),
+                                                        ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(ell_t[0]) if ell_t else None,
+                                                        ptr(ell_t[1]) if ell_t else None, int(rows_are_one_hot(ea_p)) if ell_t else 0,
+                                                        ptr(d_ea), ptr(ws), ws.numel(), stream()),
                   "glam_triplet_layer_bwd_params_acc")
-            return d_x, d_ea, None, None, None, None, None, None, None, None, flatg
+            if ctx.carried:
+                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry))
+            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),

@@ -274,7 +274,10 @@ int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const 
 
 /* glam_triplet_layer_bwd_params with addends for the five parameter gradients (each laid out like its output, any of them
  * NULL): out = gradient + addend.  The block is applied message_steps times with shared weights (src_1gp/model.py:53-54); the
- * gradient already accumulated by its later applications enters here instead of through a separate add launch.  N > 0. */
+ * gradient already accumulated by its later applications enters here instead of through a separate add launch.  N > 0.
+ * ell_dst / ell_eid_t (may be NULL): ELL records BY SOURCE — glam_ell_build on (colptr, dst, eid_t); every node of a molecular graph
+ * has at most 4 out-edges — select the software-pipelined B2 (bit-identical; the op layer passes them beyond the LLC) followed by the
+ * d_x GEMM as its own launch; edge_onehot as in glam_triplet_fwd_ell. */
 int glam_triplet_layer_bwd_params_acc(const float* x, const float* edge_attr, const float* staged, const float* xw,
                                       const float* a_ij, const float* aggr, const float* stats, const float* d_out,
                                       const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
@@ -283,7 +286,13 @@ int glam_triplet_layer_bwd_params_acc(const float* x, const float* edge_attr, co
                                       const float* att, float* d_x, float* d_weight_node, float* d_weight_edge, float* d_att,
                                       float* d_weight_scale, float* d_bias, const float* add_weight_node,
                                       const float* add_weight_edge, const float* add_att, const float* add_weight_scale,
-                                      const float* add_bias, float* d_edge_attr, void* ws, size_t ws_bytes, void* stream);
+                                      const float* add_bias, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot,
+                                      float* d_edge_attr, void* ws, size_t ws_bytes, void* stream);
+/* B2 alone (d_xw, d_a_j from alpha_e / dpre_e f32[E, 4] as B1 leaves them) over ELL records by source: the software-pipelined
+ * kernel glam_triplet_layer_bwd_params_acc runs when it is given ell_dst / ell_eid_t; for tests and isolated timing. */
+int glam_triplet_bwd_src_ell(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr,
+                             const float* w_edge, const int32_t* ell_dst, const int32_t* ell_eid_t, int64_t N, int64_t E, int H, int Cp,
+                             int De, int edge_onehot, float* d_xw, float* d_a_ij, int grid_blocks, void* stream);
 
 /* bf16 STORAGE of the gathered rows (BASELINE.json configs[2]: "bf16"; the reference itself is fp32 only): xw16 is
  * bf16[N, H*Cp], written round-to-nearest-even by the node GEMM's epilogue and widened on load by the aggregate kernels;

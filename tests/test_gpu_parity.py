@@ -1946,3 +1946,47 @@ def test_fused_gru_forward_is_bit_identical_to_the_two_launch_sequence(device, m
     for a, c in zip(*res):
         assert torch.equal(a, c)
     assert not ops._lib.load().glam_gru_fused_supported(66) and not ops._lib.load().glam_gru_fused_supported(0)
+
+
+def test_pipelined_backward_b2_equals_the_general_kernel(device, monkeypatch):
+    """The layer's backward beyond the LLC (software-pipelined B2 over ELL records by source + the d_x GEMM as its own launch) against the
+    default route (general B2 with the d_x GEMM as its epilogue): all six gradients equal bit for bit — batches that are not a multiple of
+    the tiles, isolated atoms, one-hot and continuous edge features, De = 8, a layer applied twice (gradient carry)."""
+    for B, seed, De in ((3, 1, 4), (50, 2, 4), (333, 3, 4), (40, 4, 8)):
+        b = synth_batch(B, seed=seed).to(device)
+        ea = b.edge_attr if De == 4 else torch.randn(b.edge_attr.size(0), 8, device=device)
+        if seed == 3:
+            ea = ea + 0.25 * torch.rand_like(ea)                     # not one-hot: the contraction path
+        torch.manual_seed(seed)
+        conv = layer.TripletMessage(60, De).to(device)
+        x0 = torch.randn(b.x.size(0), 60, device=device)
+        cot = torch.randn(b.x.size(0), 60, device=device)
+        res = []
+        for ell in (False, True):
+            monkeypatch.setattr(ops, "BWD_ELL", ell)
+            monkeypatch.setattr(ops.GraphIndex, "ELL_MIN_NODES", 0 if ell else 1 << 40)
+            monkeypatch.setattr(ops, "PIPE_FUSED", "0")
+            x = x0.clone().requires_grad_(True)
+            with ops.weight_scope():
+                y = conv(conv(x, b.edge_index, ea), b.edge_index, ea)
+                res.append(torch.autograd.grad(y, [x] + list(conv.parameters()), grad_outputs=cot))
+        assert all(torch.equal(a, c) for a, c in zip(*res)), (B, De)
+    # B2 alone against a plain torch statement of it
+    gi = ops.GraphIndex(b.edge_index, b.x.size(0))
+    ell_t = gi.ell_t()
+    assert ell_t is not None
+    N, E, H, Cp = gi.N, gi.E, 3, 64
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    d_aggr, alpha, dpre, w_edge, eattr = r(N, H * Cp), r(E, 4), r(E, 4), r(8, H * Cp), r(E, 8)
+    d_xw, d_a = torch.empty(N, H * Cp, device=device), torch.zeros(N, 8, device=device)
+    raw = ops._lib.load()
+    ops.check(raw.glam_triplet_bwd_src_ell(ops.ptr(d_aggr), ops.ptr(alpha), ops.ptr(dpre), ops.ptr(eattr), ops.ptr(w_edge), ops.ptr(ell_t[0]),
+                                           ops.ptr(ell_t[1]), N, E, H, Cp, 8, 0, ops.ptr(d_xw), ops.ptr(d_a), 0, ops.stream()), "b2 ell")
+    src, dst = b.edge_index[0], b.edge_index[1]
+    e_ij = (eattr.double() @ w_edge.double()).view(E, H, Cp)
+    msg = alpha[:, :H].double().unsqueeze(-1) * e_ij * d_aggr.double().view(N, H, Cp)[dst]
+    ref = torch.zeros(N, H, Cp, dtype=torch.float64, device=device).index_add_(0, src, msg).view(N, H * Cp)
+    ref_a = torch.zeros(N, 4, dtype=torch.float64, device=device).index_add_(0, src, dpre.double())
+    assert (d_xw.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert (d_a[:, 4:].double() - ref_a).abs().max().item() <= 1e-5 * max(1.0, ref_a.abs().max().item())
