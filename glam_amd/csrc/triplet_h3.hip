@@ -14,3 +14,9 @@ extern "C" int glam_debug_b1_prof(long long* host_out, int n) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_b1_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 #endif
+
+#ifdef GLAM_FWD_PROF
+extern "C" int glam_debug_fwd_prof(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_fwd_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -44,6 +44,13 @@ __device__ long long g_b1_prof[1024 * 32];
 #define B1_STAMP(k) do { } while (0)
 #endif
 
+#ifdef GLAM_FWD_PROF   // developer aid (tools/fwd_prof.py): cycle breakdown of the fused forward's tiles
+__device__ long long g_fwd_prof[512 * 8];
+#define FWD_STAMP(k) do { if (tid == 0 && blockIdx.x < 512) { const long long n__ = clock64(); fp_acc[k] += n__ - fp_last; fp_last = n__; } } while (0)
+#else
+#define FWD_STAMP(k) do { } while (0)
+#endif
+
 struct FwdArgs {
     const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
     const int* rowptr; const int* nbr; const int* eid;
@@ -142,8 +149,13 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
         // LDS-DMA: lands while the first tile is aggregated (the barrier before the first MFMA drains vmcnt)
         if (fuse_upd) lds_copy_async<kBlock>(a.img_upd, s_img, ((HC + 15) >> 4) * 256, tid);
     }
+#ifdef GLAM_FWD_PROF
+    long long fp_acc[8] = {}, fp_last = clock64();
+    const long long fp_t0 = fp_last;
+#endif
     for (int base = blockIdx.x * GPB; base < a.N; base += gridDim.x * GPB) {
       const int n = base + tid / G;
+      FWD_STAMP(0);
       if (n < a.N) {
         int beg, end;
         float4 aiv;
@@ -281,7 +293,9 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
         // (one ds_read_b128 per 16-k group), A fragments from the LDS tile.  The launch is capped at two blocks per CU
         // and strides over the 16-node tiles, so the 48 KB image is fetched 512 times instead of once per tile.
         if (fuse_upd) {
+            FWD_STAMP(1);
             __syncthreads();
+            FWD_STAMP(2);
             const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
             const int GK = (HC + 15) >> 4;
             v4f cacc = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -302,7 +316,9 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) s_out[(kq * 4 + i) * 64 + 4 * c + wave] = cacc[i];
+            FWD_STAMP(3);
             __syncthreads();
+            FWD_STAMP(4);
             const int row = tid >> 4, c4 = (tid & 15) * 4;
             if (c4 < Cp && base + row < a.N) {
                 float4 v = ld4(s_out + row * 64 + c4);
@@ -310,9 +326,17 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 st4(a.out + (size_t)(base + row) * Cp + c4, v);
             }
+            FWD_STAMP(5);
         }
       }
     }
+#ifdef GLAM_FWD_PROF
+    if (tid == 0 && blockIdx.x < 512) {
+        for (int k = 0; k < 6; ++k) g_fwd_prof[blockIdx.x * 8 + k] = fp_acc[k];
+        g_fwd_prof[blockIdx.x * 8 + 6] = fp_t0;
+        g_fwd_prof[blockIdx.x * 8 + 7] = clock64();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
