@@ -66,6 +66,36 @@ def test_config2_full_batch_fwd_bwd_all_gradients(device):
     print("\n".join(f"  config2 {n:22s} max|d| = {e:.2e}  (bound {bd:.2e})" for n, e, bd in report))
 
 
+def test_config2_beyond_the_llc_b16384_pipelined_kernels(device):
+    """"also report B = 16 384" — every [N, 180] tensor is 226 MiB, past the 256 MiB LLC, which is where the op layer
+    switches to the software-pipelined forward (fused with the update GEMM) and the pipelined backward by source.  Output and all six
+    gradients against the fp32 oracle (fp32 only: the fp64 twin of a 330 k-node batch is not a few-seconds job), scaled bounds of the
+    sweeps (tests/sweeps/big_batch_parity.py measures 4.1e-7 / 1.8e-6)."""
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    b = synth_batch(16384, seed=3)
+    N = b.x.size(0)
+    torch.manual_seed(1)
+    conv = layer.TripletMessage(60, 4)
+    x0 = torch.randn(N, 60)
+    ps0 = [p.detach().clone().requires_grad_(True) for p in conv.parameters()]
+    xo = x0.clone().requires_grad_(True)
+    ref = O.triplet_message(xo, b.edge_index, b.edge_attr, *ps0)
+    cot = torch.randn(ref.shape)
+    g_ref = torch.autograd.grad((ref * cot).sum(), [xo] + ps0)
+    convd = conv.to(device)
+    bd = b.to(device)
+    assert ops.GraphIndex.wants_ell(N, 3, 60), "the pipelined kernels are the op layer's choice at this size"
+    x = x0.to(device).requires_grad_(True)
+    out = convd(x, bd.edge_index, bd.edge_attr)
+    gs = torch.autograd.grad((out * cot.to(device)).sum(), [x] + list(convd.parameters()))
+    gi = ops.graph_index(bd.edge_index, N)
+    assert gi.ell() is not None and gi.ell_t() is not None, "molecular batch: ELL records by target and by source exist"
+    worst = (out.cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    gw = max((a.cpu() - r).abs().max().item() / max(1.0, r.abs().max().item()) for a, r in zip(gs, g_ref))
+    print(f"  config2 B=16384 N={N}: out {worst:.2e}, worst gradient {gw:.2e} (relative to scale)")
+    assert worst < 1e-5 and gw < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------
 # configs[2]: full stack, bf16 row storage
 # ---------------------------------------------------------------------------------------------
