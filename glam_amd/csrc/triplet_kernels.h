@@ -833,6 +833,12 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
       const int j = base + tid / G;
       if (j < a.N) {
         const int beg = ldio(a.colptr, (unsigned)j * 4u), end = ldio(a.colptr, (unsigned)j * 4u + 4u);
+        // d_a_i (written by B1) for the d_x tile: requested here, in front of every store of the node — issued behind the d_xw stores
+        // the load made the compiler wait for vmcnt(0), i.e. for those stores to land
+        float4 dai_v = f4zero();
+        if constexpr (G == 16) {
+            if (fuse_dx && lg == 0) dai_v = ld4o(a.d_a_ij, (unsigned)j * 32u);
+        }
         float4 acc[H][ITER];
         float4 daj = f4zero();
 #pragma unroll
@@ -913,7 +919,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_bwd_src(BwdS
             st4o(a.d_a_ij, (unsigned)j * 32u + 16u, daj);
             if constexpr (G == 16) {
                 if (fuse_dx) {
-                    st4(s_tile + (tid / G) * LDT + HC, ld4o(a.d_a_ij, (unsigned)j * 32u));
+                    st4(s_tile + (tid / G) * LDT + HC, dai_v);
                     st4(s_tile + (tid / G) * LDT + HC + 4, daj);
                 }
             }
