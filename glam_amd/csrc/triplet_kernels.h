@@ -145,9 +145,13 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
     float* s_tile = s_w + (EMUL ? DE * HC : 0);
     float* s_out = s_tile + 16 * LDT;
     float* s_img = s_out + 16 * 64;                            // update-GEMM weight image, resident for the whole block
+    float4 bias_v = f4zero();          // this thread's four columns of the out tile: loaded once, not once per tile behind the stores
     if constexpr (G == 16) {
         // LDS-DMA: lands while the first tile is aggregated (the barrier before the first MFMA drains vmcnt)
-        if (fuse_upd) lds_copy_async<kBlock>(a.img_upd, s_img, ((HC + 15) >> 4) * 256, tid);
+        if (fuse_upd) {
+            lds_copy_async<kBlock>(a.img_upd, s_img, ((HC + 15) >> 4) * 256, tid);
+            if ((tid & 15) * 4 < Cp) bias_v = ld4(a.bias_p + (tid & 15) * 4);
+        }
     }
 #ifdef GLAM_FWD_PROF
     long long fp_acc[8] = {}, fp_last = clock64();
@@ -322,8 +326,7 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             const int row = tid >> 4, c4 = (tid & 15) * 4;
             if (c4 < Cp && base + row < a.N) {
                 float4 v = ld4(s_out + row * 64 + c4);
-                const float4 b = ld4(a.bias_p + c4);
-                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                v.x += bias_v.x; v.y += bias_v.y; v.z += bias_v.z; v.w += bias_v.w;
                 st4(a.out + (size_t)(base + row) * Cp + c4, v);
             }
             FWD_STAMP(5);
