@@ -1065,7 +1065,7 @@ class _LinearLib(torch.autograd.Function):
             lib = _lib.load()
             N, D = dy.shape
             db = torch.empty(D, dtype=torch.float32, device=dy.device)
-            ws = torch.empty(lib.glam_colsum_workspace_bytes(D) if N > 2048 else 16, dtype=torch.uint8, device=dy.device)
+            ws = torch.empty(lib.glam_colsum_workspace_bytes(D), dtype=torch.uint8, device=dy.device)   # (touched for N > 2048 only)
             check(lib.glam_colsum(ptr(dy), N, D, D, ptr(db), ptr(ws), ws.numel(), stream()), "glam_colsum")
         return dx, dw, db
 
