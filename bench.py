@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--eager-allreduce", action="store_true", help="keep the gradient all-reduce outside the captured graph")
+    ap.add_argument("--steps-per-graph", type=int, default=16,
+                    help="consecutive steps captured into one hipGraph launch (each graph launch carries a ~7 us bubble on this stack: "
+                         "98.0 / 94.5 / 92.6 / 91.7 / 91.3 us per step at 1 / 2 / 4 / 8 / 16 steps per launch, tools/exp_multistep_graph.py)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--large-batch", type=int, default=16384, help="extra roofline point beyond the LLC (0 = skip)")
     ap.add_argument("--prof-reps", type=int, default=30, help="eager profiled steps behind roofline_kernels")
@@ -324,6 +327,28 @@ def main():
             with torch.cuda.graph(graph):
                 compute()
 
+    # ---- several consecutive steps per graph launch: the same kernels, the same work per step, fewer launch bubbles.  Only when the
+    #      whole step (collective included) is inside the graph; an eager all-reduce between steps keeps one step per launch ----
+    S = max(1, args.steps_per_graph)
+    graph_multi = None
+    if graph is not None and S > 1 and (world == 1 or ar_in_graph):
+        ok = 1
+        try:
+            gm = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gm):
+                for _ in range(S):
+                    compute_and_reduce() if world > 1 else compute()
+            graph_multi = gm
+        except Exception as exc:                # noqa: BLE001
+            print(f"bench.py[rank {rank}]: capturing {S} steps per graph failed ({type(exc).__name__}: {exc}); one step per launch", file=sys.stderr)
+            ok = 0
+            torch.cuda.synchronize()
+        if world > 1:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                graph_multi = None
+
     def step():
         if graph is not None:
             graph.replay()
@@ -334,17 +359,24 @@ def main():
         else:
             compute()
 
+    def run_steps(k):
+        """Exactly k steps: whole multi-step graph launches first, single-step launches for the remainder."""
+        if graph_multi is not None:
+            for _ in range(k // S):
+                graph_multi.replay()
+            k -= k // S * S
+        for _ in range(k):
+            step()
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -354,8 +386,9 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
 
-    launch = "eager" if graph is None else ("hipGraph replay" + (" (all-reduce captured in the graph)" if ar_in_graph else
-                                                                 (" + eager all-reduce" if world > 1 else "")))
+    launch = "eager" if graph is None else ("hipGraph replay" + (f", {S} steps per graph launch" if graph_multi is not None else "") +
+                                            (" (all-reduce captured in the graph)" if ar_in_graph else
+                                             (" + eager all-reduce" if world > 1 else "")))
     result = {
         "metric": "molecules/sec fwd+bwd on ESOL-shaped batches", "value": value, "unit": "molecules/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,

@@ -1990,3 +1990,38 @@ def test_pipelined_backward_b2_equals_the_general_kernel(device, monkeypatch):
     ref_a = torch.zeros(N, 4, dtype=torch.float64, device=device).index_add_(0, src, dpre.double())
     assert (d_xw.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     assert (d_a[:, 4:].double() - ref_a).abs().max().item() <= 1e-5 * max(1.0, ref_a.abs().max().item())
+
+
+def test_graphed_epochs_with_several_steps_per_graph_launch(device):
+    """GraphedTrainStep.run: consecutive steps of the cached loader captured into one graph per chunk (first epoch eager, second
+    captured, later replayed) — the per-batch stepper's trajectory bit for bit, training-mode RReLU / Dropout stream included, and an
+    lr change between epochs followed."""
+    import copy
+    from glam_amd.data import DataLoader, synth_molecule
+    from glam_amd.graphs import GraphedTrainStep
+    rng = np.random.default_rng(12)
+    mols = [synth_molecule(rng) for _ in range(40)]
+    torch.manual_seed(6)
+    net0 = model.Architecture(mol_block="_TripletMessage", message_steps=2, mol_readout="GlobalPool5", e_dim=64).to(device).train()
+    loss_fn = lambda out, b: torch.nn.functional.mse_loss(out.view(-1), b.y.view(-1))
+    results = []
+    for multi in (False, True):
+        net = copy.deepcopy(net0)
+        opt = torch.optim.Adam(net.parameters(), lr=2.0 ** -10, capturable=True)
+        loader = DataLoader(mols, batch_size=8, device=device)          # 5 cached batches
+        stepper = GraphedTrainStep(net, opt, loss_fn)
+        ops.manual_seed(21, device)
+        losses = []
+        for epoch in range(4):
+            if epoch == 3:
+                opt.param_groups[0]["lr"] = 2.0 ** -12                   # what ReduceLROnPlateau does between epochs
+            if multi:
+                losses.append(stepper.run(loader, steps_per_graph=3))   # chunks of 3 + 2 steps
+            else:
+                losses.append(torch.stack([stepper(b).reshape(()) for b in loader]))
+        if multi:
+            assert stepper.graphs() == 2, stepper.graphs()
+        results.append((torch.cat(losses), [p.detach().clone() for p in net.parameters()]))
+    (l_s, p_s), (l_m, p_m) = results
+    assert torch.equal(l_s, l_m)
+    assert all(torch.equal(a, b) for a, b in zip(p_s, p_m))
