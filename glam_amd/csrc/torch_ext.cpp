@@ -97,12 +97,14 @@ struct TripletAggregateFn : public torch::autograd::Function<TripletAggregateFn>
         const int Cp = (int)(xw.size(1) / H);
         Tensor d_xw = at::empty_like(xw), d_a = at::empty_like(a_ij), d_M = at::empty_like(M);
         Tensor d_we = emul ? at::empty_like(w_edge) : Tensor();
+        // the gradient of the bond features only when somebody asks for it (the kernels add into a zeroed buffer)
+        Tensor d_ea = ctx->needs_input_grad(2) ? at::zeros_like(edge_attr) : Tensor();
         Tensor ws = at::empty({(int64_t)glam_triplet_bwd_workspace_bytes(N, E, (int)H, Cp, (int)De)}, xw.options().dtype(at::kByte));
         check_rc(glam_triplet_bwd(fp(xw), fp(a_ij), fp(edge_attr), emul ? fp(w_edge) : nullptr, fp(M), fp(aggr), fp(stats), fp(d_aggr),
                                   ip(rowptr), ip(src), ip(eid), ip(colptr), ip(dst), ip(eid_t), N, E, (int)H, Cp, (int)De, emul ? 1 : 0,
-                                  (float)slope, fpm(d_xw), fpm(d_a), emul ? fpm(d_we) : nullptr, fpm(d_M), nullptr, ws.data_ptr(),
+                                  (float)slope, fpm(d_xw), fpm(d_a), emul ? fpm(d_we) : nullptr, fpm(d_M), fpm(d_ea), ws.data_ptr(),
                                   (size_t)ws.numel(), cur_stream()), "glam_triplet_bwd");
-        return {d_xw, d_a, Tensor(), d_we, d_M, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {d_xw, d_a, d_ea, d_we, d_M, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
@@ -155,12 +157,14 @@ struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
         Tensor d_wn = flat.narrow(0, 0, n_wn).view(wn.sizes()), d_we = flat.narrow(0, n_wn, n_we).view(we.sizes()),
                d_att = flat.narrow(0, n_wn + n_we, n_att).view(att.sizes()), d_wsc = flat.narrow(0, n_wn + n_we + n_att, n_ws).view({H * C, C}),
                d_bias = flat.narrow(0, n_wn + n_we + n_att + n_ws, C);
+        Tensor d_ea = ctx->needs_input_grad(1) ? at::zeros_like(edge_attr) : Tensor();
         Tensor ws = at::empty({(int64_t)glam_triplet_layer_bwd_workspace_bytes(N, E, (int)H, Cp, Dp)}, x.options().dtype(at::kByte));
         check_rc(glam_triplet_layer_bwd_params(fp(x), fp(edge_attr), fp(staged), fp(xw), fp(a_ij), fp(aggr), fp(stats), fp(d_out), ip(rowptr),
                                                ip(src), ip(eid), ip(colptr), ip(dst), ip(eid_t), N, E, C, (int)H, De, Cp, Dp, (float)slope, fp(wn),
-                                               fp(we), fp(att), fpm(d_x), fpm(d_wn), fpm(d_we), fpm(d_att), fpm(d_wsc), fpm(d_bias), nullptr,
+                                               fp(we), fp(att), fpm(d_x), fpm(d_wn), fpm(d_we), fpm(d_att), fpm(d_wsc), fpm(d_bias),
+                                               fpm(d_ea),
                                                ws.data_ptr(), (size_t)ws.numel(), cur_stream()), "glam_triplet_layer_bwd_params");
-        return {d_x, Tensor(), d_wn, d_we, d_att, d_wsc, d_bias, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 

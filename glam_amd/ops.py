@@ -613,16 +613,45 @@ class _TripletLayer(torch.autograd.Function):
         return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
 
 
-# GLAM_TORCH_EXT=1: the layer goes through the torch-extension operator (torch.ops.glam.triplet_layer: C++ autograd node, no ctypes
-# marshalling, no Python autograd.Function) — the route for EAGERLY issued steps; the default Python node keeps the per-pass
-# weight staging and the gradient carry of a weight_scope, which a captured hipGraph replays for free.
-USE_TORCH_EXT = os.environ.get("GLAM_TORCH_EXT", "0") == "1"
+# The layer through the torch-extension operator (torch.ops.glam.triplet_layer: C++ autograd node, no ctypes marshalling, no Python
+# autograd.Function) is the route for EAGERLY issued steps, which are bound by host time: full-model step issued eagerly 1.21 vs 1.48 ms
+# at B = 32, 1.32 vs 1.55 ms at B = 1 024.  The Python node keeps the per-pass weight staging and the gradient carry of a weight_scope,
+# which a captured hipGraph replays for free.  GLAM_TORCH_EXT: "auto" (default) = the operator while nothing is being captured and the
+# batch is cache resident (the pipelined kernels beyond the LLC are the Python node's), "1" / "0" = always / never.  Both routes give
+# the same numbers bit for bit (tested), so an eager first visit and a captured second one stay on one trajectory.
+_ext_env = os.environ.get("GLAM_TORCH_EXT", "auto")
+USE_TORCH_EXT = True if _ext_env == "1" else False if _ext_env == "0" else "auto"
+_EXT_OK = None
+
+
+def _want_torch_ext(N, H, Cp):
+    global _EXT_OK
+    if USE_TORCH_EXT is False or FEATURE_STORAGE != "fp32" or N <= 0:
+        return False
+    if USE_TORCH_EXT == "auto":
+        if torch.cuda.is_current_stream_capturing() or GraphIndex.wants_ell(N, H, Cp):
+            return False
+        if _EXT_OK is None:
+            try:
+                from . import torch_ext
+                torch_ext.load()
+                _EXT_OK = True
+            except Exception:          # noqa: BLE001 - the shim is optional in auto mode: the Python node is the same HIP path
+                _EXT_OK = False
+        return _EXT_OK
+    return True
 
 
 def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
     """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
-    if USE_TORCH_EXT and FEATURE_STORAGE == "fp32" and gi.N > 0:
+    if _want_torch_ext(gi.N, heads, x_p.size(1)):
         from . import torch_ext
+        # same checks, same exception type as the Python node (the operator's own TORCH_CHECKs would raise RuntimeError)
+        require_device(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias)
+        C = weight_node.size(0)
+        if (x_p.dim() != 2 or ea_p.dim() != 2 or gi.N != x_p.size(0) or ea_p.size(0) != gi.E or weight_node.shape != (C, heads * C)
+                or weight_scale.shape != (heads * C, C) or x_p.size(1) != (C + 3) // 4 * 4):
+            raise GlamHipError("triplet_layer: shape mismatch")
         t_ptr = gi.transpose() if torch.is_grad_enabled() else (gi.rowptr, gi.src, gi.eid)     # any int32 tensors when no backward follows
         return torch_ext.load().triplet_layer(f32c(x_p, "x"), f32c(ea_p, "edge_attr"), weight_node, weight_edge, att, weight_scale, bias,
                                               gi.rowptr, gi.src, gi.eid, t_ptr[0], t_ptr[1], t_ptr[2], heads, float(slope))

@@ -1231,7 +1231,7 @@ def test_misuse_raises_python_exceptions_and_leaves_the_device_usable(device):
     assert torch.equal(conv(x, b.edge_index, b.edge_attr), ok)        # the device is still fine
 
 
-def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device):
+def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device, monkeypatch):
     """Inside a weight scope the shared block's parameter gradients travel from application to application as one flat
     buffer (ops._ParamBundle); same sums in the same order as autograd's per-tensor accumulation."""
     torch.manual_seed(9)
@@ -1240,6 +1240,7 @@ def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device):
                              pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device).eval()
     params = [p for _, p in net.named_parameters()]
     grads = {}
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)        # the carry is the Python node's (what a captured step runs)
     for flag in (True, False):
         ops.GRAD_CARRY = flag
         try:
@@ -1257,6 +1258,10 @@ def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device):
     assert ptrs == sorted(ptrs) and ptrs[-1] - ptrs[0] < 4 * sum(p.numel() for p in conv.parameters())
     for (n, p), r in zip(net.named_parameters(), grads[False]):
         assert torch.equal(p.grad, r), n
+    # an eagerly issued step takes the torch-extension operator (no carry: autograd accumulates): same bits again
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", "auto")
+    for (n, _), a, r in zip(net.named_parameters(), torch.autograd.grad(net(b).sum(), params), grads[False]):
+        assert torch.equal(a, r), n
 
 
 def test_sharded_gradients_sum_to_the_single_device_gradient(device):
@@ -1423,6 +1428,7 @@ def test_graph_index_does_not_pin_edge_index_and_survives_its_death(device):
     (ref_g,) = torch.autograd.grad(ref_out.sum(), [x])
     ei = b.edge_index.clone()
     wr = weakref.ref(ei)
+    gc.collect()                                                      # entries of earlier tests whose tensors sit in cycles
     n_before = len(ops._GI_CACHE)
     out = conv(x, ei, b.edge_attr)
     assert len(ops._GI_CACHE) == n_before + 1
@@ -1752,9 +1758,11 @@ def test_torch_extension_ops_match_the_ctypes_route(device, monkeypatch):
     for ext in (False, True):
         monkeypatch.setattr(ops, "USE_TORCH_EXT", ext)
         x = x0.clone().requires_grad_(True)
-        out = conv(x, b.edge_index, b.edge_attr)
-        res.append((out, torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)))
+        ea = b.edge_attr.detach().clone().requires_grad_(True)        # the bond features' gradient too (layer.py:36 takes any tensor)
+        out = conv(x, b.edge_index, ea)
+        res.append((out, torch.autograd.grad(out, [x, ea] + list(conv.parameters()), grad_outputs=cot)))
     assert type(res[1][0].grad_fn).__name__ != type(res[0][0].grad_fn).__name__          # a C++ node on the extension route
+    assert float(res[1][1][1].abs().max()) > 0
     assert torch.equal(res[0][0], res[1][0])
     for a_, r_ in zip(res[1][1], res[0][1]):
         assert torch.equal(a_, r_)
