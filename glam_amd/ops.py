@@ -631,6 +631,8 @@ def _want_torch_ext(N, H, Cp):
     if USE_TORCH_EXT == "auto":
         if torch.cuda.is_current_stream_capturing() or GraphIndex.wants_ell(N, H, Cp):
             return False
+        if _EXT_OK is None and os.environ.get("GLAM_HIP_LIB"):
+            _EXT_OK = False            # the shim is linked against the in-tree libglam_hip.so, not against a substituted build
         if _EXT_OK is None:
             try:
                 from . import torch_ext

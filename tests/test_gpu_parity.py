@@ -2033,3 +2033,109 @@ def test_graphed_epochs_with_several_steps_per_graph_launch(device):
     (l_s, p_s), (l_m, p_m) = results
     assert torch.equal(l_s, l_m)
     assert all(torch.equal(a, b) for a, b in zip(p_s, p_m))
+
+
+def test_adam_one_launch_matches_the_library_optimizer(device):
+    """``glam_amd.optim.Adam`` (one HIP launch over all parameter tensors; the optimizer of trainer.py:49-50) against
+    ``torch.optim.Adam`` on the same gradient sequence: 25 steps, ragged tensor sizes (1 element, not a multiple of 4, several chunks),
+    weight decay, a learning rate a scheduler changes on the way, a parameter that gets no gradient in some steps.  Tolerance: 2e-6
+    relative to the largest parameter (fp32 re-association of the same formula; the moments to 1e-6)."""
+    from glam_amd import optim
+    torch.manual_seed(3)
+    shapes = [(1,), (7,), (60, 180), (1024, 300), (3, 5, 11), (1023,), (4097,)]
+    for wd in (0.0, 1e-2):
+        ref = [torch.nn.Parameter(torch.randn(*s, device=device)) for s in shapes]
+        mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+        o_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd, foreach=False)
+        o_mine = optim.Adam(mine, lr=1e-2, weight_decay=wd)
+        for step in range(25):
+            if step == 10:
+                for o in (o_ref, o_mine):
+                    o.param_groups[0]["lr"] = 3e-3               # what ReduceLROnPlateau does (trainer.py:85)
+            for p, q in zip(ref, mine):
+                g = torch.randn_like(p) * (10.0 ** float(torch.randint(-3, 2, (1,))))
+                p.grad, q.grad = g, g.clone()
+            o_ref.step(); o_mine.step()
+        for p, q in zip(ref, mine):
+            assert_close(q, p, 2e-6, f"adam wd={wd} param {tuple(p.shape)}")
+            assert_close(o_mine.state[q]["exp_avg"], o_ref.state[p]["exp_avg"], 1e-6, "exp_avg")
+            assert_close(o_mine.state[q]["exp_avg_sq"], o_ref.state[p]["exp_avg_sq"], 1e-6, "exp_avg_sq")
+            assert float(o_mine.state[q]["step"]) == 25.0 == float(o_ref.state[p]["step"])
+    # state_dict round trip into a fresh optimizer: the trajectory continues as if nothing happened
+    sd = o_mine.state_dict()
+    clone = [torch.nn.Parameter(q.detach().clone()) for q in mine]
+    o_clone = optim.Adam(clone, lr=1.0)
+    o_clone.load_state_dict(sd)
+    assert o_clone.param_groups[0]["lr"] == 3e-3
+    for q, c in zip(mine, clone):
+        g = torch.randn_like(q)
+        q.grad, c.grad = g, g.clone()
+    o_mine.step(); o_clone.step()
+    for q, c in zip(mine, clone):
+        assert torch.equal(q, c)
+    assert float(o_clone.state[clone[0]]["step"]) == 26.0
+    # a parameter without a gradient sits the step out (its values and moments untouched), the others move
+    before = [q.detach().clone() for q in mine]
+    mine[2].grad = None
+    o_mine.step()
+    assert torch.equal(mine[2], before[2]) and not torch.equal(mine[3], before[3])
+    # more tensors than one launch carries
+    many = [torch.nn.Parameter(torch.randn(5 + i, device=device)) for i in range(97)]
+    many_ref = [torch.nn.Parameter(p.detach().clone()) for p in many]
+    o_a, o_b = optim.Adam(many, lr=1e-2), torch.optim.Adam(many_ref, lr=1e-2)
+    for _ in range(3):
+        for p, q in zip(many, many_ref):
+            p.grad = torch.randn_like(p); q.grad = p.grad.clone()
+        o_a.step(); o_b.step()
+    for p, q in zip(many, many_ref):
+        assert_close(p, q, 2e-6, "adam many")
+    assert float(o_a.state[many[0]]["step"]) == 3.0
+    # misuse raises
+    for bad in (torch.randn(3), torch.randn(3, dtype=torch.float64, device=device)):        # no CPU fallback, fp32 only
+        q = torch.nn.Parameter(bad)
+        q.grad = torch.zeros_like(q)
+        with pytest.raises(ops.GlamHipError):
+            optim.Adam([q]).step()
+    with pytest.raises(ops.GlamHipError):
+        optim.Adam(mine, amsgrad=True)
+
+
+def test_adam_under_the_graphed_stepper_follows_the_eager_trajectory(device):
+    """Training loop of trainer.py:286-301 with ``glam_amd.optim.Adam``: eager, one graph per batch, and 16 steps per graph launch give
+    the same parameters bit for bit (device-side step count and learning rate), including a learning-rate change between epochs; and the
+    trajectory agrees with ``torch.optim.Adam`` to rounding."""
+    import copy
+    from glam_amd import optim
+    from glam_amd.data import DataLoader, synth_molecule
+    from glam_amd.graphs import GraphedTrainStep
+    rng = np.random.default_rng(4)
+    mols = [synth_molecule(rng) for _ in range(24)]
+    torch.manual_seed(6)
+    net0 = model.Architecture(mol_block="_TripletMessage", message_steps=2, mol_readout="GlobalPool5", e_dim=64).to(device).train()   # RReLU, Dropout
+    loss_fn = lambda out, b: torch.nn.functional.mse_loss(out.view(-1), b.y.view(-1))
+    results = {}
+    for mode in ("eager", "graph", "multi", "library"):
+        net = copy.deepcopy(net0)
+        ops.manual_seed(77, device)
+        opt = (torch.optim.Adam(net.parameters(), lr=2.0 ** -9, capturable=True) if mode == "library"
+               else optim.Adam(net.parameters(), lr=2.0 ** -9))
+        loader = DataLoader(mols, batch_size=8, device=device)
+        stepper = GraphedTrainStep(net, opt, loss_fn)
+        for epoch in range(4):
+            if epoch == 2:
+                opt.param_groups[0]["lr"] = 2.0 ** -11
+            if mode == "multi":
+                stepper.run(list(loader), steps_per_graph=16)
+            else:
+                for b in loader:
+                    if mode == "graph":
+                        stepper(b)
+                    else:
+                        opt.zero_grad(set_to_none=True)
+                        loss_fn(net(b), b).backward()
+                        opt.step()
+        results[mode] = [p.detach().clone() for p in net.parameters()]
+    for a, b_, c in zip(results["eager"], results["graph"], results["multi"]):
+        assert torch.equal(a, b_) and torch.equal(a, c)
+    for a, r in zip(results["eager"], results["library"]):
+        assert_close(a, r, 2e-5, "vs torch.optim.Adam")

@@ -2,7 +2,7 @@
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from glam_amd import model
+from glam_amd import model, optim
 from glam_amd.data import synth_batch, synth_protein_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -12,7 +12,8 @@ torch.manual_seed(0)
 net = model.ArchitectureDTI(graph_norm=NORM, graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU").to(dev)
 mol, pro = synth_batch(B, seed=0).to(dev), synth_protein_batch(B, seed=1, n_min=200, n_max=800).to(dev)
 y = torch.randn(B, device=dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)
+opt = (optim.Adam(net.parameters(), lr=1e-3) if os.environ.get("GLAM_ADAM", "glam") == "glam"
+           else torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True))
 
 def body():
     opt.zero_grad(set_to_none=True)

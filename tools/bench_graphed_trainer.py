@@ -4,7 +4,7 @@ import sys, os, time, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from glam_amd import model
+from glam_amd import model, optim
 from glam_amd.data import DataLoader, synth_molecule
 from glam_amd.graphs import GraphedTrainStep
 
@@ -18,7 +18,8 @@ net0 = model.Architecture(mol_block="_TripletMessage", message_steps=3, mol_read
 loss_fn = lambda out, b: torch.nn.functional.mse_loss(out.view(-1), b.y.view(-1))
 for graphed in (False, True, "run"):
     net = copy.deepcopy(net0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)
+    opt = (optim.Adam(net.parameters(), lr=1e-3) if os.environ.get("GLAM_ADAM", "glam") == "glam"
+           else torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True))
     loader = DataLoader(mols, batch_size=B, device=dev)
     stepper = GraphedTrainStep(net, opt, loss_fn)
     times = []

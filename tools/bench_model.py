@@ -40,7 +40,12 @@ else:
     args.block, args.norm = blk, "_PairNorm"
 b = synth_batch(args.batch, seed=0).to(dev)
 y = b.y.view(-1) if args.out_dim == 1 else torch.randn(args.batch, args.out_dim, device=dev).view(-1)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=os.environ.get("GLAM_FUSED_ADAM", "1") == "1")
+# GLAM_ADAM=glam (default): glam_amd.optim.Adam, one HIP launch per step; torch: the library's fused multi-tensor optimizer
+if os.environ.get("GLAM_ADAM", "glam") == "glam":
+    from glam_amd import optim
+    opt = optim.Adam(net.parameters(), lr=1e-3)
+else:
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=os.environ.get("GLAM_FUSED_ADAM", "1") == "1")
 
 if args.loss == "bcel":      # multi-task labels in {-1 (missing), 0, 1} (dataset.py:138)
     y = torch.randint(-1, 2, (args.batch * args.out_dim,), device=dev).float()

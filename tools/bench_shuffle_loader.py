@@ -3,7 +3,7 @@ its validation sync, eager step): molecules/s at B = 1024 and B = 32."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from glam_amd import model
+from glam_amd import model, optim
 from glam_amd.data import DataLoader, synth_molecule
 dev = torch.device("cuda")
 rng = np.random.default_rng(0)
@@ -11,7 +11,8 @@ mols = [synth_molecule(rng) for _ in range(8192)]
 torch.manual_seed(0)
 net = model.Architecture(mol_block="_NNConv", graph_norm="_PairNorm", graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU",
                          flat_act="ReLU").to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)
+opt = (optim.Adam(net.parameters(), lr=1e-3) if os.environ.get("GLAM_ADAM", "glam") == "glam"
+           else torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True))
 for B in (1024, 32):
     loader = DataLoader(mols if B == 1024 else mols[:2048], batch_size=B, shuffle=True, device=dev)
     times = []
