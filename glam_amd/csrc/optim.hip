@@ -3,13 +3,13 @@
 // A default-shaped model has 36 parameter tensors between 1 and 307 200 elements (355 k in all).  The library's multi-tensor kernel cuts
 // them into 65 536-element chunks — 9 workgroups on a 256-CU device, in double precision because its hyper-parameters are doubles — and
 // takes 45 us per step (profiles/r2h_kernel_stats_model_*.txt: 6 % of a 0.79 ms step).  Here: ONE launch over all tensors, 1 024-element
-// chunks (one float4 per thread, one round trip), fp32 arithmetic with the two bias corrections evaluated once per thread in double.
+// chunks (one float4 per thread, one round trip), fp32 arithmetic: 5.3 us (tools/bench_adam.py).
 //   step s = *step + 1                                   (device counter: a captured launch replays correctly)
 //   g' = g + weight_decay * p
 //   m  = m + (1 - beta1) (g' - m)          v = beta2 v + (1 - beta2) g'^2
 //   p  = p - lr / (1 - beta1^s) * m / (sqrt(v) / sqrt(1 - beta2^s) + eps)
 // The tensor addresses travel by value in the kernel arguments (gradients are fresh allocations every eager step: no table in device
-// memory to keep in sync).  The step counter is written by the LAST workgroup to finish (a ticket), after every workgroup has read it.
+// memory to keep in sync).  The step counter is written by the LAST workgroup to finish (a two-level ticket), after every workgroup has read it.
 #include "common.h"
 
 namespace glam {
@@ -38,8 +38,11 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ void __launch_bounds__(kBlock) k_adam(AdamArgs a) {
     const int tid = threadIdx.x, b = blockIdx.x;
-    int t = 0;
-    while (t < a.n - 1 && b >= a.chunk_end[t]) ++t;                       // uniform: scalar loads from the argument block
+    // owner of this workgroup: lane l compares against chunk_end[l] (one vector load from the argument block), the count of passed
+    // boundaries is the tensor index — a scalar walk over the table is a chain of up to 40 dependent scalar loads
+    const int lane = tid & 63;
+    const bool passed = lane < a.n - 1 && b >= a.chunk_end[lane];
+    const int t = __builtin_popcountll(__ballot(passed));
     const int first = t ? a.chunk_end[t - 1] : 0;
     const int off = (b - first) * kAdamChunk + 4 * tid, numel = a.numel[t];
     float* p = a.p[t]; const float* g = a.g[t]; float* m = a.m[t]; float* v = a.v[t];
@@ -54,8 +57,10 @@ __global__ void __launch_bounds__(kBlock) k_adam(AdamArgs a) {
             if (off + i < numel) { pp[i] = p[off + i]; gp[i] = g[off + i]; mp[i] = m[off + i]; vp[i] = v[off + i]; }
     }
     const double lr = a.lr_dev ? (double)*a.lr_dev : a.lr;
-    const float step_size = (float)(lr / (1.0 - pow(a.beta1, (double)s)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(a.beta2, (double)s));
+    // 1 - beta^s = -expm1(s ln beta): fp32 keeps 1e-7 relative accuracy at every s (1 - powf(beta, s) would lose four digits at s = 1),
+    // and the double-precision pow / divide / sqrt of the direct form cost 0.8 us of a 6 us launch
+    const float step_size = (float)lr / -expm1f(s * (float)log(a.beta1));
+    const float bc2_sqrt = sqrtf(-expm1f(s * (float)log(a.beta2)));
     const float omb1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, omb2 = (float)(1.0 - a.beta2), eps = (float)a.eps,
                 wd = (float)a.weight_decay;
     adam_one(pv.x, gv.x, mv.x, vv.x, omb1, b2, omb2, step_size, bc2_sqrt, eps, wd);
@@ -70,13 +75,21 @@ __global__ void __launch_bounds__(kBlock) k_adam(AdamArgs a) {
             if (off + i < numel) { p[off + i] = pp[i]; m[off + i] = mp[i]; v[off + i] = vp[i]; }
     }
     if (a.bump) {
-        // every workgroup has read *step before it takes its ticket; the last one to arrive writes the new count and re-arms the ticket
+        // Every workgroup has consumed *step (it fed the values stored above) before it takes its ticket; the last one to arrive writes the
+        // new count and re-arms the tickets.  Two levels as in rng_end (rng.h): workgroup b checks in at sub-counter b % 16 (one 128-byte
+        // line each), the last of a sub-group at the main ticket — a single counter serialises every workgroup of the launch at the
+        // coherent point (13 of this launch's 16 us), and a release fence per workgroup costs an L2 write-back each.
         __syncthreads();
         if (tid == 0) {
-            __threadfence();
-            if (atomicAdd(a.ticket, 1u) == gridDim.x - 1) {
-                *a.step = s;
-                *a.ticket = 0u;
+            const unsigned g = gridDim.x, sidx = blockIdx.x & 15u;
+            const unsigned in_sub = (g - sidx + 15u) >> 4, nsub = g < 16u ? g : 16u;
+            unsigned* sub = a.ticket + 32 * (1 + sidx);
+            if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1) {
+                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1) {
+                    __hip_atomic_store(a.step, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }

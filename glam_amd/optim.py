@@ -56,7 +56,7 @@ class Adam(torch.optim.Optimizer):
         plan.flat_m = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         plan.flat_v = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         plan.step = torch.zeros((), dtype=torch.float32, device=dev)
-        plan.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        plan.ticket = torch.zeros(544, dtype=torch.int32, device=dev)      # GLAM_ADAM_TICKET_WORDS: main ticket + 16 sub-counters, 128 B apart
         plan.table = np.zeros((len(ps), 4), dtype=np.uint64)
         plan.numel = np.array([p.numel() for p in ps], dtype=np.int64)
         plan.sub, plan.sub_key = None, None

@@ -489,8 +489,9 @@ int glam_colsum(const float* x, int64_t N, int D, int ld, float* out, void* ws, 
  * (`Adam(self.model.parameters(), lr=args.lr)`, src_1gp/trainer.py:49-50, stepped at trainer.py:301; torch.optim.Adam semantics
  * without amsgrad / maximize; weight_decay is the L2 form).  table: HOST array [n][4] of device addresses {param, grad, exp_avg,
  * exp_avg_sq} (f32, numel[i] elements each, contiguous); step: device f32 count of the steps taken so far, advanced by the launch
- * itself (a captured launch replays correctly); ticket: device u32, zero before the first call, owned by the optimizer; lr_dev: device
+ * itself (a captured launch replays correctly); ticket: device u32[GLAM_ADAM_TICKET_WORDS], zero before the first call, owned by the optimizer; lr_dev: device
  * f32 learning rate read by the launch (NULL: the host value `lr`).  In place: param, exp_avg, exp_avg_sq. */
+#define GLAM_ADAM_TICKET_WORDS 544
 int glam_adam_max_tensors(void);
 int glam_adam_step(const uint64_t* table, const int64_t* numel, int n, float* step, unsigned* ticket, const float* lr_dev, double lr,
                    double beta1, double beta2, double eps, double weight_decay, void* stream);

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
-from glam_amd import model, ops
+from glam_amd import model, ops, optim
 from glam_amd.data import synth_batch
 
 preset = sys.argv[1] if len(sys.argv) > 1 else "model_default"
@@ -17,7 +17,7 @@ else:
     net = model.Architecture(mol_block="_TripletMessage").to(dev).train()
 b = synth_batch(1024, seed=0).to(dev)
 y = b.y.view(-1)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True, fused=True)
+opt = optim.Adam(net.parameters(), lr=1e-3)
 
 def body():
     opt.zero_grad(set_to_none=True)
