@@ -2,7 +2,7 @@
 // src_1gp/trainer.py:49-50, stepped once per batch at trainer.py:301; lr moved by ReduceLROnPlateau, trainer.py:55,85).
 // A default-shaped model has 36 parameter tensors between 1 and 307 200 elements (355 k in all).  The library's multi-tensor kernel cuts
 // them into 65 536-element chunks — 9 workgroups on a 256-CU device, in double precision because its hyper-parameters are doubles — and
-// takes 45 us per step (profiles/r2h_kernel_stats_model_*.txt: 6 % of a 0.79 ms step).  Here: ONE launch over all tensors, 1 024-element
+// took 45 us per step (6 % of a 0.79 ms step before this file existed).  Here: ONE launch over all tensors, 1 024-element
 // chunks (one float4 per thread, one round trip), fp32 arithmetic: 5.3 us (tools/bench_adam.py).
 //   step s = *step + 1                                   (device counter: a captured launch replays correctly)
 //   g' = g + weight_decay * p
