@@ -375,3 +375,24 @@ def architecture_dti(sd, mol, pro, num_pairs, message_steps=3, mol_block="_NNCon
     outp = linear_block(sd, "pro_flat.", global_pool5(xp, pro.batch, num_pairs), flat_act)    # :61-62
     out = torch.cat([outm, outp, torch.cat(fusion, dim=-1)], dim=-1)             # :65
     return linear_block(sd, "lin_out1.", linear_block(sd, "lin_out0.", out, end_act), "_None")
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """One step of the trainer's optimizer (``Adam(self.model.parameters(), lr=args.lr)``, reference ``src_1gp/trainer.py:49-50``;
+    torch.optim.Adam without amsgrad / maximize, weight decay in the L2 form) on numpy fp32 arrays, in the arithmetic of
+    ``csrc/optim.hip`` — fp32 throughout, the bias corrections as ``-expm1(s ln beta)``.  ``step`` = steps taken so far.
+    Returns ``(p, m, v)`` after the step.  Pinned against ``torch.optim.Adam`` on the CPU in ``tests/test_host_logic.py``."""
+    import numpy as np
+    f = np.float32
+    p, g, m, v = (np.asarray(t, dtype=f) for t in (p, g, m, v))
+    s = f(step + 1)
+    if weight_decay:
+        g = g + f(weight_decay) * p
+    m = m + f(1.0 - beta1) * (g - m)
+    v = f(beta2) * v + f(1.0 - beta2) * g * g
+    with np.errstate(divide="ignore"):
+        bc1 = -np.expm1(s * f(np.log(beta1)), dtype=f) if beta1 > 0 else f(1)
+        bc2 = -np.expm1(s * f(np.log(beta2)), dtype=f) if beta2 > 0 else f(1)
+    step_size = f(lr) / bc1
+    denom = np.sqrt(v) / np.sqrt(bc2) + f(eps)
+    return p - step_size * (m / denom), m, v

@@ -321,3 +321,42 @@ def test_torch_extension_registers_the_boundary_ops_and_refuses_cpu_tensors():
         ns.csr_from_edge_index(torch.zeros(2, 3, dtype=torch.long), 4, 0)
     with pytest.raises(RuntimeError, match="HIP device only"):
         ns.segment_pool(torch.zeros(4, 8), torch.zeros(3, dtype=torch.int32), 0)
+
+
+def test_adam_restatement_matches_the_library_optimizer_on_cpu():
+    """The arithmetic of ``csrc/optim.hip`` (``oracle.adam_step``: fp32, bias corrections as -expm1(s ln beta)) against
+    ``torch.optim.Adam`` — the optimizer the reference's trainer constructs (trainer.py:49-50) — over 60 steps with a learning-rate
+    change and weight decay: 2e-6 of the largest parameter, moments to 1e-6.  The GPU test compares the kernel with the same reference."""
+    from oracle import glam_oracle as oracle
+    rng = np.random.default_rng(5)
+    for wd in (0.0, 1e-2):
+        p0 = rng.standard_normal(257).astype(np.float32)
+        tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        opt = torch.optim.Adam([tp], lr=1e-2, weight_decay=wd)
+        p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+        lr = 1e-2
+        for step in range(60):
+            if step == 20:
+                lr = opt.param_groups[0]["lr"] = 3e-3
+            g = (rng.standard_normal(257) * 10.0 ** rng.integers(-3, 2)).astype(np.float32)
+            tp.grad = torch.from_numpy(g.copy())
+            opt.step()
+            p, m, v = oracle.adam_step(p, g, m, v, step, lr=lr, weight_decay=wd)
+        scale = max(1.0, float(np.abs(p).max()))
+        assert np.abs(p - tp.detach().numpy()).max() <= 2e-6 * scale
+        st = opt.state[tp]
+        assert np.abs(m - st["exp_avg"].numpy()).max() <= 1e-6 * max(1.0, float(np.abs(m).max()))
+        assert np.abs(v - st["exp_avg_sq"].numpy()).max() <= 1e-6 * max(1.0, float(np.abs(v).max()))
+
+
+def test_adam_abi_rejects_bad_arguments_without_touching_a_gpu():
+    import ctypes
+    lib = _lib.load()
+    assert lib.glam_adam_max_tensors() >= 36          # a default-shaped model's parameter list goes in one launch
+    tab = (ctypes.c_uint64 * 4)(0, 0, 0, 0)
+    numel = (ctypes.c_int64 * 1)(8)
+    args = (0.001, 0.9, 0.999, 1e-8, 0.0, None)
+    assert lib.glam_adam_step(tab, numel, 1, None, None, None, *args) == _lib.GLAM_E_INVALID            # no step counter / ticket
+    assert lib.glam_adam_step(tab, numel, 1, 8, 8, None, *args) == _lib.GLAM_E_INVALID                  # null tensor addresses
+    assert lib.glam_adam_step(tab, numel, 1, 8, 8, None, 0.001, 1.0, 0.999, 1e-8, 0.0, None) == _lib.GLAM_E_INVALID   # beta1 = 1
+    assert lib.glam_adam_step(tab, numel, 0, 8, 8, None, *args) == 0                                    # nothing to do

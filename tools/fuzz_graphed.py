@@ -3,7 +3,7 @@ usage: python tools/fuzz_graphed.py [n_cases] [seed]"""
 import sys, os, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from glam_amd import model
+from glam_amd import model, optim
 from glam_amd.data import synth_batch
 from glam_amd.graphs import GraphedTrainStep
 
@@ -25,7 +25,7 @@ for case in range(n_cases):
         finals = []
         for graphed in (False, True):
             net = copy.deepcopy(net0)
-            opt = torch.optim.Adam(net.parameters(), lr=2.0 ** -10, capturable=True, fused=True)   # exactly representable: the graphed stepper keeps lr in an fp32 device tensor, the eager loop in a Python float
+            opt = (optim.Adam(net.parameters(), lr=2.0 ** -10) if case % 2 else torch.optim.Adam(net.parameters(), lr=2.0 ** -10, capturable=True, fused=True))   # exactly representable: the graphed stepper keeps lr in an fp32 device tensor, the eager loop in a Python float
             stepper = GraphedTrainStep(net, opt, loss_fn)
             for epoch in range(4):
                 for b in batches:
