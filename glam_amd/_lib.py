@@ -62,6 +62,9 @@ SIGNATURES = {
     "glam_gru_fused_rng_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8),
     "glam_colsum_workspace_bytes": (_sz, [_i32]),
     "glam_colsum": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "glam_loss_workspace_bytes": (_sz, []),
+    "glam_loss_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "glam_loss_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "glam_adam_max_tensors": (_i32, []),
     "glam_adam_step": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp] + [ctypes.c_double] * 5 + [_vp]),
     "glam_linear_narrow_supported": (_i32, [_i32, _i32]),

@@ -496,6 +496,20 @@ int glam_adam_max_tensors(void);
 int glam_adam_step(const uint64_t* table, const int64_t* numel, int n, float* step, unsigned* ticket, const float* lr_dev, double lr,
                    double beta1, double beta2, double eps, double weight_decay, void* stream);
 
+/* The training step's loss, value and gradient in one launch (mean reduction):
+ *   kind 0  squared error          — `self.criterion(output, y_true)` with nn.MSELoss, src_1gp/trainer.py:296 / loss.py:42
+ *   kind 1  BCE with logits        — nn.BCEWithLogitsLoss, loss.py:48
+ *   masked != 0: the mean runs over the elements with target >= 0 only — `criterion(y_score[y_true >= 0], y_true[y_true >= 0])`,
+ *   trainer.py:244-245 (labels of -1 are missing, dataset.py:138), without the boolean indexing (not capturable in a hipGraph).
+ * pred, target: f32[n]; loss, inv_count: f32[1] (the mean and 1 / count; count = 0 gives nan like the reference's empty mean);
+ * grad: f32[n] un-normalised d loss_i / d pred_i; ws >= glam_loss_workspace_bytes(); ticket: device u32[GLAM_ADAM_TICKET_WORDS],
+ * zero before the first call, re-armed by every call (n > 1024 only).  Fixed summation order.
+ * glam_loss_bwd: d_pred[i] = grad[i] * g_up[0] * inv_count[0] (g_up: the f32[1] gradient arriving at the loss). */
+size_t glam_loss_workspace_bytes(void);
+int glam_loss_fwd(const float* pred, const float* target, int64_t n, int kind, int masked, float* loss, float* inv_count, float* grad,
+                  void* ws, size_t ws_bytes, unsigned* ticket, void* stream);
+int glam_loss_bwd(const float* grad, const float* inv_count, const float* g_up, int64_t n, float* d_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

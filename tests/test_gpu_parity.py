@@ -2162,3 +2162,47 @@ def test_adam_kernel_against_the_oracle_restatement(device):
         opt.step()
     for p, q in zip(ps, qs):
         assert_close(q, torch.from_numpy(p), 5e-7, "k_adam vs oracle")
+
+
+@pytest.mark.parametrize("n", [1, 33, 1024, 1025, 12288, 631808])
+def test_loss_launch_matches_the_library_losses(device, n):
+    """``glam_amd.loss`` (value + gradient in one launch, one scale launch backwards) against the criteria of the reference's trainers:
+    nn.MSELoss (trainer.py:296), nn.BCEWithLogitsLoss (loss.py:48) and the classification loop's mean over the labels present
+    (``criterion(y_score[y_true >= 0], y_true[y_true >= 0].float())``, trainer.py:244-245).  1e-6 relative on the value (fp32 sums in
+    a different, fixed order), 1e-6 on the gradient; a non-unit upstream gradient; run-to-run bit-reproducible."""
+    from glam_amd import loss
+    torch.manual_seed(n)
+    x0 = torch.randn(n, device=device) * 3
+    y_reg = torch.randn(n, device=device)
+    y_cls = torch.randint(-1, 2, (n,), device=device).float()
+    if n > 1:
+        y_cls[0] = 1.0
+    cases = [("mse", lambda x: loss.get_loss("mse")(x, y_reg), lambda x: torch.nn.functional.mse_loss(x, y_reg)),
+             ("bcel", lambda x: loss.get_loss("bcel")(x, y_cls.clamp(min=0)),
+              lambda x: torch.nn.functional.binary_cross_entropy_with_logits(x, y_cls.clamp(min=0))),
+             ("bcel_masked", lambda x: loss.get_loss("bcel_masked")(x, y_cls),
+              lambda x: torch.nn.functional.binary_cross_entropy_with_logits(x[y_cls >= 0], y_cls[y_cls >= 0]))]
+    for name, mine, ref in cases:
+        if name == "bcel_masked" and not bool((y_cls >= 0).any()):
+            continue
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        la, lb = mine(xa), ref(xb)
+        (la * 0.37).backward(); (lb * 0.37).backward()
+        va, vb = float(la.detach()), float(lb.detach())
+        assert abs(va - vb) <= 1e-6 * max(1.0, abs(vb)), (name, va, vb)
+        assert_close(xa.grad, xb.grad, 1e-6, f"{name} gradient")
+        xc = x0.clone().requires_grad_(True)
+        lc = mine(xc)
+        (lc * 0.37).backward()
+        assert torch.equal(lc, la) and torch.equal(xc.grad, xa.grad)          # fixed summation order: the same bits every run
+    # shapes other than flat, and the empty selection of the masked mean (nan, as the reference's mean over nothing)
+    if n == 1024:
+        x2 = x0.view(32, 32).clone().requires_grad_(True)
+        l2 = loss.mse_loss(x2, y_reg.view(32, 32))
+        l2.backward()
+        assert x2.grad.shape == (32, 32)
+        assert torch.isnan(loss.bce_with_logits(x0, -torch.ones_like(x0), masked=True))
+        with pytest.raises(ops.GlamHipError):
+            loss.mse_loss(x0, y_reg[:-1])
+        with pytest.raises(ops.GlamHipError):
+            loss.mse_loss(x0.cpu(), y_reg.cpu())

@@ -50,7 +50,13 @@ else:
 if args.loss == "bcel":      # multi-task labels in {-1 (missing), 0, 1} (dataset.py:138)
     y = torch.randint(-1, 2, (args.batch * args.out_dim,), device=dev).float()
 
+USE_GLAM_LOSS = os.environ.get("GLAM_LOSS", "glam") == "glam"     # glam_amd.loss: value + gradient in one launch; torch: the library's ops
+if USE_GLAM_LOSS:
+    from glam_amd import loss as glam_loss
+
 def loss_of(out):
+    if USE_GLAM_LOSS:
+        return glam_loss.mse_loss(out, y) if args.loss == "mse" else glam_loss.bce_with_logits(out, y, masked=True)
     if args.loss == "mse":
         return torch.nn.functional.mse_loss(out, y)
     # mean over the valid labels only, without the data-dependent boolean indexing of the reference (not capturable)
