@@ -718,6 +718,31 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
     return launch_final_reduce(ra, (hipStream_t)stream);
 }
 
+// [d_W | d_b] of one linear y = [x | 1] W^T, weight and bias into SEPARATE contiguous tensors (autograd takes them as they are; a
+// strided view of a combined buffer costs a copy launch each): dw[I, J] = P^T Q, db[I] = column sums of P.  J + 1 <= 64.
+extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_split: N out of range");
+    GLAM_REQUIRE(dw && db, "glam_wgrad_gemm_split: null output");
+    GLAM_REQUIRE(I > 0 && J > 0 && J + 1 <= 64, "glam_wgrad_gemm_split: J + 1 must be <= 64");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        (void)hipMemsetAsync(dw, 0, (size_t)I * J * sizeof(float), s);
+        (void)hipMemsetAsync(db, 0, (size_t)I * sizeof(float), s);
+        return GLAM_OK;
+    }
+    GLAM_REQUIRE(P && Q && ws, "glam_wgrad_gemm_split: null pointer");
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "glam_wgrad_gemm_split: workspace too small");
+    GLAM_REQUIRE(aligned16(Q) && aligned16(P), "glam_wgrad_gemm_split: P / Q must be 16-byte aligned");
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, J, ldq, 1, (int)N, 0, partial, 0, 0};
+    ReduceArgs ra{};
+    ra.njobs = 1;
+    if (int rc = launch_wgrad_partials(a, dw, J, 1, s, &ra.job[0])) return rc;
+    ra.job[0].out_b = db;
+    return launch_final_reduce(ra, s);
+}
+
 // The four weight images of one linear pair y_a = x W_a^T, y_b = h W_b^T (W_* f32[M, K] as torch stores them) in ONE launch:
 // forward images (logical [K, M] = W^T) and input-gradient images (logical [M, K] = W).
 extern "C" int glam_ts_gemm_make_image_quad(const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,

@@ -1023,6 +1023,13 @@ class _LinearTall(torch.autograd.Function):
         dx = torch.matmul(dy, w) if ctx.needs_input_grad[0] else None
         lib = _lib.load()
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        if K + 1 <= 64:
+            # weight and bias gradients as separate contiguous tensors: autograd keeps them as they are (views of one [M, K + 1] buffer
+            # cost a copy launch each when they become .grad)
+            dw, db = torch.empty(M, K, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device)
+            check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), K, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
+                  "glam_wgrad_gemm_split")
+            return dx, dw, db
         dwb = torch.empty(M, K + 1, dtype=torch.float32, device=x.device)
         check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(), stream()),
               "glam_wgrad_gemm")

@@ -191,6 +191,11 @@ int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, const float* Q
                                float* db_a, const float* Pb, int Ib, int ldpb, const float* Qb, int Jb, int ldqb, int qcelu_b,
                                float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes, const float* add_w_a,
                                const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
+
+/* glam_wgrad_gemm for ONE linear y = [x | 1] W^T with the weight and bias gradients in separate contiguous tensors:
+ * dw[I, J] = P^T Q (P = dy f32[N, I], Q = x f32[N, J]), db[I] = column sums of P.  J + 1 <= 64, I <= 320. */
+int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N, void* ws,
+                          size_t ws_bytes, void* stream);
 /* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:
  * a_celu = 1: out = celu(A) @ W + bias; cgrad_src non-NULL: out[r,c] *= celu'(cgrad_src[r,c]) (the chain rule of the same
  * fold on the way back); qcelu_* in glam_wgrad_gemm_pair: the weight gradient uses celu(Q). */

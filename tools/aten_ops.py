@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
-from glam_amd import model, ops, optim
+from glam_amd import model, ops, optim, loss as glam_loss
+ops.USE_TORCH_EXT = False      # the route a captured step takes (Python nodes with the gradient carry)
 from glam_amd.data import synth_batch
 
 preset = sys.argv[1] if len(sys.argv) > 1 else "model_default"
@@ -21,7 +22,7 @@ opt = optim.Adam(net.parameters(), lr=1e-3)
 
 def body():
     opt.zero_grad(set_to_none=True)
-    loss = torch.nn.functional.mse_loss(net(b).view(-1), y)
+    loss = glam_loss.mse_loss(net(b).view(-1), y)
     loss.backward()
     opt.step()
 
