@@ -46,21 +46,29 @@ __global__ void __launch_bounds__(kBlock) k_ts_make_image(const float* W, int ld
 
 // Up to four images in one launch (the forward and transposed images of a GRU's two gate matrices change together after
 // every optimizer step): job j owns blocks [first[j], first[j+1]).
-struct ImageJob { const float* W; int ldw, transW, K, M, MT; float* img; int first; };
-struct ImageJobs { ImageJob job[4]; int njobs; };
+// gate > 0 (the fused GRU step's images, block.hip): M = 3 gates of `gate` channels, each padded to 64 columns — logical column m holds
+// channel m % 64 of gate m / 64 (source row (m / 64) * gate + m % 64 of the [3 * gate, K] matrix), k padded to 64.
+struct ImageJob { const float* W; int ldw, transW, K, M, MT; float* img; int first; int gate; };
+constexpr int kMaxImageJobs = 6;
+struct ImageJobs { ImageJob job[kMaxImageJobs]; int njobs; };
 __global__ void __launch_bounds__(kBlock) k_ts_make_images(ImageJobs js) {
     int jb = 0;
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < kMaxImageJobs; ++q)
         if (q < js.njobs && (int)blockIdx.x >= js.job[q].first) jb = q;
     const ImageJob& J = js.job[jb];
-    const int MP = J.MT * 16, Kp = (J.K + 15) & ~15;
+    const int MP = J.MT * 16, Kp = J.gate ? 64 : (J.K + 15) & ~15;
     const int idx = ((int)blockIdx.x - J.first) * kBlock + threadIdx.x;
     if (idx >= Kp * MP) return;
     const int j = idx & 3, p = (idx >> 2) % MP, k = (idx >> 2) / MP * 4 + j;
     const int m = ts_col_of_pos(p);
     float v = 0.f;
-    if (k < J.K && m < J.M) v = J.transW ? J.W[(size_t)m * J.ldw + k] : J.W[(size_t)k * J.ldw + m];
+    if (J.gate) {
+        const int g = m >> 6, ch = m & 63;
+        if (k < J.K && ch < J.gate) v = J.W[(size_t)(g * J.gate + ch) * J.ldw + k];
+    } else if (k < J.K && m < J.M) {
+        v = J.transW ? J.W[(size_t)m * J.ldw + k] : J.W[(size_t)k * J.ldw + m];
+    }
     J.img[idx] = v;
 }
 
@@ -745,23 +753,46 @@ extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float
 
 // The four weight images of one linear pair y_a = x W_a^T, y_b = h W_b^T (W_* f32[M, K] as torch stores them) in ONE launch:
 // forward images (logical [K, M] = W^T) and input-gradient images (logical [M, K] = W).
-extern "C" int glam_ts_gemm_make_image_quad(const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,
-                                            float* img_a_bwd, float* img_b_bwd, void* stream) {
-    GLAM_REQUIRE(Wa && Wb && img_a_fwd && img_b_fwd && img_a_bwd && img_b_bwd, "glam_ts_gemm_make_image_quad: null pointer");
-    if (int rc = ts_shape_ok("ts_gemm image quad", K, M)) return rc;
-    if (int rc = ts_shape_ok("ts_gemm image quad", M, K)) return rc;
+static int make_image_set(const char* fn, const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,
+                          float* img_a_bwd, float* img_b_bwd, float* gate_a, float* gate_b, void* stream) {
+    GLAM_REQUIRE(Wa && Wb && img_a_fwd && img_b_fwd && img_a_bwd && img_b_bwd, "%s: null pointer", fn);
+    if (int rc = ts_shape_ok(fn, K, M)) return rc;
+    if (int rc = ts_shape_ok(fn, M, K)) return rc;
     ImageJobs js{};
-    js.njobs = 4;
     const float* W[4] = {Wa, Wb, Wa, Wb};
     float* img[4] = {img_a_fwd, img_b_fwd, img_a_bwd, img_b_bwd};
     int blocks = 0;
     for (int q = 0; q < 4; ++q) {
         const bool fwd = q < 2;
         const int Kq = fwd ? K : M, Mq = fwd ? M : K;
-        js.job[q] = ImageJob{W[q], K, fwd ? 1 : 0, Kq, Mq, ts_mt(ts_variant(Kq, Mq)), img[q], blocks};
+        js.job[q] = ImageJob{W[q], K, fwd ? 1 : 0, Kq, Mq, ts_mt(ts_variant(Kq, Mq)), img[q], blocks, 0};
         blocks += (int)((ts_image_floats(Kq, Mq) + kBlock - 1) / kBlock);
     }
+    js.njobs = 4;
+    if (gate_a) {
+        GLAM_REQUIRE(gate_b && M == 3 * K && K <= 64 && (K & 3) == 0 && aligned16(gate_a) && aligned16(gate_b),
+                     "%s: gate-padded images need M = 3 K, K <= 64 and a multiple of 4", fn);
+        float* gimg[2] = {gate_a, gate_b};
+        for (int q = 0; q < 2; ++q) {
+            js.job[4 + q] = ImageJob{W[q], K, 1, K, 192, 12, gimg[q], blocks, K};
+            blocks += 64 * 192 / kBlock;
+        }
+        js.njobs = 6;
+    }
     hipLaunchKernelGGL(k_ts_make_images, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, js);
-    GLAM_LAUNCH_CHECK("glam_ts_gemm_make_image_quad");
+    GLAM_LAUNCH_CHECK(fn);
     return GLAM_OK;
+}
+
+extern "C" int glam_ts_gemm_make_image_quad(const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,
+                                            float* img_a_bwd, float* img_b_bwd, void* stream) {
+    return make_image_set("glam_ts_gemm_make_image_quad", Wa, Wb, K, M, img_a_fwd, img_b_fwd, img_a_bwd, img_b_bwd, nullptr, nullptr, stream);
+}
+
+// The quad plus the two gate-padded images of the fused GRU step (glam_gru_fused_make_images, block.hip) in the same launch: all six
+// are re-layouts of the same two gate matrices W_ih, W_hh f32[3 C, C] and change together.
+extern "C" int glam_gru_make_images(const float* w_ih, const float* w_hh, int C, float* img_a_fwd, float* img_b_fwd, float* img_a_bwd,
+                                    float* img_b_bwd, float* fused_ih, float* fused_hh, void* stream) {
+    GLAM_REQUIRE(fused_ih && fused_hh, "glam_gru_make_images: null pointer");
+    return make_image_set("glam_gru_make_images", w_ih, w_hh, C, 3 * C, img_a_fwd, img_b_fwd, img_a_bwd, img_b_bwd, fused_ih, fused_hh, stream);
 }

@@ -1354,8 +1354,15 @@ class _GruBlock(torch.autograd.Function):
             if not (ha is not None and ha[0] is w_ih and hb is not None and hb[0] is w_hh):
                 nf, nb = lib.glam_ts_gemm_image_bytes(C, M) // 4, lib.glam_ts_gemm_image_bytes(M, C) // 4
                 ia, ib, ta, tb = torch.empty(nf, **f), torch.empty(nf, **f), torch.empty(nb, **f), torch.empty(nb, **f)
-                check(lib.glam_ts_gemm_make_image_quad(ptr(w_ih), ptr(w_hh), C, M, ptr(ia), ptr(ib), ptr(ta), ptr(tb), st),
-                      "glam_ts_gemm_make_image_quad")
+                if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
+                    # ... and the two gate-padded images of the fused step: six re-layouts of the same two matrices, one launch
+                    fused = torch.empty(2, lib.glam_gru_fused_image_bytes() // 4, **f)
+                    check(lib.glam_gru_make_images(ptr(w_ih), ptr(w_hh), C, ptr(ia), ptr(ib), ptr(ta), ptr(tb), ptr(fused[0]), ptr(fused[1]),
+                                                   st), "glam_gru_make_images")
+                    scope.fwd[("gru-fused", id(w_ih), id(w_hh))] = (w_ih, fused)
+                else:
+                    check(lib.glam_ts_gemm_make_image_quad(ptr(w_ih), ptr(w_hh), C, M, ptr(ia), ptr(ib), ptr(ta), ptr(tb), st),
+                          "glam_ts_gemm_make_image_quad")
                 scope.fwd[ka], scope.fwd[kb] = (w_ih, ia), (w_hh, ib)
                 scope.bwd[ka], scope.bwd[kb] = (w_ih, ta), (w_hh, tb)
         h_new, out = torch.empty_like(h), torch.empty_like(h)

@@ -174,6 +174,12 @@ int glam_ts_gemm_make_image(const float* W, int ldw, int transW, int K, int M, f
  * launch: forward images (x @ W^T: glam_ts_gemm_image_bytes(K, M)) and input-gradient images (dy @ W: ..._bytes(M, K)). */
 int glam_ts_gemm_make_image_quad(const float* Wa, const float* Wb, int K, int M, float* img_a_fwd, float* img_b_fwd,
                                  float* img_a_bwd, float* img_b_bwd, void* stream);
+
+/* glam_ts_gemm_make_image_quad for a GRU's gate matrices w_ih, w_hh f32[3 C, C] (K = C, M = 3 C) PLUS the two gate-padded images of
+ * glam_gru_fused_make_images in the same launch (fused_*: glam_gru_fused_image_bytes() each): the six re-layouts of one MessageBlock's
+ * GRU (src_1gp/layer.py:246, 262) change together after every optimizer step.  C <= 64, a multiple of 4. */
+int glam_gru_make_images(const float* w_ih, const float* w_hh, int C, float* img_a_fwd, float* img_b_fwd, float* img_a_bwd,
+                         float* img_b_bwd, float* fused_ih, float* fused_hh, void* stream);
 int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, int K2, int lda2, const float* Wimg,
                  const float* bias, float* out1, int M1, int ldo1, float* out2, int M2, int ldo2, int64_t N,
                  void* stream);
