@@ -275,8 +275,10 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
 // Parameter gradients straight from the partial sets of the backward pass (k_wgrad slabs of the two weight-gradient
 // products, block partials of B1), i.e. the final fixed-order reductions AND the chain rule of k_stage_params in ONE
 // launch (it replaces k_final_reduce -> k_stage_params_bwd).  Block roles:
-//   A  d_weight_scale / d_bias        one thread per element: sum over the splits of product 1 ([aggr|1]^T d_out)
-//   B  d_weight_node row k            one block per k: d_Wa_i[k,:], d_Wa_j[k,:] first (LDS), then
+//   A  d_weight_scale / d_bias        block per (slab, tj, kq) of product 1 ([aggr|1]^T d_out): one thread per slab element, sum over
+//                                     the splits (256-byte runs per wave), scattered store
+//   B  d_weight_node                  block per (slab, tj, kq) of product 2: the element sums as in A, meanwhile d_Wa_i[k, :],
+//                                     d_Wa_j[k, :] of the block's 16 columns k (LDS), then
 //                                     d_Wcat[k,h,c] + d_Wa_i[k,h] att_i[h,c] + d_Wa_j[k,h] att_j[h,c]
 //   C  d_weight_triplet_att head h    one block per head: d_Wa_i[:,h], d_Wa_j[:,h], d_M[:,h] into LDS, then the
 //                                     contractions with W_node / W_edge
@@ -326,46 +328,75 @@ __device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e
     return group_sum<16>(part);
 }
 
+#ifdef GLAM_PG_PROF   // developer aid (tools/pg_prof.py): cycle stamps of thread 0 of every block, s_memtime = the device-wide clock
+__device__ long long g_pg_prof[512 * 8];
+#define PG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_pg_prof[blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PG_STAMP(k) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
+    PG_STAMP(0);
     __shared__ float s_dwa[2][64];
     __shared__ float s_dm[8];
     const int tid = threadIdx.x, lg = tid & 15, grp = tid >> 4;
     const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
     int b = blockIdx.x;
-    if (b < a.blocksA) {                                    // ---- A: weight_scale, bias
-        const int idx = b * kBlock + tid;
-        if (idx < H * C * C) {
-            const int row = idx / C, col = idx - row * C, h = row / C, c = row - h * C;
-            a.d_wsc[idx] = wg_sum(a.p1, a.ns1, h * Cp + c, col) + (a.c_wsc ? a.c_wsc[idx] : 0.f);
-        } else if (idx < H * C * C + C) {
-            const int col = idx - H * C * C;
-            a.d_bias[col] = wg_sum(a.p1, a.ns1, HC, col) + (a.c_bias ? a.c_bias[col] : 0.f);
+#ifdef GLAM_PG_ONLY      // developer aid (tools/pg_roles.py): time one block role alone (0 = A, 1 = B, 2 = C, 3 = D)
+    {
+        const int role = b < a.blocksA ? 0 : b < a.blocksA + a.blocksB ? 1 : b < a.blocksA + a.blocksB + a.blocksC ? 2 : 3;
+        if (role != GLAM_PG_ONLY) return;
+    }
+#endif
+    // Roles A and B read the k_wgrad slabs WITH their grain: a slab stores, for fixed (ti, tj, kq), the 64 floats (c' = j / 4, r) of
+    // rows i = 16 kq + 4 r + ti and columns j = 4 c' + tj contiguously, so a block per (slab, tj, kq) with wave = ti and lane =
+    // (c', r) loads one 256-byte run per split.  (A block per output row — 64 lanes on 64 different lines, each line wanted by 16
+    // blocks — was bound by the CU's one-line-per-cycle address path: 20 k line requests per block.)
+    const int lr = tid & 3, lc = (tid >> 2) & 15, lti = tid >> 6;
+    if (b < a.blocksA) {                                    // ---- A: weight_scale, bias  <- product 1, element (i, col)
+        const int slab = b >> 4, tj = (b >> 2) & 3, kq = b & 3;
+        const int i = slab * 64 + 16 * kq + 4 * lr + lti, col = 4 * lc + tj;
+        if (i <= HC && col < C) {
+            const int h = i / Cp, c = i - h * Cp;
+            if (i == HC) {
+                a.d_bias[col] = wg_sum(a.p1, a.ns1, i, col) + (a.c_bias ? a.c_bias[col] : 0.f);
+            } else if (c < C) {
+                const int idx = (h * C + c) * C + col;
+                a.d_wsc[idx] = wg_sum(a.p1, a.ns1, i, col) + (a.c_wsc ? a.c_wsc[idx] : 0.f);
+            }
         }
+        PG_STAMP(4);
         return;
     }
     b -= a.blocksA;
-    if (b < a.blocksB) {                                    // ---- B: weight_node row k = b
-        const int k = b;
-        if (tid < 8) {
-            const int h = tid & 3, side = tid >> 2;
-            s_dwa[0][tid] = h < H ? wg_sum(a.p2, a.ns2, HC + side * 4 + h, k) : 0.f;
+    if (b < a.blocksB) {                                    // ---- B: weight_node  <- product 2, element (i, k) + the chain rule
+        const int slab = b >> 4, tj = (b >> 2) & 3, kq = b & 3;
+        const int i = slab * 64 + 16 * kq + 4 * lr + lti, k = 4 * lc + tj;
+        const int h = i / Cp, c = i - h * Cp;
+        const bool mine = i < HC && c < C && k < C;
+        float v = mine ? wg_sum(a.p2, a.ns2, i, k) : 0.f;
+        // the attention-gradient rows of this block's 16 columns: d_Wa_i[k, h], d_Wa_j[k, h] (rows HC + side * 4 + h), 16-column runs too
+        if (tid < 2 * 4 * 16) {
+            const int c2 = tid & 15, hh = (tid >> 4) & 3, side = tid >> 6, k2 = 4 * c2 + tj;
+            s_dwa[side][hh * 16 + c2] = (hh < H && k2 < C) ? wg_sum(a.p2, a.ns2, HC + side * 4 + hh, k2) : 0.f;
         }
         __syncthreads();
-        if (tid < H * C) {
-            const int h = tid / C, c = tid - h * C;
-            float v = wg_sum(a.p2, a.ns2, h * Cp + c, k);
-            v = fmaf(s_dwa[0][h], a.att[(size_t)h * 3 * C + c], v);
-            v = fmaf(s_dwa[0][4 + h], a.att[(size_t)h * 3 * C + 2 * C + c], v);
-            a.d_wn[(size_t)k * H * C + tid] = v + (a.c_wn ? a.c_wn[(size_t)k * H * C + tid] : 0.f);
+        if (mine) {
+            v = fmaf(s_dwa[0][h * 16 + lc], a.att[(size_t)h * 3 * C + c], v);
+            v = fmaf(s_dwa[1][h * 16 + lc], a.att[(size_t)h * 3 * C + 2 * C + c], v);
+            const size_t idx = (size_t)k * H * C + h * C + c;
+            a.d_wn[idx] = v + (a.c_wn ? a.c_wn[idx] : 0.f);
         }
+        PG_STAMP(4);
         return;
     }
     b -= a.blocksB;
     if (b < a.blocksC) {                                    // ---- C: attention vector of head h = b
         const int h = b;
-        for (int idx = tid; idx < 2 * C; idx += kBlock) {
-            const int side = idx / C, k = idx - side * C;
-            s_dwa[side][k] = wg_sum(a.p2, a.ns2, HC + side * 4 + h, k);
+        // columns in slab order (k = 4 c' + tj, c' fastest): 16 lanes share a 256-byte run
+        for (int idx = tid; idx < 2 * 64; idx += kBlock) {
+            const int side = idx >> 6, k = 4 * (idx & 15) + ((idx >> 4) & 3);
+            if (k < C) s_dwa[side][k] = wg_sum(a.p2, a.ns2, HC + side * 4 + h, k);
         }
         for (int kk = grp; kk < De; kk += kBlock / 16) {
             const float v = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
@@ -392,6 +423,7 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
             }
             a.d_att[(size_t)h * 3 * C + tid] = v + (a.c_att ? a.c_att[(size_t)h * 3 * C + tid] : 0.f);
         }
+        PG_STAMP(4);
         return;
     }
     b -= a.blocksC;
@@ -399,16 +431,32 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         const int o = b * (kBlock / 16) + grp;
         if (o < De * H * C) {
             const int kk = o / (H * C), m = o - kk * H * C, h = m / C, c = m - h * C;
+            PG_STAMP(1);
             const float dwe = b1_sum16(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, lg);
+#ifdef GLAM_PG_PROF
+            if (dwe == 123.456f) PG_STAMP(7);      // consume dwe before the stamp
+#endif
+            PG_STAMP(2);
             const float dm = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
+#ifdef GLAM_PG_PROF
+            if (dm == 123.456f) PG_STAMP(7);
+#endif
+            PG_STAMP(3);
             if (lg == 0) a.d_we[o] = fmaf(dm, a.att[(size_t)h * 3 * C + C + c], dwe) + (a.c_we ? a.c_we[o] : 0.f);
         }
+        PG_STAMP(4);
     }
 }
 
 }  // namespace glam
 
 using namespace glam;
+
+#ifdef GLAM_PG_PROF
+extern "C" int glam_debug_pg_prof(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_pg_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 static int dims_ok(const char* fn, int C, int H, int De, int Cp, int Dp) {
     if (C <= 0 || H < 1 || H > 4 || De <= 0 || Cp < C || (Cp & 3))
@@ -653,7 +701,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
         const int C = po->C, De = po->De;
         ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
-                         (H * C * C + C + kBlock - 1) / kBlock, C, H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
+                         (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
         if (ss) {
             // side: roles A (d_weight_scale, d_bias <- product 1) and D (d_weight_edge <- B1 partials + d_M), after B1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an instrumented copy of libglam_hip.so for the in-kernel cycle profilers of tools/*_prof.py.
-# usage: tools/build_prof_variant.sh {b1|b1n|ts|tile|dma|gru|fwd}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
+# usage: tools/build_prof_variant.sh {b1|b1n|ts|tile|dma|gru|fwd|pg}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
 set -e
 cd "$(dirname "$0")/../glam_amd/csrc"
 make -j8 > /dev/null
@@ -12,7 +12,8 @@ case "$1" in
   dma)  src=triplet_dma.hip; def=GLAM_DMA_PROF ;;
   gru)  src=block.hip;       def=GLAM_GRU_PROF ;;
   fwd)  src=triplet_h3.hip;  def=GLAM_FWD_PROF ;;
-  *) echo "usage: $0 {b1|b1n|ts|tile|dma|gru|fwd}"; exit 2 ;;
+  pg)   src=layer.hip;       def=GLAM_PG_PROF ;;
+  *) echo "usage: $0 {b1|b1n|ts|tile|dma|gru|fwd|pg}"; exit 2 ;;
 esac
 mkdir -p ../variants
 obj=/tmp/glam_${1}_prof.o
