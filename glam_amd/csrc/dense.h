@@ -61,6 +61,12 @@ int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* ed
 int triplet_fwd_pipe_fused(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
                            const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, float slope,
                            int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s);
+// the same launch warp-specialised (triplet_ws.hip: producer waves gather, consumer waves run the update GEMM; bit-identical)
+int triplet_fwd_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
+                   const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, float slope,
+                   int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s);
+bool triplet_fwd_ws_enabled();          // GLAM_FWD_WS (default 1)
+bool triplet_fwd_ws_supported(int H, int Cp, int De, int edge_onehot);
 bool tile_fwd_supported(int H, int Cp, int Dp);
 int tile_fwd_launch(const float* x, const float* edge_attr, const float* img_node, const float* img_upd, const float* we_p,
                     const float* M, const float* bias_p, const int32_t* rowptr, const int32_t* src, const int32_t* eid,

@@ -591,6 +591,9 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
     const Staged L = staged_layout(H, Cp, Dp);
     TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
     if (int rc = launch_ts_gemm(g1, s)) return rc;
+    if (triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot))
+        return triplet_fwd_ws(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
+                              aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
     return triplet_fwd_pipe_fused(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
                                   aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
 }

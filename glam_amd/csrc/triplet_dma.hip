@@ -17,7 +17,7 @@
 // LDS per wave: 2 buffers x kEC edge rows x (H*Q + 1 + DE/4) 16-byte chunks [row chunks | a_j | edge_attr] + 2 x 4 a_i; a pass
 // whose four nodes have more than kEC edges together (4 x 4 = 16 is the worst case; 3e-5 of the molecular passes) is processed
 // node by node without prefetch.  Results are bit-identical to k_triplet_fwd (same operation order per lane).
-#include "triplet_kernels.h"
+#include "triplet_pipe.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -32,18 +32,6 @@ __device__ long long g_dma_prof[64 * 8];
 #endif
 
 constexpr int kEC = 11;                  // edge rows per pass buffer (11 x 45 chunks fit the 8 x 64-lane staging pieces of the default width)
-constexpr int kMetaSlots = 16;           // a_j / edge_attr slots of the one-piece side table (>= kEC, all written every pass)
-
-struct FwdDmaArgs {
-    const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
-    const int* ell_src; const int* ell_eid;      // [N][4] each
-    int N; int Cp; float slope;
-    float* aggr; float* stats;
-    const float* img_upd; const float* bias_p; float* out;     // fused update epilogue (k_triplet_fwd_pipe<..., FUSE = true>)
-};
-
-struct PassMeta { int deg; int off; int tot; int dmax; };   // per lane: its node's degree, packed slot offset; wave-wide edge
-                                                            // count and largest degree (wave-uniform)
 
 // One LDS-DMA piece: 64 lanes x 16 bytes, lane l lands at lds_base + 16 l (lds_base wave-uniform, in M0); source = 64-bit
 // wave-uniform base (SGPR pair) + per-lane unsigned 32-bit byte offset.  Written as inline assembly on purpose: through the
