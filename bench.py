@@ -59,6 +59,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "k_ts_gemm<12, 4, 4>": {"bound": "mfma", "flops": 2 * N * C * (HC + 8), "bytes": f * N * (C + HC + 8) + img(C, HC + 8),
                                 "note": "x @ [W_node | Wa]; a second launch per step (d_out @ W_scale^T, 2*N*C*HC flops) only where B1 has no fused variant"},
         "k_triplet_fwd+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C},
+        "k_triplet_fwd_ws+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
+                                    "note": "warp-specialised: 8 producer waves run the software-pipelined aggregate, 4 consumer waves the update GEMM "
+                                            "out of an LDS tile ring (csrc/triplet_ws.hip); the op's choice for molecular graphs at every size"},
         "k_triplet_fwd_pipe+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
                                       "note": "software-pipelined aggregate + update epilogue: the op's choice beyond the LLC"},
         "k_triplet_fwd": {"bound": "hbm", "bytes": agg_fwd},
@@ -259,6 +262,10 @@ def main():
     from glam_amd import layer, ops
     from glam_amd.data import synth_batch
     ops.FEATURE_STORAGE = args.storage
+    # one route for everything this script issues: the Python autograd node (what a hipGraph capture records).  Eagerly issued steps would
+    # otherwise go through the C++ node of the torch extension (same numbers, but the general kernels instead of the ELL ones), and
+    # roofline_kernels — taken from eager executions of the captured function — would describe kernels the timed replay does not launch
+    ops.USE_TORCH_EXT = False
     from glam_amd.parallel import broadcast_parameters, flat_view
 
     B, C, De, H = args.batch, 60, 4, 3
@@ -419,11 +426,11 @@ def main():
                     row["note"] = m["note"]
             kernels[name] = row
         step_kernel_us = sum(r["avg_us"] * r["launches_per_step"] for r in prof.values())
-        dom = "k_triplet_fwd+update"
-        if dom in kernels:
+        dom = next((n for n in ("k_triplet_fwd_ws+update", "k_triplet_fwd+update", "k_triplet_fwd_pipe+update") if n in kernels), None)
+        if dom is not None:
             k = kernels[dom]
-            result["roofline"] = {"kernel": "k_triplet_fwd<3,16,1,4,true> with the update GEMM fused (what the step launches: gather + "
-                                            "segment softmax + scatter-add + aggr @ W_scale + bias)",
+            result["roofline"] = {"kernel": dom + " (what the step launches: gather + segment softmax + scatter-add + aggr @ W_scale + bias "
+                                            "in one launch)",
                                   "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": k["frac_hbm_peak"], "frac_of_achievable_6290": k["frac_hbm_achievable"],
                                   "traffic": None, "algorithmic_bytes": k["algorithmic_bytes"], "avg_launch_us": k["avg_us"],

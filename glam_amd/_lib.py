@@ -53,6 +53,7 @@ SIGNATURES = {
     "glam_ell_build": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "glam_triplet_fwd_ell_supported": (_i32, [_i32, _i32, _i32]),
     "glam_triplet_fwd_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
+    "glam_triplet_layer_ws_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "glam_triplet_layer_fwd_ell": (_i32, [_vp] * 5 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_supported": (_i32, [_i32]),

@@ -598,6 +598,10 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
                                   aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
 }
 
+extern "C" int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot) {
+    return (triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot)) ? 1 : 0;
+}
+
 // bf16 STORAGE of the gathered rows (BASELINE config 3): xw16 is bf16[N, H*Cp]; logits, softmax and sums stay fp32
 extern "C" int glam_triplet_layer_fwd_x16(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
                                           const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,

@@ -142,7 +142,10 @@ class GraphIndex:
     def ell(self):
         """``(ell_src, ell_eid)`` int32 ``[N, 4]`` index records of the software-pipelined forward aggregate (``glam_ell_build``),
         or ``None`` when some node has more than 4 incoming edges (one host sync, once per edge list — molecular graphs never
-        do; protein contact maps always do and keep the general kernel)."""
+        do; protein contact maps always do and keep the general kernel).  While a stream capture is running the answer must
+        already be known (a read-back would invalidate the capture): unknown then means ``None``, the general kernels."""
+        if self._ell is False and torch.cuda.is_current_stream_capturing():
+            return None
         if self._ell is False:
             self._ell = None
             if self.N > 0:
@@ -157,7 +160,10 @@ class GraphIndex:
 
     def ell_t(self):
         """``(ell_dst, ell_eid_t)`` int32 ``[N, 4]``: the ELL records BY SOURCE of the software-pipelined backward B2 (``glam_ell_build`` on
-        the CSR transpose), or ``None`` when some node has more than 4 outgoing edges (one host sync, once per edge list)."""
+        the CSR transpose), or ``None`` when some node has more than 4 outgoing edges (one host sync, once per edge list; inside a
+        stream capture an answer not known yet is ``None``)."""
+        if self._ell_t is False and torch.cuda.is_current_stream_capturing():
+            return None
         if self._ell_t is False:
             self._ell_t = None
             if self.N > 0:
@@ -192,9 +198,9 @@ class GraphIndex:
 
 TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
 BWD_ELL = os.environ.get("GLAM_BWD_ELL", "1") == "1"       # A/B knob: pipelined B2 beyond the LLC
-# Fused forward with the software pipeline inside (csrc/triplet_dma.hip, FUSE = true), for molecular graphs: "auto" = beyond the LLC
-# (B = 16 384: 195 vs 240 us), "1" = always (B = 1 024: 18.2 vs 16.4 us — the general fused kernel wins while the batch is cache
-# resident), "0" = never.
+# Fused forward over ELL records (molecular graphs): "auto" = the warp-specialised kernel (csrc/triplet_ws.hip) wherever it exists
+# (one-hot bond features: every size), the barrier-coupled pipelined kernel (csrc/triplet_dma.hip, FUSE = true) beyond the LLC
+# otherwise; "1" = always an ELL route, "0" = never (the general fused kernel).
 PIPE_FUSED = os.environ.get("GLAM_PIPE_FUSED", "auto")
 
 
@@ -535,7 +541,10 @@ class _TripletLayer(torch.autograd.Function):
         # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
         # faster at B=1024 (one tile per CU) but slower beyond, where its barrier-separated phases leave the CU idle
         # (measurements in DESIGN.md).
-        want_pf = PIPE_FUSED in ("1", True) or (PIPE_FUSED == "auto" and GraphIndex.wants_ell(N, H, Cp))
+        # "auto": molecular graphs with one-hot bond features take the warp-specialised kernel at every size (15.1 vs 20.0 us at B = 1 024,
+        # 136 vs 256 us at B = 16 384 against the general fused kernel); other ELL graphs the barrier-coupled pipelined one beyond the LLC
+        want_pf = PIPE_FUSED in ("1", True) or (PIPE_FUSED == "auto" and Cp > 32 and not TILES_ENABLED and (
+            GraphIndex.wants_ell(N, H, Cp) or (N > 0 and lib.glam_triplet_layer_ws_supported(H, Cp, Dp, int(rows_are_one_hot(ea_p))))))
         ell = gi.ell() if (want_pf and not TILES_ENABLED and Cp > 32) else None
         if ell is not None:     # molecular graph: the software-pipelined aggregate with the update GEMM as its epilogue (bit-identical)
             check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), int(rows_are_one_hot(ea_p)), N,
@@ -648,6 +657,10 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
     """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
     if _want_torch_ext(gi.N, heads, x_p.size(1)):
         from . import torch_ext
+        # an eager visit goes through the C++ node (general kernels); it is also where the one-time read-backs of the ELL routes happen,
+        # so that a later CAPTURED visit of the same batch finds them cached (bit-identical results either way)
+        if PIPE_FUSED == "auto" and x_p.size(1) > 32 and gi.N > 0 and rows_are_one_hot(ea_p):
+            gi.ell()
         # same checks, same exception type as the Python node (the operator's own TORCH_CHECKs would raise RuntimeError)
         require_device(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias)
         C = weight_node.size(0)
@@ -1855,12 +1868,15 @@ _ONEHOT_CACHE: dict = {}
 
 
 def rows_are_one_hot(t):
-    """True iff every row of ``t`` is one-hot (one host sync, cached per tensor object like the CSR staging)."""
+    """True iff every row of ``t`` is one-hot (one host sync, cached per tensor object like the CSR staging).  Inside a stream capture an
+    answer that is not cached yet is ``False`` (no read-back there): the contraction path is always correct."""
     key = id(t)
     hit = _ONEHOT_CACHE.get(key)
     if hit is not None and hit[0]() is t and hit[1] == t._version:
         return hit[2]
     mark = getattr(t, "_glam_onehot", None)      # (flag, tensor version) known from the host side (data.PackedDataset): no read-back
+    if not (mark is not None and mark[1] == t._version) and t.is_cuda and torch.cuda.is_current_stream_capturing():
+        return False
     ok = bool(mark[0]) if (mark is not None and mark[1] == t._version) else \
         (bool((((t == 0) | (t == 1)).all() & (t.sum(dim=1) == 1).all()).item()) if t.numel() else True)
     try:

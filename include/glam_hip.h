@@ -422,6 +422,10 @@ int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_a
 /* glam_triplet_layer_fwd for edge lists with an ELL form (glam_ell_build, in-degree <= 4): node GEMM + the software-pipelined
  * aggregate with the update GEMM as its epilogue.  Same tensors and results (bit for bit) as glam_triplet_layer_fwd; 36 <= Cp <= 64,
  * H * Cp <= 192.  edge_onehot as in glam_triplet_fwd_ell. */
+/* 1 when glam_triplet_layer_fwd_ell runs these shapes on the warp-specialised kernel (csrc/triplet_ws.hip: producer waves gather, consumer
+ * waves run the update GEMM out of an LDS tile ring; one-hot edge features of width 4): the faster route at EVERY batch size, so callers
+ * with an ELL form take it below the LLC size as well. */
+int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot);
 int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
                                const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp, float slope,
                                float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);

@@ -1825,6 +1825,44 @@ def test_pipelined_fused_forward_equals_the_general_fused_kernel(device, monkeyp
         assert torch.isfinite(conv(x0, b.edge_index, b.edge_attr)).all()
 
 
+@pytest.mark.parametrize("C,H,B", [(60, 3, 1024), (60, 3, 7), (40, 4, 200), (64, 2, 90), (45, 3, 150), (60, 1, 64)])
+def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkeypatch, C, H, B):
+    """csrc/triplet_ws.hip (producer waves gather, consumer waves run the update GEMM out of an LDS tile ring; what the op launches for
+    molecular graphs at every size) against the general fused kernel AND the barrier-coupled pipelined one: output, the saved aggregate
+    and all six gradients equal bit for bit — every head count, padded widths, tile counts that are odd / smaller than the ring / not a
+    multiple of the producer groups, isolated atoms, both producer counts."""
+    b = synth_batch(B, seed=B + C).to(device)
+    torch.manual_seed(C + H)
+    conv = layer.TripletMessage(C, 4, heads=H).to(device)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    N = b.x.size(0)
+    x0 = torch.randn(N, C, device=device)
+    cot = torch.randn(N, C, device=device)
+    from glam_amd import _lib
+    lib = _lib.load()
+    Cp = (C + 3) // 4 * 4
+    assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 1) == 1
+    assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 0) == 0 and lib.glam_triplet_layer_ws_supported(H, Cp, 8, 1) == 0
+    res = {}
+    for name, mode, ws, prod in (("general", "0", "1", "8"), ("pipe", "1", "0", "8"), ("ws8", "auto", "1", "8"), ("ws4", "auto", "1", "4")):
+        monkeypatch.setattr(ops, "PIPE_FUSED", mode)
+        monkeypatch.setenv("GLAM_FWD_WS", ws)
+        monkeypatch.setenv("GLAM_WS_PROD", prod)
+        monkeypatch.setenv("GLAM_TORCH_EXT", "0")
+        monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+        x = x0.clone().requires_grad_(True)
+        with _lib.kernel_timer(capacity=64) as kt:
+            out = conv(x, b.edge_index, b.edge_attr)
+        launched = [n for n, _, _ in kt.records()]
+        res[name] = (out, torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot), launched)
+    assert any("k_triplet_fwd_ws" in n for n in res["ws8"][2]) and any("k_triplet_fwd_ws" in n for n in res["ws4"][2]), res["ws8"][2]
+    assert any("k_triplet_fwd_pipe" in n for n in res["pipe"][2]) and not any("_ws" in n or "_pipe" in n for n in res["general"][2])
+    for name in ("pipe", "ws8", "ws4"):
+        assert torch.equal(res["general"][0], res[name][0]), (name, (res["general"][0] - res[name][0]).abs().max().item())
+        assert all(torch.equal(a, c) for a, c in zip(res["general"][1], res[name][1])), name
+
+
 # ---------------------------------------------------------------------------------------------
 # narrow-output linear (the model's output head, model.py:47,61): row dot products instead of a library GEMM
 # ---------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ N = b.x.size(0)
 grid = min((N + 15) // 16, int(os.environ.get("GLAM_WS_GRID", "256")))
 tiles = (N + 15) // 16 / grid
 print(f"B={B}: {tiles:.1f} tiles per block; cycles per tile (mean over 64 blocks)")
-pn = ["loop top", "wait vmcnt(0)", "stores", "ballot / shuffles / lgkmcnt wait", "side-table DMA + row loads issue", "record load", "compute", "publish (incl. wait for a free slot)"]
+pn = ["loop top", "wait vmcnt(0)", "stores", "(unused)", "ballot / DPP / side-table DMA + row loads issue", "record load", "compute", "publish (incl. wait for a free slot)"]
 print(f"  producer waves 0-{P - 1} (cycles per PASS: each wave gathers every {P // 4}-th tile of the block):")
 tiles_p = tiles / (P // 4)
 for k, n in enumerate(pn):
