@@ -85,6 +85,11 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
 int triplet_bwd_src_pipe(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                          const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
                          float* d_xw, float* d_a_ij, int grid_blocks, hipStream_t s);
+// B2 + d_x = [d_xw | d_a] @ Wcat^T in one warp-specialised launch (triplet_ws.hip; one-hot edge features of width 4)
+bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot);
+int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
+                       const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De);
 

@@ -681,7 +681,8 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     int tnblk = 0;
     // d_x = [d_xw | d_a] @ Wcat^T inside B2 — unless the caller supplied ELL records by source: the pipelined B2 + its own GEMM launch
     const bool use_ell = ell_dst && ell_eid_t && Cp <= 64;
-    const bool fuse_dx = !use_ell && triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes();
+    const bool ws_dx = use_ell && triplet_bwd_src_ws_supported(H, Cp, Dp, edge_onehot);     // B2 + d_x in one warp-specialised launch
+    const bool fuse_dx = ws_dx || (!use_ell && triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes());
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,

@@ -177,8 +177,12 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
     }
     if (ell_dst && ell_eid_t && emul && Cp <= 64) {
-        // molecular graphs beyond the LLC: the software-pipelined B2 over ELL records by source (no fused d_x: the caller runs the GEMM)
-        if (img_dx || d_x) return fail(GLAM_E_INVALID, "glam_triplet_bwd: the ELL route of B2 has no fused d_x");
+        // molecular graphs: B2 over ELL records by source — warp-specialised with the d_x GEMM inside where that kernel exists, the
+        // software-pipelined B2 alone otherwise (no fused d_x there: the caller runs the GEMM)
+        if (img_dx && d_x && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
+            return triplet_bwd_src_ws(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
+                                      d_a_ij, img_dx, d_x, s);
+        if (img_dx || d_x) return fail(GLAM_E_INVALID, "glam_triplet_bwd: the ELL route of B2 has no fused d_x for these shapes");
         return triplet_bwd_src_pipe(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
                                     d_a_ij, 0, s);
     }

@@ -65,6 +65,65 @@ __device__ __forceinline__ int flag_load(const int* p) {
 }
 __device__ __forceinline__ void flag_bump(int* p) { (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+#ifdef GLAM_WS_PROF
+#define WS_PROF_PARAMS , long long* pacc, long long& plast
+#define WS_PROF_ARGS , pacc, plast
+#else
+#define WS_PROF_PARAMS
+#define WS_PROF_ARGS
+#endif
+
+// Consumer wave w of a warp-specialised block: out[16 tile .. +15, 16 w .. +15] = tile[16, K] @ W[:, 16 w .. +15] (+ bias) for every tile
+// the block's producers publish, W given as a k_ts_gemm weight image (64 logical columns).  The wave keeps its K x 16 slice of W in 48
+// registers for the whole launch; a tile's A fragments come out of the ring slot (row pitch LDT floats).
+// (Two tiles per trip with alternating accumulator chains — a 16x16x4 fp32 MFMA issues every 32 cycles but feeds the next one of its own
+// chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
+// producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
+__device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
+                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int c = lane & 15, kq = lane >> 4;
+    const int GK = (K + 15) >> 4;                             // 16-k groups, <= 12
+    const int col = 16 * w + c;
+    const int pos = (col & 3) * 16 + (col >> 2);              // position of logical column `col` in a k_ts_gemm image row
+    float4 bf[12];
+#pragma unroll
+    for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(img + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
+    const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int slot = it % kWsRing, want = 4 * (it / kWsRing + 1);
+        while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        WSTAMP(0);
+        const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
+        float4 af[12];
+#pragma unroll
+        for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
+        WSTAMP(1);
+        // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
+        // so the chain starts when the first fragment lands instead of after the twelfth
+        v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            if (g < GK) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
+        const int r0 = 16 * tile + 4 * kq;
+        if (col < Cp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
+        }
+        WSTAMP(2);
+    }
+}
+
 template <int H, int P>
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_fwd_ws(FwdDmaArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
@@ -91,53 +150,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #endif
 
     if (wave >= P) {
-        // ------------------------------------------------------------------------------------------------------------------
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
-        // ------------------------------------------------------------------------------------------------------------------
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const int w = wave - P, c = lane & 15, kq = lane >> 4;
-        const int GK = (HC + 15) >> 4;                        // 16-k groups, <= 12
-        const int col = 16 * w + c;
-        const int pos = (col & 3) * 16 + (col >> 2);          // position of logical column `col` in a k_ts_gemm image row
-        float4 bf[12];
-#pragma unroll
-        for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(a.img_upd + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
-        const float bias = col < Cp ? a.bias_p[col] : 0.f;
-        // (Two tiles per trip with alternating accumulator chains — a 16x16x4 fp32 MFMA issues every 32 cycles but feeds the next one of
-        // its own chain only after 40 — measured SLOWER: 143 vs 136 us at B = 16 384.  Back-to-back MFMAs take the issue slots the two
-        // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
-        int it = 0;
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-            const int slot = it % kWsRing, want = 4 * (it / kWsRing + 1);
-            while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            WSTAMP(0);
-            const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
-            float4 af[12];
-#pragma unroll
-            for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < HC) ? ld4(tl + 16 * g) : f4zero();
-            WSTAMP(1);
-            // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
-            // so the chain starts when the first fragment lands instead of after the twelfth
-            v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                if (g < GK) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) flag_bump(s_taken + slot);         // every fragment is in registers: the slot may be refilled
-            const int r0 = 16 * tile + 4 * kq;
-            if (col < Cp) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (r0 + i < a.N) a.out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
-            }
-            WSTAMP(2);
-        }
+        ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -358,6 +372,262 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
 #undef LANE_CONSTS
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_triplet_bwd_src_ws: backward B2 (d_xw[j] = sum over the out-edges of j of alpha_e * e_ij * d_aggr[dst], d_a_j[j] = sum dpre_e;
+// general kernel: k_triplet_bwd_src) with the input gradient d_x = [d_xw | d_a_i | d_a_j] @ Wcat^T as the consumers' GEMM — the same
+// block structure as k_triplet_fwd_ws.  ELL records BY SOURCE (dst[4] | eid[4] per node).  The side table of a pass is three lane-indexed
+// LDS-DMA pieces (alpha_e | dpre_e | edge_attr of the lane's edge) plus the node's d_a_i (written by B1) in the free lane 4 of piece 1.
+// No softmax here, so the row layout stays: the per-edge scalars are LDS broadcasts.  Bit-identical to k_triplet_bwd_src + its fused
+// d_x epilogue (same operations, same order).
+// ------------------------------------------------------------------------------------------------------------------------------
+struct SrcWsArgs {
+    const float* d_aggr; const float* alpha_e; const float* dpre_e; const float* edge_attr; const float* w_edge;
+    const int* ell_dst; const int* ell_eid;      // [N][4] each, by source
+    int N; int Cp;
+    float* d_xw; float* d_a_ij;                  // d_a_ij[N, 8]: columns 0..3 (d_a_i) are read, 4..7 (d_a_j) written
+    const float* img_dx; float* d_x;
+};
+
+template <int H, int P>
+__global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
+    constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    const int WSZ = DE * HC, KX = HC + 8;
+    const int LDT = KX + ((68 - (KX & 63)) & 63);             // row pitch = 4 mod 64 words: conflict-free A-fragment reads
+    constexpr int kSideF = 3 * 64 * 4;                        // alpha_e (| d_a_i in lane 4) | dpre_e | edge_attr, 1 KB each
+    float* s_w = smem;
+    int* s_ready = reinterpret_cast<int*>(smem + WSZ);
+    int* s_taken = s_ready + 32;
+    float* s_meta = smem + WSZ + 64;
+    float* s_ring = s_meta + P * 2 * kSideF;
+    for (int i = tid; i < WSZ / 4; i += kWsBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+    if (tid < 64) s_ready[tid] = 0;
+    __syncthreads();
+    const int ntiles = (a.N + 15) >> 4;
+#ifdef GLAM_WS_PROF
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
+#endif
+    if (wave >= P) {
+        ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        return;
+    }
+    float* wbase = s_meta + wave * (2 * kSideF);
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)smem;
+    const int npass = (a.N + 3) >> 2;
+    const int grp = wave >> 2, rw = wave & 3;
+    const int gw = 4 * (blockIdx.x + grp * gridDim.x) + rw, GW = 4 * PG * gridDim.x;
+    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;
+    int lv = lane;
+#define LANE_CONSTS()                                                                        \
+    asm volatile("" : "+v"(lv));                                                             \
+    const int j = lv >> 4, q = lv & 15;                                                      \
+    const bool qok = q < Q;                                                                  \
+    const unsigned qoff = (unsigned)(qok ? q : 0) * 16u
+
+    auto load_rec = [&](int pass, int& rs, int& re) {
+        LANE_CONSTS(); (void)qok; (void)qoff;
+        const int n = 4 * pass + j;
+        rs = -1; re = -1;
+        if (q < 4 && pass < npass && n < a.N) { rs = a.ell_dst[4 * n + q]; re = a.ell_eid[4 * n + q]; }
+    };
+    auto prefetch = [&](int pass, int rs, int re, int sel, float4 (&rows)[CH][H], int& deg, int& dmax) {
+        LANE_CONSTS();
+        const unsigned long long bal = __ballot(rs >= 0);
+        deg = __popcll((bal >> (16 * j)) & 0xFull);
+        const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
+                  d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
+        dmax = max(max(d0, d1), max(d2, d3));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 4u * (unsigned)(WSZ + 64 + (wave * 2 + sel) * kSideF));
+        const int n_i = 4 * pass + j;
+        if (q == 4 && pass < npass && n_i < a.N) dma16(a.d_a_ij, (unsigned)n_i * 32u, dst);      // the node's d_a_i (B1) for the d_x tile
+        if (bal == 0ull) return;
+        if (re >= 0) {
+            dma16(a.alpha_e, (unsigned)re * 16u, dst);
+            dma16(a.dpre_e, (unsigned)re * 16u, dst + 1024u);
+            dma16(a.edge_attr, (unsigned)re * 16u, dst + 2048u);
+        }
+        int sk[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) sk[k] = row_bcast_i(rs, k);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (k < dmax) {
+                const unsigned ro = (unsigned)max(sk[k] >= 0 ? sk[k] : sk[0], 0) * row_bytes + qoff;
+#pragma unroll
+                for (int h = 0; h < H; ++h) rows[k][h] = ld4o(a.d_aggr, ro + (unsigned)h * head_bytes);
+            }
+        }
+    };
+
+    float4 r_acc[H];
+    float4 r_da = f4zero(), r_dai = f4zero();
+    int r_n = -1;
+    auto compute = [&](auto dm_tag, int pass, int deg, int sel, const float4 (&rows)[CH][H]) {
+        constexpr int DM = decltype(dm_tag)::value;
+        LANE_CONSTS(); (void)qoff;
+        const int n = 4 * pass + j;
+#pragma unroll
+        for (int h = 0; h < H; ++h) r_acc[h] = f4zero();
+        r_da = f4zero(); r_dai = f4zero();
+        if (n >= a.N || pass >= npass) { r_n = -1; return; }
+        r_n = n;
+        const float* meta = wbase + sel * kSideF;
+        r_dai = ld4(meta + (16 * j + 4) * 4);
+        if (deg > 0) {
+            float4 al[DM];
+            int tk[DM];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                const bool valid = k < deg;
+                const int e = 16 * j + (valid ? k : 0);       // an empty slot aliases the first edge: finite data, weight 0
+                al[k] = ld4(meta + e * 4);
+                float4 dp = ld4(meta + 256 + e * 4);
+                const float4 ea = ld4(meta + 512 + e * 4);
+                if (!valid) { al[k] = f4zero(); dp = f4zero(); }
+                r_da.x += dp.x; r_da.y += dp.y; r_da.z += dp.z; r_da.w += dp.w;
+                int t = 0;
+                t = ea.y != 0.f ? 1 : t; t = ea.z != 0.f ? 2 : t; t = ea.w != 0.f ? 3 : t;
+                tk[k] = t * HC + (qok ? q : 0) * 4;
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float4 er[DM];
+#pragma unroll
+                for (int k = 0; k < DM; ++k) er[k] = ld4(s_w + tk[k] + h * Cp);
+#pragma unroll
+                for (int k = 0; k < DM; ++k) {
+                    const float4 dg = er[k] * rows[k][h];
+                    fma4(r_acc[h], f4get(al[k], h), dg);
+                }
+            }
+        }
+    };
+    auto compute_any = [&](int pass, int deg, int dmax, int sel, const float4 (&rows)[CH][H]) {
+        if (dmax <= 1) compute(std::integral_constant<int, 1>{}, pass, deg, sel, rows);
+        else if (dmax == 2) compute(std::integral_constant<int, 2>{}, pass, deg, sel, rows);
+        else if (dmax == 3) compute(std::integral_constant<int, 3>{}, pass, deg, sel, rows);
+        else compute(std::integral_constant<int, 4>{}, pass, deg, sel, rows);
+    };
+    auto publish = [&](int it) {
+        LANE_CONSTS(); (void)qoff;
+        const int slot = it % kWsRing;
+        if (it >= kWsRing) {
+            const int want = kWsCons * (it / kWsRing);
+            while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        float* tl = s_ring + slot * 16 * LDT + (rw * 4 + j) * LDT;
+        if (qok) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) st4(tl + h * Cp + q * 4, r_acc[h]);
+        }
+        if (q == 0) { st4(tl + HC, r_dai); st4(tl + HC + 4, r_da); }       // [d_a_i | d_a_j]: columns HC .. HC + 7 of the tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lv == 0) flag_bump(s_ready + slot);
+    };
+    auto store_results = [&]() {
+        if (r_n < 0) return;
+        LANE_CONSTS(); (void)qoff; (void)j;
+        if (qok) {
+            const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
+#pragma unroll
+            for (int h = 0; h < H; ++h) st4o(a.d_xw, orow + (unsigned)h * head_bytes, r_acc[h]);
+        }
+        if (q == 0) st4o(a.d_a_ij, (unsigned)r_n * 32u + 16u, r_da);
+        r_n = -1;
+    };
+    auto settle = [&](float4 (&rows)[CH][H]) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                asm volatile("" : : "v"(rows[k][h].x), "v"(rows[k][h].y), "v"(rows[k][h].z), "v"(rows[k][h].w));
+    };
+
+    float4 rows_a[CH][H], rows_b[CH][H];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h) { rows_a[k][h] = f4zero(); rows_b[k][h] = f4zero(); }
+    int rs_nxt, re_nxt;
+    int pass = gw;
+    load_rec(pass, rs_nxt, re_nxt);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+    int deg_a, dmax_a, deg_b = 0, dmax_b = 0;
+    prefetch(pass, rs_nxt, re_nxt, 0, rows_a, deg_a, dmax_a);
+    load_rec(pass + GW, rs_nxt, re_nxt);
+    const int pass_end = ntiles << 2;
+    int it = grp;
+    for (; pass - rw < pass_end; pass += 2 * GW, it += 2 * PG) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        settle(rows_a);
+        store_results();
+        prefetch(pass + GW, rs_nxt, re_nxt, 1, rows_b, deg_b, dmax_b);
+        load_rec(pass + 2 * GW, rs_nxt, re_nxt);
+        compute_any(pass, deg_a, dmax_a, 0, rows_a);
+        publish(it);
+
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
+        settle(rows_b);
+        store_results();
+        prefetch(pass + 2 * GW, rs_nxt, re_nxt, 0, rows_a, deg_a, dmax_a);
+        load_rec(pass + 3 * GW, rs_nxt, re_nxt);
+        if (pass + GW - rw < pass_end) {
+            compute_any(pass + GW, deg_b, dmax_b, 1, rows_b);
+            publish(it + PG);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_results();
+#undef LANE_CONSTS
+}
+
+template <int H, int P>
+static void launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
+    static bool big = false;
+    if (!big) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big = true;
+    }
+    const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
+    const size_t lds = ((size_t)4 * HC + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
+    GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+}
+
+bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
+    const char* e = getenv("GLAM_BWD_WS");
+    return !(e && atoi(e) == 0) && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H * Cp + 8 <= 192;
+}
+
+// B2 + d_x over ELL records by source, warp-specialised (called by triplet_bwd_impl)
+int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
+                       const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s) {
+    if (N == 0) return GLAM_OK;
+    if (!triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
+    if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a tensor exceeds 4 GiB (32-bit offsets)");
+    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x};
+    const int ntiles = (int)((N + 15) / 16);
+    const char* ge = getenv("GLAM_WS_GRID");
+    const int cap = ge ? atoi(ge) : 256;
+    const int grid = ntiles < cap ? ntiles : cap;
+    const char* pe = getenv("GLAM_WS_PROD");
+    const bool p4 = pe && atoi(pe) == 4;
+    switch (H) {
+        case 1: if (p4) launch_src_ws_p<1, 4>(a, grid, s); else launch_src_ws_p<1, 8>(a, grid, s); break;
+        case 2: if (p4) launch_src_ws_p<2, 4>(a, grid, s); else launch_src_ws_p<2, 8>(a, grid, s); break;
+        case 3: if (p4) launch_src_ws_p<3, 4>(a, grid, s); else launch_src_ws_p<3, 8>(a, grid, s); break;
+        default: launch_src_ws_p<4, 4>(a, grid, s); break;
+    }
+    GLAM_LAUNCH_CHECK("triplet_bwd_src_ws");
+    return GLAM_OK;
 }
 
 static size_t ws_lds_bytes(int H, int Cp, int P) {

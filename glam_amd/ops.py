@@ -595,7 +595,9 @@ class _TripletLayer(torch.autograd.Function):
                 return d_x, None, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
             return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
         # beyond the LLC, molecular graphs: the software-pipelined B2 over ELL records by source (bit-identical)
-        ell_t = gi.ell_t() if (N > 0 and BWD_ELL and GraphIndex.wants_ell(N, H, Cp) and d_ea is None) else None
+        # (with one-hot bond features: the warp-specialised B2 + d_x launch, at every size)
+        ell_t = gi.ell_t() if (N > 0 and BWD_ELL and d_ea is None and (GraphIndex.wants_ell(N, H, Cp) or (
+            PIPE_FUSED == "auto" and Cp > 32 and lib.glam_triplet_layer_ws_supported(H, Cp, Dp, int(rows_are_one_hot(ea_p)))))) else None
         have_carry = ctx.carried and d_carry is not None and N > 0
         if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
@@ -661,6 +663,8 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
         # so that a later CAPTURED visit of the same batch finds them cached (bit-identical results either way)
         if PIPE_FUSED == "auto" and x_p.size(1) > 32 and gi.N > 0 and rows_are_one_hot(ea_p):
             gi.ell()
+            if torch.is_grad_enabled() and BWD_ELL:
+                gi.ell_t()
         # same checks, same exception type as the Python node (the operator's own TORCH_CHECKs would raise RuntimeError)
         require_device(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias)
         C = weight_node.size(0)

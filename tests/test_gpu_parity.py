@@ -1854,9 +1854,11 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
         x = x0.clone().requires_grad_(True)
         with _lib.kernel_timer(capacity=64) as kt:
             out = conv(x, b.edge_index, b.edge_attr)
+            grads = torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)
         launched = [n for n, _, _ in kt.records()]
-        res[name] = (out, torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot), launched)
-    assert any("k_triplet_fwd_ws" in n for n in res["ws8"][2]) and any("k_triplet_fwd_ws" in n for n in res["ws4"][2]), res["ws8"][2]
+        res[name] = (out, grads, launched)
+    for name in ("ws8", "ws4"):      # forward AND backward-by-source (+ d_x) on the warp-specialised kernels
+        assert any("k_triplet_fwd_ws" in n for n in res[name][2]) and any("k_triplet_bwd_src_ws" in n for n in res[name][2]), res[name][2]
     assert any("k_triplet_fwd_pipe" in n for n in res["pipe"][2]) and not any("_ws" in n or "_pipe" in n for n in res["general"][2])
     for name in ("pipe", "ws8", "ws4"):
         assert torch.equal(res["general"][0], res[name][0]), (name, (res["general"][0] - res[name][0]).abs().max().item())
