@@ -27,6 +27,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -34,7 +35,9 @@ import subprocess
 import sys
 import time
 
+_T_START = time.perf_counter()
 import torch
+_T_TORCH = time.perf_counter()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -98,6 +101,28 @@ def rate(model, us):
         tf = model["flops"] / (us * 1e-6) / 1e12
         out.update(flops=model["flops"], achieved_TFLOPs=tf, frac_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
     return out
+
+
+def committed_traffic(kernel_label, batch):
+    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 --pmc passes of this command (profiles/r*_hbm_traffic_pmc_b<B>.json:
+    FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes; tools/rocpd_traffic.py).  PMC counters cannot be collected inside
+    an unprofiled run: the figure quoted is the newest committed one, with its file name; None when there is none for this kernel."""
+    import glob
+    import re
+    stem = re.sub(r"\+.*", "", kernel_label)               # "k_triplet_fwd_ws+update" -> "k_triplet_fwd_ws"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_pmc_b{batch}.json")), reverse=True):
+        try:
+            rows = json.load(open(path))
+        except Exception:       # noqa: BLE001
+            continue
+        rows = rows.get("kernels", rows) if isinstance(rows, dict) else rows
+        items = rows.items() if isinstance(rows, dict) else ((r.get("kernel", ""), r) for r in rows)
+        for name, r in items:
+            if isinstance(r, dict) and stem + "<" in name.replace("glam::", "") + "<":
+                tot = r.get("traffic_bytes") or r.get("hbm_bytes") or r.get("total_bytes")
+                if tot:
+                    return float(tot), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def profile_step(body, reps):
@@ -231,6 +256,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=16,
                     help="consecutive steps captured into one hipGraph launch (each graph launch carries a ~7 us bubble on this stack: "
                          "98.0 / 94.5 / 92.6 / 91.7 / 91.3 us per step at 1 / 2 / 4 / 8 / 16 steps per launch, tools/exp_multistep_graph.py)")
+    ap.add_argument("--stage-per-step", action="store_true", help="keep the parameter re-layout launch (k_stage_params) inside every step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--large-batch", type=int, default=16384, help="extra roofline point beyond the LLC (0 = skip)")
     ap.add_argument("--prof-reps", type=int, default=30, help="eager profiled steps behind roofline_kernels")
@@ -241,6 +267,14 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+
+    legs = {"import_torch": _T_TORCH - _T_START}      # wall_s per leg of this command (rank 0's clock)
+    t_leg = [time.perf_counter()]
+
+    def leg(name):
+        now = time.perf_counter()
+        legs[name] = legs.get(name, 0.0) + now - t_leg[0]
+        t_leg[0] = now
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -285,12 +319,21 @@ def main():
     batch = batch_cpu.to(dev)
     x = x_cpu.to(dev).requires_grad_(True)
     cot = cot_cpu.to(dev)
+    leg("setup (process group, synthetic batch, model to device)")
     params = list(conv.parameters())
     n_param = sum(p.numel() for p in params)
     flat = torch.zeros(n_param, device=dev)                    # gradient bucket when the grads are not one already
     live = {}
 
+    # configs[1]'s step is forward + backward of the layer: no optimizer inside it, so the parameters stand still and their staged
+    # images (GEMM weight images, W_edge, M, bias: k_stage_params) are built once, before the timed region (ops.cached_staging: they
+    # are rebuilt whenever a parameter's address or version counter changes).  In a training step the re-layout belongs to the launch
+    # that writes the parameters; --stage-per-step restores the launch inside every step.
     def compute():
+        with (contextlib.nullcontext() if args.stage_per_step else ops.cached_staging()):
+            return compute_inner()
+
+    def compute_inner():
         out = conv(x, batch.edge_index, batch.edge_attr)
         grads = torch.autograd.grad(out, params + [x], grad_outputs=cot)   # loss = <out, cot>
         bucket = flat_view(grads[:-1])          # the fused layer hands its 5 parameter gradients back as one buffer
@@ -339,6 +382,8 @@ def main():
     # ---- several consecutive steps per graph launch: the same kernels, the same work per step, fewer launch bubbles.  Only when the
     #      whole step (collective included) is inside the graph; an eager all-reduce between steps keeps one step per launch ----
     S = max(1, args.steps_per_graph)
+    if args.steps < 2 * S:
+        S = max(1, args.steps)           # a short run (the driver's --steps 20) is ONE launch shape: a single graph of exactly `steps` steps
     graph_multi = None
     if graph is not None and S > 1 and (world == 1 or ar_in_graph):
         ok = 1
@@ -382,6 +427,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    leg("eager warm-up + hipGraph capture")
     run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -394,6 +440,7 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
+    leg("warm-up steps + timed steps")
 
     launch = "eager" if graph is None else ("hipGraph replay" + (f", {S} steps per graph launch" if graph_multi is not None else "") +
                                             (" (all-reduce captured in the graph)" if ar_in_graph else
@@ -436,22 +483,28 @@ def main():
                                   "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": k["frac_hbm_peak"], "frac_of_achievable_6290": k["frac_hbm_achievable"],
                                   "traffic": None, "algorithmic_bytes": k["algorithmic_bytes"], "avg_launch_us": k["avg_us"],
-                                  "grid": k["grid"], "workload": f"B={B}",
-                                  "traffic_note": "PMC traffic is not collectable inside an unprofiled run: see profiles/ (FETCH_SIZE / "
-                                                  "WRITE_SIZE passes of this command) and DESIGN.md §4"}
+                                  "grid": k["grid"], "workload": f"B={B}"}
+            tr, src = committed_traffic(dom, B)
+            result["roofline"]["traffic"] = tr
+            result["roofline"]["traffic_note"] = (f"bytes per launch from the committed PMC passes of this command ({src}: FETCH_SIZE x 2 + WRITE_SIZE, "
+                                                  "separate rocprofv3 --pmc runs); counters cannot be read inside an unprofiled run") if tr else \
+                "PMC traffic is not collectable inside an unprofiled run and no committed pass names this kernel: see profiles/ and DESIGN.md §4"
             # the scatter-aggregate forward is the kernel BASELINE.json's metric names; by time the largest launch of the step may be
             # another one (the backward-by-target kernel since it absorbed the d_aggr GEMM): name it and its own fraction
             big = next(iter(kernels))
             result["roofline"]["largest_launch_of_the_step"] = {
                 "kernel": big, "avg_launch_us": kernels[big]["avg_us"], "frac_hbm_peak": kernels[big].get("frac_hbm_peak"),
                 "frac_mfma_f32_peak": kernels[big].get("frac_mfma_f32_peak")}
+        leg("roofline_kernels (eager profiled steps)")
         result["roofline_kernels"] = {"source": f"glam_prof_* per-dispatch timestamps, {args.prof_reps} eager executions of the captured step function "
                                                 "after the timed region", "sum_kernel_us_per_step": step_kernel_us, "kernels": kernels}
         iso = time_isolated_aggregate(conv, batch, x.detach(), args.prof_reps)
         result["roofline_isolated"] = {n: dict(r, **rate(model[n], r["avg_us"])) for n, r in iso.items() if n in model}
+        leg("roofline_isolated")
         if args.large_batch and world == 1:
             big_cpu = synth_batch(args.large_batch, seed=7)
             big = big_cpu.to(dev)
+            leg("roofline_large: synthetic batch")
             Nb, Eb = big.x.size(0), big.edge_index.size(1)
             xb = torch.randn(Nb, C, device=dev).requires_grad_(True)
             cb = torch.randn(Nb, C, device=dev)
@@ -466,19 +519,26 @@ def main():
             rl = {"workload": f"B={args.large_batch} (N={Nb}, E={Eb}: every [N,180] tensor is {Nb * 720 / 2 ** 20:.0f} MiB, beyond the 256 MiB LLC)",
                   "step_kernels": {n: dict(r, **(rate(mb[n], r["avg_us"]) if n in mb else {})) for n, r in pb.items()},
                   "isolated": {n: dict(r, **rate(mb[n], r["avg_us"])) for n, r in ib.items() if n in mb}}
-            best = min((n for n in ("k_triplet_fwd", "k_triplet_fwd_pipe") if n in rl["isolated"]), key=lambda n: rl["isolated"][n]["avg_us"],
-                       default=None)
-            if best is not None:     # the forward scatter-aggregate kernel the ops layer selects at this size (ops._TripletAggregate)
-                ki = rl["isolated"][best]
-                rl.update(kernel=best + " (gather + segment softmax + scatter-add, no fused GEMM)", achieved=ki["achieved_GBs"],
+            # frac = the fused forward scatter-aggregate kernel THE STEP LAUNCHES at this size (its update GEMM included, as at B = 1024);
+            # the aggregate kernels on their own stay under "isolated"
+            domb = next((n for n in ("k_triplet_fwd_ws+update", "k_triplet_fwd_pipe+update", "k_triplet_fwd+update") if n in rl["step_kernels"]), None)
+            if domb is not None:
+                ki = rl["step_kernels"][domb]
+                rl.update(kernel=domb + " (gather + segment softmax + scatter-add + update GEMM: what the step launches)", achieved=ki["achieved_GBs"],
                           frac=ki["frac_hbm_peak"], frac_of_achievable_6290=ki["frac_hbm_achievable"], avg_launch_us=ki["avg_us"],
-                          algorithmic_bytes=ki["algorithmic_bytes"])
+                          algorithmic_bytes=ki["algorithmic_bytes"], bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s")
+                trb, srcb = committed_traffic(domb, args.large_batch)
+                rl["traffic"], rl["traffic_source"] = trb, srcb
+            rl["sum_kernel_us_per_step"] = sum(r["avg_us"] * r["launches_per_step"] for r in pb.values())
             result["roofline_large"] = rl
             del big, xb, cb
             live.pop("big", None)
+            leg("roofline_large")
         if args.cpu_seconds > 0 and world == 1:     # rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in the barrier
             result["cpu_baseline"] = cpu_baseline(batch_cpu, conv_cpu, x_cpu, cot_cpu, args.cpu_seconds)
             result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
+            leg("cpu_baseline")
+        result["wall_s"] = dict({k: round(v, 2) for k, v in legs.items()}, total=round(time.perf_counter() - _T_START, 2))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -468,7 +468,9 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
         if (int rc = ts_plan(*b, &vb, &grid_b)) return rc;
         if (vb != variant || b->N != a.N) return fail(GLAM_E_UNSUPPORTED, "ts_gemm pair: the two products must share N and the kernel variant");
     }
-    const size_t lds = ts_image_floats(a.K1 + a.K2, a.M1 + a.M2) * sizeof(float);
+    // each job stages ITS OWN image ((K + 15) / 16 groups): the allocation must hold the larger of the two
+    size_t lds = ts_image_floats(a.K1 + a.K2, a.M1 + a.M2) * sizeof(float);
+    if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);

@@ -46,7 +46,10 @@ __global__ void __launch_bounds__(kBlock) k_adam(AdamArgs a) {
     const int first = t ? a.chunk_end[t - 1] : 0;
     const int off = (b - first) * kAdamChunk + 4 * tid, numel = a.numel[t];
     float* p = a.p[t]; const float* g = a.g[t]; float* m = a.m[t]; float* v = a.v[t];
-    const float s = *a.step + 1.f;
+    // agent-scope atomic loads, as the RNG position is read (rng.h): the previous launch's last workgroup published the count with an
+    // agent-scope store and no fence, and a plain load may be served a line cached before that update — a stale count would give
+    // some workgroups the bias correction of step s - 1, and a stale ticket winner would store the old count again
+    const float s = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1.f;
     const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && off + 4 <= numel;
     float4 pv = f4zero(), gv = f4zero(), mv = f4zero(), vv = f4zero();
     if (vec) { pv = ld4(p + off); gv = ld4(g + off); mv = ld4(m + off); vv = ld4(v + off); }
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(kBlock) k_adam(AdamArgs a) {
         for (int i = 0; i < 4; ++i)
             if (off + i < numel) { pp[i] = p[off + i]; gp[i] = g[off + i]; mp[i] = m[off + i]; vp[i] = v[off + i]; }
     }
-    const double lr = a.lr_dev ? (double)*a.lr_dev : a.lr;
+    const double lr = a.lr_dev ? (double)__hip_atomic_load(a.lr_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.lr;
     // 1 - beta^s = -expm1(s ln beta): fp32 keeps 1e-7 relative accuracy at every s (1 - powf(beta, s) would lose four digits at s = 1),
     // and the double-precision pow / divide / sqrt of the direct form cost 0.8 us of a 6 us launch
     const float step_size = (float)lr / -expm1f(s * (float)log(a.beta1));

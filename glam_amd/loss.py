@@ -29,6 +29,10 @@ class _MeanLoss(torch.autograd.Function):
         require_device(pred, target)
         if pred.shape != target.shape:
             raise GlamHipError(f"loss: prediction {tuple(pred.shape)} and target {tuple(target.shape)} differ in shape")
+        # classification labels arrive as a LongTensor (src_1gp/dataset.py:139; the reference casts with .float() at the call site,
+        # trainer.py:244-245): cast here so that criterion(y_score, y_true) is the drop-in (the mask y >= 0 survives the cast)
+        if target.dtype != torch.float32:
+            target = target.to(torch.float32)
         p, t = f32c(pred, "prediction"), f32c(target, "target")
         lib, dev, n = _lib.load(), pred.device, pred.numel()
         out = torch.empty(2, dtype=torch.float32, device=dev)             # loss | 1 / count

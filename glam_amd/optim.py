@@ -124,6 +124,33 @@ class Adam(torch.optim.Optimizer):
                 raise GlamHipError(f"glam_adam_step failed (code {rc}): {lib.glam_last_error().decode()}")
         return loss
 
+    def state_dict(self):
+        """``torch.optim.Adam``'s layout with a PRIVATE ``step`` per parameter: internally every parameter of a group shares one device
+        counter, and a checkpoint that kept the sharing would, loaded into ``torch.optim.Adam`` (capturable / fused), be advanced once
+        per parameter per step by ``_foreach_add_``."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone()
+        return sd
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plans = {}                 # raw device addresses: never carried over by pickling / copying
+
+    def __deepcopy__(self, memo):
+        # the plans hold raw addresses of the ORIGINAL moment buffers: a copy rebuilds its own from its (deep-copied) state
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, {} if k == "_plans" else copy.deepcopy(v, memo))
+        for gi, group in enumerate(new.param_groups):
+            if any(p.requires_grad for p in group["params"]) and any("exp_avg" in new.state.get(p, {}) for p in group["params"]):
+                new._plan(gi, group)
+        return new
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # adopt the loaded per-parameter tensors into fresh flat buffers NOW: the base class does not copy tensors that already have the

@@ -246,3 +246,26 @@ def test_config4_two_process_data_parallel_step_on_the_hip_model(device):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DP-OK" in outs[0], outs[0]
+
+
+@pytest.mark.parametrize("extra", [[], ["--eager-allreduce"]])
+def test_bench_multi_rank_path_runs_as_a_fresh_subprocess(device, extra):
+    """``python bench.py --gpus 2`` as the driver would run it, on the box that is there: with fewer than two devices
+    GLAM_BENCH_SHARE_GPU=1 puts both ranks on device 0 over gloo (RCCL refuses two ranks on one device) — the spawn-before-GPU
+    structure, the rank environment, the per-rank graph capture, the flag exchange and the max-over-ranks timing are the same code.
+    The JSON line must say two ranks; every rank must exit 0."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["GLAM_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "32", "--warmup", "4", "--cpu-seconds", "0",
+           "--large-batch", "0", "--prof-reps", "2"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2" and r["config"]["global_batch"] == 2048
+    assert r["value"] > 0 and r["value"] == r["value"] and r["ms_per_step"] > 0
+    assert r["scaling"] == "weak" and r["config"]["collective"]
+    if extra:
+        assert "eager all-reduce" in r["config"]["launch"] or torch.cuda.device_count() < 2

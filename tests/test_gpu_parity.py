@@ -2246,3 +2246,117 @@ def test_loss_launch_matches_the_library_losses(device, n):
             loss.mse_loss(x0, y_reg[:-1])
         with pytest.raises(ops.GlamHipError):
             loss.mse_loss(x0.cpu(), y_reg.cpu())
+
+
+def test_cached_staging_reuses_the_images_until_a_parameter_is_written(device):
+    """``ops.cached_staging()``: the parameter re-layout launch (k_stage_params) runs once, not once per pass, gives the same output and
+    gradients bit for bit, and runs again as soon as a parameter's version counter moves."""
+    from glam_amd import _lib
+    b = synth_batch(40, seed=3).to(device)
+    torch.manual_seed(1)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device, requires_grad=True)
+
+    def run():
+        with _lib.kernel_timer(capacity=64) as kt:
+            out = conv(x, b.edge_index, b.edge_attr)
+            g = torch.autograd.grad(out.sum(), [x] + list(conv.parameters()))
+        return out, g, sum("k_stage_params" in n for n, _, _ in kt.records())
+
+    ref = run()
+    assert ref[2] == 1
+    with ops.cached_staging():
+        first, second = run(), run()
+        assert first[2] == 1 and second[2] == 0
+        for got in (first, second):
+            assert torch.equal(got[0], ref[0]) and all(torch.equal(a, c) for a, c in zip(got[1], ref[1]))
+        with torch.no_grad():
+            conv.weight_scale.mul_(0.5)          # an in-place write: the images are stale
+        third = run()
+        assert third[2] == 1 and not torch.equal(third[0], ref[0])
+        assert run()[2] == 0
+    fresh = run()                                 # outside the context: per-pass staging again, same numbers as the cached images gave
+    assert fresh[2] == 1 and torch.equal(fresh[0], third[0])
+
+
+def test_adam_device_step_count_equals_the_number_of_replays(device):
+    """The launch reads the device step count and learning rate with agent-scope atomic loads (a plain load could be served a line
+    cached before the previous launch's update: stale bias correction, a stalled counter): after one eager step and k replays of a
+    captured one the count is k + 1 and the parameters equal k + 1 eager steps bit for bit; ``state_dict()`` hands out a private
+    ``step`` per parameter; a deep copy of the optimizer owns its moments."""
+    import copy
+    from glam_amd import optim
+    torch.manual_seed(0)
+    shapes = (5, 1024, 4099, 70000)
+    init = [torch.randn(n, device=device) for n in shapes]
+    grads = [torch.randn(n, device=device) for n in shapes]
+
+    def make():
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        for p, g in zip(ps, grads):
+            p.grad = g.clone()
+        return ps, optim.Adam(ps, lr=1e-2)
+
+    K = 37
+    ps_e, opt_e = make()
+    for _ in range(K + 1):
+        opt_e.step()
+    ps_g, opt_g = make()
+    opt_g.step()                                   # builds the plan eagerly (allocations, address table)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        opt_g.step()
+    for _ in range(K):
+        gr.replay()
+    torch.cuda.synchronize()
+    assert float(opt_g.state[ps_g[0]]["step"]) == K + 1 == float(opt_e.state[ps_e[0]]["step"])
+    for a, b in zip(ps_e, ps_g):
+        assert torch.equal(a, b)
+    sd = opt_g.state_dict()
+    steps = [st["step"] for st in sd["state"].values()]
+    assert len({t.data_ptr() for t in steps}) == len(steps) and all(float(t) == K + 1 for t in steps)
+    twin = copy.deepcopy(opt_g)
+    m0 = opt_g.state[ps_g[1]]["exp_avg"].clone()
+    twin.step()                                    # must write the COPY's moments and parameters, not the original's
+    torch.cuda.synchronize()
+    assert torch.equal(opt_g.state[ps_g[1]]["exp_avg"], m0) and torch.equal(ps_g[1], ps_e[1])
+
+
+def test_loss_accepts_integer_labels_like_the_reference_call_site(device):
+    """``criterion(y_score, y_true)`` with the LongTensor labels of src_1gp/dataset.py:139 (the reference writes ``.float()`` at the call
+    site, trainer.py:244-245): the masked BCE casts inside and equals the float call."""
+    from glam_amd import loss
+    g = torch.Generator().manual_seed(3)
+    score = torch.randn(64, 12, generator=g).to(device).requires_grad_(True)
+    y = torch.randint(-1, 2, (64, 12), generator=g).to(device)
+    crit = loss.get_loss("bcel_masked")
+    a = crit(score, y)
+    b = crit(score, y.float())
+    assert torch.equal(a, b)
+    (ga,), (gb,) = torch.autograd.grad(a, [score]), torch.autograd.grad(b, [score])
+    assert torch.equal(ga, gb)
+
+
+def test_ts_gemm_pair_with_different_depths_sizes_its_image_for_the_larger(device):
+    """Two products of one kernel variant but different K in one launch (glam_ts_gemm_pair): the LDS allocation must hold the larger
+    image (it was sized from the first job only)."""
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(8)
+    N, M = 500, 180
+    outs, refs, args = [], [], []
+    for K in (16, 60):
+        A = torch.randn(N, K, generator=g).to(device)
+        W = (torch.randn(K, M, generator=g) / K ** 0.5).to(device)
+        img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, device=device)
+        assert lib.glam_ts_gemm_make_image(p(W), M, 0, K, M, p(img), _lib.stream()) == 0
+        out = torch.empty(N, M, device=device)
+        outs.append(out); refs.append((A.double() @ W.double()).float()); args.append((A, K, img, out))
+    (Aa, Ka, ia, oa), (Ab, Kb, ib, ob) = args
+    rc = lib.glam_ts_gemm_pair(p(Aa), Ka, Ka, 0, p(ia), None, p(oa), M, M, None, 0, None, 0,
+                               p(Ab), Kb, Kb, 0, p(ib), None, p(ob), M, M, None, 0, None, 0, N, _lib.stream())
+    assert rc == 0, lib.glam_last_error()
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert_close(o, r, 1e-5, "ts_gemm pair, K = 16 | 60")
