@@ -76,6 +76,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "d_aggr+k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
                                      "note": "backward by target with the d_aggr GEMM fused in (one launch and one kernel boundary less)"},
         "k_triplet_bwd_src+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C},
+        "d_aggr+k_triplet_bwd_dst_ws": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
+                                        "note": "warp-specialised backward by target: matrix waves produce the d_aggr tiles ahead of the vector waves "
+                                                "(csrc/triplet_ws_b1.hip)"},
         "k_triplet_bwd_src_ws+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C,
                                     "note": "warp-specialised backward by source with the d_x GEMM as the consumers' product (csrc/triplet_ws.hip)"},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},

@@ -118,7 +118,9 @@ Tensor triplet_aggregate(const Tensor& xw, const Tensor& a_ij, const Tensor& edg
 struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
     static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& edge_attr, const Tensor& wn, const Tensor& we, const Tensor& att,
                           const Tensor& wsc, const Tensor& bias, const Tensor& rowptr, const Tensor& src, const Tensor& eid,
-                          const Tensor& colptr, const Tensor& dst, const Tensor& eid_t, int64_t H, double slope) {
+                          const Tensor& colptr, const Tensor& dst, const Tensor& eid_t, int64_t H, double slope,
+                          const c10::optional<Tensor>& ell_src, const c10::optional<Tensor>& ell_eid, const c10::optional<Tensor>& ell_dst,
+                          const c10::optional<Tensor>& ell_eid_t, bool edge_onehot) {
         want(x, at::kFloat, "x"); want(edge_attr, at::kFloat, "edge_attr"); want(wn, at::kFloat, "weight_node");
         want(we, at::kFloat, "weight_edge"); want(att, at::kFloat, "weight_triplet_att"); want(wsc, at::kFloat, "weight_scale");
         want(bias, at::kFloat, "bias"); want(rowptr, at::kInt, "rowptr"); want(src, at::kInt, "src"); want(eid, at::kInt, "eid");
@@ -133,9 +135,23 @@ struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
                  "glam_triplet_stage_params");
         Tensor xw = at::empty({N, HC}, x.options()), a_ij = at::empty({N, 8}, x.options()), aggr = at::empty({N, HC}, x.options()),
                stats = at::empty({N, 8}, x.options()), out = at::empty({N, Cp}, x.options());
-        check_rc(glam_triplet_layer_fwd(fp(x), fp(edge_attr), fp(staged), ip(rowptr), ip(src), ip(eid), nullptr, 0, N, E, (int)H, Cp, Dp,
-                                        (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()), "glam_triplet_layer_fwd");
-        ctx->save_for_backward({x, edge_attr, wn, we, att, staged, xw, a_ij, aggr, stats, rowptr, src, eid, colptr, dst, eid_t});
+        // molecular graphs (ELL index records, one-hot bond features): the warp-specialised kernels, as the Python autograd node takes them
+        const bool ell_f = ell_src.has_value() && ell_src->defined() && ell_eid.has_value() && ell_eid->defined() && N > 0 &&
+                           glam_triplet_layer_ws_supported((int)H, Cp, Dp, edge_onehot ? 1 : 0);
+        if (ell_f) {
+            want(*ell_src, at::kInt, "ell_src"); want(*ell_eid, at::kInt, "ell_eid");
+            TORCH_CHECK(ell_src->numel() == 4 * N && ell_eid->numel() == 4 * N, "triplet_layer: ELL records are int32 [N, 4]");
+            check_rc(glam_triplet_layer_fwd_ell(fp(x), fp(edge_attr), fp(staged), ip(*ell_src), ip(*ell_eid), edge_onehot ? 1 : 0, N, E, (int)H, Cp,
+                                                Dp, (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()),
+                     "glam_triplet_layer_fwd_ell");
+        } else {
+            check_rc(glam_triplet_layer_fwd(fp(x), fp(edge_attr), fp(staged), ip(rowptr), ip(src), ip(eid), nullptr, 0, N, E, (int)H, Cp, Dp,
+                                            (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()), "glam_triplet_layer_fwd");
+        }
+        const bool ell_b = ell_dst.has_value() && ell_dst->defined() && ell_eid_t.has_value() && ell_eid_t->defined();
+        ctx->save_for_backward({x, edge_attr, wn, we, att, staged, xw, a_ij, aggr, stats, rowptr, src, eid, colptr, dst, eid_t,
+                                ell_f ? *ell_src : Tensor(), ell_f ? *ell_eid : Tensor(), ell_b ? *ell_dst : Tensor(), ell_b ? *ell_eid_t : Tensor()});
+        ctx->saved_data["onehot"] = edge_onehot;
         ctx->saved_data["H"] = H;
         ctx->saved_data["slope"] = slope;
         return out;
@@ -159,19 +175,34 @@ struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
                d_bias = flat.narrow(0, n_wn + n_we + n_att + n_ws, C);
         Tensor d_ea = ctx->needs_input_grad(1) ? at::zeros_like(edge_attr) : Tensor();
         Tensor ws = at::empty({(int64_t)glam_triplet_layer_bwd_workspace_bytes(N, E, (int)H, Cp, Dp)}, x.options().dtype(at::kByte));
-        check_rc(glam_triplet_layer_bwd_params(fp(x), fp(edge_attr), fp(staged), fp(xw), fp(a_ij), fp(aggr), fp(stats), fp(d_out), ip(rowptr),
-                                               ip(src), ip(eid), ip(colptr), ip(dst), ip(eid_t), N, E, C, (int)H, De, Cp, Dp, (float)slope, fp(wn),
-                                               fp(we), fp(att), fpm(d_x), fpm(d_wn), fpm(d_we), fpm(d_att), fpm(d_wsc), fpm(d_bias),
-                                               fpm(d_ea),
-                                               ws.data_ptr(), (size_t)ws.numel(), cur_stream()), "glam_triplet_layer_bwd_params");
-        return {d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        const Tensor &ls = s[16], &le = s[17], &ld = s[18], &lt = s[19];
+        const bool onehot = ctx->saved_data["onehot"].toBool();
+        if (ld.defined() && lt.defined() && !d_ea.defined() && N > 0) {
+            want(ld, at::kInt, "ell_dst"); want(lt, at::kInt, "ell_eid_t");
+            check_rc(glam_triplet_layer_bwd_params_ell(fp(x), fp(edge_attr), fp(staged), fp(xw), fp(a_ij), fp(aggr), fp(stats), fp(d_out),
+                                                       ip(rowptr), ip(src), ip(eid), ip(colptr), ip(dst), ip(eid_t), N, E, C, (int)H, De, Cp, Dp,
+                                                       (float)slope, fp(wn), fp(we), fp(att), fpm(d_x), fpm(d_wn), fpm(d_we), fpm(d_att),
+                                                       fpm(d_wsc), fpm(d_bias), nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                       ls.defined() ? ip(ls) : nullptr, le.defined() ? ip(le) : nullptr, ip(ld), ip(lt),
+                                                       onehot ? 1 : 0, nullptr, ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+                     "glam_triplet_layer_bwd_params_ell");
+        } else {
+            check_rc(glam_triplet_layer_bwd_params(fp(x), fp(edge_attr), fp(staged), fp(xw), fp(a_ij), fp(aggr), fp(stats), fp(d_out), ip(rowptr),
+                                                   ip(src), ip(eid), ip(colptr), ip(dst), ip(eid_t), N, E, C, (int)H, De, Cp, Dp, (float)slope,
+                                                   fp(wn), fp(we), fp(att), fpm(d_x), fpm(d_wn), fpm(d_we), fpm(d_att), fpm(d_wsc), fpm(d_bias),
+                                                   fpm(d_ea), ws.data_ptr(), (size_t)ws.numel(), cur_stream()), "glam_triplet_layer_bwd_params");
+        }
+        return {d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor triplet_layer(const Tensor& x, const Tensor& edge_attr, const Tensor& wn, const Tensor& we, const Tensor& att, const Tensor& wsc,
                      const Tensor& bias, const Tensor& rowptr, const Tensor& src, const Tensor& eid, const Tensor& colptr, const Tensor& dst,
-                     const Tensor& eid_t, int64_t H, double slope) {
-    return TripletLayerFn::apply(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, colptr, dst, eid_t, H, slope);
+                     const Tensor& eid_t, int64_t H, double slope, const c10::optional<Tensor>& ell_src, const c10::optional<Tensor>& ell_eid,
+                     const c10::optional<Tensor>& ell_dst, const c10::optional<Tensor>& ell_eid_t, bool edge_onehot) {
+    return TripletLayerFn::apply(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, colptr, dst, eid_t, H, slope, ell_src, ell_eid, ell_dst,
+                                 ell_eid_t, edge_onehot);
 }
 
 // ---- readouts ------------------------------------------------------------------------------------------------------------------
@@ -258,7 +289,8 @@ TORCH_LIBRARY(glam, m) {
     m.def("triplet_aggregate(Tensor xw, Tensor a_ij, Tensor edge_attr, Tensor? w_edge, Tensor M, Tensor rowptr, Tensor src, Tensor eid, "
           "Tensor colptr, Tensor dst, Tensor eid_t, int heads, float slope=0.2) -> Tensor", &triplet_aggregate);
     m.def("triplet_layer(Tensor x, Tensor edge_attr, Tensor weight_node, Tensor weight_edge, Tensor weight_triplet_att, Tensor weight_scale, "
-          "Tensor bias, Tensor rowptr, Tensor src, Tensor eid, Tensor colptr, Tensor dst, Tensor eid_t, int heads, float slope=0.2) -> Tensor",
+          "Tensor bias, Tensor rowptr, Tensor src, Tensor eid, Tensor colptr, Tensor dst, Tensor eid_t, int heads, float slope=0.2, "
+          "Tensor? ell_src=None, Tensor? ell_eid=None, Tensor? ell_dst=None, Tensor? ell_eid_t=None, bool edge_onehot=False) -> Tensor",
           &triplet_layer);
     m.def("segment_pool(Tensor x, Tensor ptr, int mode) -> Tensor", &segment_pool);
     m.def("segment_softmax_aggregate(Tensor gate, Tensor v, Tensor ptr) -> Tensor", &segment_softmax_aggregate);

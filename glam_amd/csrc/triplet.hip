@@ -126,7 +126,8 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1, const float* img_dagg,
-                     const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot) {
+                     const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot, const int32_t* ell_src,
+                     const int32_t* ell_eid) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
@@ -150,17 +151,25 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     // d_aggr = d_out @ W_scale^T computed tile by tile inside B1 (d_aggr is then written, not read)
     const bool fuse_dagg = img_dagg && d_out && triplet_bwd_can_fuse_dagg(H, Cp, De) && emul;
     if ((img_dagg || d_out) && !fuse_dagg) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_aggr variant for H=%d Cp=%d", H, Cp);
+    int nblk = 0;
+    // molecular graphs with one-hot bond features: the warp-specialised B1 (matrix waves produce the d_aggr tiles ahead of the vector waves)
+    const bool b1_ws = ell_src && ell_eid && fuse_dagg && !d_edge_attr && !xw_bf16 && triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot);
+    if (b1_ws) {
+        if (int rc = triplet_bwd_dst_ws(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, N, E, H, Cp, De,
+                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s))
+            return rc;
+    } else {
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
                   alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16,
                   fuse_dagg ? img_dagg : nullptr, fuse_dagg ? d_out : nullptr, fuse_dagg ? const_cast<float*>(d_aggr) : nullptr};
     const size_t red_floats = (size_t)red_groups * P;
     const size_t img_floats = (size_t)((Cp + 15) & ~15) * (H * Cp <= 64 ? 64 : 192) + 16 * (size_t)(H * Cp + 4) + 16 * 64;   // image, d_aggr tile, A tile
     const size_t lds1 = ((size_t)WSZ + (fuse_dagg && img_floats > red_floats ? img_floats : red_floats)) * sizeof(float);
-    int nblk = 0;
     GLAM_PROF_LABEL(fuse_dagg ? "d_aggr+k_triplet_bwd_dst" : "k_triplet_bwd_dst");
     if (!dispatch(kTripletBwdDst, H, De, emul, sh, b1, (int)N, lds1, s, kBwdBlocks, &nblk))
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
+    }
     if (after_b1) (void)hipEventRecord(after_b1, s);      // the B1 block partials are complete: a side stream may reduce them
     if (reduce_now) {
         hipLaunchKernelGGL(k_reduce_partials, dim3((P + 15) / 16), dim3(kBlock), 0, s, partial, nblk, P, WSZ, d_w_edge, d_M);
@@ -215,7 +224,7 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 // B2 alone over ELL records by source (tests, isolated timing): d_xw[N, H*Cp], d_a_ij[N, 8] (the a_j half, columns 4..7, is written)

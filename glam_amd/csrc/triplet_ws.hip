@@ -32,38 +32,12 @@
 
 namespace glam {
 
-constexpr int kWsCons = 4;                // consumer waves: one 16-column tile of `out` each
-#ifndef GLAM_WS_RING
-#define GLAM_WS_RING 8
-#endif
-constexpr int kWsRing = GLAM_WS_RING;     // tile slots between producers and consumers
-
 #ifdef GLAM_WS_PROF   // developer aid (tools/ws_prof.py): where the producer / consumer waves spend their cycles
 __device__ long long g_ws_prof[64 * 12 * 8];
 #define WSTAMP(k) do { const long long now__ = clock64(); pacc[k] += now__ - plast; plast = now__; } while (0)
 #else
 #define WSTAMP(k) do { } while (0)
 #endif
-
-// lane n of the caller's 16-lane row (the lanes of one node) -> every lane of the row: one v_mov_b32_dpp row_newbcast (no LDS)
-template <int CTRL>
-__device__ __forceinline__ int dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_int<CTRL>(__builtin_bit_cast(int, v))); }
-__device__ __forceinline__ int row_bcast_i(int v, int n) {
-    switch (n & 15) {   // n is a compile-time constant after unrolling: the switch folds
-        case 0: return dpp_int<0x150>(v);   case 1: return dpp_int<0x151>(v);   case 2: return dpp_int<0x152>(v);   case 3: return dpp_int<0x153>(v);
-        case 4: return dpp_int<0x154>(v);   case 5: return dpp_int<0x155>(v);   case 6: return dpp_int<0x156>(v);   case 7: return dpp_int<0x157>(v);
-        case 8: return dpp_int<0x158>(v);   case 9: return dpp_int<0x159>(v);   case 10: return dpp_int<0x15A>(v);  case 11: return dpp_int<0x15B>(v);
-        case 12: return dpp_int<0x15C>(v);  case 13: return dpp_int<0x15D>(v);  case 14: return dpp_int<0x15E>(v);  default: return dpp_int<0x15F>(v);
-    }
-}
-__device__ __forceinline__ float row_bcast(float v, int n) { return __builtin_bit_cast(float, row_bcast_i(__builtin_bit_cast(int, v), n)); }
-
-__device__ __forceinline__ int flag_load(const int* p) {
-    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-__device__ __forceinline__ void flag_bump(int* p) { (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 #ifdef GLAM_WS_PROF
 #define WS_PROF_PARAMS , long long* pacc, long long& plast

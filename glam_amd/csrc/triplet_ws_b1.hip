@@ -1,0 +1,416 @@
+// Warp-specialised backward by target (B1) of the TripletMessage layer for molecular graphs (ELL index records by target, one-hot bond
+// features of width 4), with d_aggr = d_out @ W_scale^T produced inside the launch.  The roles of k_triplet_fwd_ws (triplet_ws.hip) are
+// mirrored:
+//     matrix waves V..V+3   produce the 16-node d_aggr tiles on the fp32 matrix cores, AHEAD of their use: wave w owns column tiles
+//                           3 w .. 3 w + 2 (16 columns each), keeps that 64 x 48 slice of W_scale^T in 48 registers for the whole
+//                           launch, reads the d_out rows of a tile as plain (prefetched) loads and writes the tile into an LDS ring slot
+//     vector waves 0..V-1   consume the tiles: per pass of 4 nodes read the rows of d_aggr from the slot (and write them to HBM for B2),
+//                           gather the neighbours' xw rows (prefetched into registers right after the previous pass's last use of
+//                           them), recompute alpha, d_alpha = <d_aggr[dst], e_ij * xw[src]>, softmax + leaky backward -> dpre; store
+//                           alpha_e / dpre_e per edge and d_a_i per node; accumulate d_W_edge / d_M
+// (general kernel: k_triplet_bwd_dst<..., FD = true>; reference: the autograd of src_1gp/layer.py:42-55).
+// Per-edge scalar work runs in the QUAD lane layout (lane 16 j + 4 h + k = node j, head h, slot k computes its (edge, head) once) on
+// operands each lane loads ITSELF one pass ahead (plain 4-byte gathers: no side table, no LDS-DMA, every wait counted by the compiler);
+// the channel work (d_aggr * xw chunks, the 60-channel dots) runs in the row layout (16 lanes per node).
+// d_W_edge accumulates in LDS, one private array [4 bond types][H*Cp] per (vector wave, node row of the pass), by plain
+// read - fma - write of the row of the edge's bond type (LDS executes a wave's operations in order, so two slots of one node with the
+// same type chain correctly) instead of 48 registers per lane — which is what kept the general kernel at one pass in flight and 256
+// registers.  (ds_add_f32 into one array per wave was tried first: 54 vs 21 us at B = 1 024 — the LDS retires float atomics a lane
+// at a time.)  d_M in four registers per lane.
+// alpha_e, dpre_e, d_a_i and d_aggr are bit-identical to the general kernel (same operations, same order); the d_W_edge / d_M block
+// partials are sums in a different (still fixed) order.
+#include "triplet_pipe.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace glam {
+
+struct DstWsArgs {
+    const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
+    const float* aggr; const float* stats; const float* d_out; const float* img_dagg;
+    const int* ell_src; const int* ell_eid;      // [N][4] each, by target
+    int N; int Cp; float slope;
+    float* d_aggr; float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;      // partial[gridDim.x][4 * H * Cp + 16]
+};
+
+template <int H, int V>
+__global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_ws(DstWsArgs a) {
+    constexpr int kBlockT = (V + 4) * 64, VG = V / 4, CH = 4;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
+    const int WSZ = 4 * HC, LDT = HC + 4, P = WSZ + 16;
+    constexpr int kRing = 4;                                  // tile slots (the d_W_edge arrays take the rest of the LDS)
+    float* s_w = smem;
+    int* s_ready = reinterpret_cast<int*>(smem + WSZ);        // [kRing] matrix-wave check-ins per slot
+    float* s_mt = reinterpret_cast<float*>(s_ready + 16);     // M transposed: [head][edge feature]
+    int* s_taken = s_ready + 32;                              // [kRing] vector-wave check-outs per slot
+    float* s_dw = smem + WSZ + 64;                            // per (vector wave, node row): d_W_edge [4][HC]
+    float* s_ring = s_dw + V * 4 * WSZ;                       // kRing tiles of 16 x LDT floats
+    for (int i = tid; i < WSZ / 4; i += kBlockT) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+    for (int i = tid; i < V * 4 * WSZ; i += kBlockT) s_dw[i] = 0.f;
+    if (tid < 64) {
+        if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
+        else s_ready[tid] = 0;
+    }
+    __syncthreads();
+    const int ntiles = (a.N + 15) >> 4;
+
+    if (wave >= V) {
+        // ------------------------------------------------------------------------------------------------------------------
+        // matrix waves: d_aggr tile[16, HC] = d_out[16 tile .. +15, Cp] @ W_scale^T, columns 48 w .. 48 w + 47 in this wave
+        // ------------------------------------------------------------------------------------------------------------------
+        const int w = wave - V, c = lane & 15, kq = lane >> 4;
+        const int GK = (Cp + 15) >> 4, MP = HC <= 64 ? 64 : 192;       // k groups (<= 4), positions per image row
+        float4 bf[3][4];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            const int mcol = 16 * (3 * w + ct) + c;
+            const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bf[ct][g] = (g < GK && mcol < HC) ? ld4(a.img_dagg + ((size_t)(4 * g + kq) * MP + pos) * 4) : f4zero();
+        }
+        auto load_a = [&](int tile, float4 (&af)[4]) {
+            const int row = 16 * tile + c;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = 4 * g + kq;                    // 16-byte chunk of the row
+                af[g] = (tile < ntiles && row < a.N && 4 * ch < Cp) ? ld4(a.d_out + (size_t)row * Cp + 4 * ch) : f4zero();
+            }
+        };
+        float4 af_a[4], af_b[4];
+        int tile = blockIdx.x, it = 0;
+        load_a(tile, af_a);
+        auto one_tile = [&](int it_, const float4 (&af)[4]) {
+            const int slot = it_ % kRing;
+            if (it_ >= kRing) {                             // the vector waves must have taken the slot's previous tile
+                const int want = 4 * (it_ / kRing);
+                while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            v4f acc[3];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) acc[ct] = (v4f){0.f, 0.f, 0.f, 0.f};
+            // k group outer, column tile inner: three independent accumulator chains
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < GK) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct)
+                            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[ct][g], jj), acc[ct], 0, 0, 0);
+                }
+            }
+            float* tl = s_ring + slot * 16 * LDT;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int mcol = 16 * (3 * w + ct) + c;
+                if (mcol < HC) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tl[(4 * kq + i) * LDT + mcol] = acc[ct][i];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) flag_bump(s_ready + slot);
+        };
+        for (; tile < ntiles; tile += 2 * gridDim.x, it += 2) {
+            load_a(tile + gridDim.x, af_b);                   // next tile's rows in flight under this tile's MFMAs
+            one_tile(it, af_a);
+            if (tile + (int)gridDim.x < ntiles) {
+                load_a(tile + 2 * gridDim.x, af_a);
+                one_tile(it + 1, af_b);
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------------------------
+        // vector waves
+        // ------------------------------------------------------------------------------------------------------------------
+        float* wave_dw = s_dw + wave * 4 * WSZ;
+        const int npass = (a.N + 3) >> 2;
+        const int grp = wave >> 2, rw = wave & 3;
+        const int gw = 4 * (blockIdx.x + grp * gridDim.x) + rw, GW = 4 * VG * gridDim.x;
+        const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;
+        int lv = lane;
+#define LANE_CONSTS()                                                                        \
+        asm volatile("" : "+v"(lv));                                                         \
+        const int j = lv >> 4, q = lv & 15;                                                  \
+        const bool qok = q < Q;                                                              \
+        const unsigned qoff = (unsigned)(qok ? q : 0) * 16u;                                 \
+        const int hh = (lv >> 2) & 3, kk = lv & 3, hc = hh < H ? hh : H - 1
+
+        // record in the QUAD layout: lane (j, hh, kk) holds slot kk of node j (every quad of a row loads the same four words)
+        auto load_rec = [&](int pass, int& rs, int& re) {
+            LANE_CONSTS(); (void)qok; (void)qoff; (void)q; (void)hc; (void)hh;
+            const int n = 4 * pass + j;
+            rs = -1; re = -1;
+            if (pass < npass && n < a.N) { rs = a.ell_src[4 * n + kk]; re = a.ell_eid[4 * n + kk]; }
+        };
+        // per-edge / per-node scalars of the lane's (edge, head), loaded by the lane itself one pass ahead
+        struct Scal { float aj, ai, m, s; float4 ea; };
+        float4 rows[CH][H], agr[H];
+        Scal sc;
+        sc.aj = sc.ai = sc.m = sc.s = 0.f; sc.ea = f4zero();
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int h = 0; h < H; ++h) rows[k][h] = f4zero();
+#pragma unroll
+        for (int h = 0; h < H; ++h) agr[h] = f4zero();
+        auto ldf = [](const float* base, unsigned byte_off) {      // scalar-base + 32-bit offset addressing (see ld4o)
+            return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+        };
+        auto prefetch = [&](int pass, int rs, int re) {
+            LANE_CONSTS(); (void)kk; (void)hh;
+            if (pass >= npass) return;
+            const unsigned n = (unsigned)min(4 * pass + j, a.N - 1);
+            const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;        // the hh = 0 quads carry the degree
+            const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
+                      d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
+            const int dmax = max(max(d0, d1), max(d2, d3));
+            const int src0 = row_bcast_i(rs, 0), eid0 = row_bcast_i(re, 0);
+            // an empty slot aliases the node's first edge (finite data, weight 0); a node without edges reads nothing (E may be 0)
+            sc.aj = 0.f; sc.ea = f4zero();
+            if (src0 >= 0) {
+                sc.aj = ldf(a.a_ij, (unsigned)(rs >= 0 ? rs : src0) * 32u + 16u + 4u * (unsigned)hc);
+                sc.ea = ld4o(a.edge_attr, (unsigned)(re >= 0 ? re : eid0) * 16u);
+            }
+            sc.ai = ldf(a.a_ij, n * 32u + 4u * (unsigned)hc);
+            sc.m = ldf(a.stats, n * 32u + 4u * (unsigned)hc);
+            sc.s = ldf(a.stats, n * 32u + 16u + 4u * (unsigned)hc);
+#pragma unroll
+            for (int h = 0; h < H; ++h) agr[h] = ld4o(a.aggr, n * row_bytes + (unsigned)h * head_bytes + qoff);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (k < dmax) {
+                    const int sk = row_bcast_i(rs, k);
+                    const unsigned ro = (unsigned)max(sk >= 0 ? sk : src0, 0) * row_bytes + qoff;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) rows[k][h] = ld4o(a.xw, ro + (unsigned)h * head_bytes);
+                }
+            }
+        };
+
+        float dMq[4] = {0.f, 0.f, 0.f, 0.f};                  // d_M[bond type][head hh of this lane]
+        // what the first half of a pass hands to the second (across the prefetch of the next pass)
+        float h_pre = 0.f, h_alpha = 0.f, h_dal = 0.f, h_dot = 0.f;
+        int h_t = 0;
+        // first half: phases that need the gathered rows
+        auto compute_a = [&](auto dm_tag, int pass, int it_, int rs) {
+            constexpr int DM = decltype(dm_tag)::value;
+            LANE_CONSTS(); (void)qoff;
+            const int n = 4 * pass + j;
+            const bool node_ok = pass < npass && n < a.N;
+            const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;
+            const int deg = __popcll((bal >> (16 * j)) & 0xFull);
+            // ---- quad phase 1: logit, alpha, bond type of this lane's (edge, head) ----
+            const float4 mc = ld4(s_mt + hc * 4);
+            float ee = 0.f;
+            ee = fmaf(sc.ea.x, mc.x, ee); ee = fmaf(sc.ea.y, mc.y, ee); ee = fmaf(sc.ea.z, mc.z, ee); ee = fmaf(sc.ea.w, mc.w, ee);
+            const float pre = sc.ai + ee + sc.aj;
+            const float inv = 1.f / (sc.s + 1e-16f);
+            const float alpha = softmax_exp(leaky(pre, a.slope) - sc.m) * inv;
+            int t = 0;
+            t = sc.ea.y != 0.f ? 1 : t; t = sc.ea.z != 0.f ? 2 : t; t = sc.ea.w != 0.f ? 3 : t;
+            h_pre = pre; h_alpha = alpha; h_t = t;
+            // ---- the node's d_aggr row out of the ring; on to HBM for B2 ----
+            const int slot = it_ % kRing;
+            {
+                const int want = 4 * (it_ / kRing + 1);
+                while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            float4 dag[H];
+            {
+                const float* tl = s_ring + slot * 16 * LDT + (rw * 4 + j) * LDT + (qok ? q : 0) * 4;
+#pragma unroll
+                for (int h = 0; h < H; ++h) dag[h] = ld4(tl + h * Cp);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lv == 0) flag_bump(s_taken + slot);
+            if (!qok) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) dag[h] = f4zero();
+            }
+            float dotq = 0.f, dalq = 0.f;
+            if (node_ok) {
+                if (qok) {
+                    const unsigned orow = (unsigned)n * row_bytes + (unsigned)q * 16u;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) st4o(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>
+                    float part = 0.f;
+                    part += dot4(dag[h], agr[h]);
+                    const float d = group_sum<16>(part);
+                    dotq = hc == h ? d : dotq;
+                }
+                // ---- row phase: d_alpha[k][h] = <d_aggr[n,h,:], e_ij * xw[src_k,h,:]>, d_W_edge[type_k][h] += alpha * d_aggr * xw ----
+                if (deg > 0) {
+                    int tk[DM];
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * HC + (qok ? q : 0) * 4;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        float4 er[DM];
+#pragma unroll
+                        for (int k = 0; k < DM; ++k) er[k] = ld4(s_w + tk[k] + h * Cp);
+#pragma unroll
+                        for (int k = 0; k < DM; ++k) {
+                            const float4 tv = dag[h] * rows[k][h];                   // d_aggr * x_j
+                            float part = 0.f;
+                            part += dot4(tv, er[k]);
+                            const float dal = group_sum<16>(part);
+                            dalq = (hc == h && kk == k) ? dal : dalq;
+                            const float al = row_bcast(alpha, 4 * h + k);
+                            if (k < deg && qok) {             // d_W_edge[type_k][h] += alpha * (d_aggr * x_j): this node row's private array
+                                float* d = wave_dw + j * WSZ + tk[k] + h * Cp;
+                                float4 acc = ld4(d);
+                                fma4(acc, al, tv);
+                                st4(d, acc);
+                            }
+                        }
+                    }
+                }
+            }
+            h_dot = dotq; h_dal = dalq;
+        };
+        auto compute_a_any = [&](int pass, int it_, int rs) {
+            const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;
+            const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
+                      d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
+            const int dmax = max(max(d0, d1), max(d2, d3));
+            if (dmax <= 1) compute_a(std::integral_constant<int, 1>{}, pass, it_, rs);
+            else if (dmax == 2) compute_a(std::integral_constant<int, 2>{}, pass, it_, rs);
+            else if (dmax == 3) compute_a(std::integral_constant<int, 3>{}, pass, it_, rs);
+            else compute_a(std::integral_constant<int, 4>{}, pass, it_, rs);
+        };
+        // second half: softmax + leaky backward in the quad layout, the per-edge / per-node stores
+        auto compute_b = [&](int pass, int rs, int re) {
+            LANE_CONSTS(); (void)qok; (void)qoff; (void)hc;
+            const int n = 4 * pass + j;
+            const bool node_ok = pass < npass && n < a.N;
+            const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;
+            const int deg = __popcll((bal >> (16 * j)) & 0xFull);
+            const bool valid = node_ok && kk < deg;
+            const bool live = valid && hh < H;
+            const float dl = h_alpha * (h_dal - h_dot);
+            float dp = h_pre > 0.f ? dl : dl * a.slope;
+            dp = live ? dp : 0.f;
+            const float al_st = live ? h_alpha : 0.f;
+            // d_a_i[n, hh] = ((dp_0 + dp_1) + dp_2) + dp_3 (an empty slot adds an exact zero)
+            const float dai = ((dpp_f<0x00>(dp) + dpp_f<0x55>(dp)) + dpp_f<0xAA>(dp)) + dpp_f<0xFF>(dp);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) dMq[tt] += (h_t == tt) ? dp : 0.f;
+            // lanes q < 4 (hh = 0) gather the four heads of their edge: row_shl by 4 h brings lane 4 h + kk to lane kk
+            float4 av, dv, da;
+            av.x = al_st; av.y = dpp_f<0x104>(al_st); av.z = dpp_f<0x108>(al_st); av.w = dpp_f<0x10C>(al_st);
+            dv.x = dp; dv.y = dpp_f<0x104>(dp); dv.z = dpp_f<0x108>(dp); dv.w = dpp_f<0x10C>(dp);
+            da.x = dai; da.y = dpp_f<0x104>(dai); da.z = dpp_f<0x108>(dai); da.w = dpp_f<0x10C>(dai);
+            if (q < 4 && valid) {
+                st4o(a.alpha_e, (unsigned)re * 16u, av);
+                st4o(a.dpre_e, (unsigned)re * 16u, dv);
+            }
+            if (q == 0 && node_ok) st4o(a.d_a_ij, (unsigned)n * 32u, da);
+        };
+
+        int rs, re, rs_n, re_n;
+        int pass = gw;
+        load_rec(pass, rs, re);
+        prefetch(pass, rs, re);
+        load_rec(pass + GW, rs_n, re_n);
+        const int pass_end = ntiles << 2;
+        int it = grp;
+        for (; pass - rw < pass_end; pass += GW, it += VG) {
+            compute_a_any(pass, it, rs);
+            __builtin_amdgcn_sched_barrier(0);                // the rows' registers are free from here on: everything of pass p + 1
+            prefetch(pass + GW, rs_n, re_n);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_b(pass, rs, re);
+            rs = rs_n; re = re_n;
+            load_rec(pass + 2 * GW, rs_n, re_n);
+        }
+        // every tile of this wave is done: park the lane's d_M in its own slot of the scratch behind the ring flags
+        __syncthreads();                                      // (1) the ring is dead: its memory becomes the d_M scratch
+        {
+            float* scr = s_ring + (wave * 64 + lane) * 4;
+            st4(scr, make_float4(dMq[0], dMq[1], dMq[2], dMq[3]));
+        }
+#undef LANE_CONSTS
+    }
+    if (wave >= V) __syncthreads();                           // (1) for the matrix waves
+    __syncthreads();                                          // (2)
+    // ---- block partial of d_W_edge | d_M, every sum in a fixed order ----
+    float* out = a.partial + (size_t)blockIdx.x * P;
+    for (int i = tid; i < WSZ; i += kBlockT) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int v = 0; v < V * 4; ++v) sum += s_dw[v * WSZ + i];
+        out[i] = sum;
+    }
+    if (tid < 16) {                                           // d_M[type tt][head hh]: lanes 16 j + 4 hh + kk of every vector wave
+        const int tt = tid >> 2, hh = tid & 3;
+        float sum = 0.f;
+        if (hh < H) {
+            for (int v = 0; v < V; ++v)
+                for (int jk = 0; jk < 16; ++jk) sum += s_ring[(v * 64 + 16 * (jk >> 2) + 4 * hh + (jk & 3)) * 4 + tt];
+        }
+        out[WSZ + tt * 4 + hh] = sum;
+    }
+}
+
+static size_t b1ws_lds_bytes(int H, int Cp, int V) {
+    const int HC = H * Cp;
+    return ((size_t)4 * HC + 64 + (size_t)V * 4 * 4 * HC + (size_t)4 * 16 * (HC + 4)) * sizeof(float);
+}
+
+template <int H, int V>
+static void launch_b1ws(const DstWsArgs& a, int grid, hipStream_t s) {
+    static bool big = false;
+    if (!big) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big = true;
+    }
+    GLAM_PROF_LABEL("d_aggr+k_triplet_bwd_dst_ws");
+    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
+}
+
+bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot) {
+    const char* e = getenv("GLAM_B1_WS");
+    return !(e && atoi(e) == 0) && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H <= 3;
+}
+int triplet_bwd_dst_ws_blocks(int64_t N) {
+    const int ntiles = (int)((N + 15) / 16);
+    const char* ge = getenv("GLAM_WS_GRID");
+    const int cap = ge ? atoi(ge) : 256;
+    return ntiles < cap ? ntiles : cap;
+}
+
+// B1 with the d_aggr GEMM inside, warp-specialised (called by triplet_bwd_impl).  Writes gridDim.x block partials [4 * H * Cp + 16].
+int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
+                       const float* stats, const float* d_out, const float* img_dagg, const int32_t* ell_src, const int32_t* ell_eid,
+                       int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot, float slope, float* d_aggr, float* alpha_e,
+                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s) {
+    if (!triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_dst_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
+    if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
+        return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_dst_ws: a tensor exceeds 4 GiB (32-bit offsets)");
+    DstWsArgs a{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, (int)N, Cp, slope,
+                d_aggr, alpha_e, dpre_e, d_a_ij, partial};
+    const int grid = triplet_bwd_dst_ws_blocks(N);
+    switch (H) {
+        case 1: launch_b1ws<1, 8>(a, grid, s); break;
+        case 2: launch_b1ws<2, 8>(a, grid, s); break;
+        default: launch_b1ws<3, 8>(a, grid, s); break;
+    }
+    GLAM_LAUNCH_CHECK("triplet_bwd_dst_ws");
+    *nblk_out = grid;
+    return GLAM_OK;
+}
+
+}  // namespace glam

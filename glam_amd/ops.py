@@ -198,6 +198,7 @@ class GraphIndex:
 
 TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
 BWD_ELL = os.environ.get("GLAM_BWD_ELL", "1") == "1"       # A/B knob: pipelined B2 beyond the LLC
+B1_WS = os.environ.get("GLAM_B1_WS", "1") == "1"           # A/B knob: warp-specialised B1 (needs the ELL records of both directions)
 # Fused forward over ELL records (molecular graphs): "auto" = the warp-specialised kernel (csrc/triplet_ws.hip) wherever it exists
 # (one-hot bond features: every size), the barrier-coupled pipelined kernel (csrc/triplet_dma.hip, FUSE = true) beyond the LLC
 # otherwise; "1" = always an ELL route, "0" = never (the general fused kernel).
@@ -637,18 +638,21 @@ class _TripletLayer(torch.autograd.Function):
         ell_t = gi.ell_t() if (N > 0 and BWD_ELL and d_ea is None and (GraphIndex.wants_ell(N, H, Cp) or (
             PIPE_FUSED == "auto" and Cp > 32 and lib.glam_triplet_layer_ws_supported(H, Cp, Dp, int(rows_are_one_hot(ea_p)))))) else None
         have_carry = ctx.carried and d_carry is not None and N > 0
+        # the same records by target (what the forward used): with both, B1 runs warp-specialised too
+        ell_f = gi.ell() if (ell_t is not None and B1_WS) else None
         if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
             c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
             c_wn, c_we, c_att, c_wsc, c_bias = c_parts
-            check(lib.glam_triplet_layer_bwd_params_acc(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
+            check(lib.glam_triplet_layer_bwd_params_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                         ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                         ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
                                                         ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(c_wn), ptr(c_we),
-                                                        ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(ell_t[0]) if ell_t else None,
+                                                        ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(ell_f[0]) if ell_f else None,
+                                                        ptr(ell_f[1]) if ell_f else None, ptr(ell_t[0]) if ell_t else None,
                                                         ptr(ell_t[1]) if ell_t else None, int(rows_are_one_hot(ea_p)) if ell_t else 0,
                                                         ptr(d_ea), ptr(ws), ws.numel(), stream()),
-                  "glam_triplet_layer_bwd_params_acc")
+                  "glam_triplet_layer_bwd_params_ell")
             if ctx.carried:
                 return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry))
             return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
@@ -697,12 +701,15 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
     """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
     if _want_torch_ext(gi.N, heads, x_p.size(1)):
         from . import torch_ext
-        # an eager visit goes through the C++ node (general kernels); it is also where the one-time read-backs of the ELL routes happen,
-        # so that a later CAPTURED visit of the same batch finds them cached (bit-identical results either way)
+        # the one-time read-backs of the ELL routes happen on an eager visit (a later CAPTURED visit of the same batch finds them
+        # cached); with them the C++ node launches the same warp-specialised kernels as the Python node: one trajectory, bit for bit
+        ell_f = ell_b = None
+        onehot = False
         if PIPE_FUSED == "auto" and x_p.size(1) > 32 and gi.N > 0 and rows_are_one_hot(ea_p):
-            gi.ell()
+            onehot = True
+            ell_f = gi.ell()
             if torch.is_grad_enabled() and BWD_ELL:
-                gi.ell_t()
+                ell_b = gi.ell_t()
         # same checks, same exception type as the Python node (the operator's own TORCH_CHECKs would raise RuntimeError)
         require_device(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias)
         C = weight_node.size(0)
@@ -711,7 +718,9 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
             raise GlamHipError("triplet_layer: shape mismatch")
         t_ptr = gi.transpose() if torch.is_grad_enabled() else (gi.rowptr, gi.src, gi.eid)     # any int32 tensors when no backward follows
         return torch_ext.load().triplet_layer(f32c(x_p, "x"), f32c(ea_p, "edge_attr"), weight_node, weight_edge, att, weight_scale, bias,
-                                              gi.rowptr, gi.src, gi.eid, t_ptr[0], t_ptr[1], t_ptr[2], heads, float(slope))
+                                              gi.rowptr, gi.src, gi.eid, t_ptr[0], t_ptr[1], t_ptr[2], heads, float(slope),
+                                              ell_f[0] if ell_f else None, ell_f[1] if ell_f else None,
+                                              ell_b[0] if ell_b else None, ell_b[1] if ell_b else None, onehot)
     params = (weight_node, weight_edge, att, weight_scale, bias)
     C = weight_node.size(0)
     sizes = [weight_node.numel(), weight_edge.numel(), att.numel(), heads * C * C, C]

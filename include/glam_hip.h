@@ -299,6 +299,24 @@ int glam_triplet_layer_bwd_params_acc(const float* x, const float* edge_attr, co
                                       const float* add_weight_edge, const float* add_att, const float* add_weight_scale,
                                       const float* add_bias, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot,
                                       float* d_edge_attr, void* ws, size_t ws_bytes, void* stream);
+/* glam_triplet_layer_bwd_params_acc with the ELL records of BOTH directions: ell_src / ell_eid BY TARGET (glam_ell_build on
+ * (rowptr, src, eid): what the forward used) and ell_dst / ell_eid_t BY SOURCE; either pair may be NULL.  With one-hot edge features of
+ * width 4 (edge_onehot = 1, glam_triplet_layer_ws_supported) both aggregate launches of the backward run warp-specialised: B1 with the
+ * d_aggr GEMM produced ahead by matrix waves (csrc/triplet_ws_b1.hip), B2 with the d_x GEMM as the consumers' product
+ * (csrc/triplet_ws.hip).  d_x, d_weight_node, d_weight_scale, d_bias and every per-node / per-edge intermediate equal the general
+ * route bit for bit; d_weight_edge and the edge part of d_att are the same sums in another fixed order (autograd of
+ * src_1gp/layer.py:36-61). */
+int glam_triplet_layer_bwd_params_ell(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                                      const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int C, int H, int De,
+                                      int Cp, int Dp, float slope, const float* weight_node, const float* weight_edge,
+                                      const float* att, float* d_x, float* d_weight_node, float* d_weight_edge, float* d_att,
+                                      float* d_weight_scale, float* d_bias, const float* add_weight_node,
+                                      const float* add_weight_edge, const float* add_att, const float* add_weight_scale,
+                                      const float* add_bias, const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
+                                      const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
+                                      void* stream);
 /* B2 alone (d_xw, d_a_j from alpha_e / dpre_e f32[E, 4] as B1 leaves them) over ELL records by source: the software-pipelined
  * kernel glam_triplet_layer_bwd_params_acc runs when it is given ell_dst / ell_eid_t; for tests and isolated timing. */
 int glam_triplet_bwd_src_ell(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr,

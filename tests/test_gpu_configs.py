@@ -269,3 +269,37 @@ def test_bench_multi_rank_path_runs_as_a_fresh_subprocess(device, extra):
     assert r["scaling"] == "weak" and r["config"]["collective"]
     if extra:
         assert "eager all-reduce" in r["config"]["launch"] or torch.cuda.device_count() < 2
+
+
+@pytest.mark.parametrize("mol_block,pro_block", [("_NNConv", "_GCNConv"), ("_TripletMessage", "_TripletMessage")])
+def test_config5_two_tower_model_at_bindingdb_size(device, mol_block, pro_block):
+    """BASELINE configs[4] at SURVEY §8(d)'s size: 32 ligand - protein pairs, ligands ESOL-shaped, proteins 200-800 residues with
+    x[., 49] and 8 edge features, the reference's default towers (_NNConv / _GCNConv, src_2gi_dti_scr/run.py) and the attention conv in
+    both — the whole ArchitectureDTI against the oracle (src_2gi_dti_scr/model.py:45-68 restated), output and every parameter gradient
+    bounded by the oracle's own fp64 twin (tests/conftest.py:assert_fp32_parity)."""
+    from glam_amd.data import synth_protein_batch
+    P = 32
+    torch.manual_seed(5)
+    mb = synth_batch(P, seed=11)
+    pb = synth_protein_batch(P, seed=12)                       # n_res ~ U{200..800}
+    assert pb.x.size(1) == 49 and pb.edge_attr.size(1) == 8 and 200 * P <= pb.x.size(0) <= 800 * P
+    kw = dict(mol_block=mol_block, pro_block=pro_block, graph_norm="_None", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU")
+    net = model.ArchitectureDTI(e_dim=1024, message_steps=3, graph_do="_None()", end_do="_None()", **kw).eval()
+    names = [n for n, _ in net.named_parameters()]
+    cot = torch.randn(P, 1)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        cast = lambda b: type(b)(b.x.to(dt), b.edge_index, b.edge_attr.to(dt), batch=b.batch)
+        out = O.architecture_dti(sd, cast(mb), cast(pb), P, message_steps=3, **kw)
+        gs = torch.autograd.grad((out * cot.to(dt)).sum(), [sd[n] for n in names], allow_unused=True)
+        ref[dt] = (out.detach(), gs)
+    net = net.to(device)
+    out = net(mb.to(device), pb.to(device))
+    assert_fp32_parity(out, ref[torch.float64][0], ref[torch.float32][0], "config 5 output", out_tol=1e-5)
+    gs = torch.autograd.grad((out * cot.to(device)).sum(), [p for _, p in net.named_parameters()], allow_unused=True)
+    for n, a, r64, r32 in zip(names, gs, ref[torch.float64][1], ref[torch.float32][1]):
+        if r64 is None:
+            assert a is None or float(a.abs().max()) == 0.0, n
+            continue
+        assert_fp32_parity(a, r64, r32, f"config 5 grad.{n}")
