@@ -20,6 +20,8 @@
 //               kernel's d_W_edge partials.
 #include "dense.h"
 
+#include <stdlib.h>
+
 namespace glam {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -91,7 +93,10 @@ __device__ long long g_ts_prof[1024 * 8];
 // the other's MFMAs.
 struct TsArgs2 { TsArgs a, b; int first_b; };
 
-template <int MT, int GMAX, int TPI>
+// RB ("register B", the 192-column variant): a wave is BOUND to one column split for the whole launch and keeps that 64 x 64 slice of
+// the weight image in 64 registers; it walks the row tiles.  No LDS image, no staging, no block barrier (the staging was 3.8 k of the
+// 12.5 k cycles of the launch at B = 1 024) and no B-operand LDS reads in the loop; the grid is a multiple of the column-split count.
+template <int MT, int GMAX, int TPI, bool RB = false>
 __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const bool second = (int)blockIdx.x >= two.first_b;
@@ -134,12 +139,26 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
     // spread over all blocks / CUs first and a SIMD runs one MFMA stream instead of two back to back.
     const bool spread = nitems < nblk * WPB;
     int item = spread ? bid + wave * nblk : bid * WPB + wave;
+    int stride_items = stride;
+    float4 breg[RB ? GMAX : 1][RB ? TPI : 1];
+    if constexpr (RB) {
+        // wave gw of the grid: column split gw % CS, row tiles gw / CS, gw / CS + GW / CS, ... (the host makes GW a multiple of CS)
+        const int gw = bid * WPB + wave;
+        const int cs = gw % CS;
+        item = (gw / CS) * CS + cs;
+        stride_items = stride;          // GW waves: GW / CS row tiles per step = GW items
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+            for (int t = 0; t < TPI; ++t)
+                breg[g][t] = g < G ? ld4(a.Wimg + ((size_t)(4 * g + kq) * MP + (cs * TPI + t) * 16 + c) * 4) : f4zero();
+    }
     float4 af[GMAX];
     TS_STAMP(0);
     load_afrag(item, af);              // flies while the weight image is staged
 
     // ---- stage the W image into LDS: all loads in flight first, then the LDS stores ----
-    {
+    if constexpr (!RB) {
         const int n4 = G * 4 * MP;     // float4 count
         float4 buf[kMaxStage];
 #pragma unroll
@@ -152,15 +171,15 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
             const int idx = tid + i * kTsBlock;
             if (idx < n4) st4(s_w + 4 * idx, buf[i]);
         }
+        __syncthreads();
     }
-    __syncthreads();
     TS_STAMP(1);
     TS_DRAIN();
     TS_STAMP(2);
 
     const float* wlane = s_w + (kq * MP + c) * 4;
     int pass = 0;
-    for (; item < nitems; item += stride, ++pass) {
+    for (; item < nitems; item += stride_items, ++pass) {
         const int tile = item / CS, cs = item - tile * CS;
         const int t0 = cs * TPI;       // first column tile of the item
         v4f acc[TPI];
@@ -171,7 +190,10 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
             if (g < G) {
                 float4 bv[TPI];
 #pragma unroll
-                for (int t = 0; t < TPI; ++t) bv[t] = ld4(wlane + g * 16 * MP + (t0 + t) * 64);
+                for (int t = 0; t < TPI; ++t) {
+                    if constexpr (RB) bv[t] = breg[g][t];
+                    else bv[t] = ld4(wlane + g * 16 * MP + (t0 + t) * 64);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float aj = f4get(af[g], j);
@@ -182,7 +204,7 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
             }
         }
         if (pass == 0) TS_STAMP(3);
-        load_afrag(item + stride, af);   // next item's A fragment flies under the epilogue
+        load_afrag(item + stride_items, af);   // next item's A fragment flies under the epilogue
         // C layout: tile column = lane & 15 (-> logical columns cg*64 + 4c + t), row = (lane >> 4) * 4 + i
         const int cg = t0 >> 2, tq = t0 & 3;       // TPI == 4: tq = 0; TPI == 2: tq in {0, 2}
         const int m0 = cg * 64 + 4 * c + tq;
@@ -456,6 +478,15 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
     *grid = g;
     return GLAM_OK;
 }
+// the register-B form of the 192-column variant: one 8-wave block per CU (167 registers: a second block does not fit), 255 blocks =
+// 2 040 waves, a multiple of the 3 column splits
+static bool ts_rb_enabled() { const char* e = getenv("GLAM_TS_RB"); return !e || atoi(e) != 0; }
+static int ts_rb_grid(int N) {
+    const int ntiles = (N + 15) / 16;
+    int g = (ntiles * 3 + 7) / 8;        // one item per wave
+    g = (g + 2) / 3 * 3;
+    return g > 255 ? 255 : g;
+}
 
 // b == nullptr: one product; otherwise two products of the SAME variant in one launch
 int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
@@ -473,7 +504,11 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
-    else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
+    else if (variant == 1 && !b && ts_rb_enabled()) {
+        two.first_b = ts_rb_grid(a.N);
+        GLAM_PROF_LABEL("k_ts_gemm<12, 4, 4>");
+        hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, true>), dim3(two.first_b), dim3(kTsBlock), 0, s, two);
+    } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else {
         if (a.out1_bf16 || (b && b->out1_bf16)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: bf16 output is limited to the 48 KB-image variants");
         static bool big2 = false;      // > 64 KB of dynamic LDS is opted into once
