@@ -64,6 +64,7 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 #pragma unroll
     for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(img + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
+    __syncthreads();                                          // the block's only barrier (LDS flags / W_edge staged): the loads above fly under it
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const int slot = it % kWsRing, want = 4 * (it / kWsRing + 1);
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
     }
-    __syncthreads();                                          // the only block-wide barrier
+    // the block's only barrier sits BEHIND each role's first global loads (ws_consume; the producers' first record + prefetch below)
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
@@ -305,6 +306,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int deg_a, dmax_a, deg_b = 0, dmax_b = 0;
     prefetch(pass, rs_nxt, re_nxt, 0, rows_a, deg_a, dmax_a);
     load_rec(pass + GW, rs_nxt, re_nxt);
+    __syncthreads();                                          // the block's only barrier: W_edge / flags staged; the first pass is already in flight
     const int pass_end = ntiles << 2;                         // whole 16-node tiles: every producer publishes every tile of its group
     int it = grp;                                             // local tile index of `pass`
     // two passes per trip: the register sets swap roles instead of being copied
@@ -380,7 +382,6 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     float* s_ring = s_meta + P * 2 * kSideF;
     for (int i = tid; i < WSZ / 4; i += kWsBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
     if (tid < 64) s_ready[tid] = 0;
-    __syncthreads();
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
@@ -534,6 +535,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int deg_a, dmax_a, deg_b = 0, dmax_b = 0;
     prefetch(pass, rs_nxt, re_nxt, 0, rows_a, deg_a, dmax_a);
     load_rec(pass + GW, rs_nxt, re_nxt);
+    __syncthreads();                                          // the block's only barrier (see k_triplet_fwd_ws)
     const int pass_end = ntiles << 2;
     int it = grp;
     for (; pass - rw < pass_end; pass += 2 * GW, it += 2 * PG) {

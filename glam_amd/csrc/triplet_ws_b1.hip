@@ -55,8 +55,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
     }
-    __syncthreads();
-    const int ntiles = (a.N + 15) >> 4;
+    const int ntiles = (a.N + 15) >> 4;       // (the barrier that publishes the LDS initialisation sits behind each role's first global loads)
 
     if (wave >= V) {
         // ------------------------------------------------------------------------------------------------------------------
@@ -84,6 +83,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         float4 af_a[4], af_b[4];
         int tile = blockIdx.x, it = 0;
         load_a(tile, af_a);
+        __syncthreads();                                      // LDS initialised; the weight slice and the first tile's rows are in flight
         auto one_tile = [&](int it_, const float4 (&af)[4]) {
             const int slot = it_ % kRing;
             if (it_ >= kRing) {                             // the vector waves must have taken the slot's previous tile
@@ -324,6 +324,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         load_rec(pass, rs, re);
         prefetch(pass, rs, re);
         load_rec(pass + GW, rs_n, re_n);
+        __syncthreads();                                      // LDS initialised; the first pass's operands are in flight
         const int pass_end = ntiles << 2;
         int it = grp;
         for (; pass - rw < pass_end; pass += GW, it += VG) {
