@@ -521,8 +521,9 @@ def main():
             cb = torch.randn(Nb, C, device=dev)
 
             def compute_big():
-                out = conv(xb, big.edge_index, big.edge_attr)
-                live["big"] = torch.autograd.grad(out, params + [xb], grad_outputs=cb)
+                with (contextlib.nullcontext() if args.stage_per_step else ops.cached_staging()):
+                    out = conv(xb, big.edge_index, big.edge_attr)
+                    live["big"] = torch.autograd.grad(out, params + [xb], grad_outputs=cb)
 
             mb = step_kernel_model(Nb, Eb, H, C, De)
             pb = profile_step(compute_big, max(5, args.prof_reps // 3))
