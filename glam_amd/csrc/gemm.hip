@@ -96,8 +96,11 @@ struct TsArgs2 { TsArgs a, b; int first_b; };
 // RB ("register B", the 192-column variant): a wave is BOUND to one column split for the whole launch and keeps that 64 x 64 slice of
 // the weight image in 64 registers; it walks the row tiles.  No LDS image, no staging, no block barrier (the staging was 3.8 k of the
 // 12.5 k cycles of the launch at B = 1 024) and no B-operand LDS reads in the loop; the grid is a multiple of the column-split count.
-template <int MT, int GMAX, int TPI, bool RB = false>
-__global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
+// RBLK: 0 = the LDS-image form (512 threads); 512 / 768 = the register-B form with 8 / 12 waves per block (two / three per SIMD at 167
+// registers: three pay once the launch streams — 131 vs 141 us at B = 16 384 — and cost at B = 1 024, 14.5 vs 11.6 us)
+template <int MT, int GMAX, int TPI, int RBLK = 0>
+__global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two) {
+    constexpr bool RB = RBLK != 0;
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const bool second = (int)blockIdx.x >= two.first_b;
     const TsArgs a = second ? two.b : two.a;      // by value: every field a scalar select (a reference made the compiler re-read the
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(kTsBlock) k_ts_gemm(TsArgs2 two) {
     const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
     const int ntiles = (a.N + 15) >> 4;
     const int nitems = ntiles * CS;
-    constexpr int WPB = kTsBlock / 64;
+    constexpr int WPB = (RB ? RBLK : kTsBlock) / 64;
     const int stride = nblk * WPB;
 
     // A fragment of a tile: one float4 per 16-k group, every load in flight at once
@@ -478,13 +481,14 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
     *grid = g;
     return GLAM_OK;
 }
-// the register-B form of the 192-column variant: one 8-wave block per CU (167 registers: a second block does not fit), 255 blocks =
-// 2 040 waves, a multiple of the 3 column splits
+// the register-B form of the 192-column variant: one block per CU
 static bool ts_rb_enabled() { const char* e = getenv("GLAM_TS_RB"); return !e || atoi(e) != 0; }
+static bool ts_rb_big(int N) { return N >= 131072; }       // 12-wave blocks once the launch streams from HBM
 static int ts_rb_grid(int N) {
     const int ntiles = (N + 15) / 16;
+    if (ts_rb_big(N)) return 256;        // 12 waves per block: any block count is a multiple of the 3 column splits
     int g = (ntiles * 3 + 7) / 8;        // one item per wave
-    g = (g + 2) / 3 * 3;
+    g = (g + 2) / 3 * 3;                 // 8 g waves: a multiple of the 3 column splits
     return g > 255 ? 255 : g;
 }
 
@@ -507,7 +511,8 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     else if (variant == 1 && !b && ts_rb_enabled()) {
         two.first_b = ts_rb_grid(a.N);
         GLAM_PROF_LABEL("k_ts_gemm<12, 4, 4>");
-        hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, true>), dim3(two.first_b), dim3(kTsBlock), 0, s, two);
+        if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
+        else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 512>), dim3(two.first_b), dim3(512), 0, s, two);
     } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else {
         if (a.out1_bf16 || (b && b->out1_bf16)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: bf16 output is limited to the 48 KB-image variants");
