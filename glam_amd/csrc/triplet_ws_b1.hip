@@ -50,7 +50,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     float* s_dw = smem + WSZ + 64;                            // per (vector wave, node row): d_W_edge [4][HC]
     float* s_ring = s_dw + V * 4 * WSZ;                       // kRing tiles of 16 x LDT floats
     for (int i = tid; i < WSZ / 4; i += kBlockT) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
-    for (int i = tid; i < V * 4 * WSZ; i += kBlockT) s_dw[i] = 0.f;
+    for (int i = tid; i < V * WSZ; i += kBlockT) st4(s_dw + 4 * i, f4zero());          // V * 4 arrays of WSZ floats
     if (tid < 64) {
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
@@ -255,25 +255,30 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                     int tk[DM];
 #pragma unroll
                     for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * HC + (qok ? q : 0) * 4;
+                    // slot outer, head inner: the three accumulator rows of a slot (one per head: distinct addresses) are read together,
+                    // updated and written back, so a pass costs DM LDS round trips for d_W_edge instead of DM * H dependent ones
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        float4 er[DM];
+                    for (int k = 0; k < DM; ++k) {
+                        float4 er[H], dacc[H];
+                        float* d = wave_dw + j * WSZ + tk[k];
+                        const bool upd = k < deg && qok;
 #pragma unroll
-                        for (int k = 0; k < DM; ++k) er[k] = ld4(s_w + tk[k] + h * Cp);
+                        for (int h = 0; h < H; ++h) {
+                            er[h] = ld4(s_w + tk[k] + h * Cp);
+                            dacc[h] = upd ? ld4(d + h * Cp) : f4zero();
+                        }
 #pragma unroll
-                        for (int k = 0; k < DM; ++k) {
+                        for (int h = 0; h < H; ++h) {
                             const float4 tv = dag[h] * rows[k][h];                   // d_aggr * x_j
                             float part = 0.f;
-                            part += dot4(tv, er[k]);
+                            part += dot4(tv, er[h]);
                             const float dal = group_sum<16>(part);
                             dalq = (hc == h && kk == k) ? dal : dalq;
-                            const float al = row_bcast(alpha, 4 * h + k);
-                            if (k < deg && qok) {             // d_W_edge[type_k][h] += alpha * (d_aggr * x_j): this node row's private array
-                                float* d = wave_dw + j * WSZ + tk[k] + h * Cp;
-                                float4 acc = ld4(d);
-                                fma4(acc, al, tv);
-                                st4(d, acc);
-                            }
+                            fma4(dacc[h], row_bcast(alpha, 4 * h + k), tv);          // d_W_edge[type_k][h] += alpha * (d_aggr * x_j)
+                        }
+                        if (upd) {
+#pragma unroll
+                            for (int h = 0; h < H; ++h) st4(d + h * Cp, dacc[h]);
                         }
                     }
                 }
