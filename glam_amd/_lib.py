@@ -55,6 +55,10 @@ SIGNATURES = {
     "glam_triplet_fwd_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "glam_triplet_layer_ws_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "glam_triplet_layer_fwd_ell": (_i32, [_vp] * 5 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
+    "glam_relation_mlp_supported": (_i32, [_i32, _i32, _i64]),
+    "glam_relation_mlp_workspace_bytes": (_sz, [_i32, _i32, _i64]),
+    "glam_relation_mlp_fwd": (_i32, [_vp] * 4 + [_i32, _i32, _i64, _vp, _vp, _vp]),
+    "glam_relation_mlp_bwd": (_i32, [_vp] * 3 + [_i32, _i32, _i64] + [_vp] * 5 + [_sz, _vp]),
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_supported": (_i32, [_i32]),
     "glam_gru_fused_image_bytes": (_sz, []),

@@ -367,7 +367,7 @@ class NNConv(MessagePassing):
             # instead of the reference's [E, C*C] per-edge weight tensor (612 MB at B=1024).
             Dp = _pad_de(De)
             def relation_weights():     # parameter-only: shared by the message_steps applications (ops.weight_scope)
-                w = self.nn(torch.eye(De, dtype=x.dtype, device=x.device))              # [De, in*out]
+                w = ops.relation_mlp(self.nn, De)                                        # nn(eye(De)): [De, in*out]
                 return w.view(De * self.in_channels, self.out_channels)
 
             w_rel = ops.scoped_weights(("nnconv-rel", id(self), De), self, relation_weights)

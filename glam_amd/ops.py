@@ -991,6 +991,54 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _RelationMLP(torch.autograd.Function):
+    """``nn(eye(De))`` for ``nn = Linear(De, hidden) -> ReLU -> Linear(hidden, M)``: the relation-weight table of NNConv with one-hot
+    bond features (src_1gp/layer.py:115-122) — one launch forward, two backward, instead of a dozen library launches on 4-row
+    operands (csrc/relmlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, b2):
+        require_device(w1, b1, w2, b2)
+        w1, b1, w2, b2 = f32c(w1, "w1"), f32c(b1, "b1"), f32c(w2, "w2"), f32c(b2, "b2")
+        Hd, De = w1.shape
+        M = w2.size(0)
+        lib = _lib.load()
+        h = torch.empty(De, Hd, dtype=torch.float32, device=w1.device)
+        out = torch.empty(De, M, dtype=torch.float32, device=w1.device)
+        check(lib.glam_relation_mlp_fwd(ptr(w1), ptr(b1), ptr(w2), ptr(b2), De, Hd, M, ptr(h), ptr(out), stream()), "glam_relation_mlp_fwd")
+        ctx.save_for_backward(h, w2)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        h, w2 = ctx.saved_tensors
+        De, Hd = h.shape
+        M = w2.size(0)
+        lib, dev = _lib.load(), h.device
+        d_out = f32c(d_out, "d_out")
+        f = dict(dtype=torch.float32, device=dev)
+        d_w1, d_b1, d_w2, d_b2 = torch.empty(Hd, De, **f), torch.empty(Hd, **f), torch.empty(M, Hd, **f), torch.empty(M, **f)
+        ws = torch.empty(lib.glam_relation_mlp_workspace_bytes(De, Hd, M), dtype=torch.uint8, device=dev)
+        check(lib.glam_relation_mlp_bwd(ptr(d_out), ptr(h), ptr(w2), De, Hd, M, ptr(d_w1), ptr(d_b1), ptr(d_w2), ptr(d_b2), ptr(ws),
+                                        ws.numel(), stream()), "glam_relation_mlp_bwd")
+        return d_w1, d_b1, d_w2, d_b2
+
+
+def relation_mlp(nn, De):
+    """``nn(eye(De))`` — on the HIP kernels when ``nn`` is the reference's ``Sequential(Linear(De, hidden), ReLU(), Linear(hidden, M))``
+    (fp32, on the device, a shape ``glam_relation_mlp_supported`` accepts: De <= 8, hidden a power of two up to 64), through torch
+    otherwise."""
+    mods = list(nn.children()) if isinstance(nn, torch.nn.Sequential) else []
+    if (len(mods) == 3 and isinstance(mods[0], torch.nn.Linear) and isinstance(mods[1], torch.nn.ReLU) and isinstance(mods[2], torch.nn.Linear)
+            and mods[0].bias is not None and mods[2].bias is not None and mods[0].in_features == De
+            and mods[0].weight.is_cuda and mods[0].weight.dtype == torch.float32 and mods[2].weight.dtype == torch.float32
+            and _lib.load().glam_relation_mlp_supported(De, mods[0].out_features, mods[2].out_features)):
+        return _RelationMLP.apply(mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias)
+    p = next(nn.parameters())
+    return nn(torch.eye(De, dtype=p.dtype, device=p.device))
+
+
 class _MatmulTall(torch.autograd.Function):
     """``A[N,K] @ W[K,M] (+ bias)`` for tall A and a small weight whose shape is outside the MFMA forward table: the two
     data-side products stay on the library GEMM, but the WEIGHT gradient ``A^T @ dY`` — a reduction over the N rows for
@@ -1004,6 +1052,8 @@ class _MatmulTall(torch.autograd.Function):
         ctx.save_for_backward(a, w)
         ctx.has_bias = bias is not None
         ctx.scope = _SCOPE
+        # (an 80 KB-image k_ts_gemm<4, 20, 4> for K <= 320 was measured here — NNConv's [N, 300] x [300, 60] relation product —: 18.9 us
+        # against the library's 15 at N = 20 k, at 256 registers: not kept)
         return torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
 
     @staticmethod

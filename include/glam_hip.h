@@ -448,6 +448,18 @@ int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const flo
                                const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp, float slope,
                                float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);
 
+/* The relation-weight table of NNConv with one-hot bond features (src_1gp/layer.py:115-122: nn = Linear(De, hidden) -> ReLU ->
+ * Linear(hidden, M), M = in * out): out f32[De, M] = nn(eye(De)), h f32[De, hidden] = the hidden activations (saved for the backward).
+ * w1 f32[hidden, De], b1 f32[hidden], w2 f32[M, hidden], b2 f32[M] (torch.nn.Linear layouts).  De <= 8, hidden a power of two in
+ * 4..64 (the reference's is 32), M <= 2^22: glam_relation_mlp_supported says whether a shape is inside.  One launch forward, two
+ * backward (block partials of d_h summed in block order: bit-reproducible). */
+int glam_relation_mlp_supported(int De, int hidden, int64_t M);
+size_t glam_relation_mlp_workspace_bytes(int De, int hidden, int64_t M);
+int glam_relation_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, int De, int hidden, int64_t M, float* h,
+                          float* out, void* stream);
+int glam_relation_mlp_bwd(const float* d_out, const float* h, const float* w2, int De, int hidden, int64_t M, float* d_w1, float* d_b1,
+                          float* d_w2, float* d_b2, void* ws, size_t ws_bytes, void* stream);
+
 /* dot_and_global_pool5 (src_1gp/layer.py:270-283): for every pair i, [max, mean, median, min, std] of
  * S_i = mol[seg_i] @ pro[seg_i]^T — the reference's Python loop of matmul + max / mean / median / min / std per pair
  * (median = torch.median of the flattened scores: the LOWER median; std unbiased).  One block per pair, the score matrix is

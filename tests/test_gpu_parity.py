@@ -2424,3 +2424,24 @@ def test_ts_gemm_pair_with_different_depths_sizes_its_image_for_the_larger(devic
     torch.cuda.synchronize()
     for o, r in zip(outs, refs):
         assert_close(o, r, 1e-5, "ts_gemm pair, K = 16 | 60")
+
+
+@pytest.mark.parametrize("De,Hd,C", [(4, 32, 60), (8, 32, 45), (3, 64, 15), (1, 4, 7), (5, 16, 33), (3, 17, 15)])
+def test_relation_mlp_against_torch_and_fp64(device, De, Hd, C):
+    """``ops.relation_mlp`` (csrc/relmlp.hip: nn(eye(De)) of NNConv's edge network, src_1gp/layer.py:115-122) against the same modules run
+    by torch in fp64: the table and the four parameter gradients within the fp64-twin bound."""
+    torch.manual_seed(De * 100 + C)
+    nn_ = torch.nn.Sequential(torch.nn.Linear(De, Hd), torch.nn.ReLU(), torch.nn.Linear(Hd, C * C))
+    cot = torch.randn(De, C * C)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        import copy
+        m = copy.deepcopy(nn_).to(dt)
+        o = m(torch.eye(De, dtype=dt))
+        res[dt] = (o.detach(), torch.autograd.grad((o * cot.to(dt)).sum(), list(m.parameters())))
+    nn_ = nn_.to(device)
+    out = ops.relation_mlp(nn_, De)
+    gs = torch.autograd.grad((out * cot.to(device)).sum(), list(nn_.parameters()))
+    assert_fp32_parity(out, res[torch.float64][0], res[torch.float32][0], "relation table", out_tol=1e-5)
+    for n, a, r64, r32 in zip(["w1", "b1", "w2", "b2"], gs, res[torch.float64][1], res[torch.float32][1]):
+        assert_fp32_parity(a, r64, r32, "relation mlp d_" + n)
