@@ -295,6 +295,15 @@ constexpr int kWgWaves = kWgBlock / 64;
 // Two independent products may share one launch (blocks [0, first_b) work on job a, the rest on job b).
 struct WgArgs2 { WgArgs a, b; int first_b; };
 
+// lanes whose 4 columns are the virtual ones column / zero padding read their operand from here with a row stride of 0 (no selects in
+// the loop, no registers for the constants)
+__device__ float4 g_wg_const[2] = {{1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // not const: global address space, plain global loads
+
+#ifndef GLAM_WG_ROLL
+#define GLAM_WG_ROLL 1
+#endif
+
+template <bool CELU>
 __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     __shared__ float s_red[kWgWaves * 32 * 64];        // half of the 64 accumulator registers at a time: 64 KB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
@@ -305,19 +314,18 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     const int xcd = bid & 7, loc = bid >> 3;
     const int slab = loc % a.ntile, split = (loc / a.ntile) * 8 + xcd;
     if (split >= a.nsplit) return;
-    const int row0 = (split * kWgWaves + wave) * a.rows_per_wave;
+    const int row0 = __builtin_amdgcn_readfirstlane(min((split * kWgWaves + wave) * a.rows_per_wave, a.N));     // wave-uniform: scalar loop control
     const int row1 = min(row0 + a.rows_per_wave, a.N);
     const int pcol = slab * 64 + 4 * c, qcol = 4 * c;
     const int I12 = a.I1 + a.I2;
-    // resolve the P source of this lane's 4 columns once (I1, I2 are multiples of 4: no straddling)
-    const float* pbase = nullptr;
+    // resolve this lane's P and Q sources once (I1, I2, J are multiples of 4: no straddling): base pointer + row stride in floats
+    const float* psrc = reinterpret_cast<const float*>(&g_wg_const[(a.ones && pcol == I12) ? 0 : 1]);
     int pld = 0;
-    float4 pconst = f4zero();
-    if (pcol < a.I1) { pbase = a.P1 + pcol; pld = a.ldp1; }
-    else if (pcol < I12) { pbase = a.P2 + (pcol - a.I1); pld = a.ldp2; }
-    else if (a.ones && pcol == I12) pconst = make_float4(1.f, 0.f, 0.f, 0.f);
-    const bool qok = qcol < a.J;
-    const float4 qconst = (a.qones && qcol == a.J) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
+    if (pcol < a.I1) { psrc = a.P1 + pcol; pld = a.ldp1; }
+    else if (pcol < I12) { psrc = a.P2 + (pcol - a.I1); pld = a.ldp2; }
+    const float* qsrc = reinterpret_cast<const float*>(&g_wg_const[(a.qones && qcol == a.J) ? 0 : 1]);
+    int qld = 0;
+    if (qcol < a.J) { qsrc = a.Q + qcol; qld = a.ldq; }
 
     v4f acc[4][4];
 #pragma unroll
@@ -325,31 +333,66 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int kSteps = GLAM_WG_STEPS;   // rows/4 per batch: 2*kSteps float4 loads in flight, then 16*kSteps MFMAs
-    // lanes without a P / Q column of their own read (and discard) column 0 of Q
-    const float* psrc = pbase ? pbase : a.Q;
-    if (!pbase) pld = a.ldq;
-    const float* qsrc = a.Q + (qok ? qcol : 0);
-    const int nlast = max(a.N - 1, 0);
-    for (int n0 = row0; n0 < row1; n0 += 4 * kSteps) {
-        float4 pv[kSteps], qv[kSteps];
+    constexpr int kSteps = GLAM_WG_STEPS;   // rows/4 per batch
+    auto mma = [&](float4 pv, float4 qv) {
+        if (CELU && a.q_celu) qv = celu4(qv);        // wave-uniform; celu is the identity on the constant lanes' 1 and 0
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv, ti), f4get(qv, tj), acc[ti][tj], 0, 0, 0);
+    };
+    // full batches (4 kSteps rows, no masks), then one masked batch for the rest
+    const int nfull = (row1 - row0) / (4 * kSteps);
+    // ONE running pointer per operand: requests go out in row order (step after step, batch after batch)
+    const float* pn = psrc + (size_t)(row0 + kq) * pld;
+    const float* qn = qsrc + (size_t)(row0 + kq) * qld;
+    const int pstep = 4 * pld, qstep = 4 * qld;        // floats between consecutive steps of a lane
+#if GLAM_WG_ROLL
+    // rolling prefetch: the operands of step st of the NEXT batch are requested as soon as this batch's step st has issued its MFMAs
+    // (its registers are free from then on): every load flies under 16 (kSteps - 1) of the wave's own MFMAs besides the other waves'
+    float4 pl[kSteps], ql[kSteps];
+    if (nfull > 0) {
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
+    }
+    for (int b = 0; b + 1 < nfull; ++b) {
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
-            // unconditional loads from a clamped row (no branch per load), masked afterwards
-            const int n = n0 + 4 * st + kq;
-            const bool nok = n < row1;
-            const int nc = min(n, nlast);
-            const float4 pl = ld4(psrc + (size_t)nc * pld), ql = ld4(qsrc + (size_t)nc * a.ldq);
-            pv[st] = nok ? (pbase ? pl : pconst) : f4zero();
-            qv[st] = nok ? (qok ? (a.q_celu ? celu4(ql) : ql) : qconst) : f4zero();
+            mma(pl[st], ql[st]);
+            pl[st] = ld4(pn);
+            ql[st] = ld4(qn);
+            pn += pstep;
+            qn += qstep;
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (nfull > 0) {
 #pragma unroll
-        for (int st = 0; st < kSteps; ++st)
+        for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
+    }
+#else
+    for (int b = 0; b < nfull; ++b) {
+        float4 pl[kSteps], ql[kSteps];
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti)
+        for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv[st], ti), f4get(qv[st], tj), acc[ti][tj], 0, 0, 0);
+        for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
+    }
+#endif
+    {
+        const int n0 = row0 + nfull * 4 * kSteps;
+        if (n0 < row1) {                                 // wave-uniform
+            float4 pt[kSteps], qt[kSteps];
+#pragma unroll
+            for (int st = 0; st < kSteps; ++st) {
+                const bool nok = n0 + 4 * st + kq < row1;
+                pt[st] = nok ? ld4(pn + st * pstep) : f4zero();
+                qt[st] = nok ? ld4(qn + st * qstep) : f4zero();
+            }
+#pragma unroll
+            for (int st = 0; st < kSteps; ++st) mma(pt[st], qt[st]);
+        }
     }
     // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order.  Accumulator tile t = ti*4 + tj
     //      of a lane is one float4 (r = 0..3): 8 tiles per half go to LDS as b128 stores [wave][t][lane], thread
@@ -564,7 +607,8 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
     int blocks = 0;
     if (int rc = plan_wgrad(a, out, si, sj, wgrad_budget(a.N), job, &blocks)) return rc;
     WgArgs2 two{a, a, blocks};
-    hipLaunchKernelGGL(k_wgrad, dim3(blocks), dim3(kWgBlock), 0, s, two);
+    if (a.q_celu) hipLaunchKernelGGL(k_wgrad<true>, dim3(blocks), dim3(kWgBlock), 0, s, two);
+    else hipLaunchKernelGGL(k_wgrad<false>, dim3(blocks), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad");
     return GLAM_OK;
 }
@@ -579,7 +623,8 @@ int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob
     if (int rc = plan_wgrad(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;
     if (int rc = plan_wgrad(b, out_b, si_b, sj_b, total - ba, job_b, &nb)) return rc;
     WgArgs2 two{a, b, na};
-    hipLaunchKernelGGL(k_wgrad, dim3(na + nb), dim3(kWgBlock), 0, s, two);
+    if (a.q_celu || b.q_celu) hipLaunchKernelGGL(k_wgrad<true>, dim3(na + nb), dim3(kWgBlock), 0, s, two);
+    else hipLaunchKernelGGL(k_wgrad<false>, dim3(na + nb), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad(pair)");
     return GLAM_OK;
 }

@@ -463,7 +463,10 @@ def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
 
 @pytest.mark.parametrize("N,I1,I2,ones,J", [(1000, 180, 0, 1, 60), (20400, 180, 8, 0, 60), (7, 48, 8, 0, 16), (1, 16, 0, 1, 16), (5000, 56, 8, 1, 64), (3000, 184, 4, 1, 64),
                                             # 64 < J <= 128: two column chunks in one launch (wide layers)
-                                            (20400, 276, 8, 0, 92), (5000, 276, 0, 1, 92), (33, 300, 16, 1, 128)])
+                                            (20400, 276, 8, 0, 92), (5000, 276, 0, 1, 92), (33, 300, 16, 1, 128),
+                                            # N >= 131072: the row-range form (k_wgrad_rows), 1..5 slabs, ragged last block
+                                            (131072, 180, 8, 0, 64), (140001, 180, 0, 1, 60), (131075, 48, 8, 0, 16), (131100, 120, 0, 1, 32),
+                                            (131073, 300, 16, 1, 64), (150000, 276, 8, 0, 92)])
 def test_wgrad_gemm(device, N, I1, I2, ones, J):
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
