@@ -96,8 +96,10 @@ struct TsArgs2 { TsArgs a, b; int first_b; };
 // RB ("register B", the 192-column variant): a wave is BOUND to one column split for the whole launch and keeps that 64 x 64 slice of
 // the weight image in 64 registers; it walks the row tiles.  No LDS image, no staging, no block barrier (the staging was 3.8 k of the
 // 12.5 k cycles of the launch at B = 1 024) and no B-operand LDS reads in the loop; the grid is a multiple of the column-split count.
-// RBLK: 0 = the LDS-image form (512 threads); 512 / 768 = the register-B form with 8 / 12 waves per block (two / three per SIMD at 167
-// registers: three pay once the launch streams — 131 vs 141 us at B = 16 384 — and cost at B = 1 024, 14.5 vs 11.6 us)
+// RBLK: 0 = the LDS-image form (512 threads); 512 / 768 = the register-B form with 8 / 12 waves per block (two / three per SIMD: three
+// pay once the launch streams — 131 vs 141 us at B = 16 384 — and cost at B = 1 024, 14.5 vs 11.6 us).  The register-B form is the PLAIN
+// product only (one A source, no folded CELU, no gradient epilogue, fp32 out: 118 registers instead of 167 with those paths compiled in —
+// 111 -> 103 us at B = 16 384, 11.3 -> 10.7 at B = 1 024); a 16-wave block (four per SIMD) measured 112.7 us.
 template <int MT, int GMAX, int TPI, int RBLK = 0>
 __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two) {
     constexpr bool RB = RBLK != 0;
@@ -130,10 +132,10 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
             af[g] = f4zero();
             if (rok) {
                 if (k0 < a.K1) af[g] = ld4(a.A1 + (size_t)row * a.lda1 + k0);
-                else if (k0 < K) af[g] = ld4(a.A2 + (size_t)row * a.lda2 + (k0 - a.K1));
+                else if (!RB && k0 < K) af[g] = ld4(a.A2 + (size_t)row * a.lda2 + (k0 - a.K1));
             }
         }
-        if (a.a_celu) {
+        if (!RB && a.a_celu) {
 #pragma unroll
             for (int g = 0; g < GMAX; ++g) af[g] = celu4(af[g]);      // celu(0) = 0: the zero padding stays zero
         }
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
                 float4 b = f4zero();
                 if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
                 const bool use_cg = a.cgrad_src && m0 < a.M1, use_ad = a.addend && m0 < a.M1;
-                if (a.cgrad_src || a.addend) {     // wave-uniform: the plain product keeps its lean epilogue (and its registers)
+                if (!RB && (a.cgrad_src || a.addend)) {     // wave-uniform: the plain product keeps its lean epilogue (and its registers)
                     // every load of the epilogue before its first store (a load issued between stores waits for vmcnt(0), i.e. for
                     // the previous row's store to land)
                     float4 xs[4], ad[4];
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
                         if (rr >= a.N) continue;
                         const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
                         if (m0 < a.M1) {
-                            if (a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
+                            if (!RB && a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
                             else st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
                         } else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
                     }
@@ -551,7 +553,9 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
-    else if (variant == 1 && !b && ts_rb_enabled()) {
+    else if (variant == 1 && !b && ts_rb_enabled() && a.K2 == 0 && !a.a_celu && !a.cgrad_src && !a.addend && !a.out1_bf16) {
+        // the register-B form is the plain product only (one A source, no folded CELU, no gradient epilogue, fp32 out): its registers
+        // decide its occupancy
         two.first_b = ts_rb_grid(a.N);
         GLAM_PROF_LABEL("k_ts_gemm<12, 4, 4>");
         if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
