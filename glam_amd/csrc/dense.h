@@ -20,6 +20,10 @@ struct TsArgs {
     const float* addend; int ld_add;       // non-null: out1[r, c] += addend[r, c] last (a second gradient path into the same tensor)
 };
 
+// distance between the 64 x 64 partial slabs of k_wgrad (4096 floats of data each): 16 KB + 256 B, so that the splits of one element —
+// which the reductions read 40 at a time — fall on different memory channels instead of every fourth one
+constexpr int kWgSlabStride = 4096 + 64;
+
 struct WgArgs {
     const float* P1; int I1; int ldp1;
     const float* P2; int I2; int ldp2;

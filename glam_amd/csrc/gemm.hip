@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order.  Accumulator tile t = ti*4 + tj
     //      of a lane is one float4 (r = 0..3): 8 tiles per half go to LDS as b128 stores [wave][t][lane], thread
     //      (t, lane) adds the 8 waves' float4 and stores the block partial as out[(t*64 + lane)*4 + r] ----
-    float* out = a.partial + ((size_t)slab * a.nsplit + split) * 4096;
+    float* out = a.partial + ((size_t)slab * a.nsplit + split) * kWgSlabStride;
     float4* s_red4 = reinterpret_cast<float4*>(s_red);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
 // Final fixed-order reduction of up to 3 partial sets in ONE launch.
 //   kind 0 (k_wgrad partials): element offset `o` in [0, nslab*4096) decodes to r = o%4, lane = (o/4)%64,
 //          t = (o%4096)/256, ti = t/4, tj = t%4, kq = lane/16, c = lane%16  ->  i = 64*slab + 4*(4*kq + r) + ti,
-//          j = 4*c + tj;  out[i*si + j*sj] = sum_s partial[(slab*nsplit + s)*4096 + o%4096]
+//          j = 4*c + tj;  out[i*si + j*sj] = sum_s partial[(slab*nsplit + s)*kWgSlabStride + o%4096]
 //   kind 1 (flat block partials [nsplit][n]): out[e] (e < split_at) or out2[e - split_at] = sum_s partial[s*n + e]
 __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
     __shared__ float s_part[16][17];
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
     if (e < J.n) {
         const float* p;
         size_t stride;
-        if (J.kind == 0) { p = J.partial + (size_t)(e >> 12) * J.nsplit * 4096 + (e & 4095); stride = 4096; }
+        if (J.kind == 0) { p = J.partial + (size_t)(e >> 12) * J.nsplit * kWgSlabStride + (e & 4095); stride = kWgSlabStride; }
         else { p = J.partial + e; stride = (size_t)J.n; }
         int s = rl;
         for (; s + 16 < J.nsplit; s += 32) { s0 += p[(size_t)s * stride]; s1 += p[(size_t)(s + 16) * stride]; }
@@ -580,7 +580,7 @@ constexpr int kWgradBlocksBig = 512;   // two per CU (four waves per SIMD) once 
 constexpr int kWgradBigRows = 131072;
 static int wgrad_budget(int N) { return N >= kWgradBigRows ? kWgradBlocksBig : kWgradBlocks; }
 
-size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * 4096; }     // per product: one 64 x 64 slab per block
+size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per block
 
 // fills the launch geometry of one product (at most `budget` blocks) and the matching reduce job
 static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {

@@ -280,8 +280,8 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
 //   B  d_weight_node                  block per (slab, tj, kq) of product 2: the element sums as in A, meanwhile d_Wa_i[k, :],
 //                                     d_Wa_j[k, :] of the block's 16 columns k (LDS), then
 //                                     d_Wcat[k,h,c] + d_Wa_i[k,h] att_i[h,c] + d_Wa_j[k,h] att_j[h,c]
-//   C  d_weight_triplet_att head h    one block per head: d_Wa_i[:,h], d_Wa_j[:,h], d_M[:,h] into LDS, then the
-//                                     contractions with W_node / W_edge
+//   C  d_weight_triplet_att head h    a block per (head, third: att_i | att_e | att_j): d_Wa[:,h] (or d_M[:,h]) into LDS, then the
+//                                     contraction with W_node (W_edge), 4 row quarters per column summed in order
 //   D  d_weight_edge                  a 16-lane group per element: sum over the B1 blocks + d_M[k,h] att_e[h,c]
 // Every sum runs in a fixed order (splits ascending; lane-strided partial sums + DPP butterfly for the B1 partials).
 struct ParamGradArgs {
@@ -302,30 +302,78 @@ __device__ __forceinline__ int wg_slab_offset(int i, int j) {
     const int ii = i & 63, ti = ii & 3, t = ii >> 2, kq = t >> 2, r = t & 3, c = j >> 2, tj = j & 3;
     return (((ti * 4 + tj) * 64 + kq * 16 + c) << 2) + r;
 }
-// loads are issued 32 at a time (a launch of this kernel is a handful of dependent round trips, nothing else)
+// A launch of this kernel is a handful of dependent memory round trips and nothing else, so every role ISSUES all the loads of a
+// stage before the first use: a partial sum is split into "request a batch" and "add the batch in split order", and independent sums
+// of a thread share the batch round trips.  kPgBatch = the split count of the B = 1 024 step: one round trip there.
+constexpr int kPgBatch = 40;
+struct PgBatch { float v[kPgBatch]; };
+__device__ __forceinline__ const float* wg_ptr(const float* partial, int nsplit, int i, int j) {
+    return partial + (size_t)(i >> 6) * nsplit * kWgSlabStride + wg_slab_offset(i, j);
+}
+// element stride between consecutive splits: 4096 (k_wgrad slabs) or P (B1 block partials); loads are clamped, i.e. unconditional
+__device__ __forceinline__ void pg_request(PgBatch& b, const float* p, size_t stride, int s0, int step, int n) {
+#pragma unroll
+    for (int u = 0; u < kPgBatch; ++u) b.v[u] = p[(size_t)min(s0 + step * u, n - 1) * stride];
+}
+__device__ __forceinline__ float pg_add(float sum, const PgBatch& b, int s0, int step, int n) {
+#pragma unroll
+    for (int u = 0; u < kPgBatch; ++u) sum += s0 + step * u < n ? b.v[u] : 0.f;
+    return sum;
+}
 __device__ __forceinline__ float wg_sum(const float* partial, int nsplit, int i, int j) {
-    const float* p = partial + (size_t)(i >> 6) * nsplit * 4096 + wg_slab_offset(i, j);
+    const float* p = wg_ptr(partial, nsplit, i, j);
     float sum = 0.f;
-    for (int s = 0; s < nsplit; s += 32) {
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = p[(size_t)min(s + u, nsplit - 1) * 4096];   // clamped: unconditional loads
-#pragma unroll
-        for (int u = 0; u < 32; ++u) sum += s + u < nsplit ? v[u] : 0.f;
+    for (int s = 0; s < nsplit; s += kPgBatch) {
+        PgBatch b;
+        pg_request(b, p, kWgSlabStride, s, 1, nsplit);
+        sum = pg_add(sum, b, s, 1, nsplit);
     }
     return sum;
 }
-// sum over the B1 block partials of element e, cooperatively by a 16-lane group (every lane gets the total)
+// two independent sums over the same split range, their loads in flight together
+__device__ __forceinline__ void wg_sum2(const float* pa, const float* pb, int nsplit, float& sa, float& sb) {
+    sa = sb = 0.f;
+    for (int s = 0; s < nsplit; s += kPgBatch) {
+        PgBatch a, b;
+        pg_request(a, pa, kWgSlabStride, s, 1, nsplit);
+        pg_request(b, pb, kWgSlabStride, s, 1, nsplit);
+        sa = pg_add(sa, a, s, 1, nsplit);
+        sb = pg_add(sb, b, s, 1, nsplit);
+    }
+}
+// sum over the B1 block partials of element e, cooperatively by a 16-lane group (every lane gets the total): lane lg takes blocks
+// lg, lg + 16, ...; `request` / `finish` halves so that two elements (or an element and a slab sum) share the round trip
+constexpr int kB1Batch = 16;
+struct B1Batch { float v[kB1Batch]; };
+__device__ __forceinline__ void b1_request(B1Batch& b, const float* p3, int ns3, int P, int e, int s0) {
+#pragma unroll
+    for (int u = 0; u < kB1Batch; ++u) b.v[u] = p3[(size_t)min(s0 + 16 * u, ns3 - 1) * P + e];
+}
+__device__ __forceinline__ float b1_add(float part, const B1Batch& b, int ns3, int s0) {
+#pragma unroll
+    for (int u = 0; u < kB1Batch; ++u) part += s0 + 16 * u < ns3 ? b.v[u] : 0.f;
+    return part;
+}
 __device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e, int lg) {
     float part = 0.f;
-    for (int s = lg; s < ns3; s += 16 * 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p3[(size_t)min(s + 16 * u, ns3 - 1) * P + e];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) part += s + 16 * u < ns3 ? v[u] : 0.f;
+    for (int s = lg; s < ns3; s += 16 * kB1Batch) {
+        B1Batch b;
+        b1_request(b, p3, ns3, P, e, s);
+        part = b1_add(part, b, ns3, s);
     }
     return group_sum<16>(part);
+}
+__device__ __forceinline__ void b1_sum16x2(const float* p3, int ns3, int P, int e0, int e1, int lg, float& r0, float& r1) {
+    float p0 = 0.f, p1 = 0.f;
+    for (int s = lg; s < ns3; s += 16 * kB1Batch) {
+        B1Batch a, b;
+        b1_request(a, p3, ns3, P, e0, s);
+        b1_request(b, p3, ns3, P, e1, s);
+        p0 = b1_add(p0, a, ns3, s);
+        p1 = b1_add(p1, b, ns3, s);
+    }
+    r0 = group_sum<16>(p0);
+    r1 = group_sum<16>(p1);
 }
 
 #ifdef GLAM_PG_PROF   // developer aid (tools/pg_prof.py): cycle stamps of thread 0 of every block, s_memtime = the device-wide clock
@@ -338,6 +386,7 @@ __device__ long long g_pg_prof[512 * 8];
 __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
     PG_STAMP(0);
     __shared__ float s_dwa[2][64];
+    __shared__ float s_pc[4][64];
     __shared__ float s_dm[8];
     const int tid = threadIdx.x, lg = tid & 15, grp = tid >> 4;
     const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
@@ -359,10 +408,12 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         if (i <= HC && col < C) {
             const int h = i / Cp, c = i - h * Cp;
             if (i == HC) {
-                a.d_bias[col] = wg_sum(a.p1, a.ns1, i, col) + (a.c_bias ? a.c_bias[col] : 0.f);
+                const float carry = a.c_bias ? a.c_bias[col] : 0.f;            // requested before the partials are waited for
+                a.d_bias[col] = wg_sum(a.p1, a.ns1, i, col) + carry;
             } else if (c < C) {
                 const int idx = (h * C + c) * C + col;
-                a.d_wsc[idx] = wg_sum(a.p1, a.ns1, i, col) + (a.c_wsc ? a.c_wsc[idx] : 0.f);
+                const float carry = a.c_wsc ? a.c_wsc[idx] : 0.f;
+                a.d_wsc[idx] = wg_sum(a.p1, a.ns1, i, col) + carry;
             }
         }
         PG_STAMP(4);
@@ -374,54 +425,69 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         const int i = slab * 64 + 16 * kq + 4 * lr + lti, k = 4 * lc + tj;
         const int h = i / Cp, c = i - h * Cp;
         const bool mine = i < HC && c < C && k < C;
-        float v = mine ? wg_sum(a.p2, a.ns2, i, k) : 0.f;
         // the attention-gradient rows of this block's 16 columns: d_Wa_i[k, h], d_Wa_j[k, h] (rows HC + side * 4 + h), 16-column runs too
-        if (tid < 2 * 4 * 16) {
-            const int c2 = tid & 15, hh = (tid >> 4) & 3, side = tid >> 6, k2 = 4 * c2 + tj;
-            s_dwa[side][hh * 16 + c2] = (hh < H && k2 < C) ? wg_sum(a.p2, a.ns2, HC + side * 4 + hh, k2) : 0.f;
-        }
+        const int c2 = tid & 15, hh = (tid >> 4) & 3, side = (tid >> 6) & 1, k2 = 4 * c2 + tj;
+        const bool dwa_mine = tid < 2 * 4 * 16 && hh < H && k2 < C;
+        // everything this thread will need, requested at once: its element's splits, its attention row's splits, att, the carry
+        const float* pv = wg_ptr(a.p2, a.ns2, mine ? i : 0, mine ? k : 0);
+        const float* pd = wg_ptr(a.p2, a.ns2, dwa_mine ? HC + side * 4 + hh : 0, dwa_mine ? k2 : 0);
+        const size_t idx = (size_t)k * H * C + h * C + c;
+        const float att_i = mine ? a.att[(size_t)h * 3 * C + c] : 0.f, att_j = mine ? a.att[(size_t)h * 3 * C + 2 * C + c] : 0.f;
+        const float carry = (mine && a.c_wn) ? a.c_wn[idx] : 0.f;
+        float v, dw;
+        wg_sum2(pv, pd, a.ns2, v, dw);
+        if (tid < 2 * 4 * 16) s_dwa[side][hh * 16 + c2] = dwa_mine ? dw : 0.f;
         __syncthreads();
         if (mine) {
-            v = fmaf(s_dwa[0][h * 16 + lc], a.att[(size_t)h * 3 * C + c], v);
-            v = fmaf(s_dwa[1][h * 16 + lc], a.att[(size_t)h * 3 * C + 2 * C + c], v);
-            const size_t idx = (size_t)k * H * C + h * C + c;
-            a.d_wn[idx] = v + (a.c_wn ? a.c_wn[idx] : 0.f);
+            v = fmaf(s_dwa[0][h * 16 + lc], att_i, v);
+            v = fmaf(s_dwa[1][h * 16 + lc], att_j, v);
+            a.d_wn[idx] = v + carry;
         }
         PG_STAMP(4);
         return;
     }
     b -= a.blocksB;
-    if (b < a.blocksC) {                                    // ---- C: attention vector of head h = b
-        const int h = b;
-        // columns in slab order (k = 4 c' + tj, c' fastest): 16 lanes share a 256-byte run
-        for (int idx = tid; idx < 2 * 64; idx += kBlock) {
-            const int side = idx >> 6, k = 4 * (idx & 15) + ((idx >> 4) & 3);
-            if (k < C) s_dwa[side][k] = wg_sum(a.p2, a.ns2, HC + side * 4 + h, k);
-        }
-        for (int kk = grp; kk < De; kk += kBlock / 16) {
-            const float v = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
-            if (lg == 0) s_dm[kk] = v;
-        }
-        __syncthreads();
-        if (tid < 3 * C) {
-            const int part = tid / C, c = tid - part * C;
-            float v = 0.f;
-            if (part == 1) {
-                for (int kk = 0; kk < De; ++kk) v = fmaf(s_dm[kk], a.we[(size_t)kk * H * C + h * C + c], v);
-            } else {
-                const float* dwa = s_dwa[part == 0 ? 0 : 1];
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-                int k = 0;
-                for (; k + 4 <= C; k += 4) {
-                    v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
-                    v1 = fmaf(dwa[k + 1], a.wn[(size_t)(k + 1) * H * C + h * C + c], v1);
-                    v2 = fmaf(dwa[k + 2], a.wn[(size_t)(k + 2) * H * C + h * C + c], v2);
-                    v3 = fmaf(dwa[k + 3], a.wn[(size_t)(k + 3) * H * C + h * C + c], v3);
-                }
-                for (; k < C; ++k) v0 = fmaf(dwa[k], a.wn[(size_t)k * H * C + h * C + c], v0);
-                v = (v0 + v1) + (v2 + v3);
+    if (b < a.blocksC) {                                    // ---- C: one third (att_i | att_e | att_j) of the attention vector of head h
+        const int h = b / 3, part = b - 3 * h;
+        const int c = tid & 63, kq4 = tid >> 6;
+        if (part == 1) {                                    // d_att_e[h, c] = sum_kk d_M[kk, h] W_edge[kk, h, c]
+            const bool out_mine = tid < C, dm_mine = grp < De;
+            float wcol[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) wcol[kk] = (out_mine && kk < De) ? a.we[(size_t)kk * H * C + h * C + tid] : 0.f;
+            const float carry = (out_mine && a.c_att) ? a.c_att[(size_t)h * 3 * C + C + tid] : 0.f;
+            const float dm = b1_sum16(a.p3, a.ns3, a.P, WSZ + (dm_mine ? grp : 0) * 4 + h, lg);
+            if (dm_mine && lg == 0) s_dm[grp] = dm;
+            __syncthreads();
+            if (out_mine) {
+                float v = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    if (kk < De) v = fmaf(s_dm[kk], wcol[kk], v);
+                a.d_att[(size_t)h * 3 * C + C + tid] = v + carry;
             }
-            a.d_att[(size_t)h * 3 * C + tid] = v + (a.c_att ? a.c_att[(size_t)h * 3 * C + tid] : 0.f);
+        } else {                                            // d_att_i / d_att_j[h, c] = sum_k d_Wa[k, h] W_node[k, h, c]
+            const int side = part == 0 ? 0 : 1;
+            // thread (kq4, c): the 16 rows k = 16 kq4 .. + 15 of its column of W_node, requested together with the d_Wa splits
+            // (threads < 64, columns in slab order: 16 lanes share a 256-byte run)
+            float wcol[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 16 * kq4 + r;
+                wcol[r] = (k < C && c < C) ? a.wn[(size_t)k * H * C + h * C + c] : 0.f;
+            }
+            const float carry = (tid < C && a.c_att) ? a.c_att[(size_t)h * 3 * C + 2 * C * side + tid] : 0.f;
+            if (tid < 64) {
+                const int kcol = 4 * (tid & 15) + ((tid >> 4) & 3);
+                s_dwa[0][kcol] = kcol < C ? wg_sum(a.p2, a.ns2, HC + side * 4 + h, kcol) : 0.f;
+            }
+            __syncthreads();
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = fmaf(s_dwa[0][16 * kq4 + r], wcol[r], v);
+            s_pc[kq4][c] = v;
+            __syncthreads();
+            if (tid < C) a.d_att[(size_t)h * 3 * C + 2 * C * side + tid] = (((s_pc[0][tid] + s_pc[1][tid]) + s_pc[2][tid]) + s_pc[3][tid]) + carry;
         }
         PG_STAMP(4);
         return;
@@ -432,17 +498,12 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         if (o < De * H * C) {
             const int kk = o / (H * C), m = o - kk * H * C, h = m / C, c = m - h * C;
             PG_STAMP(1);
-            const float dwe = b1_sum16(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, lg);
-#ifdef GLAM_PG_PROF
-            if (dwe == 123.456f) PG_STAMP(7);      // consume dwe before the stamp
-#endif
-            PG_STAMP(2);
-            const float dm = b1_sum16(a.p3, a.ns3, a.P, WSZ + kk * 4 + h, lg);
-#ifdef GLAM_PG_PROF
-            if (dm == 123.456f) PG_STAMP(7);
-#endif
+            const float att_e = a.att[(size_t)h * 3 * C + C + c];
+            const float carry = a.c_we ? a.c_we[o] : 0.f;
+            float dwe, dm;
+            b1_sum16x2(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, lg, dwe, dm);
             PG_STAMP(3);
-            if (lg == 0) a.d_we[o] = fmaf(dm, a.att[(size_t)h * 3 * C + C + c], dwe) + (a.c_we ? a.c_we[o] : 0.f);
+            if (lg == 0) a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
         }
         PG_STAMP(4);
     }
@@ -710,7 +771,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
         const int C = po->C, De = po->De;
         ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
-                         (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
+                         (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
         if (ss) {
             // side: roles A (d_weight_scale, d_bias <- product 1) and D (d_weight_edge <- B1 partials + d_M), after B1
