@@ -393,7 +393,8 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
                 qt[st] = nok ? ld4(qn + st * qstep) : f4zero();
             }
 #pragma unroll
-            for (int st = 0; st < kSteps; ++st) mma(pt[st], qt[st]);
+            for (int st = 0; st < kSteps; ++st)
+                if (n0 + 4 * st < row1) mma(pt[st], qt[st]);       // wave-uniform: an empty step costs no MFMAs
         }
     }
     // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order.  Accumulator tile t = ti*4 + tj
