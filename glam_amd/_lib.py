@@ -85,6 +85,7 @@ SIGNATURES = {
     "glam_ts_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _vp]),
     "glam_wgrad_workspace_bytes": (_sz, []),
     "glam_wgrad_gemm": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "glam_wgrad_gemm_add": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "glam_graph_norm_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
     "glam_graph_norm_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
     "glam_gru_gates_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),

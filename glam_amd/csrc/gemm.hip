@@ -788,12 +788,13 @@ extern "C" int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, con
                            add_b_b);
 }
 
-extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
-                               const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
-                               int stride_j, void* ws, size_t ws_bytes, void* stream) {
+static int wgrad_gemm_impl(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
+                           const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
+                           int stride_j, const float* addend, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm: N out of range");
     if (N == 0) {
         GLAM_REQUIRE(out, "glam_wgrad_gemm: null pointer");
+        GLAM_REQUIRE(!addend, "glam_wgrad_gemm_add: N = 0 with an addend (the sum is the addend: nothing to launch)");
         return zero_product(out, I1 + I2 + (ones ? 1 : 0), J + (qones ? 1 : 0), stride_i, stride_j, (hipStream_t)stream);
     }
     GLAM_REQUIRE(P1 && Q && out && ws && (I2 == 0 || P2), "glam_wgrad_gemm: null pointer");
@@ -809,13 +810,30 @@ extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P
         if (int rc = launch_wgrad_partials2(a, out, stride_i, stride_j, &rb.job[0], b, out + (size_t)64 * stride_j, stride_i, stride_j,
                                             &rb.job[1], (hipStream_t)stream))
             return rc;
+        if (addend) { rb.job[0].addend = addend; rb.job[1].addend = addend + (size_t)64 * stride_j; }
         return launch_final_reduce(rb, (hipStream_t)stream);
     }
     WgArgs a{P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, (int)N, 0, partial, 0, 0};
     ReduceArgs ra{};
     ra.njobs = 1;
     if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, (hipStream_t)stream, &ra.job[0])) return rc;
+    ra.job[0].addend = addend;
     return launch_final_reduce(ra, (hipStream_t)stream);
+}
+
+extern "C" int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
+                               const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
+                               int stride_j, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_gemm_impl(P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, N, out, stride_i, stride_j, nullptr, ws, ws_bytes, stream);
+}
+
+// out = the product + addend (f32, laid out like out: same strides) — the gradient carry of a weight applied several times per
+// forward, summed by the reduction instead of an add launch.  N > 0.
+extern "C" int glam_wgrad_gemm_add(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
+                                   const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
+                                   int stride_j, const float* addend, void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(addend, "glam_wgrad_gemm_add: null addend");
+    return wgrad_gemm_impl(P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, N, out, stride_i, stride_j, addend, ws, ws_bytes, stream);
 }
 
 // [d_W | d_b] of one linear y = [x | 1] W^T, weight and bias into SEPARATE contiguous tensors (autograd takes them as they are; a

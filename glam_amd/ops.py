@@ -1043,26 +1043,33 @@ class _MatmulTall(torch.autograd.Function):
     """``A[N,K] @ W[K,M] (+ bias)`` for tall A and a small weight whose shape is outside the MFMA forward table: the two
     data-side products stay on the library GEMM, but the WEIGHT gradient ``A^T @ dY`` — a reduction over the N rows for
     which the library's heuristics pick 32x32 tiles (77 us at N = 20 k, K = 240, M = 60) — runs on ``k_wgrad`` (≈12 us),
-    the bias gradient riding on its ones column."""
+    the bias gradient riding on its ones column.  ``carry``: the gradient carry of (w, bias) when a block applies them several
+    times per forward (see _ParamBundle): [d_w | d_bias] flat, summed by the reduction of the weight-gradient product."""
 
     @staticmethod
-    def forward(ctx, a, w, bias):
+    def forward(ctx, a, w, bias, carry=None):
         require_device(a, w, bias)
         a, w = f32c(a, "a"), f32c(w, "w")
         ctx.save_for_backward(a, w)
         ctx.has_bias = bias is not None
         ctx.scope = _SCOPE
+        ctx.carried = carry is not None
+        if ctx.carried:
+            ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
         # (an 80 KB-image k_ts_gemm<4, 20, 4> for K <= 320 was measured here — NNConv's [N, 300] x [300, 60] relation product —: 18.9 us
         # against the library's 15 at N = 20 k, at 256 registers: not kept)
-        return torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
+        out = torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
+        return (out, carry.view(-1)) if ctx.carried else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_carry=None):
         a, w = ctx.saved_tensors
-        dy = f32c(dy, "dy")
         N, K = a.shape
         M = w.size(1)
+        if dy is None:      # only with a carry (grads are not materialised then): the output itself was unused
+            return None, None, None, d_carry
+        dy = f32c(dy, "dy")
         da = None
         if ctx.needs_input_grad[0]:
             if M <= 96 and K <= 320 and K > 64:
@@ -1076,22 +1083,53 @@ class _MatmulTall(torch.autograd.Function):
             else:
                 da = torch.matmul(dy, w.t())
         dw = db = None
-        if ctx.needs_input_grad[1] or ctx.has_bias:
+        if ctx.needs_input_grad[1] or ctx.has_bias or ctx.carried:
             lib = _lib.load()
             ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
+            add = f32c(d_carry, "d_carry") if (ctx.carried and d_carry is not None and N > 0) else None
+
+            def product(*args):     # (P, I, ldp, ones, Q, J, ldq, out, si, sj): the carry, laid out like `out`, joins in the reduction
+                P, I, ldp, ones, Q, J, ldq, out, si, sj = args
+                if add is None:
+                    check(lib.glam_wgrad_gemm(ptr(P), I, ldp, None, 0, 0, ones, ptr(Q), J, ldq, 0, N, ptr(out), si, sj, ptr(ws), ws.numel(),
+                                              stream()), "glam_wgrad_gemm")
+                else:
+                    check(lib.glam_wgrad_gemm_add(ptr(P), I, ldp, None, 0, 0, ones, ptr(Q), J, ldq, 0, N, ptr(out), si, sj, ptr(add),
+                                                  ptr(ws), ws.numel(), stream()), "glam_wgrad_gemm_add")
+
             if ctx.has_bias:   # [dw ; db] = [a | 1]^T dy   (K + 1 <= 320, M <= 128: matmul_tall's bias condition)
                 dwb = torch.empty(K + 1, M, dtype=torch.float32, device=a.device)
-                check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), M, 1, ptr(ws), ws.numel(),
-                                          stream()), "glam_wgrad_gemm")
+                product(a, K, K, 1, dy, M, M, dwb, M, 1)
+                if ctx.carried:
+                    flat = dwb.view(-1)
+                    return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
                 return da, dwb[:K], dwb[K]
             dw = torch.empty(K, M, dtype=torch.float32, device=a.device)
             if M <= 128:      # dw = a^T dy: P = a (up to 320 columns), Q = dy (two 64-column chunks beyond 64)
-                check(lib.glam_wgrad_gemm(ptr(a), K, K, None, 0, 0, 0, ptr(dy), M, M, 0, N, ptr(dw), M, 1, ptr(ws), ws.numel(),
-                                          stream()), "glam_wgrad_gemm")
+                product(a, K, K, 0, dy, M, M, dw, M, 1)
             else:             # wide output: dw^T = dy^T a, written through transposed strides
-                check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(a), K, K, 0, N, ptr(dw), 1, M, ptr(ws), ws.numel(),
-                                          stream()), "glam_wgrad_gemm")
+                product(dy, M, M, 0, a, K, K, dw, 1, M)
+            if ctx.carried:
+                flat = dw.view(-1)
+                return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
         return da, dw, db
+
+
+def _matmul_tall_node(a, w, bias):
+    """``_MatmulTall`` with the gradients of (w, bias) carried across the applications of a block inside a weight_scope."""
+    K, M = w.shape
+    total = K * M + (M if bias is not None else 0)
+    params = (w,) if bias is None else (w, bias)
+
+    def split(flat):     # [d_w (K x M) | d_bias (M)]: the layout of the [a | 1]^T dy product
+        return (flat[:K * M].view(K, M),) if bias is None else (flat[:K * M].view(K, M), flat[K * M:])
+    key = ("carry-tall", id(w), id(bias))
+    carry = _carry_for(key, params, total, split) if (w.requires_grad or (bias is not None and bias.requires_grad)) else None
+    if carry is None:
+        return _MatmulTall.apply(a, w, bias)
+    out, carry = _MatmulTall.apply(a, w, bias, carry)
+    _carry_store(key, w, carry)
+    return out
 
 
 def matmul_tall(a, w, bias=None):
@@ -1100,9 +1138,9 @@ def matmul_tall(a, w, bias=None):
     K, M = w.shape
     ok = a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and a.size(0) >= 64
     if ok and bias is not None and K + 1 <= 320 and M <= 128:
-        return _MatmulTall.apply(a, w, bias)
+        return _matmul_tall_node(a, w, bias)
     if ok and ((K <= 320 and M <= 128) or (K <= 128 and M <= 320)):
-        out = _MatmulTall.apply(a, w, None)
+        out = _matmul_tall_node(a, w, None)
         return out if bias is None else out + bias
     out = torch.matmul(a, w)
     return out if bias is None else out + bias

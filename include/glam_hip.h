@@ -223,6 +223,11 @@ size_t glam_wgrad_workspace_bytes(void);
 int glam_wgrad_gemm(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
                     int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, void* ws,
                     size_t ws_bytes, void* stream);
+/* glam_wgrad_gemm + addend (f32, the strides of out): out = product + addend.  The gradient carry of a weight that a block applies
+ * several times per forward (src_1gp/model.py:53-54) is summed by the reduction instead of an add launch.  N > 0. */
+int glam_wgrad_gemm_add(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones, const float* Q,
+                        int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, const float* addend,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole TripletMessage layer (src_1gp/layer.py:36-61) as one enqueue per direction.  All node-feature

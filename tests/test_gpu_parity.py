@@ -1300,6 +1300,27 @@ def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device, monkey
         assert torch.equal(a, r), n
 
 
+@pytest.mark.parametrize("block,norm", [("_NNConv", "_None"), ("_NNConv", "_PairNorm"), ("_GCNConv", "_None")])
+def test_gradient_carry_of_tall_matmul_weights(device, block, norm):
+    """NNConv's stacked relation weight + bias (and GCN's weight) enter ``ops.matmul_tall`` once per message step: inside a weight
+    scope their gradients are carried through the weight-gradient reductions (glam_wgrad_gemm_add) instead of being summed by
+    autograd's add launches — the same sums in the same order, so the same bits."""
+    torch.manual_seed(11)
+    b = synth_batch(48, seed=4).to(device)
+    net = model.Architecture(message_steps=3, mol_block=block, graph_norm=norm, graph_do="_None()", end_do="_None()",
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device).eval()
+    params = [p for _, p in net.named_parameters()]
+    grads = {}
+    for flag in (True, False):
+        ops.GRAD_CARRY = flag
+        try:
+            grads[flag] = torch.autograd.grad(net(b).sum(), params)
+        finally:
+            ops.GRAD_CARRY = True
+    for (n, _), a, r in zip(net.named_parameters(), grads[True], grads[False]):
+        assert torch.equal(a, r), n
+
+
 def test_sharded_gradients_sum_to_the_single_device_gradient(device):
     """the correctness oracle of the data-parallel path is the single-device run on the concatenated batch.
     Two node-balanced graph shards through DataParallelStep (one process: the all-reduce is the identity) summed by hand
