@@ -128,10 +128,10 @@ def committed_traffic(kernel_label, batch):
     return None, None
 
 
-def profile_step(body, reps):
+def profile_step(body, reps, warm=3):
     """Average per-dispatch duration of every kernel `body` launches: {label: (avg_us, launches per body call)}."""
     from glam_amd import _lib
-    for _ in range(3):
+    for _ in range(warm):
         body()
     torch.cuda.synchronize()
     with _lib.kernel_timer(capacity=64 * reps) as kt:
@@ -526,7 +526,9 @@ def main():
                     live["big"] = torch.autograd.grad(out, params + [xb], grad_outputs=cb)
 
             mb = step_kernel_model(Nb, Eb, H, C, De)
-            pb = profile_step(compute_big, max(5, args.prof_reps // 3))
+            # 40 untimed steps (~30 ms) first: the device idled while the batch was synthesised on the host, and its clocks take longer than
+            # three steps to come back (the same kernels read 20 % slower with warm = 3 than in a dedicated --batch 16384 run)
+            pb = profile_step(compute_big, max(5, args.prof_reps // 3), warm=40)
             ib = time_isolated_aggregate(conv, big, xb.detach(), max(5, args.prof_reps // 3))
             rl = {"workload": f"B={args.large_batch} (N={Nb}, E={Eb}: every [N,180] tensor is {Nb * 720 / 2 ** 20:.0f} MiB, beyond the 256 MiB LLC)",
                   "step_kernels": {n: dict(r, **(rate(mb[n], r["avg_us"]) if n in mb else {})) for n, r in pb.items()},
