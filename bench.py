@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=16,
                     help="consecutive steps captured into one hipGraph launch (each graph launch carries a ~7 us bubble on this stack: "
                          "98.0 / 94.5 / 92.6 / 91.7 / 91.3 us per step at 1 / 2 / 4 / 8 / 16 steps per launch, tools/exp_multistep_graph.py)")
+    ap.add_argument("--preheat-ms", type=float, default=50.0, help="untimed graph replays before the warm-up steps until the device clocks are back up (0 = none)")
     ap.add_argument("--stage-per-step", action="store_true", help="keep the parameter re-layout launch (k_stage_params) inside every step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--large-batch", type=int, default=16384, help="extra roofline point beyond the LLC (0 = skip)")
@@ -439,6 +440,17 @@ def main():
         graph.replay()
         if world > 1 and not ar_in_graph:
             dist.all_reduce(live["bucket"])
+    # device pre-heat (untimed, reported as config.preheat_steps): the GPU's clocks drop while the host synthesises the batch and
+    # captures the graphs, and take tens of milliseconds of load to come back — a --steps 20 --warmup 5 run measured 81.8 us per step
+    # against 77.6 with the same 20 steps behind 50 ms of replays (and 76.6 in the 10 000-step run).  The timed region stays exactly
+    # `steps` steps behind `warmup` warm-up steps.
+    preheat_steps = 0
+    if args.preheat_ms > 0 and (graph is not None or graph_multi is not None):
+        t_h = time.perf_counter()
+        while time.perf_counter() - t_h < args.preheat_ms * 1e-3:
+            run_steps(S if graph_multi is not None else 1)
+            preheat_steps += S if graph_multi is not None else 1
+            torch.cuda.synchronize()
     run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -463,7 +475,7 @@ def main():
         "dtype": "f32" if args.storage == "fp32" else "bf16 rows / f32 arithmetic", "data": "synthetic",
         "config": {"workload": f"ESOL-shaped batch={B}/GPU (N={N} atoms, E={E} directed bonds), single "
                                f"TripletMessage({C},{De},heads={H}) layer fwd+bwd, fp32",
-                   "launch": launch, "parallelism": f"dp{world}", "global_batch": B * world,
+                   "launch": launch, "preheat_steps": preheat_steps, "parallelism": f"dp{world}", "global_batch": B * world,
                    "collective": None if world == 1 else ("gloo (GLAM_BENCH_SHARE_GPU functional check)" if share else
                                                           f"RCCL all-reduce of one {n_param}-float bucket, {world} ranks")},
     }
