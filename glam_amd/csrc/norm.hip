@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_fwd(const float* x, const
 //   LayerNorm: gbar = scalar mean of g, T = sum g x', M = cnt*D
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd(const float* x, const float* gy, const int* ptr, int B, int D,
-                                                          float scale, float eps, float* dx) {
+                                                          float scale, float eps, float* dx, const float* addend) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * kWavesPerBlockN + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlockN;
@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd(const float* x, const
 #pragma unroll 4
                 for (int n = beg; n < end; ++n) {
                     const size_t i = (size_t)n * D + c;
-                    dx[i] = a * (gy[i] - gbar[k]) - coef * (x[i] - mean[k]);
+                    const float v = a * (gy[i] - gbar[k]) - coef * (x[i] - mean[k]);
+                    dx[i] = addend ? v + addend[i] : v;
                 }
             }
         }
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_fwd_v4(const float* x, co
 
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_v4(const float* x, const float* gy, const int* ptr, int B, int D,
-                                                             float scale, float eps, float* dx) {
+                                                             float scale, float eps, float* dx, const float* addend) {
     const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
     const int wave = blockIdx.x * kWavesPerBlockN + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlockN;
@@ -269,10 +270,15 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_v4(const float* x, co
                     xr[u] = okr ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
                     gr[u] = okr ? ld4(gy + (size_t)n * D + 4 * c4) : f4zero();
                 }
-                if (okr)
-                    st4(dx + (size_t)n * D + 4 * c4,
-                        make_float4(a * (gr[u].x - gbar.x) - coef * (xr[u].x - mean.x), a * (gr[u].y - gbar.y) - coef * (xr[u].y - mean.y),
-                                    a * (gr[u].z - gbar.z) - coef * (xr[u].z - mean.z), a * (gr[u].w - gbar.w) - coef * (xr[u].w - mean.w)));
+                if (okr) {
+                    float4 v = make_float4(a * (gr[u].x - gbar.x) - coef * (xr[u].x - mean.x), a * (gr[u].y - gbar.y) - coef * (xr[u].y - mean.y),
+                                           a * (gr[u].z - gbar.z) - coef * (xr[u].z - mean.z), a * (gr[u].w - gbar.w) - coef * (xr[u].w - mean.w));
+                    if (addend) {      // a second gradient path into x (the block's residual): summed here instead of by an add launch
+                        const float4 ad = ld4(addend + (size_t)n * D + 4 * c4);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
+                    st4(dx + (size_t)n * D + 4 * c4, v);
+                }
             }
         }
     }
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_fwd_block(const float* x,
 
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_block(const float* x, const float* gy, const int* ptr, int B, int D,
-                                                                float scale, float eps, float* dx) {
+                                                                float scale, float eps, float* dx, const float* addend) {
     __shared__ __attribute__((aligned(16))) float s_part[16 * 16 * 4];
     __shared__ __attribute__((aligned(16))) float s_mean[64];
     __shared__ __attribute__((aligned(16))) float s_gbar[64];
@@ -374,9 +380,13 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_block(const float* x,
         if (act)
             for (int n = beg + rg; n < end; n += 16) {
                 const float4 v = ld4(x + (size_t)n * D + 4 * c4), gv = ld4(gy + (size_t)n * D + 4 * c4);
-                st4(dx + (size_t)n * D + 4 * c4,
-                    make_float4(a * (gv.x - gbar.x) - coef * (v.x - mean.x), a * (gv.y - gbar.y) - coef * (v.y - mean.y),
-                                a * (gv.z - gbar.z) - coef * (v.z - mean.z), a * (gv.w - gbar.w) - coef * (v.w - mean.w)));
+                float4 o = make_float4(a * (gv.x - gbar.x) - coef * (v.x - mean.x), a * (gv.y - gbar.y) - coef * (v.y - mean.y),
+                                       a * (gv.z - gbar.z) - coef * (v.z - mean.z), a * (gv.w - gbar.w) - coef * (v.w - mean.w));
+                if (addend) {
+                    const float4 ad = ld4(addend + (size_t)n * D + 4 * c4);
+                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                }
+                st4(dx + (size_t)n * D + 4 * c4, o);
             }
         __syncthreads();
     }
@@ -416,25 +426,39 @@ extern "C" int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N
     return GLAM_OK;
 }
 
-extern "C" int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
-                                   float scale, float eps, float* dx, void* stream) {
+static int graph_norm_bwd_impl(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                               float scale, float eps, const float* addend, float* dx, void* stream) {
     if (int rc = norm_dims("glam_graph_norm_bwd", N, B, D, mode)) return rc;
     if (N == 0 || B == 0) return GLAM_OK;
     GLAM_REQUIRE(x && gy && ptr && dx, "glam_graph_norm_bwd: null pointer");
+    GLAM_REQUIRE(!addend || (D & 3) || aligned16(addend), "glam_graph_norm_bwd_add: addend must be 16-byte aligned");
     const dim3 block(kBlock);
     if (N / B >= 64 && (D & 3) == 0 && D <= 64) {
         const dim3 grid(grid_for(B, 1));
-        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd_block<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
-        else hipLaunchKernelGGL(k_graph_norm_bwd_block<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
+        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd_block<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
+        else hipLaunchKernelGGL(k_graph_norm_bwd_block<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
         GLAM_LAUNCH_CHECK("glam_graph_norm_bwd");
         return GLAM_OK;
     }
     const dim3 grid(grid_for(B, kWavesPerBlockN));
     if ((D & 3) == 0 && D <= 64) {
-        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd_v4<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
-        else hipLaunchKernelGGL(k_graph_norm_bwd_v4<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
-    } else if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
-    else hipLaunchKernelGGL(k_graph_norm_bwd<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx);
+        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd_v4<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
+        else hipLaunchKernelGGL(k_graph_norm_bwd_v4<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
+    } else if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
+    else hipLaunchKernelGGL(k_graph_norm_bwd<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
     GLAM_LAUNCH_CHECK("glam_graph_norm_bwd");
     return GLAM_OK;
+}
+
+extern "C" int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                                   float scale, float eps, float* dx, void* stream) {
+    return graph_norm_bwd_impl(x, gy, ptr, N, B, D, mode, scale, eps, nullptr, dx, stream);
+}
+
+// dx = the normalisation's input gradient + addend (f32[N, D]): a second gradient path into the same x — the residual of a MessageBlock,
+// src_1gp/layer.py:253-265 — summed in the store instead of by an add launch.  Every node must belong to a graph (ptr[B] = N).
+extern "C" int glam_graph_norm_bwd_add(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                                       float scale, float eps, const float* addend, float* dx, void* stream) {
+    GLAM_REQUIRE(addend, "glam_graph_norm_bwd_add: null addend");
+    return graph_norm_bwd_impl(x, gy, ptr, N, B, D, mode, scale, eps, addend, dx, stream);
 }

@@ -559,15 +559,18 @@ class LayerNorm(torch.nn.Module):
         self.weight = Parameter(torch.ones(in_channels)) if affine else None
         self.bias = Parameter(torch.zeros(in_channels)) if affine else None
 
-    def forward(self, x, batch=None):
+    def forward(self, x, batch=None, with_identity=False):
+        ident = x
         if batch is None:
             x = x - x.mean()
             out = x / (x.std(unbiased=False) + self.eps)
+        elif with_identity:
+            out, ident = ops.graph_standardize(x, ops.segment_ptr(batch), self.eps, with_identity=True)
         else:
             out = ops.graph_standardize(x, ops.segment_ptr(batch), self.eps)
         if self.weight is not None:
             out = out * self.weight + self.bias
-        return out
+        return (out, ident) if with_identity else out
 
 
 class PairNorm(torch.nn.Module):
@@ -577,11 +580,12 @@ class PairNorm(torch.nn.Module):
             raise GlamHipError("PairNorm(scale_individually=True) is not used by the reference")
         self.scale, self.eps = scale, eps
 
-    def forward(self, x, batch=None):
+    def forward(self, x, batch=None, with_identity=False):
         if batch is None:
-            x = x - x.mean(dim=0, keepdim=True)
-            return self.scale * x / (self.eps + x.pow(2).sum(-1).mean()).sqrt()
-        return ops.pair_norm(x, ops.segment_ptr(batch), self.scale, self.eps)
+            xc = x - x.mean(dim=0, keepdim=True)
+            out = self.scale * xc / (self.eps + xc.pow(2).sum(-1).mean()).sqrt()
+            return (out, x) if with_identity else out
+        return ops.pair_norm(x, ops.segment_ptr(batch), self.scale, self.eps, with_identity=with_identity)
 
 
 class GraphSizeNorm(torch.nn.Module):
@@ -607,8 +611,8 @@ class _LayerNorm(torch.nn.Module):
         super().__init__()
         self.norm = LayerNorm(in_channels)
 
-    def forward(self, x, batch=None):
-        return self.norm(x, batch)
+    def forward(self, x, batch=None, with_identity=False):
+        return self.norm(x, batch, with_identity) if with_identity else self.norm(x, batch)
 
 
 class _PairNorm(torch.nn.Module):
@@ -616,8 +620,8 @@ class _PairNorm(torch.nn.Module):
         super().__init__()
         self.norm = PairNorm()
 
-    def forward(self, x, batch=None):
-        return self.norm(x, batch)
+    def forward(self, x, batch=None, with_identity=False):
+        return self.norm(x, batch, with_identity) if with_identity else self.norm(x, batch)
 
 
 class _GraphSizeNorm(torch.nn.Module):
@@ -822,7 +826,13 @@ class MessageBlock(torch.nn.Module):
         identity = x
         if h is None:
             h = x.unsqueeze(0)                       # layer.py:254 (pre-norm x seeds the GRU state)
-        x = self.norm(x, batch)
+        if (self.res is not False and batch is not None and isinstance(self.norm, (_PairNorm, _LayerNorm)) and x.is_cuda
+                and torch.is_grad_enabled() and x.requires_grad):
+            # x feeds the norm and the skip connection: the norm node hands x back as `identity`, so both gradient paths meet in its
+            # backward kernel (one add launch per application less)
+            x, identity = self.norm(x, batch, with_identity=True)
+        else:
+            x = self.norm(x, batch)
         x = _apply_dropout(self.dropout, x)
         fa = self._fusable_act()
         if self.gru is None and isinstance(self.conv, (_GCNConv, _GATConv)) and fa is not None:

@@ -1928,8 +1928,12 @@ def edge_reduce(msg, gi, reduce="sum"):
 
 
 class _GraphNorm(torch.autograd.Function):
+    """``with_identity``: the op also returns ``x`` itself as a second output — the skip connection of a MessageBlock
+    (src_1gp/layer.py:253-265: ``x`` feeds the norm AND ``x + identity``).  Both gradient paths then arrive at THIS node and the
+    backward kernel sums them in its store (glam_graph_norm_bwd_add) instead of autograd launching an add."""
+
     @staticmethod
-    def forward(ctx, x, sp, mode, scale, eps):
+    def forward(ctx, x, sp, mode, scale, eps, with_identity=False):
         require_device(x)
         x = f32c(x, "x")
         N, D = x.shape
@@ -1940,30 +1944,42 @@ class _GraphNorm(torch.autograd.Function):
               "glam_graph_norm_fwd")
         ctx.save_for_backward(x)
         ctx.sp, ctx.cfg = sp, (mode, float(scale), float(eps))
+        if with_identity:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, d_id=None):
         (x,) = ctx.saved_tensors
         mode, scale, eps = ctx.cfg
         sp = ctx.sp
         N, D = x.shape
+        if gy is None:                  # only the identity output was used
+            return d_id, None, None, None, None, None
         gy = f32c(gy, "gy")
         dx = torch.empty_like(x)
-        check(_lib.load().glam_graph_norm_bwd(ptr(x), ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ptr(dx), stream()),
+        lib = _lib.load()
+        if d_id is not None and N > 0 and sp.B > 0:
+            check(lib.glam_graph_norm_bwd_add(ptr(x), ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ptr(f32c(d_id, "d_identity")), ptr(dx),
+                                              stream()), "glam_graph_norm_bwd_add")
+            return dx, None, None, None, None, None
+        check(lib.glam_graph_norm_bwd(ptr(x), ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ptr(dx), stream()),
               "glam_graph_norm_bwd")
-        return dx, None, None, None, None
+        if d_id is not None:
+            dx = d_id if (N == 0 or sp.B == 0) else dx + d_id
+        return dx, None, None, None, None, None
 
 
-def pair_norm(x, sp, scale=1.0, eps=1e-5):
-    """PyG ``PairNorm(scale, eps=1e-5)(x, batch)`` (one kernel per direction)."""
-    return _GraphNorm.apply(x, sp, 0, scale, eps)
+def pair_norm(x, sp, scale=1.0, eps=1e-5, with_identity=False):
+    """PyG ``PairNorm(scale, eps=1e-5)(x, batch)`` (one kernel per direction); ``with_identity``: ``(y, x)`` — see _GraphNorm."""
+    return _GraphNorm.apply(x, sp, 0, scale, eps, with_identity)
 
 
-def graph_standardize(x, sp, eps=1e-5):
+def graph_standardize(x, sp, eps=1e-5, with_identity=False):
     """Statistics part of PyG's graph ``LayerNorm(x, batch)``: zero mean / unit variance per graph."""
-    return _GraphNorm.apply(x, sp, 1, 1.0, eps)
+    return _GraphNorm.apply(x, sp, 1, 1.0, eps, with_identity)
 
 
 class _EdgeWeightedSum(torch.autograd.Function):

@@ -372,6 +372,10 @@ int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B
                         float* y, void* stream);
 int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
                         float scale, float eps, float* dx, void* stream);
+/* dx = glam_graph_norm_bwd's result + addend f32[N, D]: the residual path of a MessageBlock (src_1gp/layer.py:253-265: x feeds the norm
+ * AND the block's skip connection) joins in the store instead of in an add launch.  Every node must belong to a graph (ptr[B] = N). */
+int glam_graph_norm_bwd_add(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                            float scale, float eps, const float* addend, float* dx, void* stream);
 
 /* Edge-weighted neighbour sums over a CSR-by-target: S[n,k,:] = (mean ? 1/deg_n : 1) * sum_{e -> n} w[eid e, k] *
  * x[src e, :]  (x f32[N,D], w f32[E,K], K in {1,4,8}, out f32[N,K,D]; K = 1 with w = the symmetric degree

@@ -1321,6 +1321,36 @@ def test_gradient_carry_of_tall_matmul_weights(device, block, norm):
         assert torch.equal(a, r), n
 
 
+@pytest.mark.parametrize("kind", ["pair", "layer"])
+@pytest.mark.parametrize("mols,width", [(48, 60), (7, 45), (3, 64)])
+def test_graph_norm_with_identity_sums_both_gradient_paths(device, kind, mols, width):
+    """``ops.pair_norm / graph_standardize(..., with_identity=True)`` hand ``x`` back as a second output (the skip connection of a
+    MessageBlock, src_1gp/layer.py:253-265); the backward kernel adds that path's gradient in its store (glam_graph_norm_bwd_add):
+    the same bits as autograd's add of the two paths."""
+    torch.manual_seed(mols + width)
+    b = synth_batch(mols, seed=5).to(device)
+    sp = ops.segment_ptr(b.batch)
+    N = b.x.size(0)
+    x0 = torch.randn(N, width, device=device)
+    c1, c2 = torch.randn(N, width, device=device), torch.randn(N, width, device=device)
+    f = ops.pair_norm if kind == "pair" else ops.graph_standardize
+    xa = x0.clone().requires_grad_(True)
+    ya, ida = f(xa, sp, with_identity=True)
+    assert ida.data_ptr() == xa.data_ptr()
+    (ga,) = torch.autograd.grad((ya * c1).sum() + (ida * c2).sum(), [xa])
+    xb = x0.clone().requires_grad_(True)
+    yb = f(xb, sp)
+    (gb,) = torch.autograd.grad((yb * c1).sum() + (xb * c2).sum(), [xb])
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    # only one of the two outputs used
+    xc = x0.clone().requires_grad_(True)
+    yc, idc = f(xc, sp, with_identity=True)
+    assert torch.equal(torch.autograd.grad((idc * c2).sum(), [xc])[0], c2)
+    xd = x0.clone().requires_grad_(True)
+    yd, _ = f(xd, sp, with_identity=True)
+    assert torch.equal(torch.autograd.grad((yd * c1).sum(), [xd])[0], torch.autograd.grad((f(xb, sp) * c1).sum(), [xb])[0])
+
+
 def test_sharded_gradients_sum_to_the_single_device_gradient(device):
     """the correctness oracle of the data-parallel path is the single-device run on the concatenated batch.
     Two node-balanced graph shards through DataParallelStep (one process: the all-reduce is the identity) summed by hand
