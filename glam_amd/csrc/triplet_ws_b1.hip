@@ -41,7 +41,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
-    const int WSZ = 4 * HC, LDT = HC + 4, P = WSZ + 16;
+    const int WSZ = 4 * HC, LDT = HC + 8, P = WSZ + 16;
     constexpr int kRing = 4;                                  // tile slots (the d_W_edge arrays take the rest of the LDS)
     float* s_w = smem;
     int* s_ready = reinterpret_cast<int*>(smem + WSZ);        // [kRing] matrix-wave check-ins per slot
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 
 static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     const int HC = H * Cp;
-    return ((size_t)4 * HC + 64 + (size_t)V * 4 * 4 * HC + (size_t)4 * 16 * (HC + 4)) * sizeof(float);
+    return ((size_t)4 * HC + 64 + (size_t)V * 4 * 4 * HC + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
 template <int H, int V>
