@@ -3,7 +3,7 @@
 ``Architecture`` / ``Model`` keep the reference constructor keywords (``model.py:24-33``), the
 sub-module names (checkpoint keys ``mol_lin0.*``, ``mol_conv.*``, ``mol_readout.*``, ``mol_flat.*``,
 ``lin_out1.*``) and the call ``model(batch) -> [B, out_dim]`` used by the reference trainers
-(``trainer.py:295``).  ``ArchitectureDTI`` mirrors the two-tower variant
+(``trainer.py:295``).  ``ArchitectureDDI`` mirrors the two-drug variant (``src_2gi_ddi/model.py:9-62``), ``ArchitectureDTI`` the two-tower variant
 (``src_2gi_dti_scr/model.py:14-68``).
 """
 from __future__ import annotations
@@ -112,4 +112,52 @@ class ArchitectureDTI(torch.nn.Module):
         outm = self.mol_flat(self.mol_readout(xm, data_mol.batch, nm))
         outp = self.pro_flat(self.pro_readout(xp, data_pro.batch, np_))
         out = torch.cat([outm, outp, torch.cat(fusion, dim=-1)], dim=-1)
+        return self.lin_out1(self.lin_out0(out))
+
+
+class ArchitectureDDI(torch.nn.Module):
+    """Two-drug model: two ligand towers with their own parameters and per-pair fusion (src_2gi_ddi/model.py:9-62; checkpoint keys
+    ``mol1_lin0.*``, ``mol2_lin0.*``, ``mol1_conv.*``, ``mol2_conv.*``, ``mol1_readout.*``, ``mol2_readout.*``, ``mol1_flat.*``,
+    ``mol2_flat.*``, ``lin_out0.*``, ``lin_out1.*``; parameter creation order = the reference's, so seeded inits agree)."""
+
+    def __init__(self, mol_in_dim=15, mol_edge_in_dim=4, hid_dim_alpha=4, e_dim=1024, out_dim=1, mol_block="_NNConv", message_steps=3,
+                 mol_readout="GlobalPool5",
+                 pre_norm="_None", graph_norm="_None", flat_norm="_None", end_norm="_None",
+                 pre_do="_None()", graph_do="Dropout(0.2)", flat_do="_None()", end_do="Dropout(0.2)",
+                 pre_act="RReLU", graph_act="RReLU", flat_act="RReLU", end_act="RReLU", graph_res=True):
+        super().__init__()
+        hid_dim = mol_in_dim * hid_dim_alpha
+        self.mol1_lin0 = LinearBlock(mol_in_dim, hid_dim, norm=pre_norm, dropout=pre_do, act=pre_act)
+        self.mol2_lin0 = LinearBlock(mol_in_dim, hid_dim, norm=pre_norm, dropout=pre_do, act=pre_act)
+        self.mol1_conv = MessageBlock(hid_dim, hid_dim, mol_edge_in_dim, norm=graph_norm, dropout=graph_do, conv=mol_block,
+                                      act=graph_act, res=graph_res)
+        self.mol2_conv = MessageBlock(hid_dim, hid_dim, mol_edge_in_dim, norm=graph_norm, dropout=graph_do, conv=mol_block,
+                                      act=graph_act, res=graph_res)
+        self.message_steps = message_steps
+        self.mol1_readout = _readout(mol_readout, hid_dim)
+        self.mol2_readout = _readout(mol_readout, hid_dim)
+        _mol_ro = 5 if mol_readout == "GlobalPool5" else 2
+        self.mol1_flat = LinearBlock(_mol_ro * hid_dim, hid_dim, norm=flat_norm, dropout=flat_do, act=flat_act)
+        self.mol2_flat = LinearBlock(_mol_ro * hid_dim, hid_dim, norm=flat_norm, dropout=flat_do, act=flat_act)
+        self.lin_out0 = LinearBlock(hid_dim * 2 + message_steps * 2, e_dim, norm=end_norm, dropout=end_do, act=end_act)
+        self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
+
+    def forward(self, mol1, mol2):
+        with ops.weight_scope():
+            return self._forward(mol1, mol2)
+
+    def _forward(self, mol1, mol2):
+        x1 = self.mol1_lin0(mol1.x, batch=mol1.batch)
+        x2 = self.mol2_lin0(mol2.x, batch=mol2.batch)
+        h1, h2 = None, None
+        fusion = []
+        for _ in range(self.message_steps):
+            x1, h1 = self.mol1_conv(x1, mol1.edge_index, mol1.edge_attr, h=h1, batch=mol1.batch)
+            x2, h2 = self.mol2_conv(x2, mol2.edge_index, mol2.edge_attr, h=h2, batch=mol2.batch)
+            fusion.append(dot_and_global_pool2(x1, x2, mol1.batch, mol2.batch))
+        n1 = getattr(mol1, "num_graphs", None) or None
+        n2 = getattr(mol2, "num_graphs", None) or None
+        o1 = self.mol1_flat(self.mol1_readout(x1, mol1.batch, n1))
+        o2 = self.mol2_flat(self.mol2_readout(x2, mol2.batch, n2))
+        out = torch.cat([o1, o2, torch.cat(fusion, dim=-1)], dim=-1)
         return self.lin_out1(self.lin_out0(out))

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE — golden-vector generator (runs ONLY in the build container).
 
 Imports the reference's own ``src_1gp/layer.py`` / ``model.py`` (and the two-graph
-``src_2gi_dti_scr/layer.py``) from ``/root/reference`` over ``oracle/pyg_standin``, runs them
+``src_2gi_dti_scr`` / ``src_2gi_ddi`` ``layer.py`` / ``model.py``) from ``/root/reference`` over ``oracle/pyg_standin``, runs them
 on seeded synthetic inputs, and writes inputs + parameters + outputs + autograd gradients
 to ``tests/golden/*.npz``.  While doing so it checks the restatement in
 ``oracle/glam_oracle.py`` against the reference (outputs and gradients) — that is what
@@ -66,7 +66,12 @@ def grads_of(out, cot, tensors):
     return [torch.zeros_like(t) if g is None else g for g, t in zip(gs, tensors)]
 
 
+ONLY = os.environ.get("GLAM_GOLDEN_ONLY")      # write only the fixtures whose name contains this (everything is still computed and checked)
+
+
 def save(name, meta, inputs, params, out, cot, grads):
+    if ONLY and ONLY not in name:
+        return
     arrs = {"meta": np.array(json.dumps(meta))}
     for k, v in inputs.items():
         arrs["in." + k] = v.detach().numpy()
@@ -376,6 +381,31 @@ def main():
          {"mol_x": mb.x, "mol_edge_index": mb.edge_index, "mol_edge_attr": mb.edge_attr, "mol_batch": mb.batch,
           "pro_x": pb.x, "pro_edge_index": pb.edge_index, "pro_edge_attr": pb.edge_attr, "pro_batch": pb.batch},
          {k: v for k, v in net.state_dict().items()}, out, cot, dict(zip(names, gs)))
+
+    # ---- two-drug model (src_2gi_ddi/model.py:9-62): two ligand towers, both block types of interest ----------
+    print("Architecture (two towers: ligand + ligand)")
+    layer3, model3 = load_reference("src_2gi_ddi")
+    # (seed 99 for the attention block: with ReLU outputs the last channel — GlobalPool5's sort key — is zero for many atoms, and about
+    #  half of the seeds put tied atoms among the top rows, where the reference's answer is torch.sort's tie order, not arithmetic)
+    for tag, blk, sd_, alpha in (("nnconv", "_NNConv", 93, 2), ("triplet", "_TripletMessage", 99, 4)):
+        seed(sd_)
+        kw = dict(mol_block=blk, graph_norm="_None", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU")
+        net = model3.Architecture(e_dim=64, message_steps=2, hid_dim_alpha=alpha, graph_do="_None()", end_do="_None()", **kw).eval()
+        m1 = synth_batch(4, seed=83)
+        m2 = synth_batch(4, seed=84)
+        names = [n for n, _ in net.named_parameters()]
+        out = net(m1, m2)
+        cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(16))
+        gs = grads_of(out, cot, [p for _, p in net.named_parameters()])
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        o_ref = O.architecture_ddi(sd, m1, m2, 4, message_steps=2, **kw)
+        worst = max(worst, check("ddi out", o_ref, out, 5e-6))
+        for n, g_o, g_r in zip(names, grads_of(o_ref, cot, [sd[n] for n in names]), gs):
+            worst = max(worst, check("ddi grad " + n, g_o, g_r, 2e-5))
+        save("ddi_" + tag, {"kind": "ArchitectureDDI", "B": 4, "e_dim": 64, "message_steps": 2, "hid_dim_alpha": alpha, **kw},
+             {"mol1_x": m1.x, "mol1_edge_index": m1.edge_index, "mol1_edge_attr": m1.edge_attr, "mol1_batch": m1.batch,
+              "mol2_x": m2.x, "mol2_edge_index": m2.edge_index, "mol2_edge_attr": m2.edge_attr, "mol2_batch": m2.batch},
+             {k: v for k, v in net.state_dict().items()}, out, cot, dict(zip(names, gs)))
 
     print(f"oracle pinned against the reference: worst scaled max|d| = {worst:.3e}")
 

@@ -377,6 +377,27 @@ def architecture_dti(sd, mol, pro, num_pairs, message_steps=3, mol_block="_NNCon
     return linear_block(sd, "lin_out1.", linear_block(sd, "lin_out0.", out, end_act), "_None")
 
 
+def architecture_ddi(sd, mol1, mol2, num_pairs, message_steps=3, mol_block="_NNConv", graph_norm="_None",
+                     pre_act="RReLU", graph_act="RReLU", flat_act="RReLU", end_act="RReLU", graph_res=True):
+    """Two-drug ``Architecture.forward`` (src_2gi_ddi/model.py:40-62), eval mode, GlobalPool5 readouts: two LIGAND towers with their own
+    parameters (``mol1_*`` / ``mol2_*``, the same block type) stepped side by side, ``dot_and_global_pool2`` of the two node sets after
+    every message step, readouts, ``lin_out0`` on ``[outm1 | outm2 | fusion]``, ``lin_out1``."""
+    x1 = linear_block(sd, "mol1_lin0.", mol1.x, pre_act)                          # :42
+    x2 = linear_block(sd, "mol2_lin0.", mol2.x, pre_act)                          # :43
+    h1 = h2 = None
+    fusion = []
+    for _ in range(message_steps):                                               # :48-51
+        x1, h1 = message_block(sd, "mol1_conv.", x1, mol1.edge_index, mol1.edge_attr, h1, mol1.batch, num_pairs, conv=mol_block,
+                               norm=graph_norm, act=graph_act, res=graph_res)
+        x2, h2 = message_block(sd, "mol2_conv.", x2, mol2.edge_index, mol2.edge_attr, h2, mol2.batch, num_pairs, conv=mol_block,
+                               norm=graph_norm, act=graph_act, res=graph_res)
+        fusion.append(dot_and_global_pool(x1, x2, mol1.batch, mol2.batch, num_pairs, stats=2))
+    o1 = linear_block(sd, "mol1_flat.", global_pool5(x1, mol1.batch, num_pairs), flat_act)    # :54-57
+    o2 = linear_block(sd, "mol2_flat.", global_pool5(x2, mol2.batch, num_pairs), flat_act)
+    out = torch.cat([o1, o2, torch.cat(fusion, dim=-1)], dim=-1)                 # :60
+    return linear_block(sd, "lin_out1.", linear_block(sd, "lin_out0.", out, end_act), "_None")
+
+
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     """One step of the trainer's optimizer (``Adam(self.model.parameters(), lr=args.lr)``, reference ``src_1gp/trainer.py:49-50``;
     torch.optim.Adam without amsgrad / maximize, weight decay in the L2 form) on numpy fp32 arrays, in the arithmetic of

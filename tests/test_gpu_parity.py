@@ -1494,6 +1494,39 @@ def test_two_tower_model_vs_oracle(device, mol_block, pro_block, norm):
     assert_twin_parity(run, out, gs, "dti", names)
 
 
+@pytest.mark.parametrize("name", ["ddi_nnconv", "ddi_triplet"])
+def test_two_drug_architecture_golden(device, name):
+    """ArchitectureDDI (src_2gi_ddi/model.py:9-62: two ligand towers + per-pair fusion) on the HIP path against the vectors captured from
+    the reference's own model (oracle/gen_goldens.py); bounds from the oracle's fp64 run on the same inputs.  Also: the state dict
+    keys and a seeded construction equal the fixture's (the reference's parameter creation order)."""
+    g = Golden(name)
+    m = g.meta
+    kw = dict(e_dim=m["e_dim"], message_steps=m["message_steps"], hid_dim_alpha=m["hid_dim_alpha"], mol_block=m["mol_block"],
+              graph_norm=m["graph_norm"], pre_act=m["pre_act"], graph_act=m["graph_act"], flat_act=m["flat_act"], end_act=m["end_act"],
+              graph_do="_None()", end_do="_None()")
+    net = model.ArchitectureDDI(**kw)
+    assert list(net.state_dict().keys()) == list(g.params.keys())
+    net.load_state_dict(g.params)
+    net = net.to(device).eval()
+    i = _dev(g.inputs, device)
+    m1 = Data(i["mol1_x"], i["mol1_edge_index"], i["mol1_edge_attr"], batch=i["mol1_batch"])
+    m2 = Data(i["mol2_x"], i["mol2_edge_index"], i["mol2_edge_attr"], batch=i["mol2_batch"])
+    m1.num_graphs = m2.num_graphs = m["B"]
+    out = net(m1, m2)
+    names = [n for n, _ in net.named_parameters()]
+    sd64 = {k: v.double().clone().requires_grad_(True) for k, v in g.params.items()}
+    ii = g.inputs
+    a64 = Data(ii["mol1_x"].double(), ii["mol1_edge_index"], ii["mol1_edge_attr"].double(), batch=ii["mol1_batch"])
+    b64 = Data(ii["mol2_x"].double(), ii["mol2_edge_index"], ii["mol2_edge_attr"].double(), batch=ii["mol2_batch"])
+    o64 = O.architecture_ddi(sd64, a64, b64, m["B"], message_steps=m["message_steps"], mol_block=m["mol_block"], graph_norm=m["graph_norm"],
+                             pre_act=m["pre_act"], graph_act=m["graph_act"], flat_act=m["flat_act"], end_act=m["end_act"])
+    g64 = torch.autograd.grad((o64 * g.cot.double()).sum(), [sd64[n] for n in names], allow_unused=True)
+    assert_fp32_parity(out, o64.detach(), g.out, f"{name} out (golden)", out_tol=1e-5)
+    for n, t, r64 in zip(names, _grads(out, g.cot.to(device), [p for _, p in net.named_parameters()]), g64):
+        if r64 is not None:
+            assert_fp32_parity(t, r64, g.grads[n], f"{name}/grad.{n} (golden)")
+
+
 def test_two_tower_architecture_golden(device):
     """ArchitectureDTI on the HIP path against the vectors captured from the reference's own two-tower model
     (src_2gi_dti_scr/model.py run over the PyG stand-in, oracle/gen_goldens.py)."""
