@@ -446,11 +446,21 @@ def main():
     # `steps` steps behind `warmup` warm-up steps.
     preheat_steps = 0
     if args.preheat_ms > 0 and (graph is not None or graph_multi is not None):
+        unit = S if graph_multi is not None else 1
+        torch.cuda.synchronize()
         t_h = time.perf_counter()
-        while time.perf_counter() - t_h < args.preheat_ms * 1e-3:
-            run_steps(S if graph_multi is not None else 1)
-            preheat_steps += S if graph_multi is not None else 1
-            torch.cuda.synchronize()
+        run_steps(unit)
+        torch.cuda.synchronize()
+        dur = max(time.perf_counter() - t_h, 1e-6)
+        if world > 1:       # every rank must replay the SAME number of times: the steps carry collectives
+            t = torch.tensor([dur], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dur = float(t.item())
+        n_rep = int(min(max(args.preheat_ms * 1e-3 / dur, 0.0), 5000.0))
+        for _ in range(n_rep):
+            run_steps(unit)
+        torch.cuda.synchronize()
+        preheat_steps = (1 + n_rep) * unit
     run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
