@@ -486,6 +486,50 @@ def test_wgrad_gemm(device, N, I1, I2, ones, J):
         assert_close(got, ref, 3e-6 * max(1.0, N ** 0.5 / 10), "wgrad")
 
 
+@pytest.mark.parametrize("N,I,ones,J", [(5000, 60, 1, 60), (3000, 300, 1, 60), (2000, 276, 0, 92), (777, 120, 1, 128), (131080, 60, 1, 64)])
+def test_wgrad_gemm_add_sums_the_addend_in_the_reduction(device, N, I, ones, J):
+    """``glam_wgrad_gemm_add``: product + addend laid out like the output, in both stride orders, also through the two-chunk path
+    (64 < J <= 128) and the large-N grid — exactly ``glam_wgrad_gemm``'s result plus the addend (one fp32 add per element)."""
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(N + I + J)
+    P, Q = torch.randn(N, I, generator=g).to(device), torch.randn(N, J, generator=g).to(device)
+    It = I + ones
+    ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    for si, sj, shape in [(J, 1, (It, J)), (1, It, (J, It))]:
+        add = torch.randn(shape, generator=g).to(device)
+        base, out = torch.full(shape, float("nan"), device=device), torch.full(shape, float("nan"), device=device)
+        assert lib.glam_wgrad_gemm(p(P), I, I, None, 0, 0, ones, p(Q), J, J, 0, N, p(base), si, sj, p(ws), ws.numel(), _lib.stream()) == 0
+        rc = lib.glam_wgrad_gemm_add(p(P), I, I, None, 0, 0, ones, p(Q), J, J, 0, N, p(out), si, sj, p(add), p(ws), ws.numel(), _lib.stream())
+        assert rc == 0, lib.glam_last_error()
+        assert torch.equal(out, base + add)
+    # a missing addend and an empty batch with one are argument errors, not launches
+    assert lib.glam_wgrad_gemm_add(p(P), I, I, None, 0, 0, ones, p(Q), J, J, 0, N, p(out), si, sj, None, p(ws), ws.numel(), _lib.stream()) != 0
+    assert lib.glam_wgrad_gemm_add(p(P), I, I, None, 0, 0, ones, p(Q), J, J, 0, 0, p(out), si, sj, p(add), p(ws), ws.numel(), _lib.stream()) != 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("graphs,nodes,D", [(12, 20, 60), (3, 300, 64), (5, 40, 45), (2, 700, 48)])
+def test_graph_norm_bwd_add_c_abi(device, mode, graphs, nodes, D):
+    """``glam_graph_norm_bwd_add`` in its three kernel forms (wave per graph, block per graph for hundreds of nodes, the generic
+    odd-width one): exactly ``glam_graph_norm_bwd``'s result plus the addend."""
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(graphs * 100 + D)
+    sizes = torch.randint(max(1, nodes // 2), nodes + 1, (graphs,), generator=g)
+    ptr_t = torch.zeros(graphs + 1, dtype=torch.int32)
+    ptr_t[1:] = torch.cumsum(sizes, 0)
+    N = int(ptr_t[-1])
+    x, gy, add = (torch.randn(N, D, generator=g).to(device) for _ in range(3))
+    ptr_d = ptr_t.to(device)
+    base, out = torch.empty_like(x), torch.empty_like(x)
+    assert lib.glam_graph_norm_bwd(p(x), p(gy), p(ptr_d), N, graphs, D, mode, 1.0, 1e-5, p(base), _lib.stream()) == 0
+    rc = lib.glam_graph_norm_bwd_add(p(x), p(gy), p(ptr_d), N, graphs, D, mode, 1.0, 1e-5, p(add), p(out), _lib.stream())
+    assert rc == 0, lib.glam_last_error()
+    assert torch.equal(out, base + add)
+    assert lib.glam_graph_norm_bwd_add(p(x), p(gy), p(ptr_d), N, graphs, D, mode, 1.0, 1e-5, None, p(out), _lib.stream()) != 0
+
+
 # ---------------------------------------------------------------------------------------------
 # edge cases of the boundary
 # ---------------------------------------------------------------------------------------------
