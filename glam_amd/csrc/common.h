@@ -48,6 +48,7 @@ bool prof_slot(const char* kernel, unsigned grid, hipEvent_t* start, hipEvent_t*
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64 lanes
 constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 resident blocks; grid-stride beyond
+constexpr int kBwdBlocks = 512;    // cap on the blocks of the backward-by-target kernels = rows of their d_W_edge partial buffer
 
 static inline int grid_for(int64_t work_items, int items_per_block, int cap = kMaxBlocks) {
     int64_t g = (work_items + items_per_block - 1) / items_per_block;

@@ -58,7 +58,6 @@ static int check_dims(const char* fn, int64_t N, int64_t E, int H, int Cp, int D
 }
 
 constexpr int kFusedBlocks = 512;   // fused-GEMM variants: two blocks per CU, each keeps its weight image in LDS
-constexpr int kBwdBlocks = 512;  // cap on B1 blocks = rows of the d_W_edge partial buffer
 
 }  // namespace glam
 

@@ -3,6 +3,8 @@
 #pragma once
 #include "triplet_kernels.h"
 
+#include <stdlib.h>
+
 namespace glam {
 
 constexpr int kMetaSlots = 16;           // a_j / edge_attr slots of the one-piece side table (>= 11 packed edges, all written every pass)
@@ -24,6 +26,8 @@ constexpr int kWsCons = 4;                // consumer waves: one 16-column tile 
 #define GLAM_WS_RING 8
 #endif
 constexpr int kWsRing = GLAM_WS_RING;     // tile slots between producers and consumers
+// LDS pitch (floats) of the W_edge rows (one row of H * Cp floats per bond type) in the warp-specialised kernels: a multiple of 64
+__host__ __device__ constexpr int ws_wedge_pitch(int HC) { return (HC + 63) & ~63; }
 
 // lane n of the caller's 16-lane row (the lanes of one node) -> every lane of the row: one v_mov_b32_dpp row_newbcast (no LDS)
 template <int CTRL>
@@ -39,6 +43,27 @@ __device__ __forceinline__ int row_bcast_i(int v, int n) {
     }
 }
 __device__ __forceinline__ float row_bcast(float v, int n) { return __builtin_bit_cast(float, row_bcast_i(__builtin_bit_cast(int, v), n)); }
+
+// GLAM_WS_GRID (developer knob: blocks of a warp-specialised launch, default one 12-wave block per CU), clamped to [1, max_blocks];
+// a value that does not parse as a positive number is ignored
+static inline int ws_grid_cap(int max_blocks) {
+    const char* e = getenv("GLAM_WS_GRID");
+    int v = e ? atoi(e) : 256;
+    if (v < 1) v = 256;
+    return v > max_blocks ? max_blocks : v;
+}
+// The warp-specialised kernels use 130-153 KB of dynamic LDS: the opt-in is a per-DEVICE function attribute, so it is set once per
+// (kernel instantiation, device) and its return code is reported (a launch without it fails with a generic error).  `done` is the
+// instantiation's own flag array.
+static inline int ws_opt_in_lds(const void* fn, bool (&done)[64], const char* name) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;      // (an unknown device: set the attribute every time)
+    if (done[dev] && dev != 63) return GLAM_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(GLAM_E_HIP, "%s: opting into 160 KB of dynamic LDS failed: %s", name, hipGetErrorString(e));
+    done[dev] = true;
+    return GLAM_OK;
+}
 
 __device__ __forceinline__ int flag_load(const int* p) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));

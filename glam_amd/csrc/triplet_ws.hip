@@ -105,7 +105,10 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
-    const int WSZ = DE * HC, LDT = HC + 4;
+    // W_edge rows (one per bond type) sit WP = a multiple of 64 floats apart: the rows of two nodes with DIFFERENT bond types then start
+    // on the same bank, and a 16-lane ds_read_b128 group that mixes lanes of two nodes stays conflict free (a pitch of HC = 180 floats
+    // put them 52 banks apart: 18 % of the forward's LDS cycles, 35-38 % of the backward kernels', were bank conflicts)
+    const int WP = ws_wedge_pitch(HC), WSZ = DE * WP, LDT = HC + 4;
     constexpr int kSideF = 2 * 64 * 4;                        // side table of one pass: piece 1 (a_j | a_i), piece 2 (edge_attr), 1 KB each
     float* s_w = smem;
     int* s_ready = reinterpret_cast<int*>(smem + WSZ);        // [kWsRing] producer check-ins per slot (monotonic)
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int* s_taken = s_ready + 32;                              // [kWsRing] consumer check-outs per slot
     float* s_meta = smem + WSZ + 64;                          // per producer wave: 2 side tables of 2 KB
     float* s_ring = s_meta + P * 2 * kSideF;                  // kWsRing tiles of 16 x LDT floats
-    for (int i = tid; i < WSZ / 4; i += kWsBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+    for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) {
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
             t = ea.y != 0.f ? 1 : t; t = ea.z != 0.f ? 2 : t; t = ea.w != 0.f ? 3 : t;
             int tk[DM];
 #pragma unroll
-            for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * HC + (qok ? q : 0) * 4;       // slot k's bond type: lane (hh = 0, kk = k)
+            for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * WP + (qok ? q : 0) * 4;       // slot k's bond type: lane (hh = 0, kk = k)
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 float4 er[DM];
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
-    const int WSZ = DE * HC, KX = HC + 8;
+    const int WP = ws_wedge_pitch(HC), WSZ = DE * WP, KX = HC + 8;     // W_edge row pitch: see k_triplet_fwd_ws
     const int LDT = KX + ((68 - (KX & 63)) & 63);             // row pitch = 4 mod 64 words: conflict-free A-fragment reads
     constexpr int kSideF = 3 * 64 * 4;                        // alpha_e (| d_a_i in lane 4) | dpre_e | edge_attr, 1 KB each
     float* s_w = smem;
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int* s_taken = s_ready + 32;
     float* s_meta = smem + WSZ + 64;
     float* s_ring = s_meta + P * 2 * kSideF;
-    for (int i = tid; i < WSZ / 4; i += kWsBlock) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
+    for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) s_ready[tid] = 0;
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
                 r_da.x += dp.x; r_da.y += dp.y; r_da.z += dp.z; r_da.w += dp.w;
                 int t = 0;
                 t = ea.y != 0.f ? 1 : t; t = ea.z != 0.f ? 2 : t; t = ea.w != 0.f ? 3 : t;
-                tk[k] = t * HC + (qok ? q : 0) * 4;
+                tk[k] = t * WP + (qok ? q : 0) * 4;
             }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
@@ -563,16 +566,14 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 }
 
 template <int H, int P>
-static void launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
-    static bool big = false;
-    if (!big) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big = true;
-    }
+static int launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
+    static bool big[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
-    const size_t lds = ((size_t)4 * HC + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
+    const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
     GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
     hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    return GLAM_OK;
 }
 
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
@@ -591,44 +592,43 @@ int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* d
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a tensor exceeds 4 GiB (32-bit offsets)");
     SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x};
     const int ntiles = (int)((N + 15) / 16);
-    const char* ge = getenv("GLAM_WS_GRID");
-    const int cap = ge ? atoi(ge) : 256;
+    const int cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;
     const char* pe = getenv("GLAM_WS_PROD");
     const bool p4 = pe && atoi(pe) == 4;
+    int rc = GLAM_OK;
     switch (H) {
-        case 1: if (p4) launch_src_ws_p<1, 4>(a, grid, s); else launch_src_ws_p<1, 8>(a, grid, s); break;
-        case 2: if (p4) launch_src_ws_p<2, 4>(a, grid, s); else launch_src_ws_p<2, 8>(a, grid, s); break;
-        case 3: if (p4) launch_src_ws_p<3, 4>(a, grid, s); else launch_src_ws_p<3, 8>(a, grid, s); break;
-        default: launch_src_ws_p<4, 4>(a, grid, s); break;
+        case 1: rc = p4 ? launch_src_ws_p<1, 4>(a, grid, s) : launch_src_ws_p<1, 8>(a, grid, s); break;
+        case 2: rc = p4 ? launch_src_ws_p<2, 4>(a, grid, s) : launch_src_ws_p<2, 8>(a, grid, s); break;
+        case 3: rc = p4 ? launch_src_ws_p<3, 4>(a, grid, s) : launch_src_ws_p<3, 8>(a, grid, s); break;
+        default: rc = launch_src_ws_p<4, 4>(a, grid, s); break;
     }
+    if (rc) return rc;
     GLAM_LAUNCH_CHECK("triplet_bwd_src_ws");
     return GLAM_OK;
 }
 
 static size_t ws_lds_bytes(int H, int Cp, int P) {
     const int HC = H * Cp;
-    return ((size_t)4 * HC + 64 + (size_t)P * 2 * 2 * 64 * 4 + (size_t)kWsRing * 16 * (HC + 4)) * sizeof(float);
+    return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 2 * 64 * 4 + (size_t)kWsRing * 16 * (HC + 4)) * sizeof(float);
 }
 
 template <int H, int P>
-static void launch_ws_p(const FwdDmaArgs& a, int grid, hipStream_t s) {
-    static bool big = false;
-    if (!big) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big = true;
-    }
+static int launch_ws_p(const FwdDmaArgs& a, int grid, hipStream_t s) {
+    static bool big[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P>), big, "triplet_fwd_ws")) return rc;
     GLAM_PROF_LABEL("k_triplet_fwd_ws+update");
     hipLaunchKernelGGL((k_triplet_fwd_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P), s, a);
+    return GLAM_OK;
 }
 template <int H>
-static void launch_ws(const FwdDmaArgs& a, int grid, hipStream_t s) {
+static int launch_ws(const FwdDmaArgs& a, int grid, hipStream_t s) {
     // eight producers (three waves per SIMD) where the kernel fits 168 registers without scratch, four otherwise
     const char* e = getenv("GLAM_WS_PROD");     // developer A/B: producer waves per block
     if constexpr (H <= 3) {
-        if (!(e && atoi(e) == 4)) { launch_ws_p<H, 8>(a, grid, s); return; }
+        if (!(e && atoi(e) == 4)) return launch_ws_p<H, 8>(a, grid, s);
     }
-    launch_ws_p<H, 4>(a, grid, s);
+    return launch_ws_p<H, 4>(a, grid, s);
 }
 
 // the warp-specialised kernel exists for one-hot bond features of width 4 (src_1gp/dataset.py:82: every molecular dataset of the reference)
@@ -653,15 +653,16 @@ int triplet_fwd_ws(const float* xw, const float* a_ij, const float* edge_attr, c
         return fail(GLAM_E_UNSUPPORTED, "triplet_fwd_ws: a tensor exceeds 4 GiB (32-bit offsets)");
     FwdDmaArgs a{xw, a_ij, edge_attr, w_edge, M, ell_src, ell_eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out};
     const int ntiles = (int)((N + 15) / 16);
-    const char* ge = getenv("GLAM_WS_GRID");
-    const int cap = ge ? atoi(ge) : 256;
+    const int cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;           // one 12-wave block per CU
+    int rc = GLAM_OK;
     switch (H) {
-        case 1: launch_ws<1>(a, grid, s); break;
-        case 2: launch_ws<2>(a, grid, s); break;
-        case 3: launch_ws<3>(a, grid, s); break;
-        default: launch_ws<4>(a, grid, s); break;
+        case 1: rc = launch_ws<1>(a, grid, s); break;
+        case 2: rc = launch_ws<2>(a, grid, s); break;
+        case 3: rc = launch_ws<3>(a, grid, s); break;
+        default: rc = launch_ws<4>(a, grid, s); break;
     }
+    if (rc) return rc;
     GLAM_LAUNCH_CHECK("triplet_fwd_ws");
     return GLAM_OK;
 }

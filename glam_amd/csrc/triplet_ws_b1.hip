@@ -41,16 +41,19 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
-    const int WSZ = 4 * HC, LDT = HC + 8, P = WSZ + 16;
+    // W_edge and the d_W_edge arrays keep one row per bond type at a pitch of WP floats, a multiple of 64 (and so is the array size WL):
+    // rows of different types / different node rows start on the same bank, so a 16-lane ds_read_b128 / ds_write_b128 group that mixes
+    // lanes of two nodes is conflict free (pitch HC = 180: 35-43 % of this kernel's LDS cycles were bank conflicts)
+    const int WSZ = 4 * HC, WP = ws_wedge_pitch(HC), WL = 4 * WP, LDT = HC + 8, P = WSZ + 16;
     constexpr int kRing = 4;                                  // tile slots (the d_W_edge arrays take the rest of the LDS)
     float* s_w = smem;
-    int* s_ready = reinterpret_cast<int*>(smem + WSZ);        // [kRing] matrix-wave check-ins per slot
+    int* s_ready = reinterpret_cast<int*>(smem + WL);         // [kRing] matrix-wave check-ins per slot
     float* s_mt = reinterpret_cast<float*>(s_ready + 16);     // M transposed: [head][edge feature]
     int* s_taken = s_ready + 32;                              // [kRing] vector-wave check-outs per slot
-    float* s_dw = smem + WSZ + 64;                            // per (vector wave, node row): d_W_edge [4][HC]
-    float* s_ring = s_dw + V * 4 * WSZ;                       // kRing tiles of 16 x LDT floats
-    for (int i = tid; i < WSZ / 4; i += kBlockT) st4(s_w + 4 * i, ld4(a.w_edge + 4 * i));
-    for (int i = tid; i < V * WSZ; i += kBlockT) st4(s_dw + 4 * i, f4zero());          // V * 4 arrays of WSZ floats
+    float* s_dw = smem + WL + 64;                             // per (vector wave, node row): d_W_edge [4][WP]
+    float* s_ring = s_dw + V * 4 * WL;                        // kRing tiles of 16 x LDT floats
+    for (int i = tid; i < WSZ / 4; i += kBlockT) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
+    for (int i = tid; i < V * WL; i += kBlockT) st4(s_dw + 4 * i, f4zero());           // V * 4 arrays of WL floats
     if (tid < 64) {
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         // ------------------------------------------------------------------------------------------------------------------
         // vector waves
         // ------------------------------------------------------------------------------------------------------------------
-        float* wave_dw = s_dw + wave * 4 * WSZ;
+        float* wave_dw = s_dw + wave * 4 * WL;
         const int npass = (a.N + 3) >> 2;
         const int grp = wave >> 2, rw = wave & 3;
         const int gw = 4 * (blockIdx.x + grp * gridDim.x) + rw, GW = 4 * VG * gridDim.x;
@@ -254,13 +257,13 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                 if (deg > 0) {
                     int tk[DM];
 #pragma unroll
-                    for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * HC + (qok ? q : 0) * 4;
+                    for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * WP + (qok ? q : 0) * 4;
                     // slot outer, head inner: the three accumulator rows of a slot (one per head: distinct addresses) are read together,
                     // updated and written back, so a pass costs DM LDS round trips for d_W_edge instead of DM * H dependent ones
 #pragma unroll
                     for (int k = 0; k < DM; ++k) {
                         float4 er[H], dacc[H];
-                        float* d = wave_dw + j * WSZ + tk[k];
+                        float* d = wave_dw + j * WL + tk[k];
                         const bool upd = k < deg && qok;
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
@@ -354,9 +357,10 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     // ---- block partial of d_W_edge | d_M, every sum in a fixed order ----
     float* out = a.partial + (size_t)blockIdx.x * P;
     for (int i = tid; i < WSZ; i += kBlockT) {
+        const int li = i / HC * WP + i % HC;
         float sum = 0.f;
 #pragma unroll 8
-        for (int v = 0; v < V * 4; ++v) sum += s_dw[v * WSZ + i];
+        for (int v = 0; v < V * 4; ++v) sum += s_dw[v * WL + li];
         out[i] = sum;
     }
     if (tid < 16) {                                           // d_M[type tt][head hh]: lanes 16 j + 4 hh + kk of every vector wave
@@ -372,18 +376,17 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 
 static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     const int HC = H * Cp;
-    return ((size_t)4 * HC + 64 + (size_t)V * 4 * 4 * HC + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
+    const int WL = 4 * ws_wedge_pitch(HC);
+    return ((size_t)WL + 64 + (size_t)V * 4 * WL + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
 template <int H, int V>
-static void launch_b1ws(const DstWsArgs& a, int grid, hipStream_t s) {
-    static bool big = false;
-    if (!big) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big = true;
-    }
+static int launch_b1ws(const DstWsArgs& a, int grid, hipStream_t s) {
+    static bool big[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V>), big, "triplet_bwd_dst_ws")) return rc;
     GLAM_PROF_LABEL("d_aggr+k_triplet_bwd_dst_ws");
     hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
+    return GLAM_OK;
 }
 
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot) {
@@ -392,8 +395,7 @@ bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot) {
 }
 int triplet_bwd_dst_ws_blocks(int64_t N) {
     const int ntiles = (int)((N + 15) / 16);
-    const char* ge = getenv("GLAM_WS_GRID");
-    const int cap = ge ? atoi(ge) : 256;
+    const int cap = ws_grid_cap(kBwdBlocks);      // the partial workspace holds kBwdBlocks block partials
     return ntiles < cap ? ntiles : cap;
 }
 
@@ -409,11 +411,13 @@ int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_att
     DstWsArgs a{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, (int)N, Cp, slope,
                 d_aggr, alpha_e, dpre_e, d_a_ij, partial};
     const int grid = triplet_bwd_dst_ws_blocks(N);
+    int rc = GLAM_OK;
     switch (H) {
-        case 1: launch_b1ws<1, 8>(a, grid, s); break;
-        case 2: launch_b1ws<2, 8>(a, grid, s); break;
-        default: launch_b1ws<3, 8>(a, grid, s); break;
+        case 1: rc = launch_b1ws<1, 8>(a, grid, s); break;
+        case 2: rc = launch_b1ws<2, 8>(a, grid, s); break;
+        default: rc = launch_b1ws<3, 8>(a, grid, s); break;
     }
+    if (rc) return rc;
     GLAM_LAUNCH_CHECK("triplet_bwd_dst_ws");
     *nblk_out = grid;
     return GLAM_OK;

@@ -490,8 +490,17 @@ def _carry_store(key, owner, carry):
 # the address) and NOT by kernels replayed from a graph that also holds this forward: the images are then kept until a parameter's
 # (address, version) changes — a forward-backward step whose parameters stand still (bench.py's configs[1] step: no optimizer in it)
 # starts at the node GEMM.
+# Writers the host cannot see through (address, version counter) — ``glam_amd.optim.Adam`` updates parameters through raw device
+# pointers — announce themselves by bumping PARAM_EPOCH, which is part of every entry's stamp.
 CACHED_STAGING = False
 _STAGED: dict = {}
+PARAM_EPOCH = 0
+
+
+def parameters_written():
+    """Tell the staging cache that parameters were (or will be, by a launch just enqueued) written outside torch's version counting."""
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
 
 
 @contextlib.contextmanager
@@ -506,11 +515,15 @@ def cached_staging(on=True):
 
 def _staged_cached(kind, params, build):
     key = (kind,) + tuple(id(p) for p in params)
-    stamp = tuple((p.data_ptr(), p._version) for p in params)
+    stamp = (PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in params)
     hit = _STAGED.get(key)
     if hit is not None and hit[0] == stamp and all(r() is p for r, p in zip(hit[1], params)):
         return hit[2]
     val = build()
+    if torch.cuda.is_current_stream_capturing():
+        # built inside a capture: the buffer lives in the graph's pool and is only filled when the graph is replayed — an eager pass
+        # before that would read uninitialised images, so it is never published to the cache
+        return val
     try:
         refs = tuple(weakref.ref(p, lambda _r, k=key, c=_STAGED: c.pop(k, None)) for p in params)
     except TypeError:

@@ -82,6 +82,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        from . import ops
+        ops.parameters_written()         # the launch below writes parameters through raw pointers: no version counter moves
         for gi, group in enumerate(self.param_groups):
             if not any(p.requires_grad for p in group["params"]):
                 continue

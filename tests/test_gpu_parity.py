@@ -2474,6 +2474,64 @@ def test_cached_staging_reuses_the_images_until_a_parameter_is_written(device):
     assert fresh[2] == 1 and torch.equal(fresh[0], third[0])
 
 
+def test_cached_staging_sees_the_library_optimizer_and_never_caches_inside_a_capture(device):
+    """``glam_amd.optim.Adam`` writes parameters through raw device pointers (no version counter moves), so its ``step`` bumps
+    ``ops.PARAM_EPOCH`` and the staged images are rebuilt: a training loop inside ``ops.cached_staging()`` follows the same trajectory as
+    one with per-pass staging, bit for bit.  And images built while a stream capture is running (graph-pool memory, filled only on
+    replay) never enter the cache: an eager pass right after the capture stages its own."""
+    import copy
+    from glam_amd import _lib, optim
+    b = synth_batch(24, seed=5).to(device)
+    torch.manual_seed(2)
+    conv0 = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(b.x.size(0), 60, device=device)
+
+    def train(cached, steps=4):
+        conv = copy.deepcopy(conv0)
+        opt = optim.Adam(conv.parameters(), lr=1e-2)
+        outs, staged = [], 0
+        with ops.cached_staging(cached):
+            for _ in range(steps):
+                with _lib.kernel_timer(capacity=64) as kt:
+                    out = conv(x, b.edge_index, b.edge_attr)
+                    opt.zero_grad(set_to_none=True)
+                    (out * out).sum().backward()
+                staged += sum("k_stage_params" in n for n, _, _ in kt.records())
+                opt.step()
+                outs.append(out.detach().clone())
+        return outs, staged
+
+    ref, n_ref = train(False)
+    got, n_got = train(True)
+    assert n_ref == 4 and n_got == 4                  # every step follows an optimizer write: every step re-stages
+    assert not torch.equal(ref[0], ref[1])            # (the parameters did move)
+    for a, c in zip(got, ref):
+        assert torch.equal(a, c)
+
+    # a cache miss inside a capture is not published
+    conv = copy.deepcopy(conv0)
+    with ops.cached_staging():
+        ops._STAGED.clear()
+        ops.graph_index(b.edge_index, b.x.size(0)).ell(); ops.graph_index(b.edge_index, b.x.size(0)).ell_t()
+        with torch.no_grad():
+            warm = conv(x, b.edge_index, b.edge_attr)         # eager visit: read-backs done, cache filled ...
+        ops._STAGED.clear()                                   # ... and emptied again: the capture below misses
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side), torch.no_grad():
+            with torch.cuda.graph(g, stream=side):
+                cap = conv(x, b.edge_index, b.edge_attr)
+        torch.cuda.current_stream().wait_stream(side)
+        assert not ops._STAGED                                # nothing published from inside the capture
+        with torch.no_grad():
+            eager = conv(x, b.edge_index, b.edge_attr)        # BEFORE the first replay: must not read the graph pool's images
+        assert torch.equal(eager, warm)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, warm)
+
+
 def test_adam_device_step_count_equals_the_number_of_replays(device):
     """The launch reads the device step count and learning rate with agent-scope atomic loads (a plain load could be served a line
     cached before the previous launch's update: stale bias correction, a stalled counter): after one eager step and k replays of a
