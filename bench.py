@@ -81,6 +81,16 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
                                                 "(csrc/triplet_ws_b1.hip)"},
         "k_triplet_bwd_src_ws+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C,
                                     "note": "warp-specialised backward by source with the d_x GEMM as the consumers' product (csrc/triplet_ws.hip)"},
+        # round 4: the two weight-gradient products inside the warp-specialised backward launches (their matrix waves): each launch reads
+        # one more [N, C] / [N, HC] operand (x; aggr a second time) and writes 3 slabs of block partials per block
+        "d_aggr+k_triplet_bwd_dst_ws+wgrad": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC) + f * 3 * 4096 * min(256, (N + 15) // 16),
+                                              "flops": 2 * N * C * HC + 2 * N * (HC + 1) * C,
+                                              "note": "warp-specialised backward by target; its matrix waves produce the d_aggr tiles AND accumulate "
+                                                      "[aggr | 1]^T d_out (d_weight_scale, d_bias) (csrc/triplet_ws_b1.hip)"},
+        "k_triplet_bwd_src_ws+dx+wgrad": {"bound": "hbm", "bytes": b2 + 2 * f * N * C + img(HC + 8, C) + f * 3 * 4096 * min(256, (N + 15) // 16),
+                                          "flops": 2 * N * (HC + 8) * C + 2 * N * (HC + 8) * C,
+                                          "note": "warp-specialised backward by source; its consumer waves run the d_x GEMM AND accumulate "
+                                                  "[d_xw | d_a]^T x (d_weight_node and the attention columns) (csrc/triplet_ws.hip)"},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
         "k_triplet_bwd_src_pipe": {"bound": "hbm", "bytes": b2,
                                    "note": "software-pipelined backward by source (ELL records): the op's choice beyond the LLC, followed by the d_x GEMM"},

@@ -587,6 +587,11 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
 // The fused-GEMM variants of the aggregate kernels (forward + update, B2 + d_x) keep a 48 KB weight image per block in LDS: two
 // 4-wave blocks per CU.  That wins while the launch is latency bound (B = 1024: 16.6 us against 9.7 + 11 + a launch boundary) and
 // loses once the batch is large enough for the aggregate to need its full occupancy (B = 16 384: 249 us fused against 134 + 62).
+// smallest batch (nodes) whose weight-gradient products are accumulated inside the warp-specialised backward launches
+static int64_t ws_wgrad_min_nodes() {
+    static const int64_t v = [] { const char* e = getenv("GLAM_WS_WGRAD_MIN_NODES"); return e ? atoll(e) : (int64_t)0; }();
+    return v;
+}
 static int64_t fuse_max_nodes() {
     static const int64_t v = [] { const char* e = getenv("GLAM_FUSE_MAX_NODES"); return e ? atoll(e) : (int64_t)1 << 40; }();
     return v;
@@ -745,18 +750,25 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     const bool use_ell = ell_dst && ell_eid_t && Cp <= 64;
     const bool ws_dx = use_ell && triplet_bwd_src_ws_supported(H, Cp, Dp, edge_onehot);     // B2 + d_x in one warp-specialised launch
     const bool fuse_dx = ws_dx || (!use_ell && triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes());
+    // molecular graphs (both launches warp-specialised): the two weight-gradient products ride in those launches' matrix waves
+    // (round 4; below ws_wgrad_min_nodes() the 2 x 3 x 256 slabs of block partials cost more than the k_wgrad launch they replace)
+    WsWgrad wsw{x, wg1, wg2, 0, 0, false};
+    const bool try_wg = !ss && !xw_bf16 && N >= ws_wgrad_min_nodes() && triplet_ws_wgrad_supported(H, Cp, Dp, edge_onehot);
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
                                   fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16, ss ? ss->mid : nullptr,
                                   fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr, use_ell ? ell_dst : nullptr,
-                                  use_ell ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid))
+                                  use_ell ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, try_wg ? &wsw : nullptr))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
-    if (ss) {
+    if (wsw.used) {     // already accumulated: describe the partial sets for the reductions (k_wgrad's slab format, split = block)
+        ra.job[0] = ReduceJob{0, wg1, wsw.ns1, (HC + 1 + 63) / 64 * 4096, HC + 1, Cp, Cp, 1, dstaged + G.d_wsb, nullptr, 0, 0};
+        ra.job[2] = ReduceJob{0, wg2, wsw.ns2, (HC + 8 + 63) / 64 * 4096, HC + 8, Cp, 1, HC + 8, dstaged + G.d_wcat, nullptr, 0, 0};
+    } else if (ss) {
         if (int rc = launch_wgrad_partials(w2, dstaged + G.d_wcat, 1, HC + 8, s, &ra.job[2])) return rc;
     } else if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8,
                                                &ra.job[2], s)) {   // serial schedule: both products in ONE launch

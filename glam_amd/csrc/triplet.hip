@@ -126,7 +126,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1, const float* img_dagg,
                      const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot, const int32_t* ell_src,
-                     const int32_t* ell_eid) {
+                     const int32_t* ell_eid, WsWgrad* wsw) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
@@ -153,10 +153,16 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     int nblk = 0;
     // molecular graphs with one-hot bond features: the warp-specialised B1 (matrix waves produce the d_aggr tiles ahead of the vector waves)
     const bool b1_ws = ell_src && ell_eid && fuse_dagg && !d_edge_attr && !xw_bf16 && triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot);
+    const bool b2_ws = ell_dst && ell_eid_t && emul && Cp <= 64 && img_dx && d_x && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot);
+    // both weight-gradient products inside the two warp-specialised launches (the caller then skips its k_wgrad launch)
+    const bool fuse_wg = wsw && b1_ws && b2_ws && wsw->x && wsw->p1 && wsw->p2 && triplet_ws_wgrad_supported(H, Cp, De, edge_onehot);
+    if (wsw) wsw->used = fuse_wg;
     if (b1_ws) {
         if (int rc = triplet_bwd_dst_ws(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, N, E, H, Cp, De,
-                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s))
+                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s,
+                                        fuse_wg ? wsw->p1 : nullptr))
             return rc;
+        if (fuse_wg) wsw->ns1 = nblk;
     } else {
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
                   alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16,
@@ -187,9 +193,10 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     if (ell_dst && ell_eid_t && emul && Cp <= 64) {
         // molecular graphs: B2 over ELL records by source — warp-specialised with the d_x GEMM inside where that kernel exists, the
         // software-pipelined B2 alone otherwise (no fused d_x there: the caller runs the GEMM)
-        if (img_dx && d_x && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
+        if (b2_ws)
             return triplet_bwd_src_ws(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
-                                      d_a_ij, img_dx, d_x, s);
+                                      d_a_ij, img_dx, d_x, s, fuse_wg ? wsw->x : nullptr, fuse_wg ? wsw->p2 : nullptr,
+                                      fuse_wg ? &wsw->ns2 : nullptr);
         if (img_dx || d_x) return fail(GLAM_E_INVALID, "glam_triplet_bwd: the ELL route of B2 has no fused d_x for these shapes");
         return triplet_bwd_src_pipe(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
                                     d_a_ij, 0, s);
@@ -223,7 +230,7 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
 }
 
 // B2 alone over ELL records by source (tests, isolated timing): d_xw[N, H*Cp], d_a_ij[N, 8] (the a_j half, columns 4..7, is written)

@@ -53,8 +53,19 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 // (Two tiles per trip with alternating accumulator chains — a 16x16x4 fp32 MFMA issues every 32 cycles but feeds the next one of its own
 // chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
 // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
+//
+// WG (round 4): the same waves also accumulate the WEIGHT-GRADIENT product of the tile they hold, G[i, j] = sum over the nodes n of
+// tile[n, i] * Q[n, j] (B2: tile = [d_xw | d_a_i | d_a_j], Q = x: the gradient of [W_node | Wa_i | Wa_j], the autograd of
+// src_1gp/layer.py:37), so that the N-deep product needs no launch and no second read of d_xw: wave w owns the columns j = 4 c + w of Q
+// (one scalar per lane and 4-row step, prefetched a tile ahead) and reads the tile's rows 4 st + kq as float4 A operands — the operand
+// layout of k_wgrad (gemm.hip), whose 64 x 64 slab format the block partial is written in (one slab set per block, split index =
+// blockIdx.x), so the fixed-order reductions of k_param_grads / k_final_reduce read it unchanged.  Rows past N are zero in the tile
+// (the producers publish zeros), Q is read with clamped (finite) addresses; accumulators of the pad rows i >= K and pad columns
+// j >= Cp hold garbage that no reduction reads.
+template <bool WG>
 __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
-                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
+                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane,
+                                           const float* wg_q, float* wg_partial WS_PROF_PARAMS) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int c = lane & 15, kq = lane >> 4;
     const int GK = (K + 15) >> 4;                             // 16-k groups, <= 12
@@ -64,6 +75,26 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 #pragma unroll
     for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(img + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
+    // ---- weight-gradient side ----
+    const bool wg = WG && wg_q != nullptr;                    // block-uniform
+    const int nslab = (K + 63) >> 6;                          // 64-row slabs of G (<= 3)
+    v4f acc2[3][4];
+    float qb[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned qcol = (unsigned)min(4 * c + w, Cp - 1) * 4u;           // lanes c = 15 at Cp = 60: a pad column (finite data, unread result)
+    auto load_q = [&](int tile) {                             // Q[16 tile + 4 st + kq, 4 c + w], rows clamped (the tile's rows past N are zero)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const unsigned row = (unsigned)min(16 * tile + 4 * st + kq, N - 1);
+            qb[st] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wg_q) + (row * (unsigned)Cp * 4u + qcol));
+        }
+    };
+    if constexpr (WG) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) acc2[s][ti] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (wg) load_q(blockIdx.x);
+    }
     __syncthreads();                                          // the block's only barrier (LDS flags / W_edge staged): the loads above fly under it
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
@@ -72,19 +103,67 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
         asm volatile("" ::: "memory");
         WSTAMP(0);
         const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
-        float4 af[12];
-#pragma unroll
-        for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
-        WSTAMP(1);
-        // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
-        // so the chain starts when the first fragment lands instead of after the twelfth
         v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (!WG) {
+            float4 af[12];
 #pragma unroll
-        for (int g = 0; g < 12; ++g) {
-            if (g < GK) {
+            for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
+            WSTAMP(1);
+            // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
+            // so the chain starts when the first fragment lands instead of after the twelfth
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
+            for (int g = 0; g < 12; ++g) {
+                if (g < GK) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
+                }
+            }
+        } else {
+            // the same chain with the fragments in a rolling set of six (group g + 6 is requested into group g's registers right after
+            // group g's MFMAs): 24 registers instead of 48 — the 48 accumulator registers of the weight-gradient product need the room
+            float4 af[6];
+#pragma unroll
+            for (int g = 0; g < 6; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g < GK) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
+                }
+                af[g] = (g + 6 < GK && 16 * (g + 6) + 4 * kq < K) ? ld4(tl + 16 * (g + 6)) : f4zero();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g + 6 < GK) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g + 6], jj), acc, 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (WG) {
+            if (wg) {
+                // G += tile^T Q: 4 steps of 4 rows; per step nslab float4 A operands (rows 4 st + kq, columns 64 s + 4 c ..) and 4 nslab
+                // independent accumulator tiles (back-to-back issue: no dependent chain here)
+                const float* tr = s_ring + slot * 16 * LDT + kq * LDT;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    float4 pa[3];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        if (s < nslab) pa[s] = ld4(tr + 4 * st * LDT + min(64 * s + 4 * c, LDT - 4));
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        if (s < nslab) {
+#pragma unroll
+                            for (int ti = 0; ti < 4; ++ti)
+                                acc2[s][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pa[s], ti), qb[st], acc2[s][ti], 0, 0, 0);
+                        }
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -95,7 +174,26 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
             for (int i = 0; i < 4; ++i)
                 if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
         }
+        if constexpr (WG) {
+            if (wg && tile + (int)gridDim.x < ntiles) load_q(tile + gridDim.x);        // next tile's Q scalars: a whole tile of time to land
+        }
         WSTAMP(2);
+    }
+    if constexpr (WG) {
+        if (wg) {
+            // block partial in k_wgrad's slab format: slab s of split blockIdx.x, accumulator tile t = ti * 4 + tj (tj = w), lane, r
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s < nslab) {
+                    float* slab = wg_partial + ((size_t)s * gridDim.x + blockIdx.x) * kWgSlabStride;
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti) {
+                        const v4f v = acc2[s][ti];
+                        st4(slab + ((ti * 4 + w) * 64 + lane) * 4, make_float4(v[0], v[1], v[2], v[3]));
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -129,7 +227,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
-        ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        ws_consume<false>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, nullptr, nullptr WS_PROF_ARGS);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -367,9 +465,10 @@ struct SrcWsArgs {
     int N; int Cp;
     float* d_xw; float* d_a_ij;                  // d_a_ij[N, 8]: columns 0..3 (d_a_i) are read, 4..7 (d_a_j) written
     const float* img_dx; float* d_x;
+    const float* wg_x; float* wg_partial;        // non-null: the consumers also accumulate [d_xw | d_a]^T x (k_wgrad slab partials, split = block)
 };
 
-template <int H, int P>
+template <int H, int P, bool WG>
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -390,7 +489,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        ws_consume<WG>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, a.wg_x, a.wg_partial WS_PROF_ARGS);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -565,14 +664,14 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #undef LANE_CONSTS
 }
 
-template <int H, int P>
+template <int H, int P, bool WG = false>
 static int launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), big, "triplet_bwd_src_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, WG>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
-    GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
-    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    GLAM_PROF_LABEL(WG ? "k_triplet_bwd_src_ws+dx+wgrad" : "k_triplet_bwd_src_ws+dx");
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, WG>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
     return GLAM_OK;
 }
 
@@ -581,26 +680,41 @@ bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
     return !(e && atoi(e) == 0) && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H * Cp + 8 <= 192;
 }
 
+// the weight-gradient products inside the warp-specialised backward launches exist for the reference's head count (layer.py:16: heads = 3);
+// with fewer heads the consumer path would cost the launch its fourth wave per SIMD
+bool triplet_ws_wgrad_supported(int H, int Cp, int De, int edge_onehot) {
+    const char* e = getenv("GLAM_WS_WGRAD");      // opt-in: measured slower than the k_wgrad launch it replaces at both sizes
+    const char* pe = getenv("GLAM_WS_PROD");
+    return e && atoi(e) == 1 && !(pe && atoi(pe) == 4) && H == 3 && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot) &&
+           triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot) && ws_grid_cap(kWsWgradBlocks) <= kWsWgradBlocks;
+}
+
 // B2 + d_x over ELL records by source, warp-specialised (called by triplet_bwd_impl)
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s) {
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* wg_x, float* wg_partial,
+                       int* wg_nsplit) {
     if (N == 0) return GLAM_OK;
     if (!triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
     if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a tensor exceeds 4 GiB (32-bit offsets)");
-    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x};
+    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x, wg_x, wg_partial};
     const int ntiles = (int)((N + 15) / 16);
-    const int cap = ws_grid_cap(1024);
+    const int cap = ws_grid_cap(wg_x ? kWsWgradBlocks : 1024);      // fused weight gradient: one slab set per block in the workspace
     const int grid = ntiles < cap ? ntiles : cap;
+    if (wg_x) {
+        if (!wg_partial || !wg_nsplit || !triplet_ws_wgrad_supported(H, Cp, De, edge_onehot))
+            return fail(GLAM_E_INVALID, "triplet_bwd_src_ws: fused weight gradient without a partial buffer / outside its table (H = 3)");
+        *wg_nsplit = grid;
+    }
     const char* pe = getenv("GLAM_WS_PROD");
     const bool p4 = pe && atoi(pe) == 4;
     int rc = GLAM_OK;
     switch (H) {
         case 1: rc = p4 ? launch_src_ws_p<1, 4>(a, grid, s) : launch_src_ws_p<1, 8>(a, grid, s); break;
         case 2: rc = p4 ? launch_src_ws_p<2, 4>(a, grid, s) : launch_src_ws_p<2, 8>(a, grid, s); break;
-        case 3: rc = p4 ? launch_src_ws_p<3, 4>(a, grid, s) : launch_src_ws_p<3, 8>(a, grid, s); break;
+        case 3: rc = p4 ? launch_src_ws_p<3, 4>(a, grid, s) : wg_x ? launch_src_ws_p<3, 8, true>(a, grid, s) : launch_src_ws_p<3, 8>(a, grid, s); break;
         default: rc = launch_src_ws_p<4, 4>(a, grid, s); break;
     }
     if (rc) return rc;

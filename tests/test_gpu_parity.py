@@ -2015,7 +2015,10 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
     """csrc/triplet_ws.hip (producer waves gather, consumer waves run the update GEMM out of an LDS tile ring; what the op launches for
     molecular graphs at every size) against the general fused kernel AND the barrier-coupled pipelined one: output, the saved aggregate
     and all six gradients equal bit for bit — every head count, padded widths, tile counts that are odd / smaller than the ring / not a
-    multiple of the producer groups, isolated atoms, both producer counts."""
+    multiple of the producer groups, isolated atoms, both producer counts.  Round 4: at the reference's head count (3) the two
+    weight-gradient products are accumulated inside the warp-specialised backward launches (block partials summed in another fixed
+    order: rounding-level differences in the parameter gradients, d_x still bit-equal); ``GLAM_WS_WGRAD=0`` keeps the k_wgrad launch and
+    bit equality, and the fused route launches no k_wgrad."""
     b = synth_batch(B, seed=B + C).to(device)
     torch.manual_seed(C + H)
     conv = layer.TripletMessage(C, 4, heads=H).to(device)
@@ -2030,10 +2033,12 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
     assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 1) == 1
     assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 0) == 0 and lib.glam_triplet_layer_ws_supported(H, Cp, 8, 1) == 0
     res = {}
-    for name, mode, ws, prod in (("general", "0", "1", "8"), ("pipe", "1", "0", "8"), ("ws8", "auto", "1", "8"), ("ws4", "auto", "1", "4")):
+    for name, mode, ws, prod, wg in (("general", "0", "1", "8", "1"), ("pipe", "1", "0", "8", "1"), ("ws8", "auto", "1", "8", "1"),
+                                     ("ws8_nowg", "auto", "1", "8", "0"), ("ws4", "auto", "1", "4", "1")):
         monkeypatch.setattr(ops, "PIPE_FUSED", mode)
         monkeypatch.setenv("GLAM_FWD_WS", ws)
         monkeypatch.setenv("GLAM_WS_PROD", prod)
+        monkeypatch.setenv("GLAM_WS_WGRAD", wg)
         monkeypatch.setenv("GLAM_TORCH_EXT", "0")
         monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
         x = x0.clone().requires_grad_(True)
@@ -2042,15 +2047,21 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
             grads = torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)
         launched = [n for n, _, _ in kt.records()]
         res[name] = (out, grads, launched)
-    for name in ("ws8", "ws4"):      # forward, backward by target (d_aggr inside) and backward by source (+ d_x) on the warp-specialised kernels
+    for name in ("ws8", "ws8_nowg", "ws4"):      # forward, backward by target (d_aggr inside) and backward by source (+ d_x) on the warp-specialised kernels
         for k in ("k_triplet_fwd_ws", "k_triplet_bwd_src_ws") + (("k_triplet_bwd_dst_ws",) if H <= 3 else ()):
             assert any(k in n for n in res[name][2]), (k, res[name][2])
+    fused_wg = H == 3        # the weight-gradient products ride in the backward launches: no k_wgrad launch on that route
+    assert any("wgrad" in n for n in res["ws8"][2]) and any("k_wgrad" in n for n in res["ws8"][2]) != fused_wg, res["ws8"][2]
+    assert any("k_wgrad" in n for n in res["ws8_nowg"][2]) and any("k_wgrad" in n for n in res["ws4"][2])
     assert any("k_triplet_fwd_pipe" in n for n in res["pipe"][2]) and not any("_ws" in n or "_pipe" in n for n in res["general"][2])
     names = ["x", "weight_node", "weight_edge", "weight_triplet_att", "weight_scale", "bias"]
-    for name in ("pipe", "ws8", "ws4"):
+    for name in ("pipe", "ws8", "ws8_nowg", "ws4"):
         assert torch.equal(res["general"][0], res[name][0]), (name, (res["general"][0] - res[name][0]).abs().max().item())
         for pn, a, c in zip(names, res["general"][1], res[name][1]):
-            if name != "pipe" and H <= 3 and pn in ("weight_edge", "weight_triplet_att"):
+            if name == "ws8" and fused_wg and pn != "x":
+                # N-deep sums in another fixed order (256 block partials instead of k_wgrad's row splits)
+                assert_close(c, a, 4e-6, f"{name} d_{pn}")
+            elif name != "pipe" and H <= 3 and pn in ("weight_edge", "weight_triplet_att"):
                 # the warp-specialised B1 sums the d_W_edge / d_M block partials in another (fixed) order: rounding-level differences;
                 # d_x being bit-equal pins every per-edge and per-node quantity of B1 (alpha_e, dpre_e, d_a_i, d_aggr)
                 assert_close(c, a, 2e-6, f"{name} d_{pn}")
