@@ -2034,10 +2034,13 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
     assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 0) == 0 and lib.glam_triplet_layer_ws_supported(H, Cp, 8, 1) == 0
     res = {}
     for name, mode, ws, prod, wg in (("general", "0", "1", "8", "1"), ("pipe", "1", "0", "8", "1"), ("ws8", "auto", "1", "8", "1"),
-                                     ("ws8_nowg", "auto", "1", "8", "0"), ("ws4", "auto", "1", "4", "1")):
+                                     ("ws8_nowg", "auto", "1", "8", "0"), ("ws4", "auto", "1", "4", "1"), ("ws16", "auto", "1", None, "0")):
         monkeypatch.setattr(ops, "PIPE_FUSED", mode)
         monkeypatch.setenv("GLAM_FWD_WS", ws)
-        monkeypatch.setenv("GLAM_WS_PROD", prod)
+        if prod is None:
+            monkeypatch.delenv("GLAM_WS_PROD", raising=False)      # the default: sixteen-wave kernels (rolling row set) where they exist
+        else:
+            monkeypatch.setenv("GLAM_WS_PROD", prod)
         monkeypatch.setenv("GLAM_WS_WGRAD", wg)
         monkeypatch.setenv("GLAM_TORCH_EXT", "0")
         monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
@@ -2047,7 +2050,7 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
             grads = torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)
         launched = [n for n, _, _ in kt.records()]
         res[name] = (out, grads, launched)
-    for name in ("ws8", "ws8_nowg", "ws4"):      # forward, backward by target (d_aggr inside) and backward by source (+ d_x) on the warp-specialised kernels
+    for name in ("ws8", "ws8_nowg", "ws4", "ws16"):      # forward, backward by target (d_aggr inside) and backward by source (+ d_x) on the warp-specialised kernels
         for k in ("k_triplet_fwd_ws", "k_triplet_bwd_src_ws") + (("k_triplet_bwd_dst_ws",) if H <= 3 else ()):
             assert any(k in n for n in res[name][2]), (k, res[name][2])
     fused_wg = H == 3        # the weight-gradient products ride in the backward launches: no k_wgrad launch on that route
@@ -2055,7 +2058,7 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
     assert any("k_wgrad" in n for n in res["ws8_nowg"][2]) and any("k_wgrad" in n for n in res["ws4"][2])
     assert any("k_triplet_fwd_pipe" in n for n in res["pipe"][2]) and not any("_ws" in n or "_pipe" in n for n in res["general"][2])
     names = ["x", "weight_node", "weight_edge", "weight_triplet_att", "weight_scale", "bias"]
-    for name in ("pipe", "ws8", "ws8_nowg", "ws4"):
+    for name in ("pipe", "ws8", "ws8_nowg", "ws4", "ws16"):
         assert torch.equal(res["general"][0], res[name][0]), (name, (res["general"][0] - res[name][0]).abs().max().item())
         for pn, a, c in zip(names, res["general"][1], res[name][1]):
             if name == "ws8" and fused_wg and pn != "x":
