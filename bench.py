@@ -65,11 +65,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "k_triplet_fwd_ws+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
                                     "note": "warp-specialised: 8 producer waves run the software-pipelined aggregate, 4 consumer waves the update GEMM "
                                             "out of an LDS tile ring (csrc/triplet_ws.hip); the op's choice for molecular graphs at every size"},
-        "k_triplet_fwd_pipe+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
-                                      "note": "software-pipelined aggregate + update epilogue: the op's choice beyond the LLC"},
         "k_triplet_fwd": {"bound": "hbm", "bytes": agg_fwd},
         "k_triplet_fwd_pipe": {"bound": "hbm", "bytes": agg_fwd,
-                               "note": "software-pipelined forward aggregate (csrc/triplet_dma.hip), same arithmetic and SURVEY §8(d) byte model"},
+                               "note": "software-pipelined forward aggregate (csrc/triplet_pipe.hip), same arithmetic and SURVEY §8(d) byte model"},
         "k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1},
         # B1 with d_aggr = d_out @ W_scale^T as a per-tile MFMA prologue: d_aggr is written instead of read (same bytes), d_out and the
         # weight image are read in addition
@@ -81,21 +79,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
                                                 "(csrc/triplet_ws_b1.hip)"},
         "k_triplet_bwd_src_ws+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C,
                                     "note": "warp-specialised backward by source with the d_x GEMM as the consumers' product (csrc/triplet_ws.hip)"},
-        # round 4: the two weight-gradient products inside the warp-specialised backward launches (their matrix waves): each launch reads
-        # one more [N, C] / [N, HC] operand (x; aggr a second time) and writes 3 slabs of block partials per block
-        "d_aggr+k_triplet_bwd_dst_ws+wgrad": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC) + f * 3 * 4096 * min(256, (N + 15) // 16),
-                                              "flops": 2 * N * C * HC + 2 * N * (HC + 1) * C,
-                                              "note": "warp-specialised backward by target; its matrix waves produce the d_aggr tiles AND accumulate "
-                                                      "[aggr | 1]^T d_out (d_weight_scale, d_bias) (csrc/triplet_ws_b1.hip)"},
-        "k_triplet_bwd_src_ws+dx+wgrad": {"bound": "hbm", "bytes": b2 + 2 * f * N * C + img(HC + 8, C) + f * 3 * 4096 * min(256, (N + 15) // 16),
-                                          "flops": 2 * N * (HC + 8) * C + 2 * N * (HC + 8) * C,
-                                          "note": "warp-specialised backward by source; its consumer waves run the d_x GEMM AND accumulate "
-                                                  "[d_xw | d_a]^T x (d_weight_node and the attention columns) (csrc/triplet_ws.hip)"},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
-        "k_triplet_bwd_src_pipe": {"bound": "hbm", "bytes": b2,
-                                   "note": "software-pipelined backward by source (ELL records): the op's choice beyond the LLC, followed by the d_x GEMM"},
         "k_ts_gemm<4, 12, 4>": {"bound": "mfma", "flops": 2 * N * (HC + 8) * C, "bytes": f * N * (HC + 8 + C) + img(HC + 8, C),
-                                "note": "d_x = [d_xw | d_a] @ Wcat^T as its own launch (beyond the LLC, behind the pipelined B2)"},
+                                "note": "d_x = [d_xw | d_a] @ Wcat^T as its own launch (general graphs beyond GLAM_FUSE_MAX_NODES)"},
         "k_reduce_partials": {"bound": "latency", "bytes": 0},
         # (the label glam_prof_* reports is the launch expression: the template argument is part of it)
         "k_wgrad<false>": {"bound": "mfma", "flops": 2 * N * (HC + 1) * C + 2 * N * (HC + 8) * C,
@@ -178,9 +164,7 @@ def time_isolated_aggregate(conv, batch, x, reps):
         ws = torch.empty(lib.glam_triplet_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=x.device)
 
     ell = gi.ell()      # index records of the software-pipelined forward (molecules: in-degree <= 4)
-    ell_t = gi.ell_t()  # ... and by source, for the pipelined backward B2
     onehot = int(ops.rows_are_one_hot(ea))
-    alpha_e, dpre_e = torch.rand(E, 4, device=x.device), torch.randn(E, 4, device=x.device)
 
     def body():
         lib.glam_triplet_fwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(gi.rowptr), p(gi.src), p(gi.eid), N, E, H, Cp, Dp, 1,
@@ -191,9 +175,6 @@ def time_isolated_aggregate(conv, batch, x, reps):
         lib.glam_triplet_bwd(p(xw), p(a_ij), p(ea), p(We), p(M), p(aggr), p(stats), p(d_aggr), p(gi.rowptr), p(gi.src),
                              p(gi.eid), p(colptr), p(dst), p(eid_t), N, E, H, Cp, Dp, 1, 0.2, p(d_xw), p(d_a), p(d_we),
                              p(d_M), None, p(ws), ws.numel(), st())
-        if ell_t is not None:
-            lib.glam_triplet_bwd_src_ell(p(d_aggr), p(alpha_e), p(dpre_e), p(ea), p(We), p(ell_t[0]), p(ell_t[1]), N, E, H, Cp, Dp, onehot,
-                                         p(d_xw), p(d_a), 0, st())
     return profile_step(body, reps)
 
 
@@ -276,9 +257,6 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--large-batch", type=int, default=16384, help="extra roofline point beyond the LLC (0 = skip)")
     ap.add_argument("--prof-reps", type=int, default=30, help="eager profiled steps behind roofline_kernels")
-    ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
-                    help="storage of the gathered rows xw (bf16 = BASELINE configs[2] mode: bf16 rows, fp32 arithmetic; "
-                         "the headline metric is fp32)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -313,7 +291,6 @@ def main():
 
     from glam_amd import layer, ops
     from glam_amd.data import synth_batch
-    ops.FEATURE_STORAGE = args.storage
     # one route for everything this script issues: the Python autograd node (what a hipGraph capture records).  Eagerly issued steps would
     # otherwise go through the C++ node of the torch extension (same numbers, but the general kernels instead of the ELL ones), and
     # roofline_kernels — taken from eager executions of the captured function — would describe kernels the timed replay does not launch
@@ -519,7 +496,7 @@ def main():
         "metric": "molecules/sec fwd+bwd on ESOL-shaped batches", "value": value, "unit": "molecules/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.storage == "fp32" else "bf16 rows / f32 arithmetic", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"ESOL-shaped batch={B}/GPU (N={N} atoms, E={E} directed bonds), single "
                                f"TripletMessage({C},{De},heads={H}) layer fwd+bwd, fp32",
                    "launch": launch, "preheat_steps": preheat_steps,
@@ -533,10 +510,7 @@ def main():
 
     if other is not None:
         result["staging_per_step"] = other
-    if rank == 0 and args.storage != "fp32":
-        result["roofline"] = None                  # the roofline legs describe the fp32 kernels: headline mode only
-        print(json.dumps(result), flush=True)
-    elif rank == 0:
+    if rank == 0:
         # ---- roofline: per-dispatch durations of the kernels the timed step launches (same process, same stream, the function
         #      the graph captured, issued eagerly so that every launch can carry its own begin / end events) ----
         model = step_kernel_model(N, E, H, C, De)
@@ -551,7 +525,7 @@ def main():
                     row["note"] = m["note"]
             kernels[name] = row
         step_kernel_us = sum(r["avg_us"] * r["launches_per_step"] for r in prof.values())
-        dom = next((n for n in ("k_triplet_fwd_ws+update", "k_triplet_fwd+update", "k_triplet_fwd_pipe+update") if n in kernels), None)
+        dom = next((n for n in ("k_triplet_fwd_ws+update", "k_triplet_fwd+update") if n in kernels), None)
         if dom is not None:
             k = kernels[dom]
             result["roofline"] = {"kernel": dom + " (what the step launches: gather + segment softmax + scatter-add + aggr @ W_scale + bias "
@@ -600,7 +574,7 @@ def main():
                   "isolated": {n: dict(r, **rate(mb[n], r["avg_us"])) for n, r in ib.items() if n in mb}}
             # frac = the fused forward scatter-aggregate kernel THE STEP LAUNCHES at this size (its update GEMM included, as at B = 1024);
             # the aggregate kernels on their own stay under "isolated"
-            domb = next((n for n in ("k_triplet_fwd_ws+update", "k_triplet_fwd_pipe+update", "k_triplet_fwd+update") if n in rl["step_kernels"]), None)
+            domb = next((n for n in ("k_triplet_fwd_ws+update", "k_triplet_fwd+update") if n in rl["step_kernels"]), None)
             if domb is not None:
                 ki = rl["step_kernels"][domb]
                 rl.update(kernel=domb + " (gather + segment softmax + scatter-add + update GEMM: what the step launches)", achieved=ki["achieved_GBs"],

@@ -26,9 +26,6 @@ SIGNATURES = {
     "glam_prof_read": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]),
     "glam_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "glam_csr_build": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "glam_tile_plan_workspace_bytes": (_sz, [_i64]),
-    "glam_tile_plan": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
-    "glam_triplet_tile_supported": (_i32, [_i32, _i32, _i32]),
     "glam_batch_ptr": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "glam_triplet_fwd": (_i32, [_vp] * 8 + [_i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "glam_triplet_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
@@ -110,14 +107,11 @@ SIGNATURES = {
     "glam_triplet_stage_plain": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
     "glam_triplet_stage_params": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
     "glam_triplet_stage_params_bwd": (_i32, [_vp] * 4 + [_i32] * 5 + [_vp] * 5 + [_vp]),
-    "glam_triplet_layer_fwd": (_i32, [_vp] * 7 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
-    "glam_triplet_layer_fwd_x16": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
-    "glam_triplet_layer_bwd_params_x16": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 10 + [_sz, _vp]),
+    "glam_triplet_layer_fwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_triplet_layer_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "glam_triplet_layer_bwd_params": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 11 + [_sz, _vp]),
     "glam_triplet_layer_bwd_params_acc": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 16 + [_i32, _vp, _vp, _sz, _vp]),
     "glam_triplet_layer_bwd_params_ell": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 18 + [_i32, _vp, _vp, _sz, _vp]),
-    "glam_triplet_bwd_src_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "glam_triplet_layer_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
 }
 

@@ -102,36 +102,13 @@ __device__ __forceinline__ int ldio(const int* base, unsigned byte_off) {
 }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// ---- bf16 STORAGE of gathered feature rows (arithmetic stays fp32): round-to-nearest-even pack, shift unpack ----
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-    const unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;       // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
-    return make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
-}
-__device__ __forceinline__ float4 unpack_bf16x4(uint2 p) {
-    return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16),
-                       __uint_as_float(p.y & 0xffff0000u));
-}
-// A gathered row chunk of 4 channels as it sits in registers between the load and its use: float4, or 8 bytes of bf16
-template <bool XB> struct XwRow;
-template <> struct XwRow<false> {
+// A gathered row chunk of 4 channels as it sits in registers between the load and its use
+struct XwRow {
     typedef float4 T;
     static constexpr unsigned kElem = 4u;
     static __device__ __forceinline__ T load(const float* base, unsigned byte_off) { return ld4o(base, byte_off); }
     static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
     static __device__ __forceinline__ float4 get(T v) { return v; }
-};
-template <> struct XwRow<true> {
-    typedef uint2 T;
-    static constexpr unsigned kElem = 2u;
-    static __device__ __forceinline__ T load(const float* base, unsigned byte_off) {
-        return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + byte_off);
-    }
-    static __device__ __forceinline__ T zero() { return make_uint2(0u, 0u); }
-    static __device__ __forceinline__ float4 get(T v) { return unpack_bf16x4(v); }
 };
 __device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }

@@ -48,29 +48,6 @@ bool prof_slot(const char* kernel, unsigned grid, hipEvent_t* start, hipEvent_t*
     return true;
 }
 
-// ---- side streams ----
-SideStream* side_stream() {
-    static SideStream table[16];
-    static int state[16];          // 0: not tried, 1: ready, -1: unavailable
-    // Opt-in (GLAM_OVERLAP=1).  Measured on MI355X with the B = 1024 step captured in a hipGraph: 126.6 us per step with the
-    // forked branch against 105.7 us serial — a cross-stream dependency inside a graph costs more than the 7-9 us of kernel time it
-    // hides, so the serial schedule stays the default.
-    static const bool enabled = [] { const char* e = getenv("GLAM_OVERLAP"); return e && e[0] == '1'; }();
-    if (!enabled) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (state[dev] == 0) {
-        SideStream& t = table[dev];
-        const bool ok = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess &&
-                        hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&t.mid, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
-        state[dev] = ok ? 1 : -1;
-        if (!ok) (void)hipGetLastError();
-    }
-    return state[dev] == 1 ? &table[dev] : nullptr;
-}
-
 }  // namespace glam
 
 extern "C" int glam_prof_begin(int capacity) {

@@ -140,37 +140,6 @@ __global__ void __launch_bounds__(kBlock) k_batch_ptr(const int64_t* batch, int 
     }
 }
 
-// ---- tile plan: contiguous node ranges closed under the edge set (molecule-aligned cuts) ----
-// diff[p] accumulates +1 / -1 so that its inclusive prefix sum is the number of edges crossing the cut between
-// nodes p-1 and p (integer atomics: order independent)
-__global__ void __launch_bounds__(kBlock) k_tile_cross(const int* rowptr, const int* nbr, int N, int* diff) {
-    for (int n = blockIdx.x * kBlock + threadIdx.x; n < N; n += gridDim.x * kBlock) {
-        for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
-            const int s = nbr[e], u = min(n, s), v = max(n, s);
-            if (u < v) { atomicAdd(&diff[u + 1], 1); atomicAdd(&diff[v + 1], -1); }
-        }
-    }
-}
-// excl[p + 1] = edges crossing cut p.  tile_ptr[t] = first uncrossed cut at or after t*N/T; a tile that outgrows the
-// node / edge capacity raises *err (the caller then keeps the general path)
-__global__ void __launch_bounds__(kBlock) k_tile_bounds(const int* excl, const int* rowptr, int N, int T, int max_nodes,
-                                                       int max_edges, int* tile_ptr, int* err) {
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t <= T; t += gridDim.x * kBlock) {
-        auto cut = [&](int tt) {
-            if (tt >= T) return N;
-            int p = (int)((int64_t)tt * N / T);
-            while (p < N && excl[p + 1] != 0) ++p;
-            return p;
-        };
-        const int b0 = cut(t);
-        tile_ptr[t] = b0;
-        if (t < T) {
-            const int b1 = cut(t + 1);
-            if (b1 - b0 > max_nodes || rowptr[b1] - rowptr[b0] > max_edges) *err = 1;
-        }
-    }
-}
-
 }  // namespace glam
 
 using namespace glam;
@@ -223,37 +192,5 @@ extern "C" int glam_batch_ptr(const int64_t* batch, int64_t N, int64_t B, int32_
     GLAM_REQUIRE(ptr && err_flag && (N == 0 || batch), "glam_batch_ptr: null pointer");
     hipLaunchKernelGGL(k_batch_ptr, dim3(grid_for(N + 1, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, batch, (int)N, (int)B, ptr, err_flag);
     GLAM_LAUNCH_CHECK("glam_batch_ptr");
-    return GLAM_OK;
-}
-
-namespace glam { void tile_limits(int* max_nodes, int* max_edges); }
-
-extern "C" size_t glam_tile_plan_workspace_bytes(int64_t N) {
-    const size_t nb = (size_t)(N + 2 + kScanItems - 1) / kScanItems;
-    return 2 * align_up((size_t)(N + 3) * 4, 256) + align_up((nb + 1) * 4, 256) + 256;
-}
-
-extern "C" int glam_tile_plan(const int32_t* rowptr, const int32_t* nbr, int64_t N, int64_t E, int32_t T, int32_t* tile_ptr,
-                              int32_t* err_flag, void* ws, size_t ws_bytes, void* stream) {
-    GLAM_REQUIRE(N >= 0 && E >= 0 && N < INT32_MAX - 2 && T >= 1, "glam_tile_plan: N / T out of range");
-    GLAM_REQUIRE(rowptr && tile_ptr && err_flag && ws && (E == 0 || nbr), "glam_tile_plan: null pointer");
-    GLAM_REQUIRE(ws_bytes >= glam_tile_plan_workspace_bytes(N), "glam_tile_plan: workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    const int n2 = (int)N + 2;
-    const int nb = (n2 + kScanItems - 1) / kScanItems;
-    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
-    int* diff = reinterpret_cast<int*>(base);
-    int* excl = reinterpret_cast<int*>(base + align_up((size_t)(N + 3) * 4, 256));
-    int* bsums = reinterpret_cast<int*>(base + 2 * align_up((size_t)(N + 3) * 4, 256));
-    (void)hipMemsetAsync(diff, 0, (size_t)n2 * 4, s);
-    if (N > 0 && E > 0) hipLaunchKernelGGL(k_tile_cross, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, s, rowptr, nbr, (int)N, diff);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kBlock), 0, s, diff, n2, bsums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, bsums, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kBlock), 0, s, diff, n2 - 1, bsums, excl);
-    int max_nodes = 0, max_edges = 0;
-    tile_limits(&max_nodes, &max_edges);
-    hipLaunchKernelGGL(k_tile_bounds, dim3(grid_for(T + 1, kBlock)), dim3(kBlock), 0, s, excl, rowptr, (int)N, (int)T, max_nodes,
-                       max_edges, tile_ptr, err_flag);
-    GLAM_LAUNCH_CHECK("glam_tile_plan");
     return GLAM_OK;
 }

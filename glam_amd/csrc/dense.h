@@ -16,15 +16,12 @@ struct TsArgs {
     // optional CELU(alpha = 1) folding for the GRU gate linears of MessageBlock (src_1gp/layer.py:261-262):
     int a_celu;                            // 1: the GEMM consumes celu(A) instead of A
     const float* cgrad_src; int ld_cgrad;  // non-null: out1[r, c] *= celu'(cgrad_src[r, c]) (chain rule through a folded CELU)
-    int out1_bf16;                         // 1: out1 points at bf16[N, ldo1] (round-to-nearest-even; storage of gathered rows)
     const float* addend; int ld_add;       // non-null: out1[r, c] += addend[r, c] last (a second gradient path into the same tensor)
 };
 
 // distance between the 64 x 64 partial slabs of k_wgrad (4096 floats of data each): 16 KB + 256 B, so that the splits of one element —
 // which the reductions read 40 at a time — fall on different memory channels instead of every fourth one
 constexpr int kWgSlabStride = 4096 + 64;
-// blocks of a warp-specialised launch that carries a weight-gradient product (one slab set per block: the workspace holds 3 slabs each)
-constexpr int kWsWgradBlocks = 256;
 
 struct WgArgs {
     const float* P1; int I1; int ldp1;
@@ -63,63 +60,36 @@ bool triplet_fwd_can_fuse_update(int H, int Cp, int De);
 int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
                              const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
                              int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
-                             const float* img_upd, const float* bias_p, float* out, hipStream_t s, int xw_bf16 = 0);
-int triplet_fwd_pipe_fused(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
-                           const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, float slope,
-                           int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s);
-// the same launch warp-specialised (triplet_ws.hip: producer waves gather, consumer waves run the update GEMM; bit-identical)
+                             const float* img_upd, const float* bias_p, float* out, hipStream_t s);
+// forward aggregate + update GEMM over ELL records, warp-specialised (triplet_ws.hip: producer waves gather, consumer waves run the
+// update GEMM; bit-identical to triplet_fwd_fused_update)
 int triplet_fwd_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
                    const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, float slope,
                    int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s);
 bool triplet_fwd_ws_enabled();          // GLAM_FWD_WS (default 1)
 bool triplet_fwd_ws_supported(int H, int Cp, int De, int edge_onehot);
-bool tile_fwd_supported(int H, int Cp, int Dp);
-int tile_fwd_launch(const float* x, const float* edge_attr, const float* img_node, const float* img_upd, const float* we_p,
-                    const float* M, const float* bias_p, const int32_t* rowptr, const int32_t* src, const int32_t* eid,
-                    const int32_t* tile_ptr, int T, int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr,
-                    float* stats, float* out, hipStream_t s);
-// Request / report of the weight-gradient products inside the warp-specialised backward launches: p1 / p2 = slab-partial workspaces
-// (wgrad_workspace_floats() each) of [aggr | 1]^T d_out (B1's matrix waves) and [d_xw | d_a]^T x (B2's consumer waves); `used` and the
-// split counts are filled by triplet_bwd_impl (false: the graph took other kernels and the caller launches k_wgrad itself).
-struct WsWgrad { const float* x; float* p1; float* p2; int ns1; int ns2; bool used; };
 int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
                      const float* aggr, const float* stats, const float* d_aggr, const int32_t* rowptr,
                      const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x, int xw_bf16 = 0, hipEvent_t after_b1 = nullptr,
+                     const float* img_dx, float* d_x,
                      const float* img_dagg = nullptr, const float* d_out = nullptr, const int32_t* ell_dst = nullptr,
                      const int32_t* ell_eid_t = nullptr, int edge_onehot = 0, const int32_t* ell_src = nullptr,
-                     const int32_t* ell_eid = nullptr, WsWgrad* wsw = nullptr);
+                     const int32_t* ell_eid = nullptr);
 // B1 with the d_aggr GEMM inside, warp-specialised (triplet_ws_b1.hip: matrix waves produce the d_aggr tiles ahead of the vector waves)
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
                        const float* stats, const float* d_out, const float* img_dagg, const int32_t* ell_src, const int32_t* ell_eid,
                        int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot, float slope, float* d_aggr, float* alpha_e,
-                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s, float* wg_partial = nullptr);
-// (wg_partial non-null: the matrix waves also accumulate [aggr | 1]^T d_out, *nblk_out block partials per slab in k_wgrad's slab format)
-// B2 over ELL records by source (triplet_dma.hip: software-pipelined, bit-identical to k_triplet_bwd_src)
-int triplet_bwd_src_pipe(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
-                         const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                         float* d_xw, float* d_a_ij, int grid_blocks, hipStream_t s);
+                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s);
 // B2 + d_x = [d_xw | d_a] @ Wcat^T in one warp-specialised launch (triplet_ws.hip; one-hot edge features of width 4)
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot);
-// wg_x non-null: the consumer waves also accumulate the weight-gradient product [d_xw | d_a]^T x into `wg_partial` (k_wgrad slab format,
-// *wg_nsplit block partials per slab: what launch_wgrad_partials would have produced, without the launch)
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* wg_x = nullptr,
-                       float* wg_partial = nullptr, int* wg_nsplit = nullptr);
-bool triplet_ws_wgrad_supported(int H, int Cp, int De, int edge_onehot);     // both weight-gradient products inside the WS backward launches
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De);
-
-// A library-owned side stream per device, for work inside ONE entry point that does not depend on the main chain (e.g. the
-// weight-gradient product that only needs forward activations while the main stream walks d_aggr -> B1 -> B2).  Fork / join
-// by events, so the pattern is legal inside a hipGraph capture (the side stream joins the capture and is rejoined before the
-// entry point returns).  nullptr unless GLAM_OVERLAP=1 (see core.hip for the measurement): callers then run the serial sequence.
-struct SideStream { hipStream_t s; hipEvent_t fork, mid, join; };
-SideStream* side_stream();
 
 }  // namespace glam

@@ -246,10 +246,8 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
                         const int rr = tile * 16 + kq * 4 + i;
                         if (rr >= a.N) continue;
                         const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
-                        if (m0 < a.M1) {
-                            if (!RB && a.out1_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out1) + (size_t)rr * a.ldo1 + m0) = pack_bf16x4(v);
-                            else st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
-                        } else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                        if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                        else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
                     }
                 }
             } else {
@@ -554,7 +552,7 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
-    else if (variant == 1 && !b && ts_rb_enabled() && a.K2 == 0 && !a.a_celu && !a.cgrad_src && !a.addend && !a.out1_bf16) {
+    else if (variant == 1 && !b && ts_rb_enabled() && a.K2 == 0 && !a.a_celu && !a.cgrad_src && !a.addend) {
         // the register-B form is the plain product only (one A source, no folded CELU, no gradient epilogue, fp32 out): its registers
         // decide its occupancy
         two.first_b = ts_rb_grid(a.N);
@@ -563,7 +561,6 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
         else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 512>), dim3(two.first_b), dim3(512), 0, s, two);
     } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else {
-        if (a.out1_bf16 || (b && b->out1_bf16)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: bf16 output is limited to the 48 KB-image variants");
         static bool big2 = false;      // > 64 KB of dynamic LDS is opted into once
         if (!big2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ts_gemm<20, 6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -581,12 +578,7 @@ constexpr int kWgradBlocksBig = 512;   // two per CU (four waves per SIMD) once 
 constexpr int kWgradBigRows = 131072;
 static int wgrad_budget(int N) { return N >= kWgradBigRows ? kWgradBlocksBig : kWgradBlocks; }
 
-// per product: one 64 x 64 slab per block of k_wgrad — or, when the product is accumulated inside a warp-specialised backward launch
-// (triplet_ws*.hip), three slabs for each of its kWsWgradBlocks blocks
-size_t wgrad_workspace_floats() {
-    const size_t own = (size_t)(kWgradBlocksBig + 24) * kWgSlabStride, fused = (size_t)3 * kWsWgradBlocks * kWgSlabStride;
-    return own > fused ? own : fused;
-}
+size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per block
 
 // fills the launch geometry of one product (at most `budget` blocks) and the matching reduce job
 static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {
@@ -718,8 +710,8 @@ extern "C" int glam_ts_gemm_pair(const float* Aa, int Ka, int lda, int a_celu_a,
                      aligned16(Ab) && aligned16(Wimg_b) && aligned16(out_b) && aligned16(bias_b) && aligned16(cgrad_b) && aligned16(addend_b) &&
                      !(ld_cgrad_a & 3) && !(ld_cgrad_b & 3) && !(ld_add_a & 3) && !(ld_add_b & 3),
                  "glam_ts_gemm_pair: pointers must be 16-byte aligned, leading dimensions multiples of 4");
-    TsArgs a{Aa, Ka, lda, nullptr, 0, 0, Wimg_a, bias_a, out_a, Ma, ldo_a, nullptr, 0, 0, (int)N, a_celu_a, cgrad_a, ld_cgrad_a, 0, addend_a, ld_add_a};
-    TsArgs b{Ab, Kb, ldb, nullptr, 0, 0, Wimg_b, bias_b, out_b, Mb, ldo_b, nullptr, 0, 0, (int)N, a_celu_b, cgrad_b, ld_cgrad_b, 0, addend_b, ld_add_b};
+    TsArgs a{Aa, Ka, lda, nullptr, 0, 0, Wimg_a, bias_a, out_a, Ma, ldo_a, nullptr, 0, 0, (int)N, a_celu_a, cgrad_a, ld_cgrad_a, addend_a, ld_add_a};
+    TsArgs b{Ab, Kb, ldb, nullptr, 0, 0, Wimg_b, bias_b, out_b, Mb, ldo_b, nullptr, 0, 0, (int)N, a_celu_b, cgrad_b, ld_cgrad_b, addend_b, ld_add_b};
     return launch_ts_gemm2(a, &b, (hipStream_t)stream);
 }
 
@@ -731,7 +723,7 @@ extern "C" int glam_ts_gemm_add(const float* A, int K, int lda, const float* Wim
     GLAM_REQUIRE(A && Wimg && out && addend, "glam_ts_gemm_add: null pointer");
     GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias) && aligned16(addend) && (ld_add & 3) == 0,
                  "glam_ts_gemm_add: pointers must be 16-byte aligned");
-    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N, 0, nullptr, 0, 0, addend, ld_add};
+    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N, 0, nullptr, 0, addend, ld_add};
     return launch_ts_gemm(a, (hipStream_t)stream);
 }
 

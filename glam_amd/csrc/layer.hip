@@ -587,20 +587,14 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
 // The fused-GEMM variants of the aggregate kernels (forward + update, B2 + d_x) keep a 48 KB weight image per block in LDS: two
 // 4-wave blocks per CU.  That wins while the launch is latency bound (B = 1024: 16.6 us against 9.7 + 11 + a launch boundary) and
 // loses once the batch is large enough for the aggregate to need its full occupancy (B = 16 384: 249 us fused against 134 + 62).
-// smallest batch (nodes) whose weight-gradient products are accumulated inside the warp-specialised backward launches
-static int64_t ws_wgrad_min_nodes() {
-    static const int64_t v = [] { const char* e = getenv("GLAM_WS_WGRAD_MIN_NODES"); return e ? atoll(e) : (int64_t)0; }();
-    return v;
-}
 static int64_t fuse_max_nodes() {
     static const int64_t v = [] { const char* e = getenv("GLAM_FUSE_MAX_NODES"); return e ? atoll(e) : (int64_t)1 << 40; }();
     return v;
 }
 
-static int layer_fwd_impl(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                          const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T, int64_t N, int64_t E,
-                          int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out,
-                          void* stream, int xw_bf16) {
+extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
+                                      const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
+                                      float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream) {
     if (int rc = dims_ok("glam_triplet_layer_fwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd: N out of range");
     if (N == 0) return GLAM_OK;
@@ -610,19 +604,11 @@ static int layer_fwd_impl(const float* x, const float* edge_attr, const float* s
     hipStream_t s = (hipStream_t)stream;
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
-    if (xw_bf16 && (tile_ptr || !triplet_fwd_can_fuse_update(H, Cp, Dp)))
-        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_layer_fwd_x16: bf16 row storage needs 36 <= Cp <= 64, H*Cp <= 192 and no tile plan");
-    if (tile_ptr) {   // whole layer in one launch, one block per molecule tile
-        GLAM_REQUIRE(T >= 1 && rowptr && (E == 0 || (src && eid && edge_attr)), "glam_triplet_layer_fwd: bad tile plan / CSR");
-        return tile_fwd_launch(x, edge_attr, staged + L.img_node, staged + L.img_upd, staged + L.we_p, staged + L.m,
-                               staged + L.bias_p, rowptr, src, eid, tile_ptr, T, H, Cp, Dp, slope, xw, a_ij, aggr, stats, out, s);
-    }
     TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
-    g1.out1_bf16 = xw_bf16;
     if (int rc = launch_ts_gemm(g1, s)) return rc;
-    if (triplet_fwd_can_fuse_update(H, Cp, Dp) && (xw_bf16 || N <= fuse_max_nodes()))   // aggregate + update GEMM in one launch
+    if (triplet_fwd_can_fuse_update(H, Cp, Dp) && N <= fuse_max_nodes())   // aggregate + update GEMM in one launch
         return triplet_fwd_fused_update(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp,
-                                        Dp, slope, aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s, xw_bf16);
+                                        Dp, slope, aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
     if (int rc = glam_triplet_fwd(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, rowptr, src, eid, N, E, H, Cp, Dp, 1,
                                   slope, aggr, stats, stream))
         return rc;
@@ -630,16 +616,8 @@ static int layer_fwd_impl(const float* x, const float* edge_attr, const float* s
     return launch_ts_gemm(g2, s);
 }
 
-extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                                      const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T,
-                                      int64_t N, int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij,
-                                      float* aggr, float* stats, float* out, void* stream) {
-    return layer_fwd_impl(x, edge_attr, staged, rowptr, src, eid, tile_ptr, T, N, E, H, Cp, Dp, slope, xw, a_ij, aggr, stats, out,
-                          stream, 0);
-}
-
-// Molecular graphs (in-degree <= 4, ELL index records from glam_ell_build): node GEMM, then the software-pipelined aggregate with
-// the update GEMM as its epilogue (csrc/triplet_dma.hip) — same outputs as glam_triplet_layer_fwd, bit for bit.
+// Molecular graphs (in-degree <= 4: ELL index records from glam_ell_build; one-hot bond features of width 4): node GEMM, then the
+// warp-specialised aggregate + update launch (csrc/triplet_ws.hip) — same outputs as glam_triplet_layer_fwd, bit for bit.
 extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
                                           const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp,
                                           float slope, float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream) {
@@ -650,34 +628,21 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
                  "glam_triplet_layer_fwd_ell: null pointer");
     GLAM_REQUIRE(aligned16(x) && aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(out) && aligned16(staged) &&
                      aligned16(edge_attr) && aligned16(stats), "glam_triplet_layer_fwd_ell: 16-byte alignment");
-    if (!triplet_fwd_can_fuse_update(H, Cp, Dp))
-        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_layer_fwd_ell: no fused update for H=%d Cp=%d (36 <= Cp <= 64, H*Cp <= 192)", H, Cp);
+    if (!(triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot)))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_layer_fwd_ell: the ELL route needs one-hot edge features of width 4, 36 <= Cp <= 64, H*Cp <= 192 "
+                    "(H=%d Cp=%d Dp=%d onehot=%d; glam_triplet_layer_ws_supported)", H, Cp, Dp, edge_onehot);
     hipStream_t s = (hipStream_t)stream;
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
     TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
     if (int rc = launch_ts_gemm(g1, s)) return rc;
-    if (triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot))
-        return triplet_fwd_ws(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
-                              aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
-    return triplet_fwd_pipe_fused(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
-                                  aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
+    return triplet_fwd_ws(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
+                          aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
 }
 
 extern "C" int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot) {
     return (triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot)) ? 1 : 0;
 }
-
-// bf16 STORAGE of the gathered rows (BASELINE config 3): xw16 is bf16[N, H*Cp]; logits, softmax and sums stay fp32
-extern "C" int glam_triplet_layer_fwd_x16(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                                          const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
-                                          float slope, void* xw16, float* a_ij, float* aggr, float* stats, float* out,
-                                          void* stream) {
-    return layer_fwd_impl(x, edge_attr, staged, rowptr, src, eid, nullptr, 0, N, E, H, Cp, Dp, slope,
-                          reinterpret_cast<float*>(xw16), a_ij, aggr, stats, out, stream, 1);
-}
-
-extern "C" int glam_triplet_tile_supported(int H, int Cp, int Dp) { return tile_fwd_supported(H, Cp, Dp) ? 1 : 0; }
 
 extern "C" size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp) {
     const size_t HC = (size_t)H * Cp;
@@ -698,7 +663,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                           const int32_t* rowptr, const int32_t* src, const int32_t* eid,
                           const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
                           int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
-                          float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po, int xw_bf16 = 0,
+                          float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po,
                           const int32_t* ell_dst = nullptr, const int32_t* ell_eid_t = nullptr, int edge_onehot = 0,
                           const int32_t* ell_src = nullptr, const int32_t* ell_eid = nullptr) {
     if (int rc = dims_ok("glam_triplet_layer_bwd", Cp, H, Dp, Cp, Dp)) return rc;
@@ -723,19 +688,8 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     ReduceArgs ra{};
     ra.njobs = 3;
 
-    // Schedule (parameter-gradient path).  The main stream walks the dependent chain d_aggr -> B1 -> B2 (+ d_x) -> d_Wcat product ->
-    // its share of the parameter gradients; everything that only needs forward activations or finished partials runs beside it on
-    // the library's side stream: the d_W_scale | d_bias product ([aggr | 1]^T d_out) from the very start, and — once B1's block
-    // partials exist — the d_weight_scale / d_bias / d_weight_edge reductions.  Each of these launches is latency bound on its own
-    // (~3 us of fixed dispatch cost inside a 7-15 us kernel), so overlapping them shortens the step without touching a kernel.
-    SideStream* ss = po ? side_stream() : nullptr;
     WgArgs w1{aggr, HC, HC, nullptr, 0, 0, 1, d_out, Cp, Cp, 0, (int)N, 0, wg1, 0, 0};
     WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0, 0};
-    if (ss) {
-        (void)hipEventRecord(ss->fork, s);
-        (void)hipStreamWaitEvent(ss->s, ss->fork, 0);
-        if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, ss->s, &ra.job[0])) return rc;
-    }
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
     // (inside B1 where a fused variant exists: one launch and one [N, HC] round trip less)
     static const bool fuse_dagg_on = [] { const char* e = getenv("GLAM_FUSE_DAGG"); return !e || atoi(e) != 0; }();
@@ -746,34 +700,22 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     }
     const float* tpart = nullptr;
     int tnblk = 0;
-    // d_x = [d_xw | d_a] @ Wcat^T inside B2 — unless the caller supplied ELL records by source: the pipelined B2 + its own GEMM launch
-    const bool use_ell = ell_dst && ell_eid_t && Cp <= 64;
-    const bool ws_dx = use_ell && triplet_bwd_src_ws_supported(H, Cp, Dp, edge_onehot);     // B2 + d_x in one warp-specialised launch
-    const bool fuse_dx = ws_dx || (!use_ell && triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes());
-    // molecular graphs (both launches warp-specialised): the two weight-gradient products ride in those launches' matrix waves
-    // (round 4; below ws_wgrad_min_nodes() the 2 x 3 x 256 slabs of block partials cost more than the k_wgrad launch they replace)
-    WsWgrad wsw{x, wg1, wg2, 0, 0, false};
-    const bool try_wg = !ss && !xw_bf16 && N >= ws_wgrad_min_nodes() && triplet_ws_wgrad_supported(H, Cp, Dp, edge_onehot);
+    // d_x = [d_xw | d_a] @ Wcat^T inside B2: warp-specialised over the caller's ELL records by source, or as the general kernel's epilogue
+    const bool ws_dx = ell_dst && ell_eid_t && Cp <= 64 && triplet_bwd_src_ws_supported(H, Cp, Dp, edge_onehot);
+    const bool fuse_dx = ws_dx || (triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes());
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
-                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr, xw_bf16, ss ? ss->mid : nullptr,
-                                  fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr, use_ell ? ell_dst : nullptr,
-                                  use_ell ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, try_wg ? &wsw : nullptr))
+                                  fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr,
+                                  fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr, ws_dx ? ell_dst : nullptr,
+                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
-    if (wsw.used) {     // already accumulated: describe the partial sets for the reductions (k_wgrad's slab format, split = block)
-        ra.job[0] = ReduceJob{0, wg1, wsw.ns1, (HC + 1 + 63) / 64 * 4096, HC + 1, Cp, Cp, 1, dstaged + G.d_wsb, nullptr, 0, 0};
-        ra.job[2] = ReduceJob{0, wg2, wsw.ns2, (HC + 8 + 63) / 64 * 4096, HC + 8, Cp, 1, HC + 8, dstaged + G.d_wcat, nullptr, 0, 0};
-    } else if (ss) {
-        if (int rc = launch_wgrad_partials(w2, dstaged + G.d_wcat, 1, HC + 8, s, &ra.job[2])) return rc;
-    } else if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8,
-                                               &ra.job[2], s)) {   // serial schedule: both products in ONE launch
-        return rc;
-    }
+    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s))
+        return rc;      // both products in ONE launch
     // d_x = [d_xw | d_a] @ Wcat^T
     if (!fuse_dx) {
         TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
@@ -785,21 +727,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
                          (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
-        if (ss) {
-            // side: roles A (d_weight_scale, d_bias <- product 1) and D (d_weight_edge <- B1 partials + d_M), after B1
-            ParamGradArgs pa = pg;
-            pa.blocksB = pa.blocksC = 0;
-            (void)hipStreamWaitEvent(ss->s, ss->mid, 0);
-            hipLaunchKernelGGL(k_param_grads, dim3(pa.blocksA + blocksD), dim3(kBlock), 0, ss->s, pa);
-            (void)hipEventRecord(ss->join, ss->s);
-            // main: roles B (d_weight_node) and C (d_weight_triplet_att) <- product 2 (+ d_M from the B1 partials)
-            ParamGradArgs pb = pg;
-            pb.blocksA = 0;
-            hipLaunchKernelGGL(k_param_grads, dim3(pb.blocksB + pb.blocksC), dim3(kBlock), 0, s, pb);
-            (void)hipStreamWaitEvent(s, ss->join, 0);
-        } else {
-            hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
-        }
+        hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
         GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
         return GLAM_OK;
     }
@@ -868,7 +796,7 @@ extern "C" int glam_triplet_layer_bwd_params_acc(const float* x, const float* ed
     const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias,
                       add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
     return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
-                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po, 0, ell_dst, ell_eid_t, edge_onehot);
+                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po, ell_dst, ell_eid_t, edge_onehot);
 }
 
 // The same with the ELL index records of BOTH directions (glam_ell_build on the CSR by target and on its transpose; either pair may be
@@ -894,22 +822,5 @@ extern "C" int glam_triplet_layer_bwd_params_ell(const float* x, const float* ed
     const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias,
                       add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
     return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
-                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po, 0, ell_dst, ell_eid_t, edge_onehot, ell_src, ell_eid);
-}
-
-extern "C" int glam_triplet_layer_bwd_params_x16(const float* x, const float* edge_attr, const float* staged, const void* xw16,
-                                                 const float* a_ij, const float* aggr, const float* stats, const float* d_out,
-                                                 const int32_t* rowptr, const int32_t* src, const int32_t* eid,
-                                                 const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
-                                                 int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
-                                                 const float* weight_node, const float* weight_edge, const float* att, float* d_x,
-                                                 float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
-                                                 float* d_bias, void* ws, size_t ws_bytes, void* stream) {
-    if (int rc = dims_ok("glam_triplet_layer_bwd_params_x16", C, H, De, Cp, Dp)) return rc;
-    GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
-                 "glam_triplet_layer_bwd_params_x16: null pointer");
-    if (N == 0) return zero_param_grads(C, H, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, stream);
-    const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias};
-    return layer_bwd_impl(x, edge_attr, staged, reinterpret_cast<const float*>(xw16), a_ij, aggr, stats, d_out, rowptr, src, eid,
-                          colptr, dst, eid_t, N, E, H, Cp, Dp, slope, d_x, nullptr, nullptr, ws, ws_bytes, stream, &po, 1);
+                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po, ell_dst, ell_eid_t, edge_onehot, ell_src, ell_eid);
 }

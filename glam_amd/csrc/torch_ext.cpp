@@ -145,7 +145,7 @@ struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
                                                 Dp, (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()),
                      "glam_triplet_layer_fwd_ell");
         } else {
-            check_rc(glam_triplet_layer_fwd(fp(x), fp(edge_attr), fp(staged), ip(rowptr), ip(src), ip(eid), nullptr, 0, N, E, (int)H, Cp, Dp,
+            check_rc(glam_triplet_layer_fwd(fp(x), fp(edge_attr), fp(staged), ip(rowptr), ip(src), ip(eid), N, E, (int)H, Cp, Dp,
                                             (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()), "glam_triplet_layer_fwd");
         }
         const bool ell_b = ell_dst.has_value() && ell_dst->defined() && ell_eid_t.has_value() && ell_eid_t->defined();

@@ -98,11 +98,11 @@ bool triplet_fwd_can_fuse_update(int H, int Cp, int De) {
 int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,
                              const float* M, const int32_t* rowptr, const int32_t* src, const int32_t* eid, int64_t N,
                              int64_t E, int H, int Cp, int De, float slope, float* aggr, float* stats,
-                             const float* img_upd, const float* bias_p, float* out, hipStream_t s, int xw_bf16) {
+                             const float* img_upd, const float* bias_p, float* out, hipStream_t s) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_fwd(fused)", N, E, H, Cp, De, &sh)) return rc;
     if (N == 0) return GLAM_OK;
-    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out, xw_bf16};
+    FwdArgs a{xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, (int)N, Cp, slope, aggr, stats, img_upd, bias_p, out};
     const size_t lds = ((size_t)De * H * Cp + 16 * (size_t)(H * Cp + 4) + 16 * 64 + (size_t)((H * Cp + 15) & ~15) * 64) * sizeof(float);
     GLAM_PROF_LABEL("k_triplet_fwd+update");
     if (!dispatch(kTripletFwd, H, De, 1, sh, a, (int)N, lds, s, kFusedBlocks, nullptr))
@@ -124,13 +124,11 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const int32_t* eid_t, int64_t N, int64_t E, int H, int Cp, int De, int emul, float slope,
                      float* d_xw, float* d_a_ij, float* d_w_edge, float* d_M, float* d_edge_attr, void* ws,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
-                     const float* img_dx, float* d_x, int xw_bf16, hipEvent_t after_b1, const float* img_dagg,
+                     const float* img_dx, float* d_x, const float* img_dagg,
                      const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot, const int32_t* ell_src,
-                     const int32_t* ell_eid, WsWgrad* wsw) {
+                     const int32_t* ell_eid) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
-    if (xw_bf16 && !(sh.G == 16 && sh.ITER == 1 && emul && !d_edge_attr))
-        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: bf16 row storage needs 36 <= Cp <= 64, the multi-head message and no d_edge_attr");
     const int WSZ = emul ? De * H * Cp : 0;
     const int P = WSZ + De * 4;
     GLAM_REQUIRE(xw && a_ij && M && aggr && stats && d_aggr && rowptr && colptr && d_xw && d_a_ij && ws,
@@ -152,20 +150,15 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     if ((img_dagg || d_out) && !fuse_dagg) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_aggr variant for H=%d Cp=%d", H, Cp);
     int nblk = 0;
     // molecular graphs with one-hot bond features: the warp-specialised B1 (matrix waves produce the d_aggr tiles ahead of the vector waves)
-    const bool b1_ws = ell_src && ell_eid && fuse_dagg && !d_edge_attr && !xw_bf16 && triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot);
+    const bool b1_ws = ell_src && ell_eid && fuse_dagg && !d_edge_attr && triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot);
     const bool b2_ws = ell_dst && ell_eid_t && emul && Cp <= 64 && img_dx && d_x && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot);
-    // both weight-gradient products inside the two warp-specialised launches (the caller then skips its k_wgrad launch)
-    const bool fuse_wg = wsw && b1_ws && b2_ws && wsw->x && wsw->p1 && wsw->p2 && triplet_ws_wgrad_supported(H, Cp, De, edge_onehot);
-    if (wsw) wsw->used = fuse_wg;
     if (b1_ws) {
         if (int rc = triplet_bwd_dst_ws(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, N, E, H, Cp, De,
-                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s,
-                                        fuse_wg ? wsw->p1 : nullptr))
+                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s))
             return rc;
-        if (fuse_wg) wsw->ns1 = nblk;
     } else {
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,
-                  alpha_e, dpre_e, d_a_ij, partial, red_groups, xw_bf16,
+                  alpha_e, dpre_e, d_a_ij, partial, red_groups,
                   fuse_dagg ? img_dagg : nullptr, fuse_dagg ? d_out : nullptr, fuse_dagg ? const_cast<float*>(d_aggr) : nullptr};
     const size_t red_floats = (size_t)red_groups * P;
     const size_t img_floats = (size_t)((Cp + 15) & ~15) * (H * Cp <= 64 ? 64 : 192) + 16 * (size_t)(H * Cp + 4) + 16 * 64;   // image, d_aggr tile, A tile
@@ -175,7 +168,6 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
         return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
     GLAM_LAUNCH_CHECK("glam_triplet_bwd(B1)");
     }
-    if (after_b1) (void)hipEventRecord(after_b1, s);      // the B1 block partials are complete: a side stream may reduce them
     if (reduce_now) {
         hipLaunchKernelGGL(k_reduce_partials, dim3((P + 15) / 16), dim3(kBlock), 0, s, partial, nblk, P, WSZ, d_w_edge, d_M);
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(reduce)");
@@ -190,17 +182,10 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
             return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no kernel for H=%d De=%d emul=%d", H, De, emul);
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
     }
-    if (ell_dst && ell_eid_t && emul && Cp <= 64) {
-        // molecular graphs: B2 over ELL records by source — warp-specialised with the d_x GEMM inside where that kernel exists, the
-        // software-pipelined B2 alone otherwise (no fused d_x there: the caller runs the GEMM)
-        if (b2_ws)
-            return triplet_bwd_src_ws(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
-                                      d_a_ij, img_dx, d_x, s, fuse_wg ? wsw->x : nullptr, fuse_wg ? wsw->p2 : nullptr,
-                                      fuse_wg ? &wsw->ns2 : nullptr);
-        if (img_dx || d_x) return fail(GLAM_E_INVALID, "glam_triplet_bwd: the ELL route of B2 has no fused d_x for these shapes");
-        return triplet_bwd_src_pipe(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
-                                    d_a_ij, 0, s);
-    }
+    // molecular graphs with one-hot bond features: B2 over ELL records by source with the d_x GEMM inside, warp-specialised
+    if (b2_ws)
+        return triplet_bwd_src_ws(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
+                                  d_a_ij, img_dx, d_x, s);
     const bool fuse_dx = img_dx && d_x && triplet_bwd_can_fuse_dx(H, Cp, De) && emul;
     if ((img_dx || d_x) && !fuse_dx) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_x variant for H=%d Cp=%d", H, Cp);
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij,
@@ -230,20 +215,5 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-}
-
-// B2 alone over ELL records by source (tests, isolated timing): d_xw[N, H*Cp], d_a_ij[N, 8] (the a_j half, columns 4..7, is written)
-extern "C" int glam_triplet_bwd_src_ell(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr,
-                                        const float* w_edge, const int32_t* ell_dst, const int32_t* ell_eid_t, int64_t N, int64_t E, int H,
-                                        int Cp, int De, int edge_onehot, float* d_xw, float* d_a_ij, int grid_blocks, void* stream) {
-    GLAM_REQUIRE(N >= 0 && N < INT32_MAX && E >= 0, "glam_triplet_bwd_src_ell: N / E out of range");
-    if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(d_aggr && alpha_e && dpre_e && w_edge && ell_dst && ell_eid_t && d_xw && d_a_ij && (E == 0 || edge_attr),
-                 "glam_triplet_bwd_src_ell: null pointer");
-    GLAM_REQUIRE(aligned16(d_aggr) && aligned16(alpha_e) && aligned16(dpre_e) && aligned16(edge_attr) && aligned16(w_edge) &&
-                     aligned16(ell_dst) && aligned16(ell_eid_t) && aligned16(d_xw) && aligned16(d_a_ij),
-                 "glam_triplet_bwd_src_ell: pointers must be 16-byte aligned");
-    return triplet_bwd_src_pipe(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw, d_a_ij,
-                                grid_blocks, (hipStream_t)stream);
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }

@@ -58,7 +58,6 @@ struct FwdArgs {
     float* aggr; float* stats;
     // optional fused update (G == 16 only): out[N,Cp] = aggr @ W_scale + bias, W_scale as a k_ts_gemm image
     const float* img_upd; const float* bias_p; float* out;
-    int xw_bf16;      // xw holds bf16[N, H*Cp] (storage only; G == 16, ITER == 1 variants)
 };
 
 template <int DE>
@@ -98,9 +97,9 @@ __device__ __forceinline__ float4 edge_chunk(const float* s_w, const float (&ea)
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int H, int G, int ITER, int DE, bool EMUL, bool XB = false>
+template <int H, int G, int ITER, int DE, bool EMUL>
 __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs a) {
-    typedef XwRow<XB> XR;
+    typedef XwRow XR;
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const int tid = threadIdx.x;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
@@ -353,15 +352,14 @@ struct BwdDstArgs {
     int N; int Cp; float slope;
     float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;
     int red_groups;   // rows of the LDS reduction buffer: kBlock / G (every lane group stores its own partial) or 4
-    int xw_bf16;      // see FwdArgs
     // optional fused prologue (FD variants: G == 16, ITER == 1): d_aggr[16-node tile] = d_out[tile, Cp] @ W_scale^T on the fp32
     // matrix cores, W_scale^T as a k_ts_gemm image (K = Cp, M = H*Cp).  d_aggr is then an OUTPUT (B2 reads it back).
     const float* img_dagg; const float* d_out; float* d_aggr_w;
 };
 
-template <int H, int G, int ITER, int DE, bool EMUL, bool XB = false, bool FD = false>
+template <int H, int G, int ITER, int DE, bool EMUL, bool FD = false>
 __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k_triplet_bwd_dst(BwdDstArgs a) {
-    typedef XwRow<XB> XR;
+    typedef XwRow XR;
     typedef float v4f __attribute__((ext_vector_type(4)));
     static_assert(!FD || (G == 16 && ITER == 1), "the fused d_aggr prologue maps one 16-lane group to one MFMA tile row");
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
@@ -975,18 +973,6 @@ struct FwdOp {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             big_lds = true;
         }
-        if constexpr (G == 16 && ITER == 1 && EMUL) {
-            if (a.xw_bf16) {
-                static bool big_lds16 = false;
-                if (lds > 64 * 1024 && !big_lds16) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_fwd<H, G, ITER, DE, EMUL, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                    big_lds16 = true;
-                }
-                hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL, true>), dim3(grid), dim3(kBlock), lds, s, a);
-                return;
-            }
-        }
         hipLaunchKernelGGL((k_triplet_fwd<H, G, ITER, DE, EMUL>), dim3(grid), dim3(kBlock), lds, s, a);
     }
 };
@@ -997,17 +983,10 @@ struct BwdDstOp {
             if (a.img_dagg) {
                 static bool big_lds = false;
                 if (lds > 64 * 1024 && !big_lds) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true, true>),
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
                     big_lds = true;
                 }
-                if (a.xw_bf16) hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true, true>), dim3(grid), dim3(kBlock), lds, s, a);
-                else hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, false, true>), dim3(grid), dim3(kBlock), lds, s, a);
-                return;
-            }
-            if (a.xw_bf16) {
                 hipLaunchKernelGGL((k_triplet_bwd_dst<H, G, ITER, DE, EMUL, true>), dim3(grid), dim3(kBlock), lds, s, a);
                 return;
             }

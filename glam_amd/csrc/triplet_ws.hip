@@ -33,7 +33,7 @@
 namespace glam {
 
 #ifdef GLAM_WS_PROF   // developer aid (tools/ws_prof.py): where the producer / consumer waves spend their cycles
-__device__ long long g_ws_prof[64 * 16 * 8];
+__device__ long long g_ws_prof[64 * 12 * 8];
 #define WSTAMP(k) do { const long long now__ = clock64(); pacc[k] += now__ - plast; plast = now__; } while (0)
 #else
 #define WSTAMP(k) do { } while (0)
@@ -53,19 +53,8 @@ __device__ long long g_ws_prof[64 * 16 * 8];
 // (Two tiles per trip with alternating accumulator chains — a 16x16x4 fp32 MFMA issues every 32 cycles but feeds the next one of its own
 // chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
 // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
-//
-// WG (round 4): the same waves also accumulate the WEIGHT-GRADIENT product of the tile they hold, G[i, j] = sum over the nodes n of
-// tile[n, i] * Q[n, j] (B2: tile = [d_xw | d_a_i | d_a_j], Q = x: the gradient of [W_node | Wa_i | Wa_j], the autograd of
-// src_1gp/layer.py:37), so that the N-deep product needs no launch and no second read of d_xw: wave w owns the columns j = 4 c + w of Q
-// (one scalar per lane and 4-row step, prefetched a tile ahead) and reads the tile's rows 4 st + kq as float4 A operands — the operand
-// layout of k_wgrad (gemm.hip), whose 64 x 64 slab format the block partial is written in (one slab set per block, split index =
-// blockIdx.x), so the fixed-order reductions of k_param_grads / k_final_reduce read it unchanged.  Rows past N are zero in the tile
-// (the producers publish zeros), Q is read with clamped (finite) addresses; accumulators of the pad rows i >= K and pad columns
-// j >= Cp hold garbage that no reduction reads.
-template <bool WG>
 __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
-                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane,
-                                           const float* wg_q, float* wg_partial WS_PROF_PARAMS) {
+                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int c = lane & 15, kq = lane >> 4;
     const int GK = (K + 15) >> 4;                             // 16-k groups, <= 12
@@ -75,26 +64,6 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 #pragma unroll
     for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(img + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
-    // ---- weight-gradient side ----
-    const bool wg = WG && wg_q != nullptr;                    // block-uniform
-    const int nslab = (K + 63) >> 6;                          // 64-row slabs of G (<= 3)
-    v4f acc2[3][4];
-    float qb[4] = {0.f, 0.f, 0.f, 0.f};
-    const unsigned qcol = (unsigned)min(4 * c + w, Cp - 1) * 4u;           // lanes c = 15 at Cp = 60: a pad column (finite data, unread result)
-    auto load_q = [&](int tile) {                             // Q[16 tile + 4 st + kq, 4 c + w], rows clamped (the tile's rows past N are zero)
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const unsigned row = (unsigned)min(16 * tile + 4 * st + kq, N - 1);
-            qb[st] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wg_q) + (row * (unsigned)Cp * 4u + qcol));
-        }
-    };
-    if constexpr (WG) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) acc2[s][ti] = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (wg) load_q(blockIdx.x);
-    }
     __syncthreads();                                          // the block's only barrier (LDS flags / W_edge staged): the loads above fly under it
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
@@ -103,67 +72,19 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
         asm volatile("" ::: "memory");
         WSTAMP(0);
         const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
+        float4 af[12];
+#pragma unroll
+        for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
+        WSTAMP(1);
+        // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
+        // so the chain starts when the first fragment lands instead of after the twelfth
         v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-        if constexpr (!WG) {
-            float4 af[12];
 #pragma unroll
-            for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
-            WSTAMP(1);
-            // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
-            // so the chain starts when the first fragment lands instead of after the twelfth
+        for (int g = 0; g < 12; ++g) {
+            if (g < GK) {
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                if (g < GK) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
-                }
-            }
-        } else {
-            // the same chain with the fragments in a rolling set of six (group g + 6 is requested into group g's registers right after
-            // group g's MFMAs): 24 registers instead of 48 — the 48 accumulator registers of the weight-gradient product need the room
-            float4 af[6];
-#pragma unroll
-            for (int g = 0; g < 6; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                if (g < GK) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
-                }
-                af[g] = (g + 6 < GK && 16 * (g + 6) + 4 * kq < K) ? ld4(tl + 16 * (g + 6)) : f4zero();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                if (g + 6 < GK) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g + 6], jj), acc, 0, 0, 0);
-                }
-            }
-        }
-        if constexpr (WG) {
-            if (wg) {
-                // G += tile^T Q: 4 steps of 4 rows; per step nslab float4 A operands (rows 4 st + kq, columns 64 s + 4 c ..) and 4 nslab
-                // independent accumulator tiles (back-to-back issue: no dependent chain here)
-                const float* tr = s_ring + slot * 16 * LDT + kq * LDT;
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    float4 pa[3];
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)
-                        if (s < nslab) pa[s] = ld4(tr + 4 * st * LDT + min(64 * s + 4 * c, LDT - 4));
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        if (s < nslab) {
-#pragma unroll
-                            for (int ti = 0; ti < 4; ++ti)
-                                acc2[s][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pa[s], ti), qb[st], acc2[s][ti], 0, 0, 0);
-                        }
-                    }
-                }
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -174,26 +95,7 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
             for (int i = 0; i < 4; ++i)
                 if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
         }
-        if constexpr (WG) {
-            if (wg && tile + (int)gridDim.x < ntiles) load_q(tile + gridDim.x);        // next tile's Q scalars: a whole tile of time to land
-        }
         WSTAMP(2);
-    }
-    if constexpr (WG) {
-        if (wg) {
-            // block partial in k_wgrad's slab format: slab s of split blockIdx.x, accumulator tile t = ti * 4 + tj (tj = w), lane, r
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                if (s < nslab) {
-                    float* slab = wg_partial + ((size_t)s * gridDim.x + blockIdx.x) * kWgSlabStride;
-#pragma unroll
-                    for (int ti = 0; ti < 4; ++ti) {
-                        const v4f v = acc2[s][ti];
-                        st4(slab + ((ti * 4 + w) * 64 + lane) * 4, make_float4(v[0], v[1], v[2], v[3]));
-                    }
-                }
-            }
-        }
     }
 }
 
@@ -227,7 +129,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
-        ws_consume<false>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, nullptr, nullptr WS_PROF_ARGS);
+        ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -452,218 +354,6 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// k_triplet_fwd_ws_roll (round 4): the same block with FOUR waves per SIMD — twelve producers + four consumers, sixteen waves, the launch
-// held to 128 registers.  What made room: ONE rolling row set (the next pass's rows are requested into the registers of the current
-// pass right after its last use of them, as k_triplet_bwd_dst_ws does) instead of two alternating sets (96 of the 156 registers of
-// k_triplet_fwd_ws), and the per-edge scalars (a_j, edge_attr; the node's a_i) as plain loads of the lane that owns the (node, head,
-// slot) in the quad layout — no side table, no LDS-DMA, every wait counted by the compiler (and 32 KB of LDS less).  A pass's loads
-// now have the tail of the previous pass (normalise, publish, stores) to land instead of a whole pass, which a fourth wave per SIMD
-// more than pays for.  Same operations on the same operands in the same order: bit-identical to k_triplet_fwd_ws.
-// ------------------------------------------------------------------------------------------------------------------------------
-template <int H, int P>
-__global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_fwd_ws_roll(FwdDmaArgs a) {
-    constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
-    const int WP = ws_wedge_pitch(HC), WSZ = DE * WP, LDT = HC + 4;
-    float* s_w = smem;
-    int* s_ready = reinterpret_cast<int*>(smem + WSZ);        // [kWsRing] producer check-ins per slot (monotonic)
-    float* s_mt = reinterpret_cast<float*>(s_ready + 16);     // M transposed: [head][edge feature]
-    int* s_taken = s_ready + 32;                              // [kWsRing] consumer check-outs per slot
-    float* s_ring = smem + WSZ + 64;                          // kWsRing tiles of 16 x LDT floats
-    for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
-    if (tid < 64) {
-        if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
-        else s_ready[tid] = 0;
-    }
-    const int ntiles = (a.N + 15) >> 4;
-#ifdef GLAM_WS_PROF
-    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
-#endif
-    if (wave >= P) {
-        ws_consume<false>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, nullptr, nullptr WS_PROF_ARGS);
-        return;
-    }
-    const int npass = (a.N + 3) >> 2;
-    const int grp = wave >> 2, rw = wave & 3;                 // tile group of this wave, its four rows of the group's tiles
-    const int gw = 4 * (blockIdx.x + grp * gridDim.x) + rw, GW = 4 * PG * gridDim.x;      // first pass, pass stride
-    const unsigned row_bytes = (unsigned)HC * 4u, head_bytes = (unsigned)Cp * 4u;
-    int lv = lane;
-#define LANE_CONSTS()                                                                        \
-    asm volatile("" : "+v"(lv));                                                             \
-    const int j = lv >> 4, q = lv & 15;                                                      \
-    const bool qok = q < Q;                                                                  \
-    const unsigned qoff = (unsigned)(qok ? q : 0) * 16u;                                     \
-    const int hh = (lv >> 2) & 3, kk = lv & 3, hc = hh < H ? hh : H - 1
-
-    // record in the QUAD layout: lane (j, hh, kk) holds slot kk of node j (every quad of a row loads the same four words)
-    auto load_rec = [&](int pass, int& rs, int& re) {
-        LANE_CONSTS(); (void)qok; (void)qoff; (void)q; (void)hc; (void)hh;
-        const int n = 4 * pass + j;
-        rs = -1; re = -1;
-        if (pass < npass && n < a.N) { rs = a.ell_src[4 * n + kk]; re = a.ell_eid[4 * n + kk]; }
-    };
-    auto ldf = [](const float* base, unsigned byte_off) {
-        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-    };
-    float4 rows[CH][H];
-    float sc_aj = 0.f, sc_ai = 0.f;
-    float4 sc_ea = f4zero();
-#pragma unroll
-    for (int k = 0; k < CH; ++k)
-#pragma unroll
-        for (int h = 0; h < H; ++h) rows[k][h] = f4zero();
-    // everything pass `pass` needs: the lane's own (edge, head) scalars and the rows of the node's neighbours
-    auto prefetch = [&](int pass, int rs, int re) {
-        LANE_CONSTS(); (void)kk; (void)hh;
-        if (pass >= npass) return;
-        const unsigned n = (unsigned)min(4 * pass + j, a.N - 1);
-        const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;        // the hh = 0 quads carry the degree
-        const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
-                  d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
-        const int dmax = max(max(d0, d1), max(d2, d3));
-        const int src0 = row_bcast_i(rs, 0), eid0 = row_bcast_i(re, 0);
-        // an empty slot aliases the node's first edge (finite data, weight 0); a node without edges reads nothing (E may be 0)
-        sc_aj = 0.f; sc_ea = f4zero();
-        if (src0 >= 0) {
-            sc_aj = ldf(a.a_ij, (unsigned)(rs >= 0 ? rs : src0) * 32u + 16u + 4u * (unsigned)hc);
-            sc_ea = ld4o(a.edge_attr, (unsigned)(re >= 0 ? re : eid0) * 16u);
-        }
-        sc_ai = ldf(a.a_ij, n * 32u + 4u * (unsigned)hc);
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            if (k < dmax) {                                   // scalar branch: slot k is empty in all four nodes otherwise
-                const int sk = row_bcast_i(rs, k);
-                const unsigned ro = (unsigned)max(sk >= 0 ? sk : src0, 0) * row_bytes + qoff;
-#pragma unroll
-                for (int h = 0; h < H; ++h) rows[k][h] = ld4o(a.xw, ro + (unsigned)h * head_bytes);
-            }
-        }
-    };
-
-    float4 r_acc[H];
-    float4 r_ms = f4zero();                                   // lane q = 0: segment maxima, q = 1: exp-sums (the two halves of a stats row)
-    int r_n = -1;
-    auto compute = [&](auto dm_tag, int pass, int rs) {
-        constexpr int DM = decltype(dm_tag)::value;
-        LANE_CONSTS(); (void)qoff;
-        const int n = 4 * pass + j;
-#pragma unroll
-        for (int h = 0; h < H; ++h) r_acc[h] = f4zero();
-        if (n >= a.N || pass >= npass) { r_n = -1; return; }
-        r_n = n;
-        const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;
-        const int deg = __popcll((bal >> (16 * j)) & 0xFull);
-        float p = 0.f, mq = 0.f, sq = 0.f;
-        if (deg > 0) {
-            const bool valid = kk < deg;
-            const float4 mc = ld4(s_mt + hc * 4);
-            float ee = 0.f;
-            ee = fmaf(sc_ea.x, mc.x, ee); ee = fmaf(sc_ea.y, mc.y, ee); ee = fmaf(sc_ea.z, mc.z, ee); ee = fmaf(sc_ea.w, mc.w, ee);
-            const float lk = leaky(sc_ai + ee + sc_aj, a.slope);
-            float m = valid ? lk : -INFINITY;
-            m = fmaxf(m, dpp_f<0xB1>(m));                     // quad_perm [1,0,3,2]
-            m = fmaxf(m, dpp_f<0x4E>(m));                     // quad_perm [2,3,0,1]
-            p = valid ? softmax_exp(lk - m) : 0.f;
-            // ((p0 + p1) + p2) + p3: the order of the per-slot loop (an empty slot adds an exact zero)
-            sq = ((dpp_f<0x00>(p) + dpp_f<0x55>(p)) + dpp_f<0xAA>(p)) + dpp_f<0xFF>(p);
-            mq = m;
-            int t = 0;                                        // bond type: the edge's W_edge row IS e_ij (adding the zero terms is exact)
-            t = sc_ea.y != 0.f ? 1 : t; t = sc_ea.z != 0.f ? 2 : t; t = sc_ea.w != 0.f ? 3 : t;
-            int tk[DM];
-#pragma unroll
-            for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * WP + (qok ? q : 0) * 4;       // slot k's bond type: lane (hh = 0, kk = k)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                float4 er[DM];
-#pragma unroll
-                for (int k = 0; k < DM; ++k) er[k] = ld4(s_w + tk[k] + h * Cp);
-#pragma unroll
-                for (int k = 0; k < DM; ++k) {
-                    const float pw = row_bcast(p, 4 * h + k);
-                    const float4 xj = er[k] * rows[k][h];
-                    fma4(r_acc[h], pw, xj);
-                }
-            }
-        }
-        const float inv = 1.f / (sq + 1e-16f);
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            r_acc[h] = row_bcast(inv, 4 * h) * r_acc[h];
-            const float mh = row_bcast(mq, 4 * h), sh = row_bcast(sq, 4 * h);
-            (&r_ms.x)[h] = q == 0 ? mh : sh;
-        }
-    };
-    auto compute_any = [&](int pass, int rs) {
-        const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;
-        const int d0 = __popc((unsigned)(bal & 0xF)), d1 = __popc((unsigned)((bal >> 16) & 0xF)),
-                  d2 = __popc((unsigned)((bal >> 32) & 0xF)), d3 = __popc((unsigned)((bal >> 48) & 0xF));
-        const int dmax = max(max(d0, d1), max(d2, d3));
-        if (dmax <= 1) compute(std::integral_constant<int, 1>{}, pass, rs);
-        else if (dmax == 2) compute(std::integral_constant<int, 2>{}, pass, rs);
-        else if (dmax == 3) compute(std::integral_constant<int, 3>{}, pass, rs);
-        else compute(std::integral_constant<int, 4>{}, pass, rs);
-    };
-    // this wave's four rows of local tile `it` go into ring slot it % kWsRing (rows past N are zero: out = bias, never stored)
-    auto publish = [&](int it) {
-        LANE_CONSTS(); (void)qoff; (void)hh; (void)kk; (void)hc;
-        const int slot = it % kWsRing;
-        if (it >= kWsRing) {                                  // the consumers must have taken the slot's previous tile
-            const int want = kWsCons * (it / kWsRing);
-            while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-        if (qok) {
-            float* tl = s_ring + slot * 16 * LDT + (rw * 4 + j) * LDT + q * 4;
-#pragma unroll
-            for (int h = 0; h < H; ++h) st4(tl + h * Cp, r_acc[h]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lv == 0) flag_bump(s_ready + slot);
-    };
-    auto store_results = [&]() {
-        if (r_n < 0) return;
-        LANE_CONSTS(); (void)qoff; (void)j; (void)hh; (void)kk; (void)hc;
-        if (qok) {
-            const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
-#pragma unroll
-            for (int h = 0; h < H; ++h) st4o(a.aggr, orow + (unsigned)h * head_bytes, r_acc[h]);
-        }
-        if (q < 2) st4o(a.stats, (unsigned)r_n * 32u + (unsigned)q * 16u, r_ms);
-        r_n = -1;
-    };
-
-    int rs, re, rs_n, re_n;
-    int pass = gw;
-    load_rec(pass, rs, re);
-    prefetch(pass, rs, re);
-    load_rec(pass + GW, rs_n, re_n);
-    __syncthreads();                                          // the block's only barrier: W_edge / flags staged; the first pass is already in flight
-    const int pass_end = ntiles << 2;                         // whole 16-node tiles: every producer publishes every tile of its group
-    int it = grp;
-    for (; pass - rw < pass_end; pass += GW, it += PG) {
-        WSTAMP(0);
-        compute_any(pass, rs);
-        WSTAMP(1);
-        __builtin_amdgcn_sched_barrier(0);                    // the rows' registers are free from here on: everything of pass p + 1
-        prefetch(pass + GW, rs_n, re_n);
-        __builtin_amdgcn_sched_barrier(0);
-        WSTAMP(2);
-        publish(it);
-        WSTAMP(3);
-        store_results();
-        rs = rs_n; re = re_n;
-        load_rec(pass + 2 * GW, rs_n, re_n);
-        WSTAMP(4);
-    }
-#ifdef GLAM_WS_PROF
-    if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 16 + wave) * 8 + k] = pacc[k];
-#endif
-#undef LANE_CONSTS
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
 // k_triplet_bwd_src_ws: backward B2 (d_xw[j] = sum over the out-edges of j of alpha_e * e_ij * d_aggr[dst], d_a_j[j] = sum dpre_e;
 // general kernel: k_triplet_bwd_src) with the input gradient d_x = [d_xw | d_a_i | d_a_j] @ Wcat^T as the consumers' GEMM — the same
 // block structure as k_triplet_fwd_ws.  ELL records BY SOURCE (dst[4] | eid[4] per node).  The side table of a pass is three lane-indexed
@@ -677,10 +367,9 @@ struct SrcWsArgs {
     int N; int Cp;
     float* d_xw; float* d_a_ij;                  // d_a_ij[N, 8]: columns 0..3 (d_a_i) are read, 4..7 (d_a_j) written
     const float* img_dx; float* d_x;
-    const float* wg_x; float* wg_partial;        // non-null: the consumers also accumulate [d_xw | d_a]^T x (k_wgrad slab partials, split = block)
 };
 
-template <int H, int P, bool WG>
+template <int H, int P>
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -701,7 +390,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        ws_consume<WG>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, a.wg_x, a.wg_partial WS_PROF_ARGS);
+        ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -876,57 +565,39 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #undef LANE_CONSTS
 }
 
-template <int H, int P, bool WG = false>
+template <int H, int P>
 static int launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, WG>), big, "triplet_bwd_src_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
-    GLAM_PROF_LABEL(WG ? "k_triplet_bwd_src_ws+dx+wgrad" : "k_triplet_bwd_src_ws+dx");
-    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, WG>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
     return GLAM_OK;
 }
 
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
-    const char* e = getenv("GLAM_BWD_WS");
-    return !(e && atoi(e) == 0) && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H * Cp + 8 <= 192;
-}
-
-// the weight-gradient products inside the warp-specialised backward launches exist for the reference's head count (layer.py:16: heads = 3);
-// with fewer heads the consumer path would cost the launch its fourth wave per SIMD
-bool triplet_ws_wgrad_supported(int H, int Cp, int De, int edge_onehot) {
-    const char* e = getenv("GLAM_WS_WGRAD");      // opt-in: measured slower than the k_wgrad launch it replaces at both sizes
-    const char* pe = getenv("GLAM_WS_PROD");
-    return e && atoi(e) == 1 && !(pe && atoi(pe) == 4) && H == 3 && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot) &&
-           triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot) && ws_grid_cap(kWsWgradBlocks) <= kWsWgradBlocks;
+    return triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H * Cp + 8 <= 192;
 }
 
 // B2 + d_x over ELL records by source, warp-specialised (called by triplet_bwd_impl)
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* wg_x, float* wg_partial,
-                       int* wg_nsplit) {
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s) {
     if (N == 0) return GLAM_OK;
     if (!triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
     if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a tensor exceeds 4 GiB (32-bit offsets)");
-    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x, wg_x, wg_partial};
+    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x};
     const int ntiles = (int)((N + 15) / 16);
-    const int cap = ws_grid_cap(wg_x ? kWsWgradBlocks : 1024);      // fused weight gradient: one slab set per block in the workspace
+    const int cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;
-    if (wg_x) {
-        if (!wg_partial || !wg_nsplit || !triplet_ws_wgrad_supported(H, Cp, De, edge_onehot))
-            return fail(GLAM_E_INVALID, "triplet_bwd_src_ws: fused weight gradient without a partial buffer / outside its table (H = 3)");
-        *wg_nsplit = grid;
-    }
-    const char* pe = getenv("GLAM_WS_PROD");
-    const bool p4 = pe && atoi(pe) == 4;
-    int rc = GLAM_OK;
+    int rc = GLAM_OK;      // eight producers (three waves per SIMD) where the kernel fits 168 registers without scratch, four at H = 4
     switch (H) {
-        case 1: rc = p4 ? launch_src_ws_p<1, 4>(a, grid, s) : launch_src_ws_p<1, 8>(a, grid, s); break;
-        case 2: rc = p4 ? launch_src_ws_p<2, 4>(a, grid, s) : launch_src_ws_p<2, 8>(a, grid, s); break;
-        case 3: rc = p4 ? launch_src_ws_p<3, 4>(a, grid, s) : wg_x ? launch_src_ws_p<3, 8, true>(a, grid, s) : launch_src_ws_p<3, 8>(a, grid, s); break;
+        case 1: rc = launch_src_ws_p<1, 8>(a, grid, s); break;
+        case 2: rc = launch_src_ws_p<2, 8>(a, grid, s); break;
+        case 3: rc = launch_src_ws_p<3, 8>(a, grid, s); break;
         default: rc = launch_src_ws_p<4, 4>(a, grid, s); break;
     }
     if (rc) return rc;
@@ -947,31 +618,11 @@ static int launch_ws_p(const FwdDmaArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((k_triplet_fwd_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P), s, a);
     return GLAM_OK;
 }
-static size_t ws_roll_lds_bytes(int H, int Cp) {
-    const int HC = H * Cp;
-    return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)kWsRing * 16 * (HC + 4)) * sizeof(float);
-}
-template <int H>
-static int launch_ws_roll(const FwdDmaArgs& a, int grid, hipStream_t s) {
-    static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws_roll<H, 12>), big, "triplet_fwd_ws_roll")) return rc;
-    GLAM_PROF_LABEL("k_triplet_fwd_ws+update");
-    hipLaunchKernelGGL((k_triplet_fwd_ws_roll<H, 12>), dim3(grid), dim3((12 + kWsCons) * 64), ws_roll_lds_bytes(H, a.Cp), s, a);
-    return GLAM_OK;
-}
-// sixteen waves (four per SIMD, rolling row set) where that instantiation fits 128 registers; GLAM_WS_ROLL=0: the twelve-wave form
-static bool ws_roll_enabled() { const char* e = getenv("GLAM_WS_ROLL"); return !e || atoi(e) != 0; }
 template <int H>
 static int launch_ws(const FwdDmaArgs& a, int grid, hipStream_t s) {
-    if constexpr (H <= 3) {
-        if (ws_roll_enabled() && !getenv("GLAM_WS_PROD")) return launch_ws_roll<H>(a, grid, s);
-    }
     // eight producers (three waves per SIMD) where the kernel fits 168 registers without scratch, four otherwise
-    const char* e = getenv("GLAM_WS_PROD");     // developer A/B: producer waves per block
-    if constexpr (H <= 3) {
-        if (!(e && atoi(e) == 4)) return launch_ws_p<H, 8>(a, grid, s);
-    }
-    return launch_ws_p<H, 4>(a, grid, s);
+    if constexpr (H <= 3) return launch_ws_p<H, 8>(a, grid, s);
+    else return launch_ws_p<H, 4>(a, grid, s);
 }
 
 // the warp-specialised kernel exists for one-hot bond features of width 4 (src_1gp/dataset.py:82: every molecular dataset of the reference)
@@ -980,7 +631,8 @@ bool triplet_fwd_ws_supported(int H, int Cp, int De, int edge_onehot) {
 }
 
 bool triplet_fwd_ws_enabled() {
-    const char* e = getenv("GLAM_FWD_WS");     // read per call: an A/B switch for experiments (a captured graph keeps what it captured)
+    const char* e = getenv("GLAM_WS");         // 0: no warp-specialised kernels (forward and backward).  Read per call: an A/B switch for
+                                               // experiments and tests (a captured graph keeps what it captured)
     return !e || atoi(e) != 0;
 }
 

@@ -32,10 +32,9 @@ struct DstWsArgs {
     const int* ell_src; const int* ell_eid;      // [N][4] each, by target
     int N; int Cp; float slope;
     float* d_aggr; float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;      // partial[gridDim.x][4 * H * Cp + 16]
-    float* wg_partial;       // non-null (WG kernels): the matrix waves also accumulate [aggr | 1]^T d_out (k_wgrad slab partials, split = block)
 };
 
-template <int H, int V, bool WG>
+template <int H, int V>
 __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_ws(DstWsArgs a) {
     constexpr int kBlockT = (V + 4) * 64, VG = V / 4, CH = 4;
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -76,10 +75,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             for (int g = 0; g < 4; ++g)
                 bf[ct][g] = (g < GK && mcol < HC) ? ld4(a.img_dagg + ((size_t)(4 * g + kq) * MP + pos) * 4) : f4zero();
         }
-        int lva = lane;
         auto load_a = [&](int tile, float4 (&af)[4]) {
-            if constexpr (WG) asm volatile("" : "+v"(lva));
-            const int c = lva & 15, kq = lva >> 4;
             const int row = 16 * tile + c;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -87,13 +83,18 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                 af[g] = (tile < ntiles && row < a.N && 4 * ch < Cp) ? ld4(a.d_out + (size_t)row * Cp + 4 * ch) : f4zero();
             }
         };
-        auto dagg_tile = [&](int it_, const float4 (&af)[4], v4f (&acc)[3]) {
+        float4 af_a[4], af_b[4];
+        int tile = blockIdx.x, it = 0;
+        load_a(tile, af_a);
+        __syncthreads();                                      // LDS initialised; the weight slice and the first tile's rows are in flight
+        auto one_tile = [&](int it_, const float4 (&af)[4]) {
             const int slot = it_ % kRing;
             if (it_ >= kRing) {                             // the vector waves must have taken the slot's previous tile
                 const int want = 4 * (it_ / kRing);
                 while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
+            v4f acc[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) acc[ct] = (v4f){0.f, 0.f, 0.f, 0.f};
             // k group outer, column tile inner: three independent accumulator chains
@@ -107,12 +108,6 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                             acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[ct][g], jj), acc[ct], 0, 0, 0);
                 }
             }
-        };
-        int lvp = lane;
-        auto publish_tile = [&](int it_, const v4f (&acc)[3]) {
-            if constexpr (WG) asm volatile("" : "+v"(lvp));
-            const int c = lvp & 15, kq = lvp >> 4;
-            const int slot = it_ % kRing;
             float* tl = s_ring + slot * 16 * LDT;
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
@@ -125,101 +120,12 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) flag_bump(s_ready + slot);
         };
-        if constexpr (!WG) {
-            float4 af_a[4], af_b[4];
-            int tile = blockIdx.x, it = 0;
-            load_a(tile, af_a);
-            __syncthreads();                                  // LDS initialised; the weight slice and the first tile's rows are in flight
-            v4f acc[3];
-            for (; tile < ntiles; tile += 2 * gridDim.x, it += 2) {
-                load_a(tile + gridDim.x, af_b);               // next tile's rows in flight under this tile's MFMAs
-                dagg_tile(it, af_a, acc);
-                publish_tile(it, acc);
-                if (tile + (int)gridDim.x < ntiles) {
-                    load_a(tile + 2 * gridDim.x, af_a);
-                    dagg_tile(it + 1, af_b, acc);
-                    publish_tile(it + 1, acc);
-                }
-            }
-        } else {
-            // ------------------------------------------------------------------------------------------------------------------
-            // round 4, OPT-IN (GLAM_WS_WGRAD=1; measured slower than the k_wgrad launch it replaces): the same waves also
-            // accumulate the weight-gradient product G[i, j] = sum_n [aggr | 1][n, i] * d_out[n, j] (d_weight_scale and d_bias: the
-            // autograd of src_1gp/layer.py:58-60) of the tiles they produce.  Operand layout of k_wgrad (gemm.hip): rows 4 st + kq of a
-            // tile per MFMA step; this wave owns the rows i = 64 s + 4 c + w of G (one aggr scalar per lane, slab and step) and takes
-            // d_out's row as a float4 (columns j = 4 c + tj).  Row i = HC is the virtual ones column (lane value 1: d_bias); operands
-            // of the pad rows / columns are clamped, finite reads whose accumulators no reduction looks at; rows past N carry
-            // d_out = 0.  The block partial is written in k_wgrad's slab format (split = blockIdx.x).
-            // ------------------------------------------------------------------------------------------------------------------
-            const int nslab = (HC + 1 + 63) >> 6, s1 = HC >> 6;
-            const bool one_lane = 4 * c + w == HC - 64 * s1;                   // this lane's row of slab s1 is i = HC: the ones column
-            v4f acc2[3][4];
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj) acc2[sl][tj] = (v4f){0.f, 0.f, 0.f, 0.f};
-            // operands of two steps at a time (two buffers of 3 aggr scalars + one d_out float4): step st + 2 is requested into step st's
-            // registers as soon as step st has issued its MFMAs
-            float ga[2][3];
-            float4 gb[2];
-            int lvm = lane;                                   // opaque copy of the lane id: lane-derived offsets are recomputed where they are
-                                                              // used instead of living in registers across the loop (see LANE_CONSTS below)
-            auto load_g = [&](int tile, int st, int buf) {
-                asm volatile("" : "+v"(lvm));
-                const int c = lvm & 15, kq = lvm >> 4;
-                const unsigned gbcol = (unsigned)min(4 * c, Cp - 4) * 4u;
-                const int r = 16 * tile + 4 * st + kq;
-                const unsigned row = (unsigned)min(r, a.N - 1);
-                const float4 v = ld4o(a.d_out, row * (unsigned)Cp * 4u + gbcol);
-                gb[buf] = r < a.N ? v : f4zero();
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) {
-                    if (sl < nslab) {
-                        const unsigned col = (unsigned)min(64 * sl + 4 * c + w, HC - 1);
-                        ga[buf][sl] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.aggr) + (row * (unsigned)HC + col) * 4u);
-                    }
-                }
-            };
-            float4 af[4];
-            int tile = blockIdx.x, it = 0;
-            load_a(tile, af);
-            __syncthreads();                                  // LDS initialised; the weight slice and the first tile's rows are in flight
-            v4f acc[3];
-            for (; tile < ntiles; tile += gridDim.x, ++it) {
-                dagg_tile(it, af, acc);
-                load_a(tile + gridDim.x, af);                 // the registers are free: next tile's rows fly under the rest of this tile
-                __builtin_amdgcn_sched_barrier(0);
-                publish_tile(it, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                load_g(tile, 0, 0);
-                load_g(tile, 1, 1);
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-#pragma unroll
-                    for (int sl = 0; sl < 3; ++sl) {
-                        if (sl < nslab) {
-                            const float av = (sl == s1 && one_lane) ? 1.f : ga[st & 1][sl];
-#pragma unroll
-                            for (int tj = 0; tj < 4; ++tj)
-                                acc2[sl][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f4get(gb[st & 1], tj), acc2[sl][tj], 0, 0, 0);
-                        }
-                    }
-                    if (st < 2) load_g(tile, st + 2, st & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (a.wg_partial) {
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) {
-                    if (sl < nslab) {
-                        float* slab = a.wg_partial + ((size_t)sl * gridDim.x + blockIdx.x) * kWgSlabStride;
-#pragma unroll
-                        for (int tj = 0; tj < 4; ++tj) {
-                            const v4f v = acc2[sl][tj];
-                            st4(slab + ((w * 4 + tj) * 64 + lane) * 4, make_float4(v[0], v[1], v[2], v[3]));
-                        }
-                    }
-                }
+        for (; tile < ntiles; tile += 2 * gridDim.x, it += 2) {
+            load_a(tile + gridDim.x, af_b);                   // next tile's rows in flight under this tile's MFMAs
+            one_tile(it, af_a);
+            if (tile + (int)gridDim.x < ntiles) {
+                load_a(tile + 2 * gridDim.x, af_a);
+                one_tile(it + 1, af_b);
             }
         }
     } else {
@@ -474,22 +380,21 @@ static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     return ((size_t)WL + 64 + (size_t)V * 4 * WL + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
-template <int H, int V, bool WG = false>
+template <int H, int V>
 static int launch_b1ws(const DstWsArgs& a, int grid, hipStream_t s) {
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V, WG>), big, "triplet_bwd_dst_ws")) return rc;
-    GLAM_PROF_LABEL(WG ? "d_aggr+k_triplet_bwd_dst_ws+wgrad" : "d_aggr+k_triplet_bwd_dst_ws");
-    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V, WG>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V>), big, "triplet_bwd_dst_ws")) return rc;
+    GLAM_PROF_LABEL("d_aggr+k_triplet_bwd_dst_ws");
+    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
     return GLAM_OK;
 }
 
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot) {
-    const char* e = getenv("GLAM_B1_WS");
-    return !(e && atoi(e) == 0) && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H <= 3;
+    return triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H <= 3;
 }
-static int triplet_bwd_dst_ws_blocks(int64_t N, bool wg) {
+int triplet_bwd_dst_ws_blocks(int64_t N) {
     const int ntiles = (int)((N + 15) / 16);
-    const int cap = ws_grid_cap(wg ? kWsWgradBlocks : kBwdBlocks);      // the partial workspaces hold kBwdBlocks / kWsWgradBlocks block partials
+    const int cap = ws_grid_cap(kBwdBlocks);      // the partial workspace holds kBwdBlocks block partials
     return ntiles < cap ? ntiles : cap;
 }
 
@@ -497,21 +402,19 @@ static int triplet_bwd_dst_ws_blocks(int64_t N, bool wg) {
 int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
                        const float* stats, const float* d_out, const float* img_dagg, const int32_t* ell_src, const int32_t* ell_eid,
                        int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot, float slope, float* d_aggr, float* alpha_e,
-                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s, float* wg_partial) {
+                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s) {
     if (!triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_dst_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
     if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_dst_ws: a tensor exceeds 4 GiB (32-bit offsets)");
     DstWsArgs a{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, (int)N, Cp, slope,
-                d_aggr, alpha_e, dpre_e, d_a_ij, partial, wg_partial};
-    if (wg_partial && !triplet_ws_wgrad_supported(H, Cp, De, edge_onehot))
-        return fail(GLAM_E_INVALID, "triplet_bwd_dst_ws: the fused weight gradient exists for H = 3 only");
-    const int grid = triplet_bwd_dst_ws_blocks(N, wg_partial != nullptr);
+                d_aggr, alpha_e, dpre_e, d_a_ij, partial};
+    const int grid = triplet_bwd_dst_ws_blocks(N);
     int rc = GLAM_OK;
     switch (H) {
         case 1: rc = launch_b1ws<1, 8>(a, grid, s); break;
         case 2: rc = launch_b1ws<2, 8>(a, grid, s); break;
-        default: rc = wg_partial ? launch_b1ws<3, 8, true>(a, grid, s) : launch_b1ws<3, 8>(a, grid, s); break;
+        default: rc = launch_b1ws<3, 8>(a, grid, s); break;
     }
     if (rc) return rc;
     GLAM_LAUNCH_CHECK("triplet_bwd_dst_ws");

@@ -218,8 +218,6 @@ class TripletMessage(MessagePassing):
                                     self.weight_scale, self.bias, gi, self.heads, self.negative_slope)
             return ops.slice_cols(out, C)                # pad columns are exactly zero (zero-padded W_scale / bias)
         # wide layers (3 * Cp + 8 > 192, i.e. hid_dim_alpha = 6): fused aggregate kernel between library GEMMs
-        if ops.FEATURE_STORAGE == "bf16":
-            raise GlamHipError("TripletMessage: bf16 row storage covers node_channels 33..64 (the fused kernels)")
         x_p = ops.pad_cols(x, Cp)
         if ops.wide_layer_supported(C, self.heads, De):
             out = ops.triplet_layer_wide(x_p, edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,

@@ -97,7 +97,6 @@ class GraphIndex:
         # alive for ever (a loader that builds new batch objects every step leaked one CSR per step)
         self._ei_ref = weakref.ref(ei)
         self._t = None
-        self._tiles = False            # False: not planned yet; None: no plan (general kernels); else (tile_ptr, T)
         self._ell = False              # False: not built yet; None: in-degree > 4 somewhere; else (ell_src, ell_eid)
         self._ell_t = False            # the same by source (out-degree), for the pipelined backward B2
         self._err = torch.zeros(1, **i32)
@@ -110,25 +109,6 @@ class GraphIndex:
         poll_checks()
         if validate and getattr(edge_index, "_glam_trusted", None) != edge_index._version:   # same failure class as torch's index_select on CPU
             _check_flag(self._err, f"edge_index holds node ids outside [0, {self.N})")
-
-    TILE_TARGET_NODES = 80             # ~N/256 at the ESOL batch of 1024: one tile per CU
-
-    def tile_plan(self):
-        """``(tile_ptr int32[T+1], T)`` for the molecule-tile kernels, or ``None`` when the graph has an edge-closed
-        node range larger than a tile (one host sync, once per batch object)."""
-        if self._tiles is False:
-            self._tiles = None
-            if self.N > 0:
-                lib = _lib.load()
-                T = (self.N + self.TILE_TARGET_NODES - 1) // self.TILE_TARGET_NODES
-                i32 = dict(dtype=torch.int32, device=self.device)
-                tile_ptr, err = torch.empty(T + 1, **i32), torch.zeros(1, **i32)
-                ws = torch.empty(lib.glam_tile_plan_workspace_bytes(self.N), dtype=torch.uint8, device=self.device)
-                check(lib.glam_tile_plan(ptr(self.rowptr), ptr(self.src), self.N, self.E, T, ptr(tile_ptr), ptr(err), ptr(ws),
-                                         ws.numel(), stream()), "glam_tile_plan")
-                if int(err.item()) == 0:
-                    self._tiles = (tile_ptr, T)
-        return self._tiles
 
     # the pipelined forward pays off once xw + aggr (2 * N * H * Cp * 4 bytes) no longer fit the 256 MiB LLC (measured crossover:
     # B = 8 192 -> 0.59 general vs 0.55 pipelined; B = 16 384 -> 0.44-0.48 vs 0.56-0.64 of the HBM peak); ELL_MIN_NODES overrides
@@ -196,13 +176,10 @@ class GraphIndex:
         return self._t
 
 
-TILES_ENABLED = os.environ.get("GLAM_TILES") == "1"
-BWD_ELL = os.environ.get("GLAM_BWD_ELL", "1") == "1"       # A/B knob: pipelined B2 beyond the LLC
-B1_WS = os.environ.get("GLAM_B1_WS", "1") == "1"           # A/B knob: warp-specialised B1 (needs the ELL records of both directions)
-# Fused forward over ELL records (molecular graphs): "auto" = the warp-specialised kernel (csrc/triplet_ws.hip) wherever it exists
-# (one-hot bond features: every size), the barrier-coupled pipelined kernel (csrc/triplet_dma.hip, FUSE = true) beyond the LLC
-# otherwise; "1" = always an ELL route, "0" = never (the general fused kernel).
-PIPE_FUSED = os.environ.get("GLAM_PIPE_FUSED", "auto")
+# Whole-layer route for molecular graphs (ELL form, one-hot bond features of width 4): "auto" = the warp-specialised kernels
+# (csrc/triplet_ws.hip, csrc/triplet_ws_b1.hip) wherever they exist, at every batch size; "0" = the general kernels (A/B knob of the
+# tests: the two routes are pinned to each other).
+WS_ROUTE = os.environ.get("GLAM_WS_ROUTE", "auto")
 
 
 # --------------------------------------------------------------------------------------
@@ -532,22 +509,9 @@ def _staged_cached(kind, params, build):
     return val
 
 
-# Storage of the gathered node rows xw[N, H*C] between the node GEMM and the aggregate kernels: "fp32" (the reference's
-# precision, the 1e-5 parity bar) or "bf16" (BASELINE config 3: bf16 storage, fp32 logits / softmax / accumulation).
-FEATURE_STORAGE = os.environ.get("GLAM_STORAGE", "fp32")
-
-
-@contextlib.contextmanager
-def feature_storage(kind):
-    """``with ops.feature_storage("bf16"): model(batch)`` — forward passes inside store gathered rows in bf16."""
-    global FEATURE_STORAGE
-    if kind not in ("fp32", "bf16"):
-        raise GlamHipError(f"feature_storage: {kind!r} is not 'fp32' or 'bf16'")
-    prev, FEATURE_STORAGE = FEATURE_STORAGE, kind
-    try:
-        yield
-    finally:
-        FEATURE_STORAGE = prev
+def _ws_route(lib, N, H, Cp, Dp, ea_p):
+    """The warp-specialised kernels cover this layer call (shape table in the library + one-hot rows: one cached read-back per tensor)."""
+    return WS_ROUTE != "0" and N > 0 and lib.glam_triplet_layer_ws_supported(H, Cp, Dp, 1) == 1 and rows_are_one_hot(ea_p)
 
 
 class _TripletLayer(torch.autograd.Function):
@@ -580,36 +544,19 @@ class _TripletLayer(torch.autograd.Function):
         # ops.cached_staging() the staged images additionally survive from pass to pass until a parameter is written
         staged = _staged_cached(("triplet", H, Cp, Dp), (wn, we, att, wsc, bias), build) if CACHED_STAGING else \
             _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet", id(wn), id(we), id(att), id(wsc), id(bias)), wn, build)
-        x16 = FEATURE_STORAGE == "bf16"
-        xw, a_ij = torch.empty(N, HC, dtype=torch.bfloat16 if x16 else torch.float32, device=dev), torch.empty(N, 8, **f)
+        xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
         aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
-        if x16:
-            check(lib.glam_triplet_layer_fwd_x16(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, gi.E,
-                                                 H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
-                                                 stream()), "glam_triplet_layer_fwd_x16")
-            ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
-            ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
-            return (out, carry.view(-1)) if ctx.carried else out
-        # The one-launch molecule-tile forward is opt-in (GLAM_TILES=1): bit-identical to the general kernels, 4 us
-        # faster at B=1024 (one tile per CU) but slower beyond, where its barrier-separated phases leave the CU idle
-        # (measurements in DESIGN.md).
-        # "auto": molecular graphs with one-hot bond features take the warp-specialised kernel at every size (15.1 vs 20.0 us at B = 1 024,
-        # 136 vs 256 us at B = 16 384 against the general fused kernel); other ELL graphs the barrier-coupled pipelined one beyond the LLC
-        want_pf = PIPE_FUSED in ("1", True) or (PIPE_FUSED == "auto" and Cp > 32 and not TILES_ENABLED and (
-            GraphIndex.wants_ell(N, H, Cp) or (N > 0 and lib.glam_triplet_layer_ws_supported(H, Cp, Dp, int(rows_are_one_hot(ea_p))))))
-        ell = gi.ell() if (want_pf and not TILES_ENABLED and Cp > 32) else None
-        if ell is not None:     # molecular graph: the software-pipelined aggregate with the update GEMM as its epilogue (bit-identical)
-            check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), int(rows_are_one_hot(ea_p)), N,
+        # molecular graphs with one-hot bond features take the warp-specialised kernels at every size (13.6 vs 16.8 us at B = 1 024,
+        # 136 vs 256 us at B = 16 384 against the general fused kernel); everything else the general kernels
+        ell = gi.ell() if _ws_route(lib, N, H, Cp, Dp, ea_p) else None
+        if ell is not None:
+            check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), 1, N,
                                                  gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out), stream()),
                   "glam_triplet_layer_fwd_ell")
-            ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
-            ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
-            return (out, carry.view(-1)) if ctx.carried else out
-        tiles = gi.tile_plan() if (TILES_ENABLED and lib.glam_triplet_tile_supported(H, Cp, Dp)) else None
-        tile_ptr, T = tiles if tiles is not None else (None, 0)
-        check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
-                                         ptr(tile_ptr), T, N, gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
-                                         stream()), "glam_triplet_layer_fwd")
+        else:
+            check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
+                                             N, gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
+                                             stream()), "glam_triplet_layer_fwd")
         ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
         return (out, carry.view(-1)) if ctx.carried else out
@@ -635,24 +582,10 @@ class _TripletLayer(torch.autograd.Function):
         sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
         flatg = torch.empty(sum(sizes), **f)
         d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
-        if xw.dtype == torch.bfloat16:
-            if d_ea is not None:
-                raise GlamHipError("triplet_layer: bf16 row storage has no edge_attr gradient")
-            check(lib.glam_triplet_layer_bwd_params_x16(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
-                                                        ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
-                                                        ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
-                                                        ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(ws),
-                                                        ws.numel(), stream()), "glam_triplet_layer_bwd_params_x16")
-            if ctx.carried:
-                return d_x, None, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
-            return d_x, None, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
-        # beyond the LLC, molecular graphs: the software-pipelined B2 over ELL records by source (bit-identical)
-        # (with one-hot bond features: the warp-specialised B2 + d_x launch, at every size)
-        ell_t = gi.ell_t() if (N > 0 and BWD_ELL and d_ea is None and (GraphIndex.wants_ell(N, H, Cp) or (
-            PIPE_FUSED == "auto" and Cp > 32 and lib.glam_triplet_layer_ws_supported(H, Cp, Dp, int(rows_are_one_hot(ea_p)))))) else None
+        # molecular graphs with one-hot bond features: B1 and B2 + d_x warp-specialised over the ELL records of both directions
+        ell_t = gi.ell_t() if (d_ea is None and _ws_route(lib, N, H, Cp, Dp, ea_p)) else None
         have_carry = ctx.carried and d_carry is not None and N > 0
-        # the same records by target (what the forward used): with both, B1 runs warp-specialised too
-        ell_f = gi.ell() if (ell_t is not None and B1_WS) else None
+        ell_f = gi.ell() if ell_t is not None else None          # (by target: what the forward used)
         if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
             c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
@@ -663,7 +596,7 @@ class _TripletLayer(torch.autograd.Function):
                                                         ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(c_wn), ptr(c_we),
                                                         ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(ell_f[0]) if ell_f else None,
                                                         ptr(ell_f[1]) if ell_f else None, ptr(ell_t[0]) if ell_t else None,
-                                                        ptr(ell_t[1]) if ell_t else None, int(rows_are_one_hot(ea_p)) if ell_t else 0,
+                                                        ptr(ell_t[1]) if ell_t else None, 1 if ell_t else 0,
                                                         ptr(d_ea), ptr(ws), ws.numel(), stream()),
                   "glam_triplet_layer_bwd_params_ell")
             if ctx.carried:
@@ -683,7 +616,7 @@ class _TripletLayer(torch.autograd.Function):
 # autograd.Function) is the route for EAGERLY issued steps, which are bound by host time: full-model step issued eagerly 1.21 vs 1.48 ms
 # at B = 32, 1.32 vs 1.55 ms at B = 1 024.  The Python node keeps the per-pass weight staging and the gradient carry of a weight_scope,
 # which a captured hipGraph replays for free.  GLAM_TORCH_EXT: "auto" (default) = the operator while nothing is being captured and the
-# batch is cache resident (the pipelined kernels beyond the LLC are the Python node's), "1" / "0" = always / never.  Both routes give
+# batch is cache resident, "1" / "0" = always / never.  Both routes give
 # the same numbers bit for bit (tested), so an eager first visit and a captured second one stay on one trajectory.
 _ext_env = os.environ.get("GLAM_TORCH_EXT", "auto")
 USE_TORCH_EXT = True if _ext_env == "1" else False if _ext_env == "0" else "auto"
@@ -692,7 +625,7 @@ _EXT_OK = None
 
 def _want_torch_ext(N, H, Cp):
     global _EXT_OK
-    if USE_TORCH_EXT is False or FEATURE_STORAGE != "fp32" or N <= 0 or CACHED_STAGING:     # (the C++ node stages per call)
+    if USE_TORCH_EXT is False or N <= 0 or CACHED_STAGING:     # (the C++ node stages per call)
         return False
     if USE_TORCH_EXT == "auto":
         if torch.cuda.is_current_stream_capturing() or GraphIndex.wants_ell(N, H, Cp):
@@ -718,10 +651,10 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
         # cached); with them the C++ node launches the same warp-specialised kernels as the Python node: one trajectory, bit for bit
         ell_f = ell_b = None
         onehot = False
-        if PIPE_FUSED == "auto" and x_p.size(1) > 32 and gi.N > 0 and rows_are_one_hot(ea_p):
+        if _ws_route(_lib.load(), gi.N, heads, x_p.size(1), ea_p.size(1), ea_p):
             onehot = True
             ell_f = gi.ell()
-            if torch.is_grad_enabled() and BWD_ELL:
+            if torch.is_grad_enabled():
                 ell_b = gi.ell_t()
         # same checks, same exception type as the Python node (the operator's own TORCH_CHECKs would raise RuntimeError)
         require_device(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias)

@@ -69,15 +69,6 @@ int glam_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int by, int3
 
 /* Segment pointer of a sorted graph-id vector: ptr int32[B+1] from batch int64[N] (non-decreasing),
  * as produced by PyG collation and consumed by global_*_pool(x, batch) (src_1gp/layer.py:202). */
-/* Tile plan for the molecule-tile kernels: tile_ptr int32[T+1], non-decreasing node boundaries with
- * tile_ptr[0] = 0, tile_ptr[T] = N, such that no edge of the CSR joins two different tiles (boundary t is the
- * first edge-free cut at or after t*N/T; on molecular batches that is the next molecule start).  *err_flag is
- * raised when some tile outgrows the kernels' capacity (112 nodes / 512 edges): the caller then keeps the general
- * path.  Replaces nothing in the reference - it is the precondition that lets src_1gp/layer.py:36-61 run out of
- * one CU's LDS. */
-size_t glam_tile_plan_workspace_bytes(int64_t N);
-int glam_tile_plan(const int32_t* rowptr, const int32_t* nbr, int64_t N, int64_t E, int32_t T, int32_t* tile_ptr,
-                   int32_t* err_flag, void* ws, size_t ws_bytes, void* stream);
 int glam_batch_ptr(const int64_t* batch, int64_t N, int64_t B, int32_t* ptr, int32_t* err_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -235,7 +226,7 @@ int glam_wgrad_gemm_add(const float* P1, int I1, int ldp1, const float* P2, int 
  *   glam_triplet_stage_params: parameters -> `staged` (glam_triplet_staged_floats floats): the four GEMM weight
  *     images ([W_node | Wa_i | Wa_j] with the separable-attention columns, W_scale, and their transposes),
  *     W_edge head-padded, M f32[Dp,4], bias padded.
- *   glam_triplet_layer_fwd:  x -> (xw, a_ij) -> aggr, stats -> out          (2 launches; ONE with a tile plan)
+ *   glam_triplet_layer_fwd:  x -> (xw, a_ij) -> aggr, stats -> out          (2 launches)
  *   glam_triplet_layer_bwd:  d_out -> d_x and `dstaged` (glam_triplet_dstaged_floats floats: d_Wcat[Cp,H*Cp+8] |
  *                            d_WsB[H*Cp+1,Cp] (last row = d_bias) | d_We_p | d_M), optional d_edge_attr
  *                            (9 launches, no atomics)
@@ -261,12 +252,8 @@ int glam_triplet_stage_plain(const float* weight_node, const float* weight_edge,
                              const float* weight_scale, const float* bias, int C, int H, int De, int Cp, int Dp,
                              float* plain, void* stream);
 int glam_triplet_layer_fwd(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                           const int32_t* src, const int32_t* eid, const int32_t* tile_ptr, int32_t T, int64_t N,
-                           int64_t E, int H, int Cp, int Dp, float slope, float* xw, float* a_ij, float* aggr,
-                           float* stats, float* out, void* stream);
-/* 1 when the molecule-tile kernels cover this layer shape (then pass a glam_tile_plan to the layer calls; with
- * tile_ptr = NULL the general kernels run) */
-int glam_triplet_tile_supported(int H, int Cp, int Dp);
+                           const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp, float slope,
+                           float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);
 size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp);
 int glam_triplet_layer_bwd(const float* x, const float* edge_attr, const float* staged, const float* xw,
                            const float* a_ij, const float* aggr, const float* stats, const float* d_out,
@@ -292,8 +279,8 @@ int glam_triplet_layer_bwd_params(const float* x, const float* edge_attr, const 
  * NULL): out = gradient + addend.  The block is applied message_steps times with shared weights (src_1gp/model.py:53-54); the
  * gradient already accumulated by its later applications enters here instead of through a separate add launch.  N > 0.
  * ell_dst / ell_eid_t (may be NULL): ELL records BY SOURCE — glam_ell_build on (colptr, dst, eid_t); every node of a molecular graph
- * has at most 4 out-edges — select the software-pipelined B2 (bit-identical; the op layer passes them beyond the LLC) followed by the
- * d_x GEMM as its own launch; edge_onehot as in glam_triplet_fwd_ell. */
+ * has at most 4 out-edges — select, for one-hot edge features of width 4 (edge_onehot = 1, glam_triplet_layer_ws_supported), the
+ * warp-specialised B2 + d_x launch (bit-identical); ignored otherwise.  edge_onehot as in glam_triplet_fwd_ell. */
 int glam_triplet_layer_bwd_params_acc(const float* x, const float* edge_attr, const float* staged, const float* xw,
                                       const float* a_ij, const float* aggr, const float* stats, const float* d_out,
                                       const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
@@ -322,29 +309,6 @@ int glam_triplet_layer_bwd_params_ell(const float* x, const float* edge_attr, co
                                       const float* add_bias, const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
                                       const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
                                       void* stream);
-/* B2 alone (d_xw, d_a_j from alpha_e / dpre_e f32[E, 4] as B1 leaves them) over ELL records by source: the software-pipelined
- * kernel glam_triplet_layer_bwd_params_acc runs when it is given ell_dst / ell_eid_t; for tests and isolated timing. */
-int glam_triplet_bwd_src_ell(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr,
-                             const float* w_edge, const int32_t* ell_dst, const int32_t* ell_eid_t, int64_t N, int64_t E, int H, int Cp,
-                             int De, int edge_onehot, float* d_xw, float* d_a_ij, int grid_blocks, void* stream);
-
-/* bf16 STORAGE of the gathered rows (BASELINE.json configs[2]: "bf16"; the reference itself is fp32 only): xw16 is
- * bf16[N, H*Cp], written round-to-nearest-even by the node GEMM's epilogue and widened on load by the aggregate kernels;
- * attention logits, softmax, sums, every gradient and every other tensor stay f32.  Same call sequence and arguments as
- * glam_triplet_layer_fwd / glam_triplet_layer_bwd_params otherwise.  36 <= Cp <= 64 and H*Cp + 8 <= 192 (the shapes of
- * the fused kernels: hid_dim 45 and 60); no tile plan, no edge_attr gradient. */
-int glam_triplet_layer_fwd_x16(const float* x, const float* edge_attr, const float* staged, const int32_t* rowptr,
-                               const int32_t* src, const int32_t* eid, int64_t N, int64_t E, int H, int Cp, int Dp,
-                               float slope, void* xw16, float* a_ij, float* aggr, float* stats, float* out, void* stream);
-int glam_triplet_layer_bwd_params_x16(const float* x, const float* edge_attr, const float* staged, const void* xw16,
-                                      const float* a_ij, const float* aggr, const float* stats, const float* d_out,
-                                      const int32_t* rowptr, const int32_t* src, const int32_t* eid,
-                                      const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
-                                      int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
-                                      const float* weight_node, const float* weight_edge, const float* att, float* d_x,
-                                      float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
-                                      float* d_bias, void* ws, size_t ws_bytes, void* stream);
-
 /* ---------------------------------------------------------------------------------------------
  * MessageBlock remainder: gate math of one torch.nn.GRU(C, C) step with seq_len 1 (src_1gp/layer.py:247, :262).
  * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with
@@ -446,12 +410,12 @@ int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_a
                          const int32_t* ell_src, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De,
                          float slope, int edge_onehot, float* aggr, float* stats, int grid_blocks, void* stream);
 
-/* glam_triplet_layer_fwd for edge lists with an ELL form (glam_ell_build, in-degree <= 4): node GEMM + the software-pipelined
- * aggregate with the update GEMM as its epilogue.  Same tensors and results (bit for bit) as glam_triplet_layer_fwd; 36 <= Cp <= 64,
- * H * Cp <= 192.  edge_onehot as in glam_triplet_fwd_ell. */
-/* 1 when glam_triplet_layer_fwd_ell runs these shapes on the warp-specialised kernel (csrc/triplet_ws.hip: producer waves gather, consumer
- * waves run the update GEMM out of an LDS tile ring; one-hot edge features of width 4): the faster route at EVERY batch size, so callers
- * with an ELL form take it below the LLC size as well. */
+/* glam_triplet_layer_fwd for molecular graphs — edge lists with an ELL form (glam_ell_build, in-degree <= 4) and one-hot edge features
+ * of width 4 (src_1gp/dataset.py:82): node GEMM + the warp-specialised aggregate / update launch (csrc/triplet_ws.hip: producer waves
+ * gather, consumer waves run the update GEMM out of an LDS tile ring).  Same tensors and results (bit for bit) as
+ * glam_triplet_layer_fwd; the faster route at EVERY batch size.  glam_triplet_layer_ws_supported says whether a shape is inside
+ * (36 <= Cp <= 64, H * Cp <= 192, Dp = 4, edge_onehot = 1); other shapes are GLAM_E_UNSUPPORTED here and belong to
+ * glam_triplet_layer_fwd. */
 int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot);
 int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
                                const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp, float slope,

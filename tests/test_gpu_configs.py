@@ -1,7 +1,9 @@
 """GPU (MI355X): the BASELINE.json configurations at their stated sizes, HIP path against the CPU oracle.
 
 configs[1]  ESOL batch = 1024, fp32, ONE TripletMessage(60, 4, heads=3) layer fwd + bwd: output and all six gradients
-configs[2]  full stack (3 message steps + GlobalPool5, out_dim = 2) with bf16 row storage at the dataset-sized batches
+configs[2]  full stack (3 message steps + GlobalPool5, out_dim = 2) at the dataset-sized batches (64 / 642 / 2039 molecules).  BASELINE names
+            bf16 for this row; the reference has no reduced precision, and the bf16 ROW STORAGE mode rounds 2-4 built for it never beat fp32
+             and was removed in round 4: the configuration is run, and held to the fp32 bar, in fp32
 configs[3]  Tox21 (12 tasks) / ToxCast (617 tasks) heads with the masked BCEWithLogits of src_1gp/trainer.py:234-246 at 1024
             graphs per rank; the two-shard data-parallel sum; a real 2-process run of the HIP model
 
@@ -66,11 +68,11 @@ def test_config2_full_batch_fwd_bwd_all_gradients(device):
     print("\n".join(f"  config2 {n:22s} max|d| = {e:.2e}  (bound {bd:.2e})" for n, e, bd in report))
 
 
-def test_config2_beyond_the_llc_b16384_pipelined_kernels(device):
-    """"also report B = 16 384" — every [N, 180] tensor is 226 MiB, past the 256 MiB LLC, which is where the op layer
-    switches to the software-pipelined forward (fused with the update GEMM) and the pipelined backward by source.  Output and all six
-    gradients against the fp32 oracle (fp32 only: the fp64 twin of a 330 k-node batch is not a few-seconds job), scaled bounds of the
-    sweeps (tests/sweeps/big_batch_parity.py measures 4.1e-7 / 1.8e-6)."""
+def test_config2_beyond_the_llc_b16384(device):
+    """"also report B = 16 384" — every [N, 180] tensor is 226 MiB, past the 256 MiB LLC (the warp-specialised kernels
+    with 80 tiles per block).  Output and all six gradients against the fp32 oracle on the whole batch (scaled bounds: the fp64 twin of a
+    330 k-node batch is not a few-seconds job), AND the fp64-twin bound where the batch allows it: graphs are independent, so the output
+    rows and d_x rows of the first ~200 molecules (>= 4 096 atoms) equal those of that sub-batch run alone, in fp32 and in fp64."""
     torch.set_num_threads(min(16, torch.get_num_threads()))
     b = synth_batch(16384, seed=3)
     N = b.x.size(0)
@@ -84,7 +86,7 @@ def test_config2_beyond_the_llc_b16384_pipelined_kernels(device):
     g_ref = torch.autograd.grad((ref * cot).sum(), [xo] + ps0)
     convd = conv.to(device)
     bd = b.to(device)
-    assert ops.GraphIndex.wants_ell(N, 3, 60), "the pipelined kernels are the op layer's choice at this size"
+    assert ops.GraphIndex.wants_ell(N, 3, 60), "the working set is beyond the LLC at this size"
     x = x0.to(device).requires_grad_(True)
     out = convd(x, bd.edge_index, bd.edge_attr)
     gs = torch.autograd.grad((out * cot.to(device)).sum(), [x] + list(convd.parameters()))
@@ -94,10 +96,23 @@ def test_config2_beyond_the_llc_b16384_pipelined_kernels(device):
     gw = max((a.cpu() - r).abs().max().item() / max(1.0, r.abs().max().item()) for a, r in zip(gs, g_ref))
     print(f"  config2 B=16384 N={N}: out {worst:.2e}, worst gradient {gw:.2e} (relative to scale)")
     assert worst < 1e-5 and gw < 1e-4
+    # the slice with an fp64 twin: the first graphs that hold >= 4 096 atoms
+    n_mol = int((b.batch < 4096).sum().item())
+    n_sl = int((b.batch <= b.batch[n_mol - 1]).sum().item())        # whole molecules
+    e_sl = int(((b.edge_index[0] < n_sl) & (b.edge_index[1] < n_sl)).sum().item())
+    assert bool((b.edge_index[:, :e_sl] < n_sl).all()) and bool((b.edge_index[:, e_sl:] >= n_sl).all()), "collation keeps a molecule's edges together"
+    twin = {}
+    for dt in (torch.float32, torch.float64):
+        xs = x0[:n_sl].to(dt).requires_grad_(True)
+        o = O.triplet_message(xs, b.edge_index[:, :e_sl], b.edge_attr[:e_sl].to(dt), *[p.detach().to(dt) for p in ps0])
+        twin[dt] = (o.detach(), torch.autograd.grad((o * cot[:n_sl].to(dt)).sum(), xs)[0])
+    e_o, b_o = assert_fp32_parity(out[:n_sl], twin[torch.float64][0], twin[torch.float32][0], "config2 B=16384 slice out", out_tol=1e-5)
+    e_x, b_x = assert_fp32_parity(gs[0][:n_sl], twin[torch.float64][1], twin[torch.float32][1], "config2 B=16384 slice d_x")
+    print(f"  config2 B=16384 slice of {n_sl} atoms vs its fp64 twin: out {e_o:.2e} (bound {b_o:.2e}), d_x {e_x:.2e} (bound {b_x:.2e})")
 
 
 # ---------------------------------------------------------------------------------------------
-# configs[2]: full stack, bf16 row storage
+# configs[2]: full stack at the dataset sizes
 # ---------------------------------------------------------------------------------------------
 def _arch(out_dim, **kw):
     return model.Architecture(mol_block="_TripletMessage", message_steps=3, mol_readout="GlobalPool5", e_dim=1024, out_dim=out_dim,
@@ -111,34 +126,11 @@ def _arch_oracle(net, batch, dtype):
     return out, sd
 
 
-def _triplet_bf16_rows(x, edge_index, edge_attr, wn, we, att, wsc, bias, heads=3, slope=0.2):
-    """O.triplet_message with the storage model of the bf16-row kernels: the MESSAGE reads x_j rounded to bf16 (round to
-    nearest even, straight-through gradient); logits, softmax and sums are the oracle's."""
-    N, C = x.size(0), wn.size(0)
-    xw, ew = x @ wn, edge_attr @ we
-    xq = xw + (xw.detach().float().bfloat16().to(xw.dtype) - xw.detach())
-    src, dst = edge_index[0], edge_index[1]
-    x_i, x_j = xw[dst].view(-1, heads, C), xw[src].view(-1, heads, C)
-    e_ij = ew.view(-1, heads, C)
-    alpha = torch.nn.functional.leaky_relu((torch.cat([x_i, e_ij, x_j], -1) * att).sum(-1), slope)
-    alpha = O.segment_softmax(alpha, dst, N)
-    aggr = O.scatter(alpha.view(-1, heads, 1) * e_ij * xq[src].view(-1, heads, C), dst, N, "sum")
-    return aggr.reshape(N, -1) @ wsc + bias
-
-
-@pytest.mark.parametrize("B", [64, 642])
-def test_config3_full_stack_bf16_rows(device, B, monkeypatch):
-    """FreeSolv (642 molecules) / a 64-molecule batch through Architecture(3 steps, GlobalPool5, out_dim 2 = the two tasks),
-    eval mode (RReLU = its mean slope, dropout off), gathered rows stored in bf16.  The reference has no reduced precision, so
-    parity is defined twice:
-      (1) against the oracle WITH the same storage model (message rows rounded to bf16, everything else fp32): what is left is
-          fp32 re-association plus the rows whose fp32 value sits within one fp32 ulp of a bf16 rounding boundary and rounds
-          the other way (a fraction ~2^-23 / 2^-9 of 2-4 M row elements per layer, one bf16 ulp each): bound 5e-5 of the
-          output scale, 2e-4 of each gradient's scale (measured 5e-6 / 2.5e-5);
-      (2) against the plain fp32 oracle at the bf16 bound: a stored element carries <= 2^-9 relative error, the three stacked
-          layers add theirs linearly in the worst case (3 x 2^-8 = 1.2e-2) and the maximum over 642 x 2 outputs is taken:
-          bound 3e-2 of the output scale, 6e-2 of each gradient's scale (measured 1.5e-2 / 4e-2 at B = 642).
-    The same model with fp32 rows must meet the fp32 bound (fp64 twin) on the same inputs."""
+@pytest.mark.parametrize("B", [64, 642, 2039])
+def test_config3_full_stack_at_dataset_sizes(device, B):
+    """A 64-molecule batch / FreeSolv (642 molecules) / BBBP (2 039) through Architecture(3 steps, GlobalPool5, out_dim 2 = the two tasks),
+    eval mode (RReLU = its mean slope, dropout off): output and every parameter gradient against the oracle with the fp64-twin bound
+    (the forward output additionally within BASELINE's 1e-5)."""
     torch.manual_seed(7)
     b = synth_batch(B, seed=B, n_tasks=2)
     net = _arch(2).eval()
@@ -148,38 +140,13 @@ def test_config3_full_stack_bf16_rows(device, B, monkeypatch):
     names = [n for n, _ in net.named_parameters()]
     g32 = _grads(o32, cot, [sd32[n] for n in names])
     g64 = _grads(o64, cot.double(), [sd64[n] for n in names])
-    monkeypatch.setattr(O, "triplet_message", _triplet_bf16_rows)
-    om, sdm = _arch_oracle(net, b, torch.float32)
-    gm = _grads(om, cot, [sdm[n] for n in names])
-    monkeypatch.undo()
     net = net.to(device)
-    bd = b.to(device)
-    out = net(bd)
-    assert_fp32_parity(out, o64, o32, "fp32 rows: out", out_tol=1e-5)
+    out = net(b.to(device))
+    rep = [("out",) + assert_fp32_parity(out, o64, o32, f"config3 B={B} out", out_tol=1e-5)]
     for n, a, r64, r32 in zip(names, _grads(out, cot.to(device), list(net.parameters())), g64, g32):
-        assert_fp32_parity(a, r64, r32, f"fp32 rows: grad.{n}")
-    with ops.feature_storage("bf16"):
-        out16 = net(bd)
-        gs16 = _grads(out16, cot.to(device), list(net.parameters()))
-    rel = lambda a, r: (a.detach().cpu().double() - r.detach().double()).abs().max().item() / (r.abs().max().item() + 1e-30)
-    e_model, e_fp32 = rel(out16, om), rel(out16, o64)
-    g_model = max(rel(a, r) for a, r in zip(gs16, gm))
-    g_fp32 = max(rel(a, r) for a, r in zip(gs16, g64))
-    print(f"\n  config3 B={B}: bf16 rows vs storage-model oracle: out {e_model:.2e}, worst grad {g_model:.2e} (of scale); "
-          f"vs fp32 oracle: out {e_fp32:.2e}, worst grad {g_fp32:.2e}")
-    assert e_model <= 5e-5 and g_model <= 2e-4, (e_model, g_model)
-    assert e_fp32 <= 3e-2 and g_fp32 <= 6e-2, (e_fp32, g_fp32)
-
-
-@pytest.mark.parametrize("alpha", [2, 6])
-def test_config3_bf16_rows_outside_the_fused_table_is_a_defined_error(device, alpha):
-    """hid_dim 30 / 90 (hid_dim_alpha 2 / 6): the bf16 row format exists for the 16-lane fused kernels (Cp 36..64) only.
-    Asking for it elsewhere raises GlamHipError before any launch — never a silent fp32 run reported as bf16."""
-    net = model.Architecture(mol_block="_TripletMessage", hid_dim_alpha=alpha, e_dim=64, out_dim=2).to(device).eval()
-    b = synth_batch(8, seed=1).to(device)
-    with ops.feature_storage("bf16"), pytest.raises(ops.GlamHipError):
-        net(b)
-    assert torch.isfinite(net(b)).all()          # and the fp32 path of the same model is untouched
+        rep.append((n,) + assert_fp32_parity(a, r64, r32, f"config3 B={B} grad.{n}"))
+    worst = max(rep, key=lambda r: r[1] / max(r[2], 1e-30))
+    print(f"\n  config3 B={B}: out max|d| = {rep[0][1]:.2e} (bound {rep[0][2]:.2e}); tightest gradient {worst[0]}: {worst[1]:.2e} of {worst[2]:.2e}")
 
 
 # ---------------------------------------------------------------------------------------------

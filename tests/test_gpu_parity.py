@@ -697,52 +697,6 @@ def test_two_tower_model_runs(device):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-@pytest.mark.parametrize("B,C,heads,De", [(64, 60, 3, 4), (300, 60, 3, 4), (7, 30, 3, 4), (64, 60, 1, 4), (40, 32, 2, 1), (33, 44, 3, 8)])
-def test_tile_path_is_bit_identical_to_the_general_path(device, B, C, heads, De, monkeypatch):
-    """The molecule-tile kernels (one launch per layer, operands in LDS) keep the k order of every GEMM and the edge
-    order of every segment of the general kernels: same bits, forward and backward."""
-    monkeypatch.setattr(ops, "TILES_ENABLED", True)
-    torch.manual_seed(B + C)
-    b = synth_batch(B, seed=B).to(device)
-    N, E = b.x.size(0), b.edge_index.size(1)
-    conv = layer.TripletMessage(C, De, heads=heads).to(device)
-    with torch.no_grad():
-        conv.bias.normal_(0, 0.1)
-    x = torch.randn(N, C, device=device, requires_grad=True)
-    ea = torch.rand(E, De, device=device)
-    cot = torch.randn(N, C, device=device)
-    gi = ops.graph_index(b.edge_index, N)
-    plan = gi.tile_plan()
-    assert plan is not None, "synthetic molecules must be tileable"
-    tile_ptr, T = plan
-    tp = tile_ptr.cpu()
-    assert tp[0] == 0 and tp[-1] == N and (tp[1:] >= tp[:-1]).all() and int((tp[1:] - tp[:-1]).max()) <= 112
-    tile_of = torch.bucketize(torch.arange(N), tp[1:], right=True)
-    src, dst = b.edge_index.cpu()
-    assert (tile_of[src] == tile_of[dst]).all(), "an edge crosses a tile boundary"
-    params = list(conv.parameters())
-
-    def run():
-        out = conv(x, b.edge_index, ea)
-        return [out] + list(torch.autograd.grad(out, params + [x], grad_outputs=cot))
-
-    tiled = run()
-    monkeypatch.setattr(ops, "TILES_ENABLED", False)
-    general = run()
-    for name, a, g in zip(["out"] + [n for n, _ in conv.named_parameters()] + ["x"], tiled, general):
-        assert torch.equal(a, g), f"{name}: tile path differs from the general path (max {float((a - g).abs().max()):.3e})"
-
-
-def test_tile_plan_falls_back_on_large_components(device, monkeypatch):
-    monkeypatch.setattr(ops, "TILES_ENABLED", True)
-    p = synth_protein_batch(2, seed=5, n_min=200, n_max=260).to(device)
-    gi = ops.graph_index(p.edge_index, p.x.size(0))
-    assert gi.tile_plan() is None      # a 200-residue component cannot fit a 112-node tile: general kernels
-    conv = layer.TripletMessage(48, 8).to(device)
-    out = conv(torch.randn(p.x.size(0), 48, device=device), p.edge_index, p.edge_attr)
-    assert torch.isfinite(out).all()
-
-
 def test_layer_parameter_gradients_form_one_bucket(device):
     from glam_amd.parallel import flat_view
     b = synth_batch(16, seed=1).to(device)
@@ -780,7 +734,7 @@ def test_layer_bwd_both_abi_routes_agree(device, C, H, De):
     check(lib.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(staged), stream()), "stage")
     xw, a_ij, aggr = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, HC, **f)
     stats, out = torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
-    check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), None, 0, N, E, H, Cp,
+    check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), N, E, H, Cp,
                                      Dp, 0.2, ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out), stream()), "fwd")
     ws = torch.empty(lib.glam_triplet_layer_bwd_workspace_bytes(N, E, H, Cp, Dp), dtype=torch.uint8, device=device)
 
@@ -1063,73 +1017,6 @@ def test_gcn_conv_against_oracle(device, D):
         assert_close(out, ref, TOL, "gcn out")
         for n, a, r in zip(["x", "weight", "bias"], _grads(out, cot.to(device), [x, conv.weight, conv.bias]), g_ref):
             assert_close(a, r, 3e-5, "gcn grad " + n)
-
-
-# ---------------------------------------------------------------------------------------------
-# bf16 row storage (BASELINE configs[2]; the reference is fp32 only, so parity is defined against the fp32 oracle
-# at bf16 tolerance, and against the oracle with its gathered message rows rounded to bf16 at the fp32 tolerance)
-# ---------------------------------------------------------------------------------------------
-def _triplet_with_bf16_rows(x, edge_index, edge_attr, wn, we, att, wsc, bias, heads=3, slope=0.2):
-    """O.triplet_message with the storage model of the x16 kernels: the MESSAGE reads x_j rounded to bf16
-    (round-to-nearest-even, straight-through gradient); logits, softmax and sums are those of the oracle."""
-    N, C = x.size(0), wn.size(0)
-    xw, ew = x @ wn, edge_attr @ we
-    xq = xw + (xw.detach().bfloat16().float() - xw.detach())
-    src, dst = edge_index[0], edge_index[1]
-    x_i, x_j = xw[dst].view(-1, heads, C), xw[src].view(-1, heads, C)
-    e_ij = ew.view(-1, heads, C)
-    alpha = torch.nn.functional.leaky_relu((torch.cat([x_i, e_ij, x_j], -1) * att).sum(-1), slope)
-    alpha = O.segment_softmax(alpha, dst, N)
-    aggr = O.scatter(alpha.view(-1, heads, 1) * e_ij * xq[src].view(-1, heads, C), dst, N, "sum")
-    return aggr.reshape(N, -1) @ wsc + bias
-
-
-@pytest.mark.parametrize("C,De,kind", [(60, 4, "mol"), (45, 8, "protein")])
-def test_triplet_bf16_row_storage(device, C, De, kind):
-    torch.manual_seed(300 + C)
-    b = synth_batch(96, seed=C) if kind == "mol" else synth_protein_batch(3, seed=C, n_min=150, n_max=400)
-    N = b.x.size(0)
-    # x and weight_node on coarse binary grids: x @ weight_node is then exact in fp32 (<= 17 significant bits), so the host
-    # and the device round the very same xw to bf16 and check (1) is not blurred by rounding-boundary flips
-    x0 = (torch.randn(N, C) * 4).round() / 4
-    ea0 = b.edge_attr if kind == "mol" else torch.rand(b.edge_index.size(1), De)
-    conv = layer.TripletMessage(C, De)
-    with torch.no_grad():
-        conv.bias.normal_(0, 0.1)
-        conv.weight_node.copy_((conv.weight_node * 64).round() / 64)
-    refs = []
-    for fn in (_triplet_with_bf16_rows, O.triplet_message):
-        ps0 = [p.detach().clone().requires_grad_(True) for p in conv.parameters()]
-        xo = x0.clone().requires_grad_(True)
-        out_ref = fn(xo, b.edge_index, ea0, *ps0)
-        if not refs:
-            cot = torch.randn(out_ref.shape)
-        refs.append((out_ref, _grads(out_ref, cot, [xo] + ps0)))
-    conv = conv.to(device)
-    x = x0.to(device).requires_grad_(True)
-    with ops.feature_storage("bf16"):
-        out = conv(x, b.edge_index.to(device), ea0.to(device))
-    gs = _grads(out, cot.to(device), [x] + list(conv.parameters()))
-    names = ["x"] + [n for n, _ in conv.named_parameters()]
-    # (1) exact storage model: fp32 tolerance
-    assert_close(out, refs[0][0], 2e-5, "x16 out vs storage model")
-    for n, a, r in zip(names, gs, refs[0][1]):
-        assert_close(a, r, 5e-5, f"x16 grad.{n} vs storage model")
-    # (2) the fp32 reference: bf16 tolerance (8 mantissa bits: 2^-9 relative per rounded row element)
-    scale = refs[1][0].abs().max().item()
-    assert (out.cpu() - refs[1][0]).abs().max().item() <= 1e-2 * scale
-    for n, a, r in zip(names, gs, refs[1][1]):
-        assert (a.cpu() - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-6, n
-    # fp32 storage is untouched by the switch being used elsewhere
-    out32 = conv(x, b.edge_index.to(device), ea0.to(device))
-    assert_close(out32, refs[1][0], TOL, "fp32 after bf16")
-
-
-def test_bf16_row_storage_refuses_unsupported_shapes(device):
-    b = synth_batch(4, seed=1).to(device)
-    conv = layer.TripletMessage(30, 4).to(device)          # Cp = 32: no bf16 variant of the 8-lane kernels
-    with ops.feature_storage("bf16"), pytest.raises(ops.GlamHipError):
-        conv(torch.randn(b.x.size(0), 30, device=device), b.edge_index, b.edge_attr)
 
 
 def test_triplet_four_heads_wide_fallback(device):
@@ -1985,40 +1872,14 @@ def test_torch_extension_ops_match_the_ctypes_route(device, monkeypatch):
     assert torch.isfinite(G.segment_pool(h, sp.ptr, 0)).all()
 
 
-def test_pipelined_fused_forward_equals_the_general_fused_kernel(device, monkeypatch):
-    """The layer's forward beyond the LLC (software-pipelined aggregate + update-GEMM epilogue, glam_triplet_layer_fwd_ell) against the
-    general fused kernel: output and all six gradients equal bit for bit; batches that are not a multiple of the 16-node tile,
-    isolated atoms, bf16 row storage keeping its own route."""
-    for B, seed in ((3, 1), (50, 2), (333, 3)):
-        b = synth_batch(B, seed=seed).to(device)
-        torch.manual_seed(seed)
-        conv = layer.TripletMessage(60, 4).to(device)
-        with torch.no_grad():
-            conv.bias.normal_(0, 0.1)
-        x0 = torch.randn(b.x.size(0), 60, device=device)
-        cot = torch.randn(b.x.size(0), 60, device=device)
-        res = []
-        for mode in ("0", "1"):
-            monkeypatch.setattr(ops, "PIPE_FUSED", mode)
-            x = x0.clone().requires_grad_(True)
-            out = conv(x, b.edge_index, b.edge_attr)
-            res.append((out, torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)))
-        assert torch.equal(res[0][0], res[1][0]), B
-        assert all(torch.equal(a, c) for a, c in zip(res[0][1], res[1][1])), B
-    monkeypatch.setattr(ops, "PIPE_FUSED", "1")
-    with ops.feature_storage("bf16"):
-        assert torch.isfinite(conv(x0, b.edge_index, b.edge_attr)).all()
-
-
 @pytest.mark.parametrize("C,H,B", [(60, 3, 1024), (60, 3, 7), (40, 4, 200), (64, 2, 90), (45, 3, 150), (60, 1, 64)])
 def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkeypatch, C, H, B):
-    """csrc/triplet_ws.hip (producer waves gather, consumer waves run the update GEMM out of an LDS tile ring; what the op launches for
-    molecular graphs at every size) against the general fused kernel AND the barrier-coupled pipelined one: output, the saved aggregate
-    and all six gradients equal bit for bit — every head count, padded widths, tile counts that are odd / smaller than the ring / not a
-    multiple of the producer groups, isolated atoms, both producer counts.  Round 4: at the reference's head count (3) the two
-    weight-gradient products are accumulated inside the warp-specialised backward launches (block partials summed in another fixed
-    order: rounding-level differences in the parameter gradients, d_x still bit-equal); ``GLAM_WS_WGRAD=0`` keeps the k_wgrad launch and
-    bit equality, and the fused route launches no k_wgrad."""
+    """csrc/triplet_ws.hip / triplet_ws_b1.hip (producer waves gather, consumer waves run the fused GEMM out of an LDS tile ring; what the
+    op launches for molecular graphs at every size) against the general fused kernels: output and the gradients of x, weight_node,
+    weight_scale and bias equal bit for bit — every head count, padded widths, tile counts that are odd / smaller than the ring / not a
+    multiple of the producer groups, isolated atoms; the warp-specialised B1 (H <= 3) sums the d_W_edge / d_M block partials in another
+    fixed order (rounding-level differences in weight_edge and the edge third of weight_triplet_att).  ``ops.WS_ROUTE = "0"`` and
+    ``GLAM_WS=0`` both select the general kernels."""
     b = synth_batch(B, seed=B + C).to(device)
     torch.manual_seed(C + H)
     conv = layer.TripletMessage(C, 4, heads=H).to(device)
@@ -2032,44 +1893,29 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
     Cp = (C + 3) // 4 * 4
     assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 1) == 1
     assert lib.glam_triplet_layer_ws_supported(H, Cp, 4, 0) == 0 and lib.glam_triplet_layer_ws_supported(H, Cp, 8, 1) == 0
+    monkeypatch.setenv("GLAM_TORCH_EXT", "0")
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
     res = {}
-    for name, mode, ws, prod, wg in (("general", "0", "1", "8", "1"), ("pipe", "1", "0", "8", "1"), ("ws8", "auto", "1", "8", "1"),
-                                     ("ws8_nowg", "auto", "1", "8", "0"), ("ws4", "auto", "1", "4", "1"), ("ws16", "auto", "1", None, "0")):
-        monkeypatch.setattr(ops, "PIPE_FUSED", mode)
-        monkeypatch.setenv("GLAM_FWD_WS", ws)
-        if prod is None:
-            monkeypatch.delenv("GLAM_WS_PROD", raising=False)      # the default: sixteen-wave kernels (rolling row set) where they exist
-        else:
-            monkeypatch.setenv("GLAM_WS_PROD", prod)
-        monkeypatch.setenv("GLAM_WS_WGRAD", wg)
-        monkeypatch.setenv("GLAM_TORCH_EXT", "0")
-        monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    for name, route, env in (("general", "0", "1"), ("general_env", "auto", "0"), ("ws", "auto", "1")):
+        monkeypatch.setattr(ops, "WS_ROUTE", route)
+        monkeypatch.setenv("GLAM_WS", env)
         x = x0.clone().requires_grad_(True)
         with _lib.kernel_timer(capacity=64) as kt:
             out = conv(x, b.edge_index, b.edge_attr)
             grads = torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)
-        launched = [n for n, _, _ in kt.records()]
-        res[name] = (out, grads, launched)
-    for name in ("ws8", "ws8_nowg", "ws4", "ws16"):      # forward, backward by target (d_aggr inside) and backward by source (+ d_x) on the warp-specialised kernels
-        for k in ("k_triplet_fwd_ws", "k_triplet_bwd_src_ws") + (("k_triplet_bwd_dst_ws",) if H <= 3 else ()):
-            assert any(k in n for n in res[name][2]), (k, res[name][2])
-    fused_wg = H == 3        # the weight-gradient products ride in the backward launches: no k_wgrad launch on that route
-    assert any("wgrad" in n for n in res["ws8"][2]) and any("k_wgrad" in n for n in res["ws8"][2]) != fused_wg, res["ws8"][2]
-    assert any("k_wgrad" in n for n in res["ws8_nowg"][2]) and any("k_wgrad" in n for n in res["ws4"][2])
-    assert any("k_triplet_fwd_pipe" in n for n in res["pipe"][2]) and not any("_ws" in n or "_pipe" in n for n in res["general"][2])
+        res[name] = (out, grads, [n for n, _, _ in kt.records()])
+    for k in ("k_triplet_fwd_ws", "k_triplet_bwd_src_ws") + (("k_triplet_bwd_dst_ws",) if H <= 3 else ()):
+        assert any(k in n for n in res["ws"][2]), (k, res["ws"][2])
+    assert not any("_ws" in n for n in res["general"][2] + res["general_env"][2])
+    assert torch.equal(res["general"][0], res["general_env"][0]) and all(torch.equal(a, c) for a, c in zip(res["general"][1], res["general_env"][1]))
     names = ["x", "weight_node", "weight_edge", "weight_triplet_att", "weight_scale", "bias"]
-    for name in ("pipe", "ws8", "ws8_nowg", "ws4", "ws16"):
-        assert torch.equal(res["general"][0], res[name][0]), (name, (res["general"][0] - res[name][0]).abs().max().item())
-        for pn, a, c in zip(names, res["general"][1], res[name][1]):
-            if name == "ws8" and fused_wg and pn != "x":
-                # N-deep sums in another fixed order (256 block partials instead of k_wgrad's row splits)
-                assert_close(c, a, 4e-6, f"{name} d_{pn}")
-            elif name != "pipe" and H <= 3 and pn in ("weight_edge", "weight_triplet_att"):
-                # the warp-specialised B1 sums the d_W_edge / d_M block partials in another (fixed) order: rounding-level differences;
-                # d_x being bit-equal pins every per-edge and per-node quantity of B1 (alpha_e, dpre_e, d_a_i, d_aggr)
-                assert_close(c, a, 2e-6, f"{name} d_{pn}")
-            else:
-                assert torch.equal(a, c), (name, pn, (a - c).abs().max().item())
+    assert torch.equal(res["general"][0], res["ws"][0]), (res["general"][0] - res["ws"][0]).abs().max().item()
+    for pn, a, c in zip(names, res["general"][1], res["ws"][1]):
+        if H <= 3 and pn in ("weight_edge", "weight_triplet_att"):
+            # d_x being bit-equal pins every per-edge and per-node quantity of B1 (alpha_e, dpre_e, d_a_i, d_aggr)
+            assert_close(c, a, 2e-6, f"ws d_{pn}")
+        else:
+            assert torch.equal(a, c), (pn, (a - c).abs().max().item())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -2201,52 +2047,6 @@ def test_fused_gru_forward_is_bit_identical_to_the_two_launch_sequence(device, m
     for a, c in zip(*res):
         assert torch.equal(a, c)
     assert not ops._lib.load().glam_gru_fused_supported(66) and not ops._lib.load().glam_gru_fused_supported(0)
-
-
-def test_pipelined_backward_b2_equals_the_general_kernel(device, monkeypatch):
-    """The layer's backward beyond the LLC (software-pipelined B2 over ELL records by source + the d_x GEMM as its own launch) against the
-    default route (general B2 with the d_x GEMM as its epilogue): all six gradients equal bit for bit — batches that are not a multiple of
-    the tiles, isolated atoms, one-hot and continuous edge features, De = 8, a layer applied twice (gradient carry)."""
-    for B, seed, De in ((3, 1, 4), (50, 2, 4), (333, 3, 4), (40, 4, 8)):
-        b = synth_batch(B, seed=seed).to(device)
-        ea = b.edge_attr if De == 4 else torch.randn(b.edge_attr.size(0), 8, device=device)
-        if seed == 3:
-            ea = ea + 0.25 * torch.rand_like(ea)                     # not one-hot: the contraction path
-        torch.manual_seed(seed)
-        conv = layer.TripletMessage(60, De).to(device)
-        x0 = torch.randn(b.x.size(0), 60, device=device)
-        cot = torch.randn(b.x.size(0), 60, device=device)
-        res = []
-        for ell in (False, True):
-            monkeypatch.setattr(ops, "BWD_ELL", ell)
-            monkeypatch.setattr(ops.GraphIndex, "ELL_MIN_NODES", 0 if ell else 1 << 40)
-            monkeypatch.setattr(ops, "PIPE_FUSED", "0")
-            monkeypatch.setattr(ops, "B1_WS", False)          # B2 alone is under test here: B1 on the general kernel in both runs
-            monkeypatch.setenv("GLAM_B1_WS", "0")
-            x = x0.clone().requires_grad_(True)
-            with ops.weight_scope():
-                y = conv(conv(x, b.edge_index, ea), b.edge_index, ea)
-                res.append(torch.autograd.grad(y, [x] + list(conv.parameters()), grad_outputs=cot))
-        assert all(torch.equal(a, c) for a, c in zip(*res)), (B, De)
-    # B2 alone against a plain torch statement of it
-    gi = ops.GraphIndex(b.edge_index, b.x.size(0))
-    ell_t = gi.ell_t()
-    assert ell_t is not None
-    N, E, H, Cp = gi.N, gi.E, 3, 64
-    g = torch.Generator().manual_seed(5)
-    r = lambda *s: torch.randn(*s, generator=g).to(device)
-    d_aggr, alpha, dpre, w_edge, eattr = r(N, H * Cp), r(E, 4), r(E, 4), r(8, H * Cp), r(E, 8)
-    d_xw, d_a = torch.empty(N, H * Cp, device=device), torch.zeros(N, 8, device=device)
-    raw = ops._lib.load()
-    ops.check(raw.glam_triplet_bwd_src_ell(ops.ptr(d_aggr), ops.ptr(alpha), ops.ptr(dpre), ops.ptr(eattr), ops.ptr(w_edge), ops.ptr(ell_t[0]),
-                                           ops.ptr(ell_t[1]), N, E, H, Cp, 8, 0, ops.ptr(d_xw), ops.ptr(d_a), 0, ops.stream()), "b2 ell")
-    src, dst = b.edge_index[0], b.edge_index[1]
-    e_ij = (eattr.double() @ w_edge.double()).view(E, H, Cp)
-    msg = alpha[:, :H].double().unsqueeze(-1) * e_ij * d_aggr.double().view(N, H, Cp)[dst]
-    ref = torch.zeros(N, H, Cp, dtype=torch.float64, device=device).index_add_(0, src, msg).view(N, H * Cp)
-    ref_a = torch.zeros(N, 4, dtype=torch.float64, device=device).index_add_(0, src, dpre.double())
-    assert (d_xw.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
-    assert (d_a[:, 4:].double() - ref_a).abs().max().item() <= 1e-5 * max(1.0, ref_a.abs().max().item())
 
 
 def test_graphed_epochs_with_several_steps_per_graph_launch(device):

@@ -16,7 +16,6 @@ ap.add_argument("--block", default="_TripletMessage")
 ap.add_argument("--readout", default="GlobalPool5")
 ap.add_argument("--alpha", type=int, default=4, help="hid_dim_alpha (hidden width = 15 * alpha)")
 ap.add_argument("--out-dim", type=int, default=1)
-ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"])
 ap.add_argument("--loss", default="mse", choices=["mse", "bcel"], help="bcel: masked BCEWithLogits over labels >= 0 (trainer.py:244-245)")
 ap.add_argument("--preset", default="relu", choices=["relu", "model_default", "run_default"],
                 help="relu: deterministic ReLU / no dropout (parity configuration); model_default: Architecture() keyword defaults "
@@ -27,7 +26,6 @@ ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
-ops.FEATURE_STORAGE = args.storage
 if args.preset == "relu":
     net = model.Architecture(hid_dim_alpha=args.alpha, out_dim=args.out_dim, mol_block=args.block, message_steps=3, mol_readout=args.readout, graph_norm=args.norm,
                              graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(dev)
@@ -83,6 +81,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"workload": f"Architecture({args.block}, hid_dim_alpha={args.alpha}, 3 steps, {args.readout}, e_dim=1024, norm={args.norm}, "
-                              f"out_dim={args.out_dim}, rows={args.storage}, loss={args.loss}, preset={args.preset}) fwd+bwd+Adam, B={args.batch}",
+                              f"out_dim={args.out_dim}, loss={args.loss}, preset={args.preset}) fwd+bwd+Adam, B={args.batch}",
                   "launch": "eager" if g is None else "hipGraph", "ms_per_step": dt / args.steps * 1e3,
                   "molecules_per_s": args.batch * args.steps / dt}))

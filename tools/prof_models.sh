@@ -1,5 +1,5 @@
-# Round-3 full-model numbers (run on the GPU box from the repo root: bash tools/prof_models_r3.sh TAG)
-R=$PWD; TAG=${1:-r3b}; cd /tmp && export TMPDIR=/tmp
+# Full-model numbers (run on the GPU box from the repo root: bash tools/prof_models.sh TAG)
+R=$PWD; TAG=${1:-r4b}; cd /tmp && export TMPDIR=/tmp
 db() { ls $1/*.db $1/*/*.db 2>/dev/null | head -1; }
 {
 for preset in relu model_default run_default; do
@@ -7,11 +7,8 @@ for preset in relu model_default run_default; do
   python3 $R/tools/bench_model.py --preset $preset --batch 32 2>/dev/null | tail -1
 done
 python3 $R/tools/bench_model.py --preset run_default --block _TripletMessage 2>/dev/null | tail -1
-python3 $R/tools/bench_model.py --preset relu --out-dim 2 --storage bf16 2>/dev/null | tail -1
 python3 $R/tools/bench_model.py --preset relu --out-dim 2 2>/dev/null | tail -1
-python3 $R/tools/bench_model.py --preset relu --out-dim 2 --storage bf16 --batch 642 2>/dev/null | tail -1
 python3 $R/tools/bench_model.py --preset relu --out-dim 2 --batch 642 2>/dev/null | tail -1
-python3 $R/tools/bench_model.py --preset relu --out-dim 2 --storage bf16 --batch 2039 2>/dev/null | tail -1
 python3 $R/tools/bench_model.py --preset relu --out-dim 2 --batch 2039 2>/dev/null | tail -1
 python3 $R/tools/bench_model.py --preset relu --out-dim 12 --loss bcel 2>/dev/null | tail -1
 python3 $R/tools/bench_model.py --preset relu --out-dim 617 --loss bcel 2>/dev/null | tail -1

@@ -1,5 +1,5 @@
 """Developer aid: nothing but the fused forward of one TripletMessage layer, a few times (the command a rocprofv3 --pmc pass wraps).
-usage: run_fwd_only.py B [reps] ; environment: GLAM_FWD_WS / GLAM_WS_PROD / GLAM_PIPE_FUSED select the kernel."""
+usage: run_fwd_only.py B [reps] ; environment: GLAM_WS=0 / GLAM_WS_ROUTE=0 select the general kernels."""
 import os, sys
 os.environ.setdefault("GLAM_TORCH_EXT", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -9,8 +9,6 @@ from glam_amd.data import synth_batch
 dev = torch.device("cuda:0")
 lib = _lib.load(); raw = ctypes.CDLL(_lib.LIB_PATH)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-ops.PIPE_FUSED = "1"
-os.environ["GLAM_FWD_WS"] = "1"
 b = synth_batch(B, seed=7).to(dev)
 torch.manual_seed(0)
 conv = layer.TripletMessage(60, 4).to(dev)
@@ -19,7 +17,7 @@ with torch.no_grad():
     for _ in range(3):
         conv(x, b.edge_index, b.edge_attr)
 torch.cuda.synchronize()
-P = int(os.environ.get("GLAM_WS_PROD", "8"))
+P = 8
 buf = (ctypes.c_longlong * 6144)()
 assert raw.glam_debug_ws_prof(buf, 6144) == 0
 a = np.array(buf[:], dtype=np.int64).reshape(64, 12, 8)
