@@ -1,0 +1,731 @@
+"""Dense operators of the path: linears on the hand-written MFMA kernels (k_ts_gemm / k_wgrad / narrow heads), NNConv's relation
+table, the GRU step of MessageBlock (src_1gp/layer.py:223-267).
+
+Part of ``glam_amd.ops`` (every public name here is re-exported there: ``from glam_amd import ops; ops.linear(...)``).  Knobs, the weight
+scope, the padded-column bookkeeping and the index staging live in ``glam_amd/ops.py`` and are read through ``_o`` at call time."""
+from __future__ import annotations
+
+import os
+import weakref
+
+import torch
+
+from . import _lib
+from . import ops as _o
+from ._lib import GlamHipError, check, f32c, ptr, require_device, stream
+
+# --------------------------------------------------------------------------------------
+# dense linear on the fp32 matrix cores + GRU gate math (MessageBlock remainder)
+# --------------------------------------------------------------------------------------
+def linear_supported(K, M):
+    """Shapes the tall-skinny MFMA kernels cover in both directions (gemm.hip: ts_variant 0 / 1) with room for the bias
+    ones-column in the weight-gradient kernel."""
+    Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
+    return (Kp <= 60 and Mp <= 192) or (Kp <= 188 and Mp <= 64)
+
+
+class _Linear(torch.autograd.Function):
+    """y[N,M] = x[N,K] @ w[M,K]^T + b on k_ts_gemm; d_x on k_ts_gemm, d_w / d_b on k_wgrad (K, M multiples of 4).
+    ``w`` may have FEWER columns than ``x`` (``w[M, Kw]``, ``Kw <= K``): ``x`` is then a zero-padded data matrix (atom features
+    15 -> 16) and the weight image is built straight from the unpadded parameter (the image zero-fills k >= Kw); only for an
+    ``x`` that needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        x, w = f32c(x, "x"), f32c(w, "weight")
+        b = None if b is None else f32c(b, "bias")
+        N, K = x.shape
+        M, Kw = w.shape
+        if Kw > K or (Kw < K and ctx.needs_input_grad[0]):
+            raise GlamHipError("linear: weight wider than the input / narrow weight with a differentiable input")
+        lib, dev = _lib.load(), x.device
+        scope = _o._SCOPE
+
+        def build():
+            img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, dtype=torch.float32, device=dev)
+            check(lib.glam_ts_gemm_make_image(ptr(w), Kw, 1, Kw, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+            return img
+
+        img = _o._scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
+        y = torch.empty(N, M, dtype=torch.float32, device=dev)
+        check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.scope = scope
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(M, K) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), K, 0, M, K, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+
+            img = _o._scoped(ctx.scope.bwd if ctx.scope else None, ("lin", id(w)), w, build)
+            dx = torch.empty(N, K, **f)
+            check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
+        if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]
+            check(lib.glam_wgrad_gemm(ptr(x), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), 1, K + 1, ptr(ws), ws.numel(),
+                                      stream()), "glam_wgrad_gemm")
+        else:         # out[m, k] = sum_n dy[n,m] [x|1][n,k]
+            check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(),
+                                      stream()), "glam_wgrad_gemm")
+        dw = dwb[:M, :w.size(1)]
+        db = dwb[:M, K] if ctx.has_bias else None
+        return dx, dw, db
+
+
+class _RelationMLP(torch.autograd.Function):
+    """``nn(eye(De))`` for ``nn = Linear(De, hidden) -> ReLU -> Linear(hidden, M)``: the relation-weight table of NNConv with one-hot
+    bond features (src_1gp/layer.py:115-122) — one launch forward, two backward, instead of a dozen library launches on 4-row
+    operands (csrc/relmlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, b2):
+        require_device(w1, b1, w2, b2)
+        w1, b1, w2, b2 = f32c(w1, "w1"), f32c(b1, "b1"), f32c(w2, "w2"), f32c(b2, "b2")
+        Hd, De = w1.shape
+        M = w2.size(0)
+        lib = _lib.load()
+        h = torch.empty(De, Hd, dtype=torch.float32, device=w1.device)
+        out = torch.empty(De, M, dtype=torch.float32, device=w1.device)
+        check(lib.glam_relation_mlp_fwd(ptr(w1), ptr(b1), ptr(w2), ptr(b2), De, Hd, M, ptr(h), ptr(out), stream()), "glam_relation_mlp_fwd")
+        ctx.save_for_backward(h, w2)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        h, w2 = ctx.saved_tensors
+        De, Hd = h.shape
+        M = w2.size(0)
+        lib, dev = _lib.load(), h.device
+        d_out = f32c(d_out, "d_out")
+        f = dict(dtype=torch.float32, device=dev)
+        d_w1, d_b1, d_w2, d_b2 = torch.empty(Hd, De, **f), torch.empty(Hd, **f), torch.empty(M, Hd, **f), torch.empty(M, **f)
+        ws = torch.empty(lib.glam_relation_mlp_workspace_bytes(De, Hd, M), dtype=torch.uint8, device=dev)
+        check(lib.glam_relation_mlp_bwd(ptr(d_out), ptr(h), ptr(w2), De, Hd, M, ptr(d_w1), ptr(d_b1), ptr(d_w2), ptr(d_b2), ptr(ws),
+                                        ws.numel(), stream()), "glam_relation_mlp_bwd")
+        return d_w1, d_b1, d_w2, d_b2
+
+
+def relation_mlp(nn, De):
+    """``nn(eye(De))`` — on the HIP kernels when ``nn`` is the reference's ``Sequential(Linear(De, hidden), ReLU(), Linear(hidden, M))``
+    (fp32, on the device, a shape ``glam_relation_mlp_supported`` accepts: De <= 8, hidden a power of two up to 64), through torch
+    otherwise."""
+    mods = list(nn.children()) if isinstance(nn, torch.nn.Sequential) else []
+    if (len(mods) == 3 and isinstance(mods[0], torch.nn.Linear) and isinstance(mods[1], torch.nn.ReLU) and isinstance(mods[2], torch.nn.Linear)
+            and mods[0].bias is not None and mods[2].bias is not None and mods[0].in_features == De
+            and mods[0].weight.is_cuda and mods[0].weight.dtype == torch.float32 and mods[2].weight.dtype == torch.float32
+            and _lib.load().glam_relation_mlp_supported(De, mods[0].out_features, mods[2].out_features)):
+        return _RelationMLP.apply(mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias)
+    p = next(nn.parameters())
+    return nn(torch.eye(De, dtype=p.dtype, device=p.device))
+
+
+class _MatmulTall(torch.autograd.Function):
+    """``A[N,K] @ W[K,M] (+ bias)`` for tall A and a small weight whose shape is outside the MFMA forward table: the two
+    data-side products stay on the library GEMM, but the WEIGHT gradient ``A^T @ dY`` — a reduction over the N rows for
+    which the library's heuristics pick 32x32 tiles (77 us at N = 20 k, K = 240, M = 60) — runs on ``k_wgrad`` (≈12 us),
+    the bias gradient riding on its ones column.  ``carry``: the gradient carry of (w, bias) when a block applies them several
+    times per forward (see _ParamBundle): [d_w | d_bias] flat, summed by the reduction of the weight-gradient product."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, carry=None):
+        require_device(a, w, bias)
+        a, w = f32c(a, "a"), f32c(w, "w")
+        ctx.save_for_backward(a, w)
+        ctx.has_bias = bias is not None
+        ctx.scope = _o._SCOPE
+        ctx.carried = carry is not None
+        if ctx.carried:
+            ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
+        # (an 80 KB-image k_ts_gemm<4, 20, 4> for K <= 320 was measured here — NNConv's [N, 300] x [300, 60] relation product —: 18.9 us
+        # against the library's 15 at N = 20 k, at 256 registers: not kept)
+        out = torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
+        return (out, carry.view(-1)) if ctx.carried else out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, d_carry=None):
+        a, w = ctx.saved_tensors
+        N, K = a.shape
+        M = w.size(1)
+        if dy is None:      # only with a carry (grads are not materialised then): the output itself was unused
+            return None, None, None, d_carry
+        dy = f32c(dy, "dy")
+        da = None
+        if ctx.needs_input_grad[0]:
+            if M <= 96 and K <= 320 and K > 64:
+                # dy[N, M] @ w^T[M, K] with a wide output: the 120 KB-image k_ts_gemm variant (the library GEMM picks 16x256
+                # tiles for this shape: 44 us for 60 -> 300 at N = 20 k)
+                lib = _lib.load()
+                scope = ctx.scope
+                img = _o._scoped(scope.bwd if scope else None, ("tall-dx", id(w)), w, lambda: _o._ts_image(w, M, K, True))
+                da = torch.empty(N, K, dtype=torch.float32, device=a.device)
+                check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(da), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+            else:
+                da = torch.matmul(dy, w.t())
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.has_bias or ctx.carried:
+            lib = _lib.load()
+            ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
+            add = f32c(d_carry, "d_carry") if (ctx.carried and d_carry is not None and N > 0) else None
+
+            def product(*args):     # (P, I, ldp, ones, Q, J, ldq, out, si, sj): the carry, laid out like `out`, joins in the reduction
+                P, I, ldp, ones, Q, J, ldq, out, si, sj = args
+                if add is None:
+                    check(lib.glam_wgrad_gemm(ptr(P), I, ldp, None, 0, 0, ones, ptr(Q), J, ldq, 0, N, ptr(out), si, sj, ptr(ws), ws.numel(),
+                                              stream()), "glam_wgrad_gemm")
+                else:
+                    check(lib.glam_wgrad_gemm_add(ptr(P), I, ldp, None, 0, 0, ones, ptr(Q), J, ldq, 0, N, ptr(out), si, sj, ptr(add),
+                                                  ptr(ws), ws.numel(), stream()), "glam_wgrad_gemm_add")
+
+            if ctx.has_bias:   # [dw ; db] = [a | 1]^T dy   (K + 1 <= 320, M <= 128: matmul_tall's bias condition)
+                dwb = torch.empty(K + 1, M, dtype=torch.float32, device=a.device)
+                product(a, K, K, 1, dy, M, M, dwb, M, 1)
+                if ctx.carried:
+                    flat = dwb.view(-1)
+                    return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
+                return da, dwb[:K], dwb[K]
+            dw = torch.empty(K, M, dtype=torch.float32, device=a.device)
+            if M <= 128:      # dw = a^T dy: P = a (up to 320 columns), Q = dy (two 64-column chunks beyond 64)
+                product(a, K, K, 0, dy, M, M, dw, M, 1)
+            else:             # wide output: dw^T = dy^T a, written through transposed strides
+                product(dy, M, M, 0, a, K, K, dw, 1, M)
+            if ctx.carried:
+                flat = dw.view(-1)
+                return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
+        return da, dw, db
+
+
+def _matmul_tall_node(a, w, bias):
+    """``_MatmulTall`` with the gradients of (w, bias) carried across the applications of a block inside a weight_scope."""
+    K, M = w.shape
+    total = K * M + (M if bias is not None else 0)
+    params = (w,) if bias is None else (w, bias)
+
+    def split(flat):     # [d_w (K x M) | d_bias (M)]: the layout of the [a | 1]^T dy product
+        return (flat[:K * M].view(K, M),) if bias is None else (flat[:K * M].view(K, M), flat[K * M:])
+    key = ("carry-tall", id(w), id(bias))
+    carry = _o._carry_for(key, params, total, split) if (w.requires_grad or (bias is not None and bias.requires_grad)) else None
+    if carry is None:
+        return _MatmulTall.apply(a, w, bias)
+    out, carry = _MatmulTall.apply(a, w, bias, carry)
+    _o._carry_store(key, w, carry)
+    return out
+
+
+def matmul_tall(a, w, bias=None):
+    """``a @ w (+ bias)`` with the weight gradient on the MFMA reduction kernel when it fits: one of (K, M) <= 320 and the other
+    <= 128, multiples of 4 (with a bias: K + 1 <= 320 and M <= 128)."""
+    K, M = w.shape
+    ok = a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and a.size(0) >= 64
+    if ok and bias is not None and K + 1 <= 320 and M <= 128:
+        return _matmul_tall_node(a, w, bias)
+    if ok and ((K <= 320 and M <= 128) or (K <= 128 and M <= 320)):
+        out = _matmul_tall_node(a, w, None)
+        return out if bias is None else out + bias
+    out = torch.matmul(a, w)
+    return out if bias is None else out + bias
+
+
+class _LinearTall(torch.autograd.Function):
+    """``y = x @ w^T + b`` for layer widths beyond the MFMA forward table (e.g. the GRU gate linears 92 -> 276 of
+    hid_dim_alpha = 6): the data-side products on the library GEMM, ``[d_w | d_b] = dy^T [x | 1]`` on ``k_wgrad``."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        x, w, b = f32c(x, "x"), f32c(w, "weight"), f32c(b, "bias")
+        ctx.save_for_backward(x, w)
+        N, K = x.shape
+        M = w.size(0)
+        if K <= 96 and M <= 320:       # the 120 KB-image k_ts_gemm variant (24 vs 29 us for 92 -> 276 at N = 20.7 k)
+            lib = _lib.load()
+            img = _o._scoped(_o._SCOPE.fwd if _o._SCOPE else None, ("lin", id(w)), w, lambda: _o._ts_image(w, K, M, True))
+            y = torch.empty(N, M, dtype=torch.float32, device=x.device)
+            check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
+            return y
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        dx = torch.matmul(dy, w) if ctx.needs_input_grad[0] else None
+        lib = _lib.load()
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        if K + 1 <= 64:
+            # weight and bias gradients as separate contiguous tensors: autograd keeps them as they are (views of one [M, K + 1] buffer
+            # cost a copy launch each when they become .grad)
+            dw, db = torch.empty(M, K, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device)
+            check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), K, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
+                  "glam_wgrad_gemm_split")
+            return dx, dw, db
+        dwb = torch.empty(M, K + 1, dtype=torch.float32, device=x.device)
+        check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(), stream()),
+              "glam_wgrad_gemm")
+        return dx, dwb[:, :K], dwb[:, K]
+
+
+def linear_tall_supported(K, M):
+    return K % 4 == 0 and M % 4 == 0 and M <= 320 and K + 1 <= 128
+
+
+class _LinearNarrow(torch.autograd.Function):
+    """``y[N, M] = x[N, K] @ w[M, K]^T + b`` for a handful of outputs (M <= 16: the model's output head, out_dim 1 / 2 / 12): row dot
+    products on ``glam_linear_narrow_fwd``; backward ``d_x``, ``d_w``, ``d_b`` in one pass over ``x`` + a fixed-order reduction
+    (``glam_linear_narrow_bwd``) — the GEMM library took 33 + 22 us for 1024 x 1024 -> 1, this takes a few us each way."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        x, w = f32c(x, "x"), f32c(w, "weight")
+        b = None if b is None else f32c(b, "bias")
+        N, K = x.shape
+        M = w.size(0)
+        y = torch.empty(N, M, dtype=torch.float32, device=x.device)
+        check(_lib.load().glam_linear_narrow_fwd(ptr(x), ptr(w), ptr(b), N, K, M, ptr(y), stream()), "glam_linear_narrow_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        lib = _lib.load()
+        f = dict(dtype=torch.float32, device=x.device)
+        dx = torch.empty(N, K, **f) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(M, K, **f)
+        db = torch.empty(M, **f) if ctx.has_bias else None
+        ws = torch.empty(lib.glam_linear_narrow_bwd_workspace_bytes(K, M), dtype=torch.uint8, device=x.device)
+        check(lib.glam_linear_narrow_bwd(ptr(x), ptr(w), ptr(dy), N, K, M, ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(), stream()),
+              "glam_linear_narrow_bwd")
+        return dx, dw, db
+
+
+class _LinearLib(torch.autograd.Function):
+    """``F.linear`` with the matrix products on the GEMM library (layers outside the MFMA kernels' table: the 300 -> 1024 readout MLP)
+    and the bias gradient on ``glam_colsum`` (torch's generic column reduction takes 14 us for [1024, 1024]; this takes a few)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(dy.t(), x) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.needs_input_grad[2] and dy.data_ptr() % 16:
+            db = dy.sum(0)                   # a contiguous view at a storage offset that is not 16-byte aligned: the kernel loads float4
+        elif ctx.needs_input_grad[2]:
+            lib = _lib.load()
+            N, D = dy.shape
+            db = torch.empty(D, dtype=torch.float32, device=dy.device)
+            ws = torch.empty(lib.glam_colsum_workspace_bytes(D), dtype=torch.uint8, device=dy.device)   # (touched for N > 2048 only)
+            check(lib.glam_colsum(ptr(dy), N, D, D, ptr(db), ptr(ws), ws.numel(), stream()), "glam_colsum")
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """``F.linear`` on the hand-written kernels when the shape is in their table (the layer-sized linears of the
+    path: GRU gates 60->180, input embedding 15->60, ... on the MFMA kernels; heads with <= 16 outputs as row dot products);
+    larger / odd layers (e.g. the 300->1024 readout MLP) stay on the library GEMM, which is the right tool for them."""
+    M, K = weight.shape
+    f32 = x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+    if x.dim() == 2 and x.is_cuda and f32 and M <= 16 and K >= 64 and K % 4 == 0 and not linear_supported(K, M):
+        return _LinearNarrow.apply(x, weight, bias)      # (other dtypes — fp64, autocast — fall through to F.linear below)
+    if x.dim() != 2 or not linear_supported(K, M):
+        if x.dim() == 2 and x.is_cuda and bias is not None and M % 4 == 0 and x.dtype == torch.float32 and weight.dtype == torch.float32:
+            return _LinearLib.apply(x, weight, bias)
+        return torch.nn.functional.linear(x, weight, bias)
+    Kp, Mp = (K + 3) // 4 * 4, (M + 3) // 4 * 4
+    if Kp != K:
+        x = _o.pad_cols(x, Kp)
+    if Kp != K and Mp == M and not (x.requires_grad and torch.is_grad_enabled()):
+        return _Linear.apply(x, weight, bias)    # data input (atom features): the image is built from the unpadded weight
+    if Kp != K or Mp != M:
+        # padded once per model pass (the block's linears are applied message_steps times), like every derived weight
+        w0, b0 = weight, bias
+        weight, bias = _o.scoped_weights(("lin-pad", id(w0), None if b0 is None else id(b0)), w0, lambda: (
+            torch.nn.functional.pad(w0, (0, Kp - K, 0, Mp - M)),
+            None if b0 is None else torch.nn.functional.pad(b0, (0, Mp - M))))
+    y = _Linear.apply(x, weight, bias)
+    return _o.slice_cols(y, M)                    # pad columns are x @ 0 + 0
+
+
+class _LinearSplit(torch.autograd.Function):
+    """(y1[N,M1], y2[N,M2]) = x[N,K] @ wt[K, M1+M2] with the two column blocks written to separate tensors
+    (node features + packed attention scalars of the single-head layers).  K, M1, M2 multiples of 4."""
+
+    @staticmethod
+    def forward(ctx, x, wt, M1):
+        require_device(x, wt)
+        x, wt = f32c(x, "x"), f32c(wt, "weight")
+        N, K = x.shape
+        M = wt.size(1)
+        M2 = M - M1
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M) // 4, **f)
+        check(lib.glam_ts_gemm_make_image(ptr(wt), M, 0, K, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+        y1, y2 = torch.empty(N, M1, **f), torch.empty(N, M2, **f)
+        check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), None, ptr(y1), M1, M1, ptr(y2), M2, M2, N, stream()), "glam_ts_gemm")
+        ctx.save_for_backward(x, wt)
+        ctx.M1 = M1
+        return y1, y2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy1, dy2):
+        x, wt = ctx.saved_tensors
+        N, K = x.shape
+        M = wt.size(1)
+        M1 = ctx.M1
+        M2 = M - M1
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        dy1, dy2 = f32c(dy1, "dy1"), f32c(dy2, "dy2")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            img = torch.empty(lib.glam_ts_gemm_image_bytes(M, K) // 4, **f)
+            check(lib.glam_ts_gemm_make_image(ptr(wt), M, 1, M, K, ptr(img), stream()), "glam_ts_gemm_make_image")
+            dx = torch.empty(N, K, **f)
+            check(lib.glam_ts_gemm(ptr(dy1), M1, M1, ptr(dy2), M2, M2, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()),
+                  "glam_ts_gemm")
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        dwt = torch.empty(K, M, **f)     # out[i = m, j = k] written at dwt[k, m]
+        check(lib.glam_wgrad_gemm(ptr(dy1), M1, M1, ptr(dy2), M2, M2, 0, ptr(x), K, K, 0, N, ptr(dwt), 1, M, ptr(ws), ws.numel(),
+                                  stream()), "glam_wgrad_gemm")
+        return dx, dwt, None
+
+
+def linear_split(x, wt, M1):
+    """``x @ wt`` split into the first ``M1`` and the remaining columns (both contiguous)."""
+    return _LinearSplit.apply(x, wt, M1)
+
+
+def linear_split_supported(K, M):
+    return K % 4 == 0 and M % 4 == 0 and K <= 64 and M <= 192      # K is the J side of the weight-gradient kernel
+
+
+class _GruGates(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        require_device(gi, gh, h)
+        gi, gh, h = f32c(gi, "gi"), f32c(gh, "gh"), f32c(h, "h")
+        N, C = h.shape
+        h_new = torch.empty_like(h)
+        check(_lib.load().glam_gru_gates_fwd(ptr(gi), ptr(gh), ptr(h), N, C, ptr(h_new), stream()), "glam_gru_gates_fwd")
+        ctx.save_for_backward(gi, gh, h)
+        return h_new
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_hnew):
+        gi, gh, h = ctx.saved_tensors
+        N, C = h.shape
+        d_hnew = f32c(d_hnew, "d_hnew")
+        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        check(_lib.load().glam_gru_gates_bwd(ptr(gi), ptr(gh), ptr(h), ptr(d_hnew), N, C, ptr(d_gi), ptr(d_gh), ptr(d_h),
+                                             stream()), "glam_gru_gates_bwd")
+        return d_gi, d_gh, d_h
+
+
+class _GruTail(torch.autograd.Function):
+    """GRU gates + residual + activation in one launch per direction; returns (out, h_new)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h, identity, act, slope):
+        require_device(gi, gh, h)
+        gi, gh, h = f32c(gi, "gi"), f32c(gh, "gh"), f32c(h, "h")
+        identity = None if identity is None else f32c(identity, "identity")
+        N, C = h.shape
+        h_new, out = torch.empty_like(h), torch.empty_like(h)
+        check(_lib.load().glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out),
+                                            stream()), "glam_gru_tail_fwd")
+        ctx.save_for_backward(gi, gh, h, out)
+        ctx.cfg = (act, float(slope), identity is not None)
+        return out, h_new
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, d_hstate):
+        gi, gh, h, out = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        N, C = h.shape
+        d_out = f32c(d_out, "d_out")
+        d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
+        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        d_id = torch.empty_like(h) if has_res else None
+        check(_lib.load().glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope,
+                                            ptr(d_gi), ptr(d_gh), ptr(d_h), ptr(d_id), stream()), "glam_gru_tail_bwd")
+        return d_gi, d_gh, d_h, d_id, None, None
+
+
+ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3, "rrelu": 4}
+
+
+def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False, rng=None):
+    """``h_new = GRU(celu(x) if celu_in else x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:261-266):
+    the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``.
+    ``rng = (rr_lower, rr_upper, drop_p)`` (training mode of the reference's defaults): ``act == "rrelu"`` draws its slopes in
+    the kernel and, with ``drop_p > 0``, the kernel also writes ``Dropout(drop_p)(out)`` and registers it as the dropped twin
+    of ``out`` (``take_dropped``) — available on the one-node path (C % 4 == 0, C <= 60); elsewhere the caller applies
+    ``ops.rrelu`` / ``ops.dropout`` itself (``rng`` must then be None)."""
+    C = h.size(1)
+    if rng is not None and not gru_block_supported(C, w_ih, b_ih, b_hh):
+        raise GlamHipError("gru_tail(rng=...) needs the one-node GRU block (C % 4 == 0, C <= 60)")
+    if gru_block_supported(C, w_ih, b_ih, b_hh):
+        return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in, rng)
+    Cp = (C + 3) // 4 * 4
+    if Cp != C and b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_supported(Cp, 3 * Cp) \
+            and 3 * Cp > 64:
+        # odd widths: the same node at Cp with gate-wise zero-padded weights (built once per model pass).  Pad channels
+        # stay exactly zero through the step: gates r = z = 1/2, n = tanh(0) = 0, h' = z * 0 = 0, act(0 + 0) = 0.
+        def build():
+            pw = lambda w: torch.nn.functional.pad(w.view(3, C, C), (0, Cp - C, 0, Cp - C)).reshape(3 * Cp, Cp)
+            pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
+            return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
+        wi, wh, bi, bh = _o.scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build)
+        out_p, hn_p = _gru_block(_o.pad_cols(x, Cp), _o.pad_cols(h, Cp), None if identity is None else _o.pad_cols(identity, Cp),
+                                 wi, wh, bi, bh, ACT_CODES[act], slope, celu_in)
+        return _o.slice_cols(out_p, C), _o.slice_cols(hn_p, C)
+    if b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_tall_supported(Cp, 3 * Cp) and h.size(0) >= 64:
+        # wide GRU (hid_dim_alpha = 6): library GEMMs for the gate products, k_wgrad for their weight gradients, at Cp
+        def build_wide():
+            pw = lambda w: torch.nn.functional.pad(w.view(3, C, C), (0, Cp - C, 0, Cp - C)).reshape(3 * Cp, Cp)
+            pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
+            return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
+        wi, wh, bi, bh = _o.scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build_wide) if Cp != C else \
+            (w_ih, w_hh, b_ih, b_hh)
+        x_p, h_p = _o.pad_cols(x, Cp), _o.pad_cols(h, Cp)
+        if celu_in:
+            x_p = torch.celu(x_p)
+        out_p, hn_p = _GruTail.apply(_LinearTall.apply(x_p, wi, bi), _LinearTall.apply(h_p, wh, bh), h_p,
+                                     None if identity is None else _o.pad_cols(identity, Cp), ACT_CODES[act], slope)
+        return _o.slice_cols(out_p, C), _o.slice_cols(hn_p, C)
+    if celu_in:
+        x = torch.celu(x)
+    return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
+
+
+
+
+def _want_gru_fused(N):
+    return _o.GRU_FUSED in ("1", True) or (_o.GRU_FUSED == "auto" and N >= _o.GRU_FUSED_MIN_NODES)
+
+def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
+    """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
+    M, C = w_ih.shape
+    def split(flat):      # [d_w_ih | d_b_ih | d_w_hh | d_b_hh], every piece contiguous: autograd takes the views without a copy
+        w1, b1, w2, b2 = flat.split([M * C, M, M * C, M])
+        return w1.view(M, C), w2.view(M, C), b1, b2
+    key = ("carry-gru", id(w_ih))
+    carry = _o._carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * M * (C + 1), split)
+    out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng)
+    if carry is not None:
+        _o._carry_store(key, w_ih, carry)
+    if out_drop is not None:
+        _o.register_dropped(out, out_drop, rng[2])
+    return out, h_new
+
+
+class _GruBlock(torch.autograd.Function):
+    """The whole GRU step of a MessageBlock as ONE autograd node: both gate GEMMs + gates/residual/activation forward;
+    gate backward + both input-gradient GEMMs + BOTH weight-gradient products in one launch pair backward.  Besides the
+    launches it saves (one weight-gradient launch and one reduction per step) it replaces three Python autograd nodes by
+    one, which is what an eagerly issued training step is bound by."""
+
+    @staticmethod
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None):
+        ctx.set_materialize_grads(False)     # unused outputs (the last step's h', its dropped twin) arrive as None, not as zero fills
+        require_device(x, h, w_ih, w_hh, b_ih, b_hh)
+        x, h = f32c(x, "x"), f32c(h, "h")
+        w_ih, w_hh, b_ih, b_hh = f32c(w_ih, "weight_ih"), f32c(w_hh, "weight_hh"), f32c(b_ih, "bias_ih"), f32c(b_hh, "bias_hh")
+        identity = None if identity is None else f32c(identity, "identity")
+        N, C = h.shape
+        M = 3 * C
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        scope = _o._SCOPE
+
+        def image(w):
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(C, M) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), C, 1, C, M, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+            return _o._scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
+
+        gi, gh = torch.empty(N, M, **f), torch.empty(N, M, **f)
+        st = stream()
+        if scope is not None:
+            # all four images of the step (forward and input-gradient images of both gate matrices) in ONE launch, shared by the
+            # message_steps applications of the block through the scope tables
+            ka, kb = ("lin", id(w_ih)), ("lin", id(w_hh))
+            ha, hb = scope.fwd.get(ka), scope.fwd.get(kb)
+            if not (ha is not None and ha[0] is w_ih and hb is not None and hb[0] is w_hh):
+                nf, nb = lib.glam_ts_gemm_image_bytes(C, M) // 4, lib.glam_ts_gemm_image_bytes(M, C) // 4
+                ia, ib, ta, tb = torch.empty(nf, **f), torch.empty(nf, **f), torch.empty(nb, **f), torch.empty(nb, **f)
+                if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
+                    # ... and the two gate-padded images of the fused step: six re-layouts of the same two matrices, one launch
+                    fused = torch.empty(2, lib.glam_gru_fused_image_bytes() // 4, **f)
+                    check(lib.glam_gru_make_images(ptr(w_ih), ptr(w_hh), C, ptr(ia), ptr(ib), ptr(ta), ptr(tb), ptr(fused[0]), ptr(fused[1]),
+                                                   st), "glam_gru_make_images")
+                    scope.fwd[("gru-fused", id(w_ih), id(w_hh))] = (w_ih, fused)
+                else:
+                    check(lib.glam_ts_gemm_make_image_quad(ptr(w_ih), ptr(w_hh), C, M, ptr(ia), ptr(ib), ptr(ta), ptr(tb), st),
+                          "glam_ts_gemm_make_image_quad")
+                scope.fwd[ka], scope.fwd[kb] = (w_ih, ia), (w_hh, ib)
+                scope.bwd[ka], scope.bwd[kb] = (w_ih, ta), (w_hh, tb)
+        h_new, out = torch.empty_like(h), torch.empty_like(h)
+        out_drop, eff = None, None
+        if rng is None and act == ACT_CODES["rrelu"]:
+            raise GlamHipError("gru block: act 'rrelu' needs rng=(lower, upper, drop_p)")
+        if rng is not None:
+            lo, hi, p = (float(v) for v in rng)
+            eff = torch.empty(2, dtype=torch.int64, device=dev)
+            out_drop = torch.empty_like(h) if p > 0 else None
+        # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
+        if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
+            # both gate linears + gates + residual + activation (+ RReLU / Dropout) in ONE launch (bit-identical to the sequence below)
+            def build_fused():
+                nb = lib.glam_gru_fused_image_bytes() // 4
+                buf = torch.empty(2, nb, **f)
+                check(lib.glam_gru_fused_make_images(ptr(w_ih), ptr(w_hh), C, ptr(buf[0]), ptr(buf[1]), st), "glam_gru_fused_make_images")
+                return buf
+            imgs = _o._scoped(scope.fwd if scope else None, ("gru-fused", id(w_ih), id(w_hh)), w_ih, build_fused)
+            if rng is None:
+                check(lib.glam_gru_fused_fwd(ptr(x), ptr(h), ptr(identity), ptr(imgs[0]), ptr(imgs[1]), ptr(b_ih), ptr(b_hh), N, C,
+                                             int(celu_in), act, float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), st), "glam_gru_fused_fwd")
+            else:
+                check(lib.glam_gru_fused_rng_fwd(ptr(x), ptr(h), ptr(identity), ptr(imgs[0]), ptr(imgs[1]), ptr(b_ih), ptr(b_hh), N, C,
+                                                 int(celu_in), act, float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
+                                                 ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_fused_rng_fwd")
+        else:
+            if _o.GEMM_PAIR:     # both gate linears in ONE launch (two products of the same kernel variant share the CUs)
+                img_a, img_b = image(w_ih), image(w_hh)     # both alive until the launch is enqueued (outside a scope they are temporaries:
+                #                                             the allocator would hand the first one's memory to the second)
+                check(lib.glam_ts_gemm_pair(ptr(x), C, C, int(celu_in), ptr(img_a), ptr(b_ih), ptr(gi), M, M, None, 0, None, 0,
+                                            ptr(h), C, C, 0, ptr(img_b), ptr(b_hh), ptr(gh), M, M, None, 0, None, 0, N, st),
+                      "glam_ts_gemm_pair")
+            else:
+                check(lib.glam_ts_gemm_celu(ptr(x), C, C, int(celu_in), ptr(image(w_ih)), ptr(b_ih), ptr(gi), M, M, None, 0, N, st),
+                      "glam_ts_gemm_celu")
+                check(lib.glam_ts_gemm(ptr(h), C, C, None, 0, 0, ptr(image(w_hh)), ptr(b_hh), ptr(gh), M, M, None, 0, 0, N, st), "glam_ts_gemm")
+            if rng is None:
+                check(lib.glam_gru_tail_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), ptr(h_new), ptr(out), st),
+                      "glam_gru_tail_fwd")
+            else:     # training mode: RReLU slopes / the next conv's Dropout mask drawn inside the launch
+                check(lib.glam_gru_tail_rng_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), lo, hi, p,
+                                                ptr(_o.rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
+        ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
+        ctx.eff = eff
+        ctx.cfg = (act, float(slope), identity is not None, bool(celu_in), None if rng is None else tuple(float(v) for v in rng))
+        ctx.scope = scope
+        ctx.carried = carry is not None
+        return out, h_new, out_drop, (carry.view(-1) if ctx.carried else None)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, d_hstate, d_out_drop=None, d_carry=None):
+        x, h, gi, gh, out, w_ih, w_hh = ctx.saved_tensors
+        act, slope, has_res, celu_in, rng = ctx.cfg
+        N, C = h.shape
+        M = 3 * C
+        lib, dev = _lib.load(), x.device
+        f = dict(dtype=torch.float32, device=dev)
+        st = stream()
+        d_out = None if d_out is None else f32c(d_out, "d_out")
+        d_out_drop = None if d_out_drop is None else f32c(d_out_drop, "d_out_drop")
+        d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
+        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        d_id = torch.empty_like(h) if has_res else None
+        if rng is None:
+            if d_out is None:
+                d_out = torch.zeros_like(h)
+            check(lib.glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope, ptr(d_gi),
+                                        ptr(d_gh), ptr(d_h), ptr(d_id), st), "glam_gru_tail_bwd")
+        else:
+            if d_out is None and d_out_drop is None:
+                d_out = torch.zeros_like(h)
+            check(lib.glam_gru_tail_rng_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), N, C, act, slope,
+                                            rng[0], rng[1], rng[2], ptr(ctx.eff), ptr(d_gi), ptr(d_gh), ptr(d_h), ptr(d_id), st),
+                  "glam_gru_tail_rng_bwd")
+        scope = ctx.scope
+
+        def image_t(w):
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(M, C) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), C, 0, M, C, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+            return _o._scoped(scope.bwd if scope else None, ("lin", id(w)), w, build)
+
+        dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
+        # with the folded CELU the epilogue multiplies by celu'(x): dx is the gradient of the RAW input
+        # d_h = d_gh @ W_hh^T + the direct z * g path of the gate equations (the addend of the GEMM's epilogue); both products in one launch
+        if _o.GEMM_PAIR:
+            img_a, img_b = image_t(w_ih), image_t(w_hh)
+            check(lib.glam_ts_gemm_pair(ptr(d_gi), M, M, 0, ptr(img_a), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, None, 0,
+                                        ptr(d_gh), M, M, 0, ptr(img_b), None, ptr(dh), C, C, None, 0, ptr(d_h), C, N, st),
+                  "glam_ts_gemm_pair")
+        else:
+            check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
+                  "glam_ts_gemm_celu")
+            check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")
+        # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
+        ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        # one buffer [d_w_ih | d_b_ih | d_w_hh | d_b_hh], contiguous pieces; a gradient carry (same layout) is added by the reduction
+        flat = torch.empty(2 * M * (C + 1), **f)
+        dw_ih, db_ih, dw_hh, db_hh = flat.split([M * C, M, M * C, M])
+        dc = [None] * 4
+        if ctx.carried and d_carry is not None and N > 0:
+            dc = f32c(d_carry, "d_carry").split([M * C, M, M * C, M])
+            d_carry = None
+        check(lib.glam_wgrad_gemm_pair_split(ptr(d_gi), M, M, ptr(x), C, C, int(celu_in), ptr(dw_ih), ptr(db_ih),
+                                             ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
+                                             ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
+        if ctx.carried:
+            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None
+        return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None
+
+
+def gru_block_supported(C, w_ih, b_ih, b_hh):
+    return C % 4 == 0 and C + 1 <= 64 and linear_supported(C, 3 * C) and 3 * C > 64 and b_ih is not None and b_hh is not None and \
+        tuple(w_ih.shape) == (3 * C, C)        # C + 1 <= 64: both weight gradients in ONE k_wgrad launch
+
+
+def gru_step(x, h, w_ih, w_hh, b_ih, b_hh):
+    """One ``torch.nn.GRU(C, C)`` step with seq_len 1 on its own parameters (src_1gp/layer.py:247, :262)."""
+    return _GruGates.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h)

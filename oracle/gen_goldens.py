@@ -87,11 +87,15 @@ def save(name, meta, inputs, params, out, cot, grads):
     print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+GTOL = 5e-6      # gradients of single layers / blocks (scaled); whole-model gradients: 1e-5 (deeper chains of fp32 roundings)
+
+
 def check(tag, a, b, tol=TOL):
+    """Oracle vs reference: max |d| scaled by max(1, |ref|) must stay within `tol`; returns the SCALED error."""
     err = (a - b).abs().max().item() if a.numel() else 0.0
     scale = max(1.0, b.abs().max().item() if b.numel() else 1.0)
-    assert err <= tol * scale, f"{tag}: oracle vs reference max|d|={err:.3e} (scale {scale:.2f})"
-    return err
+    assert err <= tol * scale, f"{tag}: oracle vs reference max|d|={err:.3e} (scale {scale:.2f}, tol {tol:.0e})"
+    return err / scale
 
 
 # ----------------------------------------------------------------------------------
@@ -159,7 +163,7 @@ def main():
         go = grads_of(oo, cot, [xo, eo] + po)
         worst = max(worst, check(f"triplet/{tag}/out", oo, out))
         for n_, a, r in zip(["x", "edge_attr"] + names, go, gs):
-            worst = max(worst, check(f"triplet/{tag}/grad.{n_}", a, r, 1e-5))
+            worst = max(worst, check(f"triplet/{tag}/grad.{n_}", a, r, GTOL))
         # aggregate-level intermediates for op-level kernel tests
         xw = torch.matmul(b.x, conv.weight_node).detach()
         ew = torch.matmul(b.edge_attr, conv.weight_edge).detach()
@@ -191,7 +195,7 @@ def main():
         go = grads_of(oo, cot, [xo, eo] + po)
         worst = max(worst, check(f"light/{tag}/out", oo, out))
         for n_, a, r in zip(["x", "edge_attr"] + names, go, gs):
-            worst = max(worst, check(f"light/{tag}/grad.{n_}", a, r, 1e-5))
+            worst = max(worst, check(f"light/{tag}/grad.{n_}", a, r, GTOL))
         save(f"light_{tag}", {"C": C, "De": De, "slope": 0.2, "kind": "TripletMessageLight"},
              {"x": b.x, "edge_index": b.edge_index, "edge_attr": b.edge_attr, "batch": b.batch},
              dict(zip(names, ps)), out, cot, dict(zip(["x", "edge_attr"] + names, gs)))
@@ -355,7 +359,7 @@ def main():
     oo5 = O.dot_and_global_pool(mo5, po5, mb.batch, pb.batch, 4, 5)
     go5m, go5p = grads_of(oo5, cot5, [mo5, po5])
     worst = max(worst, check("dot2", O.dot_and_global_pool(mb.x, pb.x, mb.batch, pb.batch, 4, 2), out2),
-                check("dot5", oo5, out5, 1e-5), check("dot5/g_mol", go5m, g5m, 1e-5), check("dot5/g_pro", go5p, g5p, 1e-5))
+                check("dot5", oo5, out5, GTOL), check("dot5/g_mol", go5m, g5m, GTOL), check("dot5/g_pro", go5p, g5p, GTOL))
     save("dotpool_pairs", {"kind": "dot_and_global_pool", "B": 4},
          {"mol_x": mb.x, "pro_x": pb.x, "mol_batch": mb.batch, "pro_batch": pb.batch}, {}, out2, cot,
          {"mol_x": gm, "pro_x": gp, "__out5": out5.detach(), "__cot5": cot5, "__g5_mol": g5m, "__g5_pro": g5p})
@@ -376,7 +380,7 @@ def main():
     o_ref = O.architecture_dti(sd, mb, pb, 4, message_steps=2, **kw)
     worst = max(worst, check("dti out", o_ref, out, 5e-6))
     for n, g_o, g_r in zip(names, grads_of(o_ref, cot, [sd[n] for n in names]), gs):
-        worst = max(worst, check("dti grad " + n, g_o, g_r, 2e-5))
+        worst = max(worst, check("dti grad " + n, g_o, g_r, 1e-5))
     save("dti_nnconv_gcn", {"kind": "ArchitectureDTI", "B": 4, "e_dim": 64, "message_steps": 2, **kw},
          {"mol_x": mb.x, "mol_edge_index": mb.edge_index, "mol_edge_attr": mb.edge_attr, "mol_batch": mb.batch,
           "pro_x": pb.x, "pro_edge_index": pb.edge_index, "pro_edge_attr": pb.edge_attr, "pro_batch": pb.batch},
@@ -401,7 +405,7 @@ def main():
         o_ref = O.architecture_ddi(sd, m1, m2, 4, message_steps=2, **kw)
         worst = max(worst, check("ddi out", o_ref, out, 5e-6))
         for n, g_o, g_r in zip(names, grads_of(o_ref, cot, [sd[n] for n in names]), gs):
-            worst = max(worst, check("ddi grad " + n, g_o, g_r, 2e-5))
+            worst = max(worst, check("ddi grad " + n, g_o, g_r, 1e-5))
         save("ddi_" + tag, {"kind": "ArchitectureDDI", "B": 4, "e_dim": 64, "message_steps": 2, "hid_dim_alpha": alpha, **kw},
              {"mol1_x": m1.x, "mol1_edge_index": m1.edge_index, "mol1_edge_attr": m1.edge_attr, "mol1_batch": m1.batch,
               "mol2_x": m2.x, "mol2_edge_index": m2.edge_index, "mol2_edge_attr": m2.edge_attr, "mol2_batch": m2.batch},

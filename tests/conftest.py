@@ -95,3 +95,17 @@ def assert_twin_parity(run, got_out, got_grads, what, names=None, out_tol=1e-5, 
         if r64 is None:
             continue
         assert_fp32_parity(a, r64, r32, f"{what} grad.{n}", k=k)
+
+
+def assert_golden_parity(run64, g, got_out, got_grads, what, names, out_key=None, out_tol=1e-5, k=8.0):
+    """A golden fixture IS the reference's fp32 sample of a quantity; ``run64() -> (out, [grads])`` evaluates the oracle in fp64 on the
+    fixture's inputs (its fp64 twin: the oracle is pinned to the reference by oracle/gen_goldens.py).  The HIP result must sit within
+    the fp64-twin bound of ``assert_fp32_parity``; ``names`` index ``g.grads``; ``None`` entries of the twin are skipped."""
+    o64, g64 = run64()
+    ref_out = g.out if out_key is None else g.grads[out_key]
+    if got_out is not None:
+        assert_fp32_parity(got_out, o64, ref_out, what + " out", k=k, out_tol=out_tol)
+    for n, a, r64 in zip(names, got_grads, g64):
+        if r64 is None:
+            continue
+        assert_fp32_parity(a, r64, g.grads[n], f"{what} grad.{n}", k=k)
