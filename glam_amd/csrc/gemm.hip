@@ -19,6 +19,7 @@
 //               fixed order by k_final_reduce (deterministic, no atomics), which also folds the aggregate
 //               kernel's d_W_edge partials.
 #include "dense.h"
+#include "bf16x3.h"
 
 #include <stdlib.h>
 
@@ -278,6 +279,87 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_ts_gemm_x3: the register-B form of the 192-column product (K <= 64: the node GEMM x @ [W_node | Wa_i | Wa_j]) on the bf16 matrix
+// cores in 3 x bf16 form (bf16x3.h: fp32 accuracy; 48 v_mfma_f32_16x16x32_bf16 per 16 x 64 item instead of 60 fp32 MFMAs at 1.65 x the
+// cycles each, and off the fp32 datapath).  A wave is bound to one 64-column split and keeps that slice of W — split once, in the
+// prologue — in 96 registers (two 32-k steps x four column tiles x three terms); it walks the row tiles, splitting each A fragment
+// (16 floats per lane) on the fly.  Same image, same column permutation and same epilogue as k_ts_gemm<12, 4, 4, RBLK>.
+// Lane (r = lane & 15, kb = lane >> 4): A row r / W column, k = 32 s + 8 kb .. + 7 of step s (the two operands share the k set of a lane,
+// which is all the contraction needs).
+// ------------------------------------------------------------------------------------------------
+template <int RBLK>
+__global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
+    constexpr int MP = 192, CS = 3, WPB = RBLK / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kb = lane >> 4;
+    const int K = a.K1, Kp = (K + 15) & ~15, M = a.M1 + a.M2;
+    const int ntiles = (a.N + 15) >> 4;
+    const int gw = (int)blockIdx.x * WPB + wave;
+    const int cs = gw % CS;
+    // W slice of this wave: column tile t holds the logical columns cs * 64 + 4 c + t (image position cs * 64 + 16 t + c)
+    Bf16x3 wreg[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k0 = 32 * s + 8 * kb;                   // rows k0 .. k0 + 7 of the image (zero beyond K; the image ends at Kp)
+            const float* p = a.Wimg + ((size_t)(k0 >> 2) * MP + cs * 64 + 16 * t + c) * 4;
+            wreg[s][t] = split8(k0 < Kp ? ld4(p) : f4zero(), k0 + 4 < Kp ? ld4(p + (size_t)MP * 4) : f4zero());
+        }
+    auto load_a = [&](int tile, float4 (&af)[2][2]) {
+        const int row = tile * 16 + c;
+        const bool rok = tile < ntiles && row < a.N;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k0 = 32 * s + 8 * kb + 4 * u;
+                af[s][u] = (rok && k0 < K) ? ld4(a.A1 + (size_t)row * a.lda1 + k0) : f4zero();
+            }
+    };
+    const int tstride = nblk * WPB / CS;                       // row tiles per step of this wave (the host makes the wave count a multiple of CS)
+    int tile = gw / CS;
+    float4 af[2][2];
+    load_a(tile, af);
+    for (; tile < ntiles; tile += tstride) {
+        Bf16x3 as[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) as[s] = split8(af[s][0], af[s][1]);
+        load_a(tile + tstride, af);                            // next tile's rows fly under this tile's MFMAs and stores
+        v4f_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+        // four independent accumulator chains (column tiles); within a chain: small partial products of both k steps, then the middle
+        // ones, then hi x hi
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_small(as[s], wreg[s][t], acc[t]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_mid(as[s], wreg[s][t], acc[t]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_big(as[s], wreg[s][t], acc[t]);
+        // C layout: tile column = lane & 15 (-> logical columns cs * 64 + 4 c + t), row = (lane >> 4) * 4 + i
+        const int m0 = cs * 64 + 4 * c;
+        if (m0 < M) {
+            float4 b = f4zero();
+            if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = tile * 16 + kb * 4 + i;
+                if (rr >= a.N) continue;
+                const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // G[I, J] = [P1 | P2 | 1]^T @ Q.  A wave owns a 64 x 64 output slab (16 accumulator tiles, 64 VGPRs) over its own
 // row range: per 4-row step ONE float4 load of P feeds the A operands of the 4 row tiles and ONE float4 load of Q
 // the B operands of the 4 column tiles (stride-4 permutation on both sides: tile t holds columns 4c + t), i.e.
@@ -527,6 +609,8 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
 }
 // the register-B form of the 192-column variant: one block per CU
 static bool ts_rb_enabled() { const char* e = getenv("GLAM_TS_RB"); return !e || atoi(e) != 0; }
+// GLAM_X3=0: the dense products stay on the fp32 matrix instructions (A/B switch, read per call)
+bool ts_x3_enabled() { const char* e = getenv("GLAM_X3"); return !e || atoi(e) != 0; }
 static bool ts_rb_big(int N) { return N >= 131072; }       // 12-wave blocks once the launch streams from HBM
 static int ts_rb_grid(int N) {
     const int ntiles = (N + 15) / 16;
@@ -557,7 +641,10 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
         // decide its occupancy
         two.first_b = ts_rb_grid(a.N);
         GLAM_PROF_LABEL("k_ts_gemm<12, 4, 4>");
-        if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
+        if (ts_x3_enabled()) {      // 3 x bf16 on the bf16 matrix cores (fp32 accuracy, bf16x3.h)
+            if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm_x3<768>), dim3(two.first_b), dim3(768), 0, s, a, two.first_b);
+            else hipLaunchKernelGGL((k_ts_gemm_x3<512>), dim3(two.first_b), dim3(512), 0, s, a, two.first_b);
+        } else if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
         else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 512>), dim3(two.first_b), dim3(512), 0, s, two);
     } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else {
@@ -578,7 +665,12 @@ constexpr int kWgradBlocksBig = 512;   // two per CU (four waves per SIMD) once 
 constexpr int kWgradBigRows = 131072;
 static int wgrad_budget(int N) { return N >= kWgradBigRows ? kWgradBlocksBig : kWgradBlocks; }
 
-size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per block
+// per product: one 64 x 64 slab per block of k_wgrad — or, when the product is accumulated inside the warp-specialised B2 launch
+// (triplet_ws.hip), three slabs for each of its kWsWgradBlocks blocks
+size_t wgrad_workspace_floats() {
+    const size_t own = (size_t)(kWgradBlocksBig + 24) * kWgSlabStride, fused = (size_t)3 * kWsWgradBlocks * kWgSlabStride;
+    return own > fused ? own : fused;
+}
 
 // fills the launch geometry of one product (at most `budget` blocks) and the matching reduce job
 static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {
