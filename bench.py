@@ -79,14 +79,6 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
                                                 "(csrc/triplet_ws_b1.hip)"},
         "k_triplet_bwd_src_ws+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C,
                                     "note": "warp-specialised backward by source with the d_x GEMM as the consumers' product (csrc/triplet_ws.hip)"},
-        # round 4 (batches beyond GLAM_WS_WGRAD_MIN_NODES): [d_xw | d_a]^T x rides in B2's consumer waves: one more [N, C] operand (x) and
-        # 3 slabs of block partials per block; k_wgrad then carries [aggr | 1]^T d_out alone ("k_wgrad<false> (product 1)")
-        "k_triplet_bwd_src_ws+dx+wgrad": {"bound": "hbm", "bytes": b2 + 2 * f * N * C + img(HC + 8, C) + f * 3 * 4096 * min(256, (N + 15) // 16),
-                                          "flops": 2 * N * (HC + 8) * C + 2 * N * (HC + 8) * C,
-                                          "note": "warp-specialised backward by source; its consumer waves run the d_x GEMM AND accumulate "
-                                                  "[d_xw | d_a]^T x (d_weight_node and the attention columns), interleaved one MFMA for one"},
-        "k_wgrad<false> (product 1)": {"bound": "mfma", "flops": 2 * N * (HC + 1) * C, "bytes": f * N * (HC + C),
-                                       "note": "[aggr | 1]^T d_out alone (the other weight-gradient product is inside the B2 launch)"},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
         "k_ts_gemm<4, 12, 4>": {"bound": "mfma", "flops": 2 * N * (HC + 8) * C, "bytes": f * N * (HC + 8 + C) + img(HC + 8, C),
                                 "note": "d_x = [d_xw | d_a] @ Wcat^T as its own launch (general graphs beyond GLAM_FUSE_MAX_NODES)"},
@@ -526,7 +518,7 @@ def main():
         kernels = {}
         for name, rec in sorted(prof.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
             row = dict(rec)
-            m = model.get(name + " (product 1)" if (name == "k_wgrad<false>" and "k_triplet_bwd_src_ws+dx+wgrad" in prof) else name)
+            m = model.get(name)
             if m is not None:
                 row.update(rate(m, rec["avg_us"]))
                 if "note" in m:
@@ -578,8 +570,7 @@ def main():
             pb = profile_step(compute_big, max(5, args.prof_reps // 3), warm=40)
             ib = time_isolated_aggregate(conv, big, xb.detach(), max(5, args.prof_reps // 3))
             rl = {"workload": f"B={args.large_batch} (N={Nb}, E={Eb}: every [N,180] tensor is {Nb * 720 / 2 ** 20:.0f} MiB, beyond the 256 MiB LLC)",
-                  "step_kernels": {n: dict(r, **(rate(mb[n + " (product 1)" if (n == "k_wgrad<false>" and "k_triplet_bwd_src_ws+dx+wgrad" in pb) else n],
-                                                      r["avg_us"]) if n in mb else {})) for n, r in pb.items()},
+                  "step_kernels": {n: dict(r, **(rate(mb[n], r["avg_us"]) if n in mb else {})) for n, r in pb.items()},
                   "isolated": {n: dict(r, **rate(mb[n], r["avg_us"])) for n, r in ib.items() if n in mb}}
             # frac = the fused forward scatter-aggregate kernel THE STEP LAUNCHES at this size (its update GEMM included, as at B = 1024);
             # the aggregate kernels on their own stay under "isolated"

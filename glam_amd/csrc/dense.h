@@ -22,8 +22,6 @@ struct TsArgs {
 // distance between the 64 x 64 partial slabs of k_wgrad (4096 floats of data each): 16 KB + 256 B, so that the splits of one element —
 // which the reductions read 40 at a time — fall on different memory channels instead of every fourth one
 constexpr int kWgSlabStride = 4096 + 64;
-// blocks of a warp-specialised launch that carries a weight-gradient product (one slab set per block: the workspace holds 3 slabs each)
-constexpr int kWsWgradBlocks = 256;
 
 struct WgArgs {
     const float* P1; int I1; int ldp1;
@@ -70,10 +68,6 @@ int triplet_fwd_ws(const float* xw, const float* a_ij, const float* edge_attr, c
                    int edge_onehot, float* aggr, float* stats, const float* img_upd, const float* bias_p, float* out, hipStream_t s);
 bool triplet_fwd_ws_enabled();          // GLAM_FWD_WS (default 1)
 bool triplet_fwd_ws_supported(int H, int Cp, int De, int edge_onehot);
-// Request / report of the weight-gradient product inside the warp-specialised B2 launch: x = the layer input, p2 = slab-partial
-// workspace (wgrad_workspace_floats()) of [d_xw | d_a]^T x; `used` and the split count are filled by triplet_bwd_impl (false: the
-// graph took other kernels and the caller launches k_wgrad for this product itself).
-struct WsWgrad { const float* x; float* p2; int ns2; bool used; };
 int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M,
                      const float* aggr, const float* stats, const float* d_aggr, const int32_t* rowptr,
                      const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
@@ -83,7 +77,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const float* img_dx, float* d_x,
                      const float* img_dagg = nullptr, const float* d_out = nullptr, const int32_t* ell_dst = nullptr,
                      const int32_t* ell_eid_t = nullptr, int edge_onehot = 0, const int32_t* ell_src = nullptr,
-                     const int32_t* ell_eid = nullptr, WsWgrad* wsw = nullptr);
+                     const int32_t* ell_eid = nullptr);
 // B1 with the d_aggr GEMM inside, warp-specialised (triplet_ws_b1.hip: matrix waves produce the d_aggr tiles ahead of the vector waves)
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
@@ -94,11 +88,7 @@ int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_att
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* wg_x = nullptr,
-                       float* wg_partial = nullptr, int* wg_nsplit = nullptr);
-// (wg_x non-null: the consumer waves also accumulate the weight-gradient product [d_xw | d_a]^T x into `wg_partial` — k_wgrad's slab
-//  format, *wg_nsplit block partials per slab: what launch_wgrad_partials would have produced, without the launch)
-bool triplet_ws_wgrad_supported(int H, int Cp, int De, int edge_onehot);
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De);
 

@@ -665,12 +665,7 @@ constexpr int kWgradBlocksBig = 512;   // two per CU (four waves per SIMD) once 
 constexpr int kWgradBigRows = 131072;
 static int wgrad_budget(int N) { return N >= kWgradBigRows ? kWgradBlocksBig : kWgradBlocks; }
 
-// per product: one 64 x 64 slab per block of k_wgrad — or, when the product is accumulated inside the warp-specialised B2 launch
-// (triplet_ws.hip), three slabs for each of its kWsWgradBlocks blocks
-size_t wgrad_workspace_floats() {
-    const size_t own = (size_t)(kWgradBlocksBig + 24) * kWgSlabStride, fused = (size_t)3 * kWsWgradBlocks * kWgSlabStride;
-    return own > fused ? own : fused;
-}
+size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per block
 
 // fills the launch geometry of one product (at most `budget` blocks) and the matching reduce job
 static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {

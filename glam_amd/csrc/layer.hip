@@ -587,11 +587,6 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
 // The fused-GEMM variants of the aggregate kernels (forward + update, B2 + d_x) keep a 48 KB weight image per block in LDS: two
 // 4-wave blocks per CU.  That wins while the launch is latency bound (B = 1024: 16.6 us against 9.7 + 11 + a launch boundary) and
 // loses once the batch is large enough for the aggregate to need its full occupancy (B = 16 384: 249 us fused against 134 + 62).
-// smallest batch (nodes) whose [d_xw | d_a]^T x product is accumulated inside the warp-specialised B2 launch (GLAM_WS_WGRAD_MIN_NODES)
-static int64_t ws_wgrad_min_nodes() {
-    static const int64_t v = [] { const char* e = getenv("GLAM_WS_WGRAD_MIN_NODES"); return e ? atoll(e) : (int64_t)65536; }();
-    return v;
-}
 static int64_t fuse_max_nodes() {
     static const int64_t v = [] { const char* e = getenv("GLAM_FUSE_MAX_NODES"); return e ? atoll(e) : (int64_t)1 << 40; }();
     return v;
@@ -708,27 +703,19 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     // d_x = [d_xw | d_a] @ Wcat^T inside B2: warp-specialised over the caller's ELL records by source, or as the general kernel's epilogue
     const bool ws_dx = ell_dst && ell_eid_t && Cp <= 64 && triplet_bwd_src_ws_supported(H, Cp, Dp, edge_onehot);
     const bool fuse_dx = ws_dx || (triplet_bwd_can_fuse_dx(H, Cp, Dp) && N <= fuse_max_nodes());
-    // molecular graphs beyond ws_wgrad_min_nodes(): the product [d_xw | d_a]^T x rides in B2's consumer waves (round 4); below that
-    // the 3 x 256 slabs of block partials cost the reduction more than the product costs k_wgrad
-    WsWgrad wsw{x, wg2, 0, false};
-    const bool try_wg = ws_dx && N >= ws_wgrad_min_nodes() && triplet_ws_wgrad_supported(H, Cp, Dp, edge_onehot);
     if (int rc = triplet_bwd_impl(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, aggr, stats, d_aggr, rowptr, src, eid,
                                   colptr, dst, eid_t, N, E, H, Cp, Dp, 1, slope, d_xw, d_a, dstaged + G.d_we_p,
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
                                   fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr,
                                   fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr, ws_dx ? ell_dst : nullptr,
-                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, try_wg ? &wsw : nullptr))
+                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
-    if (wsw.used) {     // product 2 is already accumulated (k_wgrad's slab format, split = block): product 1 alone takes the launch
-        if (int rc = launch_wgrad_partials(w1, dstaged + G.d_wsb, Cp, 1, s, &ra.job[0])) return rc;
-        ra.job[2] = ReduceJob{0, wg2, wsw.ns2, (HC + 8 + 63) / 64 * 4096, HC + 8, Cp, 1, HC + 8, dstaged + G.d_wcat, nullptr, 0, 0};
-    } else if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s)) {
+    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s))
         return rc;      // both products in ONE launch
-    }
     // d_x = [d_xw | d_a] @ Wcat^T
     if (!fuse_dx) {
         TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};

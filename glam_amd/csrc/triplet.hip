@@ -126,7 +126,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, const float* img_dagg,
                      const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot, const int32_t* ell_src,
-                     const int32_t* ell_eid, WsWgrad* wsw) {
+                     const int32_t* ell_eid) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     const int WSZ = emul ? De * H * Cp : 0;
@@ -183,12 +183,9 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
         GLAM_LAUNCH_CHECK("glam_triplet_bwd(d_edge_attr)");
     }
     // molecular graphs with one-hot bond features: B2 over ELL records by source with the d_x GEMM inside, warp-specialised
-    const bool fuse_wg = wsw && b2_ws && wsw->x && wsw->p2 && triplet_ws_wgrad_supported(H, Cp, De, edge_onehot);
-    if (wsw) wsw->used = fuse_wg;
     if (b2_ws)
         return triplet_bwd_src_ws(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
-                                  d_a_ij, img_dx, d_x, s, fuse_wg ? wsw->x : nullptr, fuse_wg ? wsw->p2 : nullptr,
-                                  fuse_wg ? &wsw->ns2 : nullptr);
+                                  d_a_ij, img_dx, d_x, s);
     const bool fuse_dx = img_dx && d_x && triplet_bwd_can_fuse_dx(H, Cp, De) && emul;
     if ((img_dx || d_x) && !fuse_dx) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_x variant for H=%d Cp=%d", H, Cp);
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij,
@@ -218,5 +215,5 @@ extern "C" int glam_triplet_bwd(const float* xw, const float* a_ij, const float*
     }
     return triplet_bwd_impl(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, colptr, dst, eid_t, N, E,
                             H, Cp, De, emul, slope, d_xw, d_a_ij, d_w_edge, d_M, d_edge_attr, ws, ws_bytes, s, true,
-                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }

@@ -2,6 +2,7 @@
 // pipeline) and csrc/triplet_ws.hip (warp-specialised: producer waves run the pipeline, consumer waves the MFMA epilogue).
 #pragma once
 #include "triplet_kernels.h"
+#include "bf16x3.h"
 
 #include <stdlib.h>
 
@@ -43,6 +44,15 @@ __device__ __forceinline__ int row_bcast_i(int v, int n) {
     }
 }
 __device__ __forceinline__ float row_bcast(float v, int n) { return __builtin_bit_cast(float, row_bcast_i(__builtin_bit_cast(int, v), n)); }
+
+// ---- 3 x bf16 tiles (bf16x3.h): what the producers of the warp-specialised kernels publish when the consumers' product runs on the
+// bf16 matrix cores.  A tile is three planes (hi, mid, lo) of bf16 [16 rows][192 k]; a row takes 416 bytes: 104 words = 40 mod 64 makes
+// the consumers' ds_read_b128 fragment reads (lane = row | 16-byte k block) conflict free in all four 16-lane groups of the instruction
+constexpr int kX3RowBytes = 416;
+constexpr int kX3PlaneBytes = 16 * kX3RowBytes;
+constexpr int kX3TileBytes = 3 * kX3PlaneBytes;        // 19 968
+constexpr int kWsRingX3 = 5;                           // tile slots of an x3 ring (19.5 KB each; B2 carries 48 KB of side tables besides)
+bool ts_x3_enabled();                                  // GLAM_X3 (gemm.hip)
 
 // GLAM_WS_GRID (developer knob: blocks of a warp-specialised launch, default one 12-wave block per CU), clamped to [1, max_blocks];
 // a value that does not parse as a positive number is ignored

@@ -53,24 +53,8 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 // (Two tiles per trip with alternating accumulator chains — a 16x16x4 fp32 MFMA issues every 32 cycles but feeds the next one of its own
 // chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
 // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
-//
-// WG (round 4, B2 only): the same waves also accumulate the WEIGHT-GRADIENT product of the tile they hold, G[i, j] = sum over the nodes n
-// of tile[n, i] * Q[n, j] (tile = [d_xw | d_a_i | d_a_j], Q = x: the gradient of [W_node | Wa_i | Wa_j], the autograd of
-// src_1gp/layer.py:37), so that the N-deep product needs no launch of its own and no second read of d_xw.  Wave w owns the columns
-// j = 4 c + w of Q (one scalar per lane and 4-row step, requested a tile ahead) and reads the tile's rows 4 st + kq as float4 A operands —
-// the operand layout of k_wgrad (gemm.hip), whose 64 x 64 slab format the block partial is written in (one slab set per block, split
-// index = blockIdx.x), so that the fixed-order reductions of k_param_grads / k_final_reduce read it unchanged.  Rows past N are zero in
-// the tile (the producers publish zeros), Q is read with clamped (finite) addresses; accumulators of the pad rows i >= K and pad
-// columns j >= Cp hold garbage that no reduction reads.
-// Schedule: the 48 MFMAs of the d_x chain (each waits 40 cycles for its predecessor) and the 48 independent MFMAs of G alternate one for
-// one, so the matrix pipe issues every 32 cycles with no dependency stall (96 x 32 = 3 072 cycles per tile); operands roll through
-// small register sets (six d_x fragment groups, three G operand quads) that are re-requested as soon as their last MFMA has issued.
-// The first form — the G product as a block of 48 MFMAs behind the chain, operands read up front — made this wave the critical path
-// of the launch: 223 vs 137 us at B = 16 384 (profiles/r4w_*).
-template <bool WG>
 __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
-                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane,
-                                           const float* wg_q, float* wg_partial WS_PROF_PARAMS) {
+                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int c = lane & 15, kq = lane >> 4;
     const int GK = (K + 15) >> 4;                             // 16-k groups, <= 12
@@ -80,107 +64,104 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 #pragma unroll
     for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(img + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
-    if constexpr (!WG) {
-        __syncthreads();                                      // the block's only barrier (LDS flags / W_edge staged): the loads above fly under it
-        int it = 0;
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-            const int slot = it % kWsRing, want = 4 * (it / kWsRing + 1);
-            while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            WSTAMP(0);
-            const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
-            float4 af[12];
+    __syncthreads();                                          // the block's only barrier (LDS flags / W_edge staged): the loads above fly under it
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int slot = it % kWsRing, want = 4 * (it / kWsRing + 1);
+        while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        WSTAMP(0);
+        const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
+        float4 af[12];
 #pragma unroll
-            for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
-            WSTAMP(1);
-            // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
-            // so the chain starts when the first fragment lands instead of after the twelfth
-            v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 12; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
+        WSTAMP(1);
+        // no wait here: the compiler counts the fragment reads down (lgkmcnt(11), (10), ...) in front of the MFMAs that use them,
+        // so the chain starts when the first fragment lands instead of after the twelfth
+        v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                if (g < GK) {
+        for (int g = 0; g < 12; ++g) {
+            if (g < GK) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) flag_bump(s_taken + slot);         // every fragment is in registers: the slot may be refilled
-            const int r0 = 16 * tile + 4 * kq;
-            if (col < Cp) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
-            }
-            WSTAMP(2);
-        }
-    } else {
-        // ---- d_x chain + weight-gradient product, interleaved (K = 16 GK with GK = 12: the reference's width; nslab = 3) ----
-        const int nslab = (K + 63) >> 6;                      // 64-row slabs of G (<= 3)
-        v4f acc2[3][4];
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) acc2[s][ti] = (v4f){0.f, 0.f, 0.f, 0.f};
-        float qb[4];
-        const unsigned qcol = (unsigned)min(4 * c + w, Cp - 1) * 4u;       // lanes c = 15 at Cp = 60: a pad column (finite data, unread result)
-        auto load_q1 = [&](int tile, int st) {                // Q[16 tile + 4 st + kq, 4 c + w], rows clamped (the tile's rows past N are zero)
-            const unsigned row = (unsigned)min(16 * tile + 4 * st + kq, N - 1);
-            return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wg_q) + (row * (unsigned)Cp * 4u + qcol));
-        };
-#pragma unroll
-        for (int st = 0; st < 4; ++st) qb[st] = load_q1(blockIdx.x, st);
-        __syncthreads();                                      // the block's only barrier
-        int it = 0;
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-            const int slot = it % kWsRing, want = 4 * (it / kWsRing + 1);
-            while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;          // d_x fragments: row c, columns 16 g + 4 kq ..
-            const float* tr = s_ring + slot * 16 * LDT + kq * LDT;                  // G operands: row 4 st + kq, columns 64 s + 4 c ..
-            const int nxt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
-            float4 af[6], pa[3];
-#pragma unroll
-            for (int g = 0; g < 6; ++g) af[g] = (g < GK && 16 * g + 4 * kq < K) ? ld4(tl + 16 * g) : f4zero();
-#pragma unroll
-            for (int s = 0; s < 3; ++s) pa[s] = s < nslab ? ld4(tr + min(64 * s + 4 * c, LDT - 4)) : f4zero();
-            v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 48; ++i) {
-                const int g = i >> 2, jj = i & 3;             // chain MFMA i: k group g, k index jj
-                const int st = i / 12, s = (i % 12) >> 2, ti = i & 3;      // G MFMA i: step st, slab s, row quarter ti
-                if (g < GK) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g % 6], jj), f4get(bf[g], jj), acc, 0, 0, 0);
-                if (s < nslab) acc2[s][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pa[s], ti), qb[st], acc2[s][ti], 0, 0, 0);
-                if (jj == 3 && g < 6) af[g] = (g + 6 < GK && 16 * (g + 6) + 4 * kq < K) ? ld4(tl + 16 * (g + 6)) : f4zero();
-                if (ti == 3 && st < 3) pa[s] = s < nslab ? ld4(tr + 4 * (st + 1) * LDT + min(64 * s + 4 * c, LDT - 4)) : f4zero();
-                if (ti == 3 && s == 2) qb[st] = load_q1(nxt, st);          // this step's Q scalar is done: the next tile's takes its place
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) flag_bump(s_taken + slot);         // every fragment is in registers: the slot may be refilled
-            const int r0 = 16 * tile + 4 * kq;
-            if (col < Cp) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
+                for (int jj = 0; jj < 4; ++jj)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[g], jj), acc, 0, 0, 0);
             }
         }
-        // block partial in k_wgrad's slab format: slab s of split blockIdx.x, accumulator tile t = ti * 4 + tj (tj = w), lane, r
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
+        const int r0 = 16 * tile + 4 * kq;
+        if (col < Cp) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (s < nslab) {
-                float* slab = wg_partial + ((size_t)s * gridDim.x + blockIdx.x) * kWgSlabStride;
+            for (int i = 0; i < 4; ++i)
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
+        }
+        WSTAMP(2);
+    }
+}
+
+// The same consumer on the bf16 matrix cores in 3 x bf16 form (bf16x3.h; round 4): the producers publish the tile as three bf16 planes
+// (kX3TileBytes per slot), the wave keeps its K x 16 slice of W — split once, in the prologue — in 72 registers and issues 36
+// v_mfma_f32_16x16x32_bf16 per tile (six 32-k steps x six partial products) into three accumulator chains (small / middle / hi x hi
+// partial products, summed in that order at the end) instead of 48 dependent fp32 MFMAs.  The fp32 MFMAs ran on the SIMD's one fp32
+// datapath, i.e. INSTEAD of the gather waves' vector instructions (tools/ubench/mfma_valu_overlap.hip); these run beside them.
+template <int RING>
+__device__ __forceinline__ void ws_consume_x3(const float* img, const float* bias_p, float* out, int N, int Cp, int K,
+                                              const int* s_ready, int* s_taken, const char* s_ring, int ntiles, int w, int lane) {
+    const int c = lane & 15, kb = lane >> 4;
+    const int Kp = (K + 15) & ~15;                            // rows of the weight image (zero beyond K)
+    const int col = 16 * w + c;
+    const int pos = (col & 3) * 16 + (col >> 2);              // position of logical column `col` in a k_ts_gemm image row
+    Bf16x3 wreg[6];
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) {
-                    const v4f v = acc2[s][ti];
-                    st4(slab + ((ti * 4 + w) * 64 + lane) * 4, make_float4(v[0], v[1], v[2], v[3]));
-                }
+    for (int s = 0; s < 6; ++s) {
+        const int k0 = 32 * s + 8 * kb;
+        const float* p = img + ((size_t)(k0 >> 2) * 64 + pos) * 4;
+        wreg[s] = split8(k0 < Kp ? ld4(p) : f4zero(), k0 + 4 < Kp ? ld4(p + 64 * 4) : f4zero());
+    }
+    const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
+    const int nks = (K + 31) >> 5;                            // 32-k steps that hold data (<= 6)
+    __syncthreads();                                          // the block's only barrier (LDS flags / W_edge / ring padding staged)
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int slot = it % RING, want = 4 * (it / RING + 1);
+        while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const char* tl = s_ring + slot * kX3TileBytes + c * kX3RowBytes + kb * 16;       // row c, k = 32 s + 8 kb ..
+        v4f_t acc_s = {0.f, 0.f, 0.f, 0.f}, acc_m = acc_s, acc_b = acc_s;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            if (s < nks) {
+                Bf16x3 a;
+                a.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
+                a.mid = *reinterpret_cast<const bf16x8_t*>(tl + kX3PlaneBytes + 64 * s);
+                a.lo = *reinterpret_cast<const bf16x8_t*>(tl + 2 * kX3PlaneBytes + 64 * s);
+                acc_s = mfma_x3_small(a, wreg[s], acc_s);
+                acc_m = mfma_x3_mid(a, wreg[s], acc_m);
+                acc_b = mfma_x3_big(a, wreg[s], acc_b);
             }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
+        const int r0 = 16 * tile + 4 * kb;
+        if (col < Cp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias;
         }
     }
 }
 
-template <int H, int P>
+// four consecutive channels of a published row -> the three planes of an x3 tile (8 bytes each)
+__device__ __forceinline__ void x3_store4(char* row_k, float4 v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split2(v.x, v.y, h0, m0, l0);
+    split2(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<uint2*>(row_k) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(row_k + kX3PlaneBytes) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(row_k + 2 * kX3PlaneBytes) = make_uint2(l0, l1);
+}
+
+template <int H, int P, bool X3>
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_fwd_ws(FwdDmaArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,11 +177,15 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     float* s_mt = reinterpret_cast<float*>(s_ready + 16);     // M transposed: [head][edge feature] (one ds_read_b128 per lane and pass)
     int* s_taken = s_ready + 32;                              // [kWsRing] consumer check-outs per slot
     float* s_meta = smem + WSZ + 64;                          // per producer wave: 2 side tables of 2 KB
-    float* s_ring = s_meta + P * 2 * kSideF;                  // kWsRing tiles of 16 x LDT floats
+    float* s_ring = s_meta + P * 2 * kSideF;                  // kWsRing tiles of 16 x LDT floats (X3: kRingN tiles of kX3TileBytes)
+    constexpr int kRingN = X3 ? kWsRingX3 : kWsRing;
     for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) {
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
+    }
+    if constexpr (X3) {      // the k padding of every tile row (columns H*Cp .. 191) must read as zero: the ring is cleared once
+        for (int i = tid; i < kRingN * kX3TileBytes / 16; i += kWsBlock) st4(s_ring + 4 * i, f4zero());
     }
     // the block's only barrier sits BEHIND each role's first global loads (ws_consume; the producers' first record + prefetch below)
     const int ntiles = (a.N + 15) >> 4;
@@ -210,7 +195,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
-        ws_consume<false>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, nullptr, nullptr WS_PROF_ARGS);
+        if constexpr (X3) ws_consume_x3<kRingN>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
+        else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -343,16 +329,22 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     // this wave's four rows of local tile `it` go into ring slot it % kWsRing (rows past N are zero: out = bias, never stored)
     auto publish = [&](int it) {
         LANE_CONSTS(); (void)qoff;
-        const int slot = it % kWsRing;
-        if (it >= kWsRing) {                                  // the consumers must have taken the slot's previous tile
-            const int want = kWsCons * (it / kWsRing);
+        const int slot = it % kRingN;
+        if (it >= kRingN) {                                   // the consumers must have taken the slot's previous tile
+            const int want = kWsCons * (it / kRingN);
             while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
         if (qok) {
-            float* tl = s_ring + slot * 16 * LDT + (rw * 4 + j) * LDT + q * 4;
+            if constexpr (X3) {      // three bf16 planes; k = h * Cp + 4 q .. + 3 (bf16x3.h: the exact split happens here, once per element)
+                char* tl = reinterpret_cast<char*>(s_ring) + slot * kX3TileBytes + (rw * 4 + j) * kX3RowBytes + q * 8;
 #pragma unroll
-            for (int h = 0; h < H; ++h) st4(tl + h * Cp, r_acc[h]);
+                for (int h = 0; h < H; ++h) x3_store4(tl + h * Cp * 2, r_acc[h]);
+            } else {
+                float* tl = s_ring + slot * 16 * LDT + (rw * 4 + j) * LDT + q * 4;
+#pragma unroll
+                for (int h = 0; h < H; ++h) st4(tl + h * Cp, r_acc[h]);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this pass's LDS traffic is done (also guards the side-table buffer)
         if (lv == 0) flag_bump(s_ready + slot);
@@ -448,10 +440,9 @@ struct SrcWsArgs {
     int N; int Cp;
     float* d_xw; float* d_a_ij;                  // d_a_ij[N, 8]: columns 0..3 (d_a_i) are read, 4..7 (d_a_j) written
     const float* img_dx; float* d_x;
-    const float* wg_x; float* wg_partial;        // WG kernels: the consumers also accumulate [d_xw | d_a]^T x (k_wgrad slab partials, split = block)
 };
 
-template <int H, int P, bool WG>
+template <int H, int P>
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -472,7 +463,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        ws_consume<WG>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, a.wg_x, a.wg_partial WS_PROF_ARGS);
+        ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -647,14 +638,14 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #undef LANE_CONSTS
 }
 
-template <int H, int P, bool WG = false>
+template <int H, int P>
 static int launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, WG>), big, "triplet_bwd_src_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
-    GLAM_PROF_LABEL(WG ? "k_triplet_bwd_src_ws+dx+wgrad" : "k_triplet_bwd_src_ws+dx");
-    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, WG>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
     return GLAM_OK;
 }
 
@@ -662,36 +653,24 @@ bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
     return triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H * Cp + 8 <= 192;
 }
 
-// the weight-gradient product inside the warp-specialised B2 launch exists for the reference's layer shape (layer.py:16: heads = 3;
-// hid_dim 60: K = H * Cp + 8 = 188 = three 64-row slabs, twelve 16-k groups)
-bool triplet_ws_wgrad_supported(int H, int Cp, int De, int edge_onehot) {
-    return H == 3 && Cp == 60 && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot) && ws_grid_cap(kWsWgradBlocks) <= kWsWgradBlocks;
-}
-
 // B2 + d_x over ELL records by source, warp-specialised (called by triplet_bwd_impl)
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* wg_x, float* wg_partial,
-                       int* wg_nsplit) {
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s) {
     if (N == 0) return GLAM_OK;
     if (!triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
     if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a tensor exceeds 4 GiB (32-bit offsets)");
-    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x, wg_x, wg_partial};
+    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x};
     const int ntiles = (int)((N + 15) / 16);
-    const int cap = ws_grid_cap(wg_x ? kWsWgradBlocks : 1024);      // fused weight gradient: one slab set per block in the workspace
+    const int cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;
-    if (wg_x) {
-        if (!wg_partial || !wg_nsplit || !triplet_ws_wgrad_supported(H, Cp, De, edge_onehot))
-            return fail(GLAM_E_INVALID, "triplet_bwd_src_ws: fused weight gradient without a partial buffer / outside its table (H = 3, Cp = 60)");
-        *wg_nsplit = grid;
-    }
     int rc = GLAM_OK;      // eight producers (three waves per SIMD) where the kernel fits 168 registers without scratch, four at H = 4
     switch (H) {
         case 1: rc = launch_src_ws_p<1, 8>(a, grid, s); break;
         case 2: rc = launch_src_ws_p<2, 8>(a, grid, s); break;
-        case 3: rc = wg_x ? launch_src_ws_p<3, 8, true>(a, grid, s) : launch_src_ws_p<3, 8>(a, grid, s); break;
+        case 3: rc = launch_src_ws_p<3, 8>(a, grid, s); break;
         default: rc = launch_src_ws_p<4, 4>(a, grid, s); break;
     }
     if (rc) return rc;
@@ -699,18 +678,24 @@ int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* d
     return GLAM_OK;
 }
 
-static size_t ws_lds_bytes(int H, int Cp, int P) {
+static size_t ws_lds_bytes(int H, int Cp, int P, bool x3) {
     const int HC = H * Cp;
-    return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 2 * 64 * 4 + (size_t)kWsRing * 16 * (HC + 4)) * sizeof(float);
+    const size_t ring = x3 ? (size_t)kWsRingX3 * kX3TileBytes : (size_t)kWsRing * 16 * (HC + 4) * sizeof(float);
+    return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 2 * 64 * 4) * sizeof(float) + ring;
 }
 
+template <int H, int P, bool X3>
+static int launch_ws_px(const FwdDmaArgs& a, int grid, hipStream_t s) {
+    static bool big[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P, X3>), big, "triplet_fwd_ws")) return rc;
+    GLAM_PROF_LABEL("k_triplet_fwd_ws+update");
+    hipLaunchKernelGGL((k_triplet_fwd_ws<H, P, X3>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P, X3), s, a);
+    return GLAM_OK;
+}
+// the consumers' product on the bf16 matrix cores in 3 x bf16 form (fp32 accuracy) unless GLAM_X3=0
 template <int H, int P>
 static int launch_ws_p(const FwdDmaArgs& a, int grid, hipStream_t s) {
-    static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P>), big, "triplet_fwd_ws")) return rc;
-    GLAM_PROF_LABEL("k_triplet_fwd_ws+update");
-    hipLaunchKernelGGL((k_triplet_fwd_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P), s, a);
-    return GLAM_OK;
+    return ts_x3_enabled() ? launch_ws_px<H, P, true>(a, grid, s) : launch_ws_px<H, P, false>(a, grid, s);
 }
 template <int H>
 static int launch_ws(const FwdDmaArgs& a, int grid, hipStream_t s) {

@@ -1979,16 +1979,21 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
     monkeypatch.setenv("GLAM_TORCH_EXT", "0")
     monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
     res = {}
-    for name, route, env in (("general", "0", "1"), ("general_env", "auto", "0"), ("ws", "auto", "1")):
+    # x3 = "0": every dense product on the fp32 matrix instructions (the data flow of the warp-specialised kernels is pinned bit for bit
+    # against the general ones); x3 = "1" (the default): the consumers' products in 3 x bf16 form (csrc/bf16x3.h) — fp32 accuracy, other
+    # roundings: rounding-level agreement here, the fp64-twin bound against the oracle in the tests around this one
+    for name, route, env, x3 in (("general", "0", "1", "0"), ("general_env", "auto", "0", "0"), ("ws", "auto", "1", "0"), ("ws_x3", "auto", "1", "1")):
         monkeypatch.setattr(ops, "WS_ROUTE", route)
         monkeypatch.setenv("GLAM_WS", env)
+        monkeypatch.setenv("GLAM_X3", x3)
         x = x0.clone().requires_grad_(True)
         with _lib.kernel_timer(capacity=64) as kt:
             out = conv(x, b.edge_index, b.edge_attr)
             grads = torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot)
         res[name] = (out, grads, [n for n, _, _ in kt.records()])
-    for k in ("k_triplet_fwd_ws", "k_triplet_bwd_src_ws") + (("k_triplet_bwd_dst_ws",) if H <= 3 else ()):
-        assert any(k in n for n in res["ws"][2]), (k, res["ws"][2])
+    for nm in ("ws", "ws_x3"):
+        for k in ("k_triplet_fwd_ws", "k_triplet_bwd_src_ws") + (("k_triplet_bwd_dst_ws",) if H <= 3 else ()):
+            assert any(k in n for n in res[nm][2]), (k, res[nm][2])
     assert not any("_ws" in n for n in res["general"][2] + res["general_env"][2])
     assert torch.equal(res["general"][0], res["general_env"][0]) and all(torch.equal(a, c) for a, c in zip(res["general"][1], res["general_env"][1]))
     names = ["x", "weight_node", "weight_edge", "weight_triplet_att", "weight_scale", "bias"]
@@ -1999,6 +2004,9 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
             assert_close(c, a, 2e-6, f"ws d_{pn}")
         else:
             assert torch.equal(a, c), (pn, (a - c).abs().max().item())
+    assert_close(res["ws_x3"][0], res["general"][0], 2e-6, "ws_x3 out")
+    for pn, a, c in zip(names, res["general"][1], res["ws_x3"][1]):
+        assert_close(c, a, 4e-6, f"ws_x3 d_{pn}")
 
 
 # ---------------------------------------------------------------------------------------------
