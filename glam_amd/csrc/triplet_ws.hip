@@ -442,7 +442,7 @@ struct SrcWsArgs {
     const float* img_dx; float* d_x;
 };
 
-template <int H, int P>
+template <int H, int P, bool X3>
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -456,14 +456,19 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int* s_taken = s_ready + 32;
     float* s_meta = smem + WSZ + 64;
     float* s_ring = s_meta + P * 2 * kSideF;
+    constexpr int kRingN = X3 ? kWsRingX3 : kWsRing;
     for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) s_ready[tid] = 0;
+    if constexpr (X3) {      // the k padding of every tile row must read as zero: the ring is cleared once (see k_triplet_fwd_ws)
+        for (int i = tid; i < kRingN * kX3TileBytes / 16; i += kWsBlock) st4(s_ring + 4 * i, f4zero());
+    }
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        if constexpr (X3) ws_consume_x3<kRingN>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
+        else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -565,18 +570,27 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     };
     auto publish = [&](int it) {
         LANE_CONSTS(); (void)qoff;
-        const int slot = it % kWsRing;
-        if (it >= kWsRing) {
-            const int want = kWsCons * (it / kWsRing);
+        const int slot = it % kRingN;
+        if (it >= kRingN) {
+            const int want = kWsCons * (it / kRingN);
             while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
+        if constexpr (X3) {          // three bf16 planes per tile (bf16x3.h), k = h * Cp + 4 q; [d_a_i | d_a_j] at k = HC .. HC + 7
+            char* tl = reinterpret_cast<char*>(s_ring) + slot * kX3TileBytes + (rw * 4 + j) * kX3RowBytes;
+            if (qok) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) x3_store4(tl + (h * Cp + q * 4) * 2, r_acc[h]);
+            }
+            if (q == 0) { x3_store4(tl + HC * 2, r_dai); x3_store4(tl + (HC + 4) * 2, r_da); }
+        } else {
         float* tl = s_ring + slot * 16 * LDT + (rw * 4 + j) * LDT;
         if (qok) {
 #pragma unroll
             for (int h = 0; h < H; ++h) st4(tl + h * Cp + q * 4, r_acc[h]);
         }
         if (q == 0) { st4(tl + HC, r_dai); st4(tl + HC + 4, r_da); }       // [d_a_i | d_a_j]: columns HC .. HC + 7 of the tile
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lv == 0) flag_bump(s_ready + slot);
     };
@@ -638,15 +652,20 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #undef LANE_CONSTS
 }
 
+template <int H, int P, bool X3>
+static int launch_src_ws_px(const SrcWsArgs& a, int grid, hipStream_t s) {
+    static bool big[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, X3>), big, "triplet_bwd_src_ws")) return rc;
+    const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
+    const size_t ring = X3 ? (size_t)kWsRingX3 * kX3TileBytes : (size_t)kWsRing * 16 * LDT * sizeof(float);
+    const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4) * sizeof(float) + ring;
+    GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, X3>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    return GLAM_OK;
+}
 template <int H, int P>
 static int launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
-    static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P>), big, "triplet_bwd_src_ws")) return rc;
-    const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
-    const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4 + (size_t)kWsRing * 16 * LDT) * sizeof(float);
-    GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
-    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
-    return GLAM_OK;
+    return ts_x3_enabled() ? launch_src_ws_px<H, P, true>(a, grid, s) : launch_src_ws_px<H, P, false>(a, grid, s);
 }
 
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {

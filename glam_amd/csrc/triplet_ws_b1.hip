@@ -34,7 +34,7 @@ struct DstWsArgs {
     float* d_aggr; float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;      // partial[gridDim.x][4 * H * Cp + 16]
 };
 
-template <int H, int V>
+template <int H, int V, bool X3>
 __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_ws(DstWsArgs a) {
     constexpr int kBlockT = (V + 4) * 64, VG = V / 4, CH = 4;
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -65,7 +65,87 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         // matrix waves: d_aggr tile[16, HC] = d_out[16 tile .. +15, Cp] @ W_scale^T, columns 48 w .. 48 w + 47 in this wave
         // ------------------------------------------------------------------------------------------------------------------
         const int w = wave - V, c = lane & 15, kq = lane >> 4;
-        const int GK = (Cp + 15) >> 4, MP = HC <= 64 ? 64 : 192;       // k groups (<= 4), positions per image row
+        const int MP = HC <= 64 ? 64 : 192;                   // positions per image row
+        auto publish_tile = [&](int it_, const v4f (&acc)[3]) {
+            const int slot = it_ % kRing;
+            float* tl = s_ring + slot * 16 * LDT;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int mcol = 16 * (3 * w + ct) + c;
+                if (mcol < HC) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tl[(4 * kq + i) * LDT + mcol] = acc[ct][i];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) flag_bump(s_ready + slot);
+        };
+        auto wait_slot = [&](int it_) {
+            const int slot = it_ % kRing;
+            if (it_ >= kRing) {                               // the vector waves must have taken the slot's previous tile
+                const int want = 4 * (it_ / kRing);
+                while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        };
+        if constexpr (X3) {
+            // ---- 3 x bf16 form (bf16x3.h, round 4): lane (row c, k block kq) holds 8 consecutive k of a d_out row per 32-k step; the wave's
+            //      64 x 48 slice of W_scale^T is split once into 72 registers; 36 v_mfma_f32_16x16x32_bf16 per tile (three column tiles x
+            //      two steps x six partial products, small ones first) replace 48 fp32 MFMAs that ran INSTEAD of the vector waves'
+            //      instructions on the SIMD's one fp32 datapath ----
+            const int Kp = (Cp + 15) & ~15;
+            Bf16x3 wreg[2][3];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int mcol = 16 * (3 * w + ct) + c;
+                const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int k0 = 32 * st + 8 * kq;
+                    const float* p = a.img_dagg + ((size_t)(k0 >> 2) * MP + pos) * 4;
+                    wreg[st][ct] = split8((k0 < Kp && mcol < HC) ? ld4(p) : f4zero(), (k0 + 4 < Kp && mcol < HC) ? ld4(p + (size_t)MP * 4) : f4zero());
+                }
+            }
+            auto load_a = [&](int tile, float4 (&af)[2][2]) {
+                const int row = 16 * tile + c;
+                const bool rok = tile < ntiles && row < a.N;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k0 = 32 * st + 8 * kq + 4 * u;
+                        af[st][u] = (rok && k0 < Cp) ? ld4(a.d_out + (size_t)row * Cp + k0) : f4zero();
+                    }
+            };
+            float4 af[2][2];
+            int tile = blockIdx.x, it = 0;
+            load_a(tile, af);
+            __syncthreads();                                  // LDS initialised; the weight slice and the first tile's rows are in flight
+            for (; tile < ntiles; tile += gridDim.x, ++it) {
+                Bf16x3 as[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) as[st] = split8(af[st][0], af[st][1]);
+                load_a(tile + gridDim.x, af);                 // next tile's rows in flight under this tile's MFMAs
+                wait_slot(it);
+                v4f acc[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[ct] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_small(as[st], wreg[st][ct], acc[ct]);
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_mid(as[st], wreg[st][ct], acc[ct]);
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_big(as[st], wreg[st][ct], acc[ct]);
+                publish_tile(it, acc);
+            }
+        } else {
+        const int GK = (Cp + 15) >> 4;                        // k groups (<= 4)
         float4 bf[3][4];
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
@@ -88,12 +168,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         load_a(tile, af_a);
         __syncthreads();                                      // LDS initialised; the weight slice and the first tile's rows are in flight
         auto one_tile = [&](int it_, const float4 (&af)[4]) {
-            const int slot = it_ % kRing;
-            if (it_ >= kRing) {                             // the vector waves must have taken the slot's previous tile
-                const int want = 4 * (it_ / kRing);
-                while (flag_load(s_taken + slot) < want) __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
+            wait_slot(it_);
             v4f acc[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) acc[ct] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -108,17 +183,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                             acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(af[g], jj), f4get(bf[ct][g], jj), acc[ct], 0, 0, 0);
                 }
             }
-            float* tl = s_ring + slot * 16 * LDT;
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                const int mcol = 16 * (3 * w + ct) + c;
-                if (mcol < HC) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) tl[(4 * kq + i) * LDT + mcol] = acc[ct][i];
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) flag_bump(s_ready + slot);
+            publish_tile(it_, acc);
         };
         for (; tile < ntiles; tile += 2 * gridDim.x, it += 2) {
             load_a(tile + gridDim.x, af_b);                   // next tile's rows in flight under this tile's MFMAs
@@ -127,6 +192,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                 load_a(tile + 2 * gridDim.x, af_a);
                 one_tile(it + 1, af_b);
             }
+        }
         }
     } else {
         // ------------------------------------------------------------------------------------------------------------------
@@ -380,13 +446,19 @@ static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     return ((size_t)WL + 64 + (size_t)V * 4 * WL + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
+template <int H, int V, bool X3>
+static int launch_b1ws_x(const DstWsArgs& a, int grid, hipStream_t s) {
+    static bool big[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V, X3>), big, "triplet_bwd_dst_ws")) return rc;
+    GLAM_PROF_LABEL("d_aggr+k_triplet_bwd_dst_ws");
+    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V, X3>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
+    return GLAM_OK;
+}
 template <int H, int V>
 static int launch_b1ws(const DstWsArgs& a, int grid, hipStream_t s) {
-    static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V>), big, "triplet_bwd_dst_ws")) return rc;
-    GLAM_PROF_LABEL("d_aggr+k_triplet_bwd_dst_ws");
-    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
-    return GLAM_OK;
+    // (with fewer heads the 72-register weight slice would cost the launch its fourth wave per SIMD: those keep the fp32 form)
+    if constexpr (H == 3) { if (ts_x3_enabled()) return launch_b1ws_x<H, V, true>(a, grid, s); }
+    return launch_b1ws_x<H, V, false>(a, grid, s);
 }
 
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot) {

@@ -58,9 +58,14 @@ for case in range(n_cases):
         assert any("k_triplet_fwd_ws" in n for n in ws_names) == fused and any("k_triplet_bwd_src_ws" in n for n in ws_names) == fused, ws_names
         assert any("k_triplet_bwd_dst_ws" in n for n in ws_names) == (fused and H <= 3), ws_names
         b1ws = fused and H <= 3
-        assert torch.equal(res["0"][0], res["auto"][0]), "out differs from the general kernels"
+        x3 = os.environ.get("GLAM_X3", "1") != "0"      # 3 x bf16 products in the warp-specialised kernels: rounding-level agreement
+        if x3:
+            err = (res["0"][0] - res["auto"][0]).abs().max().item()
+            assert err <= 4e-6 * max(1.0, res["0"][0].abs().max().item()), f"out vs general {err:.2e}"
+        else:
+            assert torch.equal(res["0"][0], res["auto"][0]), "out differs from the general kernels"
         for n, a, c in zip(names, res["0"][1], res["auto"][1]):
-            if n in ("weight_edge", "weight_triplet_att") and b1ws:
+            if x3 or (n in ("weight_edge", "weight_triplet_att") and b1ws):
                 err = (a - c).abs().max().item()
                 assert err <= 4e-6 * max(1.0, a.abs().max().item()), f"d_{n} vs general {err:.2e}"
             else:
