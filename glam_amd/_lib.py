@@ -24,6 +24,7 @@ SIGNATURES = {
     "glam_prof_begin": (_i32, [_i32]),
     "glam_prof_end": (_i32, []),
     "glam_prof_read": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]),
+    "glam_pad_group": (_i32, [_i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int32), _i32, _vp]),
     "glam_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "glam_csr_build": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_batch_ptr": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
@@ -32,6 +33,8 @@ SIGNATURES = {
     "glam_triplet_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _f32] + [_vp] * 6 + [_sz, _vp]),
     "glam_pool5_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "glam_pool5_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "glam_pool5_padded_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "glam_pool5_padded_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "glam_segment_pool_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "glam_segment_pool_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "glam_segment_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),

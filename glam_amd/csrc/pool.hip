@@ -64,18 +64,34 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd(const float* x, const int*
     }
 }
 
-// Wave-per-graph, D % 4 == 0 and D <= 64 (every hidden width in padded form; the readout of the default model): the
+// Wave-per-graph over float4 rows (every hidden width in its padded form; the readout of the default model): the
 // kernel above is a chain of ~3 n/4 dependent round trips per graph (22 us for 20-atom molecules at ANY batch size).
-// Here a lane owns (row group rg = lane / 16, float4 column chunk c4 = lane % 16): all row loads of a graph are in
-// flight together; the top-K rows come from per-lane candidates merged by K rounds of a wave-wide arg-max
-// (value descending, node index ascending on ties: the stable order of the serial kernel).
-__global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const int* ptr, int B, int D, int K, float* out,
+// Here a lane owns (row group rg = lane / LPR, float4 column chunk c4 = lane % LPR), LPR = 16 lanes per row (ld <= 64) or 32
+// (ld <= 128): all row loads of a graph are in flight together; the top-K rows come from per-lane candidates merged by K
+// rounds of a wave-wide arg-max (value descending, node index ascending on ties: the stable order of the serial kernel).
+// Rows are ld floats apart (ld % 4 == 0) and hold D <= ld channels, the rest zero padding (hid_dim 15 / 30 / 45 / 90 arrive as
+// 16 / 32 / 48 / 92); the output is the compact [B, (2 + K) * D] the reference produces.
+__device__ __forceinline__ void put_cols(float* o, int c0, int D, float4 v) {
+    if ((D & 3) == 0) { st4(o + c0, v); return; }       // (c0 < ld = D rounded up: c0 + 3 < D when D % 4 == 0)
+    if (c0 < D) o[c0] = v.x;
+    if (c0 + 1 < D) o[c0 + 1] = v.y;
+    if (c0 + 2 < D) o[c0 + 2] = v.z;
+    if (c0 + 3 < D) o[c0 + 3] = v.w;
+}
+__device__ __forceinline__ float4 get_cols(const float* o, int c0, int D, bool vec) {
+    if (vec) return ld4(o + c0);
+    return make_float4(c0 < D ? o[c0] : 0.f, c0 + 1 < D ? o[c0 + 1] : 0.f, c0 + 2 < D ? o[c0 + 2] : 0.f, c0 + 3 < D ? o[c0 + 3] : 0.f);
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const int* ptr, int B, int ld, int D, int K, float* out,
                                                         int* topk_idx) {
-    const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
+    constexpr int RG = 64 / LPR;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, rg = lane / LPR;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int OD = (2 + K) * D;
-    const bool act = 4 * c4 < D;
+    const bool act = 4 * c4 < ld;
     for (int g = wave; g < B; g += nwaves) {
         const int beg = ptr[g], end = ptr[g + 1];
         // candidates: lane l holds the top-K of nodes beg + l, beg + l + 64, ...
@@ -84,7 +100,7 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const i
 #pragma unroll
         for (int r = 0; r < kMaxK; ++r) { tv[r] = -INFINITY; ti[r] = 0x7fffffff; }
         for (int n = beg + lane; n < end; n += 64) {
-            float v = x[(size_t)n * D + (D - 1)];
+            float v = x[(size_t)n * ld + (D - 1)];
             int vi = n;
 #pragma unroll
             for (int r = 0; r < kMaxK; ++r) {
@@ -98,28 +114,28 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const i
         float4 acc = f4zero();
         if (act) {
             int n = beg + rg;
-            for (; n + 28 < end; n += 32) {
+            for (; n + 7 * RG < end; n += 8 * RG) {
                 float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ld4(x + (size_t)(n + 4 * u) * D + 4 * c4);
+                for (int u = 0; u < 8; ++u) v[u] = ld4(x + (size_t)(n + RG * u) * ld + 4 * c4);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
             }
-            for (; n < end; n += 4) {
-                const float4 v = ld4(x + (size_t)n * D + 4 * c4);
+            for (; n < end; n += RG) {
+                const float4 v = ld4(x + (size_t)n * ld + 4 * c4);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
+        for (int off = LPR; off <= 32; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
             acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
         }
         float* o = out + (size_t)g * OD;
         const float inv_cnt = 1.f / (float)max(end - beg, 1);
         if (act && rg == 0) {
-            st4(o + 4 * c4, inv_cnt * acc);
-            st4(o + D + 4 * c4, acc);
+            put_cols(o, 4 * c4, D, inv_cnt * acc);
+            put_cols(o + D, 4 * c4, D, acc);
         }
         // K rounds of wave-wide arg-max over the lanes' best remaining candidate
 #pragma unroll
@@ -139,8 +155,8 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const i
                     for (int q = 0; q + 1 < kMaxK; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
                     tv[kMaxK - 1] = -INFINITY; ti[kMaxK - 1] = 0x7fffffff;
                 }
-                if (act && rg == (r & 3))
-                    st4(o + (2 + r) * D + 4 * c4, sel >= 0 ? ld4(x + (size_t)sel * D + 4 * c4) : f4zero());
+                if (act && rg == (r & (RG - 1)))
+                    put_cols(o + (2 + r) * D, 4 * c4, D, sel >= 0 ? ld4(x + (size_t)sel * ld + 4 * c4) : f4zero());
                 if (lane == 0) topk_idx[(size_t)g * K + r] = sel;
             }
         }
@@ -492,34 +508,37 @@ __global__ void __launch_bounds__(kBlock) k_pool5_bwd(const float* d_out, const 
     }
 }
 
-// D % 4 == 0, D <= 64: float4 rows, four rows of a graph per wave instruction
-__global__ void __launch_bounds__(kBlock) k_pool5_bwd_v4(const float* d_out, const int* ptr, const int* topk_idx, int B, int D,
-                                                        int K, float* d_x) {
-    const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
+// float4 rows of ld floats (D channels + zero padding), 64 / LPR rows of a graph per wave instruction; d_out is the compact
+// [B, (2 + K) * D] (vec: D % 4 == 0 and 16-byte aligned, else scalar reads); the pad columns of d_x are written as zeros
+template <int LPR>
+__global__ void __launch_bounds__(kBlock) k_pool5_bwd_v4(const float* d_out, const int* ptr, const int* topk_idx, int B, int ld, int D,
+                                                        int K, int vec, float* d_x) {
+    constexpr int RG = 64 / LPR;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, rg = lane / LPR;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int OD = (2 + K) * D;
-    if (4 * c4 >= D) return;
+    if (4 * c4 >= ld) return;
     for (int g = wave; g < B; g += nwaves) {
         const int beg = ptr[g], end = ptr[g + 1];
         const float inv_cnt = 1.f / (float)max(end - beg, 1);
         const float* go = d_out + (size_t)g * OD;
-        const float4 gm = ld4(go + 4 * c4), ga = ld4(go + D + 4 * c4);
+        const float4 gm = get_cols(go, 4 * c4, D, vec), ga = get_cols(go + D, 4 * c4, D, vec);
         int ti[kMaxK];
         float4 gk[kMaxK];
 #pragma unroll
         for (int r = 0; r < kMaxK; ++r) {
             ti[r] = r < K ? topk_idx[(size_t)g * K + r] : -1;
-            gk[r] = r < K ? ld4(go + (2 + r) * D + 4 * c4) : f4zero();
+            gk[r] = r < K ? get_cols(go + (2 + r) * D, 4 * c4, D, vec) : f4zero();
         }
         float4 base = ga;
         fma4(base, inv_cnt, gm);
-        for (int n = beg + rg; n < end; n += 4) {
+        for (int n = beg + rg; n < end; n += RG) {
             float4 v = base;
 #pragma unroll
             for (int r = 0; r < kMaxK; ++r)
                 if (r < K && ti[r] == n) { v.x += gk[r].x; v.y += gk[r].y; v.z += gk[r].z; v.w += gk[r].w; }
-            st4(d_x + (size_t)n * D + 4 * c4, v);
+            st4(d_x + (size_t)n * ld + 4 * c4, v);
         }
     }
 }
@@ -846,36 +865,63 @@ static int pool_dims(const char* fn, int64_t N, int64_t B, int D) {
     return GLAM_OK;
 }
 
-extern "C" int glam_pool5_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int k, float* out,
-                              int32_t* topk_idx, void* stream) {
+// x rows are ld floats apart and hold D channels (ld == D, or ld = D rounded up to a multiple of four with zero padding)
+extern "C" int glam_pool5_padded_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int ld, int D, int k, float* out,
+                                     int32_t* topk_idx, void* stream) {
     if (int rc = pool_dims("glam_pool5_fwd", N, B, D)) return rc;
     if (k < 1 || k > kMaxK) return fail(GLAM_E_UNSUPPORTED, "glam_pool5_fwd: k=%d not in 1..%d", k, kMaxK);
+    GLAM_REQUIRE(ld >= D && (ld == D || ((ld & 3) == 0 && ld - D < 4)), "glam_pool5_fwd: ld=%d for D=%d (ld == D or D rounded up to a multiple of 4)", ld, D);
     if (B == 0) return GLAM_OK;
     GLAM_REQUIRE(ptr && out && topk_idx && (N == 0 || x), "glam_pool5_fwd: null pointer");
-    if (N / B >= 64 && (D & 3) == 0 && D <= 64)      // large graphs: a block per graph
-        hipLaunchKernelGGL(k_pool5_fwd_block, dim3(grid_for(B, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
-    else if ((D & 3) == 0 && D <= 64)
-        hipLaunchKernelGGL(k_pool5_fwd_v4, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
+    const hipStream_t s = (hipStream_t)stream;
+    const bool v4 = (ld & 3) == 0 && aligned16(x) && ((D & 3) != 0 || aligned16(out));
+    if (ld == D && N / B >= 64 && (D & 3) == 0 && D <= 64)      // large graphs: a block per graph
+        hipLaunchKernelGGL(k_pool5_fwd_block, dim3(grid_for(B, 1)), dim3(kBlock), 0, s, x, ptr, (int)B, D, k, out, topk_idx);
+    else if (v4 && ld <= 64)
+        hipLaunchKernelGGL(k_pool5_fwd_v4<16>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, s, x, ptr, (int)B, ld, D, k, out, topk_idx);
+    else if (v4 && ld <= 128)
+        hipLaunchKernelGGL(k_pool5_fwd_v4<32>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, s, x, ptr, (int)B, ld, D, k, out, topk_idx);
+    else if (ld == D)
+        hipLaunchKernelGGL(k_pool5_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, s, x, ptr, (int)B, D, k, out, topk_idx);
     else
-        hipLaunchKernelGGL(k_pool5_fwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, ptr, (int)B, D, k, out, topk_idx);
+        return fail(GLAM_E_UNSUPPORTED, "glam_pool5_fwd: padded rows need ld <= 128 and a 16-byte aligned x (ld=%d)", ld);
     GLAM_LAUNCH_CHECK("glam_pool5_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_pool5_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int k, float* out,
+                              int32_t* topk_idx, void* stream) {
+    return glam_pool5_padded_fwd(x, ptr, N, B, D, D, k, out, topk_idx, stream);
+}
+
+// d_x rows are ld floats apart; their pad columns (D..ld) are written as zeros
+extern "C" int glam_pool5_padded_bwd(const float* d_out, const int32_t* ptr, const int32_t* topk_idx, int64_t N, int64_t B,
+                                     int ld, int D, int k, float* d_x, void* stream) {
+    if (int rc = pool_dims("glam_pool5_bwd", N, B, D)) return rc;
+    if (k < 1 || k > kMaxK) return fail(GLAM_E_UNSUPPORTED, "glam_pool5_bwd: k=%d not in 1..%d", k, kMaxK);
+    GLAM_REQUIRE(ld >= D && (ld == D || ((ld & 3) == 0 && ld - D < 4)), "glam_pool5_bwd: ld=%d for D=%d (ld == D or D rounded up to a multiple of 4)", ld, D);
+    if (B == 0 || N == 0) return GLAM_OK;
+    GLAM_REQUIRE(ptr && d_out && topk_idx && d_x, "glam_pool5_bwd: null pointer");
+    const hipStream_t s = (hipStream_t)stream;
+    const int vec = (D & 3) == 0 && aligned16(d_out);
+    const bool v4 = (ld & 3) == 0 && aligned16(d_x) && (vec || ld != D);
+    if (ld == D && N / B >= 64 && (D & 3) == 0 && D <= 64 && B * (int64_t)kPool5BwdChunks < 65536)
+        hipLaunchKernelGGL(k_pool5_bwd_block, dim3((int)B * kPool5BwdChunks), dim3(kBlock), 0, s, d_out, ptr, topk_idx, (int)B, D, k, d_x);
+    else if (v4 && ld <= 64)
+        hipLaunchKernelGGL(k_pool5_bwd_v4<16>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, s, d_out, ptr, topk_idx, (int)B, ld, D, k, vec, d_x);
+    else if (v4 && ld <= 128)
+        hipLaunchKernelGGL(k_pool5_bwd_v4<32>, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, s, d_out, ptr, topk_idx, (int)B, ld, D, k, vec, d_x);
+    else if (ld == D)
+        hipLaunchKernelGGL(k_pool5_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, s, d_out, ptr, topk_idx, (int)B, D, k, d_x);
+    else
+        return fail(GLAM_E_UNSUPPORTED, "glam_pool5_bwd: padded rows need ld <= 128 and a 16-byte aligned d_x (ld=%d)", ld);
+    GLAM_LAUNCH_CHECK("glam_pool5_bwd");
     return GLAM_OK;
 }
 
 extern "C" int glam_pool5_bwd(const float* d_out, const int32_t* ptr, const int32_t* topk_idx, int64_t N, int64_t B,
                               int D, int k, float* d_x, void* stream) {
-    if (int rc = pool_dims("glam_pool5_bwd", N, B, D)) return rc;
-    if (k < 1 || k > kMaxK) return fail(GLAM_E_UNSUPPORTED, "glam_pool5_bwd: k=%d not in 1..%d", k, kMaxK);
-    if (B == 0 || N == 0) return GLAM_OK;
-    GLAM_REQUIRE(ptr && d_out && topk_idx && d_x, "glam_pool5_bwd: null pointer");
-    if (N / B >= 64 && (D & 3) == 0 && D <= 64 && B * (int64_t)kPool5BwdChunks < 65536)
-        hipLaunchKernelGGL(k_pool5_bwd_block, dim3((int)B * kPool5BwdChunks), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
-    else if ((D & 3) == 0 && D <= 64 && aligned16(d_out) && aligned16(d_x))
-        hipLaunchKernelGGL(k_pool5_bwd_v4, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
-    else
-        hipLaunchKernelGGL(k_pool5_bwd, dim3(grid_for(B, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_out, ptr, topk_idx, (int)B, D, k, d_x);
-    GLAM_LAUNCH_CHECK("glam_pool5_bwd");
-    return GLAM_OK;
+    return glam_pool5_padded_bwd(d_out, ptr, topk_idx, N, B, D, D, k, d_x, stream);
 }
 
 extern "C" int glam_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,

@@ -749,14 +749,25 @@ def _apply_dropout(mod, x):
     if type(mod) is Dropout and mod.training and mod.p > 0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
         if mod.p >= 1:
             return torch.zeros_like(x)
+        base = ops.padded_base(x)
+        if base is not None:       # odd hidden widths: the zero-padded rows are what flows (0 stays 0), x is their [N, C] view
+            twin = ops.take_dropped(base, mod.p)
+            return ops.slice_cols(twin if twin is not None else ops.dropout(base, mod.p), x.size(1))
         twin = ops.take_dropped(x, mod.p)
         return twin if twin is not None else ops.dropout(x, mod.p)
     return mod(x)
 
 
+_ZERO_KEEPING = (ReLU, LeakyReLU, CELU, RReLU)      # act(0) = 0: applied to zero-padded rows, the pad columns stay zero
+
+
 def _apply_act(mod, x):
     """``mod(x)`` for an activation slot; training-mode RReLU (the reference's default, model.py:31) draws its slopes from the
     device-side Philox stream."""
+    if type(mod) in _ZERO_KEEPING and x.is_cuda and x.dim() == 2:
+        base = ops.padded_base(x)
+        if base is not None:       # odd hidden widths: no pad / slice copies around the activation
+            return ops.slice_cols(_apply_act(mod, base), x.size(1))
     if type(mod) is RReLU and mod.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
         return ops.rrelu(x, mod.lower, mod.upper)
     return mod(x)
@@ -841,7 +852,7 @@ class MessageBlock(torch.nn.Module):
         x = self.conv(x, edge_index, edge_attr)      # layer.py:259
         if self.gru is not None:
             g = self.gru
-            if fa is not None and (fa[2] is None or ops.gru_block_supported(x.size(1), g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0)):
+            if fa is not None and (fa[2] is None or ops.gru_rng_supported(x.size(1), g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0)):
                 # CELU (layer.py:261) + GRU step + residual + activation: one autograd node
                 x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,
                                      g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1], celu_in=True, rng=fa[2])

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import collections
 import contextlib
+import ctypes
 import os
 import weakref
 
@@ -233,6 +234,46 @@ def _scoped(table, key, owner, build):
     table[key] = (owner, val)
     return val
 
+class _PadGroup(torch.autograd.Function):
+    """Zero-padded copies of several parameters of one module in ONE launch (``glam_pad_group``); the backward slices all their
+    gradients in one launch too.  ``specs[t] = (d0, d1, d2, p1, p2)``: tensor t viewed as ``[d0, d1, d2]`` becomes ``[d0, p1, p2]``."""
+
+    @staticmethod
+    def forward(ctx, specs, *params):
+        require_device(*params)
+        params = [f32c(p, "parameter") for p in params]
+        dev = params[0].device
+        outs = [torch.empty(d0 * p1 * p2, dtype=torch.float32, device=dev) for d0, _, _, p1, p2 in specs]
+        _pad_group_launch(params, outs, specs, 0)
+        ctx.specs, ctx.shapes, ctx.dev = specs, [p.shape for p in params], dev
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *d_outs):
+        specs = ctx.specs
+        grads = [torch.empty(d0 * d1 * d2, dtype=torch.float32, device=ctx.dev) for d0, d1, d2, _, _ in specs]
+        _pad_group_launch([None if g is None else f32c(g, "d_padded") for g in d_outs], grads, specs, 1)
+        return (None,) + tuple(g.view(sh) for g, sh in zip(grads, ctx.shapes))
+
+
+def _pad_group_launch(src, dst, specs, backward):
+    n = len(specs)
+    vp = ctypes.c_void_p * n
+    dims = (ctypes.c_int32 * (5 * n))(*[v for sp in specs for v in sp])
+    check(_lib.load().glam_pad_group(n, vp(*[None if t is None else t.data_ptr() for t in src]), vp(*[t.data_ptr() for t in dst]), dims,
+                                     backward, stream()), "glam_pad_group")
+
+
+def pad_group(items):
+    """``items = [(tensor, (d0, d1, d2), (p1, p2), out_shape), ...]`` (at most 8, one module's parameters): the zero-padded
+    re-layouts of all of them from one launch, gradients back through one launch."""
+    specs = tuple((d0, d1, d2, p1, p2) for _, (d0, d1, d2), (p1, p2), _ in items)
+    outs = _PadGroup.apply(specs, *[t for t, _, _, _ in items])
+    return tuple(o.view(sh) for o, (_, _, _, sh) in zip(outs, items))
+
+
 # ---- zero-padded column layout of odd-width features (hid_dim 15 / 30 / 45 / 90: C % 4 != 0) ----------------------
 # The kernels work on rows of Cp = ceil4(C) floats.  An op that produced a padded [N, Cp] tensor whose pad columns are
 # zero hands the caller the [N, C] VIEW of it (slice_cols) and remembers the padded tensor; when that view comes back as
@@ -255,17 +296,25 @@ def slice_cols(x_p, C):
     return x_p[:, :C]
 
 
+def padded_base(x):
+    """The registered zero-padded tensor that ``x[N, C]`` is the untouched view of, or None."""
+    hit = _PADDED.get(x.data_ptr()) if x.dim() == 2 else None
+    if hit is not None:
+        base = hit[0]()
+        if base is not None and base._version == hit[1] and base.size(0) == x.size(0) and base.size(1) > x.size(1) and \
+                x.stride() == (base.size(1), 1) and base.data_ptr() == x.data_ptr() and base.dtype == x.dtype:
+            return base
+    return None
+
+
 def pad_cols(x, Cp):
     """``x[N, C]`` zero-padded to ``Cp`` columns: the registered padded tensor when ``x`` is its untouched view, else one
     ``F.pad`` per tensor and model pass."""
     if x.size(1) == Cp:
         return x
-    hit = _PADDED.get(x.data_ptr())
-    if hit is not None:
-        base = hit[0]()
-        if base is not None and base._version == hit[1] and x.dim() == 2 and base.shape == (x.size(0), Cp) and \
-                x.stride() == (Cp, 1) and base.data_ptr() == x.data_ptr() and base.dtype == x.dtype:
-            return base
+    base = padded_base(x)
+    if base is not None and base.size(1) == Cp:
+        return base
     C = x.size(1)
     if not x.requires_grad and x.grad_fn is None:
         # a DATA tensor (e.g. the atom features x[N, 15] of a cached loader batch): padded once per tensor, not once per pass

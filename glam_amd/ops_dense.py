@@ -378,9 +378,11 @@ def linear(x, weight, bias=None):
     if Kp != K or Mp != M:
         # padded once per model pass (the block's linears are applied message_steps times), like every derived weight
         w0, b0 = weight, bias
-        weight, bias = _o.scoped_weights(("lin-pad", id(w0), None if b0 is None else id(b0)), w0, lambda: (
-            torch.nn.functional.pad(w0, (0, Kp - K, 0, Mp - M)),
-            None if b0 is None else torch.nn.functional.pad(b0, (0, Mp - M))))
+        def build_padded():        # weight and bias from one launch
+            items = [(w0, (1, M, K), (Mp, Kp), (Mp, Kp))] + ([] if b0 is None else [(b0, (1, 1, M), (1, Mp), (Mp,))])
+            out = _o.pad_group(items)
+            return out[0], (None if b0 is None else out[1])
+        weight, bias = _o.scoped_weights(("lin-pad", id(w0), None if b0 is None else id(b0)), w0, build_padded)
     y = _Linear.apply(x, weight, bias)
     return _o.slice_cols(y, M)                    # pad columns are x @ 0 + 0
 
@@ -502,32 +504,28 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``.
     ``rng = (rr_lower, rr_upper, drop_p)`` (training mode of the reference's defaults): ``act == "rrelu"`` draws its slopes in
     the kernel and, with ``drop_p > 0``, the kernel also writes ``Dropout(drop_p)(out)`` and registers it as the dropped twin
-    of ``out`` (``take_dropped``) — available on the one-node path (C % 4 == 0, C <= 60); elsewhere the caller applies
+    of ``out`` (``take_dropped``) — available on the one-node path (24 <= C <= 60, odd widths zero-padded); elsewhere the caller applies
     ``ops.rrelu`` / ``ops.dropout`` itself (``rng`` must then be None)."""
     C = h.size(1)
-    if rng is not None and not gru_block_supported(C, w_ih, b_ih, b_hh):
-        raise GlamHipError("gru_tail(rng=...) needs the one-node GRU block (C % 4 == 0, C <= 60)")
+    if rng is not None and not gru_rng_supported(C, w_ih, b_ih, b_hh):
+        raise GlamHipError("gru_tail(rng=...) needs the one-node GRU block (24 <= C <= 60)")
     if gru_block_supported(C, w_ih, b_ih, b_hh):
         return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in, rng)
     Cp = (C + 3) // 4 * 4
-    if Cp != C and b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_supported(Cp, 3 * Cp) \
-            and 3 * Cp > 64:
+    if _gru_padded_supported(C, w_ih, b_ih, b_hh):
         # odd widths: the same node at Cp with gate-wise zero-padded weights (built once per model pass).  Pad channels
         # stay exactly zero through the step: gates r = z = 1/2, n = tanh(0) = 0, h' = z * 0 = 0, act(0 + 0) = 0.
         def build():
-            pw = lambda w: torch.nn.functional.pad(w.view(3, C, C), (0, Cp - C, 0, Cp - C)).reshape(3 * Cp, Cp)
-            pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
-            return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
+            return _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp)
         wi, wh, bi, bh = _o.scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build)
+        # (with rng the dropped twin is registered for out_p: layer._apply_dropout finds it through the padded base of the view)
         out_p, hn_p = _gru_block(_o.pad_cols(x, Cp), _o.pad_cols(h, Cp), None if identity is None else _o.pad_cols(identity, Cp),
-                                 wi, wh, bi, bh, ACT_CODES[act], slope, celu_in)
+                                 wi, wh, bi, bh, ACT_CODES[act], slope, celu_in, rng)
         return _o.slice_cols(out_p, C), _o.slice_cols(hn_p, C)
     if b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_tall_supported(Cp, 3 * Cp) and h.size(0) >= 64:
         # wide GRU (hid_dim_alpha = 6): library GEMMs for the gate products, k_wgrad for their weight gradients, at Cp
         def build_wide():
-            pw = lambda w: torch.nn.functional.pad(w.view(3, C, C), (0, Cp - C, 0, Cp - C)).reshape(3 * Cp, Cp)
-            pb = lambda b: torch.nn.functional.pad(b.view(3, C), (0, Cp - C)).reshape(3 * Cp)
-            return pw(w_ih), pw(w_hh), pb(b_ih), pb(b_hh)
+            return _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp)
         wi, wh, bi, bh = _o.scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build_wide) if Cp != C else \
             (w_ih, w_hh, b_ih, b_hh)
         x_p, h_p = _o.pad_cols(x, Cp), _o.pad_cols(h, Cp)
@@ -541,6 +539,12 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     return _GruTail.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h, identity, ACT_CODES[act], slope)
 
 
+
+
+def _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp):
+    """Gate-wise zero-padded GRU parameters ``[3C, C] -> [3Cp, Cp]``, ``[3C] -> [3Cp]``: all four from one launch."""
+    wsp, bsp = ((3, C, C), (Cp, Cp), (3 * Cp, Cp)), ((1, 3, C), (3, Cp), (3 * Cp,))
+    return _o.pad_group([(w_ih, *wsp), (w_hh, *wsp), (b_ih, *bsp), (b_hh, *bsp)])
 
 
 def _want_gru_fused(N):
@@ -724,6 +728,18 @@ class _GruBlock(torch.autograd.Function):
 def gru_block_supported(C, w_ih, b_ih, b_hh):
     return C % 4 == 0 and C + 1 <= 64 and linear_supported(C, 3 * C) and 3 * C > 64 and b_ih is not None and b_hh is not None and \
         tuple(w_ih.shape) == (3 * C, C)        # C + 1 <= 64: both weight gradients in ONE k_wgrad launch
+
+
+def _gru_padded_supported(C, w_ih, b_ih, b_hh):
+    """Odd widths (hid_dim 30 / 45): the one-node block at Cp = ceil4(C) on gate-wise zero-padded parameters."""
+    Cp = (C + 3) // 4 * 4
+    return Cp != C and b_ih is not None and b_hh is not None and tuple(w_ih.shape) == (3 * C, C) and linear_supported(Cp, 3 * Cp) \
+        and 3 * Cp > 64 and Cp + 1 <= 64
+
+
+def gru_rng_supported(C, w_ih, b_ih, b_hh):
+    """Widths whose GRU tail draws RReLU slopes / the next step's Dropout mask inside the kernel (``gru_tail(rng=...)``)."""
+    return gru_block_supported(C, w_ih, b_ih, b_hh) or _gru_padded_supported(C, w_ih, b_ih, b_hh)
 
 
 def gru_step(x, h, w_ih, w_hh, b_ih, b_hh):

@@ -18,37 +18,42 @@ from ._lib import GlamHipError, check, f32c, ptr, require_device, stream
 # readouts
 # --------------------------------------------------------------------------------------
 class _Pool5(torch.autograd.Function):
+    """``x`` holds ``D`` channels in rows of ``x.size(1) >= D`` floats (zero padding behind them: the padded flow of odd widths)."""
+
     @staticmethod
-    def forward(ctx, x, sp, k):
+    def forward(ctx, x, sp, k, D):
         require_device(x)
         x = f32c(x, "x")
-        N, D = x.shape
+        N, ld = x.shape
         if N != sp.N:
             raise GlamHipError(f"pool: x has {N} rows but batch has {sp.N}")
         out = torch.empty(sp.B, (2 + k) * D, dtype=torch.float32, device=x.device)
         topk = torch.empty(sp.B, k, dtype=torch.int32, device=x.device)
-        check(_lib.load().glam_pool5_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, k, ptr(out), ptr(topk), stream()),
+        check(_lib.load().glam_pool5_padded_fwd(ptr(x), ptr(sp.ptr), N, sp.B, ld, D, k, ptr(out), ptr(topk), stream()),
               "glam_pool5_fwd")
         ctx.save_for_backward(topk)
-        ctx.sp, ctx.dims = sp, (N, D, k)
+        ctx.sp, ctx.dims = sp, (N, ld, D, k)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
         (topk,) = ctx.saved_tensors
-        N, D, k = ctx.dims
+        N, ld, D, k = ctx.dims
         sp = ctx.sp
         d_out = f32c(d_out, "d_out")
-        d_x = torch.empty(N, D, dtype=torch.float32, device=d_out.device)
-        check(_lib.load().glam_pool5_bwd(ptr(d_out), ptr(sp.ptr), ptr(topk), N, sp.B, D, k, ptr(d_x), stream()),
+        d_x = torch.empty(N, ld, dtype=torch.float32, device=d_out.device)
+        check(_lib.load().glam_pool5_padded_bwd(ptr(d_out), ptr(sp.ptr), ptr(topk), N, sp.B, ld, D, k, ptr(d_x), stream()),
               "glam_pool5_bwd")
-        return d_x, None, None
+        return d_x, None, None, None
 
 
 def pool5(x, sp, k=3):
     """mean || add || sort-pool(k) readout, ``[B, (2+k)*D]``."""
-    return _Pool5.apply(x, sp, k)
+    base = _o.padded_base(x) if x.dim() == 2 else None
+    if base is not None and base.size(1) <= 128 and base.size(1) - x.size(1) < 4:
+        return _Pool5.apply(base, sp, k, x.size(1))      # odd widths: straight from the zero-padded rows, no compaction copy
+    return _Pool5.apply(x, sp, k, x.size(1))
 
 
 _MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}

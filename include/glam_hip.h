@@ -50,6 +50,15 @@ int glam_prof_begin(int capacity);
 int glam_prof_end(void);
 int glam_prof_read(int i, char* name_host, int name_cap, int32_t* grid_host, float* usec_host);
 
+/* Zero-padded copies of up to 8 parameter tensors in ONE launch, and their gradients back in one.
+ * Replaces: nothing in the reference (it has no padded layouts); on this side it replaces the F.pad / slice-copy pairs that
+ * re-lay a GRU's gate matrices [3C, C] -> [3Cp, Cp] (src_1gp/layer.py:247) and a Linear's [M, K] -> [Mp, Kp] (src_1gp/layer.py:229)
+ * once per model pass when hid_dim = 15 * hid_dim_alpha is not a multiple of four (src_1gp/glam.py:60: four of five widths).
+ * Tensor t is row-major [d0, d1, d2], its padded form [d0, p1, p2]; dims = n x {d0, d1, d2, p1, p2}; src / dst are HOST arrays of n
+ * device pointers.  backward = 0: dst[t] (padded) <- src[t] (plain), zeros in the pad.  backward = 1: dst[t] (plain gradient) <-
+ * src[t] (padded gradient; NULL = that gradient does not exist: zeros). */
+int glam_pad_group(int n, const float* const* src, float* const* dst, const int32_t* dims, int backward, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * CSR staging of a COO edge list.
  * Replaces: the per-call index_select/scatter bookkeeping PyG's MessagePassing.propagate does for
@@ -116,6 +125,14 @@ int glam_pool5_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int
                    int32_t* topk_idx, void* stream);
 int glam_pool5_bwd(const float* d_out, const int32_t* ptr, const int32_t* topk_idx, int64_t N, int64_t B,
                    int D, int k, float* d_x, void* stream);
+/* The same readout on zero-padded rows: x / d_x rows are ld floats apart and hold D channels, ld = D rounded up to a multiple
+ * of four (ld <= 128; hid_dim 15 / 30 / 45 / 90 of src_1gp/glam.py:60 flow as 16 / 32 / 48 / 92), columns D..ld zero.  out / d_out
+ * stay the compact [B, (2+k)*D] of the reference, the sort key is channel D - 1; d_x's pad columns are written as zeros.  ld == D
+ * is glam_pool5_fwd / _bwd. */
+int glam_pool5_padded_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int ld, int D, int k, float* out,
+                          int32_t* topk_idx, void* stream);
+int glam_pool5_padded_bwd(const float* d_out, const int32_t* ptr, const int32_t* topk_idx, int64_t N, int64_t B,
+                          int ld, int D, int k, float* d_x, void* stream);
 
 /* mode 0 = sum, 1 = mean, 2 = max (empty segment -> 0; argmax int32[B,D] saved for backward, may be
  * NULL for modes 0/1).  Replaces torch_scatter.scatter(x, batch, dim=0, reduce=...) behind PyG's

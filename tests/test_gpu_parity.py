@@ -984,6 +984,84 @@ def test_pool5_large_graphs_block_kernel(device, sizes):
     assert_twin_parity(run, out, _grads(out, cot.to(device), [x]), "pool5", ["x"])
 
 
+@pytest.mark.parametrize("D", [15, 30, 45, 90, 92, 128])
+def test_pool5_on_zero_padded_rows(device, D):
+    """GlobalPool5 of the odd hidden widths (glam.py:60) reads the zero-padded rows the blocks hand on (ld = ceil4(D): 16 lanes per
+    row up to 64, 32 up to 128) and writes the reference's compact [B, 5 D]; sort key = channel D - 1 (not the pad), ties and
+    graphs shorter than k included.  Bit-equal to the same kernel family on the compact rows where both exist, oracle otherwise."""
+    torch.manual_seed(D)
+    sizes = [20, 1, 2, 33, 70, 3, 12]
+    N, B, ld = sum(sizes), len(sizes), (D + 3) // 4 * 4
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    x0 = torch.randn(N, D)
+    x0[22:25, D - 1] = 5.0                                 # ties among the top entries of graph 3
+    cot = torch.randn(B, 5 * D)
+    xp = torch.zeros(N, ld, device=device)
+    xp[:, :D] = x0.to(device)
+    xp.requires_grad_(True)
+    v = ops.slice_cols(xp, D) if ld != D else xp
+    out = layer.GlobalPool5()(v, batch.to(device), B)
+    (g,) = _grads(out, cot.to(device), [xp])
+    assert g.shape == (N, ld) and (ld == D or (g[:, D:] == 0).all()), "the gradient comes back in the padded layout, pads zero"
+
+    def run(dt):
+        xr = x0.to(dt).requires_grad_(True)
+        o = O.global_pool5(xr, batch, B)
+        return o.detach(), _grads(o, cot.to(dt), [xr])
+    assert_twin_parity(run, out, [g[:, :D]], f"pool5 on padded rows, D = {D}", ["x"])
+    # the C ABI directly: ld == D is the unpadded entry point; a padded call must agree with it exactly for ld <= 64
+    raw = ops._lib.load()
+    sp = ops.segment_ptr(batch.to(device), B)
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    if ld != D and ld <= 64:
+        xc = x0.to(device).contiguous()
+        o1, t1 = torch.empty(B, 5 * D, device=device), torch.empty(B, 3, dtype=torch.int32, device=device)
+        assert raw.glam_pool5_fwd(xc.data_ptr(), sp.ptr.data_ptr(), N, B, D, 3, o1.data_ptr(), t1.data_ptr(), st()) == 0
+        o2, t2 = torch.empty_like(o1), torch.empty_like(t1)
+        assert raw.glam_pool5_padded_fwd(xp.data_ptr(), sp.ptr.data_ptr(), N, B, ld, D, 3, o2.data_ptr(), t2.data_ptr(), st()) == 0
+        assert torch.equal(t1, t2)
+        assert_close(o2, o1, 1e-6, "padded vs compact rows")      # (different summation order: serial vs row groups)
+    assert raw.glam_pool5_padded_fwd(xp.data_ptr(), sp.ptr.data_ptr(), N, B, ld + 4, D, 3, out.data_ptr(), sp.ptr.data_ptr(), st()) != 0
+    assert raw.glam_pool5_padded_fwd(xp.data_ptr(), sp.ptr.data_ptr(), N, B, D - 1, D, 3, out.data_ptr(), sp.ptr.data_ptr(), st()) != 0
+
+
+def test_pad_group_c_abi(device):
+    """glam_pad_group: the zero-padded re-layouts of a module's parameters (GRU gate matrices [3C, C] -> [3Cp, Cp], biases,
+    Linear weight [M, K] -> [Mp, Kp]) from one launch, their gradients back through one; against F.pad, bit for bit."""
+    import ctypes
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    C, Cp = 45, 48
+    w1, w2, b1, b2 = (torch.randn(3 * C, C, device=device), torch.randn(3 * C, C, device=device), torch.randn(3 * C, device=device),
+                      torch.randn(3 * C, device=device))
+    wl, bl = torch.randn(30, 15, device=device), torch.randn(30, device=device)
+    items = [(w1, (3, C, C), (Cp, Cp), (3 * Cp, Cp)), (w2, (3, C, C), (Cp, Cp), (3 * Cp, Cp)), (b1, (1, 3, C), (3, Cp), (3 * Cp,)),
+             (b2, (1, 3, C), (3, Cp), (3 * Cp,)), (wl, (1, 30, 15), (32, 16), (32, 16)), (bl, (1, 1, 30), (1, 32), (32,))]
+    for t, _, _, _ in items:
+        t.requires_grad_(True)
+    outs = ops.pad_group(items)
+    want = [F.pad(w1.view(3, C, C), (0, 3, 0, 3)).reshape(3 * Cp, Cp), F.pad(w2.view(3, C, C), (0, 3, 0, 3)).reshape(3 * Cp, Cp),
+            F.pad(b1.view(3, C), (0, 3)).reshape(-1), F.pad(b2.view(3, C), (0, 3)).reshape(-1), F.pad(wl, (0, 1, 0, 2)), F.pad(bl, (0, 2))]
+    for o, w in zip(outs, want):
+        assert o.shape == w.shape and torch.equal(o, w)
+    cots = [torch.randn_like(o) for o in outs]
+    srcs = [t for t, _, _, _ in items]
+    # the gradient of the fourth output does not exist: zeros for that parameter, no error
+    got = torch.autograd.grad([o for i, o in enumerate(outs) if i != 3], srcs, [c for i, c in enumerate(cots) if i != 3], allow_unused=True)
+    ref = torch.autograd.grad([w for i, w in enumerate(want) if i != 3], srcs, [c for i, c in enumerate(cots) if i != 3], allow_unused=True)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert torch.equal(g, r if r is not None else torch.zeros_like(srcs[i])), i
+    raw = ops._lib.load()
+    vp = ctypes.c_void_p * 9
+    dims = (ctypes.c_int32 * 45)(*([1, 1, 4, 1, 4] * 9))
+    buf = torch.zeros(64, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    assert raw.glam_pad_group(9, vp(*[buf.data_ptr()] * 9), vp(*[buf.data_ptr()] * 9), dims, 0, st) != 0       # more than 8 tensors
+    bad = (ctypes.c_int32 * 5)(1, 4, 4, 3, 4)                                                                  # padded smaller than plain
+    assert raw.glam_pad_group(1, (ctypes.c_void_p * 1)(buf.data_ptr()), (ctypes.c_void_p * 1)(buf.data_ptr()), bad, 0, st) != 0
+    assert raw.glam_pad_group(0, None, None, None, 0, st) == 0
+
+
 @pytest.mark.parametrize("D", [60, 45, 92])
 def test_pair_pool5_protein_sized_segments_vs_oracle(device, D):
     """dot_and_global_pool5 on ligand x protein sized pairs (410 / 97 / 655 residues), an even and an odd score count (lower
@@ -1725,14 +1803,16 @@ def test_rrelu_and_dropout_device_stream_statistics(device):
     assert_close(blk(y.detach()), mod(torch.nn.functional.linear(y.detach(), blk.linear.weight, blk.linear.bias)), 1e-5, "eval RReLU")
 
 
-def test_default_config_training_step_uses_the_fused_tails(device, monkeypatch):
+@pytest.mark.parametrize("alpha", [4, 2, 3])
+def test_default_config_training_step_uses_the_fused_tails(device, monkeypatch, alpha):
     """Architecture() with NO overrides except the conv (model.py:24-33 defaults: RReLU x 3, graph_do = end_do = Dropout(0.2)) in
     train(): the block tail draws the RReLU slopes and writes the next step's dropped input itself (one standalone dropout
     launch for the first message step only, no torch RNG kernels); the analytic gradient matches a central difference of the
-    re-seeded forward; eval() still equals the oracle."""
+    re-seeded forward; eval() still equals the oracle.  Odd hidden widths (alpha 2, 3: 30 -> 32, 45 -> 48) take the same kernels on
+    zero-padded rows and gate-wise padded GRU parameters."""
     torch.manual_seed(3)
     b = synth_batch(48, seed=8).to(device)
-    net = model.Architecture(mol_block="_TripletMessage", e_dim=128).to(device)
+    net = model.Architecture(mol_block="_TripletMessage", e_dim=128, hid_dim_alpha=alpha).to(device)
     calls = {"dropout": 0, "rrelu": 0}
     real_drop, real_rrelu = ops.dropout, ops.rrelu
     monkeypatch.setattr(ops, "dropout", lambda x, p: (calls.__setitem__("dropout", calls["dropout"] + 1), real_drop(x, p))[1])
@@ -1751,20 +1831,21 @@ def test_default_config_training_step_uses_the_fused_tails(device, monkeypatch):
     # directional derivative along a random parameter direction (same seed on both sides: the masks are those of `out`)
     torch.manual_seed(4)
     vs = [torch.randn_like(p) * p.abs().mean() for p in net.parameters()]
-    eps = 1e-2
 
-    def loss_at(sign):
+    def loss_at(step):
         with torch.no_grad():
             for p, v in zip(net.parameters(), vs):
-                p.add_(v, alpha=sign * eps)
+                p.add_(v, alpha=step)
             ops.manual_seed(99)
             val = net(b).double().square().mean().item()
             for p, v in zip(net.parameters(), vs):
-                p.sub_(v, alpha=sign * eps)
+                p.sub_(v, alpha=step)
         return val
-    fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)
     an = sum((g.double() * v.double()).sum().item() for g, v in zip(grads, vs))
-    assert abs(fd - an) <= 3e-2 * max(abs(an), abs(fd)) + 1e-6, (fd, an)
+    # the loss is only piecewise smooth (the sort-pool's top-3 selection can flip inside a finite step): two of three step sizes
+    # have to agree with the analytic value
+    fds = [(loss_at(+eps) - loss_at(-eps)) / (2 * eps) for eps in (1e-2, 1e-3, 3e-4)]
+    assert sum(abs(fd - an) <= 3e-2 * max(abs(an), abs(fd)) + 1e-6 for fd in fds) >= 2, (fds, an)
     # eval mode: deterministic, equals the oracle (RReLU -> its mean slope, dropout off)
     net.eval()
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}

@@ -71,6 +71,28 @@ side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(3): body()
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+if args.profile:      # which torch ops (pads, copies, fills, adds, library GEMMs) a step still launches, by glam_amd call site
+    import collections, traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    SKIP = ("empty", "view", "as_strided", "slice", "select", "detach", "alias", "t.", "transpose", "expand", "reshape", "unsqueeze",
+            "squeeze", "narrow", "_unsafe_view", "permute", "_local_scalar_dense", "lift_fresh", "unbind", "split", "is_same_size")
+    rows = collections.Counter()
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if not any(name.startswith("aten." + k) for k in SKIP):
+                fr = [f for f in traceback.extract_stack() if "glam_amd/" in f.filename or "tools/bench_model" in f.filename]
+                site = " < ".join(f"{f.filename.split('/')[-1]}:{f.lineno}" for f in reversed(fr[-3:])) if fr else "(autograd engine)"
+                shp = next((tuple(a.shape) for a in args if isinstance(a, torch.Tensor)), ())
+                rows[(name, site, shp)] += 1
+            return func(*args, **(kwargs or {}))
+    gp = torch.cuda.CUDAGraph()          # inside a capture: the routes (and the glue) of the replayed step, not of an eager one
+    with torch.cuda.graph(gp), Log():
+        body()
+    torch.cuda.synchronize()
+    for (name, site, shp), c in sorted(rows.items(), key=lambda kv: (kv[0][0], -kv[1])):
+        print(f"{c:4d}  {name:34s} {str(shp):18s} {site}")
+    sys.exit(0)
 g = None
 if not args.no_graph:
     g = torch.cuda.CUDAGraph()
