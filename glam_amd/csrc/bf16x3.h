@@ -39,6 +39,15 @@ __device__ __forceinline__ Bf16x3 split8(float4 a, float4 b) {
     r.lo = __builtin_bit_cast(bf16x8_t, (u4){l[0], l[1], l[2], l[3]});
     return r;
 }
+#ifdef GLAM_X3_FAKE_WSPLIT      // timing experiment only (wrong numbers): what the prologue's weight splits cost
+__device__ __forceinline__ Bf16x3 split8w(float4 a, float4 b) {
+    Bf16x3 r;
+    r.hi = __builtin_bit_cast(bf16x8_t, a); r.mid = __builtin_bit_cast(bf16x8_t, b); r.lo = r.hi;
+    return r;
+}
+#else
+__device__ __forceinline__ Bf16x3 split8w(float4 a, float4 b) { return split8(a, b); }
+#endif
 // acc += a * b over the 32 k of one step, small partial products first (they would lose their low bits against the large ones)
 __device__ __forceinline__ v4f_t mfma_x3_small(const Bf16x3& a, const Bf16x3& b, v4f_t acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.mid, acc, 0, 0, 0);

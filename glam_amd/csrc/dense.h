@@ -49,6 +49,7 @@ struct ReduceArgs { ReduceJob job[3]; int njobs; };
 size_t ts_image_floats(int K, int M);
 int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, float* img, hipStream_t s);
 int launch_ts_gemm(const TsArgs& a, hipStream_t s);
+int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s);    // tall_x3.hip: warp-specialised 3 x bf16 products
 int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s);   // b: a second product of the same variant in the same launch
 size_t wgrad_workspace_floats();
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job);

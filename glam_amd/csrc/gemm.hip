@@ -279,7 +279,8 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_ts_gemm_x3: the register-B form of the 192-column product (K <= 64: the node GEMM x @ [W_node | Wa_i | Wa_j]) on the bf16 matrix
+// k_ts_gemm_x3: the register-B form of the wide products (K <= 64 x 192 columns: the node GEMM x @ [W_node | Wa_i | Wa_j]; K <= 96 x
+// 320 columns: the same product, the GRU gate linears and the update GEMM's input gradient at hid_dim_alpha = 6) on the bf16 matrix
 // cores in 3 x bf16 form (bf16x3.h: fp32 accuracy; 48 v_mfma_f32_16x16x32_bf16 per 16 x 64 item instead of 60 fp32 MFMAs at 1.65 x the
 // cycles each, and off the fp32 datapath).  A wave is bound to one 64-column split and keeps that slice of W — split once, in the
 // prologue — in 96 registers (two 32-k steps x four column tiles x three terms); it walks the row tiles, splitting each A fragment
@@ -287,29 +288,29 @@ __global__ void __launch_bounds__(RBLK ? RBLK : kTsBlock) k_ts_gemm(TsArgs2 two)
 // Lane (r = lane & 15, kb = lane >> 4): A row r / W column, k = 32 s + 8 kb .. + 7 of step s (the two operands share the k set of a lane,
 // which is all the contraction needs).
 // ------------------------------------------------------------------------------------------------
-template <int RBLK>
+template <int RBLK, int KS = 2, int CS = 3>      // KS 32-k steps (K <= 32 KS), CS 64-column splits (image rows of 64 CS positions)
 __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
-    constexpr int MP = 192, CS = 3, WPB = RBLK / 64;
+    constexpr int MP = 64 * CS, WPB = RBLK / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kb = lane >> 4;
     const int K = a.K1, Kp = (K + 15) & ~15, M = a.M1 + a.M2;
     const int ntiles = (a.N + 15) >> 4;
     const int gw = (int)blockIdx.x * WPB + wave;
     const int cs = gw % CS;
     // W slice of this wave: column tile t holds the logical columns cs * 64 + 4 c + t (image position cs * 64 + 16 t + c)
-    Bf16x3 wreg[2][4];
+    Bf16x3 wreg[KS][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k0 = 32 * s + 8 * kb;                   // rows k0 .. k0 + 7 of the image (zero beyond K; the image ends at Kp)
             const float* p = a.Wimg + ((size_t)(k0 >> 2) * MP + cs * 64 + 16 * t + c) * 4;
-            wreg[s][t] = split8(k0 < Kp ? ld4(p) : f4zero(), k0 + 4 < Kp ? ld4(p + (size_t)MP * 4) : f4zero());
+            wreg[s][t] = split8w(k0 < Kp ? ld4(p) : f4zero(), k0 + 4 < Kp ? ld4(p + (size_t)MP * 4) : f4zero());
         }
-    auto load_a = [&](int tile, float4 (&af)[2][2]) {
+    auto load_a = [&](int tile, float4 (&af)[KS][2]) {
         const int row = tile * 16 + c;
         const bool rok = tile < ntiles && row < a.N;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int k0 = 32 * s + 8 * kb + 4 * u;
@@ -318,12 +319,12 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
     };
     const int tstride = nblk * WPB / CS;                       // row tiles per step of this wave (the host makes the wave count a multiple of CS)
     int tile = gw / CS;
-    float4 af[2][2];
+    float4 af[KS][2];
     load_a(tile, af);
     for (; tile < ntiles; tile += tstride) {
-        Bf16x3 as[2];
+        Bf16x3 as[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) as[s] = split8(af[s][0], af[s][1]);
+        for (int s = 0; s < KS; ++s) as[s] = split8(af[s][0], af[s][1]);
         load_a(tile + tstride, af);                            // next tile's rows fly under this tile's MFMAs and stores
         v4f_t acc[4];
 #pragma unroll
@@ -331,15 +332,15 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
         // four independent accumulator chains (column tiles); within a chain: small partial products of both k steps, then the middle
         // ones, then hi x hi
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_small(as[s], wreg[s][t], acc[t]);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_mid(as[s], wreg[s][t], acc[t]);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_big(as[s], wreg[s][t], acc[t]);
         // C layout: tile column = lane & 15 (-> logical columns cs * 64 + 4 c + t), row = (lane >> 4) * 4 + i
@@ -563,14 +564,16 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
 //   1: K <= 64,  M <= 192   <12, 4>    48 KB                                                           92 -> 276 + 8)
 // (a <8, 18> variant for K <= 288, M <= 128 was measured at 28.8 us against the library GEMM's 19.2 us for 276 -> 92 at
 //  N = 20.7 k — a 144 KB image per block and 1.26 items per wave — and is not kept)
+//   3: K <= 288, M <= 96   3 x bf16 only (tall_x3.hip: no LDS image, MT = 8 positions per row)   (hid_dim_alpha = 6: 276 -> 92)
 static int ts_variant(int K, int M) {
     if (M <= 0 || K <= 0) return -1;
     if (M <= 64 && K <= 192) return 0;
     if (K <= 64 && M <= 192) return 1;
     if (K <= 96 && M <= 320) return 2;
+    if (K <= 288 && M <= 96) return 3;
     return -1;
 }
-static int ts_mt(int variant) { return variant == 0 ? 4 : variant == 1 ? 12 : 20; }
+static int ts_mt(int variant) { return variant == 0 ? 4 : variant == 1 ? 12 : variant == 2 ? 20 : 8; }
 
 size_t ts_image_floats(int K, int M) {
     const int Kp = (K + 15) & ~15, v = ts_variant(K, M);
@@ -579,7 +582,7 @@ size_t ts_image_floats(int K, int M) {
 
 static int ts_shape_ok(const char* fn, int K, int M) {
     if (ts_variant(K, M) < 0)
-        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d outside the kernel table (K<=192,M<=64 | K<=64,M<=192 | K<=96,M<=320)", fn, K, M);
+        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d outside the kernel table (K<=192,M<=64 | K<=64,M<=192 | K<=96,M<=320 | K<=288,M<=96)", fn, K, M);
     return GLAM_OK;
 }
 
@@ -601,7 +604,7 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
     const int ntiles = (a.N + 15) / 16;
     *variant = ts_variant(K, M);
     // column splits per row tile (MT / TPI).  K <= 192 x 64 columns: splitting would re-read the long A rows
-    const int nitems = ntiles * (*variant == 0 ? 1 : *variant == 1 ? 3 : 5);
+    const int nitems = ntiles * (*variant == 0 || *variant == 3 ? 1 : *variant == 1 ? 3 : 5);
     int g = nitems < 2048 ? nitems : (nitems + 7) / 8;   // < one item per wave slot: one block per item first (see `spread`)
     if (g > 256) g = 256;                // one 8-wave block per CU, items dealt round-robin over every wave of the grid
     *grid = g;
@@ -609,6 +612,8 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
 }
 // the register-B form of the 192-column variant: one block per CU
 static bool ts_rb_enabled() { const char* e = getenv("GLAM_TS_RB"); return !e || atoi(e) != 0; }
+static bool tall_x3_wide_enabled() { const char* e = getenv("GLAM_TALL_WIDE"); return !e || atoi(e) != 0; }   // A/B: 96 -> 320 on tall_x3.hip
+static bool tall_x3_enabled() { const char* e = getenv("GLAM_TALL_X3"); return !e || atoi(e) != 0; }     // A/B switch of tall_x3.hip
 // GLAM_X3=0: the dense products stay on the fp32 matrix instructions (A/B switch, read per call)
 bool ts_x3_enabled() { const char* e = getenv("GLAM_X3"); return !e || atoi(e) != 0; }
 static bool ts_rb_big(int N) { return N >= 131072; }       // 12-wave blocks once the launch streams from HBM
@@ -635,6 +640,10 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     size_t lds = ts_image_floats(a.K1 + a.K2, a.M1 + a.M2) * sizeof(float);
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
+    // the long-reduction shapes on the bf16 matrix cores (tall_x3.hip); GLAM_X3=0 keeps the fp32 matrix instructions where they exist
+    if (variant == 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
+    if (variant == 2 && ts_x3_enabled() && tall_x3_wide_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
+        return launch_tall_x3(a, b, variant, s);
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else if (variant == 1 && !b && ts_rb_enabled() && a.K2 == 0 && !a.a_celu && !a.cgrad_src && !a.addend) {
         // the register-B form is the plain product only (one A source, no folded CELU, no gradient epilogue, fp32 out): its registers
@@ -647,7 +656,14 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
         } else if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
         else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 512>), dim3(two.first_b), dim3(512), 0, s, two);
     } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
-    else {
+    else if (variant == 2 && !b && ts_rb_enabled() && ts_x3_enabled() && a.K2 == 0 && !a.a_celu && !a.cgrad_src && !a.addend) {
+        // hid_dim_alpha = 6 (92 -> 276 + 8): three 32-k steps x four column tiles of W in 144 registers, five 64-column splits
+        const int ntiles = (a.N + 15) / 16;
+        int g = ((ntiles * 5 + 7) / 8 + 4) / 5 * 5;      // one item per wave; 8 g waves: a multiple of the 5 column splits
+        if (g > 255) g = 255;
+        GLAM_PROF_LABEL("k_ts_gemm<20, 6, 4>");
+        hipLaunchKernelGGL((k_ts_gemm_x3<512, 3, 5>), dim3(g), dim3(512), 0, s, a, g);
+    } else {
         static bool big2 = false;      // > 64 KB of dynamic LDS is opted into once
         if (!big2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ts_gemm<20, 6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -773,7 +773,11 @@ class _TripletLayerWide(torch.autograd.Function):
             torch.matmul(x_p, Wcat[:, HC:], out=a_ij)                      # separable attention scalars a_i | a_j
         check(lib.glam_triplet_fwd(ptr(xw), ptr(a_ij), ptr(ea_p), ptr(We_p), ptr(M), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
                                    N, gi.E, H, Cp, Dp, 1, float(slope), ptr(aggr), ptr(stats), st), "glam_triplet_fwd")
-        torch.addmm(bias_p, aggr, Ws_p, out=out)                           # layer.py:57-61 (276 -> 92: the library GEMM wins)
+        if _wide_tall_supported(H, Cp):      # layer.py:57-61, 276 -> 92: the long-reduction 3 x bf16 kernel (tall_x3.hip)
+            img2 = _scoped(scope.fwd if scope else None, ("wide-img-upd", id(wn)), wn, lambda: _ts_image(Ws_p, HC, Cp, False))
+            check(lib.glam_ts_gemm(ptr(aggr), HC, HC, None, 0, 0, ptr(img2), ptr(bias_p), ptr(out), Cp, Cp, None, 0, 0, N, st), "glam_ts_gemm")
+        else:
+            torch.addmm(bias_p, aggr, Ws_p, out=out)
         ctx.scope = scope
         ctx.save_for_backward(x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
@@ -815,8 +819,13 @@ class _TripletLayerWide(torch.autograd.Function):
                                    ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst), ptr(eid_t), N, E, H, Cp, Dp, 1,
                                    slope, ptr(d_xw), ptr(d_a), ptr(dstaged[o_we:]), ptr(dstaged[o_m:]), ptr(d_ea), ptr(ws),
                                    ws.numel(), stream()), "glam_triplet_bwd")
-        d_x = torch.matmul(d_xw, Wcat[:, :HC].t())
-        d_x.addmm_(d_a, Wcat[:, HC:].t())
+        if _wide_tall_supported(H, Cp):      # d_x = [d_xw | d_a] @ Wcat^T: both sources in one launch
+            img4 = _scoped(scope.bwd if scope else None, ("wide-img-dx", id(wn)), wn, lambda: _ts_image(Wcat, HC + 8, Cp, True))
+            d_x = torch.empty(N, Cp, **f)
+            check(lib.glam_ts_gemm(ptr(d_xw), HC, HC, ptr(d_a), 8, 8, ptr(img4), None, ptr(d_x), Cp, Cp, None, 0, 0, N, stream()), "glam_ts_gemm")
+        else:
+            d_x = torch.matmul(d_xw, Wcat[:, :HC].t())
+            d_x.addmm_(d_a, Wcat[:, HC:].t())
         wws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         # d_WsB = [aggr | 1]^T d_out ;  d_Wcat = x^T [d_xw | d_a], computed as ([d_xw | d_a]^T x)^T
         check(lib.glam_wgrad_gemm(ptr(aggr), HC, HC, None, 0, 0, 1, ptr(d_out), Cp, Cp, 0, N, ptr(dstaged[o_wsb:]), Cp, 1,
@@ -833,6 +842,11 @@ class _TripletLayerWide(torch.autograd.Function):
 
 def _wide_gemms_supported(H, Cp):
     return Cp <= 96 and H * Cp + 8 <= 320
+
+
+def _wide_tall_supported(H, Cp):
+    """The long-reduction products of the wide layer (H Cp (+ 8) -> Cp) inside tall_x3.hip's table (K <= 288, M <= 96)."""
+    return _wide_gemms_supported(H, Cp) and H * Cp + 8 <= 288
 
 
 def _ts_image(W, K, M, transposed):

@@ -251,6 +251,7 @@ class _LinearTall(torch.autograd.Function):
         require_device(x, w, b)
         x, w, b = f32c(x, "x"), f32c(w, "weight"), f32c(b, "bias")
         ctx.save_for_backward(x, w)
+        ctx.scope = _o._SCOPE
         N, K = x.shape
         M = w.size(0)
         if K <= 96 and M <= 320:       # the 120 KB-image k_ts_gemm variant (24 vs 29 us for 92 -> 276 at N = 20.7 k)
@@ -268,8 +269,15 @@ class _LinearTall(torch.autograd.Function):
         dy = f32c(dy, "dy")
         N, K = x.shape
         M = w.size(0)
-        dx = torch.matmul(dy, w) if ctx.needs_input_grad[0] else None
         lib = _lib.load()
+        dx = None
+        if ctx.needs_input_grad[0] and M <= 288 and K <= 96 and N > 0:      # dy[N, M] @ w[M, K], long reduction: tall_x3.hip
+            scope = ctx.scope
+            img = _o._scoped(scope.bwd if scope else None, ("lin-t", id(w)), w, lambda: _o._ts_image(w, M, K, False))
+            dx = torch.empty(N, K, dtype=torch.float32, device=x.device)
+            check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+        elif ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy, w)
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
         if K + 1 <= 64:
             # weight and bias gradients as separate contiguous tensors: autograd keeps them as they are (views of one [M, K + 1] buffer

@@ -77,6 +77,8 @@ def assert_fp32_parity(got, ref64, ref32, what="", k=8.0, out_tol=None):
     noise = (r32 - r64).abs().max().item()
     bound = k * max(noise, 4 * EPS32 * max(scale, 1.0))
     err = (g - r64).abs().max().item()
+    if os.environ.get("GLAM_PARITY_REPORT"):      # developer aid: every check's error against its bound (pytest -s)
+        print(f"[parity] {what}: err {err:.3e} bound {bound:.3e} ({err / bound:.2f})", flush=True)
     assert err <= bound, f"{what}: max|d| = {err:.3e} > {k:g} x fp64-twin noise floor = {bound:.3e} (noise {noise:.3e}, scale {scale:.3g})"
     if out_tol is not None:
         assert err <= out_tol * max(1.0, scale), f"{what}: max|d| = {err:.3e} > {out_tol:.0e} * max(1, {scale:.3g})"

@@ -295,7 +295,11 @@ def test_architecture_golden(device, name):
     assert_fp32_parity(out, o64.detach(), g.out, name + " (golden)", out_tol=1e-5)
     for n, t, r64 in zip(names, gs, g64):
         if r64 is not None:
-            assert_fp32_parity(t, r64, g.grads[n], f"{name}/grad.{n} (golden)")
+            # TripletMessageLight's attention vector gets its gradient through the separable form, d_att = W_node^T (x^T d_a): fp32
+            # rounding acts on |W_node|^T |x^T d_a| (tens), not on |d_att| (0.1) — 3-4e-6 absolute whatever the upstream rounding sample
+            # (measured with the fp32-MFMA and the 3 x bf16 input-gradient products alike); the reference sums d_logit * x_i directly
+            k = 16 if ("Light" in m["mol_block"] and n.endswith("weight_triplet_att")) else 8
+            assert_fp32_parity(t, r64, g.grads[n], f"{name}/grad.{n} (golden)", k=k)
     # three Adam steps exactly as TrainerMolRegression.train_iterations (trainer.py:286-298)
     net2 = model.Architecture(e_dim=m["e_dim"], out_dim=1, message_steps=m["message_steps"],
                               mol_block=m["mol_block"], mol_readout=m["mol_readout"], graph_norm=m.get("graph_norm", "_None"))
@@ -475,7 +479,10 @@ def test_full_size_pool5_checksum(big, device):
     (1, 180, 8, 60, 0, 1, False), (4099, 16, 0, 48, 8, 0, True), (17, 48, 8, 16, 0, 1, False), (0, 60, 0, 60, 0, 0, False),
     (5000, 64, 0, 184, 8, 0, True), (700, 188, 0, 64, 0, 0, False),
     # the 120 KB-image variant of the wide layers (K <= 96, M <= 320), and a launch with fewer items than wave slots
-    (20400, 92, 0, 276, 8, 0, False), (900, 92, 0, 276, 0, 1, True), (3, 96, 0, 320, 0, 0, True), (40000, 180, 0, 60, 0, 0, True)])
+    (20400, 92, 0, 276, 8, 0, False), (900, 92, 0, 276, 0, 1, True), (3, 96, 0, 320, 0, 0, True), (40000, 180, 0, 60, 0, 0, True),
+    # the long-reduction shapes beyond the fp32 table (K <= 288, M <= 96: tall_x3.hip, hid_dim_alpha = 6), both operand sources, ragged N
+    (20400, 276, 8, 92, 0, 1, False), (900, 276, 0, 92, 0, 0, True), (5, 288, 0, 96, 0, 0, True), (3001, 200, 0, 64, 0, 0, False),
+    (70000, 276, 8, 92, 0, 0, True), (20400, 180, 8, 60, 0, 1, True), (37, 100, 4, 8, 4, 0, True)])
 def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
@@ -2171,7 +2178,7 @@ def test_colsum_and_the_library_linear_node(device, N, D):
 
 
 @pytest.mark.parametrize("N", [105, 20400])
-@pytest.mark.parametrize("K,M", [(60, 180), (180, 60)])
+@pytest.mark.parametrize("K,M", [(60, 180), (180, 60), (276, 92)])
 def test_ts_gemm_pair_equals_two_launches(device, N, K, M):
     """Two products in one launch (the GRU's gate linears / their input gradients) are bit-identical to the two single launches, with every
     per-product option: CELU on the operand, bias, CELU' of a source on the output, an addend."""
