@@ -39,6 +39,16 @@ __device__ __forceinline__ Bf16x3 split8(float4 a, float4 b) {
     r.lo = __builtin_bit_cast(bf16x8_t, (u4){l[0], l[1], l[2], l[3]});
     return r;
 }
+// Rows k0 .. k0 + 7 of column position `pos` of a k_ts_gemm weight image (Kp rows in groups of four, MP positions per group; zero beyond
+// Kp).  The two loads are UNCONDITIONAL — a row group beyond the image re-reads the last one and is zeroed by w_split8 — so a prologue can
+// issue all of a wave's weight loads back to back and wait once: a load under a condition is waited for on the spot (one L2 round trip
+// per k step, in series).
+struct WRaw8 { float4 a, b; };
+__device__ __forceinline__ WRaw8 w_load8(const float* img, int MP, int pos, int k0, int Kp) {
+    const int g0 = min(k0, Kp - 4) >> 2, g1 = min(k0 + 4, Kp - 4) >> 2;
+    return WRaw8{ld4(img + ((size_t)g0 * MP + pos) * 4), ld4(img + ((size_t)g1 * MP + pos) * 4)};
+}
+
 #ifdef GLAM_X3_FAKE_WSPLIT      // timing experiment only (wrong numbers): what the prologue's weight splits cost
 __device__ __forceinline__ Bf16x3 split8w(float4 a, float4 b) {
     Bf16x3 r;
@@ -48,6 +58,10 @@ __device__ __forceinline__ Bf16x3 split8w(float4 a, float4 b) {
 #else
 __device__ __forceinline__ Bf16x3 split8w(float4 a, float4 b) { return split8(a, b); }
 #endif
+__device__ __forceinline__ Bf16x3 w_split8(const WRaw8& r, int k0, int Kp, bool ok = true) {
+    return split8w((ok && k0 < Kp) ? r.a : f4zero(), (ok && k0 + 4 < Kp) ? r.b : f4zero());
+}
+
 // acc += a * b over the 32 k of one step, small partial products first (they would lose their low bits against the large ones)
 __device__ __forceinline__ v4f_t mfma_x3_small(const Bf16x3& a, const Bf16x3& b, v4f_t acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.mid, acc, 0, 0, 0);

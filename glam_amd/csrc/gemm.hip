@@ -298,14 +298,17 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
     const int cs = gw % CS;
     // W slice of this wave: column tile t holds the logical columns cs * 64 + 4 c + t (image position cs * 64 + 16 t + c)
     Bf16x3 wreg[KS][4];
+    {
+        WRaw8 raw[KS][4];                                     // rows 32 s + 8 kb .. + 7 of the image (zero beyond K; the image ends at Kp)
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k0 = 32 * s + 8 * kb;                   // rows k0 .. k0 + 7 of the image (zero beyond K; the image ends at Kp)
-            const float* p = a.Wimg + ((size_t)(k0 >> 2) * MP + cs * 64 + 16 * t + c) * 4;
-            wreg[s][t] = split8w(k0 < Kp ? ld4(p) : f4zero(), k0 + 4 < Kp ? ld4(p + (size_t)MP * 4) : f4zero());
-        }
+            for (int t = 0; t < 4; ++t) raw[s][t] = w_load8(a.Wimg, MP, cs * 64 + 16 * t + c, 32 * s + 8 * kb, Kp);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wreg[s][t] = w_split8(raw[s][t], 32 * s + 8 * kb, Kp);
+    }
     auto load_a = [&](int tile, float4 (&af)[KS][2]) {
         const int row = tile * 16 + c;
         const bool rok = tile < ntiles && row < a.N;
@@ -319,6 +322,12 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
     };
     const int tstride = nblk * WPB / CS;                       // row tiles per step of this wave (the host makes the wave count a multiple of CS)
     int tile = gw / CS;
+    // the wave's four output columns never change: the bias is read ONCE, here.  Read inside the loop (under its condition) the compiler
+    // re-waited for it — vmcnt(0) — in each of the four row-store blocks, i.e. for the previous row's STORE: three store round trips
+    // per item in series (the launch ran at 3.7 us per item and wave)
+    const int m0 = cs * 64 + 4 * c;
+    float4 bias4 = f4zero();
+    if (a.bias && m0 < a.M1) bias4 = ld4(a.bias + m0);
     float4 af[KS][2];
     load_a(tile, af);
     for (; tile < ntiles; tile += tstride) {
@@ -344,10 +353,8 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_big(as[s], wreg[s][t], acc[t]);
         // C layout: tile column = lane & 15 (-> logical columns cs * 64 + 4 c + t), row = (lane >> 4) * 4 + i
-        const int m0 = cs * 64 + 4 * c;
         if (m0 < M) {
-            float4 b = f4zero();
-            if (a.bias && m0 < a.M1) b = ld4(a.bias + m0);
+            const float4 b = bias4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rr = tile * 16 + kb * 4 + i;

@@ -112,11 +112,12 @@ __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bia
     const int col = 16 * w + c;
     const int pos = (col & 3) * 16 + (col >> 2);              // position of logical column `col` in a k_ts_gemm image row
     Bf16x3 wreg[6];
+    {
+        WRaw8 raw[6];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int k0 = 32 * s + 8 * kb;
-        const float* p = img + ((size_t)(k0 >> 2) * 64 + pos) * 4;
-        wreg[s] = split8(k0 < Kp ? ld4(p) : f4zero(), k0 + 4 < Kp ? ld4(p + 64 * 4) : f4zero());
+        for (int s = 0; s < 6; ++s) raw[s] = w_load8(img, 64, pos, 32 * s + 8 * kb, Kp);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wreg[s] = w_split8(raw[s], 32 * s + 8 * kb, Kp);
     }
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
     const int nks = (K + 31) >> 5;                            // 32-k steps that hold data (<= 6)

@@ -95,16 +95,19 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             //      instructions on the SIMD's one fp32 datapath ----
             const int Kp = (Cp + 15) & ~15;
             Bf16x3 wreg[2][3];
+            {
+                WRaw8 raw[2][3];
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                const int mcol = 16 * (3 * w + ct) + c;
-                const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
+                for (int ct = 0; ct < 3; ++ct) {
+                    const int mcol = min(16 * (3 * w + ct) + c, MP - 1);
+                    const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const int k0 = 32 * st + 8 * kq;
-                    const float* p = a.img_dagg + ((size_t)(k0 >> 2) * MP + pos) * 4;
-                    wreg[st][ct] = split8((k0 < Kp && mcol < HC) ? ld4(p) : f4zero(), (k0 + 4 < Kp && mcol < HC) ? ld4(p + (size_t)MP * 4) : f4zero());
+                    for (int st = 0; st < 2; ++st) raw[st][ct] = w_load8(a.img_dagg, MP, pos, 32 * st + 8 * kq, Kp);
                 }
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) wreg[st][ct] = w_split8(raw[st][ct], 32 * st + 8 * kq, Kp, 16 * (3 * w + ct) + c < HC);
             }
             auto load_a = [&](int tile, float4 (&af)[2][2]) {
                 const int row = 16 * tile + c;
