@@ -738,7 +738,7 @@ class _TripletLayerWide(torch.autograd.Function):
     No per-parameter torch glue on either pass."""
 
     @staticmethod
-    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope):
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None):
         require_device(x_p, ea_p, wn, we, att, wsc, bias)
         x_p, ea_p = f32c(x_p, "x"), f32c(ea_p, "edge_attr")
         wn, we, att, wsc, bias = (f32c(t, n) for t, n in ((wn, "weight_node"), (we, "weight_edge"),
@@ -749,6 +749,9 @@ class _TripletLayerWide(torch.autograd.Function):
         HC = H * Cp
         if gi.N != N or ea_p.size(0) != gi.E or wn.shape != (C, H * C) or wsc.shape != (H * C, C) or Cp != (C + 3) // 4 * 4:
             raise GlamHipError("triplet_layer_wide: shape mismatch")
+        ctx.carried = carry is not None      # gradient carry of the block's parameters (see _ParamBundle)
+        if ctx.carried:
+            ctx.set_materialize_grads(False)
         lib, dev = _lib.load(), x_p.device
         f = dict(dtype=torch.float32, device=dev)
 
@@ -781,11 +784,13 @@ class _TripletLayerWide(torch.autograd.Function):
         ctx.scope = scope
         ctx.save_for_backward(x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
-        return out
+        return (out, carry.view(-1)) if ctx.carried else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, d_carry=None):
+        if d_out is None:                    # the layer's output was not used: only the carry (if any) passes through
+            return (None,) * 10 + (d_carry,)
         x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
@@ -795,6 +800,8 @@ class _TripletLayerWide(torch.autograd.Function):
         d_out = f32c(d_out, "d_out")
         if N == 0:        # an empty batch: every gradient is zero
             z = lambda t: torch.zeros_like(t)
+            if ctx.carried:
+                return (torch.zeros_like(x_p), torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None) + (None,) * 8 + (d_carry,)
             return (torch.zeros_like(x_p), torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None, z(wn), z(we), z(att),
                     torch.zeros(H * C, C, **f), torch.zeros(C, **f), None, None, None)
         Wcat, Ws_p, We_p, M, _ = _plain_views(plain, H, Cp, Dp)
@@ -837,6 +844,8 @@ class _TripletLayerWide(torch.autograd.Function):
         d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
         check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn), ptr(d_we),
                                                 ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()), "glam_triplet_stage_params_bwd")
+        if ctx.carried:       # one add of the flat buffer per application instead of five per-parameter accumulations
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
         return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
 
 
@@ -871,7 +880,17 @@ def wide_layer_supported(C, heads, De):
 
 
 def triplet_layer_wide(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
-    return _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+    params = (weight_node, weight_edge, att, weight_scale, bias)
+    C = weight_node.size(0)
+    sizes = [weight_node.numel(), weight_edge.numel(), att.numel(), heads * C * C, C]
+    shapes = (weight_node.shape, weight_edge.shape, att.shape, (heads * C, C), (C,))
+    key = ("carry-triplet-wide", id(weight_node))
+    carry = _carry_for(key, params, sum(sizes), lambda flat: [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)])
+    if carry is None:
+        return _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+    out, carry = _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry)
+    _carry_store(key, weight_node, carry)
+    return out
 
 
 # --------------------------------------------------------------------------------------
