@@ -61,6 +61,9 @@ SIGNATURES = {
     "glam_relation_mlp_bwd": (_i32, [_vp] * 3 + [_i32, _i32, _i64] + [_vp] * 5 + [_sz, _vp]),
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_supported": (_i32, [_i32]),
+    "glam_gru_ws_supported": (_i32, [_i32]),
+    "glam_gru_ws_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_vp]),
+    "glam_gru_ws_rng_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 7 + [_vp]),
     "glam_gru_fused_image_bytes": (_sz, []),
     "glam_gru_fused_make_images": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5),

@@ -4,6 +4,7 @@
 // gi = celu(x) @ W_ih^T + b_ih, gh = h @ W_hh^T + b_hh are [N, 3C] (gate order r | z | n, as torch stores them).
 #include "rng.h"
 #include "dense.h"
+#include "triplet_pipe.h"
 
 namespace glam {
 
@@ -523,6 +524,212 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
     if constexpr (RNG) rng_end(rg.state, ph);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same GRU step, warp-specialised and on the bf16 matrix cores in 3 x bf16 form (bf16x3.h: fp32 accuracy) — round 4.
+// k_gru_fused_fwd above is a latency chain at B = 1024: 96 KB of weight images staged per block, then 384 fp32 matrix instructions per
+// 16-row tile on the SIMD's one fp32 datapath (5.5 us per tile and wave, two waves per SIMD), then the epilogue: 22.6 us per application.
+// Here (the structure of k_tall_x3, tall_x3.hip) 4 producer waves load x and h rows three tiles ahead, split [celu(x) | h] into bf16
+// (hi, mid, lo) planes of an LDS tile ring — plus the fp32 h and identity rows the gate equations need — and 4 consumer waves, each bound to
+// 16 channels, keep the matching 6 x (16 x 64) slices of W_ih^T / W_hh^T (r, z, n of both products) split in 144 registers: 72
+// v_mfma_f32_16x16x32_bf16 per tile and wave, W as the first operand so that a lane ends up with r, z, n pre-activations of FOUR
+// CONSECUTIVE channels of one row — gates, residual, activation (+ RReLU / Dropout on the same Philox words as every other path) in
+// registers, float4 stores.  The weights come from the k_ts_gemm images of the gate matrices (K = C, M = 3C, 192 positions per row):
+// the ones the pair launch and the backward already use — no gate-padded images.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGwP = 4, kGwC = 4, kGwRing = 4, kGwD = 3;
+constexpr int kGwPitch = 416, kGwPlane = 16 * kGwPitch;                 // bf16 planes: 128 k of [celu(x) | h] per row (triplet_pipe.h: kX3RowBytes)
+constexpr int kGwEPitch = 272, kGwEPlane = 16 * kGwEPitch;              // fp32 planes (h, identity): 64 floats + 4 per row
+constexpr int kGwTile = 3 * kGwPlane + 2 * kGwEPlane;                   // 28 672 bytes
+constexpr int kGwHeader = 128 + 6 * 64 * 4;                             // flags | biases [ih, hh][gate][64]
+constexpr size_t kGwLds = kGwHeader + (size_t)kGwRing * kGwTile;
+
+template <bool RNG>
+__global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs a, TailRng rg) {
+    constexpr int P = kGwP, NC = kGwC, RING = kGwRing, D = kGwD, PITCH = kGwPitch, PLANE = kGwPlane, EPITCH = kGwEPitch, EPLANE = kGwEPlane,
+                  TILE = kGwTile, MP = 192;
+    extern __shared__ __attribute__((aligned(16))) char s_gw[];
+    int* s_ready = reinterpret_cast<int*>(s_gw);
+    int* s_taken = s_ready + 16;
+    float* s_bias = reinterpret_cast<float*>(s_gw + 128);
+    char* s_ring = s_gw + kGwHeader;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int C = a.C, ntiles = (a.N + 15) >> 4, bid = blockIdx.x, nblk = gridDim.x;
+    Philox ph{};
+    if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
+    if (tid < 32) s_ready[tid] = 0;
+    if (tid < 6 * 64) {
+        const int ch = tid & 63, g = (tid >> 6) % 3;
+        s_bias[tid] = ch < C ? (tid < 192 ? a.b_ih : a.b_hh)[g * C + ch] : 0.f;
+    }
+    __syncthreads();
+
+    if (wave < P) {
+        // ---- producers.  A chunk of the tile = (row r, q): q < 16 -> x[row, 4 q ..], q >= 16 -> h[row, 4 (q - 16) ..]; every load is
+        //      unconditional (chunks outside the matrices read x[0..3] and are zeroed when used): D tiles of loads in flight ----
+        auto chunk_ok = [&](int tile, int j) {
+            const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
+            return tile < ntiles && tile * 16 + r < a.N && 4 * (q & 15) < C;
+        };
+        const int er = (lane + 64 * wave) >> 4, eq = (lane + 64 * wave) & 15;      // identity rows: one chunk per lane
+        auto id_ok = [&](int tile) { return a.identity && tile < ntiles && tile * 16 + er < a.N && 4 * eq < C; };
+        auto load = [&](int tile, float4 (&v)[3]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
+                const size_t e = (size_t)(tile * 16 + r) * C + 4 * (q & 15);
+                v[j] = ld4(chunk_ok(tile, j) ? (q < 16 ? a.x : a.h) + e : a.x);
+            }
+            v[2] = ld4(id_ok(tile) ? a.identity + (size_t)(tile * 16 + er) * C + 4 * eq : a.x);
+        };
+        float4 buf[D][3];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
+        for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int it = it0 + d, tile = bid + it * nblk;
+                if (tile < ntiles) {
+                    const int slot = it % RING, round = it / RING;
+                    while (flag_load(s_taken + slot) < NC * round) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    char* tl = s_ring + slot * TILE;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
+                        float4 v = chunk_ok(tile, j) ? buf[d][j] : f4zero();
+                        if (q >= 16) *reinterpret_cast<float4*>(tl + 3 * PLANE + r * EPITCH + (q - 16) * 16) = v;      // h, exact
+                        else if (a.celu_in) v = celu4(v);
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split2(v.x, v.y, h0, m0, l0);
+                        split2(v.z, v.w, h1, m1, l1);
+                        char* p = tl + r * PITCH + q * 8;
+                        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
+                    }
+                    *reinterpret_cast<float4*>(tl + 3 * PLANE + EPLANE + er * EPITCH + eq * 16) = id_ok(tile) ? buf[d][2] : f4zero();
+                    load(tile + D * nblk, buf[d]);              // this register set's next tile, D tiles ahead
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) flag_bump(s_ready + slot);
+                }
+            }
+        }
+    } else {
+        // ---- consumers: wave w owns channels 16 w .. 16 w + 15; as an operand lane (c, kb) holds W column (channel) 16 w + c, k block kb;
+        //      as a result lane it holds data row c, channels 16 w + 4 kb .. + 3 ----
+        const int w = wave - P, c = lane & 15, kb = lane >> 4;
+        const int Kp = (C + 15) & ~15;
+        Bf16x3 wih[2][3], whh[2][3];
+        {
+            WRaw8 ri[2][3], rh[2][3];
+            int chw = 16 * w + c;
+            asm volatile("" : "+v"(chw));          // (keeps these loads on the consumers' side of the role branch)
+            const bool okw = chw < C;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int col = g * C + min(chw, C - 1);
+                const int pos = (col & ~63) + (col & 3) * 16 + ((col >> 2) & 15);      // ts_pos_of_col
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { ri[s][g] = w_load8(a.img_ih, MP, pos, 32 * s + 8 * kb, Kp); rh[s][g] = w_load8(a.img_hh, MP, pos, 32 * s + 8 * kb, Kp); }
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    wih[s][g] = w_split8(ri[s][g], 32 * s + 8 * kb, Kp, okw);
+                    whh[s][g] = w_split8(rh[s][g], 32 * s + 8 * kb, Kp, okw);
+                }
+        }
+        const int ch = 16 * w + 4 * kb;
+        int it = 0;
+        for (int tile = bid; tile < ntiles; tile += nblk, ++it) {
+            const int slot = it % RING, want = P * (it / RING + 1);
+            const int row = 16 * tile + c;
+            while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const char* tl = s_ring + slot * TILE + c * PITCH + kb * 16;       // row c, k = 32 s + 8 kb ..  (s = 0, 1: celu(x); 2, 3: h)
+            v4f_t ai[3], ah[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { ai[g] = (v4f_t){0.f, 0.f, 0.f, 0.f}; ah[g] = ai[g]; }
+            // three passes over the tile's fragments (re-read from LDS: 12 + 8 + 4 reads): small partial products of every k step first,
+            // then the middle ones, then hi x hi — six independent accumulator chains
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Bf16x3 x;
+                x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
+                x.mid = *reinterpret_cast<const bf16x8_t*>(tl + PLANE + 64 * s);
+                x.lo = *reinterpret_cast<const bf16x8_t*>(tl + 2 * PLANE + 64 * s);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (s < 2) ai[g] = mfma_x3_small(wih[s][g], x, ai[g]);
+                    else ah[g] = mfma_x3_small(whh[s - 2][g], x, ah[g]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Bf16x3 x;
+                x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
+                x.mid = *reinterpret_cast<const bf16x8_t*>(tl + PLANE + 64 * s);
+                x.lo = x.mid;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (s < 2) ai[g] = mfma_x3_mid(wih[s][g], x, ai[g]);
+                    else ah[g] = mfma_x3_mid(whh[s - 2][g], x, ah[g]);
+                }
+            }
+            const char* ep = s_ring + slot * TILE + 3 * PLANE + c * EPITCH + ch * 4;
+            const float4 hv = *reinterpret_cast<const float4*>(ep), idv = *reinterpret_cast<const float4*>(ep + EPLANE);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Bf16x3 x;
+                x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
+                x.mid = x.hi; x.lo = x.hi;
+                if (s == 3) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) flag_bump(s_taken + slot);      // every fragment is in registers: the slot may be refilled
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (s < 2) ai[g] = mfma_x3_big(wih[s][g], x, ai[g]);
+                    else ah[g] = mfma_x3_big(whh[s - 2][g], x, ah[g]);
+                }
+            }
+            if (row < a.N && ch < C) {
+                float4 gi4[3], gh4[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float4 bi = *reinterpret_cast<const float4*>(s_bias + g * 64 + ch), bh = *reinterpret_cast<const float4*>(s_bias + (3 + g) * 64 + ch);
+                    gi4[g] = make_float4(ai[g][0] + bi.x, ai[g][1] + bi.y, ai[g][2] + bi.z, ai[g][3] + bi.w);
+                    gh4[g] = make_float4(ah[g][0] + bh.x, ah[g][1] + bh.y, ah[g][2] + bh.z, ah[g][3] + bh.w);
+                    st4(a.gi + (size_t)row * 3 * C + g * C + ch, gi4[g]);
+                    st4(a.gh + (size_t)row * 3 * C + g * C + ch, gh4[g]);
+                }
+                const size_t e = (size_t)row * C + ch;
+                uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (RNG) w4 = philox4(ph, e >> 2);
+                float4 hn4, o4, od4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = sigmoidf_(f4get(gi4[0], j) + f4get(gh4[0], j));
+                    const float z = sigmoidf_(f4get(gi4[1], j) + f4get(gh4[1], j));
+                    const float nn = tanh_(f4get(gi4[2], j) + r * f4get(gh4[2], j));
+                    const float hn = (1.f - z) * nn + z * f4get(hv, j);
+                    const float y = a.identity ? hn + f4get(idv, j) : hn;
+                    const unsigned wd = philox_word(w4, j);
+                    const float o = (RNG && a.act == kActRRelu) ? (y > 0.f ? y : y * rrelu_slope_w(wd, rg.lo, rg.hi)) : act_fwd(y, a.act, a.slope);
+                    (&hn4.x)[j] = hn; (&o4.x)[j] = o;
+                    if constexpr (RNG) (&od4.x)[j] = o * drop_scale_w(wd, rg.p);
+                }
+                st4(a.h_new + e, hn4);
+                st4(a.out + e, o4);
+                if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
+            }
+        }
+    }
+    if constexpr (RNG) rng_end(rg.state, ph);
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -549,6 +756,55 @@ static int gru_fused_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_
     else hipLaunchKernelGGL(k_gru_fused_fwd<false>, dim3(grid), dim3(kGruBlock), lds, s, a, TailRng{});
     GLAM_LAUNCH_CHECK("glam_gru_fused_fwd");
     return GLAM_OK;
+}
+
+// the warp-specialised 3 x bf16 form: weights from the k_ts_gemm images of the gate matrices (K = C, M = 3 C with 64 < 3 C <= 192)
+extern "C" int glam_gru_ws_supported(int C) { return C >= 24 && C <= 64 && (C & 3) == 0; }
+
+static int gru_ws_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_t s) {
+    static bool big0[64] = {}, big1[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<false>), big0, "gru_ws_fwd")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<true>), big1, "gru_ws_fwd")) return rc;
+    const int ntiles = (a.N + 15) / 16, cap = ws_grid_cap(1024);
+    const int grid = ntiles < cap ? ntiles : cap;
+    if (rg) hipLaunchKernelGGL(k_gru_fwd_ws<true>, dim3(grid), dim3((kGwP + kGwC) * 64), kGwLds, s, a, *rg);
+    else hipLaunchKernelGGL(k_gru_fwd_ws<false>, dim3(grid), dim3((kGwP + kGwC) * 64), kGwLds, s, a, TailRng{});
+    GLAM_LAUNCH_CHECK("gru_ws_fwd");
+    return GLAM_OK;
+}
+
+static int gru_ws_args_ok(const char* fn, const GruFusedArgs& a, int64_t N) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
+    if (!glam_gru_ws_supported(a.C)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in 24..64", fn, a.C);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(a.x && a.h && a.img_ih && a.img_hh && a.b_ih && a.b_hh && a.gi && a.gh && a.h_new && a.out, "%s: null pointer", fn);
+    GLAM_REQUIRE(aligned16(a.x) && aligned16(a.h) && aligned16(a.identity) && aligned16(a.img_ih) && aligned16(a.img_hh) && aligned16(a.gi) &&
+                     aligned16(a.gh) && aligned16(a.h_new) && aligned16(a.out), "%s: pointers must be 16-byte aligned", fn);
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_ws_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                               const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi,
+                               float* gh, float* h_new, float* out, void* stream) {
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_ws_fwd: activation code %d", act);
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope};
+    if (int rc = gru_ws_args_ok("glam_gru_ws_fwd", a, N)) return rc;
+    if (N == 0) return GLAM_OK;
+    return gru_ws_launch(a, nullptr, (hipStream_t)stream);
+}
+
+static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+extern "C" int glam_gru_ws_rng_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                                   const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope,
+                                   float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi,
+                                   float* gh, float* h_new, float* out, float* out_drop, void* stream) {
+    if (int rc = rng_args_ok("glam_gru_ws_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope};
+    if (int rc = gru_ws_args_ok("glam_gru_ws_rng_fwd", a, N)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(rng_state && rng_eff && aligned16(out_drop), "glam_gru_ws_rng_fwd: null RNG state / misaligned out_drop");
+    const TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, 1};
+    return gru_ws_launch(a, &rg, (hipStream_t)stream);
 }
 
 extern "C" int glam_gru_fused_supported(int C) { return C >= 4 && C <= 64 && (C & 3) == 0; }

@@ -973,6 +973,10 @@ GEMM_PAIR = os.environ.get("GLAM_GEMM_PAIR", "1") == "1"     # A/B knob: the GRU
 # B = 32 0.384 vs 0.370 ms (the 96 KB of weight images per block dominate).  "auto": from GRU_FUSED_MIN_NODES nodes on.
 GRU_FUSED = os.environ.get("GLAM_GRU_FUSED", "auto")
 GRU_FUSED_MIN_NODES = 16384
+# The same step warp-specialised on the bf16 matrix cores in 3 x bf16 form (glam_gru_ws_fwd: fp32 accuracy, different roundings than the
+# fp32 launches above; 24 <= C <= 64): the default where it applies.
+GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
+GRU_WS_MIN_NODES = int(os.environ.get("GLAM_GRU_WS_MIN_NODES", "1"))
 
 
 # ---- the dense and readout operator families live in their own modules; their names are part of this namespace ----

@@ -555,6 +555,11 @@ def _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp):
     return _o.pad_group([(w_ih, *wsp), (w_hh, *wsp), (b_ih, *bsp), (b_hh, *bsp)])
 
 
+def _want_gru_ws(lib, N, C):
+    """The warp-specialised 3 x bf16 GRU step (GLAM_GRU_WS, default on; GLAM_X3=0 keeps every dense product on the fp32 matrix cores)."""
+    return N >= _o.GRU_WS_MIN_NODES and _o.GRU_WS == "1" and os.environ.get("GLAM_X3", "1") != "0" and lib.glam_gru_ws_supported(C) == 1
+
+
 def _want_gru_fused(N):
     return _o.GRU_FUSED in ("1", True) or (_o.GRU_FUSED == "auto" and N >= _o.GRU_FUSED_MIN_NODES)
 
@@ -610,7 +615,7 @@ class _GruBlock(torch.autograd.Function):
             if not (ha is not None and ha[0] is w_ih and hb is not None and hb[0] is w_hh):
                 nf, nb = lib.glam_ts_gemm_image_bytes(C, M) // 4, lib.glam_ts_gemm_image_bytes(M, C) // 4
                 ia, ib, ta, tb = torch.empty(nf, **f), torch.empty(nf, **f), torch.empty(nb, **f), torch.empty(nb, **f)
-                if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
+                if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C) and not _want_gru_ws(lib, N, C):
                     # ... and the two gate-padded images of the fused step: six re-layouts of the same two matrices, one launch
                     fused = torch.empty(2, lib.glam_gru_fused_image_bytes() // 4, **f)
                     check(lib.glam_gru_make_images(ptr(w_ih), ptr(w_hh), C, ptr(ia), ptr(ib), ptr(ta), ptr(tb), ptr(fused[0]), ptr(fused[1]),
@@ -630,7 +635,17 @@ class _GruBlock(torch.autograd.Function):
             eff = torch.empty(2, dtype=torch.int64, device=dev)
             out_drop = torch.empty_like(h) if p > 0 else None
         # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
-        if N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
+        if _want_gru_ws(lib, N, C):
+            # the warp-specialised 3 x bf16 form of the fused step (block.hip: k_gru_fwd_ws), on the gate matrices' plain k_ts_gemm images
+            img_a, img_b = image(w_ih), image(w_hh)
+            if rng is None:
+                check(lib.glam_gru_ws_fwd(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
+                                          int(celu_in), act, float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), st), "glam_gru_ws_fwd")
+            else:
+                check(lib.glam_gru_ws_rng_fwd(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
+                                              int(celu_in), act, float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
+                                              ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_ws_rng_fwd")
+        elif N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
             # both gate linears + gates + residual + activation (+ RReLU / Dropout) in ONE launch (bit-identical to the sequence below)
             def build_fused():
                 nb = lib.glam_gru_fused_image_bytes() // 4

@@ -503,6 +503,20 @@ int glam_gru_fused_rng_fwd(const float* x, const float* h, const float* identity
                            float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
                            float* out, float* out_drop, void* stream);
 
+/* The same step (src_1gp/layer.py:261-266) warp-specialised on the bf16 matrix cores in 3 x bf16 form: every fp32 operand split exactly
+ * into three bf16 terms, six partial products per product, fp32 accumulation — fp32 accuracy (measured: closer to the fp64 result than
+ * the fp32 matrix instructions), roundings differ from glam_gru_fused_fwd at the last bits; RReLU / Dropout use the same Philox words.
+ * img_ih / img_hh are the k_ts_gemm images of W_ih^T / W_hh^T (glam_ts_gemm_make_image(w, C, 1, C, 3 C, img): the ones glam_ts_gemm_pair
+ * takes).  C a multiple of 4 in 24 .. 64. */
+int glam_gru_ws_supported(int C);
+int glam_gru_ws_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                    const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
+                    float* h_new, float* out, void* stream);
+int glam_gru_ws_rng_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                        const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
+                        float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
+                        float* out, float* out_drop, void* stream);
+
 /* ---- narrow-output linear (the model's output head) -------------------------------------------------------------------
  * y[N, M] = x[N, K] @ w[M, K]^T + b for M <= 16, K % 4 == 0: replaces torch.nn.functional.linear / its autograd for
  * `lin_out1 = LinearBlock(e_dim, out_dim)` (reference src_1gp/model.py:47,61; layer.py:223-237), where a GEMM library spends

@@ -2204,10 +2204,69 @@ def test_ts_gemm_pair_equals_two_launches(device, N, K, M):
                                  p(o1), M, M, 0, p(img_other), None, p(torch.empty(N, K, device=device)), K, K, None, 0, None, 0, N, st()) != 0
 
 
+@pytest.mark.parametrize("C,train", [(60, False), (60, True), (32, False), (48, True), (24, True)])
+def test_warp_specialised_gru_forward_against_the_fp32_launches(device, monkeypatch, C, train):
+    """glam_gru_ws_fwd / _rng_fwd (the default GRU step: gate products in 3 x bf16 form, gates + residual + activation (+ RReLU / Dropout)
+    in the consumers' epilogue) against glam_ts_gemm_pair + glam_gru_tail_* on the fp32 matrix cores: the same Philox words (identical
+    Dropout masks), outputs and every gradient equal to rounding (the gradients run through the same backward kernels on gi / gh that
+    differ in their last bits)."""
+    b = synth_batch(40, seed=C).to(device)
+    blk = layer.MessageBlock(C, C, 4, norm="_None", dropout="Dropout(0.2)" if train else "_None()", conv="_TripletMessage",
+                             act="RReLU" if train else "CELU", res=True).to(device)
+    blk.train(train)
+    x0 = torch.randn(b.x.size(0), C, device=device)
+    assert ops._lib.load().glam_gru_ws_supported(C) == 1 and not ops._lib.load().glam_gru_ws_supported(20) and not ops._lib.load().glam_gru_ws_supported(68)
+    res = []
+    for ws in ("0", "1"):
+        monkeypatch.setattr(ops, "GRU_WS", ws)
+        monkeypatch.setattr(ops, "GRU_FUSED", "0")
+        ops.manual_seed(11, device)
+        x = x0.clone().requires_grad_(True)
+        with ops.weight_scope():
+            x1, h1 = blk(x, b.edge_index, b.edge_attr, h=None, batch=b.batch)
+            xd = layer._apply_dropout(blk.dropout, x1)            # the dropped twin the tail wrote (training mode)
+            x2, h2 = blk(x1, b.edge_index, b.edge_attr, h=h1, batch=b.batch)
+            gs = torch.autograd.grad((x2 * x2).sum() + h2.sum(), [x] + list(blk.parameters()))
+        res.append([x1, xd, x2, h2] + list(gs))
+    if train:
+        assert torch.equal(res[0][1] == 0, res[1][1] == 0), "same Philox words: the same Dropout mask"
+    for i, (a, c) in enumerate(zip(*res)):
+        assert_close(c, a, 1e-5 if i >= 4 else 2e-6, f"ws vs fp32 launches, tensor {i}")
+
+
+@pytest.mark.parametrize("N,C,ident,celu", [(1, 64, True, True), (1000, 64, False, False), (20400, 60, True, True), (17, 24, True, False), (0, 60, True, True)])
+def test_gru_ws_fwd_c_abi(device, N, C, ident, celu):
+    """glam_gru_ws_fwd called directly (widths up to 64, ragged and empty row counts, with / without residual and folded CELU) against the
+    fp64 gate equations of torch.nn.GRU (src_1gp/layer.py:261-266)."""
+    raw, p, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + C)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    x, h, idn, w_ih, w_hh, b_ih, b_hh = r(N, C), r(N, C), r(N, C), r(3 * C, C) * 0.3, r(3 * C, C) * 0.3, r(3 * C), r(3 * C)
+    nb = raw.glam_ts_gemm_image_bytes(C, 3 * C) // 4
+    ia, ib = torch.empty(nb, device=device), torch.empty(nb, device=device)
+    ops.check(raw.glam_ts_gemm_make_image(p(w_ih), C, 1, C, 3 * C, p(ia), st()), "image")
+    ops.check(raw.glam_ts_gemm_make_image(p(w_hh), C, 1, C, 3 * C, p(ib), st()), "image")
+    gi, gh = torch.full((N, 3 * C), float("nan"), device=device), torch.full((N, 3 * C), float("nan"), device=device)
+    hn, out = torch.full((N, C), float("nan"), device=device), torch.full((N, C), float("nan"), device=device)
+    ops.check(raw.glam_gru_ws_fwd(p(x), p(h), p(idn) if ident else None, p(ia), p(ib), p(b_ih), p(b_hh), N, C, int(celu), 1, 0.0,
+                                  p(gi), p(gh), p(hn), p(out), st()), "glam_gru_ws_fwd")
+    xd = torch.nn.functional.celu(x.double().cpu()) if celu else x.double().cpu()
+    gi_r = xd @ w_ih.double().cpu().t() + b_ih.double().cpu()
+    gh_r = h.double().cpu() @ w_hh.double().cpu().t() + b_hh.double().cpu()
+    rr, zz = torch.sigmoid(gi_r[:, :C] + gh_r[:, :C]), torch.sigmoid(gi_r[:, C:2 * C] + gh_r[:, C:2 * C])
+    nn_ = torch.tanh(gi_r[:, 2 * C:] + rr * gh_r[:, 2 * C:])
+    hn_r = (1 - zz) * nn_ + zz * h.double().cpu()
+    out_r = torch.relu(hn_r + (idn.double().cpu() if ident else 0))
+    for got, ref, what in ((gi, gi_r, "gi"), (gh, gh_r, "gh"), (hn, hn_r, "h_new"), (out, out_r, "out")):
+        assert_close(got, ref, 2e-6, f"gru_ws {what} N={N} C={C}")
+    assert raw.glam_gru_ws_fwd(p(x), p(h), None, p(ia), p(ib), p(b_ih), p(b_hh), N, 20, 0, 1, 0.0, p(gi), p(gh), p(hn), p(out), st()) != 0
+
+
 @pytest.mark.parametrize("C,train", [(60, False), (60, True), (32, False), (48, True)])
 def test_fused_gru_forward_is_bit_identical_to_the_two_launch_sequence(device, monkeypatch, C, train):
-    """Opt-in glam_gru_fused_fwd (gate GEMMs + gates + residual + activation (+ RReLU / Dropout) in one launch) against the default
+    """Opt-in glam_gru_fused_fwd (gate GEMMs + gates + residual + activation (+ RReLU / Dropout) in one launch) against
     glam_ts_gemm_pair + glam_gru_tail_*: same outputs, same gradients, same RNG stream."""
+    monkeypatch.setattr(ops, "GRU_WS", "0")
     b = synth_batch(24, seed=C).to(device)
     blk = layer.MessageBlock(C, C, 4, norm="_None", dropout="Dropout(0.2)" if train else "_None()", conv="_TripletMessage",
                              act="RReLU" if train else "CELU", res=True).to(device)
