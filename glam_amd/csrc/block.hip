@@ -730,6 +730,188 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
     if constexpr (RNG) rng_end(rg.state, ph);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the GRU step in ONE launch: the gate gradients (k_gru_tail_bwd) and both input-gradient products
+//   d_x = [d_pr | d_pz | d_pn] @ W_ih  (* celu'(x) with the folded CELU),   d_h = [d_pr | d_pz | d_pn r] @ W_hh + g z
+// As two launches the gate kernel wrote d_gi and d_gh (2 x [N, 3C]) and the product pair read them back: 16.5 + 18.1 us per application
+// at B = 1024.  Here 4 producer waves recompute the gates of a 16-row tile from gi / gh (two tiles of loads in flight), write d_gi, d_gh
+// (the weight-gradient launch needs them) and d_identity, and publish [d_pr | d_pz | d_pn | d_pn r] — the first two gate blocks are
+// shared by both products — as bf16 (hi, mid, lo) planes plus the fp32 rows celu'(x) and g z; 8 consumer waves (four 16-channel tiles
+// per product, their 6 x (16 x 32) weight slices split in 72 registers) take 36 v_mfma_f32_16x16x32_bf16 per tile each.
+// Same gate arithmetic and Philox words as k_gru_tail_bwd<RNG>; the products in 3 x bf16 form (bf16x3.h) like glam_ts_gemm_pair's.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGbP = 4, kGbC = 8, kGbRing = 3, kGbD = 2;
+constexpr int kGbPitch = 672, kGbPlane = 16 * kGbPitch;                 // 256 k per row: four gate blocks padded to 64 channels
+constexpr int kGbTile = 3 * kGbPlane + 2 * kGwEPlane;                   // 40 960 bytes
+constexpr size_t kGbLds = 128 + (size_t)kGbRing * kGbTile;
+
+struct GruBwdArgs {
+    const float* gi; const float* gh; const float* h; const float* out; const float* d_out; const float* d_hstate; const float* x;
+    const float* img_ih_t; const float* img_hh_t;      // k_ts_gemm images of W_ih / W_hh as [3C, C] (the input-gradient products)
+    float* d_gi; float* d_gh; float* d_identity; float* d_x; float* d_h;
+    int N, C, act, celu_in; float slope;
+};
+
+template <bool RNG>
+__global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a, TailRngB rg) {
+    constexpr int P = kGbP, NC = kGbC, RING = kGbRing, D = kGbD, PITCH = kGbPitch, PLANE = kGbPlane, EPITCH = kGwEPitch, EPLANE = kGwEPlane,
+                  TILE = kGbTile;
+    extern __shared__ __attribute__((aligned(16))) char s_gb[];
+    int* s_ready = reinterpret_cast<int*>(s_gb);
+    int* s_taken = s_ready + 16;
+    char* s_ring = s_gb + 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int C = a.C, ntiles = (a.N + 15) >> 4, bid = blockIdx.x, nblk = gridDim.x;
+    if (tid < 32) s_ready[tid] = 0;
+    __syncthreads();
+
+    if (wave < P) {
+        // ---- producers: lane -> (row er, channels 4 eq .. 4 eq + 3) of the tile; unconditional loads (items outside the matrices read
+        //      gi[0..3] and are zeroed), D tiles in flight ----
+        Philox ph{};
+        if constexpr (RNG) ph = philox_init(rg.eff);
+        const int er = (lane + 64 * wave) >> 4, eq = (lane + 64 * wave) & 15;
+        auto item_ok = [&](int tile) { return tile < ntiles && tile * 16 + er < a.N && 4 * eq < C; };
+        constexpr int NL = RNG ? 12 : 11;
+        auto load = [&](int tile, float4 (&v)[NL]) {
+            const bool ok = item_ok(tile);
+            const size_t i = ((size_t)(tile * 16 + er)) * C + 4 * eq, b = ((size_t)(tile * 16 + er)) * 3 * C + 4 * eq;
+            const float* z = a.gi;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { v[g] = ld4(ok ? a.gi + b + g * C : z); v[3 + g] = ld4(ok ? a.gh + b + g * C : z); }
+            v[6] = ld4(ok ? a.h + i : z);
+            v[7] = ld4(ok ? a.out + i : z);
+            v[8] = ld4((ok && a.d_out) ? a.d_out + i : z);
+            v[9] = ld4((ok && a.d_hstate) ? a.d_hstate + i : z);
+            v[10] = ld4((ok && a.celu_in) ? a.x + i : z);
+            if constexpr (RNG) v[11] = ld4((ok && rg.d_out_drop) ? rg.d_out_drop + i : z);
+        };
+        float4 buf[D][NL];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
+        for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int it = it0 + d, tile = bid + it * nblk;
+                if (tile < ntiles) {
+                    const bool ok = item_ok(tile);
+                    const float4 (&v)[NL] = buf[d];
+                    const size_t i = ((size_t)(tile * 16 + er)) * C + 4 * eq, b = ((size_t)(tile * 16 + er)) * 3 * C + 4 * eq;
+                    uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+                    if constexpr (RNG) w4 = philox4(ph, i >> 2);
+                    float4 dy4 = f4zero(), pr4 = f4zero(), pz4 = f4zero(), pn4 = f4zero(), pnr4 = f4zero(), gz4 = f4zero(), cf4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (ok) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float ov = f4get(v[7], j);
+                            float dy;
+                            if constexpr (RNG) {
+                                const unsigned wd = philox_word(w4, j);
+                                float g0 = a.d_out ? f4get(v[8], j) : 0.f;
+                                if (rg.d_out_drop) g0 = fmaf(f4get(v[11], j), drop_scale_w(wd, rg.p), g0);
+                                dy = g0 * (a.act == kActRRelu ? (ov > 0.f ? 1.f : rrelu_slope_w(wd, rg.lo, rg.hi)) : act_grad_from_out(ov, a.act, a.slope));
+                            } else {
+                                dy = f4get(v[8], j) * act_grad_from_out(ov, a.act, a.slope);
+                            }
+                            const float g = a.d_hstate ? dy + f4get(v[9], j) : dy;
+                            const float ghn = f4get(v[5], j);
+                            const float r = sigmoidf_(f4get(v[0], j) + f4get(v[3], j));
+                            const float z = sigmoidf_(f4get(v[1], j) + f4get(v[4], j));
+                            const float nn = tanh_(f4get(v[2], j) + r * ghn);
+                            const float d_n = g * (1.f - z), d_z = g * (f4get(v[6], j) - nn);
+                            const float d_pn = d_n * (1.f - nn * nn);
+                            (&dy4.x)[j] = dy;
+                            (&pr4.x)[j] = d_pn * ghn * r * (1.f - r);
+                            (&pz4.x)[j] = d_z * z * (1.f - z);
+                            (&pn4.x)[j] = d_pn;
+                            (&pnr4.x)[j] = d_pn * r;
+                            (&gz4.x)[j] = g * z;
+                            if (a.celu_in) (&cf4.x)[j] = celu1_grad(f4get(v[10], j));
+                        }
+                        if (a.d_identity) st4(a.d_identity + i, dy4);
+                        st4(a.d_gi + b, pr4); st4(a.d_gi + b + C, pz4); st4(a.d_gi + b + 2 * C, pn4);
+                        st4(a.d_gh + b, pr4); st4(a.d_gh + b + C, pz4); st4(a.d_gh + b + 2 * C, pnr4);
+                    }
+                    load(tile + D * nblk, buf[d]);              // (before the LDS wait: this register set's next tile, D tiles ahead)
+                    const int slot = it % RING, round = it / RING;
+                    while (flag_load(s_taken + slot) < NC * round) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    char* tl = s_ring + slot * TILE;
+                    const float4 parts[4] = {pr4, pz4, pn4, pnr4};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split2(parts[q].x, parts[q].y, h0, m0, l0);
+                        split2(parts[q].z, parts[q].w, h1, m1, l1);
+                        char* p = tl + er * PITCH + q * 128 + eq * 8;
+                        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
+                    }
+                    *reinterpret_cast<float4*>(tl + 3 * PLANE + er * EPITCH + eq * 16) = cf4;
+                    *reinterpret_cast<float4*>(tl + 3 * PLANE + EPLANE + er * EPITCH + eq * 16) = gz4;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) flag_bump(s_ready + slot);
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- consumers: wave w -> product w >> 2 (0: d_x over W_ih, 1: d_h over W_hh), output channels 16 (w & 3) .. + 15 ----
+    const int w = wave - P, prod = w >> 2, ct = w & 3, c = lane & 15, kb = lane >> 4;
+    const float* img = prod ? a.img_hh_t : a.img_ih_t;
+    const int Kp = (3 * C + 15) & ~15;
+    Bf16x3 wreg[6];
+    {
+        WRaw8 raw[6];
+        int col = 16 * ct + c;
+        asm volatile("" : "+v"(col));              // (keeps these loads on the consumers' side of the role branch)
+        const bool okc = col < C;
+        const int cc = min(col, C - 1), pos = (cc & 3) * 16 + (cc >> 2);       // ts_pos_of_col within the 64 positions of a row
+#pragma unroll
+        for (int s = 0; s < 6; ++s) raw[s] = w_load8(img, 64, pos, (s >> 1) * C + 32 * (s & 1) + 8 * kb, Kp);     // rows gate * C + channel
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int ch0 = 32 * (s & 1) + 8 * kb;                                // (a gate's rows end at channel C: the next gate's follow)
+            wreg[s] = split8((okc && ch0 < C) ? raw[s].a : f4zero(), (okc && ch0 + 4 < C) ? raw[s].b : f4zero());
+        }
+    }
+    const int ch = 16 * ct + 4 * kb;
+    float* const outp = prod ? a.d_h : a.d_x;
+    int it = 0;
+    for (int tile = bid; tile < ntiles; tile += nblk, ++it) {
+        const int slot = it % RING, want = P * (it / RING + 1);
+        const int row = 16 * tile + c;
+        while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const char* tl = s_ring + slot * TILE + c * PITCH + kb * 16;
+        v4f_t acc_s = {0.f, 0.f, 0.f, 0.f}, acc_m = acc_s, acc_b = acc_s;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int ls = ((prod && s >= 4) ? 6 : 2 * (s >> 1)) + (s & 1);      // d_h reads d_pn r (block 3) where d_x reads d_pn (block 2)
+            Bf16x3 x;
+            x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * ls);
+            x.mid = *reinterpret_cast<const bf16x8_t*>(tl + PLANE + 64 * ls);
+            x.lo = *reinterpret_cast<const bf16x8_t*>(tl + 2 * PLANE + 64 * ls);
+            acc_s = mfma_x3_small(wreg[s], x, acc_s);
+            acc_m = mfma_x3_mid(wreg[s], x, acc_m);
+            acc_b = mfma_x3_big(wreg[s], x, acc_b);
+        }
+        const float4 e4 = *reinterpret_cast<const float4*>(s_ring + slot * TILE + 3 * PLANE + prod * EPLANE + c * EPITCH + ch * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flag_bump(s_taken + slot);
+        if (row < a.N && ch < C) {
+            float4 v = make_float4((acc_s[0] + acc_m[0]) + acc_b[0], (acc_s[1] + acc_m[1]) + acc_b[1], (acc_s[2] + acc_m[2]) + acc_b[2],
+                                   (acc_s[3] + acc_m[3]) + acc_b[3]);
+            if (prod) { v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w; }
+            else { v.x *= e4.x; v.y *= e4.y; v.z *= e4.z; v.w *= e4.w; }      // celu'(x), or 1
+            st4(outp + (size_t)row * C + ch, v);
+        }
+    }
+}
+
 }  // namespace glam
 
 using namespace glam;
@@ -756,6 +938,54 @@ static int gru_fused_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_
     else hipLaunchKernelGGL(k_gru_fused_fwd<false>, dim3(grid), dim3(kGruBlock), lds, s, a, TailRng{});
     GLAM_LAUNCH_CHECK("glam_gru_fused_fwd");
     return GLAM_OK;
+}
+
+static int gru_bwd_ws_launch(const GruBwdArgs& a, const TailRngB* rg, hipStream_t s) {
+    static bool big0[64] = {}, big1[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<false>), big0, "gru_bwd_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<true>), big1, "gru_bwd_ws")) return rc;
+    const int ntiles = (a.N + 15) / 16, cap = ws_grid_cap(1024);
+    const int grid = ntiles < cap ? ntiles : cap;
+    if (rg) hipLaunchKernelGGL(k_gru_bwd_ws<true>, dim3(grid), dim3((kGbP + kGbC) * 64), kGbLds, s, a, *rg);
+    else hipLaunchKernelGGL(k_gru_bwd_ws<false>, dim3(grid), dim3((kGbP + kGbC) * 64), kGbLds, s, a, TailRngB{});
+    GLAM_LAUNCH_CHECK("gru_bwd_ws");
+    return GLAM_OK;
+}
+
+static int gru_bwd_ws_args_ok(const char* fn, const GruBwdArgs& a, int64_t N, const float* d_out_drop) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
+    if (!(a.C >= 24 && a.C <= 64 && (a.C & 3) == 0)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in 24..64", fn, a.C);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(a.gi && a.gh && a.h && a.out && (a.d_out || d_out_drop) && a.img_ih_t && a.img_hh_t && a.d_gi && a.d_gh && a.d_x && a.d_h &&
+                     (!a.celu_in || a.x), "%s: null pointer", fn);
+    GLAM_REQUIRE(aligned16(a.gi) && aligned16(a.gh) && aligned16(a.h) && aligned16(a.out) && aligned16(a.d_out) && aligned16(a.d_hstate) && aligned16(a.x) &&
+                     aligned16(a.img_ih_t) && aligned16(a.img_hh_t) && aligned16(a.d_gi) && aligned16(a.d_gh) && aligned16(a.d_identity) &&
+                     aligned16(a.d_x) && aligned16(a.d_h) && aligned16(d_out_drop), "%s: pointers must be 16-byte aligned", fn);
+    return GLAM_OK;
+}
+
+extern "C" int glam_gru_bwd_ws(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
+                               const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C, int celu_in, int act, float slope,
+                               float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_bwd_ws: activation code %d", act);
+    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope};
+    if (int rc = gru_bwd_ws_args_ok("glam_gru_bwd_ws", a, N, nullptr)) return rc;
+    if (N == 0) return GLAM_OK;
+    return gru_bwd_ws_launch(a, nullptr, (hipStream_t)stream);
+}
+
+static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+extern "C" int glam_gru_bwd_ws_rng(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_out_drop,
+                                   const float* d_hstate, const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C,
+                                   int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
+                                   float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
+    if (int rc = rng_args_ok("glam_gru_bwd_ws_rng", act, rr_lower, rr_upper, drop_p)) return rc;
+    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope};
+    if (int rc = gru_bwd_ws_args_ok("glam_gru_bwd_ws_rng", a, N, d_out_drop)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(rng_eff, "glam_gru_bwd_ws_rng: null rng_eff");
+    const TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, 1};
+    return gru_bwd_ws_launch(a, &rg, (hipStream_t)stream);
 }
 
 // the warp-specialised 3 x bf16 form: weights from the k_ts_gemm images of the gate matrices (K = C, M = 3 C with 64 < 3 C <= 192)

@@ -699,7 +699,33 @@ class _GruBlock(torch.autograd.Function):
         d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
         d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
         d_id = torch.empty_like(h) if has_res else None
-        if rng is None:
+        scope = ctx.scope
+
+        def image_t(w):
+            def build():
+                img = torch.empty(lib.glam_ts_gemm_image_bytes(M, C) // 4, **f)
+                check(lib.glam_ts_gemm_make_image(ptr(w), C, 0, M, C, ptr(img), stream()), "glam_ts_gemm_make_image")
+                return img
+            return _o._scoped(scope.bwd if scope else None, ("lin", id(w)), w, build)
+
+        ws = _want_gru_ws(lib, N, C)
+        if ws:
+            # gate gradients + both input-gradient products in ONE launch (block.hip: k_gru_bwd_ws); d_h comes out complete
+            dx = torch.empty(N, C, **f)
+            img_a, img_b = image_t(w_ih), image_t(w_hh)
+            if rng is None:
+                if d_out is None:
+                    d_out = torch.zeros_like(h)
+                check(lib.glam_gru_bwd_ws(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), ptr(x), ptr(img_a), ptr(img_b), N, C,
+                                          int(celu_in), act, slope, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws")
+            else:
+                if d_out is None and d_out_drop is None:
+                    d_out = torch.zeros_like(h)
+                check(lib.glam_gru_bwd_ws_rng(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), ptr(x), ptr(img_a),
+                                              ptr(img_b), N, C, int(celu_in), act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), ptr(d_gi), ptr(d_gh),
+                                              ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng")
+            dh = d_h
+        elif rng is None:
             if d_out is None:
                 d_out = torch.zeros_like(h)
             check(lib.glam_gru_tail_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), N, C, act, slope, ptr(d_gi),
@@ -710,24 +736,18 @@ class _GruBlock(torch.autograd.Function):
             check(lib.glam_gru_tail_rng_bwd(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), N, C, act, slope,
                                             rng[0], rng[1], rng[2], ptr(ctx.eff), ptr(d_gi), ptr(d_gh), ptr(d_h), ptr(d_id), st),
                   "glam_gru_tail_rng_bwd")
-        scope = ctx.scope
-
-        def image_t(w):
-            def build():
-                img = torch.empty(lib.glam_ts_gemm_image_bytes(M, C) // 4, **f)
-                check(lib.glam_ts_gemm_make_image(ptr(w), C, 0, M, C, ptr(img), stream()), "glam_ts_gemm_make_image")
-                return img
-            return _o._scoped(scope.bwd if scope else None, ("lin", id(w)), w, build)
-
-        dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
-        # with the folded CELU the epilogue multiplies by celu'(x): dx is the gradient of the RAW input
-        # d_h = d_gh @ W_hh^T + the direct z * g path of the gate equations (the addend of the GEMM's epilogue); both products in one launch
-        if _o.GEMM_PAIR:
+        if ws:
+            pass
+        elif _o.GEMM_PAIR:
+            dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
+            # with the folded CELU the epilogue multiplies by celu'(x): dx is the gradient of the RAW input
+            # d_h = d_gh @ W_hh^T + the direct z * g path of the gate equations (the addend of the GEMM's epilogue); both products in one launch
             img_a, img_b = image_t(w_ih), image_t(w_hh)
             check(lib.glam_ts_gemm_pair(ptr(d_gi), M, M, 0, ptr(img_a), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, None, 0,
                                         ptr(d_gh), M, M, 0, ptr(img_b), None, ptr(dh), C, C, None, 0, ptr(d_h), C, N, st),
                   "glam_ts_gemm_pair")
         else:
+            dx, dh = torch.empty(N, C, **f), torch.empty(N, C, **f)
             check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
                   "glam_ts_gemm_celu")
             check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")

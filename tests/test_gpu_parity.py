@@ -3,6 +3,8 @@ from the reference, (2) the CPU oracle on fresh seeds, (3) size-independent prop
 BASELINE.json batch size.  fp32 tolerance: 1e-5 (scaled by max(1,|ref|)) as BASELINE.json states;
 gradients 2e-5..5e-5 where several layers stack."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -2260,6 +2262,42 @@ def test_gru_ws_fwd_c_abi(device, N, C, ident, celu):
     for got, ref, what in ((gi, gi_r, "gi"), (gh, gh_r, "gh"), (hn, hn_r, "h_new"), (out, out_r, "out")):
         assert_close(got, ref, 2e-6, f"gru_ws {what} N={N} C={C}")
     assert raw.glam_gru_ws_fwd(p(x), p(h), None, p(ia), p(ib), p(b_ih), p(b_hh), N, 20, 0, 1, 0.0, p(gi), p(gh), p(hn), p(out), st()) != 0
+
+
+@pytest.mark.parametrize("N,C,celu,hstate,ident", [(1, 64, True, True, True), (1000, 64, False, False, False), (20400, 60, True, True, True),
+                                                   (17, 24, False, True, True), (0, 60, True, True, True)])
+def test_gru_bwd_ws_c_abi(device, N, C, celu, hstate, ident):
+    """glam_gru_bwd_ws (gate gradients + both input-gradient products in one launch) against glam_gru_tail_bwd + glam_ts_gemm_pair on the
+    fp32 matrix cores: d_gi, d_gh, d_identity bit for bit (the same gate arithmetic), d_x and the complete d_h to rounding."""
+    raw, p, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + C + 1)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    M = 3 * C
+    gi, gh, h, out, d_out, d_hs, x, w_ih, w_hh = r(N, M), r(N, M), r(N, C), r(N, C), r(N, C), r(N, C), r(N, C), r(M, C) * 0.3, r(M, C) * 0.3
+    nb = raw.glam_ts_gemm_image_bytes(M, C) // 4
+    ta, tb = torch.empty(nb, device=device), torch.empty(nb, device=device)
+    ops.check(raw.glam_ts_gemm_make_image(p(w_ih), C, 0, M, C, p(ta), st()), "image")
+    ops.check(raw.glam_ts_gemm_make_image(p(w_hh), C, 0, M, C, p(tb), st()), "image")
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    # reference: the two-launch sequence with the products on the fp32 matrix cores
+    dgi0, dgh0, dh0, did0, dx0, dhf0 = f(N, M), f(N, M), f(N, C), f(N, C), f(N, C), f(N, C)
+    os.environ["GLAM_TALL_X3"] = "0"
+    try:
+        ops.check(raw.glam_gru_tail_bwd(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs) if hstate else None, N, C, 1, 0.0, p(dgi0), p(dgh0), p(dh0),
+                                        p(did0) if ident else None, st()), "tail_bwd")
+        ops.check(raw.glam_ts_gemm_pair(p(dgi0), M, M, 0, p(ta), None, p(dx0), C, C, p(x) if celu else None, C, None, 0,
+                                        p(dgh0), M, M, 0, p(tb), None, p(dhf0), C, C, None, 0, p(dh0), C, N, st()), "pair")
+    finally:
+        del os.environ["GLAM_TALL_X3"]
+    dgi, dgh, did, dx, dh = f(N, M), f(N, M), f(N, C), f(N, C), f(N, C)
+    ops.check(raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs) if hstate else None, p(x), p(ta), p(tb), N, C, int(celu), 1, 0.0,
+                                  p(dgi), p(dgh), p(did) if ident else None, p(dx), p(dh), st()), "glam_gru_bwd_ws")
+    assert torch.equal(dgi, dgi0) and torch.equal(dgh, dgh0) and (not ident or torch.equal(did, did0))
+    assert_close(dx, dx0, 2e-6, "d_x")
+    assert_close(dh, dhf0, 2e-6, "d_h")
+    assert raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), None, p(x), p(ta), p(tb), N, 20, 0, 1, 0.0, p(dgi), p(dgh), None, p(dx), p(dh), st()) != 0
+    if N:
+        assert raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), None, None, p(x), p(ta), p(tb), N, C, 0, 1, 0.0, p(dgi), p(dgh), None, p(dx), p(dh), st()) != 0
 
 
 @pytest.mark.parametrize("C,train", [(60, False), (60, True), (32, False), (48, True)])
