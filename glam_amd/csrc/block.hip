@@ -653,47 +653,53 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
 #pragma unroll
             for (int g = 0; g < 3; ++g) { ai[g] = (v4f_t){0.f, 0.f, 0.f, 0.f}; ah[g] = ai[g]; }
             // three passes over the tile's fragments (re-read from LDS: 12 + 8 + 4 reads): small partial products of every k step first,
-            // then the middle ones, then hi x hi — six independent accumulator chains
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            // then the middle ones, then hi x hi — six independent accumulator chains.  The reads run ONE k step ahead of the matrix
+            // instructions (a consumer is alone on its SIMD's matrix pipe: an LDS round trip per step would be exposed each time)
+            auto rd = [&](int s, int terms) {
                 Bf16x3 x;
                 x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
-                x.mid = *reinterpret_cast<const bf16x8_t*>(tl + PLANE + 64 * s);
-                x.lo = *reinterpret_cast<const bf16x8_t*>(tl + 2 * PLANE + 64 * s);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    if (s < 2) ai[g] = mfma_x3_small(wih[s][g], x, ai[g]);
-                    else ah[g] = mfma_x3_small(whh[s - 2][g], x, ah[g]);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                Bf16x3 x;
-                x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
-                x.mid = *reinterpret_cast<const bf16x8_t*>(tl + PLANE + 64 * s);
-                x.lo = x.mid;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    if (s < 2) ai[g] = mfma_x3_mid(wih[s][g], x, ai[g]);
-                    else ah[g] = mfma_x3_mid(whh[s - 2][g], x, ah[g]);
-                }
-            }
+                x.mid = terms > 1 ? *reinterpret_cast<const bf16x8_t*>(tl + PLANE + 64 * s) : x.hi;
+                x.lo = terms > 2 ? *reinterpret_cast<const bf16x8_t*>(tl + 2 * PLANE + 64 * s) : x.mid;
+                return x;
+            };
             const char* ep = s_ring + slot * TILE + 3 * PLANE + c * EPITCH + ch * 4;
-            const float4 hv = *reinterpret_cast<const float4*>(ep), idv = *reinterpret_cast<const float4*>(ep + EPLANE);
+            Bf16x3 xa = rd(0, 3);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                Bf16x3 x;
-                x.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
-                x.mid = x.hi; x.lo = x.hi;
-                if (s == 3) {
+                const Bf16x3 xb = s < 3 ? rd(s + 1, 3) : rd(0, 2);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (s < 2) ai[g] = mfma_x3_small(wih[s][g], xa, ai[g]);
+                    else ah[g] = mfma_x3_small(whh[s - 2][g], xa, ah[g]);
+                }
+                xa = xb;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const Bf16x3 xb = s < 3 ? rd(s + 1, 2) : rd(0, 1);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (s < 2) ai[g] = mfma_x3_mid(wih[s][g], xa, ai[g]);
+                    else ah[g] = mfma_x3_mid(whh[s - 2][g], xa, ah[g]);
+                }
+                xa = xb;
+            }
+            float4 hv = f4zero(), idv = f4zero();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Bf16x3 xb = xa;
+                if (s < 3) xb = rd(s + 1, 1);
+                else {
+                    hv = *reinterpret_cast<const float4*>(ep); idv = *reinterpret_cast<const float4*>(ep + EPLANE);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) flag_bump(s_taken + slot);      // every fragment is in registers: the slot may be refilled
                 }
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    if (s < 2) ai[g] = mfma_x3_big(wih[s][g], x, ai[g]);
-                    else ah[g] = mfma_x3_big(whh[s - 2][g], x, ah[g]);
+                    if (s < 2) ai[g] = mfma_x3_big(wih[s][g], xa, ai[g]);
+                    else ah[g] = mfma_x3_big(whh[s - 2][g], xa, ah[g]);
                 }
+                xa = xb;
             }
             if (row < a.N && ch < C) {
                 float4 gi4[3], gh4[3];
