@@ -619,7 +619,6 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
 }
 // the register-B form of the 192-column variant: one block per CU
 static bool ts_rb_enabled() { const char* e = getenv("GLAM_TS_RB"); return !e || atoi(e) != 0; }
-static bool tall_x3_wide_enabled() { const char* e = getenv("GLAM_TALL_WIDE"); return !e || atoi(e) != 0; }   // A/B: 96 -> 320 on tall_x3.hip
 static bool tall_x3_enabled() { const char* e = getenv("GLAM_TALL_X3"); return !e || atoi(e) != 0; }     // A/B switch of tall_x3.hip
 // GLAM_X3=0: the dense products stay on the fp32 matrix instructions (A/B switch, read per call)
 bool ts_x3_enabled() { const char* e = getenv("GLAM_X3"); return !e || atoi(e) != 0; }
@@ -649,7 +648,7 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     const int grid = grid_a + grid_b;
     // the long-reduction shapes on the bf16 matrix cores (tall_x3.hip); GLAM_X3=0 keeps the fp32 matrix instructions where they exist
     if (variant == 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
-    if (variant == 2 && ts_x3_enabled() && tall_x3_wide_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
+    if (variant == 2 && ts_x3_enabled() && tall_x3_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
         return launch_tall_x3(a, b, variant, s);
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
     else if (variant == 1 && !b && ts_rb_enabled() && a.K2 == 0 && !a.a_celu && !a.cgrad_src && !a.addend) {

@@ -257,10 +257,7 @@ static int launch_tall(const TallArgs2& two, int grid, hipStream_t s) {
 //   0: K <= 192, M <= 64  (MP 64)     3: K <= 288, M <= 96 (MP 128)     2: K <= 96, M <= 320 (MP 320), plain epilogue only
 int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s) {
     const int ntiles = (a.N + 15) / 16;
-    const char* e = getenv("GLAM_TALL_GRID");                  // developer knob: blocks per product
-    int cap = e ? atoi(e) : 256;
-    if (cap < 1 || cap > 1024) cap = 256;
-    const int g = ntiles < cap ? ntiles : cap;
+    const int g = ntiles < 256 ? ntiles : 256;                 // one block per CU and product
     TallArgs2 two{a, b ? *b : a, g};
     const int grid = b ? 2 * g : g;
     const bool epi = a.cgrad_src || a.addend || (b && (b->cgrad_src || b->addend));

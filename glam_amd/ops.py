@@ -976,7 +976,6 @@ GRU_FUSED_MIN_NODES = 16384
 # The same step warp-specialised on the bf16 matrix cores in 3 x bf16 form (glam_gru_ws_fwd: fp32 accuracy, different roundings than the
 # fp32 launches above; 24 <= C <= 64): the default where it applies.
 GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
-GRU_WS_MIN_NODES = int(os.environ.get("GLAM_GRU_WS_MIN_NODES", "1"))
 
 
 # ---- the dense and readout operator families live in their own modules; their names are part of this namespace ----

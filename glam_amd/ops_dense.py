@@ -557,7 +557,7 @@ def _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp):
 
 def _want_gru_ws(lib, N, C):
     """The warp-specialised 3 x bf16 GRU step (GLAM_GRU_WS, default on; GLAM_X3=0 keeps every dense product on the fp32 matrix cores)."""
-    return N >= _o.GRU_WS_MIN_NODES and _o.GRU_WS == "1" and os.environ.get("GLAM_X3", "1") != "0" and lib.glam_gru_ws_supported(C) == 1
+    return N > 0 and _o.GRU_WS == "1" and os.environ.get("GLAM_X3", "1") != "0" and lib.glam_gru_ws_supported(C) == 1
 
 
 def _want_gru_fused(N):
