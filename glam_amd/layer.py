@@ -204,9 +204,36 @@ class TripletMessage(MessagePassing):
         alpha = softmax(F.leaky_relu(logit, self.negative_slope), edge_index_i, ptr=None, num_nodes=size_i)
         return alpha.unsqueeze(-1) * e * xj
 
+    def _head_groups(self, x, edge_index, edge_attr):
+        """``heads > 4`` (the kernels keep at most four heads of a node in a lane group): the layer is a SUM over head groups — every
+        head contributes ``aggr_h @ W_scale[h]`` to the update (layer.py:57-61) and nothing else couples heads — so it runs as
+        ceil(heads / g) layers of g <= 4 heads on slices of the parameters, the bias added by the first."""
+        H, C, De = self.heads, self.node_channels, self.edge_channels
+        g = next((k for k in (4, 3, 2, 1) if ops.fused_layer_supported(C, k, De) or ops.wide_layer_supported(C, k, De)), 0)
+        if g == 0:
+            raise GlamHipError(f"TripletMessage({C}, {De}, heads={H}): width outside the compiled kernel table")
+        gi = ops.graph_index(edge_index, x.size(0))
+        Cp, Dp = _ceil4(C), _pad_de(De)
+        if Dp != edge_attr.size(1):
+            edge_attr = F.pad(edge_attr, (0, Dp - edge_attr.size(1)))
+        x_p = ops.pad_cols(x, Cp)
+        out = None
+        for h0 in range(0, H, g):
+            h1 = min(h0 + g, H)
+            k = h1 - h0
+            wn = self.weight_node.view(C, H, C)[:, h0:h1].reshape(C, k * C).contiguous()
+            we = self.weight_edge.view(De, H, C)[:, h0:h1].reshape(De, k * C).contiguous()
+            att = self.weight_triplet_att[:, h0:h1].contiguous()
+            ws = self.weight_scale.view(H, C, C)[h0:h1].reshape(k * C, C).contiguous()
+            bias = self.bias if h0 == 0 else torch.zeros_like(self.bias)
+            layer_fn = ops.triplet_layer if ops.fused_layer_supported(C, k, De) else ops.triplet_layer_wide
+            o = layer_fn(x_p, edge_attr, wn, we, att, ws, bias, gi, k, self.negative_slope)
+            out = o if out is None else out + o
+        return ops.slice_cols(out, C)
+
     def _fused(self, x, edge_index, edge_attr):
         if self.heads > 4:
-            raise GlamHipError("heads > 4 is outside the compiled kernel table")
+            return self._head_groups(x, edge_index, edge_attr)
         gi = ops.graph_index(edge_index, x.size(0))
         C, De = self.node_channels, self.edge_channels
         Cp, Dp = _ceil4(C), _pad_de(De)

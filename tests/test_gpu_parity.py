@@ -1198,6 +1198,29 @@ def test_triplet_four_heads_wide_fallback(device):
                        ["x"] + [n for n, _ in conv.named_parameters()])
 
 
+@pytest.mark.parametrize("C,H", [(30, 6), (60, 5), (45, 8)])
+def test_triplet_message_more_than_four_heads(device, C, H):
+    """``TripletMessage(heads > 4)`` (layer.py:16 accepts any head count; the kernels hold four per lane group): the layer as a sum over
+    head groups on parameter slices — output and every gradient against the oracle's direct formulation."""
+    torch.manual_seed(C + H)
+    b = synth_batch(16, seed=H)
+    x0 = torch.randn(b.x.size(0), C)
+    conv = layer.TripletMessage(C, 4, heads=H)
+    ps0 = [p.detach().clone() for p in conv.parameters()]
+    cot = torch.randn(b.x.size(0), C)
+
+    def run(dt):
+        xo = x0.to(dt).requires_grad_(True)
+        ps = [p.to(dt).requires_grad_(True) for p in ps0]
+        o = O.triplet_message(xo, b.edge_index, b.edge_attr.to(dt), *ps, heads=H)
+        return o, _grads(o, cot.to(dt), [xo] + ps)
+    conv = conv.to(device)
+    x = x0.to(device).requires_grad_(True)
+    out = conv(x, b.edge_index.to(device), b.edge_attr.to(device))
+    assert_twin_parity(run, out, _grads(out, cot.to(device), [x] + list(conv.parameters())), f"{H} heads, C = {C}",
+                       ["x"] + [n for n, _ in conv.named_parameters()])
+
+
 @pytest.mark.parametrize("alpha,act,block", [(1, "ReLU", "_TripletMessage"), (2, "ReLU", "_TripletMessage"), (3, "CELU", "_TripletMessage"),
                                              (6, "ReLU", "_TripletMessage"), (3, "ReLU", "_NNConv"), (2, "LeakyReLU", "_TripletMessageLight")])
 def test_architecture_odd_widths_vs_oracle(device, alpha, act, block):
