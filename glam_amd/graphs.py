@@ -44,6 +44,7 @@ class GraphedTrainStep:
                                  "(e.g. Adam(..., capturable=True, fused=True)); fused=True alone is not enough")
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.max_graphs = max_graphs
+        self._one = {}        # device -> the scalar 1.0 every step's backward starts from
         self._state = {}      # id(batch) -> [weakref, visits, graph, static_loss]
         self._multi = {}      # (id(batch), ...) -> [weakrefs, graph, static_losses]: several consecutive steps per graph launch
         self._pool = None
@@ -76,7 +77,14 @@ class GraphedTrainStep:
     def _step(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model(batch), batch)
-        loss.backward()
+        # the root gradient as a tensor kept across steps: `loss.backward()` alone launches a fill for ones_like(loss) in every step
+        one = self._one.get(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda) else None
+        if one is None and loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda and not torch.cuda.is_current_stream_capturing():
+            one = self._one[loss.device] = torch.ones((), dtype=torch.float32, device=loss.device)     # (first visits are eager)
+        if one is not None:
+            loss.backward(gradient=one)
+        else:
+            loss.backward()
         self.optimizer.step()
         # detached: a caller that keeps the returned loss (a list of per-step losses, say) would otherwise keep the step's autograd
         # graph — and its AccumulateGrad nodes, bound to the stream of THIS step — alive into the capture of a later step on the

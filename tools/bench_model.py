@@ -61,10 +61,12 @@ def loss_of(out):
     valid = (y >= 0).float()
     return (torch.nn.functional.binary_cross_entropy_with_logits(out, y.clamp(min=0), reduction="none") * valid).sum() / valid.sum().clamp(min=1)
 
+ONE = torch.ones((), device=dev)      # the root gradient, kept across steps (loss.backward() alone launches a fill per step)
+
 def body():
     opt.zero_grad(set_to_none=True)
     loss = loss_of(net(b).view(-1))
-    loss.backward()
+    loss.backward(gradient=ONE)
     opt.step()
 
 side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
