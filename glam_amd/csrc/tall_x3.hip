@@ -46,7 +46,7 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     const TsArgs a = second ? two.b : two.a;
     const int bid = second ? (int)blockIdx.x - two.first_b : (int)blockIdx.x;
     const int nblk = second ? (int)gridDim.x - two.first_b : two.first_b;
-    const int K = a.K1 + a.K2, M = a.M1 + a.M2, nks = (K + 31) >> 5, ntiles = (a.N + 15) >> 4;
+    const int K = a.K1 + a.K2, M = a.M1 + a.M2, ntiles = (a.N + 15) >> 4;
     float* s_bias = reinterpret_cast<float*>(s_tall + 128);
     if (tid < 32) s_ready[tid] = 0;
     if (tid < 16 * NC * CT) s_bias[tid] = (a.bias && tid < a.M1) ? a.bias[tid] : 0.f;
