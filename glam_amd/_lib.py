@@ -120,6 +120,7 @@ SIGNATURES = {
     "glam_triplet_layer_bwd_params": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 11 + [_sz, _vp]),
     "glam_triplet_layer_bwd_params_acc": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 16 + [_i32, _vp, _vp, _sz, _vp]),
     "glam_triplet_layer_bwd_params_ell": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 18 + [_i32, _vp, _vp, _sz, _vp]),
+    "glam_triplet_layer_bwd_params_ell_add": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 18 + [_i32, _vp, _vp, _sz, _vp, _vp]),
     "glam_triplet_layer_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
 }
 

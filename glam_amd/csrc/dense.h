@@ -78,7 +78,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const float* img_dx, float* d_x,
                      const float* img_dagg = nullptr, const float* d_out = nullptr, const int32_t* ell_dst = nullptr,
                      const int32_t* ell_eid_t = nullptr, int edge_onehot = 0, const int32_t* ell_src = nullptr,
-                     const int32_t* ell_eid = nullptr);
+                     const int32_t* ell_eid = nullptr, const float* dx_addend = nullptr);     // dx_addend: warp-specialised B2 only
 // B1 with the d_aggr GEMM inside, warp-specialised (triplet_ws_b1.hip: matrix waves produce the d_aggr tiles ahead of the vector waves)
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
@@ -89,7 +89,7 @@ int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_att
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s);
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* dx_addend = nullptr);
 bool triplet_bwd_can_fuse_dx(int H, int Cp, int De);
 bool triplet_bwd_can_fuse_dagg(int H, int Cp, int De);
 

@@ -665,7 +665,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                           int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
                           float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po,
                           const int32_t* ell_dst = nullptr, const int32_t* ell_eid_t = nullptr, int edge_onehot = 0,
-                          const int32_t* ell_src = nullptr, const int32_t* ell_eid = nullptr) {
+                          const int32_t* ell_src = nullptr, const int32_t* ell_eid = nullptr, const float* dx_addend = nullptr) {
     if (int rc = dims_ok("glam_triplet_layer_bwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_bwd: N out of range");
     GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && d_out && d_x && (dstaged || po) && ws, "glam_triplet_layer_bwd: null pointer");
@@ -708,7 +708,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
                                   fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr,
                                   fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr, ws_dx ? ell_dst : nullptr,
-                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid))
+                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, dx_addend))
         return rc;
     const int WSZ = Dp * HC;
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
@@ -801,6 +801,31 @@ extern "C" int glam_triplet_layer_bwd_params_acc(const float* x, const float* ed
 
 // The same with the ELL index records of BOTH directions (glam_ell_build on the CSR by target and on its transpose; either pair may be
 // NULL): molecular graphs with one-hot bond features then run B1 and B2 + d_x on the warp-specialised kernels (csrc/triplet_ws*.hip).
+static int layer_bwd_params_ell(const char* fn, const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                                 const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                                 const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                                 const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                                 int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                                 const float* weight_node, const float* weight_edge, const float* att, float* d_x,
+                                                 float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
+                                                 float* d_bias, const float* add_weight_node, const float* add_weight_edge,
+                                                 const float* add_att, const float* add_weight_scale, const float* add_bias,
+                                                 const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
+                                                 const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
+                                                 void* stream, const float* dx_addend) {
+    if (int rc = dims_ok(fn, C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
+                 "%s: null pointer", fn);
+    GLAM_REQUIRE(N > 0, "%s: N = 0 (add on the host side)", fn);
+    GLAM_REQUIRE((!ell_src) == (!ell_eid) && (!ell_dst) == (!ell_eid_t) && aligned16(ell_src) && aligned16(ell_eid) && aligned16(ell_dst) &&
+                     aligned16(ell_eid_t), "%s: ELL tables come in 16-byte aligned pairs", fn);
+    const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias,
+                      add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
+    return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
+                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po, ell_dst, ell_eid_t, edge_onehot, ell_src, ell_eid,
+                          dx_addend);
+}
+
 extern "C" int glam_triplet_layer_bwd_params_ell(const float* x, const float* edge_attr, const float* staged, const float* xw,
                                                  const float* a_ij, const float* aggr, const float* stats, const float* d_out,
                                                  const int32_t* rowptr, const int32_t* src, const int32_t* eid,
@@ -813,14 +838,29 @@ extern "C" int glam_triplet_layer_bwd_params_ell(const float* x, const float* ed
                                                  const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
                                                  const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
                                                  void* stream) {
-    if (int rc = dims_ok("glam_triplet_layer_bwd_params_ell", C, H, De, Cp, Dp)) return rc;
-    GLAM_REQUIRE(weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att && d_weight_scale && d_bias,
-                 "glam_triplet_layer_bwd_params_ell: null pointer");
-    GLAM_REQUIRE(N > 0, "glam_triplet_layer_bwd_params_ell: N = 0 (add on the host side)");
-    GLAM_REQUIRE((!ell_src) == (!ell_eid) && (!ell_dst) == (!ell_eid_t) && aligned16(ell_src) && aligned16(ell_eid) && aligned16(ell_dst) &&
-                     aligned16(ell_eid_t), "glam_triplet_layer_bwd_params_ell: ELL tables come in 16-byte aligned pairs");
-    const ParamOut po{weight_node, weight_edge, att, C, De, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias,
-                      add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
-    return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp,
-                          Dp, slope, d_x, nullptr, d_edge_attr, ws, ws_bytes, stream, &po, ell_dst, ell_eid_t, edge_onehot, ell_src, ell_eid);
+    return layer_bwd_params_ell("glam_triplet_layer_bwd_params_ell", x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst,
+                                eid_t, N, E, C, H, De, Cp, Dp, slope, weight_node, weight_edge, att, d_x, d_weight_node, d_weight_edge, d_att,
+                                d_weight_scale, d_bias, add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias, ell_src, ell_eid,
+                                ell_dst, ell_eid_t, edge_onehot, d_edge_attr, ws, ws_bytes, stream, nullptr);
+}
+
+// ... with a second gradient path into the layer's input: d_x = (the layer's input gradient) + d_x_addend, summed in the d_x product's
+// epilogue.  Warp-specialised route only (glam_triplet_layer_ws_supported, both ELL pairs given): GLAM_E_UNSUPPORTED otherwise.
+extern "C" int glam_triplet_layer_bwd_params_ell_add(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                                     const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                                     const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                                     const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N,
+                                                     int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                                     const float* weight_node, const float* weight_edge, const float* att, float* d_x,
+                                                     float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale,
+                                                     float* d_bias, const float* add_weight_node, const float* add_weight_edge,
+                                                     const float* add_att, const float* add_weight_scale, const float* add_bias,
+                                                     const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
+                                                     const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
+                                                     const float* d_x_addend, void* stream) {
+    GLAM_REQUIRE(aligned16(d_x_addend), "glam_triplet_layer_bwd_params_ell_add: d_x_addend must be 16-byte aligned");
+    return layer_bwd_params_ell("glam_triplet_layer_bwd_params_ell_add", x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr,
+                                dst, eid_t, N, E, C, H, De, Cp, Dp, slope, weight_node, weight_edge, att, d_x, d_weight_node, d_weight_edge,
+                                d_att, d_weight_scale, d_bias, add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias, ell_src,
+                                ell_eid, ell_dst, ell_eid_t, edge_onehot, d_edge_attr, ws, ws_bytes, stream, d_x_addend);
 }

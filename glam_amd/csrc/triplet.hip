@@ -126,7 +126,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, const float* img_dagg,
                      const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot, const int32_t* ell_src,
-                     const int32_t* ell_eid) {
+                     const int32_t* ell_eid, const float* dx_addend) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     const int WSZ = emul ? De * H * Cp : 0;
@@ -185,7 +185,8 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     // molecular graphs with one-hot bond features: B2 over ELL records by source with the d_x GEMM inside, warp-specialised
     if (b2_ws)
         return triplet_bwd_src_ws(d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid_t, N, E, H, Cp, De, edge_onehot, d_xw,
-                                  d_a_ij, img_dx, d_x, s);
+                                  d_a_ij, img_dx, d_x, s, dx_addend);
+    if (dx_addend) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: a d_x addend needs the warp-specialised backward by source");
     const bool fuse_dx = img_dx && d_x && triplet_bwd_can_fuse_dx(H, Cp, De) && emul;
     if ((img_dx || d_x) && !fuse_dx) return fail(GLAM_E_UNSUPPORTED, "glam_triplet_bwd: no fused d_x variant for H=%d Cp=%d", H, Cp);
     BwdSrcArgs b2{edge_attr, w_edge, d_aggr, alpha_e, dpre_e, colptr, dst, eid_t, (int)N, Cp, d_xw, d_a_ij,

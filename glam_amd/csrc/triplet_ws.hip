@@ -54,7 +54,8 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 // chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
 // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
 __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
-                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
+                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane,
+                                           const float* addend WS_PROF_PARAMS) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int c = lane & 15, kq = lane >> 4;
     const int GK = (K + 15) >> 4;                             // 16-k groups, <= 12
@@ -71,6 +72,12 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
         while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         WSTAMP(0);
+        const int r0 = 16 * tile + 4 * kq;
+        float ad[4] = {0.f, 0.f, 0.f, 0.f};                   // a second gradient path into the same rows (see ws_consume_x3)
+        if (addend && col < Cp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ad[i] = addend[(size_t)min(r0 + i, N - 1) * Cp + col];
+        }
         const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
         float4 af[12];
 #pragma unroll
@@ -89,11 +96,10 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
-        const int r0 = 16 * tile + 4 * kq;
         if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (acc[i] + bias) + ad[i];
         }
         WSTAMP(2);
     }
@@ -105,8 +111,12 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 // partial products, summed in that order at the end) instead of 48 dependent fp32 MFMAs.  The fp32 MFMAs ran on the SIMD's one fp32
 // datapath, i.e. INSTEAD of the gather waves' vector instructions (tools/ubench/mfma_valu_overlap.hip); these run beside them.
 template <int RING>
+// addend (may be null): out += addend, row for row — the gradient that reaches the same tensor through the block's skip connection
+// (src_1gp/layer.py:253, 264: identity = x ... x + identity) joins d_x here instead of in an add launch of its own.  Its loads are
+// issued before the wait for the tile: by the time the epilogue needs them the previous tile's stores have long landed.
 __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bias_p, float* out, int N, int Cp, int K,
-                                              const int* s_ready, int* s_taken, const char* s_ring, int ntiles, int w, int lane) {
+                                              const int* s_ready, int* s_taken, const char* s_ring, int ntiles, int w, int lane,
+                                              const float* addend = nullptr) {
     const int c = lane & 15, kb = lane >> 4;
     const int Kp = (K + 15) & ~15;                            // rows of the weight image (zero beyond K)
     const int col = 16 * w + c;
@@ -125,6 +135,12 @@ __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bia
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const int slot = it % RING, want = 4 * (it / RING + 1);
+        const int r0 = 16 * tile + 4 * kb;
+        float ad[4] = {0.f, 0.f, 0.f, 0.f};
+        if (addend && col < Cp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ad[i] = addend[(size_t)min(r0 + i, N - 1) * Cp + col];
+        }
         while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const char* tl = s_ring + slot * kX3TileBytes + c * kX3RowBytes + kb * 16;       // row c, k = 32 s + 8 kb ..
@@ -143,11 +159,10 @@ __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bia
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
-        const int r0 = 16 * tile + 4 * kb;
         if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias;
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
         }
     }
 }
@@ -197,7 +212,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
         if constexpr (X3) ws_consume_x3<kRingN>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
-        else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, nullptr WS_PROF_ARGS);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -441,6 +456,7 @@ struct SrcWsArgs {
     int N; int Cp;
     float* d_xw; float* d_a_ij;                  // d_a_ij[N, 8]: columns 0..3 (d_a_i) are read, 4..7 (d_a_j) written
     const float* img_dx; float* d_x;
+    const float* dx_addend;      // may be null: d_x += dx_addend (ws_consume_x3)
 };
 
 template <int H, int P, bool X3>
@@ -468,8 +484,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        if constexpr (X3) ws_consume_x3<kRingN>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
-        else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        if constexpr (X3) ws_consume_x3<kRingN>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
+        else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, a.dx_addend WS_PROF_ARGS);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -676,13 +692,13 @@ bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
 // B2 + d_x over ELL records by source, warp-specialised (called by triplet_bwd_impl)
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,
                        const int32_t* ell_dst, const int32_t* ell_eid, int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot,
-                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s) {
+                       float* d_xw, float* d_a_ij, const float* img_dx, float* d_x, hipStream_t s, const float* dx_addend) {
     if (N == 0) return GLAM_OK;
     if (!triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
     if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a tensor exceeds 4 GiB (32-bit offsets)");
-    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x};
+    SrcWsArgs a{d_aggr, alpha_e, dpre_e, edge_attr, w_edge, ell_dst, ell_eid, (int)N, Cp, d_xw, d_a_ij, img_dx, d_x, dx_addend};
     const int ntiles = (int)((N + 15) / 16);
     const int cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;

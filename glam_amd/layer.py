@@ -204,6 +204,21 @@ class TripletMessage(MessagePassing):
         alpha = softmax(F.leaky_relu(logit, self.negative_slope), edge_index_i, ptr=None, num_nodes=size_i)
         return alpha.unsqueeze(-1) * e * xj
 
+    def forward_with_identity(self, x, edge_index, edge_attr):
+        """``(self(x, ...), identity)`` with ``identity`` = ``x`` handed back through the layer's autograd node where that saves the
+        add launch of the skip connection (MessageBlock, layer.py:253-265); ``identity`` is plain ``x`` on every other route."""
+        C, De = self.node_channels, self.edge_channels
+        if (self.heads <= 4 and x.dim() == 2 and x.size(1) == C and edge_attr.dim() == 2 and edge_attr.size(1) == De
+                and ops.fused_layer_supported(C, self.heads, De) and x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
+            gi = ops.graph_index(edge_index, x.size(0))
+            Cp, Dp = _ceil4(C), _pad_de(De)
+            if Dp != De:
+                edge_attr = F.pad(edge_attr, (0, Dp - De))
+            out, ident = ops.triplet_layer(ops.pad_cols(x, Cp), edge_attr, self.weight_node, self.weight_edge, self.weight_triplet_att,
+                                           self.weight_scale, self.bias, gi, self.heads, self.negative_slope, with_identity=True)
+            return ops.slice_cols(out, C), ops.slice_cols(ident, C)
+        return self(x, edge_index, edge_attr), x
+
     def _head_groups(self, x, edge_index, edge_attr):
         """``heads > 4`` (the kernels keep at most four heads of a node in a lane group): the layer is a SUM over head groups — every
         head contributes ``aggr_h @ W_scale[h]`` to the update (layer.py:57-61) and nothing else couples heads — so it runs as
@@ -534,6 +549,9 @@ class _TripletMessage(torch.nn.Module):  # layer.py:125-131
 
     def forward(self, x, edge_index, edge_attr):
         return self.conv(x, edge_index, edge_attr)
+
+    def forward_with_identity(self, x, edge_index, edge_attr):
+        return self.conv.forward_with_identity(x, edge_index, edge_attr)
 
 
 class _TripletMessageLight(torch.nn.Module):  # layer.py:134-140
@@ -876,7 +894,16 @@ class MessageBlock(torch.nn.Module):
             c = self.conv.conv
             y = c(x, edge_index, add_bias=False)
             return ops.bias_res_act(y, c.bias, None if self.res is False else identity, fa[0], fa[1], rng=fa[2]), h
-        x = self.conv(x, edge_index, edge_attr)      # layer.py:259
+        if (self.res is not False and identity is x and hasattr(self.conv, "forward_with_identity") and x.is_cuda
+                and torch.is_grad_enabled() and x.requires_grad and ops.SKIP_THROUGH_CONV):
+            # x feeds the conv and the skip connection (no norm, no dropout between them): the conv node hands x back as `identity`,
+            # both gradient paths meet in the epilogue of its d_x product (one add launch per application less)
+            first = h.dim() == 3 and h.size(0) == 1 and h.data_ptr() == x.data_ptr() and h.shape[1:] == x.shape
+            x, identity = self.conv.forward_with_identity(x, edge_index, edge_attr)
+            if first:
+                h = identity.unsqueeze(0)            # (layer.py:254: the GRU state is seeded with the same tensor)
+        else:
+            x = self.conv(x, edge_index, edge_attr)  # layer.py:259
         if self.gru is not None:
             g = self.gru
             if fa is not None and (fa[2] is None or ops.gru_rng_supported(x.size(1), g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0)):

@@ -293,7 +293,9 @@ def slice_cols(x_p, C):
         if hit is not None and hit[0] is ref:
             _PADDED.pop(k, None)
     _PADDED[key] = (weakref.ref(x_p, _drop), x_p._version)
-    return x_p[:, :C]
+    v = x_p[:, :C]
+    v._glam_padded = x_p      # the view keeps its padded tensor alive (a view of a VIEW — the skip-connection alias of _TripletLayer —
+    return v                  # only references the root storage owner: the registered object would die with the caller's local)
 
 
 def padded_base(x):
@@ -568,8 +570,13 @@ class _TripletLayer(torch.autograd.Function):
     gather/softmax/scatter-add, update GEMM — and the hand-written backward of all of it."""
 
     @staticmethod
-    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None):
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None, with_identity=False):
+        """Returns ``out`` — or the tuple ``(out[, x_p itself][, carry])``.  ``with_identity``: the layer's input comes back as a second
+        output, the skip connection of a MessageBlock (src_1gp/layer.py:253-265: ``x`` feeds the conv AND ``x + identity``): both gradient
+        paths then arrive at THIS node and the d_x product's epilogue sums them (glam_triplet_layer_bwd_params_ell_add) instead of
+        autograd launching an add per block application."""
         require_device(x_p, ea_p, wn, we, att, wsc, bias)
+        x_in = x_p
         x_p, ea_p = f32c(x_p, "x"), f32c(ea_p, "edge_attr")
         wn, we, att, wsc, bias = (f32c(t, n) for t, n in ((wn, "weight_node"), (we, "weight_edge"),
                                                            (att, "weight_triplet_att"), (wsc, "weight_scale"), (bias, "bias")))
@@ -582,6 +589,7 @@ class _TripletLayer(torch.autograd.Function):
         HC = H * Cp
         f = dict(dtype=torch.float32, device=dev)
         ctx.carried = carry is not None
+        ctx.aliased = bool(with_identity)
         ctx.set_materialize_grads(False)     # the carry of the block's LAST application has no gradient yet: None, not a zero fill
         def build():
             buf = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
@@ -608,13 +616,16 @@ class _TripletLayer(torch.autograd.Function):
                                              stream()), "glam_triplet_layer_fwd")
         ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
-        return (out, carry.view(-1)) if ctx.carried else out
+        res = (out,) + ((x_in.view_as(x_in),) if ctx.aliased else ()) + ((carry.view(-1),) if ctx.carried else ())
+        return res if len(res) > 1 else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out, d_carry=None):
-        if d_out is None:                    # the layer's output was not used: only the carry (if any) passes through
-            return (None,) * 10 + (d_carry,)
+    def backward(ctx, d_out, *more):
+        d_alias = more[0] if ctx.aliased else None
+        d_carry = more[-1] if ctx.carried else None
+        if d_out is None:                    # the layer's output was not used: only the skip connection / the carry pass through
+            return (d_alias,) + (None,) * 9 + (d_carry, None)
         x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
@@ -639,26 +650,33 @@ class _TripletLayer(torch.autograd.Function):
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
             c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
             c_wn, c_we, c_att, c_wsc, c_bias = c_parts
-            check(lib.glam_triplet_layer_bwd_params_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
-                                                        ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
-                                                        ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
-                                                        ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(c_wn), ptr(c_we),
-                                                        ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(ell_f[0]) if ell_f else None,
-                                                        ptr(ell_f[1]) if ell_f else None, ptr(ell_t[0]) if ell_t else None,
-                                                        ptr(ell_t[1]) if ell_t else None, 1 if ell_t else 0,
-                                                        ptr(d_ea), ptr(ws), ws.numel(), stream()),
+            # the skip connection's gradient joins d_x in the epilogue of the d_x product (warp-specialised route)
+            in_kernel = d_alias is not None and ell_t is not None
+            addend = f32c(d_alias, "d_identity") if in_kernel else None
+            check(lib.glam_triplet_layer_bwd_params_ell_add(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
+                                                            ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
+                                                            ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
+                                                            ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(c_wn), ptr(c_we),
+                                                            ptr(c_att), ptr(c_wsc), ptr(c_bias), ptr(ell_f[0]) if ell_f else None,
+                                                            ptr(ell_f[1]) if ell_f else None, ptr(ell_t[0]) if ell_t else None,
+                                                            ptr(ell_t[1]) if ell_t else None, 1 if ell_t else 0,
+                                                            ptr(d_ea), ptr(ws), ws.numel(), ptr(addend), stream()),
                   "glam_triplet_layer_bwd_params_ell")
+            if d_alias is not None and not in_kernel:
+                d_x = d_x.add_(d_alias)
             if ctx.carried:
-                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry))
-            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
+                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry)), None
+            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
                                                 ptr(d_wn), ptr(d_we), ptr(d_att), ptr(d_wsc), ptr(d_bias), ptr(d_ea), ptr(ws),
                                                 ws.numel(), stream()), "glam_triplet_layer_bwd_params")
+        if d_alias is not None:
+            d_x = d_x.add_(d_alias)
         if ctx.carried:
-            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
-        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None
 
 
 # The layer through the torch-extension operator (torch.ops.glam.triplet_layer: C++ autograd node, no ctypes marshalling, no Python
@@ -692,8 +710,12 @@ def _want_torch_ext(N, H, Cp):
     return True
 
 
-def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2):
-    """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``."""
+def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope=0.2, with_identity=False):
+    """``TripletMessage.forward`` (src_1gp/layer.py:36-61) in padded widths: ``x_p[N,Cp] -> out[N,Cp]``.  ``with_identity``: returns
+    ``(out, identity)`` where ``identity`` is ``x_p`` handed back through the layer's autograd node (see _TripletLayer.forward) — or
+    plain ``x_p`` on the routes that have nothing to gain from it."""
+    if with_identity and not (torch.is_grad_enabled() and x_p.requires_grad) or _want_torch_ext(gi.N, heads, x_p.size(1)) and with_identity:
+        return triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope), x_p
     if _want_torch_ext(gi.N, heads, x_p.size(1)):
         from . import torch_ext
         # the one-time read-backs of the ELL routes happen on an eager visit (a later CAPTURED visit of the same batch finds them
@@ -723,12 +745,12 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
     key = ("carry-triplet", id(weight_node))
     carry = _carry_for(key, params, sum(sizes), lambda flat: [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)])
     if carry is None:
-        return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
+        return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, None, with_identity)
     # the parameters still enter as inputs (the kernels read them, and the scope's staging cache is keyed on them), but this
     # node returns no gradient for them: it flows through `carry`
-    out, carry = _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry)
-    _carry_store(key, weight_node, carry)
-    return out
+    res = _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry, with_identity)
+    _carry_store(key, weight_node, res[-1])
+    return (res[0], res[1]) if with_identity else res[0]
 
 
 class _TripletLayerWide(torch.autograd.Function):
@@ -976,6 +998,8 @@ GRU_FUSED_MIN_NODES = 16384
 # The same step warp-specialised on the bf16 matrix cores in 3 x bf16 form (glam_gru_ws_fwd: fp32 accuracy, different roundings than the
 # fp32 launches above; 24 <= C <= 64): the default where it applies.
 GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
+# MessageBlock's skip connection handed through the conv's autograd node (the d_x product's epilogue sums both gradient paths): A/B switch
+SKIP_THROUGH_CONV = os.environ.get("GLAM_SKIP_THROUGH_CONV", "1") == "1"
 
 
 # ---- the dense and readout operator families live in their own modules; their names are part of this namespace ----

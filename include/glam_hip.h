@@ -326,6 +326,21 @@ int glam_triplet_layer_bwd_params_ell(const float* x, const float* edge_attr, co
                                       const float* add_bias, const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
                                       const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
                                       void* stream);
+/* The same with a second gradient path into the layer's input: MessageBlock keeps `identity = x` (src_1gp/layer.py:253) and adds it back
+ * behind the GRU (:264), so x receives d_identity besides the layer's own input gradient.  d_x = (input gradient) + d_x_addend[N, Cp],
+ * summed in the epilogue of the d_x product instead of by an add launch per block application.  Warp-specialised route only (both ELL
+ * pairs given, glam_triplet_layer_ws_supported): GLAM_E_UNSUPPORTED otherwise.  d_x_addend == NULL is glam_triplet_layer_bwd_params_ell. */
+int glam_triplet_layer_bwd_params_ell_add(const float* x, const float* edge_attr, const float* staged, const float* xw,
+                                          const float* a_ij, const float* aggr, const float* stats, const float* d_out,
+                                          const int32_t* rowptr, const int32_t* src, const int32_t* eid, const int32_t* colptr,
+                                          const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E, int C, int H, int De,
+                                          int Cp, int Dp, float slope, const float* weight_node, const float* weight_edge,
+                                          const float* att, float* d_x, float* d_weight_node, float* d_weight_edge, float* d_att,
+                                          float* d_weight_scale, float* d_bias, const float* add_weight_node,
+                                          const float* add_weight_edge, const float* add_att, const float* add_weight_scale,
+                                          const float* add_bias, const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
+                                          const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
+                                          const float* d_x_addend, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * MessageBlock remainder: gate math of one torch.nn.GRU(C, C) step with seq_len 1 (src_1gp/layer.py:247, :262).
  * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with

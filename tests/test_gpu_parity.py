@@ -2287,6 +2287,34 @@ def test_gru_ws_fwd_c_abi(device, N, C, ident, celu):
     assert raw.glam_gru_ws_fwd(p(x), p(h), None, p(ia), p(ib), p(b_ih), p(b_hh), N, 20, 0, 1, 0.0, p(gi), p(gh), p(hn), p(out), st()) != 0
 
 
+@pytest.mark.parametrize("C", [60, 45, 32])
+def test_skip_connection_through_the_conv_node(device, monkeypatch, C):
+    """MessageBlock hands its skip connection (layer.py:253, 264) through the TripletMessage autograd node: the d_x product's epilogue adds
+    d_identity (glam_triplet_layer_bwd_params_ell_add; C = 60, 45: warp-specialised route, 45 on zero-padded rows) — or the node adds it
+    behind the general kernels (C = 32) — instead of autograd.  Same forward, the same gradient terms in another order of summation; the
+    first application's GRU state shares the handed-back tensor."""
+    b = synth_batch(40, seed=C).to(device)
+    blk = layer.MessageBlock(C, C, 4, norm="_None", dropout="_None()", conv="_TripletMessage", act="ReLU", res=True).to(device)
+    x0 = torch.randn(b.x.size(0), C, device=device)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "SKIP_THROUGH_CONV", on)
+        x = x0.clone().requires_grad_(True)
+        with ops.weight_scope():
+            x1, h1 = blk(x, b.edge_index, b.edge_attr, h=None, batch=b.batch)
+            x2, h2 = blk(x1, b.edge_index, b.edge_attr, h=h1, batch=b.batch)
+            gs = torch.autograd.grad((x2 * x2).sum() + h2.sum(), [x] + list(blk.parameters()))
+        res.append([x1, x2, h2] + list(gs))
+    for i, (a, c) in enumerate(zip(*res)):
+        if i < 3:
+            assert torch.equal(a, c)                      # the forward is the same launches
+        else:
+            assert_close(c, a, 2e-6, f"gradient {i - 3}")  # the same terms, summed in another order (x of the first application gets three)
+    # the C entry point refuses an addend where no warp-specialised backward by source runs (covered above through the op; here the error)
+    raw = ops._lib.load()
+    assert raw.glam_triplet_layer_ws_supported(3, 32, 4, 1) == 0 and raw.glam_triplet_layer_ws_supported(3, 48, 4, 1) == 1
+
+
 @pytest.mark.parametrize("N,C,celu,hstate,ident", [(1, 64, True, True, True), (1000, 64, False, False, False), (20400, 60, True, True, True),
                                                    (17, 24, False, True, True), (0, 60, True, True, True)])
 def test_gru_bwd_ws_c_abi(device, N, C, celu, hstate, ident):
