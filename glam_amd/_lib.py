@@ -62,8 +62,8 @@ SIGNATURES = {
     "glam_pair_pool5_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_supported": (_i32, [_i32]),
     "glam_gru_ws_supported": (_i32, [_i32]),
-    "glam_gru_bwd_ws": (_i32, [_vp] * 9 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
-    "glam_gru_bwd_ws_rng": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 6 + [_vp]),
+    "glam_gru_bwd_ws": (_i32, [_vp] * 9 + [_i64, _i32, _i32, _i32, _f32, _i32] + [_vp] * 5 + [_vp]),
+    "glam_gru_bwd_ws_rng": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32] + [_vp] * 5 + [_vp]),
     "glam_gru_ws_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_vp]),
     "glam_gru_ws_rng_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 7 + [_vp]),
     "glam_gru_fused_image_bytes": (_sz, []),

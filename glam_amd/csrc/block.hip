@@ -757,6 +757,8 @@ struct GruBwdArgs {
     const float* img_ih_t; const float* img_hh_t;      // k_ts_gemm images of W_ih / W_hh as [3C, C] (the input-gradient products)
     float* d_gi; float* d_gh; float* d_identity; float* d_x; float* d_h;
     int N, C, act, celu_in; float slope;
+    int merge_identity;      // 1: the skip connection and the GRU state are the SAME tensor (first application of a block, layer.py:254):
+                             //    d_h += d_identity here, d_identity is not written
 };
 
 template <bool RNG>
@@ -832,10 +834,10 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
                             (&pz4.x)[j] = d_z * z * (1.f - z);
                             (&pn4.x)[j] = d_pn;
                             (&pnr4.x)[j] = d_pn * r;
-                            (&gz4.x)[j] = g * z;
+                            (&gz4.x)[j] = a.merge_identity ? g * z + dy : g * z;
                             if (a.celu_in) (&cf4.x)[j] = celu1_grad(f4get(v[10], j));
                         }
-                        if (a.d_identity) st4(a.d_identity + i, dy4);
+                        if (a.d_identity && !a.merge_identity) st4(a.d_identity + i, dy4);
                         st4(a.d_gi + b, pr4); st4(a.d_gi + b + C, pz4); st4(a.d_gi + b + 2 * C, pn4);
                         st4(a.d_gh + b, pr4); st4(a.d_gh + b + C, pz4); st4(a.d_gh + b + 2 * C, pnr4);
                     }
@@ -972,9 +974,10 @@ static int gru_bwd_ws_args_ok(const char* fn, const GruBwdArgs& a, int64_t N, co
 
 extern "C" int glam_gru_bwd_ws(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
                                const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C, int celu_in, int act, float slope,
-                               float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
+                               int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
     if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_bwd_ws: activation code %d", act);
-    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope};
+    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope,
+                       merge_identity ? 1 : 0};
     if (int rc = gru_bwd_ws_args_ok("glam_gru_bwd_ws", a, N, nullptr)) return rc;
     if (N == 0) return GLAM_OK;
     return gru_bwd_ws_launch(a, nullptr, (hipStream_t)stream);
@@ -984,9 +987,10 @@ static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
 extern "C" int glam_gru_bwd_ws_rng(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_out_drop,
                                    const float* d_hstate, const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C,
                                    int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
-                                   float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
+                                   int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
     if (int rc = rng_args_ok("glam_gru_bwd_ws_rng", act, rr_lower, rr_upper, drop_p)) return rc;
-    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope};
+    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope,
+                       merge_identity ? 1 : 0};
     if (int rc = gru_bwd_ws_args_ok("glam_gru_bwd_ws_rng", a, N, d_out_drop)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(rng_eff, "glam_gru_bwd_ws_rng: null rng_eff");

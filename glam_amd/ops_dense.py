@@ -685,6 +685,10 @@ class _GruBlock(torch.autograd.Function):
                 check(lib.glam_gru_tail_rng_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), lo, hi, p,
                                                 ptr(_o.rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
         ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
+        # the first application of a block seeds the GRU state with the block input, which is also the skip connection (layer.py:253-254):
+        # one tensor, two roles — the backward then returns ONE gradient for it (k_gru_bwd_ws adds d_identity into d_h)
+        ctx.same_h_id = (identity is not None and identity.data_ptr() == h.data_ptr() and identity.shape == h.shape
+                         and identity.stride() == h.stride())
         ctx.eff = eff
         ctx.cfg = (act, float(slope), identity is not None, bool(celu_in), None if rng is None else tuple(float(v) for v in rng))
         ctx.scope = scope
@@ -720,17 +724,21 @@ class _GruBlock(torch.autograd.Function):
             # gate gradients + both input-gradient products in ONE launch (block.hip: k_gru_bwd_ws); d_h comes out complete
             dx = torch.empty(N, C, **f)
             img_a, img_b = image_t(w_ih), image_t(w_hh)
+            merge = int(has_res and ctx.same_h_id)
+            if merge:
+                d_id = None                   # (its gradient is part of d_h: the two inputs are one tensor)
             if rng is None:
                 if d_out is None:
                     d_out = torch.zeros_like(h)
                 check(lib.glam_gru_bwd_ws(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), ptr(x), ptr(img_a), ptr(img_b), N, C,
-                                          int(celu_in), act, slope, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws")
+                                          int(celu_in), act, slope, merge, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st),
+                      "glam_gru_bwd_ws")
             else:
                 if d_out is None and d_out_drop is None:
                     d_out = torch.zeros_like(h)
                 check(lib.glam_gru_bwd_ws_rng(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), ptr(x), ptr(img_a),
-                                              ptr(img_b), N, C, int(celu_in), act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), ptr(d_gi), ptr(d_gh),
-                                              ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng")
+                                              ptr(img_b), N, C, int(celu_in), act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), merge, ptr(d_gi),
+                                              ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng")
             dh = d_h
         elif rng is None:
             if d_out is None:

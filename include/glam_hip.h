@@ -537,14 +537,16 @@ int glam_gru_ws_rng_fwd(const float* x, const float* h, const float* identity, c
  * warp-specialised, the products in 3 x bf16 form.  d_gi / d_gh [N, 3C] are still written (the weight-gradient launch reads them), d_h
  * comes out COMPLETE (the tail kernels' d_h is only the direct part).  img_ih_t / img_hh_t: glam_ts_gemm_make_image(w, C, 0, 3 C, C, img),
  * the images glam_ts_gemm_pair takes for these products.  x is read only with celu_in; d_identity, d_hstate, d_out_drop may be NULL
- * (d_out too in the rng form when d_out_drop is given).  C a multiple of 4 in 24 .. 64. */
+ * (d_out too in the rng form when d_out_drop is given).  merge_identity = 1: the skip connection and the GRU state are the same tensor
+ * (the first application of a block, src_1gp/layer.py:254) — d_h additionally receives d_identity and d_identity is not written.
+ * C a multiple of 4 in 24 .. 64. */
 int glam_gru_bwd_ws(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
                     const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C, int celu_in, int act, float slope,
-                    float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);
+                    int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);
 int glam_gru_bwd_ws_rng(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_out_drop,
                         const float* d_hstate, const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C,
                         int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
-                        float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);
+                        int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);
 
 /* ---- narrow-output linear (the model's output head) -------------------------------------------------------------------
  * y[N, M] = x[N, K] @ w[M, K]^T + b for M <= 16, K % 4 == 0: replaces torch.nn.functional.linear / its autograd for

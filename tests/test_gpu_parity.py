@@ -2341,14 +2341,20 @@ def test_gru_bwd_ws_c_abi(device, N, C, celu, hstate, ident):
     finally:
         del os.environ["GLAM_TALL_X3"]
     dgi, dgh, did, dx, dh = f(N, M), f(N, M), f(N, C), f(N, C), f(N, C)
-    ops.check(raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs) if hstate else None, p(x), p(ta), p(tb), N, C, int(celu), 1, 0.0,
+    ops.check(raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs) if hstate else None, p(x), p(ta), p(tb), N, C, int(celu), 1, 0.0, 0,
                                   p(dgi), p(dgh), p(did) if ident else None, p(dx), p(dh), st()), "glam_gru_bwd_ws")
     assert torch.equal(dgi, dgi0) and torch.equal(dgh, dgh0) and (not ident or torch.equal(did, did0))
     assert_close(dx, dx0, 2e-6, "d_x")
     assert_close(dh, dhf0, 2e-6, "d_h")
-    assert raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), None, p(x), p(ta), p(tb), N, 20, 0, 1, 0.0, p(dgi), p(dgh), None, p(dx), p(dh), st()) != 0
+    if ident:       # merge_identity: d_h additionally carries d_identity (skip connection and GRU state are one tensor), d_identity untouched
+        dh2, did2 = f(N, C), f(N, C)
+        ops.check(raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs) if hstate else None, p(x), p(ta), p(tb), N, C, int(celu), 1, 0.0, 1,
+                                      p(dgi), p(dgh), p(did2), p(dx), p(dh2), st()), "glam_gru_bwd_ws merge")
+        assert_close(dh2, dhf0 + did0, 2e-6, "d_h + d_identity")
+        assert N == 0 or torch.isnan(did2).all()
+    assert raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), None, p(x), p(ta), p(tb), N, 20, 0, 1, 0.0, 0, p(dgi), p(dgh), None, p(dx), p(dh), st()) != 0
     if N:
-        assert raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), None, None, p(x), p(ta), p(tb), N, C, 0, 1, 0.0, p(dgi), p(dgh), None, p(dx), p(dh), st()) != 0
+        assert raw.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), None, None, p(x), p(ta), p(tb), N, C, 0, 1, 0.0, 0, p(dgi), p(dgh), None, p(dx), p(dh), st()) != 0
 
 
 @pytest.mark.parametrize("C,train", [(60, False), (60, True), (32, False), (48, True)])

@@ -37,7 +37,7 @@ for N in Ns:
     d_out, d_hs = r(N, C), r(N, C)
     dgi, dgh, did, dx, dh, dh2 = (torch.empty(N, M, device=dev), torch.empty(N, M, device=dev), torch.empty(N, C, device=dev), torch.empty(N, C, device=dev),
                                   torch.empty(N, C, device=dev), torch.empty(N, C, device=dev))
-    rows["gru_bwd_ws"].append(timeit(lambda: lib.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(x), p(ta), p(tb), N, C, 1, 1, 0.0, p(dgi), p(dgh), p(did), p(dx), p(dh), st())))
+    rows["gru_bwd_ws"].append(timeit(lambda: lib.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(x), p(ta), p(tb), N, C, 1, 1, 0.0, 0, p(dgi), p(dgh), p(did), p(dx), p(dh), st())))
     def two():
         lib.glam_gru_tail_bwd(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), N, C, 1, 0.0, p(dgi), p(dgh), p(dh), p(did), st())
         lib.glam_ts_gemm_pair(p(dgi), M, M, 0, p(ta), None, p(dx), C, C, p(x), C, None, 0, p(dgh), M, M, 0, p(tb), None, p(dh2), C, C, None, 0, p(dh), C, N, st())
