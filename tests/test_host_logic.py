@@ -360,3 +360,43 @@ def test_adam_abi_rejects_bad_arguments_without_touching_a_gpu():
     assert lib.glam_adam_step(tab, numel, 1, 8, 8, None, *args) == _lib.GLAM_E_INVALID                  # null tensor addresses
     assert lib.glam_adam_step(tab, numel, 1, 8, 8, None, 0.001, 1.0, 0.999, 1e-8, 0.0, None) == _lib.GLAM_E_INVALID   # beta1 = 1
     assert lib.glam_adam_step(tab, numel, 0, 8, 8, None, *args) == 0                                    # nothing to do
+
+
+def test_padded_view_registry_is_host_logic():
+    """ops.slice_cols / pad_cols / padded_base (the zero-padded flow of the odd hidden widths): pure bookkeeping, no kernels.  A view
+    finds its padded tensor by address, strides and version; a view of a VIEW keeps the registered object alive; an in-place write or a
+    different stride ends the trust."""
+    import gc
+    xp = torch.zeros(6, 48)
+    xp[:, :45] = torch.randn(6, 45)
+    v = ops.slice_cols(xp, 45)
+    assert v.shape == (6, 45) and ops.padded_base(v) is xp and ops.pad_cols(v, 48) is xp
+    assert ops.padded_base(v.unsqueeze(0).squeeze(0)) is xp                 # any view with the same address and strides
+    assert ops.padded_base(xp) is None and ops.slice_cols(xp, 48) is xp     # nothing to slice
+    # a registered tensor that is itself a view (the skip-connection alias of the layer node): its slice keeps it alive
+    alias = xp.view_as(xp)
+    w = ops.slice_cols(alias, 45)
+    del alias
+    gc.collect()
+    assert ops.padded_base(w) is not None and ops.padded_base(w).data_ptr() == xp.data_ptr()
+    w.add_(1.0)                                                             # the pad columns may no longer be what the producer left
+    assert ops.padded_base(w) is None
+    p = ops.pad_cols(w, 48)
+    assert p.shape == (6, 48) and torch.equal(p[:, :45], w) and (p[:, 45:] == 0).all()
+    other = torch.zeros(6, 52)[:, :45]                                      # a view nobody registered, another pitch
+    assert ops.padded_base(other) is None
+
+
+def test_pad_group_and_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks of the entry points added in round 4 run before any device work."""
+    import ctypes
+    lib = _lib.load()
+    one = (ctypes.c_void_p * 1)(1 << 20)
+    assert lib.glam_pad_group(9, one, one, (ctypes.c_int32 * 45)(), 0, None) == _lib.GLAM_E_INVALID
+    assert lib.glam_pad_group(1, one, one, (ctypes.c_int32 * 5)(1, 4, 4, 3, 4), 0, None) == _lib.GLAM_E_INVALID     # padded < plain
+    assert lib.glam_pad_group(0, None, None, None, 0, None) == 0
+    assert lib.glam_gru_ws_supported(60) == 1 and lib.glam_gru_ws_supported(20) == 0 and lib.glam_gru_ws_supported(62) == 0
+    assert lib.glam_gru_ws_fwd(None, None, None, None, None, None, None, 4, 20, 0, 1, 0.0, None, None, None, None, None) == _lib.GLAM_E_UNSUPPORTED
+    assert lib.glam_gru_bwd_ws(None, None, None, None, None, None, None, None, None, 4, 62, 0, 1, 0.0, 0, None, None, None, None, None, None) == _lib.GLAM_E_UNSUPPORTED
+    assert lib.glam_pool5_padded_fwd(None, None, 4, 2, 50, 45, 3, None, None, None) == _lib.GLAM_E_INVALID             # ld is not ceil4(D)
+    assert lib.glam_ts_gemm_image_bytes(276, 92) > 0 and lib.glam_ts_gemm_image_bytes(300, 92) >= 0
