@@ -54,8 +54,7 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 // chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
 // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
 __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
-                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane,
-                                           const float* addend WS_PROF_PARAMS) {
+                                           const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int c = lane & 15, kq = lane >> 4;
     const int GK = (K + 15) >> 4;                             // 16-k groups, <= 12
@@ -72,12 +71,6 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
         while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         WSTAMP(0);
-        const int r0 = 16 * tile + 4 * kq;
-        float ad[4] = {0.f, 0.f, 0.f, 0.f};                   // a second gradient path into the same rows (see ws_consume_x3)
-        if (addend && col < Cp) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ad[i] = addend[(size_t)min(r0 + i, N - 1) * Cp + col];
-        }
         const float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
         float4 af[12];
 #pragma unroll
@@ -96,10 +89,11 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
+        const int r0 = 16 * tile + 4 * kq;
         if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (acc[i] + bias) + ad[i];
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
         }
         WSTAMP(2);
     }
@@ -110,16 +104,22 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 // v_mfma_f32_16x16x32_bf16 per tile (six 32-k steps x six partial products) into three accumulator chains (small / middle / hi x hi
 // partial products, summed in that order at the end) instead of 48 dependent fp32 MFMAs.  The fp32 MFMAs ran on the SIMD's one fp32
 // datapath, i.e. INSTEAD of the gather waves' vector instructions (tools/ubench/mfma_valu_overlap.hip); these run beside them.
-template <int RING>
-// addend (may be null): out += addend, row for row — the gradient that reaches the same tensor through the block's skip connection
-// (src_1gp/layer.py:253, 264: identity = x ... x + identity) joins d_x here instead of in an add launch of its own.  Its loads are
-// issued before the wait for the tile: by the time the epilogue needs them the previous tile's stores have long landed.
+// ADD: out += addend, row for row — the gradient that reaches the same tensor through the block's skip connection (src_1gp/layer.py:253,
+// 264: identity = x ... x + identity) joins d_x here instead of in an add launch of its own.  A separate instantiation: the plain form
+// must not carry a load in its loop at all (even under a null pointer the compiler waits, before the epilogue, for everything the wave
+// has in flight — i.e. for the previous tile's stores: B2 went 122 -> 164 us at B = 16 384 when this was a run-time option).  The next
+// tile's addend rows are requested BEFORE this tile's stores and the loop runs over full tiles only (four unconditional stores per lane:
+// the wait for the rows can leave exactly those in flight); the ragged last tile is handled behind it.
+template <int RING, bool ADD = false>
 __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bias_p, float* out, int N, int Cp, int K,
                                               const int* s_ready, int* s_taken, const char* s_ring, int ntiles, int w, int lane,
                                               const float* addend = nullptr) {
     const int c = lane & 15, kb = lane >> 4;
     const int Kp = (K + 15) & ~15;                            // rows of the weight image (zero beyond K)
-    const int col = 16 * w + c;
+    // ADD: a lane whose column lies beyond Cp DUPLICATES column col - Cp (same weight slice, same tile: bit-identical values stored to the
+    // same address) so that every lane issues the same four stores per tile — an exec-masked store would hide their count from the
+    // compiler's wait counting
+    const int col = (ADD && 16 * w + c >= Cp) ? 16 * w + c - Cp : 16 * w + c;
     const int pos = (col & 3) * 16 + (col >> 2);              // position of logical column `col` in a k_ts_gemm image row
     Bf16x3 wreg[6];
     {
@@ -131,20 +131,16 @@ __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bia
     }
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
     const int nks = (K + 31) >> 5;                            // 32-k steps that hold data (<= 6)
-    __syncthreads();                                          // the block's only barrier (LDS flags / W_edge / ring padding staged)
-    int it = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-        const int slot = it % RING, want = 4 * (it / RING + 1);
-        const int r0 = 16 * tile + 4 * kb;
-        float ad[4] = {0.f, 0.f, 0.f, 0.f};
-        if (addend && col < Cp) {
+    const int colc = col;
+    auto load_add = [&](int tile, float (&ad)[4]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ad[i] = addend[(size_t)min(r0 + i, N - 1) * Cp + col];
-        }
-        while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
+        for (int i = 0; i < 4; ++i) ad[i] = addend[(size_t)min(16 * tile + 4 * kb + i, N - 1) * Cp + colc];
+    };
+    float ad[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ADD) { if ((int)blockIdx.x < ntiles) load_add(blockIdx.x, ad); }
+    __syncthreads();                                          // the block's only barrier (LDS flags / W_edge / ring padding staged)
+    auto product = [&](int slot, v4f_t& acc_s, v4f_t& acc_m, v4f_t& acc_b) {
         const char* tl = s_ring + slot * kX3TileBytes + c * kX3RowBytes + kb * 16;       // row c, k = 32 s + 8 kb ..
-        v4f_t acc_s = {0.f, 0.f, 0.f, 0.f}, acc_m = acc_s, acc_b = acc_s;
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             if (s < nks) {
@@ -159,10 +155,42 @@ __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bia
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) flag_bump(s_taken + slot);             // every fragment is in registers: the slot may be refilled
-        if (col < Cp) {
+    };
+    int it = 0, tile = blockIdx.x;
+    const int nfull = N >> 4;                                 // tiles whose 16 rows all exist
+    for (; tile < (ADD ? nfull : ntiles); tile += gridDim.x, ++it) {
+        const int slot = it % RING, want = 4 * (it / RING + 1);
+        const int r0 = 16 * tile + 4 * kb;
+        while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        v4f_t acc_s = {0.f, 0.f, 0.f, 0.f}, acc_m = acc_s, acc_b = acc_s;
+        product(slot, acc_s, acc_m, acc_b);
+        if constexpr (ADD) {
+            float nx[4];
+            load_add(min(tile + (int)gridDim.x, ntiles - 1), nx);          // the next tile's rows, ahead of this tile's stores
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[(size_t)(r0 + i) * Cp + colc] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ad[i] = nx[i];
+        } else if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias;
+        }
+    }
+    if constexpr (ADD) {
+        if (tile < ntiles) {                                  // the ragged last tile (at most one per launch)
+            const int slot = it % RING, want = 4 * (it / RING + 1);
+            const int r0 = 16 * tile + 4 * kb;
+            while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            v4f_t acc_s = {0.f, 0.f, 0.f, 0.f}, acc_m = acc_s, acc_b = acc_s;
+            product(slot, acc_s, acc_m, acc_b);
+            if (col < Cp) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
+            }
         }
     }
 }
@@ -212,7 +240,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
         if constexpr (X3) ws_consume_x3<kRingN>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
-        else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, nullptr WS_PROF_ARGS);
+        else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -459,7 +487,7 @@ struct SrcWsArgs {
     const float* dx_addend;      // may be null: d_x += dx_addend (ws_consume_x3)
 };
 
-template <int H, int P, bool X3>
+template <int H, int P, bool X3, bool ADD = false>      // ADD (3 x bf16 form only): d_x += a.dx_addend in the consumers' epilogue
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -484,8 +512,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        if constexpr (X3) ws_consume_x3<kRingN>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
-        else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane, a.dx_addend WS_PROF_ARGS);
+        if constexpr (X3) ws_consume_x3<kRingN, ADD>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
+        else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -669,20 +697,24 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #undef LANE_CONSTS
 }
 
-template <int H, int P, bool X3>
+template <int H, int P, bool X3, bool ADD>
 static int launch_src_ws_px(const SrcWsArgs& a, int grid, hipStream_t s) {
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, X3>), big, "triplet_bwd_src_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, X3, ADD>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t ring = X3 ? (size_t)kWsRingX3 * kX3TileBytes : (size_t)kWsRing * 16 * LDT * sizeof(float);
     const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4) * sizeof(float) + ring;
     GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
-    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, X3>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, X3, ADD>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
     return GLAM_OK;
 }
 template <int H, int P>
 static int launch_src_ws_p(const SrcWsArgs& a, int grid, hipStream_t s) {
-    return ts_x3_enabled() ? launch_src_ws_px<H, P, true>(a, grid, s) : launch_src_ws_px<H, P, false>(a, grid, s);
+    if (a.dx_addend) {
+        if (!ts_x3_enabled()) return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_src_ws: a d_x addend needs the 3 x bf16 consumers (GLAM_X3=0 is set)");
+        return launch_src_ws_px<H, P, true, true>(a, grid, s);
+    }
+    return ts_x3_enabled() ? launch_src_ws_px<H, P, true, false>(a, grid, s) : launch_src_ws_px<H, P, false, false>(a, grid, s);
 }
 
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot) {
