@@ -12,11 +12,11 @@ bad = 0
 def m4(lo, hi): return int(rng.integers(lo // 4, hi // 4 + 1)) * 4
 for case in range(n_cases):
     try:
-        N = int(rng.choice([1, 3, 15, 16, 17, 100, 1000, 5000, 20400]))
+        N = int(rng.choice([1, 3, 15, 16, 17, 100, 1000, 4097, 5000, 20400, 70001]))
         if rng.random() < 0.5:
             # ---- ts_gemm ----
-            variant = int(rng.integers(0, 3))
-            K, M = [(m4(4, 192), m4(4, 64)), (m4(4, 64), m4(4, 192)), (m4(4, 96), m4(4, 320))][variant]
+            variant = int(rng.integers(0, 4))        # 3: the long-reduction class beyond the fp32 table (tall_x3.hip)
+            K, M = [(m4(4, 192), m4(4, 64)), (m4(4, 64), m4(4, 192)), (m4(4, 96), m4(4, 320)), (m4(196, 288), m4(4, 96))][variant]
             K2 = m4(0, K - 4) if K > 4 and rng.random() < 0.4 else 0
             K1 = K - K2
             M2 = m4(4, M - 4) if M > 4 and rng.random() < 0.4 else 0
