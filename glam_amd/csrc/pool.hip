@@ -110,20 +110,18 @@ __global__ void __launch_bounds__(kBlock) k_pool5_fwd_v4(const float* x, const i
                 }
             }
         }
-        // column sums: 8 rows of this lane's row group in flight per step
+        // column sums: 8 rows of this lane's row group in flight per step, the last step masked — every load unconditional (clamped
+        // row, zeroed afterwards: a load under a condition is waited for on the spot), so a molecule of up to 8 RG nodes is ONE round trip
+        // (the row-at-a-time tail this replaces was a chain of five for 20 atoms)
         float4 acc = f4zero();
         if (act) {
-            int n = beg + rg;
-            for (; n + 7 * RG < end; n += 8 * RG) {
+            for (int n = beg + rg; n < end; n += 8 * RG) {
                 float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ld4(x + (size_t)(n + RG * u) * ld + 4 * c4);
+                for (int u = 0; u < 8; ++u) v[u] = ld4(x + (size_t)min(n + RG * u, end - 1) * ld + 4 * c4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-            }
-            for (; n < end; n += RG) {
-                const float4 v = ld4(x + (size_t)n * ld + 4 * c4);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                for (int u = 0; u < 8; ++u)
+                    if (n + RG * u < end) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
             }
         }
 #pragma unroll
