@@ -578,9 +578,10 @@ static int ts_variant(int K, int M) {
     if (K <= 64 && M <= 192) return 1;
     if (K <= 96 && M <= 320) return 2;
     if (K <= 288 && M <= 96) return 3;
+    if (K <= 320 && M <= 64) return 4;      // 3 x bf16 only (NNConv's relation product [N, De C] x [De C, C]: 300 -> 60)
     return -1;
 }
-static int ts_mt(int variant) { return variant == 0 ? 4 : variant == 1 ? 12 : variant == 2 ? 20 : 8; }
+static int ts_mt(int variant) { return variant == 0 || variant == 4 ? 4 : variant == 1 ? 12 : variant == 2 ? 20 : 8; }
 
 size_t ts_image_floats(int K, int M) {
     const int Kp = (K + 15) & ~15, v = ts_variant(K, M);
@@ -589,7 +590,7 @@ size_t ts_image_floats(int K, int M) {
 
 static int ts_shape_ok(const char* fn, int K, int M) {
     if (ts_variant(K, M) < 0)
-        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d outside the kernel table (K<=192,M<=64 | K<=64,M<=192 | K<=96,M<=320 | K<=288,M<=96)", fn, K, M);
+        return fail(GLAM_E_UNSUPPORTED, "%s: K=%d with M=%d outside the kernel table (K<=192,M<=64 | K<=64,M<=192 | K<=96,M<=320 | K<=288,M<=96 | K<=320,M<=64)", fn, K, M);
     return GLAM_OK;
 }
 
@@ -611,7 +612,7 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
     const int ntiles = (a.N + 15) / 16;
     *variant = ts_variant(K, M);
     // column splits per row tile (MT / TPI).  K <= 192 x 64 columns: splitting would re-read the long A rows
-    const int nitems = ntiles * (*variant == 0 || *variant == 3 ? 1 : *variant == 1 ? 3 : 5);
+    const int nitems = ntiles * (*variant == 0 || *variant >= 3 ? 1 : *variant == 1 ? 3 : 5);
     int g = nitems < 2048 ? nitems : (nitems + 7) / 8;   // < one item per wave slot: one block per item first (see `spread`)
     if (g > 256) g = 256;                // one 8-wave block per CU, items dealt round-robin over every wave of the grid
     *grid = g;
@@ -647,7 +648,7 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     // the long-reduction shapes on the bf16 matrix cores (tall_x3.hip); GLAM_X3=0 keeps the fp32 matrix instructions where they exist
-    if (variant == 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
+    if (variant >= 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
     if (variant == 2 && ts_x3_enabled() && tall_x3_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
         return launch_tall_x3(a, b, variant, s);
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);

@@ -255,6 +255,7 @@ static int launch_tall(const TallArgs2& two, int grid, hipStream_t s) {
 
 // shape classes (the weight image is the k_ts_gemm image of the same (K, M): its row length MP follows ts_variant in gemm.hip):
 //   0: K <= 192, M <= 64  (MP 64)     3: K <= 288, M <= 96 (MP 128)     2: K <= 96, M <= 320 (MP 320), plain epilogue only
+//   4: K <= 320, M <= 64  (MP 64)
 int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s) {
     const int ntiles = (a.N + 15) / 16;
     const int g = ntiles < 256 ? ntiles : 256;                 // one block per CU and product
@@ -266,6 +267,8 @@ int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s)
     else if (variant == 0) { GLAM_PROF_LABEL("k_tall_x3<6, 4, 1>"); rc = launch_tall<6, 4, 1, 4, 4, 64, false>(two, grid, s); }
     else if (variant == 3 && epi) { GLAM_PROF_LABEL("k_tall_x3<9, 6, 1, epi>"); rc = launch_tall<9, 6, 1, 6, 3, 128, true>(two, grid, s); }
     else if (variant == 3) { GLAM_PROF_LABEL("k_tall_x3<9, 6, 1>"); rc = launch_tall<9, 6, 1, 6, 4, 128, false>(two, grid, s); }
+    else if (variant == 4 && epi) { GLAM_PROF_LABEL("k_tall_x3<10, 4, 1, epi>"); rc = launch_tall<10, 4, 1, 4, 3, 64, true>(two, grid, s); }
+    else if (variant == 4) { GLAM_PROF_LABEL("k_tall_x3<10, 4, 1>"); rc = launch_tall<10, 4, 1, 4, 4, 64, false>(two, grid, s); }
     else if (variant == 2 && !epi) { GLAM_PROF_LABEL("k_tall_x3<3, 4, 5>"); rc = launch_tall<3, 4, 5, 4, 4, 320, false>(two, grid, s); }
     else return fail(GLAM_E_UNSUPPORTED, "tall_x3: variant %d with a celu' / addend epilogue is outside the kernel table", variant);
     if (rc) return rc;

@@ -159,9 +159,19 @@ class _MatmulTall(torch.autograd.Function):
         ctx.carried = carry is not None
         if ctx.carried:
             ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
-        # (an 80 KB-image k_ts_gemm<4, 20, 4> for K <= 320 was measured here — NNConv's [N, 300] x [300, 60] relation product —: 18.9 us
-        # against the library's 15 at N = 20 k, at 256 registers: not kept)
-        out = torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
+        N, K = a.shape
+        M = w.size(1)
+        if K % 4 == 0 and M % 4 == 0 and K <= 320 and M <= 64 and N > 0 and os.environ.get("GLAM_X3", "1") != "0":
+            # NNConv's [N, 300] x [300, 60] relation product (and any K <= 320 x M <= 64): the long-reduction 3 x bf16 kernel (tall_x3.hip)
+            # (an 80 KB-image fp32 k_ts_gemm<4, 20, 4> measured 18.9 us against the library's 15 at N = 20 k and was not kept)
+            lib = _lib.load()
+            scope = ctx.scope
+            img = _o._scoped(scope.fwd if scope else None, ("tall-fwd", id(w)), w, lambda: _o._ts_image(w, K, M, False))
+            out = torch.empty(N, M, dtype=torch.float32, device=a.device)
+            check(lib.glam_ts_gemm(ptr(a), K, K, None, 0, 0, ptr(img), ptr(f32c(bias, "bias")) if bias is not None else None, ptr(out), M, M,
+                                   None, 0, 0, N, stream()), "glam_ts_gemm")
+        else:
+            out = torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
         return (out, carry.view(-1)) if ctx.carried else out
 
     @staticmethod

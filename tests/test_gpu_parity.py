@@ -484,7 +484,9 @@ def test_full_size_pool5_checksum(big, device):
     (20400, 92, 0, 276, 8, 0, False), (900, 92, 0, 276, 0, 1, True), (3, 96, 0, 320, 0, 0, True), (40000, 180, 0, 60, 0, 0, True),
     # the long-reduction shapes beyond the fp32 table (K <= 288, M <= 96: tall_x3.hip, hid_dim_alpha = 6), both operand sources, ragged N
     (20400, 276, 8, 92, 0, 1, False), (900, 276, 0, 92, 0, 0, True), (5, 288, 0, 96, 0, 0, True), (3001, 200, 0, 64, 0, 0, False),
-    (70000, 276, 8, 92, 0, 0, True), (20400, 180, 8, 60, 0, 1, True), (37, 100, 4, 8, 4, 0, True)])
+    (70000, 276, 8, 92, 0, 0, True), (20400, 180, 8, 60, 0, 1, True), (37, 100, 4, 8, 4, 0, True),
+    # K <= 320, M <= 64 (NNConv's relation product 300 -> 60)
+    (20400, 300, 0, 60, 0, 0, True), (1000, 320, 0, 64, 0, 1, False), (7, 292, 8, 12, 0, 0, True)])
 def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
