@@ -2317,6 +2317,28 @@ def test_skip_connection_through_the_conv_node(device, monkeypatch, C):
     assert raw.glam_triplet_layer_ws_supported(3, 32, 4, 1) == 0 and raw.glam_triplet_layer_ws_supported(3, 48, 4, 1) == 1
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_layer_backward_adds_the_skip_gradient_in_the_d_x_epilogue(device, ragged):
+    """_TripletLayer(with_identity=True): the gradient arriving at the handed-back input is added to d_x inside k_triplet_bwd_src_ws<ADD>
+    (full tiles with the counted wait, the ragged last tile behind the loop) — bit for bit the separate add."""
+    b = next(bb for bb in (synth_batch(24, seed=sd) for sd in range(200)) if (bb.x.size(0) % 16 != 0) == ragged).to(device)
+    N = b.x.size(0)
+    torch.manual_seed(N)
+    conv = layer.TripletMessage(60, 4).to(device)
+    x = torch.randn(N, 60, device=device, requires_grad=True)
+    cot, cot2 = torch.randn(N, 60, device=device), torch.randn(N, 60, device=device)
+    gi = ops.graph_index(b.edge_index, N)
+    args = (b.edge_attr, conv.weight_node, conv.weight_edge, conv.weight_triplet_att, conv.weight_scale, conv.bias, gi, 3, 0.2)
+    with ops.weight_scope():      # (the Python node: the route a captured step takes)
+        out, ident = ops._TripletLayer.apply(x, *args, None, True)
+        assert ident.data_ptr() == x.data_ptr() and torch.equal(out, ops._TripletLayer.apply(x, *args))
+        (g_both,) = torch.autograd.grad((out * cot).sum() + (ident * cot2).sum(), [x], retain_graph=True)
+        (g_conv,) = torch.autograd.grad((out * cot).sum(), [x], retain_graph=True)
+        (g_skip,) = torch.autograd.grad((ident * cot2).sum(), [x])
+    assert torch.equal(g_skip, cot2)
+    assert torch.equal(g_both, g_conv + cot2)
+
+
 @pytest.mark.parametrize("N,C,celu,hstate,ident", [(1, 64, True, True, True), (1000, 64, False, False, False), (20400, 60, True, True, True),
                                                    (17, 24, False, True, True), (0, 60, True, True, True)])
 def test_gru_bwd_ws_c_abi(device, N, C, celu, hstate, ident):
