@@ -17,7 +17,7 @@ struct TallArgs2 { TsArgs a, b; int first_b; };
 
 // row pitch of a plane in bytes: 64 KS of data + padding to 40 words mod 64 (the consumers' ds_read_b128 fragment reads — lane = row | 16-byte
 // k block — are then conflict free in all four 16-lane groups; triplet_pipe.h: kX3RowBytes)
-__host__ __device__ constexpr int tall_pitch(int KS) { return KS <= 6 ? 416 : 672; }
+__host__ __device__ constexpr int tall_pitch(int KS) { return KS <= 2 ? 160 : KS <= 6 ? 416 : 672; }
 // bytes per row of an epilogue plane: 16 NC floats + 4 (the consumers' four row groups then read disjoint banks)
 __host__ __device__ constexpr int tall_epi_pitch(int NC) { return (16 * NC + 4) * 4; }
 __host__ __device__ constexpr int tall_tile_bytes(int KS, int NC, bool epi) { return 3 * 16 * tall_pitch(KS) + (epi ? 2 * 16 * tall_epi_pitch(NC) : 0); }
@@ -263,7 +263,13 @@ int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s)
     const int grid = b ? 2 * g : g;
     const bool epi = a.cgrad_src || a.addend || (b && (b->cgrad_src || b->addend));
     int rc;
-    if (variant == 0 && epi) { GLAM_PROF_LABEL("k_tall_x3<6, 4, 1, epi>"); rc = launch_tall<6, 4, 1, 4, 4, 64, true>(two, grid, s); }
+    // the narrow layers of the search space (hid_dim 15 / 30: K = 16 .. 104) do not pay for six 32-k steps per tile
+    const int Kmax = (a.K1 + a.K2) > (b ? b->K1 + b->K2 : 0) ? (a.K1 + a.K2) : (b->K1 + b->K2);
+    if (variant == 0 && Kmax <= 64 && epi) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1, epi>"); rc = launch_tall<2, 4, 1, 4, 4, 64, true>(two, grid, s); }
+    else if (variant == 0 && Kmax <= 64) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>"); rc = launch_tall<2, 4, 1, 4, 4, 64, false>(two, grid, s); }
+    else if (variant == 0 && Kmax <= 128 && epi) { GLAM_PROF_LABEL("k_tall_x3<4, 4, 1, epi>"); rc = launch_tall<4, 4, 1, 4, 4, 64, true>(two, grid, s); }
+    else if (variant == 0 && Kmax <= 128) { GLAM_PROF_LABEL("k_tall_x3<4, 4, 1>"); rc = launch_tall<4, 4, 1, 4, 4, 64, false>(two, grid, s); }
+    else if (variant == 0 && epi) { GLAM_PROF_LABEL("k_tall_x3<6, 4, 1, epi>"); rc = launch_tall<6, 4, 1, 4, 4, 64, true>(two, grid, s); }
     else if (variant == 0) { GLAM_PROF_LABEL("k_tall_x3<6, 4, 1>"); rc = launch_tall<6, 4, 1, 4, 4, 64, false>(two, grid, s); }
     else if (variant == 3 && epi) { GLAM_PROF_LABEL("k_tall_x3<9, 6, 1, epi>"); rc = launch_tall<9, 6, 1, 6, 3, 128, true>(two, grid, s); }
     else if (variant == 3) { GLAM_PROF_LABEL("k_tall_x3<9, 6, 1>"); rc = launch_tall<9, 6, 1, 6, 4, 128, false>(two, grid, s); }
