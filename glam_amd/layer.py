@@ -829,6 +829,12 @@ class LinearBlock(torch.nn.Module):
     def forward(self, x, batch=None):
         x = self.norm(x, batch)
         x = _apply_dropout(self.dropout, x)
+        a = self.act
+        if type(a) is ReLU or type(a) is LeakyReLU:      # deterministic: the dense linear's epilogue applies it (readout MLP)
+            y = ops.linear_act(x, self.linear.weight, self.linear.bias, "relu" if type(a) is ReLU else "leaky",
+                               getattr(a, "negative_slope", 0.0))
+            if y is not None:
+                return y
         x = ops.linear(x, self.linear.weight, self.linear.bias)
         return _apply_act(self.act, x)
 

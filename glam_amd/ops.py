@@ -1000,6 +1000,8 @@ GRU_FUSED_MIN_NODES = 16384
 GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
 # MessageBlock's skip connection handed through the conv's autograd node (the d_x product's epilogue sums both gradient paths): A/B switch
 SKIP_THROUGH_CONV = os.environ.get("GLAM_SKIP_THROUGH_CONV", "1") == "1"
+# the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch
+DENSE_LINEAR = os.environ.get("GLAM_DENSE_LINEAR", "1") == "1"
 
 
 # ---- the dense and readout operator families live in their own modules; their names are part of this namespace ----

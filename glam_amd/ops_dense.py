@@ -415,6 +415,68 @@ class _LinearLib(torch.autograd.Function):
         return dx, dw, db
 
 
+def linear_dense_supported(N, K, M):
+    """The square-ish class of ``csrc/dense_x3.hip`` (the readout MLP, 5 * hid_dim -> 1024): every row a multiple of 16 bytes (the kernel's
+    scalar path for other shapes is slower than the library it replaces) and enough rows for the weight gradient's reduction."""
+    return K % 4 == 0 and M % 4 == 0 and K >= 32 and N >= 4
+
+
+class _LinearDense(torch.autograd.Function):
+    """``act(F.linear(x, w, b))`` with act in {none, ReLU, LeakyReLU} on ``glam_linear_dense_fwd`` (3 x bf16 matrix cores, bias and
+    activation in the epilogue) and the whole backward — activation derivative on ``dy`` (read from the saved OUTPUT), ``dx``, ``dw``
+    and the bias gradient — in one ``glam_linear_dense_bwd`` launch: the products of the readout MLP (src_1gp/model.py:43-45, 60) that
+    ran on the GEMM library with an activation, a mask and a column-sum launch around them."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        require_device(x, w)
+        x, w = f32c(x, "x"), f32c(w, "weight")
+        b = None if b is None else f32c(b, "bias")
+        N, K = x.shape
+        M = w.size(0)
+        y = torch.empty(N, M, dtype=torch.float32, device=x.device)
+        check(_lib.load().glam_linear_dense_fwd(ptr(x), ptr(w), ptr(b), N, K, M, act, slope, ptr(y), stream()), "glam_linear_dense_fwd")
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.has_bias, ctx.slope = b is not None, (0.0 if act == 1 else slope)
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None, None
+        x, w, y = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        f = dict(dtype=torch.float32, device=x.device)
+        dx = torch.empty(N, K, **f) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(M, K, **f)
+        db = torch.empty(M, **f) if ctx.has_bias else None
+        check(_lib.load().glam_linear_dense_bwd(ptr(x), ptr(w), ptr(dy), ptr(y), ctx.slope, N, K, M, ptr(dx), ptr(dw), ptr(db), stream()),
+              "glam_linear_dense_bwd")
+        return dx, dw, db, None, None
+
+
+_DENSE_ACT = {"none": 0, "relu": 1, "leaky": 2}
+
+
+def _dense_route(x, weight, bias):
+    M, K = weight.shape
+    f32 = x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+    return (_o.DENSE_LINEAR and x.dim() == 2 and x.is_cuda and f32 and not linear_supported(K, M) and M > 16 and linear_dense_supported(x.size(0), K, M)
+            and _o.padded_base(x) is None)
+
+
+def linear_act(x, weight, bias, act="none", slope=0.0):
+    """``act(F.linear(x, weight, bias))`` for a deterministic elementwise activation (``"none"``, ``"relu"``, ``"leaky"``) in one launch
+    each way where the shape is in the dense kernel's class; ``None`` elsewhere (the caller applies ``linear`` and its activation)."""
+    if not _dense_route(x, weight, bias):
+        return None
+    return _LinearDense.apply(x, weight, bias, _DENSE_ACT[act], float(slope))
+
+
 def linear(x, weight, bias=None):
     """``F.linear`` on the hand-written kernels when the shape is in their table (the layer-sized linears of the
     path: GRU gates 60->180, input embedding 15->60, ... on the MFMA kernels; heads with <= 16 outputs as row dot products);
@@ -423,6 +485,8 @@ def linear(x, weight, bias=None):
     f32 = x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
     if x.dim() == 2 and x.is_cuda and f32 and M <= 16 and K >= 64 and K % 4 == 0 and not linear_supported(K, M):
         return _LinearNarrow.apply(x, weight, bias)      # (other dtypes — fp64, autocast — fall through to F.linear below)
+    if _dense_route(x, weight, bias):
+        return _LinearDense.apply(x, weight, bias, 0, 0.0)
     if x.dim() != 2 or not linear_supported(K, M):
         if x.dim() == 2 and x.is_cuda and bias is not None and M % 4 == 0 and x.dtype == torch.float32 and weight.dtype == torch.float32:
             return _LinearLib.apply(x, weight, bias)

@@ -565,6 +565,27 @@ int glam_linear_narrow_bwd(const float* x, const float* w, const float* dy, int6
 size_t glam_colsum_workspace_bytes(int D);
 int glam_colsum(const float* x, int64_t N, int D, int ld, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Square-ish fp32 products on the bf16 matrix cores in 3 x bf16 form (fp32 accuracy; csrc/dense_x3.hip): the readout MLP of the model
+ * (`mol_flat` LinearBlock(5 * hid_dim, e_dim = 1024) and wide output heads; /root/reference/src_1gp/model.py:43-45,60-61, LinearBlock
+ * src_1gp/layer.py:196-209 = norm -> dropout -> nn.Linear -> act), i.e. torch's F.linear and its autograd for matrices with ~1000 rows.
+ *
+ *   C[R, Cn] = act( A . B + bias ),  A(r, k) = A[r * a_rs + k * a_ks] * (gate(r, k) > 0 ? 1 : gate_slope),  B(k, c) = B[k * b_ks + c * b_cs]
+ *
+ * exactly one stride of each pair is 1 (any of the four layout combinations; no transposed copies are made).  gate (same strides as
+ * A) and bias[Cn] may be NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), applied after the bias.  rowsum non-NULL (needs
+ * b_cs == 1): rowsum[r] = sum_k A(r, k) (a virtual all-ones column of B).  K >= 4; 16-byte accesses are used where alignment and the
+ * dimensions allow (multiples of 4), scalar ones elsewhere.  Deterministic (no atomics, no split reductions). */
+int glam_dense_gemm(const float* A, int64_t a_rs, int64_t a_ks, const float* gate, float gate_slope, const float* B, int64_t b_ks,
+                    int64_t b_cs, const float* bias, int act, float act_slope, float* C, int64_t ldc, float* rowsum, int R, int Cn, int K,
+                    void* stream);
+/* y[N, M] = act(x[N, K] w[M, K]^T + b) — nn.Linear + a fused ReLU / LeakyReLU — on glam_dense_gemm's kernel (b may be NULL). */
+int glam_linear_dense_fwd(const float* x, const float* w, const float* b, int64_t N, int K, int M, int act, float slope, float* y,
+                          void* stream);
+/* Its backward in ONE launch: with g = dy * (y_gate > 0 ? 1 : gate_slope) (y_gate = the forward's OUTPUT when an activation was
+ * fused, NULL otherwise): dx[N, K] = g w, dw[M, K] = g^T x, db[M] = column sums of g.  dx may be NULL; db may be NULL; N >= 4. */
+int glam_linear_dense_bwd(const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope, int64_t N, int K, int M,
+                          float* dx, float* dw, float* db, void* stream);
+
 /* One Adam step over n parameter tensors in one launch per 40 tensors — the optimizer of the training loop that drives the path
  * (`Adam(self.model.parameters(), lr=args.lr)`, src_1gp/trainer.py:49-50, stepped at trainer.py:301; torch.optim.Adam semantics
  * without amsgrad / maximize; weight_decay is the L2 form).  table: HOST array [n][4] of device addresses {param, grad, exp_avg,

@@ -1938,7 +1938,7 @@ def test_pipelined_forward_is_bit_identical_to_the_general_kernel(device, H, C, 
     the same tensors: equal bit for bit — molecules with isolated atoms and every in-degree 0..4, N not a multiple of the pass
     size, both LDS-DMA and register variants of the pipeline.  Graphs with an in-degree above 4 report no ELL form."""
     from glam_amd import _lib
-    lib, p, st = _lib.load(), _lib.ptr, _lib.stream
+    lib, p, st = ops._lib.load(), ops._lib.ptr, ops._lib.stream
     torch.manual_seed(H * 100 + C)
     b = synth_batch(300, seed=C + H)
     N0 = b.x.size(0)
@@ -2805,3 +2805,84 @@ def test_relation_mlp_against_torch_and_fp64(device, De, Hd, C):
     assert_fp32_parity(out, res[torch.float64][0], res[torch.float32][0], "relation table", out_tol=1e-5)
     for n, a, r64, r32 in zip(["w1", "b1", "w2", "b2"], gs, res[torch.float64][1], res[torch.float32][1]):
         assert_fp32_parity(a, r64, r32, "relation mlp d_" + n)
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("R,Cn,K", [(1024, 1024, 300), (100, 300, 1024), (257, 75, 33), (5, 617, 450)])
+def test_dense_gemm_c_abi(device, a_kc, b_kc, R, Cn, K):
+    """glam_dense_gemm in all four layout combinations, with and without gate / bias / activation / the all-ones column, 16-byte and
+    scalar access paths, ragged tiles and a partial last chunk, against the fp64 product: fp32 accuracy from the 3 x bf16 form."""
+    lib, p, st = ops._lib.load(), ops._lib.ptr, ops._lib.stream
+    g = torch.Generator().manual_seed(R * 7 + Cn * 3 + K + 2 * a_kc + b_kc)
+    A, G, B, bv = (torch.randn(R, K, generator=g), torch.randn(R, K, generator=g), torch.randn(K, Cn, generator=g),
+                   torch.randn(Cn, generator=g))
+    Ad, Gd = ((A, G) if a_kc else (A.t().contiguous(), G.t().contiguous()))
+    Ad, Gd, Bd, bd = Ad.to(device), Gd.to(device), (B.t().contiguous() if b_kc else B).to(device), bv.to(device)
+    for gate, bias, act, ones in [(False, False, 0, False), (True, True, 1, True), (True, False, 2, False), (False, True, 2, True)]:
+        ones = ones and not b_kc and Cn > 1
+        gs, sl = 0.25, 0.125
+        Ag = A.double() * torch.where(G > 0, 1.0, gs).double() if gate else A.double()
+        ref = Ag @ B.double() + (bv.double() if bias else 0.0)
+        ref = ref.clamp_min(0) if act == 1 else torch.where(ref > 0, ref, ref * sl) if act == 2 else ref
+        ldc = Cn + 4
+        C = torch.full((R, ldc), float("nan"), device=device)
+        rs = torch.full((R,), float("nan"), device=device)
+        rc = lib.glam_dense_gemm(p(Ad), K if a_kc else 1, 1 if a_kc else R, p(Gd) if gate else None, gs, p(Bd), 1 if b_kc else Cn,
+                                 K if b_kc else 1, p(bd) if bias else None, act, sl, p(C), ldc, p(rs) if ones else None, R, Cn, K, st())
+        assert rc == 0, lib.glam_last_error()
+        tol = 2e-6 * max(1.0, K ** 0.5 / 8)
+        err = (C[:, :Cn].cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        assert err < tol, (gate, bias, act, ones, err)
+        assert torch.isnan(C[:, Cn:]).all(), "wrote beyond Cn"
+        if ones:
+            want = Ag.sum(1)
+            assert (rs.cpu().double() - want).abs().max().item() / max(1.0, want.abs().max().item()) < tol
+
+
+@pytest.mark.parametrize("N,K,M,act", [(1024, 300, 1024, "relu"), (642, 300, 1024, "leaky"), (33, 64, 128, "none"), (2039, 300, 1024, "relu")])
+def test_linear_dense_forward_backward_against_fp64(device, N, K, M, act):
+    """The readout MLP's linear on the dense kernel (ops.linear_act -> glam_linear_dense_fwd / _bwd: bias + activation in the epilogue,
+    activation derivative + dx + dw + db in one launch) against F.linear + the activation in fp64 (src_1gp/model.py:43-45, 60)."""
+    import torch.nn.functional as F
+    torch.manual_seed(N + K)
+    x = torch.randn(N, K, device=device, requires_grad=True)
+    w = (torch.randn(M, K, device=device) * K ** -0.5).requires_grad_(True)
+    b = torch.randn(M, device=device, requires_grad=True)
+    y = ops.linear_act(x, w, b, act, 0.2)
+    assert y is not None
+    cot = torch.randn_like(y)
+    got = torch.autograd.grad(y, (x, w, b), cot)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    pre = F.linear(xd, wd, bd)
+    # the derivative follows the sign of the kernel's own output (an element whose pre-activation is within rounding of zero may fall on
+    # either side of the kink: of 2 M elements a few do)
+    slope = {"relu": 0.0, "leaky": 0.2, "none": 1.0}[act]
+    yd = pre * torch.where(y.detach().double() > 0, 1.0, slope)
+    ref = torch.autograd.grad(yd, (xd, wd, bd), cot.double())
+    want = torch.relu(pre) if act == "relu" else F.leaky_relu(pre, 0.2) if act == "leaky" else pre
+    assert ((y.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+    for gg, rr, name in zip(got, ref, ("dx", "dw", "db")):
+        assert ((gg.double() - rr).abs().max() / rr.abs().max()).item() < 3e-6 * max(1.0, N ** 0.5 / 16), name
+    # without input gradient (the first layer of a model) and without bias
+    y2 = ops.linear_act(x.detach(), w, None, act, 0.2)
+    gw, = torch.autograd.grad(y2, (w,), cot)
+    yd2 = F.linear(xd.detach(), wd) * torch.where(y2.detach().double() > 0, 1.0, slope)
+    rw, = torch.autograd.grad(yd2, (wd,), cot.double())
+    assert ((gw.double() - rw).abs().max() / rw.abs().max()).item() < 3e-6 * max(1.0, N ** 0.5 / 16)
+
+
+def test_linear_block_routes_the_readout_mlp_to_the_dense_kernel(device):
+    """LinearBlock(300, 1024, act=ReLU) — `mol_flat` of the parity configuration — runs as one dense launch each way and agrees with
+    the unfused composition; shapes outside the class (K = 450: rows not 16-byte multiples) keep the library route."""
+    torch.manual_seed(3)
+    blk = layer.LinearBlock(300, 1024, act="ReLU()").to(device)
+    x = torch.randn(256, 300, device=device, requires_grad=True)
+    y = blk(x)
+    assert type(y.grad_fn).__name__.startswith("_LinearDense")
+    ref = torch.relu(torch.nn.functional.linear(x, blk.linear.weight, blk.linear.bias))
+    assert_close(y, ref, 5e-6, "LinearBlock dense")
+    gy, gr = torch.autograd.grad(y.sum() + (y * y).sum(), x)[0], torch.autograd.grad(ref.sum() + (ref * ref).sum(), x)[0]
+    assert_close(gy, gr, 1e-5, "LinearBlock dense dx")
+    blk2 = layer.LinearBlock(450, 1024, act="ReLU()").to(device)
+    assert not type(blk2(torch.randn(64, 450, device=device)).grad_fn).__name__.startswith("_LinearDense")
+

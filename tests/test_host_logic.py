@@ -400,3 +400,25 @@ def test_pad_group_and_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.glam_gru_bwd_ws(None, None, None, None, None, None, None, None, None, 4, 62, 0, 1, 0.0, 0, None, None, None, None, None, None) == _lib.GLAM_E_UNSUPPORTED
     assert lib.glam_pool5_padded_fwd(None, None, 4, 2, 50, 45, 3, None, None, None) == _lib.GLAM_E_INVALID             # ld is not ceil4(D)
     assert lib.glam_ts_gemm_image_bytes(276, 92) > 0 and lib.glam_ts_gemm_image_bytes(300, 92) >= 0
+
+
+def test_dense_gemm_entry_points_reject_bad_arguments_without_a_gpu():
+    """glam_dense_gemm / glam_linear_dense_fwd / _bwd check strides, sizes and the all-ones column's layout before any launch."""
+    lib = _lib.load()
+    p = 1 << 20
+    inv = _lib.GLAM_E_INVALID
+    assert lib.glam_dense_gemm(p, 300, 2, None, 0.0, p, 1, 300, None, 0, 0.0, p, 64, None, 8, 64, 300, None) == inv      # no unit stride in A
+    assert b"A's strides" in lib.glam_last_error()
+    assert lib.glam_dense_gemm(p, 300, 1, None, 0.0, p, 3, 300, None, 0, 0.0, p, 64, None, 8, 64, 300, None) == inv      # ... nor in B
+    assert lib.glam_dense_gemm(p, 300, 1, None, 0.0, p, 1, 300, None, 0, 0.0, p, 64, p, 8, 64, 300, None) == inv         # ones column, B along k
+    assert lib.glam_dense_gemm(p, 300, 1, None, 0.0, p, 1, 300, None, 3, 0.0, p, 64, None, 8, 64, 300, None) == inv      # unknown activation
+    assert lib.glam_dense_gemm(p, 300, 1, None, 0.0, p, 1, 300, None, 0, 0.0, p, 60, None, 8, 64, 300, None) == inv      # ldc < Cn
+    assert lib.glam_dense_gemm(p, 2, 1, None, 0.0, p, 1, 2, None, 0, 0.0, p, 64, None, 8, 64, 2, None) == inv            # K < 4
+    assert lib.glam_dense_gemm(None, 300, 1, None, 0.0, p, 1, 300, None, 0, 0.0, p, 64, None, 8, 64, 300, None) == inv   # null operand
+    assert lib.glam_linear_dense_fwd(p, p, None, 0, 300, 64, 0, 0.0, p, None) == inv
+    assert lib.glam_linear_dense_bwd(p, p, p, None, 0.0, 2, 300, 64, p, p, None, None) == inv                            # N < 4
+    assert lib.glam_linear_dense_bwd(p, p, p, None, 0.0, 8, 300, 64, None, None, None, None) == inv                      # nothing to compute
+    assert lib.glam_linear_dense_bwd(p, p, p, None, 0.0, 8, 300, 64, p, None, p, None) == inv                            # db without dw
+    assert ops.linear_dense_supported(1024, 300, 1024) and not ops.linear_dense_supported(1024, 450, 1024)
+    assert not ops.linear_dense_supported(2, 300, 1024) and not ops.linear_dense_supported(1024, 300, 617)
+
