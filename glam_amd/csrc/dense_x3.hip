@@ -28,8 +28,6 @@ namespace glam {
 #ifdef GLAM_DENSE_STAMP
 __device__ long long g_dense_prof[8 * 2 * 64];
 #endif
-namespace {
-
 constexpr int kGK = 32;                 // k per chunk
 #ifndef GLAM_DENSE_DEPTH
 #define GLAM_DENSE_DEPTH 2
@@ -496,7 +494,7 @@ struct Product {
     float* C; int64_t ldc; float* rowsum; int R, Cn, K;
 };
 
-int check_product(const Product& p, const char* what) {
+static int check_product(const Product& p, const char* what) {
     GLAM_REQUIRE(p.R >= 1 && p.Cn >= 1 && p.K >= 4, "%s: R = %d, Cn = %d must be >= 1 and K = %d >= 4", what, p.R, p.Cn, p.K);
     GLAM_REQUIRE(p.A && p.B && p.C, "%s: null operand", what);
     // (both strides 1: a single row / column — read as rows along k)
@@ -509,7 +507,7 @@ int check_product(const Product& p, const char* what) {
     return 0;
 }
 
-void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
+static void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
     j.A = p.A; j.a_rs = p.a_rs; j.a_ks = p.a_ks; j.gate = p.gate; j.gate_slope = p.gate_slope;
     j.B = p.B; j.b_ks = p.b_ks; j.b_cs = p.b_cs; j.bias = p.bias; j.act = p.act; j.act_slope = p.act_slope;
     j.C = p.C; j.ldc = p.ldc; j.rowsum = p.rowsum; j.R = p.R; j.Cn = p.Cn; j.K = p.K;
@@ -526,7 +524,7 @@ void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
     j.c_vec = aligned16(p.C) && p.ldc % 4 == 0;
 }
 
-int launch_products(const Product* p, int n, hipStream_t s) {
+static int launch_products(const Product* p, int n, hipStream_t s) {
     // 64-row tiles; 32-row tiles (twice the blocks) for the small batches that would leave most of the chip idle
     long long t64 = 0;
     for (int i = 0; i < n; ++i) t64 += (long long)((p[i].R + 63) / 64) * ((p[i].Cn + (p[i].rowsum ? 1 : 0) + 63) / 64);
@@ -549,7 +547,6 @@ int launch_products(const Product* p, int n, hipStream_t s) {
     return 0;
 }
 
-}  // namespace
 }  // namespace glam
 
 using namespace glam;
