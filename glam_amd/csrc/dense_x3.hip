@@ -47,7 +47,7 @@ struct GemmJob {
     float* rowsum;                              // non-null: virtual B column Cn == 1, its result goes to rowsum[r]
     int R, Cn, K;
     int tiles_r, tiles_c, first_tile;
-    int vec, c_vec;                             // 16-byte loads of A, gate and B / stores of C allowed (alignment, multiples of 4)
+    int vec, c_vec;                             // the 16-byte load path / 16-byte stores of C (aligned, ldc % 4 == 0)
 };
 struct GemmArgs { GemmJob job[2]; int njobs; int ntiles; int per_xcd; };
 
@@ -184,13 +184,21 @@ __device__ __forceinline__ Bf16x3 frag_read(const char* planes, int row, int g) 
 // partial chunk.  The loop then issues ld4(pointer), advances it, splits and writes — no selects, no bounds, no 64-bit index math.
 __device__ const float4 g_zero_quad = {0.f, 0.f, 0.f, 0.f};
 
-template <int ROWS, bool GATE, bool KC>
+// A quad whose last 4 - nv elements lie beyond the row (or beyond K) is loaded 4 - nv elements EARLIER — it ends where the data ends, no
+// byte outside the matrix is touched — and moved into place here: r[i] = e[i + 4 - nv] for i < nv, 0 beyond.
+__device__ __forceinline__ float4 shifted(float4 e, int nv) {
+    return make_float4(nv == 4 ? e.x : nv == 3 ? e.y : nv == 2 ? e.z : e.w, nv == 4 ? e.y : nv == 3 ? e.z : nv == 2 ? e.w : 0.f,
+                       nv == 4 ? e.z : nv == 3 ? e.w : 0.f, nv == 4 ? e.w : 0.f);
+}
+
+template <int ROWS, bool GATE, bool KC, bool PART>
 struct VecStage {
     static constexpr int NI = (KC && ROWS == 32) ? 1 : 2;
     const float* p[NI];
     const float* gp[NI];
     long long step[NI];
     bool dead[NI];         // beyond K in the partial last chunk
+    int nv[NI];            // elements of the quad that exist (rows along k: in the partial last chunk; rows across k: in every chunk)
     float4 q[NI], g[NI];
     int ones_e;            // rows across k only: which of the item's four rows is the all-ones row (-1 none)
 
@@ -208,18 +216,21 @@ struct VecStage {
                 p[j] = ok ? base + off : zeros;
                 gp[j] = (GATE && ok) ? gate + off : zeros;
                 step[j] = ok ? kGK : 0;
-                dead[j] = ktail + k >= K;
+                nv[j] = ok ? max(min(K - (ktail + k), 4), 0) : 4;        // (rows beyond the matrix read the zero block as it is)
+                dead[j] = nv[j] == 0;
             }
         } else {
             const int kp = t & 15, rq = (t >> 4) & (ROWS / 4 - 1), pos = row0 + 4 * rq;
-            const bool ok = pos < nrows;
+            const int nvp = max(min(nrows - pos, 4), 0);
+            const bool ok = nvp > 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int k = 2 * kp + j;
-                const long long off = (long long)k * ls + pos;
+                const long long off = (long long)k * ls + pos - (4 - nvp);       // (a partial quad starts earlier: see shifted())
                 p[j] = ok ? base + off : zeros;
                 gp[j] = (GATE && ok) ? gate + off : zeros;
                 step[j] = ok ? kGK * ls : 0;
+                nv[j] = ok ? nvp : 4;
                 dead[j] = ktail + k >= K;
             }
             if (ones_at >= pos && ones_at < pos + 4) ones_e = ones_at - pos;
@@ -232,19 +243,23 @@ struct VecStage {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const bool z = allz || (tailc && dead[j]);
-            q[j] = ld4(z ? zeros : p[j]);
-            if (GATE) g[j] = ld4(z ? zeros : gp[j]);
+            const int back = (PART && KC && tailc) ? 4 - nv[j] : 0;  // rows along k: the partial quad of the last chunk
+            q[j] = ld4(z ? zeros : p[j] - back);
+            if (GATE) g[j] = ld4(z ? zeros : gp[j] - back);
             p[j] += step[j];
             if (GATE) gp[j] += step[j];
         }
     }
-    __device__ __forceinline__ void store(char* planes, float gate_slope, bool ones_live, int k0, int K, int t) const {
+    // partial (uniform): this chunk / tile has quads that reach beyond the data (rows along k: the last chunk; across k: the last tile)
+    __device__ __forceinline__ void store(char* planes, float gate_slope, bool ones_live, bool partial, int k0, int K, int t) const {
         if (KC) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int item = t + 256 * j, row = item >> 3, kq = item & 7;
                 float4 v = pinned(q[j]);
-                if (GATE) v = gated(v, pinned(g[j]), gate_slope);
+                float4 gv = GATE ? pinned(g[j]) : v;
+                if (PART && partial && !dead[j]) { v = shifted(v, nv[j]); if (GATE) gv = shifted(gv, nv[j]); }
+                if (GATE) v = gated(v, gv, gate_slope);
                 unsigned h[2], m[2], l[2];
                 split2(v.x, v.y, h[0], m[0], l[0]);
                 split2(v.z, v.w, h[1], m[1], l[1]);
@@ -257,7 +272,12 @@ struct VecStage {
             const int kp = t & 15, rq = t >> 4;
             if (ROWS == 64 || rq < ROWS / 4) {
                 float4 v0 = pinned(q[0]), v1 = pinned(q[1]);
-                if (GATE) { v0 = gated(v0, pinned(g[0]), gate_slope); v1 = gated(v1, pinned(g[1]), gate_slope); }
+                float4 g0 = GATE ? pinned(g[0]) : v0, g1 = GATE ? pinned(g[1]) : v1;
+                if (PART && partial) {
+                    v0 = shifted(v0, nv[0]); v1 = shifted(v1, nv[1]);
+                    if (GATE) { g0 = shifted(g0, nv[0]); g1 = shifted(g1, nv[1]); }
+                }
+                if (GATE) { v0 = gated(v0, g0, gate_slope); v1 = gated(v1, g1, gate_slope); }
                 if (ones_live && ones_e >= 0) {          // (ones_live is uniform: only the last column tile has the row)
                     const int k = k0 + 2 * kp;
                     const float o0 = k < K ? 1.f : 0.f, o1 = k + 1 < K ? 1.f : 0.f;
@@ -308,7 +328,7 @@ __device__ __forceinline__ void mma_chunk(const char* bufA, const char* bufB, in
 
 // One (TR x 64) tile of one product.  Waves 2 x 2: wave (wr, wc) owns rows wr * TR/2 .. and columns wc * 32 ..; B's fragment is the
 // FIRST operand of the matrix instruction, so a lane ends up with four consecutive COLUMNS of one row of C (16-byte stores).
-template <int TR, bool GATE, bool AKC, bool BKC, bool VEC>
+template <int TR, bool GATE, bool AKC, bool BKC, int VEC>      // VEC: 0 scalar loads, 1 16-byte loads of whole quads, 2 ... with partial quads
 __device__ __forceinline__ void gemm_tile(const GemmJob& jb, int tile, char* lds) {
     constexpr int MI = TR / 32;
     // Two groups of four waves take alternate chunks, half a step apart: while one group splits and writes its next chunk (vector
@@ -349,19 +369,20 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& jb, int tile, char* lds
         const int nfull = jb.K / kGK;
         const bool has_tail = (jb.K & (kGK - 1)) != 0;
         const bool ones_live = ones_at >= col0 && ones_at < col0 + 64;
-        VecStage<TR, GATE, AKC> sa[kDepth];
-        VecStage<64, false, BKC> sb[kDepth];
+        const bool a_edge = row0 + TR > jb.R, b_edge = col0 + 64 > ncols_b;
+        VecStage<TR, GATE, AKC, VEC == 2> sa[kDepth];
+        VecStage<64, false, BKC, VEC == 2> sb[kDepth];
 #pragma unroll
         for (int s = 0; s < kDepth; ++s) {
             sa[s].init(jb.A, jb.gate, a_ls, row0, jb.R, jb.K, -1, t);
             sb[s].init(jb.B, nullptr, b_ls, col0, ncols_b, jb.K, ones_at, t);
             const int first = 2 * s + grp;              // stage s of group grp starts at chunk 2 s + grp and advances by 2 kDepth
 #pragma unroll
-            for (int j = 0; j < VecStage<TR, GATE, AKC>::NI; ++j) {
+            for (int j = 0; j < VecStage<TR, GATE, AKC, false>::NI; ++j) {
                 sa[s].p[j] += first * sa[s].step[j]; sa[s].gp[j] += first * sa[s].step[j]; sa[s].step[j] *= 2 * kDepth;
             }
 #pragma unroll
-            for (int j = 0; j < VecStage<64, false, BKC>::NI; ++j) { sb[s].p[j] += first * sb[s].step[j]; sb[s].step[j] *= 2 * kDepth; }
+            for (int j = 0; j < VecStage<64, false, BKC, false>::NI; ++j) { sb[s].p[j] += first * sb[s].step[j]; sb[s].step[j] *= 2 * kDepth; }
             sa[s].load(first, nfull, has_tail);
             sb[s].load(first, nfull, has_tail);
         }
@@ -370,8 +391,9 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& jb, int tile, char* lds
 #pragma unroll
             for (int s = 0; s < kDepth; ++s) {
                 const int c = 2 * (i0 + s) + grp;
-                sa[s].store(bufA, jb.gate_slope, false, c * kGK, jb.K, t);
-                sb[s].store(bufB, 0.f, ones_live, c * kGK, jb.K, t);
+                const bool tail = has_tail && c == nfull;
+                sa[s].store(bufA, jb.gate_slope, false, AKC ? tail : a_edge, c * kGK, jb.K, t);
+                sb[s].store(bufB, 0.f, ones_live, BKC ? tail : b_edge, c * kGK, jb.K, t);
                 DSTAMP(2 + 4 * (i0 + s));
                 __syncthreads();
                 DSTAMP(3 + 4 * (i0 + s));
@@ -477,8 +499,9 @@ __global__ void __launch_bounds__(512) k_dense_x3(GemmArgs a) {
     // one branch around the whole tile: layout of A, layout of B, gate, 16-byte accesses
 #define GLAM_DENSE_CASE(G, AK, BK)                                                     \
     case ((G) * 4 + (AK) * 2 + (BK)):                                                  \
-        if (jb.vec) gemm_tile<TR, G, AK, BK, true>(jb, tl, lds);                       \
-        else gemm_tile<TR, G, AK, BK, false>(jb, tl, lds);                             \
+        if (jb.vec == 1) gemm_tile<TR, G, AK, BK, 1>(jb, tl, lds);                     \
+        else if (jb.vec == 2) gemm_tile<TR, G, AK, BK, 2>(jb, tl, lds);                \
+        else gemm_tile<TR, G, AK, BK, 0>(jb, tl, lds);                                 \
         break;
     switch ((jb.gate ? 4 : 0) + (jb.a_ks == 1 ? 2 : 0) + (jb.b_ks == 1 ? 1 : 0)) {
         GLAM_DENSE_CASE(false, false, false) GLAM_DENSE_CASE(false, false, true) GLAM_DENSE_CASE(false, true, false)
@@ -514,13 +537,11 @@ static void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
     j.tiles_r = (p.R + TR - 1) / TR;
     j.tiles_c = (p.Cn + (p.rowsum ? 1 : 0) + 63) / 64;
     j.first_tile = first_tile;
-    // 16-byte accesses: the quads run along the unit-stride dimension; every line start and the quad positions must be multiples of 4
-    const int64_t a_ls = p.a_ks == 1 ? p.a_rs : p.a_ks;
-    const int a_npos = p.a_ks == 1 ? p.K : p.R;
-    const int64_t b_ls = p.b_ks == 1 ? p.b_cs : p.b_ks;
-    const int b_npos = p.b_ks == 1 ? p.K : p.Cn;
-    j.vec = aligned16(p.A) && a_ls % 4 == 0 && a_npos % 4 == 0 && (!p.gate || aligned16(p.gate)) && aligned16(p.B) && b_ls % 4 == 0 &&
-            b_npos % 4 == 0;
+    // 16-byte loads need dword alignment only on this hardware; the fast path needs room to start a partial quad early (shifted()):
+    // at least 4 elements along the unit-stride dimension of both operands (K >= 4 is required anyway)
+    j.vec = (p.a_ks == 1 || p.R >= 4) && (p.b_ks == 1 || p.Cn >= 4);
+    // 2: some quad of some row is partial (the reduction length for rows along k, the row / column count for rows across k)
+    if (j.vec && (((p.a_ks == 1 || p.b_ks == 1) && p.K % 4) || (p.a_ks != 1 && p.R % 4) || (p.b_ks != 1 && p.Cn % 4))) j.vec = 2;
     j.c_vec = aligned16(p.C) && p.ldc % 4 == 0;
 }
 

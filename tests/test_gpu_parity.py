@@ -2839,7 +2839,8 @@ def test_dense_gemm_c_abi(device, a_kc, b_kc, R, Cn, K):
             assert (rs.cpu().double() - want).abs().max().item() / max(1.0, want.abs().max().item()) < tol
 
 
-@pytest.mark.parametrize("N,K,M,act", [(1024, 300, 1024, "relu"), (642, 300, 1024, "leaky"), (33, 64, 128, "none"), (2039, 300, 1024, "relu")])
+@pytest.mark.parametrize("N,K,M,act", [(1024, 300, 1024, "relu"), (642, 300, 1024, "leaky"), (33, 64, 128, "none"), (2039, 300, 1024, "relu"),
+                                        (1024, 75, 1024, "relu"), (257, 450, 1024, "leaky"), (1024, 1024, 616, "none")])
 def test_linear_dense_forward_backward_against_fp64(device, N, K, M, act):
     """The readout MLP's linear on the dense kernel (ops.linear_act -> glam_linear_dense_fwd / _bwd: bias + activation in the epilogue,
     activation derivative + dx + dw + db in one launch) against F.linear + the activation in fp64 (src_1gp/model.py:43-45, 60)."""
@@ -2883,6 +2884,14 @@ def test_linear_block_routes_the_readout_mlp_to_the_dense_kernel(device):
     assert_close(y, ref, 5e-6, "LinearBlock dense")
     gy, gr = torch.autograd.grad(y.sum() + (y * y).sum(), x)[0], torch.autograd.grad(ref.sum() + (ref * ref).sum(), x)[0]
     assert_close(gy, gr, 1e-5, "LinearBlock dense dx")
+    # rows that are not multiples of 16 bytes (hid_dim 90: 450 columns) take the same route
     blk2 = layer.LinearBlock(450, 1024, act="ReLU()").to(device)
-    assert not type(blk2(torch.randn(64, 450, device=device)).grad_fn).__name__.startswith("_LinearDense")
+    x2 = torch.randn(67, 450, device=device, requires_grad=True)
+    y2 = blk2(x2)
+    assert type(y2.grad_fn).__name__.startswith("_LinearDense")
+    ref2 = torch.relu(torch.nn.functional.linear(x2, blk2.linear.weight, blk2.linear.bias))
+    assert_close(y2, ref2, 5e-6, "LinearBlock dense 450")
+    for a, r in zip(torch.autograd.grad((y2 * y2).sum(), (x2, blk2.linear.weight, blk2.linear.bias)),
+                    torch.autograd.grad((ref2 * ref2).sum(), (x2, blk2.linear.weight, blk2.linear.bias))):
+        assert_close(a, r, 1e-5, "LinearBlock dense 450 grads")
 
