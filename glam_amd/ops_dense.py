@@ -416,10 +416,11 @@ class _LinearLib(torch.autograd.Function):
 
 
 def linear_dense_supported(N, K, M):
-    """The square-ish class of ``csrc/dense_x3.hip`` (the readout MLP, 5 * hid_dim -> 1024, any hidden width): enough rows for the weight
-    gradient's reduction and for the kernel's 16-byte path (>= 4 elements along every unit-stride dimension), output rows that are
-    multiples of 16 bytes (the 617-task head's forward is faster on the library: 18 vs 26 us, scalar stores)."""
-    return K >= 32 and M % 4 == 0 and N >= 4
+    """The class of ``csrc/dense_x3.hip`` that beats the GEMM library inside a model step: the readout MLP 5 * hid_dim -> 1024 with rows
+    that are multiples of 16 bytes (hid_dim 60: 300 columns).  The kernel takes any shape, but with partial quads (K = 75, 150, 225,
+    450: the other hidden widths) or scalar output stores (the 617-task head) the model step measured 1-17 us SLOWER than on the
+    library (``tools/bench_model.py --alpha``, A/B ``GLAM_DENSE_LINEAR``), so those stay there."""
+    return K % 4 == 0 and M % 4 == 0 and K >= 32 and N >= 4
 
 
 class _LinearDense(torch.autograd.Function):

@@ -2840,7 +2840,7 @@ def test_dense_gemm_c_abi(device, a_kc, b_kc, R, Cn, K):
 
 
 @pytest.mark.parametrize("N,K,M,act", [(1024, 300, 1024, "relu"), (642, 300, 1024, "leaky"), (33, 64, 128, "none"), (2039, 300, 1024, "relu"),
-                                        (1024, 75, 1024, "relu"), (257, 450, 1024, "leaky"), (1024, 1024, 616, "none")])
+                                        (1024, 75, 1024, "relu"), (257, 450, 1024, "leaky"), (64, 1024, 617, "none")])
 def test_linear_dense_forward_backward_against_fp64(device, N, K, M, act):
     """The readout MLP's linear on the dense kernel (ops.linear_act -> glam_linear_dense_fwd / _bwd: bias + activation in the epilogue,
     activation derivative + dx + dw + db in one launch) against F.linear + the activation in fp64 (src_1gp/model.py:43-45, 60)."""
@@ -2849,8 +2849,9 @@ def test_linear_dense_forward_backward_against_fp64(device, N, K, M, act):
     x = torch.randn(N, K, device=device, requires_grad=True)
     w = (torch.randn(M, K, device=device) * K ** -0.5).requires_grad_(True)
     b = torch.randn(M, device=device, requires_grad=True)
-    y = ops.linear_act(x, w, b, act, 0.2)
-    assert y is not None
+    code = {"none": 0, "relu": 1, "leaky": 2}[act]
+    y = ops.linear_act(x, w, b, act, 0.2) if K % 4 == 0 and M % 4 == 0 else ops._LinearDense.apply(x, w, b, code, 0.2)
+    assert y is not None      # (shapes with partial quads are not routed here by ops.linear — slower than the library — but are correct)
     cot = torch.randn_like(y)
     got = torch.autograd.grad(y, (x, w, b), cot)
     xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
@@ -2865,7 +2866,7 @@ def test_linear_dense_forward_backward_against_fp64(device, N, K, M, act):
     for gg, rr, name in zip(got, ref, ("dx", "dw", "db")):
         assert ((gg.double() - rr).abs().max() / rr.abs().max()).item() < 3e-6 * max(1.0, N ** 0.5 / 16), name
     # without input gradient (the first layer of a model) and without bias
-    y2 = ops.linear_act(x.detach(), w, None, act, 0.2)
+    y2 = ops._LinearDense.apply(x.detach(), w, None, code, 0.2)
     gw, = torch.autograd.grad(y2, (w,), cot)
     yd2 = F.linear(xd.detach(), wd) * torch.where(y2.detach().double() > 0, 1.0, slope)
     rw, = torch.autograd.grad(yd2, (wd,), cot.double())
@@ -2884,14 +2885,6 @@ def test_linear_block_routes_the_readout_mlp_to_the_dense_kernel(device):
     assert_close(y, ref, 5e-6, "LinearBlock dense")
     gy, gr = torch.autograd.grad(y.sum() + (y * y).sum(), x)[0], torch.autograd.grad(ref.sum() + (ref * ref).sum(), x)[0]
     assert_close(gy, gr, 1e-5, "LinearBlock dense dx")
-    # rows that are not multiples of 16 bytes (hid_dim 90: 450 columns) take the same route
+    # rows that are not multiples of 16 bytes (hid_dim 90: 450 columns) stay on the library (measured slower on the dense kernel)
     blk2 = layer.LinearBlock(450, 1024, act="ReLU()").to(device)
-    x2 = torch.randn(67, 450, device=device, requires_grad=True)
-    y2 = blk2(x2)
-    assert type(y2.grad_fn).__name__.startswith("_LinearDense")
-    ref2 = torch.relu(torch.nn.functional.linear(x2, blk2.linear.weight, blk2.linear.bias))
-    assert_close(y2, ref2, 5e-6, "LinearBlock dense 450")
-    for a, r in zip(torch.autograd.grad((y2 * y2).sum(), (x2, blk2.linear.weight, blk2.linear.bias)),
-                    torch.autograd.grad((ref2 * ref2).sum(), (x2, blk2.linear.weight, blk2.linear.bias))):
-        assert_close(a, r, 1e-5, "LinearBlock dense 450 grads")
-
+    assert not type(blk2(torch.randn(64, 450, device=device)).grad_fn).__name__.startswith("_LinearDense")
