@@ -117,6 +117,7 @@ SIGNATURES = {
     "glam_triplet_plain_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_stage_plain": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
     "glam_triplet_stage_params": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),
+    "glam_prestage": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp), _vp]),
     "glam_triplet_stage_params_bwd": (_i32, [_vp] * 4 + [_i32] * 5 + [_vp] * 5 + [_vp]),
     "glam_triplet_layer_fwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_triplet_layer_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),

@@ -46,6 +46,35 @@ struct ReduceJob {
 };
 struct ReduceArgs { ReduceJob job[3]; int njobs; };
 
+// Up to six images in one launch (the forward and transposed images of a GRU's two gate matrices change together after
+// every optimizer step): job j owns blocks [first[j], first[j+1]).
+// gate > 0 (the fused GRU step's images, block.hip): M = 3 gates of `gate` channels, each padded to 64 columns — logical column m holds
+// channel m % 64 of gate m / 64 (source row (m / 64) * gate + m % 64 of the [3 * gate, K] matrix), k padded to 64.
+struct ImageJob { const float* W; int ldw, transW, K, M, MT; float* img; int first; int gate; };
+constexpr int kMaxImageJobs = 6;
+struct ImageJobs { ImageJob job[kMaxImageJobs]; int njobs; };
+__device__ __forceinline__ void make_images_block(const ImageJobs& js, int bid) {
+    int jb = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxImageJobs; ++q)
+        if (q < js.njobs && bid >= js.job[q].first) jb = q;
+    const ImageJob& J = js.job[jb];
+    const int MP = J.MT * 16, Kp = J.gate ? 64 : (J.K + 15) & ~15;
+    const int idx = (bid - J.first) * kBlock + threadIdx.x;
+    if (idx >= Kp * MP) return;
+    const int j = idx & 3, p = (idx >> 2) % MP, k = (idx >> 2) / MP * 4 + j;
+    const int m = ts_col_of_pos(p);
+    float v = 0.f;
+    if (J.gate) {
+        const int g = m >> 6, ch = m & 63;
+        if (k < J.K && ch < J.gate) v = J.W[(size_t)(g * J.gate + ch) * J.ldw + k];
+    } else if (k < J.K && m < J.M) {
+        v = J.transW ? J.W[(size_t)m * J.ldw + k] : J.W[(size_t)k * J.ldw + m];
+    }
+    J.img[idx] = v;
+}
+int image_job(ImageJob& j, const char* fn, const float* W, int ldw, int transW, int K, int M, float* img, int first);   // gemm.hip
+
 size_t ts_image_floats(int K, int M);
 int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, float* img, hipStream_t s);
 int launch_ts_gemm(const TsArgs& a, hipStream_t s);

@@ -47,33 +47,8 @@ __global__ void __launch_bounds__(kBlock) k_ts_make_image(const float* W, int ld
     }
 }
 
-// Up to four images in one launch (the forward and transposed images of a GRU's two gate matrices change together after
-// every optimizer step): job j owns blocks [first[j], first[j+1]).
-// gate > 0 (the fused GRU step's images, block.hip): M = 3 gates of `gate` channels, each padded to 64 columns — logical column m holds
-// channel m % 64 of gate m / 64 (source row (m / 64) * gate + m % 64 of the [3 * gate, K] matrix), k padded to 64.
-struct ImageJob { const float* W; int ldw, transW, K, M, MT; float* img; int first; int gate; };
-constexpr int kMaxImageJobs = 6;
-struct ImageJobs { ImageJob job[kMaxImageJobs]; int njobs; };
-__global__ void __launch_bounds__(kBlock) k_ts_make_images(ImageJobs js) {
-    int jb = 0;
-#pragma unroll
-    for (int q = 1; q < kMaxImageJobs; ++q)
-        if (q < js.njobs && (int)blockIdx.x >= js.job[q].first) jb = q;
-    const ImageJob& J = js.job[jb];
-    const int MP = J.MT * 16, Kp = J.gate ? 64 : (J.K + 15) & ~15;
-    const int idx = ((int)blockIdx.x - J.first) * kBlock + threadIdx.x;
-    if (idx >= Kp * MP) return;
-    const int j = idx & 3, p = (idx >> 2) % MP, k = (idx >> 2) / MP * 4 + j;
-    const int m = ts_col_of_pos(p);
-    float v = 0.f;
-    if (J.gate) {
-        const int g = m >> 6, ch = m & 63;
-        if (k < J.K && ch < J.gate) v = J.W[(size_t)(g * J.gate + ch) * J.ldw + k];
-    } else if (k < J.K && m < J.M) {
-        v = J.transW ? J.W[(size_t)m * J.ldw + k] : J.W[(size_t)k * J.ldw + m];
-    }
-    J.img[idx] = v;
-}
+// (ImageJob / ImageJobs / make_images_block: dense.h — the same block body serves glam_prestage's launch in layer.hip)
+__global__ void __launch_bounds__(kBlock) k_ts_make_images(ImageJobs js) { make_images_block(js, (int)blockIdx.x); }
 
 // Work item = (16-row tile, column split): TPI of the MT column tiles.  A 16 x 192 x 64 row tile is 192 MFMAs
 // (6.1k cycles on one SIMD): whole row tiles leave some SIMDs with two and others with none at N ~ 2e4, so the
@@ -601,6 +576,13 @@ int launch_ts_make_image(const float* W, int ldw, int transW, int K, int M, floa
                        transW, K, M, MT, img);
     GLAM_LAUNCH_CHECK("ts_make_image");
     return GLAM_OK;
+}
+
+// one job of a k_ts_make_images-style launch: returns the number of blocks it owns, < 0 (an error code) for a shape outside the table
+int image_job(ImageJob& j, const char* fn, const float* W, int ldw, int transW, int K, int M, float* img, int first) {
+    if (int rc = ts_shape_ok(fn, K, M)) return rc;
+    j = ImageJob{W, ldw, transW, K, M, ts_mt(ts_variant(K, M)), img, first, 0};
+    return (int)((ts_image_floats(K, M) + kBlock - 1) / kBlock);
 }
 
 static int ts_plan(const TsArgs& a, int* variant, int* grid) {

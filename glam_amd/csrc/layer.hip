@@ -112,16 +112,17 @@ __device__ __forceinline__ float wsp_val(const StageArgs& a, int k, int m) {
     return (c < a.C && m < a.C) ? a.wsc[(size_t)(h * a.C + c) * a.C + m] : 0.f;
 }
 
-__global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a, int copy_blocks) {
+// (bid, nblocks: the block's place in the staging part of the launch — glam_prestage appends image blocks behind it)
+__device__ __forceinline__ void stage_params_block(const StageArgs& a, int copy_blocks, int bid, int nblocks) {
     const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, Dp = a.Dp, HC = H * Cp;
     const int Kp1 = (Cp + 15) & ~15, Kp2 = (HC + 15) & ~15, Kp4 = (HC + 8 + 15) & ~15;
     const int P1 = HC + 8 <= 64 ? 64 : 192, P3 = HC <= 64 ? 64 : 192;   // image column count 16*MT
-    if ((int)blockIdx.x >= copy_blocks) {
+    if (bid >= copy_blocks) {
         // ---- dot blocks: one 16-lane group per contraction (one round trip of loads + a DPP butterfly) ----
         //   item < 8*C        : Wa[k][s] = sum_c W_node[k,h,c] att[h, side*2C + c]   (s = side*4 + h) -> node image + d_x image
         //   item >= 8*C       : M[kk][h] = sum_c W_edge[kk,h,c] att[h, C + c]
         const int lg = threadIdx.x & 15;
-        const int item = ((int)blockIdx.x - copy_blocks) * (kBlock / 16) + (threadIdx.x >> 4);
+        const int item = (bid - copy_blocks) * (kBlock / 16) + (threadIdx.x >> 4);
         const bool is_m = item >= 8 * C;
         const int r = is_m ? (item - 8 * C) >> 2 : item >> 3;          // k or kk
         const int sx = is_m ? (item - 8 * C) & 3 : item & 7, h = sx & 3, side = sx >> 2;
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a, int copy_b
     const int n1 = Kp1 * P1, n2 = Kp2 * 64, n3 = Kp1 * P3, n4 = Kp4 * 64, n5 = Dp * HC, n6 = Dp * 4, n7 = Cp;
     const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7;
     // image element idx -> (k, logical column m): layout [k/4][p][k%4], column order ts_col_of_pos
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += copy_blocks * kBlock) {
+    for (int idx = bid * kBlock + threadIdx.x; idx < total; idx += copy_blocks * kBlock) {
         int i = idx;
         bool is_dot = false;
         if (i < n1) {            // node image: K = Cp, M = HC + 8
@@ -194,6 +195,17 @@ __global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a, int copy_b
         i -= n6;
         a.base[a.L.bias_p + i] = i < C ? a.bias[i] : 0.f;
     }
+}
+
+__global__ void __launch_bounds__(kBlock) k_stage_params(StageArgs a, int copy_blocks) {
+    stage_params_block(a, copy_blocks, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The derived weights of a whole model pass in one launch: the TripletMessage's staged images and up to six k_ts_gemm weight images
+// (a GRU's four, the input linear's one) — three launches of 5 us each at the head of every training step before.
+__global__ void __launch_bounds__(kBlock) k_prestage(StageArgs a, int copy_blocks, int stage_blocks, ImageJobs js) {
+    if ((int)blockIdx.x < stage_blocks) stage_params_block(a, copy_blocks, (int)blockIdx.x, stage_blocks);
+    else make_images_block(js, (int)blockIdx.x - stage_blocks);
 }
 
 // Wide layers (H*Cp + 8 > 192, e.g. hid_dim_alpha = 6): the same derived parameters as plain row-major matrices for
@@ -565,6 +577,35 @@ extern "C" int glam_triplet_stage_params(const float* weight_node, const float* 
     const int dot_blocks = (8 * C + 4 * Dp + kBlock / 16 - 1) / (kBlock / 16);
     hipLaunchKernelGGL(k_stage_params, dim3(copy_blocks + dot_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, copy_blocks);
     GLAM_LAUNCH_CHECK("glam_triplet_stage_params");
+    return GLAM_OK;
+}
+
+extern "C" int glam_prestage(const float* weight_node, const float* weight_edge, const float* att, const float* weight_scale,
+                             const float* bias, int C, int H, int De, int Cp, int Dp, float* staged, int n_images,
+                             const float* const* W, const int* dims, float* const* img, void* stream) {
+    GLAM_REQUIRE(n_images >= 0 && n_images <= kMaxImageJobs, "glam_prestage: %d images (at most %d per launch)", n_images, kMaxImageJobs);
+    GLAM_REQUIRE(staged || n_images > 0, "glam_prestage: nothing to build");
+    GLAM_REQUIRE(n_images == 0 || (W && dims && img), "glam_prestage: null image table");
+    StageArgs a{};
+    int copy_blocks = 0, stage_blocks = 0;
+    if (staged) {
+        if (int rc = dims_ok("glam_prestage", C, H, De, Cp, Dp)) return rc;
+        GLAM_REQUIRE(weight_node && weight_edge && att && weight_scale && bias && aligned16(staged), "glam_prestage: null / misaligned pointer");
+        a = StageArgs{weight_node, weight_edge, att, weight_scale, bias, C, H, De, Cp, Dp, staged, staged_layout(H, Cp, Dp)};
+        copy_blocks = grid_for((int64_t)a.L.total, kBlock);
+        stage_blocks = copy_blocks + (8 * C + 4 * Dp + kBlock / 16 - 1) / (kBlock / 16);
+    }
+    ImageJobs js{};
+    int blocks = 0;
+    for (int q = 0; q < n_images; ++q) {
+        GLAM_REQUIRE(W[q] && img[q] && aligned16(img[q]), "glam_prestage: image %d: null / misaligned pointer", q);
+        const int nb = image_job(js.job[q], "glam_prestage", W[q], dims[4 * q], dims[4 * q + 1], dims[4 * q + 2], dims[4 * q + 3], img[q], blocks);
+        if (nb < 0) return nb;
+        blocks += nb;
+    }
+    js.njobs = n_images;
+    hipLaunchKernelGGL(k_prestage, dim3(stage_blocks + blocks), dim3(kBlock), 0, (hipStream_t)stream, a, copy_blocks, stage_blocks, js);
+    GLAM_LAUNCH_CHECK("glam_prestage");
     return GLAM_OK;
 }
 

@@ -14,7 +14,7 @@ from . import ops
 
 from .layer import _None  # noqa: F401
 from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
-from .layer import LinearBlock, MessageBlock, dot_and_global_pool2
+from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, prestage_pass
 
 
 def model_args(args):
@@ -53,6 +53,7 @@ class Architecture(torch.nn.Module):
         return out
 
     def _forward(self, data_mol):
+        prestage_pass(self.mol_lin0, self.mol_conv, data_mol.x, data_mol.edge_attr)    # (the pass's weight re-layouts from one launch)
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)                       # model.py:49
         hm = None
         for _ in range(self.message_steps):                                        # model.py:53-54

@@ -234,6 +234,54 @@ def _scoped(table, key, owner, build):
     table[key] = (owner, val)
     return val
 
+def prestage(triplet=None, images=()):
+    """The derived weights of a model pass in ONE launch (``glam_prestage``) instead of one per module at its first use: the staged
+    images of a TripletMessage (``triplet = (wn, we, att, wsc, bias, H, Dp)``) and up to six ``k_ts_gemm`` weight images
+    (``images``: ``(table, key, owner, W, ldw, transW, K, M, K_image)`` with ``table`` in {"fwd", "bwd"} — the scope table and key
+    under which the lazy builder of the op looks the image up).  The entries are put into the active ``weight_scope`` exactly as the
+    lazy builders would put them, so an op whose route differs from the caller's guess just builds its own as before.  Returns the
+    number of entries built (0: no scope, switched off, or everything already there)."""
+    scope = _SCOPE
+    if scope is None or not PRESTAGE:
+        return 0
+    lib = _lib.load()
+    f = None
+    args_t = [None] * 5 + [0] * 5 + [None]
+    built = 0
+    if triplet is not None and not CACHED_STAGING:
+        wn, we, att, wsc, bias, H, Dp = triplet
+        key = ("triplet", id(wn), id(we), id(att), id(wsc), id(bias))
+        hit = scope.fwd.get(key)
+        ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (wn, we, att, wsc, bias))
+        if ok and not (hit is not None and hit[0] is wn):
+            C, De = wn.size(0), we.size(0)
+            Cp = (C + 3) // 4 * 4
+            f = dict(dtype=torch.float32, device=wn.device)
+            buf = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
+            args_t = [ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), C, H, De, Cp, Dp, ptr(buf)]
+            scope.fwd[key] = (wn, buf)
+            built += 1
+    jobs = []
+    for table, key, owner, W, ldw, transW, K, M, Kimg in images:
+        tab = scope.fwd if table == "fwd" else scope.bwd
+        hit = tab.get(key)
+        if (hit is not None and hit[0] is owner) or not (W.is_cuda and W.dtype == torch.float32 and W.is_contiguous()) or len(jobs) == 6:
+            continue
+        f = f or dict(dtype=torch.float32, device=W.device)
+        img = torch.empty(lib.glam_ts_gemm_image_bytes(Kimg, M) // 4, **f)
+        jobs.append((W, (ldw, transW, K, M), img))
+        tab[key] = (owner, img)
+        built += 1
+    if built == 0:
+        return 0
+    n = len(jobs)
+    wp = (ctypes.c_void_p * max(n, 1))(*[ptr(j[0]) for j in jobs])
+    ip = (ctypes.c_void_p * max(n, 1))(*[ptr(j[2]) for j in jobs])
+    dims = (ctypes.c_int32 * (4 * max(n, 1)))(*[v for j in jobs for v in j[1]])
+    check(lib.glam_prestage(*args_t, n, wp, dims, ip, stream()), "glam_prestage")
+    return built
+
+
 class _PadGroup(torch.autograd.Function):
     """Zero-padded copies of several parameters of one module in ONE launch (``glam_pad_group``); the backward slices all their
     gradients in one launch too.  ``specs[t] = (d0, d1, d2, p1, p2)``: tensor t viewed as ``[d0, d1, d2]`` becomes ``[d0, p1, p2]``."""
@@ -1000,6 +1048,8 @@ GRU_FUSED_MIN_NODES = 16384
 GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
 # MessageBlock's skip connection handed through the conv's autograd node (the d_x product's epilogue sums both gradient paths): A/B switch
 SKIP_THROUGH_CONV = os.environ.get("GLAM_SKIP_THROUGH_CONV", "1") == "1"
+# the derived weights of a model pass from one launch (glam_prestage) instead of one per module: A/B switch
+PRESTAGE = os.environ.get("GLAM_PRESTAGE", "1") == "1"
 # the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch
 DENSE_LINEAR = os.environ.get("GLAM_DENSE_LINEAR", "1") == "1"
 

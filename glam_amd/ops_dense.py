@@ -675,6 +675,15 @@ def _want_gru_ws(lib, N, C):
     return N > 0 and _o.GRU_WS == "1" and os.environ.get("GLAM_X3", "1") != "0" and lib.glam_gru_ws_supported(C) == 1
 
 
+def gru_images_plain(N, C):
+    """True when the GRU step of this size runs on the four plain ``k_ts_gemm`` images of its gate matrices (the warp-specialised step,
+    or the unfused gate linears) — the set ``ops.prestage`` can build ahead; the fp32 fused step needs its gate-padded images too."""
+    lib = _lib.load()
+    if N <= 0 or not linear_supported(C, 3 * C) or lib.glam_ts_gemm_image_bytes(3 * C, C) <= 0:
+        return False
+    return _want_gru_ws(lib, N, C) or not (_want_gru_fused(N) and lib.glam_gru_fused_supported(C))
+
+
 def _want_gru_fused(N):
     return _o.GRU_FUSED in ("1", True) or (_o.GRU_FUSED == "auto" and N >= _o.GRU_FUSED_MIN_NODES)
 

@@ -237,6 +237,14 @@ int glam_wgrad_gemm_add(const float* P1, int I1, int ldp1, const float* P2, int 
                         int J, int ldq, int qones, int64_t N, float* out, int stride_i, int stride_j, const float* addend,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* The derived weights of a model pass in ONE launch (three launches of ~5 us each at the head of every training step before): the staged
+ * images of a TripletMessage (exactly glam_triplet_stage_params; staged == NULL: none) and n_images <= 6 weight images of
+ * glam_ts_gemm (exactly glam_ts_gemm_make_image each: dims[4 q ..] = {ldw, transW, K, M} of image q — e.g. the four images of a GRU's
+ * gate matrices and the one of the input linear, /root/reference/src_1gp/model.py:40-42). */
+int glam_prestage(const float* weight_node, const float* weight_edge, const float* att, const float* weight_scale, const float* bias,
+                  int C, int H, int De, int Cp, int Dp, float* staged, int n_images, const float* const* W, const int* dims,
+                  float* const* img, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole TripletMessage layer (src_1gp/layer.py:36-61) as one enqueue per direction.  All node-feature
  * widths are the padded Cp (x f32[N,Cp], out f32[N,Cp]; the host mirror pads/slices when C % 4 != 0).

@@ -2910,3 +2910,48 @@ def test_dense_gemm_rounding_is_unbiased(device):
     assert abs(z) < 6.0, f"mean error {e.mean().item():+.2e} is {z:+.1f} sigma from zero (rms {rms:.2e})"
     assert rms < e_lib, f"rms error {rms:.2e} vs the library's {e_lib:.2e}"
 
+
+def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
+    """ops.prestage / glam_prestage: the input linear's GEMM image, the TripletMessage's staged images and the GRU's four gate images
+    come from ONE launch at the head of a model pass (three launches before), land in the weight scope under the keys the ops look
+    them up with (no k_stage_params / k_ts_make_image(s) launch follows), and the pass is bit-identical to the lazily staged one."""
+    from glam_amd._lib import kernel_timer
+    torch.manual_seed(11)
+    b = synth_batch(48, seed=5).to(device)
+    net = model.Architecture(mol_block="_TripletMessage", message_steps=3, pre_act="ReLU", graph_act="ReLU", flat_act="ReLU",
+                             graph_do="_None()", end_do="_None()").to(device)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)       # (the eager C++ node stages per call; a captured step uses this route)
+
+    def run(flag):
+        monkeypatch.setattr(ops, "PRESTAGE", flag)
+        net.zero_grad()
+        with kernel_timer() as kt:
+            out = net(b)
+            out.square().sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()], [r[0] for r in kt.records()]
+
+    o1, g1, k1 = run(True)
+    o0, g0, k0 = run(False)
+    assert torch.equal(o1, o0)
+    for a, c in zip(g1, g0):
+        assert torch.equal(a, c)
+    staging = lambda names: [n for n in names if "k_stage_params" == n.split("<")[0] or "k_ts_make_image" in n or "k_prestage" in n]
+    assert staging(k1) == ["k_prestage"], staging(k1)
+    assert len(staging(k0)) == 3 and "k_prestage" not in staging(k0), staging(k0)
+    # C ABI: the image table is bounded, empty calls and shapes outside the kernel table are refused
+    lib = ops._lib.load()
+    import ctypes
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 0, None, None, None, None) == ops._lib.GLAM_E_INVALID
+    w = torch.randn(60, 60, device=device)
+    img = torch.empty(lib.glam_ts_gemm_image_bytes(60, 60) // 4, device=device)
+    vp = ctypes.c_void_p
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 7, (vp * 7)(*[w.data_ptr()] * 7), (ctypes.c_int32 * 28)(*([60, 1, 60, 60] * 7)),
+                             (vp * 7)(*[img.data_ptr()] * 7), ops._lib.stream()) == ops._lib.GLAM_E_INVALID
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 1, (vp * 1)(w.data_ptr()), (ctypes.c_int32 * 4)(60, 1, 500, 500),
+                             (vp * 1)(img.data_ptr()), ops._lib.stream()) == ops._lib.GLAM_E_UNSUPPORTED
+    ref = torch.empty_like(img)
+    assert lib.glam_ts_gemm_make_image(w.data_ptr(), 60, 1, 60, 60, ref.data_ptr(), ops._lib.stream()) == 0
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 1, (vp * 1)(w.data_ptr()), (ctypes.c_int32 * 4)(60, 1, 60, 60),
+                             (vp * 1)(img.data_ptr()), ops._lib.stream()) == 0
+    assert torch.equal(img, ref)
+

@@ -421,4 +421,6 @@ def test_dense_gemm_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.glam_linear_dense_bwd(p, p, p, None, 0.0, 8, 300, 64, p, None, p, None) == inv                            # db without dw
     assert ops.linear_dense_supported(1024, 300, 1024) and not ops.linear_dense_supported(1024, 450, 1024) and not ops.linear_dense_supported(64, 1024, 617)
     assert not ops.linear_dense_supported(2, 300, 1024) and not ops.linear_dense_supported(1024, 16, 1024)
+    assert lib.glam_prestage(None, None, None, None, None, 0, 0, 0, 0, 0, None, 0, None, None, None, None) == inv          # nothing to build
+    assert lib.glam_prestage(None, None, None, None, None, 0, 0, 0, 0, 0, None, 7, None, None, None, None) == inv          # more than six images
 
