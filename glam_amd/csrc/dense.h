@@ -40,6 +40,7 @@ struct ReduceJob {
     int kind; const float* partial; int nsplit; int n; int I, J, si, sj; float* out; float* out2; int split_at;
     int first_block;
     const float* addend;                   // kind 0, non-null: out[i, j] = sum + addend[i, j] (same strides: a gradient carry)
+    int jw;                                // kind 0, > 0: only columns j < jw of `out` exist (a Q whose last columns are padding)
     float* out_b; const float* add_b;      // kind 0, out_b non-null: the LAST column (j = J - 1, the bias gradient of a [Q | 1]
                                            // product) goes to out_b[i] (+ add_b[i]) instead of out: weight and bias gradients land
                                            // in separate contiguous tensors (autograd takes them without a copy)

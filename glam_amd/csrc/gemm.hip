@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(kBlock) k_final_reduce(ReduceArgs ra) {
             if (i < J.I && j < J.J) {
                 if (J.out_b && j == J.J - 1) {
                     J.out_b[i] = J.add_b ? s + J.add_b[i] : s;
-                } else {
+                } else if (J.jw == 0 || j < J.jw) {
                     const size_t o2 = (size_t)i * J.si + (size_t)j * J.sj;
                     J.out[o2] = J.addend ? s + J.addend[o2] : s;
                 }
@@ -931,10 +931,15 @@ extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float
                                      void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_split: N out of range");
     GLAM_REQUIRE(dw && db, "glam_wgrad_gemm_split: null output");
-    GLAM_REQUIRE(I > 0 && J > 0 && J + 1 <= 64, "glam_wgrad_gemm_split: J + 1 must be <= 64");
+    // J need not be a multiple of 4 when the rows of Q are (ldq >= ceil4(J)): the product runs over the padded width and the reduction
+    // writes the J real columns of dw[I, J] only — the gradient of a weight narrower than its zero-padded input (15 -> 16 columns)
+    // arrives contiguous instead of as a strided view that autograd copies
+    const int Jw = J;
+    J = (J + 3) & ~3;
+    GLAM_REQUIRE(I > 0 && Jw > 0 && J + 1 <= 64 && ldq >= J, "glam_wgrad_gemm_split: ceil4(J) + 1 must be <= 64 and ldq >= ceil4(J)");
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
-        (void)hipMemsetAsync(dw, 0, (size_t)I * J * sizeof(float), s);
+        (void)hipMemsetAsync(dw, 0, (size_t)I * Jw * sizeof(float), s);
         (void)hipMemsetAsync(db, 0, (size_t)I * sizeof(float), s);
         return GLAM_OK;
     }
@@ -945,8 +950,9 @@ extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float
     WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, J, ldq, 1, (int)N, 0, partial, 0, 0};
     ReduceArgs ra{};
     ra.njobs = 1;
-    if (int rc = launch_wgrad_partials(a, dw, J, 1, s, &ra.job[0])) return rc;
+    if (int rc = launch_wgrad_partials(a, dw, Jw, 1, s, &ra.job[0])) return rc;
     ra.job[0].out_b = db;
+    ra.job[0].jw = Jw;
     return launch_final_reduce(ra, s);
 }
 

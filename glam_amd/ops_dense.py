@@ -78,10 +78,12 @@ class _Linear(torch.autograd.Function):
         if K + 1 <= 64:
             # weight and bias gradients as separate contiguous tensors: autograd keeps them as they are (views of one [M, K + 1] buffer
             # cost a copy launch each when they become .grad)
-            dw, db = torch.empty(M, K, **f), torch.empty(M, **f)
-            check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), K, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
+            # (a weight narrower than the zero-padded input, 15 -> 16 columns: the reduction writes its real columns only)
+            Kw = w.size(1)
+            dw, db = torch.empty(M, Kw, **f), torch.empty(M, **f)
+            check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
                   "glam_wgrad_gemm_split")
-            return dx, (dw if w.size(1) == K else dw[:, :w.size(1)]), (db if ctx.has_bias else None)
+            return dx, dw, (db if ctx.has_bias else None)
         dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
         if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]
             check(lib.glam_wgrad_gemm(ptr(x), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), 1, K + 1, ptr(ws), ws.numel(),

@@ -207,7 +207,8 @@ int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, const float* Q
                                const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 
 /* glam_wgrad_gemm for ONE linear y = [x | 1] W^T with the weight and bias gradients in separate contiguous tensors:
- * dw[I, J] = P^T Q (P = dy f32[N, I], Q = x f32[N, J]), db[I] = column sums of P.  J + 1 <= 64, I <= 320. */
+ * dw[I, J] = P^T Q (P = dy f32[N, I], Q = x f32[N, J]), db[I] = column sums of P.  ceil4(J) + 1 <= 64, I <= 320; J need not be a
+ * multiple of 4 when ldq >= ceil4(J) (a weight narrower than its zero-padded input: dw stays contiguous [I, J]). */
 int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N, void* ws,
                           size_t ws_bytes, void* stream);
 /* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:

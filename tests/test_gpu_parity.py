@@ -2955,3 +2955,28 @@ def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
                              (vp * 1)(img.data_ptr()), ops._lib.stream()) == 0
     assert torch.equal(img, ref)
 
+
+def test_wgrad_split_writes_a_narrow_weight_gradient_contiguously(device):
+    """glam_wgrad_gemm_split with J = 15 over rows of 16 floats (the input linear 15 -> 60 on zero-padded atom features): dw comes out
+    as a contiguous [I, 15] tensor (no strided view for autograd to copy), db beside it; nothing is written beyond them."""
+    lib, p = ops._lib.load(), ops._lib.ptr
+    torch.manual_seed(2)
+    N, I, J = 5000, 60, 15
+    dy = torch.randn(N, I, device=device)
+    x = torch.randn(N, 16, device=device)
+    x[:, 15] = 7.0                                            # (the pad column is not trusted to be zero)
+    buf = torch.full((I * J + 8,), float("nan"), device=device)
+    db = torch.full((I + 4,), float("nan"), device=device)
+    ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    assert lib.glam_wgrad_gemm_split(p(dy), I, I, p(x), J, 16, p(buf), p(db), N, p(ws), ws.numel(), ops._lib.stream()) == 0, lib.glam_last_error()
+    ref = dy.double().t() @ x[:, :J].double()
+    assert_close(buf[:I * J].view(I, J), ref, 2e-5, "narrow dw")
+    assert_close(db[:I], dy.double().sum(0), 2e-5, "narrow db")
+    assert torch.isnan(buf[I * J:]).all() and torch.isnan(db[I:]).all()
+    assert lib.glam_wgrad_gemm_split(p(dy), I, I, p(x), J, 15, p(buf), p(db), N, p(ws), ws.numel(), ops._lib.stream()) != 0     # ldq < ceil4(J)
+    lin = layer.LinearBlock(15, 60, act="_None").to(device)
+    xin = torch.randn(300, 15, device=device)
+    lin(xin).sum().backward()
+    assert lin.linear.weight.grad.is_contiguous() and lin.linear.weight.grad.shape == (60, 15)
+    assert_close(lin.linear.weight.grad, xin.sum(0).expand(60, 15), 2e-5, "LinearBlock(15, 60) weight gradient")
+
