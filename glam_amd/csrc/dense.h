@@ -33,6 +33,10 @@ struct WgArgs {
     float* partial;                        // [slab][nsplit][16 tiles][64 lanes][4]
     int nsplit; int ntile;
     int q_celu;                            // 1: the product uses celu(Q) (weight gradient of a linear fed through a folded CELU)
+    // nseg > 1 (k_wgrad<.., SEG>): nseg operand sets of seg_rows rows each, summed into ONE product (N = nseg * seg_rows): set 0 is
+    // (P1, P2, Q), set s > 0 is (segP1[s - 1], segP2[s - 1], segQ[s - 1]) with the same widths and row strides
+    int nseg; int seg_rows;
+    const float* segP1[2]; const float* segP2[2]; const float* segQ[2];
 };
 
 // see k_final_reduce in gemm.hip

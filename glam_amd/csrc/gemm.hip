@@ -368,7 +368,7 @@ __device__ float4 g_wg_const[2] = {{1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; 
 #define GLAM_WG_ROLL 1
 #endif
 
-template <bool CELU>
+template <bool CELU, bool SEG>
 __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     __shared__ float s_red[kWgWaves * 32 * 64];        // half of the 64 accumulator registers at a time: 64 KB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
@@ -407,58 +407,77 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
             for (int tj = 0; tj < 4; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv, ti), f4get(qv, tj), acc[ti][tj], 0, 0, 0);
     };
-    // full batches (4 kSteps rows, no masks), then one masked batch for the rest
-    const int nfull = (row1 - row0) / (4 * kSteps);
-    // ONE running pointer per operand: requests go out in row order (step after step, batch after batch)
-    const float* pn = psrc + (size_t)(row0 + kq) * pld;
-    const float* qn = qsrc + (size_t)(row0 + kq) * qld;
-    const int pstep = 4 * pld, qstep = 4 * qld;        // floats between consecutive steps of a lane
-#if GLAM_WG_ROLL
-    // rolling prefetch: the operands of step st of the NEXT batch are requested as soon as this batch's step st has issued its MFMAs
-    // (its registers are free from then on): every load flies under 16 (kSteps - 1) of the wave's own MFMAs besides the other waves'
-    float4 pl[kSteps], ql[kSteps];
-    if (nfull > 0) {
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
-    }
-    for (int b = 0; b + 1 < nfull; ++b) {
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) {
-            mma(pl[st], ql[st]);
-            pl[st] = ld4(pn);
-            ql[st] = ld4(qn);
-            pn += pstep;
-            qn += qstep;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (nfull > 0) {
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
-    }
-#else
-    for (int b = 0; b < nfull; ++b) {
+    // the rows [r0, r1) of one operand set (ps / qs: this lane's column of P / Q, row 0)
+    auto rows = [&](int r0, int r1, const float* ps, const float* qs) {
+        // full batches (4 kSteps rows, no masks), then one masked batch for the rest
+        const int nfull = (r1 - r0) / (4 * kSteps);
+        // ONE running pointer per operand: requests go out in row order (step after step, batch after batch)
+        const float* pn = ps + (size_t)(r0 + kq) * pld;
+        const float* qn = qs + (size_t)(r0 + kq) * qld;
+        const int pstep = 4 * pld, qstep = 4 * qld;        // floats between consecutive steps of a lane
+    #if GLAM_WG_ROLL
+        // rolling prefetch: the operands of step st of the NEXT batch are requested as soon as this batch's step st has issued its MFMAs
+        // (its registers are free from then on): every load flies under 16 (kSteps - 1) of the wave's own MFMAs besides the other waves'
         float4 pl[kSteps], ql[kSteps];
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
-    }
-#endif
-    {
-        const int n0 = row0 + nfull * 4 * kSteps;
-        if (n0 < row1) {                                 // wave-uniform
-            float4 pt[kSteps], qt[kSteps];
-#pragma unroll
-            for (int st = 0; st < kSteps; ++st) {
-                const bool nok = n0 + 4 * st + kq < row1;
-                pt[st] = nok ? ld4(pn + st * pstep) : f4zero();
-                qt[st] = nok ? ld4(qn + st * qstep) : f4zero();
-            }
-#pragma unroll
-            for (int st = 0; st < kSteps; ++st)
-                if (n0 + 4 * st < row1) mma(pt[st], qt[st]);       // wave-uniform: an empty step costs no MFMAs
+        if (nfull > 0) {
+    #pragma unroll
+            for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
         }
+        for (int b = 0; b + 1 < nfull; ++b) {
+    #pragma unroll
+            for (int st = 0; st < kSteps; ++st) {
+                mma(pl[st], ql[st]);
+                pl[st] = ld4(pn);
+                ql[st] = ld4(qn);
+                pn += pstep;
+                qn += qstep;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nfull > 0) {
+    #pragma unroll
+            for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
+        }
+    #else
+        for (int b = 0; b < nfull; ++b) {
+            float4 pl[kSteps], ql[kSteps];
+    #pragma unroll
+            for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
+    #pragma unroll
+            for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
+        }
+    #endif
+        {
+            const int n0 = r0 + nfull * 4 * kSteps;
+            if (n0 < r1) {                                 // wave-uniform
+                float4 pt[kSteps], qt[kSteps];
+    #pragma unroll
+                for (int st = 0; st < kSteps; ++st) {
+                    const bool nok = n0 + 4 * st + kq < r1;
+                    pt[st] = nok ? ld4(pn + st * pstep) : f4zero();
+                    qt[st] = nok ? ld4(qn + st * qstep) : f4zero();
+                }
+    #pragma unroll
+                for (int st = 0; st < kSteps; ++st)
+                    if (n0 + 4 * st < r1) mma(pt[st], qt[st]);       // wave-uniform: an empty step costs no MFMAs
+            }
+        }
+    };
+    if (!SEG) {
+        rows(row0, row1, psrc, qsrc);
+    } else {
+        // several operand sets of seg_rows rows each behind one another (the applications of a block that shares its weights): a wave's
+        // range lies in one set or straddles ONE boundary (rows_per_wave <= seg_rows)
+        const int s0 = row0 / a.seg_rows, bnd = (s0 + 1) * a.seg_rows;
+        const int e0 = min(row1, bnd);
+        auto base = [&](int sg, bool isq) -> const float* {
+            if (isq) return qld == 0 ? qsrc : (sg == 0 ? a.Q : a.segQ[sg - 1]) + qcol;
+            if (pld == 0) return psrc;
+            if (pcol < a.I1) return (sg == 0 ? a.P1 : a.segP1[sg - 1]) + pcol;
+            return (sg == 0 ? a.P2 : a.segP2[sg - 1]) + (pcol - a.I1);
+        };
+        rows(row0 - s0 * a.seg_rows, e0 - s0 * a.seg_rows, base(s0, false), base(s0, true));
+        if (row1 > bnd) rows(0, row1 - bnd, base(s0 + 1, false), base(s0 + 1, true));
     }
     // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order.  Accumulator tile t = ti*4 + tj
     //      of a lane is one float4 (r = 0..3): 8 tiles per half go to LDS as b128 stores [wave][t][lane], thread
@@ -701,8 +720,9 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
     int blocks = 0;
     if (int rc = plan_wgrad(a, out, si, sj, wgrad_budget(a.N), job, &blocks)) return rc;
     WgArgs2 two{a, a, blocks};
-    if (a.q_celu) hipLaunchKernelGGL(k_wgrad<true>, dim3(blocks), dim3(kWgBlock), 0, s, two);
-    else hipLaunchKernelGGL(k_wgrad<false>, dim3(blocks), dim3(kWgBlock), 0, s, two);
+    GLAM_PROF_LABEL(a.q_celu ? "k_wgrad<true>" : "k_wgrad<false>");      // (the labels bench.py's kernel table is keyed by)
+    if (a.q_celu) hipLaunchKernelGGL((k_wgrad<true, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
+    else hipLaunchKernelGGL((k_wgrad<false, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad");
     return GLAM_OK;
 }
@@ -716,9 +736,14 @@ int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob
     int na = 0, nb = 0;
     if (int rc = plan_wgrad(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;
     if (int rc = plan_wgrad(b, out_b, si_b, sj_b, total - ba, job_b, &nb)) return rc;
+    if ((a.nseg > 1 && a.rows_per_wave > a.seg_rows) || (b.nseg > 1 && b.rows_per_wave > b.seg_rows))
+        return fail(GLAM_E_UNSUPPORTED, "wgrad: %d operand sets of %d rows are too short for a wave's %d rows (run them one by one)", a.nseg,
+                    a.seg_rows, a.rows_per_wave);
     WgArgs2 two{a, b, na};
-    if (a.q_celu || b.q_celu) hipLaunchKernelGGL(k_wgrad<true>, dim3(na + nb), dim3(kWgBlock), 0, s, two);
-    else hipLaunchKernelGGL(k_wgrad<false>, dim3(na + nb), dim3(kWgBlock), 0, s, two);
+    GLAM_PROF_LABEL(a.nseg > 1 ? "k_wgrad<true, sets>" : (a.q_celu || b.q_celu) ? "k_wgrad<true>" : "k_wgrad<false>");
+    if (a.nseg > 1) hipLaunchKernelGGL((k_wgrad<true, true>), dim3(na + nb), dim3(kWgBlock), 0, s, two);
+    else if (a.q_celu || b.q_celu) hipLaunchKernelGGL((k_wgrad<true, false>), dim3(na + nb), dim3(kWgBlock), 0, s, two);
+    else hipLaunchKernelGGL((k_wgrad<false, false>), dim3(na + nb), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad(pair)");
     return GLAM_OK;
 }
@@ -875,6 +900,40 @@ extern "C" int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, con
     return wgrad_pair_impl("glam_wgrad_gemm_pair_split", Pa, Ia, ldpa, 0, Qa, Ja, ldqa, 1, qcelu_a, dw_a, Ja, 1, Pb, Ib, ldpb, 0, Qb, Jb,
                            ldqb, 1, qcelu_b, dw_b, Jb, 1, N, ws, ws_bytes, add_w_a, add_w_b, (hipStream_t)stream, db_a, add_b_a, db_b,
                            add_b_b);
+}
+
+// The same pair of products summed over nseg <= 3 operand sets of N rows each (the applications of a block that shares its weights:
+// message_steps GRU steps, src_1gp/model.py:53-54) in ONE launch + ONE reduction.
+extern "C" int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, int Ia, int ldpa, const float* const* Qa, int Ja, int ldqa,
+                                              int qcelu_a, float* dw_a, float* db_a, const float* const* Pb, int Ib, int ldpb,
+                                              const float* const* Qb, int Jb, int ldqb, int qcelu_b, float* dw_b, float* db_b, int64_t N,
+                                              void* ws, size_t ws_bytes, const float* add_w_a, const float* add_b_a, const float* add_w_b,
+                                              const float* add_b_b, void* stream) {
+    const char* fn = "glam_wgrad_gemm_pair_split_seg";
+    GLAM_REQUIRE(nseg >= 1 && nseg <= 3, "%s: %d operand sets (1..3)", fn, nseg);
+    GLAM_REQUIRE(Pa && Qa && Pb && Qb && dw_a && db_a && dw_b && db_b && ws, "%s: null pointer", fn);
+    GLAM_REQUIRE(N >= 1 && N * nseg < INT32_MAX, "%s: N out of range", fn);
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace too small", fn);
+    for (int q = 0; q < nseg; ++q)
+        GLAM_REQUIRE(Pa[q] && Qa[q] && Pb[q] && Qb[q] && aligned16(Pa[q]) && aligned16(Qa[q]) && aligned16(Pb[q]) && aligned16(Qb[q]),
+                     "%s: operand set %d: null / misaligned pointer", fn, q);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    WgArgs a{Pa[0], Ia, ldpa, nullptr, 0, 0, 0, Qa[0], Ja, ldqa, 1, (int)(N * nseg), 0, partial, 0, 0, qcelu_a};
+    WgArgs b{Pb[0], Ib, ldpb, nullptr, 0, 0, 0, Qb[0], Jb, ldqb, 1, (int)(N * nseg), 0, partial + wgrad_workspace_floats(), 0, 0, qcelu_b};
+    a.nseg = b.nseg = nseg;
+    a.seg_rows = b.seg_rows = (int)N;
+    for (int q = 1; q < nseg; ++q) {
+        a.segP1[q - 1] = Pa[q]; a.segQ[q - 1] = Qa[q];
+        b.segP1[q - 1] = Pb[q]; b.segQ[q - 1] = Qb[q];
+    }
+    ReduceArgs ra{};
+    ra.njobs = 2;
+    if (int rc = launch_wgrad_partials2(a, dw_a, Ja, 1, &ra.job[0], b, dw_b, Jb, 1, &ra.job[1], (hipStream_t)stream)) return rc;
+    ra.job[0].addend = add_w_a;
+    ra.job[1].addend = add_w_b;
+    ra.job[0].out_b = db_a; ra.job[0].add_b = add_b_a;
+    ra.job[1].out_b = db_b; ra.job[1].add_b = add_b_b;
+    return launch_final_reduce(ra, (hipStream_t)stream);
 }
 
 static int wgrad_gemm_impl(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,

@@ -1048,6 +1048,8 @@ GRU_FUSED_MIN_NODES = 16384
 GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
 # MessageBlock's skip connection handed through the conv's autograd node (the d_x product's epilogue sums both gradient paths): A/B switch
 SKIP_THROUGH_CONV = os.environ.get("GLAM_SKIP_THROUGH_CONV", "1") == "1"
+# the GRU's weight gradients of all applications of a block in one launch pair (glam_wgrad_gemm_pair_split_seg): A/B switch
+GRU_WGRAD_BATCH = os.environ.get("GLAM_GRU_WGRAD_BATCH", "1") == "1"
 # the derived weights of a model pass from one launch (glam_prestage) instead of one per module: A/B switch
 PRESTAGE = os.environ.get("GLAM_PRESTAGE", "1") == "1"
 # the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch

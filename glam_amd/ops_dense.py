@@ -5,6 +5,7 @@ Part of ``glam_amd.ops`` (every public name here is re-exported there: ``from gl
 scope, the padded-column bookkeeping and the index staging live in ``glam_amd/ops.py`` and are read through ``_o`` at call time."""
 from __future__ import annotations
 
+import ctypes
 import os
 import weakref
 
@@ -696,13 +697,18 @@ def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=
         w1, b1, w2, b2 = flat.split([M * C, M, M * C, M])
         return w1.view(M, C), w2.view(M, C), b1, b2
     key = ("carry-gru", id(w_ih))
+    hit = _o._SCOPE.fwd.get(key) if _o._SCOPE is not None else None
+    first = not (hit is not None and hit[0] is w_ih)        # the block's first application of this pass: its backward runs LAST
     carry = _o._carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * M * (C + 1), split)
-    out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng)
+    out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng, first)
     if carry is not None:
         _o._carry_store(key, w_ih, carry)
     if out_drop is not None:
         _o.register_dropped(out, out_drop, rng[2])
     return out, h_new
+
+
+_GRU_BATCH_MIN_ROWS = 2048      # (a wave's row range must fit into one operand set: glam_wgrad_gemm_pair_split_seg)
 
 
 class _GruBlock(torch.autograd.Function):
@@ -712,7 +718,7 @@ class _GruBlock(torch.autograd.Function):
     one, which is what an eagerly issued training step is bound by."""
 
     @staticmethod
-    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None):
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None, first_app=True):
         ctx.set_materialize_grads(False)     # unused outputs (the last step's h', its dropped twin) arrive as None, not as zero fills
         require_device(x, h, w_ih, w_hh, b_ih, b_hh)
         x, h = f32c(x, "x"), f32c(h, "h")
@@ -812,6 +818,7 @@ class _GruBlock(torch.autograd.Function):
         ctx.cfg = (act, float(slope), identity is not None, bool(celu_in), None if rng is None else tuple(float(v) for v in rng))
         ctx.scope = scope
         ctx.carried = carry is not None
+        ctx.first_app = bool(first_app)
         return out, h_new, out_drop, (carry.view(-1) if ctx.carried else None)
 
     @staticmethod
@@ -885,6 +892,33 @@ class _GruBlock(torch.autograd.Function):
             check(lib.glam_ts_gemm_celu(ptr(d_gi), M, M, 0, ptr(image_t(w_ih)), None, ptr(dx), C, C, ptr(x) if celu_in else None, C, N, st),
                   "glam_ts_gemm_celu")
             check(lib.glam_ts_gemm_add(ptr(d_gh), M, M, ptr(image_t(w_hh)), None, ptr(dh), C, C, ptr(d_h), C, N, st), "glam_ts_gemm_add")
+        if ctx.carried and scope is not None and _o.GRU_WGRAD_BATCH and N >= _GRU_BATCH_MIN_ROWS:
+            # The weight gradients of ALL applications of the block in one launch pair: every application but the first parks its
+            # operands in the scope and passes the carry on untouched; the first one (its backward runs last: everything later in
+            # the forward depends on its outputs) multiplies the parked sets together — [d_gi_1; d_gi_2; d_gi_3]^T [x_1; x_2; x_3] —
+            # three sets per launch.  3 launches + 3 reductions -> 1 + 1 per training step at message_steps = 3.
+            key = ("gru-parked", id(w_ih))
+            parked = scope.bwd.setdefault(key, (w_ih, []))[1]
+            parked.append((d_gi, x, d_gh, h, bool(celu_in)))
+            if not ctx.first_app:
+                return dx, dh, d_id, None, None, None, None, None, None, None, d_carry, None, None
+            sets = list(parked)
+            parked.clear()
+            flat = torch.empty(2 * M * (C + 1), **f)
+            dw_ih, db_ih, dw_hh, db_hh = flat.split([M * C, M, M * C, M])
+            add = [None] * 4 if d_carry is None else list(f32c(d_carry, "d_carry").split([M * C, M, M * C, M]))
+            vp = ctypes.c_void_p
+            while sets:
+                grp = [t for t in sets if t[4] == sets[0][4]][:3]
+                sets = [t for t in sets if all(t is not u for u in grp)]
+                n = len(grp)
+                ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+                arr = lambda i: (vp * n)(*[t[i].data_ptr() for t in grp])
+                check(lib.glam_wgrad_gemm_pair_split_seg(n, arr(0), M, M, arr(1), C, C, int(grp[0][4]), ptr(dw_ih), ptr(db_ih), arr(2), M, M,
+                                                         arr(3), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(), ptr(add[0]),
+                                                         ptr(add[1]), ptr(add[2]), ptr(add[3]), st), "glam_wgrad_gemm_pair_split_seg")
+                add = [dw_ih, db_ih, dw_hh, db_hh]        # a further group adds onto the result in place
+            return dx, dh, d_id, None, None, None, None, None, None, None, flat, None, None
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         # one buffer [d_w_ih | d_b_ih | d_w_hh | d_b_hh], contiguous pieces; a gradient carry (same layout) is added by the reduction
@@ -898,8 +932,8 @@ class _GruBlock(torch.autograd.Function):
                                              ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
                                              ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
         if ctx.carried:
-            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None
-        return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None
+            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None, None
+        return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None, None
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):

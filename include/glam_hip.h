@@ -206,6 +206,16 @@ int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, const float* Q
                                float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes, const float* add_w_a,
                                const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 
+/* glam_wgrad_gemm_pair_split summed over nseg <= 3 operand sets of N rows each — Pa[s], Qa[s], Pb[s], Qb[s] with the same widths and
+ * row strides — in ONE launch + ONE reduction: the weight gradients of a block applied message_steps times with shared weights
+ * (/root/reference/src_1gp/model.py:53-54; the GRU's two gate matrices, src_1gp/layer.py:247) are one product over all its
+ * applications instead of one per application.  N must be at least a wave's row range (GLAM_E_UNSUPPORTED otherwise: run the sets
+ * one by one with the addends). */
+int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, int Ia, int ldpa, const float* const* Qa, int Ja, int ldqa, int qcelu_a,
+                                   float* dw_a, float* db_a, const float* const* Pb, int Ib, int ldpb, const float* const* Qb, int Jb,
+                                   int ldqb, int qcelu_b, float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes,
+                                   const float* add_w_a, const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
+
 /* glam_wgrad_gemm for ONE linear y = [x | 1] W^T with the weight and bias gradients in separate contiguous tensors:
  * dw[I, J] = P^T Q (P = dy f32[N, I], Q = x f32[N, J]), db[I] = column sums of P.  ceil4(J) + 1 <= 64, I <= 320; J need not be a
  * multiple of 4 when ldq >= ceil4(J) (a weight narrower than its zero-padded input: dw stays contiguous [I, J]). */

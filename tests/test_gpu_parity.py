@@ -2980,3 +2980,64 @@ def test_wgrad_split_writes_a_narrow_weight_gradient_contiguously(device):
     assert lin.linear.weight.grad.is_contiguous() and lin.linear.weight.grad.shape == (60, 15)
     assert_close(lin.linear.weight.grad, xin.sum(0).expand(60, 15), 2e-5, "LinearBlock(15, 60) weight gradient")
 
+
+@pytest.mark.parametrize("nseg,N", [(1, 5000), (2, 2500), (3, 20400), (3, 777)])
+def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
+    """glam_wgrad_gemm_pair_split_seg: both weight-gradient products of a GRU summed over the operand sets of up to three applications
+    in one launch + one reduction (waves whose row range straddles a set boundary included), with a carry addend, against fp64; one
+    set is the plain entry point bit for bit; sets too short for a wave's row range are refused."""
+    import ctypes
+    lib, p = ops._lib.load(), ops._lib.ptr
+    torch.manual_seed(nseg * 13 + N)
+    C, M = 60, 180
+    sets = [(torch.randn(N, M, device=device), torch.randn(N, C, device=device), torch.randn(N, M, device=device),
+             torch.randn(N, C, device=device)) for _ in range(nseg)]
+    add = [torch.randn(M, C, device=device), torch.randn(M, device=device), torch.randn(M, C, device=device), torch.randn(M, device=device)]
+    out = [torch.full_like(t, float("nan")) for t in add]
+    ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    arr = lambda i: (ctypes.c_void_p * nseg)(*[t[i].data_ptr() for t in sets])
+    rc = lib.glam_wgrad_gemm_pair_split_seg(nseg, arr(0), M, M, arr(1), C, C, 1, p(out[0]), p(out[1]), arr(2), M, M, arr(3), C, C, 0, p(out[2]),
+                                            p(out[3]), N, p(ws), ws.numel(), p(add[0]), p(add[1]), p(add[2]), p(add[3]), ops._lib.stream())
+    assert rc == 0, lib.glam_last_error()
+    celu = lambda t: torch.nn.functional.celu(t.double())
+    ref = [sum(t[0].double().t() @ celu(t[1]) for t in sets) + add[0].double(), sum(t[0].double().sum(0) for t in sets) + add[1].double(),
+           sum(t[2].double().t() @ t[3].double() for t in sets) + add[2].double(), sum(t[2].double().sum(0) for t in sets) + add[3].double()]
+    for o, r, name in zip(out, ref, ("dw_ih", "db_ih", "dw_hh", "db_hh")):
+        assert_close(o, r, 3e-6 * max(1.0, (nseg * N) ** 0.5 / 16), name)
+    if nseg == 1:
+        one = [torch.empty_like(t) for t in add]
+        t = sets[0]
+        assert lib.glam_wgrad_gemm_pair_split(p(t[0]), M, M, p(t[1]), C, C, 1, p(one[0]), p(one[1]), p(t[2]), M, M, p(t[3]), C, C, 0, p(one[2]),
+                                              p(one[3]), N, p(ws), ws.numel(), p(add[0]), p(add[1]), p(add[2]), p(add[3]), ops._lib.stream()) == 0
+        for a, b in zip(out, one):
+            assert torch.equal(a, b)
+    short = [(torch.randn(2, M, device=device), torch.randn(2, C, device=device)) * 2 for _ in range(3)]
+    arr2 = lambda i: (ctypes.c_void_p * 3)(*[t[i].data_ptr() for t in short])
+    assert lib.glam_wgrad_gemm_pair_split_seg(3, arr2(0), M, M, arr2(1), C, C, 0, p(out[0]), p(out[1]), arr2(2), M, M, arr2(3), C, C, 0, p(out[2]),
+                                              p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream()) == ops._lib.GLAM_E_UNSUPPORTED
+    assert lib.glam_wgrad_gemm_pair_split_seg(4, arr2(0), M, M, arr2(1), C, C, 0, p(out[0]), p(out[1]), arr2(2), M, M, arr2(3), C, C, 0, p(out[2]),
+                                              p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream()) == ops._lib.GLAM_E_INVALID
+
+
+@pytest.mark.parametrize("steps", [1, 3, 4])
+def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, monkeypatch):
+    """MessageBlock applied message_steps times: the GRU's weight gradients as ONE product over the parked operand sets of all
+    applications (four applications: a group of three, then one added in place) against one product per application."""
+    torch.manual_seed(steps)
+    b = synth_batch(160, seed=3).to(device)        # ~3 200 atoms: above the batching threshold
+    net = model.Architecture(mol_block="_TripletMessage", message_steps=steps).to(device).eval()
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", flag)
+        net.zero_grad()
+        out = net(b)
+        out.square().sum().backward()
+        grads[flag] = ({n: p.grad.clone() for n, p in net.named_parameters()}, out.detach().clone())
+    assert torch.equal(grads[True][1], grads[False][1])
+    for n in grads[True][0]:
+        a, c = grads[True][0][n], grads[False][0][n]
+        if "gru" in n:
+            assert_close(a, c, 3e-6, n)          # (another summation order)
+        else:
+            assert torch.equal(a, c), n
+
