@@ -818,24 +818,22 @@ def _apply_act(mod, x):
     return mod(x)
 
 
-def prestage_pass(lin_block, block, x, edge_attr):
-    """The weight re-layouts the first applications of ``lin_block`` (the input LinearBlock) and ``block`` (the MessageBlock) would
-    each build with a launch of their own — the linear's GEMM image, the TripletMessage's staged images, the four images of the GRU's
-    gate matrices — from ONE launch at the head of the pass (``ops.prestage``: the entries land in the pass's ``weight_scope`` under the
-    keys the ops look them up with).  Only the default routes are anticipated; anything else is built by its op as before."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
-        return 0
+def _prestage_items(lin_block, block, x, edge_attr):
+    """(triplet, images) of one tower for ``ops.prestage``: what the first applications of ``lin_block`` (the input LinearBlock) and
+    ``block`` (the MessageBlock) would each build with a launch of their own on their default routes."""
     triplet, images = None, []
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return triplet, images
     lin = getattr(lin_block, "linear", None)
-    if lin is not None and isinstance(getattr(lin_block, "norm", None), _None):
+    if lin is not None:
         M, Kw = lin.weight.shape
         Kx = _ceil4(x.size(1))
         if x.size(1) == Kw and M % 4 == 0 and ops.linear_supported(Kx, M) and not (Kx != Kw and x.requires_grad):
             images.append(("fwd", ("lin", id(lin.weight)), lin.weight, lin.weight, Kw, 1, Kw, M, Kx))
     conv = getattr(block, "conv", None)
     tm = getattr(conv, "conv", None) if isinstance(conv, _TripletMessage) else None
-    if type(tm) is TripletMessage and tm.heads <= 4 and edge_attr.dim() == 2 and edge_attr.size(1) == tm.edge_channels \
-            and ops.fused_layer_supported(tm.node_channels, tm.heads, tm.edge_channels):
+    if type(tm) is TripletMessage and tm.heads <= 4 and edge_attr is not None and edge_attr.dim() == 2 \
+            and edge_attr.size(1) == tm.edge_channels and ops.fused_layer_supported(tm.node_channels, tm.heads, tm.edge_channels):
         triplet = (tm.weight_node, tm.weight_edge, tm.weight_triplet_att, tm.weight_scale, tm.bias, tm.heads, _pad_de(tm.edge_channels))
     gru = getattr(block, "gru", None)
     if gru is not None:
@@ -844,7 +842,25 @@ def prestage_pass(lin_block, block, x, edge_attr):
         if C % 4 == 0 and w_ih.shape == (3 * C, C) and ops.gru_images_plain(x.size(0), C):
             images += [("fwd", ("lin", id(w_ih)), w_ih, w_ih, C, 1, C, 3 * C, C), ("fwd", ("lin", id(w_hh)), w_hh, w_hh, C, 1, C, 3 * C, C),
                        ("bwd", ("lin", id(w_ih)), w_ih, w_ih, C, 0, 3 * C, C, 3 * C), ("bwd", ("lin", id(w_hh)), w_hh, w_hh, C, 0, 3 * C, C, 3 * C)]
-    return ops.prestage(triplet, images)
+    return triplet, images
+
+
+def prestage_pass(*towers):
+    """The weight re-layouts of a model pass from as few launches as possible (``ops.prestage``: one TripletMessage staging + six GEMM
+    images per launch) instead of one launch per module at its first use.  ``towers``: ``(input LinearBlock, MessageBlock, x,
+    edge_attr)`` per graph tower.  The entries land in the pass's ``weight_scope`` under the keys the ops look them up with; only the
+    default routes are anticipated, anything else is built by its op as before."""
+    built, triplet, images = 0, None, []
+    for tower in towers:
+        t, im = _prestage_items(*tower)
+        if (t is not None and triplet is not None) or len(images) + len(im) > 6:
+            built += ops.prestage(triplet, images)
+            triplet, images = None, []
+        triplet = t if t is not None else triplet
+        images += im
+    if triplet is not None or images:
+        built += ops.prestage(triplet, images)
+    return built
 
 
 class LinearBlock(torch.nn.Module):

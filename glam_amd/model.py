@@ -53,7 +53,7 @@ class Architecture(torch.nn.Module):
         return out
 
     def _forward(self, data_mol):
-        prestage_pass(self.mol_lin0, self.mol_conv, data_mol.x, data_mol.edge_attr)    # (the pass's weight re-layouts from one launch)
+        prestage_pass((self.mol_lin0, self.mol_conv, data_mol.x, data_mol.edge_attr))  # (the pass's weight re-layouts from one launch)
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)                       # model.py:49
         hm = None
         for _ in range(self.message_steps):                                        # model.py:53-54
@@ -100,6 +100,8 @@ class ArchitectureDTI(torch.nn.Module):
             return self._forward(data_mol, data_pro)
 
     def _forward(self, data_mol, data_pro):
+        prestage_pass((self.mol_lin0, self.mol_conv, data_mol.x, data_mol.edge_attr),
+                      (self.pro_lin0, self.pro_conv, data_pro.x, data_pro.edge_attr))
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)
         xp = self.pro_lin0(data_pro.x, batch=data_pro.batch)
         hm, hp = None, None
@@ -148,6 +150,7 @@ class ArchitectureDDI(torch.nn.Module):
             return self._forward(mol1, mol2)
 
     def _forward(self, mol1, mol2):
+        prestage_pass((self.mol1_lin0, self.mol1_conv, mol1.x, mol1.edge_attr), (self.mol2_lin0, self.mol2_conv, mol2.x, mol2.edge_attr))
         x1 = self.mol1_lin0(mol1.x, batch=mol1.batch)
         x2 = self.mol2_lin0(mol2.x, batch=mol2.batch)
         h1, h2 = None, None
