@@ -323,10 +323,17 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_mid(as[s], wreg[s][t], acc[t]);
+        // (the large products in a chain of their own, added to the small + middle sums once at the end: the matrix instruction aligns
+        //  a small accumulator to the large products by truncation — towards -inf, a bias — where the final fp32 add rounds to nearest)
+        v4f_t accb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accb[t] = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_big(as[s], wreg[s][t], acc[t]);
+            for (int t = 0; t < 4; ++t) accb[t] = mfma_x3_big(as[s], wreg[s][t], accb[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += accb[t];
         // C layout: tile column = lane & 15 (-> logical columns cs * 64 + 4 c + t), row = (lane >> 4) * 4 + i
         if (m0 < M) {
             const float4 b = bias4;

@@ -194,6 +194,9 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
             // on top of the CT KS weight slices would not fit)
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[j] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+            v4f_t accb[CT];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) accb[j] = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 Bf16x3 x;
@@ -222,8 +225,11 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
                     if (lane == 0) flag_bump(s_taken + slot);
                 }
 #pragma unroll
-                for (int j = 0; j < CT; ++j) acc[j] = mfma_x3_big(wreg[s][j], x, acc[j]);
+                for (int j = 0; j < CT; ++j) accb[j] = mfma_x3_big(wreg[s][j], x, accb[j]);
             }
+            // (the large products in a chain of their own: see k_ts_gemm_x3)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[j] += accb[j];
         }
         if (row < a.N) {
 #pragma unroll
