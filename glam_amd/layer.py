@@ -806,16 +806,27 @@ def _apply_dropout(mod, x):
 _ZERO_KEEPING = (ReLU, LeakyReLU, CELU, RReLU)      # act(0) = 0: applied to zero-padded rows, the pad columns stay zero
 
 
-def _apply_act(mod, x):
+def _apply_act(mod, x, next_dropout=0.0):
     """``mod(x)`` for an activation slot; training-mode RReLU (the reference's default, model.py:31) draws its slopes from the
-    device-side Philox stream."""
+    device-side Philox stream.  ``next_dropout`` = p of a training-mode ``Dropout(p)`` that is applied to the result next (nothing in
+    between): the RReLU launch then writes the dropped twin too (``ops.take_dropped`` hands it to that dropout, whose own launch —
+    and its backward — disappear)."""
     if type(mod) in _ZERO_KEEPING and x.is_cuda and x.dim() == 2:
         base = ops.padded_base(x)
         if base is not None:       # odd hidden widths: no pad / slice copies around the activation
-            return ops.slice_cols(_apply_act(mod, base), x.size(1))
+            return ops.slice_cols(_apply_act(mod, base, next_dropout), x.size(1))
     if type(mod) is RReLU and mod.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
-        return ops.rrelu(x, mod.lower, mod.upper)
+        return ops.rrelu(x, mod.lower, mod.upper, drop_p=float(next_dropout))
     return mod(x)
+
+
+def following_dropout(block):
+    """p of the training-mode ``Dropout(p)`` that ``block`` (a LinearBlock / MessageBlock) applies to its input first, 0.0 when
+    something else touches the input before it (a norm) or there is none: the hint for the producer's activation launch."""
+    d = getattr(block, "dropout", None)
+    if type(d) is Dropout and d.training and 0.0 < d.p < 1.0 and isinstance(getattr(block, "norm", None), _None):
+        return float(d.p)
+    return 0.0
 
 
 def _prestage_items(lin_block, block, x, edge_attr):
@@ -871,7 +882,7 @@ class LinearBlock(torch.nn.Module):
         self.linear = Linear(in_dim, out_dim)
         self.act = _act(act)
 
-    def forward(self, x, batch=None):
+    def forward(self, x, batch=None, next_dropout=0.0):
         x = self.norm(x, batch)
         x = _apply_dropout(self.dropout, x)
         a = self.act
@@ -881,7 +892,7 @@ class LinearBlock(torch.nn.Module):
             if y is not None:
                 return y
         x = ops.linear(x, self.linear.weight, self.linear.bias)
-        return _apply_act(self.act, x)
+        return _apply_act(self.act, x, next_dropout)
 
 
 class MessageBlock(torch.nn.Module):

@@ -14,7 +14,7 @@ from . import ops
 
 from .layer import _None  # noqa: F401
 from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
-from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, prestage_pass
+from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, following_dropout, prestage_pass
 
 
 def model_args(args):
@@ -54,14 +54,15 @@ class Architecture(torch.nn.Module):
 
     def _forward(self, data_mol):
         prestage_pass((self.mol_lin0, self.mol_conv, data_mol.x, data_mol.edge_attr))  # (the pass's weight re-layouts from one launch)
-        xm = self.mol_lin0(data_mol.x, batch=data_mol.batch)                       # model.py:49
+        # (next_dropout: the block behind applies Dropout to this output first — the activation's launch writes the dropped twin)
+        xm = self.mol_lin0(data_mol.x, batch=data_mol.batch, next_dropout=following_dropout(self.mol_conv))     # model.py:49
         hm = None
         for _ in range(self.message_steps):                                        # model.py:53-54
             xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
         # PyG's pools read the graph count back from ``batch``; a collated Batch already knows it
         num_graphs = getattr(data_mol, "num_graphs", None) or None
         outm = self.mol_readout(xm, data_mol.batch, num_graphs)                    # model.py:57
-        outm = self.mol_flat(outm)                                                 # model.py:60
+        outm = self.mol_flat(outm, next_dropout=following_dropout(self.lin_out1))  # model.py:60
         return self.lin_out1(outm)                                                 # model.py:61
 
 
