@@ -940,13 +940,16 @@ class MessageBlock(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, h=None, batch=None):
         identity = x
-        if h is None:
+        seeded = h is None
+        if seeded:
             h = x.unsqueeze(0)                       # layer.py:254 (pre-norm x seeds the GRU state)
         if (self.res is not False and batch is not None and isinstance(self.norm, (_PairNorm, _LayerNorm)) and x.is_cuda
                 and torch.is_grad_enabled() and x.requires_grad):
             # x feeds the norm and the skip connection: the norm node hands x back as `identity`, so both gradient paths meet in its
             # backward kernel (one add launch per application less)
             x, identity = self.norm(x, batch, with_identity=True)
+            if seeded:
+                h = identity.unsqueeze(0)            # ... and the GRU state of the first application is that same tensor: one gradient
         else:
             x = self.norm(x, batch)
         x = _apply_dropout(self.dropout, x)
