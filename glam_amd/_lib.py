@@ -99,6 +99,9 @@ SIGNATURES = {
     "glam_graph_norm_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
     "glam_graph_norm_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
     "glam_graph_norm_bwd_add": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "glam_graph_norm_drop_supported": (_i32, [_i64, _i64, _i32]),
+    "glam_graph_norm_drop_fwd": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "glam_graph_norm_drop_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "glam_gru_gates_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "glam_wgrad_gemm_pair": (_i32, ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32] * 2) + [_i64, _vp, _sz, _vp]),
     "glam_ts_gemm_celu": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp]),

@@ -69,8 +69,7 @@ struct TailRngB { const long long* eff; float lo, hi, p; const float* d_out_drop
 // One Philox word per element: the RReLU slope comes from its high 16 bits, the Dropout decision from its low 16 bits
 // (independent halves of one uniform word).  Word of element i = philox4(i / 4)[i % 4], whatever thread computes it: the
 // vectorised paths below draw one Philox block per FOUR consecutive elements, the scalar paths one per element.
-__device__ __forceinline__ float rrelu_slope_w(unsigned w, float lo, float hi) { return fmaf(hi - lo, (float)(w >> 16) * (1.f / 65536.f), lo); }
-__device__ __forceinline__ float drop_scale_w(unsigned w, float p) { return (float)(w & 0xffffu) * (1.f / 65536.f) >= p ? 1.f / (1.f - p) : 0.f; }
+// (rrelu_slope_w / drop_scale_w: rng.h)
 __device__ __forceinline__ unsigned rng_word(const Philox& ph, size_t i) { return philox_word(philox4(ph, i >> 2), (int)(i & 3)); }
 __device__ __forceinline__ float4 ld4c(const float* p) { return *reinterpret_cast<const float4*>(p); }
 

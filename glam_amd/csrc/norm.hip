@@ -6,6 +6,7 @@
 //           y = x' / sqrt(mean_{n,c} x'^2 + eps)        (the per-channel weight/bias stay in the host mirror)
 // Statistics are recomputed in the backward pass from x (saved), so nothing but x is kept.
 #include "common.h"
+#include "rng.h"
 
 namespace glam {
 
@@ -150,9 +151,17 @@ __device__ __forceinline__ float4 rg_sum(float4 v) {      // over the 4 row grou
     return v;
 }
 
-template <int MODE>
+// DROP: the training-mode Dropout(p) that follows the norm in a MessageBlock (src_1gp/layer.py:255-256) from the same launch: y_drop =
+// y * mask / (1 - p) on the device-side Philox stream (element i draws word i % 4 of philox4(i / 4), like every RNG kernel of the
+// library); y itself is only stored when somebody wants it.
+struct NormDrop { long long* state; long long* eff; float p; float* y_drop; };
+struct NormDropB { const long long* eff; float p; const float* gy_drop; };
+
+template <int MODE, bool DROP>
 __global__ void __launch_bounds__(kBlock) k_graph_norm_fwd_v4(const float* x, const int* ptr, int B, int D, float scale,
-                                                             float eps, float* y) {
+                                                             float eps, float* y, NormDrop nd) {
+    Philox ph{};
+    if constexpr (DROP) ph = rng_begin(nd.state, nd.eff);
     const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
     const int wave = blockIdx.x * kWavesPerBlockN + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlockN;
@@ -197,17 +206,38 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_fwd_v4(const float* x, co
             for (int u = 0; u < kRowsPerLane; ++u) {
                 const int n = b0 + rg + 4 * u;
                 if (!small) row[u] = (act && n < end) ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
-                if (act && n < end)
-                    st4(y + (size_t)n * D + 4 * c4, make_float4((row[u].x - mean.x) * a, (row[u].y - mean.y) * a,
-                                                                 (row[u].z - mean.z) * a, (row[u].w - mean.w) * a));
+                if (act && n < end) {
+                    const size_t off = (size_t)n * D + 4 * c4;
+                    const float4 v = make_float4((row[u].x - mean.x) * a, (row[u].y - mean.y) * a, (row[u].z - mean.z) * a, (row[u].w - mean.w) * a);
+                    if (!DROP || y) st4(y + off, v);
+                    if constexpr (DROP) {
+                        const uint4 w4 = philox4(ph, off >> 2);
+                        st4(nd.y_drop + off, make_float4(v.x * drop_scale_w(w4.x, nd.p), v.y * drop_scale_w(w4.y, nd.p),
+                                                         v.z * drop_scale_w(w4.z, nd.p), v.w * drop_scale_w(w4.w, nd.p)));
+                    }
+                }
             }
         }
     }
+    if constexpr (DROP) rng_end(nd.state, ph);
 }
 
-template <int MODE>
+template <int MODE, bool DROP>
 __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_v4(const float* x, const float* gy, const int* ptr, int B, int D,
-                                                             float scale, float eps, float* dx, const float* addend) {
+                                                             float scale, float eps, float* dx, const float* addend, NormDropB nd) {
+    Philox ph{};
+    if constexpr (DROP) ph = philox_init(nd.eff);
+    // the gradient of y: gy, plus (DROP) the dropped twin's gradient through the regenerated mask (gy may then be null)
+    auto gload = [&](size_t off) -> float4 {
+        float4 g = (!DROP || gy) ? ld4(gy + off) : f4zero();
+        if constexpr (DROP) {
+            const float4 gd = ld4(nd.gy_drop + off);
+            const uint4 w4 = philox4(ph, off >> 2);
+            g.x = fmaf(gd.x, drop_scale_w(w4.x, nd.p), g.x); g.y = fmaf(gd.y, drop_scale_w(w4.y, nd.p), g.y);
+            g.z = fmaf(gd.z, drop_scale_w(w4.z, nd.p), g.z); g.w = fmaf(gd.w, drop_scale_w(w4.w, nd.p), g.w);
+        }
+        return g;
+    };
     const int lane = threadIdx.x & 63, c4 = lane & 15, rg = lane >> 4;
     const int wave = blockIdx.x * kWavesPerBlockN + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * kWavesPerBlockN;
@@ -225,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_v4(const float* x, co
                 const int n = b0 + rg + 4 * u;
                 const bool okr = act && n < end;
                 xr[u] = okr ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
-                gr[u] = okr ? ld4(gy + (size_t)n * D + 4 * c4) : f4zero();
+                gr[u] = okr ? gload((size_t)n * D + 4 * c4) : f4zero();
             }
 #pragma unroll
             for (int u = 0; u < kRowsPerLane; ++u) {
@@ -247,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_v4(const float* x, co
                 const bool okr = act && n < end;
                 if (!small) {
                     xr[u] = okr ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
-                    gr[u] = okr ? ld4(gy + (size_t)n * D + 4 * c4) : f4zero();
+                    gr[u] = okr ? gload((size_t)n * D + 4 * c4) : f4zero();
                 }
                 if (okr) {
                     const float d0 = xr[u].x - mean.x, d1 = xr[u].y - mean.y, d2 = xr[u].z - mean.z, d3 = xr[u].w - mean.w;
@@ -268,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) k_graph_norm_bwd_v4(const float* x, co
                 const bool okr = act && n < end;
                 if (!small) {
                     xr[u] = okr ? ld4(x + (size_t)n * D + 4 * c4) : f4zero();
-                    gr[u] = okr ? ld4(gy + (size_t)n * D + 4 * c4) : f4zero();
+                    gr[u] = okr ? gload((size_t)n * D + 4 * c4) : f4zero();
                 }
                 if (okr) {
                     float4 v = make_float4(a * (gr[u].x - gbar.x) - coef * (xr[u].x - mean.x), a * (gr[u].y - gbar.y) - coef * (xr[u].y - mean.y),
@@ -418,8 +448,8 @@ extern "C" int glam_graph_norm_fwd(const float* x, const int32_t* ptr, int64_t N
     }
     const dim3 grid(grid_for(B, kWavesPerBlockN));
     if ((D & 3) == 0 && D <= 64) {
-        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_fwd_v4<0>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
-        else hipLaunchKernelGGL(k_graph_norm_fwd_v4<1>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
+        if (mode == 0) hipLaunchKernelGGL((k_graph_norm_fwd_v4<0, false>), grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y, NormDrop{});
+        else hipLaunchKernelGGL((k_graph_norm_fwd_v4<1, false>), grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y, NormDrop{});
     } else if (mode == 0) hipLaunchKernelGGL(k_graph_norm_fwd<0>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
     else hipLaunchKernelGGL(k_graph_norm_fwd<1>, grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y);
     GLAM_LAUNCH_CHECK("glam_graph_norm_fwd");
@@ -442,8 +472,8 @@ static int graph_norm_bwd_impl(const float* x, const float* gy, const int32_t* p
     }
     const dim3 grid(grid_for(B, kWavesPerBlockN));
     if ((D & 3) == 0 && D <= 64) {
-        if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd_v4<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
-        else hipLaunchKernelGGL(k_graph_norm_bwd_v4<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
+        if (mode == 0) hipLaunchKernelGGL((k_graph_norm_bwd_v4<0, false>), grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend, NormDropB{});
+        else hipLaunchKernelGGL((k_graph_norm_bwd_v4<1, false>), grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend, NormDropB{});
     } else if (mode == 0) hipLaunchKernelGGL(k_graph_norm_bwd<0>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
     else hipLaunchKernelGGL(k_graph_norm_bwd<1>, grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend);
     GLAM_LAUNCH_CHECK("glam_graph_norm_bwd");
@@ -462,3 +492,43 @@ extern "C" int glam_graph_norm_bwd_add(const float* x, const float* gy, const in
     GLAM_REQUIRE(addend, "glam_graph_norm_bwd_add: null addend");
     return graph_norm_bwd_impl(x, gy, ptr, N, B, D, mode, scale, eps, addend, dx, stream);
 }
+
+// ---- the norm + the Dropout(p) behind it (MessageBlock: x = norm(x); x = dropout(x); src_1gp/layer.py:255-256) in one launch each way ----
+extern "C" int glam_graph_norm_drop_supported(int64_t N, int64_t B, int D) {
+    return B > 0 && N > 0 && N / B < 64 && (D & 3) == 0 && D <= 64;       // the lane-per-row kernels (molecule-sized graphs)
+}
+
+extern "C" int glam_graph_norm_drop_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode, float scale, float eps,
+                                        float drop_p, int64_t* rng_state, int64_t* rng_eff, float* y, float* y_drop, void* stream) {
+    if (int rc = norm_dims("glam_graph_norm_drop_fwd", N, B, D, mode)) return rc;
+    GLAM_REQUIRE(drop_p > 0.f && drop_p < 1.f, "glam_graph_norm_drop_fwd: dropout p = %g outside (0, 1)", drop_p);
+    if (!glam_graph_norm_drop_supported(N, B, D))
+        return fail(GLAM_E_UNSUPPORTED, "glam_graph_norm_drop_fwd: N=%lld B=%lld D=%d outside the fused kernels (D %% 4 == 0, D <= 64, < 64 nodes per graph)",
+                    (long long)N, (long long)B, D);
+    GLAM_REQUIRE(x && ptr && y_drop && rng_state && rng_eff && aligned16(x) && aligned16(y) && aligned16(y_drop),
+                 "glam_graph_norm_drop_fwd: null / misaligned pointer");
+    const dim3 block(kBlock), grid(grid_for(B, kWavesPerBlockN));
+    NormDrop nd{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), drop_p, y_drop};
+    if (mode == 0) hipLaunchKernelGGL((k_graph_norm_fwd_v4<0, true>), grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y, nd);
+    else hipLaunchKernelGGL((k_graph_norm_fwd_v4<1, true>), grid, block, 0, (hipStream_t)stream, x, ptr, (int)B, D, scale, eps, y, nd);
+    GLAM_LAUNCH_CHECK("glam_graph_norm_drop_fwd");
+    return GLAM_OK;
+}
+
+extern "C" int glam_graph_norm_drop_bwd(const float* x, const float* gy, const float* gy_drop, const int32_t* ptr, int64_t N, int64_t B, int D,
+                                        int mode, float scale, float eps, float drop_p, const int64_t* rng_eff, const float* addend, float* dx,
+                                        void* stream) {
+    if (int rc = norm_dims("glam_graph_norm_drop_bwd", N, B, D, mode)) return rc;
+    GLAM_REQUIRE(drop_p > 0.f && drop_p < 1.f, "glam_graph_norm_drop_bwd: dropout p = %g outside (0, 1)", drop_p);
+    if (!glam_graph_norm_drop_supported(N, B, D))
+        return fail(GLAM_E_UNSUPPORTED, "glam_graph_norm_drop_bwd: N=%lld B=%lld D=%d outside the fused kernels", (long long)N, (long long)B, D);
+    GLAM_REQUIRE(x && gy_drop && ptr && dx && rng_eff && aligned16(x) && aligned16(gy) && aligned16(gy_drop) && aligned16(addend) && aligned16(dx),
+                 "glam_graph_norm_drop_bwd: null / misaligned pointer");
+    const dim3 block(kBlock), grid(grid_for(B, kWavesPerBlockN));
+    NormDropB nd{reinterpret_cast<const long long*>(rng_eff), drop_p, gy_drop};
+    if (mode == 0) hipLaunchKernelGGL((k_graph_norm_bwd_v4<0, true>), grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend, nd);
+    else hipLaunchKernelGGL((k_graph_norm_bwd_v4<1, true>), grid, block, 0, (hipStream_t)stream, x, gy, ptr, (int)B, D, scale, eps, dx, addend, nd);
+    GLAM_LAUNCH_CHECK("glam_graph_norm_drop_bwd");
+    return GLAM_OK;
+}
+

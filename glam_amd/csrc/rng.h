@@ -76,4 +76,9 @@ __device__ __forceinline__ void rng_end(long long* state, const Philox& p) {
     }
 }
 
+// One Philox word per element: an RReLU slope comes from its high 16 bits, a Dropout decision from its low 16 bits (independent halves
+// of one uniform word)
+__device__ __forceinline__ float rrelu_slope_w(unsigned w, float lo, float hi) { return fmaf(hi - lo, (float)(w >> 16) * (1.f / 65536.f), lo); }
+__device__ __forceinline__ float drop_scale_w(unsigned w, float p) { return (float)(w & 0xffffu) * (1.f / 65536.f) >= p ? 1.f / (1.f - p) : 0.f; }
+
 }  // namespace glam

@@ -623,12 +623,16 @@ class PairNorm(torch.nn.Module):
             raise GlamHipError("PairNorm(scale_individually=True) is not used by the reference")
         self.scale, self.eps = scale, eps
 
-    def forward(self, x, batch=None, with_identity=False):
+    def forward(self, x, batch=None, with_identity=False, drop_p=0.0):
         if batch is None:
             xc = x - x.mean(dim=0, keepdim=True)
             out = self.scale * xc / (self.eps + xc.pow(2).sum(-1).mean()).sqrt()
             return (out, x) if with_identity else out
-        return ops.pair_norm(x, ops.segment_ptr(batch), self.scale, self.eps, with_identity=with_identity)
+        return ops.pair_norm(x, ops.segment_ptr(batch), self.scale, self.eps, with_identity=with_identity, drop_p=drop_p)
+
+    def drop_supported(self, x, batch):
+        """The training-mode Dropout behind this norm can come from the norm's own launch (``forward(..., drop_p=p)``)."""
+        return batch is not None and ops.graph_norm_drop_supported(x, ops.segment_ptr(batch))
 
 
 class GraphSizeNorm(torch.nn.Module):
@@ -663,7 +667,9 @@ class _PairNorm(torch.nn.Module):
         super().__init__()
         self.norm = PairNorm()
 
-    def forward(self, x, batch=None, with_identity=False):
+    def forward(self, x, batch=None, with_identity=False, drop_p=0.0):
+        if drop_p > 0:
+            return self.norm(x, batch, with_identity, drop_p)
         return self.norm(x, batch, with_identity) if with_identity else self.norm(x, batch)
 
 
@@ -915,6 +921,14 @@ class MessageBlock(torch.nn.Module):
         g = self.gru
         return ops.gru_step(x, h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
 
+    def _norm_drop_p(self, x, batch):
+        """p when this block's training-mode Dropout can come out of its norm's launch (a PairNorm over molecule-sized graphs), else 0."""
+        d = self.dropout
+        if (type(d) is Dropout and d.training and 0.0 < d.p < 1.0 and isinstance(self.norm, _PairNorm) and ops.NORM_DROP
+                and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and self.norm.norm.drop_supported(x, batch)):
+            return float(d.p)
+        return 0.0
+
     def _fusable_act(self):
         """(code, slope, rng) when ``self.act`` is one the tail kernels apply themselves, else None.  ``rng`` is
         ``(rr_lower, rr_upper, drop_p)`` in training mode when the kernel has random numbers to draw: RReLU slopes, and — when
@@ -947,12 +961,16 @@ class MessageBlock(torch.nn.Module):
                 and torch.is_grad_enabled() and x.requires_grad):
             # x feeds the norm and the skip connection: the norm node hands x back as `identity`, so both gradient paths meet in its
             # backward kernel (one add launch per application less)
-            x, identity = self.norm(x, batch, with_identity=True)
+            # ... and with it the training-mode Dropout that follows (layer.py:255-256: run.py's PairNorm + Dropout(0.2)): one launch
+            drop_p = self._norm_drop_p(x, batch)
+            x, identity = self.norm(x, batch, with_identity=True, drop_p=drop_p) if drop_p > 0 else self.norm(x, batch, with_identity=True)
             if seeded:
                 h = identity.unsqueeze(0)            # ... and the GRU state of the first application is that same tensor: one gradient
         else:
-            x = self.norm(x, batch)
-        x = _apply_dropout(self.dropout, x)
+            drop_p = self._norm_drop_p(x, batch)
+            x = self.norm(x, batch, drop_p=drop_p) if drop_p > 0 else self.norm(x, batch)
+        if drop_p == 0:
+            x = _apply_dropout(self.dropout, x)
         fa = self._fusable_act()
         if self.gru is None and isinstance(self.conv, (_GCNConv, _GATConv)) and fa is not None:
             # no GRU (layer.py:248): conv bias + residual + activation as one launch per direction

@@ -1050,6 +1050,8 @@ GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
 SKIP_THROUGH_CONV = os.environ.get("GLAM_SKIP_THROUGH_CONV", "1") == "1"
 # the GRU's weight gradients of all applications of a block in one launch pair (glam_wgrad_gemm_pair_split_seg): A/B switch
 GRU_WGRAD_BATCH = os.environ.get("GLAM_GRU_WGRAD_BATCH", "1") == "1"
+# PairNorm + the Dropout behind it from one launch each way (glam_graph_norm_drop_*): A/B switch
+NORM_DROP = os.environ.get("GLAM_NORM_DROP", "1") == "1"
 # the derived weights of a model pass from one launch (glam_prestage) instead of one per module: A/B switch
 PRESTAGE = os.environ.get("GLAM_PRESTAGE", "1") == "1"
 # the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch

@@ -310,15 +310,24 @@ class _GraphNorm(torch.autograd.Function):
     backward kernel sums them in its store (glam_graph_norm_bwd_add) instead of autograd launching an add."""
 
     @staticmethod
-    def forward(ctx, x, sp, mode, scale, eps, with_identity=False):
+    def forward(ctx, x, sp, mode, scale, eps, with_identity=False, drop_p=0.0):
         require_device(x)
         x = f32c(x, "x")
         N, D = x.shape
         if N != sp.N:
             raise GlamHipError(f"graph_norm: x has {N} rows but batch has {sp.N}")
-        y = torch.zeros_like(x) if sp.B == 0 else torch.empty_like(x)
-        check(_lib.load().glam_graph_norm_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, mode, float(scale), float(eps), ptr(y), stream()),
-              "glam_graph_norm_fwd")
+        ctx.drop_p, ctx.eff = float(drop_p), None
+        if drop_p > 0:
+            # the training-mode Dropout(drop_p) behind the norm from the same launch: the output IS the dropped tensor (graph_norm_drop_supported)
+            y = torch.empty_like(x)
+            ctx.eff = torch.empty(2, dtype=torch.int64, device=x.device)
+            check(_lib.load().glam_graph_norm_drop_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, mode, float(scale), float(eps), float(drop_p),
+                                                       ptr(_o.rng_state(x.device)), ptr(ctx.eff), None, ptr(y), stream()),
+                  "glam_graph_norm_drop_fwd")
+        else:
+            y = torch.zeros_like(x) if sp.B == 0 else torch.empty_like(x)
+            check(_lib.load().glam_graph_norm_fwd(ptr(x), ptr(sp.ptr), N, sp.B, D, mode, float(scale), float(eps), ptr(y), stream()),
+                  "glam_graph_norm_fwd")
         ctx.save_for_backward(x)
         ctx.sp, ctx.cfg = sp, (mode, float(scale), float(eps))
         if with_identity:
@@ -334,29 +343,41 @@ class _GraphNorm(torch.autograd.Function):
         sp = ctx.sp
         N, D = x.shape
         if gy is None:                  # only the identity output was used
-            return d_id, None, None, None, None, None
+            return d_id, None, None, None, None, None, None
         gy = f32c(gy, "gy")
         dx = torch.empty_like(x)
         lib = _lib.load()
+        if ctx.drop_p > 0:              # gy is the gradient of the DROPPED output: the mask is regenerated inside the launch
+            check(lib.glam_graph_norm_drop_bwd(ptr(x), None, ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ctx.drop_p, ptr(ctx.eff),
+                                               ptr(None if d_id is None else f32c(d_id, "d_identity")), ptr(dx), stream()),
+                  "glam_graph_norm_drop_bwd")
+            return dx, None, None, None, None, None, None
         if d_id is not None and N > 0 and sp.B > 0:
             check(lib.glam_graph_norm_bwd_add(ptr(x), ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ptr(f32c(d_id, "d_identity")), ptr(dx),
                                               stream()), "glam_graph_norm_bwd_add")
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None
         check(lib.glam_graph_norm_bwd(ptr(x), ptr(gy), ptr(sp.ptr), N, sp.B, D, mode, scale, eps, ptr(dx), stream()),
               "glam_graph_norm_bwd")
         if d_id is not None:
             dx = d_id if (N == 0 or sp.B == 0) else dx + d_id
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def pair_norm(x, sp, scale=1.0, eps=1e-5, with_identity=False):
-    """PyG ``PairNorm(scale, eps=1e-5)(x, batch)`` (one kernel per direction); ``with_identity``: ``(y, x)`` — see _GraphNorm."""
-    return _GraphNorm.apply(x, sp, 0, scale, eps, with_identity)
+def graph_norm_drop_supported(x, sp):
+    """The norm + Dropout launch pair exists for this shape (molecule-sized graphs, a multiple of 4 channels <= 64)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and sp.B > 0
+            and _lib.load().glam_graph_norm_drop_supported(x.size(0), sp.B, x.size(1)) == 1)
+
+
+def pair_norm(x, sp, scale=1.0, eps=1e-5, with_identity=False, drop_p=0.0):
+    """PyG ``PairNorm(scale, eps=1e-5)(x, batch)`` (one kernel per direction); ``with_identity``: ``(y, x)`` — see _GraphNorm;
+    ``drop_p > 0`` (``graph_norm_drop_supported``): the result is ``Dropout(drop_p)(PairNorm(x))`` in training mode, from the one launch."""
+    return _GraphNorm.apply(x, sp, 0, scale, eps, with_identity, drop_p)
 
 
 def graph_standardize(x, sp, eps=1e-5, with_identity=False):
     """Statistics part of PyG's graph ``LayerNorm(x, batch)``: zero mean / unit variance per graph."""
-    return _GraphNorm.apply(x, sp, 1, 1.0, eps, with_identity)
+    return _GraphNorm.apply(x, sp, 1, 1.0, eps, with_identity, 0.0)
 
 
 class _EdgeWeightedSum(torch.autograd.Function):

@@ -392,6 +392,19 @@ int glam_graph_norm_bwd(const float* x, const float* gy, const int32_t* ptr, int
 int glam_graph_norm_bwd_add(const float* x, const float* gy, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
                             float scale, float eps, const float* addend, float* dx, void* stream);
 
+/* The norm and the training-mode Dropout(p) a MessageBlock applies right behind it (x = norm(x); x = dropout(x),
+ * /root/reference/src_1gp/layer.py:255-256; run.py's default configuration: _PairNorm + Dropout(0.2)) in ONE launch each way, on the
+ * device-side Philox stream (rng_state: int64[GLAM_RNG_STATE_WORDS], advanced by the launch; rng_eff: int64[2], the stream position
+ * the forward used, handed to the backward, which regenerates the mask).  y_drop = y * mask / (1 - p); y (the plain output) may be
+ * NULL when nobody reads it.  Backward: dx = norm'(gy + mask / (1 - p) * gy_drop) (+ addend, may be NULL: see
+ * glam_graph_norm_bwd_add); gy may be NULL.  Molecule-sized graphs only (glam_graph_norm_drop_supported: D % 4 == 0, D <= 64, fewer
+ * than 64 nodes per graph on average), GLAM_E_UNSUPPORTED otherwise (run the two ops one after the other). */
+int glam_graph_norm_drop_supported(int64_t N, int64_t B, int D);
+int glam_graph_norm_drop_fwd(const float* x, const int32_t* ptr, int64_t N, int64_t B, int D, int mode, float scale, float eps, float drop_p,
+                             int64_t* rng_state, int64_t* rng_eff, float* y, float* y_drop, void* stream);
+int glam_graph_norm_drop_bwd(const float* x, const float* gy, const float* gy_drop, const int32_t* ptr, int64_t N, int64_t B, int D, int mode,
+                             float scale, float eps, float drop_p, const int64_t* rng_eff, const float* addend, float* dx, void* stream);
+
 /* Edge-weighted neighbour sums over a CSR-by-target: S[n,k,:] = (mean ? 1/deg_n : 1) * sum_{e -> n} w[eid e, k] *
  * x[src e, :]  (x f32[N,D], w f32[E,K], K in {1,4,8}, out f32[N,K,D]; K = 1 with w = the symmetric degree
  * normalisation is GCNConv's propagate, src_2gi_dti_scr/layer.py:143-149).  With one-hot edge features this is the per-relation

@@ -3042,3 +3042,47 @@ def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, m
         else:
             assert torch.equal(a, c), n
 
+
+@pytest.mark.parametrize("block", ["_NNConv", "_TripletMessage"])
+def test_pair_norm_and_the_dropout_behind_it_in_one_launch(device, monkeypatch, block):
+    """run.py's default block (norm = _PairNorm, Dropout(0.2); src_1gp/layer.py:255-256) in training mode: the Dropout comes out of the
+    norm's launch (glam_graph_norm_drop_fwd / _bwd) — the same Philox words for the same elements as the stand-alone Dropout launch, so
+    the whole training step is bit-identical to the two-launch form; three launches per direction and step less."""
+    from glam_amd._lib import kernel_timer
+    torch.manual_seed(21)
+    b = synth_batch(64, seed=9).to(device)
+    net = model.Architecture(mol_block=block, graph_norm="_PairNorm", message_steps=3).to(device).train()
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "NORM_DROP", flag)
+        ops.manual_seed(1234)
+        net.zero_grad()
+        with kernel_timer() as kt:
+            out = net(b)
+            out.square().sum().backward()
+        names = [r[0] for r in kt.records()]
+        res[flag] = (out.detach().clone(), [p.grad.clone() for p in net.parameters()],
+                     sum("k_bias_res_act_fwd" in n for n in names), sum("k_bias_res_act_bwd" in n for n in names))
+    assert torch.equal(res[True][0], res[False][0])
+    for a, c in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, c)
+    assert res[False][2] - res[True][2] == 3 and res[False][3] - res[True][3] == 3, (res[True][2:], res[False][2:])
+    # C ABI: shapes outside the fused kernels are refused, p must lie in (0, 1)
+    lib, p = ops._lib.load(), ops._lib.ptr
+    x = torch.randn(100, 60, device=device)
+    sp = ops.segment_ptr(torch.arange(100, device=device) // 10)
+    y = torch.empty_like(x)
+    eff = torch.empty(2, dtype=torch.int64, device=device)
+    st = ops.rng_state(device)
+    assert lib.glam_graph_norm_drop_fwd(p(x), p(sp.ptr), 100, 10, 60, 0, 1.0, 1e-5, 0.0, p(st), p(eff), None, p(y), ops._lib.stream()) == ops._lib.GLAM_E_INVALID
+    assert lib.glam_graph_norm_drop_fwd(p(x), p(sp.ptr), 100, 1, 60, 0, 1.0, 1e-5, 0.2, p(st), p(eff), None, p(y), ops._lib.stream()) == ops._lib.GLAM_E_UNSUPPORTED
+    assert lib.glam_graph_norm_drop_supported(100, 10, 60) == 1 and lib.glam_graph_norm_drop_supported(100, 10, 62) == 0
+    # the plain output beside the dropped one: y_drop is y * {0, 1 / (1 - p)}
+    yp = torch.empty_like(x)
+    assert lib.glam_graph_norm_drop_fwd(p(x), p(sp.ptr), 100, 10, 60, 0, 1.0, 1e-5, 0.25, p(st), p(eff), p(yp), p(y), ops._lib.stream()) == 0
+    ref = ops.pair_norm(x, sp)
+    assert torch.equal(yp, ref)
+    keep = y != 0
+    assert torch.equal(y[keep], (ref * (1.0 / 0.75))[keep]) and 0.6 < keep.float().mean().item() < 0.9
+
