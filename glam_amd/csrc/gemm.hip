@@ -726,9 +726,13 @@ static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJ
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
     int blocks = 0;
     if (int rc = plan_wgrad(a, out, si, sj, wgrad_budget(a.N), job, &blocks)) return rc;
+    if (a.nseg > 1 && a.rows_per_wave > a.seg_rows)
+        return fail(GLAM_E_UNSUPPORTED, "wgrad: %d operand sets of %d rows are too short for a wave's %d rows (run them one by one)", a.nseg,
+                    a.seg_rows, a.rows_per_wave);
     WgArgs2 two{a, a, blocks};
-    GLAM_PROF_LABEL(a.q_celu ? "k_wgrad<true>" : "k_wgrad<false>");      // (the labels bench.py's kernel table is keyed by)
-    if (a.q_celu) hipLaunchKernelGGL((k_wgrad<true, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
+    GLAM_PROF_LABEL(a.nseg > 1 ? "k_wgrad<true, sets>" : a.q_celu ? "k_wgrad<true>" : "k_wgrad<false>");      // (the labels bench.py's kernel table is keyed by)
+    if (a.nseg > 1) hipLaunchKernelGGL((k_wgrad<true, true>), dim3(blocks), dim3(kWgBlock), 0, s, two);
+    else if (a.q_celu) hipLaunchKernelGGL((k_wgrad<true, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
     else hipLaunchKernelGGL((k_wgrad<false, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad");
     return GLAM_OK;
@@ -989,6 +993,31 @@ extern "C" int glam_wgrad_gemm_add(const float* P1, int I1, int ldp1, const floa
                                    int stride_j, const float* addend, void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(addend, "glam_wgrad_gemm_add: null addend");
     return wgrad_gemm_impl(P1, I1, ldp1, P2, I2, ldp2, ones, Q, J, ldq, qones, N, out, stride_i, stride_j, addend, ws, ws_bytes, stream);
+}
+
+// glam_wgrad_gemm (one P block) summed over nseg <= 3 operand sets of N rows each, + an optional addend: the weight gradient of a
+// tall matmul applied message_steps times with shared weights (NNConv's relation product, src_1gp/layer.py:115-122) as ONE product.
+extern "C" int glam_wgrad_gemm_sets(int nseg, const float* const* P, int I, int ldp, int ones, const float* const* Q, int J, int ldq,
+                                    int64_t N, float* out, int stride_i, int stride_j, const float* addend, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    const char* fn = "glam_wgrad_gemm_sets";
+    GLAM_REQUIRE(nseg >= 1 && nseg <= 3, "%s: %d operand sets (1..3)", fn, nseg);
+    GLAM_REQUIRE(P && Q && out && ws, "%s: null pointer", fn);
+    GLAM_REQUIRE(N >= 1 && N * nseg < INT32_MAX, "%s: N out of range", fn);
+    GLAM_REQUIRE(J <= 64, "%s: J = %d > 64 (chunked products run set by set)", fn, J);
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace too small", fn);
+    for (int q = 0; q < nseg; ++q)
+        GLAM_REQUIRE(P[q] && Q[q] && aligned16(P[q]) && aligned16(Q[q]), "%s: operand set %d: null / misaligned pointer", fn, q);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    WgArgs a{P[0], I, ldp, nullptr, 0, 0, ones, Q[0], J, ldq, 0, (int)(N * nseg), 0, partial, 0, 0};
+    a.nseg = nseg;
+    a.seg_rows = (int)N;
+    for (int q = 1; q < nseg; ++q) { a.segP1[q - 1] = P[q]; a.segQ[q - 1] = Q[q]; }
+    ReduceArgs ra{};
+    ra.njobs = 1;
+    if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, (hipStream_t)stream, &ra.job[0])) return rc;
+    ra.job[0].addend = addend;
+    return launch_final_reduce(ra, (hipStream_t)stream);
 }
 
 // [d_W | d_b] of one linear y = [x | 1] W^T, weight and bias into SEPARATE contiguous tensors (autograd takes them as they are; a

@@ -153,13 +153,14 @@ class _MatmulTall(torch.autograd.Function):
     times per forward (see _ParamBundle): [d_w | d_bias] flat, summed by the reduction of the weight-gradient product."""
 
     @staticmethod
-    def forward(ctx, a, w, bias, carry=None):
+    def forward(ctx, a, w, bias, carry=None, first_app=True):
         require_device(a, w, bias)
         a, w = f32c(a, "a"), f32c(w, "w")
         ctx.save_for_backward(a, w)
         ctx.has_bias = bias is not None
         ctx.scope = _o._SCOPE
         ctx.carried = carry is not None
+        ctx.first_app = bool(first_app)
         if ctx.carried:
             ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
         N, K = a.shape
@@ -184,7 +185,7 @@ class _MatmulTall(torch.autograd.Function):
         N, K = a.shape
         M = w.size(1)
         if dy is None:      # only with a carry (grads are not materialised then): the output itself was unused
-            return None, None, None, d_carry
+            return None, None, None, d_carry, None
         dy = f32c(dy, "dy")
         da = None
         if ctx.needs_input_grad[0]:
@@ -199,6 +200,28 @@ class _MatmulTall(torch.autograd.Function):
             else:
                 da = torch.matmul(dy, w.t())
         dw = db = None
+        scope = ctx.scope
+        if ctx.carried and ctx.has_bias and M <= 64 and scope is not None and _o.GRU_WGRAD_BATCH and N >= _GRU_BATCH_MIN_ROWS:
+            # the weight gradient of ALL applications of the block in one launch (see _GruBlock.backward): every application but the first
+            # parks (a, dy); the first one — its backward runs last — multiplies the parked sets together, three per launch
+            lib = _lib.load()
+            parked = scope.bwd.setdefault(("tall-parked", id(w)), (w, []))[1]
+            parked.append((a, dy))
+            if not ctx.first_app:
+                return da, None, None, d_carry, None
+            sets = list(parked)
+            parked.clear()
+            dwb = torch.empty(K + 1, M, dtype=torch.float32, device=a.device)
+            add = None if d_carry is None else f32c(d_carry, "d_carry")
+            vp = ctypes.c_void_p
+            while sets:
+                grp, sets = sets[:3], sets[3:]
+                n = len(grp)
+                ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
+                check(lib.glam_wgrad_gemm_sets(n, (vp * n)(*[t[0].data_ptr() for t in grp]), K, K, 1, (vp * n)(*[t[1].data_ptr() for t in grp]),
+                                               M, M, N, ptr(dwb), M, 1, ptr(add), ptr(ws), ws.numel(), stream()), "glam_wgrad_gemm_sets")
+                add = dwb
+            return da, None, None, dwb.view(-1), None
         if ctx.needs_input_grad[1] or ctx.has_bias or ctx.carried:
             lib = _lib.load()
             ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=a.device)
@@ -218,8 +241,8 @@ class _MatmulTall(torch.autograd.Function):
                 product(a, K, K, 1, dy, M, M, dwb, M, 1)
                 if ctx.carried:
                     flat = dwb.view(-1)
-                    return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
-                return da, dwb[:K], dwb[K]
+                    return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry)), None
+                return da, dwb[:K], dwb[K], None, None
             dw = torch.empty(K, M, dtype=torch.float32, device=a.device)
             if M <= 128:      # dw = a^T dy: P = a (up to 320 columns), Q = dy (two 64-column chunks beyond 64)
                 product(a, K, K, 0, dy, M, M, dw, M, 1)
@@ -227,8 +250,8 @@ class _MatmulTall(torch.autograd.Function):
                 product(dy, M, M, 0, a, K, K, dw, 1, M)
             if ctx.carried:
                 flat = dw.view(-1)
-                return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
-        return da, dw, db
+                return da, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry)), None
+        return da, dw, db, None, None
 
 
 def _matmul_tall_node(a, w, bias):
@@ -240,10 +263,12 @@ def _matmul_tall_node(a, w, bias):
     def split(flat):     # [d_w (K x M) | d_bias (M)]: the layout of the [a | 1]^T dy product
         return (flat[:K * M].view(K, M),) if bias is None else (flat[:K * M].view(K, M), flat[K * M:])
     key = ("carry-tall", id(w), id(bias))
+    hit = _o._SCOPE.fwd.get(key) if _o._SCOPE is not None else None
+    first = not (hit is not None and hit[0] is w)          # the block's first application of this pass: its backward runs LAST
     carry = _o._carry_for(key, params, total, split) if (w.requires_grad or (bias is not None and bias.requires_grad)) else None
     if carry is None:
         return _MatmulTall.apply(a, w, bias)
-    out, carry = _MatmulTall.apply(a, w, bias, carry)
+    out, carry = _MatmulTall.apply(a, w, bias, carry, first)
     _o._carry_store(key, w, carry)
     return out
 

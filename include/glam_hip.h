@@ -206,6 +206,13 @@ int glam_wgrad_gemm_pair_split(const float* Pa, int Ia, int ldpa, const float* Q
                                float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes, const float* add_w_a,
                                const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 
+/* glam_wgrad_gemm (one P block, J <= 64) summed over nseg <= 3 operand sets of N rows each (+ an optional addend laid out like out): the
+ * weight gradient of a tall matmul that a block applies message_steps times with shared weights — NNConv's relation product
+ * [x_r | 1]^T dy, /root/reference/src_1gp/layer.py:115-122 — as ONE launch + ONE reduction.  GLAM_E_UNSUPPORTED when N is shorter than a
+ * wave's row range. */
+int glam_wgrad_gemm_sets(int nseg, const float* const* P, int I, int ldp, int ones, const float* const* Q, int J, int ldq, int64_t N,
+                         float* out, int stride_i, int stride_j, const float* addend, void* ws, size_t ws_bytes, void* stream);
+
 /* glam_wgrad_gemm_pair_split summed over nseg <= 3 operand sets of N rows each — Pa[s], Qa[s], Pb[s], Qb[s] with the same widths and
  * row strides — in ONE launch + ONE reduction: the weight gradients of a block applied message_steps times with shared weights
  * (/root/reference/src_1gp/model.py:53-54; the GRU's two gate matrices, src_1gp/layer.py:247) are one product over all its

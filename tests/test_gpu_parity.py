@@ -3020,13 +3020,15 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
                                               p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream()) == ops._lib.GLAM_E_INVALID
 
 
+@pytest.mark.parametrize("block", ["_TripletMessage", "_NNConv"])
 @pytest.mark.parametrize("steps", [1, 3, 4])
-def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, monkeypatch):
-    """MessageBlock applied message_steps times: the GRU's weight gradients as ONE product over the parked operand sets of all
-    applications (four applications: a group of three, then one added in place) against one product per application."""
+def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch):
+    """MessageBlock applied message_steps times: the GRU's weight gradients (and, with _NNConv, the relation product's:
+    glam_wgrad_gemm_sets) as ONE product over the parked operand sets of all applications (four applications: a group of three, then
+    one added in place) against one product per application."""
     torch.manual_seed(steps)
     b = synth_batch(160, seed=3).to(device)        # ~3 200 atoms: above the batching threshold
-    net = model.Architecture(mol_block="_TripletMessage", message_steps=steps).to(device).eval()
+    net = model.Architecture(mol_block=block, message_steps=steps).to(device).eval()
     grads = {}
     for flag in (True, False):
         monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", flag)
@@ -3037,7 +3039,7 @@ def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, m
     assert torch.equal(grads[True][1], grads[False][1])
     for n in grads[True][0]:
         a, c = grads[True][0][n], grads[False][0][n]
-        if "gru" in n:
+        if "gru" in n or (block == "_NNConv" and "mol_conv.conv" in n):
             assert_close(a, c, 3e-6, n)          # (another summation order)
         else:
             assert torch.equal(a, c), n
