@@ -131,6 +131,10 @@ SIGNATURES = {
     "glam_triplet_layer_bwd_params_acc": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 16 + [_i32, _vp, _vp, _sz, _vp]),
     "glam_triplet_layer_bwd_params_ell": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 18 + [_i32, _vp, _vp, _sz, _vp]),
     "glam_triplet_layer_bwd_params_ell_add": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32] + [_vp] * 18 + [_i32, _vp, _vp, _sz, _vp, _vp]),
+    "glam_triplet_layer_bwd_data_ell": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                               _sz, _vp, ctypes.POINTER(ctypes.c_int64), _vp]),
+    "glam_triplet_layer_param_grads_sets": (_i32, [_i32, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64, _i32, _i32, _i32, _i32, _i32]
+                                            + [_vp] * 13 + [_vp, _sz, _vp]),
     "glam_triplet_layer_bwd": (_i32, [_vp] * 14 + [_i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_sz, _vp]),
 }
 

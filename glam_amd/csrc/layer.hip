@@ -300,6 +300,7 @@ struct ParamGradArgs {
     const float* p1; int ns1;            // product 1 partials: i in [0, HC], j in [0, Cp)
     const float* p2; int ns2;            // product 2 partials ([d_xw|d_a]^T x): i in [0, HC+8), j in [0, Cp)
     const float* p3; int ns3; int P;     // B1 block partials [ns3][P]: d_We_p (Dp*HC) | d_M (Dp*4)
+    // ns3 rows in up to three buffers of ns3_each rows (the applications of a layer that shares its weights: p3, p3b, p3c)
     const float* wn; const float* we; const float* att;
     int C, H, De, Cp, Dp;
     float* d_wn; float* d_we; float* d_att; float* d_wsc; float* d_bias;
@@ -307,6 +308,7 @@ struct ParamGradArgs {
     // optional addends, laid out like the outputs (the gradient carry of a layer applied message_steps times: summed here instead
     // of by a separate add launch)
     const float* c_wn; const float* c_we; const float* c_att; const float* c_wsc; const float* c_bias;
+    const float* p3b; const float* p3c; int ns3_each;      // (ns3_each == ns3: one buffer)
 };
 
 // element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (inverse of the decode in k_final_reduce)
@@ -357,30 +359,42 @@ __device__ __forceinline__ void wg_sum2(const float* pa, const float* pb, int ns
 // lg, lg + 16, ...; `request` / `finish` halves so that two elements (or an element and a slab sum) share the round trip
 constexpr int kB1Batch = 16;
 struct B1Batch { float v[kB1Batch]; };
-__device__ __forceinline__ void b1_request(B1Batch& b, const float* p3, int ns3, int P, int e, int s0) {
+// SETS: the rows lie in up to three buffers of `each` rows ([0, each) | [each, 2 each) | [2 each, ..): the applications of a layer that
+// shares its weights); a separate instantiation — the row-to-buffer selects cost the one-buffer kernel of the headline step 4.5 us
+struct B1Src { const float* p3; const float* p3b; const float* p3c; int each; };
+template <bool SETS>
+__device__ __forceinline__ void b1_request(B1Batch& b, const B1Src& src, int ns3, int P, int e, int s0) {
 #pragma unroll
-    for (int u = 0; u < kB1Batch; ++u) b.v[u] = p3[(size_t)min(s0 + 16 * u, ns3 - 1) * P + e];
+    for (int u = 0; u < kB1Batch; ++u) {
+        const int s = min(s0 + 16 * u, ns3 - 1);
+        if (!SETS) { b.v[u] = src.p3[(size_t)s * P + e]; continue; }
+        const bool in0 = s < src.each, in1 = s < 2 * src.each;
+        const float* base = in0 ? src.p3 : in1 ? src.p3b : src.p3c;
+        b.v[u] = base[(size_t)(s - (in0 ? 0 : in1 ? src.each : 2 * src.each)) * P + e];
+    }
 }
 __device__ __forceinline__ float b1_add(float part, const B1Batch& b, int ns3, int s0) {
 #pragma unroll
     for (int u = 0; u < kB1Batch; ++u) part += s0 + 16 * u < ns3 ? b.v[u] : 0.f;
     return part;
 }
-__device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e, int lg) {
+template <bool SETS>
+__device__ __forceinline__ float b1_sum16(const B1Src& p3, int ns3, int P, int e, int lg) {
     float part = 0.f;
     for (int s = lg; s < ns3; s += 16 * kB1Batch) {
         B1Batch b;
-        b1_request(b, p3, ns3, P, e, s);
+        b1_request<SETS>(b, p3, ns3, P, e, s);
         part = b1_add(part, b, ns3, s);
     }
     return group_sum<16>(part);
 }
-__device__ __forceinline__ void b1_sum16x2(const float* p3, int ns3, int P, int e0, int e1, int lg, float& r0, float& r1) {
+template <bool SETS>
+__device__ __forceinline__ void b1_sum16x2(const B1Src& p3, int ns3, int P, int e0, int e1, int lg, float& r0, float& r1) {
     float p0 = 0.f, p1 = 0.f;
     for (int s = lg; s < ns3; s += 16 * kB1Batch) {
         B1Batch a, b;
-        b1_request(a, p3, ns3, P, e0, s);
-        b1_request(b, p3, ns3, P, e1, s);
+        b1_request<SETS>(a, p3, ns3, P, e0, s);
+        b1_request<SETS>(b, p3, ns3, P, e1, s);
         p0 = b1_add(p0, a, ns3, s);
         p1 = b1_add(p1, b, ns3, s);
     }
@@ -395,6 +409,7 @@ __device__ long long g_pg_prof[512 * 8];
 #define PG_STAMP(k) do { } while (0)
 #endif
 
+template <bool SETS>
 __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
     PG_STAMP(0);
     __shared__ float s_dwa[2][64];
@@ -468,7 +483,7 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) wcol[kk] = (out_mine && kk < De) ? a.we[(size_t)kk * H * C + h * C + tid] : 0.f;
             const float carry = (out_mine && a.c_att) ? a.c_att[(size_t)h * 3 * C + C + tid] : 0.f;
-            const float dm = b1_sum16(a.p3, a.ns3, a.P, WSZ + (dm_mine ? grp : 0) * 4 + h, lg);
+            const float dm = b1_sum16<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, WSZ + (dm_mine ? grp : 0) * 4 + h, lg);
             if (dm_mine && lg == 0) s_dm[grp] = dm;
             __syncthreads();
             if (out_mine) {
@@ -513,7 +528,7 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
             const float att_e = a.att[(size_t)h * 3 * C + C + c];
             const float carry = a.c_we ? a.c_we[o] : 0.f;
             float dwe, dm;
-            b1_sum16x2(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, lg, dwe, dm);
+            b1_sum16x2<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, lg, dwe, dm);
             PG_STAMP(3);
             if (lg == 0) a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
         }
@@ -706,7 +721,8 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                           int64_t E, int H, int Cp, int Dp, float slope, float* d_x, float* dstaged,
                           float* d_edge_attr, void* ws, size_t ws_bytes, void* stream, const ParamOut* po,
                           const int32_t* ell_dst = nullptr, const int32_t* ell_eid_t = nullptr, int edge_onehot = 0,
-                          const int32_t* ell_src = nullptr, const int32_t* ell_eid = nullptr, const float* dx_addend = nullptr) {
+                          const int32_t* ell_src = nullptr, const int32_t* ell_eid = nullptr, const float* dx_addend = nullptr,
+                          int64_t* defer_info = nullptr) {
     if (int rc = dims_ok("glam_triplet_layer_bwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_bwd: N out of range");
     GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && d_out && d_x && (dstaged || po) && ws, "glam_triplet_layer_bwd: null pointer");
@@ -752,6 +768,19 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                                   ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, dx_addend))
         return rc;
     const int WSZ = Dp * HC;
+    if (defer_info) {
+        // the data half only: the parameter half (both weight-gradient products + k_param_grads) runs later, over the operand sets of all
+        // applications of the layer (glam_triplet_layer_param_grads_sets), which finds this application's pieces in `ws` through these
+        if (!fuse_dx) {
+            TsArgs g2{d_xw, HC, HC, d_a, 8, 8, staged + L.img_dx, nullptr, d_x, Cp, Cp, nullptr, 0, 0, (int)N};
+            if (int rc = launch_ts_gemm(g2, s)) return rc;
+        }
+        defer_info[0] = (int64_t)(reinterpret_cast<const char*>(tpart) - reinterpret_cast<const char*>(ws));
+        defer_info[1] = tnblk;
+        defer_info[2] = (int64_t)(reinterpret_cast<const char*>(d_xw) - reinterpret_cast<const char*>(ws));
+        defer_info[3] = (int64_t)(reinterpret_cast<const char*>(d_a) - reinterpret_cast<const char*>(ws));
+        return GLAM_OK;
+    }
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
@@ -767,8 +796,10 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
         ParamGradArgs pg{ra.job[0].partial, ra.job[0].nsplit, ra.job[2].partial, ra.job[2].nsplit, tpart, tnblk, WSZ + Dp * 4,
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
                          (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
+        pg.ns3_each = tnblk;
         const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_param_grads, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
+        GLAM_PROF_LABEL("k_param_grads");
+        hipLaunchKernelGGL(k_param_grads<false>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
         GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
         return GLAM_OK;
     }
@@ -904,4 +935,76 @@ extern "C" int glam_triplet_layer_bwd_params_ell_add(const float* x, const float
                                 dst, eid_t, N, E, C, H, De, Cp, Dp, slope, weight_node, weight_edge, att, d_x, d_weight_node, d_weight_edge,
                                 d_att, d_weight_scale, d_bias, add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias, ell_src,
                                 ell_eid, ell_dst, ell_eid_t, edge_onehot, d_edge_attr, ws, ws_bytes, stream, d_x_addend);
+}
+
+// ---- a layer applied message_steps times with shared weights (src_1gp/model.py:53-54): every application's backward runs its DATA half
+//      (d_x: B1, B2 with the d_x product) and leaves its operands in its workspace; the PARAMETER half — both weight-gradient products
+//      and k_param_grads — runs once, over the operand sets of up to three applications ----
+extern "C" int glam_triplet_layer_bwd_data_ell(const float* x, const float* edge_attr, const float* staged, const float* xw, const float* a_ij,
+                                               const float* aggr, const float* stats, const float* d_out, const int32_t* rowptr,
+                                               const int32_t* src, const int32_t* eid, const int32_t* colptr, const int32_t* dst,
+                                               const int32_t* eid_t, int64_t N, int64_t E, int C, int H, int De, int Cp, int Dp, float slope,
+                                               float* d_x, const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
+                                               const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
+                                               const float* d_x_addend, int64_t* info, void* stream) {
+    const char* fn = "glam_triplet_layer_bwd_data_ell";
+    if (int rc = dims_ok(fn, C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(N > 0 && info, "%s: N = 0 / null info", fn);
+    GLAM_REQUIRE((!ell_src) == (!ell_eid) && (!ell_dst) == (!ell_eid_t) && aligned16(ell_src) && aligned16(ell_eid) && aligned16(ell_dst) &&
+                     aligned16(ell_eid_t) && aligned16(d_x_addend), "%s: ELL tables come in 16-byte aligned pairs", fn);
+    const ParamOut po{};
+    return layer_bwd_impl(x, edge_attr, staged, xw, a_ij, aggr, stats, d_out, rowptr, src, eid, colptr, dst, eid_t, N, E, H, Cp, Dp, slope, d_x,
+                          nullptr, d_edge_attr, ws, ws_bytes, stream, &po, ell_dst, ell_eid_t, edge_onehot, ell_src, ell_eid, d_x_addend, info);
+}
+
+extern "C" int glam_triplet_layer_param_grads_sets(int nseg, const void* const* ws_set, const int64_t* info, const float* const* x,
+                                                   const float* const* aggr, const float* const* d_out, int64_t N, int C, int H, int De, int Cp,
+                                                   int Dp, const float* weight_node, const float* weight_edge, const float* att,
+                                                   float* d_weight_node, float* d_weight_edge, float* d_att, float* d_weight_scale, float* d_bias,
+                                                   const float* add_weight_node, const float* add_weight_edge, const float* add_att,
+                                                   const float* add_weight_scale, const float* add_bias, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "glam_triplet_layer_param_grads_sets";
+    if (int rc = dims_ok(fn, C, H, De, Cp, Dp)) return rc;
+    GLAM_REQUIRE(nseg >= 1 && nseg <= 3, "%s: %d operand sets (1..3)", fn, nseg);
+    GLAM_REQUIRE(ws_set && info && x && aggr && d_out && weight_node && weight_edge && att && d_weight_node && d_weight_edge && d_att &&
+                     d_weight_scale && d_bias && ws, "%s: null pointer", fn);
+    GLAM_REQUIRE(N > 0 && N * nseg < INT32_MAX, "%s: N out of range", fn);
+    GLAM_REQUIRE(ws_bytes >= 2 * glam_wgrad_workspace_bytes(), "%s: workspace too small (two products)", fn);
+    const int HC = H * Cp, WSZ = Dp * HC;
+    const int tnblk = (int)info[1];
+    const float* tp[3] = {nullptr, nullptr, nullptr};
+    const float* dxw[3] = {nullptr, nullptr, nullptr};
+    const float* da[3] = {nullptr, nullptr, nullptr};
+    for (int q = 0; q < nseg; ++q) {
+        GLAM_REQUIRE(ws_set[q] && x[q] && aggr[q] && d_out[q] && aligned16(x[q]) && aligned16(aggr[q]) && aligned16(d_out[q]),
+                     "%s: operand set %d: null / misaligned pointer", fn, q);
+        GLAM_REQUIRE(info[4 * q + 1] == tnblk, "%s: the sets come from launches of different grids", fn);
+        const char* b = reinterpret_cast<const char*>(ws_set[q]);
+        tp[q] = reinterpret_cast<const float*>(b + info[4 * q]);
+        dxw[q] = reinterpret_cast<const float*>(b + info[4 * q + 2]);
+        da[q] = reinterpret_cast<const float*>(b + info[4 * q + 3]);
+    }
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    //   d_WsB[HC+1, Cp] = [aggr | 1]^T d_out,   d_Wcat[Cp, HC+8] = x^T [d_xw | d_a] (as its transpose), each summed over the sets
+    WgArgs w1{aggr[0], HC, HC, nullptr, 0, 0, 1, d_out[0], Cp, Cp, 0, (int)(N * nseg), 0, partial, 0, 0};
+    WgArgs w2{dxw[0], HC, HC, da[0], 8, 8, 0, x[0], Cp, Cp, 0, (int)(N * nseg), 0, partial + wgrad_workspace_floats(), 0, 0};
+    w1.nseg = w2.nseg = nseg;
+    w1.seg_rows = w2.seg_rows = (int)N;
+    for (int q = 1; q < nseg; ++q) {
+        w1.segP1[q - 1] = aggr[q]; w1.segQ[q - 1] = d_out[q];
+        w2.segP1[q - 1] = dxw[q]; w2.segP2[q - 1] = da[q]; w2.segQ[q - 1] = x[q];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ReduceJob j1{}, j2{};
+    if (int rc = launch_wgrad_partials2(w1, nullptr, Cp, 1, &j1, w2, nullptr, 1, HC + 8, &j2, s)) return rc;
+    ParamGradArgs pg{j1.partial, j1.nsplit, j2.partial, j2.nsplit, tp[0], tnblk * nseg, WSZ + Dp * 4, weight_node, weight_edge, att, C, H, De, Cp,
+                     Dp, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H,
+                     add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
+    pg.p3b = tp[1]; pg.p3c = tp[2]; pg.ns3_each = tnblk;
+    const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
+    GLAM_PROF_LABEL("k_param_grads<sets>");
+    if (nseg == 1) hipLaunchKernelGGL(k_param_grads<false>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
+    else hipLaunchKernelGGL(k_param_grads<true>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
+    GLAM_LAUNCH_CHECK(fn);
+    return GLAM_OK;
 }

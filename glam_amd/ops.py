@@ -618,7 +618,7 @@ class _TripletLayer(torch.autograd.Function):
     gather/softmax/scatter-add, update GEMM — and the hand-written backward of all of it."""
 
     @staticmethod
-    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None, with_identity=False):
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None, with_identity=False, first_app=True):
         """Returns ``out`` — or the tuple ``(out[, x_p itself][, carry])``.  ``with_identity``: the layer's input comes back as a second
         output, the skip connection of a MessageBlock (src_1gp/layer.py:253-265: ``x`` feeds the conv AND ``x + identity``): both gradient
         paths then arrive at THIS node and the d_x product's epilogue sums them (glam_triplet_layer_bwd_params_ell_add) instead of
@@ -638,6 +638,8 @@ class _TripletLayer(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         ctx.carried = carry is not None
         ctx.aliased = bool(with_identity)
+        ctx.first_app = bool(first_app)
+        ctx.scope = _SCOPE
         ctx.set_materialize_grads(False)     # the carry of the block's LAST application has no gradient yet: None, not a zero fill
         def build():
             buf = torch.empty(lib.glam_triplet_staged_floats(H, Cp, Dp), **f)
@@ -673,7 +675,7 @@ class _TripletLayer(torch.autograd.Function):
         d_alias = more[0] if ctx.aliased else None
         d_carry = more[-1] if ctx.carried else None
         if d_out is None:                    # the layer's output was not used: only the skip connection / the carry pass through
-            return (d_alias,) + (None,) * 9 + (d_carry, None)
+            return (d_alias,) + (None,) * 9 + (d_carry, None, None)
         x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
@@ -694,6 +696,44 @@ class _TripletLayer(torch.autograd.Function):
         ell_t = gi.ell_t() if (d_ea is None and _ws_route(lib, N, H, Cp, Dp, ea_p)) else None
         have_carry = ctx.carried and d_carry is not None and N > 0
         ell_f = gi.ell() if ell_t is not None else None          # (by target: what the forward used)
+        scope = ctx.scope
+        if ctx.carried and ell_t is not None and scope is not None and GRU_WGRAD_BATCH and N >= 2048:
+            # The parameter gradients of ALL applications of the layer from one launch pair: every application runs the DATA half of its
+            # backward (d_x) and parks its operands — its workspace holds d_xw, d_a and the block partials of d_W_edge / d_M —; the first
+            # application (its backward runs last) runs both weight-gradient products over the parked sets and k_param_grads ONCE
+            # (glam_triplet_layer_param_grads_sets).  3 x (k_wgrad + k_param_grads) -> 1 + 1 per training step at message_steps = 3.
+            in_kernel = d_alias is not None and os.environ.get("GLAM_X3", "1") != "0"
+            addend = f32c(d_alias, "d_identity") if in_kernel else None
+            info = (ctypes.c_int64 * 4)()
+            check(lib.glam_triplet_layer_bwd_data_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(d_out),
+                                                      ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst), ptr(eid_t), N, E, C, H, De,
+                                                      Cp, Dp, slope, ptr(d_x), ptr(ell_f[0]), ptr(ell_f[1]), ptr(ell_t[0]), ptr(ell_t[1]), 1,
+                                                      None, ptr(ws), ws.numel(), ptr(addend), info, stream()), "glam_triplet_layer_bwd_data_ell")
+            if d_alias is not None and not in_kernel:
+                d_x = d_x.add_(d_alias)
+            parked = scope.bwd.setdefault(("triplet-parked", id(wn)), (wn, []))[1]
+            parked.append((ws, tuple(info), x_p, aggr, d_out))
+            if not ctx.first_app:
+                return d_x, d_ea, None, None, None, None, None, None, None, None, d_carry, None, None
+            sets = list(parked)
+            parked.clear()
+            carry_in = f32c(d_carry, "d_carry") if d_carry is not None else None
+            vp = ctypes.c_void_p
+            while sets:
+                grp, sets = sets[:3], sets[3:]
+                n = len(grp)
+                out = torch.empty(sum(sizes), **f)
+                o = [t.view(sh) for t, sh in zip(out.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,)))]
+                c = carry_in.split(sizes) if carry_in is not None else (None,) * 5
+                ws2 = torch.empty(2 * lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+                infos = (ctypes.c_int64 * (4 * n))(*[v for t in grp for v in t[1]])
+                arr = lambda i: (vp * n)(*[t[i].data_ptr() for t in grp])
+                check(lib.glam_triplet_layer_param_grads_sets(n, arr(0), infos, arr(2), arr(3), arr(4), N, C, H, De, Cp, Dp, ptr(wn), ptr(we),
+                                                              ptr(att), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(o[4]), ptr(c[0]), ptr(c[1]),
+                                                              ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(ws2), ws2.numel(), stream()),
+                      "glam_triplet_layer_param_grads_sets")
+                carry_in = out
+            return d_x, d_ea, None, None, None, None, None, None, None, None, carry_in, None, None
         if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
             c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
@@ -713,8 +753,8 @@ class _TripletLayer(torch.autograd.Function):
             if d_alias is not None and not in_kernel:
                 d_x = d_x.add_(d_alias)
             if ctx.carried:
-                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry)), None
-            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None
+                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry)), None, None
+            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None, None
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
@@ -723,8 +763,8 @@ class _TripletLayer(torch.autograd.Function):
         if d_alias is not None:
             d_x = d_x.add_(d_alias)
         if ctx.carried:
-            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None
-        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None, None
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None, None
 
 
 # The layer through the torch-extension operator (torch.ops.glam.triplet_layer: C++ autograd node, no ctypes marshalling, no Python
@@ -791,12 +831,14 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
     sizes = [weight_node.numel(), weight_edge.numel(), att.numel(), heads * C * C, C]
     shapes = (weight_node.shape, weight_edge.shape, att.shape, (heads * C, C), (C,))
     key = ("carry-triplet", id(weight_node))
+    hit = _SCOPE.fwd.get(key) if _SCOPE is not None else None
+    first = not (hit is not None and hit[0] is weight_node)      # the layer's first application of this pass: its backward runs LAST
     carry = _carry_for(key, params, sum(sizes), lambda flat: [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)])
     if carry is None:
         return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, None, with_identity)
     # the parameters still enter as inputs (the kernels read them, and the scope's staging cache is keyed on them), but this
     # node returns no gradient for them: it flows through `carry`
-    res = _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry, with_identity)
+    res = _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry, with_identity, first)
     _carry_store(key, weight_node, res[-1])
     return (res[0], res[1]) if with_identity else res[0]
 

@@ -367,6 +367,27 @@ int glam_triplet_layer_bwd_params_ell_add(const float* x, const float* edge_attr
                                           const float* add_bias, const int32_t* ell_src, const int32_t* ell_eid, const int32_t* ell_dst,
                                           const int32_t* ell_eid_t, int edge_onehot, float* d_edge_attr, void* ws, size_t ws_bytes,
                                           const float* d_x_addend, void* stream);
+
+/* A layer applied message_steps times with shared weights (/root/reference/src_1gp/model.py:53-54), warp-specialised route: every
+ * application's backward runs its DATA half — glam_triplet_layer_bwd_data_ell: everything of glam_triplet_layer_bwd_params_ell_add
+ * that produces d_x (d_x_addend may be NULL) — and leaves its operands (d_xw, d_a, the block partials of d_W_edge / d_M) in ITS
+ * workspace `ws`, whose layout it reports in info (host int64[4]: byte offsets and the partial row count).  The PARAMETER half
+ * runs once over the operand sets of nseg <= 3 applications: glam_triplet_layer_param_grads_sets(ws_set[s], info[4 s ..], x[s],
+ * aggr[s], d_out[s]) = both weight-gradient products as ONE k_wgrad launch over all sets + ONE k_param_grads (optional addends: the
+ * gradient carry).  Its own ws: >= 2 * glam_wgrad_workspace_bytes().  The workspaces of the applications must stay untouched until
+ * then.  Same numbers as the per-application form up to the order of the fixed-order sums. */
+int glam_triplet_layer_bwd_data_ell(const float* x, const float* edge_attr, const float* staged, const float* xw, const float* a_ij,
+                                    const float* aggr, const float* stats, const float* d_out, const int32_t* rowptr, const int32_t* src,
+                                    const int32_t* eid, const int32_t* colptr, const int32_t* dst, const int32_t* eid_t, int64_t N, int64_t E,
+                                    int C, int H, int De, int Cp, int Dp, float slope, float* d_x, const int32_t* ell_src,
+                                    const int32_t* ell_eid, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot,
+                                    float* d_edge_attr, void* ws, size_t ws_bytes, const float* d_x_addend, int64_t* info, void* stream);
+int glam_triplet_layer_param_grads_sets(int nseg, const void* const* ws_set, const int64_t* info, const float* const* x,
+                                        const float* const* aggr, const float* const* d_out, int64_t N, int C, int H, int De, int Cp, int Dp,
+                                        const float* weight_node, const float* weight_edge, const float* att, float* d_weight_node,
+                                        float* d_weight_edge, float* d_att, float* d_weight_scale, float* d_bias,
+                                        const float* add_weight_node, const float* add_weight_edge, const float* add_att,
+                                        const float* add_weight_scale, const float* add_bias, void* ws, size_t ws_bytes, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * MessageBlock remainder: gate math of one torch.nn.GRU(C, C) step with seq_len 1 (src_1gp/layer.py:247, :262).
  * gi = celu(x) @ W_ih^T + b_ih and gh = h @ W_hh^T + b_hh (f32[N,3C], gate order r|z|n; computed with

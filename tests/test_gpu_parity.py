@@ -3023,8 +3023,9 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
 @pytest.mark.parametrize("block", ["_TripletMessage", "_NNConv"])
 @pytest.mark.parametrize("steps", [1, 3, 4])
 def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch):
-    """MessageBlock applied message_steps times: the GRU's weight gradients (and, with _NNConv, the relation product's:
-    glam_wgrad_gemm_sets) as ONE product over the parked operand sets of all applications (four applications: a group of three, then
+    """MessageBlock applied message_steps times: the GRU's weight gradients, the TripletMessage's parameter gradients
+    (glam_triplet_layer_bwd_data_ell + glam_triplet_layer_param_grads_sets) and NNConv's relation product's (glam_wgrad_gemm_sets) as
+    ONE product each over the parked operand sets of all applications (four applications: a group of three, then
     one added in place) against one product per application."""
     torch.manual_seed(steps)
     b = synth_batch(160, seed=3).to(device)        # ~3 200 atoms: above the batching threshold
@@ -3039,7 +3040,7 @@ def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, b
     assert torch.equal(grads[True][1], grads[False][1])
     for n in grads[True][0]:
         a, c = grads[True][0][n], grads[False][0][n]
-        if "gru" in n or (block == "_NNConv" and "mol_conv.conv" in n):
+        if "mol_conv" in n:                      # GRU, TripletMessage / NNConv parameters: one product over all applications
             assert_close(a, c, 3e-6, n)          # (another summation order)
         else:
             assert torch.equal(a, c), n
