@@ -3040,8 +3040,8 @@ def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, b
     assert torch.equal(grads[True][1], grads[False][1])
     for n in grads[True][0]:
         a, c = grads[True][0][n], grads[False][0][n]
-        if "mol_conv" in n:                      # GRU, TripletMessage / NNConv parameters: one product over all applications
-            assert_close(a, c, 3e-6, n)          # (another summation order)
+        if "mol_conv" in n and steps > 1:        # GRU, TripletMessage / NNConv parameters: one product over all applications
+            assert_close(a, c, 3e-6, n)          # (another summation order; ONE application: the same launches, bit for bit)
         else:
             assert torch.equal(a, c), n
 
