@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_narrow_fwd(const float* x, co
 // partial[split][m][k] (m < M: d_w, m == M: column 0 holds d_b's partial, written by the blocks of column chunk 0)
 template <int MT>
 __global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, const float* w, const float* dy, int N, int K, int M,
-                                                             float* dx, float* partial) {
+                                                             float* dx, float* partial, float* dw_direct, float* db_direct) {
     __shared__ float4 s_red[16][17];            // [row lane][column lane] (+1: bank spread), one output row at a time
     __shared__ float s_db[16][MT];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, co
                 float4 s = f4zero();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { const float4 v = s_red[r][cl]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-                st4(partial + ((size_t)split * (M + 1) + m) * K + k, s);
+                // one row split (small batches): the block's sums ARE the result — no partial set, no reduction launch
+                if (nsplit == 1) st4(dw_direct + (size_t)m * K + k, s);
+                else st4(partial + ((size_t)split * (M + 1) + m) * K + k, s);
             }
             __syncthreads();
         }
@@ -94,7 +96,8 @@ __global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, co
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += s_db[r][threadIdx.x];
-        partial[((size_t)split * (M + 1) + M) * K + threadIdx.x] = s;
+        if (nsplit == 1) { if (db_direct) db_direct[threadIdx.x] = s; }
+        else partial[((size_t)split * (M + 1) + M) * K + threadIdx.x] = s;
     }
 }
 
@@ -224,14 +227,17 @@ extern "C" int glam_linear_narrow_bwd(const float* x, const float* w, const floa
     GLAM_REQUIRE(x && w && dy, "glam_linear_narrow_bwd: null pointer");
     GLAM_REQUIRE(aligned16(x) && aligned16(w) && aligned16(dx) && aligned16(ws), "glam_linear_narrow_bwd: pointers must be 16-byte aligned");
     float* partial = static_cast<float*>(ws);
-    const int nsplit = (int)(N < kNarrowSplits * 16 ? (N + 15) / 16 : kNarrowSplits);
+    // up to 256 rows (the reference's batch of 32): one row split, sums written straight to dw / db — ONE launch, 2.3 us at N = 32;
+    // beyond: row splits + the fixed-order reduction (one split walks its rows serially: 15.8 us at N = 1 024 against 9.7 for the pair)
+    const int nsplit = N <= 256 ? 1 : (int)(N < kNarrowSplits * 16 ? (N + 15) / 16 : kNarrowSplits);
     const dim3 grid((K + 63) / 64, nsplit);
-    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_bwd<1>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
-    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_bwd<2>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
-    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_bwd<4>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
-    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_bwd<8>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
-    else hipLaunchKernelGGL((k_linear_narrow_bwd<16>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial);
+    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_bwd<1>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
+    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_bwd<2>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
+    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_bwd<4>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
+    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_bwd<8>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
+    else hipLaunchKernelGGL((k_linear_narrow_bwd<16>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
     GLAM_LAUNCH_CHECK("glam_linear_narrow_bwd");
+    if (nsplit == 1) return GLAM_OK;
     hipLaunchKernelGGL(k_linear_narrow_reduce, dim3((M * K + M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, nsplit, K, M, dw, db);
     GLAM_LAUNCH_CHECK("glam_linear_narrow_bwd(reduce)");
     return GLAM_OK;

@@ -2129,7 +2129,7 @@ def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkey
 # narrow-output linear (the model's output head, model.py:47,61): row dot products instead of a library GEMM
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,K,M,bias", [(1024, 1024, 1, True), (1024, 1024, 2, True), (37, 300, 12, True), (1, 64, 16, False),
-                                        (2039, 1024, 1, True), (640, 1024, 5, False)])
+                                        (2039, 1024, 1, True), (640, 1024, 5, False), (200, 1024, 2, True), (5000, 300, 3, True)])
 def test_narrow_linear_against_the_fp64_twin(device, N, K, M, bias):
     from tests.conftest import assert_fp32_parity
     g = torch.Generator().manual_seed(N * 7 + K + M)
