@@ -697,7 +697,7 @@ class _TripletLayer(torch.autograd.Function):
         have_carry = ctx.carried and d_carry is not None and N > 0
         ell_f = gi.ell() if ell_t is not None else None          # (by target: what the forward used)
         scope = ctx.scope
-        if ctx.carried and ell_t is not None and scope is not None and GRU_WGRAD_BATCH and N >= 2048:
+        if ctx.carried and ell_t is not None and scope is not None and GRU_WGRAD_BATCH and N >= 512:
             # The parameter gradients of ALL applications of the layer from one launch pair: every application runs the DATA half of its
             # backward (d_x) and parks its operands — its workspace holds d_xw, d_a and the block partials of d_W_edge / d_M —; the first
             # application (its backward runs last) runs both weight-gradient products over the parked sets and k_param_grads ONCE

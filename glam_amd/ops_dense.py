@@ -733,7 +733,7 @@ def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=
     return out, h_new
 
 
-_GRU_BATCH_MIN_ROWS = 2048      # (a wave's row range must fit into one operand set: glam_wgrad_gemm_pair_split_seg)
+_GRU_BATCH_MIN_ROWS = 512       # (a wave's row range must fit into one operand set: glam_wgrad_gemm_pair_split_seg)
 
 
 class _GruBlock(torch.autograd.Function):

@@ -1390,6 +1390,9 @@ def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device, monkey
     params = [p for _, p in net.named_parameters()]
     grads = {}
     monkeypatch.setattr(ops, "USE_TORCH_EXT", False)        # the carry is the Python node's (what a captured step runs)
+    # (one product per application + the carried addend: the form this test pins; the default — ONE product over the parked operand sets
+    #  of all applications, test_gru_weight_gradients_of_all_applications_in_one_launch — sums in another order)
+    monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", False)
     for flag in (True, False):
         ops.GRAD_CARRY = flag
         try:
@@ -1414,7 +1417,7 @@ def test_gradient_carry_is_bit_identical_to_autograd_accumulation(device, monkey
 
 
 @pytest.mark.parametrize("block,norm", [("_NNConv", "_None"), ("_NNConv", "_PairNorm"), ("_GCNConv", "_None")])
-def test_gradient_carry_of_tall_matmul_weights(device, block, norm):
+def test_gradient_carry_of_tall_matmul_weights(device, block, norm, monkeypatch):
     """NNConv's stacked relation weight + bias (and GCN's weight) enter ``ops.matmul_tall`` once per message step: inside a weight
     scope their gradients are carried through the weight-gradient reductions (glam_wgrad_gemm_add) instead of being summed by
     autograd's add launches — the same sums in the same order, so the same bits."""
@@ -1424,6 +1427,7 @@ def test_gradient_carry_of_tall_matmul_weights(device, block, norm):
                              pre_act="ReLU", graph_act="ReLU", flat_act="ReLU").to(device).eval()
     params = [p for _, p in net.named_parameters()]
     grads = {}
+    monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", False)      # (the per-application form: see the test above)
     for flag in (True, False):
         ops.GRAD_CARRY = flag
         try:
@@ -1432,6 +1436,9 @@ def test_gradient_carry_of_tall_matmul_weights(device, block, norm):
             ops.GRAD_CARRY = True
     for (n, _), a, r in zip(net.named_parameters(), grads[True], grads[False]):
         assert torch.equal(a, r), n
+    monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", True)       # one product over all applications: the same sums in another order
+    for (n, _), a, r in zip(net.named_parameters(), torch.autograd.grad(net(b).sum(), params), grads[False]):
+        assert_close(a, r, 3e-6, n)
 
 
 @pytest.mark.parametrize("kind", ["pair", "layer"])
