@@ -23,6 +23,7 @@
 // 26.6 us for the backward pair (library: 13.4 + 11.8 + mask 5.1 + bias gradient 5.7).
 #include "bf16x3.h"
 #include "dense.h"
+#include <stdlib.h>
 
 namespace glam {
 #ifdef GLAM_DENSE_STAMP
@@ -511,6 +512,122 @@ __global__ void __launch_bounds__(512) k_dense_x3(GemmArgs a) {
 #undef GLAM_DENSE_CASE
 }
 
+// ---- both operands with rows along k (the forward y = x W^T): fragments straight from memory into registers -------------------------
+// A lane of the 16 x 16 x 32 matrix instruction holds eight consecutive k of one row: with rows along k that is 32 contiguous bytes of
+// the operand itself, so the tile needs no LDS, no transposition and no barrier — each wave loads, splits and multiplies its own
+// (32 x 32) sub-tile, two chunks of 32 k in flight in registers.  The two waves that share a row (column) tile load it twice (L1).
+// [1024, 300] x [300, 1024]: 11.9 us against 13.3 for the staged kernel above, [2039, 300]: 18.3 against 24.5 (two waves per sub-tile on
+// alternate chunks — a second wave per SIMD to overlap split and multiply — measured 12.7 / 22.7: twice the operand loads).  With fewer
+// than 128 tiles the staged kernel's 32-row tiles fill the chip better (B = 32: 8.8 against 10.8 us).
+struct KcArgs {
+    const float* A; long long a_rs; const float* B; long long b_cs; const float* bias; int act; float act_slope;
+    float* C; long long ldc; int R, Cn, K, tiles_c, ntiles, per_xcd, c_vec;
+};
+
+__device__ __forceinline__ void kc_load(float4 (&q)[2], const float* row, int k, int K, bool row_ok) {
+    // (unconditional loads from clamped addresses; what lies beyond K or the matrix is zeroed at the split)
+    q[0] = ld4(row + min(k, K - 4));
+    q[1] = ld4(row + min(k + 4, K - 4));
+    (void)row_ok;
+}
+__device__ __forceinline__ Bf16x3 kc_split(const float4 (&q)[2], int k, int K, bool row_ok) {
+    const float4 z = f4zero();
+    return split8((row_ok && k < K) ? pinned(q[0]) : z, (row_ok && k + 4 < K) ? pinned(q[1]) : z);
+}
+
+__global__ void __launch_bounds__(256) k_dense_kc(KcArgs a) {
+    const int b = blockIdx.x;
+    const int tile = (b & 7) * a.per_xcd + (b >> 3);
+    if (tile >= a.ntiles) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1, g = lane >> 4, r = lane & 15;
+    const int tr = tile / a.tiles_c, tc = tile - tr * a.tiles_c;
+    const int row0 = tr * 64 + wr * 32, col0 = tc * 64 + wc * 32;
+    const float* arow[2];
+    const float* brow[2];
+    bool aok[2], bok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = row0 + 16 * i + r, cb = col0 + 16 * i + r;
+        aok[i] = ra < a.R; bok[i] = cb < a.Cn;
+        arow[i] = a.A + (long long)min(ra, a.R - 1) * a.a_rs;
+        brow[i] = a.B + (long long)min(cb, a.Cn - 1) * a.b_cs;
+    }
+    float4 bias4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + 16 * j + 4 * g;
+        const float* zeros = reinterpret_cast<const float*>(&g_zero_quad);
+        const float* bp = a.bias ? a.bias : zeros;
+        const int last = a.bias ? a.Cn - 1 : 0;
+        bias4[j] = make_float4(bp[min(col, last)], bp[min(col + 1, last)], bp[min(col + 2, last)], bp[min(col + 3, last)]);
+    }
+    v4f_t acc3[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc3[c][i][0] = (v4f_t){0.f, 0.f, 0.f, 0.f}; acc3[c][i][1] = acc3[c][i][0]; }
+    const int nchunks = (a.K + kGK - 1) / kGK;
+    float4 qa[2][2][2], qb[2][2][2];           // [stage][tile][half]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            kc_load(qa[s][i], arow[i], s * kGK + 8 * g, a.K, aok[i]);
+            kc_load(qb[s][i], brow[i], s * kGK + 8 * g, a.K, bok[i]);
+        }
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = (c0 + s) * kGK + 8 * g;
+            Bf16x3 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { fa[i] = kc_split(qa[s][i], k, a.K, aok[i]); fb[i] = kc_split(qb[s][i], k, a.K, bok[i]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { kc_load(qa[s][i], arow[i], k + 2 * kGK, a.K, aok[i]); kc_load(qb[s][i], brow[i], k + 2 * kGK, a.K, bok[i]); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc3[0][i][j] = mfma_x3_small(fb[j], fa[i], acc3[0][i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc3[1][i][j] = mfma_x3_mid(fb[j], fa[i], acc3[1][i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc3[2][i][j] = mfma_x3_big(fb[j], fa[i], acc3[2][i][j]);
+        }
+    }
+    v4f_t accs[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accs[i][j] = (acc3[0][i][j] + acc3[1][i][j]) + acc3[2][i][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 16 * i + r;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + 16 * j + 4 * g;
+            if (row >= a.R || col >= a.Cn) continue;
+            const v4f_t s3 = accs[i][j];
+            float v[4] = {s3[0] + bias4[j].x, s3[1] + bias4[j].y, s3[2] + bias4[j].z, s3[3] + bias4[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a.act == 1) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                else if (a.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
+            }
+            float* dst = a.C + (long long)row * a.ldc + col;
+            if (a.c_vec && col + 3 < a.Cn) st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < a.Cn) dst[e] = v[e];
+            }
+        }
+    }
+}
+
 struct Product {
     const float* A; int64_t a_rs, a_ks; const float* gate; float gate_slope;
     const float* B; int64_t b_ks, b_cs; const float* bias; int act; float act_slope;
@@ -545,7 +662,22 @@ static void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
     j.c_vec = aligned16(p.C) && p.ldc % 4 == 0;
 }
 
+static bool kc_route(const Product& p) {
+    static const bool on = [] { const char* e = getenv("GLAM_DENSE_KC"); return !e || atoi(e) != 0; }();
+    return on && p.a_ks == 1 && p.b_ks == 1 && !p.gate && !p.rowsum && p.K >= 8 && p.K % 4 == 0 && p.a_rs % 4 == 0 && p.b_cs % 4 == 0 &&
+           aligned16(p.A) && aligned16(p.B);
+}
+
 static int launch_products(const Product* p, int n, hipStream_t s) {
+    if (n == 1 && kc_route(p[0]) && (long long)((p[0].R + 63) / 64) * ((p[0].Cn + 63) / 64) >= 128) {      // (few tiles: the 32-row staged tiles fill the chip better)
+        KcArgs a{p[0].A, p[0].a_rs, p[0].B, p[0].b_cs, p[0].bias, p[0].act, p[0].act_slope, p[0].C, p[0].ldc, p[0].R, p[0].Cn, p[0].K,
+                 (p[0].Cn + 63) / 64, 0, 0, aligned16(p[0].C) && p[0].ldc % 4 == 0};
+        a.ntiles = ((p[0].R + 63) / 64) * a.tiles_c;
+        a.per_xcd = (a.ntiles + 7) / 8;
+        hipLaunchKernelGGL(k_dense_kc, dim3(a.per_xcd * 8), dim3(256), 0, s, a);
+        GLAM_LAUNCH_CHECK("k_dense_kc");
+        return 0;
+    }
     // 64-row tiles; 32-row tiles (twice the blocks) for the small batches that would leave most of the chip idle
     long long t64 = 0;
     for (int i = 0; i < n; ++i) t64 += (long long)((p[i].R + 63) / 64) * ((p[i].Cn + (p[i].rowsum ? 1 : 0) + 63) / 64);
