@@ -424,3 +424,23 @@ def test_dense_gemm_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.glam_prestage(None, None, None, None, None, 0, 0, 0, 0, 0, None, 0, None, None, None, None) == inv          # nothing to build
     assert lib.glam_prestage(None, None, None, None, None, 0, 0, 0, 0, 0, None, 7, None, None, None, None) == inv          # more than six images
 
+
+def test_launch_saving_hints_are_host_logic():
+    """following_dropout (the hint that lets an activation launch write the dropped twin), the prestage item lists and the operand-set
+    thresholds are decided on the host: a training-mode Dropout with nothing in front of it gives its p, anything else 0; CPU tensors
+    stage nothing."""
+    blk = layer.LinearBlock(1024, 1, norm="_None", dropout="Dropout(0.2)", act="_None")
+    assert layer.following_dropout(blk.train()) == pytest.approx(0.2)
+    assert layer.following_dropout(blk.eval()) == 0.0
+    assert layer.following_dropout(layer.LinearBlock(60, 60, norm="_PairNorm", dropout="Dropout(0.2)").train()) == 0.0     # a norm sits in front
+    assert layer.following_dropout(layer.LinearBlock(60, 60, norm="_None", dropout="_None()").train()) == 0.0
+    mb = layer.MessageBlock(60, 60, 4, norm="_None", dropout="Dropout(0.1)", conv="_TripletMessage", act="RReLU()").train()
+    assert layer.following_dropout(mb) == pytest.approx(0.1)
+    lin = layer.LinearBlock(15, 60)
+    x, ea = torch.randn(40, 15), torch.zeros(80, 4)
+    assert layer.prestage_pass((lin, mb, x, ea)) == 0                 # CPU tensors: nothing to stage, nothing launched
+    trip, images = layer._prestage_items(lin, mb, x.to("meta") if False else x, ea)
+    assert trip is None and images == []
+    assert ops.prestage(None, []) == 0
+    assert ops.GRU_WGRAD_BATCH in (True, False) and ops.PRESTAGE in (True, False) and ops.NORM_DROP in (True, False) and ops.DENSE_LINEAR in (True, False)
+
