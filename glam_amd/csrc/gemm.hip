@@ -1020,6 +1020,38 @@ extern "C" int glam_wgrad_gemm_sets(int nseg, const float* const* P, int I, int 
     return launch_final_reduce(ra, (hipStream_t)stream);
 }
 
+// [d_W | d_b] of one linear y = [act(x) | 1] W^T with up to 127 inputs: dw[I, J] = P^T act(Q) and db[I] = column sums of P in SEPARATE
+// contiguous outputs (optional addends laid out like them: the gradient carry), act = CELU when q_celu (the CELU in front of a
+// MessageBlock's GRU folded into the gate product, src_1gp/layer.py:261).  J <= 64: one product; beyond: the two column chunks of Q
+// (64 | J - 64 | 1) as the two products of one launch.
+extern "C" int glam_wgrad_gemm_linear(const float* P, int I, int ldp, const float* Q, int J, int ldq, int q_celu, float* dw, float* db,
+                                      const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "glam_wgrad_gemm_linear";
+    GLAM_REQUIRE(N >= 1 && N < INT32_MAX, "%s: N out of range (N = 0: zero the outputs on the host side)", fn);
+    GLAM_REQUIRE(P && Q && dw && db && ws, "%s: null pointer", fn);
+    GLAM_REQUIRE(I > 0 && J > 0 && (J & 3) == 0 && J + 1 <= 128, "%s: J = %d must be a multiple of 4 with J + 1 <= 128", fn, J);
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace too small", fn);
+    GLAM_REQUIRE(aligned16(P) && aligned16(Q), "%s: P / Q must be 16-byte aligned", fn);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    ReduceArgs ra{};
+    if (J + 1 <= 64) {
+        WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, J, ldq, 1, (int)N, 0, partial, 0, 0, q_celu};
+        ra.njobs = 1;
+        if (int rc = launch_wgrad_partials(a, dw, J, 1, s, &ra.job[0])) return rc;
+        ra.job[0].addend = add_w; ra.job[0].out_b = db; ra.job[0].add_b = add_b;
+        return launch_final_reduce(ra, s);
+    }
+    WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, 64, ldq, 0, (int)N, 0, partial, 0, 0, q_celu};
+    WgArgs b{P, I, ldp, nullptr, 0, 0, 0, Q + 64, J - 64, ldq, 1, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0, q_celu};
+    ra.njobs = 2;
+    if (int rc = launch_wgrad_partials2(a, dw, J, 1, &ra.job[0], b, dw + 64, J, 1, &ra.job[1], s)) return rc;
+    ra.job[0].addend = add_w;
+    ra.job[1].addend = add_w ? add_w + 64 : nullptr;
+    ra.job[1].out_b = db; ra.job[1].add_b = add_b;
+    return launch_final_reduce(ra, s);
+}
+
 // [d_W | d_b] of one linear y = [x | 1] W^T, weight and bias into SEPARATE contiguous tensors (autograd takes them as they are; a
 // strided view of a combined buffer costs a copy launch each): dw[I, J] = P^T Q, db[I] = column sums of P.  J + 1 <= 64.
 extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N,

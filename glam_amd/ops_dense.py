@@ -288,27 +288,35 @@ def matmul_tall(a, w, bias=None):
 
 
 class _LinearTall(torch.autograd.Function):
-    """``y = x @ w^T + b`` for layer widths beyond the MFMA forward table (e.g. the GRU gate linears 92 -> 276 of
-    hid_dim_alpha = 6): both data-side products on the warp-specialised 3 x bf16 kernels (tall_x3.hip), ``[d_w | d_b] = dy^T [x | 1]``
-    on ``k_wgrad``.  ``carry``: the gradient carry of (w, b) when a block applies them several times per forward (see _ParamBundle):
-    ``[d_w | d_b]`` as one ``[M, K + 1]`` buffer, summed by the reduction of the weight-gradient product."""
+    """``y = act(x) @ w^T + b`` for layer widths beyond the MFMA forward table (e.g. the GRU gate linears 92 -> 276 of
+    hid_dim_alpha = 6): both data-side products on the warp-specialised 3 x bf16 kernels (tall_x3.hip), ``d_w = dy^T act(x)`` and ``d_b``
+    on ``k_wgrad`` as two contiguous tensors (``glam_wgrad_gemm_linear``: no strided views for autograd to copy).  ``celu_in``: act = the
+    CELU MessageBlock applies in front of its GRU (src_1gp/layer.py:261), folded into the operand loads of all three products instead
+    of a launch each way.  ``carry``: the gradient carry of (w, b) when a block applies them several times per forward (see
+    _ParamBundle): ``[d_w | d_b]`` flat, summed by the reduction of the weight-gradient product."""
 
     @staticmethod
-    def forward(ctx, x, w, b, carry=None):
+    def forward(ctx, x, w, b, carry=None, celu_in=False):
         require_device(x, w, b)
         x, w, b = f32c(x, "x"), f32c(w, "weight"), f32c(b, "bias")
-        ctx.save_for_backward(x, w)
         ctx.scope = _o._SCOPE
         ctx.carried = carry is not None
         if ctx.carried:
             ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
         N, K = x.shape
         M = w.size(0)
+        ctx.fold = bool(celu_in) and K <= 96 and M <= 288 and K + 1 <= 128 and N > 0      # every product has a CELU-aware kernel
+        if celu_in and not ctx.fold:
+            x = torch.celu(x)
+        ctx.save_for_backward(x, w)
         if K <= 96 and M <= 320:       # 92 -> 276: k_tall_x3<3, 4, 5> (15 us at N = 20.4 k; the library 29, the fp32 LDS-image kernel 24)
             lib = _lib.load()
             img = _o._scoped(_o._SCOPE.fwd if _o._SCOPE else None, ("lin", id(w)), w, lambda: _o._ts_image(w, K, M, True))
             y = torch.empty(N, M, dtype=torch.float32, device=x.device)
-            check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
+            if ctx.fold:
+                check(lib.glam_ts_gemm_celu(ptr(x), K, K, 1, ptr(img), ptr(b), ptr(y), M, M, None, 0, N, stream()), "glam_ts_gemm_celu")
+            else:
+                check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
         else:
             y = torch.addmm(b, x, w.t())
         return (y, carry.view(-1)) if ctx.carried else y
@@ -317,54 +325,56 @@ class _LinearTall(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, d_carry=None):
         if dy is None:      # only with a carry (grads are not materialised then): the output itself was unused
-            return None, None, None, d_carry
+            return None, None, None, d_carry, None
         x, w = ctx.saved_tensors
         dy = f32c(dy, "dy")
         N, K = x.shape
         M = w.size(0)
         lib = _lib.load()
+        f = dict(dtype=torch.float32, device=x.device)
         dx = None
         if ctx.needs_input_grad[0] and M <= 288 and K <= 96 and N > 0:      # dy[N, M] @ w[M, K], long reduction: tall_x3.hip
             scope = ctx.scope
             img = _o._scoped(scope.bwd if scope else None, ("lin-t", id(w)), w, lambda: _o._ts_image(w, M, K, False))
-            dx = torch.empty(N, K, dtype=torch.float32, device=x.device)
-            check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+            dx = torch.empty(N, K, **f)
+            if ctx.fold:        # ... * celu'(x) in the epilogue
+                check(lib.glam_ts_gemm_celu(ptr(dy), M, M, 0, ptr(img), None, ptr(dx), K, K, ptr(x), K, N, stream()), "glam_ts_gemm_celu")
+            else:
+                check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(dx), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
         elif ctx.needs_input_grad[0]:
             dx = torch.matmul(dy, w)
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
-        if K + 1 <= 64 and not ctx.carried:
-            # weight and bias gradients as separate contiguous tensors: autograd keeps them as they are (views of one [M, K + 1] buffer
-            # cost a copy launch each when they become .grad)
-            dw, db = torch.empty(M, K, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device)
-            check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), K, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
-                  "glam_wgrad_gemm_split")
-            return dx, dw, db, None
-        dwb = torch.empty(M, K + 1, dtype=torch.float32, device=x.device)
         add = f32c(d_carry, "d_carry") if (ctx.carried and d_carry is not None and N > 0) else None
-        if add is None:
-            check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(), stream()),
-                  "glam_wgrad_gemm")
-        else:       # the gradient accumulated by the block's later applications joins in the reduction
-            check(lib.glam_wgrad_gemm_add(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(add), ptr(ws), ws.numel(),
-                                          stream()), "glam_wgrad_gemm_add")
-        if ctx.carried:
-            flat = dwb.view(-1)
-            return dx, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry))
-        return dx, dwb[:, :K], dwb[:, K], None
+        if K % 4 == 0 and K + 1 <= 128 and M <= 320 and N > 0:
+            # weight and bias gradients as two contiguous pieces of one buffer [d_w (M x K) | d_b (M)]
+            flat = torch.empty(M * (K + 1), **f)
+            dw, db = flat[:M * K].view(M, K), flat[M * K:]
+            aw, ab = (add[:M * K], add[M * K:]) if add is not None else (None, None)
+            check(lib.glam_wgrad_gemm_linear(ptr(dy), M, M, ptr(x), K, K, int(ctx.fold), ptr(dw), ptr(db), ptr(aw), ptr(ab), N, ptr(ws),
+                                             ws.numel(), stream()), "glam_wgrad_gemm_linear")
+            if ctx.carried:
+                return dx, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry)), None
+            return dx, dw, db, None, None
+        dwb = torch.empty(M, K + 1, **f)
+        check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(), stream()),
+              "glam_wgrad_gemm")
+        if ctx.carried:      # (layout of the carry: [d_w | d_b])
+            flat = torch.cat([dwb[:, :K].reshape(-1), dwb[:, K]])
+            return dx, None, None, (flat if d_carry is None else flat.add_(d_carry)), None
+        return dx, dwb[:, :K], dwb[:, K], None, None
 
 
-def _linear_tall_node(x, w, b):
+def _linear_tall_node(x, w, b, celu_in=False):
     """``_LinearTall`` with the gradients of (w, b) carried across the applications of a block inside a weight_scope."""
     M, K = w.shape
 
-    def split(flat):     # [d_w | d_b] as the [M, K + 1] result of the dy^T [x | 1] product
-        dwb = flat.view(M, K + 1)
-        return dwb[:, :K], dwb[:, K]
+    def split(flat):     # [d_w (M x K) | d_b (M)]: two contiguous pieces
+        return flat[:M * K].view(M, K), flat[M * K:]
     key = ("carry-lintall", id(w), id(b))
     carry = _o._carry_for(key, (w, b), M * (K + 1), split) if (w.requires_grad or b.requires_grad) else None
     if carry is None:
-        return _LinearTall.apply(x, w, b)
-    y, carry = _LinearTall.apply(x, w, b, carry)
+        return _LinearTall.apply(x, w, b, None, celu_in)
+    y, carry = _LinearTall.apply(x, w, b, carry, celu_in)
     _o._carry_store(key, w, carry)
     return y
 
@@ -680,9 +690,7 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
         wi, wh, bi, bh = _o.scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build_wide) if Cp != C else \
             (w_ih, w_hh, b_ih, b_hh)
         x_p, h_p = _o.pad_cols(x, Cp), _o.pad_cols(h, Cp)
-        if celu_in:
-            x_p = torch.celu(x_p)
-        out_p, hn_p = _GruTail.apply(_linear_tall_node(x_p, wi, bi), _linear_tall_node(h_p, wh, bh), h_p,
+        out_p, hn_p = _GruTail.apply(_linear_tall_node(x_p, wi, bi, celu_in), _linear_tall_node(h_p, wh, bh), h_p,
                                      None if identity is None else _o.pad_cols(identity, Cp), ACT_CODES[act], slope)
         return _o.slice_cols(out_p, C), _o.slice_cols(hn_p, C)
     if celu_in:

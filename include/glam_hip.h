@@ -223,6 +223,12 @@ int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, int Ia, int
                                    int ldqb, int qcelu_b, float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes,
                                    const float* add_w_a, const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 
+/* [d_W | d_b] of ONE linear y = [act(x) | 1] W^T with up to 127 inputs, weight and bias gradients in separate contiguous tensors with
+ * optional addends (the gradient carry): dw[I, J] = P^T act(Q) (+ add_w), db[I] = column sums of P (+ add_b); act = CELU(alpha = 1)
+ * when q_celu (the CELU in front of a MessageBlock's GRU, /root/reference/src_1gp/layer.py:261, folded into the gate product of a
+ * wide layer).  J % 4 == 0, J + 1 <= 128, I <= 320, N >= 1. */
+int glam_wgrad_gemm_linear(const float* P, int I, int ldp, const float* Q, int J, int ldq, int q_celu, float* dw, float* db,
+                           const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes, void* stream);
 /* glam_wgrad_gemm for ONE linear y = [x | 1] W^T with the weight and bias gradients in separate contiguous tensors:
  * dw[I, J] = P^T Q (P = dy f32[N, I], Q = x f32[N, J]), db[I] = column sums of P.  ceil4(J) + 1 <= 64, I <= 320; J need not be a
  * multiple of 4 when ldq >= ceil4(J) (a weight narrower than its zero-padded input: dw stays contiguous [I, J]). */
