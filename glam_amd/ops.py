@@ -880,6 +880,16 @@ class _TripletLayerWide(torch.autograd.Function):
         aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
         mfma = _wide_gemms_supported(H, Cp)
         st = stream()
+        if scope is not None and any(ctx.needs_input_grad):
+            # the four GEMM images of the pass (two for the forward, two for the backward) from one launch instead of four
+            imgs = []
+            if mfma:
+                imgs += [("fwd", ("wide-img-node", id(wn)), wn, Wcat, Wcat.stride(0), 0, Cp, HC + 8, Cp),
+                         ("bwd", ("wide-img-dagg", id(wn)), wn, Ws_p, Ws_p.stride(0), 1, Cp, HC, Cp)]
+            if _wide_tall_supported(H, Cp):
+                imgs += [("fwd", ("wide-img-upd", id(wn)), wn, Ws_p, Ws_p.stride(0), 0, HC, Cp, HC),
+                         ("bwd", ("wide-img-dx", id(wn)), wn, Wcat, Wcat.stride(0), 1, HC + 8, Cp, HC + 8)]
+            prestage(None, imgs)
         if mfma:     # the 120 KB-image k_ts_gemm variant: xw and a_ij in one launch
             img1 = _scoped(scope.fwd if scope else None, ("wide-img-node", id(wn)), wn, lambda: _ts_image(Wcat, Cp, HC + 8, False))
             check(lib.glam_ts_gemm(ptr(x_p), Cp, Cp, None, 0, 0, ptr(img1), None, ptr(xw), HC, HC, ptr(a_ij), 8, 8, N, st), "glam_ts_gemm")

@@ -690,6 +690,11 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
         wi, wh, bi, bh = _o.scoped_weights(("gru-pad", id(w_ih), id(w_hh), id(b_ih), id(b_hh)), w_ih, build_wide) if Cp != C else \
             (w_ih, w_hh, b_ih, b_hh)
         x_p, h_p = _o.pad_cols(x, Cp), _o.pad_cols(h, Cp)
+        if torch.is_grad_enabled() and Cp <= 96:
+            # the four images of the two gate linears (forward and input-gradient products) from one launch instead of four
+            Kc, Mc = Cp, 3 * Cp
+            _o.prestage(None, [("fwd", ("lin", id(wi)), wi, wi, Kc, 1, Kc, Mc, Kc), ("fwd", ("lin", id(wh)), wh, wh, Kc, 1, Kc, Mc, Kc),
+                               ("bwd", ("lin-t", id(wi)), wi, wi, Kc, 0, Mc, Kc, Mc), ("bwd", ("lin-t", id(wh)), wh, wh, Kc, 0, Mc, Kc, Mc)])
         out_p, hn_p = _GruTail.apply(_linear_tall_node(x_p, wi, bi, celu_in), _linear_tall_node(h_p, wh, bh), h_p,
                                      None if identity is None else _o.pad_cols(identity, Cp), ACT_CODES[act], slope)
         return _o.slice_cols(out_p, C), _o.slice_cols(hn_p, C)
