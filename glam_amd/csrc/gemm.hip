@@ -1024,10 +1024,28 @@ extern "C" int glam_wgrad_gemm_sets(int nseg, const float* const* P, int I, int 
 // contiguous outputs (optional addends laid out like them: the gradient carry), act = CELU when q_celu (the CELU in front of a
 // MessageBlock's GRU folded into the gate product, src_1gp/layer.py:261).  J <= 64: one product; beyond: the two column chunks of Q
 // (64 | J - 64 | 1) as the two products of one launch.
+static int wgrad_linear_impl(const char* fn, int nseg, const float* const* Ps, const float* const* Qs, int I, int ldp, int J, int ldq, int q_celu,
+                             float* dw, float* db, const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int glam_wgrad_gemm_linear(const float* P, int I, int ldp, const float* Q, int J, int ldq, int q_celu, float* dw, float* db,
                                       const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes, void* stream) {
-    const char* fn = "glam_wgrad_gemm_linear";
-    GLAM_REQUIRE(N >= 1 && N < INT32_MAX, "%s: N out of range (N = 0: zero the outputs on the host side)", fn);
+    return wgrad_linear_impl("glam_wgrad_gemm_linear", 1, &P, &Q, I, ldp, J, ldq, q_celu, dw, db, add_w, add_b, N, ws, ws_bytes, stream);
+}
+
+// ... summed over nseg <= 3 operand sets of N rows each (the applications of a block that shares the linear's weights)
+extern "C" int glam_wgrad_gemm_linear_sets(int nseg, const float* const* P, int I, int ldp, const float* const* Q, int J, int ldq, int q_celu,
+                                           float* dw, float* db, const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes,
+                                           void* stream) {
+    GLAM_REQUIRE(nseg >= 1 && nseg <= 3 && P && Q, "glam_wgrad_gemm_linear_sets: %d operand sets (1..3) / null table", nseg);
+    return wgrad_linear_impl("glam_wgrad_gemm_linear_sets", nseg, P, Q, I, ldp, J, ldq, q_celu, dw, db, add_w, add_b, N, ws, ws_bytes, stream);
+}
+
+static int wgrad_linear_impl(const char* fn, int nseg, const float* const* Ps, const float* const* Qs, int I, int ldp, int J, int ldq, int q_celu,
+                             float* dw, float* db, const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes, void* stream) {
+    const float* P = Ps[0];
+    const float* Q = Qs[0];
+    GLAM_REQUIRE(N >= 1 && N * nseg < INT32_MAX, "%s: N out of range (N = 0: zero the outputs on the host side)", fn);
+    for (int q = 0; q < nseg; ++q) GLAM_REQUIRE(Ps[q] && Qs[q] && aligned16(Ps[q]) && aligned16(Qs[q]), "%s: operand set %d: null / misaligned", fn, q);
     GLAM_REQUIRE(P && Q && dw && db && ws, "%s: null pointer", fn);
     GLAM_REQUIRE(I > 0 && J > 0 && (J & 3) == 0 && J + 1 <= 128, "%s: J = %d must be a multiple of 4 with J + 1 <= 128", fn, J);
     GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace too small", fn);
@@ -1035,15 +1053,22 @@ extern "C" int glam_wgrad_gemm_linear(const float* P, int I, int ldp, const floa
     hipStream_t s = (hipStream_t)stream;
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     ReduceArgs ra{};
+    auto sets = [&](WgArgs& w, int qoff) {
+        w.nseg = nseg; w.seg_rows = (int)N;
+        for (int q = 1; q < nseg; ++q) { w.segP1[q - 1] = Ps[q]; w.segQ[q - 1] = Qs[q] + qoff; }
+    };
     if (J + 1 <= 64) {
-        WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, J, ldq, 1, (int)N, 0, partial, 0, 0, q_celu};
+        WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, J, ldq, 1, (int)(N * nseg), 0, partial, 0, 0, q_celu};
+        sets(a, 0);
         ra.njobs = 1;
         if (int rc = launch_wgrad_partials(a, dw, J, 1, s, &ra.job[0])) return rc;
         ra.job[0].addend = add_w; ra.job[0].out_b = db; ra.job[0].add_b = add_b;
         return launch_final_reduce(ra, s);
     }
-    WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, 64, ldq, 0, (int)N, 0, partial, 0, 0, q_celu};
-    WgArgs b{P, I, ldp, nullptr, 0, 0, 0, Q + 64, J - 64, ldq, 1, (int)N, 0, partial + wgrad_workspace_floats(), 0, 0, q_celu};
+    WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, 64, ldq, 0, (int)(N * nseg), 0, partial, 0, 0, q_celu};
+    WgArgs b{P, I, ldp, nullptr, 0, 0, 0, Q + 64, J - 64, ldq, 1, (int)(N * nseg), 0, partial + wgrad_workspace_floats(), 0, 0, q_celu};
+    sets(a, 0);
+    sets(b, 64);
     ra.njobs = 2;
     if (int rc = launch_wgrad_partials2(a, dw, J, 1, &ra.job[0], b, dw + 64, J, 1, &ra.job[1], s)) return rc;
     ra.job[0].addend = add_w;

@@ -296,11 +296,12 @@ class _LinearTall(torch.autograd.Function):
     _ParamBundle): ``[d_w | d_b]`` flat, summed by the reduction of the weight-gradient product."""
 
     @staticmethod
-    def forward(ctx, x, w, b, carry=None, celu_in=False):
+    def forward(ctx, x, w, b, carry=None, celu_in=False, first_app=True):
         require_device(x, w, b)
         x, w, b = f32c(x, "x"), f32c(w, "weight"), f32c(b, "bias")
         ctx.scope = _o._SCOPE
         ctx.carried = carry is not None
+        ctx.first_app = bool(first_app)
         if ctx.carried:
             ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
         N, K = x.shape
@@ -325,7 +326,7 @@ class _LinearTall(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, d_carry=None):
         if dy is None:      # only with a carry (grads are not materialised then): the output itself was unused
-            return None, None, None, d_carry, None
+            return None, None, None, d_carry, None, None
         x, w = ctx.saved_tensors
         dy = f32c(dy, "dy")
         N, K = x.shape
@@ -344,6 +345,30 @@ class _LinearTall(torch.autograd.Function):
         elif ctx.needs_input_grad[0]:
             dx = torch.matmul(dy, w)
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        scope = ctx.scope
+        if (ctx.carried and scope is not None and _o.GRU_WGRAD_BATCH and N >= _GRU_BATCH_MIN_ROWS and K % 4 == 0 and K + 1 <= 128 and M <= 320):
+            # the weight gradient of ALL applications of the block in one launch (see _GruBlock.backward): every application but the first
+            # parks (dy, x); the first one — its backward runs last — multiplies the parked sets together, three per launch
+            parked = scope.bwd.setdefault(("lintall-parked", id(w)), (w, []))[1]
+            parked.append((dy, x, bool(ctx.fold)))
+            if not ctx.first_app:
+                return dx, None, None, d_carry, None, None
+            sets = list(parked)
+            parked.clear()
+            addf = None if d_carry is None else f32c(d_carry, "d_carry")
+            vp = ctypes.c_void_p
+            while sets:
+                grp = [t for t in sets if t[2] == sets[0][2]][:3]
+                sets = [t for t in sets if all(t is not u for u in grp)]
+                n = len(grp)
+                flat = torch.empty(M * (K + 1), **f)
+                aw, ab = (addf[:M * K], addf[M * K:]) if addf is not None else (None, None)
+                ws2 = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
+                check(lib.glam_wgrad_gemm_linear_sets(n, (vp * n)(*[t[0].data_ptr() for t in grp]), M, M, (vp * n)(*[t[1].data_ptr() for t in grp]),
+                                                      K, K, int(grp[0][2]), ptr(flat[:M * K]), ptr(flat[M * K:]), ptr(aw), ptr(ab), N, ptr(ws2),
+                                                      ws2.numel(), stream()), "glam_wgrad_gemm_linear_sets")
+                addf = flat
+            return dx, None, None, addf, None, None
         add = f32c(d_carry, "d_carry") if (ctx.carried and d_carry is not None and N > 0) else None
         if K % 4 == 0 and K + 1 <= 128 and M <= 320 and N > 0:
             # weight and bias gradients as two contiguous pieces of one buffer [d_w (M x K) | d_b (M)]
@@ -353,15 +378,15 @@ class _LinearTall(torch.autograd.Function):
             check(lib.glam_wgrad_gemm_linear(ptr(dy), M, M, ptr(x), K, K, int(ctx.fold), ptr(dw), ptr(db), ptr(aw), ptr(ab), N, ptr(ws),
                                              ws.numel(), stream()), "glam_wgrad_gemm_linear")
             if ctx.carried:
-                return dx, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry)), None
-            return dx, dw, db, None, None
+                return dx, None, None, (flat if (add is not None or d_carry is None) else flat.add_(d_carry)), None, None
+            return dx, dw, db, None, None, None
         dwb = torch.empty(M, K + 1, **f)
         check(lib.glam_wgrad_gemm(ptr(dy), M, M, None, 0, 0, 0, ptr(x), K, K, 1, N, ptr(dwb), K + 1, 1, ptr(ws), ws.numel(), stream()),
               "glam_wgrad_gemm")
         if ctx.carried:      # (layout of the carry: [d_w | d_b])
             flat = torch.cat([dwb[:, :K].reshape(-1), dwb[:, K]])
-            return dx, None, None, (flat if d_carry is None else flat.add_(d_carry)), None
-        return dx, dwb[:, :K], dwb[:, K], None, None
+            return dx, None, None, (flat if d_carry is None else flat.add_(d_carry)), None, None
+        return dx, dwb[:, :K], dwb[:, K], None, None, None
 
 
 def _linear_tall_node(x, w, b, celu_in=False):
@@ -371,10 +396,12 @@ def _linear_tall_node(x, w, b, celu_in=False):
     def split(flat):     # [d_w (M x K) | d_b (M)]: two contiguous pieces
         return flat[:M * K].view(M, K), flat[M * K:]
     key = ("carry-lintall", id(w), id(b))
+    hit = _o._SCOPE.fwd.get(key) if _o._SCOPE is not None else None
+    first = not (hit is not None and hit[0] is w)          # the block's first application of this pass: its backward runs LAST
     carry = _o._carry_for(key, (w, b), M * (K + 1), split) if (w.requires_grad or b.requires_grad) else None
     if carry is None:
         return _LinearTall.apply(x, w, b, None, celu_in)
-    y, carry = _LinearTall.apply(x, w, b, carry, celu_in)
+    y, carry = _LinearTall.apply(x, w, b, carry, celu_in, first)
     _o._carry_store(key, w, carry)
     return y
 

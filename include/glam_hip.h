@@ -229,6 +229,11 @@ int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, int Ia, int
  * wide layer).  J % 4 == 0, J + 1 <= 128, I <= 320, N >= 1. */
 int glam_wgrad_gemm_linear(const float* P, int I, int ldp, const float* Q, int J, int ldq, int q_celu, float* dw, float* db,
                            const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes, void* stream);
+/* ... summed over nseg <= 3 operand sets of N rows each (the applications of a block that shares the linear: see
+ * glam_wgrad_gemm_pair_split_seg). */
+int glam_wgrad_gemm_linear_sets(int nseg, const float* const* P, int I, int ldp, const float* const* Q, int J, int ldq, int q_celu,
+                                float* dw, float* db, const float* add_w, const float* add_b, int64_t N, void* ws, size_t ws_bytes,
+                                void* stream);
 /* glam_wgrad_gemm for ONE linear y = [x | 1] W^T with the weight and bias gradients in separate contiguous tensors:
  * dw[I, J] = P^T Q (P = dy f32[N, I], Q = x f32[N, J]), db[I] = column sums of P.  ceil4(J) + 1 <= 64, I <= 320; J need not be a
  * multiple of 4 when ldq >= ceil4(J) (a weight narrower than its zero-padded input: dw stays contiguous [I, J]). */
