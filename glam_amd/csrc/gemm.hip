@@ -1020,6 +1020,43 @@ extern "C" int glam_wgrad_gemm_sets(int nseg, const float* const* P, int I, int 
     return launch_final_reduce(ra, (hipStream_t)stream);
 }
 
+// glam_wgrad_gemm in full ([P1 | P2 | 1]^T Q, any output strides, J up to 128 as two column chunks) summed over nseg <= 3 operand sets
+// of N rows each: the two N-deep weight gradients of the wide TripletMessage (hid_dim_alpha = 6) over all applications of the layer.
+extern "C" int glam_wgrad_gemm_sets2(int nseg, const float* const* P1, int I1, int ldp1, const float* const* P2, int I2, int ldp2, int ones,
+                                     const float* const* Q, int J, int ldq, int64_t N, float* out, int stride_i, int stride_j,
+                                     const float* addend, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "glam_wgrad_gemm_sets2";
+    GLAM_REQUIRE(nseg >= 1 && nseg <= 3 && P1 && Q && (I2 == 0 || P2), "%s: %d operand sets (1..3) / null table", fn, nseg);
+    GLAM_REQUIRE(N >= 1 && N * nseg < INT32_MAX && out && ws, "%s: N out of range / null pointer", fn);
+    GLAM_REQUIRE(ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace too small", fn);
+    GLAM_REQUIRE(J > 0 && (J & 3) == 0 && J <= 128, "%s: J = %d must be a multiple of 4 up to 128", fn, J);
+    for (int q = 0; q < nseg; ++q)
+        GLAM_REQUIRE(P1[q] && Q[q] && (I2 == 0 || P2[q]) && aligned16(P1[q]) && aligned16(Q[q]) && (I2 == 0 || aligned16(P2[q])),
+                     "%s: operand set %d: null / misaligned pointer", fn, q);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    auto make = [&](int qoff, int Jc, float* part) {
+        WgArgs w{P1[0], I1, ldp1, I2 ? P2[0] : nullptr, I2, ldp2, ones, Q[0] + qoff, Jc, ldq, 0, (int)(N * nseg), 0, part, 0, 0};
+        w.nseg = nseg; w.seg_rows = (int)N;
+        for (int q = 1; q < nseg; ++q) { w.segP1[q - 1] = P1[q]; w.segP2[q - 1] = I2 ? P2[q] : nullptr; w.segQ[q - 1] = Q[q] + qoff; }
+        return w;
+    };
+    ReduceArgs ra{};
+    if (J <= 64) {
+        WgArgs a = make(0, J, partial);
+        ra.njobs = 1;
+        if (int rc = launch_wgrad_partials(a, out, stride_i, stride_j, s, &ra.job[0])) return rc;
+        ra.job[0].addend = addend;
+        return launch_final_reduce(ra, s);
+    }
+    WgArgs a = make(0, 64, partial), b = make(64, J - 64, partial + wgrad_workspace_floats());
+    ra.njobs = 2;
+    if (int rc = launch_wgrad_partials2(a, out, stride_i, stride_j, &ra.job[0], b, out + (size_t)64 * stride_j, stride_i, stride_j, &ra.job[1], s))
+        return rc;
+    if (addend) { ra.job[0].addend = addend; ra.job[1].addend = addend + (size_t)64 * stride_j; }
+    return launch_final_reduce(ra, s);
+}
+
 // [d_W | d_b] of one linear y = [act(x) | 1] W^T with up to 127 inputs: dw[I, J] = P^T act(Q) and db[I] = column sums of P in SEPARATE
 // contiguous outputs (optional addends laid out like them: the gradient carry), act = CELU when q_celu (the CELU in front of a
 // MessageBlock's GRU folded into the gate product, src_1gp/layer.py:261).  J <= 64: one product; beyond: the two column chunks of Q

@@ -850,8 +850,9 @@ class _TripletLayerWide(torch.autograd.Function):
     No per-parameter torch glue on either pass."""
 
     @staticmethod
-    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None):
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None, first_app=True):
         require_device(x_p, ea_p, wn, we, att, wsc, bias)
+        ctx.first_app = bool(first_app)
         x_p, ea_p = f32c(x_p, "x"), f32c(ea_p, "edge_attr")
         wn, we, att, wsc, bias = (f32c(t, n) for t, n in ((wn, "weight_node"), (we, "weight_edge"),
                                                            (att, "weight_triplet_att"), (wsc, "weight_scale"), (bias, "bias")))
@@ -912,7 +913,7 @@ class _TripletLayerWide(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out, d_carry=None):
         if d_out is None:                    # the layer's output was not used: only the carry (if any) passes through
-            return (None,) * 10 + (d_carry,)
+            return (None,) * 10 + (d_carry, None)
         x_p, ea_p, wn, we, att, plain, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
@@ -923,9 +924,9 @@ class _TripletLayerWide(torch.autograd.Function):
         if N == 0:        # an empty batch: every gradient is zero
             z = lambda t: torch.zeros_like(t)
             if ctx.carried:
-                return (torch.zeros_like(x_p), torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None) + (None,) * 8 + (d_carry,)
+                return (torch.zeros_like(x_p), torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None) + (None,) * 8 + (d_carry, None)
             return (torch.zeros_like(x_p), torch.zeros_like(ea_p) if ctx.needs_input_grad[1] else None, z(wn), z(we), z(att),
-                    torch.zeros(H * C, C, **f), torch.zeros(C, **f), None, None, None)
+                    torch.zeros(H * C, C, **f), torch.zeros(C, **f), None, None, None, None, None)
         Wcat, Ws_p, We_p, M, _ = _plain_views(plain, H, Cp, Dp)
         colptr, dst, eid_t = gi.transpose()
         # dstaged: d_Wcat[Cp, HC+8] | d_WsB[HC+1, Cp] | d_We_p[Dp, HC] | d_M[Dp, 4]   (include/glam_hip.h)
@@ -955,20 +956,54 @@ class _TripletLayerWide(torch.autograd.Function):
         else:
             d_x = torch.matmul(d_xw, Wcat[:, :HC].t())
             d_x.addmm_(d_a, Wcat[:, HC:].t())
+        sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
+        shapes = (wn.shape, we.shape, att.shape, (H * C, C), (C,))
+        if ctx.carried and scope is not None and GRU_WGRAD_BATCH and N >= 512 and Cp <= 128:
+            # the parameter gradients of ALL applications of the layer from one set of launches (see _TripletLayer.backward): every
+            # application parks its operands (and its small d_W_edge / d_M sums); the first one — its backward runs last — runs both N-deep
+            # products over the parked sets (glam_wgrad_gemm_sets2) and the chain rule (k_stage_params_bwd is linear in dstaged) ONCE
+            parked = scope.bwd.setdefault(("wide-parked", id(wn)), (wn, []))[1]
+            parked.append((aggr, d_out, d_xw, d_a, x_p, dstaged))
+            if not ctx.first_app:
+                return d_x, d_ea, None, None, None, None, None, None, None, None, d_carry, None
+            sets = list(parked)
+            parked.clear()
+            vp = ctypes.c_void_p
+            small = dstaged[o_we:]                       # d_We_p | d_M: sums over the applications
+            for t in sets[:-1]:
+                small.add_(t[5][o_we:])
+            first_group = True
+            while sets:
+                grp, sets = sets[:3], sets[3:]
+                n = len(grp)
+                arr = lambda i: (vp * n)(*[t[i].data_ptr() for t in grp])
+                wws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+                check(lib.glam_wgrad_gemm_sets2(n, arr(0), HC, HC, None, 0, 0, 1, arr(1), Cp, Cp, N, ptr(dstaged[o_wsb:]), Cp, 1,
+                                                None if first_group else ptr(dstaged[o_wsb:]), ptr(wws), wws.numel(), stream()),
+                      "glam_wgrad_gemm_sets2")
+                wws2 = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+                check(lib.glam_wgrad_gemm_sets2(n, arr(2), HC, HC, arr(3), 8, 8, 0, arr(4), Cp, Cp, N, ptr(dstaged), 1, HC + 8,
+                                                None if first_group else ptr(dstaged), ptr(wws2), wws2.numel(), stream()),
+                      "glam_wgrad_gemm_sets2")
+                first_group = False
+            flatg = torch.empty(sum(sizes), **f)
+            d_wn, d_we, d_att, d_wsc, d_bias = (t.view(sh) for t, sh in zip(flatg.split(sizes), shapes))
+            check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn), ptr(d_we),
+                                                    ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()), "glam_triplet_stage_params_bwd")
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None
         wws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         # d_WsB = [aggr | 1]^T d_out ;  d_Wcat = x^T [d_xw | d_a], computed as ([d_xw | d_a]^T x)^T
         check(lib.glam_wgrad_gemm(ptr(aggr), HC, HC, None, 0, 0, 1, ptr(d_out), Cp, Cp, 0, N, ptr(dstaged[o_wsb:]), Cp, 1,
                                   ptr(wws), wws.numel(), stream()), "glam_wgrad_gemm")
         check(lib.glam_wgrad_gemm(ptr(d_xw), HC, HC, ptr(d_a), 8, 8, 0, ptr(x_p), Cp, Cp, 0, N, ptr(dstaged), 1, HC + 8,
                                   ptr(wws), wws.numel(), stream()), "glam_wgrad_gemm")
-        sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
         flatg = torch.empty(sum(sizes), **f)
-        d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,))))
+        d_wn, d_we, d_att, d_wsc, d_bias = (t.view(s) for t, s in zip(flatg.split(sizes), shapes))
         check(lib.glam_triplet_stage_params_bwd(ptr(wn), ptr(we), ptr(att), ptr(dstaged), C, H, De, Cp, Dp, ptr(d_wn), ptr(d_we),
                                                 ptr(d_att), ptr(d_wsc), ptr(d_bias), stream()), "glam_triplet_stage_params_bwd")
         if ctx.carried:       # one add of the flat buffer per application instead of five per-parameter accumulations
-            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry))
-        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None
 
 
 def _wide_gemms_supported(H, Cp):
@@ -1007,10 +1042,12 @@ def triplet_layer_wide(x_p, ea_p, weight_node, weight_edge, att, weight_scale, b
     sizes = [weight_node.numel(), weight_edge.numel(), att.numel(), heads * C * C, C]
     shapes = (weight_node.shape, weight_edge.shape, att.shape, (heads * C, C), (C,))
     key = ("carry-triplet-wide", id(weight_node))
+    hit = _SCOPE.fwd.get(key) if _SCOPE is not None else None
+    first = not (hit is not None and hit[0] is weight_node)      # the layer's first application of this pass: its backward runs LAST
     carry = _carry_for(key, params, sum(sizes), lambda flat: [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)])
     if carry is None:
         return _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope)
-    out, carry = _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry)
+    out, carry = _TripletLayerWide.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry, first)
     _carry_store(key, weight_node, carry)
     return out
 

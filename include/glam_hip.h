@@ -223,6 +223,11 @@ int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, int Ia, int
                                    int ldqb, int qcelu_b, float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes,
                                    const float* add_w_a, const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 
+/* glam_wgrad_gemm in full ([P1 | P2 | 1]^T Q, output strides, J <= 128) summed over nseg <= 3 operand sets of N rows each (+ an
+ * optional addend laid out like out): the N-deep weight gradients of the wide TripletMessage over all applications of the layer. */
+int glam_wgrad_gemm_sets2(int nseg, const float* const* P1, int I1, int ldp1, const float* const* P2, int I2, int ldp2, int ones,
+                          const float* const* Q, int J, int ldq, int64_t N, float* out, int stride_i, int stride_j, const float* addend,
+                          void* ws, size_t ws_bytes, void* stream);
 /* [d_W | d_b] of ONE linear y = [act(x) | 1] W^T with up to 127 inputs, weight and bias gradients in separate contiguous tensors with
  * optional addends (the gradient carry): dw[I, J] = P^T act(Q) (+ add_w), db[I] = column sums of P (+ add_b); act = CELU(alpha = 1)
  * when q_celu (the CELU in front of a MessageBlock's GRU, /root/reference/src_1gp/layer.py:261, folded into the gate product of a

@@ -3096,3 +3096,27 @@ def test_pair_norm_and_the_dropout_behind_it_in_one_launch(device, monkeypatch, 
     keep = y != 0
     assert torch.equal(y[keep], (ref * (1.0 / 0.75))[keep]) and 0.6 < keep.float().mean().item() < 0.9
 
+
+@pytest.mark.parametrize("steps", [3, 4])
+def test_wide_layer_parameter_gradients_of_all_applications_in_one_launch(device, steps, monkeypatch):
+    """hid_dim_alpha = 6 (C = 90 -> 92: the wide TripletMessage path and the wide GRU's gate linears): the N-deep weight gradients of all
+    applications as one product each over the parked operand sets (glam_wgrad_gemm_sets2, glam_wgrad_gemm_linear_sets; four
+    applications: three sets + one added in place) against one product per application; forward and data gradients bit for bit."""
+    torch.manual_seed(steps + 40)
+    b = synth_batch(160, seed=6).to(device)
+    net = model.Architecture(hid_dim_alpha=6, mol_block="_TripletMessage", message_steps=steps).to(device).eval()
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", flag)
+        net.zero_grad()
+        out = net(b)
+        out.square().sum().backward()
+        res[flag] = ({n: p.grad.clone() for n, p in net.named_parameters()}, out.detach().clone())
+    assert torch.equal(res[True][1], res[False][1])
+    for n in res[True][0]:
+        a, c = res[True][0][n], res[False][0][n]
+        if "mol_conv" in n:
+            assert_close(a, c, 3e-6, n)
+        else:
+            assert torch.equal(a, c), n
+
