@@ -697,17 +697,18 @@ class _TripletLayer(torch.autograd.Function):
         have_carry = ctx.carried and d_carry is not None and N > 0
         ell_f = gi.ell() if ell_t is not None else None          # (by target: what the forward used)
         scope = ctx.scope
-        if ctx.carried and ell_t is not None and scope is not None and GRU_WGRAD_BATCH and N >= 512:
+        if ctx.carried and d_ea is None and scope is not None and GRU_WGRAD_BATCH and N >= 512:
             # The parameter gradients of ALL applications of the layer from one launch pair: every application runs the DATA half of its
             # backward (d_x) and parks its operands — its workspace holds d_xw, d_a and the block partials of d_W_edge / d_M —; the first
             # application (its backward runs last) runs both weight-gradient products over the parked sets and k_param_grads ONCE
             # (glam_triplet_layer_param_grads_sets).  3 x (k_wgrad + k_param_grads) -> 1 + 1 per training step at message_steps = 3.
-            in_kernel = d_alias is not None and os.environ.get("GLAM_X3", "1") != "0"
+            in_kernel = d_alias is not None and ell_t is not None and os.environ.get("GLAM_X3", "1") != "0"   # (warp-specialised route only)
             addend = f32c(d_alias, "d_identity") if in_kernel else None
             info = (ctypes.c_int64 * 4)()
             check(lib.glam_triplet_layer_bwd_data_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(d_out),
                                                       ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst), ptr(eid_t), N, E, C, H, De,
-                                                      Cp, Dp, slope, ptr(d_x), ptr(ell_f[0]), ptr(ell_f[1]), ptr(ell_t[0]), ptr(ell_t[1]), 1,
+                                                      Cp, Dp, slope, ptr(d_x), ptr(ell_f[0]) if ell_f else None, ptr(ell_f[1]) if ell_f else None,
+                                                      ptr(ell_t[0]) if ell_t else None, ptr(ell_t[1]) if ell_t else None, 1 if ell_t else 0,
                                                       None, ptr(ws), ws.numel(), ptr(addend), info, stream()), "glam_triplet_layer_bwd_data_ell")
             if d_alias is not None and not in_kernel:
                 d_x = d_x.add_(d_alias)
