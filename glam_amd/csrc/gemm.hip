@@ -693,8 +693,11 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) { return launch_ts_gemm2(a, n
 
 constexpr int kWgradBlocks = 256;      // about one 8-wave block per CU: the right grid while the operands are cache resident
 constexpr int kWgradBlocksBig = 512;   // two per CU (four waves per SIMD) once they stream from HBM: B = 16 384: 169 vs 182 us, B = 1 024: 15.0 vs 14.4
-constexpr int kWgradBigRows = 131072;
-static int wgrad_budget(int N) { return N >= kWgradBigRows ? kWgradBlocksBig : kWgradBlocks; }
+static int wgrad_big_rows() {      // (GLAM_WG_BIG_ROWS: A/B switch)
+    static const int v = [] { const char* e = getenv("GLAM_WG_BIG_ROWS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 131072; }();
+    return v;
+}
+static int wgrad_budget(int N) { return N >= wgrad_big_rows() ? kWgradBlocksBig : kWgradBlocks; }
 
 size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per block
 
@@ -742,7 +745,7 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
 int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
                            int sj_b, ReduceJob* job_b, hipStream_t s) {
     const int ta = (a.I1 + a.I2 + (a.ones ? 1 : 0) + 63) / 64, tb = (b.I1 + b.I2 + (b.ones ? 1 : 0) + 63) / 64;
-    const int total = a.N >= kWgradBigRows ? 2 * GLAM_WG_PAIR_BLOCKS : GLAM_WG_PAIR_BLOCKS;
+    const int total = a.N >= wgrad_big_rows() ? 2 * GLAM_WG_PAIR_BLOCKS : GLAM_WG_PAIR_BLOCKS;
     const int ba = ta + tb > 0 ? total * ta / (ta + tb) : total / 2;
     int na = 0, nb = 0;
     if (int rc = plan_wgrad(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;

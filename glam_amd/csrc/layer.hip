@@ -359,47 +359,91 @@ __device__ __forceinline__ void wg_sum2(const float* pa, const float* pb, int ns
 // lg, lg + 16, ...; `request` / `finish` halves so that two elements (or an element and a slab sum) share the round trip
 constexpr int kB1Batch = 16;
 struct B1Batch { float v[kB1Batch]; };
-// SETS: the rows lie in up to three buffers of `each` rows ([0, each) | [each, 2 each) | [2 each, ..): the applications of a layer that
-// shares its weights); a separate instantiation — the row-to-buffer selects cost the one-buffer kernel of the headline step 4.5 us
+// the rows of up to three buffers of `each` rows behind one another (the applications of a layer that shares its weights): the SETS
+// instantiation, whose loops run set by set — a wave-uniform base pointer per set.  (A per-lane row-to-buffer select made the compiler
+// branch around the loads and wait for each on the spot: role D alone took 18.8 us of k_param_grads<true>, role C 10.7; and as part
+// of the one-buffer kernel the selects cost the headline step 4.5 us.)
 struct B1Src { const float* p3; const float* p3b; const float* p3c; int each; };
-template <bool SETS>
-__device__ __forceinline__ void b1_request(B1Batch& b, const B1Src& src, int ns3, int P, int e, int s0) {
+__device__ __forceinline__ const float* b1_set(const B1Src& src, int q, int nset) {
+    return q == 1 && nset > 1 ? src.p3b : q == 2 && nset > 2 ? src.p3c : src.p3;      // (a set that is not there re-reads the first; masked)
+}
+__device__ __forceinline__ void b1_request(B1Batch& b, const float* p3, int ns3, int P, int e, int s0) {
 #pragma unroll
-    for (int u = 0; u < kB1Batch; ++u) {
-        const int s = min(s0 + 16 * u, ns3 - 1);
-        if (!SETS) { b.v[u] = src.p3[(size_t)s * P + e]; continue; }
-        const bool in0 = s < src.each, in1 = s < 2 * src.each;
-        const float* base = in0 ? src.p3 : in1 ? src.p3b : src.p3c;
-        b.v[u] = base[(size_t)(s - (in0 ? 0 : in1 ? src.each : 2 * src.each)) * P + e];
-    }
+    for (int u = 0; u < kB1Batch; ++u) b.v[u] = p3[(size_t)min(s0 + 16 * u, ns3 - 1) * P + e];
 }
 __device__ __forceinline__ float b1_add(float part, const B1Batch& b, int ns3, int s0) {
 #pragma unroll
     for (int u = 0; u < kB1Batch; ++u) part += s0 + 16 * u < ns3 ? b.v[u] : 0.f;
     return part;
 }
-template <bool SETS>
-__device__ __forceinline__ float b1_sum16(const B1Src& p3, int ns3, int P, int e, int lg) {
+__device__ __forceinline__ float b1_sum16(const float* p3, int ns3, int P, int e, int lg) {
     float part = 0.f;
     for (int s = lg; s < ns3; s += 16 * kB1Batch) {
         B1Batch b;
-        b1_request<SETS>(b, p3, ns3, P, e, s);
+        b1_request(b, p3, ns3, P, e, s);
         part = b1_add(part, b, ns3, s);
     }
     return group_sum<16>(part);
 }
-template <bool SETS>
-__device__ __forceinline__ void b1_sum16x2(const B1Src& p3, int ns3, int P, int e0, int e1, int lg, float& r0, float& r1) {
+// the same over the sets: the batches of all three in flight together, added set after set
+__device__ __forceinline__ float b1_sum16_sets(const B1Src& src, int ns3, int P, int e, int lg) {
+    const int nset = ns3 / src.each;
+    float part = 0.f;
+    for (int s = lg; s < src.each; s += 16 * kB1Batch) {
+        B1Batch b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b1_request(b[q], b1_set(src, q, nset), src.each, P, e, s);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) part = b1_add(part, b[q], q < nset ? src.each : 0, s);
+    }
+    return group_sum<16>(part);
+}
+__device__ __forceinline__ void b1_sum16x2(const float* p3, int ns3, int P, int e0, int e1, int lg, float& r0, float& r1) {
     float p0 = 0.f, p1 = 0.f;
     for (int s = lg; s < ns3; s += 16 * kB1Batch) {
         B1Batch a, b;
-        b1_request<SETS>(a, p3, ns3, P, e0, s);
-        b1_request<SETS>(b, p3, ns3, P, e1, s);
+        b1_request(a, p3, ns3, P, e0, s);
+        b1_request(b, p3, ns3, P, e1, s);
         p0 = b1_add(p0, a, ns3, s);
         p1 = b1_add(p1, b, ns3, s);
     }
     r0 = group_sum<16>(p0);
     r1 = group_sum<16>(p1);
+}
+
+// Role D's loads, with the grain of the partial rows: lanes (el = lane & 7) on 8 consecutive elements — one 32-byte run of a row —
+// and (rl = lane >> 3, wave) on 32 interleaved row classes; a lane adds its rows s = r0, r0 + 32, ... in order.  (A 16-lane group per
+// element puts the 64 lanes of a load on 16 rows x 4 elements = 16 lines, and the CU's address path takes a line per cycle: for three
+// operand sets of 384 rows x 752 elements on the 45 role-D blocks that was most of k_param_grads<true>'s 18.8 us.)
+#ifndef GLAM_PG_ROWS8_ALL
+#define GLAM_PG_ROWS8_ALL 1      // 0: the one-buffer instantiation (the headline step's) keeps 16-lane groups per element (5.1 against 4.4 us)
+#endif
+template <bool SETS>
+__device__ __forceinline__ void b1_rows8(const B1Src& src, int ns3, int P, int e0, int e1, int r0, float& p0, float& p1) {
+    constexpr int BATCH = SETS ? 16 : 12, NQ = SETS ? 3 : 1;
+    const int each = SETS ? src.each : ns3, nset = SETS ? ns3 / src.each : 1;
+    p0 = p1 = 0.f;
+    for (int s0 = r0; s0 < each; s0 += 32 * BATCH) {
+        float va[NQ][BATCH], vb[NQ][BATCH];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* base = b1_set(src, q, nset);
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const float* row = base + (size_t)min(s0 + 32 * u, each - 1) * P;
+                va[q][u] = row[e0];
+                vb[q][u] = row[e1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const bool ok = q < nset && s0 + 32 * u < each;
+                p0 += ok ? va[q][u] : 0.f;
+                p1 += ok ? vb[q][u] : 0.f;
+            }
+    }
 }
 
 #ifdef GLAM_PG_PROF   // developer aid (tools/pg_prof.py): cycle stamps of thread 0 of every block, s_memtime = the device-wide clock
@@ -483,7 +527,8 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) wcol[kk] = (out_mine && kk < De) ? a.we[(size_t)kk * H * C + h * C + tid] : 0.f;
             const float carry = (out_mine && a.c_att) ? a.c_att[(size_t)h * 3 * C + C + tid] : 0.f;
-            const float dm = b1_sum16<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, WSZ + (dm_mine ? grp : 0) * 4 + h, lg);
+            const int e_dm = WSZ + (dm_mine ? grp : 0) * 4 + h;
+            const float dm = SETS ? b1_sum16_sets(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, e_dm, lg) : b1_sum16(a.p3, a.ns3, a.P, e_dm, lg);
             if (dm_mine && lg == 0) s_dm[grp] = dm;
             __syncthreads();
             if (out_mine) {
@@ -521,6 +566,27 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
     }
     b -= a.blocksC;
     {                                                       // ---- D: weight_edge, 16 lanes per element
+        if constexpr (SETS || GLAM_PG_ROWS8_ALL) {          // 8 elements per block
+            const int w = tid >> 6, el = tid & 7, rl = (tid >> 3) & 7;
+            const int o = b * 8 + el;
+            const bool mine = o < De * H * C;
+            const int oc = mine ? o : 0;
+            const int kk = oc / (H * C), m = oc - kk * H * C, h = m / C, c = m - h * C;
+            const float att_e = a.att[(size_t)h * 3 * C + C + c];
+            const float carry = a.c_we ? a.c_we[oc] : 0.f;
+            float p0, p1;
+            b1_rows8<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, w * 8 + rl, p0, p1);
+            p0 += __shfl_xor(p0, 8, 64);  p1 += __shfl_xor(p1, 8, 64);
+            p0 += __shfl_xor(p0, 16, 64); p1 += __shfl_xor(p1, 16, 64);
+            p0 += __shfl_xor(p0, 32, 64); p1 += __shfl_xor(p1, 32, 64);
+            if (rl == 0) { s_pc[w][el] = p0; s_pc[w][8 + el] = p1; }
+            __syncthreads();
+            if (tid < 8 && mine) {
+                const float dwe = ((s_pc[0][el] + s_pc[1][el]) + s_pc[2][el]) + s_pc[3][el];
+                const float dm = ((s_pc[0][8 + el] + s_pc[1][8 + el]) + s_pc[2][8 + el]) + s_pc[3][8 + el];
+                a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
+            }
+        } else {
         const int o = b * (kBlock / 16) + grp;
         if (o < De * H * C) {
             const int kk = o / (H * C), m = o - kk * H * C, h = m / C, c = m - h * C;
@@ -528,9 +594,10 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
             const float att_e = a.att[(size_t)h * 3 * C + C + c];
             const float carry = a.c_we ? a.c_we[o] : 0.f;
             float dwe, dm;
-            b1_sum16x2<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, lg, dwe, dm);
+            b1_sum16x2(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, lg, dwe, dm);
             PG_STAMP(3);
             if (lg == 0) a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
+        }
         }
         PG_STAMP(4);
     }
@@ -797,7 +864,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
                          (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
         pg.ns3_each = tnblk;
-        const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
+        const int blocksD = GLAM_PG_ROWS8_ALL ? (De * H * C + 7) / 8 : (De * H * C * 16 + kBlock - 1) / kBlock;
         GLAM_PROF_LABEL("k_param_grads");
         hipLaunchKernelGGL(k_param_grads<false>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
         GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
@@ -1001,7 +1068,7 @@ extern "C" int glam_triplet_layer_param_grads_sets(int nseg, const void* const* 
                      Dp, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H,
                      add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
     pg.p3b = tp[1]; pg.p3c = tp[2]; pg.ns3_each = tnblk;
-    const int blocksD = (De * H * C * 16 + kBlock - 1) / kBlock;
+    const int blocksD = (nseg > 1 || GLAM_PG_ROWS8_ALL) ? (De * H * C + 7) / 8 : (De * H * C * 16 + kBlock - 1) / kBlock;
     GLAM_PROF_LABEL("k_param_grads<sets>");
     if (nseg == 1) hipLaunchKernelGGL(k_param_grads<false>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
     else hipLaunchKernelGGL(k_param_grads<true>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
