@@ -1,3 +1,4 @@
+# k_param_grads<SETS> (the operand-set instantiation) role by role under rocprofv3, in the full-model step (GPU box): see tools/README.md
 R=/root/repo; cd /tmp; export TMPDIR=/tmp
 for r in ${ROLES:-0 1 2 3}; do
   export GLAM_HIP_LIB=$R/glam_amd/variants/lib_pg_only$r.so
