@@ -3028,13 +3028,14 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
 
 
 @pytest.mark.parametrize("block", ["_TripletMessage", "_NNConv"])
-@pytest.mark.parametrize("steps", [1, 3, 4])
+@pytest.mark.parametrize("steps", [1, 2, 3, 4])
 def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch):
     """MessageBlock applied message_steps times: the GRU's weight gradients, the TripletMessage's parameter gradients
     (glam_triplet_layer_bwd_data_ell + glam_triplet_layer_param_grads_sets) and NNConv's relation product's (glam_wgrad_gemm_sets) as
     ONE product each over the parked operand sets of all applications (four applications: a group of three, then
     one added in place) against one product per application."""
     torch.manual_seed(steps)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)       # the Python node: what a captured step runs (the eager C++ node parks nothing)
     b = synth_batch(160, seed=3).to(device)        # ~3 200 atoms: above the batching threshold
     net = model.Architecture(mol_block=block, message_steps=steps).to(device).eval()
     grads = {}
@@ -3051,6 +3052,34 @@ def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, b
             assert_close(a, c, 3e-6, n)          # (another summation order; ONE application: the same launches, bit for bit)
         else:
             assert torch.equal(a, c), n
+    if steps > 1:     # (identical bits everywhere would mean the parked route was not taken)
+        assert any(not torch.equal(grads[True][0][n], grads[False][0][n]) for n in grads[True][0] if "mol_conv.conv" in n)
+
+
+@pytest.mark.parametrize("alpha,edge_dim,steps", [(2, 4, 3), (2, 4, 2), (3, 4, 4), (1, 4, 3), (4, 8, 3), (4, 8, 2), (2, 7, 3)])
+def test_triplet_parameter_gradients_over_parked_sets_on_the_general_kernels(device, alpha, edge_dim, steps, monkeypatch):
+    """The same for the widths and edge features the warp-specialised kernels do not take (hidden width 15 / 30 / 45: general aggregate
+    kernels; continuous edge features of width 7 / 8): two and three operand sets, k_param_grads<SETS> reading 512 partial rows per
+    set, against one product per application."""
+    torch.manual_seed(10 * alpha + steps)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)       # the Python node: what a captured step runs
+    b = synth_batch(160, seed=5).to(device)
+    if edge_dim != 4:
+        b.edge_attr = torch.randn(b.edge_attr.shape[0], edge_dim, device=device)
+    net = model.Architecture(mol_block="_TripletMessage", hid_dim_alpha=alpha, mol_edge_in_dim=edge_dim, message_steps=steps,
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", graph_do="_None()", end_do="_None()").to(device)
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", flag)
+        net.zero_grad()
+        out = net(b)
+        out.square().sum().backward()
+        grads[flag] = ({n: p.grad.clone() for n, p in net.named_parameters()}, out.detach().clone())
+    assert torch.equal(grads[True][1], grads[False][1])
+    for n in grads[True][0]:
+        assert_close(grads[True][0][n], grads[False][0][n], 3e-6, n)
+    # (the one product sums in another order: identical bits everywhere would mean the parked route was not taken)
+    assert any(not torch.equal(grads[True][0][n], grads[False][0][n]) for n in grads[True][0] if "mol_conv.conv" in n)
 
 
 @pytest.mark.parametrize("block", ["_NNConv", "_TripletMessage"])
