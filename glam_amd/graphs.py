@@ -13,7 +13,9 @@ batch object comes back each epoch with the same tensors at the same addresses â
 * later visits: one ``hipGraphLaunch``.
 
 Every visit performs exactly one optimizer step, so the parameter trajectory is the eager one (same kernels, same
-order; the kernels are deterministic).  ``GraphedTrainStep.run(batches)`` goes one step further for the epoch loop: up to
+order; the kernels are deterministic) â€” to the bit below 512 atoms per batch or with a block applied once; above that a captured
+step sums the weight gradients of all applications of a block in one product (``ops.GRU_WGRAD_BATCH``), the eager first visit one
+per application: equal within fp32 rounding.  ``GraphedTrainStep.run(batches)`` goes one step further for the epoch loop: up to
 ``steps_per_graph`` CONSECUTIVE steps (one per batch, in order) are captured into one graph â€” every ``hipGraphLaunch`` carries a
 bubble of â‰ˆ7 Âµs on this stack (a 99 Âµs step replays in 92 Âµs at eight steps per launch, bench.py), and an ESOL epoch at the reference's
 batch size is 36 launches otherwise.  Requirements: an optimizer created with ``capturable=True`` (Adam/AdamW), a
