@@ -3056,8 +3056,9 @@ def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, b
         assert any(not torch.equal(grads[True][0][n], grads[False][0][n]) for n in grads[True][0] if "mol_conv.conv" in n)
 
 
-@pytest.mark.parametrize("alpha,edge_dim,steps", [(2, 4, 3), (2, 4, 2), (3, 4, 4), (1, 4, 3), (4, 8, 3), (4, 8, 2), (2, 7, 3)])
-def test_triplet_parameter_gradients_over_parked_sets_on_the_general_kernels(device, alpha, edge_dim, steps, monkeypatch):
+@pytest.mark.parametrize("alpha,edge_dim,steps,heads", [(2, 4, 3, 3), (2, 4, 2, 3), (3, 4, 4, 3), (1, 4, 3, 3), (4, 8, 3, 3), (4, 8, 2, 3),
+                                                         (2, 7, 3, 3), (4, 4, 3, 1), (4, 4, 2, 2), (2, 4, 3, 4), (4, 8, 3, 2), (1, 5, 2, 4)])
+def test_triplet_parameter_gradients_over_parked_sets_on_the_general_kernels(device, alpha, edge_dim, steps, heads, monkeypatch):
     """The same for the widths and edge features the warp-specialised kernels do not take (hidden width 15 / 30 / 45: general aggregate
     kernels; continuous edge features of width 7 / 8): two and three operand sets, k_param_grads<SETS> reading 512 partial rows per
     set, against one product per application."""
@@ -3067,7 +3068,10 @@ def test_triplet_parameter_gradients_over_parked_sets_on_the_general_kernels(dev
     if edge_dim != 4:
         b.edge_attr = torch.randn(b.edge_attr.shape[0], edge_dim, device=device)
     net = model.Architecture(mol_block="_TripletMessage", hid_dim_alpha=alpha, mol_edge_in_dim=edge_dim, message_steps=steps,
-                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", graph_do="_None()", end_do="_None()").to(device)
+                             pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", graph_do="_None()", end_do="_None()")
+    if heads != 3:       # (the model's block has three heads, layer.py:239; the kernels take one to four)
+        net.mol_conv.conv.conv = layer.TripletMessage(15 * alpha, edge_dim, heads=heads)
+    net = net.to(device)
     grads = {}
     for flag in (True, False):
         monkeypatch.setattr(ops, "GRU_WGRAD_BATCH", flag)
