@@ -87,6 +87,10 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "k_wgrad<false>": {"bound": "mfma", "flops": 2 * N * (HC + 1) * C + 2 * N * (HC + 8) * C,
                            "bytes": f * N * (HC + C) + f * N * (HC + 8 + C),
                            "note": "both weight-gradient products ([aggr | 1]^T d_out, [d_xw | d_a]^T x) in one launch"},
+        "k_wgrad_x3<false>": {"bound": "hbm", "flops": 2 * N * (HC + 1) * C + 2 * N * (HC + 8) * C,
+                              "bytes": f * N * (HC + C) + f * N * (HC + 8 + C),
+                              "note": "the same two products warp-specialised on the bf16 matrix cores in 3 x bf16 form (csrc/wgrad_x3.hip): "
+                                      "memory-bound by construction, so it is priced against the HBM roofline"},
         "k_param_grads": {"bound": "latency", "bytes": 0},
     }
 

@@ -17,10 +17,13 @@ GLAM_E_INVALID, GLAM_E_UNSUPPORTED, GLAM_E_HIP = -1, -2, -3
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
+ABI_VERSION = 2     # = GLAM_ABI_VERSION of include/glam_hip.h: bumped with every change of an exported signature (kept next to SIGNATURES)
+
 # name -> (restype, argtypes); mirrors include/glam_hip.h one to one
 SIGNATURES = {
     "glam_abi_version": (_i32, []),
     "glam_last_error": (ctypes.c_char_p, []),
+    "glam_route_enabled": (_i32, [ctypes.c_char_p]),
     "glam_prof_begin": (_i32, [_i32]),
     "glam_prof_end": (_i32, []),
     "glam_prof_read": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]),
@@ -161,10 +164,20 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI and the header disagree
         fn.restype, fn.argtypes = res, args
-    if lib.glam_abi_version() != 1:
-        raise GlamHipError("libglam_hip.so ABI version mismatch")
+    if lib.glam_abi_version() != ABI_VERSION:
+        raise GlamHipError(f"{LIB_PATH}: ABI version {lib.glam_abi_version()}, this package binds version {ABI_VERSION} "
+                           "(a stale build: `make -C glam_amd/csrc`)")
     _lib = lib
     return lib
+
+
+def route_enabled(name):
+    """Whether the library's alternative route ``name`` ("x3", "wgrad_x3") is on in this process.  The library reads the environment
+    (``GLAM_X3``, ``GLAM_WGRAD_X3``) once and with its own parsing; every host-side route decision asks it instead of re-parsing."""
+    rc = load().glam_route_enabled(name.encode())
+    if rc < 0:
+        check(rc, f"glam_route_enabled({name})")
+    return rc == 1
 
 
 def check(rc, what):

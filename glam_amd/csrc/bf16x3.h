@@ -27,6 +27,18 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
     const f32x2_t r2 = {r1[0] - __builtin_bit_cast(float, m << 16), r1[1] - __builtin_bit_cast(float, m & 0xffff0000u)};  // exact
     hi = h; mid = m; lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
+// The same split for two values that do NOT sit in adjacent registers (k_wgrad_x3: the same column of two rows), spelled on scalars: with
+// the <2 x float> form the compiler builds v_pk_add_f32 operands out of two v_mov each (8.4 vector instructions per value instead of 5.5,
+// and packed fp32 instructions are the expensive ones beside matrix instructions)
+__device__ __forceinline__ void split2s(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){x0, x1}, bf16x2_t));
+    float a0 = x0 - __builtin_bit_cast(float, h << 16), a1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);            // exact
+    asm volatile("" : "+v"(a0), "+v"(a1));      // (keeps the two subtractions scalar: no SLP packing)
+    const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a0, a1}, bf16x2_t));
+    float b0 = a0 - __builtin_bit_cast(float, m << 16), b1 = a1 - __builtin_bit_cast(float, m & 0xffff0000u);            // exact
+    asm volatile("" : "+v"(b0), "+v"(b1));
+    hi = h; mid = m; lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){b0, b1}, bf16x2_t));
+}
 // eight consecutive k (two float4) -> one operand of v_mfma_f32_16x16x32_bf16 per term
 __device__ __forceinline__ Bf16x3 split8(float4 a, float4 b) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));

@@ -37,7 +37,11 @@ struct WgArgs {
     // (P1, P2, Q), set s > 0 is (segP1[s - 1], segP2[s - 1], segQ[s - 1]) with the same widths and row strides
     int nseg; int seg_rows;
     const float* segP1[2]; const float* segP2[2]; const float* segQ[2];
+    int rows_per_split;                    // k_wgrad_x3 (wgrad_x3.hip): rows of a block, a multiple of 32 (plan_wgrad_x3)
 };
+
+// Two independent products may share one launch (blocks [0, first_b) work on job a, the rest on job b).
+struct WgArgs2 { WgArgs a, b; int first_b; };
 
 // see k_final_reduce in gemm.hip
 struct ReduceJob {
@@ -90,6 +94,7 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
 int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
                            int sj_b, ReduceJob* job_b, hipStream_t s);
 int launch_final_reduce(ReduceArgs ra, hipStream_t s);
+int launch_wgrad_x3(const WgArgs2& two, int blocks, hipStream_t s);     // wgrad_x3.hip: the same products, warp-specialised on the bf16 matrix cores
 
 bool triplet_fwd_can_fuse_update(int H, int Cp, int De);
 int triplet_fwd_fused_update(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge,

@@ -22,6 +22,7 @@
 #include "bf16x3.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace glam {
 
@@ -363,9 +364,6 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
 #endif
 constexpr int kWgBlock = 512;
 constexpr int kWgWaves = kWgBlock / 64;
-
-// Two independent products may share one launch (blocks [0, first_b) work on job a, the rest on job b).
-struct WgArgs2 { WgArgs a, b; int first_b; };
 
 // lanes whose 4 columns are the virtual ones column / zero padding read their operand from here with a row stride of 0 (no selects in
 // the loop, no registers for the constants)
@@ -726,8 +724,48 @@ static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJ
     return GLAM_OK;
 }
 
+// k_wgrad_x3 (wgrad_x3.hip): one 16-wave block per CU whatever the size; a block = (slab, row split) with rows_per_split a multiple of
+// the 32-row step; the splits of a multi-set product are dealt set by set (nsplit = splits per set x nseg)
+static bool wgrad_x3_enabled() {      // (GLAM_WGRAD_X3: A/B switch; GLAM_X3=0 puts every product back on the fp32 matrix instructions)
+    static const bool v = [] { const char* e = getenv("GLAM_WGRAD_X3"); return !e || atoi(e) != 0; }();
+    return v && ts_x3_enabled();
+}
+static int plan_wgrad_x3(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {
+    const int I = a.I1 + a.I2 + (a.ones ? 1 : 0);
+    const int Jt = a.J + (a.qones ? 1 : 0);
+    if (I > 320 || Jt > 64 || I <= 0 || a.J <= 0 || (a.J & 3) || (a.ldq & 3) || (a.I1 & 3) || (a.I2 & 3) || (a.ldp1 & 3) ||
+        (a.I2 && (a.ldp2 & 3)))
+        return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d+%d J=%d outside the kernel table (I <= 320, J <= 64, multiples of 4)",
+                    a.I1, a.I2, a.J);
+    const int nslab = (I + 63) / 64;
+    const int nseg = a.nseg > 1 ? a.nseg : 1;
+    const int64_t rows = nseg > 1 ? a.seg_rows : a.N;          // rows of one operand set
+    int nsplit = budget / nslab / 8 * 8;         // multiple of 8: one XCD per row split
+    if (nsplit < 8) nsplit = 8;
+    int per = nsplit / nseg;
+    const int max_per = (int)((rows + 63) / 64);               // at least two steps per block when the problem is small
+    if (per > max_per) per = max_per;
+    if (per < 1) per = 1;
+    int rps = (int)((rows + per - 1) / per);
+    rps = (rps + 31) & ~31;
+    if (rps < 32) rps = 32;
+    per = (int)((rows + rps - 1) / rps);                       // no empty split
+    if (per < 1) per = 1;
+    a.rows_per_split = rps;
+    a.rows_per_wave = rps;
+    a.nsplit = per * nseg;
+    a.ntile = nslab;
+    *blocks = (a.nsplit + 7) / 8 * 8 * nslab;
+    *job = ReduceJob{0, a.partial, a.nsplit, nslab * 4096, I, Jt, si, sj, out, nullptr, 0, 0};
+    return GLAM_OK;
+}
+
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
     int blocks = 0;
+    if (wgrad_x3_enabled()) {
+        if (int rc = plan_wgrad_x3(a, out, si, sj, kWgradBlocks, job, &blocks)) return rc;
+        return launch_wgrad_x3(WgArgs2{a, a, blocks}, blocks, s);
+    }
     if (int rc = plan_wgrad(a, out, si, sj, wgrad_budget(a.N), job, &blocks)) return rc;
     if (a.nseg > 1 && a.rows_per_wave > a.seg_rows)
         return fail(GLAM_E_UNSUPPORTED, "wgrad: %d operand sets of %d rows are too short for a wave's %d rows (run them one by one)", a.nseg,
@@ -745,9 +783,15 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
 int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
                            int sj_b, ReduceJob* job_b, hipStream_t s) {
     const int ta = (a.I1 + a.I2 + (a.ones ? 1 : 0) + 63) / 64, tb = (b.I1 + b.I2 + (b.ones ? 1 : 0) + 63) / 64;
-    const int total = a.N >= wgrad_big_rows() ? 2 * GLAM_WG_PAIR_BLOCKS : GLAM_WG_PAIR_BLOCKS;
+    const bool x3 = wgrad_x3_enabled();
+    const int total = (!x3 && a.N >= wgrad_big_rows()) ? 2 * GLAM_WG_PAIR_BLOCKS : GLAM_WG_PAIR_BLOCKS;
     const int ba = ta + tb > 0 ? total * ta / (ta + tb) : total / 2;
     int na = 0, nb = 0;
+    if (x3) {
+        if (int rc = plan_wgrad_x3(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;
+        if (int rc = plan_wgrad_x3(b, out_b, si_b, sj_b, total - ba, job_b, &nb)) return rc;
+        return launch_wgrad_x3(WgArgs2{a, b, na}, na + nb, s);
+    }
     if (int rc = plan_wgrad(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;
     if (int rc = plan_wgrad(b, out_b, si_b, sj_b, total - ba, job_b, &nb)) return rc;
     if ((a.nseg > 1 && a.rows_per_wave > a.seg_rows) || (b.nseg > 1 && b.rows_per_wave > b.seg_rows))
@@ -793,6 +837,13 @@ extern "C" int glam_debug_ts_prof(long long* host_out, int n) {
 #endif
 
 using namespace glam;
+
+extern "C" int glam_route_enabled(const char* route) {
+    GLAM_REQUIRE(route, "glam_route_enabled: null name");
+    if (!strcmp(route, "x3")) return ts_x3_enabled() ? 1 : 0;
+    if (!strcmp(route, "wgrad_x3")) return wgrad_x3_enabled() ? 1 : 0;
+    return fail(GLAM_E_INVALID, "glam_route_enabled: unknown route '%s'", route);
+}
 
 extern "C" size_t glam_ts_gemm_image_bytes(int K, int M) { return ts_image_floats(K, M) * sizeof(float); }
 

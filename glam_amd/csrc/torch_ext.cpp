@@ -284,6 +284,9 @@ Tensor sort_pool_topk_last(const Tensor& x, const Tensor& ptr, int64_t k) { retu
 }  // namespace
 
 TORCH_LIBRARY(glam, m) {
+    // this shim was compiled against one set of C signatures: a libglam_hip.so of another ABI version would be called with shifted arguments
+    TORCH_CHECK(glam_abi_version() == GLAM_ABI_VERSION, "_glam_torch.so was built for ABI version ", GLAM_ABI_VERSION,
+                " of libglam_hip.so, the loaded library reports ", glam_abi_version(), " (rebuild: make -C glam_amd/csrc)");
     m.def("csr_from_edge_index(Tensor edge_index, int N, int by=0) -> (Tensor, Tensor, Tensor, Tensor)", &csr_from_edge_index);
     m.def("batch_ptr(Tensor batch, int num_graphs) -> (Tensor, Tensor)", &batch_ptr);
     m.def("triplet_aggregate(Tensor xw, Tensor a_ij, Tensor edge_attr, Tensor? w_edge, Tensor M, Tensor rowptr, Tensor src, Tensor eid, "

@@ -702,7 +702,7 @@ class _TripletLayer(torch.autograd.Function):
             # backward (d_x) and parks its operands — its workspace holds d_xw, d_a and the block partials of d_W_edge / d_M —; the first
             # application (its backward runs last) runs both weight-gradient products over the parked sets and k_param_grads ONCE
             # (glam_triplet_layer_param_grads_sets).  3 x (k_wgrad + k_param_grads) -> 1 + 1 per training step at message_steps = 3.
-            in_kernel = d_alias is not None and ell_t is not None and os.environ.get("GLAM_X3", "1") != "0"   # (warp-specialised route only)
+            in_kernel = d_alias is not None and ell_t is not None and _lib.route_enabled("x3")   # (warp-specialised route only)
             addend = f32c(d_alias, "d_identity") if in_kernel else None
             info = (ctypes.c_int64 * 4)()
             check(lib.glam_triplet_layer_bwd_data_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(d_out),
@@ -740,7 +740,7 @@ class _TripletLayer(torch.autograd.Function):
             c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
             c_wn, c_we, c_att, c_wsc, c_bias = c_parts
             # the skip connection's gradient joins d_x in the epilogue of the d_x product (warp-specialised route)
-            in_kernel = d_alias is not None and ell_t is not None and os.environ.get("GLAM_X3", "1") != "0"     # (a 3 x bf16 consumer option)
+            in_kernel = d_alias is not None and ell_t is not None and _lib.route_enabled("x3")     # (a 3 x bf16 consumer option)
             addend = f32c(d_alias, "d_identity") if in_kernel else None
             check(lib.glam_triplet_layer_bwd_params_ell_add(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                             ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),

@@ -165,7 +165,7 @@ class _MatmulTall(torch.autograd.Function):
             ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
         N, K = a.shape
         M = w.size(1)
-        if K % 4 == 0 and M % 4 == 0 and K <= 320 and M <= 64 and N > 0 and os.environ.get("GLAM_X3", "1") != "0":
+        if K % 4 == 0 and M % 4 == 0 and K <= 320 and M <= 64 and N > 0 and _lib.route_enabled("x3"):
             # NNConv's [N, 300] x [300, 60] relation product (and any K <= 320 x M <= 64): the long-reduction 3 x bf16 kernel (tall_x3.hip)
             # (an 80 KB-image fp32 k_ts_gemm<4, 20, 4> measured 18.9 us against the library's 15 at N = 20 k and was not kept)
             lib = _lib.load()
@@ -740,7 +740,7 @@ def _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp):
 
 def _want_gru_ws(lib, N, C):
     """The warp-specialised 3 x bf16 GRU step (GLAM_GRU_WS, default on; GLAM_X3=0 keeps every dense product on the fp32 matrix cores)."""
-    return N > 0 and _o.GRU_WS == "1" and os.environ.get("GLAM_X3", "1") != "0" and lib.glam_gru_ws_supported(C) == 1
+    return N > 0 and _o.GRU_WS == "1" and _lib.route_enabled("x3") and lib.glam_gru_ws_supported(C) == 1
 
 
 def gru_images_plain(N, C):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLAM_ABI_VERSION 1
+#define GLAM_ABI_VERSION 2   /* bumped whenever an exported signature changes or an entry point goes away */
 
 #define GLAM_OK 0
 #define GLAM_E_INVALID (-1)     /* bad argument (null pointer, negative size, misaligned) */
@@ -37,6 +37,13 @@ extern "C" {
 
 int glam_abi_version(void);
 const char* glam_last_error(void);
+
+/* Which of the library's alternative routes are switched on in THIS process (the environment is read once, by the library):
+ * "x3" = every dense product of the layer / GRU kernels in 3 x bf16 form on the bf16 matrix cores (GLAM_X3, default 1),
+ * "wgrad_x3" = the weight-gradient products on the warp-specialised 3 x bf16 kernel (GLAM_WGRAD_X3, default 1; needs "x3").
+ * The host side asks here instead of parsing the variables itself, so that both sides always agree on a route.
+ * Replaces: nothing in the reference (it has one route).  Returns 1 / 0, GLAM_E_INVALID for an unknown name. */
+int glam_route_enabled(const char* route);
 
 /* Per-launch kernel timing (measurement aid of bench.py; the reference has no profiling hooks at all —
  * only wall-clock suffixes in its log lines, src_1gp/trainer.py:140-147).

@@ -3021,8 +3021,14 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
             assert torch.equal(a, b)
     short = [(torch.randn(2, M, device=device), torch.randn(2, C, device=device)) * 2 for _ in range(3)]
     arr2 = lambda i: (ctypes.c_void_p * 3)(*[t[i].data_ptr() for t in short])
-    assert lib.glam_wgrad_gemm_pair_split_seg(3, arr2(0), M, M, arr2(1), C, C, 0, p(out[0]), p(out[1]), arr2(2), M, M, arr2(3), C, C, 0, p(out[2]),
-                                              p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream()) == ops._lib.GLAM_E_UNSUPPORTED
+    rc = lib.glam_wgrad_gemm_pair_split_seg(3, arr2(0), M, M, arr2(1), C, C, 0, p(out[0]), p(out[1]), arr2(2), M, M, arr2(3), C, C, 0, p(out[2]),
+                                            p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream())
+    if ops._lib.route_enabled("wgrad_x3"):      # k_wgrad_x3 deals its blocks set by set: any set length runs
+        assert rc == 0, lib.glam_last_error()
+        assert_close(out[0], sum(t[0].double().t() @ t[1].double() for t in short), 3e-6, "dw_ih of three two-row sets")
+        assert_close(out[3], sum(t[2].double().sum(0) for t in short), 3e-6, "db_hh of three two-row sets")
+    else:                                       # k_wgrad: a wave's row range must fit one set
+        assert rc == ops._lib.GLAM_E_UNSUPPORTED
     assert lib.glam_wgrad_gemm_pair_split_seg(4, arr2(0), M, M, arr2(1), C, C, 0, p(out[0]), p(out[1]), arr2(2), M, M, arr2(3), C, C, 0, p(out[2]),
                                               p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream()) == ops._lib.GLAM_E_INVALID
 
