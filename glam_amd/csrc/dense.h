@@ -90,9 +90,12 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s);
 int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s);    // tall_x3.hip: warp-specialised 3 x bf16 products
 int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s);   // b: a second product of the same variant in the same launch
 size_t wgrad_workspace_floats();
-int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job);
+// many_splits: the reduction behind the launch takes any split count in its stride (k_final_reduce) — k_wgrad_x3 leaves one partial
+// per CU and product, 128 or 256 per element, against k_wgrad's 40; k_param_grads (layer.hip) reads them in batches of 40 from
+// about a hundred blocks and loses more than the product launch gains (B = 1 024: 4.4 -> 12.7 us), so the layer keeps k_wgrad
+int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job, bool many_splits = true);
 int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
-                           int sj_b, ReduceJob* job_b, hipStream_t s);
+                           int sj_b, ReduceJob* job_b, hipStream_t s, bool many_splits = true);
 int launch_final_reduce(ReduceArgs ra, hipStream_t s);
 int launch_wgrad_x3(const WgArgs2& two, int blocks, hipStream_t s);     // wgrad_x3.hip: the same products, warp-specialised on the bf16 matrix cores
 

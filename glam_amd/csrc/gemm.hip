@@ -697,7 +697,7 @@ static int wgrad_big_rows() {      // (GLAM_WG_BIG_ROWS: A/B switch)
 }
 static int wgrad_budget(int N) { return N >= wgrad_big_rows() ? kWgradBlocksBig : kWgradBlocks; }
 
-size_t wgrad_workspace_floats() { return (size_t)(kWgradBlocksBig + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per block
+size_t wgrad_workspace_floats() { return (size_t)(3 * 256 + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per (slab, split); k_wgrad_x3: <= 768
 
 // fills the launch geometry of one product (at most `budget` blocks) and the matching reduce job
 static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJob* job, int* blocks) {
@@ -724,8 +724,10 @@ static int plan_wgrad(WgArgs& a, float* out, int si, int sj, int budget, ReduceJ
     return GLAM_OK;
 }
 
-// k_wgrad_x3 (wgrad_x3.hip): one 16-wave block per CU whatever the size; a block = (slab, row split) with rows_per_split a multiple of
-// the 32-row step; the splits of a multi-set product are dealt set by set (nsplit = splits per set x nseg)
+// k_wgrad_x3 (wgrad_x3.hip): one 8-wave block per CU whatever the size; a block = (group of up to three slabs, row split) with
+// rows_per_split a multiple of the 32-row step; the splits of a multi-set product are dealt set by set (nsplit = splits per set x nseg).
+// Every split leaves one partial slab per slab of the product, so the split count is also bounded by the workspace (kWxMaxSlabs).
+constexpr int kWxSlabsPerBlock = 3, kWxMaxSlabs = 3 * 256;
 static bool wgrad_x3_enabled() {      // (GLAM_WGRAD_X3: A/B switch; GLAM_X3=0 puts every product back on the fp32 matrix instructions)
     static const bool v = [] { const char* e = getenv("GLAM_WGRAD_X3"); return !e || atoi(e) != 0; }();
     return v && ts_x3_enabled();
@@ -737,10 +739,12 @@ static int plan_wgrad_x3(WgArgs& a, float* out, int si, int sj, int budget, Redu
         (a.I2 && (a.ldp2 & 3)))
         return fail(GLAM_E_UNSUPPORTED, "wgrad: I=%d+%d J=%d outside the kernel table (I <= 320, J <= 64, multiples of 4)",
                     a.I1, a.I2, a.J);
-    const int nslab = (I + 63) / 64;
+    const int nslab = (I + 63) / 64, ngrp = (nslab + kWxSlabsPerBlock - 1) / kWxSlabsPerBlock;
     const int nseg = a.nseg > 1 ? a.nseg : 1;
     const int64_t rows = nseg > 1 ? a.seg_rows : a.N;          // rows of one operand set
-    int nsplit = budget / nslab / 8 * 8;         // multiple of 8: one XCD per row split
+    int nsplit = budget / ngrp;
+    if (nsplit > kWxMaxSlabs / nslab) nsplit = kWxMaxSlabs / nslab;
+    nsplit = nsplit / 8 * 8;                     // multiple of 8: one XCD per row split
     if (nsplit < 8) nsplit = 8;
     int per = nsplit / nseg;
     const int max_per = (int)((rows + 63) / 64);               // at least two steps per block when the problem is small
@@ -755,14 +759,22 @@ static int plan_wgrad_x3(WgArgs& a, float* out, int si, int sj, int budget, Redu
     a.rows_per_wave = rps;
     a.nsplit = per * nseg;
     a.ntile = nslab;
-    *blocks = (a.nsplit + 7) / 8 * 8 * nslab;
+    *blocks = (a.nsplit + 7) / 8 * 8 * ngrp;
     *job = ReduceJob{0, a.partial, a.nsplit, nslab * 4096, I, Jt, si, sj, out, nullptr, 0, 0};
     return GLAM_OK;
 }
 
-int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job) {
+// rows from which k_wgrad_x3 takes a launch (GLAM_WGRAD_X3_ROWS: A/B switch): below, its fixed cost — 8-wave blocks behind a barrier,
+// the first 48 KB stage — and the larger reduction cancel what the bf16 matrix instructions save (N = 20 400: 13.55 vs 13.57 us)
+static int wgrad_x3_rows() {       // (read at every launch: the tests switch it)
+    const char* e = getenv("GLAM_WGRAD_X3_ROWS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 32768;
+}
+
+int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job, bool many_splits) {
     int blocks = 0;
-    if (wgrad_x3_enabled()) {
+    if (many_splits && a.N >= wgrad_x3_rows() && wgrad_x3_enabled()) {
         if (int rc = plan_wgrad_x3(a, out, si, sj, kWgradBlocks, job, &blocks)) return rc;
         return launch_wgrad_x3(WgArgs2{a, a, blocks}, blocks, s);
     }
@@ -781,15 +793,17 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
 
 // two products in one launch; the block budget is shared in proportion to their slab counts
 int launch_wgrad_partials2(WgArgs a, float* out_a, int si_a, int sj_a, ReduceJob* job_a, WgArgs b, float* out_b, int si_b,
-                           int sj_b, ReduceJob* job_b, hipStream_t s) {
+                           int sj_b, ReduceJob* job_b, hipStream_t s, bool many_splits) {
     const int ta = (a.I1 + a.I2 + (a.ones ? 1 : 0) + 63) / 64, tb = (b.I1 + b.I2 + (b.ones ? 1 : 0) + 63) / 64;
-    const bool x3 = wgrad_x3_enabled();
+    const bool x3 = many_splits && a.N >= wgrad_x3_rows() && b.N >= wgrad_x3_rows() && wgrad_x3_enabled();
     const int total = (!x3 && a.N >= wgrad_big_rows()) ? 2 * GLAM_WG_PAIR_BLOCKS : GLAM_WG_PAIR_BLOCKS;
     const int ba = ta + tb > 0 ? total * ta / (ta + tb) : total / 2;
     int na = 0, nb = 0;
     if (x3) {
-        if (int rc = plan_wgrad_x3(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;
-        if (int rc = plan_wgrad_x3(b, out_b, si_b, sj_b, total - ba, job_b, &nb)) return rc;
+        const int ga = (ta + kWxSlabsPerBlock - 1) / kWxSlabsPerBlock, gb = (tb + kWxSlabsPerBlock - 1) / kWxSlabsPerBlock;
+        const int xa = total * ga / (ga + gb);                  // the budget follows the slab groups (the blocks per row split)
+        if (int rc = plan_wgrad_x3(a, out_a, si_a, sj_a, xa, job_a, &na)) return rc;
+        if (int rc = plan_wgrad_x3(b, out_b, si_b, sj_b, total - xa, job_b, &nb)) return rc;
         return launch_wgrad_x3(WgArgs2{a, b, na}, na + nb, s);
     }
     if (int rc = plan_wgrad(a, out_a, si_a, sj_a, ba, job_a, &na)) return rc;

@@ -851,7 +851,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
-    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s))
+    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s, false))
         return rc;      // both products in ONE launch
     // d_x = [d_xw | d_a] @ Wcat^T
     if (!fuse_dx) {
@@ -1063,7 +1063,7 @@ extern "C" int glam_triplet_layer_param_grads_sets(int nseg, const void* const* 
     }
     hipStream_t s = (hipStream_t)stream;
     ReduceJob j1{}, j2{};
-    if (int rc = launch_wgrad_partials2(w1, nullptr, Cp, 1, &j1, w2, nullptr, 1, HC + 8, &j2, s)) return rc;
+    if (int rc = launch_wgrad_partials2(w1, nullptr, Cp, 1, &j1, w2, nullptr, 1, HC + 8, &j2, s, false)) return rc;
     ParamGradArgs pg{j1.partial, j1.nsplit, j2.partial, j2.nsplit, tp[0], tnblk * nseg, WSZ + Dp * 4, weight_node, weight_edge, att, C, H, De, Cp,
                      Dp, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H,
                      add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};

@@ -515,13 +515,22 @@ def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
         assert_close(o2, ref[:, M1:], 2e-6, "ts_gemm out2")
 
 
+@pytest.fixture(params=["default", "x3"])
+def wgrad_route(request, monkeypatch):
+    """The weight-gradient products on both kernels: "default" = k_wgrad below 32 768 rows and k_wgrad_x3 (csrc/wgrad_x3.hip) from there,
+    "x3" = k_wgrad_x3 at every size (GLAM_WGRAD_X3_ROWS is read at each launch)."""
+    if request.param == "x3":
+        monkeypatch.setenv("GLAM_WGRAD_X3_ROWS", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("N,I1,I2,ones,J", [(1000, 180, 0, 1, 60), (20400, 180, 8, 0, 60), (7, 48, 8, 0, 16), (1, 16, 0, 1, 16), (5000, 56, 8, 1, 64), (3000, 184, 4, 1, 64),
                                             # 64 < J <= 128: two column chunks in one launch (wide layers)
                                             (20400, 276, 8, 0, 92), (5000, 276, 0, 1, 92), (33, 300, 16, 1, 128),
                                             # N >= 131072: the row-range form (k_wgrad_rows), 1..5 slabs, ragged last block
                                             (131072, 180, 8, 0, 64), (140001, 180, 0, 1, 60), (131075, 48, 8, 0, 16), (131100, 120, 0, 1, 32),
                                             (131073, 300, 16, 1, 64), (150000, 276, 8, 0, 92)])
-def test_wgrad_gemm(device, N, I1, I2, ones, J):
+def test_wgrad_gemm(device, N, I1, I2, ones, J, wgrad_route):
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
     g = torch.Generator().manual_seed(N + I1)
@@ -541,7 +550,7 @@ def test_wgrad_gemm(device, N, I1, I2, ones, J):
 
 
 @pytest.mark.parametrize("N,I,ones,J", [(5000, 60, 1, 60), (3000, 300, 1, 60), (2000, 276, 0, 92), (777, 120, 1, 128), (131080, 60, 1, 64)])
-def test_wgrad_gemm_add_sums_the_addend_in_the_reduction(device, N, I, ones, J):
+def test_wgrad_gemm_add_sums_the_addend_in_the_reduction(device, N, I, ones, J, wgrad_route):
     """``glam_wgrad_gemm_add``: product + addend laid out like the output, in both stride orders, also through the two-chunk path
     (64 < J <= 128) and the large-N grid — exactly ``glam_wgrad_gemm``'s result plus the addend (one fp32 add per element)."""
     from glam_amd import _lib
@@ -1297,7 +1306,7 @@ def test_graph_norms_mixed_graph_sizes(device, kind, D):
     assert_twin_parity(run, out, _grads(out, cot.to(device), [x]), kind, ["x"])
 
 
-def test_wgrad_gemm_chunked_with_ones_column(device):
+def test_wgrad_gemm_chunked_with_ones_column(device, wgrad_route):
     """[d_W | d_b] = dy^T [x | 1] with 64 < K + 1 <= 128: the ones column rides on the second column chunk."""
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
@@ -2964,7 +2973,7 @@ def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
     assert torch.equal(img, ref)
 
 
-def test_wgrad_split_writes_a_narrow_weight_gradient_contiguously(device):
+def test_wgrad_split_writes_a_narrow_weight_gradient_contiguously(device, wgrad_route):
     """glam_wgrad_gemm_split with J = 15 over rows of 16 floats (the input linear 15 -> 60 on zero-padded atom features): dw comes out
     as a contiguous [I, 15] tensor (no strided view for autograd to copy), db beside it; nothing is written beyond them."""
     lib, p = ops._lib.load(), ops._lib.ptr
@@ -2990,7 +2999,7 @@ def test_wgrad_split_writes_a_narrow_weight_gradient_contiguously(device):
 
 
 @pytest.mark.parametrize("nseg,N", [(1, 5000), (2, 2500), (3, 20400), (3, 777)])
-def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
+def test_wgrad_pair_split_seg_c_abi(device, nseg, N, wgrad_route):
     """glam_wgrad_gemm_pair_split_seg: both weight-gradient products of a GRU summed over the operand sets of up to three applications
     in one launch + one reduction (waves whose row range straddles a set boundary included), with a carry addend, against fp64; one
     set is the plain entry point bit for bit; sets too short for a wave's row range are refused."""
@@ -3023,7 +3032,7 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
     arr2 = lambda i: (ctypes.c_void_p * 3)(*[t[i].data_ptr() for t in short])
     rc = lib.glam_wgrad_gemm_pair_split_seg(3, arr2(0), M, M, arr2(1), C, C, 0, p(out[0]), p(out[1]), arr2(2), M, M, arr2(3), C, C, 0, p(out[2]),
                                             p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream())
-    if ops._lib.route_enabled("wgrad_x3"):      # k_wgrad_x3 deals its blocks set by set: any set length runs
+    if wgrad_route == "x3" and ops._lib.route_enabled("wgrad_x3"):      # k_wgrad_x3 deals its blocks set by set: any set length runs
         assert rc == 0, lib.glam_last_error()
         assert_close(out[0], sum(t[0].double().t() @ t[1].double() for t in short), 3e-6, "dw_ih of three two-row sets")
         assert_close(out[3], sum(t[2].double().sum(0) for t in short), 3e-6, "db_hh of three two-row sets")
@@ -3035,7 +3044,7 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N):
 
 @pytest.mark.parametrize("block", ["_TripletMessage", "_NNConv"])
 @pytest.mark.parametrize("steps", [1, 2, 3, 4])
-def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch):
+def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch, wgrad_route):
     """MessageBlock applied message_steps times: the GRU's weight gradients, the TripletMessage's parameter gradients
     (glam_triplet_layer_bwd_data_ell + glam_triplet_layer_param_grads_sets) and NNConv's relation product's (glam_wgrad_gemm_sets) as
     ONE product each over the parked operand sets of all applications (four applications: a group of three, then

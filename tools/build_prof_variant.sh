@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an instrumented copy of libglam_hip.so for the in-kernel cycle profilers of tools/*_prof.py.
-# usage: tools/build_prof_variant.sh {b1|b1n|ts|dma|gru|fwd|pg|ws|wx}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
+# usage: tools/build_prof_variant.sh {b1|b1n|ts|dma|gru|fwd|pg|ws}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
 set -e
 cd "$(dirname "$0")/../glam_amd/csrc"
 make -j8 > /dev/null
@@ -13,8 +13,7 @@ case "$1" in
   fwd)  src=triplet_h3.hip;  def=GLAM_FWD_PROF ;;
   pg)   src=layer.hip;       def=GLAM_PG_PROF ;;
   ws)   src=triplet_ws.hip;  def=GLAM_WS_PROF ;;
-  wx)   src=wgrad_x3.hip;    def=GLAM_WX_PROF ;;
-  *) echo "usage: $0 {b1|b1n|ts|dma|gru|fwd|pg|ws|wx}"; exit 2 ;;
+  *) echo "usage: $0 {b1|b1n|ts|dma|gru|fwd|pg|ws}"; exit 2 ;;
 esac
 mkdir -p ../variants
 obj=/tmp/glam_${1}_prof.o
