@@ -28,6 +28,7 @@ SIGNATURES = {
     "glam_prof_end": (_i32, []),
     "glam_prof_read": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]),
     "glam_pad_group": (_i32, [_i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int32), _i32, _vp]),
+    "glam_batch_fingerprint": (_i32, [_i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _vp]),
     "glam_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "glam_csr_build": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_batch_ptr": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),

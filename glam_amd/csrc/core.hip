@@ -151,3 +151,58 @@ extern "C" int glam_pad_group(int n, const float* const* src, float* const* dst,
     GLAM_LAUNCH_CHECK("glam_pad_group");
     return GLAM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Content fingerprint of a batch's index tensors (glam_batch_fingerprint in include/glam_hip.h): a 64-bit hash of up to four device
+// buffers, position-sensitive (every 32-bit word is mixed with its index and its buffer's number before the commutative combine), one
+// launch.  The graphed-callable route of glam_amd.graphs recognises a batch it has staged and captured before by it — the reference's
+// trainer hands the model a freshly collated device copy every iteration (src_1gp/trainer.py:294), so object identity says nothing.
+// ------------------------------------------------------------------------------------------------
+namespace glam {
+struct FingerprintArgs { const uint32_t* p[4]; unsigned long long words[4]; int n; unsigned long long* out; };
+__device__ __forceinline__ unsigned long long fp_mix(unsigned long long z) {        // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(kBlock) k_fingerprint(FingerprintArgs a) {
+    __shared__ unsigned long long s_part[kBlock / 64];
+    unsigned long long h = 0;
+    for (int t = 0; t < a.n; ++t) {
+        const unsigned long long salt = 0x9E3779B97F4A7C15ull * (unsigned long long)(t + 1);
+        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < a.words[t]; i += (unsigned long long)gridDim.x * kBlock)
+            h += fp_mix(((unsigned long long)a.p[t][i] << 32 | (i & 0xffffffffull)) ^ salt ^ (i >> 32));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += s_part[w];
+        atomicAdd(a.out, s);             // integer addition: commutative, the result does not depend on the block order
+    }
+}
+}  // namespace glam
+
+extern "C" int glam_batch_fingerprint(int n, const void* const* bufs, const int64_t* nbytes, uint64_t* out_dev, void* stream) {
+    using namespace glam;
+    GLAM_REQUIRE(n >= 1 && n <= 4 && bufs && nbytes && out_dev, "glam_batch_fingerprint: n=%d not in 1..4 / null pointer", n);
+    FingerprintArgs a{};
+    unsigned long long total = 0;
+    for (int t = 0; t < n; ++t) {
+        GLAM_REQUIRE(nbytes[t] >= 0 && (nbytes[t] & 3) == 0 && (nbytes[t] == 0 || bufs[t]) && (reinterpret_cast<uintptr_t>(bufs[t]) & 3u) == 0,
+                     "glam_batch_fingerprint: buffer %d must be 4-byte aligned with a size that is a multiple of 4", t);
+        a.p[t] = static_cast<const uint32_t*>(bufs[t]);
+        a.words[t] = (unsigned long long)nbytes[t] / 4;
+        total += a.words[t];
+    }
+    a.n = n;
+    a.out = reinterpret_cast<unsigned long long*>(out_dev);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out_dev, 0, sizeof(uint64_t), s) != hipSuccess) return fail(GLAM_E_HIP, "glam_batch_fingerprint: memset failed");
+    if (total == 0) return GLAM_OK;
+    hipLaunchKernelGGL(k_fingerprint, dim3(grid_for((int64_t)total, 4 * kBlock, 256)), dim3(kBlock), 0, s, a);
+    GLAM_LAUNCH_CHECK("glam_batch_fingerprint");
+    return GLAM_OK;
+}

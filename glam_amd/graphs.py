@@ -23,6 +23,9 @@ loss function of ``(output, batch)`` that stays on the device, and no data-depen
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
+import os
 import weakref
 
 import torch
@@ -78,7 +81,8 @@ class GraphedTrainStep:
 
     def _step(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
-        loss = self.loss_fn(self.model(batch), batch)
+        with no_graphed_call():           # the whole step is this class's graph: the model's own graphed-callable route stays out of it
+            loss = self.loss_fn(self.model(batch), batch)
         # the root gradient as a tensor kept across steps: `loss.backward()` alone launches a fill for ones_like(loss) in every step
         one = self._one.get(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda) else None
         if one is None and loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda and not torch.cuda.is_current_stream_capturing():
@@ -173,14 +177,242 @@ class GraphedForward:
                 return self.model(*batches)
             refs = [weakref.ref(b, lambda _r, k=key, d=self._state: d.pop(k, None)) for b in batches]
             self._state[key] = [refs, None, None]
-            return self.model(*batches)
+            with no_graphed_call():
+                return self.model(*batches)
         if st[1] is None:
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, pool=self._pool):
+            with torch.cuda.graph(graph, pool=self._pool), no_graphed_call():
                 st[2] = self.model(*batches)
             if self._pool is None:
                 self._pool = graph.pool()
             st[1] = graph
         st[1].replay()
         return st[2].clone()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The graphed-callable route: ``model(batch)`` itself replays hipGraphs, so the reference's training loop runs UNCHANGED
+# (src_1gp/trainer.py:286-304: ``optimizer.zero_grad(); output = self.model(mol_batch); loss.backward(); optimizer.step()``, any
+# optimizer, a fresh device copy of the batch every iteration).
+# ---------------------------------------------------------------------------------------------------------------------------------
+GRAPHED_CALL = os.environ.get("GLAM_GRAPHED_CALL", "1") != "0"      # process-wide switch; per model: ``model.graphed_call = False``
+_suspended = 0
+
+
+@contextlib.contextmanager
+def no_graphed_call():
+    """Inside: every model takes its eager forward (used by the whole-step graphs above and by the route's own captures)."""
+    global _suspended
+    _suspended += 1
+    try:
+        yield
+    finally:
+        _suspended -= 1
+
+
+# module-level A/B switches of glam_amd.ops and the library's environment switches: a captured graph bakes the route in, so they are part
+# of a graph's key (flipping one between two calls of a model — the parity tests do — must not replay the other route)
+_OPS_KNOBS = ("VALIDATE", "WS_ROUTE", "GRAD_CARRY", "CACHED_STAGING", "USE_TORCH_EXT", "GEMM_PAIR", "GRU_FUSED", "GRU_FUSED_MIN_NODES", "GRU_WS",
+              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR")
+_ENV_KNOBS = ("GLAM_X3", "GLAM_WS", "GLAM_WGRAD_X3", "GLAM_WGRAD_X3_ROWS", "GLAM_TALL_X3", "GLAM_DENSE_KC", "GLAM_TS_RB", "GLAM_FWD_WS")
+
+
+def _route_signature():
+    from . import ops
+    return tuple(getattr(ops, k, None) for k in _OPS_KNOBS) + tuple(os.environ.get(k) for k in _ENV_KNOBS)
+
+
+class _Replay(torch.autograd.Function):
+    """One autograd node for the whole model: forward = replay of the captured forward graph, backward = replay of the captured
+    backward graph (the ``torch.cuda.make_graphed_callables`` shape).  The parameters are inputs of the node so that their gradients
+    reach ``p.grad`` through autograd like any others (hooks, accumulation, any optimizer)."""
+
+    @staticmethod
+    def forward(ctx, st, *params):
+        ctx.st = st
+        st.fwd.replay()
+        return st.out.detach().clone()               # (static outputs stay private: a caller may keep the result across steps)
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        # A gradient buffer of this graph that autograd took over as p.grad in an earlier backward (p.grad was None then) and that is
+        # still p.grad now — zero_grad(set_to_none=False), or a second backward before the optimizer step — would be overwritten by the
+        # replay below and then added to itself: such a p.grad gets a private copy first.  (zero_grad()'s default, set_to_none=True,
+        # never comes here: no copies on the common path.)
+        for p, buf in zip(st.params, st.grads):
+            if buf is not None and p.grad is not None and p.grad.data_ptr() == buf.data_ptr():
+                p.grad = p.grad.clone()
+        st.gout.copy_(g)
+        st.bwd.replay()
+        return (None, *[None if buf is None else buf.detach() for buf in st.grads])
+
+
+class _CallState:
+    __slots__ = ("static", "visits", "fwd", "bwd", "out", "gout", "params", "grads", "x_sig")
+
+    def __init__(self, static):
+        self.static, self.visits = static, 0
+        self.fwd = self.bwd = self.out = self.gout = self.params = self.grads = self.x_sig = None
+
+
+class GraphedCallable:
+    """``route(module, eager_forward, batch)`` = ``eager_forward(batch)``, from hipGraphs once a batch has been seen before.
+
+    A batch is recognised by CONTENT: the shapes plus a 64-bit fingerprint of ``edge_index``, ``batch`` and ``edge_attr``
+    (``glam_batch_fingerprint``, one launch and one 8-byte read-back per call; skipped when the very same tensors come back, as
+    with ``glam_amd.data.DataLoader(cache=True)``) — the reference's trainer collates and copies every batch anew in every epoch,
+    but its loader does not shuffle (``trainer.py:37-38``), so the same batches recur.
+
+    * first visit of a content: the batch's tensors are copied into private static tensors and the model runs eagerly ON THEM (this
+      is where the CSR / ELL staging and its one validation sync happen, cached on the static tensors);
+    * second visit: the forward is captured into one hipGraph and — when autograd is recording — the backward into another, through
+      ``torch.autograd.grad`` on the static output;
+    * from then on ``model(batch)`` copies ``batch.x`` into the static tensor and replays the forward graph; the result carries ONE
+      autograd node whose backward replays the backward graph and hands the parameters' gradients to autograd.
+
+    Per-graph memory pools (a forward's saved activations must survive until its backward whatever else runs in between).  The route
+    stays eager — silently, it is an optimisation — for CPU tensors, inside someone else's stream capture, when ``batch.x`` requires a
+    gradient, for empty batches, when the model has forward hooks, beyond ``max_graphs`` contents or when less than a quarter of the
+    device memory is free.  ``model.graphed_call = False`` or ``GLAM_GRAPHED_CALL=0`` switch it off."""
+
+    def __init__(self, max_graphs=4096):
+        self.max_graphs = max_graphs
+        self._states = {}          # key -> _CallState
+        self._by_obj = {}          # id(batch) -> (weakref, tensor signature, key): the same tensors again need no fingerprint
+        self._fp = None
+        self._param_ids = None
+        self._params = self._first = None
+        self._frozen = ()
+
+    def __deepcopy__(self, memo):
+        return GraphedCallable(self.max_graphs)      # graphs and static tensors belong to the original module's parameters
+
+    def __getstate__(self):
+        return {"max_graphs": self.max_graphs}
+
+    def __setstate__(self, state):
+        self.__init__(state.get("max_graphs", 4096))
+
+    def graphs(self):
+        return sum((s.fwd is not None) + (s.bwd is not None) for s in self._states.values())
+
+    def clear(self):
+        self._states.clear()
+        self._by_obj.clear()
+
+    # -- recognition -----------------------------------------------------------------------------------------------------------
+    def _fingerprint(self, tensors):
+        from . import _lib
+        lib = _lib.load()
+        dev = tensors[0].device
+        if self._fp is None or self._fp.device != dev:
+            self._fp = torch.empty(1, dtype=torch.int64, device=dev)
+        n = len(tensors)
+        bufs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        sizes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in tensors])
+        _lib.check(lib.glam_batch_fingerprint(n, bufs, sizes, self._fp.data_ptr(), _lib.stream()), "glam_batch_fingerprint")
+        return int(self._fp.item())                  # (the one read-back of a recognised call)
+
+    def _key(self, module, data, index):
+        flags = (module.training, torch.is_grad_enabled(), _route_signature())
+        ent = self._by_obj.get(id(data))
+        # the same batch OBJECT holding the same index tensor OBJECTS, unwritten since (addresses alone would not do: a freed tensor's
+        # address comes back with other content)
+        if ent is not None and ent[0]() is data and all(r() is t and v == t._version for (r, v), t in zip(ent[1], index)):
+            return ent[2][:-1] + (flags,)
+        sig = tuple((weakref.ref(t), t._version) for t in index)
+        fp = self._fingerprint(index)
+        key = (tuple(data.x.shape), tuple(tuple(t.shape) for t in index), getattr(data, "num_graphs", None), fp, flags)
+        try:
+            ref = weakref.ref(data, lambda _r, k=id(data), d=self._by_obj: d.pop(k, None))
+            self._by_obj[id(data)] = (ref, sig, key)
+        except TypeError:                            # a batch type without weak references: fingerprinted every time
+            pass
+        return key
+
+    # -- the route ---------------------------------------------------------------------------------------------------------------
+    def __call__(self, module, eager_forward, data):
+        x, ei, ea, bv = (getattr(data, k, None) for k in ("x", "edge_index", "edge_attr", "batch"))
+        if (not GRAPHED_CALL or _suspended or not getattr(module, "graphed_call", True) or not all(torch.is_tensor(t) for t in (x, ei, ea, bv))
+                or not x.is_cuda or x.dtype != torch.float32 or x.requires_grad or x.numel() == 0 or ei.numel() == 0
+                or ei.dtype != torch.int64 or bv.dtype != torch.int64 or ea.dtype != torch.float32
+                or not (ei.is_contiguous() and ea.is_contiguous() and bv.is_contiguous() and x.is_contiguous())
+                or module._forward_hooks or module._forward_pre_hooks or torch.cuda.is_current_stream_capturing()):
+            return eager_forward(data)
+        # the trainable parameters, re-walked only when the cheap probe fails (walking the module tree costs ~25 us per call): the first
+        # parameter object and every cached one's requires_grad — module.to() / .half() / load into new tensors replace them all
+        params = self._params
+        if (params is None or next(module.parameters(), None) is not self._first or not all(p.requires_grad for p in params)
+                or any(p.requires_grad for p in self._frozen)):
+            params = self._params = tuple(p for p in module.parameters() if p.requires_grad)
+            self._frozen = tuple(p for p in module.parameters() if not p.requires_grad)
+            self._first = next(module.parameters(), None)
+            pids = tuple(id(p) for p in module.parameters())
+            if pids != self._param_ids:              # parameters replaced / frozen since the captures: they bake addresses in
+                self.clear()
+                self._param_ids = pids
+        key = self._key(module, data, (ei, bv, ea))
+        st = self._states.get(key)
+        if st is None:
+            if len(self._states) >= self.max_graphs:
+                return eager_forward(data)
+            from .data import Batch
+            static = Batch(x=x.detach().clone(), edge_index=ei.clone(), edge_attr=ea.clone(), batch=bv.clone())
+            ng = getattr(data, "num_graphs", None)
+            if ng is not None:
+                static.num_graphs = ng
+            st = self._states[key] = _CallState(static)
+        elif st.x_sig is None or st.x_sig[0]() is not x or st.x_sig[1] != x._version:
+            st.static.x.copy_(x)                     # (a cached loader hands the same tensor object back, unwritten: nothing to copy)
+        st.x_sig = (weakref.ref(x), x._version)      # the OBJECT, not its address: a freed tensor's address comes back with other content
+        st.visits += 1
+        if st.fwd is None:
+            free, total = torch.cuda.mem_get_info(x.device)
+            if st.visits < 2 or free < total // 4:
+                with no_graphed_call():
+                    return eager_forward(st.static)
+            self._capture(st, module, eager_forward, params)
+        if st.bwd is None:
+            st.fwd.replay()
+            return st.out.detach().clone()
+        return _Replay.apply(st, *st.params)
+
+    def _capture(self, st, module, eager_forward, params):
+        grad = torch.is_grad_enabled() and len(params) > 0
+        # a NEW features tensor for the capture: whatever the eager visit derived from the old one and cached on it (the zero-padded copy
+        # of the atom features, ops.pad_cols) must be recomputed INSIDE the graph — later calls bring other features
+        st.static.x = st.static.x.clone()
+        torch.cuda.synchronize()
+        fwd = torch.cuda.CUDAGraph()
+        if not grad:
+            with torch.cuda.graph(fwd), no_graphed_call():
+                st.out = eager_forward(st.static)
+            st.fwd = fwd
+            return
+        # The captured forward runs on PROXY leaves (detached aliases of the parameters: same storage, so optimizer updates show).  A
+        # parameter's AccumulateGrad node is bound to the stream it was created on and lives as long as any autograd graph that reaches
+        # it — and the reference's loop still holds last iteration's ``loss`` when it calls the model again (trainer.py:296-299): with the
+        # parameters themselves as leaves the captured graph would end in nodes of the caller's stream, the backward capture would
+        # join that stream, and the runtime crashes at capture end (tools/repro_graphed_call.py, V=4 / V=5).
+        names = [n for n, p in module.named_parameters() if p.requires_grad]
+        proxies = tuple(p.detach().requires_grad_() for p in params)
+        with torch.cuda.graph(fwd), no_graphed_call():
+            out = torch.func.functional_call(module, dict(zip(names, proxies)), (st.static,))
+        st.fwd, st.out = fwd, out
+        if out.requires_grad:
+            st.gout = torch.zeros_like(out)
+            bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(bwd, pool=fwd.pool()):
+                grads = torch.autograd.grad(out, proxies, st.gout, allow_unused=True)
+            st.bwd, st.params, st.grads = bwd, params, tuple(grads)
+
+
+def graphed_call(module, eager_forward, data):
+    """``eager_forward(data)`` through ``module``'s graphed-callable route (created on first use, stored outside the module's
+    parameters / buffers / submodules: state dicts and ``module.to()`` never see it)."""
+    route = module.__dict__.get("_glam_graphed_route")
+    if route is None:
+        route = module.__dict__["_glam_graphed_route"] = GraphedCallable()
+    return route(module, eager_forward, data)

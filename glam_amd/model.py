@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import graphs, ops
 
 from .layer import _None  # noqa: F401
 from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
@@ -47,6 +47,11 @@ class Architecture(torch.nn.Module):
         self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
 
     def forward(self, data_mol):
+        # a batch content seen before is replayed from hipGraphs (glam_amd.graphs.GraphedCallable): the reference's eager training
+        # loop (src_1gp/trainer.py:286-304) runs unchanged at graphed speed; ``model.graphed_call = False`` keeps every call eager
+        return graphs.graphed_call(self, self._eager_forward, data_mol)
+
+    def _eager_forward(self, data_mol):
         with ops.weight_scope():     # weight re-layouts are shared by the message_steps applications of the block
             out = self._forward(data_mol)
         ops.poll_checks()            # deferred id checks of foreign batches (GLAM_VALIDATE=deferred) whose flag has come back

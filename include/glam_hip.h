@@ -66,6 +66,14 @@ int glam_prof_read(int i, char* name_host, int name_cap, int32_t* grid_host, flo
  * src[t] (padded gradient; NULL = that gradient does not exist: zeros). */
 int glam_pad_group(int n, const float* const* src, float* const* dst, const int32_t* dims, int backward, void* stream);
 
+/* 64-bit content fingerprint of up to four device buffers (bufs / nbytes: HOST arrays of n device pointers and byte counts, each
+ * 4-byte aligned and a multiple of 4 bytes) into the device word out_dev, in one launch; position-sensitive, independent of the
+ * launch geometry.  Replaces: nothing in the reference — its trainer collates and copies a fresh batch every iteration
+ * (src_1gp/trainer.py:292-295), so a batch that comes back every epoch (the loader does not shuffle: trainer.py:37-38) can only be
+ * recognised by content; glam_amd.graphs keys its staged index structures and captured hipGraphs on the fingerprint of
+ * (edge_index, batch, edge_attr).  Not for use inside a stream capture by the caller that wants to read the word back. */
+int glam_batch_fingerprint(int n, const void* const* bufs, const int64_t* nbytes, uint64_t* out_dev, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * CSR staging of a COO edge list.
  * Replaces: the per-call index_select/scatter bookkeeping PyG's MessagePassing.propagate does for
