@@ -39,6 +39,15 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 #define WSTAMP(k) do { } while (0)
 #endif
 
+// Timeline stamps (-DGLAM_WS_TL, tools/ws_timeline.py): wave entry, prologue done, first publish, loop end, last stores issued, drained —
+// six per wave, none inside the steady loop (stamps there perturb a loop of this granularity: profiles/r5_wgrad_x3_forms.txt)
+#ifdef GLAM_WS_TL
+__device__ long long g_ws_tl[2 * 256 * 12 * 6];      // [kernel: forward | backward by source][block][wave][stamp]
+#define WS_TL(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_ws_tl[(((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k)] = clock64(); } while (0)
+#else
+#define WS_TL(kid, k) do { } while (0)
+#endif
+
 #ifdef GLAM_WS_PROF
 #define WS_PROF_PARAMS , long long* pacc, long long& plast
 #define WS_PROF_ARGS , pacc, plast
@@ -223,13 +232,21 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     float* s_meta = smem + WSZ + 64;                          // per producer wave: 2 side tables of 2 KB
     float* s_ring = s_meta + P * 2 * kSideF;                  // kWsRing tiles of 16 x LDT floats (X3: kRingN tiles of kX3TileBytes)
     constexpr int kRingN = X3 ? kWsRingX3 : kWsRing;
+    WS_TL(0, 0);
     for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) {
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
         else s_ready[tid] = 0;
     }
-    if constexpr (X3) {      // the k padding of every tile row (columns H*Cp .. 191) must read as zero: the ring is cleared once
-        for (int i = tid; i < kRingN * kX3TileBytes / 16; i += kWsBlock) st4(s_ring + 4 * i, f4zero());
+    if constexpr (X3) {
+        // the k padding of every tile row (columns H*Cp .. 191 of the 384 data bytes) must read as zero, and the producers never write
+        // it: cleared once — the 16-byte chunks from the one that holds column H*Cp on, not the whole ring (100 KB of LDS stores were
+        // ~1 000 cycles of every block's prologue: profiles/r5_ws_timeline_b1024.txt)
+        const int c0 = (2 * HC) >> 4, nch = 24 - c0;          // chunks per row: [c0, 24)
+        for (int i = tid; i < kRingN * 48 * nch; i += kWsBlock) {
+            const int row = i / nch, ch = c0 + i - row * nch;
+            st4(reinterpret_cast<float*>(reinterpret_cast<char*>(s_ring) + row * kX3RowBytes + 16 * ch), f4zero());
+        }
     }
     // the block's only barrier sits BEHIND each role's first global loads (ws_consume; the producers' first record + prefetch below)
     const int ntiles = (a.N + 15) >> 4;
@@ -241,6 +258,9 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
         if constexpr (X3) ws_consume_x3<kRingN>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
         else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        WS_TL(0, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_TL(0, 5);
 #ifdef GLAM_WS_PROF
         if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -429,6 +449,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     __syncthreads();                                          // the block's only barrier: W_edge / flags staged; the first pass is already in flight
     const int pass_end = ntiles << 2;                         // whole 16-node tiles: every producer publishes every tile of its group
     int it = grp;                                             // local tile index of `pass`
+    WS_TL(0, 1);
     // two passes per trip: the register sets swap roles instead of being copied
     for (; pass - rw < pass_end; pass += 2 * GW, it += 2 * PG) {
         WSTAMP(0);
@@ -445,6 +466,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         WSTAMP(6);
         publish(it);
         WSTAMP(7);
+        if (it == grp) WS_TL(0, 2);
 
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
         settle(rows_b);
@@ -462,8 +484,12 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
             WSTAMP(7);
         }
     }
+    WS_TL(0, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_results();
+    WS_TL(0, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WS_TL(0, 5);
 #ifdef GLAM_WS_PROF
     if (lane == 0 && blockIdx.x < 64) for (int k = 0; k < 8; ++k) g_ws_prof[(blockIdx.x * 12 + wave) * 8 + k] = pacc[k];
 #endif
@@ -502,10 +528,15 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     float* s_meta = smem + WSZ + 64;
     float* s_ring = s_meta + P * 2 * kSideF;
     constexpr int kRingN = X3 ? kWsRingX3 : kWsRing;
+    WS_TL(1, 0);
     for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) s_ready[tid] = 0;
-    if constexpr (X3) {      // the k padding of every tile row must read as zero: the ring is cleared once (see k_triplet_fwd_ws)
-        for (int i = tid; i < kRingN * kX3TileBytes / 16; i += kWsBlock) st4(s_ring + 4 * i, f4zero());
+    if constexpr (X3) {      // the k padding of every tile row (columns KX .. 191) must read as zero: cleared once (see k_triplet_fwd_ws)
+        const int c0 = (2 * KX) >> 4, nch = 24 - c0;
+        for (int i = tid; i < kRingN * 48 * nch; i += kWsBlock) {
+            const int row = i / nch, ch = c0 + i - row * nch;
+            st4(reinterpret_cast<float*>(reinterpret_cast<char*>(s_ring) + row * kX3RowBytes + 16 * ch), f4zero());
+        }
     }
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
@@ -514,6 +545,9 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     if (wave >= P) {
         if constexpr (X3) ws_consume_x3<kRingN, ADD>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
         else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        WS_TL(1, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_TL(1, 5);
         return;
     }
     float* wbase = s_meta + wave * (2 * kSideF);
@@ -673,6 +707,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     __syncthreads();                                          // the block's only barrier (see k_triplet_fwd_ws)
     const int pass_end = ntiles << 2;
     int it = grp;
+    WS_TL(1, 1);
     for (; pass - rw < pass_end; pass += 2 * GW, it += 2 * PG) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
         settle(rows_a);
@@ -681,6 +716,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         load_rec(pass + 2 * GW, rs_nxt, re_nxt);
         compute_any(pass, deg_a, dmax_a, 0, rows_a);
         publish(it);
+        if (it == grp) WS_TL(1, 2);
 
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
         settle(rows_b);
@@ -692,8 +728,12 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
             publish(it + PG);
         }
     }
+    WS_TL(1, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_results();
+    WS_TL(1, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WS_TL(1, 5);
 #undef LANE_CONSTS
 }
 
@@ -811,6 +851,11 @@ int triplet_fwd_ws(const float* xw, const float* a_ij, const float* edge_attr, c
 
 }  // namespace glam
 
+#ifdef GLAM_WS_TL
+extern "C" int glam_debug_ws_tl(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_ws_tl), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef GLAM_WS_PROF
 extern "C" int glam_debug_ws_prof(long long* host_out, int n) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_ws_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;

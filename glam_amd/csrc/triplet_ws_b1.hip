@@ -26,6 +26,14 @@
 
 namespace glam {
 
+#ifdef GLAM_WS_TL      // timeline stamps (tools/ws_timeline.py; see triplet_ws.hip): [block][wave][stamp]
+__device__ long long g_b1_tl[256 * 12 * 6];
+#define B1_TL(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_b1_tl[(blockIdx.x * 12 + (threadIdx.x >> 6)) * 6 + (k)] = clock64(); } while (0)
+#else
+#define B1_TL(k) do { } while (0)
+#endif
+
+
 struct DstWsArgs {
     const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
     const float* aggr; const float* stats; const float* d_out; const float* img_dagg;
@@ -52,6 +60,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     int* s_taken = s_ready + 32;                              // [kRing] vector-wave check-outs per slot
     float* s_dw = smem + WL + 64;                             // per (vector wave, node row): d_W_edge [4][WP]
     float* s_ring = s_dw + V * 4 * WL;                        // kRing tiles of 16 x LDT floats
+    B1_TL(0);
     for (int i = tid; i < WSZ / 4; i += kBlockT) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     for (int i = tid; i < V * WL; i += kBlockT) st4(s_dw + 4 * i, f4zero());           // V * 4 arrays of WL floats
     if (tid < 64) {
@@ -124,6 +133,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             int tile = blockIdx.x, it = 0;
             load_a(tile, af);
             __syncthreads();                                  // LDS initialised; the weight slice and the first tile's rows are in flight
+            B1_TL(1);
             for (; tile < ntiles; tile += gridDim.x, ++it) {
                 Bf16x3 as[2];
 #pragma unroll
@@ -402,9 +412,11 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         prefetch(pass, rs, re);
         load_rec(pass + GW, rs_n, re_n);
         __syncthreads();                                      // LDS initialised; the first pass's operands are in flight
+        B1_TL(1);
         const int pass_end = ntiles << 2;
         int it = grp;
         for (; pass - rw < pass_end; pass += GW, it += VG) {
+            if (it == grp + VG) B1_TL(2);                     // (the first pass of this wave is done)
             compute_a_any(pass, it, rs);
             __builtin_amdgcn_sched_barrier(0);                // the rows' registers are free from here on: everything of pass p + 1
             prefetch(pass + GW, rs_n, re_n);
@@ -414,6 +426,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             load_rec(pass + 2 * GW, rs_n, re_n);
         }
         // every tile of this wave is done: park the lane's d_M in its own slot of the scratch behind the ring flags
+        B1_TL(3);
         __syncthreads();                                      // (1) the ring is dead: its memory becomes the d_M scratch
         {
             float* scr = s_ring + (wave * 64 + lane) * 4;
@@ -421,8 +434,9 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         }
 #undef LANE_CONSTS
     }
-    if (wave >= V) __syncthreads();                           // (1) for the matrix waves
+    if (wave >= V) { B1_TL(3); __syncthreads(); }             // (1) for the matrix waves
     __syncthreads();                                          // (2)
+    B1_TL(4);
     // ---- block partial of d_W_edge | d_M, every sum in a fixed order ----
     float* out = a.partial + (size_t)blockIdx.x * P;
     for (int i = tid; i < WSZ; i += kBlockT) {
@@ -441,6 +455,10 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         }
         out[WSZ + tt * 4 + hh] = sum;
     }
+#ifdef GLAM_WS_TL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B1_TL(5);
+#endif
 }
 
 static size_t b1ws_lds_bytes(int H, int Cp, int V) {
@@ -498,3 +516,9 @@ int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_att
 }
 
 }  // namespace glam
+
+#ifdef GLAM_WS_TL
+extern "C" int glam_debug_b1_tl(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_b1_tl), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
