@@ -670,11 +670,44 @@ class _TripletLayer(torch.autograd.Function):
         return res if len(res) > 1 else out
 
     @staticmethod
+    def _flush_parked(parked, N, C, H, De, Cp, Dp, wn, we, att, carry_in):
+        """Both weight-gradient products + k_param_grads over the parked operand sets (three per launch pair), chained through the
+        gradient carry.  The list is emptied whatever happens: a set left behind by an interrupted backward would be counted again by
+        a retried one (``retain_graph=True``)."""
+        lib, dev = _lib.load(), wn.device
+        sizes = [wn.numel(), we.numel(), att.numel(), H * C * C, C]
+        sets = list(parked)
+        parked.clear()
+        vp = ctypes.c_void_p
+        while sets:
+            grp, sets = sets[:3], sets[3:]
+            n = len(grp)
+            out = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            o = [t.view(sh) for t, sh in zip(out.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,)))]
+            c = carry_in.split(sizes) if carry_in is not None else (None,) * 5
+            ws2 = torch.empty(2 * lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+            infos = (ctypes.c_int64 * (4 * n))(*[v for t in grp for v in t[1]])
+            arr = lambda i: (vp * n)(*[t[i].data_ptr() for t in grp])
+            check(lib.glam_triplet_layer_param_grads_sets(n, arr(0), infos, arr(2), arr(3), arr(4), N, C, H, De, Cp, Dp, ptr(wn), ptr(we),
+                                                          ptr(att), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(o[4]), ptr(c[0]), ptr(c[1]),
+                                                          ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(ws2), ws2.numel(), stream()),
+                  "glam_triplet_layer_param_grads_sets")
+            carry_in = out
+        return carry_in
+
+    @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out, *more):
         d_alias = more[0] if ctx.aliased else None
         d_carry = more[-1] if ctx.carried else None
         if d_out is None:                    # the layer's output was not used: only the skip connection / the carry pass through
+            scope = getattr(ctx, "scope", None)
+            parked = scope.bwd.get(("triplet-parked", id(ctx.saved_tensors[2]))) if (scope is not None and ctx.first_app) else None
+            if parked and parked[1]:         # later applications parked their operand sets for this one to multiply: do it without a set of our own
+                x_p, ea_p, wn, we, att = ctx.saved_tensors[:5]
+                C, H, De, Cp, Dp, _slope = ctx.dims
+                d_carry = _TripletLayer._flush_parked(parked[1], ctx.gi.N, C, H, De, Cp, Dp, wn, we, att,
+                                                      f32c(d_carry, "d_carry") if d_carry is not None else None)
             return (d_alias,) + (None,) * 9 + (d_carry, None, None)
         x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
@@ -716,24 +749,7 @@ class _TripletLayer(torch.autograd.Function):
             parked.append((ws, tuple(info), x_p, aggr, d_out))
             if not ctx.first_app:
                 return d_x, d_ea, None, None, None, None, None, None, None, None, d_carry, None, None
-            sets = list(parked)
-            parked.clear()
-            carry_in = f32c(d_carry, "d_carry") if d_carry is not None else None
-            vp = ctypes.c_void_p
-            while sets:
-                grp, sets = sets[:3], sets[3:]
-                n = len(grp)
-                out = torch.empty(sum(sizes), **f)
-                o = [t.view(sh) for t, sh in zip(out.split(sizes), (wn.shape, we.shape, att.shape, (H * C, C), (C,)))]
-                c = carry_in.split(sizes) if carry_in is not None else (None,) * 5
-                ws2 = torch.empty(2 * lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
-                infos = (ctypes.c_int64 * (4 * n))(*[v for t in grp for v in t[1]])
-                arr = lambda i: (vp * n)(*[t[i].data_ptr() for t in grp])
-                check(lib.glam_triplet_layer_param_grads_sets(n, arr(0), infos, arr(2), arr(3), arr(4), N, C, H, De, Cp, Dp, ptr(wn), ptr(we),
-                                                              ptr(att), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(o[4]), ptr(c[0]), ptr(c[1]),
-                                                              ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(ws2), ws2.numel(), stream()),
-                      "glam_triplet_layer_param_grads_sets")
-                carry_in = out
+            carry_in = _TripletLayer._flush_parked(parked, N, C, H, De, Cp, Dp, wn, we, att, f32c(d_carry, "d_carry") if d_carry is not None else None)
             return d_x, d_ea, None, None, None, None, None, None, None, None, carry_in, None, None
         if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself

@@ -496,7 +496,7 @@ class _LinearDense(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, slope):
-        require_device(x, w)
+        require_device(x, w) if b is None else require_device(x, w, b)
         x, w = f32c(x, "x"), f32c(w, "weight")
         b = None if b is None else f32c(b, "bias")
         N, K = x.shape
@@ -518,12 +518,18 @@ class _LinearDense(torch.autograd.Function):
         N, K = x.shape
         M = w.size(0)
         f = dict(dtype=torch.float32, device=x.device)
+        # only what autograd asks for (a frozen layer: no dy^T x product; the entry point takes NULL for each output)
         dx = torch.empty(N, K, **f) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(M, K, **f)
-        db = torch.empty(M, **f) if ctx.has_bias else None
+        dw = torch.empty(M, K, **f) if ctx.needs_input_grad[1] else None
+        db = torch.empty(M, **f) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if dx is None and dw is None and db is None:
+            return None, None, None, None, None
+        need_dw = dw is not None
+        if db is not None and dw is None:
+            dw = torch.empty(M, K, **f)      # (the bias gradient is the all-ones column of the dy^T [x | 1] product: it comes with dw)
         check(_lib.load().glam_linear_dense_bwd(ptr(x), ptr(w), ptr(dy), ptr(y), ctx.slope, N, K, M, ptr(dx), ptr(dw), ptr(db), stream()),
               "glam_linear_dense_bwd")
-        return dx, dw, db, None, None
+        return dx, (dw if need_dw else None), db, None, None
 
 
 _DENSE_ACT = {"none": 0, "relu": 1, "leaky": 2}
