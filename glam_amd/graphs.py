@@ -265,9 +265,10 @@ class GraphedCallable:
     with ``glam_amd.data.DataLoader(cache=True)``) — the reference's trainer collates and copies every batch anew in every epoch,
     but its loader does not shuffle (``trainer.py:37-38``), so the same batches recur.
 
-    * first visit of a content: the batch's tensors are copied into private static tensors and the model runs eagerly ON THEM (this
-      is where the CSR / ELL staging and its one validation sync happen, cached on the static tensors);
-    * second visit: the forward is captured into one hipGraph and — when autograd is recording — the backward into another, through
+    * first visit of a content: the model runs eagerly on the caller's batch, as it always did;
+    * second visit: the batch's tensors are copied into private static tensors and the model runs eagerly ON THEM (this is where their
+      CSR / ELL staging and its one validation sync happen, cached on the static tensors);
+    * third visit: the forward is captured into one hipGraph and — when autograd is recording — the backward into another, through
       ``torch.autograd.grad`` on the static output;
     * from then on ``model(batch)`` copies ``batch.x`` into the static tensor and replays the forward graph; the result carries ONE
       autograd node whose backward replays the backward graph and hands the parameters' gradients to autograd.
@@ -358,19 +359,26 @@ class GraphedCallable:
         if st is None:
             if len(self._states) >= self.max_graphs:
                 return eager_forward(data)
+            st = self._states[key] = _CallState(None)
+        st.visits += 1
+        if st.visits == 1:
+            # first visit: the caller's own batch, eagerly — exactly what happened before this route existed (its index tensors get
+            # their CSR / ELL staging, so a caller that captures a graph of its own around ``model(batch)`` later finds them staged)
+            with no_graphed_call():
+                return eager_forward(data)
+        if st.static is None:
             from .data import Batch
-            static = Batch(x=x.detach().clone(), edge_index=ei.clone(), edge_attr=ea.clone(), batch=bv.clone())
+            st.static = Batch(x=x.detach().clone(), edge_index=ei.clone(), edge_attr=ea.clone(), batch=bv.clone())
             ng = getattr(data, "num_graphs", None)
             if ng is not None:
-                static.num_graphs = ng
-            st = self._states[key] = _CallState(static)
+                st.static.num_graphs = ng
         elif st.x_sig is None or st.x_sig[0]() is not x or st.x_sig[1] != x._version:
             st.static.x.copy_(x)                     # (a cached loader hands the same tensor object back, unwritten: nothing to copy)
         st.x_sig = (weakref.ref(x), x._version)      # the OBJECT, not its address: a freed tensor's address comes back with other content
-        st.visits += 1
         if st.fwd is None:
             free, total = torch.cuda.mem_get_info(x.device)
-            if st.visits < 2 or free < total // 4:
+            if st.visits < 3 or free < total // 4:
+                # second visit: eagerly on the private static copy (ITS index tensors are staged here: one validation sync)
                 with no_graphed_call():
                     return eager_forward(st.static)
             self._capture(st, module, eager_forward, params)
