@@ -270,14 +270,8 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kb = lane >> 4;
     const int K = a.K1, Kp = (K + 15) & ~15, M = a.M1 + a.M2;
     const int ntiles = (a.N + 15) >> 4;
-#ifdef GLAM_TS_XCD      // experiment: row tile t on XCD t % 8 (the tile -> block mapping of the warp-specialised layer kernels that read xw)
-    const int xcd = (int)blockIdx.x & 7, lw = ((int)blockIdx.x >> 3) * WPB + wave, wpx = (nblk >> 3) * WPB;       // waves per XCD
-    const int gw = lw;
-    const int cs = gw % CS;
-#else
     const int gw = (int)blockIdx.x * WPB + wave;
     const int cs = gw % CS;
-#endif
     // W slice of this wave: column tile t holds the logical columns cs * 64 + 4 c + t (image position cs * 64 + 16 t + c)
     Bf16x3 wreg[KS][4];
     {
@@ -302,13 +296,8 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
                 af[s][u] = (rok && k0 < K) ? ld4(a.A1 + (size_t)row * a.lda1 + k0) : f4zero();
             }
     };
-#ifdef GLAM_TS_XCD
-    const int tstride = 8 * (wpx / CS);
-    int tile = (lw < wpx / CS * CS) ? 8 * (lw / CS) + xcd : ntiles;
-#else
     const int tstride = nblk * WPB / CS;                       // row tiles per step of this wave (the host makes the wave count a multiple of CS)
     int tile = gw / CS;
-#endif
     // the wave's four output columns never change: the bias is read ONCE, here.  Read inside the loop (under its condition) the compiler
     // re-waited for it — vmcnt(0) — in each of the four row-store blocks, i.e. for the previous row's STORE: three store round trips
     // per item in series (the launch ran at 3.7 us per item and wave)
@@ -645,13 +634,8 @@ static int ts_rb_grid(int N) {
     const int ntiles = (N + 15) / 16;
     if (ts_rb_big(N)) return 256;        // 12 waves per block: any block count is a multiple of the 3 column splits
     int g = (ntiles * 3 + 7) / 8;        // one item per wave
-#ifdef GLAM_TS_XCD
-    g = (g + 7) / 8 * 8;
-    return g > 256 ? 256 : g;
-#else
     g = (g + 2) / 3 * 3;                 // 8 g waves: a multiple of the 3 column splits
     return g > 255 ? 255 : g;
-#endif
 }
 
 // b == nullptr: one product; otherwise two products of the SAME variant in one launch
