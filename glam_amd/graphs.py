@@ -316,32 +316,43 @@ class GraphedCallable:
         _lib.check(lib.glam_batch_fingerprint(n, bufs, sizes, self._fp.data_ptr(), _lib.stream()), "glam_batch_fingerprint")
         return int(self._fp.item())                  # (the one read-back of a recognised call)
 
-    def _key(self, module, data, index):
+    def _key(self, module, datas, index):
         flags = (module.training, torch.is_grad_enabled(), _route_signature())
-        ent = self._by_obj.get(id(data))
-        # the same batch OBJECT holding the same index tensor OBJECTS, unwritten since (addresses alone would not do: a freed tensor's
+        okey = tuple(id(d) for d in datas)
+        ent = self._by_obj.get(okey)
+        # the same batch OBJECT(S) holding the same index tensor OBJECTS, unwritten since (addresses alone would not do: a freed tensor's
         # address comes back with other content)
-        if ent is not None and ent[0]() is data and all(r() is t and v == t._version for (r, v), t in zip(ent[1], index)):
+        if (ent is not None and all(r() is d for r, d in zip(ent[0], datas))
+                and all(r() is t and v == t._version for (r, v), t in zip(ent[1], index))):
             return ent[2][:-1] + (flags,)
         sig = tuple((weakref.ref(t), t._version) for t in index)
-        fp = self._fingerprint(index)
-        key = (tuple(data.x.shape), tuple(tuple(t.shape) for t in index), getattr(data, "num_graphs", None), fp, flags)
+        fp = tuple(self._fingerprint(index[k:k + 3]) for k in range(0, len(index), 3))
+        key = (tuple(tuple(d.x.shape) for d in datas), tuple(tuple(t.shape) for t in index),
+               tuple(getattr(d, "num_graphs", None) for d in datas), fp, flags)
         try:
-            ref = weakref.ref(data, lambda _r, k=id(data), d=self._by_obj: d.pop(k, None))
-            self._by_obj[id(data)] = (ref, sig, key)
+            refs = tuple(weakref.ref(d, lambda _r, k=okey, c=self._by_obj: c.pop(k, None)) for d in datas)
+            self._by_obj[okey] = (refs, sig, key)
         except TypeError:                            # a batch type without weak references: fingerprinted every time
             pass
         return key
 
     # -- the route ---------------------------------------------------------------------------------------------------------------
-    def __call__(self, module, eager_forward, data):
-        x, ei, ea, bv = (getattr(data, k, None) for k in ("x", "edge_index", "edge_attr", "batch"))
-        if (not GRAPHED_CALL or _suspended or not getattr(module, "graphed_call", True) or not all(torch.is_tensor(t) for t in (x, ei, ea, bv))
-                or not x.is_cuda or x.dtype != torch.float32 or x.requires_grad or x.numel() == 0 or ei.numel() == 0
-                or ei.dtype != torch.int64 or bv.dtype != torch.int64 or ea.dtype != torch.float32
-                or not (ei.is_contiguous() and ea.is_contiguous() and bv.is_contiguous() and x.is_contiguous())
-                or module._forward_hooks or module._forward_pre_hooks or torch.cuda.is_current_stream_capturing()):
-            return eager_forward(data)
+    @staticmethod
+    def _fields(data):
+        return tuple(getattr(data, k, None) for k in ("x", "edge_index", "edge_attr", "batch"))
+
+    def __call__(self, module, eager_forward, *datas):
+        """``eager_forward(*datas)``; every argument is a batch (``x``, ``edge_index``, ``edge_attr``, ``batch``): one for ``Architecture``,
+        ligand + protein for ``ArchitectureDTI``, two drugs for ``ArchitectureDDI``."""
+        fields = [self._fields(d) for d in datas]
+        ok = (GRAPHED_CALL and not _suspended and getattr(module, "graphed_call", True) and len(datas) > 0
+              and not module._forward_hooks and not module._forward_pre_hooks and not torch.cuda.is_current_stream_capturing())
+        for x, ei, ea, bv in (fields if ok else ()):
+            ok = (ok and all(torch.is_tensor(t) for t in (x, ei, ea, bv)) and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+                  and x.numel() > 0 and ei.numel() > 0 and ei.dtype == torch.int64 and bv.dtype == torch.int64 and ea.dtype == torch.float32
+                  and ei.is_contiguous() and ea.is_contiguous() and bv.is_contiguous() and x.is_contiguous())
+        if not ok:
+            return eager_forward(*datas)
         # the trainable parameters, re-walked only when the cheap probe fails (walking the module tree costs ~25 us per call): the first
         # parameter object and every cached one's requires_grad — module.to() / .half() / load into new tensors replace them all
         params = self._params
@@ -354,33 +365,40 @@ class GraphedCallable:
             if pids != self._param_ids:              # parameters replaced / frozen since the captures: they bake addresses in
                 self.clear()
                 self._param_ids = pids
-        key = self._key(module, data, (ei, bv, ea))
+        key = self._key(module, datas, tuple(t for _x, ei, ea, bv in fields for t in (ei, bv, ea)))
         st = self._states.get(key)
         if st is None:
             if len(self._states) >= self.max_graphs:
-                return eager_forward(data)
+                return eager_forward(*datas)
             st = self._states[key] = _CallState(None)
         st.visits += 1
         if st.visits == 1:
             # first visit: the caller's own batch, eagerly — exactly what happened before this route existed (its index tensors get
             # their CSR / ELL staging, so a caller that captures a graph of its own around ``model(batch)`` later finds them staged)
             with no_graphed_call():
-                return eager_forward(data)
+                return eager_forward(*datas)
         if st.static is None:
             from .data import Batch
-            st.static = Batch(x=x.detach().clone(), edge_index=ei.clone(), edge_attr=ea.clone(), batch=bv.clone())
-            ng = getattr(data, "num_graphs", None)
-            if ng is not None:
-                st.static.num_graphs = ng
-        elif st.x_sig is None or st.x_sig[0]() is not x or st.x_sig[1] != x._version:
-            st.static.x.copy_(x)                     # (a cached loader hands the same tensor object back, unwritten: nothing to copy)
-        st.x_sig = (weakref.ref(x), x._version)      # the OBJECT, not its address: a freed tensor's address comes back with other content
+            st.static, st.x_sig = [], [None] * len(datas)
+            for d, (x, ei, ea, bv) in zip(datas, fields):
+                sb = Batch(x=x.detach().clone(), edge_index=ei.clone(), edge_attr=ea.clone(), batch=bv.clone())
+                ng = getattr(d, "num_graphs", None)
+                if ng is not None:
+                    sb.num_graphs = ng
+                st.static.append(sb)
+        else:
+            for k, (x, _ei, _ea, _bv) in enumerate(fields):
+                sig = st.x_sig[k]
+                if sig is None or sig[0]() is not x or sig[1] != x._version:
+                    st.static[k].x.copy_(x)          # (a cached loader hands the same tensor object back, unwritten: nothing to copy)
+        # the OBJECT, not its address: a freed tensor's address comes back with other content
+        st.x_sig = [(weakref.ref(f[0]), f[0]._version) for f in fields]
         if st.fwd is None:
-            free, total = torch.cuda.mem_get_info(x.device)
+            free, total = torch.cuda.mem_get_info(fields[0][0].device)
             if st.visits < 3 or free < total // 4:
                 # second visit: eagerly on the private static copy (ITS index tensors are staged here: one validation sync)
                 with no_graphed_call():
-                    return eager_forward(st.static)
+                    return eager_forward(*st.static)
             self._capture(st, module, eager_forward, params)
         if st.bwd is None:
             st.fwd.replay()
@@ -391,12 +409,13 @@ class GraphedCallable:
         grad = torch.is_grad_enabled() and len(params) > 0
         # a NEW features tensor for the capture: whatever the eager visit derived from the old one and cached on it (the zero-padded copy
         # of the atom features, ops.pad_cols) must be recomputed INSIDE the graph — later calls bring other features
-        st.static.x = st.static.x.clone()
+        for sb in st.static:
+            sb.x = sb.x.clone()
         torch.cuda.synchronize()
         fwd = torch.cuda.CUDAGraph()
         if not grad:
             with torch.cuda.graph(fwd), no_graphed_call():
-                st.out = eager_forward(st.static)
+                st.out = eager_forward(*st.static)
             st.fwd = fwd
             return
         # The captured forward runs on PROXY leaves (detached aliases of the parameters: same storage, so optimizer updates show).  A
@@ -407,7 +426,7 @@ class GraphedCallable:
         names = [n for n, p in module.named_parameters() if p.requires_grad]
         proxies = tuple(p.detach().requires_grad_() for p in params)
         with torch.cuda.graph(fwd), no_graphed_call():
-            out = torch.func.functional_call(module, dict(zip(names, proxies)), (st.static,))
+            out = torch.func.functional_call(module, dict(zip(names, proxies)), tuple(st.static))
         st.fwd, st.out = fwd, out
         if out.requires_grad:
             st.gout = torch.zeros_like(out)
@@ -417,10 +436,10 @@ class GraphedCallable:
             st.bwd, st.params, st.grads = bwd, params, tuple(grads)
 
 
-def graphed_call(module, eager_forward, data):
-    """``eager_forward(data)`` through ``module``'s graphed-callable route (created on first use, stored outside the module's
+def graphed_call(module, eager_forward, *datas):
+    """``eager_forward(*datas)`` through ``module``'s graphed-callable route (created on first use, stored outside the module's
     parameters / buffers / submodules: state dicts and ``module.to()`` never see it)."""
     route = module.__dict__.get("_glam_graphed_route")
     if route is None:
         route = module.__dict__["_glam_graphed_route"] = GraphedCallable()
-    return route(module, eager_forward, data)
+    return route(module, eager_forward, *datas)

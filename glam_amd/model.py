@@ -102,6 +102,9 @@ class ArchitectureDTI(torch.nn.Module):
         self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
 
     def forward(self, data_mol, data_pro):
+        return graphs.graphed_call(self, self._eager_forward, data_mol, data_pro)      # (see Architecture.forward)
+
+    def _eager_forward(self, data_mol, data_pro):
         with ops.weight_scope():
             return self._forward(data_mol, data_pro)
 
@@ -152,6 +155,9 @@ class ArchitectureDDI(torch.nn.Module):
         self.lin_out1 = LinearBlock(e_dim, out_dim, norm=end_norm, dropout=end_do, act="_None")
 
     def forward(self, mol1, mol2):
+        return graphs.graphed_call(self, self._eager_forward, mol1, mol2)              # (see Architecture.forward)
+
+    def _eager_forward(self, mol1, mol2):
         with ops.weight_scope():
             return self._forward(mol1, mol2)
 

@@ -153,3 +153,35 @@ def test_training_mode_randomness_advances_between_replays(device):
     out = net(_fresh(b))
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_two_input_models_take_the_route_too(device):
+    """``ArchitectureDTI`` (ligand + protein) in the same unchanged loop: route on vs off over five visits of two pair batches — the same
+    trajectory within fp32 rounding (above 512 nodes a captured step sums the weight gradients of all applications of a block in one
+    product, the eager one per application), with graphs replayed."""
+    from glam_amd.data import synth_protein_batch
+    from tests.conftest import assert_close
+    torch.manual_seed(11)
+    net0 = model.ArchitectureDTI(graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU", e_dim=64).to(device)
+    pairs = [(synth_batch(4, seed=s).to(device), synth_protein_batch(4, seed=s + 10, n_min=40, n_max=90).to(device)) for s in (1, 2)]
+    ys = [torch.randn(4, device=device) for _ in pairs]
+    results = []
+    for routed in (False, True):
+        net = copy.deepcopy(net0)
+        net.graphed_call = routed
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        losses = []
+        for _epoch in range(5):
+            for (mol, pro), y in zip(pairs, ys):
+                opt.zero_grad()
+                loss = torch.nn.functional.mse_loss(net(_fresh(mol), _fresh(pro)).view(-1), y)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        if routed:
+            assert net.__dict__["_glam_graphed_route"].graphs() == 4
+        results.append((losses, [p.detach().clone() for p in net.parameters()]))
+    (l_e, p_e), (l_g, p_g) = results
+    assert np.allclose(l_e, l_g, rtol=2e-5, atol=1e-6), (l_e, l_g)
+    for a, r in zip(p_g, p_e):
+        assert_close(a, r, 2e-5, "parameter")
