@@ -663,7 +663,7 @@ static void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
 }
 
 static bool kc_route(const Product& p) {
-    static const bool on = [] { const char* e = getenv("GLAM_DENSE_KC"); return !e || atoi(e) != 0; }();
+    static const bool on = true;
     return on && p.a_ks == 1 && p.b_ks == 1 && !p.gate && !p.rowsum && p.K >= 8 && p.K % 4 == 0 && p.a_rs % 4 == 0 && p.b_cs % 4 == 0 &&
            aligned16(p.A) && aligned16(p.B);
 }

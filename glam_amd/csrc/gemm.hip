@@ -625,7 +625,7 @@ static int ts_plan(const TsArgs& a, int* variant, int* grid) {
     return GLAM_OK;
 }
 // the register-B form of the 192-column variant: one block per CU
-static bool ts_rb_enabled() { const char* e = getenv("GLAM_TS_RB"); return !e || atoi(e) != 0; }
+static bool ts_rb_enabled() { return true; }       // (the register-B form of the wide products: an A/B switch until round 5)
 static bool tall_x3_enabled() { const char* e = getenv("GLAM_TALL_X3"); return !e || atoi(e) != 0; }     // A/B switch of tall_x3.hip
 // GLAM_X3=0: the dense products stay on the fp32 matrix instructions (A/B switch, read per call)
 bool ts_x3_enabled() { const char* e = getenv("GLAM_X3"); return !e || atoi(e) != 0; }
@@ -691,10 +691,7 @@ int launch_ts_gemm(const TsArgs& a, hipStream_t s) { return launch_ts_gemm2(a, n
 
 constexpr int kWgradBlocks = 256;      // about one 8-wave block per CU: the right grid while the operands are cache resident
 constexpr int kWgradBlocksBig = 512;   // two per CU (four waves per SIMD) once they stream from HBM: B = 16 384: 169 vs 182 us, B = 1 024: 15.0 vs 14.4
-static int wgrad_big_rows() {      // (GLAM_WG_BIG_ROWS: A/B switch)
-    static const int v = [] { const char* e = getenv("GLAM_WG_BIG_ROWS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 131072; }();
-    return v;
-}
+static int wgrad_big_rows() { return 131072; }
 static int wgrad_budget(int N) { return N >= wgrad_big_rows() ? kWgradBlocksBig : kWgradBlocks; }
 
 size_t wgrad_workspace_floats() { return (size_t)(3 * 256 + 24) * kWgSlabStride; }     // per product: one 64 x 64 slab per (slab, split); k_wgrad_x3: <= 768

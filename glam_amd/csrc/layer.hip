@@ -711,7 +711,7 @@ extern "C" int glam_triplet_stage_params_bwd(const float* weight_node, const flo
 // 4-wave blocks per CU.  That wins while the launch is latency bound (B = 1024: 16.6 us against 9.7 + 11 + a launch boundary) and
 // loses once the batch is large enough for the aggregate to need its full occupancy (B = 16 384: 249 us fused against 134 + 62).
 static int64_t fuse_max_nodes() {
-    static const int64_t v = [] { const char* e = getenv("GLAM_FUSE_MAX_NODES"); return e ? atoll(e) : (int64_t)1 << 40; }();
+    static const int64_t v = (int64_t)1 << 40;
     return v;
 }
 
@@ -816,7 +816,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     WgArgs w2{d_xw, HC, HC, d_a, 8, 8, 0, x, Cp, Cp, 0, (int)N, 0, wg2, 0, 0};
     // main chain: d_aggr = d_out @ Ws_p^T -> B1 -> B2
     // (inside B1 where a fused variant exists: one launch and one [N, HC] round trip less)
-    static const bool fuse_dagg_on = [] { const char* e = getenv("GLAM_FUSE_DAGG"); return !e || atoi(e) != 0; }();
+    static const bool fuse_dagg_on = true;
     const bool fuse_dagg = fuse_dagg_on && triplet_bwd_can_fuse_dagg(H, Cp, Dp);
     if (!fuse_dagg) {
         TsArgs g1{d_out, Cp, Cp, nullptr, 0, 0, staged + L.img_dagg, nullptr, d_aggr, HC, HC, nullptr, 0, 0, (int)N};

@@ -113,7 +113,7 @@ class GraphIndex:
 
     # the pipelined forward pays off once xw + aggr (2 * N * H * Cp * 4 bytes) no longer fit the 256 MiB LLC (measured crossover:
     # B = 8 192 -> 0.59 general vs 0.55 pipelined; B = 16 384 -> 0.44-0.48 vs 0.56-0.64 of the HBM peak); ELL_MIN_NODES overrides
-    ELL_MIN_NODES = int(os.environ.get("GLAM_ELL_MIN_NODES", "-1"))
+    ELL_MIN_NODES = -1          # (>= 0: a node count from which the ELL form is wanted regardless of the LLC)
     LLC_BYTES = 256 << 20
 
     @classmethod
@@ -526,7 +526,7 @@ def fused_layer_supported(C, heads, De):
 # backward receives the gradients accumulated by the later applications, adds its own flat gradient buffer (one add), and
 # hands the sum on; the bundle's backward splits the total into per-parameter views.  Works for .backward() and
 # autograd.grad alike; outside a scope (or without grad) the ops return per-parameter gradients as before.
-GRAD_CARRY = os.environ.get("GLAM_GRAD_CARRY", "1") == "1"
+GRAD_CARRY = True            # (module switches like this one are attributes, not environment variables: the tests flip them in place)
 
 
 class _ParamBundle(torch.autograd.Function):
@@ -1142,26 +1142,26 @@ def rows_are_one_hot(t):
 
 
 # ---- knobs of the dense / readout operators (glam_amd/ops_dense.py, ops_readout.py read them through this module) ----
-GEMM_PAIR = os.environ.get("GLAM_GEMM_PAIR", "1") == "1"     # A/B knob: the GRU's two products per direction in one launch
+GEMM_PAIR = True     # A/B knob: the GRU's two products per direction in one launch
 # Gate GEMMs + gate math + tail of the forward GRU step in ONE launch (glam_gru_fused_fwd, bit-identical to the pair launch + tail
 # kernel, tested).  Its work item is coarse (a 16-row tile x both products x all three gates) and its epilogue runs at the chip's write
 # bandwidth, so it pays once a wave has several tiles to pipeline: model step at B = 8 192 3.90 vs 4.08 ms, B = 1 024 0.807 vs 0.814 ms,
 # B = 32 0.384 vs 0.370 ms (the 96 KB of weight images per block dominate).  "auto": from GRU_FUSED_MIN_NODES nodes on.
-GRU_FUSED = os.environ.get("GLAM_GRU_FUSED", "auto")
+GRU_FUSED = "auto"
 GRU_FUSED_MIN_NODES = 16384
 # The same step warp-specialised on the bf16 matrix cores in 3 x bf16 form (glam_gru_ws_fwd: fp32 accuracy, different roundings than the
 # fp32 launches above; 24 <= C <= 64): the default where it applies.
-GRU_WS = os.environ.get("GLAM_GRU_WS", "1")
+GRU_WS = "1"
 # MessageBlock's skip connection handed through the conv's autograd node (the d_x product's epilogue sums both gradient paths): A/B switch
-SKIP_THROUGH_CONV = os.environ.get("GLAM_SKIP_THROUGH_CONV", "1") == "1"
+SKIP_THROUGH_CONV = True
 # the GRU's weight gradients of all applications of a block in one launch pair (glam_wgrad_gemm_pair_split_seg): A/B switch
-GRU_WGRAD_BATCH = os.environ.get("GLAM_GRU_WGRAD_BATCH", "1") == "1"
+GRU_WGRAD_BATCH = True
 # PairNorm + the Dropout behind it from one launch each way (glam_graph_norm_drop_*): A/B switch
-NORM_DROP = os.environ.get("GLAM_NORM_DROP", "1") == "1"
+NORM_DROP = True
 # the derived weights of a model pass from one launch (glam_prestage) instead of one per module: A/B switch
-PRESTAGE = os.environ.get("GLAM_PRESTAGE", "1") == "1"
+PRESTAGE = True
 # the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch
-DENSE_LINEAR = os.environ.get("GLAM_DENSE_LINEAR", "1") == "1"
+DENSE_LINEAR = True
 
 
 # ---- the dense and readout operator families live in their own modules; their names are part of this namespace ----

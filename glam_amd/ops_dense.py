@@ -484,7 +484,7 @@ def linear_dense_supported(N, K, M):
     """The class of ``csrc/dense_x3.hip`` that beats the GEMM library inside a model step: the readout MLP 5 * hid_dim -> 1024 with rows
     that are multiples of 16 bytes (hid_dim 60: 300 columns).  The kernel takes any shape, but with partial quads (K = 75, 150, 225,
     450: the other hidden widths) or scalar output stores (the 617-task head) the model step measured 1-17 us SLOWER than on the
-    library (``tools/bench_model.py --alpha``, A/B ``GLAM_DENSE_LINEAR``), so those stay there."""
+    library (``tools/bench_model.py --alpha``, A/B ``ops.DENSE_LINEAR``), so those stay there."""
     return K % 4 == 0 and M % 4 == 0 and K >= 32 and N >= 4
 
 
@@ -745,7 +745,7 @@ def _gru_padded(w_ih, w_hh, b_ih, b_hh, C, Cp):
 
 
 def _want_gru_ws(lib, N, C):
-    """The warp-specialised 3 x bf16 GRU step (GLAM_GRU_WS, default on; GLAM_X3=0 keeps every dense product on the fp32 matrix cores)."""
+    """The warp-specialised 3 x bf16 GRU step (``ops.GRU_WS``, default on; GLAM_X3=0 keeps every dense product on the fp32 matrix cores)."""
     return N > 0 and _o.GRU_WS == "1" and _lib.route_enabled("x3") and lib.glam_gru_ws_supported(C) == 1
 
 

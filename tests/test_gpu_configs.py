@@ -215,16 +215,34 @@ def test_config4_two_process_data_parallel_step_on_the_hip_model(device):
     ranks share device 0 and the collective runs on gloo (RCCL refuses two ranks on one device) — same code path above the
     backend.  The children are fresh interpreters started before they touch the GPU."""
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PYTHONPATH=ROOT,
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = []
-    for r in range(2):
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py")],
-                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+
+    def run_once():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PYTHONPATH=ROOT, PYTHONFAULTHANDLER="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = []
+        for r in range(2):
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py")],
+                                          env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs, hung = [], False
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=240)[0].decode())
+            except subprocess.TimeoutExpired:      # a hung rank: kill both and show what they printed (not the driver's whole time limit)
+                hung = True
+                for q in procs:
+                    q.kill()
+                outs.append("TIMEOUT\n" + p.communicate()[0].decode())
+        return procs, outs, hung
+
+    # (three processes on one device — this one and two fresh interpreters initialising the runtime at the same moment — have hung in the
+    #  rendezvous on some boxes, roughly one run in three on a bad one; a hung attempt is killed after four minutes and repeated once)
+    procs, outs, hung = run_once()
+    if hung:
+        print("first attempt hung:\n" + "\n".join(outs))
+        procs, outs, hung = run_once()
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DP-OK" in outs[0], outs[0]
 
@@ -241,7 +259,14 @@ def test_bench_multi_rank_path_runs_as_a_fresh_subprocess(device, extra):
         env["GLAM_BENCH_SHARE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "32", "--warmup", "4", "--cpu-seconds", "0",
            "--large-batch", "0", "--prof-reps", "2"] + extra
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    for attempt in range(2):       # (a hung rendezvous of the child ranks is killed after five minutes and repeated once: see the test above)
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            break
+        except subprocess.TimeoutExpired as exc:
+            print(f"attempt {attempt} hung: {(exc.stderr or b'').decode()[-1000:]}")
+            if attempt == 1:
+                raise
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
