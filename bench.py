@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def step_kernel_model(N, E, H=3, C=60, De=4):
+def step_kernel_model(N, E, H=3, C=60, De=4, x3=True):
     """Algorithmic (compulsory) HBM bytes and dense flops per launch of every kernel of the step: fp32 + int32 CSR, every
     tensor once.  Keys are the labels glam_prof_* reports."""
     HC, f = H * C, 4
@@ -74,9 +74,10 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "d_aggr+k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
                                      "note": "backward by target with the d_aggr GEMM fused in (one launch and one kernel boundary less)"},
         "k_triplet_bwd_src+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C},
-        "d_aggr+k_triplet_bwd_dst_ws": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
+        # the 3 x bf16 form (the default) does not read aggr: sum_e alpha_e d_alpha_e comes from the node's own edges (round 5)
+        "d_aggr+k_triplet_bwd_dst_ws": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC) - (f * N * HC if x3 else 0), "flops": 2 * N * C * HC,
                                         "note": "warp-specialised backward by target: matrix waves produce the d_aggr tiles ahead of the vector waves "
-                                                "(csrc/triplet_ws_b1.hip)"},
+                                                "(csrc/triplet_ws_b1.hip); reads xw (gather), d_out, a_ij, stats, edge records — aggr only with GLAM_X3=0"},
         "k_triplet_bwd_src_ws+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C,
                                     "note": "warp-specialised backward by source with the d_x GEMM as the consumers' product (csrc/triplet_ws.hip)"},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},
@@ -517,7 +518,9 @@ def main():
     if rank == 0:
         # ---- roofline: per-dispatch durations of the kernels the timed step launches (same process, same stream, the function
         #      the graph captured, issued eagerly so that every launch can carry its own begin / end events) ----
-        model = step_kernel_model(N, E, H, C, De)
+        from glam_amd import _lib as _glib
+        x3_on = _glib.route_enabled("x3")
+        model = step_kernel_model(N, E, H, C, De, x3=x3_on)
         prof = profile_step(compute, args.prof_reps)
         kernels = {}
         for name, rec in sorted(prof.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
@@ -568,7 +571,7 @@ def main():
                     out = conv(xb, big.edge_index, big.edge_attr)
                     live["big"] = torch.autograd.grad(out, params + [xb], grad_outputs=cb)
 
-            mb = step_kernel_model(Nb, Eb, H, C, De)
+            mb = step_kernel_model(Nb, Eb, H, C, De, x3=x3_on)
             # 40 untimed steps (~30 ms) first: the device idled while the batch was synthesised on the host, and its clocks take longer than
             # three steps to come back (the same kernels read 20 % slower with warm = 3 than in a dedicated --batch 16384 run)
             pb = profile_step(compute_big, max(5, args.prof_reps // 3), warm=40)

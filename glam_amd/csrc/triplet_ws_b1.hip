@@ -263,8 +263,10 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             sc.ai = ldf(a.a_ij, n * 32u + 4u * (unsigned)hc);
             sc.m = ldf(a.stats, n * 32u + 4u * (unsigned)hc);
             sc.s = ldf(a.stats, n * 32u + 16u + 4u * (unsigned)hc);
+            if constexpr (!X3) {       // (the 3 x bf16 form takes sum_e alpha_e d_alpha_e from the edges themselves: compute_b)
 #pragma unroll
-            for (int h = 0; h < H; ++h) agr[h] = ld4o(a.aggr, n * row_bytes + (unsigned)h * head_bytes + qoff);
+                for (int h = 0; h < H; ++h) agr[h] = ld4o(a.aggr, n * row_bytes + (unsigned)h * head_bytes + qoff);
+            }
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 if (k < dmax) {
@@ -324,13 +326,15 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 #pragma unroll
                     for (int h = 0; h < H; ++h) st4o(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
                 }
+                if constexpr (!X3) {
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>
-                    float part = 0.f;
-                    part += dot4(dag[h], agr[h]);
-                    const float d = group_sum<16>(part);
-                    dotq = hc == h ? d : dotq;
+                    for (int h = 0; h < H; ++h) {
+                        // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>
+                        float part = 0.f;
+                        part += dot4(dag[h], agr[h]);
+                        const float d = group_sum<16>(part);
+                        dotq = hc == h ? d : dotq;
+                    }
                 }
                 // ---- row phase: d_alpha[k][h] = <d_aggr[n,h,:], e_ij * xw[src_k,h,:]>, d_W_edge[type_k][h] += alpha * d_aggr * xw ----
                 if (deg > 0) {
@@ -386,7 +390,16 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             const int deg = __popcll((bal >> (16 * j)) & 0xFull);
             const bool valid = node_ok && kk < deg;
             const bool live = valid && hh < H;
-            const float dl = h_alpha * (h_dal - h_dot);
+            // softmax backward: d_logit_e = alpha_e (d_alpha_e - S), S = sum over the node's edges of alpha_e' d_alpha_e'.  The fp32 form
+            // (GLAM_X3=0: bit-identical to the general kernel) takes S as <d_aggr[n,h,:], aggr[n,h,:]> — the same number, since aggr is that
+            // weighted sum — which costs a second [N, H, Cp] row read per node; the default form sums the node's (at most four) products
+            // where they already sit, in the quad of lanes (j, hh, 0..3): B1 no longer reads aggr at all (-28 % of its bytes)
+            float S = h_dot;
+            if constexpr (X3) {
+                const float pq = live ? h_alpha * h_dal : 0.f;
+                S = ((dpp_f<0x00>(pq) + dpp_f<0x55>(pq)) + dpp_f<0xAA>(pq)) + dpp_f<0xFF>(pq);
+            }
+            const float dl = h_alpha * (h_dal - S);
             float dp = h_pre > 0.f ? dl : dl * a.slope;
             dp = live ? dp : 0.f;
             const float al_st = live ? h_alpha : 0.f;
