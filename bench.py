@@ -55,7 +55,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4, x3=True):
     HC, f = H * C, 4
     img = lambda K, M: ((K + 15) // 16 * 16) * (64 if M <= 64 else 192) * f      # weight image of a k_ts_gemm launch
     agg_fwd = f * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H)        # xw, aggr, edge_attr, src+eid, rowptr, a_ij, stats
-    b1 = f * (3 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H + 2 * E * H + N * H)
+    # backward by target: xw (gather) + d_aggr; aggr is not read any more (round 5: sum_e alpha_e d_alpha_e comes from the node's own edges
+    # whenever they fit one chunk of four — always, for molecules; GLAM_X3=0 is bit-identical, it does not bring the read back)
+    b1 = f * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * N * H + 2 * N * H + 2 * E * H + N * H)
     b2 = f * (2 * N * HC + E * De + 2 * E + (N + 1) + 2 * E * H + N * H)
     return {
         "k_stage_params": {"bound": "latency", "bytes": f * (C * HC + De * HC + 3 * HC + HC * C + C) + img(C, HC + 8) + img(HC, C) + img(C, HC) + img(HC + 8, C)},
@@ -74,10 +76,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4, x3=True):
         "d_aggr+k_triplet_bwd_dst": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
                                      "note": "backward by target with the d_aggr GEMM fused in (one launch and one kernel boundary less)"},
         "k_triplet_bwd_src+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C},
-        # the 3 x bf16 form (the default) does not read aggr: sum_e alpha_e d_alpha_e comes from the node's own edges (round 5)
-        "d_aggr+k_triplet_bwd_dst_ws": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC) - (f * N * HC if x3 else 0), "flops": 2 * N * C * HC,
+        "d_aggr+k_triplet_bwd_dst_ws": {"bound": "hbm", "bytes": b1 + f * N * C + img(C, HC), "flops": 2 * N * C * HC,
                                         "note": "warp-specialised backward by target: matrix waves produce the d_aggr tiles ahead of the vector waves "
-                                                "(csrc/triplet_ws_b1.hip); reads xw (gather), d_out, a_ij, stats, edge records — aggr only with GLAM_X3=0"},
+                                                "(csrc/triplet_ws_b1.hip); reads xw (gather), d_out, a_ij, stats, edge records"},
         "k_triplet_bwd_src_ws+dx": {"bound": "hbm", "bytes": b2 + f * N * C + img(HC + 8, C), "flops": 2 * N * (HC + 8) * C,
                                     "note": "warp-specialised backward by source with the d_x GEMM as the consumers' product (csrc/triplet_ws.hip)"},
         "k_triplet_bwd_src": {"bound": "hbm", "bytes": b2},

@@ -464,15 +464,26 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
       const int beg = ldio(a.rowptr, (unsigned)nc * 4u), end = ldio(a.rowptr, (unsigned)nc * 4u + 4u);
       const float4 aiv = ld4o(a.a_ij, (unsigned)nc * 32u);
       const float4 mv = ld4o(a.stats, (unsigned)nc * 32u), sv = ld4o(a.stats, (unsigned)nc * 32u + 16u);
+      // sum_e alpha_e * d_alpha_e of the softmax backward: a node whose edges fit ONE chunk (every atom of a molecule) sums the products
+      // where they are computed, in the chunk loop below; only a node with more edges takes the identity
+      // sum_e alpha_e d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]> and reads its aggr row for it (round 5: B1 no longer reads aggr for
+      // molecular graphs, a quarter of its bytes; the warp-specialised kernel does the same in its quad lanes)
+      constexpr int CH = ITER == 1 ? GLAM_B1_CH : 2;   // edges per chunk: all loads of a chunk in flight together
+      const bool many = end - beg > CH;
       float4 dag[H][ITER], agr[H][ITER];
 #pragma unroll
       for (int h = 0; h < H; ++h)
 #pragma unroll
           for (int it = 0; it < ITER; ++it) {
-              const unsigned off = (unsigned)nc * row_bytes + (unsigned)h * head_bytes + chunk_off[it];
-              agr[h][it] = ld4o(a.aggr, off);
-              if constexpr (!FD) dag[h][it] = ok[it] ? ld4o(a.d_aggr, off) : f4zero();
+              agr[h][it] = f4zero();
+              if constexpr (!FD) dag[h][it] = ok[it] ? ld4o(a.d_aggr, (unsigned)nc * row_bytes + (unsigned)h * head_bytes + chunk_off[it]) : f4zero();
           }
+      if (many) {                                               // (one branch around all of them: in flight together)
+#pragma unroll
+          for (int h = 0; h < H; ++h)
+#pragma unroll
+              for (int it = 0; it < ITER; ++it) agr[h][it] = ld4o(a.aggr, (unsigned)nc * row_bytes + (unsigned)h * head_bytes + chunk_off[it]);
+      }
       if constexpr (FD) {
         // ---- d_aggr tile = d_out[base .. base+16, :] @ W_scale^T: wave w owns column tile t = w of every 64-column group ----
         const int wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
@@ -539,11 +550,10 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
                 }
                 part += dot4(dag[h][it], agr[h][it]);
             }
-            // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>  (aggr is the alpha-weighted sum)
+            // (nodes with more than one chunk of edges) sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>
             dot[h] = group_sum<G>(part);
         }
         B1_STAMP(1);
-        constexpr int CH = ITER == 1 ? GLAM_B1_CH : 2;   // edges per chunk: all loads of a chunk in flight together
         for (int e0 = beg; e0 < end; e0 += CH) {
             int sidx[CH], eidx[CH];
             bool val[CH];
@@ -610,11 +620,19 @@ __global__ void __launch_bounds__(kBlock, (FD && DE == 4) ? 2 : GLAM_B1_WAVES) k
                         }
                     }
                 }
+                float dal[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) dal[k] = val[k] ? group_sum<G>(part[k]) : 0.f;
+                float S = dot[h];
+                if (!many) {                                    // ((p0 + p1) + p2) + p3, an absent edge adds an exact zero
+                    S = val[0] ? alpha[0][h] * dal[0] : 0.f;
+#pragma unroll
+                    for (int k = 1; k < CH; ++k) S += val[k] ? alpha[k][h] * dal[k] : 0.f;
+                }
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     if (!val[k]) continue;
-                    const float dalpha = group_sum<G>(part[k]);
-                    const float dl = alpha[k][h] * (dalpha - dot[h]);
+                    const float dl = alpha[k][h] * (dal[k] - S);
                     dp[k][h] = pre[k][h] > 0.f ? dl : dl * a.slope;
                     dai[h] += dp[k][h];
 #pragma unroll

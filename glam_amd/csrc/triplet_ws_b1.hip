@@ -233,15 +233,13 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         };
         // per-edge / per-node scalars of the lane's (edge, head), loaded by the lane itself one pass ahead
         struct Scal { float aj, ai, m, s; float4 ea; };
-        float4 rows[CH][H], agr[H];
+        float4 rows[CH][H];
         Scal sc;
         sc.aj = sc.ai = sc.m = sc.s = 0.f; sc.ea = f4zero();
 #pragma unroll
         for (int k = 0; k < CH; ++k)
 #pragma unroll
             for (int h = 0; h < H; ++h) rows[k][h] = f4zero();
-#pragma unroll
-        for (int h = 0; h < H; ++h) agr[h] = f4zero();
         auto ldf = [](const float* base, unsigned byte_off) {      // scalar-base + 32-bit offset addressing (see ld4o)
             return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
         };
@@ -263,10 +261,6 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             sc.ai = ldf(a.a_ij, n * 32u + 4u * (unsigned)hc);
             sc.m = ldf(a.stats, n * 32u + 4u * (unsigned)hc);
             sc.s = ldf(a.stats, n * 32u + 16u + 4u * (unsigned)hc);
-            if constexpr (!X3) {       // (the 3 x bf16 form takes sum_e alpha_e d_alpha_e from the edges themselves: compute_b)
-#pragma unroll
-                for (int h = 0; h < H; ++h) agr[h] = ld4o(a.aggr, n * row_bytes + (unsigned)h * head_bytes + qoff);
-            }
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 if (k < dmax) {
@@ -280,7 +274,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 
         float dMq[4] = {0.f, 0.f, 0.f, 0.f};                  // d_M[bond type][head hh of this lane]
         // what the first half of a pass hands to the second (across the prefetch of the next pass)
-        float h_pre = 0.f, h_alpha = 0.f, h_dal = 0.f, h_dot = 0.f;
+        float h_pre = 0.f, h_alpha = 0.f, h_dal = 0.f;
         int h_t = 0;
         // first half: phases that need the gathered rows
         auto compute_a = [&](auto dm_tag, int pass, int it_, int rs) {
@@ -319,22 +313,12 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 #pragma unroll
                 for (int h = 0; h < H; ++h) dag[h] = f4zero();
             }
-            float dotq = 0.f, dalq = 0.f;
+            float dalq = 0.f;
             if (node_ok) {
                 if (qok) {
                     const unsigned orow = (unsigned)n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
                     for (int h = 0; h < H; ++h) st4o(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
-                }
-                if constexpr (!X3) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        // sum_e alpha_e * d_alpha_e == <d_aggr[n,h,:], aggr[n,h,:]>
-                        float part = 0.f;
-                        part += dot4(dag[h], agr[h]);
-                        const float d = group_sum<16>(part);
-                        dotq = hc == h ? d : dotq;
-                    }
                 }
                 // ---- row phase: d_alpha[k][h] = <d_aggr[n,h,:], e_ij * xw[src_k,h,:]>, d_W_edge[type_k][h] += alpha * d_aggr * xw ----
                 if (deg > 0) {
@@ -369,7 +353,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                     }
                 }
             }
-            h_dot = dotq; h_dal = dalq;
+            h_dal = dalq;
         };
         auto compute_a_any = [&](int pass, int it_, int rs) {
             const unsigned long long bal = __ballot(rs >= 0) & 0x000F000F000F000Full;
@@ -390,15 +374,12 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             const int deg = __popcll((bal >> (16 * j)) & 0xFull);
             const bool valid = node_ok && kk < deg;
             const bool live = valid && hh < H;
-            // softmax backward: d_logit_e = alpha_e (d_alpha_e - S), S = sum over the node's edges of alpha_e' d_alpha_e'.  The fp32 form
-            // (GLAM_X3=0: bit-identical to the general kernel) takes S as <d_aggr[n,h,:], aggr[n,h,:]> — the same number, since aggr is that
-            // weighted sum — which costs a second [N, H, Cp] row read per node; the default form sums the node's (at most four) products
-            // where they already sit, in the quad of lanes (j, hh, 0..3): B1 no longer reads aggr at all (-28 % of its bytes)
-            float S = h_dot;
-            if constexpr (X3) {
-                const float pq = live ? h_alpha * h_dal : 0.f;
-                S = ((dpp_f<0x00>(pq) + dpp_f<0x55>(pq)) + dpp_f<0xAA>(pq)) + dpp_f<0xFF>(pq);
-            }
+            // softmax backward: d_logit_e = alpha_e (d_alpha_e - S), S = sum over the node's edges of alpha_e' d_alpha_e', summed where the
+            // (at most four) products already sit: the quad of lanes (j, hh, 0..3), in the order of the general kernel's one-chunk nodes
+            // (bit-identical to it with GLAM_X3=0).  Until round 5 S was taken as <d_aggr[n,h,:], aggr[n,h,:]> — the same number, aggr being
+            // that weighted sum — at the price of a second [N, H, Cp] row read per node: B1 no longer reads aggr (-28 % of its bytes)
+            const float pq = live ? h_alpha * h_dal : 0.f;
+            const float S = ((dpp_f<0x00>(pq) + dpp_f<0x55>(pq)) + dpp_f<0xAA>(pq)) + dpp_f<0xFF>(pq);
             const float dl = h_alpha * (h_dal - S);
             float dp = h_pre > 0.f ? dl : dl * a.slope;
             dp = live ? dp : 0.f;
