@@ -62,7 +62,8 @@ __device__ long long g_ws_tl[2 * 256 * 12 * 6];      // [kernel: forward | backw
 // (Two tiles per trip with alternating accumulator chains — a 16x16x4 fp32 MFMA issues every 32 cycles but feeds the next one of its own
 // chain only after 40 — measured SLOWER: 143 vs 136 us for the forward at B = 16 384.  Back-to-back MFMAs take the issue slots the two
 // producer waves of the SIMD need; the single chain's gaps are where their vector instructions go.)
-__device__ __forceinline__ void ws_consume(const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
+template <class Stage>      // stage(): the block's LDS staging, run behind this wave's weight loads (see k_triplet_fwd_ws)
+__device__ __forceinline__ void ws_consume(Stage stage, const float* img, const float* bias_p, float* out, int N, int Cp, int K, int LDT,
                                            const int* s_ready, int* s_taken, const float* s_ring, int ntiles, int w, int lane WS_PROF_PARAMS) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int c = lane & 15, kq = lane >> 4;
@@ -73,6 +74,7 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 #pragma unroll
     for (int g = 0; g < 12; ++g) bf[g] = g < GK ? ld4(img + ((size_t)(4 * g + kq) * 64 + pos) * 4) : f4zero();
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
+    stage();
     __syncthreads();                                          // the block's only barrier (LDS flags / W_edge staged): the loads above fly under it
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
@@ -119,8 +121,8 @@ __device__ __forceinline__ void ws_consume(const float* img, const float* bias_p
 // has in flight — i.e. for the previous tile's stores: B2 went 122 -> 164 us at B = 16 384 when this was a run-time option).  The next
 // tile's addend rows are requested BEFORE this tile's stores and the loop runs over full tiles only (four unconditional stores per lane:
 // the wait for the rows can leave exactly those in flight); the ragged last tile is handled behind it.
-template <int RING, bool ADD = false>
-__device__ __forceinline__ void ws_consume_x3(const float* img, const float* bias_p, float* out, int N, int Cp, int K,
+template <int RING, bool ADD = false, class Stage>
+__device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, const float* bias_p, float* out, int N, int Cp, int K,
                                               const int* s_ready, int* s_taken, const char* s_ring, int ntiles, int w, int lane,
                                               const float* addend = nullptr) {
     const int c = lane & 15, kb = lane >> 4;
@@ -135,6 +137,7 @@ __device__ __forceinline__ void ws_consume_x3(const float* img, const float* bia
         WRaw8 raw[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) raw[s] = w_load8(img, 64, pos, 32 * s + 8 * kb, Kp);
+        stage();      // (the block's LDS staging: its W_edge load flies with the weight slice, the split waits for both)
 #pragma unroll
         for (int s = 0; s < 6; ++s) wreg[s] = w_split8(raw[s], 32 * s + 8 * kb, Kp);
     }
@@ -233,6 +236,10 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     float* s_ring = s_meta + P * 2 * kSideF;                  // kWsRing tiles of 16 x LDT floats (X3: kRingN tiles of kX3TileBytes)
     constexpr int kRingN = X3 ? kWsRingX3 : kWsRing;
     WS_TL(0, 0);
+    // LDS staging, called by each role BEHIND its first global loads (the producers' first record): the W_edge load then flies together
+    // with them instead of ahead of them — at the start of a launch every first touch is a ~2 000-cycle miss, and the prologue was two of
+    // them back to back
+    auto stage_lds = [&]() {
     for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) {
         if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
@@ -248,6 +255,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
             st4(reinterpret_cast<float*>(reinterpret_cast<char*>(s_ring) + row * kX3RowBytes + 16 * ch), f4zero());
         }
     }
+    };
     // the block's only barrier sits BEHIND each role's first global loads (ws_consume; the producers' first record + prefetch below)
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
@@ -256,8 +264,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
-        if constexpr (X3) ws_consume_x3<kRingN>(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
-        else ws_consume(a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        if constexpr (X3) ws_consume_x3<kRingN>(stage_lds, a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
+        else ws_consume(stage_lds, a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         WS_TL(0, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WS_TL(0, 5);
@@ -442,6 +450,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int rs_nxt, re_nxt;
     int pass = gw;
     load_rec(pass, rs_nxt, re_nxt);
+    stage_lds();
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
     int deg_a, dmax_a, deg_b = 0, dmax_b = 0;
     prefetch(pass, rs_nxt, re_nxt, 0, rows_a, deg_a, dmax_a);
@@ -529,6 +538,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     float* s_ring = s_meta + P * 2 * kSideF;
     constexpr int kRingN = X3 ? kWsRingX3 : kWsRing;
     WS_TL(1, 0);
+    auto stage_lds = [&]() {      // called by each role behind its first global loads (see k_triplet_fwd_ws)
     for (int i = tid; i < DE * HC / 4; i += kWsBlock) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
     if (tid < 64) s_ready[tid] = 0;
     if constexpr (X3) {      // the k padding of every tile row (columns KX .. 191) must read as zero: cleared once (see k_triplet_fwd_ws)
@@ -538,13 +548,14 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
             st4(reinterpret_cast<float*>(reinterpret_cast<char*>(s_ring) + row * kX3RowBytes + 16 * ch), f4zero());
         }
     }
+    };
     const int ntiles = (a.N + 15) >> 4;
 #ifdef GLAM_WS_PROF
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        if constexpr (X3) ws_consume_x3<kRingN, ADD>(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
-        else ws_consume(a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
+        if constexpr (X3) ws_consume_x3<kRingN, ADD>(stage_lds, a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
+        else ws_consume(stage_lds, a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         WS_TL(1, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WS_TL(1, 5);
@@ -700,6 +711,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     int rs_nxt, re_nxt;
     int pass = gw;
     load_rec(pass, rs_nxt, re_nxt);
+    stage_lds();
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs_nxt), "+v"(re_nxt) : : "memory");
     int deg_a, dmax_a, deg_b = 0, dmax_b = 0;
     prefetch(pass, rs_nxt, re_nxt, 0, rows_a, deg_a, dmax_a);

@@ -61,12 +61,18 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     float* s_dw = smem + WL + 64;                             // per (vector wave, node row): d_W_edge [4][WP]
     float* s_ring = s_dw + V * 4 * WL;                        // kRing tiles of 16 x LDT floats
     B1_TL(0);
-    for (int i = tid; i < WSZ / 4; i += kBlockT) st4(s_w + (4 * i) / HC * WP + (4 * i) % HC, ld4(a.w_edge + 4 * i));
-    for (int i = tid; i < V * WL; i += kBlockT) st4(s_dw + 4 * i, f4zero());           // V * 4 arrays of WL floats
-    if (tid < 64) {
-        if ((tid >> 4) == 1) s_mt[tid & 15] = a.M[(tid & 3) * 4 + ((tid >> 2) & 3)];
-        else s_ready[tid] = 0;
-    }
+    // LDS staging, called by each role BEHIND its first global loads (see k_triplet_fwd_ws): the matrix waves' weight slice and first
+    // d_out rows, the vector waves' first record
+    auto stage_lds = [&]() {
+        const float4 wv = tid < WSZ / 4 ? ld4(a.w_edge + 4 * tid) : f4zero();         // (WSZ / 4 <= 192 < the block)
+        const float mv = (tid >> 4) == 1 ? a.M[(tid & 3) * 4 + ((tid >> 2) & 3)] : 0.f;
+        for (int i = tid; i < V * WL; i += kBlockT) st4(s_dw + 4 * i, f4zero());       // V * 4 arrays of WL floats: under the loads
+        if (tid < WSZ / 4) st4(s_w + (4 * tid) / HC * WP + (4 * tid) % HC, wv);
+        if (tid < 64) {
+            if ((tid >> 4) == 1) s_mt[tid & 15] = mv;
+            else s_ready[tid] = 0;
+        }
+    };
     const int ntiles = (a.N + 15) >> 4;       // (the barrier that publishes the LDS initialisation sits behind each role's first global loads)
 
     if (wave >= V) {
@@ -104,19 +110,13 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             //      instructions on the SIMD's one fp32 datapath ----
             const int Kp = (Cp + 15) & ~15;
             Bf16x3 wreg[2][3];
-            {
-                WRaw8 raw[2][3];
+            WRaw8 raw[2][3];
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
-                    const int mcol = min(16 * (3 * w + ct) + c, MP - 1);
-                    const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
+            for (int ct = 0; ct < 3; ++ct) {
+                const int mcol = min(16 * (3 * w + ct) + c, MP - 1);
+                const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) raw[st][ct] = w_load8(a.img_dagg, MP, pos, 32 * st + 8 * kq, Kp);
-                }
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) wreg[st][ct] = w_split8(raw[st][ct], 32 * st + 8 * kq, Kp, 16 * (3 * w + ct) + c < HC);
+                for (int st = 0; st < 2; ++st) raw[st][ct] = w_load8(a.img_dagg, MP, pos, 32 * st + 8 * kq, Kp);
             }
             auto load_a = [&](int tile, float4 (&af)[2][2]) {
                 const int row = 16 * tile + c;
@@ -132,7 +132,12 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             float4 af[2][2];
             int tile = blockIdx.x, it = 0;
             load_a(tile, af);
-            __syncthreads();                                  // LDS initialised; the weight slice and the first tile's rows are in flight
+            stage_lds();
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) wreg[st][ct] = w_split8(raw[st][ct], 32 * st + 8 * kq, Kp, 16 * (3 * w + ct) + c < HC);
+            __syncthreads();                                  // LDS initialised; the first tile's rows are in flight or here
             B1_TL(1);
             for (; tile < ntiles; tile += gridDim.x, ++it) {
                 Bf16x3 as[2];
@@ -179,6 +184,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         float4 af_a[4], af_b[4];
         int tile = blockIdx.x, it = 0;
         load_a(tile, af_a);
+        stage_lds();
         __syncthreads();                                      // LDS initialised; the weight slice and the first tile's rows are in flight
         auto one_tile = [&](int it_, const float4 (&af)[4]) {
             wait_slot(it_);
@@ -403,6 +409,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         int rs, re, rs_n, re_n;
         int pass = gw;
         load_rec(pass, rs, re);
+        stage_lds();
         prefetch(pass, rs, re);
         load_rec(pass + GW, rs_n, re_n);
         __syncthreads();                                      // LDS initialised; the first pass's operands are in flight
