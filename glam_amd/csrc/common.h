@@ -97,6 +97,22 @@ __device__ __forceinline__ float4 ld4o(const float* base, unsigned byte_off) {
 __device__ __forceinline__ void st4o(float* base, unsigned byte_off, float4 v) {
     *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// The same store WRITTEN THROUGH the XCD's L2 (`sc1`, agent scope) — for the large output tensors of a launch.  Each XCD has its own
+// write-back L2 and the L2s are not coherent with each other: what a launch leaves dirty there goes out with the release at its end,
+// after the last wave, before the next launch may start (tools/ubench/store_policy.hip: 20 MB of plain stores cost a launch 0.6-0.8 us
+// that `sc1` stores do not; `nt` does not help).  The next launch starts with an invalidated L2 either way, so nothing is lost.
+// A raw buffer store rather than inline assembly: the compiler keeps counting it in vmcnt.
+typedef unsigned glam_v4u __attribute__((ext_vector_type(4)));
+// (`base` and `uniform_off` must be wave-uniform: they travel in scalar registers; byte_off is the lane's part)
+__device__ __forceinline__ void st4o_wt(float* base, unsigned byte_off, float4 v, unsigned uniform_off = 0) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(glam_v4u{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, (int)byte_off,
+                                           (int)uniform_off, 16);
+}
+__device__ __forceinline__ void stfo_wt(float* base, unsigned byte_off, float v, unsigned uniform_off = 0) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)uniform_off, 16);
+}
 __device__ __forceinline__ int ldio(const int* base, unsigned byte_off) {
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off);
 }

@@ -42,8 +42,10 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 // Timeline stamps (-DGLAM_WS_TL, tools/ws_timeline.py): wave entry, prologue done, first publish, loop end, last stores issued, drained —
 // six per wave, none inside the steady loop (stamps there perturb a loop of this granularity: profiles/r5_wgrad_x3_forms.txt)
 #ifdef GLAM_WS_TL
-__device__ long long g_ws_tl[2 * 256 * 12 * 6];      // [kernel: forward | backward by source][block][wave][stamp]
-#define WS_TL(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_ws_tl[(((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k)] = clock64(); } while (0)
+__device__ long long g_ws_tl[2 * 256 * 12 * 6];      // [kernel: forward | backward by source][block][wave][stamp], shader clock of the CU
+__device__ long long g_ws_rt[2 * 256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter (the shader clocks of two CUs are not in step)
+#define WS_TL(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
+    g_ws_tl[i_] = clock64(); g_ws_rt[i_] = wall_clock64(); } } while (0)
 #else
 #define WS_TL(kid, k) do { } while (0)
 #endif
@@ -104,7 +106,7 @@ __device__ __forceinline__ void ws_consume(Stage stage, const float* img, const 
         if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
+                if (r0 + i < N) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, acc[i] + bias);
         }
         WSTAMP(2);
     }
@@ -181,13 +183,13 @@ __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, con
             float nx[4];
             load_add(min(tile + (int)gridDim.x, ntiles - 1), nx);          // the next tile's rows, ahead of this tile's stores
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[(size_t)(r0 + i) * Cp + colc] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
+            for (int i = 0; i < 4; ++i) stfo_wt(out, (unsigned)((r0 + i) * Cp + colc) * 4u, (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) ad[i] = nx[i];
         } else if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias;
+                if (r0 + i < N) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias);
         }
     }
     if constexpr (ADD) {
@@ -201,7 +203,7 @@ __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, con
             if (col < Cp) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
+                    if (r0 + i < N) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i]);
             }
         }
     }
@@ -427,9 +429,9 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         if (qok) {
             const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
-            for (int h = 0; h < H; ++h) st4o(a.aggr, orow + (unsigned)h * head_bytes, r_acc[h]);
+            for (int h = 0; h < H; ++h) st4o_wt(a.aggr, orow + (unsigned)h * head_bytes, r_acc[h]);
         }
-        if (q < 2) st4o(a.stats, (unsigned)r_n * 32u + (unsigned)q * 16u, r_ms);
+        if (q < 2) st4o_wt(a.stats, (unsigned)r_n * 32u + (unsigned)q * 16u, r_ms);
         r_n = -1;
     };
     // the rows in flight are (re)defined by an empty asm right after the pipeline's own vmcnt(0): the compiler retires its count of
@@ -690,9 +692,9 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         if (qok) {
             const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
-            for (int h = 0; h < H; ++h) st4o(a.d_xw, orow + (unsigned)h * head_bytes, r_acc[h]);
+            for (int h = 0; h < H; ++h) st4o_wt(a.d_xw, orow + (unsigned)h * head_bytes, r_acc[h]);
         }
-        if (q == 0) st4o(a.d_a_ij, (unsigned)r_n * 32u + 16u, r_da);
+        if (q == 0) st4o_wt(a.d_a_ij, (unsigned)r_n * 32u + 16u, r_da);
         r_n = -1;
     };
     auto settle = [&](float4 (&rows)[CH][H]) {
@@ -866,6 +868,9 @@ int triplet_fwd_ws(const float* xw, const float* a_ij, const float* edge_attr, c
 #ifdef GLAM_WS_TL
 extern "C" int glam_debug_ws_tl(long long* host_out, int n) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_ws_tl), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int glam_debug_ws_rt(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_ws_rt), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef GLAM_WS_PROF

@@ -28,7 +28,9 @@ namespace glam {
 
 #ifdef GLAM_WS_TL      // timeline stamps (tools/ws_timeline.py; see triplet_ws.hip): [block][wave][stamp]
 __device__ long long g_b1_tl[256 * 12 * 6];
-#define B1_TL(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_b1_tl[(blockIdx.x * 12 + (threadIdx.x >> 6)) * 6 + (k)] = clock64(); } while (0)
+__device__ long long g_b1_rt[256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter
+#define B1_TL(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (blockIdx.x * 12 + (threadIdx.x >> 6)) * 6 + (k); \
+    g_b1_tl[i_] = clock64(); g_b1_rt[i_] = wall_clock64(); } } while (0)
 #else
 #define B1_TL(k) do { } while (0)
 #endif
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                 if (qok) {
                     const unsigned orow = (unsigned)n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
-                    for (int h = 0; h < H; ++h) st4o(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
+                    for (int h = 0; h < H; ++h) st4o_wt(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
                 }
                 // ---- row phase: d_alpha[k][h] = <d_aggr[n,h,:], e_ij * xw[src_k,h,:]>, d_W_edge[type_k][h] += alpha * d_aggr * xw ----
                 if (deg > 0) {
@@ -400,10 +402,10 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             dv.x = dp; dv.y = dpp_f<0x104>(dp); dv.z = dpp_f<0x108>(dp); dv.w = dpp_f<0x10C>(dp);
             da.x = dai; da.y = dpp_f<0x104>(dai); da.z = dpp_f<0x108>(dai); da.w = dpp_f<0x10C>(dai);
             if (q < 4 && valid) {
-                st4o(a.alpha_e, (unsigned)re * 16u, av);
-                st4o(a.dpre_e, (unsigned)re * 16u, dv);
+                st4o_wt(a.alpha_e, (unsigned)re * 16u, av);
+                st4o_wt(a.dpre_e, (unsigned)re * 16u, dv);
             }
-            if (q == 0 && node_ok) st4o(a.d_a_ij, (unsigned)n * 32u, da);
+            if (q == 0 && node_ok) st4o_wt(a.d_a_ij, (unsigned)n * 32u, da);
         };
 
         int rs, re, rs_n, re_n;
@@ -521,5 +523,8 @@ int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_att
 #ifdef GLAM_WS_TL
 extern "C" int glam_debug_b1_tl(long long* host_out, int n) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_b1_tl), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int glam_debug_b1_rt(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_b1_rt), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 #endif

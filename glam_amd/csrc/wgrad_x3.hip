@@ -226,11 +226,11 @@ __global__ void __launch_bounds__(kWxThreads) k_wgrad_x3(WgArgs2 two) {
     for (int u = 0; u < 3; ++u) {
         const int T = 3 * w + u, slab = grp * kWxSlabs + (T >> 2), ti = T & 3;
         if (slab >= a.ntile) continue;                     // (a group's slabs beyond the product: zero columns, nothing to store)
-        float* out = a.partial + ((size_t)slab * a.nsplit + split) * kWgSlabStride;
+        float* out = a.partial + ((size_t)__builtin_amdgcn_readfirstlane(slab) * a.nsplit + split) * kWgSlabStride;      // (wave-uniform)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
             const v4f_t v = master[u][tj] + (ca[u][tj] + cb[u][tj]);
-            st4(out + ((ti * 4 + tj) * 64 + lane) * 4, make_float4(v[0], v[1], v[2], v[3]));
+            st4o_wt(out, (unsigned)(((ti * 4 + tj) * 64 + lane) * 16), make_float4(v[0], v[1], v[2], v[3]));
         }
     }
 }

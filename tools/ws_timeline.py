@@ -42,11 +42,20 @@ tl = np.array(buf[:], dtype=np.int64).reshape(2, 256, 12, 6)
 buf1 = (ctypes.c_longlong * (256 * 12 * 6))()
 assert raw.glam_debug_b1_tl(buf1, len(buf1)) == 0
 tl1 = np.array(buf1[:], dtype=np.int64).reshape(256, 12, 6)
-clk = None
+bufr = (ctypes.c_longlong * (2 * 256 * 12 * 6))()
+assert raw.glam_debug_ws_rt(bufr, len(bufr)) == 0
+rt = np.array(bufr[:], dtype=np.int64).reshape(2, 256, 12, 6)
+bufr1 = (ctypes.c_longlong * (256 * 12 * 6))()
+assert raw.glam_debug_b1_rt(bufr1, len(bufr1)) == 0
+rt1 = np.array(bufr1[:], dtype=np.int64).reshape(256, 12, 6)
 
-def table(name, a, nprod, label, vector_first):
+def tl_valid(a):
+    return a[:, 0, 0] > 0
+
+def table(name, a, rt, nprod, label, vector_first):
     """a: [blocks, 12, 6]; the first `nprod` waves gather (or, B1: the first 8 are the vector waves), the rest run the matrix product"""
-    a = a[a[:, 0, 0] > 0]
+    a_all = a
+    a = a[tl_valid(a)]
     nb = len(a)
     t0 = a[:, :, 0].min(axis=1)[:, None]
     g, m = a[:, :nprod], a[:, nprod:]
@@ -69,11 +78,22 @@ def table(name, a, nprod, label, vector_first):
     steady = (g[:, :, 3] - g[:, :, 2]).mean() / max(passes - 1.0, 1e-9)
     print(f"   -> prologue {(g[:, :, 1] - t0).mean():.0f} | first pass exposed {first:.0f} | steady {steady:.0f} per further pass ({passes - 1:.2f} of them) | "
           f"drain {(a[:, :, 5].max(axis=1) - g[:, :, 3].max(axis=1)).mean():.0f} | block lifetime mean {life.mean():.0f}, max {life.max():.0f} cycles")
+    # the launch as a whole on the device-wide 100 MHz counter (10 ns steps): when the blocks start and end relative to the launch's first stamp
+    r = rt[tl_valid(a_all)]
+    r0 = r[:, :, 0].min()
+    b_start = (r[:, :, 0].min(axis=1) - r0) / 100.0
+    b_end = (r[:, :, 5].max(axis=1) - r0) / 100.0
+    g_pro = (r[:, :nprod, 1].max(axis=1) - r0) / 100.0
+    span = b_end.max()
+    print(f"   -> device-wide clock, us from the launch's first stamp: blocks start at mean {b_start.mean():.2f} (90 % by {np.quantile(b_start, 0.9):.2f}, last {b_start.max():.2f}), "
+          f"pass their barrier at mean {g_pro.mean():.2f}, end at mean {b_end.mean():.2f} (10 % by {np.quantile(b_end, 0.1):.2f}, last {span:.2f}); "
+          f"block lifetime mean {(b_end - b_start).mean():.2f} us; CU-time idle before the first and after the last wave of a block: "
+          f"{b_start.mean():.2f} + {(span - b_end).mean():.2f} us of {span:.2f}")
     if us:
         print(f"   -> at the dispatch's {us:.2f} us a mean block lifetime of {life.mean():.0f} cycles leaves {us - life.mean() / 2100:.2f} us of ramp + tail at 2.1 GHz "
               f"({us - life.mean() / 1900:.2f} at 1.9)")
 
 print(f"B = {B}: N = {N}, {ntiles} tiles; clock cycles relative to the start of the block's first wave")
-table("forward  k_triplet_fwd_ws", tl[0], 8, "k_triplet_fwd_ws+update", False)
-table("backward by target  k_triplet_bwd_dst_ws (B1; gather = its 8 vector waves, matrix = the 4 d_aggr waves)", tl1, 8, "d_aggr+k_triplet_bwd_dst_ws", True)
-table("backward by source  k_triplet_bwd_src_ws (B2)", tl[1], 8, "k_triplet_bwd_src_ws+dx", False)
+table("forward  k_triplet_fwd_ws", tl[0], rt[0], 8, "k_triplet_fwd_ws+update", False)
+table("backward by target  k_triplet_bwd_dst_ws (B1; gather = its 8 vector waves, matrix = the 4 d_aggr waves)", tl1, rt1, 8, "d_aggr+k_triplet_bwd_dst_ws", True)
+table("backward by source  k_triplet_bwd_src_ws (B2)", tl[1], rt[1], 8, "k_triplet_bwd_src_ws+dx", False)
