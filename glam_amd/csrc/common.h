@@ -113,6 +113,21 @@ __device__ __forceinline__ void stfo_wt(float* base, unsigned byte_off, float v,
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)uniform_off, 16);
 }
+// WHEN: only launches over at most kWtMaxRows rows (nodes).  There the write-back at the end is a visible share of the launch (the
+// headline step at B = 1 024: 68.0 -> 62.6 us); over more rows the L2 merges the partial lines a tile's stores leave before it evicts
+// them, and the same stores written through cost MORE (B = 4 096: +5 %, B = 16 384: +15-30 % per kernel; B = 2 048: even) —
+// profiles/r5_store_policy.txt.  The choice is a wave-uniform branch on a kernel argument (st4o_sel) or a template argument (st4o_t).
+constexpr int kWtMaxRows = 32768;
+__device__ __forceinline__ void st4o_sel(bool wt, float* base, unsigned byte_off, float4 v, unsigned uniform_off = 0) {
+    if (wt) st4o_wt(base, byte_off, v, uniform_off);
+    else st4o(base, byte_off + uniform_off, v);
+}
+// the same choice made at compile time (the warp-specialised kernels: a branch around the stores of their steady loops cost them half
+// of what the policy gains — the hosts pick the instantiation)
+template <bool WT> __device__ __forceinline__ void st4o_t(float* base, unsigned byte_off, float4 v) {
+    if constexpr (WT) st4o_wt(base, byte_off, v);
+    else st4o(base, byte_off, v);
+}
 __device__ __forceinline__ int ldio(const int* base, unsigned byte_off) {
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off);
 }

@@ -338,18 +338,29 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
         // C layout: tile column = lane & 15 (-> logical columns cs * 64 + 4 c + t), row = (lane >> 4) * 4 + i
         if (m0 < M) {
             const float4 b = bias4;
-            // written through the L2 (st4o_wt): wave-uniform base of the tile's rows + the lane's offset inside the tile
-            const size_t trow = (size_t)__builtin_amdgcn_readfirstlane(tile) * 16;
-            float* o1 = a.out1 + trow * a.ldo1;
-            float* o2 = a.out2 + trow * a.ldo2;
-            const bool first = m0 < a.M1;
-            const unsigned lane_off = first ? (unsigned)(kb * 4 * a.ldo1 + m0) * 4u : (unsigned)(kb * 4 * a.ldo2 + (m0 - a.M1)) * 4u;
+            if constexpr (RBLK == 768) {      // (the 12-wave form only runs over >= 131 072 rows: plain stores)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (tile * 16 + kb * 4 + i >= a.N) continue;
-                const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
-                if (first) st4o_wt(o1, lane_off, v, (unsigned)(i * a.ldo1) * 4u);
-                else st4o_wt(o2, lane_off, v, (unsigned)(i * a.ldo2) * 4u);
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = tile * 16 + kb * 4 + i;
+                    if (rr >= a.N) continue;
+                    const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                    if (m0 < a.M1) st4(a.out1 + (size_t)rr * a.ldo1 + m0, v);
+                    else st4(a.out2 + (size_t)rr * a.ldo2 + (m0 - a.M1), v);
+                }
+            } else {
+                // written through the L2 when the launch is small (st4o_sel): wave-uniform base of the tile's rows + the lane's offset inside
+                const size_t trow = (size_t)__builtin_amdgcn_readfirstlane(tile) * 16;
+                float* o1 = a.out1 + trow * a.ldo1;
+                float* o2 = a.out2 + trow * a.ldo2;
+                const bool first = m0 < a.M1, wt = a.N <= kWtMaxRows;
+                const unsigned lane_off = first ? (unsigned)(kb * 4 * a.ldo1 + m0) * 4u : (unsigned)(kb * 4 * a.ldo2 + (m0 - a.M1)) * 4u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (tile * 16 + kb * 4 + i >= a.N) continue;
+                    const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                    if (first) st4o_sel(wt, o1, lane_off, v, (unsigned)(i * a.ldo1) * 4u);
+                    else st4o_sel(wt, o2, lane_off, v, (unsigned)(i * a.ldo2) * 4u);
+                }
             }
         }
     }
@@ -512,7 +523,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
                 const float4 v = s_red4[(w * 8 + t) * 64 + lane];
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
-            st4o_wt(out, (unsigned)(((half * 8 + t) * 64 + lane) * 16), sum);      // (written through the L2: see st4o_wt)
+            st4o_sel(a.N <= kWtMaxRows, out, (unsigned)(((half * 8 + t) * 64 + lane) * 16), sum);      // (see st4o_wt)
         }
     }
 }

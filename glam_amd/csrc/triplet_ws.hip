@@ -106,7 +106,7 @@ __device__ __forceinline__ void ws_consume(Stage stage, const float* img, const 
         if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, acc[i] + bias);
+                if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = acc[i] + bias;
         }
         WSTAMP(2);
     }
@@ -123,7 +123,7 @@ __device__ __forceinline__ void ws_consume(Stage stage, const float* img, const 
 // has in flight — i.e. for the previous tile's stores: B2 went 122 -> 164 us at B = 16 384 when this was a run-time option).  The next
 // tile's addend rows are requested BEFORE this tile's stores and the loop runs over full tiles only (four unconditional stores per lane:
 // the wait for the rows can leave exactly those in flight); the ragged last tile is handled behind it.
-template <int RING, bool ADD = false, class Stage>
+template <int RING, bool ADD = false, bool WT = false, class Stage>      // WT: stores written through the L2 (common.h: st4o_wt)
 __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, const float* bias_p, float* out, int N, int Cp, int K,
                                               const int* s_ready, int* s_taken, const char* s_ring, int ntiles, int w, int lane,
                                               const float* addend = nullptr) {
@@ -183,13 +183,16 @@ __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, con
             float nx[4];
             load_add(min(tile + (int)gridDim.x, ntiles - 1), nx);          // the next tile's rows, ahead of this tile's stores
 #pragma unroll
-            for (int i = 0; i < 4; ++i) stfo_wt(out, (unsigned)((r0 + i) * Cp + colc) * 4u, (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i]);
+            for (int i = 0; i < 4; ++i) out[(size_t)(r0 + i) * Cp + colc] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];      // (plain stores: the wait for the next addend rows stands behind the stores of the tile before — written through the L2 they take longer than a tile)
 #pragma unroll
             for (int i = 0; i < 4; ++i) ad[i] = nx[i];
         } else if (col < Cp) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < N) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias);
+                if (r0 + i < N) {
+                    if constexpr (WT) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias);
+                    else out[(size_t)(r0 + i) * Cp + col] = ((acc_s[i] + acc_m[i]) + acc_b[i]) + bias;
+                }
         }
     }
     if constexpr (ADD) {
@@ -203,7 +206,7 @@ __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, con
             if (col < Cp) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (r0 + i < N) stfo_wt(out, (unsigned)((r0 + i) * Cp + col) * 4u, (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i]);
+                    if (r0 + i < N) out[(size_t)(r0 + i) * Cp + col] = (((acc_s[i] + acc_m[i]) + acc_b[i]) + bias) + ad[i];
             }
         }
     }
@@ -219,7 +222,7 @@ __device__ __forceinline__ void x3_store4(char* row_k, float4 v) {
     *reinterpret_cast<uint2*>(row_k + 2 * kX3PlaneBytes) = make_uint2(l0, l1);
 }
 
-template <int H, int P, bool X3>
+template <int H, int P, bool X3, bool WT = false>      // WT: the large outputs are written through the L2 (small launches; common.h: st4o_wt)
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_fwd_ws(FwdDmaArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 
     if (wave >= P) {
         // consumer: out[16 tile .. +15, 16 w .. +15] = aggr_tile[16, HC] @ W_scale[:, 16 w .. +15] + bias
-        if constexpr (X3) ws_consume_x3<kRingN>(stage_lds, a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
+        if constexpr (X3) ws_consume_x3<kRingN, false, WT>(stage_lds, a.img_upd, a.bias_p, a.out, a.N, Cp, HC, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane);
         else ws_consume(stage_lds, a.img_upd, a.bias_p, a.out, a.N, Cp, HC, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         WS_TL(0, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -429,9 +432,9 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         if (qok) {
             const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
-            for (int h = 0; h < H; ++h) st4o_wt(a.aggr, orow + (unsigned)h * head_bytes, r_acc[h]);
+            for (int h = 0; h < H; ++h) st4o_t<WT>(a.aggr, orow + (unsigned)h * head_bytes, r_acc[h]);
         }
-        if (q < 2) st4o_wt(a.stats, (unsigned)r_n * 32u + (unsigned)q * 16u, r_ms);
+        if (q < 2) st4o_t<WT>(a.stats, (unsigned)r_n * 32u + (unsigned)q * 16u, r_ms);
         r_n = -1;
     };
     // the rows in flight are (re)defined by an empty asm right after the pipeline's own vmcnt(0): the compiler retires its count of
@@ -524,7 +527,7 @@ struct SrcWsArgs {
     const float* dx_addend;      // may be null: d_x += dx_addend (ws_consume_x3)
 };
 
-template <int H, int P, bool X3, bool ADD = false>      // ADD (3 x bf16 form only): d_x += a.dx_addend in the consumers' epilogue
+template <int H, int P, bool X3, bool ADD = false, bool WT = false>      // ADD (3 x bf16 form only): d_x += a.dx_addend in the consumers' epilogue; WT: see k_triplet_fwd_ws
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_bwd_src_ws(SrcWsArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = clock64();
 #endif
     if (wave >= P) {
-        if constexpr (X3) ws_consume_x3<kRingN, ADD>(stage_lds, a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
+        if constexpr (X3) ws_consume_x3<kRingN, ADD, WT>(stage_lds, a.img_dx, nullptr, a.d_x, a.N, Cp, KX, s_ready, s_taken, reinterpret_cast<const char*>(s_ring), ntiles, wave - P, lane, a.dx_addend);
         else ws_consume(stage_lds, a.img_dx, nullptr, a.d_x, a.N, Cp, KX, LDT, s_ready, s_taken, s_ring, ntiles, wave - P, lane WS_PROF_ARGS);
         WS_TL(1, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -692,9 +695,9 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         if (qok) {
             const unsigned orow = (unsigned)r_n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
-            for (int h = 0; h < H; ++h) st4o_wt(a.d_xw, orow + (unsigned)h * head_bytes, r_acc[h]);
+            for (int h = 0; h < H; ++h) st4o_t<WT>(a.d_xw, orow + (unsigned)h * head_bytes, r_acc[h]);
         }
-        if (q == 0) st4o_wt(a.d_a_ij, (unsigned)r_n * 32u + 16u, r_da);
+        if (q == 0) st4o_t<WT>(a.d_a_ij, (unsigned)r_n * 32u + 16u, r_da);
         r_n = -1;
     };
     auto settle = [&](float4 (&rows)[CH][H]) {
@@ -751,15 +754,16 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #undef LANE_CONSTS
 }
 
-template <int H, int P, bool X3, bool ADD>
+template <int H, int P, bool X3, bool ADD, bool WT = false>
 static int launch_src_ws_px(const SrcWsArgs& a, int grid, hipStream_t s) {
+    if constexpr (X3 && !WT) { if (a.N <= kWtMaxRows) return launch_src_ws_px<H, P, X3, ADD, true>(a, grid, s); }
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, X3, ADD>), big, "triplet_bwd_src_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, X3, ADD, WT>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t ring = X3 ? (size_t)kWsRingX3 * kX3TileBytes : (size_t)kWsRing * 16 * LDT * sizeof(float);
     const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4) * sizeof(float) + ring;
     GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
-    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, X3, ADD>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
+    hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, X3, ADD, WT>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
     return GLAM_OK;
 }
 template <int H, int P>
@@ -806,12 +810,13 @@ static size_t ws_lds_bytes(int H, int Cp, int P, bool x3) {
     return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 2 * 64 * 4) * sizeof(float) + ring;
 }
 
-template <int H, int P, bool X3>
+template <int H, int P, bool X3, bool WT = false>
 static int launch_ws_px(const FwdDmaArgs& a, int grid, hipStream_t s) {
+    if constexpr (X3 && !WT) { if (a.N <= kWtMaxRows) return launch_ws_px<H, P, X3, true>(a, grid, s); }
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P, X3>), big, "triplet_fwd_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P, X3, WT>), big, "triplet_fwd_ws")) return rc;
     GLAM_PROF_LABEL("k_triplet_fwd_ws+update");
-    hipLaunchKernelGGL((k_triplet_fwd_ws<H, P, X3>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P, X3), s, a);
+    hipLaunchKernelGGL((k_triplet_fwd_ws<H, P, X3, WT>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P, X3), s, a);
     return GLAM_OK;
 }
 // the consumers' product on the bf16 matrix cores in 3 x bf16 form (fp32 accuracy) unless GLAM_X3=0

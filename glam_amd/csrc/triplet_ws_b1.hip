@@ -44,7 +44,7 @@ struct DstWsArgs {
     float* d_aggr; float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;      // partial[gridDim.x][4 * H * Cp + 16]
 };
 
-template <int H, int V, bool X3>
+template <int H, int V, bool X3, bool WT = false>      // WT: the outputs are written through the L2 (small launches; common.h: st4o_wt)
 __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_ws(DstWsArgs a) {
     constexpr int kBlockT = (V + 4) * 64, VG = V / 4, CH = 4;
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                 if (qok) {
                     const unsigned orow = (unsigned)n * row_bytes + (unsigned)q * 16u;
 #pragma unroll
-                    for (int h = 0; h < H; ++h) st4o_wt(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
+                    for (int h = 0; h < H; ++h) st4o_t<WT>(a.d_aggr, orow + (unsigned)h * head_bytes, dag[h]);
                 }
                 // ---- row phase: d_alpha[k][h] = <d_aggr[n,h,:], e_ij * xw[src_k,h,:]>, d_W_edge[type_k][h] += alpha * d_aggr * xw ----
                 if (deg > 0) {
@@ -402,10 +402,10 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             dv.x = dp; dv.y = dpp_f<0x104>(dp); dv.z = dpp_f<0x108>(dp); dv.w = dpp_f<0x10C>(dp);
             da.x = dai; da.y = dpp_f<0x104>(dai); da.z = dpp_f<0x108>(dai); da.w = dpp_f<0x10C>(dai);
             if (q < 4 && valid) {
-                st4o_wt(a.alpha_e, (unsigned)re * 16u, av);
-                st4o_wt(a.dpre_e, (unsigned)re * 16u, dv);
+                st4o_t<WT>(a.alpha_e, (unsigned)re * 16u, av);
+                st4o_t<WT>(a.dpre_e, (unsigned)re * 16u, dv);
             }
-            if (q == 0 && node_ok) st4o_wt(a.d_a_ij, (unsigned)n * 32u, da);
+            if (q == 0 && node_ok) st4o_t<WT>(a.d_a_ij, (unsigned)n * 32u, da);
         };
 
         int rs, re, rs_n, re_n;
@@ -470,12 +470,13 @@ static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     return ((size_t)WL + 64 + (size_t)V * 4 * WL + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
-template <int H, int V, bool X3>
+template <int H, int V, bool X3, bool WT = false>
 static int launch_b1ws_x(const DstWsArgs& a, int grid, hipStream_t s) {
+    if constexpr (X3 && !WT) { if (a.N <= kWtMaxRows) return launch_b1ws_x<H, V, X3, true>(a, grid, s); }
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V, X3>), big, "triplet_bwd_dst_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_dst_ws<H, V, X3, WT>), big, "triplet_bwd_dst_ws")) return rc;
     GLAM_PROF_LABEL("d_aggr+k_triplet_bwd_dst_ws");
-    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V, X3>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
+    hipLaunchKernelGGL((k_triplet_bwd_dst_ws<H, V, X3, WT>), dim3(grid), dim3((V + 4) * 64), b1ws_lds_bytes(H, a.Cp, V), s, a);
     return GLAM_OK;
 }
 template <int H, int V>

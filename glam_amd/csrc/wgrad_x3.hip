@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(kWxThreads) k_wgrad_x3(WgArgs2 two) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
             const v4f_t v = master[u][tj] + (ca[u][tj] + cb[u][tj]);
-            st4o_wt(out, (unsigned)(((ti * 4 + tj) * 64 + lane) * 16), make_float4(v[0], v[1], v[2], v[3]));
+            st4o_sel(a.N <= kWtMaxRows, out, (unsigned)(((ti * 4 + tj) * 64 + lane) * 16), make_float4(v[0], v[1], v[2], v[3]));
         }
     }
 }
