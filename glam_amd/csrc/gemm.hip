@@ -362,6 +362,142 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
                     else st4o_sel(wt, o2, lane_off, v, (unsigned)(i * a.ldo2) * 4u);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);      // one split's 96 operand registers at a time (hoisted, the three sets spill)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ts_gemm_x3_sw: the same product for launches that are all prologue (N < 131 072 rows: at B = 1 024 a wave of k_ts_gemm_x3 sees two
+// items).  There 2 040 waves each fetch and split their own 15 KB slice of W, and every row tile is fetched by three waves (one per column
+// split): 181 KB come into a CU for the 19 KB of x it works on, and at the ~11 B/clk a CU takes in that IS the launch (7.8 of its 8.8-9.4 us).
+// Here the block splits W ONCE — wave w loads and splits three of the 24 (column split, k step, column tile) fragments — into LDS in
+// operand layout (72 KB), and a wave takes a row tile through all three column splits, its operands of W out of LDS (24 conflict-free
+// 16-byte reads per split): 65 KB per CU.  No handshakes (one barrier behind the prologue), unlike the producer / consumer form of
+// tall_x3.hip that was tried for this shape (profiles/NEGATIVES.md).  Same arithmetic in the same order as k_ts_gemm_x3: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int CS>
+__global__ void __launch_bounds__(512) k_ts_gemm_x3_sw(TsArgs a) {
+    constexpr int MP = 64 * CS, NF = CS * KS * 4, FPW = NF / 8;
+    static_assert(NF % 8 == 0, "fragments per wave");
+    extern __shared__ __attribute__((aligned(16))) char s_wf[];      // [fragment (cs, s, t)][term][lane] x 16 bytes
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kb = lane >> 4;
+    const int K = a.K1, Kp = (K + 15) & ~15, M = a.M1 + a.M2;
+    const int ntiles = (a.N + 15) >> 4;
+    auto load_a = [&](int tile, float4 (&af)[KS][2]) {
+        const int row = tile * 16 + c;
+        const bool rok = tile < ntiles && row < a.N;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k0 = 32 * s + 8 * kb + 4 * u;
+                af[s][u] = (rok && k0 < K) ? ld4(a.A1 + (size_t)row * a.lda1 + k0) : f4zero();
+            }
+    };
+    // Block b works on row tiles b, b + blocks, ... (nt_b of them).  A wave's work is a list of units (tile, column splits cs0 .. cs1 - 1):
+    //   - whole tiles (all splits: one fetch and one split of the rows) round the 8 waves while 8 tiles are left;
+    //   - of the r < 8 tiles left over, four go whole to waves 0-3 (one per SIMD) if r >= 4, the others split by split to waves 4-7
+    //     (r >= 4) or to all 8 waves (r < 4): at B = 1 024 (5 tiles per block) no SIMD runs two whole tiles while another runs one, and a
+    //     small launch (one tile per block) puts its three splits on three SIMDs.
+    // (Measured at B = 1 024: whole tiles only 7.6-8.0 us; every tile split by split — its rows fetched and split three times — 8.3-8.5.)
+    const int nblk = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int nt_b = bid < ntiles ? (ntiles - bid + nblk - 1) / nblk : 0, nfull = nt_b & ~7, r = nt_b - nfull;
+    const int nA = nfull >> 3;                                 // whole tiles of this wave in the first phase
+    // unit n of this wave -> its tile (ntiles = none) and column splits
+    auto unit = [&](int n, int& cs0, int& cs1) -> int {
+        cs0 = 0; cs1 = CS;
+        if (n < nA) return bid + (wave + 8 * n) * nblk;
+        const int m = n - nA;
+        if (r >= 4) {
+            if (wave < 4) return m == 0 ? bid + (nfull + wave) * nblk : ntiles;
+            const int jx = (wave - 4) + 4 * m;
+            if (jx >= CS * (r - 4)) return ntiles;
+            cs0 = jx % CS; cs1 = cs0 + 1;
+            return bid + (nfull + 4 + jx / CS) * nblk;
+        }
+        const int jx = wave + 8 * m;
+        if (jx >= CS * r) return ntiles;
+        cs0 = jx % CS; cs1 = cs0 + 1;
+        return bid + (nfull + jx / CS) * nblk;
+    };
+    int n = 0, cs0, cs1, cs0n, cs1n;
+    int tile = unit(0, cs0, cs1);
+    WRaw8 raw[FPW];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave * FPW + i, cs = f / (KS * 4), s = (f >> 2) % KS, t = f & 3;
+        raw[i] = w_load8(a.Wimg, MP, cs * 64 + 16 * t + c, 32 * s + 8 * kb, Kp);
+    }
+    float4 af[KS][2];
+    load_a(tile, af);
+    // the bias goes to LDS (one float per column position; zero where there is none): a split reads its four with its operands
+    float* s_bias = reinterpret_cast<float*>(s_wf + (size_t)NF * 3 * 1024);
+    if (tid < MP) s_bias[tid] = (a.bias && tid < a.M1) ? a.bias[tid] : 0.f;
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave * FPW + i, s = (f >> 2) % KS;
+        const Bf16x3 w = w_split8(raw[i], 32 * s + 8 * kb, Kp);
+        char* p = s_wf + ((size_t)(f * 3) * 64 + lane) * 16;
+        *reinterpret_cast<bf16x8_t*>(p) = w.hi;
+        *reinterpret_cast<bf16x8_t*>(p + 1024) = w.mid;
+        *reinterpret_cast<bf16x8_t*>(p + 2048) = w.lo;
+    }
+    __syncthreads();
+    const bool wt = a.N <= kWtMaxRows;
+    for (; tile < ntiles; ++n, tile = unit(n, cs0, cs1)) {
+        Bf16x3 as[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) as[s] = split8(af[s][0], af[s][1]);
+        load_a(unit(n + 1, cs0n, cs1n), af);                   // the wave's next unit (if any) flies under this one
+        const size_t trow = (size_t)__builtin_amdgcn_readfirstlane(tile) * 16;
+        float* o1 = a.out1 + trow * a.ldo1;
+        float* o2 = a.out2 + trow * a.ldo2;
+#pragma unroll 1
+        for (int cs = cs0; cs < cs1; ++cs) {
+            Bf16x3 wreg[KS][4];
+            const char* wf = s_wf + ((size_t)(cs * KS * 4 * 3) * 64 + lane) * 16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const char* p = wf + (size_t)((s * 4 + t) * 3) * 1024;
+                    wreg[s][t].hi = *reinterpret_cast<const bf16x8_t*>(p);
+                    wreg[s][t].mid = *reinterpret_cast<const bf16x8_t*>(p + 1024);
+                    wreg[s][t].lo = *reinterpret_cast<const bf16x8_t*>(p + 2048);
+                }
+            const int m0 = cs * 64 + 4 * c;
+            const float4 b = ld4(s_bias + m0);
+            v4f_t acc[4], accb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { acc[t] = (v4f_t){0.f, 0.f, 0.f, 0.f}; accb[t] = acc[t]; }
+            // (the chains of k_ts_gemm_x3: small partial products of both k steps, the middle ones, hi x hi in a chain of its own)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_small(as[s], wreg[s][t], acc[t]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_x3_mid(as[s], wreg[s][t], acc[t]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accb[t] = mfma_x3_big(as[s], wreg[s][t], accb[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += accb[t];
+            // C layout: tile column = lane & 15 (-> logical columns cs * 64 + 4 c + t), row = (lane >> 4) * 4 + i
+            if (m0 < M) {
+                const bool first = m0 < a.M1;
+                const unsigned lane_off = first ? (unsigned)(kb * 4 * a.ldo1 + m0) * 4u : (unsigned)(kb * 4 * a.ldo2 + (m0 - a.M1)) * 4u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (tile * 16 + kb * 4 + i >= a.N) continue;
+                    const float4 v = make_float4(acc[0][i] + b.x, acc[1][i] + b.y, acc[2][i] + b.z, acc[3][i] + b.w);
+                    if (first) st4o_sel(wt, o1, lane_off, v, (unsigned)(i * a.ldo1) * 4u);
+                    else st4o_sel(wt, o2, lane_off, v, (unsigned)(i * a.ldo2) * 4u);
+                }
+            }
         }
     }
 }
@@ -645,6 +781,7 @@ static bool ts_rb_enabled() { return true; }       // (the register-B form of th
 static bool tall_x3_enabled() { const char* e = getenv("GLAM_TALL_X3"); return !e || atoi(e) != 0; }     // A/B switch of tall_x3.hip
 // GLAM_X3=0: the dense products stay on the fp32 matrix instructions (A/B switch, read per call)
 bool ts_x3_enabled() { const char* e = getenv("GLAM_X3"); return !e || atoi(e) != 0; }
+static bool ts_sw_enabled() { const char* e = getenv("GLAM_TS_SW"); return !e || atoi(e) != 0; }      // A/B switch of k_ts_gemm_x3_sw
 static bool ts_rb_big(int N) { return N >= 131072; }       // 12-wave blocks once the launch streams from HBM
 static int ts_rb_grid(int N) {
     const int ntiles = (N + 15) / 16;
@@ -681,7 +818,18 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
         GLAM_PROF_LABEL("k_ts_gemm<12, 4, 4>");
         if (ts_x3_enabled()) {      // 3 x bf16 on the bf16 matrix cores (fp32 accuracy, bf16x3.h)
             if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm_x3<768>), dim3(two.first_b), dim3(768), 0, s, a, two.first_b);
-            else hipLaunchKernelGGL((k_ts_gemm_x3<512>), dim3(two.first_b), dim3(512), 0, s, a, two.first_b);
+            else if (ts_sw_enabled()) {      // W split once per block, a wave per row tile (k_ts_gemm_x3_sw)
+                static bool big[64] = {};      // > 64 KB of dynamic LDS is opted into once per device
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+                if (!big[dev] || dev == 63) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ts_gemm_x3_sw<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 73 * 1024) != hipSuccess)
+                        return fail(GLAM_E_HIP, "ts_gemm_x3_sw: opting into 72 KB of dynamic LDS failed");
+                    big[dev] = true;
+                }
+                const int ntiles = (a.N + 15) / 16, g = (ntiles + 1) / 2;
+                hipLaunchKernelGGL((k_ts_gemm_x3_sw<2, 3>), dim3(g < 256 ? g : 256), dim3(512), 3 * 2 * 4 * 3 * 1024 + 1024, s, a);
+            } else hipLaunchKernelGGL((k_ts_gemm_x3<512>), dim3(two.first_b), dim3(512), 0, s, a, two.first_b);
         } else if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
         else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 512>), dim3(two.first_b), dim3(512), 0, s, two);
     } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
