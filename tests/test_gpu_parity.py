@@ -515,6 +515,41 @@ def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
         assert_close(o2, ref[:, M1:], 2e-6, "ts_gemm out2")
 
 
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 100, 640, 2047, 4113, 20400, 20401, 40800, 131071])
+@pytest.mark.parametrize("bias,M2", [(True, 8), (False, 0)])
+def test_node_gemm_w_once_per_block_equals_w_per_wave(device, monkeypatch, N, bias, M2):
+    """The node GEMM x[N, 60] @ [W_node | Wa][60, 180 (+ 8)] below 131 072 rows (layer.py:37: ``self.weight_node``; k_ts_gemm_x3_sw: W split
+    once per block into LDS, whole tiles and single column splits dealt over the waves) against k_ts_gemm_x3 (a W slice per wave,
+    GLAM_TS_SW=0): the same arithmetic in the same order, bit for bit — every unit mapping (whole tiles round the waves, 1..7 tiles left
+    over, fewer tiles than blocks, a ragged last tile), with and without the second output and the bias; and against fp64."""
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    if not _lib.route_enabled("x3"):
+        pytest.skip("GLAM_X3=0: both routes are the fp32 kernel")
+    g = torch.Generator().manual_seed(N)
+    K, M1 = 60, 180
+    A = torch.randn(N, K, generator=g).to(device)
+    W = torch.randn(K, M1 + M2, generator=g).to(device)
+    b = torch.randn(M1, generator=g).to(device) if bias else None
+    img = torch.empty(lib.glam_ts_gemm_image_bytes(K, M1 + M2) // 4, device=device)
+    assert lib.glam_ts_gemm_make_image(p(W), M1 + M2, 0, K, M1 + M2, p(img), _lib.stream()) == 0, lib.glam_last_error()
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("GLAM_TS_SW", sw)
+        o1 = torch.full((N, M1), float("nan"), device=device)
+        o2 = torch.full((N, max(M2, 1)), float("nan"), device=device)
+        rc = lib.glam_ts_gemm(p(A), K, K, None, 0, 0, p(img), p(b), p(o1), M1, M1, p(o2) if M2 else None, M2, max(M2, 4), N, _lib.stream())
+        assert rc == 0, lib.glam_last_error()
+        outs.append((o1, o2))
+    assert torch.equal(outs[0][0], outs[1][0]) and (not M2 or torch.equal(outs[0][1], outs[1][1]))
+    ref = A.double() @ W.double()
+    if bias:
+        ref[:, :M1] += b.double()
+    assert_close(outs[0][0], ref[:, :M1], 2e-6, "node GEMM out1")
+    if M2:
+        assert_close(outs[0][1], ref[:, M1:], 2e-6, "node GEMM out2")
+
+
 @pytest.fixture(params=["default", "x3"])
 def wgrad_route(request, monkeypatch):
     """The weight-gradient products on both kernels: "default" = k_wgrad below 32 768 rows and k_wgrad_x3 (csrc/wgrad_x3.hip) from there,
