@@ -368,13 +368,16 @@ __global__ void __launch_bounds__(RBLK) k_ts_gemm_x3(TsArgs a, int nblk) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_ts_gemm_x3_sw: the same product for launches that are all prologue (N < 131 072 rows: at B = 1 024 a wave of k_ts_gemm_x3 sees two
-// items).  There 2 040 waves each fetch and split their own 15 KB slice of W, and every row tile is fetched by three waves (one per column
+// k_ts_gemm_x3_sw: the same product, W split once per block (the default at every size).  At B = 1 024 a wave of k_ts_gemm_x3 sees two
+// items.  There 2 040 waves each fetch and split their own 15 KB slice of W, and every row tile is fetched by three waves (one per column
 // split): 181 KB come into a CU for the 19 KB of x it works on, and at the ~11 B/clk a CU takes in that IS the launch (7.8 of its 8.8-9.4 us).
 // Here the block splits W ONCE — wave w loads and splits three of the 24 (column split, k step, column tile) fragments — into LDS in
 // operand layout (72 KB), and a wave takes a row tile through all three column splits, its operands of W out of LDS (24 conflict-free
 // 16-byte reads per split): 65 KB per CU.  No handshakes (one barrier behind the prologue), unlike the producer / consumer form of
 // tall_x3.hip that was tried for this shape (profiles/NEGATIVES.md).  Same arithmetic in the same order as k_ts_gemm_x3: bit-identical.
+// Beyond the LLC it wins for another reason: a row of the output leaves ONE wave as 752 contiguous bytes within a few hundred cycles,
+// where the three column-split waves of k_ts_gemm_x3 wrote 256-byte pieces of it at unrelated times (N = 326 400: 114 -> 72 us alone,
+// 79-82 -> 62 us inside the B = 16 384 step = 0.66 of the HBM roofline).
 // ------------------------------------------------------------------------------------------------
 template <int KS, int CS>
 __global__ void __launch_bounds__(512) k_ts_gemm_x3_sw(TsArgs a) {
@@ -817,19 +820,19 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
         two.first_b = ts_rb_grid(a.N);
         GLAM_PROF_LABEL("k_ts_gemm<12, 4, 4>");
         if (ts_x3_enabled()) {      // 3 x bf16 on the bf16 matrix cores (fp32 accuracy, bf16x3.h)
-            if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm_x3<768>), dim3(two.first_b), dim3(768), 0, s, a, two.first_b);
-            else if (ts_sw_enabled()) {      // W split once per block, a wave per row tile (k_ts_gemm_x3_sw)
+            if (ts_sw_enabled()) {      // W split once per block, whole row tiles per wave (k_ts_gemm_x3_sw), at every size
                 static bool big[64] = {};      // > 64 KB of dynamic LDS is opted into once per device
                 int dev = 0;
                 if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
                 if (!big[dev] || dev == 63) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ts_gemm_x3_sw<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 73 * 1024) != hipSuccess)
-                        return fail(GLAM_E_HIP, "ts_gemm_x3_sw: opting into 72 KB of dynamic LDS failed");
+                        return fail(GLAM_E_HIP, "ts_gemm_x3_sw: opting into 73 KB of dynamic LDS failed");
                     big[dev] = true;
                 }
                 const int ntiles = (a.N + 15) / 16, g = (ntiles + 1) / 2;
                 hipLaunchKernelGGL((k_ts_gemm_x3_sw<2, 3>), dim3(g < 256 ? g : 256), dim3(512), 3 * 2 * 4 * 3 * 1024 + 1024, s, a);
-            } else hipLaunchKernelGGL((k_ts_gemm_x3<512>), dim3(two.first_b), dim3(512), 0, s, a, two.first_b);
+            } else if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm_x3<768>), dim3(two.first_b), dim3(768), 0, s, a, two.first_b);
+            else hipLaunchKernelGGL((k_ts_gemm_x3<512>), dim3(two.first_b), dim3(512), 0, s, a, two.first_b);
         } else if (ts_rb_big(a.N)) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 768>), dim3(two.first_b), dim3(768), 0, s, two);
         else hipLaunchKernelGGL((k_ts_gemm<12, 4, 4, 512>), dim3(two.first_b), dim3(512), 0, s, two);
     } else if (variant == 1) hipLaunchKernelGGL((k_ts_gemm<12, 4, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);

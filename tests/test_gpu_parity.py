@@ -515,12 +515,12 @@ def test_ts_gemm(device, N, K1, K2, M1, M2, trans, bias):
         assert_close(o2, ref[:, M1:], 2e-6, "ts_gemm out2")
 
 
-@pytest.mark.parametrize("N", [1, 15, 16, 17, 100, 640, 2047, 4113, 20400, 20401, 40800, 131071])
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 100, 640, 2047, 4113, 20400, 20401, 40800, 131071, 131072, 326411])
 @pytest.mark.parametrize("bias,M2", [(True, 8), (False, 0)])
 def test_node_gemm_w_once_per_block_equals_w_per_wave(device, monkeypatch, N, bias, M2):
-    """The node GEMM x[N, 60] @ [W_node | Wa][60, 180 (+ 8)] below 131 072 rows (layer.py:37: ``self.weight_node``; k_ts_gemm_x3_sw: W split
-    once per block into LDS, whole tiles and single column splits dealt over the waves) against k_ts_gemm_x3 (a W slice per wave,
-    GLAM_TS_SW=0): the same arithmetic in the same order, bit for bit — every unit mapping (whole tiles round the waves, 1..7 tiles left
+    """The node GEMM x[N, 60] @ [W_node | Wa][60, 180 (+ 8)] (layer.py:37: ``self.weight_node``; k_ts_gemm_x3_sw: W split once per block
+    into LDS, whole tiles and single column splits dealt over the waves) against k_ts_gemm_x3 (a W slice per wave, GLAM_TS_SW=0; its
+    12-wave form from 131 072 rows): the same arithmetic in the same order, bit for bit — every unit mapping (whole tiles round the waves, 1..7 tiles left
     over, fewer tiles than blocks, a ragged last tile), with and without the second output and the bias; and against fp64."""
     from glam_amd import _lib
     lib, p = _lib.load(), _lib.ptr
