@@ -536,6 +536,14 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
 // registers, float4 stores.  The weights come from the k_ts_gemm images of the gate matrices (K = C, M = 3C, 192 positions per row):
 // the ones the pair launch and the backward already use — no gate-padded images.
 // ------------------------------------------------------------------------------------------------
+#ifdef GLAM_WS_TL      // timeline stamps of the two warp-specialised GRU kernels (tools/gru_timeline.py; see triplet_ws.hip)
+__device__ long long g_gru_tl[2 * 256 * 12 * 6];      // [forward | backward][block][wave][stamp], shader clock of the CU
+__device__ long long g_gru_rt[2 * 256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter
+#define GRU_TL(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
+    g_gru_tl[i_] = clock64(); g_gru_rt[i_] = wall_clock64(); } } while (0)
+#else
+#define GRU_TL(kid, k) do { } while (0)
+#endif
 constexpr int kGwP = 4, kGwC = 4, kGwRing = 4, kGwD = 3;
 constexpr int kGwPitch = 416, kGwPlane = 16 * kGwPitch;                 // bf16 planes: 128 k of [celu(x) | h] per row (triplet_pipe.h: kX3RowBytes)
 constexpr int kGwEPitch = 272, kGwEPlane = 16 * kGwEPitch;              // fp32 planes (h, identity): 64 floats + 4 per row
@@ -555,13 +563,19 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, ntiles = (a.N + 15) >> 4, bid = blockIdx.x, nblk = gridDim.x;
     Philox ph{};
+    GRU_TL(0, 0);
     if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
-    if (tid < 32) s_ready[tid] = 0;
-    if (tid < 6 * 64) {
-        const int ch = tid & 63, g = (tid >> 6) % 3;
-        s_bias[tid] = ch < C ? (tid < 192 ? a.b_ih : a.b_hh)[g * C + ch] : 0.f;
-    }
-    __syncthreads();
+    // the LDS staging (flags, biases) and the block's one barrier, called by each role BEHIND its first global loads: the bias load then
+    // flies together with them instead of ahead of them (two start-up misses back to back were 4-5 k cycles of every block: see
+    // k_triplet_fwd_ws)
+    auto stage_lds = [&]() {
+        if (tid < 32) s_ready[tid] = 0;
+        if (tid < 6 * 64) {
+            const int ch = tid & 63, g = (tid >> 6) % 3;
+            s_bias[tid] = ch < C ? (tid < 192 ? a.b_ih : a.b_hh)[g * C + ch] : 0.f;
+        }
+        __syncthreads();
+    };
 
     if (wave < P) {
         // ---- producers.  A chunk of the tile = (row r, q): q < 16 -> x[row, 4 q ..], q >= 16 -> h[row, 4 (q - 16) ..]; every load is
@@ -584,10 +598,13 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
         float4 buf[D][3];
 #pragma unroll
         for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
+        stage_lds();
+        GRU_TL(0, 1);
         for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int it = it0 + d, tile = bid + it * nblk;
+                if (it == 1) GRU_TL(0, 2);
                 if (tile < ntiles) {
                     const int slot = it % RING, round = it / RING;
                     while (flag_load(s_taken + slot) < NC * round) __builtin_amdgcn_s_sleep(1);
@@ -614,6 +631,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 }
             }
         }
+        GRU_TL(0, 3);
     } else {
         // ---- consumers: wave w owns channels 16 w .. 16 w + 15; as an operand lane (c, kb) holds W column (channel) 16 w + c, k block kb;
         //      as a result lane it holds data row c, channels 16 w + 4 kb .. + 3 ----
@@ -632,6 +650,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
 #pragma unroll
                 for (int s = 0; s < 2; ++s) { ri[s][g] = w_load8(a.img_ih, MP, pos, 32 * s + 8 * kb, Kp); rh[s][g] = w_load8(a.img_hh, MP, pos, 32 * s + 8 * kb, Kp); }
             }
+            stage_lds();
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -642,7 +661,9 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
         }
         const int ch = 16 * w + 4 * kb;
         int it = 0;
+        GRU_TL(0, 1);
         for (int tile = bid; tile < ntiles; tile += nblk, ++it) {
+            if (it == 1) GRU_TL(0, 2);
             const int slot = it % RING, want = P * (it / RING + 1);
             const int row = 16 * tile + c;
             while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
@@ -731,7 +752,12 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
             }
         }
+        GRU_TL(0, 3);
     }
+#ifdef GLAM_WS_TL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GRU_TL(0, 5);
+#endif
     if constexpr (RNG) rng_end(rg.state, ph);
 }
 
@@ -770,6 +796,7 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
     char* s_ring = s_gb + 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, ntiles = (a.N + 15) >> 4, bid = blockIdx.x, nblk = gridDim.x;
+    GRU_TL(1, 0);
     if (tid < 32) s_ready[tid] = 0;
     __syncthreads();
 
@@ -797,10 +824,12 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
         float4 buf[D][NL];
 #pragma unroll
         for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
+        GRU_TL(1, 1);
         for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int it = it0 + d, tile = bid + it * nblk;
+                if (it == 1) GRU_TL(1, 2);
                 if (tile < ntiles) {
                     const bool ok = item_ok(tile);
                     const float4 (&v)[NL] = buf[d];
@@ -863,6 +892,11 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
                 }
             }
         }
+        GRU_TL(1, 3);
+#ifdef GLAM_WS_TL
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GRU_TL(1, 5);
+#endif
         return;
     }
 
@@ -888,7 +922,9 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
     const int ch = 16 * ct + 4 * kb;
     float* const outp = prod ? a.d_h : a.d_x;
     int it = 0;
+    GRU_TL(1, 1);
     for (int tile = bid; tile < ntiles; tile += nblk, ++it) {
+        if (it == 1) GRU_TL(1, 2);
         const int slot = it % RING, want = P * (it / RING + 1);
         const int row = 16 * tile + c;
         while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
@@ -917,6 +953,11 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
             st4(outp + (size_t)row * C + ch, v);
         }
     }
+    GRU_TL(1, 3);
+#ifdef GLAM_WS_TL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GRU_TL(1, 5);
+#endif
 }
 
 }  // namespace glam
@@ -924,6 +965,12 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
 using namespace glam;
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+#ifdef GLAM_WS_TL
+extern "C" int glam_debug_gru_tl(long long* host_out, int n, int device_wide) {
+    return (device_wide ? hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_rt), (size_t)n * sizeof(long long))
+                        : hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_tl), (size_t)n * sizeof(long long))) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef GLAM_GRU_PROF
 extern "C" int glam_debug_gru_prof(long long* host_out, int n) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_prof), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
