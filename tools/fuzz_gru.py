@@ -12,6 +12,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
+    torch.manual_seed(1000 * (int(sys.argv[2]) if len(sys.argv) > 2 else 0) + case)
     C = int(rng.integers(6, 17)) * 4
     N = int(rng.choice([1, 15, 16, 17, 31, 100, 1000, 4097, 20400]))
     celu, ident, hstate = bool(rng.random() < 0.5), bool(rng.random() < 0.7), bool(rng.random() < 0.6)
@@ -33,6 +34,8 @@ for case in range(n_cases):
     y = hn_r + (ids if ident else 0)
     out_r = [y, torch.relu(y), torch.nn.functional.leaky_relu(y, slope), torch.nn.functional.celu(y)][act]
     d_out, d_hs = r(N, C), r(N, C)
+    if act in (1, 2):      # no gradient through elements at the kink: fp32 and fp64 may land on different sides of it (1 in ~1e6 elements)
+        d_out = d_out * (y.detach().abs() > 1e-5)
     loss = (out_r * d_out).sum() + ((hn_r * d_hs).sum() if hstate else 0)
     grads = torch.autograd.grad(loss, [xs, hs] + ([] if (merge or not ident) else [ids]))
     f32 = lambda t: t.detach().float().to(dev).contiguous()
