@@ -539,8 +539,10 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
 #ifdef GLAM_WS_TL      // timeline stamps of the two warp-specialised GRU kernels (tools/gru_timeline.py; see triplet_ws.hip)
 __device__ long long g_gru_tl[2 * 256 * 12 * 6];      // [forward | backward][block][wave][stamp], shader clock of the CU
 __device__ long long g_gru_rt[2 * 256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter
-#define GRU_TL(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
-    g_gru_tl[i_] = clock64(); g_gru_rt[i_] = wall_clock64(); } } while (0)
+// (the clock reads are volatile assembly: the compiler moves a plain clock64() across waits and loads)
+#define GRU_TL(kid, k) do { unsigned long long c_, r_; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory"); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
+    g_gru_tl[i_] = (long long)c_; g_gru_rt[i_] = (long long)r_; } } while (0)
 #else
 #define GRU_TL(kid, k) do { } while (0)
 #endif
@@ -558,24 +560,19 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
     extern __shared__ __attribute__((aligned(16))) char s_gw[];
     int* s_ready = reinterpret_cast<int*>(s_gw);
     int* s_taken = s_ready + 16;
-    float* s_bias = reinterpret_cast<float*>(s_gw + 128);
     char* s_ring = s_gw + kGwHeader;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, ntiles = (a.N + 15) >> 4, bid = blockIdx.x, nblk = gridDim.x;
     Philox ph{};
     GRU_TL(0, 0);
     if constexpr (RNG) ph = rng_begin(rg.state, rg.eff);
-    // the LDS staging (flags, biases) and the block's one barrier, called by each role BEHIND its first global loads: the bias load then
-    // flies together with them instead of ahead of them (two start-up misses back to back were 4-5 k cycles of every block: see
-    // k_triplet_fwd_ws)
-    auto stage_lds = [&]() {
-        if (tid < 32) s_ready[tid] = 0;
-        if (tid < 6 * 64) {
-            const int ch = tid & 63, g = (tid >> 6) % 3;
-            s_bias[tid] = ch < C ? (tid < 192 ? a.b_ih : a.b_hh)[g * C + ch] : 0.f;
-        }
-        __syncthreads();
-    };
+    // One barrier, at once (it only publishes the zeroed ring flags).  What the waves load first is ORDERED: the CU has one queue into
+    // memory, and the consumers' weight slices — 96 loads, 98 KB per block, ~5 k cycles to arrive (tools/ubench/slice_loads.hip) — ahead of
+    // the producers' first tiles kept the ring empty until 13 k cycles into a 33 k-cycle block (tools/gru_timeline.py).  The producers go
+    // first; the consumers wait for their check-in (s_ready[8]) before they issue theirs.  The biases ride in the consumers' registers.
+    if (tid < 32) s_ready[tid] = 0;
+    __syncthreads();
+    if (wave < P) GRU_TL(0, 4);
 
     if (wave < P) {
         // ---- producers.  A chunk of the tile = (row r, q): q < 16 -> x[row, 4 q ..], q >= 16 -> h[row, 4 (q - 16) ..]; every load is
@@ -586,19 +583,24 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
         };
         const int er = (lane + 64 * wave) >> 4, eq = (lane + 64 * wave) & 15;      // identity rows: one chunk per lane
         auto id_ok = [&](int tile) { return a.identity && tile < ntiles && tile * 16 + er < a.N && 4 * eq < C; };
+        // the three sources as VALUES in scalar registers: with `q < 16 ? a.x : a.h` written on the argument struct the compiler selected
+        // between the ADDRESSES of the two fields and loaded the pointer per lane — a dependent memory round trip and a wait for
+        // everything in flight in front of every row load (590 cycles per load in the prologue, and no prefetch in the loop)
+        const float* px = a.x; const float* ph_ = a.h; const float* pid = a.identity;
+        asm volatile("" : "+s"(px), "+s"(ph_), "+s"(pid));
         auto load = [&](int tile, float4 (&v)[3]) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
                 const size_t e = (size_t)(tile * 16 + r) * C + 4 * (q & 15);
-                v[j] = ld4(chunk_ok(tile, j) ? (q < 16 ? a.x : a.h) + e : a.x);
+                v[j] = ld4(chunk_ok(tile, j) ? (q < 16 ? px : ph_) + e : px);
             }
-            v[2] = ld4(id_ok(tile) ? a.identity + (size_t)(tile * 16 + er) * C + 4 * eq : a.x);
+            v[2] = ld4(id_ok(tile) ? pid + (size_t)(tile * 16 + er) * C + 4 * eq : px);
         };
         float4 buf[D][3];
 #pragma unroll
         for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
-        stage_lds();
+        if (lane == 0) flag_bump(s_ready + 8);      // (this wave's first loads are in the queue)
         GRU_TL(0, 1);
         for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
 #pragma unroll
@@ -626,6 +628,10 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                     }
                     *reinterpret_cast<float4*>(tl + 3 * PLANE + EPLANE + er * EPITCH + eq * 16) = id_ok(tile) ? buf[d][2] : f4zero();
                     load(tile + D * nblk, buf[d]);              // this register set's next tile, D tiles ahead
+                    // beyond the LLC three tiles of loads in flight per producer make the launch SLOWER (N = 326 400: 248 -> 280 us; the
+                    // pointer loads this kernel used to do by accident — see `px` above — had kept it to one): there the producer waits
+                    // for its prefetch
+                    if (a.N > 131072) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) flag_bump(s_ready + slot);
                 }
@@ -643,6 +649,8 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             int chw = 16 * w + c;
             asm volatile("" : "+v"(chw));          // (keeps these loads on the consumers' side of the role branch)
             const bool okw = chw < C;
+            while (flag_load(s_ready + 8) < P) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const int col = g * C + min(chw, C - 1);
@@ -650,7 +658,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
 #pragma unroll
                 for (int s = 0; s < 2; ++s) { ri[s][g] = w_load8(a.img_ih, MP, pos, 32 * s + 8 * kb, Kp); rh[s][g] = w_load8(a.img_hh, MP, pos, 32 * s + 8 * kb, Kp); }
             }
-            stage_lds();
+            GRU_TL(0, 1);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -660,8 +668,19 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 }
         }
         const int ch = 16 * w + 4 * kb;
+        float4 bias_i[3], bias_h[3];               // the lane's four channels of every gate (zero beyond C)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int cb = g * C + min(ch, C - 4);      // (unconditional loads: one under a condition is waited for on the spot)
+            bias_i[g] = ld4(a.b_ih + cb);
+            bias_h[g] = ld4(a.b_hh + cb);
+        }
+        if (ch >= C) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { bias_i[g] = f4zero(); bias_h[g] = f4zero(); }
+        }
+        GRU_TL(0, 4);
         int it = 0;
-        GRU_TL(0, 1);
         for (int tile = bid; tile < ntiles; tile += nblk, ++it) {
             if (it == 1) GRU_TL(0, 2);
             const int slot = it % RING, want = P * (it / RING + 1);
@@ -725,7 +744,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 float4 gi4[3], gh4[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    const float4 bi = *reinterpret_cast<const float4*>(s_bias + g * 64 + ch), bh = *reinterpret_cast<const float4*>(s_bias + (3 + g) * 64 + ch);
+                    const float4 bi = bias_i[g], bh = bias_h[g];
                     gi4[g] = make_float4(ai[g][0] + bi.x, ai[g][1] + bi.y, ai[g][2] + bi.z, ai[g][3] + bi.w);
                     gh4[g] = make_float4(ah[g][0] + bh.x, ah[g][1] + bh.y, ah[g][2] + bh.z, ah[g][3] + bh.w);
                     st4(a.gi + (size_t)row * 3 * C + g * C + ch, gi4[g]);
@@ -824,6 +843,7 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
         float4 buf[D][NL];
 #pragma unroll
         for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
+        if (lane == 0) flag_bump(s_ready + 8);      // (this wave's first loads are in the CU's queue: the consumers may issue theirs)
         GRU_TL(1, 1);
         for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
 #pragma unroll
@@ -911,6 +931,10 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
         asm volatile("" : "+v"(col));              // (keeps these loads on the consumers' side of the role branch)
         const bool okc = col < C;
         const int cc = min(col, C - 1), pos = (cc & 3) * 16 + (cc >> 2);       // ts_pos_of_col within the 64 positions of a row
+        // the producers' first tiles go into the CU's memory queue AHEAD of the 96 weight loads (see k_gru_fwd_ws): the producers are this
+        // launch's long pole (4.7 k cycles per tile), and behind the weights their first tile was published 15 k cycles into the block
+        while (flag_load(s_ready + 8) < P) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int s = 0; s < 6; ++s) raw[s] = w_load8(img, 64, pos, (s >> 1) * C + 32 * (s & 1) + 8 * kb, Kp);     // rows gate * C + channel
 #pragma unroll

@@ -48,6 +48,9 @@ for kid, name, nwaves in ((0, "k_gru_fwd_ws (4 producers + 4 consumers)", 8), (1
     t0 = a[:, :, 0].min(axis=1)[:, None]
     g, m = a[:, :4], a[:, 4:]
     print(f"{name}: {len(a)} blocks, {ntiles / len(a):.2f} tiles per block, N = {N}")
+    if kid == 0:
+        for label, v in (("producers: barrier passed", g[:, :, 4] - t0), ("consumers: weight loads issued", m[:, :, 1] - t0), ("consumers: barrier passed", m[:, :, 4] - t0)):
+            print(f"   {label:36s} mean {v.mean():8.0f}   min {v.min():8.0f}   max {v.max():8.0f}")
     for label, v in (("wave entry", a[:, :, 0] - t0), ("producers: first loads issued", g[:, :, 1] - t0), ("producers: first tile published", g[:, :, 2] - t0),
                      ("producers: loop end", g[:, :, 3] - t0), ("producers: drained", g[:, :, 5] - t0), ("consumers: weight slice split", m[:, :, 1] - t0),
                      ("consumers: first tile done", m[:, :, 2] - t0), ("consumers: loop end", m[:, :, 3] - t0), ("consumers: drained", m[:, :, 5] - t0)):
