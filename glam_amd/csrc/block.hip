@@ -82,13 +82,11 @@ __device__ __forceinline__ float act_fwd(float y, int act, float slope) {
     }
 }
 // d act / d y from the OUTPUT (out > 0 <=> y > 0 for all three; CELU: exp(y) = out + 1 on the negative side)
+// (selects, not a switch: as a switch on the wave-uniform `act` every element of an unrolled epilogue became four small basic blocks,
+//  each with its own conservative wait for the loads in flight)
 __device__ __forceinline__ float act_grad_from_out(float out, int act, float slope) {
-    switch (act) {
-        case kActRelu: return out > 0.f ? 1.f : 0.f;
-        case kActLeaky: return out > 0.f ? 1.f : slope;
-        case kActCelu: return out > 0.f ? 1.f : out + 1.f;
-        default: return 1.f;
-    }
+    const float neg = act == kActRelu ? 0.f : act == kActLeaky ? slope : act == kActCelu ? out + 1.f : 1.f;
+    return out > 0.f ? 1.f : neg;
 }
 
 template <bool RNG>
