@@ -44,8 +44,10 @@ __device__ long long g_ws_prof[64 * 12 * 8];
 #ifdef GLAM_WS_TL
 __device__ long long g_ws_tl[2 * 256 * 12 * 6];      // [kernel: forward | backward by source][block][wave][stamp], shader clock of the CU
 __device__ long long g_ws_rt[2 * 256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter (the shader clocks of two CUs are not in step)
-#define WS_TL(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
-    g_ws_tl[i_] = clock64(); g_ws_rt[i_] = wall_clock64(); } } while (0)
+// (clock reads as volatile assembly: the compiler moves a plain clock64() across the waits and loads it is meant to bracket)
+#define WS_TL(kid, k) do { unsigned long long c_, r_; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory"); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
+    g_ws_tl[i_] = (long long)c_; g_ws_rt[i_] = (long long)r_; } } while (0)
 #else
 #define WS_TL(kid, k) do { } while (0)
 #endif

@@ -29,8 +29,9 @@ namespace glam {
 #ifdef GLAM_WS_TL      // timeline stamps (tools/ws_timeline.py; see triplet_ws.hip): [block][wave][stamp]
 __device__ long long g_b1_tl[256 * 12 * 6];
 __device__ long long g_b1_rt[256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter
-#define B1_TL(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (blockIdx.x * 12 + (threadIdx.x >> 6)) * 6 + (k); \
-    g_b1_tl[i_] = clock64(); g_b1_rt[i_] = wall_clock64(); } } while (0)
+#define B1_TL(k) do { unsigned long long c_, r_; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory"); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (blockIdx.x * 12 + (threadIdx.x >> 6)) * 6 + (k); \
+    g_b1_tl[i_] = (long long)c_; g_b1_rt[i_] = (long long)r_; } } while (0)
 #else
 #define B1_TL(k) do { } while (0)
 #endif
