@@ -568,7 +568,9 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(pv, ti), f4get(qv, tj), acc[ti][tj], 0, 0, 0);
     };
     // the rows [r0, r1) of one operand set (ps / qs: this lane's column of P / Q, row 0)
-    auto rows = [&](int r0, int r1, const float* ps, const float* qs) {
+    // (always_inline: the SETS instantiation calls it twice, and as a real function its by-reference captures — the argument struct, the
+    //  64 accumulator registers — went through scratch memory: 408 bytes per lane, 87 scratch instructions)
+    auto rows = [&](int r0, int r1, const float* ps, const float* qs) __attribute__((always_inline)) {
         // full batches (4 kSteps rows, no masks), then one masked batch for the rest
         const int nfull = (r1 - r0) / (4 * kSteps);
         // ONE running pointer per operand: requests go out in row order (step after step, batch after batch)
@@ -628,16 +630,29 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     } else {
         // several operand sets of seg_rows rows each behind one another (the applications of a block that shares its weights): a wave's
         // range lies in one set or straddles ONE boundary (rows_per_wave <= seg_rows)
-        const int s0 = row0 / a.seg_rows, bnd = (s0 + 1) * a.seg_rows;
+        const int s0 = __builtin_amdgcn_readfirstlane(row0 / a.seg_rows), bnd = (s0 + 1) * a.seg_rows;
         const int e0 = min(row1, bnd);
-        auto base = [&](int sg, bool isq) -> const float* {
-            if (isq) return qld == 0 ? qsrc : (sg == 0 ? a.Q : a.segQ[sg - 1]) + qcol;
-            if (pld == 0) return psrc;
-            if (pcol < a.I1) return (sg == 0 ? a.P1 : a.segP1[sg - 1]) + pcol;
-            return (sg == 0 ? a.P2 : a.segP2[sg - 1]) + (pcol - a.I1);
-        };
-        rows(row0 - s0 * a.seg_rows, e0 - s0 * a.seg_rows, base(s0, false), base(s0, true));
-        if (row1 > bnd) rows(0, row1 - bnd, base(s0 + 1, false), base(s0 + 1, true));
+        // The nine base pointers as VALUES in scalar registers, each loaded from BOTH argument structs and pinned before anything selects
+        // between them.  A select between two argument FIELDS (`sg == 0 ? a.Q : a.segQ[0]`, `a.segQ[sg - 1]`, `second ? two.b.x : two.a.x`)
+        // is folded into a load from a selected ADDRESS, and a kernel argument addressed dynamically is first copied to scratch memory:
+        // 168-408 bytes per lane and 87 scratch instructions in this kernel (k_gru_fwd_ws had the same fold as per-lane pointer loads).
+#define GLAM_WG_PICK(name, field)                                                          \
+        const float* name;                                                                 \
+        { const float* x_ = two.a.field; const float* y_ = two.b.field; asm volatile("" : "+s"(x_), "+s"(y_)); name = second ? y_ : x_; }
+        GLAM_WG_PICK(q0, Q) GLAM_WG_PICK(q1, segQ[0]) GLAM_WG_PICK(q2, segQ[1])
+        GLAM_WG_PICK(p10, P1) GLAM_WG_PICK(p11, segP1[0]) GLAM_WG_PICK(p12, segP1[1])
+        GLAM_WG_PICK(p20, P2) GLAM_WG_PICK(p21, segP2[0]) GLAM_WG_PICK(p22, segP2[1])
+#undef GLAM_WG_PICK
+        // (plain values, no capturing lambda: see above)
+        const bool p_first = pcol < a.I1;
+        const int poff = p_first ? pcol : pcol - a.I1;
+        const float* pa0 = p_first ? p10 : p20; const float* pa1 = p_first ? p11 : p21; const float* pa2 = p_first ? p12 : p22;
+        const float* pb_s0 = pld == 0 ? psrc : (s0 == 0 ? pa0 : s0 == 1 ? pa1 : pa2) + poff;
+        const float* pb_s1 = pld == 0 ? psrc : (s0 == 0 ? pa1 : pa2) + poff;
+        const float* qb_s0 = qld == 0 ? qsrc : (s0 == 0 ? q0 : s0 == 1 ? q1 : q2) + qcol;
+        const float* qb_s1 = qld == 0 ? qsrc : (s0 == 0 ? q1 : q2) + qcol;
+        rows(row0 - s0 * a.seg_rows, e0 - s0 * a.seg_rows, pb_s0, qb_s0);
+        if (row1 > bnd) rows(0, row1 - bnd, pb_s1, qb_s1);
     }
     // ---- sum the 8 waves lane-for-lane (identical register layouts) in wave order.  Accumulator tile t = ti*4 + tj
     //      of a lane is one float4 (r = 0..3): 8 tiles per half go to LDS as b128 stores [wave][t][lane], thread

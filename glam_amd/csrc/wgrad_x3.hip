@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(kWxThreads) k_wgrad_x3(WgArgs2 two) {
         const int g = wave, c = lane & 15, kb = lane >> 4;
         // this lane's source column block: base pointer + row stride in floats (I1, I2, J are multiples of 4: no straddling)
         const float* P1 = a.P1; const float* P2 = a.P2; const float* Q = a.Q;
-        if (SEG && set > 0) { P1 = a.segP1[set - 1]; P2 = a.segP2[set - 1]; Q = a.segQ[set - 1]; }
+        // (static indices: `a.segP1[set - 1]` made the compiler put the whole argument struct into scratch memory — 168 bytes per lane —
+        // to index it)
+        if (SEG && set == 1) { P1 = a.segP1[0]; P2 = a.segP2[0]; Q = a.segQ[0]; }
+        if (SEG && set >= 2) { P1 = a.segP1[1]; P2 = a.segP2[1]; Q = a.segQ[1]; }
         const float* src;
         int ld = 0;
         if (g < kWxSlabs) {
@@ -247,7 +250,8 @@ static int launch_wx(const WgArgs2& two, int blocks, hipStream_t s) {
 int launch_wgrad_x3(const WgArgs2& two, int blocks, hipStream_t s) {
     const bool seg = two.a.nseg > 1, celu = two.a.q_celu || two.b.q_celu;
     int rc;
-    if (seg) { GLAM_PROF_LABEL("k_wgrad_x3<true, sets>"); rc = launch_wx<true, true>(two, blocks, s); }
+    if (seg && !celu) { GLAM_PROF_LABEL("k_wgrad_x3<false, sets>"); rc = launch_wx<false, true>(two, blocks, s); }
+    else if (seg) { GLAM_PROF_LABEL("k_wgrad_x3<true, sets>"); rc = launch_wx<true, true>(two, blocks, s); }
     else if (celu) { GLAM_PROF_LABEL("k_wgrad_x3<true>"); rc = launch_wx<true, false>(two, blocks, s); }
     else { GLAM_PROF_LABEL("k_wgrad_x3<false>"); rc = launch_wx<false, false>(two, blocks, s); }
     if (rc) return rc;
