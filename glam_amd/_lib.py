@@ -17,7 +17,7 @@ GLAM_E_INVALID, GLAM_E_UNSUPPORTED, GLAM_E_HIP = -1, -2, -3
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
-ABI_VERSION = 2     # = GLAM_ABI_VERSION of include/glam_hip.h: bumped with every change of an exported signature (kept next to SIGNATURES)
+ABI_VERSION = 3     # = GLAM_ABI_VERSION of include/glam_hip.h: bumped with every change of an exported signature (kept next to SIGNATURES)
 
 # name -> (restype, argtypes); mirrors include/glam_hip.h one to one
 SIGNATURES = {
@@ -70,6 +70,8 @@ SIGNATURES = {
     "glam_gru_bwd_ws_rng": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32] + [_vp] * 5 + [_vp]),
     "glam_gru_ws_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 4 + [_vp]),
     "glam_gru_ws_rng_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 7 + [_vp]),
+    "glam_gru_ws_fwd_xc": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
+    "glam_gru_ws_rng_fwd_xc": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8 + [_vp]),
     "glam_gru_fused_image_bytes": (_sz, []),
     "glam_gru_fused_make_images": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5),

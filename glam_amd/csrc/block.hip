@@ -358,6 +358,8 @@ struct GruFusedArgs {
     const float* x; const float* h; const float* identity; const float* img_ih; const float* img_hh; const float* b_ih; const float* b_hh;
     float* gi; float* gh; float* h_new; float* out;
     int N, C, celu_in, act; float slope;
+    float* x_celu;      // k_gru_fwd_ws, may be null: celu(x) [N, C] as the producers compute it — what the backward (celu_in = 2) and the weight
+                        // gradient (Q without its CELU) then read INSTEAD of x: no exponential in either
 };
 
 __global__ void __launch_bounds__(kBlock) k_gru_fused_images(const float* w_ih, const float* w_hh, int C, float* img_ih, float* img_hh) {
@@ -615,7 +617,10 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                         const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
                         float4 v = chunk_ok(tile, j) ? buf[d][j] : f4zero();
                         if (q >= 16) *reinterpret_cast<float4*>(tl + 3 * PLANE + r * EPITCH + (q - 16) * 16) = v;      // h, exact
-                        else if (a.celu_in) v = celu4(v);
+                        else if (a.celu_in) {
+                            v = celu4(v);
+                            if (a.x_celu && chunk_ok(tile, j)) st4(a.x_celu + (size_t)(tile * 16 + r) * C + 4 * q, v);
+                        }
                         unsigned h0, m0, l0, h1, m1, l1;
                         split2(v.x, v.y, h0, m0, l0);
                         split2(v.z, v.w, h1, m1, l1);
@@ -881,7 +886,8 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
                             (&pn4.x)[j] = d_pn;
                             (&pnr4.x)[j] = d_pn * r;
                             (&gz4.x)[j] = a.merge_identity ? g * z + dy : g * z;
-                            if (a.celu_in) (&cf4.x)[j] = celu1_grad(f4get(v[10], j));
+                            if (a.celu_in == 2) { const float xc = f4get(v[10], j); (&cf4.x)[j] = xc > 0.f ? 1.f : xc + 1.f; }      // x holds celu(x)
+                            else if (a.celu_in) (&cf4.x)[j] = celu1_grad(f4get(v[10], j));
                         }
                         if (a.d_identity && !a.merge_identity) st4(a.d_identity + i, dy4);
                         st4(a.d_gi + b, pr4); st4(a.d_gi + b + C, pz4); st4(a.d_gi + b + 2 * C, pn4);
@@ -1091,28 +1097,58 @@ static int gru_ws_args_ok(const char* fn, const GruFusedArgs& a, int64_t N) {
     return GLAM_OK;
 }
 
+static int gru_ws_fwd_impl(const char* fn, const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                           const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
+                           float* h_new, float* out, float* x_celu, hipStream_t s) {
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);
+    GLAM_REQUIRE(!x_celu || (celu_in && aligned16(x_celu)), "%s: x_celu needs celu_in and 16-byte alignment", fn);
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu};
+    if (int rc = gru_ws_args_ok(fn, a, N)) return rc;
+    if (N == 0) return GLAM_OK;
+    return gru_ws_launch(a, nullptr, s);
+}
 extern "C" int glam_gru_ws_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                                const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi,
                                float* gh, float* h_new, float* out, void* stream) {
-    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_ws_fwd: activation code %d", act);
-    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope};
-    if (int rc = gru_ws_args_ok("glam_gru_ws_fwd", a, N)) return rc;
-    if (N == 0) return GLAM_OK;
-    return gru_ws_launch(a, nullptr, (hipStream_t)stream);
+    return gru_ws_fwd_impl("glam_gru_ws_fwd", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new, out, nullptr,
+                           (hipStream_t)stream);
+}
+// ... also writing x_celu[N, C] = celu(x) (celu_in must be set): the tensor to keep for the backward INSTEAD of x — glam_gru_bwd_ws with
+// celu_in = 2 takes celu'(x) from it (x > 0 ? 1 : celu(x) + 1) and the weight gradient reads it as Q without a CELU of its own
+extern "C" int glam_gru_ws_fwd_xc(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                                  const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi,
+                                  float* gh, float* h_new, float* out, float* x_celu, void* stream) {
+    return gru_ws_fwd_impl("glam_gru_ws_fwd_xc", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new, out, x_celu,
+                           (hipStream_t)stream);
 }
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+static int gru_ws_rng_fwd_impl(const char* fn, const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                               const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
+                               float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
+                               float* out, float* out_drop, float* x_celu, hipStream_t s) {
+    if (int rc = rng_args_ok(fn, act, rr_lower, rr_upper, drop_p)) return rc;
+    GLAM_REQUIRE(!x_celu || (celu_in && aligned16(x_celu)), "%s: x_celu needs celu_in and 16-byte alignment", fn);
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu};
+    if (int rc = gru_ws_args_ok(fn, a, N)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(rng_state && rng_eff && aligned16(out_drop), "%s: null RNG state / misaligned out_drop", fn);
+    const TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, 1};
+    return gru_ws_launch(a, &rg, s);
+}
 extern "C" int glam_gru_ws_rng_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                                    const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope,
                                    float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi,
                                    float* gh, float* h_new, float* out, float* out_drop, void* stream) {
-    if (int rc = rng_args_ok("glam_gru_ws_rng_fwd", act, rr_lower, rr_upper, drop_p)) return rc;
-    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope};
-    if (int rc = gru_ws_args_ok("glam_gru_ws_rng_fwd", a, N)) return rc;
-    if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(rng_state && rng_eff && aligned16(out_drop), "glam_gru_ws_rng_fwd: null RNG state / misaligned out_drop");
-    const TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, 1};
-    return gru_ws_launch(a, &rg, (hipStream_t)stream);
+    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, rr_lower, rr_upper,
+                               drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, nullptr, (hipStream_t)stream);
+}
+extern "C" int glam_gru_ws_rng_fwd_xc(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                                      const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope,
+                                      float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi,
+                                      float* gh, float* h_new, float* out, float* out_drop, float* x_celu, void* stream) {
+    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd_xc", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, rr_lower, rr_upper,
+                               drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, x_celu, (hipStream_t)stream);
 }
 
 extern "C" int glam_gru_fused_supported(int C) { return C >= 4 && C <= 64 && (C & 3) == 0; }

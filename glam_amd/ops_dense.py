@@ -838,16 +838,23 @@ class _GruBlock(torch.autograd.Function):
             eff = torch.empty(2, dtype=torch.int64, device=dev)
             out_drop = torch.empty_like(h) if p > 0 else None
         # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
+        x_keep, x_is_celu = x, False
         if _want_gru_ws(lib, N, C):
             # the warp-specialised 3 x bf16 form of the fused step (block.hip: k_gru_fwd_ws), on the gate matrices' plain k_ts_gemm images
             img_a, img_b = image(w_ih), image(w_hh)
+            # with the folded CELU the launch also writes celu(x): the backward and the weight gradient read THAT instead of x and apply
+            # no exponential of their own (glam_gru_ws_fwd_xc)
+            xc = torch.empty_like(x) if (celu_in and N > 0) else None
             if rng is None:
-                check(lib.glam_gru_ws_fwd(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
-                                          int(celu_in), act, float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), st), "glam_gru_ws_fwd")
+                check(lib.glam_gru_ws_fwd_xc(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
+                                             int(celu_in), act, float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), ptr(xc), st),
+                      "glam_gru_ws_fwd_xc")
             else:
-                check(lib.glam_gru_ws_rng_fwd(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
-                                              int(celu_in), act, float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
-                                              ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_ws_rng_fwd")
+                check(lib.glam_gru_ws_rng_fwd_xc(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
+                                                 int(celu_in), act, float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
+                                                 ptr(h_new), ptr(out), ptr(out_drop), ptr(xc), st), "glam_gru_ws_rng_fwd_xc")
+            if xc is not None:
+                x_keep, x_is_celu = xc, True
         elif N > 0 and _want_gru_fused(N) and lib.glam_gru_fused_supported(C):
             # both gate linears + gates + residual + activation (+ RReLU / Dropout) in ONE launch (bit-identical to the sequence below)
             def build_fused():
@@ -880,7 +887,8 @@ class _GruBlock(torch.autograd.Function):
             else:     # training mode: RReLU slopes / the next conv's Dropout mask drawn inside the launch
                 check(lib.glam_gru_tail_rng_fwd(ptr(gi), ptr(gh), ptr(h), ptr(identity), N, C, act, float(slope), lo, hi, p,
                                                 ptr(_o.rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
-        ctx.save_for_backward(x, h, gi, gh, out, w_ih, w_hh)
+        ctx.save_for_backward(x_keep, h, gi, gh, out, w_ih, w_hh)
+        ctx.x_is_celu = x_is_celu
         # the first application of a block seeds the GRU state with the block input, which is also the skip connection (layer.py:253-254):
         # one tensor, two roles — the backward then returns ONE gradient for it (k_gru_bwd_ws adds d_identity into d_h)
         ctx.same_h_id = (identity is not None and identity.data_ptr() == h.data_ptr() and identity.shape == h.shape
@@ -897,6 +905,9 @@ class _GruBlock(torch.autograd.Function):
     def backward(ctx, d_out, d_hstate, d_out_drop=None, d_carry=None):
         x, h, gi, gh, out, w_ih, w_hh = ctx.saved_tensors
         act, slope, has_res, celu_in, rng = ctx.cfg
+        # x_is_celu: `x` holds celu(x) (the warp-specialised forward wrote it): celu' comes from it (flag 2) and Q needs no CELU
+        celu_bwd = 2 if ctx.x_is_celu else int(celu_in)
+        celu_q = celu_in and not ctx.x_is_celu
         N, C = h.shape
         M = 3 * C
         lib, dev = _lib.load(), x.device
@@ -928,13 +939,13 @@ class _GruBlock(torch.autograd.Function):
                 if d_out is None:
                     d_out = torch.zeros_like(h)
                 check(lib.glam_gru_bwd_ws(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), ptr(x), ptr(img_a), ptr(img_b), N, C,
-                                          int(celu_in), act, slope, merge, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st),
+                                          celu_bwd, act, slope, merge, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st),
                       "glam_gru_bwd_ws")
             else:
                 if d_out is None and d_out_drop is None:
                     d_out = torch.zeros_like(h)
                 check(lib.glam_gru_bwd_ws_rng(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), ptr(x), ptr(img_a),
-                                              ptr(img_b), N, C, int(celu_in), act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), merge, ptr(d_gi),
+                                              ptr(img_b), N, C, celu_bwd, act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), merge, ptr(d_gi),
                                               ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng")
             dh = d_h
         elif rng is None:
@@ -970,7 +981,7 @@ class _GruBlock(torch.autograd.Function):
             # three sets per launch.  3 launches + 3 reductions -> 1 + 1 per training step at message_steps = 3.
             key = ("gru-parked", id(w_ih))
             parked = scope.bwd.setdefault(key, (w_ih, []))[1]
-            parked.append((d_gi, x, d_gh, h, bool(celu_in)))
+            parked.append((d_gi, x, d_gh, h, bool(celu_q)))
             if not ctx.first_app:
                 return dx, dh, d_id, None, None, None, None, None, None, None, d_carry, None, None
             sets = list(parked)
@@ -999,7 +1010,7 @@ class _GruBlock(torch.autograd.Function):
         if ctx.carried and d_carry is not None and N > 0:
             dc = f32c(d_carry, "d_carry").split([M * C, M, M * C, M])
             d_carry = None
-        check(lib.glam_wgrad_gemm_pair_split(ptr(d_gi), M, M, ptr(x), C, C, int(celu_in), ptr(dw_ih), ptr(db_ih),
+        check(lib.glam_wgrad_gemm_pair_split(ptr(d_gi), M, M, ptr(x), C, C, int(celu_q), ptr(dw_ih), ptr(db_ih),
                                              ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
                                              ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
         if ctx.carried:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLAM_ABI_VERSION 2   /* bumped whenever an exported signature changes or an entry point goes away */
+#define GLAM_ABI_VERSION 3   /* bumped whenever an exported signature changes or an entry point goes away */
 
 #define GLAM_OK 0
 #define GLAM_E_INVALID (-1)     /* bad argument (null pointer, negative size, misaligned) */
@@ -622,6 +622,18 @@ int glam_gru_ws_rng_fwd(const float* x, const float* h, const float* identity, c
                         const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
                         float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
                         float* out, float* out_drop, void* stream);
+/* ... also writing x_celu[N, C] = celu(x), the CELU of src_1gp/layer.py:261 as the launch applies it (celu_in must be set; x_celu may be
+ * NULL): the tensor to keep for the backward INSTEAD of x.  glam_gru_bwd_ws(_rng) with celu_in = 2 takes x as celu(x) and forms
+ * celu'(x) = x > 0 ? 1 : celu(x) + 1 from it, and the weight gradient of W_ih reads it as Q without a CELU of its own
+ * (glam_wgrad_gemm_pair_split(_seg) with qcelu_a = 0): no exponential in either (the one wave that applied the CELU to all of Q set the
+ * pace of the weight-gradient launch: 35.3 -> 25.8 us for three applications at N = 20 400). */
+int glam_gru_ws_fwd_xc(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                       const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
+                       float* h_new, float* out, float* x_celu, void* stream);
+int glam_gru_ws_rng_fwd_xc(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
+                           const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
+                           float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
+                           float* out, float* out_drop, float* x_celu, void* stream);
 
 /* Backward of the same step in ONE launch: glam_gru_tail_bwd (resp. glam_gru_tail_rng_bwd) + the two input-gradient products
  *   d_x = d_gi @ W_ih (* celu'(x) when celu_in), d_h = d_gh @ W_hh + the direct g z path,

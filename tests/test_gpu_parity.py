@@ -3077,6 +3077,47 @@ def test_wgrad_pair_split_seg_c_abi(device, nseg, N, wgrad_route):
                                               p(out[3]), 2, p(ws), ws.numel(), None, None, None, None, ops._lib.stream()) == ops._lib.GLAM_E_INVALID
 
 
+@pytest.mark.parametrize("N,C", [(20400, 60), (777, 44), (16, 24)])
+def test_gru_forward_keeps_celu_x_for_the_backward(device, N, C):
+    """glam_gru_ws_fwd_xc: the same outputs as glam_gru_ws_fwd bit for bit plus x_celu = celu(x) (src_1gp/layer.py:261) as the launch applies
+    it; glam_gru_bwd_ws with celu_in = 2 on x_celu gives the gradients of celu_in = 1 on x (d_gi, d_gh, d_h, d_identity bit for bit: they do
+    not involve celu'; d_x within rounding: celu'(x) = celu(x) + 1 instead of exp(x) on the negative side)."""
+    lib, p = ops._lib.load(), ops._lib.ptr
+    st = ops._lib.stream
+    torch.manual_seed(N + C)
+    M = 3 * C
+    r = lambda *s: torch.randn(*s, device=device)
+    x, h, idn, w_ih, w_hh, b_ih, b_hh = r(N, C), r(N, C), r(N, C), r(M, C) * 0.3, r(M, C) * 0.3, r(M), r(M)
+    ia, ib = (torch.empty(lib.glam_ts_gemm_image_bytes(C, M) // 4, device=device) for _ in range(2))
+    ta, tb = (torch.empty(lib.glam_ts_gemm_image_bytes(M, C) // 4, device=device) for _ in range(2))
+    for w, i, t in ((w_ih, ia, ta), (w_hh, ib, tb)):
+        assert lib.glam_ts_gemm_make_image(p(w), C, 1, C, M, p(i), st()) == 0
+        assert lib.glam_ts_gemm_make_image(p(w), C, 0, M, C, p(t), st()) == 0
+    nan = lambda *s: torch.full(s, float("nan"), device=device)
+    a = [nan(N, M), nan(N, M), nan(N, C), nan(N, C)]
+    b = [nan(N, M), nan(N, M), nan(N, C), nan(N, C)]
+    xc = nan(N, C)
+    assert lib.glam_gru_ws_fwd(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(a[0]), p(a[1]), p(a[2]), p(a[3]), st()) == 0
+    assert lib.glam_gru_ws_fwd_xc(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(xc),
+                                  st()) == 0, lib.glam_last_error()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert_close(xc, torch.nn.functional.celu(x.double()), 2e-7, "x_celu")
+    assert lib.glam_gru_ws_fwd_xc(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 0, 1, 0.0, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(xc),
+                                  st()) == ops._lib.GLAM_E_INVALID                       # x_celu without the folded CELU
+    d_out, d_hs = r(N, C), r(N, C)
+    res = []
+    for flag, xin in ((1, x), (2, xc)):
+        o = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C)]
+        rc = lib.glam_gru_bwd_ws(p(a[0]), p(a[1]), p(h), p(a[3]), p(d_out), p(d_hs), p(xin), p(ta), p(tb), N, C, flag, 1, 0.0, 0, p(o[0]), p(o[1]),
+                                 p(o[2]), p(o[3]), p(o[4]), st())
+        assert rc == 0, lib.glam_last_error()
+        res.append(o)
+    for k in (0, 1, 2, 4):
+        assert torch.equal(res[0][k], res[1][k])
+    assert_close(res[1][3], res[0][3].double(), 3e-7, "d_x from celu(x)")
+
+
 @pytest.mark.parametrize("block", ["_TripletMessage", "_NNConv"])
 @pytest.mark.parametrize("steps", [1, 2, 3, 4])
 def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch, wgrad_route):
