@@ -593,9 +593,9 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             for (int j = 0; j < 2; ++j) {
                 const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
                 const size_t e = (size_t)(tile * 16 + r) * C + 4 * (q & 15);
-                v[j] = ld4(chunk_ok(tile, j) ? (q < 16 ? px : ph_) + e : px);
+                v[j] = ld4g(chunk_ok(tile, j) ? (q < 16 ? px : ph_) + e : px);      // (ld4g: the pinned pointers are generic to the compiler)
             }
-            v[2] = ld4(id_ok(tile) ? pid + (size_t)(tile * 16 + er) * C + 4 * eq : px);
+            v[2] = ld4g(id_ok(tile) ? pid + (size_t)(tile * 16 + er) * C + 4 * eq : px);
         };
         float4 buf[D][3];
 #pragma unroll

@@ -88,6 +88,20 @@ __device__ __forceinline__ float cross_group_sum(float v) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// ... from / to an address KNOWN to be global memory.  A pointer that reaches a load through a run-time choice (a job struct picked by
+// block index, a select against the address of a __device__ constant) is a generic pointer to the compiler and the access becomes a
+// flat_load / flat_store: those count in BOTH wait counters, so every wait for an LDS operation (lgkmcnt) also waits for the global loads
+// in flight — in a kernel that stages through LDS this serialises its prefetch.
+typedef float glam_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) glam_v4f glam_gv4;
+typedef __attribute__((address_space(1))) float glam_gf1;
+__device__ __forceinline__ float4 ld4g(const float* p) {
+    const glam_v4f v = *(const glam_gv4*)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ld1g(const float* p) { return *(const glam_gf1*)(p); }
+__device__ __forceinline__ void st4g(float* p, float4 v) { *(glam_gv4*)(p) = (glam_v4f){v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st1g(float* p, float v) { *(glam_gf1*)(p) = v; }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // base + 32-bit BYTE offset: lets the compiler use the scalar-base + 32-bit-VGPR-offset addressing mode instead of
 // 64-bit pointer arithmetic on the vector ALU (the hosts check that every tensor stays below 4 GiB)

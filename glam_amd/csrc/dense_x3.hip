@@ -68,11 +68,11 @@ __device__ __forceinline__ Quad ld_quad(const float* __restrict__ p, long long l
     const int lc = min(line, nlines - 1);
     const float* row = p + (long long)lc * ls;
     if (VEC) {
-        q.v = ld4(row + max(min(pos, npos - 4), 0));
+        q.v = ld4g(row + max(min(pos, npos - 4), 0));
         q.n = (line < nlines && pos < npos) ? 4 : 0;
     } else {
         const int last = npos - 1;
-        q.v = make_float4(row[min(pos, last)], row[min(pos + 1, last)], row[min(pos + 2, last)], row[min(pos + 3, last)]);
+        q.v = make_float4(ld1g(row + min(pos, last)), ld1g(row + min(pos + 1, last)), ld1g(row + min(pos + 2, last)), ld1g(row + min(pos + 3, last)));
         q.n = line < nlines ? max(min(npos - pos, 4), 0) : 0;
     }
     return q;
@@ -245,8 +245,8 @@ struct VecStage {
         for (int j = 0; j < NI; ++j) {
             const bool z = allz || (tailc && dead[j]);
             const int back = (PART && KC && tailc) ? 4 - nv[j] : 0;  // rows along k: the partial quad of the last chunk
-            q[j] = ld4(z ? zeros : p[j] - back);
-            if (GATE) g[j] = ld4(z ? zeros : gp[j] - back);
+            q[j] = ld4g(z ? zeros : p[j] - back);
+            if (GATE) g[j] = ld4g(z ? zeros : gp[j] - back);
             p[j] += step[j];
             if (GATE) gp[j] += step[j];
         }
@@ -358,7 +358,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& jb, int tile, char* lds
         const float* zeros = reinterpret_cast<const float*>(&g_zero_quad);
         const float* bp = jb.bias ? jb.bias : zeros;
         const int last = jb.bias ? jb.Cn - 1 : 0;
-        bias4[j] = make_float4(bp[min(col, last)], bp[min(col + 1, last)], bp[min(col + 2, last)], bp[min(col + 3, last)]);
+        bias4[j] = make_float4(ld1g(bp + min(col, last)), ld1g(bp + min(col + 1, last)), ld1g(bp + min(col + 2, last)), ld1g(bp + min(col + 3, last)));
     }
     DSTAMP(0);
     char* bufA = lds + grp * (6 * kGPlane);            // one buffer per group (its write and its reads are a barrier apart)
@@ -466,7 +466,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& jb, int tile, char* lds
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (ones_at >= 0 && col <= ones_at && ones_at < col + 4) {
                 const int e1 = ones_at - col;
-                jb.rowsum[row] = e1 == 0 ? v[0] : e1 == 1 ? v[1] : e1 == 2 ? v[2] : v[3];
+                st1g(jb.rowsum + row, e1 == 0 ? v[0] : e1 == 1 ? v[1] : e1 == 2 ? v[2] : v[3]);
             }
             if (col >= jb.Cn) continue;
             v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
@@ -476,10 +476,10 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& jb, int tile, char* lds
                 else if (jb.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * jb.act_slope;
             }
             float* dst = jb.C + (long long)row * jb.ldc + col;
-            if (jb.c_vec && col + 3 < jb.Cn) st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+            if (jb.c_vec && col + 3 < jb.Cn) st4g(dst, make_float4(v[0], v[1], v[2], v[3]));
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (col + e < jb.Cn) dst[e] = v[e];
+                for (int e = 0; e < 4; ++e) if (col + e < jb.Cn) st1g(dst + e, v[e]);
             }
         }
     }
@@ -526,8 +526,8 @@ struct KcArgs {
 
 __device__ __forceinline__ void kc_load(float4 (&q)[2], const float* row, int k, int K, bool row_ok) {
     // (unconditional loads from clamped addresses; what lies beyond K or the matrix is zeroed at the split)
-    q[0] = ld4(row + min(k, K - 4));
-    q[1] = ld4(row + min(k + 4, K - 4));
+    q[0] = ld4g(row + min(k, K - 4));
+    q[1] = ld4g(row + min(k + 4, K - 4));
     (void)row_ok;
 }
 __device__ __forceinline__ Bf16x3 kc_split(const float4 (&q)[2], int k, int K, bool row_ok) {
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256) k_dense_kc(KcArgs a) {
         const float* zeros = reinterpret_cast<const float*>(&g_zero_quad);
         const float* bp = a.bias ? a.bias : zeros;
         const int last = a.bias ? a.Cn - 1 : 0;
-        bias4[j] = make_float4(bp[min(col, last)], bp[min(col + 1, last)], bp[min(col + 2, last)], bp[min(col + 3, last)]);
+        bias4[j] = make_float4(ld1g(bp + min(col, last)), ld1g(bp + min(col + 1, last)), ld1g(bp + min(col + 2, last)), ld1g(bp + min(col + 3, last)));
     }
     v4f_t acc3[3][2][2];
 #pragma unroll
@@ -619,10 +619,10 @@ __global__ void __launch_bounds__(256) k_dense_kc(KcArgs a) {
                 else if (a.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
             }
             float* dst = a.C + (long long)row * a.ldc + col;
-            if (a.c_vec && col + 3 < a.Cn) st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+            if (a.c_vec && col + 3 < a.Cn) st4g(dst, make_float4(v[0], v[1], v[2], v[3]));
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (col + e < a.Cn) dst[e] = v[e];
+                for (int e = 0; e < 4; ++e) if (col + e < a.Cn) st1g(dst + e, v[e]);
             }
         }
     }

@@ -583,14 +583,14 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
         float4 pl[kSteps], ql[kSteps];
         if (nfull > 0) {
     #pragma unroll
-            for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
+            for (int st = 0; st < kSteps; ++st) { pl[st] = ld4g(pn); ql[st] = ld4g(qn); pn += pstep; qn += qstep; }
         }
         for (int b = 0; b + 1 < nfull; ++b) {
     #pragma unroll
             for (int st = 0; st < kSteps; ++st) {
                 mma(pl[st], ql[st]);
-                pl[st] = ld4(pn);
-                ql[st] = ld4(qn);
+                pl[st] = ld4g(pn);
+                ql[st] = ld4g(qn);
                 pn += pstep;
                 qn += qstep;
                 __builtin_amdgcn_sched_barrier(0);
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
         for (int b = 0; b < nfull; ++b) {
             float4 pl[kSteps], ql[kSteps];
     #pragma unroll
-            for (int st = 0; st < kSteps; ++st) { pl[st] = ld4(pn); ql[st] = ld4(qn); pn += pstep; qn += qstep; }
+            for (int st = 0; st < kSteps; ++st) { pl[st] = ld4g(pn); ql[st] = ld4g(qn); pn += pstep; qn += qstep; }
     #pragma unroll
             for (int st = 0; st < kSteps; ++st) mma(pl[st], ql[st]);
         }
@@ -616,8 +616,8 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     #pragma unroll
                 for (int st = 0; st < kSteps; ++st) {
                     const bool nok = n0 + 4 * st + kq < r1;
-                    pt[st] = nok ? ld4(pn + st * pstep) : f4zero();
-                    qt[st] = nok ? ld4(qn + st * qstep) : f4zero();
+                    pt[st] = nok ? ld4g(pn + st * pstep) : f4zero();
+                    qt[st] = nok ? ld4g(qn + st * qstep) : f4zero();
                 }
     #pragma unroll
                 for (int st = 0; st < kSteps; ++st)
