@@ -72,6 +72,12 @@ SIGNATURES = {
     "glam_gru_ws_rng_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 7 + [_vp]),
     "glam_gru_ws_fwd_xc": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_gru_ws_rng_fwd_xc": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8 + [_vp]),
+    "glam_gru_ws_pre_bytes": (_sz, []),
+    "glam_gru_ws_make_pre": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "glam_gru_ws_fwd_pre": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
+    "glam_gru_ws_rng_fwd_pre": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8 + [_vp]),
+    "glam_gru_bwd_ws_pre": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _i32] + [_vp] * 5 + [_vp]),
+    "glam_gru_bwd_ws_rng_pre": (_i32, [_vp] * 9 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32] + [_vp] * 5 + [_vp]),
     "glam_gru_fused_image_bytes": (_sz, []),
     "glam_gru_fused_make_images": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "glam_gru_fused_fwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5),

@@ -51,6 +51,8 @@ __device__ __forceinline__ Bf16x3 split8(float4 a, float4 b) {
     r.lo = __builtin_bit_cast(bf16x8_t, (u4){l[0], l[1], l[2], l[3]});
     return r;
 }
+// one stored operand fragment (16 bytes of a lane) from global memory
+__device__ __forceinline__ bf16x8_t ldfrag(const char* p) { return __builtin_bit_cast(bf16x8_t, *(const glam_gv4*)(p)); }
 // Rows k0 .. k0 + 7 of column position `pos` of a k_ts_gemm weight image (Kp rows in groups of four, MP positions per group; zero beyond
 // Kp).  The two loads are UNCONDITIONAL — a row group beyond the image re-reads the last one and is zeroed by w_split8 — so a prologue can
 // issue all of a wave's weight loads back to back and wait once: a load under a condition is waited for on the spot (one L2 round trip

@@ -360,6 +360,7 @@ struct GruFusedArgs {
     int N, C, celu_in, act; float slope;
     float* x_celu;      // k_gru_fwd_ws, may be null: celu(x) [N, C] as the producers compute it — what the backward (celu_in = 2) and the weight
                         // gradient (Q without its CELU) then read INSTEAD of x: no exponential in either
+    const void* pre;    // k_gru_fwd_ws, may be null: both gate matrices as the consumers' 3 x bf16 fragments (k_gru_ws_pre) — img_ih / img_hh unused
 };
 
 __global__ void __launch_bounds__(kBlock) k_gru_fused_images(const float* w_ih, const float* w_hh, int C, float* img_ih, float* img_hh) {
@@ -538,13 +539,17 @@ __global__ void __launch_bounds__(kGruBlock) k_gru_fused_fwd(GruFusedArgs a, Tai
 // ------------------------------------------------------------------------------------------------
 #ifdef GLAM_WS_TL      // timeline stamps of the two warp-specialised GRU kernels (tools/gru_timeline.py; see triplet_ws.hip)
 __device__ long long g_gru_tl[2 * 256 * 12 * 6];      // [forward | backward][block][wave][stamp], shader clock of the CU
-__device__ long long g_gru_rt[2 * 256 * 12 * 6];      // the same stamps on the device-wide 100 MHz counter
+__device__ long long g_gru_rt[2 * 256 * 12 * 6];
+__device__ long long g_gru_finef[256 * 12 * 16];     // forward, consumer tiles it == 0 (slots 0..4) and it == 2 (slots 8..12)      // the same stamps on the device-wide 100 MHz counter
 // (the clock reads are volatile assembly: the compiler moves a plain clock64() across waits and loads)
+#define GRU_FINEF(k) do { unsigned long long c_, r_; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory"); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_gru_finef[(blockIdx.x * 12 + (threadIdx.x >> 6)) * 16 + (k)] = (long long)c_; } while (0)
 #define GRU_TL(kid, k) do { unsigned long long c_, r_; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory"); \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { const int i_ = (((kid) * 256 + blockIdx.x) * 12 + (threadIdx.x >> 6)) * 6 + (k); \
     g_gru_tl[i_] = (long long)c_; g_gru_rt[i_] = (long long)r_; } } while (0)
 #else
 #define GRU_TL(kid, k) do { } while (0)
+#define GRU_FINEF(k) do { } while (0)
 #endif
 constexpr int kGwP = 4, kGwC = 4, kGwRing = 4, kGwD = 3;
 constexpr int kGwPitch = 416, kGwPlane = 16 * kGwPitch;                 // bf16 planes: 128 k of [celu(x) | h] per row (triplet_pipe.h: kX3RowBytes)
@@ -652,8 +657,24 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             int chw = 16 * w + c;
             asm volatile("" : "+v"(chw));          // (keeps these loads on the consumers' side of the role branch)
             const bool okw = chw < C;
+            GRU_FINEF(5);
             while (flag_load(s_ready + 8) < P) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
+            GRU_FINEF(6);
+            if (a.pre) {
+                // the fragments as k_gru_ws_pre wrote them: split already, in lane order — 36 coalesced 1 KB loads and no vector work
+                // (split here, 256 blocks each spent ~4 k cycles of their ~31 k on the same 96 values per lane: tools/gru_timeline.py)
+                const char* base = reinterpret_cast<const char*>(a.pre) + (size_t)w * (36 * 1024) + lane * 16;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const char* f = base + (g * 2 + s) * (6 * 1024);
+                        wih[s][g].hi = ldfrag(f); wih[s][g].mid = ldfrag(f + 1024); wih[s][g].lo = ldfrag(f + 2048);
+                        whh[s][g].hi = ldfrag(f + 3072); whh[s][g].mid = ldfrag(f + 4096); whh[s][g].lo = ldfrag(f + 5120);
+                    }
+                GRU_TL(0, 1);
+            } else {
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const int col = g * C + min(chw, C - 1);
@@ -662,6 +683,11 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 for (int s = 0; s < 2; ++s) { ri[s][g] = w_load8(a.img_ih, MP, pos, 32 * s + 8 * kb, Kp); rh[s][g] = w_load8(a.img_hh, MP, pos, 32 * s + 8 * kb, Kp); }
             }
             GRU_TL(0, 1);
+#ifdef GLAM_WS_TL
+            GRU_FINEF(7);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GRU_FINEF(13);
+#endif
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -669,6 +695,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                     wih[s][g] = w_split8(ri[s][g], 32 * s + 8 * kb, Kp, okw);
                     whh[s][g] = w_split8(rh[s][g], 32 * s + 8 * kb, Kp, okw);
                 }
+            }
         }
         const int ch = 16 * w + 4 * kb;
         float4 bias_i[3], bias_h[3];               // the lane's four channels of every gate (zero beyond C)
@@ -688,8 +715,10 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             if (it == 1) GRU_TL(0, 2);
             const int slot = it % RING, want = P * (it / RING + 1);
             const int row = 16 * tile + c;
+            if (it == 0) GRU_FINEF(0); else if (it == 2) GRU_FINEF(8);
             while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
+            if (it == 0) GRU_FINEF(1); else if (it == 2) GRU_FINEF(9);
             const char* tl = s_ring + slot * TILE + c * PITCH + kb * 16;       // row c, k = 32 s + 8 kb ..  (s = 0, 1: celu(x); 2, 3: h)
             v4f_t ai[3], ah[3];
 #pragma unroll
@@ -743,6 +772,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 }
                 xa = xb;
             }
+            if (it == 0) GRU_FINEF(2); else if (it == 2) GRU_FINEF(10);
             if (row < a.N && ch < C) {
                 float4 gi4[3], gh4[3];
 #pragma unroll
@@ -753,6 +783,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                     st4(a.gi + (size_t)row * 3 * C + g * C + ch, gi4[g]);
                     st4(a.gh + (size_t)row * 3 * C + g * C + ch, gh4[g]);
                 }
+                if (it == 0) GRU_FINEF(3); else if (it == 2) GRU_FINEF(11);
                 const size_t e = (size_t)row * C + ch;
                 uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
                 if constexpr (RNG) w4 = philox4(ph, e >> 2);
@@ -773,6 +804,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 st4(a.out + e, o4);
                 if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
             }
+            if (it == 0) GRU_FINEF(4); else if (it == 2) GRU_FINEF(12);
         }
         GRU_TL(0, 3);
     }
@@ -806,6 +838,7 @@ struct GruBwdArgs {
     int N, C, act, celu_in; float slope;
     int merge_identity;      // 1: the skip connection and the GRU state are the SAME tensor (first application of a block, layer.py:254):
                              //    d_h += d_identity here, d_identity is not written
+    const void* pre;         // may be null: both matrices as the consumers' 3 x bf16 fragments (k_gru_ws_pre) — img_ih_t / img_hh_t unused
 };
 
 template <bool RNG>
@@ -939,12 +972,18 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
         // launch's long pole (4.7 k cycles per tile), and behind the weights their first tile was published 15 k cycles into the block
         while (flag_load(s_ready + 8) < P) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
+        if (a.pre) {      // split already, in lane order (k_gru_ws_pre): see k_gru_fwd_ws
+            const char* base = reinterpret_cast<const char*>(a.pre) + (size_t)w * (18 * 1024) + lane * 16;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) { wreg[s].hi = ldfrag(base + s * 3072); wreg[s].mid = ldfrag(base + s * 3072 + 1024); wreg[s].lo = ldfrag(base + s * 3072 + 2048); }
+        } else {
 #pragma unroll
         for (int s = 0; s < 6; ++s) raw[s] = w_load8(img, 64, pos, (s >> 1) * C + 32 * (s & 1) + 8 * kb, Kp);     // rows gate * C + channel
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const int ch0 = 32 * (s & 1) + 8 * kb;                                // (a gate's rows end at channel C: the next gate's follow)
             wreg[s] = split8((okc && ch0 < C) ? raw[s].a : f4zero(), (okc && ch0 + 4 < C) ? raw[s].b : f4zero());
+        }
         }
     }
     const int ch = 16 * ct + 4 * kb;
@@ -994,6 +1033,9 @@ using namespace glam;
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
 #ifdef GLAM_WS_TL
+extern "C" int glam_debug_gru_finef(long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_finef), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
 extern "C" int glam_debug_gru_tl(long long* host_out, int n, int device_wide) {
     return (device_wide ? hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_rt), (size_t)n * sizeof(long long))
                         : hipMemcpyFromSymbol(host_out, HIP_SYMBOL(glam::g_gru_tl), (size_t)n * sizeof(long long))) == hipSuccess ? 0 : 1;
@@ -1022,6 +1064,40 @@ static int gru_fused_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_
     return GLAM_OK;
 }
 
+// The gate matrices as the matrix waves of k_gru_fwd_ws / k_gru_bwd_ws hold them: every operand fragment split into its three bf16 terms
+// ONCE per weight update, stored in lane order (fragment f, term t, lane l -> 16 bytes at ((3 f + t) * 64 + l) * 16) — the values
+// split8 produces in the kernels' own prologue, which 256 blocks x 6 launches of a training step otherwise each redo.
+//   forward image : f = 12 w + 2 (2 g + s) + m     wave w (channels 16 w ..), gate g, k step s, matrix m (0: W_ih, 1: W_hh);
+//                   lane (c, kb) holds W_m[g C + 16 w + c][32 s + 8 kb .. + 7]
+//   backward image: f = 6 w + s                     wave w = 4 m + ct (columns 16 ct ..), s = 2 gate + k step of the gate's C rows;
+//                   lane (c, kb) holds W_m[(s >> 1) C + 32 (s & 1) + 8 kb .. + 7][16 ct + c]
+// (zero where the channel / column index reaches C)
+constexpr int kGruPreFrags = 48, kGruPreBytes = kGruPreFrags * 3 * 1024;
+__global__ void __launch_bounds__(64) k_gru_ws_pre(const float* w_ih, const float* w_hh, int C, char* pre_fwd, char* pre_bwd) {
+    const int lane = threadIdx.x, c = lane & 15, kb = lane >> 4;
+    const bool bwd = blockIdx.x >= kGruPreFrags;
+    const int f = blockIdx.x - (bwd ? kGruPreFrags : 0);
+    char* dst = bwd ? pre_bwd : pre_fwd;
+    if (!dst) return;
+    float v[8];
+    if (!bwd) {
+        const int w = f / 12, r = f % 12, gs = r >> 1, m = r & 1, g = gs >> 1, s = gs & 1;
+        const float* W = m ? w_hh : w_ih;
+        const int ch = 16 * w + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = 32 * s + 8 * kb + j; v[j] = (ch < C && k < C) ? W[(size_t)(g * C + ch) * C + k] : 0.f; }
+    } else {
+        const int w = f / 6, s = f % 6, m = w >> 2, ct = w & 3;
+        const float* W = m ? w_hh : w_ih;
+        const int col = 16 * ct + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int ch = 32 * (s & 1) + 8 * kb + j; v[j] = (col < C && ch < C) ? W[(size_t)((s >> 1) * C + ch) * C + col] : 0.f; }
+    }
+    const Bf16x3 x = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    char* o = dst + (size_t)f * 3072 + lane * 16;
+    *reinterpret_cast<bf16x8_t*>(o) = x.hi; *reinterpret_cast<bf16x8_t*>(o + 1024) = x.mid; *reinterpret_cast<bf16x8_t*>(o + 2048) = x.lo;
+}
+
 static int gru_bwd_ws_launch(const GruBwdArgs& a, const TailRngB* rg, hipStream_t s) {
     static bool big0[64] = {}, big1[64] = {};
     if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<false>), big0, "gru_bwd_ws")) return rc;
@@ -1038,38 +1114,82 @@ static int gru_bwd_ws_args_ok(const char* fn, const GruBwdArgs& a, int64_t N, co
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
     if (!(a.C >= 24 && a.C <= 64 && (a.C & 3) == 0)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in 24..64", fn, a.C);
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(a.gi && a.gh && a.h && a.out && (a.d_out || d_out_drop) && a.img_ih_t && a.img_hh_t && a.d_gi && a.d_gh && a.d_x && a.d_h &&
+    GLAM_REQUIRE(a.gi && a.gh && a.h && a.out && (a.d_out || d_out_drop) && (a.pre || (a.img_ih_t && a.img_hh_t)) && a.d_gi && a.d_gh && a.d_x && a.d_h &&
                      (!a.celu_in || a.x), "%s: null pointer", fn);
     GLAM_REQUIRE(aligned16(a.gi) && aligned16(a.gh) && aligned16(a.h) && aligned16(a.out) && aligned16(a.d_out) && aligned16(a.d_hstate) && aligned16(a.x) &&
                      aligned16(a.img_ih_t) && aligned16(a.img_hh_t) && aligned16(a.d_gi) && aligned16(a.d_gh) && aligned16(a.d_identity) &&
-                     aligned16(a.d_x) && aligned16(a.d_h) && aligned16(d_out_drop), "%s: pointers must be 16-byte aligned", fn);
+                     aligned16(a.d_x) && aligned16(a.d_h) && aligned16(d_out_drop) && aligned16(a.pre), "%s: pointers must be 16-byte aligned", fn);
     return GLAM_OK;
 }
 
+static int gru_bwd_ws_impl(const char* fn, const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                           const float* d_hstate, const float* x, const float* img_ih_t, const float* img_hh_t, const void* pre, int64_t N, int C,
+                           int celu_in, int act, float slope, int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x,
+                           float* d_h, hipStream_t s) {
+    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);
+    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope,
+                       merge_identity ? 1 : 0, pre};
+    if (int rc = gru_bwd_ws_args_ok(fn, a, N, nullptr)) return rc;
+    if (N == 0) return GLAM_OK;
+    return gru_bwd_ws_launch(a, nullptr, s);
+}
 extern "C" int glam_gru_bwd_ws(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
                                const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C, int celu_in, int act, float slope,
                                int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
-    if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "glam_gru_bwd_ws: activation code %d", act);
-    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope,
-                       merge_identity ? 1 : 0};
-    if (int rc = gru_bwd_ws_args_ok("glam_gru_bwd_ws", a, N, nullptr)) return rc;
-    if (N == 0) return GLAM_OK;
-    return gru_bwd_ws_launch(a, nullptr, (hipStream_t)stream);
+    return gru_bwd_ws_impl("glam_gru_bwd_ws", gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, nullptr, N, C, celu_in, act, slope,
+                           merge_identity, d_gi, d_gh, d_identity, d_x, d_h, (hipStream_t)stream);
+}
+// ... with the matrices from the backward image of glam_gru_ws_make_pre instead of the two k_ts_gemm images (same values, bit for bit)
+extern "C" int glam_gru_bwd_ws_pre(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
+                                   const float* x, const void* pre_bwd, int64_t N, int C, int celu_in, int act, float slope,
+                                   int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
+    GLAM_REQUIRE(pre_bwd || N == 0, "glam_gru_bwd_ws_pre: null image");
+    return gru_bwd_ws_impl("glam_gru_bwd_ws_pre", gi, gh, h, out, d_out, d_hstate, x, nullptr, nullptr, pre_bwd, N, C, celu_in, act, slope,
+                           merge_identity, d_gi, d_gh, d_identity, d_x, d_h, (hipStream_t)stream);
 }
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
+static int gru_bwd_ws_rng_impl(const char* fn, const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                               const float* d_out_drop, const float* d_hstate, const float* x, const float* img_ih_t, const float* img_hh_t,
+                               const void* pre, int64_t N, int C, int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p,
+                               const int64_t* rng_eff, int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h,
+                               hipStream_t s) {
+    if (int rc = rng_args_ok(fn, act, rr_lower, rr_upper, drop_p)) return rc;
+    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope,
+                       merge_identity ? 1 : 0, pre};
+    if (int rc = gru_bwd_ws_args_ok(fn, a, N, d_out_drop)) return rc;
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(rng_eff, "%s: null rng_eff", fn);
+    const TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, 1};
+    return gru_bwd_ws_launch(a, &rg, s);
+}
 extern "C" int glam_gru_bwd_ws_rng(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_out_drop,
                                    const float* d_hstate, const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C,
                                    int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
                                    int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
-    if (int rc = rng_args_ok("glam_gru_bwd_ws_rng", act, rr_lower, rr_upper, drop_p)) return rc;
-    const GruBwdArgs a{gi, gh, h, out, d_out, d_hstate, x, img_ih_t, img_hh_t, d_gi, d_gh, d_identity, d_x, d_h, (int)N, C, act, celu_in, slope,
-                       merge_identity ? 1 : 0};
-    if (int rc = gru_bwd_ws_args_ok("glam_gru_bwd_ws_rng", a, N, d_out_drop)) return rc;
-    if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(rng_eff, "glam_gru_bwd_ws_rng: null rng_eff");
-    const TailRngB rg{reinterpret_cast<const long long*>(rng_eff), rr_lower, rr_upper, drop_p, d_out_drop, 1};
-    return gru_bwd_ws_launch(a, &rg, (hipStream_t)stream);
+    return gru_bwd_ws_rng_impl("glam_gru_bwd_ws_rng", gi, gh, h, out, d_out, d_out_drop, d_hstate, x, img_ih_t, img_hh_t, nullptr, N, C, celu_in,
+                               act, slope, rr_lower, rr_upper, drop_p, rng_eff, merge_identity, d_gi, d_gh, d_identity, d_x, d_h,
+                               (hipStream_t)stream);
+}
+extern "C" int glam_gru_bwd_ws_rng_pre(const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                                       const float* d_out_drop, const float* d_hstate, const float* x, const void* pre_bwd, int64_t N, int C,
+                                       int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
+                                       int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream) {
+    GLAM_REQUIRE(pre_bwd || N == 0, "glam_gru_bwd_ws_rng_pre: null image");
+    return gru_bwd_ws_rng_impl("glam_gru_bwd_ws_rng_pre", gi, gh, h, out, d_out, d_out_drop, d_hstate, x, nullptr, nullptr, pre_bwd, N, C,
+                               celu_in, act, slope, rr_lower, rr_upper, drop_p, rng_eff, merge_identity, d_gi, d_gh, d_identity, d_x, d_h,
+                               (hipStream_t)stream);
+}
+
+extern "C" size_t glam_gru_ws_pre_bytes(void) { return (size_t)kGruPreBytes; }
+// both images (either may be null) from weight_ih / weight_hh [3C, C] (contiguous) in one launch
+extern "C" int glam_gru_ws_make_pre(const float* w_ih, const float* w_hh, int C, void* pre_fwd, void* pre_bwd, void* stream) {
+    if (!(C >= 24 && C <= 64 && (C & 3) == 0)) return fail(GLAM_E_UNSUPPORTED, "glam_gru_ws_make_pre: C=%d must be a multiple of 4 in 24..64", C);
+    GLAM_REQUIRE(w_ih && w_hh && aligned16(pre_fwd) && aligned16(pre_bwd), "glam_gru_ws_make_pre: null / misaligned pointer");
+    if (!pre_fwd && !pre_bwd) return GLAM_OK;
+    hipLaunchKernelGGL(k_gru_ws_pre, dim3(2 * kGruPreFrags), dim3(64), 0, (hipStream_t)stream, w_ih, w_hh, C, (char*)pre_fwd, (char*)pre_bwd);
+    GLAM_LAUNCH_CHECK("glam_gru_ws_make_pre");
+    return GLAM_OK;
 }
 
 // the warp-specialised 3 x bf16 form: weights from the k_ts_gemm images of the gate matrices (K = C, M = 3 C with 64 < 3 C <= 192)
@@ -1091,18 +1211,18 @@ static int gru_ws_args_ok(const char* fn, const GruFusedArgs& a, int64_t N) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
     if (!glam_gru_ws_supported(a.C)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in 24..64", fn, a.C);
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(a.x && a.h && a.img_ih && a.img_hh && a.b_ih && a.b_hh && a.gi && a.gh && a.h_new && a.out, "%s: null pointer", fn);
-    GLAM_REQUIRE(aligned16(a.x) && aligned16(a.h) && aligned16(a.identity) && aligned16(a.img_ih) && aligned16(a.img_hh) && aligned16(a.gi) &&
+    GLAM_REQUIRE(a.x && a.h && (a.pre || (a.img_ih && a.img_hh)) && a.b_ih && a.b_hh && a.gi && a.gh && a.h_new && a.out, "%s: null pointer", fn);
+    GLAM_REQUIRE(aligned16(a.x) && aligned16(a.h) && aligned16(a.identity) && aligned16(a.img_ih) && aligned16(a.img_hh) && aligned16(a.pre) && aligned16(a.gi) &&
                      aligned16(a.gh) && aligned16(a.h_new) && aligned16(a.out), "%s: pointers must be 16-byte aligned", fn);
     return GLAM_OK;
 }
 
 static int gru_ws_fwd_impl(const char* fn, const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
-                           const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
+                           const void* pre, const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
                            float* h_new, float* out, float* x_celu, hipStream_t s) {
     if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);
     GLAM_REQUIRE(!x_celu || (celu_in && aligned16(x_celu)), "%s: x_celu needs celu_in and 16-byte alignment", fn);
-    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu};
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu, pre};
     if (int rc = gru_ws_args_ok(fn, a, N)) return rc;
     if (N == 0) return GLAM_OK;
     return gru_ws_launch(a, nullptr, s);
@@ -1110,7 +1230,7 @@ static int gru_ws_fwd_impl(const char* fn, const float* x, const float* h, const
 extern "C" int glam_gru_ws_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                                const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi,
                                float* gh, float* h_new, float* out, void* stream) {
-    return gru_ws_fwd_impl("glam_gru_ws_fwd", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new, out, nullptr,
+    return gru_ws_fwd_impl("glam_gru_ws_fwd", x, h, identity, img_ih, img_hh, nullptr, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new, out, nullptr,
                            (hipStream_t)stream);
 }
 // ... also writing x_celu[N, C] = celu(x) (celu_in must be set): the tensor to keep for the backward INSTEAD of x — glam_gru_bwd_ws with
@@ -1118,18 +1238,18 @@ extern "C" int glam_gru_ws_fwd(const float* x, const float* h, const float* iden
 extern "C" int glam_gru_ws_fwd_xc(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                                   const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi,
                                   float* gh, float* h_new, float* out, float* x_celu, void* stream) {
-    return gru_ws_fwd_impl("glam_gru_ws_fwd_xc", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new, out, x_celu,
+    return gru_ws_fwd_impl("glam_gru_ws_fwd_xc", x, h, identity, img_ih, img_hh, nullptr, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new, out, x_celu,
                            (hipStream_t)stream);
 }
 
 static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
 static int gru_ws_rng_fwd_impl(const char* fn, const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
-                               const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
+                               const void* pre, const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
                                float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
                                float* out, float* out_drop, float* x_celu, hipStream_t s) {
     if (int rc = rng_args_ok(fn, act, rr_lower, rr_upper, drop_p)) return rc;
     GLAM_REQUIRE(!x_celu || (celu_in && aligned16(x_celu)), "%s: x_celu needs celu_in and 16-byte alignment", fn);
-    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu};
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu, pre};
     if (int rc = gru_ws_args_ok(fn, a, N)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(rng_state && rng_eff && aligned16(out_drop), "%s: null RNG state / misaligned out_drop", fn);
@@ -1140,15 +1260,33 @@ extern "C" int glam_gru_ws_rng_fwd(const float* x, const float* h, const float* 
                                    const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope,
                                    float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi,
                                    float* gh, float* h_new, float* out, float* out_drop, void* stream) {
-    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, rr_lower, rr_upper,
+    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd", x, h, identity, img_ih, img_hh, nullptr, b_ih, b_hh, N, C, celu_in, act, slope, rr_lower, rr_upper,
                                drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, nullptr, (hipStream_t)stream);
 }
 extern "C" int glam_gru_ws_rng_fwd_xc(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                                       const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope,
                                       float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi,
                                       float* gh, float* h_new, float* out, float* out_drop, float* x_celu, void* stream) {
-    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd_xc", x, h, identity, img_ih, img_hh, b_ih, b_hh, N, C, celu_in, act, slope, rr_lower, rr_upper,
+    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd_xc", x, h, identity, img_ih, img_hh, nullptr, b_ih, b_hh, N, C, celu_in, act, slope, rr_lower, rr_upper,
                                drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, x_celu, (hipStream_t)stream);
+}
+
+// ... with the gate matrices from the forward image of glam_gru_ws_make_pre instead of the two k_ts_gemm images (same values, bit for
+// bit; x_celu may be null)
+extern "C" int glam_gru_ws_fwd_pre(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                                   const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh, float* h_new,
+                                   float* out, float* x_celu, void* stream) {
+    GLAM_REQUIRE(pre_fwd || N == 0, "glam_gru_ws_fwd_pre: null image");
+    return gru_ws_fwd_impl("glam_gru_ws_fwd_pre", x, h, identity, nullptr, nullptr, pre_fwd, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh, h_new,
+                           out, x_celu, (hipStream_t)stream);
+}
+extern "C" int glam_gru_ws_rng_fwd_pre(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                                       const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower, float rr_upper,
+                                       float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new, float* out,
+                                       float* out_drop, float* x_celu, void* stream) {
+    GLAM_REQUIRE(pre_fwd || N == 0, "glam_gru_ws_rng_fwd_pre: null image");
+    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd_pre", x, h, identity, nullptr, nullptr, pre_fwd, b_ih, b_hh, N, C, celu_in, act, slope,
+                               rr_lower, rr_upper, drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, x_celu, (hipStream_t)stream);
 }
 
 extern "C" int glam_gru_fused_supported(int C) { return C >= 4 && C <= 64 && (C & 3) == 0; }

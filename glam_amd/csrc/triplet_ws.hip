@@ -139,11 +139,21 @@ __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, con
     Bf16x3 wreg[6];
     {
         WRaw8 raw[6];
+#ifdef GLAM_HACK_PRESPLIT
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {       // TIMING ONLY (wrong values): fragments as if stored split, in lane order
+            auto at = [&](int k) { return reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const char*>(img) + (((w * 18 + k) * 1024) % (Kp * 256)) + lane * 16); };
+            wreg[s].hi = *at(3 * s); wreg[s].mid = *at(3 * s + 1); wreg[s].lo = *at(3 * s + 2);
+        }
+        (void)raw; (void)pos;
+        stage();
+#else
 #pragma unroll
         for (int s = 0; s < 6; ++s) raw[s] = w_load8(img, 64, pos, 32 * s + 8 * kb, Kp);
         stage();      // (the block's LDS staging: its W_edge load flies with the weight slice, the split waits for both)
 #pragma unroll
         for (int s = 0; s < 6; ++s) wreg[s] = w_split8(raw[s], 32 * s + 8 * kb, Kp);
+#endif
     }
     const float bias = (bias_p && col < Cp) ? bias_p[col] : 0.f;
     const int nks = (K + 31) >> 5;                            // 32-k steps that hold data (<= 6)

@@ -1156,6 +1156,9 @@ GRU_WS = "1"
 SKIP_THROUGH_CONV = True
 # the GRU's weight gradients of all applications of a block in one launch pair (glam_wgrad_gemm_pair_split_seg): A/B switch
 GRU_WGRAD_BATCH = True
+# the warp-specialised GRU step on pre-split operand fragments of its gate matrices (glam_gru_ws_make_pre) instead of splitting the plain
+# images in every block's prologue: A/B switch (GLAM_GRU_PRE=0)
+GRU_PRE = os.environ.get("GLAM_GRU_PRE", "1") != "0"
 # PairNorm + the Dropout behind it from one launch each way (glam_graph_norm_drop_*): A/B switch
 NORM_DROP = True
 # the derived weights of a model pass from one launch (glam_prestage) instead of one per module: A/B switch

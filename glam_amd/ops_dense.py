@@ -749,13 +749,25 @@ def _want_gru_ws(lib, N, C):
     return N > 0 and _o.GRU_WS == "1" and _lib.route_enabled("x3") and lib.glam_gru_ws_supported(C) == 1
 
 
+def _gru_pre(lib, scope, w_ih, w_hh, C, dev, st):
+    """[2, bytes] uint8: the forward and the backward image of ``glam_gru_ws_make_pre`` for this pair of gate matrices — one launch per
+    weight scope (a training step), shared by every application of the block and by its backward."""
+    def build():
+        buf = torch.empty(2, lib.glam_gru_ws_pre_bytes(), dtype=torch.uint8, device=dev)
+        check(lib.glam_gru_ws_make_pre(ptr(w_ih), ptr(w_hh), C, ptr(buf[0]), ptr(buf[1]), st), "glam_gru_ws_make_pre")
+        return buf
+    return _o._scoped(scope.fwd if scope else None, ("gru-pre", id(w_ih), id(w_hh)), w_ih, build)
+
+
 def gru_images_plain(N, C):
     """True when the GRU step of this size runs on the four plain ``k_ts_gemm`` images of its gate matrices (the warp-specialised step,
     or the unfused gate linears) — the set ``ops.prestage`` can build ahead; the fp32 fused step needs its gate-padded images too."""
     lib = _lib.load()
     if N <= 0 or not linear_supported(C, 3 * C) or lib.glam_ts_gemm_image_bytes(3 * C, C) <= 0:
         return False
-    return _want_gru_ws(lib, N, C) or not (_want_gru_fused(N) and lib.glam_gru_fused_supported(C))
+    if _want_gru_ws(lib, N, C):
+        return not _o.GRU_PRE          # (the warp-specialised step reads its own pre-split images: glam_gru_ws_make_pre)
+    return not (_want_gru_fused(N) and lib.glam_gru_fused_supported(C))
 
 
 def _want_gru_fused(N):
@@ -810,7 +822,9 @@ class _GruBlock(torch.autograd.Function):
 
         gi, gh = torch.empty(N, M, **f), torch.empty(N, M, **f)
         st = stream()
-        if scope is not None:
+        ws_route = _want_gru_ws(lib, N, C)
+        pre = _gru_pre(lib, scope, w_ih, w_hh, C, dev, st) if (ws_route and _o.GRU_PRE) else None
+        if scope is not None and pre is None:
             # all four images of the step (forward and input-gradient images of both gate matrices) in ONE launch, shared by the
             # message_steps applications of the block through the scope tables
             ka, kb = ("lin", id(w_ih)), ("lin", id(w_hh))
@@ -839,17 +853,26 @@ class _GruBlock(torch.autograd.Function):
             out_drop = torch.empty_like(h) if p > 0 else None
         # celu_in: x is the raw conv output and the CELU of layer.py:261 is applied inside the gate GEMM's operand load
         x_keep, x_is_celu = x, False
-        if _want_gru_ws(lib, N, C):
-            # the warp-specialised 3 x bf16 form of the fused step (block.hip: k_gru_fwd_ws), on the gate matrices' plain k_ts_gemm images
-            img_a, img_b = image(w_ih), image(w_hh)
-            # with the folded CELU the launch also writes celu(x): the backward and the weight gradient read THAT instead of x and apply
-            # no exponential of their own (glam_gru_ws_fwd_xc)
+        if ws_route:
+            # the warp-specialised 3 x bf16 form of the fused step (block.hip: k_gru_fwd_ws).  With the folded CELU the launch also writes
+            # celu(x): the backward and the weight gradient read THAT instead of x and apply no exponential of their own
             xc = torch.empty_like(x) if (celu_in and N > 0) else None
-            if rng is None:
+            if pre is not None:
+                # ... on the gate matrices as pre-split operand fragments (glam_gru_ws_make_pre: once per weight update, not per block)
+                if rng is None:
+                    check(lib.glam_gru_ws_fwd_pre(ptr(x), ptr(h), ptr(identity), ptr(pre[0]), ptr(b_ih), ptr(b_hh), N, C, int(celu_in), act,
+                                                  float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), ptr(xc), st), "glam_gru_ws_fwd_pre")
+                else:
+                    check(lib.glam_gru_ws_rng_fwd_pre(ptr(x), ptr(h), ptr(identity), ptr(pre[0]), ptr(b_ih), ptr(b_hh), N, C, int(celu_in), act,
+                                                      float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh), ptr(h_new),
+                                                      ptr(out), ptr(out_drop), ptr(xc), st), "glam_gru_ws_rng_fwd_pre")
+            elif rng is None:
+                img_a, img_b = image(w_ih), image(w_hh)       # (the plain k_ts_gemm images: GLAM_GRU_PRE=0)
                 check(lib.glam_gru_ws_fwd_xc(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
                                              int(celu_in), act, float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), ptr(xc), st),
                       "glam_gru_ws_fwd_xc")
             else:
+                img_a, img_b = image(w_ih), image(w_hh)
                 check(lib.glam_gru_ws_rng_fwd_xc(ptr(x), ptr(h), ptr(identity), ptr(img_a), ptr(img_b), ptr(b_ih), ptr(b_hh), N, C,
                                                  int(celu_in), act, float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
                                                  ptr(h_new), ptr(out), ptr(out_drop), ptr(xc), st), "glam_gru_ws_rng_fwd_xc")
@@ -889,6 +912,7 @@ class _GruBlock(torch.autograd.Function):
                                                 ptr(_o.rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
         ctx.save_for_backward(x_keep, h, gi, gh, out, w_ih, w_hh)
         ctx.x_is_celu = x_is_celu
+        ctx.pre = pre
         # the first application of a block seeds the GRU state with the block input, which is also the skip connection (layer.py:253-254):
         # one tensor, two roles — the backward then returns ONE gradient for it (k_gru_bwd_ws adds d_identity into d_h)
         ctx.same_h_id = (identity is not None and identity.data_ptr() == h.data_ptr() and identity.shape == h.shape
@@ -931,22 +955,33 @@ class _GruBlock(torch.autograd.Function):
         if ws:
             # gate gradients + both input-gradient products in ONE launch (block.hip: k_gru_bwd_ws); d_h comes out complete
             dx = torch.empty(N, C, **f)
-            img_a, img_b = image_t(w_ih), image_t(w_hh)
+            pre = ctx.pre
+            img_a, img_b = (None, None) if pre is not None else (image_t(w_ih), image_t(w_hh))
             merge = int(has_res and ctx.same_h_id)
             if merge:
                 d_id = None                   # (its gradient is part of d_h: the two inputs are one tensor)
             if rng is None:
                 if d_out is None:
                     d_out = torch.zeros_like(h)
-                check(lib.glam_gru_bwd_ws(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), ptr(x), ptr(img_a), ptr(img_b), N, C,
-                                          celu_bwd, act, slope, merge, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st),
-                      "glam_gru_bwd_ws")
+                if pre is not None:
+                    check(lib.glam_gru_bwd_ws_pre(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), ptr(x), ptr(pre[1]), N, C,
+                                                  celu_bwd, act, slope, merge, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st),
+                          "glam_gru_bwd_ws_pre")
+                else:
+                    check(lib.glam_gru_bwd_ws(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_hstate), ptr(x), ptr(img_a), ptr(img_b), N,
+                                              C, celu_bwd, act, slope, merge, ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st),
+                          "glam_gru_bwd_ws")
             else:
                 if d_out is None and d_out_drop is None:
                     d_out = torch.zeros_like(h)
-                check(lib.glam_gru_bwd_ws_rng(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), ptr(x), ptr(img_a),
-                                              ptr(img_b), N, C, celu_bwd, act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), merge, ptr(d_gi),
-                                              ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng")
+                if pre is not None:
+                    check(lib.glam_gru_bwd_ws_rng_pre(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), ptr(x),
+                                                      ptr(pre[1]), N, C, celu_bwd, act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), merge,
+                                                      ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng_pre")
+                else:
+                    check(lib.glam_gru_bwd_ws_rng(ptr(gi), ptr(gh), ptr(h), ptr(out), ptr(d_out), ptr(d_out_drop), ptr(d_hstate), ptr(x),
+                                                  ptr(img_a), ptr(img_b), N, C, celu_bwd, act, slope, rng[0], rng[1], rng[2], ptr(ctx.eff), merge,
+                                                  ptr(d_gi), ptr(d_gh), ptr(d_id), ptr(dx), ptr(d_h), st), "glam_gru_bwd_ws_rng")
             dh = d_h
         elif rng is None:
             if d_out is None:

@@ -635,6 +635,29 @@ int glam_gru_ws_rng_fwd_xc(const float* x, const float* h, const float* identity
                            float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
                            float* out, float* out_drop, float* x_celu, void* stream);
 
+/* The gate matrices as the matrix waves of the warp-specialised step hold them: every 16 x 8 operand fragment already split into its
+ * three bf16 terms, stored in lane order, ONCE per weight update (one launch for both images; either may be NULL).  weight_ih / weight_hh
+ * are torch.nn.GRUCell's [3C, C] (layer.py:250), contiguous.  The *_pre entry points below read these instead of the k_ts_gemm images and
+ * compute bit-identical results: what they drop is the prologue in which all 256 blocks of every launch re-split the same matrices
+ * (~4 k of a block's ~31 k cycles at N = 20 400: forward 18.4 -> 15.2 us, backward 21.6 -> 20.0 us per application).
+ * glam_gru_ws_pre_bytes(): size of ONE image (144 KB, 16-byte aligned), any supported C. */
+size_t glam_gru_ws_pre_bytes(void);
+int glam_gru_ws_make_pre(const float* w_ih, const float* w_hh, int C, void* pre_fwd, void* pre_bwd, void* stream);
+int glam_gru_ws_fwd_pre(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih, const float* b_hh,
+                        int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh, float* h_new, float* out,
+                        float* x_celu, void* stream);
+int glam_gru_ws_rng_fwd_pre(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                            const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower, float rr_upper,
+                            float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new, float* out,
+                            float* out_drop, float* x_celu, void* stream);
+int glam_gru_bwd_ws_pre(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
+                        const float* x, const void* pre_bwd, int64_t N, int C, int celu_in, int act, float slope, int merge_identity,
+                        float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);
+int glam_gru_bwd_ws_rng_pre(const float* gi, const float* gh, const float* h, const float* out, const float* d_out,
+                            const float* d_out_drop, const float* d_hstate, const float* x, const void* pre_bwd, int64_t N, int C,
+                            int celu_in, int act, float slope, float rr_lower, float rr_upper, float drop_p, const int64_t* rng_eff,
+                            int merge_identity, float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);
+
 /* Backward of the same step in ONE launch: glam_gru_tail_bwd (resp. glam_gru_tail_rng_bwd) + the two input-gradient products
  *   d_x = d_gi @ W_ih (* celu'(x) when celu_in), d_h = d_gh @ W_hh + the direct g z path,
  * warp-specialised, the products in 3 x bf16 form.  d_gi / d_gh [N, 3C] are still written (the weight-gradient launch reads them), d_h

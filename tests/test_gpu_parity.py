@@ -3118,6 +3118,98 @@ def test_gru_forward_keeps_celu_x_for_the_backward(device, N, C):
     assert_close(res[1][3], res[0][3].double(), 3e-7, "d_x from celu(x)")
 
 
+@pytest.mark.parametrize("N,C", [(20400, 60), (777, 44), (16, 24), (5000, 64), (0, 32)])
+def test_gru_step_on_presplit_gate_matrices_equals_the_plain_images(device, N, C):
+    """glam_gru_ws_make_pre + the *_pre entry points (the gate matrices of torch.nn.GRUCell, src_1gp/layer.py:250, as operand fragments
+    split into their three bf16 terms once per weight update): every output of the forward and the backward equals, bit for bit, what
+    the same kernels compute from the k_ts_gemm images (they split the same values in every block's prologue) — with and without the
+    RReLU / Dropout draws, and with either image left out of the make call."""
+    lib, p = ops._lib.load(), ops._lib.ptr
+    st = ops._lib.stream
+    torch.manual_seed(N + C)
+    M = 3 * C
+    r = lambda *s: torch.randn(*s, device=device)
+    x, h, idn, w_ih, w_hh, b_ih, b_hh = r(N, C), r(N, C), r(N, C), r(M, C) * 0.3, r(M, C) * 0.3, r(M), r(M)
+    ia, ib = (torch.empty(lib.glam_ts_gemm_image_bytes(C, M) // 4, device=device) for _ in range(2))
+    ta, tb = (torch.empty(lib.glam_ts_gemm_image_bytes(M, C) // 4, device=device) for _ in range(2))
+    for w, i, t in ((w_ih, ia, ta), (w_hh, ib, tb)):
+        assert lib.glam_ts_gemm_make_image(p(w), C, 1, C, M, p(i), st()) == 0
+        assert lib.glam_ts_gemm_make_image(p(w), C, 0, M, C, p(t), st()) == 0
+    nb = lib.glam_gru_ws_pre_bytes()
+    assert nb == 48 * 3 * 1024
+    pre = torch.full((2, nb), 0xAB, dtype=torch.uint8, device=device)
+    assert lib.glam_gru_ws_make_pre(p(w_ih), p(w_hh), C, p(pre[0]), p(pre[1]), st()) == 0, lib.glam_last_error()
+    one = torch.full((2, nb), 0xAB, dtype=torch.uint8, device=device)
+    assert lib.glam_gru_ws_make_pre(p(w_ih), p(w_hh), C, p(one[0]), None, st()) == 0
+    assert lib.glam_gru_ws_make_pre(p(w_ih), p(w_hh), C, None, p(one[1]), st()) == 0
+    assert torch.equal(one, pre)
+    assert lib.glam_gru_ws_make_pre(p(w_ih), p(w_hh), 66, p(pre[0]), p(pre[1]), st()) == ops._lib.GLAM_E_UNSUPPORTED
+    nan = lambda *s: torch.full(s, float("nan"), device=device)
+    # forward, eval mode
+    a = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C)]
+    b = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C)]
+    assert lib.glam_gru_ws_fwd_xc(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]),
+                                  st()) == 0, lib.glam_last_error()
+    assert lib.glam_gru_ws_fwd_pre(p(x), p(h), p(idn), p(pre[0]), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(b[4]),
+                                   st()) == 0, lib.glam_last_error()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v) or (N == 0)
+        assert N == 0 or not torch.isnan(v).any()
+    if N > 0:
+        assert lib.glam_gru_ws_fwd_pre(p(x), p(h), p(idn), None, p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(b[4]),
+                                       st()) == ops._lib.GLAM_E_INVALID
+    # backward, eval mode (x = celu(x) as the forward kept it)
+    d_out, d_hs = r(N, C), r(N, C)
+    res = []
+    for use_pre in (False, True):
+        o = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C)]
+        if use_pre:
+            rc = lib.glam_gru_bwd_ws_pre(p(a[0]), p(a[1]), p(h), p(a[3]), p(d_out), p(d_hs), p(a[4]), p(pre[1]), N, C, 2, 1, 0.0, 0, p(o[0]),
+                                         p(o[1]), p(o[2]), p(o[3]), p(o[4]), st())
+        else:
+            rc = lib.glam_gru_bwd_ws(p(a[0]), p(a[1]), p(h), p(a[3]), p(d_out), p(d_hs), p(a[4]), p(ta), p(tb), N, C, 2, 1, 0.0, 0, p(o[0]), p(o[1]),
+                                     p(o[2]), p(o[3]), p(o[4]), st())
+        assert rc == 0, lib.glam_last_error()
+        res.append(o)
+    for u, v in zip(*res):
+        assert N == 0 or (torch.equal(u, v) and not torch.isnan(v).any())
+    if N == 0:
+        return
+    # training mode: RReLU slopes and the next Dropout's mask drawn inside the launch (the same draws from the same state)
+    lo, hi, dp = 0.125, 1.0 / 3.0, 0.15
+    outs, effs = [], []
+    for use_pre in (False, True):
+        state = torch.tensor([1234] + [0] * (ops.RNG_STATE_WORDS - 1), dtype=torch.int64, device=device)
+        eff = torch.zeros(2, dtype=torch.int64, device=device)
+        o = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C), nan(N, C)]
+        if use_pre:
+            rc = lib.glam_gru_ws_rng_fwd_pre(p(x), p(h), p(idn), p(pre[0]), p(b_ih), p(b_hh), N, C, 1, 4, 0.0, lo, hi, dp, p(state), p(eff), p(o[0]),
+                                             p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(o[5]), st())
+        else:
+            rc = lib.glam_gru_ws_rng_fwd_xc(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 1, 4, 0.0, lo, hi, dp, p(state), p(eff), p(o[0]),
+                                            p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(o[5]), st())
+        assert rc == 0, lib.glam_last_error()
+        outs.append(o); effs.append(eff)
+    for u, v in zip(*outs):
+        assert torch.equal(u, v) and not torch.isnan(v).any()
+    assert torch.equal(effs[0], effs[1])
+    d_drop = r(N, C)
+    res = []
+    for use_pre in (False, True):
+        o = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C)]
+        f = outs[0]
+        if use_pre:
+            rc = lib.glam_gru_bwd_ws_rng_pre(p(f[0]), p(f[1]), p(h), p(f[3]), p(d_out), p(d_drop), p(d_hs), p(f[5]), p(pre[1]), N, C, 2, 4, 0.0, lo, hi,
+                                             dp, p(effs[0]), 0, p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), st())
+        else:
+            rc = lib.glam_gru_bwd_ws_rng(p(f[0]), p(f[1]), p(h), p(f[3]), p(d_out), p(d_drop), p(d_hs), p(f[5]), p(ta), p(tb), N, C, 2, 4, 0.0, lo, hi,
+                                         dp, p(effs[0]), 0, p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), st())
+        assert rc == 0, lib.glam_last_error()
+        res.append(o)
+    for u, v in zip(*res):
+        assert torch.equal(u, v) and not torch.isnan(v).any()
+
+
 @pytest.mark.parametrize("block", ["_TripletMessage", "_NNConv"])
 @pytest.mark.parametrize("steps", [1, 2, 3, 4])
 def test_gru_weight_gradients_of_all_applications_in_one_launch(device, steps, block, monkeypatch, wgrad_route):

@@ -60,3 +60,20 @@ for kid, name, nwaves in ((0, "k_gru_fwd_ws (4 producers + 4 consumers)", 8), (1
     bs, be = (rr[:, :, 0].min(axis=1) - r0) / 100.0, (rr[:, :, 5].max(axis=1) - r0) / 100.0
     print(f"   block lifetime mean {life.mean():.0f} cycles, max {life.max():.0f}; device-wide clock: blocks start at mean {bs.mean():.2f} us (last {bs.max():.2f}), "
           f"end at mean {be.mean():.2f} (last {be.max():.2f})")
+
+# phases inside a consumer tile of the forward: the first and the third of the wave
+buf = (ctypes.c_longlong * (256 * 12 * 16))()
+if hasattr(raw, "glam_debug_gru_finef") and raw.glam_debug_gru_finef(buf, len(buf)) == 0:
+    fz = np.array(buf[:], dtype=np.int64).reshape(256, 12, 16)[:, 4:8]
+    names = ["wait for the tile", "LDS reads + 72 matrix instructions", "bias + 6 stores (gi, gh)", "gates + 2 stores"]
+    for base, what in ((0, "first"), (8, "third")):
+        print(f"k_gru_fwd_ws consumers, the wave's {what} tile:")
+        for k, nme in enumerate(names):
+            a0, a1 = fz[:, :, base + k], fz[:, :, base + k + 1]
+            d = (a1 - a0)[(a0 > 0) & (a1 > 0)]
+            if d.size: print(f"   {nme:48s} mean {d.mean():7.0f}   min {d.min():7.0f}   max {d.max():7.0f}")
+    print("k_gru_fwd_ws consumers, before the first tile (cycles between stamps):")
+    for nme, k0, k1 in (("wait for the producers' check-in", 5, 6), ("24 weight loads issued", 6, 7), ("... arrived", 7, 13), ("split into 36 fragments (+ bias loads)", 13, 0)):
+        a0, a1 = fz[:, :, k0], fz[:, :, k1]
+        d = (a1 - a0)[(a0 > 0) & (a1 > 0)]
+        if d.size: print(f"   {nme:48s} mean {d.mean():7.0f}   min {d.min():7.0f}   max {d.max():7.0f}")
