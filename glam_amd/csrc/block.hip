@@ -658,7 +658,8 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             asm volatile("" : "+v"(chw));          // (keeps these loads on the consumers' side of the role branch)
             const bool okw = chw < C;
             GRU_FINEF(5);
-            while (flag_load(s_ready + 8) < P) __builtin_amdgcn_s_sleep(1);
+            // (the 36 coalesced loads of the pre-split image do not hold the producers' first tile up: no wait — 0.2 us at N <= 5 120)
+            if (!a.pre) while (flag_load(s_ready + 8) < P) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             GRU_FINEF(6);
             if (a.pre) {
@@ -1064,38 +1065,12 @@ static int gru_fused_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_
     return GLAM_OK;
 }
 
-// The gate matrices as the matrix waves of k_gru_fwd_ws / k_gru_bwd_ws hold them: every operand fragment split into its three bf16 terms
-// ONCE per weight update, stored in lane order (fragment f, term t, lane l -> 16 bytes at ((3 f + t) * 64 + l) * 16) — the values
-// split8 produces in the kernels' own prologue, which 256 blocks x 6 launches of a training step otherwise each redo.
-//   forward image : f = 12 w + 2 (2 g + s) + m     wave w (channels 16 w ..), gate g, k step s, matrix m (0: W_ih, 1: W_hh);
-//                   lane (c, kb) holds W_m[g C + 16 w + c][32 s + 8 kb .. + 7]
-//   backward image: f = 6 w + s                     wave w = 4 m + ct (columns 16 ct ..), s = 2 gate + k step of the gate's C rows;
-//                   lane (c, kb) holds W_m[(s >> 1) C + 32 (s & 1) + 8 kb .. + 7][16 ct + c]
-// (zero where the channel / column index reaches C)
-constexpr int kGruPreFrags = 48, kGruPreBytes = kGruPreFrags * 3 * 1024;
+// (layouts and values: gru_pre_fragment, dense.h — glam_prestage builds the same images inside its own launch)
 __global__ void __launch_bounds__(64) k_gru_ws_pre(const float* w_ih, const float* w_hh, int C, char* pre_fwd, char* pre_bwd) {
-    const int lane = threadIdx.x, c = lane & 15, kb = lane >> 4;
     const bool bwd = blockIdx.x >= kGruPreFrags;
-    const int f = blockIdx.x - (bwd ? kGruPreFrags : 0);
+    const int f = blockIdx.x - (bwd ? kGruPreFrags : 0), m = f / 24;
     char* dst = bwd ? pre_bwd : pre_fwd;
-    if (!dst) return;
-    float v[8];
-    if (!bwd) {
-        const int w = f / 12, r = f % 12, gs = r >> 1, m = r & 1, g = gs >> 1, s = gs & 1;
-        const float* W = m ? w_hh : w_ih;
-        const int ch = 16 * w + c;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int k = 32 * s + 8 * kb + j; v[j] = (ch < C && k < C) ? W[(size_t)(g * C + ch) * C + k] : 0.f; }
-    } else {
-        const int w = f / 6, s = f % 6, m = w >> 2, ct = w & 3;
-        const float* W = m ? w_hh : w_ih;
-        const int col = 16 * ct + c;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int ch = 32 * (s & 1) + 8 * kb + j; v[j] = (col < C && ch < C) ? W[(size_t)((s >> 1) * C + ch) * C + col] : 0.f; }
-    }
-    const Bf16x3 x = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
-    char* o = dst + (size_t)f * 3072 + lane * 16;
-    *reinterpret_cast<bf16x8_t*>(o) = x.hi; *reinterpret_cast<bf16x8_t*>(o + 1024) = x.mid; *reinterpret_cast<bf16x8_t*>(o + 2048) = x.lo;
+    if (dst) gru_pre_fragment(m ? w_hh : w_ih, C, bwd, m, f % 24, threadIdx.x, dst);
 }
 
 static int gru_bwd_ws_launch(const GruBwdArgs& a, const TailRngB* rg, hipStream_t s) {

@@ -2,6 +2,7 @@
 // layer.hip (whole-layer sequencing).  Not part of the C ABI.
 #pragma once
 #include "common.h"
+#include "bf16x3.h"
 
 namespace glam {
 
@@ -59,7 +60,37 @@ struct ReduceArgs { ReduceJob job[3]; int njobs; };
 // every optimizer step): job j owns blocks [first[j], first[j+1]).
 // gate > 0 (the fused GRU step's images, block.hip): M = 3 gates of `gate` channels, each padded to 64 columns — logical column m holds
 // channel m % 64 of gate m / 64 (source row (m / 64) * gate + m % 64 of the [3 * gate, K] matrix), k padded to 64.
+// gate < 0 (the warp-specialised GRU step's pre-split images, block.hip): matrix M (0: W_ih, 1: W_hh) of a GRU with K channels into its
+// 24 fragments of the forward (gate = -1) or the backward (gate = -2) image `img` — gru_pre_fragment below.
 struct ImageJob { const float* W; int ldw, transW, K, M, MT; float* img; int first; int gate; };
+constexpr int kGruPreFrags = 48, kGruPreBytes = kGruPreFrags * 3 * 1024;
+// The gate matrices as the matrix waves of k_gru_fwd_ws / k_gru_bwd_ws hold them: every operand fragment split into its three bf16 terms
+// ONCE per weight update, stored in lane order (fragment f, term t, lane l -> 16 bytes at ((3 f + t) * 64 + l) * 16) — the values
+// split8 produces in the kernels' own prologue, which 256 blocks x 6 launches of a training step otherwise each redo.
+//   forward image : f = 12 w + 2 (2 g + s) + m     wave w (channels 16 w ..), gate g, k step s, matrix m (0: W_ih, 1: W_hh);
+//                   lane (c, kb) holds W_m[g C + 16 w + c][32 s + 8 kb .. + 7]
+//   backward image: f = 6 (4 m + ct) + s            wave 4 m + ct (columns 16 ct ..), s = 2 gate + k step of the gate's C rows;
+//                   lane (c, kb) holds W_m[(s >> 1) C + 32 (s & 1) + 8 kb .. + 7][16 ct + c]
+// (zero where the channel / column index reaches C).  fl = 0 .. 23: the matrix's fragments (forward: 6 w + 2 g + s, backward: 6 ct + s).
+__device__ __forceinline__ void gru_pre_fragment(const float* W, int C, bool bwd, int m, int fl, int lane, char* dst) {
+    const int c = lane & 15, kb = lane >> 4;
+    float v[8];
+    int f;
+    if (!bwd) {
+        const int w = fl / 6, gs = fl % 6, g = gs >> 1, s = gs & 1, ch = 16 * w + c;
+        f = 2 * fl + m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = 32 * s + 8 * kb + j; v[j] = (ch < C && k < C) ? W[(size_t)(g * C + ch) * C + k] : 0.f; }
+    } else {
+        const int ct = fl / 6, s = fl % 6, col = 16 * ct + c;
+        f = 24 * m + fl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int ch = 32 * (s & 1) + 8 * kb + j; v[j] = (col < C && ch < C) ? W[(size_t)((s >> 1) * C + ch) * C + col] : 0.f; }
+    }
+    const Bf16x3 x = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    char* o = dst + (size_t)f * 3072 + lane * 16;
+    *reinterpret_cast<bf16x8_t*>(o) = x.hi; *reinterpret_cast<bf16x8_t*>(o + 1024) = x.mid; *reinterpret_cast<bf16x8_t*>(o + 2048) = x.lo;
+}
 constexpr int kMaxImageJobs = 6;
 struct ImageJobs { ImageJob job[kMaxImageJobs]; int njobs; };
 __device__ __forceinline__ void make_images_block(const ImageJobs& js, int bid) {
@@ -68,8 +99,12 @@ __device__ __forceinline__ void make_images_block(const ImageJobs& js, int bid) 
     for (int q = 1; q < kMaxImageJobs; ++q)
         if (q < js.njobs && bid >= js.job[q].first) jb = q;
     const ImageJob& J = js.job[jb];
-    const int MP = J.MT * 16, Kp = J.gate ? 64 : (J.K + 15) & ~15;
     const int idx = (bid - J.first) * kBlock + threadIdx.x;
+    if (J.gate < 0) {
+        if (idx < 24 * 64) gru_pre_fragment(J.W, J.K, J.gate == -2, J.M, idx >> 6, idx & 63, reinterpret_cast<char*>(J.img));
+        return;
+    }
+    const int MP = J.MT * 16, Kp = J.gate ? 64 : (J.K + 15) & ~15;
     if (idx >= Kp * MP) return;
     const int j = idx & 3, p = (idx >> 2) % MP, k = (idx >> 2) / MP * 4 + j;
     const int m = ts_col_of_pos(p);

@@ -681,7 +681,18 @@ extern "C" int glam_prestage(const float* weight_node, const float* weight_edge,
     int blocks = 0;
     for (int q = 0; q < n_images; ++q) {
         GLAM_REQUIRE(W[q] && img[q] && aligned16(img[q]), "glam_prestage: image %d: null / misaligned pointer", q);
-        const int nb = image_job(js.job[q], "glam_prestage", W[q], dims[4 * q], dims[4 * q + 1], dims[4 * q + 2], dims[4 * q + 3], img[q], blocks);
+        int nb;
+        if (dims[4 * q + 1] >= 2) {
+            // transW = 2 / 3: matrix M (0: weight_ih, 1: weight_hh) of a GRU with K channels into the forward / backward image of
+            // glam_gru_ws_make_pre (img = that image, shared by both matrices' jobs)
+            const int Cg = dims[4 * q + 2], m = dims[4 * q + 3];
+            GLAM_REQUIRE(dims[4 * q + 1] <= 3 && (m == 0 || m == 1) && dims[4 * q] == Cg, "glam_prestage: image %d: bad pre-split job", q);
+            if (!(Cg >= 24 && Cg <= 64 && (Cg & 3) == 0)) return fail(GLAM_E_UNSUPPORTED, "glam_prestage: image %d: C=%d must be a multiple of 4 in 24..64", q, Cg);
+            js.job[q] = ImageJob{W[q], Cg, 0, Cg, m, 0, img[q], blocks, dims[4 * q + 1] == 2 ? -1 : -2};
+            nb = (24 * 64 + kBlock - 1) / kBlock;
+        } else {
+            nb = image_job(js.job[q], "glam_prestage", W[q], dims[4 * q], dims[4 * q + 1], dims[4 * q + 2], dims[4 * q + 3], img[q], blocks);
+        }
         if (nb < 0) return nb;
         blocks += nb;
     }

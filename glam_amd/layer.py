@@ -838,9 +838,9 @@ def following_dropout(block):
 def _prestage_items(lin_block, block, x, edge_attr):
     """(triplet, images) of one tower for ``ops.prestage``: what the first applications of ``lin_block`` (the input LinearBlock) and
     ``block`` (the MessageBlock) would each build with a launch of their own on their default routes."""
-    triplet, images = None, []
+    triplet, images, gru_pre = None, [], []
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
-        return triplet, images
+        return triplet, images, gru_pre
     lin = getattr(lin_block, "linear", None)
     if lin is not None:
         M, Kw = lin.weight.shape
@@ -859,7 +859,9 @@ def _prestage_items(lin_block, block, x, edge_attr):
         if C % 4 == 0 and w_ih.shape == (3 * C, C) and ops.gru_images_plain(x.size(0), C):
             images += [("fwd", ("lin", id(w_ih)), w_ih, w_ih, C, 1, C, 3 * C, C), ("fwd", ("lin", id(w_hh)), w_hh, w_hh, C, 1, C, 3 * C, C),
                        ("bwd", ("lin", id(w_ih)), w_ih, w_ih, C, 0, 3 * C, C, 3 * C), ("bwd", ("lin", id(w_hh)), w_hh, w_hh, C, 0, 3 * C, C, 3 * C)]
-    return triplet, images
+        elif C % 4 == 0 and w_ih.shape == (3 * C, C) and ops.gru_images_pre(x.size(0), C):
+            gru_pre.append((w_ih, w_hh, C))
+    return triplet, images, gru_pre
 
 
 def prestage_pass(*towers):
@@ -867,16 +869,17 @@ def prestage_pass(*towers):
     images per launch) instead of one launch per module at its first use.  ``towers``: ``(input LinearBlock, MessageBlock, x,
     edge_attr)`` per graph tower.  The entries land in the pass's ``weight_scope`` under the keys the ops look them up with; only the
     default routes are anticipated, anything else is built by its op as before."""
-    built, triplet, images = 0, None, []
+    built, triplet, images, pres = 0, None, [], []
     for tower in towers:
-        t, im = _prestage_items(*tower)
-        if (t is not None and triplet is not None) or len(images) + len(im) > 6:
-            built += ops.prestage(triplet, images)
-            triplet, images = None, []
+        t, im, gp = _prestage_items(*tower)
+        if (t is not None and triplet is not None) or len(images) + len(im) + 4 * (len(pres) + len(gp)) > 6:
+            built += ops.prestage(triplet, images, pres)
+            triplet, images, pres = None, [], []
         triplet = t if t is not None else triplet
         images += im
-    if triplet is not None or images:
-        built += ops.prestage(triplet, images)
+        pres += gp
+    if triplet is not None or images or pres:
+        built += ops.prestage(triplet, images, pres)
     return built
 
 

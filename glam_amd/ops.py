@@ -234,13 +234,14 @@ def _scoped(table, key, owner, build):
     table[key] = (owner, val)
     return val
 
-def prestage(triplet=None, images=()):
+def prestage(triplet=None, images=(), gru_pre=()):
     """The derived weights of a model pass in ONE launch (``glam_prestage``) instead of one per module at its first use: the staged
     images of a TripletMessage (``triplet = (wn, we, att, wsc, bias, H, Dp)``) and up to six ``k_ts_gemm`` weight images
     (``images``: ``(table, key, owner, W, ldw, transW, K, M, K_image)`` with ``table`` in {"fwd", "bwd"} — the scope table and key
     under which the lazy builder of the op looks the image up).  The entries are put into the active ``weight_scope`` exactly as the
     lazy builders would put them, so an op whose route differs from the caller's guess just builds its own as before.  Returns the
-    number of entries built (0: no scope, switched off, or everything already there)."""
+    number of entries built (0: no scope, switched off, or everything already there).  ``gru_pre``: ``(w_ih, w_hh, C)`` per GRU whose
+    warp-specialised step wants its pre-split images (``glam_gru_ws_make_pre``; four of the six jobs of a launch)."""
     scope = _SCOPE
     if scope is None or not PRESTAGE:
         return 0
@@ -271,6 +272,16 @@ def prestage(triplet=None, images=()):
         img = torch.empty(lib.glam_ts_gemm_image_bytes(Kimg, M) // 4, **f)
         jobs.append((W, (ldw, transW, K, M), img))
         tab[key] = (owner, img)
+        built += 1
+    for w_ih, w_hh, C in gru_pre:
+        key = ("gru-pre", id(w_ih), id(w_hh))
+        hit = scope.fwd.get(key)
+        ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (w_ih, w_hh))
+        if (hit is not None and hit[0] is w_ih) or not ok or len(jobs) + 4 > 6:
+            continue
+        buf = torch.empty(2, lib.glam_gru_ws_pre_bytes(), dtype=torch.uint8, device=w_ih.device)
+        jobs += [(w_ih, (C, 2, C, 0), buf[0]), (w_hh, (C, 2, C, 1), buf[0]), (w_ih, (C, 3, C, 0), buf[1]), (w_hh, (C, 3, C, 1), buf[1])]
+        scope.fwd[key] = (w_ih, buf)
         built += 1
     if built == 0:
         return 0

@@ -770,6 +770,11 @@ def gru_images_plain(N, C):
     return not (_want_gru_fused(N) and lib.glam_gru_fused_supported(C))
 
 
+def gru_images_pre(N, C):
+    """True when the GRU step of this size reads the pre-split images of ``glam_gru_ws_make_pre`` (the warp-specialised step, default)."""
+    return bool(_o.GRU_PRE) and _want_gru_ws(_lib.load(), N, C)
+
+
 def _want_gru_fused(N):
     return _o.GRU_FUSED in ("1", True) or (_o.GRU_FUSED == "auto" and N >= _o.GRU_FUSED_MIN_NODES)
 

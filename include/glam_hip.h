@@ -289,7 +289,9 @@ int glam_wgrad_gemm_add(const float* P1, int I1, int ldp1, const float* P2, int 
 /* The derived weights of a model pass in ONE launch (three launches of ~5 us each at the head of every training step before): the staged
  * images of a TripletMessage (exactly glam_triplet_stage_params; staged == NULL: none) and n_images <= 6 weight images of
  * glam_ts_gemm (exactly glam_ts_gemm_make_image each: dims[4 q ..] = {ldw, transW, K, M} of image q — e.g. the four images of a GRU's
- * gate matrices and the one of the input linear, /root/reference/src_1gp/model.py:40-42). */
+ * gate matrices and the one of the input linear, /root/reference/src_1gp/model.py:40-42).  transW = 2 / 3 makes image q one matrix's
+ * half of a glam_gru_ws_make_pre image instead: {ldw = C, 2: forward image | 3: backward image, K = C, M = 0: weight_ih | 1: weight_hh},
+ * img[q] = that image (the two matrices' jobs name the same one). */
 int glam_prestage(const float* weight_node, const float* weight_edge, const float* att, const float* weight_scale, const float* bias,
                   int C, int H, int De, int Cp, int Dp, float* staged, int n_images, const float* const* W, const int* dims,
                   float* const* img, void* stream);

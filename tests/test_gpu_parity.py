@@ -2964,9 +2964,10 @@ def test_dense_gemm_rounding_is_unbiased(device):
 
 
 def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
-    """ops.prestage / glam_prestage: the input linear's GEMM image, the TripletMessage's staged images and the GRU's four gate images
-    come from ONE launch at the head of a model pass (three launches before), land in the weight scope under the keys the ops look
-    them up with (no k_stage_params / k_ts_make_image(s) launch follows), and the pass is bit-identical to the lazily staged one."""
+    """ops.prestage / glam_prestage: the input linear's GEMM image, the TripletMessage's staged images and the GRU's gate matrices (the
+    pre-split images of its warp-specialised step; GLAM_GRU_PRE=0: the four k_ts_gemm images) come from ONE launch at the head of a
+    model pass (three launches before), land in the weight scope under the keys the ops look them up with (no k_stage_params /
+    k_ts_make_image(s) / k_gru_ws_pre launch follows), and the pass is bit-identical to the lazily staged one."""
     from glam_amd._lib import kernel_timer
     torch.manual_seed(11)
     b = synth_batch(48, seed=5).to(device)
@@ -2974,8 +2975,9 @@ def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
                              graph_do="_None()", end_do="_None()").to(device)
     monkeypatch.setattr(ops, "USE_TORCH_EXT", False)       # (the eager C++ node stages per call; a captured step uses this route)
 
-    def run(flag):
+    def run(flag, pre=True):
         monkeypatch.setattr(ops, "PRESTAGE", flag)
+        monkeypatch.setattr(ops, "GRU_PRE", pre)
         net.zero_grad()
         with kernel_timer() as kt:
             out = net(b)
@@ -2987,9 +2989,16 @@ def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
     assert torch.equal(o1, o0)
     for a, c in zip(g1, g0):
         assert torch.equal(a, c)
-    staging = lambda names: [n for n in names if "k_stage_params" == n.split("<")[0] or "k_ts_make_image" in n or "k_prestage" in n]
+    staging = lambda names: [n for n in names if "k_stage_params" == n.split("<")[0] or "k_ts_make_image" in n or "k_prestage" in n
+                             or "k_gru_ws_pre" in n]
     assert staging(k1) == ["k_prestage"], staging(k1)
-    assert len(staging(k0)) == 3 and "k_prestage" not in staging(k0), staging(k0)
+    assert len(staging(k0)) == 3 and "k_prestage" not in staging(k0) and "k_gru_ws_pre" in staging(k0), staging(k0)
+    o2, g2, k2 = run(True, pre=False)               # the plain images of the gate matrices: the same pass, bit for bit
+    o3, g3, k3 = run(False, pre=False)
+    assert torch.equal(o2, o1) and torch.equal(o3, o1)
+    for a, c, d in zip(g1, g2, g3):
+        assert torch.equal(a, c) and torch.equal(a, d)
+    assert staging(k2) == ["k_prestage"] and len(staging(k3)) == 3 and "k_gru_ws_pre" not in staging(k3), (staging(k2), staging(k3))
     # C ABI: the image table is bounded, empty calls and shapes outside the kernel table are refused
     lib = ops._lib.load()
     import ctypes
@@ -3006,6 +3015,20 @@ def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
     assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 1, (vp * 1)(w.data_ptr()), (ctypes.c_int32 * 4)(60, 1, 60, 60),
                              (vp * 1)(img.data_ptr()), ops._lib.stream()) == 0
     assert torch.equal(img, ref)
+    # the pre-split images of a GRU's gate matrices as four jobs (transW = 2 / 3) = glam_gru_ws_make_pre
+    C = 44
+    w_ih, w_hh = torch.randn(3 * C, C, device=device), torch.randn(3 * C, C, device=device)
+    nb = lib.glam_gru_ws_pre_bytes()
+    want = torch.full((2, nb), 0xCD, dtype=torch.uint8, device=device)
+    got = torch.full((2, nb), 0xCD, dtype=torch.uint8, device=device)
+    assert lib.glam_gru_ws_make_pre(w_ih.data_ptr(), w_hh.data_ptr(), C, want[0].data_ptr(), want[1].data_ptr(), ops._lib.stream()) == 0
+    Wp = (vp * 4)(w_ih.data_ptr(), w_hh.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr())
+    ip = (vp * 4)(got[0].data_ptr(), got[0].data_ptr(), got[1].data_ptr(), got[1].data_ptr())
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 4, Wp, (ctypes.c_int32 * 16)(C, 2, C, 0, C, 2, C, 1, C, 3, C, 0, C, 3, C, 1), ip,
+                             ops._lib.stream()) == 0, lib.glam_last_error()
+    assert torch.equal(got, want) and not (want == 0xCD).all()
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 1, Wp, (ctypes.c_int32 * 4)(C, 2, C, 2), ip, ops._lib.stream()) == ops._lib.GLAM_E_INVALID
+    assert lib.glam_prestage(*([None] * 5 + [0] * 5 + [None]), 1, Wp, (ctypes.c_int32 * 4)(20, 2, 20, 0), ip, ops._lib.stream()) == ops._lib.GLAM_E_UNSUPPORTED
 
 
 def test_wgrad_split_writes_a_narrow_weight_gradient_contiguously(device, wgrad_route):

@@ -439,8 +439,8 @@ def test_launch_saving_hints_are_host_logic():
     lin = layer.LinearBlock(15, 60)
     x, ea = torch.randn(40, 15), torch.zeros(80, 4)
     assert layer.prestage_pass((lin, mb, x, ea)) == 0                 # CPU tensors: nothing to stage, nothing launched
-    trip, images = layer._prestage_items(lin, mb, x.to("meta") if False else x, ea)
-    assert trip is None and images == []
+    trip, images, pres = layer._prestage_items(lin, mb, x.to("meta") if False else x, ea)
+    assert trip is None and images == [] and pres == []
     assert ops.prestage(None, []) == 0
     assert ops.GRU_WGRAD_BATCH in (True, False) and ops.PRESTAGE in (True, False) and ops.NORM_DROP in (True, False) and ops.DENSE_LINEAR in (True, False)
 

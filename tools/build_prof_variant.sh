@@ -14,7 +14,6 @@ case "$1" in
   pg)   src=layer.hip;       def=GLAM_PG_PROF ;;
   ws)   src=triplet_ws.hip;  def=GLAM_WS_PROF ;;
   tl)   src="triplet_ws.hip triplet_ws_b1.hip block.hip"; def=GLAM_WS_TL ;;   # timeline stamps of the three warp-specialised kernels (tools/ws_timeline.py)
-  hack) src="block.hip triplet_ws.hip"; def=GLAM_HACK_PRESPLIT ;;       # timing experiment (wrong values)
   *) echo "usage: $0 {b1|b1n|ts|dma|gru|fwd|pg|ws|tl}"; exit 2 ;;
 esac
 mkdir -p ../variants

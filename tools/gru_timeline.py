@@ -23,8 +23,14 @@ for w, i, t in ((w_ih, ia, ta), (w_hh, ib, tb)):
 gi, gh, hn, out = torch.empty(N, M, device=dev), torch.empty(N, M, device=dev), torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
 d_out, d_hs = r(N, C), r(N, C)
 dgi, dgh, did, dx, dh = torch.empty(N, M, device=dev), torch.empty(N, M, device=dev), torch.empty(N, C, device=dev), torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
+PRE = os.environ.get("PRE", "1") != "0"          # the pre-split images (the model's route) or the plain k_ts_gemm images
+pre = torch.empty(2, lib.glam_gru_ws_pre_bytes(), dtype=torch.uint8, device=dev)
+assert lib.glam_gru_ws_make_pre(p(w_ih), p(w_hh), C, p(pre[0]), p(pre[1]), st()) == 0
+def fwd_pre(): assert lib.glam_gru_ws_fwd_pre(p(x), p(h), p(idn), p(pre[0]), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(gi), p(gh), p(hn), p(out), None, st()) == 0
+def bwd_pre(): assert lib.glam_gru_bwd_ws_pre(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(x), p(pre[1]), N, C, 1, 1, 0.0, 0, p(dgi), p(dgh), p(did), p(dx), p(dh), st()) == 0
 def fwd(): assert lib.glam_gru_ws_fwd(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(gi), p(gh), p(hn), p(out), st()) == 0
 def bwd(): assert lib.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(x), p(ta), p(tb), N, C, 1, 1, 0.0, 0, p(dgi), p(dgh), p(did), p(dx), p(dh), st()) == 0
+if PRE: fwd, bwd = fwd_pre, bwd_pre
 for _ in range(5): fwd(); bwd()
 torch.cuda.synchronize()
 with _lib.kernel_timer(capacity=64) as kt:
