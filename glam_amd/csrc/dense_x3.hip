@@ -24,6 +24,7 @@
 #include "bf16x3.h"
 #include "dense.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace glam {
 #ifdef GLAM_DENSE_STAMP
@@ -530,16 +531,23 @@ __device__ __forceinline__ void kc_load(float4 (&q)[2], const float* row, int k,
     q[1] = ld4g(row + min(k + 4, K - 4));
     (void)row_ok;
 }
-__device__ __forceinline__ Bf16x3 kc_split(const float4 (&q)[2], int k, int K, bool row_ok) {
-    const float4 z = f4zero();
-    return split8((row_ok && k < K) ? pinned(q[0]) : z, (row_ok && k + 4 < K) ? pinned(q[1]) : z);
+// `full`: the whole chunk lies inside K (uniform): no select at all.  Rows / columns beyond the matrix keep whatever the clamped loads
+// brought — their products only reach output elements that are never stored.  (The selects of the ragged last chunk stand OUTSIDE the
+// asm that pins the use of the loaded registers: inside the conditional the compiler made each a divergent branch with an
+// s_waitcnt vmcnt(0) in it — every step waited for the prefetch of the step after the next.)
+__device__ __forceinline__ Bf16x3 kc_split(const float4 (&q)[2], int k, int K, bool full) {
+    if (full) return split8(q[0], q[1]);
+    const float4 a = pinned(q[0]), b = pinned(q[1]), z = f4zero();
+    return split8(k < K ? a : z, k + 4 < K ? b : z);
 }
 
-__global__ void __launch_bounds__(256) k_dense_kc(KcArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_dense_kc(KcArgs a) {
+    constexpr int KS = 1;      // (wave groups taking alternate chunks of the same tile — k split inside the block, partial sums through LDS —
+                               //  were slower: 12.4 against 10.8 us with two groups; the step is bound by its instruction count)
     const int b = blockIdx.x;
     const int tile = (b & 7) * a.per_xcd + (b >> 3);
     if (tile >= a.ntiles) return;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1, g = lane >> 4, r = lane & 15;
+    const int t = threadIdx.x, grp = 0, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1, g = lane >> 4, r = lane & 15;
     const int tr = tile / a.tiles_c, tc = tile - tr * a.tiles_c;
     const int row0 = tr * 64 + wr * 32, col0 = tc * 64 + wc * 32;
     const float* arow[2];
@@ -572,32 +580,43 @@ __global__ void __launch_bounds__(256) k_dense_kc(KcArgs a) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            kc_load(qa[s][i], arow[i], s * kGK + 8 * g, a.K, aok[i]);
-            kc_load(qb[s][i], brow[i], s * kGK + 8 * g, a.K, bok[i]);
+            kc_load(qa[s][i], arow[i], (grp + KS * s) * kGK + 8 * g, a.K, aok[i]);
+            kc_load(qb[s][i], brow[i], (grp + KS * s) * kGK + 8 * g, a.K, bok[i]);
         }
-    for (int c0 = 0; c0 < nchunks; c0 += 2) {
+    // one step: split stage s (chunk c), refill the stage with chunk c + 2 KS, multiply.  FULL: the chunk lies inside K — no select
+    // anywhere in the step (the main loop: a select in it, divergent or not, cost the precise wait counts — every step waited for ALL
+    // loads in flight, the prefetch included)
+    auto step = [&](int s, int c, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int k = c * kGK + 8 * g;
+        Bf16x3 fa[2], fb[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int k = (c0 + s) * kGK + 8 * g;
-            Bf16x3 fa[2], fb[2];
+        for (int i = 0; i < 2; ++i) { fa[i] = kc_split(qa[s][i], k, a.K, FULL); fb[i] = kc_split(qb[s][i], k, a.K, FULL); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { fa[i] = kc_split(qa[s][i], k, a.K, aok[i]); fb[i] = kc_split(qb[s][i], k, a.K, bok[i]); }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 2; ++i) { kc_load(qa[s][i], arow[i], k + 2 * KS * kGK, a.K, aok[i]); kc_load(qb[s][i], brow[i], k + 2 * KS * kGK, a.K, bok[i]); }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { kc_load(qa[s][i], arow[i], k + 2 * kGK, a.K, aok[i]); kc_load(qb[s][i], brow[i], k + 2 * kGK, a.K, bok[i]); }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) acc3[0][i][j] = mfma_x3_small(fb[j], fa[i], acc3[0][i][j]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc3[0][i][j] = mfma_x3_small(fb[j], fa[i], acc3[0][i][j]);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) acc3[1][i][j] = mfma_x3_mid(fb[j], fa[i], acc3[1][i][j]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc3[1][i][j] = mfma_x3_mid(fb[j], fa[i], acc3[1][i][j]);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc3[2][i][j] = mfma_x3_big(fb[j], fa[i], acc3[2][i][j]);
-        }
+            for (int j = 0; j < 2; ++j) acc3[2][i][j] = mfma_x3_big(fb[j], fa[i], acc3[2][i][j]);
+    };
+    const int nfull = a.K / kGK;
+    int c0 = grp;                                             // this group's chunks: grp, grp + KS, ... (two in flight)
+    for (; c0 + KS < nfull; c0 += 2 * KS) {                   // pairs of chunks that both lie inside K
+        step(0, c0, std::true_type{});
+        step(1, c0 + KS, std::true_type{});
+    }
+    for (; c0 < nchunks; c0 += 2 * KS) {                      // the last pair: a ragged chunk, one beyond K (all zero)
+        step(0, c0, std::false_type{});
+        step(1, c0 + KS, std::false_type{});
     }
     v4f_t accs[2][2];
 #pragma unroll
