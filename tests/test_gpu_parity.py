@@ -2992,7 +2992,8 @@ def test_prestage_builds_the_pass_weights_in_one_launch(device, monkeypatch):
     staging = lambda names: [n for n in names if "k_stage_params" == n.split("<")[0] or "k_ts_make_image" in n or "k_prestage" in n
                              or "k_gru_ws_pre" in n]
     assert staging(k1) == ["k_prestage"], staging(k1)
-    assert len(staging(k0)) == 3 and "k_prestage" not in staging(k0) and "k_gru_ws_pre" in staging(k0), staging(k0)
+    pre_route = ops.gru_images_pre(int(b.x.size(0)), net.mol_conv.gru.weight_ih_l0.size(1))      # (off with GLAM_X3=0: the GRU step is not warp-specialised)
+    assert len(staging(k0)) == 3 and "k_prestage" not in staging(k0) and ("k_gru_ws_pre" in staging(k0)) == pre_route, staging(k0)
     o2, g2, k2 = run(True, pre=False)               # the plain images of the gate matrices: the same pass, bit for bit
     o3, g3, k3 = run(False, pre=False)
     assert torch.equal(o2, o1) and torch.equal(o3, o1)

@@ -1,4 +1,4 @@
-"""Randomised sweep of the warp-specialised GRU launches (glam_gru_ws_fwd, glam_gru_bwd_ws) against the fp64 gate equations of
+"""Randomised sweep of the warp-specialised GRU launches (glam_gru_ws_fwd, glam_gru_bwd_ws, and both on the pre-split images) against the fp64 gate equations of
 torch.nn.GRU and their autograd: widths 24..64, ragged row counts, with / without residual, folded CELU, hidden-state gradient,
 merged identity.  usage: fuzz_gru.py [n] [seed]"""
 import sys, os
@@ -61,6 +61,20 @@ for case in range(n_cases):
         assert rc == 0, lib.glam_last_error()
         e = [tol(dx, grads[0]), tol(dh, grads[1])] + ([tol(did, grads[2])] if (ident and not merge) else [])
         assert max(e) < 1e-5, f"backward {e}"
+        # the same launches on the pre-split images of the gate matrices (glam_gru_ws_make_pre): every output bit for bit
+        pre = torch.empty(2, lib.glam_gru_ws_pre_bytes(), dtype=torch.uint8, device=dev)
+        assert lib.glam_gru_ws_make_pre(p(wi), p(wh), C, p(pre[0]), p(pre[1]), st()) == 0, lib.glam_last_error()
+        gi2, gh2, hn2, out2 = nan(N, M), nan(N, M), nan(N, C), nan(N, C)
+        rc = lib.glam_gru_ws_fwd_pre(p(xd), p(hd), p(idp) if ident else None, p(pre[0]), p(bi), p(bh), N, C, int(celu), act, slope, p(gi2), p(gh2), p(hn2),
+                                     p(out2), None, st())
+        assert rc == 0, lib.glam_last_error()
+        assert all(torch.equal(u, v) for u, v in ((gi, gi2), (gh, gh2), (hn, hn2), (out, out2))), "forward on the pre-split image differs"
+        o2 = [nan(N, M), nan(N, M), nan(N, C), nan(N, C), nan(N, C)]
+        rc = lib.glam_gru_bwd_ws_pre(p(gi), p(gh), p(hd), p(out), p(d_out_d), p(d_hs_d) if hstate else None, p(xd), p(pre[1]), N, C, int(celu), act, slope,
+                                     int(merge), p(o2[0]), p(o2[1]), p(o2[2]) if ident else None, p(o2[3]), p(o2[4]), st())
+        assert rc == 0, lib.glam_last_error()
+        pairs = [(dgi, o2[0]), (dgh, o2[1]), (dx, o2[3]), (dh, o2[4])] + ([(did, o2[2])] if (ident and not merge) else [])
+        assert all(torch.equal(u, v) for u, v in pairs), "backward on the pre-split image differs"
     except AssertionError as ex:
         bad += 1
         print(f"case {case}: N={N} C={C} celu={celu} ident={ident} hstate={hstate} merge={merge} act={act}: {ex}")
