@@ -87,6 +87,9 @@ SIGNATURES = {
     "glam_dense_gemm": (_i32, [_vp, _i64, _i64, _vp, _f32, _vp, _i64, _i64, _vp, _i32, _f32, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "glam_linear_dense_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp]),
     "glam_linear_dense_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "glam_dense_ws_bytes": (_sz, []),
+    "glam_linear_dense_fwd_ws": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "glam_linear_dense_bwd_ws": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_wgrad_gemm_sets2": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "glam_wgrad_gemm_sets": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "glam_wgrad_gemm_pair_split_seg": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, _vp, _vp, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, _vp, _vp,

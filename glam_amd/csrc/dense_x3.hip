@@ -50,8 +50,15 @@ struct GemmJob {
     int R, Cn, K;
     int tiles_r, tiles_c, first_tile;
     int vec, c_vec;                             // the 16-byte load path / 16-byte stores of C (aligned, ldc % 4 == 0)
+    // k split across blocks (few tiles, long reductions: dx of a batch of 32 is 5 tiles of 32 chunks): unit = (tile, split); split sp takes
+    // chunks [sp * cps, (sp + 1) * cps) and writes its (TR x 64) partial tile to part[(tile * splits + sp)], its piece of the all-ones
+    // column to part_rs[...]; k_dense_splitk_reduce adds the partials in split order and applies bias / activation.  first_tile counts UNITS.
+    int splits, cps;
+    float* part; float* part_rs;
 };
 struct GemmArgs { GemmJob job[2]; int njobs; int ntiles; int per_xcd; };
+constexpr int kSplitMaxUnits = 512;                                // workspace: part_rs [units][64] | part [units][64 x 64]
+constexpr size_t kSplitWsBytes = (size_t)kSplitMaxUnits * 64 * 4 + (size_t)kSplitMaxUnits * 64 * 64 * 4;
 
 #ifdef GLAM_DENSE_STAMP   // developer aid: clock stamps of thread 0 of each wave group of the first 8 blocks
 #define DSTAMP(k) do { if ((threadIdx.x & 255) == 0 && blockIdx.x < 8 && (k) < 64) g_dense_prof[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 64 + (k)] = (long long)clock64(); } while (0)
@@ -493,11 +500,22 @@ template <int TR>
 __global__ void __launch_bounds__(512) k_dense_x3(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int b = blockIdx.x;
-    const int tile = (b & 7) * a.per_xcd + (b >> 3);
-    if (tile >= a.ntiles) return;
-    const bool second = a.njobs > 1 && tile >= a.job[1].first_tile;
-    const GemmJob& jb = second ? a.job[1] : a.job[0];
-    const int tl = tile - jb.first_tile;
+    const int unit = (b & 7) * a.per_xcd + (b >> 3);
+    if (unit >= a.ntiles) return;
+    const bool second = a.njobs > 1 && unit >= a.job[1].first_tile;
+    GemmJob jb = second ? a.job[1] : a.job[0];
+    const int S = jb.splits, lu = unit - jb.first_tile, tl = S > 1 ? lu / S : lu, sp = lu - tl * S;
+    const int Kall = jb.K;
+    const int trow = tl / jb.tiles_c, row0 = trow * TR, col0 = (tl - trow * jb.tiles_c) * 64;
+    if (S > 1) {
+        const long long k0 = (long long)sp * jb.cps * kGK;
+        jb.A += k0 * jb.a_ks; if (jb.gate) jb.gate += k0 * jb.a_ks;
+        jb.B += k0 * jb.b_ks;
+        jb.K = min(Kall - (int)k0, jb.cps * kGK);
+        jb.C = jb.part + ((size_t)tl * S + sp) * (TR * 64) - ((long long)row0 * 64 + col0);
+        jb.ldc = 64; jb.c_vec = 1; jb.bias = nullptr; jb.act = 0;
+        if (jb.rowsum) jb.rowsum = jb.part_rs + ((size_t)tl * S + sp) * TR - row0;
+    }
     // one branch around the whole tile: layout of A, layout of B, gate, 16-byte accesses
 #define GLAM_DENSE_CASE(G, AK, BK)                                                     \
     case ((G) * 4 + (AK) * 2 + (BK)):                                                  \
@@ -511,6 +529,50 @@ __global__ void __launch_bounds__(512) k_dense_x3(GemmArgs a) {
         GLAM_DENSE_CASE(true, true, false) GLAM_DENSE_CASE(true, true, true)
     }
 #undef GLAM_DENSE_CASE
+}
+
+// The second launch of a k-split product: block = one tile of one job, adds the tile's partials in split order and applies the bias /
+// activation (a launch boundary instead of tickets and device-wide fences between the blocks of one launch: on this chip a fence
+// writes back and invalidates a whole L2 — the fenced form took 18.6 us where the unsplit product takes 8.2).
+template <int TR>
+__global__ void __launch_bounds__(256) k_dense_splitk_reduce(GemmArgs a) {
+    int t = blockIdx.x, q = 0;
+    while (q < a.njobs && (a.job[q].splits <= 1 || t >= a.job[q].tiles_r * a.job[q].tiles_c)) {
+        if (a.job[q].splits > 1) t -= a.job[q].tiles_r * a.job[q].tiles_c;
+        ++q;
+    }
+    if (q >= a.njobs) return;
+    const GemmJob& jb = a.job[q];
+    const int S = jb.splits, tl = t, trow = tl / jb.tiles_c, row0 = trow * TR, col0 = (tl - trow * jb.tiles_c) * 64;
+    const float* pbase = jb.part + (size_t)tl * S * (TR * 64);
+    for (int e = threadIdx.x; e < TR * 16; e += 256) {
+        const int r = e >> 4, c4 = (e & 15) * 4, row = row0 + r, col = col0 + c4;
+        if (row >= jb.R || col >= jb.Cn) continue;
+        float4 acc = ld4g(pbase + r * 64 + c4);
+        for (int s = 1; s < S; ++s) {
+            const float4 v = ld4g(pbase + (size_t)s * (TR * 64) + r * 64 + c4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (jb.bias && col + i < jb.Cn) v[i] += jb.bias[col + i];
+            if (jb.act == 1) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            else if (jb.act == 2) v[i] = v[i] > 0.f ? v[i] : v[i] * jb.act_slope;
+        }
+        float* dst = jb.C + (long long)row * jb.ldc + col;
+        if (jb.c_vec && col + 3 < jb.Cn) st4g(dst, make_float4(v[0], v[1], v[2], v[3]));
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (col + i < jb.Cn) st1g(dst + i, v[i]);
+        }
+    }
+    if (jb.rowsum && jb.Cn >= col0 && jb.Cn < col0 + 64 && (int)threadIdx.x < TR && row0 + (int)threadIdx.x < jb.R) {
+        const float* pr = jb.part_rs + (size_t)tl * S * TR + threadIdx.x;
+        float acc = ld1g(pr);
+        for (int s = 1; s < S; ++s) acc += ld1g(pr + (size_t)s * TR);
+        st1g(jb.rowsum + row0 + threadIdx.x, acc);
+    }
 }
 
 // ---- both operands with rows along k (the forward y = x W^T): fragments straight from memory into registers -------------------------
@@ -679,6 +741,7 @@ static void fill_job(GemmJob& j, const Product& p, int TR, int first_tile) {
     // 2: some quad of some row is partial (the reduction length for rows along k, the row / column count for rows across k)
     if (j.vec && (((p.a_ks == 1 || p.b_ks == 1) && p.K % 4) || (p.a_ks != 1 && p.R % 4) || (p.b_ks != 1 && p.Cn % 4))) j.vec = 2;
     j.c_vec = aligned16(p.C) && p.ldc % 4 == 0;
+    j.splits = 1; j.cps = 0; j.part = nullptr; j.part_rs = nullptr;
 }
 
 static bool kc_route(const Product& p) {
@@ -687,7 +750,7 @@ static bool kc_route(const Product& p) {
            aligned16(p.A) && aligned16(p.B);
 }
 
-static int launch_products(const Product* p, int n, hipStream_t s) {
+static int launch_products(const Product* p, int n, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0) {
     if (n == 1 && kc_route(p[0]) && (long long)((p[0].R + 63) / 64) * ((p[0].Cn + 63) / 64) >= 128) {      // (few tiles: the 32-row staged tiles fill the chip better)
         KcArgs a{p[0].A, p[0].a_rs, p[0].B, p[0].b_cs, p[0].bias, p[0].act, p[0].act_slope, p[0].C, p[0].ldc, p[0].R, p[0].Cn, p[0].K,
                  (p[0].Cn + 63) / 64, 0, 0, aligned16(p[0].C) && p[0].ldc % 4 == 0};
@@ -704,9 +767,33 @@ static int launch_products(const Product* p, int n, hipStream_t s) {
     GemmArgs a{};
     a.njobs = n;
     int first = 0;
+    // a job of few tiles and a long reduction: k split across blocks, up to 8 ways, at least four chunks per split, within the CUs the other
+    // job leaves (needs the caller's workspace; a second launch adds the partials)
+    long long tiles_all = 0;
+    for (int i = 0; i < n; ++i) tiles_all += (long long)((p[i].R + TR - 1) / TR) * ((p[i].Cn + (p[i].rowsum ? 1 : 0) + 63) / 64);
+    int reduce_tiles = 0;
     for (int i = 0; i < n; ++i) {
         fill_job(a.job[i], p[i], TR, first);
-        const long long tl = (long long)a.job[i].tiles_r * a.job[i].tiles_c;
+        long long tl = (long long)a.job[i].tiles_r * a.job[i].tiles_c;
+        const int nch = (p[i].K + kGK - 1) / kGK;
+        if (ws && ws_bytes >= kSplitWsBytes && tl <= 32 && nch >= 16) {
+            const long long room = 256 - (tiles_all - tl);
+            int S = (int)((room > tl ? room : tl) / tl);
+            if (S > 8) S = 8;
+            if (S > nch / 4) S = nch / 4;
+            if (S > 1) {
+                const int cps = (nch + S - 1) / S;
+                S = (nch + cps - 1) / cps;
+                if (S > 1 && first + tl * S <= kSplitMaxUnits) {
+                    GemmJob& j = a.job[i];
+                    j.splits = S; j.cps = cps;
+                    j.part_rs = reinterpret_cast<float*>(ws) + (size_t)first * 64;
+                    j.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kSplitMaxUnits * 64 * 4) + (size_t)first * 64 * 64;
+                    reduce_tiles += (int)tl;
+                    tl *= S;
+                }
+            }
+        }
         GLAM_REQUIRE(first + tl < (1 << 24), "glam_dense_gemm: %lld tiles", first + tl);
         first += (int)tl;
     }
@@ -716,6 +803,11 @@ static int launch_products(const Product* p, int n, hipStream_t s) {
     if (TR == 64) hipLaunchKernelGGL(k_dense_x3<64>, dim3(grid), dim3(512), kGLds, s, a);
     else hipLaunchKernelGGL(k_dense_x3<32>, dim3(grid), dim3(512), kGLds, s, a);
     GLAM_LAUNCH_CHECK("k_dense_x3");
+    if (reduce_tiles) {
+        if (TR == 64) hipLaunchKernelGGL(k_dense_splitk_reduce<64>, dim3(reduce_tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_dense_splitk_reduce<32>, dim3(reduce_tiles), dim3(256), 0, s, a);
+        GLAM_LAUNCH_CHECK("k_dense_splitk_reduce");
+    }
     return 0;
 }
 
@@ -745,8 +837,37 @@ extern "C" int glam_linear_dense_fwd(const float* x, const float* w, const float
     return launch_products(&p, 1, (hipStream_t)stream);
 }
 
+extern "C" size_t glam_dense_ws_bytes(void) { return kSplitWsBytes; }
+
+static int ws_ok(const char* fn, const void* ws, size_t ws_bytes) {
+    GLAM_REQUIRE(!ws || (aligned16(ws) && ws_bytes >= kSplitWsBytes), "%s: the workspace needs glam_dense_ws_bytes() = %zu bytes, 16-byte aligned", fn,
+                 kSplitWsBytes);
+    return 0;
+}
+
+extern "C" int glam_linear_dense_fwd_ws(const float* x, const float* w, const float* b, int64_t N, int K, int M, int act, float slope,
+                                        float* y, void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(N >= 1 && N < (1 << 30), "glam_linear_dense_fwd_ws: N = %lld", (long long)N);
+    if (int rc = ws_ok("glam_linear_dense_fwd_ws", ws, ws_bytes)) return rc;
+    const Product p{x, K, 1, nullptr, 0.f, w, 1, K, b, act, slope, y, M, nullptr, (int)N, M, K};
+    if (int rc = check_product(p, "glam_linear_dense_fwd_ws")) return rc;
+    return launch_products(&p, 1, (hipStream_t)stream, ws, ws_bytes);
+}
+
+static int linear_dense_bwd_impl(const char* fn, const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope,
+                                 int64_t N, int K, int M, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t s);
+extern "C" int glam_linear_dense_bwd_ws(const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope, int64_t N,
+                                        int K, int M, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = ws_ok("glam_linear_dense_bwd_ws", ws, ws_bytes)) return rc;
+    return linear_dense_bwd_impl("glam_linear_dense_bwd_ws", x, w, dy, y_gate, gate_slope, N, K, M, dx, dw, db, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int glam_linear_dense_bwd(const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope, int64_t N,
                                      int K, int M, float* dx, float* dw, float* db, void* stream) {
+    return linear_dense_bwd_impl("glam_linear_dense_bwd", x, w, dy, y_gate, gate_slope, N, K, M, dx, dw, db, nullptr, 0, (hipStream_t)stream);
+}
+static int linear_dense_bwd_impl(const char* fn, const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope,
+                                 int64_t N, int K, int M, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t stream) {
+    (void)fn;
     GLAM_REQUIRE(N >= 4 && N < (1 << 30), "glam_linear_dense_bwd: N = %lld (the weight gradient reduces over N >= 4 rows)", (long long)N);
     GLAM_REQUIRE(dw || dx, "glam_linear_dense_bwd: nothing to compute");
     GLAM_REQUIRE(dw || !db, "glam_linear_dense_bwd: db comes with dw");
@@ -758,5 +879,5 @@ extern "C" int glam_linear_dense_bwd(const float* x, const float* w, const float
     if (dx) p[n++] = Product{dy, M, 1, y_gate, gate_slope, w, K, 1, nullptr, 0, 0.f, dx, K, nullptr, (int)N, K, M};
     for (int i = 0; i < n; ++i)
         if (int rc = check_product(p[i], "glam_linear_dense_bwd")) return rc;
-    return launch_products(p, n, (hipStream_t)stream);
+    return launch_products(p, n, stream, ws, ws_bytes);
 }

@@ -1170,6 +1170,8 @@ GRU_WGRAD_BATCH = True
 # the warp-specialised GRU step on pre-split operand fragments of its gate matrices (glam_gru_ws_make_pre) instead of splitting the plain
 # images in every block's prologue: A/B switch (GLAM_GRU_PRE=0)
 GRU_PRE = os.environ.get("GLAM_GRU_PRE", "1") != "0"
+# the readout MLP's products of few tiles split k across blocks (glam_linear_dense_*_ws; matters at the reference's batch of 32): A/B switch
+DENSE_SPLITK = os.environ.get("GLAM_DENSE_SPLITK", "1") != "0"
 # PairNorm + the Dropout behind it from one launch each way (glam_graph_norm_drop_*): A/B switch
 NORM_DROP = True
 # the derived weights of a model pass from one launch (glam_prestage) instead of one per module: A/B switch

@@ -488,6 +488,21 @@ def linear_dense_supported(N, K, M):
     return K % 4 == 0 and M % 4 == 0 and K >= 32 and N >= 4
 
 
+_DENSE_WS = {}
+
+
+def _dense_ws(dev):
+    """The split-k workspace of ``glam_linear_dense_fwd_ws`` / ``_bwd_ws`` (``ops.DENSE_SPLITK``; None: switched off): one per device;
+    the launches that share it are ordered on the process's one compute stream."""
+    if not _o.DENSE_SPLITK:
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _DENSE_WS.get(key)
+    if ws is None:
+        ws = _DENSE_WS[key] = torch.empty(_lib.load().glam_dense_ws_bytes(), dtype=torch.uint8, device=dev)
+    return ws
+
+
 class _LinearDense(torch.autograd.Function):
     """``act(F.linear(x, w, b))`` with act in {none, ReLU, LeakyReLU} on ``glam_linear_dense_fwd`` (3 x bf16 matrix cores, bias and
     activation in the epilogue) and the whole backward — activation derivative on ``dy`` (read from the saved OUTPUT), ``dx``, ``dw``
@@ -502,7 +517,9 @@ class _LinearDense(torch.autograd.Function):
         N, K = x.shape
         M = w.size(0)
         y = torch.empty(N, M, dtype=torch.float32, device=x.device)
-        check(_lib.load().glam_linear_dense_fwd(ptr(x), ptr(w), ptr(b), N, K, M, act, slope, ptr(y), stream()), "glam_linear_dense_fwd")
+        ws = _dense_ws(x.device)
+        check(_lib.load().glam_linear_dense_fwd_ws(ptr(x), ptr(w), ptr(b), N, K, M, act, slope, ptr(y), ptr(ws), 0 if ws is None else ws.numel(),
+                                                   stream()), "glam_linear_dense_fwd_ws")
         ctx.save_for_backward(x, w, y if act else None)
         ctx.has_bias, ctx.slope = b is not None, (0.0 if act == 1 else slope)
         ctx.set_materialize_grads(False)
@@ -527,8 +544,9 @@ class _LinearDense(torch.autograd.Function):
         need_dw = dw is not None
         if db is not None and dw is None:
             dw = torch.empty(M, K, **f)      # (the bias gradient is the all-ones column of the dy^T [x | 1] product: it comes with dw)
-        check(_lib.load().glam_linear_dense_bwd(ptr(x), ptr(w), ptr(dy), ptr(y), ctx.slope, N, K, M, ptr(dx), ptr(dw), ptr(db), stream()),
-              "glam_linear_dense_bwd")
+        ws = _dense_ws(x.device)
+        check(_lib.load().glam_linear_dense_bwd_ws(ptr(x), ptr(w), ptr(dy), ptr(y), ctx.slope, N, K, M, ptr(dx), ptr(dw), ptr(db), ptr(ws),
+                                                   0 if ws is None else ws.numel(), stream()), "glam_linear_dense_bwd_ws")
         return dx, (dw if need_dw else None), db, None, None
 
 

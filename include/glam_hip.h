@@ -713,6 +713,18 @@ int glam_linear_dense_fwd(const float* x, const float* w, const float* b, int64_
  * fused, NULL otherwise): dx[N, K] = g w, dw[M, K] = g^T x, db[M] = column sums of g.  dx may be NULL; db may be NULL; N >= 4. */
 int glam_linear_dense_bwd(const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope, int64_t N, int K, int M,
                           float* dx, float* dw, float* db, void* stream);
+/* The same two products with a workspace (glam_dense_ws_bytes() bytes, 16-byte aligned, contents irrelevant; launches that share it must
+ * be ordered on one stream) that lets a product of few tiles and a long reduction split k across blocks — dx of the reference's batch
+ * of 32 (run.py:40) is 5 tiles of 32 serial chunks beside 160 one-chunk tiles of dw.  Each split writes its partial tile; a second
+ * launch adds them in split order and applies bias / activation (run-to-run identical; a launch boundary, not tickets: a device-wide
+ * fence between the blocks of one launch writes back and invalidates a whole L2 on this chip).  A product with more than 32 tiles or
+ * fewer than 16 chunks of 32 is not split and equals the plain entry points' result bit for bit.  ws == NULL: exactly the plain entry
+ * points. */
+size_t glam_dense_ws_bytes(void);
+int glam_linear_dense_fwd_ws(const float* x, const float* w, const float* b, int64_t N, int K, int M, int act, float slope, float* y,
+                             void* ws, size_t ws_bytes, void* stream);
+int glam_linear_dense_bwd_ws(const float* x, const float* w, const float* dy, const float* y_gate, float gate_slope, int64_t N, int K,
+                             int M, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
 /* One Adam step over n parameter tensors in one launch per 40 tensors — the optimizer of the training loop that drives the path
  * (`Adam(self.model.parameters(), lr=args.lr)`, src_1gp/trainer.py:49-50, stepped at trainer.py:301; torch.optim.Adam semantics

@@ -2925,6 +2925,56 @@ def test_linear_dense_forward_backward_against_fp64(device, N, K, M, act):
     assert ((gw.double() - rw).abs().max() / rw.abs().max()).item() < 3e-6 * max(1.0, N ** 0.5 / 16)
 
 
+@pytest.mark.parametrize("N,K,M,act", [(32, 300, 1024, 1), (8, 300, 1024, 2), (32, 1024, 300, 0), (64, 300, 1024, 1), (33, 64, 128, 0), (4, 32, 4, 1),
+                                        (100, 1024, 617, 2), (1024, 300, 1024, 1)])
+def test_linear_dense_k_split_across_blocks(device, N, K, M, act):
+    """glam_linear_dense_fwd_ws / _bwd_ws (the readout MLP at the reference's batch of 32, run.py:40: few tiles, long reductions — k split
+    across blocks, partial tiles added in split order by a second launch): against fp64; the same bits on every run and whatever the
+    workspace held before; with many tiles (N = 1024) and with ws = NULL exactly the plain entry points."""
+    import torch.nn.functional as F
+    lib, p, st = ops._lib.load(), ops._lib.ptr, ops._lib.stream
+    torch.manual_seed(N * 7 + K)
+    x, w, b = torch.randn(N, K, device=device), torch.randn(M, K, device=device) * K ** -0.5, torch.randn(M, device=device)
+    dy = torch.randn(N, M, device=device)
+    nb = lib.glam_dense_ws_bytes()
+    ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device=device)          # (NaN patterns: nothing of it may reach a result)
+    nan = lambda *s: torch.full(s, float("nan"), device=device)
+    slope = 0.2
+    def run(ws_t):
+        y, dx, dw, db = nan(N, M), nan(N, K), nan(M, K), nan(M)
+        a = (p(ws_t), nb) if ws_t is not None else (None, 0)
+        assert lib.glam_linear_dense_fwd_ws(p(x), p(w), p(b), N, K, M, act, slope, p(y), *a, st()) == 0, lib.glam_last_error()
+        gate = p(y) if act else None
+        if N >= 4:
+            assert lib.glam_linear_dense_bwd_ws(p(x), p(w), p(dy), gate, 0.0 if act == 1 else slope, N, K, M, p(dx), p(dw), p(db), *a, st()) == 0, \
+                lib.glam_last_error()
+        return y, dx, dw, db
+    got = run(ws)
+    for _ in range(3):
+        again = run(ws)
+        for u, v in zip(got, again):
+            assert torch.equal(u, v)
+    plain = run(None)
+    yp, dxp, dwp, dbp = nan(N, M), nan(N, K), nan(M, K), nan(M)
+    assert lib.glam_linear_dense_fwd(p(x), p(w), p(b), N, K, M, act, slope, p(yp), st()) == 0
+    assert torch.equal(plain[0], yp)
+    if N >= 1024:
+        for u, v in zip(got, plain):
+            assert torch.equal(u, v)                                                           # many tiles: nothing is split
+    xd, wd, bd = x.double(), w.double(), b.double()
+    pre = F.linear(xd, wd, bd)
+    want = torch.relu(pre) if act == 1 else F.leaky_relu(pre, slope) if act == 2 else pre
+    assert ((got[0].double() - want).abs().max() / want.abs().max()).item() < 2e-6
+    assert not torch.isnan(got[0]).any()
+    g = dy.double() * (torch.where(got[0].double() > 0, 1.0, 0.0 if act == 1 else slope) if act else 1.0)
+    tol = 3e-6 * max(1.0, N ** 0.5 / 16)
+    for name, u, r in (("dx", got[1], g @ wd), ("dw", got[2], g.t() @ xd), ("db", got[3], g.sum(0))):
+        assert ((u.double() - r).abs().max() / r.abs().max()).item() < tol, name
+    # a workspace that is too small or misaligned is refused
+    assert lib.glam_linear_dense_fwd_ws(p(x), p(w), p(b), N, K, M, act, slope, p(got[0]), p(ws), nb - 16, st()) == ops._lib.GLAM_E_INVALID
+    assert lib.glam_linear_dense_fwd_ws(p(x), p(w), p(b), N, K, M, act, slope, p(got[0]), ws.data_ptr() + 4, nb, st()) == ops._lib.GLAM_E_INVALID
+
+
 def test_linear_block_routes_the_readout_mlp_to_the_dense_kernel(device):
     """LinearBlock(300, 1024, act=ReLU) — `mol_flat` of the parity configuration — runs as one dense launch each way and agrees with
     the unfused composition; shapes outside the class (K = 450: rows not 16-byte multiples) keep the library route."""

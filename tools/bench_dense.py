@@ -37,7 +37,10 @@ for (N, K, M) in [(1024, 300, 1024), (642, 300, 1024), (2039, 300, 1024), (32, 3
     t_b = timed(lambda: lib.glam_linear_dense_bwd(p(x), p(w), p(dy), p(y), 0.0, N, K, M, p(dx), p(dw), p(db), _lib.stream()))
     t_w = timed(lambda: lib.glam_linear_dense_bwd(p(x), p(w), p(dy), p(y), 0.0, N, K, M, None, p(dw), p(db), _lib.stream()))
     t_x = timed(lambda: lib.glam_linear_dense_bwd(p(x), p(w), p(dy), p(y), 0.0, N, K, M, p(dx), None, None, _lib.stream()))
-    line = f"N={N} K={K} M={M}: forward {t_f:.2f} us, backward pair {t_b:.2f} us (dw alone {t_w:.2f}, dx alone {t_x:.2f})"
+    ws = torch.zeros(lib.glam_dense_ws_bytes(), dtype=torch.uint8, device=dev)
+    t_fs = timed(lambda: lib.glam_linear_dense_fwd_ws(p(x), p(w), p(b), N, K, M, 1, 0.0, p(y), p(ws), ws.numel(), _lib.stream()))
+    t_bs = timed(lambda: lib.glam_linear_dense_bwd_ws(p(x), p(w), p(dy), p(y), 0.0, N, K, M, p(dx), p(dw), p(db), p(ws), ws.numel(), _lib.stream()))
+    line = f"N={N} K={K} M={M}: forward {t_f:.2f} us, backward pair {t_b:.2f} us (dw alone {t_w:.2f}, dx alone {t_x:.2f}); with the split-k workspace {t_fs:.2f} / {t_bs:.2f}"
     if not ours_only:
         t_lf = timed(lambda: torch.relu(torch.addmm(b, x, w.t())))
         t_lb = timed(lambda: ((dy * (y > 0)) @ w, (dy * (y > 0)).t() @ x, dy.sum(0)))
