@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GLAM_HIP_LIB", os.path.join(_HERE, "libglam_hip.so"))   # override: kernel experiments
+LIB_PATH = os.environ.get("GLAM_HIP_LIB") or os.path.join(_HERE, "libglam_hip.so")   # override: kernel experiments (empty = unset)
 
 GLAM_E_INVALID, GLAM_E_UNSUPPORTED, GLAM_E_HIP = -1, -2, -3
 
