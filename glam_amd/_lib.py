@@ -47,6 +47,7 @@ SIGNATURES = {
     "glam_edge_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "glam_edge_wsum_fwd": (_i32, [_vp] * 5 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "glam_edge_wsum_bwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "glam_edge_wsum_bwd_add": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "glam_pair_pool_workspace_bytes": (_sz, [_i64, _i32]),
     "glam_pair_pool_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_pair_pool_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),

@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_fwd_v4(const float* x, con
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd_v4(const float* d_out, const float* w, const int* colptr, const int* dst,
                                                             const int* eid_t, const int* rowptr, int N, int D, int mean,
-                                                            int self_slot, float* dx) {
+                                                            int self_slot, float* dx, const float* addend) {
     const int D4 = D >> 2, KS = K + self_slot;
     const size_t total = (size_t)N * D4;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
@@ -790,6 +790,10 @@ __global__ void __launch_bounds__(kBlock) k_edge_wsum_bwd_v4(const float* d_out,
 #pragma unroll
             for (int k = 0; k < K; ++k) fma4(t, f4get(wv[k >> 2], k & 3), g[k]);
             fma4(acc, sc, t);
+        }
+        if (addend) {      // a second gradient path into x (the skip connection around the conv), added last: what the autograd engine's add computes
+            const float4 ad = ld4(addend + (size_t)j * D + c);
+            acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
         }
         st4(dx + (size_t)j * D + c, acc);
     }
@@ -1056,11 +1060,29 @@ extern "C" int glam_edge_wsum_bwd(const float* d_out, const float* w, const int3
     else if (K == 1) hipLaunchKernelGGL(k_edge_wsum_bwd<1>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else if ((D & 3) == 0 && aligned16(d_out) && aligned16(w) && aligned16(dx)) {
         const dim3 g4(grid_for(N * (D / 4), kBlock));
-        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd_v4<4>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot, dx);
-        else hipLaunchKernelGGL(k_edge_wsum_bwd_v4<8>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot, dx);
+        if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd_v4<4>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot, dx, (const float*)nullptr);
+        else hipLaunchKernelGGL(k_edge_wsum_bwd_v4<8>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot, dx, (const float*)nullptr);
     } else if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd<4>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     else hipLaunchKernelGGL(k_edge_wsum_bwd<8>, grid, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, dx);
     GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd");
+    return GLAM_OK;
+}
+
+// ... + addend[N, D] (may be NULL): dx = (the sums) + addend, the add launch of a skip connection around the layer folded into this
+// one.  Only the 16-byte form (K in {4, 8}, D % 4 == 0, aligned tensors); anything else is refused (the caller adds afterwards).
+extern "C" int glam_edge_wsum_bwd_add(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst,
+                                      const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K,
+                                      int mean, int self_slot, const float* addend, float* dx, void* stream) {
+    if (int rc = pool_dims("glam_edge_wsum_bwd_add", N, E, D)) return rc;
+    if (!((K == 4 || K == 8) && (D & 3) == 0 && aligned16(d_out) && aligned16(w) && aligned16(dx) && aligned16(addend)))
+        return fail(GLAM_E_UNSUPPORTED, "glam_edge_wsum_bwd_add: K in {4, 8}, D %% 4 == 0 and 16-byte aligned tensors only");
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(d_out && colptr && rowptr && dx && (E == 0 || (w && dst && eid_t)), "glam_edge_wsum_bwd_add: null pointer");
+    const dim3 g4(grid_for(N * (D / 4), kBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 4) hipLaunchKernelGGL(k_edge_wsum_bwd_v4<4>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot ? 1 : 0, dx, addend);
+    else hipLaunchKernelGGL(k_edge_wsum_bwd_v4<8>, g4, block, 0, s, d_out, w, colptr, dst, eid_t, rowptr, (int)N, D, mean, self_slot ? 1 : 0, dx, addend);
+    GLAM_LAUNCH_CHECK("glam_edge_wsum_bwd_add");
     return GLAM_OK;
 }
 

@@ -398,7 +398,19 @@ class NNConv(MessagePassing):
         if self.bias is not None:
             zeros_(self.bias)
 
-    def forward(self, x, edge_index, edge_attr, size=None):
+    def forward_with_identity(self, x, edge_index, edge_attr):
+        """``(self(x, ...), identity)`` with ``identity`` = ``x`` handed back through the relation-sum node where the layer runs as one
+        stacked GEMM (one-hot bonds, root term as the self slot): the skip connection's gradient is added inside that node's backward
+        launch; plain ``x`` on every other route."""
+        return self.forward(x, edge_index, edge_attr, with_identity=True)
+
+    def forward(self, x, edge_index, edge_attr, size=None, with_identity=False):
+        out = self._forward(x, edge_index, edge_attr, with_identity)
+        if with_identity:
+            return out if isinstance(out, tuple) else (out, x)
+        return out
+
+    def _forward(self, x, edge_index, edge_attr, with_identity):
         gi = ops.graph_index(edge_index, x.size(0))
         De = edge_attr.size(1)
         if De <= 8 and not edge_attr.requires_grad and ops.rows_are_one_hot(edge_attr):
@@ -422,6 +434,9 @@ class NNConv(MessagePassing):
                     w = w_rel if Dp == De else F.pad(w_rel.view(De, C, -1), (0, 0, 0, 0, 0, Dp - De)).reshape(Dp * C, -1)
                     return torch.cat([w, self.root], dim=0).contiguous()
                 w_all = ops.scoped_weights(("nnconv-stack", id(self), De), self, stacked)
+                if with_identity:
+                    S, ident = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"), self_slot=True, with_identity=True)
+                    return ops.matmul_tall(S.view(x.size(0), (Dp + 1) * C), w_all, self.bias), ident
                 S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"), self_slot=True)      # [N, Dp + 1, in]
                 return ops.matmul_tall(S.view(x.size(0), (Dp + 1) * C), w_all, self.bias)
             S = ops.edge_weighted_sum(x, ea, gi, mean=(self.aggr == "mean"))           # [N, Dp, in]
@@ -473,7 +488,12 @@ class GCNConv(MessagePassing):
         dis = dis.masked_fill(dis == float("inf"), 0)
         return dis[ei[0]] * w * dis[ei[1]]
 
-    def forward(self, x, edge_index, edge_weight=None, add_bias=True):
+    def forward_with_identity(self, x, edge_index):
+        """``(self(x, edge_index, add_bias=False), identity)`` with ``identity`` = ``x`` handed back through the node of the ``x @ W``
+        product where that saves the add launch of the skip connection around the conv (MessageBlock, layer.py:253-265)."""
+        return self.forward(x, edge_index, add_bias=False, with_identity=True)
+
+    def forward(self, x, edge_index, edge_weight=None, add_bias=True, with_identity=False):
         n = x.size(0)
         gi0 = ops.graph_index(edge_index, n)
         ei, gi, mask = _with_self_loops(gi0, edge_index, n, True)
@@ -487,12 +507,17 @@ class GCNConv(MessagePassing):
             inv = ~mask
             loop_w[edge_index[0][inv]] = edge_weight[inv]
             norm = self._norm(ei, gi, torch.cat([edge_weight[mask], loop_w])).view(-1, 1)
-        xw = ops.matmul_tall(x, self.weight)
+        ident = x
+        if with_identity:
+            xw, ident = ops.matmul_tall(x, self.weight, with_identity=True)
+        else:
+            xw = ops.matmul_tall(x, self.weight)
         if norm.requires_grad:         # learnable edge weights: per-edge messages, so that autograd reaches them
             out = ops.edge_reduce(norm * xw.index_select(0, ei[0]), gi, "sum")
         else:                          # one gather-scale-sum kernel per direction (K = 1 relation)
             out = ops.edge_weighted_sum(xw, norm, gi).view(n, xw.size(1))
-        return out if (self.bias is None or not add_bias) else out + self.bias
+        out = out if (self.bias is None or not add_bias) else out + self.bias
+        return (out, ident) if with_identity else out
 
 
 class GATConv(MessagePassing):
@@ -540,6 +565,9 @@ class _NNConv(torch.nn.Module):  # layer.py:115-122
 
     def forward(self, x, edge_index, edge_attr):
         return self.conv(x, edge_index, edge_attr)
+
+    def forward_with_identity(self, x, edge_index, edge_attr):
+        return self.conv.forward_with_identity(x, edge_index, edge_attr)
 
 
 class _TripletMessage(torch.nn.Module):  # layer.py:125-131
@@ -978,7 +1006,13 @@ class MessageBlock(torch.nn.Module):
         if self.gru is None and isinstance(self.conv, (_GCNConv, _GATConv)) and fa is not None:
             # no GRU (layer.py:248): conv bias + residual + activation as one launch per direction
             c = self.conv.conv
-            y = c(x, edge_index, add_bias=False)
+            if (self.res is not False and identity is x and hasattr(c, "forward_with_identity") and x.is_cuda and torch.is_grad_enabled()
+                    and x.requires_grad and ops.SKIP_THROUGH_CONV):
+                # x feeds the conv and the skip connection: the x @ W node hands x back as `identity`, both gradient paths meet in the
+                # epilogue of its d_x product (one add launch per application less)
+                y, identity = c.forward_with_identity(x, edge_index)
+            else:
+                y = c(x, edge_index, add_bias=False)
             return ops.bias_res_act(y, c.bias, None if self.res is False else identity, fa[0], fa[1], rng=fa[2]), h
         if (self.res is not False and identity is x and hasattr(self.conv, "forward_with_identity") and x.is_cuda
                 and torch.is_grad_enabled() and x.requires_grad and ops.SKIP_THROUGH_CONV):

@@ -153,15 +153,20 @@ class _MatmulTall(torch.autograd.Function):
     times per forward (see _ParamBundle): [d_w | d_bias] flat, summed by the reduction of the weight-gradient product."""
 
     @staticmethod
-    def forward(ctx, a, w, bias, carry=None, first_app=True):
+    def forward(ctx, a, w, bias, carry=None, first_app=True, with_identity=False):
+        """``with_identity``: ``a`` comes back as a second output — the skip connection of the caller (MessageBlock around a GCNConv,
+        layer.py:253-265) takes it from there, so that its gradient arrives HERE and joins ``dy @ w^T`` in that product's epilogue
+        instead of in an add launch of the autograd engine."""
         require_device(a, w, bias)
+        a_in = a
         a, w = f32c(a, "a"), f32c(w, "w")
         ctx.save_for_backward(a, w)
         ctx.has_bias = bias is not None
         ctx.scope = _o._SCOPE
         ctx.carried = carry is not None
+        ctx.aliased = bool(with_identity)
         ctx.first_app = bool(first_app)
-        if ctx.carried:
+        if ctx.carried or ctx.aliased:
             ctx.set_materialize_grads(False)     # the carry of the LAST application has no gradient yet: None, not a zero fill
         N, K = a.shape
         M = w.size(1)
@@ -176,20 +181,40 @@ class _MatmulTall(torch.autograd.Function):
                                    None, 0, 0, N, stream()), "glam_ts_gemm")
         else:
             out = torch.matmul(a, w) if bias is None else torch.addmm(f32c(bias, "bias"), a, w)
-        return (out, carry.view(-1)) if ctx.carried else out
+        res = (out,) + ((a_in.view_as(a_in),) if ctx.aliased else ()) + ((carry.view(-1),) if ctx.carried else ())
+        return res if len(res) > 1 else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy, d_carry=None):
+    def backward(ctx, dy, *more):
+        d_alias = more[0] if ctx.aliased else None
+        d_carry = more[-1] if ctx.carried else None
+        res = _MatmulTall._backward(ctx, dy, d_alias, d_carry)
+        return res + (None,)                              # (with_identity)
+
+    @staticmethod
+    def _backward(ctx, dy, d_alias, d_carry):
         a, w = ctx.saved_tensors
         N, K = a.shape
         M = w.size(1)
-        if dy is None:      # only with a carry (grads are not materialised then): the output itself was unused
-            return None, None, None, d_carry, None
+        if dy is None:      # only with a carry / an alias (grads are not materialised then): the output itself was unused
+            return d_alias, None, None, d_carry, None
         dy = f32c(dy, "dy")
         da = None
         if ctx.needs_input_grad[0]:
-            if M <= 96 and K <= 320 and K > 64:
+            if M <= 64 and K <= 64 and M % 4 == 0 and K % 4 == 0 and linear_supported(M, K) and N > 0:
+                # a layer-sized product (GCNConv 60 -> 60): k_ts_gemm, the skip connection's gradient added in its epilogue
+                lib = _lib.load()
+                scope = ctx.scope
+                img = _o._scoped(scope.bwd if scope else None, ("tall-dx", id(w)), w, lambda: _o._ts_image(w, M, K, True))
+                da = torch.empty(N, K, dtype=torch.float32, device=a.device)
+                if d_alias is not None:
+                    d_alias = f32c(d_alias, "d_identity")
+                    check(lib.glam_ts_gemm_add(ptr(dy), M, M, ptr(img), None, ptr(da), K, K, ptr(d_alias), K, N, stream()), "glam_ts_gemm_add")
+                    d_alias = None
+                else:
+                    check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(da), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
+            elif M <= 96 and K <= 320 and K > 64:
                 # dy[N, M] @ w^T[M, K] with a wide output: the 120 KB-image k_ts_gemm variant (the library GEMM picks 16x256
                 # tiles for this shape: 44 us for 60 -> 300 at N = 20 k)
                 lib = _lib.load()
@@ -199,6 +224,10 @@ class _MatmulTall(torch.autograd.Function):
                 check(lib.glam_ts_gemm(ptr(dy), M, M, None, 0, 0, ptr(img), None, ptr(da), K, K, None, 0, 0, N, stream()), "glam_ts_gemm")
             else:
                 da = torch.matmul(dy, w.t())
+            if d_alias is not None:
+                da = da + d_alias
+        elif d_alias is not None:
+            da = d_alias
         dw = db = None
         scope = ctx.scope
         if ctx.carried and ctx.has_bias and M <= 64 and scope is not None and _o.GRU_WGRAD_BATCH and N >= _GRU_BATCH_MIN_ROWS:
@@ -254,7 +283,7 @@ class _MatmulTall(torch.autograd.Function):
         return da, dw, db, None, None
 
 
-def _matmul_tall_node(a, w, bias):
+def _matmul_tall_node(a, w, bias, with_identity=False):
     """``_MatmulTall`` with the gradients of (w, bias) carried across the applications of a block inside a weight_scope."""
     K, M = w.shape
     total = K * M + (M if bias is not None else 0)
@@ -267,24 +296,31 @@ def _matmul_tall_node(a, w, bias):
     first = not (hit is not None and hit[0] is w)          # the block's first application of this pass: its backward runs LAST
     carry = _o._carry_for(key, params, total, split) if (w.requires_grad or (bias is not None and bias.requires_grad)) else None
     if carry is None:
-        return _MatmulTall.apply(a, w, bias)
-    out, carry = _MatmulTall.apply(a, w, bias, carry, first)
-    _o._carry_store(key, w, carry)
-    return out
+        return _MatmulTall.apply(a, w, bias, None, True, with_identity)
+    res = _MatmulTall.apply(a, w, bias, carry, first, with_identity)
+    _o._carry_store(key, w, res[-1])
+    return (res[0], res[1]) if with_identity else res[0]
 
 
-def matmul_tall(a, w, bias=None):
+def matmul_tall(a, w, bias=None, with_identity=False):
     """``a @ w (+ bias)`` with the weight gradient on the MFMA reduction kernel when it fits: one of (K, M) <= 320 and the other
-    <= 128, multiples of 4 (with a bias: K + 1 <= 320 and M <= 128)."""
+    <= 128, multiples of 4 (with a bias: K + 1 <= 320 and M <= 128).  ``with_identity``: returns ``(out, identity)`` with ``identity`` =
+    ``a`` handed back through the product's autograd node where that saves the add launch of a skip connection around it (plain ``a``
+    elsewhere)."""
     K, M = w.shape
     ok = a.dim() == 2 and a.is_cuda and K % 4 == 0 and M % 4 == 0 and a.size(0) >= 64
+    alias = bool(with_identity) and ok and torch.is_grad_enabled() and a.requires_grad and a.dtype == torch.float32
+    def fin(out, ident=None):
+        return (out, a if ident is None else ident) if with_identity else out
     if ok and bias is not None and K + 1 <= 320 and M <= 128:
-        return _matmul_tall_node(a, w, bias)
+        r = _matmul_tall_node(a, w, bias, alias)
+        return fin(*r) if alias else fin(r)
     if ok and ((K <= 320 and M <= 128) or (K <= 128 and M <= 320)):
-        out = _matmul_tall_node(a, w, None)
-        return out if bias is None else out + bias
+        r = _matmul_tall_node(a, w, None, alias)
+        out, ident = r if alias else (r, None)
+        return fin(out if bias is None else out + bias, ident)
     out = torch.matmul(a, w)
-    return out if bias is None else out + bias
+    return fin(out if bias is None else out + bias)
 
 
 class _LinearTall(torch.autograd.Function):

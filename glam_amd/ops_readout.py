@@ -382,8 +382,9 @@ def graph_standardize(x, sp, eps=1e-5, with_identity=False):
 
 class _EdgeWeightedSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, gi, mean, self_slot):
+    def forward(ctx, x, w, gi, mean, self_slot, with_identity=False):
         require_device(x, w)
+        x_in = x
         x, w = f32c(x, "x"), f32c(w, "w")
         N, D = x.shape
         E, K = w.shape
@@ -394,25 +395,44 @@ class _EdgeWeightedSum(torch.autograd.Function):
                                              int(self_slot), ptr(out), stream()), "glam_edge_wsum_fwd")
         ctx.save_for_backward(w)
         ctx.gi, ctx.cfg = gi, (N, E, D, K, int(mean), int(self_slot))
+        ctx.aliased = bool(with_identity)
+        if ctx.aliased:
+            ctx.set_materialize_grads(False)
+            return out, x_in.view_as(x_in)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, d_alias=None):
         (w,) = ctx.saved_tensors
         gi = ctx.gi
         N, E, D, K, mean, self_slot = ctx.cfg
+        if d_out is None:                    # (only with the alias: the sums themselves were not used)
+            return d_alias, None, None, None, None, None
         d_out = f32c(d_out, "d_out")
         colptr, dst, eid_t = gi.transpose()
         dx = torch.empty(N, D, dtype=torch.float32, device=d_out.device)
-        check(_lib.load().glam_edge_wsum_bwd(ptr(d_out), ptr(w), ptr(colptr), ptr(dst), ptr(eid_t), ptr(gi.rowptr), N, E, D, K,
-                                             mean, self_slot, ptr(dx), stream()), "glam_edge_wsum_bwd")
-        return dx, None, None, None, None
+        lib = _lib.load()
+        if d_alias is not None and K in (4, 8) and D % 4 == 0:
+            # the skip connection's gradient joins the sums in this launch (no add launch of the autograd engine)
+            d_alias = f32c(d_alias, "d_identity")
+            check(lib.glam_edge_wsum_bwd_add(ptr(d_out), ptr(w), ptr(colptr), ptr(dst), ptr(eid_t), ptr(gi.rowptr), N, E, D, K, mean, self_slot,
+                                             ptr(d_alias), ptr(dx), stream()), "glam_edge_wsum_bwd_add")
+            return dx, None, None, None, None, None
+        check(lib.glam_edge_wsum_bwd(ptr(d_out), ptr(w), ptr(colptr), ptr(dst), ptr(eid_t), ptr(gi.rowptr), N, E, D, K,
+                                     mean, self_slot, ptr(dx), stream()), "glam_edge_wsum_bwd")
+        return (dx if d_alias is None else dx + d_alias), None, None, None, None, None
 
 
-def edge_weighted_sum(x, w, gi, mean=False, self_slot=False):
+def edge_weighted_sum(x, w, gi, mean=False, self_slot=False, with_identity=False):
     """``S[n,k,:] = (1/deg_n) sum_{e->n} w[e,k] * x[src_e,:]`` -> ``[N, K, D]`` (no gradient w.r.t. ``w``: edge data);
-    ``self_slot``: ``[N, K+1, D]`` with ``S[n,K,:] = x[n,:]`` (K in {4, 8}, D % 4 == 0)."""
+    ``self_slot``: ``[N, K+1, D]`` with ``S[n,K,:] = x[n,:]`` (K in {4, 8}, D % 4 == 0).  ``with_identity``: returns ``(S, identity)`` with
+    ``identity`` = ``x`` handed back through this node (a skip connection around the caller then sends its gradient here: it is added
+    inside the backward launch)."""
+    if with_identity:
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _EdgeWeightedSum.apply(x, w, gi, mean, self_slot, True)
+        return _EdgeWeightedSum.apply(x, w, gi, mean, self_slot), x
     return _EdgeWeightedSum.apply(x, w, gi, mean, self_slot)
 
 

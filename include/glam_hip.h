@@ -476,6 +476,11 @@ int glam_edge_wsum_fwd(const float* x, const float* w, const int32_t* rowptr, co
 int glam_edge_wsum_bwd(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst,
                        const int32_t* eid_t, const int32_t* rowptr, int64_t N, int64_t E, int D, int K, int mean,
                        int self_slot, float* dx, void* stream);
+/* ... dx = (the same sums) + addend[N, D] (NULL: none): the gradient of a skip connection around the layer (MessageBlock,
+ * src_1gp/layer.py:253-265) joins here instead of in an add launch of its own.  16-byte form only (K in {4, 8}, D % 4 == 0, aligned). */
+int glam_edge_wsum_bwd_add(const float* d_out, const float* w, const int32_t* colptr, const int32_t* dst, const int32_t* eid_t,
+                           const int32_t* rowptr, int64_t N, int64_t E, int D, int K, int mean, int self_slot, const float* addend,
+                           float* dx, void* stream);
 /* self_slot = 1 (K in {4, 8}, D % 4 == 0): out is f32[N, K+1, D] and slot K of node n is x[n] itself — NNConv's root term
  * x_i @ root (src_1gp/layer.py:119) as one more relation, so that the layer is ONE GEMM [N, (K+1) D] x [(K+1) D, out]. */
 

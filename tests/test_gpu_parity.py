@@ -1196,6 +1196,33 @@ def test_graph_norms_on_protein_sized_graphs(device, kind):
     assert_twin_parity(run, out, _grads(out, cot.to(device), [x]), kind, ["x"])
 
 
+@pytest.mark.parametrize("conv", ["_GCNConv", "_NNConv"])
+def test_block_skip_connection_through_the_conv_node(device, monkeypatch, conv):
+    """MessageBlock around a GCNConv (the protein tower of the two-tower model, src_1gp/layer.py:248-265; no GRU) or an NNConv (the ligand
+    tower; GRU behind it): with ops.SKIP_THROUGH_CONV the block input comes back from the conv's first node (``x @ W``, resp. the relation
+    sums) as the skip connection's operand and its gradient joins that node's own d_x inside its backward launch (glam_ts_gemm_add,
+    glam_edge_wsum_bwd_add) — same outputs bit for bit, same gradients as with the add launch of the autograd engine, also when the
+    block input has a second consumer."""
+    torch.manual_seed(5)
+    b = synth_batch(64, seed=2).to(device)
+    blk = layer.MessageBlock(60, 60, 4, norm="_None", dropout="_None()", conv=conv, act="ReLU()").to(device)
+    x0 = torch.randn(b.x.size(0), 60, device=device)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "SKIP_THROUGH_CONV", flag)
+        x = x0.clone().requires_grad_(True)
+        xin = x * 1.5                                   # (a non-leaf input, as inside the model)
+        y, hh = blk(xin, b.edge_index, b.edge_attr)
+        y2, _ = blk(y, b.edge_index, b.edge_attr, hh if conv == "_NNConv" else None)       # applied twice: the first output feeds the second block AND the loss
+        blk.zero_grad()
+        (y2.square().sum() + y.sum()).backward()
+        res[flag] = (y.detach().clone(), y2.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert_close(res[True][2], res[False][2].double(), 2e-6, "d_x")
+    for u, v in zip(res[True][3], res[False][3]):
+        assert_close(u, v.double(), 2e-6, "parameter gradient")
+
+
 @pytest.mark.parametrize("D", [30, 32, 60])
 def test_gcn_conv_against_oracle(device, D):
     """GCNConv: cached symmetric normalisation + the K = 1 gather-scale-sum kernels (float4 when D % 4 == 0)."""
