@@ -123,7 +123,7 @@ class ArchitectureDTI(torch.nn.Module):
         np_ = getattr(data_pro, "num_graphs", None) or None
         outm = self.mol_flat(self.mol_readout(xm, data_mol.batch, nm))
         outp = self.pro_flat(self.pro_readout(xp, data_pro.batch, np_))
-        out = torch.cat([outm, outp, torch.cat(fusion, dim=-1)], dim=-1)
+        out = ops.cat_cols([outm, outp] + fusion)      # (model.py:74-75; contiguous gradients for every piece from one launch)
         return self.lin_out1(self.lin_out0(out))
 
 
@@ -175,5 +175,5 @@ class ArchitectureDDI(torch.nn.Module):
         n2 = getattr(mol2, "num_graphs", None) or None
         o1 = self.mol1_flat(self.mol1_readout(x1, mol1.batch, n1))
         o2 = self.mol2_flat(self.mol2_readout(x2, mol2.batch, n2))
-        out = torch.cat([o1, o2, torch.cat(fusion, dim=-1)], dim=-1)
+        out = ops.cat_cols([o1, o2] + fusion)
         return self.lin_out1(self.lin_out0(out))

@@ -325,6 +325,46 @@ def _pad_group_launch(src, dst, specs, backward):
                                      backward, stream()), "glam_pad_group")
 
 
+class _CatCols(torch.autograd.Function):
+    """``torch.cat(tensors, dim=1)`` of up to eight [R, C_t] matrices whose backward hands every input a CONTIGUOUS gradient from ONE
+    launch (``glam_pad_group`` in its slicing direction, the column block of tensor t read as a "padded" [1, R, total] tensor that
+    starts at its first column) — autograd's own CatBackward returns strided views, and every consumer that needs rows of C_t floats
+    (the readout linears, the pair pools of the two-tower models: src_2gi_dti_scr/model.py:60-75) then copies its piece with a launch
+    of its own."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ctx.widths = [t.size(1) for t in ts]
+        ctx.set_materialize_grads(False)
+        return torch.cat(ts, dim=1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * len(ctx.widths)
+        g = f32c(g, "d_cat")
+        R, total = g.shape
+        outs = [torch.empty(R, c, dtype=torch.float32, device=g.device) if need else None for c, need in zip(ctx.widths, ctx.needs_input_grad)]
+        src, dst, specs, off = [], [], [], 0
+        for c, o in zip(ctx.widths, outs):
+            if o is not None and R > 0 and c > 0:
+                src.append(g.view(-1)[off:]); dst.append(o); specs.append((1, R, c, R, total))
+            off += c
+        if specs:
+            _pad_group_launch(src, dst, specs, 1)
+        return tuple(outs)
+
+
+def cat_cols(tensors):
+    """``torch.cat(tensors, dim=-1)``; for 2-D fp32 device matrices (at most eight) with contiguous gradients from one launch (_CatCols)."""
+    ts = list(tensors)
+    if (1 < len(ts) <= 8 and all(t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.size(0) == ts[0].size(0) for t in ts)
+            and torch.is_grad_enabled() and any(t.requires_grad for t in ts)):
+        return _CatCols.apply(*ts)
+    return torch.cat(ts, dim=-1)
+
+
 def pad_group(items):
     """``items = [(tensor, (d0, d1, d2), (p1, p2), out_shape), ...]`` (at most 8, one module's parameters): the zero-padded
     re-layouts of all of them from one launch, gradients back through one launch."""

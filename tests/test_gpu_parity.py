@@ -1196,6 +1196,37 @@ def test_graph_norms_on_protein_sized_graphs(device, kind):
     assert_twin_parity(run, out, _grads(out, cot.to(device), [x]), kind, ["x"])
 
 
+def test_cat_cols_hands_back_contiguous_gradients_from_one_launch(device):
+    """ops.cat_cols = torch.cat(dim=-1) (the fusion vector of the two-tower models, src_2gi_dti_scr/model.py:60-75): same value, and in
+    the backward every input receives its column block as a CONTIGUOUS tensor from one glam_pad_group launch (autograd's CatBackward
+    hands out strided views, copied once per consumer)."""
+    from glam_amd._lib import kernel_timer
+    torch.manual_seed(2)
+    widths = (60, 60, 2, 2, 2, 5, 1)
+    ts = [torch.randn(32, c, device=device, requires_grad=(i != 3)) for i, c in enumerate(widths)]
+    out = ops.cat_cols(ts)
+    assert torch.equal(out, torch.cat(ts, dim=-1)) and type(out.grad_fn).__name__.startswith("_CatCols")
+    cot = torch.randn_like(out)
+    seen = {}
+    for i, t in enumerate(ts):
+        if t.requires_grad:
+            t.register_hook(lambda g, i=i: seen.__setitem__(i, (g.is_contiguous(), tuple(g.shape))))
+    with kernel_timer() as kt:
+        out.backward(cot)
+    assert [r[0].split("<")[0] for r in kt.records()] == ["k_pad_group"]
+    off = 0
+    for i, (t, c) in enumerate(zip(ts, widths)):
+        if t.requires_grad:
+            assert torch.equal(t.grad, cot[:, off:off + c]) and seen[i] == (True, (32, c))
+        else:
+            assert t.grad is None
+        off += c
+    # outside its class: plain torch.cat
+    assert ops.cat_cols([torch.randn(3, 2), torch.randn(3, 4)]).shape == (3, 6)
+    with torch.no_grad():
+        assert ops.cat_cols(ts).grad_fn is None
+
+
 @pytest.mark.parametrize("conv", ["_GCNConv", "_NNConv"])
 def test_block_skip_connection_through_the_conv_node(device, monkeypatch, conv):
     """MessageBlock around a GCNConv (the protein tower of the two-tower model, src_1gp/layer.py:248-265; no GRU) or an NNConv (the ligand
