@@ -51,6 +51,8 @@ SIGNATURES = {
     "glam_pair_pool_workspace_bytes": (_sz, [_i64, _i32]),
     "glam_pair_pool_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_pair_pool_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),
+    "glam_pair_pool_add_supported": (_i32, [_i32]),
+    "glam_pair_pool_bwd_add": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "glam_gru_tail_rng_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "glam_gru_tail_rng_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 6),
     "glam_bias_res_act_rng_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

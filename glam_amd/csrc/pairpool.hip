@@ -127,7 +127,10 @@ __global__ void __launch_bounds__(64) k_pair_finish(const float* mol, const int*
 // rows s*16 + k*16*16 + rg of pair i (and, for s == 0, its ligand rows); column sums come from the forward pass.
 __global__ void __launch_bounds__(kBlock) k_pair_pool_bwd_split(const float* mol, const float* pro, const int* mptr,
                                                                const int* pptr, const int* arg, const float* sums,
-                                                               const float* d_out, int D, float* d_mol, float* d_pro) {
+                                                               const float* d_out, int D, float* d_mol, float* d_pro,
+                                                               const float* add_mol, const float* add_pro) {
+    // add_mol / add_pro (may be null): a second gradient path into the two feature matrices (the next message step's, when the
+    // caller took them back from this node), added last — what an add launch of the autograd engine would compute
     const int i = blockIdx.x / kPairSplit, sp = blockIdx.x % kPairSplit, tid = threadIdx.x;
     const int c4 = tid & 15, rg = tid >> 4;
     if (4 * c4 >= D) return;
@@ -144,6 +147,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_pool_bwd_split(const float* mol
             const float4 t = ld4(mol + (size_t)am * D + 4 * c4);
             v.x = fmaf(gmax, t.x, v.x); v.y = fmaf(gmax, t.y, v.y); v.z = fmaf(gmax, t.z, v.z); v.w = fmaf(gmax, t.w, v.w);
         }
+        if (add_pro) { const float4 t = ld4(add_pro + (size_t)b * D + 4 * c4); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
         st4(d_pro + (size_t)b * D + 4 * c4, v);
     }
     if (sp == 0)
@@ -153,6 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_pool_bwd_split(const float* mol
                 const float4 t = ld4(pro + (size_t)ap * D + 4 * c4);
                 v.x = fmaf(gmax, t.x, v.x); v.y = fmaf(gmax, t.y, v.y); v.z = fmaf(gmax, t.z, v.z); v.w = fmaf(gmax, t.w, v.w);
             }
+            if (add_mol) { const float4 t = ld4(add_mol + (size_t)a * D + 4 * c4); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             st4(d_mol + (size_t)a * D + 4 * c4, v);
         }
 }
@@ -519,10 +524,28 @@ extern "C" int glam_pair_pool_bwd(const float* mol, const float* pro, const int3
     GLAM_REQUIRE(mol && pro && mol_ptr && pro_ptr && argmax && sums && d_out && d_mol && d_pro, "glam_pair_pool_bwd: null pointer");
     if (pair_split(D))
         hipLaunchKernelGGL(k_pair_pool_bwd_split, dim3((int)P * kPairSplit), dim3(kBlock), 0, (hipStream_t)stream, mol, pro, mol_ptr,
-                           pro_ptr, argmax, sums, d_out, D, d_mol, d_pro);
+                           pro_ptr, argmax, sums, d_out, D, d_mol, d_pro, (const float*)nullptr, (const float*)nullptr);
     else
         hipLaunchKernelGGL(k_pair_pool_bwd, dim3((int)P), dim3(kBlock), 0, (hipStream_t)stream, mol, pro, mol_ptr, pro_ptr, argmax,
                            d_out, D, d_mol, d_pro);
     GLAM_LAUNCH_CHECK("glam_pair_pool_bwd");
     return GLAM_OK;
 }
+
+// ... d_mol += add_mol, d_pro += add_pro (either may be NULL): the gradient of the NEXT message step's use of the two matrices, when
+// the caller took them back from this node (one add launch per tower and step less).  Only the widths of the split kernel
+// (pair_split(D)); every row must belong to a pair (the segments cover both matrices).
+extern "C" int glam_pair_pool_bwd_add(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
+                                      const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D,
+                                      const float* add_mol, const float* add_pro, float* d_mol, float* d_pro, void* stream) {
+    GLAM_REQUIRE(P >= 0 && P < INT32_MAX / kPairSplit, "glam_pair_pool_bwd_add: P out of range");
+    if (D <= 0 || D > kMaxD || !pair_split(D)) return fail(GLAM_E_UNSUPPORTED, "glam_pair_pool_bwd_add: D=%d outside the split kernel's widths", D);
+    if (P == 0) return GLAM_OK;
+    GLAM_REQUIRE(mol && pro && mol_ptr && pro_ptr && argmax && sums && d_out && d_mol && d_pro, "glam_pair_pool_bwd_add: null pointer");
+    GLAM_REQUIRE(aligned16(add_mol) && aligned16(add_pro), "glam_pair_pool_bwd_add: addends must be 16-byte aligned");
+    hipLaunchKernelGGL(k_pair_pool_bwd_split, dim3((int)P * kPairSplit), dim3(kBlock), 0, (hipStream_t)stream, mol, pro, mol_ptr, pro_ptr,
+                       argmax, sums, d_out, D, d_mol, d_pro, add_mol, add_pro);
+    GLAM_LAUNCH_CHECK("glam_pair_pool_bwd_add");
+    return GLAM_OK;
+}
+extern "C" int glam_pair_pool_add_supported(int D) { return D > 0 && D <= kMaxD && pair_split(D) ? 1 : 0; }

@@ -1054,8 +1054,9 @@ def dot_and_global_pool5(mol_out, pro_out, mol_batch, pro_batch):   # src_1gp/la
     return ops.pair_pool5(ops.pad_cols(mol_out, Cp), ops.pad_cols(pro_out, Cp), msp, psp)
 
 
-def dot_and_global_pool2(mol_out, pro_out, mol_batch, pro_batch):   # src_2gi_dti_scr/layer.py:270-283
-    """[max, mean] of the ligand x residue score matrix of every pair: one HIP launch (no per-pair loop / syncs)."""
+def dot_and_global_pool2(mol_out, pro_out, mol_batch, pro_batch, with_identity=False):   # src_2gi_dti_scr/layer.py:270-283
+    """[max, mean] of the ligand x residue score matrix of every pair: one HIP launch (no per-pair loop / syncs).  ``with_identity``:
+    ``(out, mol_out, pro_out)`` — the two matrices handed back through the fusion node for their next use (see ops.pair_pool)."""
     msp = ops.segment_ptr(mol_batch)
     psp = ops.segment_ptr(pro_batch, msp.B)
-    return ops.pair_pool(mol_out, pro_out, msp, psp)
+    return ops.pair_pool(mol_out, pro_out, msp, psp, with_identity)

@@ -118,7 +118,10 @@ class ArchitectureDTI(torch.nn.Module):
         for _ in range(self.message_steps):
             xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
             xp, hp = self.pro_conv(xp, data_pro.edge_index, data_pro.edge_attr, h=hp, batch=data_pro.batch)
-            fusion.append(dot_and_global_pool2(xm, xp, data_mol.batch, data_pro.batch))
+            # (every step's outputs feed this fusion AND the next step / the readouts: they come back from the fusion node, so that both
+            #  gradients meet inside its backward launch instead of in an add launch per tower)
+            f, xm, xp = dot_and_global_pool2(xm, xp, data_mol.batch, data_pro.batch, with_identity=True)
+            fusion.append(f)
         nm = getattr(data_mol, "num_graphs", None) or None
         np_ = getattr(data_pro, "num_graphs", None) or None
         outm = self.mol_flat(self.mol_readout(xm, data_mol.batch, nm))
@@ -170,7 +173,8 @@ class ArchitectureDDI(torch.nn.Module):
         for _ in range(self.message_steps):
             x1, h1 = self.mol1_conv(x1, mol1.edge_index, mol1.edge_attr, h=h1, batch=mol1.batch)
             x2, h2 = self.mol2_conv(x2, mol2.edge_index, mol2.edge_attr, h=h2, batch=mol2.batch)
-            fusion.append(dot_and_global_pool2(x1, x2, mol1.batch, mol2.batch))
+            f, x1, x2 = dot_and_global_pool2(x1, x2, mol1.batch, mol2.batch, with_identity=True)
+            fusion.append(f)
         n1 = getattr(mol1, "num_graphs", None) or None
         n2 = getattr(mol2, "num_graphs", None) or None
         o1 = self.mol1_flat(self.mol1_readout(x1, mol1.batch, n1))

@@ -445,8 +445,9 @@ _ONEHOT_CACHE: dict = {}
 
 class _PairPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mol, pro, msp, psp):
+    def forward(ctx, mol, pro, msp, psp, with_identity=False):
         require_device(mol, pro)
+        mol_in, pro_in = mol, pro
         mol, pro = f32c(mol, "mol_out"), f32c(pro, "pro_out")
         if msp.B != psp.B or mol.size(1) != pro.size(1) or mol.size(0) != msp.N or pro.size(0) != psp.N:
             raise GlamHipError("pair_pool: the two batches disagree (pair count / width / node count)")
@@ -460,22 +461,44 @@ class _PairPool(torch.autograd.Function):
                                      ws.numel(), stream()), "glam_pair_pool_fwd")
         ctx.save_for_backward(mol, pro, arg, sums)
         ctx.sps = (msp, psp)
+        ctx.aliased = bool(with_identity)
+        if ctx.aliased:      # the two inputs come back as outputs: what the caller does with them next sends its gradient HERE
+            ctx.set_materialize_grads(False)
+            return out, mol_in.view_as(mol_in), pro_in.view_as(pro_in)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, d_ma=None, d_pa=None):
         mol, pro, arg, sums = ctx.saved_tensors
         msp, psp = ctx.sps
+        if d_out is None:                    # (only with the aliases: the fusion values themselves were not used)
+            return d_ma, d_pa, None, None, None
         d_out = f32c(d_out, "d_out")
         d_mol, d_pro = torch.empty_like(mol), torch.empty_like(pro)
-        check(_lib.load().glam_pair_pool_bwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(arg), ptr(sums), ptr(d_out), msp.B,
-                                             mol.size(1), ptr(d_mol), ptr(d_pro), stream()), "glam_pair_pool_bwd")
-        return d_mol, d_pro, None, None
+        lib = _lib.load()
+        if d_ma is not None or d_pa is not None:
+            d_ma = None if d_ma is None else f32c(d_ma, "d_mol (next use)")
+            d_pa = None if d_pa is None else f32c(d_pa, "d_pro (next use)")
+            check(lib.glam_pair_pool_bwd_add(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(arg), ptr(sums), ptr(d_out), msp.B, mol.size(1),
+                                             ptr(d_ma), ptr(d_pa), ptr(d_mol), ptr(d_pro), stream()), "glam_pair_pool_bwd_add")
+        else:
+            check(lib.glam_pair_pool_bwd(ptr(mol), ptr(pro), ptr(msp.ptr), ptr(psp.ptr), ptr(arg), ptr(sums), ptr(d_out), msp.B,
+                                         mol.size(1), ptr(d_mol), ptr(d_pro), stream()), "glam_pair_pool_bwd")
+        return d_mol, d_pro, None, None, None
 
 
-def pair_pool(mol_out, pro_out, msp, psp):
-    """``[max, mean]`` of ``mol[seg_i] @ pro[seg_i].T`` per pair -> ``[P, 2]`` (dot_and_global_pool2)."""
+def pair_pool(mol_out, pro_out, msp, psp, with_identity=False):
+    """``[max, mean]`` of ``mol[seg_i] @ pro[seg_i].T`` per pair -> ``[P, 2]`` (dot_and_global_pool2).  ``with_identity``: returns
+    ``(out, mol_out, pro_out)`` with the two matrices handed back through this node where that saves the add launches of their second
+    use (the next message step): its gradient is then added inside this node's backward launch."""
+    if with_identity:
+        D = mol_out.size(1)
+        if (torch.is_grad_enabled() and mol_out.requires_grad and pro_out.requires_grad and mol_out.is_cuda
+                and mol_out.dtype == torch.float32 and pro_out.dtype == torch.float32 and mol_out.size(1) == pro_out.size(1)
+                and _lib.load().glam_pair_pool_add_supported(D) == 1):
+            return _PairPool.apply(mol_out, pro_out, msp, psp, True)
+        return _PairPool.apply(mol_out, pro_out, msp, psp), mol_out, pro_out
     return _PairPool.apply(mol_out, pro_out, msp, psp)
 
 

@@ -496,6 +496,13 @@ int glam_pair_pool_fwd(const float* mol, const float* pro, const int32_t* mol_pt
 int glam_pair_pool_bwd(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr,
                        const int32_t* argmax, const float* sums, const float* d_out, int64_t P, int D, float* d_mol,
                        float* d_pro, void* stream);
+/* ... d_mol += add_mol, d_pro += add_pro (either may be NULL): the gradient of the next message step's use of the two feature
+ * matrices (src_2gi_dti_scr/model.py:66-70: every step's outputs feed this fusion AND the next step), when the caller took them
+ * back from this node — one add launch per tower and step less.  glam_pair_pool_add_supported(D): the widths that have it. */
+int glam_pair_pool_add_supported(int D);
+int glam_pair_pool_bwd_add(const float* mol, const float* pro, const int32_t* mol_ptr, const int32_t* pro_ptr, const int32_t* argmax,
+                           const float* sums, const float* d_out, int64_t P, int D, const float* add_mol, const float* add_pro,
+                           float* d_mol, float* d_pro, void* stream);
 
 /* Training-mode block tails of the reference's DEFAULT configuration (src_1gp/model.py:30-31, run.py:35-37: RReLU activations,
  * Dropout(0.2) in front of every conv) — the same launches as glam_gru_tail_* / glam_bias_res_act_* with two additions:

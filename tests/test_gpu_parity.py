@@ -1166,6 +1166,42 @@ def test_pair_pool_protein_sized_segments(device):
     assert_twin_parity(run, out, _grads(out, cot.to(device), [m, p]), "pair pool", ["mol", "pro"])
 
 
+def test_pair_pool_hands_its_operands_on_with_their_next_gradient_added_inside(device):
+    """dot_and_global_pool2(..., with_identity=True) (src_2gi_dti_scr/model.py:66-70: every step's node features feed the fusion AND
+    the next message step): the two matrices come back from the fusion node, and the gradient of what the caller does with them next
+    is added inside the node's backward launch (glam_pair_pool_bwd_add) — same values, same gradients as the plain call followed by an
+    add launch of the autograd engine."""
+    from glam_amd._lib import kernel_timer
+    torch.manual_seed(4)
+    nm, npr, D = [20, 13, 28], [410, 97, 655], 60
+    mb = torch.repeat_interleave(torch.arange(3), torch.tensor(nm)).to(device)
+    pb = torch.repeat_interleave(torch.arange(3), torch.tensor(npr)).to(device)
+    mol, pro = torch.randn(sum(nm), D, device=device), torch.randn(sum(npr), D, device=device)
+    wm, wp, cot = torch.randn(sum(nm), D, device=device), torch.randn(sum(npr), D, device=device), torch.randn(3, 2, device=device)
+    res = []
+    for alias in (True, False):
+        m, p = mol.clone().requires_grad_(True), pro.clone().requires_grad_(True)
+        mi, pi = m * 1.0, p * 1.0
+        if alias:
+            out, m2, p2 = layer.dot_and_global_pool2(mi, pi, mb, pb, with_identity=True)
+            assert m2.data_ptr() == mi.data_ptr() and p2.data_ptr() == pi.data_ptr()
+        else:
+            out, m2, p2 = layer.dot_and_global_pool2(mi, pi, mb, pb), mi, pi
+        loss = (out * cot).sum() + (m2 * wm).sum() + (p2.square() * wp).sum()
+        with kernel_timer() as kt:
+            gm, gp = torch.autograd.grad(loss, (m, p))
+        res.append((out.detach(), gm, gp, [r[0] for r in kt.records()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert sum("k_pair_pool_bwd" in n for n in res[0][3]) == 1
+    # only one of the two used again / none: still the same
+    m, p = mol.clone().requires_grad_(True), pro.clone().requires_grad_(True)
+    out, m2, p2 = layer.dot_and_global_pool2(m * 1.0, p * 1.0, mb, pb, with_identity=True)
+    gm, gp = torch.autograd.grad((out * cot).sum() + (m2 * wm).sum(), (m, p))
+    assert torch.equal(gm, res[1][1]) and not torch.isnan(gp).any()
+    lib = ops._lib.load()
+    assert lib.glam_pair_pool_add_supported(60) == 1 and lib.glam_pair_pool_add_supported(62) == 0
+
+
 @pytest.mark.parametrize("kind", ["pair", "layer"])
 def test_graph_norms_on_protein_sized_graphs(device, kind):
     """N / B >= 64 routes PairNorm / graph LayerNorm to the block-per-graph kernels."""
