@@ -535,6 +535,8 @@ def _dense_ws(dev):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ws = _DENSE_WS.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None      # (born inside a capture it would live in that graph's private pool and outlive it here: this launch goes unsplit)
         ws = _DENSE_WS[key] = torch.empty(_lib.load().glam_dense_ws_bytes(), dtype=torch.uint8, device=dev)
     return ws
 
