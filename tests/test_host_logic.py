@@ -441,6 +441,10 @@ def test_launch_saving_hints_are_host_logic():
     assert layer.prestage_pass((lin, mb, x, ea)) == 0                 # CPU tensors: nothing to stage, nothing launched
     trip, images, pres = layer._prestage_items(lin, mb, x.to("meta") if False else x, ea)
     assert trip is None and images == [] and pres == []
-    assert ops.prestage(None, []) == 0
+    assert ops.prestage(None, []) == 0 and ops.prestage(None, [], [(torch.zeros(180, 60), torch.zeros(180, 60), 60)]) == 0      # no scope: nothing built
+    # ops.cat_cols outside its class (CPU tensors, no gradient wanted, more than eight pieces) is torch.cat
+    a, b = torch.randn(3, 2, requires_grad=True), torch.randn(3, 4)
+    assert torch.equal(ops.cat_cols([a, b]), torch.cat([a, b], dim=-1)) and not type(ops.cat_cols([a, b]).grad_fn).__name__.startswith("_CatCols")
+    assert ops.cat_cols([torch.zeros(2, 1)] * 9).shape == (2, 9)
     assert ops.GRU_WGRAD_BATCH in (True, False) and ops.PRESTAGE in (True, False) and ops.NORM_DROP in (True, False) and ops.DENSE_LINEAR in (True, False)
 
