@@ -18,6 +18,7 @@ struct TsArgs {
     int a_celu;                            // 1: the GEMM consumes celu(A) instead of A
     const float* cgrad_src; int ld_cgrad;  // non-null: out1[r, c] *= celu'(cgrad_src[r, c]) (chain rule through a folded CELU)
     const float* addend; int ld_add;       // non-null: out1[r, c] += addend[r, c] last (a second gradient path into the same tensor)
+    int out_relu;                          // 1: out = max(out, 0) — the ReLU of a LinearBlock (src_1gp/layer.py:236) in the epilogue (k_tall_x3 only)
 };
 
 // distance between the 64 x 64 partial slabs of k_wgrad (4096 floats of data each): 16 KB + 256 B, so that the splits of one element —

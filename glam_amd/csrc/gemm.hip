@@ -826,6 +826,7 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     const int grid = grid_a + grid_b;
     // the long-reduction shapes on the bf16 matrix cores (tall_x3.hip); GLAM_X3=0 keeps the fp32 matrix instructions where they exist
     if (variant >= 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
+    if (a.out_relu || (b && b->out_relu)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: the ReLU epilogue exists in k_tall_x3 only (glam_ts_gemm_relu_supported)");
     if (variant == 2 && ts_x3_enabled() && tall_x3_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
         return launch_tall_x3(a, b, variant, s);
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
@@ -1054,6 +1055,24 @@ extern "C" int glam_ts_gemm(const float* A1, int K1, int lda1, const float* A2, 
     GLAM_REQUIRE(aligned16(A1) && aligned16(A2) && aligned16(Wimg) && aligned16(out1) && aligned16(out2) && aligned16(bias),
                  "glam_ts_gemm: pointers must be 16-byte aligned");
     TsArgs a{A1, K1, lda1, A2, K2, lda2, Wimg, bias, out1, M1, ldo1, out2, M2, ldo2, (int)N};
+    return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
+// out = max(A @ W + bias, 0): the linear + ReLU of a LinearBlock whose shape runs on k_tall_x3 (the input embeddings 15 -> 60 ...)
+extern "C" int glam_ts_gemm_relu_supported(int K, int M) {
+    if (K <= 0 || M <= 0 || (K & 3) || (M & 3)) return 0;
+    const int v = ts_variant(K, M);        // (< 0: outside the kernel table)
+    return (v >= 3 || (v == 0 && ts_x3_enabled() && tall_x3_enabled())) ? 1 : 0;
+}
+extern "C" int glam_ts_gemm_relu(const float* A, int K, int lda, const float* Wimg, const float* bias, float* out, int M, int ldo, int64_t N,
+                                 void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_ts_gemm_relu: N out of range");
+    if (!glam_ts_gemm_relu_supported(K, M)) return fail(GLAM_E_UNSUPPORTED, "glam_ts_gemm_relu: K=%d M=%d does not run on k_tall_x3", K, M);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(A && Wimg && out, "glam_ts_gemm_relu: null pointer");
+    GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias), "glam_ts_gemm_relu: pointers must be 16-byte aligned");
+    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N};
+    a.out_relu = 1;
     return launch_ts_gemm(a, (hipStream_t)stream);
 }
 

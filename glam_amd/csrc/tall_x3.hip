@@ -240,6 +240,7 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
                 float4 v = make_float4(acc[j][0] + bj.x, acc[j][1] + bj.y, acc[j][2] + bj.z, acc[j][3] + bj.w);
                 if (use_cg) { v.x *= celu1_grad(cg.x); v.y *= celu1_grad(cg.y); v.z *= celu1_grad(cg.z); v.w *= celu1_grad(cg.w); }
                 if (use_ad) { v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
+                if (a.out_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (col < a.M1) st4(a.out1 + (size_t)row * a.ldo1 + col, v);
                 else st4(a.out2 + (size_t)row * a.ldo2 + (col - a.M1), v);
             }

@@ -928,6 +928,10 @@ class LinearBlock(torch.nn.Module):
                                getattr(a, "negative_slope", 0.0))
             if y is not None:
                 return y
+            if type(a) is ReLU:                            # ... or the tall product's (the input embeddings)
+                y = ops.linear_relu(x, self.linear.weight, self.linear.bias)
+                if y is not None:
+                    return y
         x = ops.linear(x, self.linear.weight, self.linear.bias)
         return _apply_act(self.act, x, next_dropout)
 

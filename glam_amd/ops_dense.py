@@ -32,7 +32,9 @@ class _Linear(torch.autograd.Function):
     ``x`` that needs no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, relu=False):
+        """``relu``: ``max(y, 0)`` in the product's epilogue (glam_ts_gemm_relu; the caller checked glam_ts_gemm_relu_supported); the
+        backward masks ``dy`` by the saved output first."""
         require_device(x, w, b)
         x, w = f32c(x, "x"), f32c(w, "weight")
         b = None if b is None else f32c(b, "bias")
@@ -50,8 +52,12 @@ class _Linear(torch.autograd.Function):
 
         img = _o._scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
         y = torch.empty(N, M, dtype=torch.float32, device=dev)
-        check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
-        ctx.save_for_backward(x, w)
+        if relu:
+            check(lib.glam_ts_gemm_relu(ptr(x), K, K, ptr(img), ptr(b), ptr(y), M, M, N, stream()), "glam_ts_gemm_relu")
+            ctx.save_for_backward(x, w, y)
+        else:
+            check(lib.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y), M, M, None, 0, 0, N, stream()), "glam_ts_gemm")
+            ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.scope = scope
         return y
@@ -59,8 +65,10 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[:2]
         dy = f32c(dy, "dy")
+        if len(ctx.saved_tensors) == 3:      # the fused ReLU: dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[2], 0.0)
         N, K = x.shape
         M = w.size(0)
         lib, dev = _lib.load(), x.device
@@ -84,7 +92,7 @@ class _Linear(torch.autograd.Function):
             dw, db = torch.empty(M, Kw, **f), torch.empty(M, **f)
             check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
                   "glam_wgrad_gemm_split")
-            return dx, dw, (db if ctx.has_bias else None)
+            return dx, dw, (db if ctx.has_bias else None), None
         dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
         if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]
             check(lib.glam_wgrad_gemm(ptr(x), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), 1, K + 1, ptr(ws), ws.numel(),
@@ -94,7 +102,7 @@ class _Linear(torch.autograd.Function):
                                       stream()), "glam_wgrad_gemm")
         dw = dwb[:M, :w.size(1)]
         db = dwb[:M, K] if ctx.has_bias else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class _RelationMLP(torch.autograd.Function):
@@ -635,6 +643,22 @@ def linear(x, weight, bias=None):
         weight, bias = _o.scoped_weights(("lin-pad", id(w0), None if b0 is None else id(b0)), w0, build_padded)
     y = _Linear.apply(x, weight, bias)
     return _o.slice_cols(y, M)                    # pad columns are x @ 0 + 0
+
+
+def linear_relu(x, weight, bias=None):
+    """``relu(F.linear(x, weight, bias))`` with the ReLU in the epilogue of the product where its shape runs on ``k_tall_x3`` (the input
+    embeddings of the models: 15 -> 60 ...); ``None`` elsewhere (the caller applies ``linear`` and the activation)."""
+    M, K = weight.shape
+    Kp = (K + 3) // 4 * 4
+    f32 = x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+    if not (x.dim() == 2 and x.is_cuda and f32 and M % 4 == 0 and linear_supported(K, M) and not _dense_route(x, weight, bias)
+            and _lib.load().glam_ts_gemm_relu_supported(Kp, M) == 1):
+        return None
+    if Kp != K:
+        if x.requires_grad and torch.is_grad_enabled():
+            return None                      # (a padded differentiable input takes the padded-weight route of ``linear``)
+        x = _o.pad_cols(x, Kp)
+    return _Linear.apply(x, weight, bias, True)
 
 
 class _LinearSplit(torch.autograd.Function):

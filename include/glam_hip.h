@@ -259,6 +259,14 @@ int glam_wgrad_gemm_linear_sets(int nseg, const float* const* P, int I, int ldp,
  * multiple of 4 when ldq >= ceil4(J) (a weight narrower than its zero-padded input: dw stays contiguous [I, J]). */
 int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N, void* ws,
                           size_t ws_bytes, void* stream);
+/* out[N, M] = max(A[N, K] @ W + bias, 0): the Linear + ReLU of a LinearBlock (src_1gp/layer.py:232-237) whose shape runs on the
+ * warp-specialised tall kernel (glam_ts_gemm_relu_supported(K, M): the input embeddings 15 -> 60 of the parity configuration and of the
+ * two-tower models) — the activation in the product's epilogue instead of an elementwise launch behind it.  Wimg, alignment and
+ * leading dimensions as glam_ts_gemm. */
+int glam_ts_gemm_relu_supported(int K, int M);
+int glam_ts_gemm_relu(const float* A, int K, int lda, const float* Wimg, const float* bias, float* out, int M, int ldo, int64_t N,
+                      void* stream);
+
 /* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:
  * a_celu = 1: out = celu(A) @ W + bias; cgrad_src non-NULL: out[r,c] *= celu'(cgrad_src[r,c]) (the chain rule of the same
  * fold on the way back); qcelu_* in glam_wgrad_gemm_pair: the weight gradient uses celu(Q). */

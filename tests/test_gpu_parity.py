@@ -3069,6 +3069,32 @@ def test_linear_dense_k_split_across_blocks(device, N, K, M, act):
     assert lib.glam_linear_dense_fwd_ws(p(x), p(w), p(b), N, K, M, act, slope, p(got[0]), ws.data_ptr() + 4, nb, st()) == ops._lib.GLAM_E_INVALID
 
 
+@pytest.mark.parametrize("N,K,M,diff_x", [(20400, 15, 60, False), (606, 15, 60, False), (777, 60, 60, True), (64, 32, 44, True), (5, 15, 60, False)])
+def test_linear_block_relu_in_the_tall_products_epilogue(device, N, K, M, diff_x):
+    """LinearBlock(K, M, act=ReLU) where the product runs on k_tall_x3 (the input embedding of the models, src_1gp/model.py:40 /
+    layer.py:232-237): glam_ts_gemm_relu applies the activation in the epilogue — the same values as linear + relu, bit for bit, and
+    the same gradients (the backward masks dy by the saved output)."""
+    torch.manual_seed(N + K)
+    blk = layer.LinearBlock(K, M, act="ReLU()").to(device)
+    x = torch.randn(N, K, device=device, requires_grad=diff_x)
+    y = blk(x)
+    lin = ops.linear(x, blk.linear.weight, blk.linear.bias)
+    ref = torch.relu(lin)
+    fused = type(y.grad_fn).__name__.startswith("_Linear") and not type(y.grad_fn).__name__.startswith("_LinearDense")
+    assert fused == bool(ops._lib.load().glam_ts_gemm_relu_supported((K + 3) // 4 * 4, M)) or (K % 4 and diff_x)
+    assert torch.equal(y, ref)
+    cot = torch.randn_like(y)
+    wrt = [blk.linear.weight, blk.linear.bias] + ([x] if diff_x else [])
+    g1 = torch.autograd.grad(y, wrt, cot)
+    g0 = torch.autograd.grad(ref, wrt, cot)
+    for u, v in zip(g1, g0):
+        assert torch.equal(u, v)
+    xd, wd, bd = x.detach().double(), blk.linear.weight.detach().double(), blk.linear.bias.detach().double()
+    assert_close(y, torch.relu(torch.nn.functional.linear(xd, wd, bd)), 2e-6, "linear + relu")
+    lib = ops._lib.load()
+    assert lib.glam_ts_gemm_relu_supported(300, 1024) == 0 and lib.glam_ts_gemm_relu_supported(15, 60) == 0
+
+
 def test_linear_block_routes_the_readout_mlp_to_the_dense_kernel(device):
     """LinearBlock(300, 1024, act=ReLU) — `mol_flat` of the parity configuration — runs as one dense launch each way and agrees with
     the unfused composition; shapes outside the class (K = 450: rows not 16-byte multiples) keep the library route."""
