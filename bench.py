@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def step_kernel_model(N, E, H=3, C=60, De=4, x3=True):
+def step_kernel_model(N, E, H=3, C=60, De=4):
     """Algorithmic (compulsory) HBM bytes and dense flops per launch of every kernel of the step: fp32 + int32 CSR, every
     tensor once.  Keys are the labels glam_prof_* reports."""
     HC, f = H * C, 4
@@ -519,9 +519,7 @@ def main():
     if rank == 0:
         # ---- roofline: per-dispatch durations of the kernels the timed step launches (same process, same stream, the function
         #      the graph captured, issued eagerly so that every launch can carry its own begin / end events) ----
-        from glam_amd import _lib as _glib
-        x3_on = _glib.route_enabled("x3")
-        model = step_kernel_model(N, E, H, C, De, x3=x3_on)
+        model = step_kernel_model(N, E, H, C, De)
         prof = profile_step(compute, args.prof_reps)
         kernels = {}
         for name, rec in sorted(prof.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
@@ -572,7 +570,7 @@ def main():
                     out = conv(xb, big.edge_index, big.edge_attr)
                     live["big"] = torch.autograd.grad(out, params + [xb], grad_outputs=cb)
 
-            mb = step_kernel_model(Nb, Eb, H, C, De, x3=x3_on)
+            mb = step_kernel_model(Nb, Eb, H, C, De)
             # 40 untimed steps (~30 ms) first: the device idled while the batch was synthesised on the host, and its clocks take longer than
             # three steps to come back (the same kernels read 20 % slower with warm = 3 than in a dedicated --batch 16384 run)
             pb = profile_step(compute_big, max(5, args.prof_reps // 3), warm=40)

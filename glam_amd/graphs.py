@@ -214,13 +214,14 @@ def no_graphed_call():
 # module-level A/B switches of glam_amd.ops and the library's environment switches: a captured graph bakes the route in, so they are part
 # of a graph's key (flipping one between two calls of a model — the parity tests do — must not replay the other route)
 _OPS_KNOBS = ("VALIDATE", "WS_ROUTE", "GRAD_CARRY", "CACHED_STAGING", "USE_TORCH_EXT", "GEMM_PAIR", "GRU_FUSED", "GRU_FUSED_MIN_NODES", "GRU_WS",
-              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR")
+              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "GRU_PRE", "DENSE_SPLITK", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR")
 _ENV_KNOBS = ("GLAM_X3", "GLAM_WS", "GLAM_WGRAD_X3", "GLAM_WGRAD_X3_ROWS", "GLAM_TALL_X3", "GLAM_WS_GRID")
 
 
 def _route_signature():
     from . import ops
-    return tuple(getattr(ops, k, None) for k in _OPS_KNOBS) + tuple(os.environ.get(k) for k in _ENV_KNOBS)
+    return (tuple(getattr(ops, k, None) for k in _OPS_KNOBS) + (ops.GraphIndex.ELL_MIN_NODES,)
+            + tuple(os.environ.get(k) for k in _ENV_KNOBS))
 
 
 class _Replay(torch.autograd.Function):
@@ -231,12 +232,21 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, st, *params):
         ctx.st = st
+        st.gen += 1                                  # this replay owns the state's static activations until its backward has run
+        ctx.gen = st.gen
+        st.pending = weakref.ref(ctx)
         st.fwd.replay()
         return st.out.detach().clone()               # (static outputs stay private: a caller may keep the result across steps)
 
     @staticmethod
     def backward(ctx, g):
         st = ctx.st
+        if ctx.gen != st.gen:
+            # (the route itself never gets here: a call that finds an earlier output of this state still waiting for its backward runs
+            # eagerly — GraphedCallable.__call__; this guards a state whose graphs were replayed behind the route's back)
+            raise RuntimeError("glam_amd.graphs: the captured activations of this output were overwritten by a later forward of the same "
+                               "batch before its backward ran; set model.graphed_call = False for this pattern")
+        st.pending = None
         # A gradient buffer of this graph that autograd took over as p.grad in an earlier backward (p.grad was None then) and that is
         # still p.grad now — zero_grad(set_to_none=False), or a second backward before the optimizer step — would be overwritten by the
         # replay below and then added to itself: such a p.grad gets a private copy first.  (zero_grad()'s default, set_to_none=True,
@@ -250,11 +260,11 @@ class _Replay(torch.autograd.Function):
 
 
 class _CallState:
-    __slots__ = ("static", "visits", "fwd", "bwd", "out", "gout", "params", "grads", "x_sig")
+    __slots__ = ("static", "visits", "fwd", "bwd", "out", "gout", "params", "grads", "x_sig", "gen", "pending")
 
     def __init__(self, static):
-        self.static, self.visits = static, 0
-        self.fwd = self.bwd = self.out = self.gout = self.params = self.grads = self.x_sig = None
+        self.static, self.visits, self.gen = static, 0, 0
+        self.fwd = self.bwd = self.out = self.gout = self.params = self.grads = self.x_sig = self.pending = None
 
 
 class GraphedCallable:
@@ -275,17 +285,24 @@ class GraphedCallable:
 
     Per-graph memory pools (a forward's saved activations must survive until its backward whatever else runs in between).  The route
     stays eager — silently, it is an optimisation — for CPU tensors, inside someone else's stream capture, when ``batch.x`` requires a
-    gradient, for empty batches, when the model has forward hooks, beyond ``max_graphs`` contents or when less than a quarter of the
-    device memory is free.  ``model.graphed_call = False`` or ``GLAM_GRAPHED_CALL=0`` switch it off."""
+    gradient, for empty batches, when the model has forward hooks, beyond ``max_graphs`` contents, when less than a quarter of the
+    device memory is free, and for a content whose previous output is still alive and has not been back-propagated yet (two forwards
+    of one batch before the first backward — a consistency loss, say: a graph has ONE set of static activations, so the second
+    forward runs eagerly and both backwards are right).  ``model.graphed_call = False`` or ``GLAM_GRAPHED_CALL=0`` switch it off.
+
+    Captured graphs bake the parameters' ADDRESSES and the trainable set in.  They are dropped, and captured again on later visits,
+    whenever a parameter object was replaced, a parameter's storage moved (``module.to()`` / ``.cpu()`` / ``.cuda()`` / ``.double()`` /
+    ``.float()`` keep the ``Parameter`` objects and swap their ``.data``) or a ``requires_grad`` flag changed (freeze / unfreeze)."""
 
     def __init__(self, max_graphs=4096):
         self.max_graphs = max_graphs
         self._states = {}          # key -> _CallState
         self._by_obj = {}          # id(batch) -> (weakref, tensor signature, key): the same tensors again need no fingerprint
         self._fp = None
-        self._param_ids = None
+        self._param_key = None     # (id, requires_grad) of every parameter the captures were made with
+        self._all = None           # every parameter, in module order
         self._params = self._first = None
-        self._frozen = ()
+        self._probe = None         # (data_ptr, requires_grad) of every parameter at the last call
 
     def __deepcopy__(self, memo):
         return GraphedCallable(self.max_graphs)      # graphs and static tensors belong to the original module's parameters
@@ -353,18 +370,22 @@ class GraphedCallable:
                   and ei.is_contiguous() and ea.is_contiguous() and bv.is_contiguous() and x.is_contiguous())
         if not ok:
             return eager_forward(*datas)
-        # the trainable parameters, re-walked only when the cheap probe fails (walking the module tree costs ~25 us per call): the first
-        # parameter object and every cached one's requires_grad — module.to() / .half() / load into new tensors replace them all
+        # The captures bake the parameters' addresses and the trainable set in.  Probe per call, without walking the module tree (~25 us):
+        # the first parameter object (a model re-built or loaded into new Parameters), and of every cached parameter its storage address
+        # and requires_grad — module.to() / .cpu() / .cuda() / .double() / .float() keep the Parameter OBJECTS and swap their .data, a
+        # fine-tuning schedule flips requires_grad on the same objects.  Any difference: walk again, and drop every graph unless the walk
+        # finds the very same (object, requires_grad, address) set.
         params = self._params
-        if (params is None or next(module.parameters(), None) is not self._first or not all(p.requires_grad for p in params)
-                or any(p.requires_grad for p in self._frozen)):
-            params = self._params = tuple(p for p in module.parameters() if p.requires_grad)
-            self._frozen = tuple(p for p in module.parameters() if not p.requires_grad)
-            self._first = next(module.parameters(), None)
-            pids = tuple(id(p) for p in module.parameters())
-            if pids != self._param_ids:              # parameters replaced / frozen since the captures: they bake addresses in
+        probe = None if self._all is None else tuple((p.data_ptr(), p.requires_grad) for p in self._all)
+        if params is None or next(module.parameters(), None) is not self._first or probe != self._probe:
+            self._all = tuple(module.parameters())
+            self._first = self._all[0] if self._all else None
+            params = self._params = tuple(p for p in self._all if p.requires_grad)
+            self._probe = tuple((p.data_ptr(), p.requires_grad) for p in self._all)
+            pkey = tuple((id(p), p.requires_grad, p.data_ptr(), p.dtype, p.device) for p in self._all)
+            if pkey != self._param_key:
                 self.clear()
-                self._param_ids = pids
+                self._param_key = pkey
         key = self._key(module, datas, tuple(t for _x, ei, ea, bv in fields for t in (ei, bv, ea)))
         st = self._states.get(key)
         if st is None:
@@ -403,6 +424,11 @@ class GraphedCallable:
         if st.bwd is None:
             st.fwd.replay()
             return st.out.detach().clone()
+        if st.pending is not None and st.pending() is not None:
+            # an earlier output of this content is alive and has not been back-propagated: its backward needs the static activations a
+            # replay would overwrite — this forward runs eagerly on the caller's batch (its own activations, its own autograd graph)
+            with no_graphed_call():
+                return eager_forward(*datas)
         return _Replay.apply(st, *st.params)
 
     def _capture(self, st, module, eager_forward, params):

@@ -185,3 +185,115 @@ def test_two_input_models_take_the_route_too(device):
     assert np.allclose(l_e, l_g, rtol=2e-5, atol=1e-6), (l_e, l_g)
     for a, r in zip(p_g, p_e):
         assert_close(a, r, 2e-5, "parameter")
+
+
+def _train_steps(net, opt, b, n):
+    losses = []
+    for _ in range(n):
+        opt.zero_grad()
+        loss = _loss(net(_fresh(b)), b)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    return losses
+
+
+@pytest.mark.parametrize("trip", ["cpu_cuda", "double_float"])
+def test_moved_parameter_storage_drops_the_captures(device, trip):
+    """``model.cpu(); model.cuda()`` / ``model.double(); model.float()`` keep the Parameter OBJECTS and swap their storage (the
+    ``best = copy.deepcopy(model.cpu()); model.cuda()`` idiom of a checkpointing trainer): graphs captured before the round trip read the
+    old addresses and must be dropped — the routed trajectory stays the eager one to the bit, and the weights the graphs read are the
+    ones the optimizer writes."""
+    torch.manual_seed(12)
+    net0 = _net(device)
+    b = synth_batch(9, seed=31).to(device)
+    results = []
+    for routed in (False, True):
+        net = copy.deepcopy(net0)
+        net.graphed_call = routed
+        opt = torch.optim.SGD(net.parameters(), lr=1e-2)     # (no per-parameter state tied to the old storage)
+        losses = _train_steps(net, opt, b, 5)
+        if routed:
+            assert net.__dict__["_glam_graphed_route"].graphs() == 2
+        ptr = next(net.parameters()).data_ptr()
+        ident = [id(p) for p in net.parameters()]
+        if trip == "cpu_cuda":
+            net.cpu()
+            net.to(device)
+        else:
+            net.double()
+            net.float()
+        assert [id(p) for p in net.parameters()] == ident and next(net.parameters()).data_ptr() != ptr, "the premise: same objects, new storage"
+        losses += _train_steps(net, opt, b, 5)
+        if routed:
+            assert net.__dict__["_glam_graphed_route"].graphs() == 2, "captured again on the new storage"
+        with torch.no_grad():
+            losses.append(_loss(net(_fresh(b)), b).item())
+        results.append((losses, [p.detach().clone() for p in net.parameters()]))
+    (l_e, p_e), (l_g, p_g) = results
+    assert l_e == l_g, (l_e, l_g)
+    assert l_e[5] != l_e[4], "training went on after the round trip"
+    for a, r in zip(p_g, p_e):
+        assert torch.equal(a, r)
+
+
+def test_freeze_then_unfreeze_after_capture(device):
+    """A fine-tuning schedule: the message-passing blocks frozen for the first epochs, unfrozen later — on the same Parameter objects,
+    after graphs were captured with the smaller trainable set.  The newly trainable parameters must receive gradients (eager's, to the
+    bit) on already-captured batches."""
+    torch.manual_seed(13)
+    net0 = _net(device)
+    b = synth_batch(9, seed=33).to(device)
+    results = []
+    for routed in (False, True):
+        net = copy.deepcopy(net0)
+        net.graphed_call = routed
+        backbone = [p for n, p in net.named_parameters() if n.startswith("mol_conv")]
+        assert backbone
+        for p in backbone:
+            p.requires_grad_(False)
+        grads = []
+        for phase in range(3):                       # frozen, unfrozen, frozen again
+            for p in backbone:
+                p.requires_grad_(phase == 1)
+            for _ in range(4):
+                net.zero_grad(set_to_none=True)
+                _loss(net(_fresh(b)), b).backward()
+            grads.append([None if p.grad is None else p.grad.clone() for p in net.parameters()])
+            if routed:
+                assert net.__dict__["_glam_graphed_route"].graphs() == 2, phase
+        results.append(grads)
+    for ge, gg in zip(*results):
+        for a, r in zip(gg, ge):
+            assert (a is None) == (r is None)
+            assert a is None or torch.equal(a, r)
+    assert all(g is not None for g in results[1][1]) and any(g is None for g in results[1][0]) and any(g is None for g in results[1][2])
+
+
+def test_two_forwards_of_one_batch_before_the_first_backward(device):
+    """A consistency loss: the same graph structure with two feature tensors, both outputs back-propagated afterwards.  A captured graph
+    has ONE set of static activations — the second forward must not overwrite what the first output's backward needs."""
+    torch.manual_seed(14)
+    net = _net(device)
+    ref = copy.deepcopy(net)
+    ref.graphed_call = False
+    b = synth_batch(9, seed=35).to(device)
+    b2 = _fresh(b)
+    b2.x = torch.randn_like(b.x)
+    for _ in range(4):                               # (captured from the third visit)
+        net.zero_grad(set_to_none=True)
+        _loss(net(_fresh(b)), b).backward()
+    assert net.__dict__["_glam_graphed_route"].graphs() == 2
+    for m in (net, ref):
+        m.zero_grad(set_to_none=True)
+        o1 = m(_fresh(b))
+        o2 = m(_fresh(b2))                           # same content key, o1's backward still pending
+        (_loss(o1, b) + 0.5 * _loss(o2, b) + (o1 - o2).pow(2).mean()).backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(p.grad, q.grad)
+    # ... and the route is back on replays once nothing is pending
+    st = next(iter(net.__dict__["_glam_graphed_route"]._states.values()))
+    gen = st.gen
+    net.zero_grad(set_to_none=True)
+    _loss(net(_fresh(b)), b).backward()
+    assert st.gen == gen + 1

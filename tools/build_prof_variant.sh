@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an instrumented copy of libglam_hip.so for the in-kernel cycle profilers of tools/*_prof.py.
-# usage: tools/build_prof_variant.sh {b1|b1n|ts|dma|gru|fwd|pg|ws|tl}   ->  glam_amd/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
+# usage: tools/build_prof_variant.sh {b1|b1n|ts|dma|gru|fwd|pg|ws|tl}   ->  tools/tmp/variants/lib_<name>prof.so  (use via GLAM_HIP_LIB=...)
 set -e
 cd "$(dirname "$0")/../glam_amd/csrc"
 make -j8 > /dev/null
@@ -16,12 +16,12 @@ case "$1" in
   tl)   src="triplet_ws.hip triplet_ws_b1.hip block.hip"; def=GLAM_WS_TL ;;   # timeline stamps of the three warp-specialised kernels (tools/ws_timeline.py)
   *) echo "usage: $0 {b1|b1n|ts|dma|gru|fwd|pg|ws|tl}"; exit 2 ;;
 esac
-mkdir -p ../variants
+mkdir -p ../../tools/tmp/variants
 objs=""; keep=$(ls build/*.o)
 for f in $src; do
   obj=/tmp/glam_${1}_prof_${f%.hip}.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -D$def -c $f -o $obj
   objs="$objs $obj"; keep=$(echo "$keep" | grep -v "build/${f%.hip}.o")
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/lib_${1}prof.so $keep $objs
-echo "glam_amd/variants/lib_${1}prof.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/tmp/variants/lib_${1}prof.so $keep $objs
+echo "tools/tmp/variants/lib_${1}prof.so"

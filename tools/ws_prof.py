@@ -1,5 +1,5 @@
 """Developer aid: where the producer / consumer waves of k_triplet_fwd_ws spend their cycles (library built with
-tools/build_prof_variant.sh ws, run with GLAM_HIP_LIB=glam_amd/variants/lib_wsprof.so)."""
+tools/build_prof_variant.sh ws, run with GLAM_HIP_LIB=tools/tmp/variants/lib_wsprof.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
