@@ -17,7 +17,7 @@ GLAM_E_INVALID, GLAM_E_UNSUPPORTED, GLAM_E_HIP = -1, -2, -3
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
-ABI_VERSION = 3     # = GLAM_ABI_VERSION of include/glam_hip.h: bumped with every change of an exported signature (kept next to SIGNATURES)
+ABI_VERSION = 4     # = GLAM_ABI_VERSION of include/glam_hip.h: bumped with every change of an exported signature (kept next to SIGNATURES)
 
 # name -> (restype, argtypes); mirrors include/glam_hip.h one to one
 SIGNATURES = {
@@ -61,6 +61,7 @@ SIGNATURES = {
     "glam_triplet_fwd_ell_supported": (_i32, [_i32, _i32, _i32]),
     "glam_triplet_fwd_ell": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "glam_triplet_layer_ws_supported": (_i32, [_i32, _i32, _i32, _i32]),
+    "glam_triplet_layer_infer_supported": (_i32, [_i32, _i32, _i32]),
     "glam_triplet_layer_fwd_ell": (_i32, [_vp] * 5 + [_i32, _i64, _i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_relation_mlp_supported": (_i32, [_i32, _i32, _i64]),
     "glam_relation_mlp_workspace_bytes": (_sz, [_i32, _i32, _i64]),

@@ -284,18 +284,21 @@ __global__ void __launch_bounds__(kBlock) k_stage_params_bwd(const float* wn, co
 
 
 // ------------------------------------------------------------------------------------------------
-// Parameter gradients straight from the partial sets of the backward pass (k_wgrad slabs of the two weight-gradient
+// Parameter gradients straight from the partial sets of the backward pass (k_wgrad / k_wgrad_x3 slabs of the two weight-gradient
 // products, block partials of B1), i.e. the final fixed-order reductions AND the chain rule of k_stage_params in ONE
 // launch (it replaces k_final_reduce -> k_stage_params_bwd).  Block roles:
-//   A  d_weight_scale / d_bias        block per (slab, tj, kq) of product 1 ([aggr|1]^T d_out): one thread per slab element, sum over
-//                                     the splits (256-byte runs per wave), scattered store
-//   B  d_weight_node                  block per (slab, tj, kq) of product 2: the element sums as in A, meanwhile d_Wa_i[k, :],
-//                                     d_Wa_j[k, :] of the block's 16 columns k (LDS), then
+//   A  d_weight_scale / d_bias        block per (slab, tj, kq) of product 1 ([aggr|1]^T d_out)
+//   B  d_weight_node                  block per (slab, tj, kq) of product 2, plus d_Wa_i[k, :], d_Wa_j[k, :] of the block's 16 columns k, then
 //                                     d_Wcat[k,h,c] + d_Wa_i[k,h] att_i[h,c] + d_Wa_j[k,h] att_j[h,c]
 //   C  d_weight_triplet_att head h    a block per (head, third: att_i | att_e | att_j): d_Wa[:,h] (or d_M[:,h]) into LDS, then the
 //                                     contraction with W_node (W_edge), 4 row quarters per column summed in order
-//   D  d_weight_edge                  a 16-lane group per element: sum over the B1 blocks + d_M[k,h] att_e[h,c]
-// Every sum runs in a fixed order (splits ascending; lane-strided partial sums + DPP butterfly for the B1 partials).
+//   D  d_weight_edge                  a block per 8 float4 columns of the B1 block partials + d_M[k,h] att_e[h,c]
+// Round 6: every partial is read as 16 bytes.  A slab stores the four rows i = 16 kq + 4 r + ti (r = 0..3) of column j = 4 c + tj next to
+// one another — one float4 UNIT (ti, tj, kq, c) —, so a role A / B block owns 64 units x nsplit splits: thread (split class sc = wave,
+// ti, c) adds the splits s = sc, sc + 4, ... of its unit in ascending order (one 1 KB request per wave and split: four 256-byte runs),
+// the four classes meet in LDS in class order, and thread (ti, c, r) finishes its element.  A quarter of the load instructions of the
+// scalar form, and with the 128 splits k_wgrad_x3 leaves (one block per CU) two round trips instead of four; the B1 block partials
+// ([blocks][P], P a multiple of 4) likewise, 8 float4 columns x 32 row classes per block.  Every sum runs in a fixed order.
 struct ParamGradArgs {
     const float* p1; int ns1;            // product 1 partials: i in [0, HC], j in [0, Cp)
     const float* p2; int ns2;            // product 2 partials ([d_xw|d_a]^T x): i in [0, HC+8), j in [0, Cp)
@@ -311,52 +314,73 @@ struct ParamGradArgs {
     const float* p3b; const float* p3c; int ns3_each;      // (ns3_each == ns3: one buffer)
 };
 
-// element (i, j) of a k_wgrad product: offset inside its 64 x 64 slab (inverse of the decode in k_final_reduce)
-__device__ __forceinline__ int wg_slab_offset(int i, int j) {
-    const int ii = i & 63, ti = ii & 3, t = ii >> 2, kq = t >> 2, r = t & 3, c = j >> 2, tj = j & 3;
-    return (((ti * 4 + tj) * 64 + kq * 16 + c) << 2) + r;
+// float4 unit (ti, tj, kq, c) of a 64 x 64 slab: rows 16 kq + 4 r + ti (r = the component), column 4 c + tj (the decode of k_final_reduce)
+__device__ __forceinline__ int wg_unit(int ti, int tj, int kq, int c) { return ((ti * 4 + tj) * 64 + kq * 16 + c) << 2; }
+__device__ __forceinline__ const float* wg_unit_ptr(const float* partial, int nsplit, int slab, int ti, int tj, int kq, int c) {
+    return partial + (size_t)slab * nsplit * kWgSlabStride + wg_unit(ti, tj, kq, c);
+}
+__device__ __forceinline__ void add4(float4& a, const float4& v, bool ok) {
+    a.x += ok ? v.x : 0.f; a.y += ok ? v.y : 0.f; a.z += ok ? v.z : 0.f; a.w += ok ? v.w : 0.f;
 }
 // A launch of this kernel is a handful of dependent memory round trips and nothing else, so every role ISSUES all the loads of a
-// stage before the first use: a partial sum is split into "request a batch" and "add the batch in split order", and independent sums
-// of a thread share the batch round trips.  kPgBatch = the split count of the B = 1 024 step: one round trip there.
-constexpr int kPgBatch = 40;
-struct PgBatch { float v[kPgBatch]; };
-__device__ __forceinline__ const float* wg_ptr(const float* partial, int nsplit, int i, int j) {
-    return partial + (size_t)(i >> 6) * nsplit * kWgSlabStride + wg_slab_offset(i, j);
-}
-// element stride between consecutive splits: 4096 (k_wgrad slabs) or P (B1 block partials); loads are clamped, i.e. unconditional
-__device__ __forceinline__ void pg_request(PgBatch& b, const float* p, size_t stride, int s0, int step, int n) {
+// stage before the first use (clamped addresses, i.e. unconditional loads: a load under a condition is waited for on the spot), and the
+// independent sums of a thread share the round trips.
+// the splits s = sc, sc + 4, ... < nsplit of unit `p`, added in ascending order (NB requests per round trip)
+template <int NB>
+__device__ __forceinline__ float4 wg_class_sum(const float* p, int nsplit, int sc) {
+    float4 acc = f4zero();
+    for (int s0 = sc; s0 < nsplit; s0 += 4 * NB) {
+        float4 v[NB];
 #pragma unroll
-    for (int u = 0; u < kPgBatch; ++u) b.v[u] = p[(size_t)min(s0 + step * u, n - 1) * stride];
-}
-__device__ __forceinline__ float pg_add(float sum, const PgBatch& b, int s0, int step, int n) {
+        for (int u = 0; u < NB; ++u) v[u] = ld4g(p + (size_t)min(s0 + 4 * u, nsplit - 1) * kWgSlabStride);
 #pragma unroll
-    for (int u = 0; u < kPgBatch; ++u) sum += s0 + step * u < n ? b.v[u] : 0.f;
-    return sum;
-}
-__device__ __forceinline__ float wg_sum(const float* partial, int nsplit, int i, int j) {
-    const float* p = wg_ptr(partial, nsplit, i, j);
-    float sum = 0.f;
-    for (int s = 0; s < nsplit; s += kPgBatch) {
-        PgBatch b;
-        pg_request(b, p, kWgSlabStride, s, 1, nsplit);
-        sum = pg_add(sum, b, s, 1, nsplit);
+        for (int u = 0; u < NB; ++u) add4(acc, v[u], s0 + 4 * u < nsplit);
     }
-    return sum;
+    return acc;
 }
-// two independent sums over the same split range, their loads in flight together
-__device__ __forceinline__ void wg_sum2(const float* pa, const float* pb, int nsplit, float& sa, float& sb) {
-    sa = sb = 0.f;
-    for (int s = 0; s < nsplit; s += kPgBatch) {
-        PgBatch a, b;
-        pg_request(a, pa, kWgSlabStride, s, 1, nsplit);
-        pg_request(b, pb, kWgSlabStride, s, 1, nsplit);
-        sa = pg_add(sa, a, s, 1, nsplit);
-        sb = pg_add(sb, b, s, 1, nsplit);
+// ... of two or three units, their requests in flight together
+template <int NB>
+__device__ __forceinline__ void wg_class_sum3(const float* pa, const float* pb, const float* pc, bool three, int nsplit, int sc,
+                                              float4& sa, float4& sb, float4& sc3) {
+    sa = sb = sc3 = f4zero();
+    for (int s0 = sc; s0 < nsplit; s0 += 4 * NB) {
+        float4 va[NB], vb[NB], vc[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const size_t o = (size_t)min(s0 + 4 * u, nsplit - 1) * kWgSlabStride;
+            va[u] = ld4g(pa + o);
+            vb[u] = ld4g(pb + o);
+        }
+        if (three) {                                          // (block-uniform)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) vc[u] = ld4g(pc + (size_t)min(s0 + 4 * u, nsplit - 1) * kWgSlabStride);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const bool ok = s0 + 4 * u < nsplit;
+            add4(sa, va[u], ok);
+            add4(sb, vb[u], ok);
+            if (three) add4(sc3, vc[u], ok);
+        }
     }
 }
+// component r of a unit, r known at run time only (block-uniform).  Three selects: indexing the float4 (f4get's chain is folded into that)
+// puts it into scratch memory
+__device__ __forceinline__ float pick4(float4 v, int r) {
+    float x = v.x;
+    asm volatile("" : "+v"(x));
+    x = r == 1 ? v.y : x;
+    asm volatile("" : "+v"(x));
+    x = r == 2 ? v.z : x;
+    asm volatile("" : "+v"(x));
+    return r == 3 ? v.w : x;
+}
+// the row class of a gradient row i: slab, kq and the component r of its units (ti = i & 3)
+struct WgRow { int slab, kq, r, ti; };
+__device__ __forceinline__ WgRow wg_row(int i) { const int ii = i & 63, t = ii >> 2; return WgRow{i >> 6, t >> 2, t & 3, ii & 3}; }
+
 // sum over the B1 block partials of element e, cooperatively by a 16-lane group (every lane gets the total): lane lg takes blocks
-// lg, lg + 16, ...; `request` / `finish` halves so that two elements (or an element and a slab sum) share the round trip
+// lg, lg + 16, ...
 constexpr int kB1Batch = 16;
 struct B1Batch { float v[kB1Batch]; };
 // the rows of up to three buffers of `each` rows behind one another (the applications of a layer that shares its weights): the SETS
@@ -398,41 +422,25 @@ __device__ __forceinline__ float b1_sum16_sets(const B1Src& src, int ns3, int P,
     }
     return group_sum<16>(part);
 }
-__device__ __forceinline__ void b1_sum16x2(const float* p3, int ns3, int P, int e0, int e1, int lg, float& r0, float& r1) {
-    float p0 = 0.f, p1 = 0.f;
-    for (int s = lg; s < ns3; s += 16 * kB1Batch) {
-        B1Batch a, b;
-        b1_request(a, p3, ns3, P, e0, s);
-        b1_request(b, p3, ns3, P, e1, s);
-        p0 = b1_add(p0, a, ns3, s);
-        p1 = b1_add(p1, b, ns3, s);
-    }
-    r0 = group_sum<16>(p0);
-    r1 = group_sum<16>(p1);
-}
 
-// Role D's loads, with the grain of the partial rows: lanes (el = lane & 7) on 8 consecutive elements — one 32-byte run of a row —
-// and (rl = lane >> 3, wave) on 32 interleaved row classes; a lane adds its rows s = r0, r0 + 32, ... in order.  (A 16-lane group per
-// element puts the 64 lanes of a load on 16 rows x 4 elements = 16 lines, and the CU's address path takes a line per cycle: for three
-// operand sets of 384 rows x 752 elements on the 45 role-D blocks that was most of k_param_grads<true>'s 18.8 us.)
-#ifndef GLAM_PG_ROWS8_ALL
-#define GLAM_PG_ROWS8_ALL 1      // 0: the one-buffer instantiation (the headline step's) keeps 16-lane groups per element (5.1 against 4.4 us)
-#endif
+// Role D's loads, with the grain of the partial rows: lane (col8 = lane & 7) on 8 consecutive float4 columns — one 128-byte run of a
+// row — and (rc = tid >> 3) on 32 interleaved row classes; a thread adds its rows s = rc, rc + 32, ... in order, two columns (its weight
+// column and a d_M column) sharing the round trips.
 template <bool SETS>
-__device__ __forceinline__ void b1_rows8(const B1Src& src, int ns3, int P, int e0, int e1, int r0, float& p0, float& p1) {
-    constexpr int BATCH = SETS ? 16 : 12, NQ = SETS ? 3 : 1;
+__device__ __forceinline__ void b1_cols(const B1Src& src, int ns3, int P, int col_a, int col_b, int rc, float4& sa, float4& sb) {
+    constexpr int BATCH = SETS ? 4 : 8, NQ = SETS ? 3 : 1;
     const int each = SETS ? src.each : ns3, nset = SETS ? ns3 / src.each : 1;
-    p0 = p1 = 0.f;
-    for (int s0 = r0; s0 < each; s0 += 32 * BATCH) {
-        float va[NQ][BATCH], vb[NQ][BATCH];
+    sa = sb = f4zero();
+    for (int s0 = rc; s0 < each; s0 += 32 * BATCH) {
+        float4 va[NQ][BATCH], vb[NQ][BATCH];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const float* base = b1_set(src, q, nset);
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const float* row = base + (size_t)min(s0 + 32 * u, each - 1) * P;
-                va[q][u] = row[e0];
-                vb[q][u] = row[e1];
+                va[q][u] = ld4g(row + 4 * col_a);
+                vb[q][u] = ld4g(row + 4 * col_b);
             }
         }
 #pragma unroll
@@ -440,10 +448,18 @@ __device__ __forceinline__ void b1_rows8(const B1Src& src, int ns3, int P, int e
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const bool ok = q < nset && s0 + 32 * u < each;
-                p0 += ok ? va[q][u] : 0.f;
-                p1 += ok ? vb[q][u] : 0.f;
+                add4(sa, va[q][u], ok);
+                add4(sb, vb[q][u], ok);
             }
     }
+}
+// lanes l, l + 8, ..., l + 56 of a wave (the eight row classes it holds per column) summed into every one of them, in a fixed order
+__device__ __forceinline__ float4 rows8_sum(float4 v) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+    }
+    return v;
 }
 
 #ifdef GLAM_PG_PROF   // developer aid (tools/pg_prof.py): cycle stamps of thread 0 of every block, s_memtime = the device-wide clock
@@ -453,14 +469,150 @@ __device__ long long g_pg_prof[512 * 8];
 #define PG_STAMP(k) do { } while (0)
 #endif
 
+// ---- the four roles, one function each (separate register allocations in the compiler's eyes: as one body the kernel held 106 scalar
+//      registers, spilled 14 of them and kept a scratch segment) ----
+template <int NB>
+__device__ __forceinline__ void pg_role_a(const ParamGradArgs& a, int b, float4* s_red) {
+    const int tid = threadIdx.x, C = a.C, Cp = a.Cp, HC = a.H * Cp;
+    const int slab = b >> 4, tj = (b >> 2) & 3, kq = b & 3;
+    // the element this thread finishes: (ti, c, r) -> row i, column col
+    const int lr = tid & 3, lc = (tid >> 2) & 15, lti = tid >> 6;
+    const int i = slab * 64 + 16 * kq + 4 * lr + lti, col = 4 * lc + tj;
+    const int h = i / Cp, c = i - h * Cp;
+    const bool is_bias = i == HC && col < C, mine = i < HC && c < C && col < C;
+    const int idx = (h * C + c) * C + col;
+    float carry = 0.f;                                        // requested before the partials are waited for
+    if (is_bias && a.c_bias) carry = a.c_bias[col];
+    if (mine && a.c_wsc) carry = a.c_wsc[idx];
+    s_red[tid] = wg_class_sum<NB>(wg_unit_ptr(a.p1, a.ns1, slab, (tid >> 4) & 3, tj, kq, tid & 15), a.ns1, tid >> 6);
+    __syncthreads();
+    const float* sr = reinterpret_cast<const float*>(s_red) + (lti * 16 + lc) * 4 + lr;
+    const float v = ((sr[0] + sr[256]) + sr[512]) + sr[768];
+    if (is_bias) a.d_bias[col] = v + carry;
+    else if (mine) a.d_wsc[idx] = v + carry;
+}
+
+template <int NB>
+__device__ __forceinline__ void pg_role_b(const ParamGradArgs& a, int b, float4* s_red, float* s_dw) {
+    const int tid = threadIdx.x, C = a.C, H = a.H, Cp = a.Cp, HC = H * Cp;
+    const int slab = b >> 4, tj = (b >> 2) & 3, kq = b & 3;
+    const int lr = tid & 3, lc = (tid >> 2) & 15, lti = tid >> 6;
+    const int i = slab * 64 + 16 * kq + 4 * lr + lti, k = 4 * lc + tj;
+    const int h = i / Cp, c = i - h * Cp;
+    const bool mine = i < HC && c < C && k < C;
+    const size_t idx = (size_t)k * H * C + h * C + c;
+    const float att_i = mine ? a.att[(size_t)h * 3 * C + c] : 0.f, att_j = mine ? a.att[(size_t)h * 3 * C + 2 * C + c] : 0.f;
+    const float carry = (mine && a.c_wn) ? a.c_wn[idx] : 0.f;
+    // the attention-gradient rows of this block's 16 columns: d_Wa_i[k, hh] = row HC + hh, d_Wa_j[k, hh] = row HC + 4 + hh (HC is a multiple
+    // of 4, so ti = hh); thread (sc, hh, c2) reads their units — ONE unit when both rows share it (components r and r + 1)
+    const int sc = tid >> 6, hh = (tid >> 4) & 3, c2 = tid & 15;
+    const WgRow ri = wg_row(HC + hh), rj = wg_row(HC + 4 + hh);
+    const bool two = ri.slab != rj.slab || ri.kq != rj.kq;    // (block-uniform)
+    float4 sm, si, sj;
+    wg_class_sum3<NB>(wg_unit_ptr(a.p2, a.ns2, slab, hh, tj, kq, c2), wg_unit_ptr(a.p2, a.ns2, ri.slab, ri.ti, tj, ri.kq, c2),
+                      wg_unit_ptr(a.p2, a.ns2, rj.slab, rj.ti, tj, rj.kq, c2), two, a.ns2, sc, sm, si, sj);
+    s_red[tid] = sm;
+    s_dw[tid] = pick4(si, ri.r);                              // [sc][hh][c2]
+    s_dw[256 + tid] = pick4(two ? sj : si, rj.r);
+    __syncthreads();
+    if (mine) {
+        const float* sr = reinterpret_cast<const float*>(s_red) + (lti * 16 + lc) * 4 + lr;
+        float v = ((sr[0] + sr[256]) + sr[512]) + sr[768];
+        const float* di = s_dw + h * 16 + lc;
+        const float dwa_i = ((di[0] + di[64]) + di[128]) + di[192], dwa_j = ((di[256] + di[320]) + di[384]) + di[448];
+        v = fmaf(dwa_i, att_i, v);
+        v = fmaf(dwa_j, att_j, v);
+        a.d_wn[idx] = v + carry;
+    }
+}
+
+template <bool SETS, int NB>
+__device__ __forceinline__ void pg_role_c(const ParamGradArgs& a, int b, float* s_dwa, float (*s_pc)[64], float* s_dm) {
+    const int tid = threadIdx.x, lg = tid & 15, grp = tid >> 4;
+    const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
+    const int h = b / 3, part = b - 3 * h;
+    const int c = tid & 63, kq4 = tid >> 6;
+    if (part == 1) {                                    // d_att_e[h, c] = sum_kk d_M[kk, h] W_edge[kk, h, c]
+        const bool out_mine = tid < C, dm_mine = grp < De;
+        float wcol[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) wcol[kk] = (out_mine && kk < De) ? a.we[(size_t)kk * H * C + h * C + tid] : 0.f;
+        const float carry = (out_mine && a.c_att) ? a.c_att[(size_t)h * 3 * C + C + tid] : 0.f;
+        const int e_dm = WSZ + (dm_mine ? grp : 0) * 4 + h;
+        const float dm = SETS ? b1_sum16_sets(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, e_dm, lg) : b1_sum16(a.p3, a.ns3, a.P, e_dm, lg);
+        if (dm_mine && lg == 0) s_dm[grp] = dm;
+        __syncthreads();
+        if (out_mine) {
+            float v = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (kk < De) v = fmaf(s_dm[kk], wcol[kk], v);
+            a.d_att[(size_t)h * 3 * C + C + tid] = v + carry;
+        }
+    } else {                                            // d_att_i / d_att_j[h, c] = sum_k d_Wa[k, h] W_node[k, h, c]
+        const int side = part == 0 ? 0 : 1;
+        // thread (kq4, c): the 16 rows k = 16 kq4 .. + 15 of its column of W_node, requested together with the d_Wa splits
+        float wcol[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = 16 * kq4 + r;
+            wcol[r] = (k < C && c < C) ? a.wn[(size_t)k * H * C + h * C + c] : 0.f;
+        }
+        const float carry = (tid < C && a.c_att) ? a.c_att[(size_t)h * 3 * C + 2 * C * side + tid] : 0.f;
+        // d_Wa[k, h] for every column k = 4 c' + tj: thread (sc, tj, c') adds the splits of its unit of row HC + 4 side + h
+        const WgRow rw = wg_row(HC + 4 * side + h);
+        const float4 sv = wg_class_sum<NB>(wg_unit_ptr(a.p2, a.ns2, rw.slab, rw.ti, (tid >> 4) & 3, rw.kq, tid & 15), a.ns2, tid >> 6);
+        s_pc[tid >> 6][tid & 63] = pick4(sv, rw.r);
+        __syncthreads();
+        if (tid < 64) {
+            const int kcol = 4 * (tid & 15) + ((tid >> 4) & 3);
+            s_dwa[kcol] = kcol < C ? ((s_pc[0][tid] + s_pc[1][tid]) + s_pc[2][tid]) + s_pc[3][tid] : 0.f;
+        }
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v = fmaf(s_dwa[16 * kq4 + r], wcol[r], v);
+        s_pc[kq4][c] = v;
+        __syncthreads();
+        if (tid < C) a.d_att[(size_t)h * 3 * C + 2 * C * side + tid] = (((s_pc[0][tid] + s_pc[1][tid]) + s_pc[2][tid]) + s_pc[3][tid]) + carry;
+    }
+}
+
+template <bool SETS>
+__device__ __forceinline__ void pg_role_d(const ParamGradArgs& a, int b, float4* s_red) {
+    const int tid = threadIdx.x, w = tid >> 6, col8 = tid & 7, rc = tid >> 3;
+    const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
+    // the element thread (col8' = tid >> 2, comp = tid & 3) of the first 32 finishes
+    const int e = 4 * (b * 8 + ((tid >> 2) & 7)) + (tid & 3);
+    const int kk = min(e / HC, a.Dp - 1), m = e - kk * HC, h = min(m / Cp, H - 1), c = m - h * Cp;
+    const bool mine = tid < 32 && e < WSZ && kk < De && c < C;
+    const int o = (kk * H + h) * C + (mine ? c : 0);
+    const float att_e = mine ? a.att[(size_t)h * 3 * C + C + c] : 0.f;
+    const float carry = (mine && a.c_we) ? a.c_we[o] : 0.f;
+    const int col_a = min(b * 8 + col8, WSZ / 4 - 1), col_b = WSZ / 4 + min(col8, a.Dp - 1);      // weight column | d_M row (kk = col8)
+    float4 sa, sb;
+    b1_cols<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, col_a, col_b, rc, sa, sb);
+    sa = rows8_sum(sa);
+    sb = rows8_sum(sb);
+    if ((tid & 63) < 8) { s_red[w * 16 + col8] = sa; s_red[w * 16 + 8 + col8] = sb; }
+    __syncthreads();
+    if (mine) {
+        const float* sr = reinterpret_cast<const float*>(s_red);
+        const int ia = ((tid >> 2) & 7) * 4 + (tid & 3), ib = (8 + kk) * 4 + h;
+        const float dwe = ((sr[ia] + sr[64 + ia]) + sr[128 + ia]) + sr[192 + ia];
+        const float dm = ((sr[ib] + sr[64 + ib]) + sr[128 + ib]) + sr[192 + ib];
+        a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
+    }
+}
+
 template <bool SETS>
 __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
     PG_STAMP(0);
-    __shared__ float s_dwa[2][64];
+    __shared__ float4 s_red[256];
+    __shared__ float s_dw[512];
     __shared__ float s_pc[4][64];
+    __shared__ float s_dwa[64];
     __shared__ float s_dm[8];
-    const int tid = threadIdx.x, lg = tid & 15, grp = tid >> 4;
-    const int C = a.C, H = a.H, De = a.De, Cp = a.Cp, HC = H * Cp, WSZ = a.Dp * HC;
     int b = blockIdx.x;
 #ifdef GLAM_PG_ONLY      // developer aid (tools/pg_roles.py): time one block role alone (0 = A, 1 = B, 2 = C, 3 = D)
     {
@@ -468,139 +620,18 @@ __global__ void __launch_bounds__(kBlock) k_param_grads(ParamGradArgs a) {
         if (role != GLAM_PG_ONLY) return;
     }
 #endif
-    // Roles A and B read the k_wgrad slabs WITH their grain: a slab stores, for fixed (ti, tj, kq), the 64 floats (c' = j / 4, r) of
-    // rows i = 16 kq + 4 r + ti and columns j = 4 c' + tj contiguously, so a block per (slab, tj, kq) with wave = ti and lane =
-    // (c', r) loads one 256-byte run per split.  (A block per output row — 64 lanes on 64 different lines, each line wanted by 16
-    // blocks — was bound by the CU's one-line-per-cycle address path: 20 k line requests per block.)
-    const int lr = tid & 3, lc = (tid >> 2) & 15, lti = tid >> 6;
-    if (b < a.blocksA) {                                    // ---- A: weight_scale, bias  <- product 1, element (i, col)
-        const int slab = b >> 4, tj = (b >> 2) & 3, kq = b & 3;
-        const int i = slab * 64 + 16 * kq + 4 * lr + lti, col = 4 * lc + tj;
-        if (i <= HC && col < C) {
-            const int h = i / Cp, c = i - h * Cp;
-            if (i == HC) {
-                const float carry = a.c_bias ? a.c_bias[col] : 0.f;            // requested before the partials are waited for
-                a.d_bias[col] = wg_sum(a.p1, a.ns1, i, col) + carry;
-            } else if (c < C) {
-                const int idx = (h * C + c) * C + col;
-                const float carry = a.c_wsc ? a.c_wsc[idx] : 0.f;
-                a.d_wsc[idx] = wg_sum(a.p1, a.ns1, i, col) + carry;
-            }
-        }
-        PG_STAMP(4);
-        return;
+    // (NB = the requests per round trip and split class: 10 covers the 40 splits of the B = 1 024 step in one trip without masked loads)
+    const bool few1 = a.ns1 <= 40, few2 = a.ns2 <= 40;
+    if (b < a.blocksA) {
+        if (few1) pg_role_a<10>(a, b, s_red); else pg_role_a<16>(a, b, s_red);
+    } else if ((b -= a.blocksA) < a.blocksB) {
+        if (few2) pg_role_b<10>(a, b, s_red, s_dw); else pg_role_b<16>(a, b, s_red, s_dw);
+    } else if ((b -= a.blocksB) < a.blocksC) {
+        if (few2) pg_role_c<SETS, 10>(a, b, s_dwa, s_pc, s_dm); else pg_role_c<SETS, 16>(a, b, s_dwa, s_pc, s_dm);
+    } else {
+        pg_role_d<SETS>(a, b - a.blocksC, s_red);
     }
-    b -= a.blocksA;
-    if (b < a.blocksB) {                                    // ---- B: weight_node  <- product 2, element (i, k) + the chain rule
-        const int slab = b >> 4, tj = (b >> 2) & 3, kq = b & 3;
-        const int i = slab * 64 + 16 * kq + 4 * lr + lti, k = 4 * lc + tj;
-        const int h = i / Cp, c = i - h * Cp;
-        const bool mine = i < HC && c < C && k < C;
-        // the attention-gradient rows of this block's 16 columns: d_Wa_i[k, h], d_Wa_j[k, h] (rows HC + side * 4 + h), 16-column runs too
-        const int c2 = tid & 15, hh = (tid >> 4) & 3, side = (tid >> 6) & 1, k2 = 4 * c2 + tj;
-        const bool dwa_mine = tid < 2 * 4 * 16 && hh < H && k2 < C;
-        // everything this thread will need, requested at once: its element's splits, its attention row's splits, att, the carry
-        const float* pv = wg_ptr(a.p2, a.ns2, mine ? i : 0, mine ? k : 0);
-        const float* pd = wg_ptr(a.p2, a.ns2, dwa_mine ? HC + side * 4 + hh : 0, dwa_mine ? k2 : 0);
-        const size_t idx = (size_t)k * H * C + h * C + c;
-        const float att_i = mine ? a.att[(size_t)h * 3 * C + c] : 0.f, att_j = mine ? a.att[(size_t)h * 3 * C + 2 * C + c] : 0.f;
-        const float carry = (mine && a.c_wn) ? a.c_wn[idx] : 0.f;
-        float v, dw;
-        wg_sum2(pv, pd, a.ns2, v, dw);
-        if (tid < 2 * 4 * 16) s_dwa[side][hh * 16 + c2] = dwa_mine ? dw : 0.f;
-        __syncthreads();
-        if (mine) {
-            v = fmaf(s_dwa[0][h * 16 + lc], att_i, v);
-            v = fmaf(s_dwa[1][h * 16 + lc], att_j, v);
-            a.d_wn[idx] = v + carry;
-        }
-        PG_STAMP(4);
-        return;
-    }
-    b -= a.blocksB;
-    if (b < a.blocksC) {                                    // ---- C: one third (att_i | att_e | att_j) of the attention vector of head h
-        const int h = b / 3, part = b - 3 * h;
-        const int c = tid & 63, kq4 = tid >> 6;
-        if (part == 1) {                                    // d_att_e[h, c] = sum_kk d_M[kk, h] W_edge[kk, h, c]
-            const bool out_mine = tid < C, dm_mine = grp < De;
-            float wcol[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) wcol[kk] = (out_mine && kk < De) ? a.we[(size_t)kk * H * C + h * C + tid] : 0.f;
-            const float carry = (out_mine && a.c_att) ? a.c_att[(size_t)h * 3 * C + C + tid] : 0.f;
-            const int e_dm = WSZ + (dm_mine ? grp : 0) * 4 + h;
-            const float dm = SETS ? b1_sum16_sets(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, e_dm, lg) : b1_sum16(a.p3, a.ns3, a.P, e_dm, lg);
-            if (dm_mine && lg == 0) s_dm[grp] = dm;
-            __syncthreads();
-            if (out_mine) {
-                float v = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-                    if (kk < De) v = fmaf(s_dm[kk], wcol[kk], v);
-                a.d_att[(size_t)h * 3 * C + C + tid] = v + carry;
-            }
-        } else {                                            // d_att_i / d_att_j[h, c] = sum_k d_Wa[k, h] W_node[k, h, c]
-            const int side = part == 0 ? 0 : 1;
-            // thread (kq4, c): the 16 rows k = 16 kq4 .. + 15 of its column of W_node, requested together with the d_Wa splits
-            // (threads < 64, columns in slab order: 16 lanes share a 256-byte run)
-            float wcol[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 16 * kq4 + r;
-                wcol[r] = (k < C && c < C) ? a.wn[(size_t)k * H * C + h * C + c] : 0.f;
-            }
-            const float carry = (tid < C && a.c_att) ? a.c_att[(size_t)h * 3 * C + 2 * C * side + tid] : 0.f;
-            if (tid < 64) {
-                const int kcol = 4 * (tid & 15) + ((tid >> 4) & 3);
-                s_dwa[0][kcol] = kcol < C ? wg_sum(a.p2, a.ns2, HC + side * 4 + h, kcol) : 0.f;
-            }
-            __syncthreads();
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v = fmaf(s_dwa[0][16 * kq4 + r], wcol[r], v);
-            s_pc[kq4][c] = v;
-            __syncthreads();
-            if (tid < C) a.d_att[(size_t)h * 3 * C + 2 * C * side + tid] = (((s_pc[0][tid] + s_pc[1][tid]) + s_pc[2][tid]) + s_pc[3][tid]) + carry;
-        }
-        PG_STAMP(4);
-        return;
-    }
-    b -= a.blocksC;
-    {                                                       // ---- D: weight_edge, 16 lanes per element
-        if constexpr (SETS || GLAM_PG_ROWS8_ALL) {          // 8 elements per block
-            const int w = tid >> 6, el = tid & 7, rl = (tid >> 3) & 7;
-            const int o = b * 8 + el;
-            const bool mine = o < De * H * C;
-            const int oc = mine ? o : 0;
-            const int kk = oc / (H * C), m = oc - kk * H * C, h = m / C, c = m - h * C;
-            const float att_e = a.att[(size_t)h * 3 * C + C + c];
-            const float carry = a.c_we ? a.c_we[oc] : 0.f;
-            float p0, p1;
-            b1_rows8<SETS>(B1Src{a.p3, a.p3b, a.p3c, a.ns3_each}, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, w * 8 + rl, p0, p1);
-            p0 += __shfl_xor(p0, 8, 64);  p1 += __shfl_xor(p1, 8, 64);
-            p0 += __shfl_xor(p0, 16, 64); p1 += __shfl_xor(p1, 16, 64);
-            p0 += __shfl_xor(p0, 32, 64); p1 += __shfl_xor(p1, 32, 64);
-            if (rl == 0) { s_pc[w][el] = p0; s_pc[w][8 + el] = p1; }
-            __syncthreads();
-            if (tid < 8 && mine) {
-                const float dwe = ((s_pc[0][el] + s_pc[1][el]) + s_pc[2][el]) + s_pc[3][el];
-                const float dm = ((s_pc[0][8 + el] + s_pc[1][8 + el]) + s_pc[2][8 + el]) + s_pc[3][8 + el];
-                a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
-            }
-        } else {
-        const int o = b * (kBlock / 16) + grp;
-        if (o < De * H * C) {
-            const int kk = o / (H * C), m = o - kk * H * C, h = m / C, c = m - h * C;
-            PG_STAMP(1);
-            const float att_e = a.att[(size_t)h * 3 * C + C + c];
-            const float carry = a.c_we ? a.c_we[o] : 0.f;
-            float dwe, dm;
-            b1_sum16x2(a.p3, a.ns3, a.P, kk * HC + h * Cp + c, WSZ + kk * 4 + h, lg, dwe, dm);
-            PG_STAMP(3);
-            if (lg == 0) a.d_we[o] = fmaf(dm, att_e, dwe) + carry;
-        }
-        }
-        PG_STAMP(4);
-    }
+    PG_STAMP(4);
 }
 
 }  // namespace glam
@@ -732,9 +763,12 @@ extern "C" int glam_triplet_layer_fwd(const float* x, const float* edge_attr, co
     if (int rc = dims_ok("glam_triplet_layer_fwd", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd: N out of range");
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(x && staged && xw && a_ij && aggr && stats && out, "glam_triplet_layer_fwd: null pointer");
+    GLAM_REQUIRE(x && staged && xw && a_ij && out && (!aggr) == (!stats), "glam_triplet_layer_fwd: null pointer");
     GLAM_REQUIRE(aligned16(x) && aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(out) && aligned16(staged),
                  "glam_triplet_layer_fwd: 16-byte alignment");
+    // aggr = stats = NULL: the inference forward (nothing is kept for a backward pass) — where the update GEMM runs inside the aggregate launch
+    if (!aggr && !(triplet_fwd_can_fuse_update(H, Cp, Dp) && N <= fuse_max_nodes()))
+        return fail(GLAM_E_UNSUPPORTED, "glam_triplet_layer_fwd: aggr = NULL needs the fused update (glam_triplet_layer_infer_supported; H=%d Cp=%d Dp=%d)", H, Cp, Dp);
     hipStream_t s = (hipStream_t)stream;
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
@@ -758,8 +792,8 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
     if (int rc = dims_ok("glam_triplet_layer_fwd_ell", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd_ell: N out of range");
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(x && staged && ell_src && ell_eid && xw && a_ij && aggr && stats && out && (E == 0 || edge_attr),
-                 "glam_triplet_layer_fwd_ell: null pointer");
+    GLAM_REQUIRE(x && staged && ell_src && ell_eid && xw && a_ij && (!aggr) == (!stats) && out && (E == 0 || edge_attr),
+                 "glam_triplet_layer_fwd_ell: null pointer");      // (aggr = stats = NULL: the inference forward, nothing kept for a backward pass)
     GLAM_REQUIRE(aligned16(x) && aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(out) && aligned16(staged) &&
                      aligned16(edge_attr) && aligned16(stats), "glam_triplet_layer_fwd_ell: 16-byte alignment");
     if (!(triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot)))
@@ -777,6 +811,9 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
 extern "C" int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot) {
     return (triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, Dp, edge_onehot)) ? 1 : 0;
 }
+
+// does glam_triplet_layer_fwd take aggr = stats = NULL for this shape (the ELL route always does)?
+extern "C" int glam_triplet_layer_infer_supported(int H, int Cp, int Dp) { return triplet_fwd_can_fuse_update(H, Cp, Dp) ? 1 : 0; }
 
 extern "C" size_t glam_triplet_layer_bwd_workspace_bytes(int64_t N, int64_t E, int H, int Cp, int Dp) {
     const size_t HC = (size_t)H * Cp;
@@ -862,7 +899,9 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
     ra.job[1] = ReduceJob{1, tpart, tnblk, WSZ + Dp * 4, 0, 0, 0, 0, dstaged + G.d_we_p, dstaged + G.d_m, WSZ, 0};
     //   d_WsB[HC+1, Cp] = [aggr | 1]^T @ d_out (last row = d_bias)
     //   d_Wcat[Cp, HC+8] = x^T @ [d_xw | d_a], computed as ([d_xw|d_a]^T x)^T
-    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s, false))
+    // (many_splits: from 32 768 rows on the products run warp-specialised on the bf16 matrix cores — k_wgrad_x3, one block per CU, 128
+    //  partials per element; k_param_grads / k_final_reduce take any split count)
+    if (int rc = launch_wgrad_partials2(w1, dstaged + G.d_wsb, Cp, 1, &ra.job[0], w2, dstaged + G.d_wcat, 1, HC + 8, &ra.job[2], s, true))
         return rc;      // both products in ONE launch
     // d_x = [d_xw | d_a] @ Wcat^T
     if (!fuse_dx) {
@@ -875,7 +914,7 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                          po->wn, po->we, po->att, C, H, De, Cp, Dp, po->d_wn, po->d_we, po->d_att, po->d_wsc, po->d_bias,
                          (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H, po->c_wn, po->c_we, po->c_att, po->c_wsc, po->c_bias};
         pg.ns3_each = tnblk;
-        const int blocksD = GLAM_PG_ROWS8_ALL ? (De * H * C + 7) / 8 : (De * H * C * 16 + kBlock - 1) / kBlock;
+        const int blocksD = (WSZ / 4 + 7) / 8;
         GLAM_PROF_LABEL("k_param_grads");
         hipLaunchKernelGGL(k_param_grads<false>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
         GLAM_LAUNCH_CHECK("glam_triplet_layer_bwd(param grads)");
@@ -1074,12 +1113,12 @@ extern "C" int glam_triplet_layer_param_grads_sets(int nseg, const void* const* 
     }
     hipStream_t s = (hipStream_t)stream;
     ReduceJob j1{}, j2{};
-    if (int rc = launch_wgrad_partials2(w1, nullptr, Cp, 1, &j1, w2, nullptr, 1, HC + 8, &j2, s, false)) return rc;
+    if (int rc = launch_wgrad_partials2(w1, nullptr, Cp, 1, &j1, w2, nullptr, 1, HC + 8, &j2, s, true)) return rc;
     ParamGradArgs pg{j1.partial, j1.nsplit, j2.partial, j2.nsplit, tp[0], tnblk * nseg, WSZ + Dp * 4, weight_node, weight_edge, att, C, H, De, Cp,
                      Dp, d_weight_node, d_weight_edge, d_att, d_weight_scale, d_bias, (HC + 1 + 63) / 64 * 16, (HC + 8 + 63) / 64 * 16, 3 * H,
                      add_weight_node, add_weight_edge, add_att, add_weight_scale, add_bias};
     pg.p3b = tp[1]; pg.p3c = tp[2]; pg.ns3_each = tnblk;
-    const int blocksD = (nseg > 1 || GLAM_PG_ROWS8_ALL) ? (De * H * C + 7) / 8 : (De * H * C * 16 + kBlock - 1) / kBlock;
+    const int blocksD = (WSZ / 4 + 7) / 8;
     GLAM_PROF_LABEL("k_param_grads<sets>");
     if (nseg == 1) hipLaunchKernelGGL(k_param_grads<false>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);
     else hipLaunchKernelGGL(k_param_grads<true>, dim3(pg.blocksA + pg.blocksB + pg.blocksC + blocksD), dim3(kBlock), 0, s, pg);

@@ -114,6 +114,53 @@ Tensor triplet_aggregate(const Tensor& xw, const Tensor& a_ij, const Tensor& edg
     return TripletAggregateFn::apply(xw, a_ij, edge_attr, w_edge, M, rowptr, src, eid, colptr, dst, eid_t, H, slope);
 }
 
+// the forward launches of the layer; `infer`: nothing is kept for a backward pass (aggr = stats = NULL: the kernels store neither)
+static Tensor layer_launch(const Tensor& x, const Tensor& edge_attr, const Tensor& wn, const Tensor& we, const Tensor& att, const Tensor& wsc,
+                           const Tensor& bias, const Tensor& rowptr, const Tensor& src, const Tensor& eid, int64_t H, double slope, bool ell_f,
+                           const c10::optional<Tensor>& ell_src, const c10::optional<Tensor>& ell_eid, bool edge_onehot, bool infer,
+                           Tensor& staged, Tensor& xw, Tensor& a_ij, Tensor& aggr, Tensor& stats) {
+    const int64_t N = x.size(0), E = src.numel();
+    const int C = (int)wn.size(0), De = (int)we.size(0), Cp = (int)x.size(1), Dp = (int)edge_attr.size(1);
+    const int HC = (int)H * Cp;
+    staged = at::empty({(int64_t)glam_triplet_staged_floats((int)H, Cp, Dp)}, x.options());
+    check_rc(glam_triplet_stage_params(fp(wn), fp(we), fp(att), fp(wsc), fp(bias), C, (int)H, De, Cp, Dp, fpm(staged), cur_stream()),
+             "glam_triplet_stage_params");
+    xw = at::empty({N, HC}, x.options());
+    a_ij = at::empty({N, 8}, x.options());
+    Tensor out = at::empty({N, Cp}, x.options());
+    infer = infer && (ell_f || glam_triplet_layer_infer_supported((int)H, Cp, Dp));
+    if (!infer) {
+        aggr = at::empty({N, HC}, x.options());
+        stats = at::empty({N, 8}, x.options());
+    }
+    float* aggr_p = infer ? nullptr : fpm(aggr);
+    float* stats_p = infer ? nullptr : fpm(stats);
+    // molecular graphs (ELL index records, one-hot bond features): the warp-specialised kernels, as the Python autograd node takes them
+    if (ell_f) {
+        want(*ell_src, at::kInt, "ell_src"); want(*ell_eid, at::kInt, "ell_eid");
+        TORCH_CHECK(ell_src->numel() == 4 * N && ell_eid->numel() == 4 * N, "triplet_layer: ELL records are int32 [N, 4]");
+        check_rc(glam_triplet_layer_fwd_ell(fp(x), fp(edge_attr), fp(staged), ip(*ell_src), ip(*ell_eid), edge_onehot ? 1 : 0, N, E, (int)H, Cp,
+                                            Dp, (float)slope, fpm(xw), fpm(a_ij), aggr_p, stats_p, fpm(out), cur_stream()),
+                 "glam_triplet_layer_fwd_ell");
+    } else {
+        check_rc(glam_triplet_layer_fwd(fp(x), fp(edge_attr), fp(staged), ip(rowptr), ip(src), ip(eid), N, E, (int)H, Cp, Dp,
+                                        (float)slope, fpm(xw), fpm(a_ij), aggr_p, stats_p, fpm(out), cur_stream()), "glam_triplet_layer_fwd");
+    }
+    return out;
+}
+
+static void layer_checks(const Tensor& x, const Tensor& edge_attr, const Tensor& wn, const Tensor& we, const Tensor& att, const Tensor& wsc,
+                         const Tensor& bias, const Tensor& rowptr, const Tensor& src, const Tensor& eid, int64_t H) {
+    want(x, at::kFloat, "x"); want(edge_attr, at::kFloat, "edge_attr"); want(wn, at::kFloat, "weight_node");
+    want(we, at::kFloat, "weight_edge"); want(att, at::kFloat, "weight_triplet_att"); want(wsc, at::kFloat, "weight_scale");
+    want(bias, at::kFloat, "bias"); want(rowptr, at::kInt, "rowptr"); want(src, at::kInt, "src"); want(eid, at::kInt, "eid");
+    const int64_t N = x.size(0), E = src.numel();
+    const int C = (int)wn.size(0), De = (int)we.size(0), Cp = (int)x.size(1), Dp = (int)edge_attr.size(1);
+    TORCH_CHECK(Cp == (C + 3) / 4 * 4 && (Dp == 4 || Dp == 8) && De <= Dp && wn.size(1) == H * C && wsc.size(0) == H * C && wsc.size(1) == C &&
+                    bias.numel() == C && att.numel() == H * 3 * C && edge_attr.size(0) == E && rowptr.numel() == N + 1,
+                "triplet_layer: shape mismatch (x must be [N, ceil4(C)], edge_attr [E, 4 | 8])");
+}
+
 // ---- the whole TripletMessage layer (glam_triplet_stage_params -> glam_triplet_layer_fwd / glam_triplet_layer_bwd_params) -----
 struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
     static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& edge_attr, const Tensor& wn, const Tensor& we, const Tensor& att,
@@ -121,33 +168,14 @@ struct TripletLayerFn : public torch::autograd::Function<TripletLayerFn> {
                           const Tensor& colptr, const Tensor& dst, const Tensor& eid_t, int64_t H, double slope,
                           const c10::optional<Tensor>& ell_src, const c10::optional<Tensor>& ell_eid, const c10::optional<Tensor>& ell_dst,
                           const c10::optional<Tensor>& ell_eid_t, bool edge_onehot) {
-        want(x, at::kFloat, "x"); want(edge_attr, at::kFloat, "edge_attr"); want(wn, at::kFloat, "weight_node");
-        want(we, at::kFloat, "weight_edge"); want(att, at::kFloat, "weight_triplet_att"); want(wsc, at::kFloat, "weight_scale");
-        want(bias, at::kFloat, "bias"); want(rowptr, at::kInt, "rowptr"); want(src, at::kInt, "src"); want(eid, at::kInt, "eid");
-        const int64_t N = x.size(0), E = src.numel();
-        const int C = (int)wn.size(0), De = (int)we.size(0), Cp = (int)x.size(1), Dp = (int)edge_attr.size(1);
-        TORCH_CHECK(Cp == (C + 3) / 4 * 4 && (Dp == 4 || Dp == 8) && De <= Dp && wn.size(1) == H * C && wsc.size(0) == H * C && wsc.size(1) == C &&
-                        bias.numel() == C && att.numel() == H * 3 * C && edge_attr.size(0) == E && rowptr.numel() == N + 1,
-                    "triplet_layer: shape mismatch (x must be [N, ceil4(C)], edge_attr [E, 4 | 8])");
-        const int HC = (int)H * Cp;
-        Tensor staged = at::empty({(int64_t)glam_triplet_staged_floats((int)H, Cp, Dp)}, x.options());
-        check_rc(glam_triplet_stage_params(fp(wn), fp(we), fp(att), fp(wsc), fp(bias), C, (int)H, De, Cp, Dp, fpm(staged), cur_stream()),
-                 "glam_triplet_stage_params");
-        Tensor xw = at::empty({N, HC}, x.options()), a_ij = at::empty({N, 8}, x.options()), aggr = at::empty({N, HC}, x.options()),
-               stats = at::empty({N, 8}, x.options()), out = at::empty({N, Cp}, x.options());
-        // molecular graphs (ELL index records, one-hot bond features): the warp-specialised kernels, as the Python autograd node takes them
+        layer_checks(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, H);
+        const int64_t N = x.size(0);
+        const int Cp = (int)x.size(1), Dp = (int)edge_attr.size(1);
+        Tensor staged, xw, a_ij, aggr, stats;
         const bool ell_f = ell_src.has_value() && ell_src->defined() && ell_eid.has_value() && ell_eid->defined() && N > 0 &&
                            glam_triplet_layer_ws_supported((int)H, Cp, Dp, edge_onehot ? 1 : 0);
-        if (ell_f) {
-            want(*ell_src, at::kInt, "ell_src"); want(*ell_eid, at::kInt, "ell_eid");
-            TORCH_CHECK(ell_src->numel() == 4 * N && ell_eid->numel() == 4 * N, "triplet_layer: ELL records are int32 [N, 4]");
-            check_rc(glam_triplet_layer_fwd_ell(fp(x), fp(edge_attr), fp(staged), ip(*ell_src), ip(*ell_eid), edge_onehot ? 1 : 0, N, E, (int)H, Cp,
-                                                Dp, (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()),
-                     "glam_triplet_layer_fwd_ell");
-        } else {
-            check_rc(glam_triplet_layer_fwd(fp(x), fp(edge_attr), fp(staged), ip(rowptr), ip(src), ip(eid), N, E, (int)H, Cp, Dp,
-                                            (float)slope, fpm(xw), fpm(a_ij), fpm(aggr), fpm(stats), fpm(out), cur_stream()), "glam_triplet_layer_fwd");
-        }
+        Tensor out = layer_launch(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, H, slope, ell_f, ell_src, ell_eid, edge_onehot, false,
+                                  staged, xw, a_ij, aggr, stats);
         const bool ell_b = ell_dst.has_value() && ell_dst->defined() && ell_eid_t.has_value() && ell_eid_t->defined();
         ctx->save_for_backward({x, edge_attr, wn, we, att, staged, xw, a_ij, aggr, stats, rowptr, src, eid, colptr, dst, eid_t,
                                 ell_f ? *ell_src : Tensor(), ell_f ? *ell_eid : Tensor(), ell_b ? *ell_dst : Tensor(), ell_b ? *ell_eid_t : Tensor()});
@@ -201,6 +229,17 @@ Tensor triplet_layer(const Tensor& x, const Tensor& edge_attr, const Tensor& wn,
                      const Tensor& bias, const Tensor& rowptr, const Tensor& src, const Tensor& eid, const Tensor& colptr, const Tensor& dst,
                      const Tensor& eid_t, int64_t H, double slope, const c10::optional<Tensor>& ell_src, const c10::optional<Tensor>& ell_eid,
                      const c10::optional<Tensor>& ell_dst, const c10::optional<Tensor>& ell_eid_t, bool edge_onehot) {
+    // no backward can follow (torch.no_grad(), or nothing that requires a gradient): the inference forward, outside autograd
+    const bool grad = at::GradMode::is_enabled() && (x.requires_grad() || edge_attr.requires_grad() || wn.requires_grad() || we.requires_grad() ||
+                                                     att.requires_grad() || wsc.requires_grad() || bias.requires_grad());
+    if (!grad) {
+        layer_checks(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, H);
+        const bool ell_f = ell_src.has_value() && ell_src->defined() && ell_eid.has_value() && ell_eid->defined() && x.size(0) > 0 &&
+                           glam_triplet_layer_ws_supported((int)H, (int)x.size(1), (int)edge_attr.size(1), edge_onehot ? 1 : 0);
+        Tensor staged, xw, a_ij, aggr, stats;
+        return layer_launch(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, H, slope, ell_f, ell_src, ell_eid, edge_onehot, true, staged, xw,
+                            a_ij, aggr, stats);
+    }
     return TripletLayerFn::apply(x, edge_attr, wn, we, att, wsc, bias, rowptr, src, eid, colptr, dst, eid_t, H, slope, ell_src, ell_eid, ell_dst,
                                  ell_eid_t, edge_onehot);
 }

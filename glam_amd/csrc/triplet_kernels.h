@@ -275,13 +275,13 @@ __global__ void __launch_bounds__(kBlock, GLAM_FWD_WAVES) k_triplet_fwd(FwdArgs 
             for (int it = 0; it < ITER; ++it)
                 if (ok[it]) {
                     const float4 v = inv * acc[h][it];
-                    st4o(a.aggr, orow + chunk_off[it] + (unsigned)h * head_bytes, v);
+                    if (a.aggr) st4o(a.aggr, orow + chunk_off[it] + (unsigned)h * head_bytes, v);      // (NULL: the inference forward of the fused-update launch)
                     if constexpr (G == 16) {
                         if (fuse_upd) st4(s_tile + (tid / G) * LDT + h * Cp + q[it] * 4, v);
                     }
                 }
         }
-        if (lg == 0) {
+        if (lg == 0 && a.stats) {
             float4 mv = f4zero(), sv = f4zero();
             float* mp = &mv.x; float* sp = &sv.x;
 #pragma unroll

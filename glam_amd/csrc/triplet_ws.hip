@@ -234,7 +234,9 @@ __device__ __forceinline__ void x3_store4(char* row_k, float4 v) {
     *reinterpret_cast<uint2*>(row_k + 2 * kX3PlaneBytes) = make_uint2(l0, l1);
 }
 
-template <int H, int P, bool X3, bool WT = false>      // WT: the large outputs are written through the L2 (small launches; common.h: st4o_wt)
+// INF: the inference instantiation (torch.no_grad(): src_1gp/trainer.py:306-327 evaluates every split after every epoch) — `aggr` and
+// `stats` exist only for a backward pass, so nothing is stored for them (15.3 of the 22.5 MB the launch writes at B = 1 024)
+template <int H, int P, bool X3, bool WT = false, bool INF = false>      // WT: the large outputs are written through the L2 (small launches; common.h: st4o_wt)
 __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_triplet_fwd_ws(FwdDmaArgs a) {
     constexpr int kWsBlock = (P + kWsCons) * 64, PG = P / 4, DE = 4, CH = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -405,8 +407,10 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             r_acc[h] = row_bcast(inv, 4 * h) * r_acc[h];
-            const float mh = row_bcast(mq, 4 * h), sh = row_bcast(sq, 4 * h);
-            (&r_ms.x)[h] = q == 0 ? mh : sh;
+            if constexpr (!INF) {
+                const float mh = row_bcast(mq, 4 * h), sh = row_bcast(sq, 4 * h);
+                (&r_ms.x)[h] = q == 0 ? mh : sh;
+            }
         }
     };
     auto compute_any = [&](int pass, int deg, int dmax, int sel, const float4 (&rows)[CH][H]) {
@@ -439,6 +443,7 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
         if (lv == 0) flag_bump(s_ready + slot);
     };
     auto store_results = [&]() {
+        if constexpr (INF) { r_n = -1; return; }
         if (r_n < 0) return;
         LANE_CONSTS(); (void)qoff; (void)j;
         if (qok) {
@@ -822,13 +827,14 @@ static size_t ws_lds_bytes(int H, int Cp, int P, bool x3) {
     return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 2 * 64 * 4) * sizeof(float) + ring;
 }
 
-template <int H, int P, bool X3, bool WT = false>
+template <int H, int P, bool X3, bool WT = false, bool INF = false>
 static int launch_ws_px(const FwdDmaArgs& a, int grid, hipStream_t s) {
-    if constexpr (X3 && !WT) { if (a.N <= kWtMaxRows) return launch_ws_px<H, P, X3, true>(a, grid, s); }
+    if constexpr (X3 && !WT) { if (a.N <= kWtMaxRows) return launch_ws_px<H, P, X3, true, INF>(a, grid, s); }
+    if constexpr (!INF) { if (!a.aggr) return launch_ws_px<H, P, X3, WT, true>(a, grid, s); }
     static bool big[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P, X3, WT>), big, "triplet_fwd_ws")) return rc;
-    GLAM_PROF_LABEL("k_triplet_fwd_ws+update");
-    hipLaunchKernelGGL((k_triplet_fwd_ws<H, P, X3, WT>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P, X3), s, a);
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_fwd_ws<H, P, X3, WT, INF>), big, "triplet_fwd_ws")) return rc;
+    GLAM_PROF_LABEL(INF ? "k_triplet_fwd_ws<inference>+update" : "k_triplet_fwd_ws+update");
+    hipLaunchKernelGGL((k_triplet_fwd_ws<H, P, X3, WT, INF>), dim3(grid), dim3((P + kWsCons) * 64), ws_lds_bytes(H, a.Cp, P, X3), s, a);
     return GLAM_OK;
 }
 // the consumers' product on the bf16 matrix cores in 3 x bf16 form (fp32 accuracy) unless GLAM_X3=0

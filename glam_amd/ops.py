@@ -702,11 +702,14 @@ class _TripletLayer(torch.autograd.Function):
         # ops.cached_staging() the staged images additionally survive from pass to pass until a parameter is written
         staged = _staged_cached(("triplet", H, Cp, Dp), (wn, we, att, wsc, bias), build) if CACHED_STAGING else \
             _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet", id(wn), id(we), id(att), id(wsc), id(bias)), wn, build)
-        xw, a_ij = torch.empty(N, HC, **f), torch.empty(N, 8, **f)
-        aggr, stats, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
+        xw, a_ij, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
         # molecular graphs with one-hot bond features take the warp-specialised kernels at every size (13.6 vs 16.8 us at B = 1 024,
         # 136 vs 256 us at B = 16 384 against the general fused kernel); everything else the general kernels
         ell = gi.ell() if _ws_route(lib, N, H, Cp, Dp, ea_p) else None
+        # no backward will come (torch.no_grad(): the evaluation passes of src_1gp/trainer.py:306-327): the inference forward, which keeps
+        # neither `aggr` nor `stats` (two thirds of what the launch writes)
+        infer = INFER_FWD and not any(ctx.needs_input_grad) and (ell is not None or bool(lib.glam_triplet_layer_infer_supported(H, Cp, Dp)))
+        aggr, stats = (None, None) if infer else (torch.empty(N, HC, **f), torch.empty(N, 8, **f))
         if ell is not None:
             check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), 1, N,
                                                  gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out), stream()),
@@ -715,7 +718,8 @@ class _TripletLayer(torch.autograd.Function):
             check(lib.glam_triplet_layer_fwd(ptr(x_p), ptr(ea_p), ptr(staged), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid),
                                              N, gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out),
                                              stream()), "glam_triplet_layer_fwd")
-        ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
+        if not infer:
+            ctx.save_for_backward(x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats)
         ctx.gi, ctx.dims = gi, (C, H, De, Cp, Dp, float(slope))
         res = (out,) + ((x_in.view_as(x_in),) if ctx.aliased else ()) + ((carry.view(-1),) if ctx.carried else ())
         return res if len(res) > 1 else out
@@ -1218,6 +1222,8 @@ NORM_DROP = True
 PRESTAGE = True
 # the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch
 DENSE_LINEAR = True
+# a TripletMessage forward that no backward can follow (torch.no_grad()) stores neither aggr nor stats: A/B switch
+INFER_FWD = os.environ.get("GLAM_INFER_FWD", "1") != "0"
 
 
 # ---- the dense and readout operator families live in their own modules; their names are part of this namespace ----

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLAM_ABI_VERSION 3   /* bumped whenever an exported signature changes or an entry point goes away */
+#define GLAM_ABI_VERSION 4   /* bumped whenever an exported signature changes or an entry point goes away */
 
 #define GLAM_OK 0
 #define GLAM_E_INVALID (-1)     /* bad argument (null pointer, negative size, misaligned) */
@@ -560,8 +560,13 @@ int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_a
  * gather, consumer waves run the update GEMM out of an LDS tile ring).  Same tensors and results (bit for bit) as
  * glam_triplet_layer_fwd; the faster route at EVERY batch size.  glam_triplet_layer_ws_supported says whether a shape is inside
  * (36 <= Cp <= 64, H * Cp <= 192, Dp = 4, edge_onehot = 1); other shapes are GLAM_E_UNSUPPORTED here and belong to
- * glam_triplet_layer_fwd. */
+ * glam_triplet_layer_fwd.
+ * The INFERENCE forward (src_1gp/trainer.py:306-327: @torch.no_grad() evaluation of every split after every epoch): aggr = stats = NULL —
+ * both exist only for a backward pass, and the launch then stores neither (15.3 of the 22.5 MB it writes at 1 024 molecules).  Always
+ * available here; glam_triplet_layer_fwd takes NULL where glam_triplet_layer_infer_supported says so (the shapes whose update GEMM runs
+ * inside the aggregate launch).  xw and a_ij are still written: the aggregate reads them. */
 int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot);
+int glam_triplet_layer_infer_supported(int H, int Cp, int Dp);
 int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
                                const int32_t* ell_eid, int edge_onehot, int64_t N, int64_t E, int H, int Cp, int Dp, float slope,
                                float* xw, float* a_ij, float* aggr, float* stats, float* out, void* stream);

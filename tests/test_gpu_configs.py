@@ -40,7 +40,16 @@ def _twins(fn, tensors):
 # ---------------------------------------------------------------------------------------------
 # configs[1]: the headline configuration, whole batch, forward and all six gradients
 # ---------------------------------------------------------------------------------------------
-def test_config2_full_batch_fwd_bwd_all_gradients(device):
+@pytest.fixture(params=["default", "wgrad_x3"])
+def layer_wgrad_route(request, monkeypatch):
+    """The layer's two weight-gradient products: "default" = k_wgrad (fp32 matrix instructions, 40 partials per element for k_param_grads)
+    below 32 768 rows, "wgrad_x3" = the warp-specialised 3 x bf16 kernel at every size (one block per CU: up to 128 partials per element)."""
+    if request.param == "wgrad_x3":
+        monkeypatch.setenv("GLAM_WGRAD_X3_ROWS", "1")
+    return request.param
+
+
+def test_config2_full_batch_fwd_bwd_all_gradients(device, layer_wgrad_route):
     b = synth_batch(1024, seed=0)
     torch.manual_seed(0)
     conv = layer.TripletMessage(60, 4)

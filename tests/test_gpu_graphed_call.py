@@ -223,7 +223,9 @@ def test_moved_parameter_storage_drops_the_captures(device, trip):
         else:
             net.double()
             net.float()
-        assert [id(p) for p in net.parameters()] == ident and next(net.parameters()).data_ptr() != ptr, "the premise: same objects, new storage"
+        assert [id(p) for p in net.parameters()] == ident, "the premise: the same Parameter objects"
+        if routed:          # (the captures' proxies pin the old storage, so the new one is elsewhere; unrouted, the allocator may hand the block back)
+            assert next(net.parameters()).data_ptr() != ptr, "the premise: new storage"
         losses += _train_steps(net, opt, b, 5)
         if routed:
             assert net.__dict__["_glam_graphed_route"].graphs() == 2, "captured again on the new storage"

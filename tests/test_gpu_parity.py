@@ -125,6 +125,76 @@ def test_triplet_message_golden(device, name):
     assert_golden_parity(run64, g, out, gs, name, ["x", "edge_attr"] + names)
 
 
+@pytest.mark.parametrize("ext", [False, True])
+@pytest.mark.parametrize("name", golden_names("triplet_"))
+def test_triplet_message_golden_inference_forward(device, name, ext, monkeypatch):
+    """``torch.no_grad()`` (the evaluation passes of src_1gp/trainer.py:306-327): the forward that keeps nothing for a backward — no
+    ``aggr``, no ``stats`` store — gives the training forward's output bit for bit and the golden one within the bound, through the Python
+    node and through the torch-extension operator; ``INFER_FWD = False`` is the A/B route."""
+    g = Golden(name)
+    conv = layer.TripletMessage(g.meta["C"], g.meta["De"]).to(device)
+    conv.load_state_dict(g.params)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", ext)
+    x, ei, ea = g.inputs["x"].to(device), g.inputs["edge_index"].to(device), g.inputs["edge_attr"].to(device)
+    out_train = conv(x.clone().requires_grad_(True), ei, ea).detach()
+    with torch.no_grad():
+        out_inf = conv(x, ei, ea)
+        monkeypatch.setattr(ops, "INFER_FWD", False)
+        out_kept = conv(x, ei, ea)
+    assert not out_inf.requires_grad
+    assert torch.equal(out_inf, out_train) and torch.equal(out_kept, out_train)
+    assert_close(out_inf, g.out, TOL, name + " (inference forward)")
+
+
+def test_inference_forward_launches_and_c_abi(device, monkeypatch):
+    """At the headline size: under ``torch.no_grad()`` the step launches the inference instantiation of the warp-specialised forward (its own
+    label in the kernel trace), the general fused-update kernel takes NULL too where ``glam_triplet_layer_infer_supported`` says so, and
+    through the C ABI ``aggr = stats = NULL`` leaves ``out`` bit-equal while a lone NULL is an argument error."""
+    from glam_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    b = synth_batch(1024, seed=0).to(device)
+    torch.manual_seed(0)
+    conv = layer.TripletMessage(60, 4).to(device)
+    N = b.x.size(0)
+    x = torch.randn(N, 60, device=device)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    outs, labels = {}, {}
+    for route in ("auto", "0"):
+        monkeypatch.setattr(ops, "WS_ROUTE", route)
+        for grad in (True, False):
+            with _lib.kernel_timer(capacity=16) as kt, (torch.enable_grad() if grad else torch.no_grad()):
+                outs[route, grad] = conv(x.clone().requires_grad_(grad), b.edge_index, b.edge_attr).detach()
+            labels[route, grad] = [n for n, _, _ in kt.records()]
+        assert torch.equal(outs[route, True], outs[route, False]), route
+    assert any("k_triplet_fwd_ws<inference>" in n for n in labels["auto", False]), labels["auto", False]
+    assert not any("inference" in n for n in labels["auto", True])
+    assert lib.glam_triplet_layer_infer_supported(3, 60, 4) == 1
+    # C ABI
+    gi = ops.graph_index(b.edge_index, N)
+    ell = gi.ell()
+    with torch.no_grad():
+        staged = torch.empty(lib.glam_triplet_staged_floats(3, 60, 4), device=device)
+        assert lib.glam_triplet_stage_params(p(conv.weight_node), p(conv.weight_edge), p(conv.weight_triplet_att), p(conv.weight_scale), p(conv.bias),
+                                             60, 3, 4, 60, 4, p(staged), _lib.stream()) == 0
+    f = dict(dtype=torch.float32, device=device)
+    res = []
+    for keep in (True, False):
+        xw, a_ij, out = torch.empty(N, 180, **f), torch.empty(N, 8, **f), torch.full((N, 60), float("nan"), **f)
+        aggr, stats = (torch.empty(N, 180, **f), torch.empty(N, 8, **f)) if keep else (None, None)
+        rc = lib.glam_triplet_layer_fwd_ell(p(x), p(b.edge_attr), p(staged), p(ell[0]), p(ell[1]), 1, N, gi.E, 3, 60, 4, 0.2, p(xw), p(a_ij), p(aggr),
+                                            p(stats), p(out), _lib.stream())
+        assert rc == 0, lib.glam_last_error()
+        res.append(out)
+        out2 = torch.full((N, 60), float("nan"), **f)
+        rc = lib.glam_triplet_layer_fwd(p(x), p(b.edge_attr), p(staged), p(gi.rowptr), p(gi.src), p(gi.eid), N, gi.E, 3, 60, 4, 0.2, p(xw), p(a_ij),
+                                        p(aggr), p(stats), p(out2), _lib.stream())
+        assert rc == 0, lib.glam_last_error()
+        res.append(out2)
+    assert torch.equal(res[0], res[2]) and torch.equal(res[1], res[3]) and torch.equal(res[0], outs["auto", True])
+    assert lib.glam_triplet_layer_fwd_ell(p(x), p(b.edge_attr), p(staged), p(ell[0]), p(ell[1]), 1, N, gi.E, 3, 60, 4, 0.2, p(xw), p(a_ij), None,
+                                          p(torch.empty(N, 8, **f)), p(out), _lib.stream()) != 0
+
+
 @pytest.mark.parametrize("name", golden_names("triplet_"))
 def test_triplet_aggregate_op_golden(device, name):
     """Op level: the fused kernel alone against the reference's aggregate (before ``update``)."""

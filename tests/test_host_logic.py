@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libglam_hip.so does not export {n}"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and include/glam_hip.h disagree"
-    assert _lib.load().glam_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().glam_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_abi_rejects_bad_arguments_without_touching_a_gpu():
