@@ -37,6 +37,64 @@ __device__ long long g_b1_rt[256 * 12 * 6];      // the same stamps on the devic
 #endif
 
 
+// part[k][h] (k < DM slots, h < H heads) summed over the 16 lanes of a node's row, sum (k, h) DELIVERED TO LANE 4 h + k of the row — the
+// quad layout of the per-edge scalars — instead of DM * H full butterflies (every lane ending with every total) and as many selects.
+// The same pairings in the same order as group_sum<16> (xor 1, xor 2, row_half_mirror, row_mirror), so every total is bit-equal to it;
+// at each step a lane keeps the half of its values its position asks for and hands the other half to its partner: DM * H + ... -> 1
+// values per lane.  The mirror steps pair lane i with 7 - i / 15 - i, whose slot index is the reverse one: the odd quads work on
+// reversed slots (kc = 3 - kk) and are turned round at the end.  Lanes whose (k, h) does not exist end with finite garbage.
+template <int DM, int H>
+__device__ __forceinline__ float row_sums_to_quads(const float (&part)[DM][H], int lv) {
+    const int qd = (lv >> 2) & 3, kk = lv & 3;
+    const bool oddq = qd & 1;
+    const int kc = oddq ? 3 - kk : kk;
+    const bool p1 = kc & 1, p2 = kc & 2;
+    float w0[H], w1[H], u[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        if constexpr (DM >= 2) {
+            const float keep = p1 ? part[1][h] : part[0][h], give = p1 ? part[0][h] : part[1][h];
+            w0[h] = keep + dpp_f<0xB1>(give);                 // quad_perm [1,0,3,2]
+        } else {
+            w0[h] = part[0][h] + dpp_f<0xB1>(part[0][h]);
+        }
+        if constexpr (DM >= 4) {
+            const float keep = p1 ? part[3][h] : part[2][h], give = p1 ? part[2][h] : part[3][h];
+            w1[h] = keep + dpp_f<0xB1>(give);
+        } else if constexpr (DM == 3) {
+            w1[h] = part[2][h] + dpp_f<0xB1>(part[2][h]);
+        } else {
+            w1[h] = 0.f;
+        }
+        if constexpr (DM >= 3) {
+            const float keep = p2 ? w1[h] : w0[h], give = p2 ? w0[h] : w1[h];
+            u[h] = keep + dpp_f<0x4E>(give);                  // quad_perm [2,3,0,1]
+        } else {
+            u[h] = w0[h] + dpp_f<0x4E>(w0[h]);
+        }
+    }
+    // heads: quads 0 and 3 keep head 0, quads 1 and 2 head 1 across the 8-lane halves; then quads 0, 1 keep that and quads 2, 3 head 2
+    float r;
+    if constexpr (H == 1) {
+        const float a8 = u[0] + dpp_f<0x141>(u[0]);           // row_half_mirror
+        r = a8 + dpp_f<0x140>(a8);                            // row_mirror
+    } else {
+        const bool p3 = qd == 0 || qd == 3;
+        const float keep = p3 ? u[0] : u[1], give = p3 ? u[1] : u[0];
+        const float a8 = keep + dpp_f<0x141>(give);
+        if constexpr (H == 2) {
+            r = a8 + dpp_f<0x140>(a8);
+        } else {
+            const float b8 = u[2] + dpp_f<0x141>(u[2]);
+            const bool p4 = qd < 2;
+            const float keep4 = p4 ? a8 : b8, give4 = p4 ? b8 : a8;
+            r = keep4 + dpp_f<0x140>(give4);
+        }
+    }
+    const float rr = dpp_f<0x1B>(r);                          // quad_perm [3,2,1,0]
+    return oddq ? rr : r;
+}
+
 struct DstWsArgs {
     const float* xw; const float* a_ij; const float* edge_attr; const float* w_edge; const float* M;
     const float* aggr; const float* stats; const float* d_out; const float* img_dagg;
@@ -55,21 +113,24 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     // W_edge and the d_W_edge arrays keep one row per bond type at a pitch of WP floats, a multiple of 64 (and so is the array size WL):
     // rows of different types / different node rows start on the same bank, so a 16-lane ds_read_b128 / ds_write_b128 group that mixes
     // lanes of two nodes is conflict free (pitch HC = 180: 35-43 % of this kernel's LDS cycles were bank conflicts)
+    // The d_W_edge arrays take a head per 64 floats (WD = 64 H per bond type): every one of a row's 16 lanes owns a float4 of every head —
+    // also the lanes beyond the row's Cp / 4 chunks, whose products are zero — so the accumulator update below is unconditional
     const int WSZ = 4 * HC, WP = ws_wedge_pitch(HC), WL = 4 * WP, LDT = HC + 8, P = WSZ + 16;
+    constexpr int WD = 64 * H, WLD = 4 * WD;
     constexpr int kRing = 4;                                  // tile slots (the d_W_edge arrays take the rest of the LDS)
     float* s_w = smem;
     int* s_ready = reinterpret_cast<int*>(smem + WL);         // [kRing] matrix-wave check-ins per slot
     float* s_mt = reinterpret_cast<float*>(s_ready + 16);     // M transposed: [head][edge feature]
     int* s_taken = s_ready + 32;                              // [kRing] vector-wave check-outs per slot
-    float* s_dw = smem + WL + 64;                             // per (vector wave, node row): d_W_edge [4][WP]
-    float* s_ring = s_dw + V * 4 * WL;                        // kRing tiles of 16 x LDT floats
+    float* s_dw = smem + WL + 64;                             // per (vector wave, node row): d_W_edge [4][H][64]
+    float* s_ring = s_dw + V * 4 * WLD;                       // kRing tiles of 16 x LDT floats
     B1_TL(0);
     // LDS staging, called by each role BEHIND its first global loads (see k_triplet_fwd_ws): the matrix waves' weight slice and first
     // d_out rows, the vector waves' first record
     auto stage_lds = [&]() {
         const float4 wv = tid < WSZ / 4 ? ld4(a.w_edge + 4 * tid) : f4zero();         // (WSZ / 4 <= 192 < the block)
         const float mv = (tid >> 4) == 1 ? a.M[(tid & 3) * 4 + ((tid >> 2) & 3)] : 0.f;
-        for (int i = tid; i < V * WL; i += kBlockT) st4(s_dw + 4 * i, f4zero());       // V * 4 arrays of WL floats: under the loads
+        for (int i = tid; i < V * WLD; i += kBlockT) st4(s_dw + 4 * i, f4zero());      // V * 4 arrays of WLD floats: under the loads
         if (tid < WSZ / 4) st4(s_w + (4 * tid) / HC * WP + (4 * tid) % HC, wv);
         if (tid < 64) {
             if ((tid >> 4) == 1) s_mt[tid & 15] = mv;
@@ -220,7 +281,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         // ------------------------------------------------------------------------------------------------------------------
         // vector waves
         // ------------------------------------------------------------------------------------------------------------------
-        float* wave_dw = s_dw + wave * 4 * WL;
+        float* wave_dw = s_dw + wave * 4 * WLD;
         const int npass = (a.N + 3) >> 2;
         const int grp = wave >> 2, rw = wave & 3;
         const int gw = 4 * (blockIdx.x + grp * gridDim.x) + rw, GW = 4 * VG * gridDim.x;
@@ -331,35 +392,33 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
                 }
                 // ---- row phase: d_alpha[k][h] = <d_aggr[n,h,:], e_ij * xw[src_k,h,:]>, d_W_edge[type_k][h] += alpha * d_aggr * xw ----
                 if (deg > 0) {
-                    int tk[DM];
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) tk[k] = row_bcast_i(t, k) * WP + (qok ? q : 0) * 4;
+                    // the update's weight: an empty slot (it aliases the node's first edge: finite data) adds an exact zero, so every lane
+                    // of the row runs the read - fma - write of every slot — no exec-mask region around each LDS access
+                    const float alpha_w = kk < deg ? alpha : 0.f;
+                    float part[DM][H];
                     // slot outer, head inner: the three accumulator rows of a slot (one per head: distinct addresses) are read together,
                     // updated and written back, so a pass costs DM LDS round trips for d_W_edge instead of DM * H dependent ones
 #pragma unroll
                     for (int k = 0; k < DM; ++k) {
                         float4 er[H], dacc[H];
-                        float* d = wave_dw + j * WL + tk[k];
-                        const bool upd = k < deg && qok;
+                        const int tkk = row_bcast_i(t, k);
+                        const float* e = s_w + tkk * WP + (qok ? q : 0) * 4;
+                        float* d = wave_dw + j * WLD + tkk * WD + q * 4;
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
-                            er[h] = ld4(s_w + tk[k] + h * Cp);
-                            dacc[h] = upd ? ld4(d + h * Cp) : f4zero();
+                            er[h] = ld4(e + h * Cp);
+                            dacc[h] = ld4(d + h * 64);
                         }
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
                             const float4 tv = dag[h] * rows[k][h];                   // d_aggr * x_j
-                            float part = 0.f;
-                            part += dot4(tv, er[h]);
-                            const float dal = group_sum<16>(part);
-                            dalq = (hc == h && kk == k) ? dal : dalq;
-                            fma4(dacc[h], row_bcast(alpha, 4 * h + k), tv);          // d_W_edge[type_k][h] += alpha * (d_aggr * x_j)
+                            part[k][h] = dot4(tv, er[h]);
+                            fma4(dacc[h], row_bcast(alpha_w, 4 * h + k), tv);        // d_W_edge[type_k][h] += alpha * (d_aggr * x_j)
                         }
-                        if (upd) {
 #pragma unroll
-                            for (int h = 0; h < H; ++h) st4(d + h * Cp, dacc[h]);
-                        }
+                        for (int h = 0; h < H; ++h) st4(d + h * 64, dacc[h]);
                     }
+                    dalq = row_sums_to_quads<DM, H>(part, lv);
                 }
             }
             h_dal = dalq;
@@ -444,10 +503,11 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     // ---- block partial of d_W_edge | d_M, every sum in a fixed order ----
     float* out = a.partial + (size_t)blockIdx.x * P;
     for (int i = tid; i < WSZ; i += kBlockT) {
-        const int li = i / HC * WP + i % HC;
+        const int tt = i / HC, m = i - tt * HC, h = m / Cp;
+        const int li = tt * WD + h * 64 + (m - h * Cp);
         float sum = 0.f;
 #pragma unroll 8
-        for (int v = 0; v < V * 4; ++v) sum += s_dw[v * WL + li];
+        for (int v = 0; v < V * 4; ++v) sum += s_dw[v * WLD + li];
         out[i] = sum;
     }
     if (tid < 16) {                                           // d_M[type tt][head hh]: lanes 16 j + 4 hh + kk of every vector wave
@@ -467,8 +527,8 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 
 static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     const int HC = H * Cp;
-    const int WL = 4 * ws_wedge_pitch(HC);
-    return ((size_t)WL + 64 + (size_t)V * 4 * WL + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
+    const int WL = 4 * ws_wedge_pitch(HC), WLD = 4 * 64 * H;      // W_edge rows | the d_W_edge arrays [4 types][H][64]
+    return ((size_t)WL + 64 + (size_t)V * 4 * WLD + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
 template <int H, int V, bool X3, bool WT = false>

@@ -211,7 +211,7 @@ def test_moved_parameter_storage_drops_the_captures(device, trip):
     for routed in (False, True):
         net = copy.deepcopy(net0)
         net.graphed_call = routed
-        opt = torch.optim.SGD(net.parameters(), lr=1e-2)     # (no per-parameter state tied to the old storage)
+        opt = torch.optim.SGD(net.parameters(), lr=1e-4)     # (no per-parameter state tied to the old storage)
         losses = _train_steps(net, opt, b, 5)
         if routed:
             assert net.__dict__["_glam_graphed_route"].graphs() == 2
@@ -291,8 +291,14 @@ def test_two_forwards_of_one_batch_before_the_first_backward(device):
         o1 = m(_fresh(b))
         o2 = m(_fresh(b2))                           # same content key, o1's backward still pending
         (_loss(o1, b) + 0.5 * _loss(o2, b) + (o1 - o2).pow(2).mean()).backward()
-    for p, q in zip(net.parameters(), ref.parameters()):
-        assert torch.equal(p.grad, q.grad)
+    # (one backward over two graphs: autograd adds the four per-application gradients of a shared block one by one in the eager run, the
+    #  replayed graph hands over its two already summed — the same numbers in another association: rounding-level agreement, not bits)
+    from tests.conftest import assert_close
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert_close(p.grad, q.grad, 2e-6, f"grad {n}")
+    # the wrong answer this guards against — the first output's backward run on the second forward's activations — is far outside that
+    o1 = ref(_fresh(b))
+    assert (o1 - ref(_fresh(b2))).abs().max() > 1e-2
     # ... and the route is back on replays once nothing is pending
     st = next(iter(net.__dict__["_glam_graphed_route"]._states.values()))
     gen = st.gen
