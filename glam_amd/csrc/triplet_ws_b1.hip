@@ -488,34 +488,62 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             rs = rs_n; re = re_n;
             load_rec(pass + 2 * GW, rs_n, re_n);
         }
-        // every tile of this wave is done: park the lane's d_M in its own slot of the scratch behind the ring flags
+        // every tile of this wave is done: the wave's total of d_M[type][head] — over the quad's slots by DPP, over the four node rows
+        // through the crossbar — parked by lane 4 hh in the wave's 16 floats of the scratch (the dead ring)
         B1_TL(3);
-        __syncthreads();                                      // (1) the ring is dead: its memory becomes the d_M scratch
-        {
-            float* scr = s_ring + (wave * 64 + lane) * 4;
-            st4(scr, make_float4(dMq[0], dMq[1], dMq[2], dMq[3]));
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            float x = dMq[tt];
+            x += dpp_f<0xB1>(x);
+            x += dpp_f<0x4E>(x);
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            dMq[tt] = x;
         }
+        __syncthreads();                                      // (1) the ring is dead: its memory becomes the d_M scratch
+        if (lane < 16 && (lane & 3) == 0) st4(s_ring + (wave * 4 + (lane >> 2)) * 4, make_float4(dMq[0], dMq[1], dMq[2], dMq[3]));
 #undef LANE_CONSTS
     }
     if (wave >= V) { B1_TL(3); __syncthreads(); }             // (1) for the matrix waves
     __syncthreads();                                          // (2)
     B1_TL(4);
-    // ---- block partial of d_W_edge | d_M, every sum in a fixed order ----
+    // ---- block partial of d_W_edge | d_M, every sum in a fixed order: thread (array group g, float4 column c4) adds its 8 of the 32
+    //      arrays, the four groups meet in the dead ring behind the d_M scratch, thread c4 adds them in group order and stores 16 bytes ----
     float* out = a.partial + (size_t)blockIdx.x * P;
-    for (int i = tid; i < WSZ; i += kBlockT) {
-        const int tt = i / HC, m = i - tt * HC, h = m / Cp;
-        const int li = tt * WD + h * 64 + (m - h * Cp);
-        float sum = 0.f;
-#pragma unroll 8
-        for (int v = 0; v < V * 4; ++v) sum += s_dw[v * WLD + li];
-        out[i] = sum;
+    {
+        constexpr int NC4 = 4 * H * 16, NG = 4, PER = V * 4 / NG;                      // float4 columns of an array; array groups
+        static_assert(V * 4 % NG == 0 && NG * NC4 <= kBlockT, "reduction geometry");
+        float* s_part = s_ring + V * 64 * 4;
+        if (tid < NG * NC4) {
+            const int g = tid / NC4, c4 = tid - g * NC4;
+            float4 acc = ld4(s_dw + (size_t)(g * PER) * WLD + 4 * c4);
+#pragma unroll
+            for (int v = 1; v < PER; ++v) {
+                const float4 x = ld4(s_dw + (size_t)(g * PER + v) * WLD + 4 * c4);
+                acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+            }
+            st4(s_part + 4 * tid, acc);
+        }
+        __syncthreads();
+        if (tid < NC4) {
+            const int tt = tid / (H * 16), hq = tid - tt * (H * 16), h = hq >> 4, q = hq & 15;
+            if (q < Q) {
+                float4 acc = ld4(s_part + 4 * tid);
+#pragma unroll
+                for (int g = 1; g < NG; ++g) {
+                    const float4 x = ld4(s_part + 4 * (g * NC4 + tid));
+                    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                }
+                st4(out + tt * HC + h * Cp + 4 * q, acc);
+            }
+        }
     }
-    if (tid < 16) {                                           // d_M[type tt][head hh]: lanes 16 j + 4 hh + kk of every vector wave
+    if (tid < 16) {                                           // d_M[type tt][head hh]: the vector waves' totals in wave order
         const int tt = tid >> 2, hh = tid & 3;
         float sum = 0.f;
         if (hh < H) {
-            for (int v = 0; v < V; ++v)
-                for (int jk = 0; jk < 16; ++jk) sum += s_ring[(v * 64 + 16 * (jk >> 2) + 4 * hh + (jk & 3)) * 4 + tt];
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum += s_ring[(v * 4 + hh) * 4 + tt];
         }
         out[WSZ + tt * 4 + hh] = sum;
     }

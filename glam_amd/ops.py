@@ -669,7 +669,7 @@ class _TripletLayer(torch.autograd.Function):
     gather/softmax/scatter-add, update GEMM — and the hand-written backward of all of it."""
 
     @staticmethod
-    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None, with_identity=False, first_app=True):
+    def forward(ctx, x_p, ea_p, wn, we, att, wsc, bias, gi, H, slope, carry=None, with_identity=False, first_app=True, no_backward=False):
         """Returns ``out`` — or the tuple ``(out[, x_p itself][, carry])``.  ``with_identity``: the layer's input comes back as a second
         output, the skip connection of a MessageBlock (src_1gp/layer.py:253-265: ``x`` feeds the conv AND ``x + identity``): both gradient
         paths then arrive at THIS node and the d_x product's epilogue sums them (glam_triplet_layer_bwd_params_ell_add) instead of
@@ -708,7 +708,8 @@ class _TripletLayer(torch.autograd.Function):
         ell = gi.ell() if _ws_route(lib, N, H, Cp, Dp, ea_p) else None
         # no backward will come (torch.no_grad(): the evaluation passes of src_1gp/trainer.py:306-327): the inference forward, which keeps
         # neither `aggr` nor `stats` (two thirds of what the launch writes)
-        infer = INFER_FWD and not any(ctx.needs_input_grad) and (ell is not None or bool(lib.glam_triplet_layer_infer_supported(H, Cp, Dp)))
+        # (`no_backward` comes from the caller: inside forward() autograd is off and needs_input_grad ignores torch.no_grad())
+        infer = INFER_FWD and no_backward and (ell is not None or bool(lib.glam_triplet_layer_infer_supported(H, Cp, Dp)))
         aggr, stats = (None, None) if infer else (torch.empty(N, HC, **f), torch.empty(N, 8, **f))
         if ell is not None:
             check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), 1, N,
@@ -763,7 +764,7 @@ class _TripletLayer(torch.autograd.Function):
                 C, H, De, Cp, Dp, _slope = ctx.dims
                 d_carry = _TripletLayer._flush_parked(parked[1], ctx.gi.N, C, H, De, Cp, Dp, wn, we, att,
                                                       f32c(d_carry, "d_carry") if d_carry is not None else None)
-            return (d_alias,) + (None,) * 9 + (d_carry, None, None)
+            return (d_alias,) + (None,) * 9 + (d_carry, None, None, None)
         x_p, ea_p, wn, we, att, staged, xw, a_ij, aggr, stats = ctx.saved_tensors
         C, H, De, Cp, Dp, slope = ctx.dims
         gi = ctx.gi
@@ -803,9 +804,9 @@ class _TripletLayer(torch.autograd.Function):
             parked = scope.bwd.setdefault(("triplet-parked", id(wn)), (wn, []))[1]
             parked.append((ws, tuple(info), x_p, aggr, d_out))
             if not ctx.first_app:
-                return d_x, d_ea, None, None, None, None, None, None, None, None, d_carry, None, None
+                return d_x, d_ea, None, None, None, None, None, None, None, None, d_carry, None, None, None
             carry_in = _TripletLayer._flush_parked(parked, N, C, H, De, Cp, Dp, wn, we, att, f32c(d_carry, "d_carry") if d_carry is not None else None)
-            return d_x, d_ea, None, None, None, None, None, None, None, None, carry_in, None, None
+            return d_x, d_ea, None, None, None, None, None, None, None, None, carry_in, None, None, None
         if have_carry or ell_t is not None:
             # the gradient accumulated by the later applications of the block is summed by k_param_grads itself
             c_parts = f32c(d_carry, "d_carry").split(sizes) if have_carry else (None,) * 5
@@ -825,8 +826,8 @@ class _TripletLayer(torch.autograd.Function):
             if d_alias is not None and not in_kernel:
                 d_x = d_x.add_(d_alias)
             if ctx.carried:
-                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry)), None, None
-            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None, None
+                return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if (have_carry or d_carry is None) else flatg.add_(d_carry)), None, None, None
+            return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None, None, None
         check(lib.glam_triplet_layer_bwd_params(ptr(x_p), ptr(ea_p), ptr(staged), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats),
                                                 ptr(d_out), ptr(gi.rowptr), ptr(gi.src), ptr(gi.eid), ptr(colptr), ptr(dst),
                                                 ptr(eid_t), N, E, C, H, De, Cp, Dp, slope, ptr(wn), ptr(we), ptr(att), ptr(d_x),
@@ -835,8 +836,8 @@ class _TripletLayer(torch.autograd.Function):
         if d_alias is not None:
             d_x = d_x.add_(d_alias)
         if ctx.carried:
-            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None, None
-        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None, None
+            return d_x, d_ea, None, None, None, None, None, None, None, None, (flatg if d_carry is None else flatg.add_(d_carry)), None, None, None
+        return d_x, d_ea, d_wn, d_we, d_att, d_wsc, d_bias, None, None, None, None, None, None, None
 
 
 # The layer through the torch-extension operator (torch.ops.glam.triplet_layer: C++ autograd node, no ctypes marshalling, no Python
@@ -907,7 +908,9 @@ def triplet_layer(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, 
     first = not (hit is not None and hit[0] is weight_node)      # the layer's first application of this pass: its backward runs LAST
     carry = _carry_for(key, params, sum(sizes), lambda flat: [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)])
     if carry is None:
-        return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, None, with_identity)
+        # no backward can follow (torch.no_grad(), or nothing that requires a gradient): the inference forward
+        no_backward = not (torch.is_grad_enabled() and any(t.requires_grad for t in (x_p, ea_p) + params))
+        return _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, None, with_identity, True, no_backward)
     # the parameters still enter as inputs (the kernels read them, and the scope's staging cache is keyed on them), but this
     # node returns no gradient for them: it flows through `carry`
     res = _TripletLayer.apply(x_p, ea_p, weight_node, weight_edge, att, weight_scale, bias, gi, heads, slope, carry, with_identity, first)
