@@ -101,6 +101,7 @@ SIGNATURES = {
     "glam_wgrad_gemm_linear_sets": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "glam_wgrad_gemm_linear": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "glam_wgrad_gemm_split": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "glam_wgrad_gemm_split_relu": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "glam_gru_make_images": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "glam_loss_workspace_bytes": (_sz, []),
     "glam_loss_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -100,6 +100,12 @@ __device__ __forceinline__ float4 ld4g(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float ld1g(const float* p) { return *(const glam_gf1*)(p); }
+// ... with the non-temporal policy: an operand ONE workgroup reads ONCE (a streamed row block) need not displace the lines other waves
+// gather from the XCD's L2 (MI355X_MICROARCH.md, nt-weights row: issued -> landed -18 % on streamed-once data)
+__device__ __forceinline__ float4 ld4nt(const float* p) {
+    const glam_v4f v = __builtin_nontemporal_load((const glam_gv4*)(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void st4g(float* p, float4 v) { *(glam_gv4*)(p) = (glam_v4f){v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st1g(float* p, float v) { *(glam_gf1*)(p) = v; }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

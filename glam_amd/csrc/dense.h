@@ -40,6 +40,8 @@ struct WgArgs {
     int nseg; int seg_rows;
     const float* segP1[2]; const float* segP2[2]; const float* segQ[2];
     int rows_per_split;                    // k_wgrad_x3 (wgrad_x3.hip): rows of a block, a multiple of 32 (plan_wgrad_x3)
+    const float* pmask;                    // k_wgrad<.., PMASK>: P1 is used as P1 * (pmask > 0), pmask laid out like P1 (the ReLU behind a linear:
+                                           // its backward folded into the weight-gradient product, glam_wgrad_gemm_split_relu)
 };
 
 // Two independent products may share one launch (blocks [0, first_b) work on job a, the rest on job b).

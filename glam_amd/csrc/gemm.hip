@@ -523,13 +523,17 @@ constexpr int kWgWaves = kWgBlock / 64;
 // lanes whose 4 columns are the virtual ones column / zero padding read their operand from here with a row stride of 0 (no selects in
 // the loop, no registers for the constants)
 __device__ float4 g_wg_const[2] = {{1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // not const: global address space, plain global loads
+__device__ float4 g_wg_pass = {1.f, 1.f, 1.f, 1.f};       // the mask of the lanes a PMASK product does not mask (stride 0)
 
 #ifndef GLAM_WG_ROLL
 #define GLAM_WG_ROLL 1
 #endif
 
-template <bool CELU, bool SEG>
+// PMASK: P1 enters as P1 * (pmask > 0) — the backward of a ReLU in front of the product (dy of LinearBlock + ReLU, src_1gp/layer.py:232-237)
+// applied where dy is consumed instead of by an elementwise launch of its own
+template <bool CELU, bool SEG, bool PMASK = false>
 __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
+    static_assert(!(SEG && PMASK), "the masked product has one operand set");
     __shared__ float s_red[kWgWaves * 32 * 64];        // half of the 64 accumulator registers at a time: 64 KB
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, kq = lane >> 4;
     const bool second = (int)blockIdx.x >= two.first_b;
@@ -551,6 +555,9 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
     const float* qsrc = reinterpret_cast<const float*>(&g_wg_const[(a.qones && qcol == a.J) ? 0 : 1]);
     int qld = 0;
     if (qcol < a.J) { qsrc = a.Q + qcol; qld = a.ldq; }
+    const float* msrc = reinterpret_cast<const float*>(&g_wg_pass);
+    int mld = 0;
+    if (PMASK && pcol < a.I1) { msrc = a.pmask + pcol; mld = a.ldp1; }
 
     v4f acc[4][4];
 #pragma unroll
@@ -559,8 +566,9 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     constexpr int kSteps = GLAM_WG_STEPS;   // rows/4 per batch
-    auto mma = [&](float4 pv, float4 qv) {
+    auto mma = [&](float4 pv, float4 qv, float4 mv = f4zero()) {
         if (CELU && a.q_celu) qv = celu4(qv);        // wave-uniform; celu is the identity on the constant lanes' 1 and 0
+        if (PMASK) { pv.x = mv.x > 0.f ? pv.x : 0.f; pv.y = mv.y > 0.f ? pv.y : 0.f; pv.z = mv.z > 0.f ? pv.z : 0.f; pv.w = mv.w > 0.f ? pv.w : 0.f; }
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -577,6 +585,30 @@ __global__ void __launch_bounds__(kWgBlock) k_wgrad(WgArgs2 two) {
         const float* pn = ps + (size_t)(r0 + kq) * pld;
         const float* qn = qs + (size_t)(r0 + kq) * qld;
         const int pstep = 4 * pld, qstep = 4 * qld;        // floats between consecutive steps of a lane
+        if constexpr (PMASK) {
+            // (the masked product is the small one behind the first linear: the plain batch loop, the mask rows requested with the operands)
+            const float* mn = msrc + (size_t)(r0 + kq) * mld;
+            const int mstep = 4 * mld;
+            for (int n0 = r0; n0 < r1; n0 += 4 * kSteps) {
+                float4 pt[kSteps], qt[kSteps], mt[kSteps];
+#pragma unroll
+                for (int st = 0; st < kSteps; ++st) {
+                    const int rr = min(n0 + 4 * st + kq, r1 - 1) - (r0 + kq);      // clamped: unconditional loads, zeroed below
+                    pt[st] = ld4g(pn + (size_t)rr * pld);
+                    qt[st] = ld4g(qn + (size_t)rr * qld);
+                    mt[st] = ld4g(mn + (size_t)rr * mld);
+                }
+#pragma unroll
+                for (int st = 0; st < kSteps; ++st) {
+                    if (n0 + 4 * st < r1) {                 // wave-uniform
+                        if (n0 + 4 * st + kq >= r1) pt[st] = f4zero();
+                        mma(pt[st], qt[st], mt[st]);
+                    }
+                }
+            }
+            (void)pstep; (void)qstep; (void)mstep; (void)nfull;
+            return;
+        }
     #if GLAM_WG_ROLL
         // rolling prefetch: the operands of step st of the NEXT batch are requested as soon as this batch's step st has issued its MFMAs
         // (its registers are free from then on): every load flies under 16 (kSteps - 1) of the wave's own MFMAs besides the other waves'
@@ -954,7 +986,7 @@ static int wgrad_x3_rows() {       // (read at every launch: the tests switch it
 
 int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, ReduceJob* job, bool many_splits) {
     int blocks = 0;
-    if (many_splits && a.N >= wgrad_x3_rows() && wgrad_x3_enabled()) {
+    if (many_splits && a.N >= wgrad_x3_rows() && wgrad_x3_enabled() && !a.pmask) {
         if (int rc = plan_wgrad_x3(a, out, si, sj, kWgradBlocks, job, &blocks)) return rc;
         return launch_wgrad_x3(WgArgs2{a, a, blocks}, blocks, s);
     }
@@ -963,8 +995,11 @@ int launch_wgrad_partials(WgArgs a, float* out, int si, int sj, hipStream_t s, R
         return fail(GLAM_E_UNSUPPORTED, "wgrad: %d operand sets of %d rows are too short for a wave's %d rows (run them one by one)", a.nseg,
                     a.seg_rows, a.rows_per_wave);
     WgArgs2 two{a, a, blocks};
-    GLAM_PROF_LABEL(a.nseg > 1 ? "k_wgrad<true, sets>" : a.q_celu ? "k_wgrad<true>" : "k_wgrad<false>");      // (the labels bench.py's kernel table is keyed by)
-    if (a.nseg > 1) hipLaunchKernelGGL((k_wgrad<true, true>), dim3(blocks), dim3(kWgBlock), 0, s, two);
+    GLAM_PROF_LABEL(a.pmask ? "k_wgrad<relu mask>" : a.nseg > 1 ? "k_wgrad<true, sets>" : a.q_celu ? "k_wgrad<true>" : "k_wgrad<false>");      // (the labels bench.py's kernel table is keyed by)
+    if (a.pmask) {
+        if (a.nseg > 1 || a.q_celu) return fail(GLAM_E_UNSUPPORTED, "wgrad: the masked product takes one operand set and no folded CELU");
+        hipLaunchKernelGGL((k_wgrad<false, false, true>), dim3(blocks), dim3(kWgBlock), 0, s, two);
+    } else if (a.nseg > 1) hipLaunchKernelGGL((k_wgrad<true, true>), dim3(blocks), dim3(kWgBlock), 0, s, two);
     else if (a.q_celu) hipLaunchKernelGGL((k_wgrad<true, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
     else hipLaunchKernelGGL((k_wgrad<false, false>), dim3(blocks), dim3(kWgBlock), 0, s, two);
     GLAM_LAUNCH_CHECK("wgrad");
@@ -1382,8 +1417,21 @@ static int wgrad_linear_impl(const char* fn, int nseg, const float* const* Ps, c
 
 // [d_W | d_b] of one linear y = [x | 1] W^T, weight and bias into SEPARATE contiguous tensors (autograd takes them as they are; a
 // strided view of a combined buffer costs a copy launch each): dw[I, J] = P^T Q, db[I] = column sums of P.  J + 1 <= 64.
+static int wgrad_gemm_split(const float* P, const float* pmask, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N,
+                            void* ws, size_t ws_bytes, void* stream);
 extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N,
                                      void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_gemm_split(P, nullptr, I, ldp, Q, J, ldq, dw, db, N, ws, ws_bytes, stream);
+}
+// ... of a linear whose output went through a ReLU (LinearBlock + ReLU, src_1gp/layer.py:232-237): P = dy * (Y > 0), Y f32[N, I] with
+// P's row stride = the saved output — the ReLU's backward inside the product instead of an elementwise launch in front of it
+extern "C" int glam_wgrad_gemm_split_relu(const float* P, const float* Y, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db,
+                                          int64_t N, void* ws, size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(Y && aligned16(Y), "glam_wgrad_gemm_split_relu: null / misaligned mask");
+    return wgrad_gemm_split(P, Y, I, ldp, Q, J, ldq, dw, db, N, ws, ws_bytes, stream);
+}
+static int wgrad_gemm_split(const float* P, const float* pmask, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N,
+                            void* ws, size_t ws_bytes, void* stream) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_wgrad_gemm_split: N out of range");
     GLAM_REQUIRE(dw && db, "glam_wgrad_gemm_split: null output");
     // J need not be a multiple of 4 when the rows of Q are (ldq >= ceil4(J)): the product runs over the padded width and the reduction
@@ -1403,6 +1451,7 @@ extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float
     GLAM_REQUIRE(aligned16(Q) && aligned16(P), "glam_wgrad_gemm_split: P / Q must be 16-byte aligned");
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     WgArgs a{P, I, ldp, nullptr, 0, 0, 0, Q, J, ldq, 1, (int)N, 0, partial, 0, 0};
+    a.pmask = pmask;
     ReduceArgs ra{};
     ra.njobs = 1;
     if (int rc = launch_wgrad_partials(a, dw, Jw, 1, s, &ra.job[0])) return rc;

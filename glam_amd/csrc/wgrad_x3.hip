@@ -31,6 +31,9 @@
 
 namespace glam {
 
+#ifndef GLAM_WX_NT
+#define GLAM_WX_NT 0      // 1: the producers' row loads with the non-temporal policy (every operand row is read once, by one block)
+#endif
 constexpr int kWxProd = 4, kWxCons = 4, kWxSlabs = 3;
 constexpr int kWxThreads = (kWxProd + kWxCons) * 64;
 constexpr int kWxUnit = 1024;                  // one column class t of one group: [16 c][4 kb] x 16 bytes
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(kWxThreads) k_wgrad_x3(WgArgs2 two) {
         auto load = [&](int s, float4 (&v)[8]) {
             const int rb = row0 + 32 * s + 8 * kb;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = ld4(src + (size_t)min(rb + i, row1 - 1) * ld);
+            for (int i = 0; i < 8; ++i) v[i] = GLAM_WX_NT ? ld4nt(src + (size_t)min(rb + i, row1 - 1) * ld) : ld4(src + (size_t)min(rb + i, row1 - 1) * ld);
 #ifdef GLAM_WX_NOLOAD       // timing experiment only (wrong numbers): every step re-reads the block's first rows (cache hits)
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = ld4(src + (size_t)min(row0 + 8 * kb + i, row1 - 1) * ld);

@@ -214,7 +214,7 @@ def no_graphed_call():
 # module-level A/B switches of glam_amd.ops and the library's environment switches: a captured graph bakes the route in, so they are part
 # of a graph's key (flipping one between two calls of a model — the parity tests do — must not replay the other route)
 _OPS_KNOBS = ("VALIDATE", "WS_ROUTE", "GRAD_CARRY", "CACHED_STAGING", "USE_TORCH_EXT", "GEMM_PAIR", "GRU_FUSED", "GRU_FUSED_MIN_NODES", "GRU_WS",
-              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "GRU_PRE", "DENSE_SPLITK", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR", "INFER_FWD")
+              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "GRU_PRE", "DENSE_SPLITK", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR", "INFER_FWD", "RELU_IN_WGRAD")
 _ENV_KNOBS = ("GLAM_X3", "GLAM_WS", "GLAM_WGRAD_X3", "GLAM_WGRAD_X3_ROWS", "GLAM_TALL_X3", "GLAM_WS_GRID")
 
 
@@ -376,12 +376,13 @@ class GraphedCallable:
         # fine-tuning schedule flips requires_grad on the same objects.  Any difference: walk again, and drop every graph unless the walk
         # finds the very same (object, requires_grad, address) set.
         params = self._params
-        probe = None if self._all is None else tuple((p.data_ptr(), p.requires_grad) for p in self._all)
+        # (two list comprehensions: 3 us for the default model's 15 parameters; a generator of pairs costs 7)
+        probe = None if self._all is None else ([p.data_ptr() for p in self._all], [p.requires_grad for p in self._all])
         if params is None or next(module.parameters(), None) is not self._first or probe != self._probe:
             self._all = tuple(module.parameters())
             self._first = self._all[0] if self._all else None
             params = self._params = tuple(p for p in self._all if p.requires_grad)
-            self._probe = tuple((p.data_ptr(), p.requires_grad) for p in self._all)
+            self._probe = ([p.data_ptr() for p in self._all], [p.requires_grad for p in self._all])
             pkey = tuple((id(p), p.requires_grad, p.data_ptr(), p.dtype, p.device) for p in self._all)
             if pkey != self._param_key:
                 self.clear()

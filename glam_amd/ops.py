@@ -1225,6 +1225,9 @@ NORM_DROP = True
 PRESTAGE = True
 # the readout MLP's linear on csrc/dense_x3.hip (0: the GEMM library + separate activation / mask / column-sum launches): A/B switch
 DENSE_LINEAR = True
+# the backward of a ReLU fused into a linear, inside that linear's weight-gradient product (glam_wgrad_gemm_split_relu) where the product
+# is the gradient's only consumer: A/B switch (False: an elementwise launch in front of the product)
+RELU_IN_WGRAD = True
 # a TripletMessage forward that no backward can follow (torch.no_grad()) stores neither aggr nor stats: A/B switch
 INFER_FWD = os.environ.get("GLAM_INFER_FWD", "1") != "0"
 

@@ -67,10 +67,14 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors[:2]
         dy = f32c(dy, "dy")
-        if len(ctx.saved_tensors) == 3:      # the fused ReLU: dy * (y > 0)
-            dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[2], 0.0)
         N, K = x.shape
         M = w.size(0)
+        y_relu = ctx.saved_tensors[2] if len(ctx.saved_tensors) == 3 else None
+        # the fused ReLU's backward dy * (y > 0): inside the weight-gradient product where that is dy's only consumer (the first linear
+        # of the model: atom features need no gradient), an elementwise launch otherwise
+        mask_in_product = y_relu is not None and _o.RELU_IN_WGRAD and not ctx.needs_input_grad[0] and K + 1 <= 64
+        if y_relu is not None and not mask_in_product:
+            dy = torch.ops.aten.threshold_backward(dy, y_relu, 0.0)
         lib, dev = _lib.load(), x.device
         f = dict(dtype=torch.float32, device=dev)
         dx = None
@@ -90,8 +94,12 @@ class _Linear(torch.autograd.Function):
             # (a weight narrower than the zero-padded input, 15 -> 16 columns: the reduction writes its real columns only)
             Kw = w.size(1)
             dw, db = torch.empty(M, Kw, **f), torch.empty(M, **f)
-            check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
-                  "glam_wgrad_gemm_split")
+            if mask_in_product:
+                check(lib.glam_wgrad_gemm_split_relu(ptr(dy), ptr(y_relu), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
+                      "glam_wgrad_gemm_split_relu")
+            else:
+                check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
+                      "glam_wgrad_gemm_split")
             return dx, dw, (db if ctx.has_bias else None), None
         dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
         if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]

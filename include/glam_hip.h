@@ -259,6 +259,10 @@ int glam_wgrad_gemm_linear_sets(int nseg, const float* const* P, int I, int ldp,
  * multiple of 4 when ldq >= ceil4(J) (a weight narrower than its zero-padded input: dw stays contiguous [I, J]). */
 int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N, void* ws,
                           size_t ws_bytes, void* stream);
+/* ... of a linear whose output went through a ReLU (LinearBlock + ReLU, src_1gp/layer.py:232-237): P = dy * (Y > 0) with Y f32[N, I]
+ * (row stride ldp) = the saved output — the ReLU's backward inside the product instead of an elementwise launch in front of it. */
+int glam_wgrad_gemm_split_relu(const float* P, const float* Y, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db,
+                               int64_t N, void* ws, size_t ws_bytes, void* stream);
 /* out[N, M] = max(A[N, K] @ W + bias, 0): the Linear + ReLU of a LinearBlock (src_1gp/layer.py:232-237) whose shape runs on the
  * warp-specialised tall kernel (glam_ts_gemm_relu_supported(K, M): the input embeddings 15 -> 60 of the parity configuration and of the
  * two-tower models) — the activation in the product's epilogue instead of an elementwise launch behind it.  Wimg, alignment and

@@ -3165,6 +3165,32 @@ def test_linear_block_relu_in_the_tall_products_epilogue(device, N, K, M, diff_x
     assert lib.glam_ts_gemm_relu_supported(300, 1024) == 0 and lib.glam_ts_gemm_relu_supported(15, 60) == 0
 
 
+@pytest.mark.parametrize("N", [1, 37, 606, 20400, 40000])
+def test_relu_backward_inside_the_weight_gradient_product(device, N, monkeypatch):
+    """The first linear of the models (15 -> 60 + ReLU, src_1gp/model.py:40; atom features need no gradient): the ReLU's backward
+    ``dy * (y > 0)`` runs inside the weight-gradient product (glam_wgrad_gemm_split_relu: one launch less per step) — the gradients of the
+    elementwise-launch route bit for bit, at sizes on both sides of the row counts where the product changes its grid."""
+    from glam_amd import _lib
+    torch.manual_seed(N)
+    blk = layer.LinearBlock(15, 60, act="ReLU()").to(device)
+    x = torch.randn(N, 15, device=device)
+    cot = torch.randn(N, 60, device=device)
+    res = {}
+    for inside in (True, False):
+        monkeypatch.setattr(ops, "RELU_IN_WGRAD", inside)
+        y = blk(x)
+        with _lib.kernel_timer(capacity=16) as kt:
+            res[inside] = torch.autograd.grad(y, [blk.linear.weight, blk.linear.bias], cot)
+        names = [n for n, _, _ in kt.records()]
+        assert any("relu mask" in n for n in names) == inside, names
+    for u, v in zip(res[True], res[False]):
+        assert torch.equal(u, v)
+    yd = torch.relu(torch.nn.functional.linear(x.double(), blk.linear.weight.double(), blk.linear.bias.double()))
+    gd = cot.double() * (yd > 0)
+    assert_close(res[True][0], gd.t() @ x.double(), 3e-6 * max(1.0, N ** 0.5 / 10), "d_weight")
+    assert_close(res[True][1], gd.sum(0), 3e-6 * max(1.0, N ** 0.5 / 10), "d_bias")
+
+
 def test_linear_block_routes_the_readout_mlp_to_the_dense_kernel(device):
     """LinearBlock(300, 1024, act=ReLU) — `mol_flat` of the parity configuration — runs as one dense launch each way and agrees with
     the unfused composition; shapes outside the class (K = 450: rows not 16-byte multiples) keep the library route."""
