@@ -1427,7 +1427,7 @@ extern "C" int glam_wgrad_gemm_split(const float* P, int I, int ldp, const float
 // P's row stride = the saved output — the ReLU's backward inside the product instead of an elementwise launch in front of it
 extern "C" int glam_wgrad_gemm_split_relu(const float* P, const float* Y, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db,
                                           int64_t N, void* ws, size_t ws_bytes, void* stream) {
-    GLAM_REQUIRE(Y && aligned16(Y), "glam_wgrad_gemm_split_relu: null / misaligned mask");
+    GLAM_REQUIRE((Y || N == 0) && aligned16(Y), "glam_wgrad_gemm_split_relu: null / misaligned mask");
     return wgrad_gemm_split(P, Y, I, ldp, Q, J, ldq, dw, db, N, ws, ws_bytes, stream);
 }
 static int wgrad_gemm_split(const float* P, const float* pmask, int I, int ldp, const float* Q, int J, int ldq, float* dw, float* db, int64_t N,

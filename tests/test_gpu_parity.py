@@ -3184,7 +3184,10 @@ def test_relu_backward_inside_the_weight_gradient_product(device, N, monkeypatch
         names = [n for n, _, _ in kt.records()]
         assert any("relu mask" in n for n in names) == inside, names
     for u, v in zip(res[True], res[False]):
-        assert torch.equal(u, v)
+        if N < 32768:
+            assert torch.equal(u, v)
+        else:       # (from 32 768 rows the unmasked product runs on k_wgrad_x3, the masked one stays on k_wgrad: other roundings)
+            assert_close(u, v, 3e-6 * N ** 0.5 / 10, "masked vs unmasked route")
     yd = torch.relu(torch.nn.functional.linear(x.double(), blk.linear.weight.double(), blk.linear.bias.double()))
     gd = cot.double() * (yd > 0)
     assert_close(res[True][0], gd.t() @ x.double(), 3e-6 * max(1.0, N ** 0.5 / 10), "d_weight")
