@@ -158,6 +158,7 @@ def test_inference_forward_launches_and_c_abi(device, monkeypatch):
     N = b.x.size(0)
     x = torch.randn(N, 60, device=device)
     monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    monkeypatch.setattr(ops, "INFER_FWD", True)
     outs, labels = {}, {}
     for route in ("auto", "0"):
         monkeypatch.setattr(ops, "WS_ROUTE", route)
@@ -2286,7 +2287,7 @@ def test_torch_extension_ops_match_the_ctypes_route(device, monkeypatch):
     assert torch.isfinite(G.segment_pool(h, sp.ptr, 0)).all()
 
 
-@pytest.mark.parametrize("C,H,B", [(60, 3, 1024), (60, 3, 7), (40, 4, 200), (64, 2, 90), (45, 3, 150), (60, 1, 64)])
+@pytest.mark.parametrize("C,H,B", [(60, 3, 1024), (60, 3, 7), (40, 4, 200), (64, 2, 90), (45, 3, 150), (60, 1, 64), (36, 3, 100), (52, 2, 33), (37, 1, 20)])
 def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkeypatch, C, H, B):
     """csrc/triplet_ws.hip / triplet_ws_b1.hip (producer waves gather, consumer waves run the fused GEMM out of an LDS tile ring; what the
     op launches for molecular graphs at every size) against the general fused kernels: output and the gradients of x, weight_node,
@@ -3176,13 +3177,15 @@ def test_relu_backward_inside_the_weight_gradient_product(device, N, monkeypatch
     x = torch.randn(N, 15, device=device)
     cot = torch.randn(N, 60, device=device)
     res = {}
+    fused = bool(_lib.load().glam_ts_gemm_relu_supported(16, 60))      # (GLAM_X3=0: no ReLU epilogue, so no mask to fold either)
+    monkeypatch.delenv("GLAM_WGRAD_X3_ROWS", raising=False)
     for inside in (True, False):
         monkeypatch.setattr(ops, "RELU_IN_WGRAD", inside)
         y = blk(x)
         with _lib.kernel_timer(capacity=16) as kt:
             res[inside] = torch.autograd.grad(y, [blk.linear.weight, blk.linear.bias], cot)
         names = [n for n, _, _ in kt.records()]
-        assert any("relu mask" in n for n in names) == inside, names
+        assert any("relu mask" in n for n in names) == (inside and fused), names
     for u, v in zip(res[True], res[False]):
         if N < 32768:
             assert torch.equal(u, v)
