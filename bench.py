@@ -20,6 +20,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   roofline_kernels  every kernel of the step: durations from per-dispatch begin/end timestamps (glam_prof_*:
                     hipExtLaunchKernel events, the figures a rocprofv3 kernel trace reports) taken in THIS run from
                     eager executions of the very function the graph captured; bytes / flops per DESIGN.md §4
+  roofline_inference the forward under torch.no_grad() (the reference's evaluation passes): the inference instantiation of the same kernel
   roofline_isolated the aggregate kernels alone (no fused GEMM; general and software-pipelined forward), SURVEY.md §8(d)'s formula
   roofline_large    the same kernels at B = 16 384 (working set beyond the 256 MiB LLC); frac = the forward scatter-aggregate
   cpu_baseline      the CPU oracle (reference-shaped port, oracle/glam_oracle.py) timed on this host
@@ -67,6 +68,9 @@ def step_kernel_model(N, E, H=3, C=60, De=4):
         "k_triplet_fwd_ws+update": {"bound": "hbm", "bytes": agg_fwd + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
                                     "note": "warp-specialised: 8 producer waves run the software-pipelined aggregate, 4 consumer waves the update GEMM "
                                             "out of an LDS tile ring (csrc/triplet_ws.hip); the op's choice for molecular graphs at every size"},
+        # torch.no_grad() (src_1gp/trainer.py:306-327): neither aggr nor stats is stored
+        "k_triplet_fwd_ws<inference>+update": {"bound": "hbm", "bytes": agg_fwd - f * (N * HC + 2 * N * H) + f * N * C + img(HC, C), "flops": 2 * N * HC * C,
+                                               "note": "the inference instantiation: reads xw (gather), a_ij, edge records; writes out only"},
         "k_triplet_fwd": {"bound": "hbm", "bytes": agg_fwd},
         "k_triplet_fwd_pipe": {"bound": "hbm", "bytes": agg_fwd,
                                "note": "software-pipelined forward aggregate (csrc/triplet_pipe.hip), same arithmetic and SURVEY §8(d) byte model"},
@@ -554,6 +558,13 @@ def main():
         leg("roofline_kernels (eager profiled steps)")
         result["roofline_kernels"] = {"source": f"glam_prof_* per-dispatch timestamps, {args.prof_reps} eager executions of the captured step function "
                                                 "after the timed region", "sum_kernel_us_per_step": step_kernel_us, "kernels": kernels}
+        # the inference forward (what the evaluation passes of the reference's trainer launch: no aggr / stats store), same batch
+        def infer():
+            with torch.no_grad(), ops.cached_staging():
+                conv(x.detach(), batch.edge_index, batch.edge_attr)
+        pi = profile_step(infer, args.prof_reps)
+        result["roofline_inference"] = {n: dict(r, **(rate(model[n], r["avg_us"]) if n in model else {})) for n, r in pi.items()}
+        leg("roofline_inference")
         iso = time_isolated_aggregate(conv, batch, x.detach(), args.prof_reps)
         result["roofline_isolated"] = {n: dict(r, **rate(model[n], r["avg_us"])) for n, r in iso.items() if n in model}
         leg("roofline_isolated")
