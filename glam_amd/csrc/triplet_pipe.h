@@ -29,6 +29,8 @@ constexpr int kWsCons = 4;                // consumer waves: one 16-column tile 
 constexpr int kWsRing = GLAM_WS_RING;     // tile slots between producers and consumers
 // LDS pitch (floats) of the W_edge rows (one row of H * Cp floats per bond type) in the warp-specialised kernels: a multiple of 64
 __host__ __device__ constexpr int ws_wedge_pitch(int HC) { return (HC + 63) & ~63; }
+// ... as a function of the head count alone (H * Cp <= 64 H): a compile-time constant in the kernels
+__host__ __device__ constexpr int ws_wedge_pitch_h(int H) { return 64 * H; }
 
 // lane n of the caller's 16-lane row (the lanes of one node) -> every lane of the row: one v_mov_b32_dpp row_newbcast (no LDS)
 template <int CTRL>

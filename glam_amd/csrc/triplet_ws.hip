@@ -245,7 +245,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     // W_edge rows (one per bond type) sit WP = a multiple of 64 floats apart: the rows of two nodes with DIFFERENT bond types then start
     // on the same bank, and a 16-lane ds_read_b128 group that mixes lanes of two nodes stays conflict free (a pitch of HC = 180 floats
     // put them 52 banks apart: 18 % of the forward's LDS cycles, 35-38 % of the backward kernels', were bank conflicts)
-    const int WP = ws_wedge_pitch(HC), WSZ = DE * WP, LDT = HC + 4;
+    constexpr int WP = ws_wedge_pitch_h(H);                 // (a compile-time pitch: the row offset of a bond type is a shift-add, not a 32-bit multiply)
+    const int WSZ = DE * WP, LDT = HC + 4;
     constexpr int kSideF = 2 * 64 * 4;                        // side table of one pass: piece 1 (a_j | a_i), piece 2 (edge_attr), 1 KB each
     float* s_w = smem;
     int* s_ready = reinterpret_cast<int*>(smem + WSZ);        // [kWsRing] producer check-ins per slot (monotonic)
@@ -550,7 +551,8 @@ __global__ void __launch_bounds__((P + kWsCons) * 64, (P + kWsCons) / 4) k_tripl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cp = a.Cp, Q = Cp >> 2, HC = H * Cp;
-    const int WP = ws_wedge_pitch(HC), WSZ = DE * WP, KX = HC + 8;     // W_edge row pitch: see k_triplet_fwd_ws
+    constexpr int WP = ws_wedge_pitch_h(H);                 // W_edge row pitch: see k_triplet_fwd_ws
+    const int WSZ = DE * WP, KX = HC + 8;
     const int LDT = KX + ((68 - (KX & 63)) & 63);             // row pitch = 4 mod 64 words: conflict-free A-fragment reads
     constexpr int kSideF = 3 * 64 * 4;                        // alpha_e (| d_a_i in lane 4) | dpre_e | edge_attr, 1 KB each
     float* s_w = smem;
@@ -778,7 +780,7 @@ static int launch_src_ws_px(const SrcWsArgs& a, int grid, hipStream_t s) {
     if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_triplet_bwd_src_ws<H, P, X3, ADD, WT>), big, "triplet_bwd_src_ws")) return rc;
     const int HC = H * a.Cp, KX = HC + 8, LDT = KX + ((68 - (KX & 63)) & 63);
     const size_t ring = X3 ? (size_t)kWsRingX3 * kX3TileBytes : (size_t)kWsRing * 16 * LDT * sizeof(float);
-    const size_t lds = ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 3 * 64 * 4) * sizeof(float) + ring;
+    const size_t lds = ((size_t)4 * ws_wedge_pitch_h(H) + 64 + (size_t)P * 2 * 3 * 64 * 4) * sizeof(float) + ring;
     GLAM_PROF_LABEL("k_triplet_bwd_src_ws+dx");
     hipLaunchKernelGGL((k_triplet_bwd_src_ws<H, P, X3, ADD, WT>), dim3(grid), dim3((P + kWsCons) * 64), lds, s, a);
     return GLAM_OK;
@@ -824,7 +826,7 @@ int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* d
 static size_t ws_lds_bytes(int H, int Cp, int P, bool x3) {
     const int HC = H * Cp;
     const size_t ring = x3 ? (size_t)kWsRingX3 * kX3TileBytes : (size_t)kWsRing * 16 * (HC + 4) * sizeof(float);
-    return ((size_t)4 * ws_wedge_pitch(HC) + 64 + (size_t)P * 2 * 2 * 64 * 4) * sizeof(float) + ring;
+    return ((size_t)4 * ws_wedge_pitch_h(H) + 64 + (size_t)P * 2 * 2 * 64 * 4) * sizeof(float) + ring;
 }
 
 template <int H, int P, bool X3, bool WT = false, bool INF = false>

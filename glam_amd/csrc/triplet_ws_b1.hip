@@ -115,8 +115,8 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
     // lanes of two nodes is conflict free (pitch HC = 180: 35-43 % of this kernel's LDS cycles were bank conflicts)
     // The d_W_edge arrays take a head per 64 floats (WD = 64 H per bond type): every one of a row's 16 lanes owns a float4 of every head —
     // also the lanes beyond the row's Cp / 4 chunks, whose products are zero — so the accumulator update below is unconditional
-    const int WSZ = 4 * HC, WP = ws_wedge_pitch(HC), WL = 4 * WP, LDT = HC + 8, P = WSZ + 16;
-    constexpr int WD = 64 * H, WLD = 4 * WD;
+    constexpr int WP = ws_wedge_pitch_h(H), WL = 4 * WP, WD = WP, WLD = 4 * WD;
+    const int WSZ = 4 * HC, LDT = HC + 8, P = WSZ + 16;
     constexpr int kRing = 4;                                  // tile slots (the d_W_edge arrays take the rest of the LDS)
     float* s_w = smem;
     int* s_ready = reinterpret_cast<int*>(smem + WL);         // [kRing] matrix-wave check-ins per slot
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 
 static size_t b1ws_lds_bytes(int H, int Cp, int V) {
     const int HC = H * Cp;
-    const int WL = 4 * ws_wedge_pitch(HC), WLD = 4 * 64 * H;      // W_edge rows | the d_W_edge arrays [4 types][H][64]
+    const int WL = 4 * ws_wedge_pitch_h(H), WLD = 4 * 64 * H;     // W_edge rows | the d_W_edge arrays [4 types][H][64]
     return ((size_t)WL + 64 + (size_t)V * 4 * WLD + (size_t)4 * 16 * (HC + 8)) * sizeof(float);
 }
 
