@@ -158,13 +158,14 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      const float* img_dx, float* d_x,
                      const float* img_dagg = nullptr, const float* d_out = nullptr, const int32_t* ell_dst = nullptr,
                      const int32_t* ell_eid_t = nullptr, int edge_onehot = 0, const int32_t* ell_src = nullptr,
-                     const int32_t* ell_eid = nullptr, const float* dx_addend = nullptr);     // dx_addend: warp-specialised B2 only
+                     const int32_t* ell_eid = nullptr, const float* dx_addend = nullptr,      // dx_addend: warp-specialised B2 only
+                     const float* dagg_pre = nullptr);      // W_scale^T as pre-split fragments of the warp-specialised B1's matrix waves (layer.hip: Staged)
 // B1 with the d_aggr GEMM inside, warp-specialised (triplet_ws_b1.hip: matrix waves produce the d_aggr tiles ahead of the vector waves)
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
                        const float* stats, const float* d_out, const float* img_dagg, const int32_t* ell_src, const int32_t* ell_eid,
                        int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot, float slope, float* d_aggr, float* alpha_e,
-                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s);
+                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s, const float* dagg_pre = nullptr);
 // B2 + d_x = [d_xw | d_a] @ Wcat^T in one warp-specialised launch (triplet_ws.hip; one-hot edge features of width 4)
 bool triplet_bwd_src_ws_supported(int H, int Cp, int De, int edge_onehot);
 int triplet_bwd_src_ws(const float* d_aggr, const float* alpha_e, const float* dpre_e, const float* edge_attr, const float* w_edge,

@@ -19,8 +19,13 @@ namespace glam {
 
 // layout of the staged-parameter buffer (floats; every offset is a multiple of 4)
 struct Staged {
-    size_t img_node, img_upd, img_dagg, img_dx, we_p, m, bias_p, total;
+    size_t img_node, img_upd, img_dagg, img_dx, we_p, m, bias_p, dagg_pre, total;
 };
+// W_scale^T as the operand fragments of B1's four matrix waves, ALREADY split into their three bf16 terms, in lane order:
+// [wave w][k step st][column tile ct][term][lane] x 16 bytes (kDaggPreFloats floats; H = 3 only).  The matrix waves produce the tiles the
+// vector waves wait for, and their prologue — 24 scattered weight loads, then 400 vector instructions of splits — stood in front of the
+// first tile (r6_ws_timeline_b1024.txt: first tile 4.3 k cycles behind the block's barrier); 36 coalesced 1 KB loads replace it.
+constexpr int kDaggPreFloats = 4 * 2 * 3 * 3 * 64 * 4;
 static Staged staged_layout(int H, int Cp, int Dp) {
     const int HC = H * Cp;
     Staged s;
@@ -32,6 +37,8 @@ static Staged staged_layout(int H, int Cp, int Dp) {
     s.we_p = o;     o += (size_t)Dp * HC;
     s.m = o;        o += (size_t)Dp * 4;
     s.bias_p = o;   o += (size_t)Cp;
+    o = (o + 63) & ~(size_t)63;                          // (256-byte aligned: 1 KB coalesced fragment loads)
+    s.dagg_pre = o; o += (H == 3 && HC <= 192) ? kDaggPreFloats : 0;
     s.total = o;
     return s;
 }
@@ -150,7 +157,8 @@ __device__ __forceinline__ void stage_params_block(const StageArgs& a, int copy_
         return;
     }
     const int n1 = Kp1 * P1, n2 = Kp2 * 64, n3 = Kp1 * P3, n4 = Kp4 * 64, n5 = Dp * HC, n6 = Dp * 4, n7 = Cp;
-    const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7;
+    const int n8 = (H == 3 && HC <= 192) ? 4 * 2 * 3 * 64 : 0;          // pre-split fragments of B1's matrix waves: one item per (w, st, ct, lane)
+    const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7 + n8;
     // image element idx -> (k, logical column m): layout [k/4][p][k%4], column order ts_col_of_pos
     for (int idx = bid * kBlock + threadIdx.x; idx < total; idx += copy_blocks * kBlock) {
         int i = idx;
@@ -193,7 +201,24 @@ __device__ __forceinline__ void stage_params_block(const StageArgs& a, int copy_
             continue;
         }
         i -= n6;
-        a.base[a.L.bias_p + i] = i < C ? a.bias[i] : 0.f;
+        if (i < n7) {
+            a.base[a.L.bias_p + i] = i < C ? a.bias[i] : 0.f;
+            continue;
+        }
+        i -= n7;
+        {   // (w, st, ct, lane = (c, kq)): rows k0 .. k0 + 7 of column mcol of W_scale^T — the values k_triplet_bwd_dst_ws's matrix wave w
+            // reads out of the d_aggr image (w_load8) and splits (w_split8): the same function on the same numbers, bit-identical
+            const int lane = i & 63, f = i >> 6, ct = f % 3, st = (f / 3) & 1, w = f / 6;
+            const int c = lane & 15, kq = lane >> 4, mcol = 16 * (3 * w + ct) + c, k0 = 32 * st + 8 * kq;
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (k0 + u < Cp && mcol < HC) ? wsp_val(a, mcol, k0 + u) : 0.f;
+            const Bf16x3 fr = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+            float* dst = a.base + a.L.dagg_pre + ((size_t)(f * 3) * 64 + lane) * 4;
+            *reinterpret_cast<bf16x8_t*>(dst) = fr.hi;
+            *reinterpret_cast<bf16x8_t*>(dst + 256) = fr.mid;
+            *reinterpret_cast<bf16x8_t*>(dst + 512) = fr.lo;
+        }
     }
 }
 
@@ -880,7 +905,8 @@ static int layer_bwd_impl(const float* x, const float* edge_attr, const float* s
                                   dstaged + G.d_m, d_edge_attr, tws, tws_bytes, s, false, &tpart, &tnblk,
                                   fuse_dx ? staged + L.img_dx : nullptr, fuse_dx ? d_x : nullptr,
                                   fuse_dagg ? staged + L.img_dagg : nullptr, fuse_dagg ? d_out : nullptr, ws_dx ? ell_dst : nullptr,
-                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, dx_addend))
+                                  ws_dx ? ell_eid_t : nullptr, edge_onehot, ell_src, ell_eid, dx_addend,
+                                  (fuse_dagg && L.total > L.dagg_pre) ? staged + L.dagg_pre : nullptr))
         return rc;
     const int WSZ = Dp * HC;
     if (defer_info) {

@@ -126,7 +126,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
                      size_t ws_bytes, hipStream_t s, bool reduce_now, const float** partial_out, int* nblk_out,
                      const float* img_dx, float* d_x, const float* img_dagg,
                      const float* d_out, const int32_t* ell_dst, const int32_t* ell_eid_t, int edge_onehot, const int32_t* ell_src,
-                     const int32_t* ell_eid, const float* dx_addend) {
+                     const int32_t* ell_eid, const float* dx_addend, const float* dagg_pre) {
     Shape sh;
     if (int rc = check_dims("glam_triplet_bwd", N, E, H, Cp, De, &sh)) return rc;
     const int WSZ = emul ? De * H * Cp : 0;
@@ -154,7 +154,7 @@ int triplet_bwd_impl(const float* xw, const float* a_ij, const float* edge_attr,
     const bool b2_ws = ell_dst && ell_eid_t && emul && Cp <= 64 && img_dx && d_x && triplet_bwd_src_ws_supported(H, Cp, De, edge_onehot);
     if (b1_ws) {
         if (int rc = triplet_bwd_dst_ws(xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, N, E, H, Cp, De,
-                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s))
+                                        edge_onehot, slope, const_cast<float*>(d_aggr), alpha_e, dpre_e, d_a_ij, partial, &nblk, s, dagg_pre))
             return rc;
     } else {
     BwdDstArgs b1{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_aggr, rowptr, src, eid, (int)N, Cp, slope,

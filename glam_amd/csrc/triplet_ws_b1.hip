@@ -24,6 +24,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef GLAM_B1_EARLY
+#define GLAM_B1_EARLY 0      // 1: the matrix waves' first product AHEAD of the block's barrier (measured even: 12.6 us either way at B = 1 024 — the
+                             // barrier moves from 6.2 k to 7.1 k cycles, the first tile is out 1.6 k behind it in both forms; bit-identical)
+#endif
+#ifndef GLAM_B1_MPRIO
+#define GLAM_B1_MPRIO 0      // s_setprio of the matrix waves (0: none; 3 measured: B = 1 024 even, B = 16 384 +5 %: NEGATIVES.md)
+#endif
+
 namespace glam {
 
 #ifdef GLAM_WS_TL      // timeline stamps (tools/ws_timeline.py; see triplet_ws.hip): [block][wave][stamp]
@@ -101,6 +109,7 @@ struct DstWsArgs {
     const int* ell_src; const int* ell_eid;      // [N][4] each, by target
     int N; int Cp; float slope;
     float* d_aggr; float* alpha_e; float* dpre_e; float* d_a_ij; float* partial;      // partial[gridDim.x][4 * H * Cp + 16]
+    const float* dagg_pre;      // may be null: W_scale^T as the matrix waves' operand fragments, split already (layer.hip: Staged::dagg_pre)
 };
 
 template <int H, int V, bool X3, bool WT = false>      // WT: the outputs are written through the L2 (small launches; common.h: st4o_wt)
@@ -143,6 +152,12 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
         // ------------------------------------------------------------------------------------------------------------------
         // matrix waves: d_aggr tile[16, HC] = d_out[16 tile .. +15, Cp] @ W_scale^T, columns 48 w .. 48 w + 47 in this wave
         // ------------------------------------------------------------------------------------------------------------------
+#if GLAM_B1_MPRIO
+        // The vector waves WAIT for these tiles (r6_ws_timeline_b*.txt: a tile every 2.9 k cycles from the matrix waves against 1.9 k the
+        // two gather groups could take: the launch runs at the matrix waves' pace at both sizes).  Their vector work — the operand split,
+        // the addresses of the tile stores — shares a SIMD's issue slots with two gather waves: static priority puts it first.
+        __builtin_amdgcn_s_setprio(GLAM_B1_MPRIO);
+#endif
         const int w = wave - V, c = lane & 15, kq = lane >> 4;
         const int MP = HC <= 64 ? 64 : 192;                   // positions per image row
         auto publish_tile = [&](int it_, const v4f (&acc)[3]) {
@@ -155,6 +170,18 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
 #pragma unroll
                     for (int i = 0; i < 4; ++i) tl[(4 * kq + i) * LDT + mcol] = acc[ct][i];
                 }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) flag_bump(s_ready + slot);
+        };
+        // the X3 product's result layout (W as the first operand): lane (node c, column block kq) holds columns 16 (3 w + ct) + 4 kq .. + 3
+        auto publish_tile4 = [&](int it_, const v4f (&acc)[3]) {
+            const int slot = it_ % kRing;
+            float* tl = s_ring + slot * 16 * LDT + c * LDT + 4 * kq;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int m0 = 16 * (3 * w + ct);
+                if (m0 + 4 * kq < HC) st4(tl + m0, make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) flag_bump(s_ready + slot);
@@ -175,12 +202,28 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             const int Kp = (Cp + 15) & ~15;
             Bf16x3 wreg[2][3];
             WRaw8 raw[2][3];
+            const bool pre = a.dagg_pre != nullptr;           // (block-uniform)
+            if (pre) {
+                // the fragments split already, in lane order: 36 coalesced 1 KB loads, no vector work (the splits — 400 instructions per
+                // wave — stood between the weight loads and the FIRST tile every vector wave of the block waits for)
+                const char* fp = reinterpret_cast<const char*>(a.dagg_pre) + ((size_t)(w * 6) * 3 * 64 + lane) * 16;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        const char* q = fp + (size_t)((st * 3 + ct) * 3) * 1024;
+                        wreg[st][ct].hi = ldfrag(q);
+                        wreg[st][ct].mid = ldfrag(q + 1024);
+                        wreg[st][ct].lo = ldfrag(q + 2048);
+                    }
+            } else {
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 const int mcol = min(16 * (3 * w + ct) + c, MP - 1);
                 const int pos = (mcol & ~63) + (mcol & 3) * 16 + ((mcol >> 2) & 15);     // ts_pos_of_col
 #pragma unroll
                 for (int st = 0; st < 2; ++st) raw[st][ct] = w_load8(a.img_dagg, MP, pos, 32 * st + 8 * kq, Kp);
+            }
             }
             auto load_a = [&](int tile, float4 (&af)[2][2]) {
                 const int row = 16 * tile + c;
@@ -197,34 +240,61 @@ __global__ void __launch_bounds__((V + 4) * 64, (V + 4) / 4) k_triplet_bwd_dst_w
             int tile = blockIdx.x, it = 0;
             load_a(tile, af);
             stage_lds();
+            if (!pre) {
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
+                for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-                for (int st = 0; st < 2; ++st) wreg[st][ct] = w_split8(raw[st][ct], 32 * st + 8 * kq, Kp, 16 * (3 * w + ct) + c < HC);
-            __syncthreads();                                  // LDS initialised; the first tile's rows are in flight or here
-            B1_TL(1);
-            for (; tile < ntiles; tile += gridDim.x, ++it) {
+                    for (int st = 0; st < 2; ++st) wreg[st][ct] = w_split8(raw[st][ct], 32 * st + 8 * kq, Kp, 16 * (3 * w + ct) + c < HC);
+            }
+            // the product of one tile out of `af` (whose registers take the NEXT tile's rows under the matrix instructions)
+            auto product = [&](int next_tile, v4f (&acc)[3]) {
+#ifdef GLAM_B1_NOMM      // timing experiment only (wrong numbers): the matrix waves without their operand split and matrix instructions
+                load_a(next_tile, af);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[ct] = (v4f){af[0][0].x, af[0][1].y, af[1][0].z, af[1][1].w};
+                return;
+#endif
                 Bf16x3 as[2];
 #pragma unroll
                 for (int st = 0; st < 2; ++st) as[st] = split8(af[st][0], af[st][1]);
-                load_a(tile + gridDim.x, af);                 // next tile's rows in flight under this tile's MFMAs
-                wait_slot(it);
-                v4f acc[3];
+                load_a(next_tile, af);
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) acc[ct] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_small(as[st], wreg[st][ct], acc[ct]);
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_small(wreg[st][ct], as[st], acc[ct]);
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_mid(as[st], wreg[st][ct], acc[ct]);
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_mid(wreg[st][ct], as[st], acc[ct]);
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_big(as[st], wreg[st][ct], acc[ct]);
-                publish_tile(it, acc);
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_x3_big(wreg[st][ct], as[st], acc[ct]);
+            };
+            // (GLAM_B1_EARLY: the FIRST tile's product ahead of the block's barrier — it needs nothing the barrier publishes, only its store
+            //  into the ring and the check-in flag do; measured even, see the macro)
+#if GLAM_B1_EARLY
+            v4f acc0[3];
+            product(tile + gridDim.x, acc0);                  // (every block has a first tile: grid <= ntiles)
+            __syncthreads();                                  // LDS initialised
+            B1_TL(1);
+            publish_tile4(0, acc0);
+            B1_TL(2);                                         // (timeline builds: the first tile is out; the fourth)
+            tile += gridDim.x;
+            it = 1;
+#else
+            __syncthreads();
+            B1_TL(1);
+#endif
+            for (; tile < ntiles; tile += gridDim.x, ++it) {
+                v4f acc[3];
+                wait_slot(it);
+                product(tile + gridDim.x, acc);
+                publish_tile4(it, acc);
+                if (it == 0) B1_TL(2);
+                if (it == 3) B1_TL(4);
             }
         } else {
         const int GK = (Cp + 15) >> 4;                        // k groups (<= 4)
@@ -575,6 +645,9 @@ static int launch_b1ws(const DstWsArgs& a, int grid, hipStream_t s) {
     return launch_b1ws_x<H, V, false>(a, grid, s);
 }
 
+// GLAM_B1_PRE=0: the matrix waves split the plain d_aggr image in every block's prologue (A/B switch; bit-identical)
+static bool b1_pre_enabled() { const char* e = getenv("GLAM_B1_PRE"); return !e || atoi(e) != 0; }
+
 bool triplet_bwd_dst_ws_supported(int H, int Cp, int De, int edge_onehot) {
     return triplet_fwd_ws_enabled() && triplet_fwd_ws_supported(H, Cp, De, edge_onehot) && H <= 3;
 }
@@ -588,13 +661,13 @@ int triplet_bwd_dst_ws_blocks(int64_t N) {
 int triplet_bwd_dst_ws(const float* xw, const float* a_ij, const float* edge_attr, const float* w_edge, const float* M, const float* aggr,
                        const float* stats, const float* d_out, const float* img_dagg, const int32_t* ell_src, const int32_t* ell_eid,
                        int64_t N, int64_t E, int H, int Cp, int De, int edge_onehot, float slope, float* d_aggr, float* alpha_e,
-                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s) {
+                       float* dpre_e, float* d_a_ij, float* partial, int* nblk_out, hipStream_t s, const float* dagg_pre) {
     if (!triplet_bwd_dst_ws_supported(H, Cp, De, edge_onehot))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_dst_ws: H=%d Cp=%d De=%d onehot=%d outside the kernel table", H, Cp, De, edge_onehot);
     if ((uint64_t)N * H * Cp * 4 >= (1ull << 32) || (uint64_t)E * De * 4 >= (1ull << 32))
         return fail(GLAM_E_UNSUPPORTED, "triplet_bwd_dst_ws: a tensor exceeds 4 GiB (32-bit offsets)");
     DstWsArgs a{xw, a_ij, edge_attr, w_edge, M, aggr, stats, d_out, img_dagg, ell_src, ell_eid, (int)N, Cp, slope,
-                d_aggr, alpha_e, dpre_e, d_a_ij, partial};
+                d_aggr, alpha_e, dpre_e, d_a_ij, partial, (H == 3 && b1_pre_enabled()) ? dagg_pre : nullptr};
     const int grid = triplet_bwd_dst_ws_blocks(N);
     int rc = GLAM_OK;
     switch (H) {

@@ -2287,6 +2287,27 @@ def test_torch_extension_ops_match_the_ctypes_route(device, monkeypatch):
     assert torch.isfinite(G.segment_pool(h, sp.ptr, 0)).all()
 
 
+@pytest.mark.parametrize("C,B", [(60, 1024), (60, 5), (45, 150), (36, 40), (64, 33)])
+def test_b1_matrix_waves_on_presplit_fragments(device, monkeypatch, C, B):
+    """The warp-specialised backward by target reads W_scale^T as operand fragments split into their three bf16 terms by the staging
+    launch (Staged::dagg_pre: one launch per weight update) instead of splitting the plain image in every block's prologue
+    (``GLAM_B1_PRE=0``): the same split function on the same numbers — every gradient bit for bit."""
+    b = synth_batch(B, seed=B + C).to(device)
+    torch.manual_seed(C)
+    conv = layer.TripletMessage(C, 4, heads=3).to(device)
+    N = b.x.size(0)
+    x0, cot = torch.randn(N, C, device=device), torch.randn(N, C, device=device)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    res = []
+    for pre in ("1", "0"):
+        monkeypatch.setenv("GLAM_B1_PRE", pre)
+        x = x0.clone().requires_grad_(True)
+        out = conv(x, b.edge_index, b.edge_attr)
+        res.append(torch.autograd.grad(out, [x] + list(conv.parameters()), grad_outputs=cot))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("C,H,B", [(60, 3, 1024), (60, 3, 7), (40, 4, 200), (64, 2, 90), (45, 3, 150), (60, 1, 64), (36, 3, 100), (52, 2, 33), (37, 1, 20)])
 def test_warp_specialised_forward_equals_the_general_fused_kernel(device, monkeypatch, C, H, B):
     """csrc/triplet_ws.hip / triplet_ws_b1.hip (producer waves gather, consumer waves run the fused GEMM out of an LDS tile ring; what the

@@ -71,6 +71,9 @@ def table(name, a, rt, nprod, label, vector_first):
             ("gather waves: drained", g[:, :, 5] - t0),
             ("matrix waves: loop end", m[:, :, 3] - t0),
             ("matrix waves: drained", m[:, :, 5] - t0)]
+    if vector_first:      # B1: the matrix waves PRODUCE the tiles the vector waves wait for
+        rows += [("matrix waves: barrier passed", m[:, :, 1] - t0), ("matrix waves: first tile published", m[:, :, 2] - t0),
+                 ("matrix waves: fourth tile published (the ring is full)", m[:, :, 4] - t0)]
     for n_, v in rows:
         v = v[v > -1e15]
         print(f"   {n_:55s} mean {v.mean():8.0f}   min {v.min():8.0f}   max {v.max():8.0f}")
