@@ -174,9 +174,13 @@ __device__ __forceinline__ void ws_consume_x3(Stage stage, const float* img, con
                 a.hi = *reinterpret_cast<const bf16x8_t*>(tl + 64 * s);
                 a.mid = *reinterpret_cast<const bf16x8_t*>(tl + kX3PlaneBytes + 64 * s);
                 a.lo = *reinterpret_cast<const bf16x8_t*>(tl + 2 * kX3PlaneBytes + 64 * s);
+#ifdef GLAM_WS_NOMM      // timing experiment only (wrong numbers): the consumers without their matrix instructions
+                acc_s += __builtin_bit_cast(v4f_t, a.hi); acc_m += __builtin_bit_cast(v4f_t, a.mid); acc_b += __builtin_bit_cast(v4f_t, a.lo);
+#else
                 acc_s = mfma_x3_small(a, wreg[s], acc_s);
                 acc_m = mfma_x3_mid(a, wreg[s], acc_m);
                 acc_b = mfma_x3_big(a, wreg[s], acc_b);
+#endif
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -41,6 +41,10 @@ constexpr int kWxGroup = 4 * kWxUnit;          // [4 t]
 constexpr int kWxPlane = kWxProd * kWxGroup;   // [P slab 0 | P slab 1 | P slab 2 | Q]
 constexpr int kWxStage = 3 * kWxPlane;         // hi | mid | lo: 48 KB per 32-row step
 constexpr int kWxRing = 3;
+#ifndef GLAM_WX_DEPTH
+#define GLAM_WX_DEPTH 3
+#endif
+constexpr int kWxDepth = GLAM_WX_DEPTH;        // register stages of a producer: steps of loads in flight
 constexpr int kWxHeader = 256;                 // s_ready[16] | s_taken[16]
 constexpr int kWxFlush = 8;                    // steps between two master-accumulator updates
 constexpr size_t kWxLds = kWxHeader + (size_t)kWxRing * kWxStage;
@@ -147,23 +151,22 @@ __global__ void __launch_bounds__(kWxThreads) k_wgrad_x3(WgArgs2 two) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) flag_bump(s_ready + slot);
         };
-        // three steps of loads in flight per wave (registers): 96 KB per CU.  The steady loop has no condition between a step's loads
-        // and their use, so the wait in front of a split is for exactly that register set; the last steps of the block — the ragged one
-        // among them — run behind it
-        float4 buf[3][8];
-        load(0, buf[0]);
-        load(1, buf[1]);
-        load(2, buf[2]);
-        int s = 0;
-        for (; s + 2 < nfull; s += 3) {
+        // kWxDepth steps of loads in flight per wave (registers; the LDS ring behind them has three stages): 32 KB per wave and step of
+        // depth.  The steady loop has no condition between a step's loads and their use, so the wait in front of a split is for exactly
+        // that register set; the last steps of the block — the ragged one among them — run behind it
+        float4 buf[kWxDepth][8];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < kWxDepth; ++d) load(d, buf[d]);
+        int s = 0;
+        for (; s + kWxDepth - 1 < nfull; s += kWxDepth) {
+#pragma unroll
+            for (int d = 0; d < kWxDepth; ++d) {
                 emit(s + d, buf[d], std::false_type{});
-                load(s + d + 3, buf[d]);                   // (beyond the block: clamped re-reads, never used)
+                load(s + d + kWxDepth, buf[d]);            // (beyond the block: clamped re-reads, never used)
             }
         }
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+        for (int d = 0; d < kWxDepth; ++d)
             if (s + d < nsteps) emit(s + d, buf[d], std::true_type{});
         return;
     }
