@@ -98,6 +98,8 @@ SIGNATURES = {
     "glam_wgrad_gemm_sets": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "glam_wgrad_gemm_pair_split_seg": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, _vp, _vp, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, _vp, _vp,
                                        _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "glam_wgrad_gemm_gru_gates_seg": (_i32, [_i32, ctypes.POINTER(_vp), _i32, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _vp, _vp, _vp, _vp,
+                                      _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "glam_wgrad_gemm_linear_sets": (_i32, [_i32, ctypes.POINTER(_vp), _i32, _i32, ctypes.POINTER(_vp), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "glam_wgrad_gemm_linear": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "glam_wgrad_gemm_split": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),

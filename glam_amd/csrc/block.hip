@@ -356,7 +356,9 @@ constexpr int kGruImgFloats = 64 * 192;
 
 struct GruFusedArgs {
     const float* x; const float* h; const float* identity; const float* img_ih; const float* img_hh; const float* b_ih; const float* b_hh;
-    float* gi; float* gh; float* h_new; float* out;
+    float* gi; float* gh; float* h_new; float* out;      // k_gru_fwd_ws, gh null: gi is [N, 4C] = [r | z | n | gh_n], the gates themselves
+                                                         // (what k_gru_bwd_ws<.., true> reads: 4C instead of 6C floats per row written
+                                                         // here and read there, and no sigmoid / tanh in the backward)
     int N, C, celu_in, act; float slope;
     float* x_celu;      // k_gru_fwd_ws, may be null: celu(x) [N, C] as the producers compute it — what the backward (celu_in = 2) and the weight
                         // gradient (Q without its CELU) then read INSTEAD of x: no exponential in either
@@ -699,6 +701,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             }
         }
         const int ch = 16 * w + 4 * kb;
+        const bool gates = a.gh == nullptr;
         float4 bias_i[3], bias_h[3];               // the lane's four channels of every gate (zero beyond C)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -781,14 +784,16 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                     const float4 bi = bias_i[g], bh = bias_h[g];
                     gi4[g] = make_float4(ai[g][0] + bi.x, ai[g][1] + bi.y, ai[g][2] + bi.z, ai[g][3] + bi.w);
                     gh4[g] = make_float4(ah[g][0] + bh.x, ah[g][1] + bh.y, ah[g][2] + bh.z, ah[g][3] + bh.w);
-                    st4(a.gi + (size_t)row * 3 * C + g * C + ch, gi4[g]);
-                    st4(a.gh + (size_t)row * 3 * C + g * C + ch, gh4[g]);
+                    if (!gates) {
+                        st4(a.gi + (size_t)row * 3 * C + g * C + ch, gi4[g]);
+                        st4(a.gh + (size_t)row * 3 * C + g * C + ch, gh4[g]);
+                    }
                 }
                 if (it == 0) GRU_FINEF(3); else if (it == 2) GRU_FINEF(11);
                 const size_t e = (size_t)row * C + ch;
                 uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
                 if constexpr (RNG) w4 = philox4(ph, e >> 2);
-                float4 hn4, o4, od4;
+                float4 hn4, o4, od4, r4, z4, n4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float r = sigmoidf_(f4get(gi4[0], j) + f4get(gh4[0], j));
@@ -799,7 +804,12 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                     const unsigned wd = philox_word(w4, j);
                     const float o = (RNG && a.act == kActRRelu) ? (y > 0.f ? y : y * rrelu_slope_w(wd, rg.lo, rg.hi)) : act_fwd(y, a.act, a.slope);
                     (&hn4.x)[j] = hn; (&o4.x)[j] = o;
+                    (&r4.x)[j] = r; (&z4.x)[j] = z; (&n4.x)[j] = nn;
                     if constexpr (RNG) (&od4.x)[j] = o * drop_scale_w(wd, rg.p);
+                }
+                if (gates) {      // [r | z | n | gh_n]: all the backward takes from the two pre-activation matrices (see GruFusedArgs)
+                    float* gp = a.gi + (size_t)row * 4 * C + ch;
+                    st4(gp, r4); st4(gp + C, z4); st4(gp + 2 * C, n4); st4(gp + 3 * C, gh4[2]);
                 }
                 st4(a.h_new + e, hn4);
                 st4(a.out + e, o4);
@@ -842,7 +852,7 @@ struct GruBwdArgs {
     const void* pre;         // may be null: both matrices as the consumers' 3 x bf16 fragments (k_gru_ws_pre) — img_ih_t / img_hh_t unused
 };
 
-template <bool RNG>
+template <bool RNG, bool GATES>
 __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a, TailRngB rg) {
     constexpr int P = kGbP, NC = kGbC, RING = kGbRing, D = kGbD, PITCH = kGbPitch, PLANE = kGbPlane, EPITCH = kGwEPitch, EPLANE = kGwEPlane,
                   TILE = kGbTile;
@@ -863,19 +873,26 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
         if constexpr (RNG) ph = philox_init(rg.eff);
         const int er = (lane + 64 * wave) >> 4, eq = (lane + 64 * wave) & 15;
         auto item_ok = [&](int tile) { return tile < ntiles && tile * 16 + er < a.N && 4 * eq < C; };
-        constexpr int NL = RNG ? 12 : 11;
+        // GATES: gi is [N, 4C] = [r | z | n | gh_n] as k_gru_fwd_ws wrote it (gh null) and d_gi is written as [N, 4C] =
+        // [d_pr | d_pz | d_pn | d_pn r] (d_gh null): 8C instead of 12C floats per row through this launch's memory side
+        constexpr int NG = GATES ? 4 : 6, GW = GATES ? 4 : 3, NL = NG + (RNG ? 6 : 5);
         auto load = [&](int tile, float4 (&v)[NL]) {
             const bool ok = item_ok(tile);
-            const size_t i = ((size_t)(tile * 16 + er)) * C + 4 * eq, b = ((size_t)(tile * 16 + er)) * 3 * C + 4 * eq;
+            const size_t i = ((size_t)(tile * 16 + er)) * C + 4 * eq, b = ((size_t)(tile * 16 + er)) * GW * C + 4 * eq;
             const float* z = a.gi;
+            if constexpr (GATES) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) { v[g] = ld4(ok ? a.gi + b + g * C : z); v[3 + g] = ld4(ok ? a.gh + b + g * C : z); }
-            v[6] = ld4(ok ? a.h + i : z);
-            v[7] = ld4(ok ? a.out + i : z);
-            v[8] = ld4((ok && a.d_out) ? a.d_out + i : z);
-            v[9] = ld4((ok && a.d_hstate) ? a.d_hstate + i : z);
-            v[10] = ld4((ok && a.celu_in) ? a.x + i : z);
-            if constexpr (RNG) v[11] = ld4((ok && rg.d_out_drop) ? rg.d_out_drop + i : z);
+                for (int g = 0; g < 4; ++g) v[g] = ld4(ok ? a.gi + b + g * C : z);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { v[g] = ld4(ok ? a.gi + b + g * C : z); v[3 + g] = ld4(ok ? a.gh + b + g * C : z); }
+            }
+            v[NG] = ld4(ok ? a.h + i : z);
+            v[NG + 1] = ld4(ok ? a.out + i : z);
+            v[NG + 2] = ld4((ok && a.d_out) ? a.d_out + i : z);
+            v[NG + 3] = ld4((ok && a.d_hstate) ? a.d_hstate + i : z);
+            v[NG + 4] = ld4((ok && a.celu_in) ? a.x + i : z);
+            if constexpr (RNG) v[NG + 5] = ld4((ok && rg.d_out_drop) ? rg.d_out_drop + i : z);
         };
         float4 buf[D][NL];
 #pragma unroll
@@ -890,29 +907,33 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
                 if (tile < ntiles) {
                     const bool ok = item_ok(tile);
                     const float4 (&v)[NL] = buf[d];
-                    const size_t i = ((size_t)(tile * 16 + er)) * C + 4 * eq, b = ((size_t)(tile * 16 + er)) * 3 * C + 4 * eq;
+                    const size_t i = ((size_t)(tile * 16 + er)) * C + 4 * eq, b = ((size_t)(tile * 16 + er)) * GW * C + 4 * eq;
                     uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
                     if constexpr (RNG) w4 = philox4(ph, i >> 2);
                     float4 dy4 = f4zero(), pr4 = f4zero(), pz4 = f4zero(), pn4 = f4zero(), pnr4 = f4zero(), gz4 = f4zero(), cf4 = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (ok) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float ov = f4get(v[7], j);
+                            const float ov = f4get(v[NG + 1], j);
                             float dy;
                             if constexpr (RNG) {
                                 const unsigned wd = philox_word(w4, j);
-                                float g0 = a.d_out ? f4get(v[8], j) : 0.f;
-                                if (rg.d_out_drop) g0 = fmaf(f4get(v[11], j), drop_scale_w(wd, rg.p), g0);
+                                float g0 = a.d_out ? f4get(v[NG + 2], j) : 0.f;
+                                if (rg.d_out_drop) g0 = fmaf(f4get(v[NG + 5], j), drop_scale_w(wd, rg.p), g0);
                                 dy = g0 * (a.act == kActRRelu ? (ov > 0.f ? 1.f : rrelu_slope_w(wd, rg.lo, rg.hi)) : act_grad_from_out(ov, a.act, a.slope));
                             } else {
-                                dy = f4get(v[8], j) * act_grad_from_out(ov, a.act, a.slope);
+                                dy = f4get(v[NG + 2], j) * act_grad_from_out(ov, a.act, a.slope);
                             }
-                            const float g = a.d_hstate ? dy + f4get(v[9], j) : dy;
-                            const float ghn = f4get(v[5], j);
-                            const float r = sigmoidf_(f4get(v[0], j) + f4get(v[3], j));
-                            const float z = sigmoidf_(f4get(v[1], j) + f4get(v[4], j));
-                            const float nn = tanh_(f4get(v[2], j) + r * ghn);
-                            const float d_n = g * (1.f - z), d_z = g * (f4get(v[6], j) - nn);
+                            const float g = a.d_hstate ? dy + f4get(v[NG + 3], j) : dy;
+                            float ghn, r, z, nn;
+                            if constexpr (GATES) { r = f4get(v[0], j); z = f4get(v[1], j); nn = f4get(v[2], j); ghn = f4get(v[3], j); }
+                            else {
+                                ghn = f4get(v[5], j);
+                                r = sigmoidf_(f4get(v[0], j) + f4get(v[3], j));
+                                z = sigmoidf_(f4get(v[1], j) + f4get(v[4], j));
+                                nn = tanh_(f4get(v[2], j) + r * ghn);
+                            }
+                            const float d_n = g * (1.f - z), d_z = g * (f4get(v[NG], j) - nn);
                             const float d_pn = d_n * (1.f - nn * nn);
                             (&dy4.x)[j] = dy;
                             (&pr4.x)[j] = d_pn * ghn * r * (1.f - r);
@@ -920,12 +941,13 @@ __global__ void __launch_bounds__((kGbP + kGbC) * 64) k_gru_bwd_ws(GruBwdArgs a,
                             (&pn4.x)[j] = d_pn;
                             (&pnr4.x)[j] = d_pn * r;
                             (&gz4.x)[j] = a.merge_identity ? g * z + dy : g * z;
-                            if (a.celu_in == 2) { const float xc = f4get(v[10], j); (&cf4.x)[j] = xc > 0.f ? 1.f : xc + 1.f; }      // x holds celu(x)
-                            else if (a.celu_in) (&cf4.x)[j] = celu1_grad(f4get(v[10], j));
+                            if (a.celu_in == 2) { const float xc = f4get(v[NG + 4], j); (&cf4.x)[j] = xc > 0.f ? 1.f : xc + 1.f; }      // x holds celu(x)
+                            else if (a.celu_in) (&cf4.x)[j] = celu1_grad(f4get(v[NG + 4], j));
                         }
                         if (a.d_identity && !a.merge_identity) st4(a.d_identity + i, dy4);
                         st4(a.d_gi + b, pr4); st4(a.d_gi + b + C, pz4); st4(a.d_gi + b + 2 * C, pn4);
-                        st4(a.d_gh + b, pr4); st4(a.d_gh + b + C, pz4); st4(a.d_gh + b + 2 * C, pnr4);
+                        if constexpr (GATES) st4(a.d_gi + b + 3 * C, pnr4);
+                        else { st4(a.d_gh + b, pr4); st4(a.d_gh + b + C, pz4); st4(a.d_gh + b + 2 * C, pnr4); }
                     }
                     load(tile + D * nblk, buf[d]);              // (before the LDS wait: this register set's next tile, D tiles ahead)
                     const int slot = it % RING, round = it / RING;
@@ -1074,13 +1096,20 @@ __global__ void __launch_bounds__(64) k_gru_ws_pre(const float* w_ih, const floa
 }
 
 static int gru_bwd_ws_launch(const GruBwdArgs& a, const TailRngB* rg, hipStream_t s) {
-    static bool big0[64] = {}, big1[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<false>), big0, "gru_bwd_ws")) return rc;
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<true>), big1, "gru_bwd_ws")) return rc;
+    static bool big0[64] = {}, big1[64] = {}, big2[64] = {}, big3[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<false, false>), big0, "gru_bwd_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<true, false>), big1, "gru_bwd_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<false, true>), big2, "gru_bwd_ws")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_bwd_ws<true, true>), big3, "gru_bwd_ws")) return rc;
     const int ntiles = (a.N + 15) / 16, cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;
-    if (rg) hipLaunchKernelGGL(k_gru_bwd_ws<true>, dim3(grid), dim3((kGbP + kGbC) * 64), kGbLds, s, a, *rg);
-    else hipLaunchKernelGGL(k_gru_bwd_ws<false>, dim3(grid), dim3((kGbP + kGbC) * 64), kGbLds, s, a, TailRngB{});
+    const dim3 g(grid), b((kGbP + kGbC) * 64);
+    if (!a.gh) {      // the gates themselves in, the four gradient blocks out (see the kernel)
+        GLAM_PROF_LABEL(rg ? "k_gru_bwd_ws<true, gates>" : "k_gru_bwd_ws<false, gates>");
+        if (rg) hipLaunchKernelGGL((k_gru_bwd_ws<true, true>), g, b, kGbLds, s, a, *rg);
+        else hipLaunchKernelGGL((k_gru_bwd_ws<false, true>), g, b, kGbLds, s, a, TailRngB{});
+    } else if (rg) hipLaunchKernelGGL((k_gru_bwd_ws<true, false>), g, b, kGbLds, s, a, *rg);
+    else hipLaunchKernelGGL((k_gru_bwd_ws<false, false>), g, b, kGbLds, s, a, TailRngB{});
     GLAM_LAUNCH_CHECK("gru_bwd_ws");
     return GLAM_OK;
 }
@@ -1089,8 +1118,10 @@ static int gru_bwd_ws_args_ok(const char* fn, const GruBwdArgs& a, int64_t N, co
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
     if (!(a.C >= 24 && a.C <= 64 && (a.C & 3) == 0)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in 24..64", fn, a.C);
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(a.gi && a.gh && a.h && a.out && (a.d_out || d_out_drop) && (a.pre || (a.img_ih_t && a.img_hh_t)) && a.d_gi && a.d_gh && a.d_x && a.d_h &&
+    GLAM_REQUIRE(a.gi && a.h && a.out && (a.d_out || d_out_drop) && (a.pre || (a.img_ih_t && a.img_hh_t)) && a.d_gi && a.d_x && a.d_h &&
                      (!a.celu_in || a.x), "%s: null pointer", fn);
+    GLAM_REQUIRE((a.gh == nullptr) == (a.d_gh == nullptr), "%s: gh and d_gh are both given (gi, gh, d_gi, d_gh as [N, 3C]) or both null (gi = the "
+                 "gates [N, 4C] of a forward without gh, d_gi = [N, 4C])", fn);
     GLAM_REQUIRE(aligned16(a.gi) && aligned16(a.gh) && aligned16(a.h) && aligned16(a.out) && aligned16(a.d_out) && aligned16(a.d_hstate) && aligned16(a.x) &&
                      aligned16(a.img_ih_t) && aligned16(a.img_hh_t) && aligned16(a.d_gi) && aligned16(a.d_gh) && aligned16(a.d_identity) &&
                      aligned16(a.d_x) && aligned16(a.d_h) && aligned16(d_out_drop) && aligned16(a.pre), "%s: pointers must be 16-byte aligned", fn);
@@ -1176,6 +1207,7 @@ static int gru_ws_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_t s
     if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<true>), big1, "gru_ws_fwd")) return rc;
     const int ntiles = (a.N + 15) / 16, cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;
+    if (!a.gh) GLAM_PROF_LABEL(rg ? "k_gru_fwd_ws<true, gates>" : "k_gru_fwd_ws<false, gates>");
     if (rg) hipLaunchKernelGGL(k_gru_fwd_ws<true>, dim3(grid), dim3((kGwP + kGwC) * 64), kGwLds, s, a, *rg);
     else hipLaunchKernelGGL(k_gru_fwd_ws<false>, dim3(grid), dim3((kGwP + kGwC) * 64), kGwLds, s, a, TailRng{});
     GLAM_LAUNCH_CHECK("gru_ws_fwd");
@@ -1186,7 +1218,7 @@ static int gru_ws_args_ok(const char* fn, const GruFusedArgs& a, int64_t N) {
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
     if (!glam_gru_ws_supported(a.C)) return fail(GLAM_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in 24..64", fn, a.C);
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(a.x && a.h && (a.pre || (a.img_ih && a.img_hh)) && a.b_ih && a.b_hh && a.gi && a.gh && a.h_new && a.out, "%s: null pointer", fn);
+    GLAM_REQUIRE(a.x && a.h && (a.pre || (a.img_ih && a.img_hh)) && a.b_ih && a.b_hh && a.gi && a.h_new && a.out, "%s: null pointer", fn);
     GLAM_REQUIRE(aligned16(a.x) && aligned16(a.h) && aligned16(a.identity) && aligned16(a.img_ih) && aligned16(a.img_hh) && aligned16(a.pre) && aligned16(a.gi) &&
                      aligned16(a.gh) && aligned16(a.h_new) && aligned16(a.out), "%s: pointers must be 16-byte aligned", fn);
     return GLAM_OK;

@@ -1248,6 +1248,54 @@ extern "C" int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, 
     return launch_final_reduce(ra, (hipStream_t)stream);
 }
 
+// Both weight gradients of a GRU step from the ONE gate-gradient matrix glam_gru_bwd_ws writes when d_gh is null: D[n] = [d_pr | d_pz |
+// d_pn | d_pn r] (4C floats per row).  d_gi = D[:, 0:3C] and d_gh = [D[:, 0:2C] | D[:, 3C:4C]] are column blocks of it (the [P1 | P2]
+// operand of k_wgrad / k_wgrad_x3), so
+//   dw_ih[3C, C] = d_gi^T X, db_ih = column sums of d_gi,   dw_hh[3C, C] = d_gh^T H, db_hh = column sums of d_gh
+// run as glam_wgrad_gemm_pair_split_seg does (same launch, same reduction, same order of additions: bit-identical to it on the expanded
+// matrices), summed over nseg <= 3 operand sets (D[s], X[s], H[s]) of N rows each; X, H with row strides ldx, ldh.
+extern "C" int glam_wgrad_gemm_gru_gates_seg(int nseg, const float* const* D, int C, const float* const* X, int ldx, int qcelu,
+                                             const float* const* H, int ldh, float* dw_ih, float* db_ih, float* dw_hh, float* db_hh,
+                                             int64_t N, void* ws, size_t ws_bytes, const float* add_w_ih, const float* add_b_ih,
+                                             const float* add_w_hh, const float* add_b_hh, void* stream) {
+    const char* fn = "glam_wgrad_gemm_gru_gates_seg";
+    GLAM_REQUIRE(nseg >= 1 && nseg <= 3, "%s: %d operand sets (1..3)", fn, nseg);
+    GLAM_REQUIRE(C > 0 && (C & 3) == 0 && C + 1 <= 64 && ldx >= C && ldh >= C && (ldx & 3) == 0 && (ldh & 3) == 0,
+                 "%s: C=%d must be a multiple of 4 below 64 (row strides %d, %d: multiples of 4, >= C)", fn, C, ldx, ldh);
+    GLAM_REQUIRE(D && X && H && dw_ih && db_ih && dw_hh && db_hh, "%s: null pointer", fn);
+    GLAM_REQUIRE(N >= 0 && N * nseg < INT32_MAX, "%s: N out of range", fn);
+    if (N == 0) {
+        GLAM_REQUIRE(!add_w_ih && !add_b_ih && !add_w_hh && !add_b_hh, "%s: N = 0 with an addend (add on the host side)", fn);
+        hipStream_t s = (hipStream_t)stream;
+        (void)hipMemsetAsync(dw_ih, 0, (size_t)3 * C * C * sizeof(float), s);
+        (void)hipMemsetAsync(db_ih, 0, (size_t)3 * C * sizeof(float), s);
+        (void)hipMemsetAsync(dw_hh, 0, (size_t)3 * C * C * sizeof(float), s);
+        (void)hipMemsetAsync(db_hh, 0, (size_t)3 * C * sizeof(float), s);
+        return GLAM_OK;
+    }
+    GLAM_REQUIRE(ws && ws_bytes >= glam_wgrad_workspace_bytes(), "%s: workspace missing / too small", fn);
+    for (int q = 0; q < nseg; ++q)
+        GLAM_REQUIRE(D[q] && X[q] && H[q] && aligned16(D[q]) && aligned16(X[q]) && aligned16(H[q]), "%s: operand set %d: null / misaligned pointer",
+                     fn, q);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    WgArgs a{D[0], 3 * C, 4 * C, nullptr, 0, 0, 0, X[0], C, ldx, 1, (int)(N * nseg), 0, partial, 0, 0, qcelu};
+    WgArgs b{D[0], 2 * C, 4 * C, D[0] + 3 * C, C, 4 * C, 0, H[0], C, ldh, 1, (int)(N * nseg), 0, partial + wgrad_workspace_floats(), 0, 0, 0};
+    a.nseg = b.nseg = nseg;
+    a.seg_rows = b.seg_rows = (int)N;
+    for (int q = 1; q < nseg; ++q) {
+        a.segP1[q - 1] = D[q]; a.segQ[q - 1] = X[q];
+        b.segP1[q - 1] = D[q]; b.segP2[q - 1] = D[q] + 3 * C; b.segQ[q - 1] = H[q];
+    }
+    ReduceArgs ra{};
+    ra.njobs = 2;
+    if (int rc = launch_wgrad_partials2(a, dw_ih, C, 1, &ra.job[0], b, dw_hh, C, 1, &ra.job[1], (hipStream_t)stream)) return rc;
+    ra.job[0].addend = add_w_ih;
+    ra.job[1].addend = add_w_hh;
+    ra.job[0].out_b = db_ih; ra.job[0].add_b = add_b_ih;
+    ra.job[1].out_b = db_hh; ra.job[1].add_b = add_b_hh;
+    return launch_final_reduce(ra, (hipStream_t)stream);
+}
+
 static int wgrad_gemm_impl(const float* P1, int I1, int ldp1, const float* P2, int I2, int ldp2, int ones,
                            const float* Q, int J, int ldq, int qones, int64_t N, float* out, int stride_i,
                            int stride_j, const float* addend, void* ws, size_t ws_bytes, void* stream) {

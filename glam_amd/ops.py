@@ -1217,6 +1217,10 @@ GRU_WGRAD_BATCH = True
 # the warp-specialised GRU step on pre-split operand fragments of its gate matrices (glam_gru_ws_make_pre) instead of splitting the plain
 # images in every block's prologue: A/B switch (GLAM_GRU_PRE=0)
 GRU_PRE = os.environ.get("GLAM_GRU_PRE", "1") != "0"
+# the warp-specialised GRU step keeps THE GATES [r | z | n | gh_n] (4C floats per row) for its backward instead of both pre-activation
+# matrices (6C), and the backward writes ONE gate-gradient matrix [N, 4C] instead of d_gi and d_gh (they share two of three blocks):
+# A/B switch (GLAM_GRU_GATES=0)
+GRU_GATES = os.environ.get("GLAM_GRU_GATES", "1") != "0"
 # the readout MLP's products of few tiles split k across blocks (glam_linear_dense_*_ws; matters at the reference's batch of 32): A/B switch
 DENSE_SPLITK = os.environ.get("GLAM_DENSE_SPLITK", "1") != "0"
 # PairNorm + the Dropout behind it from one launch each way (glam_graph_norm_drop_*): A/B switch

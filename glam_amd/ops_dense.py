@@ -913,9 +913,11 @@ class _GruBlock(torch.autograd.Function):
                 return img
             return _o._scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
 
-        gi, gh = torch.empty(N, M, **f), torch.empty(N, M, **f)
         st = stream()
         ws_route = _want_gru_ws(lib, N, C)
+        # (the warp-specialised step: gi = the gates [r | z | n | gh_n], no gh — see ops.GRU_GATES)
+        gates = bool(ws_route and _o.GRU_GATES)
+        gi, gh = (torch.empty(N, 4 * C, **f), None) if gates else (torch.empty(N, M, **f), torch.empty(N, M, **f))
         pre = _gru_pre(lib, scope, w_ih, w_hh, C, dev, st) if (ws_route and _o.GRU_PRE) else None
         if scope is not None and pre is None:
             # all four images of the step (forward and input-gradient images of both gate matrices) in ONE launch, shared by the
@@ -1005,6 +1007,7 @@ class _GruBlock(torch.autograd.Function):
                                                 ptr(_o.rng_state(dev)), ptr(eff), ptr(h_new), ptr(out), ptr(out_drop), st), "glam_gru_tail_rng_fwd")
         ctx.save_for_backward(x_keep, h, gi, gh, out, w_ih, w_hh)
         ctx.x_is_celu = x_is_celu
+        ctx.gates = gates
         ctx.pre = pre
         # the first application of a block seeds the GRU state with the block input, which is also the skip connection (layer.py:253-254):
         # one tensor, two roles — the backward then returns ONE gradient for it (k_gru_bwd_ws adds d_identity into d_h)
@@ -1033,7 +1036,8 @@ class _GruBlock(torch.autograd.Function):
         d_out = None if d_out is None else f32c(d_out, "d_out")
         d_out_drop = None if d_out_drop is None else f32c(d_out_drop, "d_out_drop")
         d_hstate = None if d_hstate is None else f32c(d_hstate, "d_hstate")
-        d_gi, d_gh, d_h = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        gates = ctx.gates                     # gi = [r | z | n | gh_n]; d_gi = [d_pr | d_pz | d_pn | d_pn r], no d_gh
+        d_gi, d_gh, d_h = torch.empty_like(gi), (None if gates else torch.empty_like(gh)), torch.empty_like(h)
         d_id = torch.empty_like(h) if has_res else None
         scope = ctx.scope
 
@@ -1044,7 +1048,7 @@ class _GruBlock(torch.autograd.Function):
                 return img
             return _o._scoped(scope.bwd if scope else None, ("lin", id(w)), w, build)
 
-        ws = _want_gru_ws(lib, N, C)
+        ws = gates or _want_gru_ws(lib, N, C)
         if ws:
             # gate gradients + both input-gradient products in ONE launch (block.hip: k_gru_bwd_ws); d_h comes out complete
             dx = torch.empty(N, C, **f)
@@ -1109,7 +1113,7 @@ class _GruBlock(torch.autograd.Function):
             # three sets per launch.  3 launches + 3 reductions -> 1 + 1 per training step at message_steps = 3.
             key = ("gru-parked", id(w_ih))
             parked = scope.bwd.setdefault(key, (w_ih, []))[1]
-            parked.append((d_gi, x, d_gh, h, bool(celu_q)))
+            parked.append((d_gi, x, d_gh, h, bool(celu_q), gates))
             if not ctx.first_app:
                 return dx, dh, d_id, None, None, None, None, None, None, None, d_carry, None, None
             sets = list(parked)
@@ -1119,14 +1123,19 @@ class _GruBlock(torch.autograd.Function):
             add = [None] * 4 if d_carry is None else list(f32c(d_carry, "d_carry").split([M * C, M, M * C, M]))
             vp = ctypes.c_void_p
             while sets:
-                grp = [t for t in sets if t[4] == sets[0][4]][:3]
+                grp = [t for t in sets if t[4:] == sets[0][4:]][:3]
                 sets = [t for t in sets if all(t is not u for u in grp)]
                 n = len(grp)
                 ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
                 arr = lambda i: (vp * n)(*[t[i].data_ptr() for t in grp])
-                check(lib.glam_wgrad_gemm_pair_split_seg(n, arr(0), M, M, arr(1), C, C, int(grp[0][4]), ptr(dw_ih), ptr(db_ih), arr(2), M, M,
-                                                         arr(3), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(), ptr(add[0]),
-                                                         ptr(add[1]), ptr(add[2]), ptr(add[3]), st), "glam_wgrad_gemm_pair_split_seg")
+                if grp[0][5]:
+                    check(lib.glam_wgrad_gemm_gru_gates_seg(n, arr(0), C, arr(1), C, int(grp[0][4]), arr(3), C, ptr(dw_ih), ptr(db_ih),
+                                                            ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(), ptr(add[0]), ptr(add[1]),
+                                                            ptr(add[2]), ptr(add[3]), st), "glam_wgrad_gemm_gru_gates_seg")
+                else:
+                    check(lib.glam_wgrad_gemm_pair_split_seg(n, arr(0), M, M, arr(1), C, C, int(grp[0][4]), ptr(dw_ih), ptr(db_ih), arr(2), M, M,
+                                                             arr(3), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(), ptr(add[0]),
+                                                             ptr(add[1]), ptr(add[2]), ptr(add[3]), st), "glam_wgrad_gemm_pair_split_seg")
                 add = [dw_ih, db_ih, dw_hh, db_hh]        # a further group adds onto the result in place
             return dx, dh, d_id, None, None, None, None, None, None, None, flat, None, None
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
@@ -1138,9 +1147,15 @@ class _GruBlock(torch.autograd.Function):
         if ctx.carried and d_carry is not None and N > 0:
             dc = f32c(d_carry, "d_carry").split([M * C, M, M * C, M])
             d_carry = None
-        check(lib.glam_wgrad_gemm_pair_split(ptr(d_gi), M, M, ptr(x), C, C, int(celu_q), ptr(dw_ih), ptr(db_ih),
-                                             ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
-                                             ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
+        if gates:
+            one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+            check(lib.glam_wgrad_gemm_gru_gates_seg(1, one(d_gi), C, one(x), C, int(celu_q), one(h), C, ptr(dw_ih), ptr(db_ih), ptr(dw_hh),
+                                                    ptr(db_hh), N, ptr(ws), ws.numel(), ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st),
+                  "glam_wgrad_gemm_gru_gates_seg")
+        else:
+            check(lib.glam_wgrad_gemm_pair_split(ptr(d_gi), M, M, ptr(x), C, C, int(celu_q), ptr(dw_ih), ptr(db_ih),
+                                                 ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
+                                                 ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
         if ctx.carried:
             return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None, None
         return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None, None

@@ -238,6 +238,18 @@ int glam_wgrad_gemm_pair_split_seg(int nseg, const float* const* Pa, int Ia, int
                                    int ldqb, int qcelu_b, float* dw_b, float* db_b, int64_t N, void* ws, size_t ws_bytes,
                                    const float* add_w_a, const float* add_b_a, const float* add_w_b, const float* add_b_b, void* stream);
 
+/* Both weight gradients of a GRU step (torch.nn.GRU(C, C), /root/reference/src_1gp/layer.py:247, :262) from the ONE gate-gradient
+ * matrix glam_gru_bwd_ws writes when its d_gh is NULL: D[n] = [d_pr | d_pz | d_pn | d_pn r], 4C floats per row.  d_gi = D[:, 0:3C] and
+ * d_gh = [D[:, 0:2C] | D[:, 3C:4C]] are column blocks of it:
+ *   dw_ih[3C, C] = d_gi^T X (celu(X) with qcelu), db_ih[3C] = column sums of d_gi, dw_hh[3C, C] = d_gh^T H, db_hh[3C] = column sums of d_gh,
+ * summed over nseg <= 3 operand sets (D[s], X[s], H[s]) of N rows each (X, H with row strides ldx, ldh), + optional addends laid out
+ * like the outputs — glam_wgrad_gemm_pair_split_seg on the two expanded matrices, bit for bit, without their 2C duplicated columns
+ * in memory.  C a multiple of 4, C + 1 <= 64.  ws >= glam_wgrad_workspace_bytes(). */
+int glam_wgrad_gemm_gru_gates_seg(int nseg, const float* const* D, int C, const float* const* X, int ldx, int qcelu,
+                                  const float* const* H, int ldh, float* dw_ih, float* db_ih, float* dw_hh, float* db_hh, int64_t N,
+                                  void* ws, size_t ws_bytes, const float* add_w_ih, const float* add_b_ih, const float* add_w_hh,
+                                  const float* add_b_hh, void* stream);
+
 /* glam_wgrad_gemm in full ([P1 | P2 | 1]^T Q, output strides, J <= 128) summed over nseg <= 3 operand sets of N rows each (+ an
  * optional addend laid out like out): the N-deep weight gradients of the wide TripletMessage over all applications of the layer. */
 int glam_wgrad_gemm_sets2(int nseg, const float* const* P1, int I1, int ldp1, const float* const* P2, int I2, int ldp2, int ones,
@@ -644,7 +656,11 @@ int glam_gru_fused_rng_fwd(const float* x, const float* h, const float* identity
  * into three bf16 terms, six partial products per product, fp32 accumulation — fp32 accuracy (measured: closer to the fp64 result than
  * the fp32 matrix instructions), roundings differ from glam_gru_fused_fwd at the last bits; RReLU / Dropout use the same Philox words.
  * img_ih / img_hh are the k_ts_gemm images of W_ih^T / W_hh^T (glam_ts_gemm_make_image(w, C, 1, C, 3 C, img): the ones glam_ts_gemm_pair
- * takes).  C a multiple of 4 in 24 .. 64. */
+ * takes).  C a multiple of 4 in 24 .. 64.
+ * gh = NULL (every glam_gru_ws_*fwd* form): gi is [N, 4C] and receives THE GATES [r | z | n | gh_n] instead of the two pre-activation
+ * matrices — all the backward takes from them (r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r gh_n): the values
+ * the backward would recompute, bit for bit).  4C instead of 6C floats per row written here and read by glam_gru_bwd_ws* (which takes
+ * this matrix when ITS gh is NULL), and no sigmoid / tanh in the backward's vector waves. */
 int glam_gru_ws_supported(int C);
 int glam_gru_ws_fwd(const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                     const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
@@ -696,6 +712,9 @@ int glam_gru_bwd_ws_rng_pre(const float* gi, const float* gh, const float* h, co
  * the images glam_ts_gemm_pair takes for these products.  x is read only with celu_in; d_identity, d_hstate, d_out_drop may be NULL
  * (d_out too in the rng form when d_out_drop is given).  merge_identity = 1: the skip connection and the GRU state are the same tensor
  * (the first application of a block, src_1gp/layer.py:254) — d_h additionally receives d_identity and d_identity is not written.
+ * gh = NULL and d_gh = NULL (both or neither; every glam_gru_bwd_ws* form): gi is the gate matrix [N, 4C] of a forward called with
+ * gh = NULL, and d_gi is written as [N, 4C] = [d_pr | d_pz | d_pn | d_pn r] — d_gi and d_gh differ in their last block only;
+ * glam_wgrad_gemm_gru_gates_seg forms both weight gradients from it.  Same d_x, d_h, d_identity and gate gradients, bit for bit.
  * C a multiple of 4 in 24 .. 64. */
 int glam_gru_bwd_ws(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
                     const float* x, const float* img_ih_t, const float* img_hh_t, int64_t N, int C, int celu_in, int act, float slope,

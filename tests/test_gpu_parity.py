@@ -3653,3 +3653,136 @@ def test_wide_layer_parameter_gradients_of_all_applications_in_one_launch(device
         else:
             assert torch.equal(a, c), n
 
+
+
+@pytest.mark.parametrize("N,C,ident,celu,train", [(1, 64, True, True, False), (1000, 64, False, False, False), (20400, 60, True, True, False),
+                                                  (20400, 60, True, True, True), (17, 24, True, False, True), (0, 60, True, True, False)])
+def test_gru_ws_keeps_the_gates_instead_of_both_pre_activations(device, N, C, ident, celu, train):
+    """gh = NULL / d_gh = NULL on the warp-specialised GRU step (torch.nn.GRU's gate equations, src_1gp/layer.py:261-266): the forward keeps
+    [r | z | n | gh_n] (4C floats per row) instead of gi and gh (6C), the backward reads them and writes ONE gate-gradient matrix
+    [d_pr | d_pz | d_pn | d_pn r] instead of d_gi and d_gh.  Same h_new, out, d_x, d_h, d_identity and gate gradients as the two-matrix form,
+    bit for bit — they are the values the backward recomputed — in the plain and the RReLU / Dropout form."""
+    raw, p, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + C + 7)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    M = 3 * C
+    x, h, idn, w_ih, w_hh, b_ih, b_hh = r(N, C), r(N, C), r(N, C), r(M, C) * 0.3, r(M, C) * 0.3, r(M), r(M)
+    d_out, d_hs, d_drop = r(N, C), r(N, C), r(N, C)
+    nb = raw.glam_gru_ws_pre_bytes()
+    pre = torch.empty(2, nb, dtype=torch.uint8, device=device)
+    assert raw.glam_gru_ws_make_pre(p(w_ih), p(w_hh), C, p(pre[0]), p(pre[1]), st()) == 0
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    lo, hi, dp = 0.125, 1.0 / 3, 0.2
+    act = 4 if train else 1
+    res = []
+    for gates in (False, True):
+        gi, gh = (f(N, 4 * C), None) if gates else (f(N, M), f(N, M))
+        hn, out, drop, xc = f(N, C), f(N, C), f(N, C), f(N, C)
+        state = torch.tensor([77] + [0] * (ops.RNG_STATE_WORDS - 1), dtype=torch.int64, device=device)
+        eff = torch.zeros(2, dtype=torch.int64, device=device)
+        idp = p(idn) if ident else None
+        if train:
+            rc = raw.glam_gru_ws_rng_fwd_pre(p(x), p(h), idp, p(pre[0]), p(b_ih), p(b_hh), N, C, int(celu), act, 0.0, lo, hi, dp, p(state), p(eff),
+                                             p(gi), p(gh), p(hn), p(out), p(drop), p(xc) if celu else None, st())
+        else:
+            rc = raw.glam_gru_ws_fwd_pre(p(x), p(h), idp, p(pre[0]), p(b_ih), p(b_hh), N, C, int(celu), act, 0.0, p(gi), p(gh), p(hn), p(out),
+                                         p(xc) if celu else None, st())
+        assert rc == 0, raw.glam_last_error()
+        dgi, dgh = (f(N, 4 * C), None) if gates else (f(N, M), f(N, M))
+        did, dx, dh = f(N, C), f(N, C), f(N, C)
+        xin, flag = (xc, 2) if celu else (x, 0)
+        if train:
+            rc = raw.glam_gru_bwd_ws_rng_pre(p(gi), p(gh), p(h), p(out), p(d_out), p(d_drop), p(d_hs), p(xin), p(pre[1]), N, C, flag, act, 0.0, lo, hi,
+                                             dp, p(eff), 0, p(dgi), p(dgh), p(did) if ident else None, p(dx), p(dh), st())
+        else:
+            rc = raw.glam_gru_bwd_ws_pre(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(xin), p(pre[1]), N, C, flag, act, 0.0, 0, p(dgi), p(dgh),
+                                         p(did) if ident else None, p(dx), p(dh), st())
+        assert rc == 0, raw.glam_last_error()
+        res.append((gi, gh, hn, out, drop, dgi, dgh, did, dx, dh))
+    (gi, gh, hn, out, drop, dgi, dgh, did, dx, dh), (G, _, hn2, out2, drop2, D, _, did2, dx2, dh2) = res
+    assert torch.equal(hn, hn2) and torch.equal(out, out2) and torch.equal(dx, dx2) and torch.equal(dh, dh2)
+    assert not train or torch.equal(drop, drop2)
+    assert not ident or torch.equal(did, did2)
+    # the gate gradients: d_gi = D[:, :3C], d_gh = [D[:, :2C] | D[:, 3C:]]
+    assert torch.equal(D[:, :M], dgi) and torch.equal(torch.cat([D[:, :2 * C], D[:, M:]], 1), dgh)
+    # the gates: what the gate equations give on the two pre-activation matrices (fp64), and gh_n itself
+    rr, zz = torch.sigmoid(gi[:, :C].double() + gh[:, :C].double()), torch.sigmoid(gi[:, C:2 * C].double() + gh[:, C:2 * C].double())
+    nn_ = torch.tanh(gi[:, 2 * C:].double() + rr * gh[:, 2 * C:].double())
+    assert_close(G[:, :C], rr, 2e-6, "r")
+    assert_close(G[:, C:2 * C], zz, 2e-6, "z")
+    assert_close(G[:, 2 * C:M], nn_, 2e-6, "n")
+    assert torch.equal(G[:, M:], gh[:, 2 * C:])
+    if N:
+        # one of the pair without the other is an error, not a guess
+        assert raw.glam_gru_bwd_ws_pre(p(G), None, p(h), p(out), p(d_out), p(d_hs), p(x), p(pre[1]), N, C, 0, 1, 0.0, 0, p(D), p(dgh), None, p(dx), p(dh),
+                                       st()) == ops._lib.GLAM_E_INVALID
+        assert raw.glam_gru_bwd_ws_pre(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(x), p(pre[1]), N, C, 0, 1, 0.0, 0, p(dgi), None, None, p(dx), p(dh),
+                                       st()) == ops._lib.GLAM_E_INVALID
+
+
+@pytest.mark.parametrize("N,C,nseg,celu,add", [(20400, 60, 3, False, True), (20400, 60, 1, True, False), (40000, 60, 2, False, False), (700, 48, 3, False, True),
+                                               (33, 24, 1, False, False), (0, 60, 1, False, False)])
+def test_gru_weight_gradients_from_the_one_gate_gradient_matrix(device, N, C, nseg, celu, add):
+    """glam_wgrad_gemm_gru_gates_seg: d_W_ih, d_b_ih, d_W_hh, d_b_hh of torch.nn.GRU (src_1gp/layer.py:247) from D = [d_pr | d_pz | d_pn | d_pn r]
+    — glam_wgrad_gemm_pair_split_seg on the expanded d_gi = D[:, :3C], d_gh = [D[:, :2C] | D[:, 3C:]] bit for bit (same launch, same order of
+    additions), and the fp64 products to rounding."""
+    import ctypes
+    raw, p, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + C + nseg)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    M = 3 * C
+    D, X, H = [r(N, 4 * C) for _ in range(nseg)], [r(N, C) for _ in range(nseg)], [r(N, C) for _ in range(nseg)]
+    dgi = [d[:, :M].contiguous() for d in D]
+    dgh = [torch.cat([d[:, :2 * C], d[:, M:]], 1).contiguous() for d in D]
+    adds = [r(M, C), r(M), r(M, C), r(M)] if add else [None] * 4
+    arr = lambda ts: (ctypes.c_void_p * nseg)(*[t.data_ptr() for t in ts])
+    ws = torch.empty(raw.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    got = [f(M, C), f(M), f(M, C), f(M)]
+    rc = raw.glam_wgrad_gemm_gru_gates_seg(nseg, arr(D), C, arr(X), C, int(celu), arr(H), C, p(got[0]), p(got[1]), p(got[2]), p(got[3]), N, p(ws),
+                                           ws.numel(), *[p(t) for t in adds], st())
+    assert rc == 0, raw.glam_last_error()
+    if N == 0:
+        assert all(not t.any() for t in got)
+        return
+    want = [f(M, C), f(M), f(M, C), f(M)]
+    rc = raw.glam_wgrad_gemm_pair_split_seg(nseg, arr(dgi), M, M, arr(X), C, C, int(celu), p(want[0]), p(want[1]), arr(dgh), M, M, arr(H), C, C, 0,
+                                            p(want[2]), p(want[3]), N, p(ws), ws.numel(), *[p(t) for t in adds], st())
+    if rc == 0:       # (sets shorter than a wave's row range: the two-matrix form refuses, the caller runs them one by one)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    else:
+        assert nseg > 1 and N < 1024
+    xs = [torch.nn.functional.celu(t.double()) if celu else t.double() for t in X]
+    ref = [sum(a.double().t() @ b for a, b in zip(dgi, xs)), sum(a.double().sum(0) for a in dgi),
+           sum(a.double().t() @ b.double() for a, b in zip(dgh, H)), sum(a.double().sum(0) for a in dgh)]
+    for a, b, t, what in zip(got, ref, adds, ("d_W_ih", "d_b_ih", "d_W_hh", "d_b_hh")):
+        assert_close(a, b + (t.double() if t is not None else 0), 3e-6, what)
+    assert raw.glam_wgrad_gemm_gru_gates_seg(nseg, arr(D), 62, arr(X), C, 0, arr(H), C, p(got[0]), p(got[1]), p(got[2]), p(got[3]), N, p(ws), ws.numel(),
+                                             None, None, None, None, st()) == ops._lib.GLAM_E_INVALID
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_message_block_on_kept_gates_matches_the_two_matrix_form(device, monkeypatch, train):
+    """MessageBlock (src_1gp/layer.py:240-266) applied three times with shared weights (model.py:53-54): ops.GRU_GATES on / off give the same
+    outputs and the same gradients of the input and of every parameter, bit for bit (the weight gradients of all three applications in one
+    launch from the three gate-gradient matrices)."""
+    b = synth_batch(700, seed=5).to(device)
+    torch.manual_seed(3)
+    kw = dict(norm="_None", dropout="Dropout(0.2)" if train else "_None()", conv="_TripletMessage", act="RReLU" if train else "ReLU", res=True)
+    blk = layer.MessageBlock(60, 60, 4, **kw).to(device)
+    blk.train(train)
+    x0 = torch.randn(b.x.size(0), 60, device=device)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "GRU_GATES", on)
+        ops.manual_seed(11, device)
+        x = x0.clone().requires_grad_(True)
+        with ops.weight_scope():
+            y, hs = x, None
+            for _ in range(3):
+                y, hs = blk(y, b.edge_index, b.edge_attr, h=hs, batch=b.batch)
+            gs = torch.autograd.grad((y * y).sum() + hs.sum(), [x] + list(blk.parameters()))
+        res.append([y, hs] + list(gs))
+    for i, (a, c) in enumerate(zip(*res)):
+        assert torch.equal(a, c), i
