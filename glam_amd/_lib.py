@@ -80,6 +80,8 @@ SIGNATURES = {
     "glam_gru_ws_make_pre": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "glam_gru_ws_fwd_pre": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp]),
     "glam_gru_ws_rng_fwd_pre": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8 + [_vp]),
+    "glam_gru_ws_fwd_pre_node": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _i32, _f32] + [_vp] * 5 + [_vp, _i32, _vp, _vp] + [_vp]),
+    "glam_gru_ws_rng_fwd_pre_node": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32] + [_vp] * 8 + [_vp, _i32, _vp, _vp] + [_vp]),
     "glam_gru_bwd_ws_pre": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _i32] + [_vp] * 5 + [_vp]),
     "glam_gru_bwd_ws_rng_pre": (_i32, [_vp] * 9 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32] + [_vp] * 5 + [_vp]),
     "glam_gru_fused_image_bytes": (_sz, []),
@@ -146,6 +148,8 @@ SIGNATURES = {
     "glam_s2s_attn_bwd": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp, _vp, _vp]),
     "glam_gru_gates_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "glam_triplet_staged_floats": (_sz, [_i32, _i32, _i32]),
+    "glam_triplet_staged_node_image": (_sz, [_i32, _i32, _i32]),
+    "glam_triplet_staged_node_fragments": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_dstaged_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_plain_floats": (_sz, [_i32, _i32, _i32]),
     "glam_triplet_stage_plain": (_i32, [_vp] * 5 + [_i32] * 5 + [_vp, _vp]),

@@ -2,6 +2,7 @@
 // The two gate GEMMs run on k_ts_gemm (gemm.hip); this file holds the fused gate math and its backward.
 //   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
 // gi = celu(x) @ W_ih^T + b_ih, gh = h @ W_hh^T + b_hh are [N, 3C] (gate order r | z | n, as torch stores them).
+#include <type_traits>
 #include "rng.h"
 #include "dense.h"
 #include "triplet_pipe.h"
@@ -363,6 +364,11 @@ struct GruFusedArgs {
     float* x_celu;      // k_gru_fwd_ws, may be null: celu(x) [N, C] as the producers compute it — what the backward (celu_in = 2) and the weight
                         // gradient (Q without its CELU) then read INSTEAD of x: no exponential in either
     const void* pre;    // k_gru_fwd_ws, may be null: both gate matrices as the consumers' 3 x bf16 fragments (k_gru_ws_pre) — img_ih / img_hh unused
+    // k_gru_fwd_ws, xw non-null: the block is applied again (src_1gp/model.py:53-54) and this step's output rows ARE the next application's
+    // conv input: the producers multiply every finished tile by [W_node | Wa] (node_pre: the matrix as their pre-split operand fragments,
+    // layer.hip: kNodePreFloats; K = C, node_m1 + 8 <= 192 columns) before it leaves LDS and write xw[N, node_m1] | a_ij[N, 8] — the next
+    // TripletMessage starts at its aggregate launch
+    const void* node_pre; float* xw; float* a_ij; int node_m1;
 };
 
 __global__ void __launch_bounds__(kBlock) k_gru_fused_images(const float* w_ih, const float* w_hh, int C, float* img_ih, float* img_hh) {
@@ -553,14 +559,20 @@ __device__ long long g_gru_finef[256 * 12 * 16];     // forward, consumer tiles 
 #define GRU_TL(kid, k) do { } while (0)
 #define GRU_FINEF(k) do { } while (0)
 #endif
+#ifndef GLAM_GRU_NODE_PRIO
+#define GLAM_GRU_NODE_PRIO 0
+#endif
 constexpr int kGwP = 4, kGwC = 4, kGwRing = 4, kGwD = 3;
 constexpr int kGwPitch = 416, kGwPlane = 16 * kGwPitch;                 // bf16 planes: 128 k of [celu(x) | h] per row (triplet_pipe.h: kX3RowBytes)
 constexpr int kGwEPitch = 272, kGwEPlane = 16 * kGwEPitch;              // fp32 planes (h, identity): 64 floats + 4 per row
 constexpr int kGwTile = 3 * kGwPlane + 2 * kGwEPlane;                   // 28 672 bytes
 constexpr int kGwHeader = 128 + 6 * 64 * 4;                             // flags | biases [ih, hh][gate][64]
 constexpr size_t kGwLds = kGwHeader + (size_t)kGwRing * kGwTile;
+// the finished rows on their way to the node product, four tiles
+constexpr int kGwXPitch = 272, kGwXTile = 16 * kGwXPitch, kGwXRing = 4;      // fp32 rows (64 channels + 4): the producers split them
+constexpr size_t kGwLdsNode = kGwLds + (size_t)kGwXRing * kGwXTile;
 
-template <bool RNG>
+template <bool RNG, bool NODE>
 __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs a, TailRng rg) {
     constexpr int P = kGwP, NC = kGwC, RING = kGwRing, D = kGwD, PITCH = kGwPitch, PLANE = kGwPlane, EPITCH = kGwEPitch, EPLANE = kGwEPlane,
                   TILE = kGwTile, MP = 192;
@@ -568,6 +580,14 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
     int* s_ready = reinterpret_cast<int*>(s_gw);
     int* s_taken = s_ready + 16;
     char* s_ring = s_gw + kGwHeader;
+    // node product (a.xw): consumers -> producers, a second ring.  s_xready[slot]: consumer waves that wrote their 16 channels of the
+    // tile, s_xtaken[slot]: producer waves that hold its fragments in registers (both count up over the block's tiles)
+    constexpr int XPITCH = kGwXPitch, XTILE = kGwXTile;
+    int* s_xready = s_ready + 12;
+    int* s_xtaken = s_taken + 12;
+    char* s_xn = s_ring + RING * TILE;
+    constexpr bool node = NODE;      // (an instantiation of its own: decided at run time, every wait for a prefetched row in front of the
+                                     //  branch had to assume the shorter history — the one without the node weights' 18 loads)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int C = a.C, ntiles = (a.N + 15) >> 4, bid = blockIdx.x, nblk = gridDim.x;
     Philox ph{};
@@ -609,42 +629,138 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
         for (int d = 0; d < D; ++d) load(bid + d * nblk, buf[d]);
         if (lane == 0) flag_bump(s_ready + 8);      // (this wave's first loads are in the queue)
         GRU_TL(0, 1);
+        // ---- the node product of a finished tile: x_next[16, C] @ [W_node | Wa] — producer wave p owns output columns 48 p .. 48 p + 47
+        //      (three 16-column fragments, W as the FIRST matrix operand: a lane ends up with four consecutive columns of one row).
+        //      The partial products of k_ts_gemm_x3_sw in its order (there x is the first operand): the same bits as the stand-alone
+        //      launch.  The weights come split already, in lane order (the staging launch wrote them: 18 coalesced 1 KB loads per wave
+        //      behind the first tiles' rows; from the fp32 image — 12 scattered loads per lane in front of everything the block's other
+        //      waves ask for, then the splits — every first tile went out 3.4 k cycles later) ----
+        const int nc = lane & 15, nkb = lane >> 4;
+        Bf16x3 wn[2][3];
+        const int my_tiles = bid < ntiles ? (ntiles - bid + nblk - 1) / nblk : 0;
+        int jn = 0;                                  // the next finished tile to multiply
+        auto node_ready = [&](int j) { return j < my_tiles && flag_load(s_xready + (j & 3)) >= NC * ((j >> 2) + 1); };
+        auto node_product = [&](int j) {
+            asm volatile("" ::: "memory");
+            const int xs = j & 3, tile = bid + j * nblk;
+            const char* xb = s_xn + xs * XTILE + nc * XPITCH + nkb * 32;       // row nc, k = 32 s + 8 nkb ..: fp32, split here (the
+            float4 xr[2][2];                                                   // consumers set the pace: they write one 16-byte piece)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { xr[s][0] = *reinterpret_cast<const float4*>(xb + 128 * s); xr[s][1] = *reinterpret_cast<const float4*>(xb + 128 * s + 16); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) flag_bump(s_xtaken + xs);
+            Bf16x3 xv[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) xv[s] = split8(xr[s][0], xr[s][1]);
+            v4f_t acc[3], accb[3];
+#pragma unroll
+            for (int j3 = 0; j3 < 3; ++j3) { acc[j3] = (v4f_t){0.f, 0.f, 0.f, 0.f}; accb[j3] = acc[j3]; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j3 = 0; j3 < 3; ++j3) {      // x.mid w.mid, x.hi w.lo, x.lo w.hi
+                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].mid, xv[s].mid, acc[j3], 0, 0, 0);
+                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].lo, xv[s].hi, acc[j3], 0, 0, 0);
+                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].hi, xv[s].lo, acc[j3], 0, 0, 0);
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j3 = 0; j3 < 3; ++j3) {      // x.hi w.mid, x.mid w.hi
+                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].mid, xv[s].hi, acc[j3], 0, 0, 0);
+                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].hi, xv[s].mid, acc[j3], 0, 0, 0);
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j3 = 0; j3 < 3; ++j3) accb[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].hi, xv[s].hi, accb[j3], 0, 0, 0);
+            const int row = 16 * tile + nc;
+            if (row < a.N) {
+#pragma unroll
+                for (int j3 = 0; j3 < 3; ++j3) {
+                    const int col0 = 16 * (3 * wave + j3) + 4 * nkb;
+                    const float4 v = make_float4(acc[j3][0] + accb[j3][0], acc[j3][1] + accb[j3][1], acc[j3][2] + accb[j3][2], acc[j3][3] + accb[j3][3]);
+                    if (col0 < a.node_m1) st4(a.xw + (size_t)row * a.node_m1 + col0, v);
+                    else if (col0 < a.node_m1 + 8) st4(a.a_ij + (size_t)row * 8 + (col0 - a.node_m1), v);
+                }
+            }
+        };
+        // one tile out of register set d into ring slot it % RING (the slot is free), and that set's next loads
+        auto publish = [&](auto dc, int it) {
+            constexpr int d = decltype(dc)::value;
+            const int tile = bid + it * nblk, slot = it % RING;
+            asm volatile("" ::: "memory");
+            char* tl = s_ring + slot * TILE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
+                float4 v = chunk_ok(tile, j) ? buf[d][j] : f4zero();
+                if (q >= 16) *reinterpret_cast<float4*>(tl + 3 * PLANE + r * EPITCH + (q - 16) * 16) = v;      // h, exact
+                else if (a.celu_in) {
+                    v = celu4(v);
+                    if (a.x_celu && chunk_ok(tile, j)) st4(a.x_celu + (size_t)(tile * 16 + r) * C + 4 * q, v);
+                }
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2(v.x, v.y, h0, m0, l0);
+                split2(v.z, v.w, h1, m1, l1);
+                char* p = tl + r * PITCH + q * 8;
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
+            }
+            *reinterpret_cast<float4*>(tl + 3 * PLANE + EPLANE + er * EPITCH + eq * 16) = id_ok(tile) ? buf[d][2] : f4zero();
+            load(tile + D * nblk, buf[d]);              // this register set's next tile, D tiles ahead
+            // beyond the LLC three tiles of loads in flight per producer make the launch SLOWER (N = 326 400: 248 -> 280 us; the
+            // pointer loads this kernel used to do by accident — see `px` above — had kept it to one): there the producer waits
+            // for its prefetch
+            if (a.N > 131072) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) flag_bump(s_ready + slot);
+        };
+        // With the node product a STATIC schedule: iteration `it` first multiplies tile it - RING (finished a little after its ring slot
+        // came free: the consumers bump s_taken in front of their epilogue and s_xready behind it), then publishes tile `it`; the last RING
+        // tiles follow behind the loop.  The product's three stores share the memory counter with the row prefetch: at a fixed place in
+        // the iteration the compiler counts them (the wait for a register set stays "all but the newer loads and stores"); taken whenever
+        // a finished tile showed up — a loop over events — every wait had to assume the shortest history, the prefetch was one tile deep
+        // and a producer pass took 5.5 k cycles instead of 2.7 k
+        if constexpr (NODE) {
+            // the block's first tile goes out in front of the loop and the node weights are asked for BEHIND it (straight-line code: the
+            // counts the waits are built from stay exact): 72 KB per block that nobody needs before the consumers are through their first
+            // tile — issued with the first rows, they stood in the CU's queue in front of the consumers' own 144 KB
+            if (my_tiles > 0) publish(std::integral_constant<int, 0>{}, 0);
+            const char* base = reinterpret_cast<const char*>(a.node_pre) + (size_t)wave * (18 * 1024) + lane * 16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j3 = 0; j3 < 3; ++j3) {
+                    const char* f = base + (s * 3 + j3) * 3072;
+                    wn[s][j3].hi = ldfrag(f); wn[s][j3].mid = ldfrag(f + 1024); wn[s][j3].lo = ldfrag(f + 2048);
+                }
+        }
         for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int it = it0 + d, tile = bid + it * nblk;
                 if (it == 1) GRU_TL(0, 2);
-                if (tile < ntiles) {
+                if (tile < ntiles && !(NODE && it == 0)) {
                     const int slot = it % RING, round = it / RING;
                     while (flag_load(s_taken + slot) < NC * round) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                    char* tl = s_ring + slot * TILE;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int idx = lane + 64 * (wave + P * j), r = idx >> 5, q = idx & 31;
-                        float4 v = chunk_ok(tile, j) ? buf[d][j] : f4zero();
-                        if (q >= 16) *reinterpret_cast<float4*>(tl + 3 * PLANE + r * EPITCH + (q - 16) * 16) = v;      // h, exact
-                        else if (a.celu_in) {
-                            v = celu4(v);
-                            if (a.x_celu && chunk_ok(tile, j)) st4(a.x_celu + (size_t)(tile * 16 + r) * C + 4 * q, v);
-                        }
-                        unsigned h0, m0, l0, h1, m1, l1;
-                        split2(v.x, v.y, h0, m0, l0);
-                        split2(v.z, v.w, h1, m1, l1);
-                        char* p = tl + r * PITCH + q * 8;
-                        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
-                        *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
+                    if (node && it >= RING) {
+                        while (!node_ready(jn)) __builtin_amdgcn_s_sleep(1);
+                        node_product(jn);
+                        ++jn;
                     }
-                    *reinterpret_cast<float4*>(tl + 3 * PLANE + EPLANE + er * EPITCH + eq * 16) = id_ok(tile) ? buf[d][2] : f4zero();
-                    load(tile + D * nblk, buf[d]);              // this register set's next tile, D tiles ahead
-                    // beyond the LLC three tiles of loads in flight per producer make the launch SLOWER (N = 326 400: 248 -> 280 us; the
-                    // pointer loads this kernel used to do by accident — see `px` above — had kept it to one): there the producer waits
-                    // for its prefetch
-                    if (a.N > 131072) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) flag_bump(s_ready + slot);
+                    static_assert(D == 3, "register sets");
+                    if (d == 0) publish(std::integral_constant<int, 0>{}, it);
+                    else if (d == 1) publish(std::integral_constant<int, 1>{}, it);
+                    else publish(std::integral_constant<int, 2>{}, it);
                 }
+            }
+        }
+        if (node) {
+            for (; jn < my_tiles; ++jn) {
+                while (!node_ready(jn)) __builtin_amdgcn_s_sleep(1);
+                node_product(jn);
             }
         }
         GRU_TL(0, 3);
@@ -702,6 +818,9 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
         }
         const int ch = 16 * w + 4 * kb;
         const bool gates = a.gh == nullptr;
+#if GLAM_GRU_NODE_PRIO
+        if (node) __builtin_amdgcn_s_setprio(GLAM_GRU_NODE_PRIO);      // the consumers set the pace: their matrix instructions before the node product's
+#endif
         float4 bias_i[3], bias_h[3];               // the lane's four channels of every gate (zero beyond C)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -720,7 +839,14 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             const int slot = it % RING, want = P * (it / RING + 1);
             const int row = 16 * tile + c;
             if (it == 0) GRU_FINEF(0); else if (it == 2) GRU_FINEF(8);
+            // (the slot of the node ring this tile's rows go to: its check rides along with the wait for the tile)
+            int xt = 0;
+            if (node && it >= kGwXRing) xt = __hip_atomic_load(s_xtaken + (it & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             while (flag_load(s_ready + slot) < want) __builtin_amdgcn_s_sleep(1);
+            if (node && it >= kGwXRing) {
+                xt = __builtin_amdgcn_readfirstlane(xt);
+                while (xt < P * (it >> 2)) { __builtin_amdgcn_s_sleep(1); xt = flag_load(s_xtaken + (it & 3)); }
+            }
             asm volatile("" ::: "memory");
             if (it == 0) GRU_FINEF(1); else if (it == 2) GRU_FINEF(9);
             const char* tl = s_ring + slot * TILE + c * PITCH + kb * 16;       // row c, k = 32 s + 8 kb ..  (s = 0, 1: celu(x); 2, 3: h)
@@ -777,6 +903,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 xa = xb;
             }
             if (it == 0) GRU_FINEF(2); else if (it == 2) GRU_FINEF(10);
+            float* const xp = reinterpret_cast<float*>(s_xn + (it & 3) * XTILE + c * XPITCH) + ch;      // the lane's piece of the next conv input
             if (row < a.N && ch < C) {
                 float4 gi4[3], gh4[3];
 #pragma unroll
@@ -807,6 +934,11 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                     (&r4.x)[j] = r; (&z4.x)[j] = z; (&n4.x)[j] = nn;
                     if constexpr (RNG) (&od4.x)[j] = o * drop_scale_w(wd, rg.p);
                 }
+                if (node) {       // (in front of the stores: the LDS write is through by the time they are issued)
+                    float4 xnext = o4;
+                    if constexpr (RNG) { if (rg.out_drop) xnext = od4; }      // (the next conv reads the dropped twin)
+                    *reinterpret_cast<float4*>(xp) = xnext;
+                }
                 if (gates) {      // [r | z | n | gh_n]: all the backward takes from the two pre-activation matrices (see GruFusedArgs)
                     float* gp = a.gi + (size_t)row * 4 * C + ch;
                     st4(gp, r4); st4(gp + C, z4); st4(gp + 2 * C, n4); st4(gp + 3 * C, gh4[2]);
@@ -814,6 +946,12 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
                 st4(a.h_new + e, hn4);
                 st4(a.out + e, o4);
                 if constexpr (RNG) { if (rg.out_drop) st4(rg.out_drop + e, od4); }
+            } else if (node) {
+                *reinterpret_cast<float4*>(xp) = f4zero();      // (zero beyond the matrix: the product runs over 64 channels)
+            }
+            if (node) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) flag_bump(s_xready + (it & 3));
             }
             if (it == 0) GRU_FINEF(4); else if (it == 2) GRU_FINEF(12);
         }
@@ -1202,14 +1340,25 @@ extern "C" int glam_gru_ws_make_pre(const float* w_ih, const float* w_hh, int C,
 extern "C" int glam_gru_ws_supported(int C) { return C >= 24 && C <= 64 && (C & 3) == 0; }
 
 static int gru_ws_launch(const GruFusedArgs& a, const TailRng* rg, hipStream_t s) {
-    static bool big0[64] = {}, big1[64] = {};
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<false>), big0, "gru_ws_fwd")) return rc;
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<true>), big1, "gru_ws_fwd")) return rc;
+    static bool big0[64] = {}, big1[64] = {}, big2[64] = {}, big3[64] = {};
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<false, false>), big0, "gru_ws_fwd")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<true, false>), big1, "gru_ws_fwd")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<false, true>), big2, "gru_ws_fwd")) return rc;
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_gru_fwd_ws<true, true>), big3, "gru_ws_fwd")) return rc;
     const int ntiles = (a.N + 15) / 16, cap = ws_grid_cap(1024);
     const int grid = ntiles < cap ? ntiles : cap;
-    if (!a.gh) GLAM_PROF_LABEL(rg ? "k_gru_fwd_ws<true, gates>" : "k_gru_fwd_ws<false, gates>");
-    if (rg) hipLaunchKernelGGL(k_gru_fwd_ws<true>, dim3(grid), dim3((kGwP + kGwC) * 64), kGwLds, s, a, *rg);
-    else hipLaunchKernelGGL(k_gru_fwd_ws<false>, dim3(grid), dim3((kGwP + kGwC) * 64), kGwLds, s, a, TailRng{});
+    const size_t lds = a.xw ? kGwLdsNode : kGwLds;
+    if (a.xw) GLAM_PROF_LABEL(rg ? "k_gru_fwd_ws<true>+node" : "k_gru_fwd_ws<false>+node");
+    else if (!a.gh) GLAM_PROF_LABEL(rg ? "k_gru_fwd_ws<true, gates>" : "k_gru_fwd_ws<false, gates>");
+    const dim3 g(grid), b((kGwP + kGwC) * 64);
+    if (a.xw) {
+        if (rg) hipLaunchKernelGGL((k_gru_fwd_ws<true, true>), g, b, lds, s, a, *rg);
+        else hipLaunchKernelGGL((k_gru_fwd_ws<false, true>), g, b, lds, s, a, TailRng{});
+    } else {
+        if (a.gh) GLAM_PROF_LABEL(rg ? "k_gru_fwd_ws<true>" : "k_gru_fwd_ws<false>");      // (the names the stringified launch used to have)
+        if (rg) hipLaunchKernelGGL((k_gru_fwd_ws<true, false>), g, b, lds, s, a, *rg);
+        else hipLaunchKernelGGL((k_gru_fwd_ws<false, false>), g, b, lds, s, a, TailRng{});
+    }
     GLAM_LAUNCH_CHECK("gru_ws_fwd");
     return GLAM_OK;
 }
@@ -1224,13 +1373,25 @@ static int gru_ws_args_ok(const char* fn, const GruFusedArgs& a, int64_t N) {
     return GLAM_OK;
 }
 
+// the node product of the NEXT application of the block inside this launch (see GruFusedArgs): all four given or none
+struct GruNode { const void* img; int cols; float* xw; float* a_ij; };
+static int gru_node_ok(const char* fn, const GruNode& n, int C) {
+    if (!n.img && !n.xw && !n.a_ij) return GLAM_OK;
+    GLAM_REQUIRE(n.img && n.xw && n.a_ij && aligned16(n.img) && aligned16(n.xw) && aligned16(n.a_ij), "%s: node image, xw and a_ij are given together, 16-byte aligned", fn);
+    if (!(n.cols > 0 && (n.cols & 3) == 0 && n.cols + 8 > 64 && n.cols + 8 <= 192 && C >= 24))
+        return fail(GLAM_E_UNSUPPORTED, "%s: the node product takes 56 < H*Cp <= 184 columns, a multiple of 4 (%d)", fn, n.cols);
+    return GLAM_OK;
+}
+
 static int gru_ws_fwd_impl(const char* fn, const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                            const void* pre, const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
-                           float* h_new, float* out, float* x_celu, hipStream_t s) {
+                           float* h_new, float* out, float* x_celu, hipStream_t s, GruNode nd = GruNode{nullptr, 0, nullptr, nullptr}) {
     if (act < kActNone || act > kActCelu) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d", fn, act);
     GLAM_REQUIRE(!x_celu || (celu_in && aligned16(x_celu)), "%s: x_celu needs celu_in and 16-byte alignment", fn);
-    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu, pre};
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu, pre,
+                         nd.img, nd.xw, nd.a_ij, nd.cols};
     if (int rc = gru_ws_args_ok(fn, a, N)) return rc;
+    if (int rc = gru_node_ok(fn, nd, C)) return rc;
     if (N == 0) return GLAM_OK;
     return gru_ws_launch(a, nullptr, s);
 }
@@ -1253,11 +1414,13 @@ static int rng_args_ok(const char* fn, int act, float lo, float hi, float p);
 static int gru_ws_rng_fwd_impl(const char* fn, const float* x, const float* h, const float* identity, const float* img_ih, const float* img_hh,
                                const void* pre, const float* b_ih, const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
                                float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new,
-                               float* out, float* out_drop, float* x_celu, hipStream_t s) {
+                               float* out, float* out_drop, float* x_celu, hipStream_t s, GruNode nd = GruNode{nullptr, 0, nullptr, nullptr}) {
     if (int rc = rng_args_ok(fn, act, rr_lower, rr_upper, drop_p)) return rc;
     GLAM_REQUIRE(!x_celu || (celu_in && aligned16(x_celu)), "%s: x_celu needs celu_in and 16-byte alignment", fn);
-    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu, pre};
+    const GruFusedArgs a{x, h, identity, img_ih, img_hh, b_ih, b_hh, gi, gh, h_new, out, (int)N, C, celu_in, act, slope, x_celu, pre,
+                         nd.img, nd.xw, nd.a_ij, nd.cols};
     if (int rc = gru_ws_args_ok(fn, a, N)) return rc;
+    if (int rc = gru_node_ok(fn, nd, C)) return rc;
     if (N == 0) return GLAM_OK;
     GLAM_REQUIRE(rng_state && rng_eff && aligned16(out_drop), "%s: null RNG state / misaligned out_drop", fn);
     const TailRng rg{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p, out_drop, 1};
@@ -1294,6 +1457,32 @@ extern "C" int glam_gru_ws_rng_fwd_pre(const float* x, const float* h, const flo
     GLAM_REQUIRE(pre_fwd || N == 0, "glam_gru_ws_rng_fwd_pre: null image");
     return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd_pre", x, h, identity, nullptr, nullptr, pre_fwd, b_ih, b_hh, N, C, celu_in, act, slope,
                                rr_lower, rr_upper, drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, x_celu, (hipStream_t)stream);
+}
+
+// ... and the node product of the block's NEXT application (src_1gp/model.py:53-54: the same block is applied message_steps times, so
+// this step's output rows — the dropped twin in the rng form when out_drop is given — are the next TripletMessage's input): the launch
+// also writes xw[N, node_cols] | a_ij[N, 8] = out @ [W_node | Wa] from node_pre, that matrix as the producers' pre-split operand
+// fragments (K = C rows, node_cols + 8 columns: glam_triplet_staged_node_fragments) — what glam_ts_gemm writes for the same rows, bit for bit;
+// glam_triplet_layer_fwd_ell with x = NULL then starts at its aggregate launch.
+extern "C" int glam_gru_ws_fwd_pre_node(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                                        const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh,
+                                        float* h_new, float* out, float* x_celu, const void* node_pre, int node_cols, float* xw,
+                                        float* a_ij, void* stream) {
+    GLAM_REQUIRE(pre_fwd || N == 0, "glam_gru_ws_fwd_pre_node: null image");
+    GLAM_REQUIRE(node_pre && xw && a_ij, "glam_gru_ws_fwd_pre_node: null node image / output");
+    return gru_ws_fwd_impl("glam_gru_ws_fwd_pre_node", x, h, identity, nullptr, nullptr, pre_fwd, b_ih, b_hh, N, C, celu_in, act, slope, gi, gh,
+                           h_new, out, x_celu, (hipStream_t)stream, GruNode{node_pre, node_cols, xw, a_ij});
+}
+extern "C" int glam_gru_ws_rng_fwd_pre_node(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                                            const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower,
+                                            float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh,
+                                            float* h_new, float* out, float* out_drop, float* x_celu, const void* node_pre,
+                                            int node_cols, float* xw, float* a_ij, void* stream) {
+    GLAM_REQUIRE(pre_fwd || N == 0, "glam_gru_ws_rng_fwd_pre_node: null image");
+    GLAM_REQUIRE(node_pre && xw && a_ij, "glam_gru_ws_rng_fwd_pre_node: null node image / output");
+    return gru_ws_rng_fwd_impl("glam_gru_ws_rng_fwd_pre_node", x, h, identity, nullptr, nullptr, pre_fwd, b_ih, b_hh, N, C, celu_in, act, slope,
+                               rr_lower, rr_upper, drop_p, rng_state, rng_eff, gi, gh, h_new, out, out_drop, x_celu, (hipStream_t)stream,
+                               GruNode{node_pre, node_cols, xw, a_ij});
 }
 
 extern "C" int glam_gru_fused_supported(int C) { return C >= 4 && C <= 64 && (C & 3) == 0; }

@@ -19,13 +19,18 @@ namespace glam {
 
 // layout of the staged-parameter buffer (floats; every offset is a multiple of 4)
 struct Staged {
-    size_t img_node, img_upd, img_dagg, img_dx, we_p, m, bias_p, dagg_pre, total;
+    size_t img_node, img_upd, img_dagg, img_dx, we_p, m, bias_p, dagg_pre, node_pre, total;
 };
 // W_scale^T as the operand fragments of B1's four matrix waves, ALREADY split into their three bf16 terms, in lane order:
 // [wave w][k step st][column tile ct][term][lane] x 16 bytes (kDaggPreFloats floats; H = 3 only).  The matrix waves produce the tiles the
 // vector waves wait for, and their prologue — 24 scattered weight loads, then 400 vector instructions of splits — stood in front of the
 // first tile (r6_ws_timeline_b1024.txt: first tile 4.3 k cycles behind the block's barrier); 36 coalesced 1 KB loads replace it.
 constexpr int kDaggPreFloats = 4 * 2 * 3 * 3 * 64 * 4;
+// [W_node | Wa] as the operand fragments of the node product inside k_gru_fwd_ws (block.hip: the GRU step of a block that is applied again
+// writes the next application's x @ [W_node | Wa]): [producer wave p][k step s][column tile j][term][lane] x 16 bytes — lane (c, kb) of
+// fragment (p, s, j) holds W[32 s + 8 kb .. + 7][16 (3 p + j) + c], split into its three bf16 terms (zero beyond the matrix).  The same
+// size as the B1 image; present when the node image has 192 column positions (64 < H * Cp + 8 <= 192).
+constexpr int kNodePreFloats = 4 * 2 * 3 * 3 * 64 * 4;
 static Staged staged_layout(int H, int Cp, int Dp) {
     const int HC = H * Cp;
     Staged s;
@@ -39,6 +44,7 @@ static Staged staged_layout(int H, int Cp, int Dp) {
     s.bias_p = o;   o += (size_t)Cp;
     o = (o + 63) & ~(size_t)63;                          // (256-byte aligned: 1 KB coalesced fragment loads)
     s.dagg_pre = o; o += (H == 3 && HC <= 192) ? kDaggPreFloats : 0;
+    s.node_pre = o; o += (HC + 8 > 64 && HC + 8 <= 192) ? kNodePreFloats : 0;
     s.total = o;
     return s;
 }
@@ -152,13 +158,21 @@ __device__ __forceinline__ void stage_params_block(const StageArgs& a, int copy_
                 const int m = HC + sx;                       // Wcat[k = r][m]
                 a.base[a.L.img_node + ((size_t)(r >> 2) * P1 + ts_pos_of_col(m)) * 4 + (r & 3)] = v;
                 a.base[a.L.img_dx + ((size_t)(m >> 2) * 64 + ts_pos_of_col(r)) * 4 + (m & 3)] = v;   // Wcat^T[m][r]
+                if (a.L.total > a.L.node_pre) {              // ... and its three bf16 terms into the node product's fragment image
+                    const int f = ((m / 48) * 2 + (r >> 5)) * 3 + (m % 48) / 16, ln = ((r & 31) >> 3) * 16 + (m & 15);
+                    unsigned hh, mm, ll;
+                    split2(v, 0.f, hh, mm, ll);
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(a.base + a.L.node_pre) + ((size_t)(f * 3) * 64 + ln) * 8 + (r & 7);
+                    dst[0] = (unsigned short)hh; dst[64 * 8] = (unsigned short)mm; dst[2 * 64 * 8] = (unsigned short)ll;
+                }
             }
         }
         return;
     }
     const int n1 = Kp1 * P1, n2 = Kp2 * 64, n3 = Kp1 * P3, n4 = Kp4 * 64, n5 = Dp * HC, n6 = Dp * 4, n7 = Cp;
     const int n8 = (H == 3 && HC <= 192) ? 4 * 2 * 3 * 64 : 0;          // pre-split fragments of B1's matrix waves: one item per (w, st, ct, lane)
-    const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7 + n8;
+    const int n9 = (a.L.total > a.L.node_pre) ? 4 * 2 * 3 * 64 : 0;      // pre-split fragments of the node product inside the GRU step: (p, s, j, lane)
+    const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7 + n8 + n9;
     // image element idx -> (k, logical column m): layout [k/4][p][k%4], column order ts_col_of_pos
     for (int idx = bid * kBlock + threadIdx.x; idx < total; idx += copy_blocks * kBlock) {
         int i = idx;
@@ -206,6 +220,30 @@ __device__ __forceinline__ void stage_params_block(const StageArgs& a, int copy_
             continue;
         }
         i -= n7;
+        if (i >= n8) {
+            // (p, s, j, lane = (c, kb)): rows k0 .. k0 + 7 of column mcol of [W_node | Wa].  The attention columns are the dot blocks'
+            // (they write their elements' three terms themselves): here only what is zero there — the rows beyond C
+            i -= n8;
+            const int lane = i & 63, f = i >> 6, j = f % 3, st = (f / 3) & 1, w = f / 6;
+            const int c = lane & 15, kb = lane >> 4, mcol = 16 * (3 * w + j) + c, k0 = 32 * st + 8 * kb;
+            float v[8];
+            bool dot[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dot[u] = false; v[u] = (k0 + u < Cp && mcol < HC + 8) ? wcat_val(a, k0 + u, mcol, &dot[u]) : 0.f; }
+            const Bf16x3 fr = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+            float* dst = a.base + a.L.node_pre + ((size_t)(f * 3) * 64 + lane) * 4;
+            if (!(dot[0] | dot[1] | dot[2] | dot[3] | dot[4] | dot[5] | dot[6] | dot[7])) {
+                *reinterpret_cast<bf16x8_t*>(dst) = fr.hi;
+                *reinterpret_cast<bf16x8_t*>(dst + 256) = fr.mid;
+                *reinterpret_cast<bf16x8_t*>(dst + 512) = fr.lo;
+            } else {
+                unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (!dot[u]) { d16[u] = 0; d16[512 + u] = 0; d16[1024 + u] = 0; }
+            }
+            continue;
+        }
         {   // (w, st, ct, lane = (c, kq)): rows k0 .. k0 + 7 of column mcol of W_scale^T — the values k_triplet_bwd_dst_ws's matrix wave w
             // reads out of the d_aggr image (w_load8) and splits (w_split8): the same function on the same numbers, bit-identical
             const int lane = i & 63, f = i >> 6, ct = f % 3, st = (f / 3) & 1, w = f / 6;
@@ -817,7 +855,7 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
     if (int rc = dims_ok("glam_triplet_layer_fwd_ell", Cp, H, Dp, Cp, Dp)) return rc;
     GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_triplet_layer_fwd_ell: N out of range");
     if (N == 0) return GLAM_OK;
-    GLAM_REQUIRE(x && staged && ell_src && ell_eid && xw && a_ij && (!aggr) == (!stats) && out && (E == 0 || edge_attr),
+    GLAM_REQUIRE(staged && ell_src && ell_eid && xw && a_ij && (!aggr) == (!stats) && out && (E == 0 || edge_attr),
                  "glam_triplet_layer_fwd_ell: null pointer");      // (aggr = stats = NULL: the inference forward, nothing kept for a backward pass)
     GLAM_REQUIRE(aligned16(x) && aligned16(xw) && aligned16(a_ij) && aligned16(aggr) && aligned16(out) && aligned16(staged) &&
                      aligned16(edge_attr) && aligned16(stats), "glam_triplet_layer_fwd_ell: 16-byte alignment");
@@ -827,10 +865,21 @@ extern "C" int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr
     hipStream_t s = (hipStream_t)stream;
     const int HC = H * Cp;
     const Staged L = staged_layout(H, Cp, Dp);
-    TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
-    if (int rc = launch_ts_gemm(g1, s)) return rc;
+    if (x) {      // (x = NULL: xw and a_ij hold the node product already — glam_gru_ws_*_fwd_pre_node wrote them with the rows themselves)
+        TsArgs g1{x, Cp, Cp, nullptr, 0, 0, staged + L.img_node, nullptr, xw, HC, HC, a_ij, 8, 8, (int)N};
+        if (int rc = launch_ts_gemm(g1, s)) return rc;
+    }
     return triplet_fwd_ws(xw, a_ij, edge_attr, staged + L.we_p, staged + L.m, ell_src, ell_eid, N, E, H, Cp, Dp, slope, edge_onehot,
                           aggr, stats, staged + L.img_upd, staged + L.bias_p, out, s);
+}
+
+// where the k_ts_gemm image of [W_node | Wa] (K = Cp, H*Cp + 8 columns) sits inside the staged buffer, in floats: what
+// glam_gru_ws_*_fwd_pre_node takes as node_img
+extern "C" size_t glam_triplet_staged_node_image(int H, int Cp, int Dp) { return staged_layout(H, Cp, Dp).img_node; }
+// ... and of the same matrix as the pre-split operand fragments of that launch's producer waves (72 KB; (size_t)-1: none for this shape)
+extern "C" size_t glam_triplet_staged_node_fragments(int H, int Cp, int Dp) {
+    const Staged L = staged_layout(H, Cp, Dp);
+    return L.total > L.node_pre ? L.node_pre : (size_t)-1;
 }
 
 extern "C" int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot) {

@@ -987,6 +987,18 @@ class MessageBlock(torch.nn.Module):
             return "leaky", (float(a.lower) + float(a.upper)) / 2, None      # eval: the fixed mean slope
         return None                                  # PReLU (learnable slope): stays on torch
 
+    def _next_node(self, n_rows, fa):
+        """``ops.next_node_spec`` of this block's conv when the rows the GRU tail is about to write reach that conv unchanged in the next
+        application: no norm, and a dropout slot that is empty, inactive, or the training-mode Dropout whose mask the tail draws."""
+        conv = self.conv.conv if isinstance(self.conv, _TripletMessage) else None
+        if conv is None or not isinstance(self.norm, _None):
+            return None
+        d = self.dropout
+        live = type(d) is Dropout and self.training and 0 < d.p
+        if not (isinstance(d, _None) or type(d) is Dropout) or (live and not (d.p < 1 and fa[2] is not None and fa[2][2] == float(d.p))):
+            return None
+        return ops.next_node_spec(conv, n_rows)
+
     def forward(self, x, edge_index, edge_attr, h=None, batch=None):
         identity = x
         seeded = h is None
@@ -1031,9 +1043,12 @@ class MessageBlock(torch.nn.Module):
         if self.gru is not None:
             g = self.gru
             if fa is not None and (fa[2] is None or ops.gru_rng_supported(x.size(1), g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0)):
-                # CELU (layer.py:261) + GRU step + residual + activation: one autograd node
+                # CELU (layer.py:261) + GRU step + residual + activation: one autograd node — which, when this block is applied again
+                # (model.py:53-54) and nothing but the fused Dropout stands between its output and its conv, also writes the node
+                # product of that next application
                 x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,
-                                     g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1], celu_in=True, rng=fa[2])
+                                     g.bias_ih_l0, g.bias_hh_l0, act=fa[0], slope=fa[1], celu_in=True, rng=fa[2],
+                                     node=self._next_node(x.size(0), fa))
                 return x, hn.unsqueeze(0)
             if fa is not None and fa[0] != "rrelu":  # odd widths in training mode: fused tail without the dropped twin
                 x, hn = ops.gru_tail(x, h.squeeze(0), None if self.res is False else identity, g.weight_ih_l0, g.weight_hh_l0,

@@ -62,8 +62,9 @@ class Architecture(torch.nn.Module):
         # (next_dropout: the block behind applies Dropout to this output first — the activation's launch writes the dropped twin)
         xm = self.mol_lin0(data_mol.x, batch=data_mol.batch, next_dropout=following_dropout(self.mol_conv))     # model.py:49
         hm = None
-        for _ in range(self.message_steps):                                        # model.py:53-54
-            xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
+        for i in range(self.message_steps):                                        # model.py:53-54
+            with ops.block_feeds_itself(i + 1 < self.message_steps):      # (its output is the same block's next input)
+                xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
         # PyG's pools read the graph count back from ``batch``; a collated Batch already knows it
         num_graphs = getattr(data_mol, "num_graphs", None) or None
         outm = self.mol_readout(xm, data_mol.batch, num_graphs)                    # model.py:57
@@ -115,8 +116,9 @@ class ArchitectureDTI(torch.nn.Module):
         xp = self.pro_lin0(data_pro.x, batch=data_pro.batch)
         hm, hp = None, None
         fusion = []
-        for _ in range(self.message_steps):
-            xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
+        for i in range(self.message_steps):
+            with ops.block_feeds_itself(i + 1 < self.message_steps):      # (its output is the same block's next input)
+                xm, hm = self.mol_conv(xm, data_mol.edge_index, data_mol.edge_attr, h=hm, batch=data_mol.batch)
             xp, hp = self.pro_conv(xp, data_pro.edge_index, data_pro.edge_attr, h=hp, batch=data_pro.batch)
             # (every step's outputs feed this fusion AND the next step / the readouts: they come back from the fusion node, so that both
             #  gradients meet inside its backward launch instead of in an add launch per tower)
@@ -170,9 +172,10 @@ class ArchitectureDDI(torch.nn.Module):
         x2 = self.mol2_lin0(mol2.x, batch=mol2.batch)
         h1, h2 = None, None
         fusion = []
-        for _ in range(self.message_steps):
-            x1, h1 = self.mol1_conv(x1, mol1.edge_index, mol1.edge_attr, h=h1, batch=mol1.batch)
-            x2, h2 = self.mol2_conv(x2, mol2.edge_index, mol2.edge_attr, h=h2, batch=mol2.batch)
+        for i in range(self.message_steps):
+            with ops.block_feeds_itself(i + 1 < self.message_steps):      # (the fusion hands the rows back untouched)
+                x1, h1 = self.mol1_conv(x1, mol1.edge_index, mol1.edge_attr, h=h1, batch=mol1.batch)
+                x2, h2 = self.mol2_conv(x2, mol2.edge_index, mol2.edge_attr, h=h2, batch=mol2.batch)
             f, x1, x2 = dot_and_global_pool2(x1, x2, mol1.batch, mol2.batch, with_identity=True)
             fusion.append(f)
         n1 = getattr(mol1, "num_graphs", None) or None

@@ -702,17 +702,22 @@ class _TripletLayer(torch.autograd.Function):
         # ops.cached_staging() the staged images additionally survive from pass to pass until a parameter is written
         staged = _staged_cached(("triplet", H, Cp, Dp), (wn, we, att, wsc, bias), build) if CACHED_STAGING else \
             _scoped(_SCOPE.fwd if _SCOPE else None, ("triplet", id(wn), id(we), id(att), id(wsc), id(bias)), wn, build)
-        xw, a_ij, out = torch.empty(N, HC, **f), torch.empty(N, 8, **f), torch.empty(N, Cp, **f)
+        out = torch.empty(N, Cp, **f)
         # molecular graphs with one-hot bond features take the warp-specialised kernels at every size (13.6 vs 16.8 us at B = 1 024,
         # 136 vs 256 us at B = 16 384 against the general fused kernel); everything else the general kernels
         ell = gi.ell() if _ws_route(lib, N, H, Cp, Dp, ea_p) else None
+        # the node product may exist already: the previous application's GRU step wrote it with these very rows (ops.NODE_IN_GRU)
+        given = take_node_product(x_p, staged) if ell is not None else None
+        xw, a_ij = given if given is not None else (torch.empty(N, HC, **f), torch.empty(N, 8, **f))
+        if ell is not None and _SCOPE is not None:
+            _SCOPE.fwd[("triplet-ell", id(wn))] = (wn, True)
         # no backward will come (torch.no_grad(): the evaluation passes of src_1gp/trainer.py:306-327): the inference forward, which keeps
         # neither `aggr` nor `stats` (two thirds of what the launch writes)
         # (`no_backward` comes from the caller: inside forward() autograd is off and needs_input_grad ignores torch.no_grad())
         infer = INFER_FWD and no_backward and (ell is not None or bool(lib.glam_triplet_layer_infer_supported(H, Cp, Dp)))
         aggr, stats = (None, None) if infer else (torch.empty(N, HC, **f), torch.empty(N, 8, **f))
         if ell is not None:
-            check(lib.glam_triplet_layer_fwd_ell(ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), 1, N,
+            check(lib.glam_triplet_layer_fwd_ell(None if given is not None else ptr(x_p), ptr(ea_p), ptr(staged), ptr(ell[0]), ptr(ell[1]), 1, N,
                                                  gi.E, H, Cp, Dp, float(slope), ptr(xw), ptr(a_ij), ptr(aggr), ptr(stats), ptr(out), stream()),
                   "glam_triplet_layer_fwd_ell")
         else:
@@ -1221,6 +1226,67 @@ GRU_PRE = os.environ.get("GLAM_GRU_PRE", "1") != "0"
 # matrices (6C), and the backward writes ONE gate-gradient matrix [N, 4C] instead of d_gi and d_gh (they share two of three blocks):
 # A/B switch (GLAM_GRU_GATES=0)
 GRU_GATES = os.environ.get("GLAM_GRU_GATES", "1") != "0"
+# a MessageBlock that is applied again (src_1gp/model.py:53-54) has the GRU step of one application write the node product
+# x @ [W_node | Wa] of the next (block.hip: k_gru_fwd_ws + node; glam_gru_ws_fwd_pre_node), whose TripletMessage then starts at its
+# aggregate launch: A/B switch (GLAM_NODE_IN_GRU=0)
+NODE_IN_GRU = os.environ.get("GLAM_NODE_IN_GRU", "1") != "0"
+# ... while a launch saved outweighs the matrix and vector work the node product adds to the GRU step's four SIMDs (A/B on one box,
+# model step: B = 32 -3.5 %, 1 024 -1.5 %, 2 048 -1.2 %, 4 096 +0.6 %, 8 192 +1.0 %)
+NODE_IN_GRU_MAX_ROWS = 65536
+_FEEDS_ITSELF = False
+
+
+@contextlib.contextmanager
+def block_feeds_itself(on=True):
+    """The caller's statement that the output of the MessageBlock applications inside goes into the SAME block again (model.py:53-54:
+    all but the last of the message_steps applications)."""
+    global _FEEDS_ITSELF
+    prev, _FEEDS_ITSELF = _FEEDS_ITSELF, bool(on)
+    try:
+        yield
+    finally:
+        _FEEDS_ITSELF = prev
+
+
+_NODE_PRODUCTS: dict = {}      # data_ptr(rows) -> (weakref(rows), rows._version, rows.shape, staged, xw, a_ij)
+
+
+def register_node_product(rows, staged, xw, a_ij):
+    """``xw | a_ij = rows @ [W_node | Wa]`` of the layer whose staged images are ``staged`` exist already (the GRU step that wrote ``rows``
+    wrote them): ``_TripletLayer`` takes them when exactly these rows arrive with exactly these images."""
+    key = rows.data_ptr()
+
+    def _gone(ref, k=key):
+        hit = _NODE_PRODUCTS.get(k)
+        if hit is not None and hit[0] is ref:
+            _NODE_PRODUCTS.pop(k, None)
+    _NODE_PRODUCTS[key] = (weakref.ref(rows, _gone), rows._version, tuple(rows.shape), staged, xw, a_ij)
+
+
+def take_node_product(x, staged):
+    hit = _NODE_PRODUCTS.get(x.data_ptr())
+    if hit is None:
+        return None
+    if hit[0]() is None or hit[1] != x._version or hit[2] != tuple(x.shape) or not x.is_contiguous() or hit[3] is not staged or not NODE_IN_GRU:
+        return None
+    _NODE_PRODUCTS.pop(x.data_ptr(), None)
+    return hit[4], hit[5]
+
+
+def next_node_spec(conv, N):
+    """``(staged, H * Cp)`` when the TripletMessage ``conv`` — applied a moment ago inside the active weight scope — will take its next
+    input's node product from the GRU step (warp-specialised route, unpadded width), else None."""
+    if not (NODE_IN_GRU and _FEEDS_ITSELF and _SCOPE is not None and not CACHED_STAGING and GRU_PRE and GRU_WS == "1"):
+        return None
+    C, H, De = conv.node_channels, conv.heads, conv.edge_channels
+    if C % 4 or not (1 <= H <= 4 and fused_layer_supported(C, H, De)) or H * C + 8 <= 64 or N > NODE_IN_GRU_MAX_ROWS or _want_torch_ext(N, H, C):
+        return None
+    wn = conv.weight_node
+    took = _SCOPE.fwd.get(("triplet-ell", id(wn)))
+    hit = _SCOPE.fwd.get(("triplet", id(wn), id(conv.weight_edge), id(conv.weight_triplet_att), id(conv.weight_scale), id(conv.bias)))
+    if took is None or took[0] is not wn or hit is None or hit[0] is not wn:
+        return None
+    return hit[1], H * C
 # the readout MLP's products of few tiles split k across blocks (glam_linear_dense_*_ws; matters at the reference's batch of 32): A/B switch
 DENSE_SPLITK = os.environ.get("GLAM_DENSE_SPLITK", "1") != "0"
 # PairNorm + the Dropout behind it from one launch each way (glam_graph_norm_drop_*): A/B switch

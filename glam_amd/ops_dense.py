@@ -781,7 +781,7 @@ class _GruTail(torch.autograd.Function):
 ACT_CODES = {"none": 0, "relu": 1, "leaky": 2, "celu": 3, "rrelu": 4}
 
 
-def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False, rng=None):
+def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu_in=False, rng=None, node=None):
     """``h_new = GRU(celu(x) if celu_in else x, h)`` (one step), ``out = act(h_new + identity)`` (src_1gp/layer.py:261-266):
     the two gate GEMMs plus ONE elementwise launch per direction.  Returns ``(out, h_new)``.
     ``rng = (rr_lower, rr_upper, drop_p)`` (training mode of the reference's defaults): ``act == "rrelu"`` draws its slopes in
@@ -792,7 +792,8 @@ def gru_tail(x, h, identity, w_ih, w_hh, b_ih, b_hh, act="none", slope=0.0, celu
     if rng is not None and not gru_rng_supported(C, w_ih, b_ih, b_hh):
         raise GlamHipError("gru_tail(rng=...) needs the one-node GRU block (24 <= C <= 60)")
     if gru_block_supported(C, w_ih, b_ih, b_hh):
-        return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in, rng)
+        # node = (staged, H * Cp) of ops.next_node_spec: the launch also writes the node product of the block's next application
+        return _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, ACT_CODES[act], slope, celu_in, rng, node)
     Cp = (C + 3) // 4 * 4
     if _gru_padded_supported(C, w_ih, b_ih, b_hh):
         # odd widths: the same node at Cp with gate-wise zero-padded weights (built once per model pass).  Pad channels
@@ -866,7 +867,7 @@ def gru_images_pre(N, C):
 def _want_gru_fused(N):
     return _o.GRU_FUSED in ("1", True) or (_o.GRU_FUSED == "auto" and N >= _o.GRU_FUSED_MIN_NODES)
 
-def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None):
+def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=None, node=None):
     """``_GruBlock`` with the gradients of its four parameters carried across the block's applications (see _ParamBundle)."""
     M, C = w_ih.shape
     def split(flat):      # [d_w_ih | d_b_ih | d_w_hh | d_b_hh], every piece contiguous: autograd takes the views without a copy
@@ -876,11 +877,15 @@ def _gru_block(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, rng=
     hit = _o._SCOPE.fwd.get(key) if _o._SCOPE is not None else None
     first = not (hit is not None and hit[0] is w_ih)        # the block's first application of this pass: its backward runs LAST
     carry = _o._carry_for(key, (w_ih, w_hh, b_ih, b_hh), 2 * M * (C + 1), split)
-    out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng, first)
+    took = {} if node is not None else None        # (filled by the forward when its route wrote the product: xw, a_ij)
+    out, h_new, out_drop, carry = _GruBlock.apply(x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry, rng, first,
+                                                  None if node is None else (node[0], node[1], took))
     if carry is not None:
         _o._carry_store(key, w_ih, carry)
     if out_drop is not None:
         _o.register_dropped(out, out_drop, rng[2])
+    if took:
+        _o.register_node_product(out_drop if out_drop is not None else out, node[0], took["xw"], took["a_ij"])
     return out, h_new
 
 
@@ -894,7 +899,7 @@ class _GruBlock(torch.autograd.Function):
     one, which is what an eagerly issued training step is bound by."""
 
     @staticmethod
-    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None, first_app=True):
+    def forward(ctx, x, h, identity, w_ih, w_hh, b_ih, b_hh, act, slope, celu_in, carry=None, rng=None, first_app=True, node=None):
         ctx.set_materialize_grads(False)     # unused outputs (the last step's h', its dropped twin) arrive as None, not as zero fills
         require_device(x, h, w_ih, w_hh, b_ih, b_hh)
         x, h = f32c(x, "x"), f32c(h, "h")
@@ -952,7 +957,23 @@ class _GruBlock(torch.autograd.Function):
             # the warp-specialised 3 x bf16 form of the fused step (block.hip: k_gru_fwd_ws).  With the folded CELU the launch also writes
             # celu(x): the backward and the weight gradient read THAT instead of x and apply no exponential of their own
             xc = torch.empty_like(x) if (celu_in and N > 0) else None
-            if pre is not None:
+            if pre is not None and node is not None and N > 0:
+                # ... and with the node product of the block's NEXT application (ops.NODE_IN_GRU): its producers multiply every finished
+                # tile by [W_node | Wa] before it leaves LDS
+                staged, cols, took = node
+                nimg = staged[lib.glam_triplet_staged_node_fragments(cols // C, C, 4):]      # ([W_node | Wa] as the producers' operand fragments)
+                xw, a_ij = torch.empty(N, cols, **f), torch.empty(N, 8, **f)
+                if rng is None:
+                    check(lib.glam_gru_ws_fwd_pre_node(ptr(x), ptr(h), ptr(identity), ptr(pre[0]), ptr(b_ih), ptr(b_hh), N, C, int(celu_in), act,
+                                                       float(slope), ptr(gi), ptr(gh), ptr(h_new), ptr(out), ptr(xc), ptr(nimg), cols, ptr(xw),
+                                                       ptr(a_ij), st), "glam_gru_ws_fwd_pre_node")
+                else:
+                    check(lib.glam_gru_ws_rng_fwd_pre_node(ptr(x), ptr(h), ptr(identity), ptr(pre[0]), ptr(b_ih), ptr(b_hh), N, C, int(celu_in),
+                                                           act, float(slope), lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(gi), ptr(gh),
+                                                           ptr(h_new), ptr(out), ptr(out_drop), ptr(xc), ptr(nimg), cols, ptr(xw), ptr(a_ij), st),
+                          "glam_gru_ws_rng_fwd_pre_node")
+                took["xw"], took["a_ij"] = xw, a_ij
+            elif pre is not None:
                 # ... on the gate matrices as pre-split operand fragments (glam_gru_ws_make_pre: once per weight update, not per block)
                 if rng is None:
                     check(lib.glam_gru_ws_fwd_pre(ptr(x), ptr(h), ptr(identity), ptr(pre[0]), ptr(b_ih), ptr(b_hh), N, C, int(celu_in), act,
@@ -1115,7 +1136,7 @@ class _GruBlock(torch.autograd.Function):
             parked = scope.bwd.setdefault(key, (w_ih, []))[1]
             parked.append((d_gi, x, d_gh, h, bool(celu_q), gates))
             if not ctx.first_app:
-                return dx, dh, d_id, None, None, None, None, None, None, None, d_carry, None, None
+                return dx, dh, d_id, None, None, None, None, None, None, None, d_carry, None, None, None
             sets = list(parked)
             parked.clear()
             flat = torch.empty(2 * M * (C + 1), **f)
@@ -1137,7 +1158,7 @@ class _GruBlock(torch.autograd.Function):
                                                              arr(3), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(), ptr(add[0]),
                                                              ptr(add[1]), ptr(add[2]), ptr(add[3]), st), "glam_wgrad_gemm_pair_split_seg")
                 add = [dw_ih, db_ih, dw_hh, db_hh]        # a further group adds onto the result in place
-            return dx, dh, d_id, None, None, None, None, None, None, None, flat, None, None
+            return dx, dh, d_id, None, None, None, None, None, None, None, flat, None, None, None
         # [d_W | d_b] of both linears: out[m, k] = sum_n dy[n, m] * [x | 1][n, k], two products, one launch + one reduction
         ws = torch.empty(lib.glam_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         # one buffer [d_w_ih | d_b_ih | d_w_hh | d_b_hh], contiguous pieces; a gradient carry (same layout) is added by the reduction
@@ -1157,8 +1178,8 @@ class _GruBlock(torch.autograd.Function):
                                                  ptr(d_gh), M, M, ptr(h), C, C, 0, ptr(dw_hh), ptr(db_hh), N, ptr(ws), ws.numel(),
                                                  ptr(dc[0]), ptr(dc[1]), ptr(dc[2]), ptr(dc[3]), st), "glam_wgrad_gemm_pair_split")
         if ctx.carried:
-            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None, None
-        return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None, None
+            return dx, dh, d_id, None, None, None, None, None, None, None, (flat if d_carry is None else flat.add_(d_carry)), None, None, None
+        return dx, dh, d_id, dw_ih.view(M, C), dw_hh.view(M, C), db_ih, db_hh, None, None, None, None, None, None, None
 
 
 def gru_block_supported(C, w_ih, b_ih, b_hh):

@@ -334,6 +334,11 @@ int glam_prestage(const float* weight_node, const float* weight_edge, const floa
  *                            weight_triplet_att / weight_scale / bias.
  * Limits: H*Cp + 8 <= 192 and Cp <= 64 (C <= 60 at H = 3). */
 size_t glam_triplet_staged_floats(int H, int Cp, int Dp);
+/* offsets (floats) inside `staged` of [W_node | Wa] (K = Cp rows, H * Cp + 8 columns): as its k_ts_gemm image (what the layer's own node
+ * GEMM reads), and as the pre-split operand fragments of the node product inside the GRU step (72 KB: node_pre of
+ * glam_gru_ws_fwd_pre_node; (size_t)-1 where the shape has none: H * Cp + 8 <= 64) */
+size_t glam_triplet_staged_node_image(int H, int Cp, int Dp);
+size_t glam_triplet_staged_node_fragments(int H, int Cp, int Dp);
 size_t glam_triplet_dstaged_floats(int H, int Cp, int Dp);
 int glam_triplet_stage_params(const float* weight_node, const float* weight_edge, const float* att,
                               const float* weight_scale, const float* bias, int C, int H, int De, int Cp, int Dp,
@@ -580,7 +585,10 @@ int glam_triplet_fwd_ell(const float* xw, const float* a_ij, const float* edge_a
  * The INFERENCE forward (src_1gp/trainer.py:306-327: @torch.no_grad() evaluation of every split after every epoch): aggr = stats = NULL —
  * both exist only for a backward pass, and the launch then stores neither (15.3 of the 22.5 MB it writes at 1 024 molecules).  Always
  * available here; glam_triplet_layer_fwd takes NULL where glam_triplet_layer_infer_supported says so (the shapes whose update GEMM runs
- * inside the aggregate launch).  xw and a_ij are still written: the aggregate reads them. */
+ * inside the aggregate launch).  xw and a_ij are still written: the aggregate reads them.
+ * x = NULL: xw and a_ij HOLD the node product already — the previous application's GRU step wrote them with the rows themselves
+ * (glam_gru_ws_fwd_pre_node; /root/reference/src_1gp/model.py:53-54 applies one block message_steps times) — and the call is the
+ * aggregate / update launch alone. */
 int glam_triplet_layer_ws_supported(int H, int Cp, int Dp, int edge_onehot);
 int glam_triplet_layer_infer_supported(int H, int Cp, int Dp);
 int glam_triplet_layer_fwd_ell(const float* x, const float* edge_attr, const float* staged, const int32_t* ell_src,
@@ -697,6 +705,23 @@ int glam_gru_ws_rng_fwd_pre(const float* x, const float* h, const float* identit
                             const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower, float rr_upper,
                             float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new, float* out,
                             float* out_drop, float* x_celu, void* stream);
+/* ... and the node product of the block's NEXT application inside the same launch.  /root/reference/src_1gp/model.py:53-54 applies ONE
+ * MessageBlock message_steps times: this step's output rows (`out`; in the rng form the dropped twin `out_drop` when it is given — what
+ * layer.py:255-259 hands the conv) are the next TripletMessage's input, and its first product x @ [W_node | Wa] (layer.py:37 + the
+ * separable attention columns) needs nothing else.  The producer waves take every finished 16-row tile out of LDS — the consumers leave
+ * it there split into bf16 terms — through the 3 x bf16 product against node_pre (that matrix as pre-split operand fragments inside the
+ * layer's staged buffer: staged + glam_triplet_staged_node_fragments(H, Cp, Dp); K = C = Cp, node_cols = H * Cp with 56 < node_cols <= 184) while the
+ * ring is full, and write xw[N, node_cols] and a_ij[N, 8]: the values glam_ts_gemm / glam_triplet_layer_fwd_ell write for the same
+ * rows, bit for bit (same partial products in the same order).  glam_triplet_layer_fwd_ell with x = NULL then starts at its aggregate
+ * launch: one launch and one re-read of the rows less per application. */
+int glam_gru_ws_fwd_pre_node(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                             const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float* gi, float* gh, float* h_new,
+                             float* out, float* x_celu, const void* node_pre, int node_cols, float* xw, float* a_ij, void* stream);
+int glam_gru_ws_rng_fwd_pre_node(const float* x, const float* h, const float* identity, const void* pre_fwd, const float* b_ih,
+                                 const float* b_hh, int64_t N, int C, int celu_in, int act, float slope, float rr_lower, float rr_upper,
+                                 float drop_p, int64_t* rng_state, int64_t* rng_eff, float* gi, float* gh, float* h_new, float* out,
+                                 float* out_drop, float* x_celu, const void* node_pre, int node_cols, float* xw, float* a_ij,
+                                 void* stream);
 int glam_gru_bwd_ws_pre(const float* gi, const float* gh, const float* h, const float* out, const float* d_out, const float* d_hstate,
                         const float* x, const void* pre_bwd, int64_t N, int C, int celu_in, int act, float slope, int merge_identity,
                         float* d_gi, float* d_gh, float* d_identity, float* d_x, float* d_h, void* stream);

@@ -3786,3 +3786,96 @@ def test_message_block_on_kept_gates_matches_the_two_matrix_form(device, monkeyp
         res.append([y, hs] + list(gs))
     for i, (a, c) in enumerate(zip(*res)):
         assert torch.equal(a, c), i
+
+
+@pytest.mark.parametrize("N,C,H,ident,celu,train", [(20400, 60, 3, True, True, False), (20400, 60, 3, True, True, True), (1000, 64, 2, False, False, False),
+                                                    (17, 48, 3, True, False, True), (5000, 36, 4, True, True, False), (1, 60, 3, True, True, False)])
+def test_gru_step_writes_the_node_product_of_the_next_application(device, N, C, H, ident, celu, train):
+    """glam_gru_ws_(rng_)fwd_pre_node: the GRU step of one application of a MessageBlock (src_1gp/layer.py:261-266) also writes
+    xw | a_ij = out @ [W_node | Wa] — the first product of the block's next TripletMessage (layer.py:37; model.py:53-54 applies the same block
+    message_steps times) — from the layer's staged node image.  Every other output as without it, bit for bit; the product equal to
+    glam_ts_gemm's on the same rows bit for bit (the dropped twin in the rng form), and to the fp64 product to rounding."""
+    raw, p, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + C + H)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    M, HC = 3 * C, H * C
+    x, h, idn, w_ih, w_hh, b_ih, b_hh = r(N, C), r(N, C), r(N, C), r(M, C) * 0.3, r(M, C) * 0.3, r(M), r(M)
+    wn, we, att, wsc, bias = r(C, HC) * 0.2, r(4, HC) * 0.2, r(1, H, 3 * C) * 0.2, r(HC, C) * 0.2, r(C)
+    staged = torch.empty(raw.glam_triplet_staged_floats(H, C, 4), device=device)
+    assert raw.glam_triplet_stage_params(p(wn), p(we), p(att), p(wsc), p(bias), C, H, 4, C, 4, p(staged), st()) == 0
+    nimg, nfrag = staged[raw.glam_triplet_staged_node_image(H, C, 4):], staged[raw.glam_triplet_staged_node_fragments(H, C, 4):]
+    pre = torch.empty(2, raw.glam_gru_ws_pre_bytes(), dtype=torch.uint8, device=device)
+    assert raw.glam_gru_ws_make_pre(p(w_ih), p(w_hh), C, p(pre[0]), p(pre[1]), st()) == 0
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    lo, hi, dp = 0.125, 1.0 / 3, 0.2
+    res = []
+    for node in (False, True):
+        G, hn, out, drop, xc, xw, a_ij = f(N, 4 * C), f(N, C), f(N, C), f(N, C), f(N, C), f(N, HC), f(N, 8)
+        state = torch.tensor([91] + [0] * (ops.RNG_STATE_WORDS - 1), dtype=torch.int64, device=device)
+        eff = torch.zeros(2, dtype=torch.int64, device=device)
+        idp, xcp = (p(idn) if ident else None), (p(xc) if celu else None)
+        tail = (p(nfrag), HC, p(xw), p(a_ij), st()) if node else (st(),)
+        if train:
+            fn = raw.glam_gru_ws_rng_fwd_pre_node if node else raw.glam_gru_ws_rng_fwd_pre
+            rc = fn(p(x), p(h), idp, p(pre[0]), p(b_ih), p(b_hh), N, C, int(celu), 4, 0.0, lo, hi, dp, p(state), p(eff), p(G), None, p(hn), p(out),
+                    p(drop), xcp, *tail)
+        else:
+            fn = raw.glam_gru_ws_fwd_pre_node if node else raw.glam_gru_ws_fwd_pre
+            rc = fn(p(x), p(h), idp, p(pre[0]), p(b_ih), p(b_hh), N, C, int(celu), 1, 0.0, p(G), None, p(hn), p(out), xcp, *tail)
+        assert rc == 0, raw.glam_last_error()
+        res.append((G, hn, out, drop, xc, xw, a_ij))
+    for u, v in zip(res[0][:5], res[1][:5]):
+        assert torch.equal(u, v) or (torch.isnan(u).all() and torch.isnan(v).all())
+    rows = res[1][3] if train else res[1][2]
+    xw, a_ij = res[1][5], res[1][6]
+    want_xw, want_a = f(N, HC), f(N, 8)
+    assert raw.glam_ts_gemm(p(rows), C, C, None, 0, 0, p(nimg), None, p(want_xw), HC, HC, p(want_a), 8, 8, N, st()) == 0, raw.glam_last_error()
+    if ops._lib.route_enabled("x3"):       # (GLAM_X3=0 puts glam_ts_gemm on the fp32 matrix instructions: equal to rounding then)
+        assert torch.equal(xw, want_xw) and torch.equal(a_ij, want_a)
+    assert not torch.isnan(xw).any() and not torch.isnan(a_ij).any()
+    assert_close(xw, want_xw, 2e-6, "xw vs glam_ts_gemm")
+    assert_close(a_ij, want_a, 2e-6, "a_ij vs glam_ts_gemm")
+    wa = torch.zeros(C, 8, dtype=torch.float64)
+    for hh in range(H):
+        wa[:, hh] = wn.double().cpu()[:, hh * C:(hh + 1) * C] @ att.double().cpu()[0, hh, :C]
+        wa[:, 4 + hh] = wn.double().cpu()[:, hh * C:(hh + 1) * C] @ att.double().cpu()[0, hh, 2 * C:]
+    assert_close(xw, rows.double().cpu() @ wn.double().cpu(), 2e-6, "xw")
+    assert_close(a_ij, rows.double().cpu() @ wa, 2e-6, "a_ij")
+    # all of (image, xw, a_ij) or none; widths outside the image table
+    assert raw.glam_gru_ws_fwd_pre_node(p(x), p(h), None, p(pre[0]), p(b_ih), p(b_hh), N, C, 0, 1, 0.0, p(G), None, p(hn), p(out), None, p(nfrag), HC, None,
+                                        p(a_ij), st()) == ops._lib.GLAM_E_INVALID
+    assert raw.glam_gru_ws_fwd_pre_node(p(x), p(h), None, p(pre[0]), p(b_ih), p(b_hh), N, C, 0, 1, 0.0, p(G), None, p(hn), p(out), None, p(nfrag), 40, p(xw),
+                                        p(a_ij), st()) == ops._lib.GLAM_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("train,B", [(False, 700), (True, 700), (False, 3)])
+def test_model_step_with_the_node_product_inside_the_gru_step(device, monkeypatch, train, B):
+    """Architecture (src_1gp/model.py:36-62) forward + backward with ops.NODE_IN_GRU on / off: the same outputs and the same gradients bit for
+    bit — the product the next TripletMessage finds ready is the one its own launch would write — and two launches less per step (the node
+    GEMMs of the second and third application)."""
+    b = synth_batch(B, seed=8).to(device)
+    torch.manual_seed(5)
+    kw = dict(mol_block="_TripletMessage", hid_dim_alpha=4, e_dim=256, out_dim=1, message_steps=3, mol_readout="GlobalPool5")
+    if not train:
+        kw.update(pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", graph_do="_None()", end_do="_None()")
+    from glam_amd import graphs
+    from glam_amd._lib import kernel_timer
+    net = model.Architecture(**kw).to(device)
+    net.train(train)
+    monkeypatch.setattr(graphs, "GRAPHED_CALL", False)      # (eager launches: the timer sees them)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)        # (the Python nodes: the route of a captured step)
+    res, counts = [], []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "NODE_IN_GRU", on)
+        ops.manual_seed(11, device)
+        net.zero_grad(set_to_none=True)
+        with kernel_timer(capacity=256) as kt:
+            y = net(b)
+            y.square().sum().backward()
+        names = [k for k, _, _ in kt.records()]
+        counts.append((sum("k_ts_gemm" in k for k in names), sum("+node" in k for k in names)))
+        res.append([y.detach().clone()] + [q.grad.clone() for q in net.parameters()])
+    for i, (u, v) in enumerate(zip(*res)):
+        assert torch.equal(u, v), i
+    if B >= 16 and ops._lib.route_enabled("x3"):       # (the warp-specialised GRU step; a handful of molecules: one tile per block all the same)
+        assert counts[0][1] == 0 and counts[1][1] == 2 and counts[0][0] - counts[1][0] == 2, counts

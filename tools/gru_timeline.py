@@ -31,6 +31,19 @@ def bwd_pre(): assert lib.glam_gru_bwd_ws_pre(p(gi), p(gh), p(h), p(out), p(d_ou
 def fwd(): assert lib.glam_gru_ws_fwd(p(x), p(h), p(idn), p(ia), p(ib), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(gi), p(gh), p(hn), p(out), st()) == 0
 def bwd(): assert lib.glam_gru_bwd_ws(p(gi), p(gh), p(h), p(out), p(d_out), p(d_hs), p(x), p(ta), p(tb), N, C, 1, 1, 0.0, 0, p(dgi), p(dgh), p(did), p(dx), p(dh), st()) == 0
 if PRE: fwd, bwd = fwd_pre, bwd_pre
+if os.environ.get("NODE", "0") != "0" or os.environ.get("GATES", "0") != "0":
+    # the model's forward: the gates kept (gh = NULL) and, with NODE=1, the node product of the block's next application inside the launch
+    H = 3
+    G4 = torch.empty(N, 4 * C, device=dev)
+    wn, we, att, wsc, bias = r(C, H * C) * 0.2, r(4, H * C) * 0.2, r(1, H, 3 * C) * 0.2, r(H * C, C) * 0.2, r(C)
+    staged = torch.empty(lib.glam_triplet_staged_floats(H, C, 4), device=dev)
+    assert lib.glam_triplet_stage_params(p(wn), p(we), p(att), p(wsc), p(bias), C, H, 4, C, 4, p(staged), st()) == 0
+    nimg = staged[lib.glam_triplet_staged_node_fragments(H, C, 4):]
+    xw, a_ij, xc = torch.empty(N, H * C, device=dev), torch.empty(N, 8, device=dev), torch.empty(N, C, device=dev)
+    if os.environ.get("NODE", "0") != "0":
+        def fwd(): assert lib.glam_gru_ws_fwd_pre_node(p(x), p(h), p(idn), p(pre[0]), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(G4), None, p(hn), p(out), p(xc), p(nimg), H * C, p(xw), p(a_ij), st()) == 0
+    else:
+        def fwd(): assert lib.glam_gru_ws_fwd_pre(p(x), p(h), p(idn), p(pre[0]), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(G4), None, p(hn), p(out), p(xc), st()) == 0
 for _ in range(5): fwd(); bwd()
 torch.cuda.synchronize()
 with _lib.kernel_timer(capacity=64) as kt:
