@@ -19,6 +19,10 @@ struct TsArgs {
     const float* cgrad_src; int ld_cgrad;  // non-null: out1[r, c] *= celu'(cgrad_src[r, c]) (chain rule through a folded CELU)
     const float* addend; int ld_add;       // non-null: out1[r, c] += addend[r, c] last (a second gradient path into the same tensor)
     int out_relu;                          // 1: out = max(out, 0) — the ReLU of a LinearBlock (src_1gp/layer.py:236) in the epilogue (k_tall_x3 only)
+    // rng_state non-null (k_tall_x3, one product per launch, out1 contiguous: ldo1 = M1, no out2): the training-mode RReLU(rr_lo, rr_hi)
+    // of a LinearBlock in the epilogue — and, out_drop non-null, the dropped twin Dropout(drop_p)(out) the next block starts with — on
+    // the Philox words glam_bias_res_act_rng_fwd draws for the same elements of the same stream position (rng.h)
+    long long* rng_state; long long* rng_eff; float rr_lo, rr_hi, drop_p; float* out_drop;
 };
 
 // distance between the 64 x 64 partial slabs of k_wgrad (4096 floats of data each): 16 KB + 256 B, so that the splits of one element —

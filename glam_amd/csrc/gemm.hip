@@ -857,8 +857,9 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     // the long-reduction shapes on the bf16 matrix cores (tall_x3.hip); GLAM_X3=0 keeps the fp32 matrix instructions where they exist
+    if (b && (a.rng_state || b->rng_state)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm pair: the RReLU epilogue takes a launch of its own (the stream-position ticket counts its blocks)");
     if (variant >= 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
-    if (a.out_relu || (b && b->out_relu)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: the ReLU epilogue exists in k_tall_x3 only (glam_ts_gemm_relu_supported)");
+    if (a.out_relu || (b && b->out_relu) || a.rng_state) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: the ReLU / RReLU epilogues exist in k_tall_x3 only (glam_ts_gemm_relu_supported)");
     if (variant == 2 && ts_x3_enabled() && tall_x3_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
         return launch_tall_x3(a, b, variant, s);
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
@@ -1108,6 +1109,33 @@ extern "C" int glam_ts_gemm_relu(const float* A, int K, int lda, const float* Wi
     GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias), "glam_ts_gemm_relu: pointers must be 16-byte aligned");
     TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, ldo, nullptr, 0, 0, (int)N};
     a.out_relu = 1;
+    return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int glam_ts_gemm_rrelu_supported(int K, int M) {
+    if (K <= 0 || M <= 0 || (K & 3) || (M & 3) || K > 64) return 0;
+    return (ts_variant(K, M) == 0 && ts_x3_enabled() && tall_x3_enabled()) ? 1 : 0;
+}
+
+// out = RReLU(lower, upper)(A @ W + bias) in TRAINING mode (src_1gp/model.py:31: the reference's default activation) and, out_drop
+// non-null, out_drop = Dropout(drop_p)(out) — the twin the block behind starts with (layer.py:255-256) — from the device-side Philox
+// stream (rng.h): the words glam_bias_res_act_rng_fwd would draw for the same elements at the same stream position, so the pair
+// (glam_ts_gemm, glam_bias_res_act_rng_fwd) and this one launch write the same bits; rng_eff receives the (seed, offset) pair for
+// glam_bias_res_act_rng_bwd.  out, out_drop: [N, M] contiguous.  Shapes: glam_ts_gemm_rrelu_supported (the input embeddings).
+extern "C" int glam_ts_gemm_rrelu(const float* A, int K, int lda, const float* Wimg, const float* bias, int M, int64_t N, float rr_lower,
+                                  float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* out, float* out_drop,
+                                  void* stream) {
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "glam_ts_gemm_rrelu: N out of range");
+    if (!glam_ts_gemm_rrelu_supported(K, M)) return fail(GLAM_E_UNSUPPORTED, "glam_ts_gemm_rrelu: K=%d M=%d outside k_tall_x3's RReLU epilogue (K <= 64, M <= 64)", K, M);
+    GLAM_REQUIRE(rr_lower > 0.f && rr_lower <= rr_upper && drop_p >= 0.f && drop_p < 1.f, "glam_ts_gemm_rrelu: needs 0 < lower <= upper and 0 <= p < 1 "
+                 "(got %g, %g, %g)", rr_lower, rr_upper, drop_p);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(A && Wimg && out && rng_state && rng_eff, "glam_ts_gemm_rrelu: null pointer");
+    GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias) && aligned16(out_drop), "glam_ts_gemm_rrelu: pointers must be 16-byte aligned");
+    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, M, nullptr, 0, 0, (int)N};
+    a.rng_state = reinterpret_cast<long long*>(rng_state);
+    a.rng_eff = reinterpret_cast<long long*>(rng_eff);
+    a.rr_lo = rr_lower; a.rr_hi = rr_upper; a.drop_p = drop_p; a.out_drop = out_drop;
     return launch_ts_gemm(a, (hipStream_t)stream);
 }
 

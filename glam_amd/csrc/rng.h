@@ -55,9 +55,15 @@ __device__ __forceinline__ Philox rng_begin(long long* state, long long* eff) {
 // forward epilogue: the last block to arrive advances the stream position.  A block takes its ticket after it has CONSUMED the
 // values it loaded from `state` (they fed its Philox key), so every read of the pair precedes the one store.  No fences: a
 // release fence per block (an L2 write-back each) made the 2048-block tail kernels 5x slower than their arithmetic.
+__device__ __forceinline__ void rng_ticket(long long* state, const Philox& p);
 __device__ __forceinline__ void rng_end(long long* state, const Philox& p) {
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) rng_ticket(state, p);
+}
+// the block's ticket, by ONE thread, after every thread of the block that read the pair has used it (rng_end: the block's barrier; a
+// warp-specialised kernel whose other role has left: the last wave of the role that draws, counted in LDS)
+__device__ __forceinline__ void rng_ticket(long long* state, const Philox& p) {
+    {
         // Two-level ticket: block b first checks in at sub-counter b % 16 (each on its own 128-byte line: state[32 + 16 s]); the last
         // block of a sub-group checks in at the main ticket (state[16]).  One counter for all blocks serialised ~10 ns per block at the
         // coherent point — 5 us of a 512-block launch; now at most grid / 16 + 16 same-address operations are in any chain.

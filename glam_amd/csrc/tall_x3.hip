@@ -9,6 +9,7 @@
 //   block = P producer + NC consumer waves; LDS ring of RING tiles [3 planes][16 rows][pitch]; producers check in per slot (s_ready),
 //   consumers release it (s_taken): the block's only barrier is the one after the flag initialisation.
 #include "dense.h"
+#include "rng.h"
 #include "triplet_pipe.h"
 
 namespace glam {
@@ -28,7 +29,7 @@ constexpr int kTallHeader = 128 + 320 * 4; // s_ready[16] | s_taken[16] | bias[3
 // EPI: the tile also carries the epilogue's operands (celu' source rows and addend rows of the 16 x 64 output block, fp32): the producers
 // fetch them with the same look-ahead as A, so the consumers' loop has no global loads at all — a load there is issued behind the previous
 // tile's stores and waiting for it means waiting for them (one in-order counter): a full memory round trip per tile on the MFMA waves
-template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI>
+template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI, bool RNG = false>
 __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     static_assert(!EPI || (CT == 1 && P >= NC), "the epilogue planes are 16 x 16 NC, at most one float4 chunk per producer lane");
     constexpr int PITCH = tall_pitch(KS), PLANE = 16 * PITCH, TILE = tall_tile_bytes(KS, NC, EPI);
@@ -157,6 +158,15 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     // the result holds data row c and the four CONSECUTIVE output columns 16 tile_j + 4 kb .. + 3 — one float4 store per column tile
     // (with the operands the other way round it held one column of four rows: four scalar stores, 4 x the store instructions)
     const int col0 = 16 * CT * w + 4 * kb;                      // this lane's first column of tile j: col0 + 16 j
+    // training-mode RReLU (+ the next Dropout's twin) in the epilogue: this launch's stream position, read by the waves that draw
+    Philox ph{};
+    if constexpr (RNG) {      // (an instantiation of its own: as a run-time branch it cost every shape ~10 registers, and the widest one spilled)
+        const long long seed = __hip_atomic_load(a.rng_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long off = __hip_atomic_load(a.rng_state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.rng_eff && blockIdx.x == 0 && tid == P * 64) { a.rng_eff[0] = seed; a.rng_eff[1] = off; }
+        const long long pair[2] = {seed, off};
+        ph = philox_init(pair);
+    }
     const bool use_cg = EPI && a.cgrad_src && col0 < a.M1, use_ad = EPI && a.addend && col0 < a.M1;
     auto do_tile = [&](int tile, int it) {
         const int slot = it % RING, want = P * (it / RING + 1);
@@ -241,6 +251,18 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
                 if (use_cg) { v.x *= celu1_grad(cg.x); v.y *= celu1_grad(cg.y); v.z *= celu1_grad(cg.z); v.w *= celu1_grad(cg.w); }
                 if (use_ad) { v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
                 if (a.out_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if constexpr (RNG) {      // (the quad of the flat [N, M1] output this lane holds: the words of the stand-alone launch)
+                    const size_t e = (size_t)row * a.ldo1 + col;
+                    const uint4 w4 = philox4(ph, e >> 2);
+                    float4 od;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned wd = philox_word(w4, q);
+                        const float vq = f4get(v, q), o = vq > 0.f ? vq : vq * rrelu_slope_w(wd, a.rr_lo, a.rr_hi);
+                        (&v.x)[q] = o; (&od.x)[q] = o * drop_scale_w(wd, a.drop_p);
+                    }
+                    if (a.out_drop) st4(a.out_drop + e, od);
+                }
                 if (col < a.M1) st4(a.out1 + (size_t)row * a.ldo1 + col, v);
                 else st4(a.out2 + (size_t)row * a.ldo2 + (col - a.M1), v);
             }
@@ -248,15 +270,21 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     };
     int it = 0;
     for (int tile = bid; tile < ntiles; tile += nblk, ++it) do_tile(tile, it);
+    if constexpr (RNG) {
+        // the block's ticket for the stream position (rng.h): the last consumer wave to finish takes it — the producers never read the pair
+        int last = 0;
+        if (lane == 0) last = __hip_atomic_fetch_add(s_ready + 15, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == NC - 1;
+        if (last) rng_ticket(a.rng_state, ph);
+    }
 }
 
-template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI>
+template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI, bool RNG = false>
 static int launch_tall(const TallArgs2& two, int grid, hipStream_t s) {
     static bool big[64] = {};
     constexpr size_t lds = kTallHeader + (size_t)RING * tall_tile_bytes(KS, NC, EPI);
     static_assert(lds <= 160 * 1024, "ring exceeds the LDS of a CU");
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_tall_x3<KS, NC, CT, P, RING, MP, EPI>), big, "tall_x3")) return rc;
-    hipLaunchKernelGGL((k_tall_x3<KS, NC, CT, P, RING, MP, EPI>), dim3(grid), dim3((P + NC) * 64), lds, s, two);
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_tall_x3<KS, NC, CT, P, RING, MP, EPI, RNG>), big, "tall_x3")) return rc;
+    hipLaunchKernelGGL((k_tall_x3<KS, NC, CT, P, RING, MP, EPI, RNG>), dim3(grid), dim3((P + NC) * 64), lds, s, two);
     return GLAM_OK;
 }
 
@@ -272,7 +300,14 @@ int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s)
     int rc;
     // the narrow layers of the search space (hid_dim 15 / 30: K = 16 .. 104) do not pay for six 32-k steps per tile
     const int Kmax = (a.K1 + a.K2) > (b ? b->K1 + b->K2 : 0) ? (a.K1 + a.K2) : (b->K1 + b->K2);
-    if (variant == 0 && Kmax <= 64 && epi) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1, epi>"); rc = launch_tall<2, 4, 1, 4, 4, 64, true>(two, grid, s); }
+    if (a.rng_state) {
+        // the training-mode RReLU epilogue: the input embeddings (K <= 64, M <= 64), one product per launch
+        if (!(variant == 0 && Kmax <= 64 && !epi && !b && a.M2 == 0 && a.ldo1 == a.M1))
+            return fail(GLAM_E_UNSUPPORTED, "tall_x3: the RReLU epilogue takes K <= 64, M <= 64, one contiguous output");
+        GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>+rrelu");
+        rc = launch_tall<2, 4, 1, 4, 4, 64, false, true>(two, grid, s);
+    }
+    else if (variant == 0 && Kmax <= 64 && epi) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1, epi>"); rc = launch_tall<2, 4, 1, 4, 4, 64, true>(two, grid, s); }
     else if (variant == 0 && Kmax <= 64) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>"); rc = launch_tall<2, 4, 1, 4, 4, 64, false>(two, grid, s); }
     else if (variant == 0 && Kmax <= 128 && epi) { GLAM_PROF_LABEL("k_tall_x3<4, 4, 1, epi>"); rc = launch_tall<4, 4, 1, 4, 4, 64, true>(two, grid, s); }
     else if (variant == 0 && Kmax <= 128) { GLAM_PROF_LABEL("k_tall_x3<4, 4, 1>"); rc = launch_tall<4, 4, 1, 4, 4, 64, false>(two, grid, s); }

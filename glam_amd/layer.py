@@ -932,6 +932,11 @@ class LinearBlock(torch.nn.Module):
                 y = ops.linear_relu(x, self.linear.weight, self.linear.bias)
                 if y is not None:
                     return y
+        if type(a) is RReLU and a.training and 0 < a.lower <= a.upper and x.is_cuda and x.dim() == 2:
+            # training-mode RReLU: in the tall product's epilogue too (the input embeddings)
+            y = ops.linear_rrelu(x, self.linear.weight, self.linear.bias, a.lower, a.upper, float(next_dropout))
+            if y is not None:
+                return y
         x = ops.linear(x, self.linear.weight, self.linear.bias)
         return _apply_act(self.act, x, next_dropout)
 

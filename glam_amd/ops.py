@@ -1230,6 +1230,9 @@ GRU_GATES = os.environ.get("GLAM_GRU_GATES", "1") != "0"
 # x @ [W_node | Wa] of the next (block.hip: k_gru_fwd_ws + node; glam_gru_ws_fwd_pre_node), whose TripletMessage then starts at its
 # aggregate launch: A/B switch (GLAM_NODE_IN_GRU=0)
 NODE_IN_GRU = os.environ.get("GLAM_NODE_IN_GRU", "1") != "0"
+# the training-mode RReLU of a LinearBlock (and the dropped twin behind it) in the epilogue of its product where that runs on k_tall_x3
+# (the input embeddings) instead of a launch of its own: A/B switch (GLAM_RRELU_IN_GEMM=0)
+RRELU_IN_GEMM = os.environ.get("GLAM_RRELU_IN_GEMM", "1") != "0"
 # ... while a launch saved outweighs the matrix and vector work the node product adds to the GRU step's four SIMDs (A/B on one box,
 # model step: B = 32 -3.5 %, 1 024 -1.5 %, 2 048 -1.2 %, 4 096 +0.6 %, 8 192 +1.0 %)
 NODE_IN_GRU_MAX_ROWS = 65536

@@ -32,9 +32,11 @@ class _Linear(torch.autograd.Function):
     ``x`` that needs no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu=False):
+    def forward(ctx, x, w, b, relu=False, rrelu=None):
         """``relu``: ``max(y, 0)`` in the product's epilogue (glam_ts_gemm_relu; the caller checked glam_ts_gemm_relu_supported); the
-        backward masks ``dy`` by the saved output first."""
+        backward masks ``dy`` by the saved output first.  ``rrelu = (lower, upper, drop_p)``: the training-mode RReLU in the epilogue
+        (glam_ts_gemm_rrelu) and, ``drop_p > 0``, the dropped twin as a second output — returns ``(y, y_drop)``; the backward regenerates
+        the slopes / the mask from the recorded stream position (glam_bias_res_act_rng_bwd)."""
         require_device(x, w, b)
         x, w = f32c(x, "x"), f32c(w, "weight")
         b = None if b is None else f32c(b, "bias")
@@ -52,6 +54,19 @@ class _Linear(torch.autograd.Function):
 
         img = _o._scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
         y = torch.empty(N, M, dtype=torch.float32, device=dev)
+        ctx.rrelu = None
+        if rrelu is not None:
+            ctx.set_materialize_grads(False)
+            lo, hi, p = (float(v) for v in rrelu)
+            eff = torch.empty(2, dtype=torch.int64, device=dev)
+            y_drop = torch.empty_like(y) if p > 0 else None
+            check(lib.glam_ts_gemm_rrelu(ptr(x), K, K, ptr(img), ptr(b), M, N, lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(y), ptr(y_drop),
+                                         stream()), "glam_ts_gemm_rrelu")
+            ctx.save_for_backward(x, w, y)
+            ctx.rrelu, ctx.eff = (lo, hi, p), eff
+            ctx.has_bias = b is not None
+            ctx.scope = scope
+            return y, y_drop
         if relu:
             check(lib.glam_ts_gemm_relu(ptr(x), K, K, ptr(img), ptr(b), ptr(y), M, M, N, stream()), "glam_ts_gemm_relu")
             ctx.save_for_backward(x, w, y)
@@ -64,12 +79,22 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy_drop=None):
         x, w = ctx.saved_tensors[:2]
-        dy = f32c(dy, "dy")
         N, K = x.shape
         M = w.size(0)
-        y_relu = ctx.saved_tensors[2] if len(ctx.saved_tensors) == 3 else None
+        if ctx.rrelu is not None:
+            # the activation's backward on the regenerated slopes / mask: d_pre = d_y * (y > 0 ? 1 : slope) + d_y_drop * mask / (1 - p) * ...
+            y_act = ctx.saved_tensors[2]
+            dy = None if dy is None else f32c(dy, "dy")
+            dy_drop = None if dy_drop is None else f32c(dy_drop, "dy_drop")
+            d_pre = torch.empty_like(y_act)
+            lo, hi, p = ctx.rrelu
+            check(_lib.load().glam_bias_res_act_rng_bwd(ptr(y_act), ptr(dy), ptr(dy_drop), N, M, _o.ACT_CODES["rrelu"], 0.0, lo, hi, p, ptr(ctx.eff),
+                                                        ptr(d_pre), stream()), "glam_bias_res_act_rng_bwd")
+            dy = d_pre
+        dy = f32c(dy, "dy")
+        y_relu = ctx.saved_tensors[2] if (len(ctx.saved_tensors) == 3 and ctx.rrelu is None) else None
         # the fused ReLU's backward dy * (y > 0): inside the weight-gradient product where that is dy's only consumer (the first linear
         # of the model: atom features need no gradient), an elementwise launch otherwise
         mask_in_product = y_relu is not None and _o.RELU_IN_WGRAD and not ctx.needs_input_grad[0] and K + 1 <= 64
@@ -100,7 +125,7 @@ class _Linear(torch.autograd.Function):
             else:
                 check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
                       "glam_wgrad_gemm_split")
-            return dx, dw, (db if ctx.has_bias else None), None
+            return dx, dw, (db if ctx.has_bias else None), None, None
         dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
         if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]
             check(lib.glam_wgrad_gemm(ptr(x), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), 1, K + 1, ptr(ws), ws.numel(),
@@ -110,7 +135,7 @@ class _Linear(torch.autograd.Function):
                                       stream()), "glam_wgrad_gemm")
         dw = dwb[:M, :w.size(1)]
         db = dwb[:M, K] if ctx.has_bias else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _RelationMLP(torch.autograd.Function):
@@ -667,6 +692,26 @@ def linear_relu(x, weight, bias=None):
             return None                      # (a padded differentiable input takes the padded-weight route of ``linear``)
         x = _o.pad_cols(x, Kp)
     return _Linear.apply(x, weight, bias, True)
+
+
+def linear_rrelu(x, weight, bias, lower, upper, drop_p=0.0):
+    """Training-mode ``RReLU(lower, upper)(F.linear(x, weight, bias))`` with the activation — and, ``drop_p > 0``, the dropped twin the
+    following ``Dropout(drop_p)`` picks up (``ops.take_dropped``) — in the epilogue of the product where its shape runs on ``k_tall_x3``
+    with that epilogue (the input embeddings: 15 -> 60 ...); ``None`` elsewhere (the caller applies ``linear`` and ``rrelu``)."""
+    M, K = weight.shape
+    Kp = (K + 3) // 4 * 4
+    f32 = x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+    if not (_o.RRELU_IN_GEMM and x.dim() == 2 and x.is_cuda and f32 and M % 4 == 0 and linear_supported(K, M) and not _dense_route(x, weight, bias)
+            and 0 < lower <= upper and 0 <= drop_p < 1 and _lib.load().glam_ts_gemm_rrelu_supported(Kp, M) == 1):
+        return None
+    if Kp != K:
+        if x.requires_grad and torch.is_grad_enabled():
+            return None
+        x = _o.pad_cols(x, Kp)
+    y, y_drop = _Linear.apply(x, weight, bias, False, (float(lower), float(upper), float(drop_p)))
+    if y_drop is not None:
+        _o.register_dropped(y, y_drop, drop_p)
+    return y
 
 
 class _LinearSplit(torch.autograd.Function):

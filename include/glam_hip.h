@@ -282,6 +282,15 @@ int glam_wgrad_gemm_split_relu(const float* P, const float* Y, int I, int ldp, c
 int glam_ts_gemm_relu_supported(int K, int M);
 int glam_ts_gemm_relu(const float* A, int K, int lda, const float* Wimg, const float* bias, float* out, int M, int ldo, int64_t N,
                       void* stream);
+/* ... with the TRAINING-mode RReLU(rr_lower, rr_upper) of /root/reference/src_1gp/model.py:31 (the reference's default activation) in the
+ * epilogue and, out_drop non-NULL, out_drop = Dropout(drop_p)(out): the twin the block behind starts with (layer.py:255-256) — from the
+ * device-side Philox stream: the words glam_bias_res_act_rng_fwd draws for the same elements at the same stream position, so
+ * glam_ts_gemm + glam_bias_res_act_rng_fwd and this ONE launch write the same bits, and glam_bias_res_act_rng_bwd with rng_eff is its
+ * activation backward.  out, out_drop: [N, M] contiguous.  Shapes: glam_ts_gemm_rrelu_supported (K <= 64, M <= 64: the input embeddings
+ * mol_lin0 / pro_lin0 of model.py:40-49). */
+int glam_ts_gemm_rrelu_supported(int K, int M);
+int glam_ts_gemm_rrelu(const float* A, int K, int lda, const float* Wimg, const float* bias, int M, int64_t N, float rr_lower,
+                       float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* out, float* out_drop, void* stream);
 
 /* glam_ts_gemm with the CELU(alpha=1) that MessageBlock applies in front of its GRU (src_1gp/layer.py:261) folded in:
  * a_celu = 1: out = celu(A) @ W + bias; cgrad_src non-NULL: out[r,c] *= celu'(cgrad_src[r,c]) (the chain rule of the same

@@ -3879,3 +3879,63 @@ def test_model_step_with_the_node_product_inside_the_gru_step(device, monkeypatc
         assert torch.equal(u, v), i
     if B >= 16 and ops._lib.route_enabled("x3"):       # (the warp-specialised GRU step; a handful of molecules: one tile per block all the same)
         assert counts[0][1] == 0 and counts[1][1] == 2 and counts[0][0] - counts[1][0] == 2, counts
+
+
+@pytest.mark.parametrize("N,K,M,p", [(20400, 16, 60, 0.2), (20400, 16, 60, 0.0), (17, 32, 64, 0.5), (1, 16, 28, 0.2), (0, 16, 60, 0.2)])
+def test_rrelu_and_the_dropped_twin_in_the_embedding_products_epilogue(device, N, K, M, p):
+    """glam_ts_gemm_rrelu (the LinearBlock of src_1gp/layer.py:223-237 with the reference's default activation, model.py:31, in training
+    mode): the same bits as glam_ts_gemm followed by glam_bias_res_act_rng_fwd from the same stream position — output, dropped twin, the
+    recorded (seed, offset) pair and the position the stream is left at — and glam_bias_res_act_rng_bwd on its output is its backward."""
+    raw, ptr, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + K + M)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    x, w, b = r(N, K), r(M, K) * 0.5, r(M)
+    img = torch.empty(raw.glam_ts_gemm_image_bytes(K, M) // 4, device=device)
+    assert raw.glam_ts_gemm_make_image(ptr(w), K, 1, K, M, ptr(img), st()) == 0
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    lo, hi = 0.125, 1.0 / 3
+    mk = lambda: (torch.tensor([4242] + [0] * (ops.RNG_STATE_WORDS - 1), dtype=torch.int64, device=device), torch.zeros(2, dtype=torch.int64, device=device))
+    # two launches
+    s0, e0 = mk()
+    y0, o0, d0 = f(N, M), f(N, M), f(N, M)
+    assert raw.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(y0), M, M, None, 0, 0, N, st()) == 0
+    assert raw.glam_bias_res_act_rng_fwd(ptr(y0), None, None, N, M, 4, 0.0, lo, hi, p, ptr(s0), ptr(e0), ptr(o0), ptr(d0) if p > 0 else None, st()) == 0
+    # one
+    s1, e1 = mk()
+    o1, d1 = f(N, M), f(N, M)
+    assert raw.glam_ts_gemm_rrelu(ptr(x), K, K, ptr(img), ptr(b), M, N, lo, hi, p, ptr(s1), ptr(e1), ptr(o1), ptr(d1) if p > 0 else None, st()) == 0, raw.glam_last_error()
+    if N == 0:
+        return
+    assert torch.equal(o0, o1) and not torch.isnan(o1).any()
+    assert p == 0 or (torch.equal(d0, d1) and 0.0 < (d1 == 0).float().mean().item() < 1.0 or N * M < 64)
+    assert torch.equal(e0, e1) and torch.equal(s0[:2], s1[:2]) and int(s1[1]) == 1        # the next launch draws from the next position
+    assert (o1 < 0).any() or N * M < 8                                                     # (negative inputs keep a slope: not a ReLU)
+    # widths outside the epilogue's table
+    assert raw.glam_ts_gemm_rrelu_supported(16, 60) == 1 and raw.glam_ts_gemm_rrelu_supported(128, 60) == 0
+    assert raw.glam_ts_gemm_rrelu(ptr(x), K, K, ptr(img), ptr(b), M, N, 0.0, hi, p, ptr(s1), ptr(e1), ptr(o1), None, st()) == ops._lib.GLAM_E_INVALID
+
+
+@pytest.mark.parametrize("next_p", [0.0, 0.2])
+def test_linear_block_with_training_mode_rrelu_in_one_launch(device, monkeypatch, next_p):
+    """LinearBlock(15 -> 60, act RReLU).train() — mol_lin0 of the reference's default model (model.py:40, :49) — with ops.RRELU_IN_GEMM on /
+    off: the same output, dropped twin and gradients bit for bit, one launch less."""
+    from glam_amd._lib import kernel_timer
+    torch.manual_seed(2)
+    blk = layer.LinearBlock(15, 60, act="RReLU").to(device).train()
+    x = torch.randn(5000, 15, device=device)
+    res, counts = [], []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "RRELU_IN_GEMM", on)
+        ops.manual_seed(7, device)
+        blk.zero_grad(set_to_none=True)
+        with ops.weight_scope(), kernel_timer(capacity=64) as kt:
+            y = blk(x, next_dropout=next_p)
+            twin = ops.take_dropped(y, next_p) if next_p else None
+            ((y * y).sum() + (twin.sum() if twin is not None else 0)).backward()
+        counts.append(len(kt.records()))
+        res.append([y.detach(), None if twin is None else twin.detach(), blk.linear.weight.grad.clone(), blk.linear.bias.grad.clone()])
+    for u, v in zip(*res):
+        assert (u is None and v is None) or torch.equal(u, v)
+    assert (next_p == 0) == (res[0][1] is None)
+    if ops._lib.route_enabled("x3"):
+        assert counts[0] - counts[1] == 1, counts

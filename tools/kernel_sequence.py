@@ -10,8 +10,12 @@ from glam_amd.data import synth_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda")
 torch.manual_seed(0)
-net = model.Architecture(mol_block="_TripletMessage", message_steps=3, graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU",
-                         flat_act="ReLU").to(dev)
+PRESET = sys.argv[2] if len(sys.argv) > 2 else "relu"
+if PRESET == "model_default":      # Architecture()'s keyword defaults in training mode: RReLU x 3, Dropout(0.2) twice
+    net = model.Architecture(mol_block="_TripletMessage", message_steps=3).to(dev).train()
+else:
+    net = model.Architecture(mol_block="_TripletMessage", message_steps=3, graph_do="_None()", end_do="_None()", pre_act="ReLU", graph_act="ReLU",
+                             flat_act="ReLU").to(dev)
 net.graphed_call = False      # (eager launches: every one carries its own events)
 b = synth_batch(B, seed=0).to(dev)
 y = b.y.view(-1)
