@@ -120,6 +120,7 @@ SIGNATURES = {
     "glam_ts_gemm_relu_supported": (_i32, [_i32, _i32]),
     "glam_ts_gemm_relu": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),
     "glam_ts_gemm_rrelu_supported": (_i32, [_i32, _i32]),
+    "glam_ts_gemm_act_node": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "glam_ts_gemm_rrelu": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "glam_ts_gemm_image_bytes": (_sz, [_i32, _i32]),
     "glam_ts_gemm_make_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

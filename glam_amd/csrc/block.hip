@@ -6,6 +6,7 @@
 #include "rng.h"
 #include "dense.h"
 #include "triplet_pipe.h"
+#include "node_product.h"
 
 namespace glam {
 
@@ -568,9 +569,9 @@ constexpr int kGwEPitch = 272, kGwEPlane = 16 * kGwEPitch;              // fp32 
 constexpr int kGwTile = 3 * kGwPlane + 2 * kGwEPlane;                   // 28 672 bytes
 constexpr int kGwHeader = 128 + 6 * 64 * 4;                             // flags | biases [ih, hh][gate][64]
 constexpr size_t kGwLds = kGwHeader + (size_t)kGwRing * kGwTile;
-// the finished rows on their way to the node product, four tiles
-constexpr int kGwXPitch = 272, kGwXTile = 16 * kGwXPitch, kGwXRing = 4;      // fp32 rows (64 channels + 4): the producers split them
-constexpr size_t kGwLdsNode = kGwLds + (size_t)kGwXRing * kGwXTile;
+// ... + the finished rows on their way to the node product (node_product.h)
+constexpr int kGwXPitch = kNodeXPitch, kGwXTile = kNodeXTile, kGwXRing = kNodeXRing;
+constexpr size_t kGwLdsNode = kGwLds + kNodeXBytes;
 
 template <bool RNG, bool NODE>
 __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs a, TailRng rg) {
@@ -635,56 +636,12 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
         //      launch.  The weights come split already, in lane order (the staging launch wrote them: 18 coalesced 1 KB loads per wave
         //      behind the first tiles' rows; from the fp32 image — 12 scattered loads per lane in front of everything the block's other
         //      waves ask for, then the splits — every first tile went out 3.4 k cycles later) ----
-        const int nc = lane & 15, nkb = lane >> 4;
         Bf16x3 wn[2][3];
         const int my_tiles = bid < ntiles ? (ntiles - bid + nblk - 1) / nblk : 0;
         int jn = 0;                                  // the next finished tile to multiply
         auto node_ready = [&](int j) { return j < my_tiles && flag_load(s_xready + (j & 3)) >= NC * ((j >> 2) + 1); };
-        auto node_product = [&](int j) {
-            asm volatile("" ::: "memory");
-            const int xs = j & 3, tile = bid + j * nblk;
-            const char* xb = s_xn + xs * XTILE + nc * XPITCH + nkb * 32;       // row nc, k = 32 s + 8 nkb ..: fp32, split here (the
-            float4 xr[2][2];                                                   // consumers set the pace: they write one 16-byte piece)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { xr[s][0] = *reinterpret_cast<const float4*>(xb + 128 * s); xr[s][1] = *reinterpret_cast<const float4*>(xb + 128 * s + 16); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) flag_bump(s_xtaken + xs);
-            Bf16x3 xv[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) xv[s] = split8(xr[s][0], xr[s][1]);
-            v4f_t acc[3], accb[3];
-#pragma unroll
-            for (int j3 = 0; j3 < 3; ++j3) { acc[j3] = (v4f_t){0.f, 0.f, 0.f, 0.f}; accb[j3] = acc[j3]; }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j3 = 0; j3 < 3; ++j3) {      // x.mid w.mid, x.hi w.lo, x.lo w.hi
-                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].mid, xv[s].mid, acc[j3], 0, 0, 0);
-                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].lo, xv[s].hi, acc[j3], 0, 0, 0);
-                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].hi, xv[s].lo, acc[j3], 0, 0, 0);
-                }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j3 = 0; j3 < 3; ++j3) {      // x.hi w.mid, x.mid w.hi
-                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].mid, xv[s].hi, acc[j3], 0, 0, 0);
-                    acc[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].hi, xv[s].mid, acc[j3], 0, 0, 0);
-                }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j3 = 0; j3 < 3; ++j3) accb[j3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[s][j3].hi, xv[s].hi, accb[j3], 0, 0, 0);
-            const int row = 16 * tile + nc;
-            if (row < a.N) {
-#pragma unroll
-                for (int j3 = 0; j3 < 3; ++j3) {
-                    const int col0 = 16 * (3 * wave + j3) + 4 * nkb;
-                    const float4 v = make_float4(acc[j3][0] + accb[j3][0], acc[j3][1] + accb[j3][1], acc[j3][2] + accb[j3][2], acc[j3][3] + accb[j3][3]);
-                    if (col0 < a.node_m1) st4(a.xw + (size_t)row * a.node_m1 + col0, v);
-                    else if (col0 < a.node_m1 + 8) st4(a.a_ij + (size_t)row * 8 + (col0 - a.node_m1), v);
-                }
-            }
-        };
+        const NodeOut nout{a.xw, a.a_ij, a.node_m1, a.N};
+        auto node_product = [&](int j) { node_product_tile(wn, s_xn, s_xtaken, j & 3, bid + j * nblk, wave, lane, nout); };
         // one tile out of register set d into ring slot it % RING (the slot is free), and that set's next loads
         auto publish = [&](auto dc, int it) {
             constexpr int d = decltype(dc)::value;
@@ -728,14 +685,7 @@ __global__ void __launch_bounds__((kGwP + kGwC) * 64) k_gru_fwd_ws(GruFusedArgs 
             // counts the waits are built from stay exact): 72 KB per block that nobody needs before the consumers are through their first
             // tile — issued with the first rows, they stood in the CU's queue in front of the consumers' own 144 KB
             if (my_tiles > 0) publish(std::integral_constant<int, 0>{}, 0);
-            const char* base = reinterpret_cast<const char*>(a.node_pre) + (size_t)wave * (18 * 1024) + lane * 16;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j3 = 0; j3 < 3; ++j3) {
-                    const char* f = base + (s * 3 + j3) * 3072;
-                    wn[s][j3].hi = ldfrag(f); wn[s][j3].mid = ldfrag(f + 1024); wn[s][j3].lo = ldfrag(f + 2048);
-                }
+            node_load_fragments(wn, a.node_pre, wave, lane);
         }
         for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
 #pragma unroll

@@ -23,6 +23,9 @@ struct TsArgs {
     // of a LinearBlock in the epilogue — and, out_drop non-null, the dropped twin Dropout(drop_p)(out) the next block starts with — on
     // the Philox words glam_bias_res_act_rng_fwd draws for the same elements of the same stream position (rng.h)
     long long* rng_state; long long* rng_eff; float rr_lo, rr_hi, drop_p; float* out_drop;
+    // node_pre non-null (k_tall_x3<2, 4, 1>, one product per launch, M1 <= 64): out1's rows are the input of a TripletMessage — the producers
+    // also write node_xw[N, node_m1] | node_a[N, 8] = out1 (out_drop when given) @ [W_node | Wa] (node_product.h)
+    const void* node_pre; float* node_xw; float* node_a; int node_m1;
 };
 
 // distance between the 64 x 64 partial slabs of k_wgrad (4096 floats of data each): 16 KB + 256 B, so that the splits of one element —

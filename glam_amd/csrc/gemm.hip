@@ -857,9 +857,10 @@ int launch_ts_gemm2(const TsArgs& a, const TsArgs* b, hipStream_t s) {
     if (b) { const size_t lb = ts_image_floats(b->K1 + b->K2, b->M1 + b->M2) * sizeof(float); if (lb > lds) lds = lb; }
     const int grid = grid_a + grid_b;
     // the long-reduction shapes on the bf16 matrix cores (tall_x3.hip); GLAM_X3=0 keeps the fp32 matrix instructions where they exist
-    if (b && (a.rng_state || b->rng_state)) return fail(GLAM_E_UNSUPPORTED, "ts_gemm pair: the RReLU epilogue takes a launch of its own (the stream-position ticket counts its blocks)");
+    if (b && (a.rng_state || b->rng_state || a.node_pre || b->node_pre))
+        return fail(GLAM_E_UNSUPPORTED, "ts_gemm pair: the RReLU epilogue / the node product take a launch of their own");
     if (variant >= 3 || (variant == 0 && ts_x3_enabled() && tall_x3_enabled())) return launch_tall_x3(a, b, variant, s);
-    if (a.out_relu || (b && b->out_relu) || a.rng_state) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: the ReLU / RReLU epilogues exist in k_tall_x3 only (glam_ts_gemm_relu_supported)");
+    if (a.out_relu || (b && b->out_relu) || a.rng_state || a.node_pre) return fail(GLAM_E_UNSUPPORTED, "ts_gemm: the ReLU / RReLU epilogues exist in k_tall_x3 only (glam_ts_gemm_relu_supported)");
     if (variant == 2 && ts_x3_enabled() && tall_x3_enabled() && !a.cgrad_src && !a.addend && !(b && (b->cgrad_src || b->addend)))
         return launch_tall_x3(a, b, variant, s);
     if (variant == 0) hipLaunchKernelGGL((k_ts_gemm<4, 12, 4>), dim3(grid), dim3(kTsBlock), lds, s, two);
@@ -1136,6 +1137,39 @@ extern "C" int glam_ts_gemm_rrelu(const float* A, int K, int lda, const float* W
     a.rng_state = reinterpret_cast<long long*>(rng_state);
     a.rng_eff = reinterpret_cast<long long*>(rng_eff);
     a.rr_lo = rr_lower; a.rr_hi = rr_upper; a.drop_p = drop_p; a.out_drop = out_drop;
+    return launch_ts_gemm(a, (hipStream_t)stream);
+}
+
+// The input embedding in front of a TripletMessage (src_1gp/model.py:49, :53): out = act(A @ W + bias) — act 0: none, 1: ReLU,
+// 4: training-mode RReLU (+ the dropped twin, as glam_ts_gemm_rrelu) — AND the TripletMessage's node product of those rows in the same
+// launch: xw[N, node_cols] | a_ij[N, 8] = out (out_drop when given) @ [W_node | Wa] from node_pre, the layer's pre-split fragment image
+// (staged + glam_triplet_staged_node_fragments) — the values glam_ts_gemm writes for the same rows, bit for bit (node_product.h);
+// glam_triplet_layer_fwd_ell with x = NULL then starts at its aggregate launch.  M <= 64 (M = the layer's Cp), K <= 64.
+extern "C" int glam_ts_gemm_act_node(const float* A, int K, int lda, const float* Wimg, const float* bias, int M, int64_t N, int act,
+                                     float rr_lower, float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* out,
+                                     float* out_drop, const void* node_pre, int node_cols, float* xw, float* a_ij, void* stream) {
+    const char* fn = "glam_ts_gemm_act_node";
+    GLAM_REQUIRE(N >= 0 && N < INT32_MAX, "%s: N out of range", fn);
+    if (!glam_ts_gemm_rrelu_supported(K, M)) return fail(GLAM_E_UNSUPPORTED, "%s: K=%d M=%d outside k_tall_x3's node-product form (K <= 64, M <= 64)", fn, K, M);
+    if (!(act == 0 || act == 1 || act == 4)) return fail(GLAM_E_UNSUPPORTED, "%s: activation code %d (0 none, 1 ReLU, 4 training-mode RReLU)", fn, act);
+    if (!(node_cols > 0 && (node_cols & 3) == 0 && node_cols + 8 > 64 && node_cols + 8 <= 192 && M >= 24))
+        return fail(GLAM_E_UNSUPPORTED, "%s: the node product takes 56 < H*Cp <= 184 columns, a multiple of 4 (%d)", fn, node_cols);
+    if (act == 4)
+        GLAM_REQUIRE(rr_lower > 0.f && rr_lower <= rr_upper && drop_p >= 0.f && drop_p < 1.f, "%s: needs 0 < lower <= upper and 0 <= p < 1 (got %g, %g, %g)",
+                     fn, rr_lower, rr_upper, drop_p);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(A && Wimg && out && node_pre && xw && a_ij && (act != 4 || (rng_state && rng_eff)) && (act == 4 || !out_drop), "%s: null pointer / a dropped "
+                 "twin without the RReLU form", fn);
+    GLAM_REQUIRE(aligned16(A) && aligned16(Wimg) && aligned16(out) && aligned16(bias) && aligned16(out_drop) && aligned16(node_pre) && aligned16(xw) &&
+                     aligned16(a_ij), "%s: pointers must be 16-byte aligned", fn);
+    TsArgs a{A, K, lda, nullptr, 0, 0, Wimg, bias, out, M, M, nullptr, 0, 0, (int)N};
+    a.out_relu = act == 1;
+    if (act == 4) {
+        a.rng_state = reinterpret_cast<long long*>(rng_state);
+        a.rng_eff = reinterpret_cast<long long*>(rng_eff);
+        a.rr_lo = rr_lower; a.rr_hi = rr_upper; a.drop_p = drop_p; a.out_drop = out_drop;
+    }
+    a.node_pre = node_pre; a.node_xw = xw; a.node_a = a_ij; a.node_m1 = node_cols;
     return launch_ts_gemm(a, (hipStream_t)stream);
 }
 

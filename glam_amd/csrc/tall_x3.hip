@@ -11,6 +11,8 @@
 #include "dense.h"
 #include "rng.h"
 #include "triplet_pipe.h"
+#include "node_product.h"
+#include <type_traits>
 
 namespace glam {
 
@@ -29,9 +31,10 @@ constexpr int kTallHeader = 128 + 320 * 4; // s_ready[16] | s_taken[16] | bias[3
 // EPI: the tile also carries the epilogue's operands (celu' source rows and addend rows of the 16 x 64 output block, fp32): the producers
 // fetch them with the same look-ahead as A, so the consumers' loop has no global loads at all — a load there is issued behind the previous
 // tile's stores and waiting for it means waiting for them (one in-order counter): a full memory round trip per tile on the MFMA waves
-template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI, bool RNG = false>
+template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI, bool RNG = false, bool NODE = false>
 __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     static_assert(!EPI || (CT == 1 && P >= NC), "the epilogue planes are 16 x 16 NC, at most one float4 chunk per producer lane");
+    static_assert(!NODE || (CT == 1 && NC == 4 && P == 4 && RING == 4 && !EPI), "the node product: four consumers of 16 channels, four producers");
     constexpr int PITCH = tall_pitch(KS), PLANE = 16 * PITCH, TILE = tall_tile_bytes(KS, NC, EPI);
     constexpr int EPITCH = tall_epi_pitch(NC), EPLANE = 16 * EPITCH;   // bytes
     constexpr int QN = KS * 8;                                  // float4 chunks of a tile row (data + zero fill up to 32 KS)
@@ -42,6 +45,11 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     int* s_ready = reinterpret_cast<int*>(s_tall);
     int* s_taken = s_ready + 16;
     char* s_ring = s_tall + kTallHeader;
+    // NODE: the rows this launch writes feed a TripletMessage — the consumers leave every finished tile in a second ring, the producers
+    // multiply it by [W_node | Wa] (node_product.h)
+    int* s_xready = s_ready + 10;
+    int* s_xtaken = s_taken + 10;
+    char* s_xn = s_ring + RING * tall_tile_bytes(KS, NC, EPI);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool second = (int)blockIdx.x >= two.first_b;
     const TsArgs a = second ? two.b : two.a;
@@ -85,13 +93,12 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
             load(bid + d * nblk, buf[d]);
             if constexpr (EPI) load_epi(bid + d * nblk, ebuf[d]);
         }
-        for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int it = it0 + d, tile = bid + it * nblk;
-                if (tile < ntiles) {
-                    const int slot = it % RING, round = it / RING;
-                    while (flag_load(s_taken + slot) < NC * round) __builtin_amdgcn_s_sleep(1);
+        // one tile out of register set d into its ring slot (the slot is free), and that set's next loads
+        auto publish = [&](auto dc, int it) {
+            constexpr int d = decltype(dc)::value;
+            const int tile = bid + it * nblk, slot = it % RING;
+            {
+                {
                     asm volatile("" ::: "memory");
                     char* tl = s_ring + slot * TILE;
 #pragma unroll
@@ -123,6 +130,37 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
                     if (lane == 0) flag_bump(s_ready + slot);
                 }
             }
+        };
+        static_assert(D == 3, "register sets");
+        // NODE (the schedule of k_gru_fwd_ws<.., NODE>, block.hip): the first tile out in front of the loop, the product's weights asked
+        // for behind it, then iteration `it` multiplies finished tile it - RING before it publishes tile `it`; the last tiles behind the loop
+        Bf16x3 wn[2][3];
+        const int my_tiles = bid < ntiles ? (ntiles - bid + nblk - 1) / nblk : 0;
+        int jn = 0;
+        const NodeOut nout{a.node_xw, a.node_a, a.node_m1, a.N};
+        auto node_wait = [&](int j) { while (flag_load(s_xready + (j & 3)) < NC * ((j >> 2) + 1)) __builtin_amdgcn_s_sleep(1); };
+        if constexpr (NODE) {
+            if (my_tiles > 0) publish(std::integral_constant<int, 0>{}, 0);
+            node_load_fragments(wn, a.node_pre, wave, lane);
+        }
+        for (int it0 = 0; bid + it0 * nblk < ntiles; it0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int it = it0 + d, tile = bid + it * nblk;
+                if (tile < ntiles && !(NODE && it == 0)) {
+                    const int slot = it % RING, round = it / RING;
+                    while (flag_load(s_taken + slot) < NC * round) __builtin_amdgcn_s_sleep(1);
+                    if constexpr (NODE) {
+                        if (it >= RING) { node_wait(jn); node_product_tile(wn, s_xn, s_xtaken, jn & 3, bid + jn * nblk, wave, lane, nout); ++jn; }
+                    }
+                    if (d == 0) publish(std::integral_constant<int, 0>{}, it);
+                    else if (d == 1) publish(std::integral_constant<int, 1>{}, it);
+                    else publish(std::integral_constant<int, 2>{}, it);
+                }
+            }
+        }
+        if constexpr (NODE) {
+            for (; jn < my_tiles; ++jn) { node_wait(jn); node_product_tile(wn, s_xn, s_xtaken, jn & 3, bid + jn * nblk, wave, lane, nout); }
         }
         return;
     }
@@ -241,6 +279,10 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[j] += accb[j];
         }
+        float4 xnext = f4zero();                                // NODE: the lane's piece of the rows the TripletMessage reads
+        if constexpr (NODE) {
+            if (it >= kNodeXRing) while (flag_load(s_xtaken + (it & 3)) < P * (it >> 2)) __builtin_amdgcn_s_sleep(1);
+        }
         if (row < a.N) {
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
@@ -262,10 +304,16 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
                         (&v.x)[q] = o; (&od.x)[q] = o * drop_scale_w(wd, a.drop_p);
                     }
                     if (a.out_drop) st4(a.out_drop + e, od);
-                }
+                    if constexpr (NODE) { if (a.out_drop) xnext = od; else xnext = v; }
+                } else if constexpr (NODE) xnext = v;
                 if (col < a.M1) st4(a.out1 + (size_t)row * a.ldo1 + col, v);
                 else st4(a.out2 + (size_t)row * a.ldo2 + (col - a.M1), v);
             }
+        }
+        if constexpr (NODE) {
+            *reinterpret_cast<float4*>(s_xn + (it & 3) * kNodeXTile + c * kNodeXPitch + col0 * 4) = xnext;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) flag_bump(s_xready + (it & 3));
         }
     };
     int it = 0;
@@ -278,13 +326,13 @@ __global__ void __launch_bounds__((P + NC) * 64) k_tall_x3(TallArgs2 two) {
     }
 }
 
-template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI, bool RNG = false>
+template <int KS, int NC, int CT, int P, int RING, int MP, bool EPI, bool RNG = false, bool NODE = false>
 static int launch_tall(const TallArgs2& two, int grid, hipStream_t s) {
     static bool big[64] = {};
-    constexpr size_t lds = kTallHeader + (size_t)RING * tall_tile_bytes(KS, NC, EPI);
+    constexpr size_t lds = kTallHeader + (size_t)RING * tall_tile_bytes(KS, NC, EPI) + (NODE ? kNodeXBytes : 0);
     static_assert(lds <= 160 * 1024, "ring exceeds the LDS of a CU");
-    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_tall_x3<KS, NC, CT, P, RING, MP, EPI, RNG>), big, "tall_x3")) return rc;
-    hipLaunchKernelGGL((k_tall_x3<KS, NC, CT, P, RING, MP, EPI, RNG>), dim3(grid), dim3((P + NC) * 64), lds, s, two);
+    if (int rc = ws_opt_in_lds(reinterpret_cast<const void*>(&k_tall_x3<KS, NC, CT, P, RING, MP, EPI, RNG, NODE>), big, "tall_x3")) return rc;
+    hipLaunchKernelGGL((k_tall_x3<KS, NC, CT, P, RING, MP, EPI, RNG, NODE>), dim3(grid), dim3((P + NC) * 64), lds, s, two);
     return GLAM_OK;
 }
 
@@ -300,12 +348,14 @@ int launch_tall_x3(const TsArgs& a, const TsArgs* b, int variant, hipStream_t s)
     int rc;
     // the narrow layers of the search space (hid_dim 15 / 30: K = 16 .. 104) do not pay for six 32-k steps per tile
     const int Kmax = (a.K1 + a.K2) > (b ? b->K1 + b->K2 : 0) ? (a.K1 + a.K2) : (b->K1 + b->K2);
-    if (a.rng_state) {
-        // the training-mode RReLU epilogue: the input embeddings (K <= 64, M <= 64), one product per launch
+    if (a.rng_state || a.node_pre) {
+        // the training-mode RReLU epilogue / the node product of the TripletMessage behind: the input embeddings (K <= 64, M <= 64), one
+        // product per launch
         if (!(variant == 0 && Kmax <= 64 && !epi && !b && a.M2 == 0 && a.ldo1 == a.M1))
-            return fail(GLAM_E_UNSUPPORTED, "tall_x3: the RReLU epilogue takes K <= 64, M <= 64, one contiguous output");
-        GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>+rrelu");
-        rc = launch_tall<2, 4, 1, 4, 4, 64, false, true>(two, grid, s);
+            return fail(GLAM_E_UNSUPPORTED, "tall_x3: the RReLU epilogue / the node product take K <= 64, M <= 64, one contiguous output");
+        if (a.rng_state && a.node_pre) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>+rrelu+node"); rc = launch_tall<2, 4, 1, 4, 4, 64, false, true, true>(two, grid, s); }
+        else if (a.node_pre) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>+node"); rc = launch_tall<2, 4, 1, 4, 4, 64, false, false, true>(two, grid, s); }
+        else { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>+rrelu"); rc = launch_tall<2, 4, 1, 4, 4, 64, false, true>(two, grid, s); }
     }
     else if (variant == 0 && Kmax <= 64 && epi) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1, epi>"); rc = launch_tall<2, 4, 1, 4, 4, 64, true>(two, grid, s); }
     else if (variant == 0 && Kmax <= 64) { GLAM_PROF_LABEL("k_tall_x3<2, 4, 1>"); rc = launch_tall<2, 4, 1, 4, 4, 64, false>(two, grid, s); }

@@ -854,6 +854,19 @@ def _apply_act(mod, x, next_dropout=0.0):
     return mod(x)
 
 
+def first_node_spec(block, n_rows, edge_index, edge_attr):
+    """``ops.first_node_spec`` of ``block``'s TripletMessage when the output of the LinearBlock in front of it reaches that conv unchanged
+    (no norm; a dropout slot that is empty, inactive, or the training-mode Dropout whose mask that LinearBlock's launch draws:
+    ``following_dropout``), else None — the hint for ``LinearBlock.forward(next_node=...)``."""
+    conv = block.conv.conv if isinstance(getattr(block, "conv", None), _TripletMessage) else None
+    if conv is None or not isinstance(block.norm, _None) or not (isinstance(block.dropout, _None) or type(block.dropout) is Dropout):
+        return None
+    d = block.dropout
+    if type(d) is Dropout and d.training and not (0.0 < d.p < 1.0):
+        return None
+    return ops.first_node_spec(conv, n_rows, edge_index, edge_attr)
+
+
 def following_dropout(block):
     """p of the training-mode ``Dropout(p)`` that ``block`` (a LinearBlock / MessageBlock) applies to its input first, 0.0 when
     something else touches the input before it (a norm) or there is none: the hint for the producer's activation launch."""
@@ -919,7 +932,10 @@ class LinearBlock(torch.nn.Module):
         self.linear = Linear(in_dim, out_dim)
         self.act = _act(act)
 
-    def forward(self, x, batch=None, next_dropout=0.0):
+    def forward(self, x, batch=None, next_dropout=0.0, next_node=None):
+        """``next_dropout``: p of the training-mode Dropout the block behind applies to this output first (``following_dropout``);
+        ``next_node``: that block is a MessageBlock whose TripletMessage reads this output (``first_node_spec``) — the product's launch
+        then also writes the dropped twin / the TripletMessage's node product where its kernel can."""
         x = self.norm(x, batch)
         x = _apply_dropout(self.dropout, x)
         a = self.act
@@ -929,12 +945,12 @@ class LinearBlock(torch.nn.Module):
             if y is not None:
                 return y
             if type(a) is ReLU:                            # ... or the tall product's (the input embeddings)
-                y = ops.linear_relu(x, self.linear.weight, self.linear.bias)
+                y = ops.linear_relu(x, self.linear.weight, self.linear.bias, node=next_node)
                 if y is not None:
                     return y
         if type(a) is RReLU and a.training and 0 < a.lower <= a.upper and x.is_cuda and x.dim() == 2:
             # training-mode RReLU: in the tall product's epilogue too (the input embeddings)
-            y = ops.linear_rrelu(x, self.linear.weight, self.linear.bias, a.lower, a.upper, float(next_dropout))
+            y = ops.linear_rrelu(x, self.linear.weight, self.linear.bias, a.lower, a.upper, float(next_dropout), node=next_node)
             if y is not None:
                 return y
         x = ops.linear(x, self.linear.weight, self.linear.bias)

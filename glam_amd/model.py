@@ -14,7 +14,7 @@ from . import graphs, ops
 
 from .layer import _None  # noqa: F401
 from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
-from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, following_dropout, prestage_pass
+from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, first_node_spec, following_dropout, prestage_pass
 
 
 def model_args(args):
@@ -60,7 +60,9 @@ class Architecture(torch.nn.Module):
     def _forward(self, data_mol):
         prestage_pass((self.mol_lin0, self.mol_conv, data_mol.x, data_mol.edge_attr))  # (the pass's weight re-layouts from one launch)
         # (next_dropout: the block behind applies Dropout to this output first — the activation's launch writes the dropped twin)
-        xm = self.mol_lin0(data_mol.x, batch=data_mol.batch, next_dropout=following_dropout(self.mol_conv))     # model.py:49
+        # (... and next_node: that block's TripletMessage reads this output — the embedding's launch writes its node product too)
+        xm = self.mol_lin0(data_mol.x, batch=data_mol.batch, next_dropout=following_dropout(self.mol_conv),     # model.py:49
+                           next_node=first_node_spec(self.mol_conv, data_mol.x.size(0), data_mol.edge_index, data_mol.edge_attr))
         hm = None
         for i in range(self.message_steps):                                        # model.py:53-54
             with ops.block_feeds_itself(i + 1 < self.message_steps):      # (its output is the same block's next input)

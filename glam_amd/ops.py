@@ -1276,6 +1276,24 @@ def take_node_product(x, staged):
     return hit[4], hit[5]
 
 
+def first_node_spec(conv, N, edge_index, edge_attr):
+    """``(staged, H * Cp)`` when the TripletMessage ``conv`` will take the node product of its FIRST input from the launch that writes that
+    input (the input embedding: ``linear_relu`` / ``linear_rrelu`` with ``node=``): its staged images exist already (``prestage``), and the
+    call will run on the warp-specialised route (one-hot bond features, an ELL form of the edge list).  Else None."""
+    if not (NODE_IN_GRU and _SCOPE is not None and not CACHED_STAGING and N > 0):
+        return None
+    C, H, De = conv.node_channels, conv.heads, conv.edge_channels
+    if C % 4 or De != 4 or not (1 <= H <= 4 and fused_layer_supported(C, H, De)) or H * C + 8 <= 64 or N > NODE_IN_GRU_MAX_ROWS or _want_torch_ext(N, H, C):
+        return None
+    wn = conv.weight_node
+    hit = _SCOPE.fwd.get(("triplet", id(wn), id(conv.weight_edge), id(conv.weight_triplet_att), id(conv.weight_scale), id(conv.bias)))
+    if hit is None or hit[0] is not wn or edge_attr is None or edge_attr.dim() != 2 or edge_attr.size(1) != De or edge_attr.dtype != torch.float32:
+        return None
+    if not _ws_route(_lib.load(), N, H, C, De, edge_attr) or graph_index(edge_index, N).ell() is None:
+        return None
+    return hit[1], H * C
+
+
 def next_node_spec(conv, N):
     """``(staged, H * Cp)`` when the TripletMessage ``conv`` — applied a moment ago inside the active weight scope — will take its next
     input's node product from the GRU step (warp-specialised route, unpadded width), else None."""

@@ -32,11 +32,12 @@ class _Linear(torch.autograd.Function):
     ``x`` that needs no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu=False, rrelu=None):
+    def forward(ctx, x, w, b, relu=False, rrelu=None, node=None):
         """``relu``: ``max(y, 0)`` in the product's epilogue (glam_ts_gemm_relu; the caller checked glam_ts_gemm_relu_supported); the
         backward masks ``dy`` by the saved output first.  ``rrelu = (lower, upper, drop_p)``: the training-mode RReLU in the epilogue
         (glam_ts_gemm_rrelu) and, ``drop_p > 0``, the dropped twin as a second output — returns ``(y, y_drop)``; the backward regenerates
-        the slopes / the mask from the recorded stream position (glam_bias_res_act_rng_bwd)."""
+        the slopes / the mask from the recorded stream position (glam_bias_res_act_rng_bwd).  ``node = (staged, H * Cp, took)``: the rows
+        feed a TripletMessage — the launch also writes its node product (glam_ts_gemm_act_node; ``took`` receives ``xw`` / ``a_ij``)."""
         require_device(x, w, b)
         x, w = f32c(x, "x"), f32c(w, "weight")
         b = None if b is None else f32c(b, "bias")
@@ -55,19 +56,33 @@ class _Linear(torch.autograd.Function):
         img = _o._scoped(scope.fwd if scope else None, ("lin", id(w)), w, build)
         y = torch.empty(N, M, dtype=torch.float32, device=dev)
         ctx.rrelu = None
+        nd = None
+        if node is not None and N > 0:
+            staged, cols, took = node
+            nd = (staged[lib.glam_triplet_staged_node_fragments(cols // M, M, 4):], cols, torch.empty(N, cols, dtype=torch.float32, device=dev),
+                  torch.empty(N, 8, dtype=torch.float32, device=dev))
+            took["xw"], took["a_ij"] = nd[2], nd[3]
         if rrelu is not None:
             ctx.set_materialize_grads(False)
             lo, hi, p = (float(v) for v in rrelu)
             eff = torch.empty(2, dtype=torch.int64, device=dev)
             y_drop = torch.empty_like(y) if p > 0 else None
-            check(lib.glam_ts_gemm_rrelu(ptr(x), K, K, ptr(img), ptr(b), M, N, lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(y), ptr(y_drop),
-                                         stream()), "glam_ts_gemm_rrelu")
+            if nd is not None:
+                check(lib.glam_ts_gemm_act_node(ptr(x), K, K, ptr(img), ptr(b), M, N, 4, lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(y), ptr(y_drop),
+                                                ptr(nd[0]), nd[1], ptr(nd[2]), ptr(nd[3]), stream()), "glam_ts_gemm_act_node")
+            else:
+                check(lib.glam_ts_gemm_rrelu(ptr(x), K, K, ptr(img), ptr(b), M, N, lo, hi, p, ptr(_o.rng_state(dev)), ptr(eff), ptr(y), ptr(y_drop),
+                                             stream()), "glam_ts_gemm_rrelu")
             ctx.save_for_backward(x, w, y)
             ctx.rrelu, ctx.eff = (lo, hi, p), eff
             ctx.has_bias = b is not None
             ctx.scope = scope
             return y, y_drop
-        if relu:
+        if relu and nd is not None:
+            check(lib.glam_ts_gemm_act_node(ptr(x), K, K, ptr(img), ptr(b), M, N, 1, 0.0, 0.0, 0.0, None, None, ptr(y), None, ptr(nd[0]), nd[1],
+                                            ptr(nd[2]), ptr(nd[3]), stream()), "glam_ts_gemm_act_node")
+            ctx.save_for_backward(x, w, y)
+        elif relu:
             check(lib.glam_ts_gemm_relu(ptr(x), K, K, ptr(img), ptr(b), ptr(y), M, M, N, stream()), "glam_ts_gemm_relu")
             ctx.save_for_backward(x, w, y)
         else:
@@ -125,7 +140,7 @@ class _Linear(torch.autograd.Function):
             else:
                 check(lib.glam_wgrad_gemm_split(ptr(dy), M, M, ptr(x), Kw, K, ptr(dw), ptr(db), N, ptr(ws), ws.numel(), stream()),
                       "glam_wgrad_gemm_split")
-            return dx, dw, (db if ctx.has_bias else None), None, None
+            return dx, dw, (db if ctx.has_bias else None), None, None, None
         dwb = torch.empty(M + 1, K + 1, **f)          # [d_w | d_b] (+ a spare row / column for the ones trick)
         if M <= 64:   # out[k, m] = sum_n [x|1][n,k] dy[n,m]  ->  written transposed into dwb[m, k]
             check(lib.glam_wgrad_gemm(ptr(x), K, K, None, 0, 0, 1, ptr(dy), M, M, 0, N, ptr(dwb), 1, K + 1, ptr(ws), ws.numel(),
@@ -135,7 +150,7 @@ class _Linear(torch.autograd.Function):
                                       stream()), "glam_wgrad_gemm")
         dw = dwb[:M, :w.size(1)]
         db = dwb[:M, K] if ctx.has_bias else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _RelationMLP(torch.autograd.Function):
@@ -678,7 +693,7 @@ def linear(x, weight, bias=None):
     return _o.slice_cols(y, M)                    # pad columns are x @ 0 + 0
 
 
-def linear_relu(x, weight, bias=None):
+def linear_relu(x, weight, bias=None, node=None):
     """``relu(F.linear(x, weight, bias))`` with the ReLU in the epilogue of the product where its shape runs on ``k_tall_x3`` (the input
     embeddings of the models: 15 -> 60 ...); ``None`` elsewhere (the caller applies ``linear`` and the activation)."""
     M, K = weight.shape
@@ -691,10 +706,23 @@ def linear_relu(x, weight, bias=None):
         if x.requires_grad and torch.is_grad_enabled():
             return None                      # (a padded differentiable input takes the padded-weight route of ``linear``)
         x = _o.pad_cols(x, Kp)
-    return _Linear.apply(x, weight, bias, True)
+    nd, took = _node_arg(node, M) if _lib.load().glam_ts_gemm_rrelu_supported(Kp, M) == 1 else (None, None)
+    y = _Linear.apply(x, weight, bias, True, None, nd)
+    if took:
+        _o.register_node_product(y, node[0], took["xw"], took["a_ij"])
+    return y
 
 
-def linear_rrelu(x, weight, bias, lower, upper, drop_p=0.0):
+def _node_arg(node, M):
+    """``node`` of ``linear_relu`` / ``linear_rrelu`` as ``_Linear`` takes it (+ the dict the forward fills), or None where the product's
+    width is not the layer's."""
+    if node is None or node[1] % M or not _o.NODE_IN_GRU:
+        return None, None
+    took = {}
+    return (node[0], node[1], took), took
+
+
+def linear_rrelu(x, weight, bias, lower, upper, drop_p=0.0, node=None):
     """Training-mode ``RReLU(lower, upper)(F.linear(x, weight, bias))`` with the activation — and, ``drop_p > 0``, the dropped twin the
     following ``Dropout(drop_p)`` picks up (``ops.take_dropped``) — in the epilogue of the product where its shape runs on ``k_tall_x3``
     with that epilogue (the input embeddings: 15 -> 60 ...); ``None`` elsewhere (the caller applies ``linear`` and ``rrelu``)."""
@@ -708,9 +736,12 @@ def linear_rrelu(x, weight, bias, lower, upper, drop_p=0.0):
         if x.requires_grad and torch.is_grad_enabled():
             return None
         x = _o.pad_cols(x, Kp)
-    y, y_drop = _Linear.apply(x, weight, bias, False, (float(lower), float(upper), float(drop_p)))
+    nd, took = _node_arg(node, M)
+    y, y_drop = _Linear.apply(x, weight, bias, False, (float(lower), float(upper), float(drop_p)), nd)
     if y_drop is not None:
         _o.register_dropped(y, y_drop, drop_p)
+    if took:      # (``node = (staged, H * Cp)`` of ops.first_node_spec: the TripletMessage behind finds its node product ready)
+        _o.register_node_product(y_drop if y_drop is not None else y, node[0], took["xw"], took["a_ij"])
     return y
 
 

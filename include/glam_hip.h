@@ -289,6 +289,15 @@ int glam_ts_gemm_relu(const float* A, int K, int lda, const float* Wimg, const f
  * activation backward.  out, out_drop: [N, M] contiguous.  Shapes: glam_ts_gemm_rrelu_supported (K <= 64, M <= 64: the input embeddings
  * mol_lin0 / pro_lin0 of model.py:40-49). */
 int glam_ts_gemm_rrelu_supported(int K, int M);
+/* The input embedding in front of a TripletMessage (/root/reference/src_1gp/model.py:49, :53) with the TripletMessage's node product of
+ * its rows in the same launch: out = act(A @ W + bias) — act 0: none, 1: ReLU, 4: training-mode RReLU (+ the dropped twin out_drop,
+ * as glam_ts_gemm_rrelu; rng_* unused otherwise) — and xw[N, node_cols] | a_ij[N, 8] = out (out_drop when given) @ [W_node | Wa] from
+ * node_pre (staged + glam_triplet_staged_node_fragments): what glam_ts_gemm writes for the same rows, bit for bit.
+ * glam_triplet_layer_fwd_ell with x = NULL then starts at its aggregate launch.  Shapes: glam_ts_gemm_rrelu_supported(K, M), M = the
+ * layer's Cp >= 24, 56 < node_cols = H * Cp <= 184. */
+int glam_ts_gemm_act_node(const float* A, int K, int lda, const float* Wimg, const float* bias, int M, int64_t N, int act, float rr_lower,
+                          float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* out, float* out_drop,
+                          const void* node_pre, int node_cols, float* xw, float* a_ij, void* stream);
 int glam_ts_gemm_rrelu(const float* A, int K, int lda, const float* Wimg, const float* bias, int M, int64_t N, float rr_lower,
                        float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* out, float* out_drop, void* stream);
 

@@ -167,7 +167,9 @@ def test_inference_forward_launches_and_c_abi(device, monkeypatch):
                 outs[route, grad] = conv(x.clone().requires_grad_(grad), b.edge_index, b.edge_attr).detach()
             labels[route, grad] = [n for n, _, _ in kt.records()]
         assert torch.equal(outs[route, True], outs[route, False]), route
-    assert any("k_triplet_fwd_ws<inference>" in n for n in labels["auto", False]), labels["auto", False]
+    ws = lib.glam_triplet_layer_ws_supported(3, 60, 4, 1) == 1        # (GLAM_WS=0: the general kernels everywhere; their NULL form is below)
+    if ws:
+        assert any("k_triplet_fwd_ws<inference>" in n for n in labels["auto", False]), labels["auto", False]
     assert not any("inference" in n for n in labels["auto", True])
     assert lib.glam_triplet_layer_infer_supported(3, 60, 4) == 1
     # C ABI
@@ -184,7 +186,10 @@ def test_inference_forward_launches_and_c_abi(device, monkeypatch):
         aggr, stats = (torch.empty(N, 180, **f), torch.empty(N, 8, **f)) if keep else (None, None)
         rc = lib.glam_triplet_layer_fwd_ell(p(x), p(b.edge_attr), p(staged), p(ell[0]), p(ell[1]), 1, N, gi.E, 3, 60, 4, 0.2, p(xw), p(a_ij), p(aggr),
                                             p(stats), p(out), _lib.stream())
-        assert rc == 0, lib.glam_last_error()
+        assert (rc == 0) == ws, lib.glam_last_error()
+        if not ws:
+            assert rc == _lib.GLAM_E_UNSUPPORTED
+            out = outs["auto", True]
         res.append(out)
         out2 = torch.full((N, 60), float("nan"), **f)
         rc = lib.glam_triplet_layer_fwd(p(x), p(b.edge_attr), p(staged), p(gi.rowptr), p(gi.src), p(gi.eid), N, gi.E, 3, 60, 4, 0.2, p(xw), p(a_ij),
@@ -2072,7 +2077,10 @@ def test_default_config_training_step_uses_the_fused_tails(device, monkeypatch, 
     out = net(b)
     # standalone launches: RReLU after mol_lin0 and mol_flat — each also writes the dropped twin for the Dropout that follows it (before
     # message step 1, before lin_out1), so no dropout launch of its own is left
-    assert calls == {"dropout": 0, "rrelu": 2}, calls
+    # (hid 60: mol_lin0's RReLU and its twin come out of the embedding product's own epilogue — glam_ts_gemm_rrelu / _act_node — so ONE
+    # stand-alone RReLU launch is left)
+    fused_embedding = alpha == 4 and ops.RRELU_IN_GEMM and ops._lib.route_enabled("x3")
+    assert calls == {"dropout": 0, "rrelu": 1 if fused_embedding else 2}, calls
     loss = out.square().mean()
     grads = torch.autograd.grad(loss, list(net.parameters()))
     ops.manual_seed(99)
@@ -3851,8 +3859,8 @@ def test_gru_step_writes_the_node_product_of_the_next_application(device, N, C, 
 @pytest.mark.parametrize("train,B", [(False, 700), (True, 700), (False, 3)])
 def test_model_step_with_the_node_product_inside_the_gru_step(device, monkeypatch, train, B):
     """Architecture (src_1gp/model.py:36-62) forward + backward with ops.NODE_IN_GRU on / off: the same outputs and the same gradients bit for
-    bit — the product the next TripletMessage finds ready is the one its own launch would write — and two launches less per step (the node
-    GEMMs of the second and third application)."""
+    bit — the product a TripletMessage finds ready is the one its own launch would write — and three launches less per step (all three node
+    GEMMs: the first application's comes out of the input embedding's launch)."""
     b = synth_batch(B, seed=8).to(device)
     torch.manual_seed(5)
     kw = dict(mol_block="_TripletMessage", hid_dim_alpha=4, e_dim=256, out_dim=1, message_steps=3, mol_readout="GlobalPool5")
@@ -3877,8 +3885,11 @@ def test_model_step_with_the_node_product_inside_the_gru_step(device, monkeypatc
         res.append([y.detach().clone()] + [q.grad.clone() for q in net.parameters()])
     for i, (u, v) in enumerate(zip(*res)):
         assert torch.equal(u, v), i
-    if B >= 16 and ops._lib.route_enabled("x3"):       # (the warp-specialised GRU step; a handful of molecules: one tile per block all the same)
-        assert counts[0][1] == 0 and counts[1][1] == 2 and counts[0][0] - counts[1][0] == 2, counts
+    if B >= 16 and ops._lib.route_enabled("x3") and ops._lib.load().glam_triplet_layer_ws_supported(3, 60, 4, 1) == 1 and ops.GRU_PRE:
+        # (the warp-specialised GRU step and layer: GLAM_X3=0 / GLAM_WS=0 / GLAM_GRU_PRE=0 switch the route off; a handful of molecules: one
+        #  tile per block all the same)
+        # (the embedding's launch writes the first application's product, the GRU steps of the first two the second's and third's)
+        assert counts[0][1] == 0 and counts[1][1] == 3 and counts[0][0] - counts[1][0] == 3, counts
 
 
 @pytest.mark.parametrize("N,K,M,p", [(20400, 16, 60, 0.2), (20400, 16, 60, 0.0), (17, 32, 64, 0.5), (1, 16, 28, 0.2), (0, 16, 60, 0.2)])
@@ -3887,6 +3898,9 @@ def test_rrelu_and_the_dropped_twin_in_the_embedding_products_epilogue(device, N
     mode): the same bits as glam_ts_gemm followed by glam_bias_res_act_rng_fwd from the same stream position — output, dropped twin, the
     recorded (seed, offset) pair and the position the stream is left at — and glam_bias_res_act_rng_bwd on its output is its backward."""
     raw, ptr, st = ops._lib.load(), ops.ptr, ops.stream
+    if not ops._lib.route_enabled("x3"):      # (GLAM_X3=0: no k_tall_x3, no such epilogue — the two-launch form is what runs)
+        assert raw.glam_ts_gemm_rrelu_supported(K, M) == 0
+        return
     g = torch.Generator().manual_seed(N + K + M)
     r = lambda *s: torch.randn(*s, generator=g).to(device)
     x, w, b = r(N, K), r(M, K) * 0.5, r(M)
@@ -3939,3 +3953,56 @@ def test_linear_block_with_training_mode_rrelu_in_one_launch(device, monkeypatch
     assert (next_p == 0) == (res[0][1] is None)
     if ops._lib.route_enabled("x3"):
         assert counts[0] - counts[1] == 1, counts
+
+
+@pytest.mark.parametrize("N,K,M,H,act,p", [(20400, 16, 60, 3, 1, 0.0), (20400, 16, 60, 3, 4, 0.2), (20400, 16, 60, 3, 4, 0.0), (5000, 16, 60, 3, 0, 0.0),
+                                           (17, 32, 64, 2, 4, 0.5), (1, 16, 48, 3, 1, 0.0), (70, 16, 36, 4, 4, 0.2), (0, 16, 60, 3, 1, 0.0)])
+def test_embedding_launch_writes_the_node_product_of_the_first_application(device, N, K, M, H, act, p):
+    """glam_ts_gemm_act_node: the input embedding (LinearBlock, src_1gp/model.py:40, :49) with none / ReLU / training-mode RReLU (+ dropped
+    twin) AND the node product of the TripletMessage behind it (layer.py:37) in one launch — output, twin, stream position as
+    glam_ts_gemm(_relu / _rrelu) writes them, xw | a_ij as glam_ts_gemm on those rows (the twin when there is one), all bit for bit."""
+    raw, ptr, st = ops._lib.load(), ops.ptr, ops.stream
+    if not ops._lib.route_enabled("x3"):
+        assert raw.glam_ts_gemm_rrelu_supported(K, M) == 0
+        return
+    g = torch.Generator().manual_seed(N + K + M + act)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    HC = H * M
+    x, w, b = r(N, K), r(M, K) * 0.5, r(M)
+    wn, we, att, wsc, bias = r(M, HC) * 0.2, r(4, HC) * 0.2, r(1, H, 3 * M) * 0.2, r(HC, M) * 0.2, r(M)
+    staged = torch.empty(raw.glam_triplet_staged_floats(H, M, 4), device=device)
+    assert raw.glam_triplet_stage_params(ptr(wn), ptr(we), ptr(att), ptr(wsc), ptr(bias), M, H, 4, M, 4, ptr(staged), st()) == 0
+    nimg, nfrag = staged[raw.glam_triplet_staged_node_image(H, M, 4):], staged[raw.glam_triplet_staged_node_fragments(H, M, 4):]
+    img = torch.empty(raw.glam_ts_gemm_image_bytes(K, M) // 4, device=device)
+    assert raw.glam_ts_gemm_make_image(ptr(w), K, 1, K, M, ptr(img), st()) == 0
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    lo, hi = 0.125, 1.0 / 3
+    mk = lambda: (torch.tensor([99] + [0] * (ops.RNG_STATE_WORDS - 1), dtype=torch.int64, device=device), torch.zeros(2, dtype=torch.int64, device=device))
+    s0, e0 = mk()
+    o0, d0 = f(N, M), f(N, M)
+    if act == 4:
+        assert raw.glam_ts_gemm_rrelu(ptr(x), K, K, ptr(img), ptr(b), M, N, lo, hi, p, ptr(s0), ptr(e0), ptr(o0), ptr(d0) if p > 0 else None, st()) == 0
+    elif act == 1:
+        assert raw.glam_ts_gemm_relu(ptr(x), K, K, ptr(img), ptr(b), ptr(o0), M, M, N, st()) == 0
+    else:
+        assert raw.glam_ts_gemm(ptr(x), K, K, None, 0, 0, ptr(img), ptr(b), ptr(o0), M, M, None, 0, 0, N, st()) == 0
+    rows = d0 if (act == 4 and p > 0) else o0
+    xw0, a0 = f(N, HC), f(N, 8)
+    assert raw.glam_ts_gemm(ptr(rows), M, M, None, 0, 0, ptr(nimg), None, ptr(xw0), HC, HC, ptr(a0), 8, 8, N, st()) == 0
+    s1, e1 = mk()
+    o1, d1, xw1, a1 = f(N, M), f(N, M), f(N, HC), f(N, 8)
+    rc = raw.glam_ts_gemm_act_node(ptr(x), K, K, ptr(img), ptr(b), M, N, act, lo, hi, p, ptr(s1) if act == 4 else None, ptr(e1) if act == 4 else None,
+                                   ptr(o1), ptr(d1) if (act == 4 and p > 0) else None, ptr(nfrag), HC, ptr(xw1), ptr(a1), st())
+    assert rc == 0, raw.glam_last_error()
+    if N == 0:
+        return
+    assert torch.equal(o0, o1) and not torch.isnan(o1).any()
+    if act == 4:
+        assert torch.equal(e0, e1) and torch.equal(s0[:2], s1[:2]) and (p == 0 or torch.equal(d0, d1))
+    if ops._lib.route_enabled("x3"):
+        assert torch.equal(xw0, xw1) and torch.equal(a0, a1)
+    assert_close(xw1, xw0, 2e-6, "xw")
+    assert_close(a1, a0, 2e-6, "a_ij")
+    assert not torch.isnan(xw1).any() and not torch.isnan(a1).any()
+    assert raw.glam_ts_gemm_act_node(ptr(x), K, K, ptr(img), ptr(b), M, N, 2, lo, hi, p, None, None, ptr(o1), None, ptr(nfrag), HC, ptr(xw1), ptr(a1),
+                                     st()) == ops._lib.GLAM_E_UNSUPPORTED
