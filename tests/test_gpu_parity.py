@@ -3889,7 +3889,8 @@ def test_model_step_with_the_node_product_inside_the_gru_step(device, monkeypatc
         # (the warp-specialised GRU step and layer: GLAM_X3=0 / GLAM_WS=0 / GLAM_GRU_PRE=0 switch the route off; a handful of molecules: one
         #  tile per block all the same)
         # (the embedding's launch writes the first application's product, the GRU steps of the first two the second's and third's)
-        assert counts[0][1] == 0 and counts[1][1] == 3 and counts[0][0] - counts[1][0] == 3, counts
+        want = 3 if (not train or ops.RRELU_IN_GEMM) else 2      # (training mode: the embedding's product carries it only with its RReLU in the epilogue)
+        assert counts[0][1] == 0 and counts[1][1] == want and counts[0][0] - counts[1][0] == want, counts
 
 
 @pytest.mark.parametrize("N,K,M,p", [(20400, 16, 60, 0.2), (20400, 16, 60, 0.0), (17, 32, 64, 0.5), (1, 16, 28, 0.2), (0, 16, 60, 0.2)])

@@ -40,6 +40,8 @@ if os.environ.get("NODE", "0") != "0" or os.environ.get("GATES", "0") != "0":
     assert lib.glam_triplet_stage_params(p(wn), p(we), p(att), p(wsc), p(bias), C, H, 4, C, 4, p(staged), st()) == 0
     nimg = staged[lib.glam_triplet_staged_node_fragments(H, C, 4):]
     xw, a_ij, xc = torch.empty(N, H * C, device=dev), torch.empty(N, 8, device=dev), torch.empty(N, C, device=dev)
+    D4 = torch.empty(N, 4 * C, device=dev)
+    def bwd(): assert lib.glam_gru_bwd_ws_pre(p(G4), None, p(h), p(out), p(d_out), p(d_hs), p(xc), p(pre[1]), N, C, 2, 1, 0.0, 0, p(D4), None, p(did), p(dx), p(dh), st()) == 0
     if os.environ.get("NODE", "0") != "0":
         def fwd(): assert lib.glam_gru_ws_fwd_pre_node(p(x), p(h), p(idn), p(pre[0]), p(b_ih), p(b_hh), N, C, 1, 1, 0.0, p(G4), None, p(hn), p(out), p(xc), p(nimg), H * C, p(xw), p(a_ij), st()) == 0
     else:
