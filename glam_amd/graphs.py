@@ -218,10 +218,17 @@ _OPS_KNOBS = ("VALIDATE", "WS_ROUTE", "GRAD_CARRY", "CACHED_STAGING", "USE_TORCH
 _ENV_KNOBS = ("GLAM_X3", "GLAM_WS", "GLAM_WGRAD_X3", "GLAM_WGRAD_X3_ROWS", "GLAM_TALL_X3", "GLAM_WS_GRID", "GLAM_B1_PRE")
 
 
+_OPS_GET = None
+
+
 def _route_signature():
+    global _OPS_GET
     from . import ops
-    return (tuple(getattr(ops, k, None) for k in _OPS_KNOBS) + (ops.GraphIndex.ELL_MIN_NODES,)
-            + tuple(os.environ.get(k) for k in _ENV_KNOBS))
+    if _OPS_GET is None:
+        import operator
+        _OPS_GET = operator.attrgetter(*_OPS_KNOBS)      # (one C call for the 22 switches: this runs on every call of a routed model)
+    env = os.environ
+    return _OPS_GET(ops) + (ops.GraphIndex.ELL_MIN_NODES,) + tuple([env.get(k) for k in _ENV_KNOBS])
 
 
 class _Replay(torch.autograd.Function):

@@ -18,6 +18,7 @@ import ctypes
 
 import numpy as np
 import torch
+from torch.optim import optimizer as _topt      # (the module: its global step-hook tables)
 
 from . import _lib
 from ._lib import GlamHipError
@@ -36,7 +37,7 @@ class Adam(torch.optim.Optimizer):
         self._plans = {}          # group index -> _Plan
 
     class _Plan:
-        __slots__ = ("params", "table", "numel", "step", "ticket", "flat_m", "flat_v", "sub", "sub_key")
+        __slots__ = ("params", "table", "numel", "step", "ticket", "flat_m", "flat_v", "sub", "sub_key", "gptrs", "pptrs")
 
     def _plan(self, gi, group):
         plan = self._plans.get(gi)
@@ -60,6 +61,7 @@ class Adam(torch.optim.Optimizer):
         plan.table = np.zeros((len(ps), 4), dtype=np.uint64)
         plan.numel = np.array([p.numel() for p in ps], dtype=np.int64)
         plan.sub, plan.sub_key = None, None
+        plan.gptrs, plan.pptrs = None, None          # gradient / parameter addresses as the table holds them (step(): one list compare)
         off = 0
         for i, (p, n) in enumerate(zip(ps, sizes)):
             m, v = plan.flat_m[off:off + p.numel()].view_as(p), plan.flat_v[off:off + p.numel()].view_as(p)
@@ -75,8 +77,25 @@ class Adam(torch.optim.Optimizer):
         self._plans[gi] = plan
         return plan
 
-    @torch.no_grad()
+    def zero_grad(self, set_to_none: bool = True):
+        """``torch.optim.Optimizer.zero_grad``; its default (``set_to_none=True``) as the plain loop it amounts to — the base class's
+        goes through a dynamo guard and a profiler scope, 25 us per call where the reference's loop is bound by host time (its batch of
+        32: DESIGN.md §7)."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.grad = None
+
     def step(self, closure=None):
+        # (torch wraps an optimizer's step in a profiler scope that also runs the step hooks — Optimizer.profile_hook_step, ≈15 us per
+        #  call; `step.hooked` below keeps it off this class, and the hooks, when there are any, are run here)
+        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _topt._global_optimizer_pre_hooks or _topt._global_optimizer_post_hooks:
+            return Adam._hooked_step(self, closure)
+        return self._step(closure)
+
+    def _step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -84,13 +103,37 @@ class Adam(torch.optim.Optimizer):
         lib = _lib.load()
         from . import ops
         ops.parameters_written()         # the launch below writes parameters through raw pointers: no version counter moves
+        with torch.no_grad():
+            self._launch(lib)
+        return loss
+
+    def _launch(self, lib):
         for gi, group in enumerate(self.param_groups):
             if not any(p.requires_grad for p in group["params"]):
                 continue
             plan = self._plan(gi, group)
             table, numel = plan.table, plan.numel
             missing = None
-            for i, p in enumerate(plan.params):
+            grads = [p.grad for p in plan.params]
+            complete = all([g is not None for g in grads])      # (`None in grads` would compare TENSORS with None: a torch call each)
+            if complete:
+                # the common step: every parameter has a gradient — the addresses against last step's, one list compare each (a loop
+                # over numpy elements cost 35 us for the default model's 24 tensors)
+                gp, pp = [g.data_ptr() for g in grads], [p.data_ptr() for p in plan.params]
+                if gp != plan.gptrs:
+                    for i, (g, p) in enumerate(zip(grads, plan.params)):
+                        if table[i, 1] != gp[i]:                             # a gradient tensor not seen at this address yet
+                            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or g.is_sparse:
+                                raise GlamHipError("glam_amd.optim.Adam: gradients must be dense contiguous fp32 tensors on the parameter's device")
+                            table[i, 1] = gp[i]
+                    plan.gptrs = gp
+                if pp != plan.pptrs:                                         # `p.data = ...` since the last step
+                    for i in range(len(pp)):
+                        table[i, 0] = pp[i]
+                    plan.pptrs = pp
+            else:
+                plan.gptrs = plan.pptrs = None
+            for i, p in (() if complete else enumerate(plan.params)):
                 g = p.grad
                 if g is None:
                     missing = missing or []
@@ -124,7 +167,6 @@ class Adam(torch.optim.Optimizer):
                                     float(group["weight_decay"]), torch.cuda.current_stream(plan.step.device).cuda_stream)
             if rc != 0:
                 raise GlamHipError(f"glam_adam_step failed (code {rc}): {lib.glam_last_error().decode()}")
-        return loss
 
     def state_dict(self):
         """``torch.optim.Adam``'s layout with a PRIVATE ``step`` per parameter: internally every parameter of a group shares one device
@@ -166,3 +208,9 @@ class Adam(torch.optim.Optimizer):
         super().add_param_group(param_group)
         if hasattr(self, "_plans"):
             self._plans.clear()
+
+
+# torch wraps `cls.step` in Optimizer.profile_hook_step when the first instance is built — unless the function says it is hooked already:
+# Adam.step runs the wrapper itself, and only when a step hook is registered (see there)
+Adam._hooked_step = torch.optim.Optimizer.profile_hook_step(Adam._step)
+Adam.step.hooked = True
