@@ -116,6 +116,8 @@ SIGNATURES = {
     "glam_linear_narrow_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "glam_linear_narrow_bwd_workspace_bytes": (_sz, [_i32, _i32]),
     "glam_linear_narrow_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "glam_linear_narrow_act_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "glam_linear_narrow_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "glam_pair_pool5_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _vp, _vp, _vp]),
     "glam_ts_gemm_relu_supported": (_i32, [_i32, _i32]),
     "glam_ts_gemm_relu": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),

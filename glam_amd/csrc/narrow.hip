@@ -8,22 +8,48 @@
 //             d_x[n, chunk] = sum_m dy[n, m] w[m, chunk] and accumulating d_w[m, chunk] += dy[n, m] x[n, chunk]; the 16 row lanes
 //             are summed through LDS in lane order, the row splits by a second launch in split order (no atomics: bit-reproducible).
 #include "common.h"
+#include "rng.h"
 
 namespace glam {
+
+// ACT (round 6): x is the PRE-activation of the hidden layer in front of the head (mol_flat, src_1gp/model.py:43-45, :60) and the head
+// applies that layer's training-mode RReLU(lo, hi) and its own Dropout(p) (layer.py:232-236) to every element it reads:
+//   y = Linear(Dropout(RReLU(x))).  Neither the activated matrix nor its dropped twin is ever written, and the two elementwise launches
+// (and their two backward launches) are gone; the words are the ones glam_bias_res_act_rng_fwd draws for the same elements at the same
+// stream position, so y equals the three-launch pipeline's bit for bit.  The backward regenerates them from the recorded pair.
+struct NarrowAct { long long* state; long long* eff; float lo, hi, p; };
+__device__ __forceinline__ float4 narrow_act(float4 v, const uint4& w4, const NarrowAct& a, float4* factor) {
+    float4 o, f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned wd = philox_word(w4, j);
+        const float vj = f4get(v, j), sl = vj > 0.f ? 1.f : rrelu_slope_w(wd, a.lo, a.hi), sc = drop_scale_w(wd, a.p);
+        const float act = vj > 0.f ? vj : vj * rrelu_slope_w(wd, a.lo, a.hi);
+        (&o.x)[j] = act * sc;
+        (&f.x)[j] = sl;
+        (void)sc;
+    }
+    if (factor) *factor = f;
+    return o;
+}
 
 constexpr int kNarrowMaxM = 16;
 constexpr int kNarrowSplits = 16;      // row splits of the backward (partials [splits][M + 1][K])
 
-template <int MT>
-__global__ void __launch_bounds__(kBlock) k_linear_narrow_fwd(const float* x, const float* w, const float* b, int N, int K, int M, float* y) {
+template <int MT, bool ACT = false>
+__global__ void __launch_bounds__(kBlock) k_linear_narrow_fwd(const float* x, const float* w, const float* b, int N, int K, int M, float* y,
+                                                             NarrowAct ra) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Philox ph{};
+    if constexpr (ACT) ph = rng_begin(ra.state, ra.eff);
     for (int n = blockIdx.x * (kBlock / 64) + wave; n < N; n += gridDim.x * (kBlock / 64)) {
         float acc[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = 0.f;
         const float* xr = x + (size_t)n * K;
         for (int k = 4 * lane; k < K; k += 256) {
-            const float4 xv = ld4(xr + k);
+            float4 xv = ld4(xr + k);
+            if constexpr (ACT) xv = narrow_act(xv, philox4(ph, ((size_t)n * K + k) >> 2), ra, nullptr);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 if (m < M) {
@@ -40,12 +66,16 @@ __global__ void __launch_bounds__(kBlock) k_linear_narrow_fwd(const float* x, co
                 if (m < M) y[(size_t)n * M + m] = acc[m] + (b ? b[m] : 0.f);
         }
     }
+    if constexpr (ACT) rng_end(ra.state, ph);
 }
 
 // partial[split][m][k] (m < M: d_w, m == M: column 0 holds d_b's partial, written by the blocks of column chunk 0)
-template <int MT>
+template <int MT, bool ACT = false>
 __global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, const float* w, const float* dy, int N, int K, int M,
-                                                             float* dx, float* partial, float* dw_direct, float* db_direct) {
+                                                             float* dx, float* partial, float* dw_direct, float* db_direct,
+                                                             NarrowAct ra) {
+    Philox ph{};
+    if constexpr (ACT) ph = philox_init(ra.eff);
     __shared__ float4 s_red[16][17];            // [row lane][column lane] (+1: bank spread), one output row at a time
     __shared__ float s_db[16][MT];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -63,7 +93,13 @@ __global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, co
         dbs[m] = 0.f;
     }
     for (int n = r0 + rl; n < r1; n += 16) {
-        const float4 xv = kok ? ld4(x + (size_t)n * K + k) : f4zero();
+        float4 xv = kok ? ld4(x + (size_t)n * K + k) : f4zero();
+        float4 f0 = f4zero();
+        uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (ACT) {      // what the forward multiplied with: Dropout(RReLU(x)), on the regenerated words
+            w4 = philox4(ph, ((size_t)n * K + (kok ? k : 0)) >> 2);
+            xv = narrow_act(xv, w4, ra, &f0);
+        }
         float4 dxv = f4zero();
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -73,6 +109,10 @@ __global__ void __launch_bounds__(kBlock) k_linear_narrow_bwd(const float* x, co
                 fma4(dxv, g, wv[m]);
                 dbs[m] += g;
             }
+        if constexpr (ACT) {      // ... and back through both: the chain of glam_bias_res_act_rng_bwd, in its order of operations
+#pragma unroll
+            for (int j = 0; j < 4; ++j) (&dxv.x)[j] = fmaf(f4get(dxv, j), drop_scale_w(philox_word(w4, j), ra.p), 0.f) * f4get(f0, j);
+        }
         if (dx && kok) st4(dx + (size_t)n * K + k, dxv);
     }
 #pragma unroll
@@ -201,12 +241,35 @@ extern "C" int glam_linear_narrow_fwd(const float* x, const float* w, const floa
     GLAM_REQUIRE(aligned16(x) && aligned16(w), "glam_linear_narrow_fwd: x and w must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(N, kBlock / 64);
-    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_fwd<1>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
-    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_fwd<2>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
-    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_fwd<4>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
-    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_fwd<8>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
-    else hipLaunchKernelGGL((k_linear_narrow_fwd<16>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y);
+    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_fwd<1>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, NarrowAct{});
+    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_fwd<2>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, NarrowAct{});
+    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_fwd<4>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, NarrowAct{});
+    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_fwd<8>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, NarrowAct{});
+    else hipLaunchKernelGGL((k_linear_narrow_fwd<16>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, NarrowAct{});
     GLAM_LAUNCH_CHECK("glam_linear_narrow_fwd");
+    return GLAM_OK;
+}
+
+// y = Linear(Dropout(p)(RReLU(lower, upper)(x))) in training mode: the output head reading the hidden layer's PRE-activation (see
+// NarrowAct above).  rng_eff receives the (seed, offset) pair glam_linear_narrow_act_bwd regenerates the words from.
+extern "C" int glam_linear_narrow_act_fwd(const float* x, const float* w, const float* b, int64_t N, int K, int M, float rr_lower,
+                                          float rr_upper, float drop_p, int64_t* rng_state, int64_t* rng_eff, float* y, void* stream) {
+    if (int rc = narrow_dims("glam_linear_narrow_act_fwd", N, K, M)) return rc;
+    GLAM_REQUIRE(rr_lower > 0.f && rr_lower <= rr_upper && drop_p >= 0.f && drop_p < 1.f, "glam_linear_narrow_act_fwd: needs 0 < lower <= upper and "
+                 "0 <= p < 1 (got %g, %g, %g)", rr_lower, rr_upper, drop_p);
+    if (N == 0) return GLAM_OK;
+    GLAM_REQUIRE(x && w && y && rng_state && rng_eff, "glam_linear_narrow_act_fwd: null pointer");
+    GLAM_REQUIRE(aligned16(x) && aligned16(w), "glam_linear_narrow_act_fwd: x and w must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(N, kBlock / 64);
+    const NarrowAct ra{reinterpret_cast<long long*>(rng_state), reinterpret_cast<long long*>(rng_eff), rr_lower, rr_upper, drop_p};
+    GLAM_PROF_LABEL("k_linear_narrow_fwd<rrelu+dropout>");
+    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_fwd<1, true>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, ra);
+    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_fwd<2, true>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, ra);
+    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_fwd<4, true>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, ra);
+    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_fwd<8, true>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, ra);
+    else hipLaunchKernelGGL((k_linear_narrow_fwd<16, true>), dim3(grid), dim3(kBlock), 0, s, x, w, b, (int)N, K, M, y, ra);
+    GLAM_LAUNCH_CHECK("glam_linear_narrow_act_fwd");
     return GLAM_OK;
 }
 
@@ -214,8 +277,25 @@ extern "C" size_t glam_linear_narrow_bwd_workspace_bytes(int K, int M) {
     return (size_t)kNarrowSplits * (size_t)(M + 1) * (size_t)K * sizeof(float);
 }
 
+static int narrow_bwd_impl(const char* fn, const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw,
+                           float* db, void* ws, size_t ws_bytes, void* stream, const NarrowAct* act);
 extern "C" int glam_linear_narrow_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw,
                                       float* db, void* ws, size_t ws_bytes, void* stream) {
+    return narrow_bwd_impl("glam_linear_narrow_bwd", x, w, dy, N, K, M, dx, dw, db, ws, ws_bytes, stream, nullptr);
+}
+// backward of glam_linear_narrow_act_fwd: x is the same pre-activation; dx = the gradient of THAT (through the Dropout and the RReLU, on
+// the words regenerated from rng_eff), dw / db as the head's (its input Dropout(RReLU(x)) is recomputed, never read)
+extern "C" int glam_linear_narrow_act_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float rr_lower,
+                                          float rr_upper, float drop_p, const int64_t* rng_eff, float* dx, float* dw, float* db, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    GLAM_REQUIRE(rr_lower > 0.f && rr_lower <= rr_upper && drop_p >= 0.f && drop_p < 1.f && (rng_eff || N == 0), "glam_linear_narrow_act_bwd: needs "
+                 "0 < lower <= upper, 0 <= p < 1 and the recorded stream position");
+    const NarrowAct ra{nullptr, const_cast<long long*>(reinterpret_cast<const long long*>(rng_eff)), rr_lower, rr_upper, drop_p};
+    return narrow_bwd_impl("glam_linear_narrow_act_bwd", x, w, dy, N, K, M, dx, dw, db, ws, ws_bytes, stream, &ra);
+}
+static int narrow_bwd_impl(const char* fn0, const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw,
+                           float* db, void* ws, size_t ws_bytes, void* stream, const NarrowAct* act) {
+    (void)fn0;
     if (int rc = narrow_dims("glam_linear_narrow_bwd", N, K, M)) return rc;
     GLAM_REQUIRE(dw && ws && ws_bytes >= glam_linear_narrow_bwd_workspace_bytes(K, M), "glam_linear_narrow_bwd: null output / workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -231,11 +311,20 @@ extern "C" int glam_linear_narrow_bwd(const float* x, const float* w, const floa
     // beyond: row splits + the fixed-order reduction (one split walks its rows serially: 15.8 us at N = 1 024 against 9.7 for the pair)
     const int nsplit = N <= 256 ? 1 : (int)(N < kNarrowSplits * 16 ? (N + 15) / 16 : kNarrowSplits);
     const dim3 grid((K + 63) / 64, nsplit);
-    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_bwd<1>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
-    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_bwd<2>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
-    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_bwd<4>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
-    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_bwd<8>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
-    else hipLaunchKernelGGL((k_linear_narrow_bwd<16>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db);
+    if (act) {
+        const NarrowAct ra = *act;
+        GLAM_PROF_LABEL("k_linear_narrow_bwd<rrelu+dropout>");
+        if (M == 1) hipLaunchKernelGGL((k_linear_narrow_bwd<1, true>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, ra);
+        else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_bwd<2, true>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, ra);
+        else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_bwd<4, true>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, ra);
+        else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_bwd<8, true>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, ra);
+        else hipLaunchKernelGGL((k_linear_narrow_bwd<16, true>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, ra);
+    } else
+    if (M == 1) hipLaunchKernelGGL((k_linear_narrow_bwd<1>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, NarrowAct{});
+    else if (M <= 2) hipLaunchKernelGGL((k_linear_narrow_bwd<2>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, NarrowAct{});
+    else if (M <= 4) hipLaunchKernelGGL((k_linear_narrow_bwd<4>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, NarrowAct{});
+    else if (M <= 8) hipLaunchKernelGGL((k_linear_narrow_bwd<8>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, NarrowAct{});
+    else hipLaunchKernelGGL((k_linear_narrow_bwd<16>), grid, dim3(kBlock), 0, s, x, w, dy, (int)N, K, M, dx, partial, dw, db, NarrowAct{});
     GLAM_LAUNCH_CHECK("glam_linear_narrow_bwd");
     if (nsplit == 1) return GLAM_OK;
     hipLaunchKernelGGL(k_linear_narrow_reduce, dim3((M * K + M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, nsplit, K, M, dw, db);

@@ -214,7 +214,7 @@ def no_graphed_call():
 # module-level A/B switches of glam_amd.ops and the library's environment switches: a captured graph bakes the route in, so they are part
 # of a graph's key (flipping one between two calls of a model — the parity tests do — must not replay the other route)
 _OPS_KNOBS = ("VALIDATE", "WS_ROUTE", "GRAD_CARRY", "CACHED_STAGING", "USE_TORCH_EXT", "GEMM_PAIR", "GRU_FUSED", "GRU_FUSED_MIN_NODES", "GRU_WS",
-              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "GRU_PRE", "GRU_GATES", "NODE_IN_GRU", "NODE_IN_GRU_MAX_ROWS", "RRELU_IN_GEMM", "DENSE_SPLITK", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR", "INFER_FWD", "RELU_IN_WGRAD")
+              "SKIP_THROUGH_CONV", "GRU_WGRAD_BATCH", "GRU_PRE", "GRU_GATES", "NODE_IN_GRU", "NODE_IN_GRU_MAX_ROWS", "RRELU_IN_GEMM", "HEAD_ACT_FUSED", "DENSE_SPLITK", "NORM_DROP", "PRESTAGE", "DENSE_LINEAR", "INFER_FWD", "RELU_IN_WGRAD")
 _ENV_KNOBS = ("GLAM_X3", "GLAM_WS", "GLAM_WGRAD_X3", "GLAM_WGRAD_X3_ROWS", "GLAM_TALL_X3", "GLAM_WS_GRID", "GLAM_B1_PRE")
 
 

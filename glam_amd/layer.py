@@ -854,6 +854,25 @@ def _apply_act(mod, x, next_dropout=0.0):
     return mod(x)
 
 
+def flat_then_head(flat, head, x, batch=None):
+    """``head(flat(x))`` for two LinearBlocks in a row (``mol_flat`` -> ``lin_out1``, src_1gp/model.py:60-61).  In the reference's default
+    configuration in training mode — ``flat`` ends in RReLU, ``head`` is Dropout(p) + a linear with a handful of outputs and nothing else —
+    the head reads ``flat``'s PRE-activation and applies both itself (``ops.rrelu_dropout_linear_narrow``): the RReLU launch, the dropped
+    twin and their two backward launches disappear.  Every other configuration: the two calls as written."""
+    a, d = flat.act, head.dropout
+    if (isinstance(flat, LinearBlock) and isinstance(head, LinearBlock) and type(a) is RReLU and a.training and 0 < a.lower <= a.upper
+            and isinstance(head.norm, _None) and isinstance(head.act, _None) and x.is_cuda and x.dim() == 2
+            and (isinstance(d, _None) or (type(d) is Dropout and (not d.training or 0 <= d.p < 1)))):
+        p = float(d.p) if (type(d) is Dropout and d.training) else 0.0
+        h = _apply_dropout(flat.dropout, flat.norm(x, batch))
+        pre = ops.linear(h, flat.linear.weight, flat.linear.bias)
+        y = ops.rrelu_dropout_linear_narrow(pre, head.linear.weight, head.linear.bias, a.lower, a.upper, p) if pre.dim() == 2 else None
+        if y is not None:
+            return y
+        return head(_apply_act(a, pre, following_dropout(head)))
+    return head(flat(x, batch, next_dropout=following_dropout(head)))
+
+
 def first_node_spec(block, n_rows, edge_index, edge_attr):
     """``ops.first_node_spec`` of ``block``'s TripletMessage when the output of the LinearBlock in front of it reaches that conv unchanged
     (no norm; a dropout slot that is empty, inactive, or the training-mode Dropout whose mask that LinearBlock's launch draws:
@@ -939,9 +958,10 @@ class LinearBlock(torch.nn.Module):
         x = self.norm(x, batch)
         x = _apply_dropout(self.dropout, x)
         a = self.act
-        if type(a) is ReLU or type(a) is LeakyReLU:      # deterministic: the dense linear's epilogue applies it (readout MLP)
+        if type(a) is ReLU or type(a) is LeakyReLU or (type(a) is RReLU and not a.training):
+            # deterministic (an RReLU in eval mode is a LeakyReLU of its mean slope): the dense linear's epilogue applies it (readout MLP)
             y = ops.linear_act(x, self.linear.weight, self.linear.bias, "relu" if type(a) is ReLU else "leaky",
-                               getattr(a, "negative_slope", 0.0))
+                               (a.lower + a.upper) / 2 if type(a) is RReLU else getattr(a, "negative_slope", 0.0))
             if y is not None:
                 return y
             if type(a) is ReLU:                            # ... or the tall product's (the input embeddings)

@@ -14,7 +14,7 @@ from . import graphs, ops
 
 from .layer import _None  # noqa: F401
 from .layer import GlobalPool5, GlobalLAPool, Set2Set  # noqa: F401  (resolved from config strings)
-from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, first_node_spec, following_dropout, prestage_pass
+from .layer import LinearBlock, MessageBlock, dot_and_global_pool2, first_node_spec, flat_then_head, following_dropout, prestage_pass
 
 
 def model_args(args):
@@ -70,8 +70,9 @@ class Architecture(torch.nn.Module):
         # PyG's pools read the graph count back from ``batch``; a collated Batch already knows it
         num_graphs = getattr(data_mol, "num_graphs", None) or None
         outm = self.mol_readout(xm, data_mol.batch, num_graphs)                    # model.py:57
-        outm = self.mol_flat(outm, next_dropout=following_dropout(self.lin_out1))  # model.py:60
-        return self.lin_out1(outm)                                                 # model.py:61
+        # model.py:60-61 — in the default configuration in training mode the head applies mol_flat's RReLU and its own Dropout to
+        # the elements it reads (layer.flat_then_head)
+        return flat_then_head(self.mol_flat, self.lin_out1, outm)
 
 
 Model = Architecture

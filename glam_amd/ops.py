@@ -1233,6 +1233,9 @@ NODE_IN_GRU = os.environ.get("GLAM_NODE_IN_GRU", "1") != "0"
 # the training-mode RReLU of a LinearBlock (and the dropped twin behind it) in the epilogue of its product where that runs on k_tall_x3
 # (the input embeddings) instead of a launch of its own: A/B switch (GLAM_RRELU_IN_GEMM=0)
 RRELU_IN_GEMM = os.environ.get("GLAM_RRELU_IN_GEMM", "1") != "0"
+# the output head applies the training-mode RReLU of the layer in front of it and its own Dropout to the elements it reads
+# (glam_linear_narrow_act_*): no activated matrix, no dropped twin, two launches less each way: A/B switch (GLAM_HEAD_ACT=0)
+HEAD_ACT_FUSED = os.environ.get("GLAM_HEAD_ACT", "1") != "0"
 # ... while a launch saved outweighs the matrix and vector work the node product adds to the GRU step's four SIMDs (A/B on one box,
 # model step: B = 32 -3.5 %, 1 024 -1.5 %, 2 048 -1.2 %, 4 096 +0.6 %, 8 192 +1.0 %)
 NODE_IN_GRU_MAX_ROWS = 65536

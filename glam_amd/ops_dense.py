@@ -541,6 +541,59 @@ class _LinearNarrow(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearNarrowAct(torch.autograd.Function):
+    """``y = Linear(Dropout(p)(RReLU(lower, upper)(x)))`` in training mode with ``x`` the PRE-activation of the layer in front of the head
+    (``mol_flat`` -> ``lin_out1``, src_1gp/model.py:60-61): the row dot products apply both to every element they read
+    (``glam_linear_narrow_act_fwd`` / ``_bwd``); neither the activated matrix nor the dropped twin exists."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lower, upper, p):
+        require_device(x, w, b)
+        x, w = f32c(x, "x"), f32c(w, "weight")
+        b = None if b is None else f32c(b, "bias")
+        N, K = x.shape
+        M = w.size(0)
+        y = torch.empty(N, M, dtype=torch.float32, device=x.device)
+        eff = torch.empty(2, dtype=torch.int64, device=x.device)
+        check(_lib.load().glam_linear_narrow_act_fwd(ptr(x), ptr(w), ptr(b), N, K, M, float(lower), float(upper), float(p),
+                                                     ptr(_o.rng_state(x.device)), ptr(eff), ptr(y), stream()), "glam_linear_narrow_act_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias, ctx.eff, ctx.cfg = b is not None, eff, (float(lower), float(upper), float(p))
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None, None, None
+        x, w = ctx.saved_tensors
+        dy = f32c(dy, "dy")
+        N, K = x.shape
+        M = w.size(0)
+        lib = _lib.load()
+        f = dict(dtype=torch.float32, device=x.device)
+        dx = torch.empty(N, K, **f) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(M, K, **f)
+        db = torch.empty(M, **f) if ctx.has_bias else None
+        ws = torch.empty(lib.glam_linear_narrow_bwd_workspace_bytes(K, M), dtype=torch.uint8, device=x.device)
+        lo, hi, p = ctx.cfg
+        check(lib.glam_linear_narrow_act_bwd(ptr(x), ptr(w), ptr(dy), N, K, M, lo, hi, p, ptr(ctx.eff), ptr(dx), ptr(dw), ptr(db), ptr(ws),
+                                             ws.numel(), stream()), "glam_linear_narrow_act_bwd")
+        return dx, dw, db, None, None, None
+
+
+def rrelu_dropout_linear_narrow(x, weight, bias, lower, upper, p):
+    """Training-mode ``F.linear(F.dropout(rrelu(x, lower, upper), p), weight, bias)`` for a head of at most 16 outputs, one launch each
+    way (``x``: the pre-activation); ``None`` where the shape is outside the row-dot-product kernels (the caller runs the three steps)."""
+    M, K = weight.shape
+    f32 = x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+    if not (_o.HEAD_ACT_FUSED and x.dim() == 2 and x.is_cuda and f32 and M <= 16 and K >= 64 and K % 4 == 0 and x.size(1) == K
+            and 0 < lower <= upper and 0 <= p < 1 and _o.padded_base(x) is None):
+        return None
+    return _LinearNarrowAct.apply(x, weight, bias, lower, upper, p)
+
+
 class _LinearLib(torch.autograd.Function):
     """``F.linear`` with the matrix products on the GEMM library (layers outside the MFMA kernels' table: the 300 -> 1024 readout MLP)
     and the bias gradient on ``glam_colsum`` (torch's generic column reduction takes 14 us for [1024, 1024]; this takes a few)."""

@@ -777,6 +777,18 @@ int glam_linear_narrow_fwd(const float* x, const float* w, const float* b, int64
 size_t glam_linear_narrow_bwd_workspace_bytes(int K, int M);
 int glam_linear_narrow_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float* dx, float* dw, float* db,
                            void* ws, size_t ws_bytes, void* stream);
+/* The head reading the hidden layer's PRE-activation: y = Linear(Dropout(drop_p)(RReLU(rr_lower, rr_upper)(x))) in TRAINING mode — the
+ * RReLU of `mol_flat` (/root/reference/src_1gp/model.py:43-45, :60, default activation model.py:31) and the Dropout `lin_out1` starts
+ * with (layer.py:232-236, model.py:30) applied to every element as the row dot products read it.  Neither the activated matrix nor its
+ * dropped twin is written: the two elementwise launches and their two backward launches are gone.  The words are the ones
+ * glam_bias_res_act_rng_fwd draws for the same elements at the same stream position (y equals the three-launch pipeline's bit for
+ * bit); rng_eff receives the (seed, offset) pair.  glam_linear_narrow_act_bwd: x is the same pre-activation, dx the gradient of THAT
+ * (through the Dropout and the RReLU, words regenerated from rng_eff), dw / db the head's. */
+int glam_linear_narrow_act_fwd(const float* x, const float* w, const float* b, int64_t N, int K, int M, float rr_lower, float rr_upper,
+                               float drop_p, int64_t* rng_state, int64_t* rng_eff, float* y, void* stream);
+int glam_linear_narrow_act_bwd(const float* x, const float* w, const float* dy, int64_t N, int K, int M, float rr_lower, float rr_upper,
+                               float drop_p, const int64_t* rng_eff, float* dx, float* dw, float* db, void* ws, size_t ws_bytes,
+                               void* stream);
 
 /* Column sums out[D] = sum_n x[n, 0..D) of a row-major f32[N, ld] matrix (D, ld multiples of 4): the bias gradient of a linear whose
  * matrix products stay on the GEMM library (the 300 -> 1024 readout MLP, src_1gp/model.py:44-46).  ws (>= glam_colsum_workspace_bytes)

@@ -2079,8 +2079,9 @@ def test_default_config_training_step_uses_the_fused_tails(device, monkeypatch, 
     # message step 1, before lin_out1), so no dropout launch of its own is left
     # (hid 60: mol_lin0's RReLU and its twin come out of the embedding product's own epilogue — glam_ts_gemm_rrelu / _act_node — so ONE
     # stand-alone RReLU launch is left)
+    # (... and mol_flat's RReLU and the Dropout behind it are applied by the head as it reads: glam_linear_narrow_act_fwd — none left)
     fused_embedding = alpha == 4 and ops.RRELU_IN_GEMM and ops._lib.route_enabled("x3")
-    assert calls == {"dropout": 0, "rrelu": 1 if fused_embedding else 2}, calls
+    assert calls == {"dropout": 0, "rrelu": 2 - int(fused_embedding) - int(ops.HEAD_ACT_FUSED)}, calls
     loss = out.square().mean()
     grads = torch.autograd.grad(loss, list(net.parameters()))
     ops.manual_seed(99)
@@ -4007,3 +4008,67 @@ def test_embedding_launch_writes_the_node_product_of_the_first_application(devic
     assert not torch.isnan(xw1).any() and not torch.isnan(a1).any()
     assert raw.glam_ts_gemm_act_node(ptr(x), K, K, ptr(img), ptr(b), M, N, 2, lo, hi, p, None, None, ptr(o1), None, ptr(nfrag), HC, ptr(xw1), ptr(a1),
                                      st()) == ops._lib.GLAM_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("N,K,M,p", [(1024, 1024, 1, 0.2), (32, 1024, 1, 0.2), (300, 256, 12, 0.5), (1000, 64, 2, 0.0), (3, 1024, 16, 0.2), (0, 1024, 1, 0.2)])
+def test_head_applies_the_hidden_layers_rrelu_and_its_own_dropout(device, N, K, M, p):
+    """glam_linear_narrow_act_fwd / _bwd: y = Linear(Dropout(p)(RReLU(x))) in training mode with x the PRE-activation of mol_flat
+    (src_1gp/model.py:43-47, :60-61; layer.py:232-236) — the bits of the three-launch pipeline (glam_bias_res_act_rng_fwd writing the
+    activated matrix and its dropped twin, then glam_linear_narrow_fwd on the twin) forward and backward, from the same stream position."""
+    raw, ptr, st = ops._lib.load(), ops.ptr, ops.stream
+    g = torch.Generator().manual_seed(N + K + M)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    x, w, b, dy = r(N, K), r(M, K) * 0.1, r(M), r(N, M)
+    f = lambda *s: torch.full(s, float("nan"), device=device)
+    lo, hi = 0.125, 1.0 / 3
+    mk = lambda: (torch.tensor([5] + [0] * (ops.RNG_STATE_WORDS - 1), dtype=torch.int64, device=device), torch.zeros(2, dtype=torch.int64, device=device))
+    ws = torch.empty(raw.glam_linear_narrow_bwd_workspace_bytes(K, M), dtype=torch.uint8, device=device)
+    # three launches forward, two backward
+    s0, e0 = mk()
+    act, twin, y0 = f(N, K), f(N, K), f(N, M)
+    assert raw.glam_bias_res_act_rng_fwd(ptr(x), None, None, N, K, 4, 0.0, lo, hi, p, ptr(s0), ptr(e0), ptr(act), ptr(twin) if p > 0 else None, st()) == 0
+    rows = twin if p > 0 else act
+    assert raw.glam_linear_narrow_fwd(ptr(rows), ptr(w), ptr(b), N, K, M, ptr(y0), st()) == 0
+    d_rows, dw0, db0, dx0 = f(N, K), f(M, K), f(M), f(N, K)
+    assert raw.glam_linear_narrow_bwd(ptr(rows), ptr(w), ptr(dy), N, K, M, ptr(d_rows), ptr(dw0), ptr(db0), ptr(ws), ws.numel(), st()) == 0
+    if N:
+        assert raw.glam_bias_res_act_rng_bwd(ptr(act), ptr(d_rows) if p == 0 else None, ptr(d_rows) if p > 0 else None, N, K, 4, 0.0, lo, hi, p, ptr(e0),
+                                             ptr(dx0), st()) == 0
+    # one each way
+    s1, e1 = mk()
+    y1, dx1, dw1, db1 = f(N, M), f(N, K), f(M, K), f(M)
+    assert raw.glam_linear_narrow_act_fwd(ptr(x), ptr(w), ptr(b), N, K, M, lo, hi, p, ptr(s1), ptr(e1), ptr(y1), st()) == 0, raw.glam_last_error()
+    assert raw.glam_linear_narrow_act_bwd(ptr(x), ptr(w), ptr(dy), N, K, M, lo, hi, p, ptr(e1), ptr(dx1), ptr(dw1), ptr(db1), ptr(ws), ws.numel(), st()) == 0
+    if N == 0:
+        assert not dw1.any() and not db1.any()
+        return
+    assert torch.equal(y0, y1) and torch.equal(e0, e1) and int(s1[1]) == 1
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1) and torch.equal(dx0, dx1) and not torch.isnan(dx1).any()
+    assert raw.glam_linear_narrow_act_fwd(ptr(x), ptr(w), ptr(b), N, K, M, 0.0, hi, p, ptr(s1), ptr(e1), ptr(y1), st()) == ops._lib.GLAM_E_INVALID
+
+
+def test_default_model_head_without_an_activated_matrix(device, monkeypatch):
+    """Architecture() defaults in train() (model.py:24-33): ops.HEAD_ACT_FUSED on / off — same outputs and gradients bit for bit, four
+    launches less per step (mol_flat's RReLU + twin, its backward, folded into the head's two launches)."""
+    from glam_amd import graphs
+    from glam_amd._lib import kernel_timer
+    b = synth_batch(200, seed=4).to(device)
+    torch.manual_seed(9)
+    net = model.Architecture(mol_block="_TripletMessage", e_dim=256).to(device).train()
+    monkeypatch.setattr(graphs, "GRAPHED_CALL", False)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    res, counts = [], []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "HEAD_ACT_FUSED", on)
+        ops.manual_seed(3, device)
+        net.zero_grad(set_to_none=True)
+        with kernel_timer(capacity=256) as kt:
+            y = net(b)
+            y.square().sum().backward()
+        names = [k for k, _, _ in kt.records()]
+        counts.append((sum("k_bias_res_act" in k for k in names), sum("rrelu+dropout" in k for k in names)))
+        res.append([y.detach().clone()] + [q.grad.clone() for q in net.parameters()])
+    for i, (u, v) in enumerate(zip(*res)):
+        assert torch.equal(u, v), i
+    # (the stand-alone RReLU launches of mol_flat, forward and backward, against the head's two launches doing their work)
+    assert counts[0][0] - counts[1][0] == 2 and counts[0][1] == 0 and counts[1][1] == 2, counts

@@ -21,7 +21,7 @@ python3 tools/kernel_sequence.py 32 model_default 2>&1 | grep -v amdgpu.ids > gp
 python3 tools/kernel_sequence.py 1024 model_default 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_kernel_sequence_b1024_model_default.txt
 # A/B of this round's switches on the model step, one box
 for p in relu model_default; do for b in 32 1024; do
-  for k in GLAM_X3=1 GLAM_GRU_GATES=0 GLAM_NODE_IN_GRU=0 GLAM_RRELU_IN_GEMM=0; do
+  for k in GLAM_X3=1 GLAM_GRU_GATES=0 GLAM_NODE_IN_GRU=0 GLAM_RRELU_IN_GEMM=0 GLAM_HEAD_ACT=0; do
     echo "$p B=$b $k: $(env $k python3 tools/bench_model.py --batch $b --steps 300 --preset $p 2>/dev/null | tail -1 | grep -o 'ms_per_step[^,]*')"
   done; done; done > gpurun_out/${TAG}_ab_switches.txt
 python3 tools/fork_price.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_fork_price.txt
