@@ -4072,3 +4072,32 @@ def test_default_model_head_without_an_activated_matrix(device, monkeypatch):
         assert torch.equal(u, v), i
     # (the stand-alone RReLU launches of mol_flat, forward and backward, against the head's two launches doing their work)
     assert counts[0][0] - counts[1][0] == 2 and counts[0][1] == 0 and counts[1][1] == 2, counts
+
+
+@pytest.mark.parametrize("arch", ["ddi", "dti"])
+def test_two_input_models_with_triplet_towers_and_node_products(device, monkeypatch, arch):
+    """ArchitectureDDI / ArchitectureDTI (src_2gi_ddi/model.py, src_2gi_dti_scr/model.py) with `_TripletMessage` ligand towers: the GRU
+    steps of both towers write the next application's node product (the per-pair fusion hands the rows back untouched); ops.NODE_IN_GRU
+    on / off give the same outputs and gradients bit for bit."""
+    from glam_amd import graphs
+    monkeypatch.setattr(graphs, "GRAPHED_CALL", False)
+    monkeypatch.setattr(ops, "USE_TORCH_EXT", False)
+    torch.manual_seed(1)
+    kw = dict(mol_block="_TripletMessage", message_steps=3, e_dim=128, pre_act="ReLU", graph_act="ReLU", flat_act="ReLU", end_act="ReLU",
+              graph_do="_None()", end_do="_None()")
+    if arch == "ddi":
+        net = model.ArchitectureDDI(**kw).to(device)
+        a, b = synth_batch(300, seed=1).to(device), synth_batch(300, seed=2).to(device)
+    else:
+        net = model.ArchitectureDTI(pro_block="_GCNConv", **kw).to(device)
+        a, b = synth_batch(6, seed=1).to(device), synth_protein_batch(6, seed=2, n_min=40, n_max=90).to(device)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "NODE_IN_GRU", on)
+        net.zero_grad(set_to_none=True)
+        y = net(a, b)
+        y.square().sum().backward()
+        res.append([y.detach().clone()] + [q.grad.clone() for q in net.parameters() if q.grad is not None])
+    assert len(res[0]) == len(res[1]) > 5
+    for i, (u, v) in enumerate(zip(*res)):
+        assert torch.equal(u, v), i
