@@ -9,7 +9,7 @@ GLAM_X3=0 TAIL=1 run python3 -m pytest tests -m gpu -q
 GLAM_INFER_FWD=0 GLAM_TS_SW=0 TAIL=1 run python3 -m pytest tests -m gpu -q
 GLAM_GRU_PRE=0 GLAM_DENSE_SPLITK=0 TAIL=1 run python3 -m pytest tests -m gpu -q
 GLAM_GRU_GATES=0 GLAM_NODE_IN_GRU=0 GLAM_RRELU_IN_GEMM=0 GLAM_HEAD_ACT=0 TAIL=1 run python3 -m pytest tests -m gpu -q
-for f in tests/sweeps/fuzz_ws.py tests/sweeps/fuzz_parity.py tests/sweeps/fuzz_model.py tests/sweeps/fuzz_dti.py tools/fuzz_gemm.py tools/fuzz_gru.py \
+for f in tests/sweeps/fuzz_ws.py tests/sweeps/fuzz_parity.py tests/sweeps/fuzz_model.py tests/sweeps/fuzz_dti.py tools/fuzz_gemm.py tools/fuzz_gru.py tools/fuzz_node.py \
          tools/fuzz_dense.py tools/fuzz_graphed.py tools/misuse_probe.py; do
   [ -f $f ] && TAIL=2 run python3 $f
 done
